@@ -1,0 +1,84 @@
+"""Build libxfeat_hip.so (hipcc, gfx950 only) in-tree.
+
+    python -m accelerated_features_amd.build [--force]
+
+Sources: accelerated_features_amd/csrc/*.hip ; output: accelerated_features_amd/libxfeat_hip.so
+(the .so is git-ignored; it travels to the GPU box with the repo snapshot).
+"""
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "libxfeat_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=on"]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libxfeat_hip.so cannot be built (ROCm toolchain required)")
+
+
+def _sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hdr.append(os.path.join(os.path.dirname(HERE), "include", "xfeat_hip.h"))
+    return hdr
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = _deps()
+    jobs = []
+    for src in _sources():
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for src, rc, out in ex.map(compile_one, jobs):
+                if verbose and out.strip():
+                    print(out, file=sys.stderr)
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+                if verbose:
+                    print("compiled", os.path.basename(src))
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + ".o") for s in _sources()]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        if verbose:
+            print("linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

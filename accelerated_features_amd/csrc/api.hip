@@ -1,0 +1,653 @@
+// C ABI of libxfeat_hip.so (include/xfeat_hip.h): weight packing, workspace planning and the
+// launch sequences of the hot path.  No compute happens on the host; there is no CPU fallback.
+#include "../../include/xfeat_hip.h"
+#include "kernels.hpp"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace xfh;
+
+// ------------------------------------------------------------------------------------------
+// error reporting
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(XFH_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(XFH_ERR_HIP, "%s: kernel launch failed: %s", what, hipGetErrorString(e));
+    return XFH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// network description (== accelerated_features_amd/spec.py::CONVS, reference model.py:33-111)
+// ------------------------------------------------------------------------------------------
+struct ConvSpec { int cin, cout, ks, stride, bn; };
+static const ConvSpec kConvs[L_NUM] = {
+    {1, 24, 1, 1, 0},                                                      // skip1.1
+    {1, 4, 3, 1, 1}, {4, 8, 3, 2, 1}, {8, 8, 3, 1, 1}, {8, 24, 3, 2, 1},   // block1
+    {24, 24, 3, 1, 1}, {24, 24, 3, 1, 1},                                  // block2
+    {24, 64, 3, 2, 1}, {64, 64, 3, 1, 1}, {64, 64, 1, 1, 1},               // block3
+    {64, 64, 3, 2, 1}, {64, 64, 3, 1, 1}, {64, 64, 3, 1, 1},               // block4
+    {64, 128, 3, 2, 1}, {128, 128, 3, 1, 1}, {128, 128, 3, 1, 1}, {128, 64, 1, 1, 1},   // block5
+    {64, 64, 3, 1, 1}, {64, 64, 3, 1, 1}, {64, 64, 1, 1, 0},               // block_fusion
+    {64, 64, 1, 1, 1}, {64, 64, 1, 1, 1}, {64, 1, 1, 1, 0},                // heatmap_head
+    {64, 64, 1, 1, 1}, {64, 64, 1, 1, 1}, {64, 64, 1, 1, 1}, {64, 65, 1, 1, 0},   // keypoint_head
+};
+struct FineSpec { int k, n, bn; };
+static const FineSpec kFine[5] = {{128, 512, 1}, {512, 512, 1}, {512, 512, 1}, {512, 512, 1}, {512, 64, 0}};
+static const double kBnEps = 1e-5;
+
+static int num_arrays() {
+    int n = 0;
+    for (int i = 0; i < L_NUM; ++i) n += kConvs[i].bn ? 3 : 2;
+    for (int i = 0; i < 5; ++i) n += kFine[i].bn ? 4 : 2;
+    return n;
+}
+static size_t array_floats(int idx) {
+    int a = 0;
+    for (int i = 0; i < L_NUM; ++i) {
+        const ConvSpec& c = kConvs[i];
+        const int cnt = c.bn ? 3 : 2;
+        if (idx < a + cnt) return (idx - a == 0) ? (size_t)c.cout * c.cin * c.ks * c.ks : (size_t)c.cout;
+        a += cnt;
+    }
+    for (int i = 0; i < 5; ++i) {
+        const FineSpec& f = kFine[i];
+        const int cnt = f.bn ? 4 : 2;
+        if (idx < a + cnt) return (idx - a == 0) ? (size_t)f.n * f.k : (size_t)f.n;
+        a += cnt;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// profiler: HIP events around one kernel family, on the launch stream
+// ------------------------------------------------------------------------------------------
+namespace xfh {
+struct Profiler {
+    int which = 0;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t used = 0;
+    double flops = 0, bytes = 0;
+};
+void prof_begin(Profiler* p, int which, hipStream_t st) {
+    if (!p || p->which != which) return;
+    if (p->used + 2 > p->ev.size()) {
+        hipEvent_t a, b;
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        p->ev.push_back(a);
+        p->ev.push_back(b);
+    }
+    (void)hipEventRecord(p->ev[p->used], st);
+}
+void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes) {
+    if (!p || p->which != which) return;
+    (void)hipEventRecord(p->ev[p->used + 1], st);
+    p->used += 2;
+    p->flops += flops;
+    p->bytes += bytes;
+}
+}  // namespace xfh
+
+struct xfh_context {
+    int device;
+    float* blob;          // device weights
+    NetWeights nw;
+    Profiler prof;
+};
+
+// ------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base((char*)p) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* r = base ? (T*)(base + off) : nullptr;
+        off += n * sizeof(T);
+        return r;
+    }
+};
+
+struct BackboneWs {
+    double* part;
+    float *gray, *t0, *t1, *t2, *x1, *x2a, *x2b, *x3a, *x3b, *x3c, *x4a, *x4b, *x4c, *x5a, *x5b, *x5c, *x5d;
+    float *pyr, *f0, *f1, *hh0, *hh1, *kh0, *kh1, *kh2, *logits;
+};
+static size_t carve_backbone(void* ws, int B, int H, int W, BackboneWs& o) {
+    Carver c(ws);
+    const size_t HW = (size_t)H * W, b = B;
+    o.part = c.take<double>(b * GS_CHUNKS * 2);
+    o.gray = c.take<float>(b * HW);
+    o.t0 = c.take<float>(b * 4 * HW);
+    o.t1 = c.take<float>(b * 8 * HW / 4);
+    o.t2 = c.take<float>(b * 8 * HW / 4);
+    o.x1 = c.take<float>(b * 24 * HW / 16);
+    o.x2a = c.take<float>(b * 24 * HW / 16);
+    o.x2b = c.take<float>(b * 24 * HW / 16);
+    o.x3a = c.take<float>(b * 64 * HW / 64);
+    o.x3b = c.take<float>(b * 64 * HW / 64);
+    o.x3c = c.take<float>(b * 64 * HW / 64);
+    o.x4a = c.take<float>(b * 64 * HW / 256);
+    o.x4b = c.take<float>(b * 64 * HW / 256);
+    o.x4c = c.take<float>(b * 64 * HW / 256);
+    o.x5a = c.take<float>(b * 128 * HW / 1024);
+    o.x5b = c.take<float>(b * 128 * HW / 1024);
+    o.x5c = c.take<float>(b * 128 * HW / 1024);
+    o.x5d = c.take<float>(b * 64 * HW / 1024);
+    o.pyr = c.take<float>(b * 64 * HW / 64);
+    o.f0 = c.take<float>(b * 64 * HW / 64);
+    o.f1 = c.take<float>(b * 64 * HW / 64);
+    o.hh0 = c.take<float>(b * 64 * HW / 64);
+    o.hh1 = c.take<float>(b * 64 * HW / 64);
+    o.kh0 = c.take<float>(b * 64 * HW / 64);
+    o.kh1 = c.take<float>(b * 64 * HW / 64);
+    o.kh2 = c.take<float>(b * 64 * HW / 64);
+    o.logits = c.take<float>(b * 65 * HW / 64);
+    return align_up(c.off, 256);
+}
+
+static size_t carve_detect(void* ws, int B, int H, int W, int top_k, int cap, DetectWs& o) {
+    Carver c(ws);
+    const size_t WPR = ceil_div(W, 64), b = B;
+    o.mask = c.take<unsigned long long>(b * H * WPR);
+    o.wcount = c.take<int>(b * H * WPR);
+    o.cand = c.take<unsigned>(b * cap);
+    o.keys = c.take<unsigned long long>(b * cap);
+    o.sel = c.take<unsigned>(b * top_k);
+    o.nsel = c.take<int>(b);
+    o.invnorm = c.take<float>(b * (H / 8) * (W / 8));
+    return align_up(c.off, 256);
+}
+
+struct DenseWs { unsigned long long* keys; unsigned* sel; int* nsel; };
+static size_t carve_dense(void* ws, int B, int hc, int wc, int k, DenseWs& o) {
+    Carver c(ws);
+    o.keys = c.take<unsigned long long>((size_t)B * hc * wc);
+    o.sel = c.take<unsigned>((size_t)B * k);
+    o.nsel = c.take<int>(B);
+    return align_up(c.off, 256);
+}
+
+static size_t carve_match(void* ws, int P, int N1, int N2, MatchWs& o) {
+    Carver c(ws);
+    o.match12 = c.take<int>((size_t)P * N1);
+    o.rowmax = c.take<float>((size_t)P * N1);
+    o.colpart = c.take<unsigned long long>((size_t)P * match_row_blocks(N1) * N2);
+    return align_up(c.off, 256);
+}
+
+struct RefineWs { int32_t *offs, *total, *rowmap; float *actA, *actB, *rows; unsigned char* keep; };
+static size_t carve_refine(void* ws, int P, int N, RefineWs& o) {
+    Carver c(ws);
+    const size_t M = (size_t)P * N;
+    o.offs = c.take<int32_t>(P + 1);
+    o.total = c.take<int32_t>(1);
+    o.rowmap = c.take<int32_t>(M);
+    o.actA = c.take<float>(M * 512);
+    o.actB = c.take<float>(M * 512);
+    o.rows = c.take<float>(M * 4);
+    o.keep = c.take<unsigned char>(M);
+    return align_up(c.off, 256);
+}
+
+static int check_ws(const void* ws, size_t have, size_t need) {
+    if (!ws) return fail(XFH_ERR_WORKSPACE, "workspace is NULL (need %zu bytes)", need);
+    if (((uintptr_t)ws & 255) != 0) return fail(XFH_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+    if (have < need) return fail(XFH_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", have, need);
+    return XFH_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// exported functions
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int xfh_version(void) { return XFH_VERSION; }
+const char* xfh_last_error(void) { return g_err; }
+int xfh_num_weight_arrays(void) { return num_arrays(); }
+size_t xfh_weight_array_floats(int i) { return array_floats(i); }
+
+int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_handle* out) {
+    if (!host_arrays || !out) return fail(XFH_ERR_ARG, "xfh_create: NULL argument");
+    if (n_arrays != num_arrays()) return fail(XFH_ERR_WEIGHTS, "xfh_create: expected %d weight arrays, got %d", num_arrays(), n_arrays);
+    for (int i = 0; i < n_arrays; ++i)
+        if (!host_arrays[i]) return fail(XFH_ERR_WEIGHTS, "xfh_create: weight array %d is NULL", i);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(XFH_ERR_DEVICE, "xfh_create: no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(XFH_ERR_DEVICE, "xfh_create: device %d out of range (%d visible)", device, ndev);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(XFH_ERR_DEVICE, "xfh_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+
+    std::vector<float> blob;
+    auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
+    struct Off { size_t oihw, kc, kcp, bias; } coff[L_NUM];
+    struct FOff { size_t w, b; } foff[5];
+    int ai = 0;
+    for (int li = 0; li < L_NUM; ++li) {
+        const ConvSpec& c = kConvs[li];
+        const int kk = c.ks * c.ks, cpad = (c.cout + 31) / 32 * 32;
+        const float* w = host_arrays[ai++];
+        std::vector<double> scale(c.cout, 1.0), shift(c.cout, 0.0);
+        if (c.bn) {
+            const float* rm = host_arrays[ai++];
+            const float* rv = host_arrays[ai++];
+            for (int o = 0; o < c.cout; ++o) {
+                if (!(rv[o] + kBnEps > 0)) return fail(XFH_ERR_WEIGHTS, "layer %d: running_var[%d] = %g is not positive", li, o, rv[o]);
+                scale[o] = 1.0 / std::sqrt((double)rv[o] + kBnEps);
+                shift[o] = -(double)rm[o] * scale[o];
+            }
+        } else {
+            const float* b = host_arrays[ai++];
+            for (int o = 0; o < c.cout; ++o) shift[o] = b[o];
+        }
+        coff[li].oihw = reserve((size_t)c.cout * c.cin * kk);
+        coff[li].kc = reserve((size_t)c.cin * kk * c.cout);
+        coff[li].kcp = reserve((size_t)c.cin * kk * cpad);
+        coff[li].bias = reserve(cpad);
+        for (int o = 0; o < c.cout; ++o) {
+            for (int i = 0; i < c.cin; ++i)
+                for (int t = 0; t < kk; ++t) {
+                    const float v = (float)((double)w[((size_t)o * c.cin + i) * kk + t] * scale[o]);
+                    blob[coff[li].oihw + ((size_t)o * c.cin + i) * kk + t] = v;
+                    blob[coff[li].kc + ((size_t)i * kk + t) * c.cout + o] = v;
+                    blob[coff[li].kcp + ((size_t)i * kk + t) * cpad + o] = v;
+                }
+            blob[coff[li].bias + o] = (float)shift[o];
+        }
+    }
+    for (int fi = 0; fi < 5; ++fi) {
+        const FineSpec& f = kFine[fi];
+        const int npad = (f.n + 63) / 64 * 64;
+        const float* w = host_arrays[ai++];
+        const float* b = host_arrays[ai++];
+        std::vector<double> scale(f.n, 1.0), shift(f.n, 0.0);
+        if (f.bn) {
+            const float* rm = host_arrays[ai++];
+            const float* rv = host_arrays[ai++];
+            for (int o = 0; o < f.n; ++o) {
+                if (!(rv[o] + kBnEps > 0)) return fail(XFH_ERR_WEIGHTS, "fine_matcher %d: running_var[%d] not positive", fi, o);
+                scale[o] = 1.0 / std::sqrt((double)rv[o] + kBnEps);
+                shift[o] = ((double)b[o] - (double)rm[o]) * scale[o];
+            }
+        } else {
+            for (int o = 0; o < f.n; ++o) shift[o] = b[o];
+        }
+        foff[fi].w = reserve((size_t)f.k * npad);
+        foff[fi].b = reserve(npad);
+        for (int o = 0; o < f.n; ++o) {
+            for (int i = 0; i < f.k; ++i) blob[foff[fi].w + (size_t)i * npad + o] = (float)((double)w[(size_t)o * f.k + i] * scale[o]);
+            blob[foff[fi].b + o] = (float)shift[o];
+        }
+    }
+
+    xfh_context* ctx = new xfh_context();
+    ctx->device = device;
+    ctx->blob = nullptr;
+    hipError_t e = hipMalloc((void**)&ctx->blob, blob.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(ctx->blob, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (ctx->blob) (void)hipFree(ctx->blob);
+        delete ctx;
+        return fail(XFH_ERR_HIP, "xfh_create: weight upload failed: %s", hipGetErrorString(e));
+    }
+    for (int li = 0; li < L_NUM; ++li) {
+        const ConvSpec& c = kConvs[li];
+        ConvW& w = ctx->nw.conv[li];
+        w.cin = c.cin; w.cout = c.cout; w.ks = c.ks; w.stride = c.stride; w.relu = c.bn; w.cout_pad = (c.cout + 31) / 32 * 32;
+        w.w_oihw = ctx->blob + coff[li].oihw;
+        w.w_kc = ctx->blob + coff[li].kc;
+        w.w_kcp = ctx->blob + coff[li].kcp;
+        w.bias = ctx->blob + coff[li].bias;
+    }
+    for (int fi = 0; fi < 5; ++fi) {
+        LinW& l = ctx->nw.fine[fi];
+        l.k = kFine[fi].k; l.n = kFine[fi].n; l.n_pad = (kFine[fi].n + 63) / 64 * 64; l.relu = kFine[fi].bn;
+        l.w_kn = ctx->blob + foff[fi].w;
+        l.bias = ctx->blob + foff[fi].b;
+    }
+    *out = ctx;
+    return XFH_OK;
+}
+
+void xfh_destroy(xfh_handle h) {
+    if (!h) return;
+    for (hipEvent_t e : h->prof.ev) (void)hipEventDestroy(e);
+    if (h->blob) (void)hipFree(h->blob);
+    delete h;
+}
+
+int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout, float scale_h,
+                        float scale_w, xfh_stream stream) {
+    if (!src || !dst || planes <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0)
+        return fail(XFH_ERR_ARG, "xfh_resize_bilinear: bad argument");
+    if (planes > 65535) return fail(XFH_ERR_ARG, "xfh_resize_bilinear: more than 65535 planes");
+    launch_resize_bilinear(src, planes, Hin, Win, dst, Hout, Wout, scale_h, scale_w, (hipStream_t)stream);
+    return check_launch("xfh_resize_bilinear");
+}
+
+static int check_img(const char* fn, int B, int C, int H, int W) {
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return fail(XFH_ERR_ARG, "%s: non-positive dimension", fn);
+    if (H % 32 || W % 32) return fail(XFH_ERR_ARG, "%s: H and W must be multiples of 32 (got %dx%d)", fn, H, W);
+    if (H >= 65536 || W >= 65536) return fail(XFH_ERR_ARG, "%s: image side >= 65536", fn);
+    if (B > 65535) return fail(XFH_ERR_ARG, "%s: batch > 65535", fn);
+    return XFH_OK;
+}
+
+size_t xfh_backbone_workspace_bytes(int B, int C, int H, int W) {
+    (void)C;
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    BackboneWs o;
+    return carve_backbone(nullptr, B, H, W, o);
+}
+
+static int conv_mfma_checked(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out, bool nhwc,
+                             hipStream_t st) {
+    const ConvW& c = h->nw.conv[layer];
+    const int pad = c.ks / 2;
+    const int Hout = (Hin + 2 * pad - c.ks) / c.stride + 1, Wout = (Win + 2 * pad - c.ks) / c.stride + 1;
+    // which >= 100 selects one layer (100 + layer index), otherwise the whole family
+    int pid = h->prof.which >= 100 ? 100 + layer : XFH_PROF_CONV_MFMA;
+    if (h->prof.which == XFH_PROF_CONV_64_64_S1 && c.cin == 64 && c.cout == 64 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_64_64_S1;
+    prof_begin(&h->prof, pid, st);
+    const int rc = launch_conv_mfma(c, in, B, Hin, Win, out, nhwc, st);
+    const double bytes = 4.0 * ((double)B * c.cin * Hin * Win + (double)B * c.cout * Hout * Wout + (double)c.cin * c.cout * c.ks * c.ks);
+    prof_end(&h->prof, pid, st, conv_flops(c, B, Hout, Wout), bytes);
+    if (rc) return fail(XFH_ERR_UNSUPPORTED, "no MFMA conv instantiation for layer %d (%d->%d k%d s%d) at %dx%d", layer, c.cin, c.cout, c.ks, c.stride, Hin, Win);
+    return XFH_OK;
+}
+
+int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, float* feats, float* logits, float* heat,
+                 float* reliab, void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    if (!h || !img || !feats || !reliab) return fail(XFH_ERR_ARG, "xfh_backbone: NULL argument");
+    if (!logits && !heat) return fail(XFH_ERR_ARG, "xfh_backbone: logits and heat are both NULL");
+    int rc = check_img("xfh_backbone", B, C, H, W);
+    if (rc) return rc;
+    BackboneWs w;
+    const size_t need = carve_backbone(workspace, B, H, W, w);
+    if ((rc = check_ws(workspace, workspace_bytes, need))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const NetWeights& nw = h->nw;
+    const int H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
+
+    launch_gray_norm(img, B, C, H, W, w.part, w.gray, st);
+    prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
+    launch_block1(nw, w.gray, B, H, W, w.t0, w.t1, w.t2, w.x1, st);
+    prof_end(&h->prof, XFH_PROF_BLOCK1, st, 0, 0);
+#define CONV(layer, in, hin, win, out, nhwc) \
+    if ((rc = conv_mfma_checked(h, layer, in, B, hin, win, out, nhwc, st))) return rc
+    CONV(L_BLOCK2_0, w.x1, H4, W4, w.x2a, false);
+    CONV(L_BLOCK2_1, w.x2a, H4, W4, w.x2b, false);
+    CONV(L_BLOCK3_0, w.x2b, H4, W4, w.x3a, false);
+    CONV(L_BLOCK3_1, w.x3a, H8, W8, w.x3b, false);
+    CONV(L_BLOCK3_2, w.x3b, H8, W8, w.x3c, false);
+    CONV(L_BLOCK4_0, w.x3c, H8, W8, w.x4a, false);
+    CONV(L_BLOCK4_1, w.x4a, H16, W16, w.x4b, false);
+    CONV(L_BLOCK4_2, w.x4b, H16, W16, w.x4c, false);
+    CONV(L_BLOCK5_0, w.x4c, H16, W16, w.x5a, false);
+    CONV(L_BLOCK5_1, w.x5a, H32, W32, w.x5b, false);
+    CONV(L_BLOCK5_2, w.x5b, H32, W32, w.x5c, false);
+    CONV(L_BLOCK5_3, w.x5c, H32, W32, w.x5d, false);
+    launch_pyramid_sum(w.x3c, w.x4c, w.x5d, w.pyr, B * 64, H8, W8, H16, W16, H32, W32, st);
+    CONV(L_FUSION_0, w.pyr, H8, W8, w.f0, false);
+    CONV(L_FUSION_1, w.f0, H8, W8, w.f1, false);
+    CONV(L_FUSION_2, w.f1, H8, W8, feats, true);     // -> channels-last M1
+#undef CONV
+
+    // heads on channels-last rows
+    const int M = B * H8 * W8;
+    prof_begin(&h->prof, XFH_PROF_HEADS, st);
+    LinSrc rm{};
+    rm.ldx = 64;
+    auto lin = [&](int layer, const float* x, float* y, int ldy) {
+        const ConvW& c = nw.conv[layer];
+        LinSrc s = rm;
+        s.x = x;
+        return launch_linear_mfma(c.w_kcp, c.bias, 64, c.cout, c.cout_pad, c.relu != 0, LOAD_ROWMAJOR, s, M, nullptr, y, ldy, st);
+    };
+    int bad = 0;
+    bad |= lin(L_HEAT_0, feats, w.hh0, 64);
+    bad |= lin(L_HEAT_1, w.hh0, w.hh1, 64);
+    launch_dot_sigmoid(w.hh1, M, nw.conv[L_HEAT_2].w_oihw, nw.conv[L_HEAT_2].bias, reliab, st);
+    {
+        const ConvW& c = nw.conv[L_KP_0];
+        LinSrc s{};
+        s.x = w.gray; s.H = H; s.W = W;
+        bad |= launch_linear_mfma(c.w_kcp, c.bias, 64, c.cout, c.cout_pad, true, LOAD_UNFOLD8, s, M, nullptr, w.kh0, 64, st);
+    }
+    bad |= lin(L_KP_1, w.kh0, w.kh1, 64);
+    bad |= lin(L_KP_2, w.kh1, w.kh2, 64);
+    float* lg = logits ? logits : w.logits;
+    bad |= lin(L_KP_3, w.kh2, lg, 65);
+    if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_backbone: missing linear kernel instantiation");
+    if (heat) launch_softmax_heat(lg, B, H8, W8, heat, st);
+    prof_end(&h->prof, XFH_PROF_HEADS, st, 0, 0);
+    return check_launch("xfh_backbone");
+}
+
+int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out, int variant,
+                   xfh_stream stream) {
+    if (!h || !in || !out) return fail(XFH_ERR_ARG, "xfh_conv_layer: NULL argument");
+    if (layer < 0 || layer >= L_NUM) return fail(XFH_ERR_ARG, "xfh_conv_layer: layer %d out of range", layer);
+    if (B <= 0 || Hin <= 0 || Win <= 0 || B > 4000) return fail(XFH_ERR_ARG, "xfh_conv_layer: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const ConvW& c = h->nw.conv[layer];
+    if (variant == 1) {
+        launch_conv_generic(c, in, B, Hin, Win, out, st);
+        return check_launch("xfh_conv_layer(generic)");
+    }
+    if (layer >= L_BLOCK1_0 && layer <= L_BLOCK1_3) {
+        launch_block1_layer(h->nw, layer, in, B, Hin, Win, out, st);
+        return check_launch("xfh_conv_layer(block1)");
+    }
+    if (layer == L_SKIP1 || layer >= L_HEAT_0)
+        return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: layer %d runs fused / channels-last in the backbone; use variant 1", layer);
+    int rc = conv_mfma_checked(h, layer, in, B, Hin, Win, out, false, st);
+    if (rc) return rc;
+    return check_launch("xfh_conv_layer(mfma)");
+}
+
+size_t xfh_detect_workspace_bytes(int B, int H, int W, int top_k, int nms_capacity) {
+    if (B <= 0 || H <= 0 || W <= 0 || top_k <= 0 || nms_capacity <= 0) return 0;
+    DetectWs o;
+    return carve_detect(nullptr, B, H, W, top_k, nms_capacity, o);
+}
+
+int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats, int B, int H, int W,
+                      float threshold, int top_k, int nms_capacity, float rw, float rh, float* kpts, float* scores,
+                      float* desc, int32_t* n_valid, int32_t* n_candidates, void* workspace, size_t workspace_bytes,
+                      xfh_stream stream) {
+    if (!h || !heat || !reliab || !feats || !kpts || !scores || !desc || !n_valid || !n_candidates)
+        return fail(XFH_ERR_ARG, "xfh_detect_sparse: NULL argument");
+    int rc = check_img("xfh_detect_sparse", B, 1, H, W);
+    if (rc) return rc;
+    if (top_k <= 0 || top_k > 16384) return fail(XFH_ERR_UNSUPPORTED, "xfh_detect_sparse: top_k %d outside 1..16384", top_k);
+    if (nms_capacity <= 0 || (long)nms_capacity > (long)H * W) return fail(XFH_ERR_ARG, "xfh_detect_sparse: nms_capacity %d outside 1..H*W", nms_capacity);
+    DetectWs w;
+    const size_t need = carve_detect(workspace, B, H, W, top_k, nms_capacity, w);
+    if ((rc = check_ws(workspace, workspace_bytes, need))) return rc;
+    launch_detect(w, heat, reliab, feats, B, H, W, threshold, top_k, nms_capacity, rw, rh, kpts, scores, desc, n_valid,
+                  n_candidates, (hipStream_t)stream);
+    return check_launch("xfh_detect_sparse");
+}
+
+size_t xfh_dense_workspace_bytes(int B, int hc, int wc, int k) {
+    if (B <= 0 || hc <= 0 || wc <= 0 || k <= 0) return 0;
+    DenseWs o;
+    return carve_dense(nullptr, B, hc, wc, k, o);
+}
+
+int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int B, int hc, int wc, int k, float rw,
+                      float rh, float scale_div, float* kpts, float* desc, int32_t* cell_index, void* workspace,
+                      size_t workspace_bytes, xfh_stream stream) {
+    if (!h || !reliab || !feats || !kpts || !desc) return fail(XFH_ERR_ARG, "xfh_extract_dense: NULL argument");
+    if (B <= 0 || hc <= 0 || wc <= 0 || B > 65535) return fail(XFH_ERR_ARG, "xfh_extract_dense: bad shape");
+    if (k <= 0 || k > hc * wc) return fail(XFH_ERR_ARG, "xfh_extract_dense: k %d outside 1..h*w", k);
+    if (k > 16384) return fail(XFH_ERR_UNSUPPORTED, "xfh_extract_dense: k %d > 16384", k);
+    if (!(scale_div > 0.f)) return fail(XFH_ERR_ARG, "xfh_extract_dense: scale_div must be positive");
+    DenseWs w;
+    const size_t need = carve_dense(workspace, B, hc, wc, k, w);
+    int rc = check_ws(workspace, workspace_bytes, need);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    launch_topk_desc(reliab, B, hc * wc, k, w.keys, w.sel, w.nsel, st);
+    launch_dense_gather(feats, w.sel, B, hc, wc, k, rw, rh, scale_div, kpts, desc, cell_index, st);
+    return check_launch("xfh_extract_dense");
+}
+
+size_t xfh_match_workspace_bytes(int P, int N1, int N2) {
+    if (P <= 0 || N1 <= 0 || N2 <= 0) return 0;
+    MatchWs o;
+    return carve_match(nullptr, P, N1, N2, o);
+}
+
+int xfh_match_mnn(xfh_handle h, const float* d1, size_t pair_stride1, const float* d2, size_t pair_stride2,
+                  const int32_t* n1, const int32_t* n2, int n_stride, int n_offset2, int P, int N1, int N2,
+                  float min_cossim, int64_t* idx0, int64_t* idx1, int32_t* n_matches, void* workspace,
+                  size_t workspace_bytes, xfh_stream stream) {
+    if (!d1 || !d2 || !idx0 || !idx1 || !n_matches) return fail(XFH_ERR_ARG, "xfh_match_mnn: NULL argument");
+    if (P <= 0 || N1 <= 0 || N2 <= 0 || P > 65535) return fail(XFH_ERR_ARG, "xfh_match_mnn: bad shape");
+    if (N2 > 16384) return fail(XFH_ERR_UNSUPPORTED, "xfh_match_mnn: N2 %d > 16384", N2);
+    if ((pair_stride1 & 3) || (pair_stride2 & 3)) return fail(XFH_ERR_ARG, "xfh_match_mnn: pair strides must be multiples of 4 floats");
+    MatchWs w;
+    const size_t need = carve_match(workspace, P, N1, N2, w);
+    int rc = check_ws(workspace, workspace_bytes, need);
+    if (rc) return rc;
+    launch_match(w, d1, pair_stride1, d2, pair_stride2, n1, n2, n_stride, n_offset2, P, N1, N2, min_cossim, idx0, idx1,
+                 n_matches, (hipStream_t)stream, h ? &h->prof : nullptr);
+    return check_launch("xfh_match_mnn");
+}
+
+size_t xfh_refine_workspace_bytes(int P, int N) {
+    if (P <= 0 || N <= 0) return 0;
+    RefineWs o;
+    return carve_refine(nullptr, P, N, o);
+}
+
+int xfh_refine_matches(xfh_handle h, const float* desc0, const float* desc1, const float* kp0, const float* kp1,
+                       const float* scale0, const int64_t* idx0, const int64_t* idx1, const int32_t* n_matches, int P,
+                       int N, float fine_conf, float* out, int32_t* n_out, void* workspace, size_t workspace_bytes,
+                       xfh_stream stream) {
+    if (!h || !desc0 || !desc1 || !kp0 || !kp1 || !scale0 || !idx0 || !idx1 || !n_matches || !out || !n_out)
+        return fail(XFH_ERR_ARG, "xfh_refine_matches: NULL argument");
+    if (P <= 0 || N <= 0 || P > 65535 || (long)P * N > 0x7fffffffL / 512) return fail(XFH_ERR_ARG, "xfh_refine_matches: bad shape");
+    RefineWs w;
+    const size_t need = carve_refine(workspace, P, N, w);
+    int rc = check_ws(workspace, workspace_bytes, need);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int M = P * N;
+    launch_refine_rowmap(n_matches, P, N, w.offs, w.rowmap, w.total, st);
+    const LinW* f = h->nw.fine;
+    LinSrc g{};
+    g.x = desc0; g.x2 = desc1; g.idx0 = idx0; g.idx1 = idx1; g.rowmap = w.rowmap; g.N = N;
+    int bad = launch_linear_mfma(f[0].w_kn, f[0].bias, 128, f[0].n, f[0].n_pad, true, LOAD_GATHER2, g, M, w.total, w.actA, 512, st);
+    LinSrc r{};
+    r.ldx = 512;
+    r.x = w.actA;
+    bad |= launch_linear_mfma(f[1].w_kn, f[1].bias, 512, f[1].n, f[1].n_pad, true, LOAD_ROWMAJOR, r, M, w.total, w.actB, 512, st);
+    r.x = w.actB;
+    bad |= launch_linear_mfma(f[2].w_kn, f[2].bias, 512, f[2].n, f[2].n_pad, true, LOAD_ROWMAJOR, r, M, w.total, w.actA, 512, st);
+    r.x = w.actA;
+    bad |= launch_linear_mfma(f[3].w_kn, f[3].bias, 512, f[3].n, f[3].n_pad, true, LOAD_ROWMAJOR, r, M, w.total, w.actB, 512, st);
+    r.x = w.actB;
+    bad |= launch_linear_mfma(f[4].w_kn, f[4].bias, 512, f[4].n, f[4].n_pad, false, LOAD_ROWMAJOR, r, M, w.total, w.actA, 64, st);
+    if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_refine_matches: missing linear kernel instantiation");
+    launch_refine_finish(w.actA, w.rowmap, w.offs, w.total, kp0, kp1, scale0, idx0, idx1, P, N, fine_conf, out, n_out,
+                         w.rows, w.keep, st);
+    return check_launch("xfh_refine_matches");
+}
+
+int xfh_kpts_heatmap(const float* logits, int B, int hc, int wc, float* heat, xfh_stream stream) {
+    if (!logits || !heat || B <= 0 || hc <= 0 || wc <= 0) return fail(XFH_ERR_ARG, "xfh_kpts_heatmap: bad argument");
+    launch_softmax_heat(logits, B, hc, wc, heat, (hipStream_t)stream);
+    return check_launch("xfh_kpts_heatmap");
+}
+
+int xfh_nms(xfh_handle h, const float* heat, int B, int H, int W, float threshold, int capacity, int64_t* xy,
+            int32_t* n_candidates, void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    (void)h;
+    if (!heat || !xy || !n_candidates) return fail(XFH_ERR_ARG, "xfh_nms: NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0 || H >= 65536 || W >= 65536 || B > 65535) return fail(XFH_ERR_ARG, "xfh_nms: bad shape");
+    if (capacity <= 0 || (long)capacity > (long)H * W) return fail(XFH_ERR_ARG, "xfh_nms: capacity outside 1..H*W");
+    DetectWs w;
+    const size_t need = carve_detect(workspace, B, H, W, 1, capacity, w);
+    int rc = check_ws(workspace, workspace_bytes, need);
+    if (rc) return rc;
+    launch_nms_only(w, heat, B, H, W, threshold, capacity, xy, n_candidates, (hipStream_t)stream);
+    return check_launch("xfh_nms");
+}
+
+int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* workspace, size_t workspace_bytes,
+                     xfh_stream stream) {
+    if (!h || !x || !out || n <= 0) return fail(XFH_ERR_ARG, "xfh_fine_matcher: bad argument");
+    RefineWs w;
+    const size_t need = carve_refine(workspace, 1, n, w);
+    int rc = check_ws(workspace, workspace_bytes, need);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const LinW* f = h->nw.fine;
+    LinSrc r{};
+    r.ldx = 128; r.x = x;
+    int bad = launch_linear_mfma(f[0].w_kn, f[0].bias, 128, f[0].n, f[0].n_pad, true, LOAD_ROWMAJOR, r, n, nullptr, w.actA, 512, st);
+    r.ldx = 512; r.x = w.actA;
+    bad |= launch_linear_mfma(f[1].w_kn, f[1].bias, 512, f[1].n, f[1].n_pad, true, LOAD_ROWMAJOR, r, n, nullptr, w.actB, 512, st);
+    r.x = w.actB;
+    bad |= launch_linear_mfma(f[2].w_kn, f[2].bias, 512, f[2].n, f[2].n_pad, true, LOAD_ROWMAJOR, r, n, nullptr, w.actA, 512, st);
+    r.x = w.actA;
+    bad |= launch_linear_mfma(f[3].w_kn, f[3].bias, 512, f[3].n, f[3].n_pad, true, LOAD_ROWMAJOR, r, n, nullptr, w.actB, 512, st);
+    r.x = w.actB;
+    bad |= launch_linear_mfma(f[4].w_kn, f[4].bias, 512, f[4].n, f[4].n_pad, false, LOAD_ROWMAJOR, r, n, nullptr, out, 64, st);
+    if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_fine_matcher: missing linear kernel instantiation");
+    return check_launch("xfh_fine_matcher");
+}
+
+int xfh_profile_select(xfh_handle h, int which) {
+    if (!h) return fail(XFH_ERR_ARG, "xfh_profile_select: NULL handle");
+    h->prof.which = which;
+    h->prof.used = 0;
+    h->prof.flops = h->prof.bytes = 0;
+    return XFH_OK;
+}
+
+int xfh_profile_read(xfh_handle h, int* n_launches, double* total_ms, double* total_flops, double* total_bytes) {
+    if (!h) return fail(XFH_ERR_ARG, "xfh_profile_read: NULL handle");
+    double ms = 0;
+    for (size_t i = 0; i + 1 < h->prof.used; i += 2) {
+        HIP_TRY(hipEventSynchronize(h->prof.ev[i + 1]));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, h->prof.ev[i], h->prof.ev[i + 1]));
+        ms += t;
+    }
+    if (n_launches) *n_launches = (int)(h->prof.used / 2);
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = h->prof.flops;
+    if (total_bytes) *total_bytes = h->prof.bytes;
+    h->prof.used = 0;
+    h->prof.flops = h->prof.bytes = 0;
+    return XFH_OK;
+}
+
+}  // extern "C"

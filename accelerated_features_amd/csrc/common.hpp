@@ -1,0 +1,53 @@
+// Shared device/host helpers for libxfeat_hip (gfx950 only: 64-lane wavefronts assumed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace xfh {
+
+constexpr int WAVE = 64;
+
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- wavefront reductions (64 lanes) ---------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline unsigned long long shfl_xor_u64(unsigned long long v, int o) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, o, 64);
+    hi = __shfl_xor(hi, o, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ inline unsigned long long u64_max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
+
+// Monotone map float -> uint32: a < b  <=>  ord(a) < ord(b)   (NaN not expected on this path).
+__device__ inline unsigned float_ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline float ord_float(unsigned o) {
+    unsigned u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+
+}  // namespace xfh

@@ -1,0 +1,423 @@
+// Sparse detection: 5x5 NMS + ordered compaction, scoring, top-k, descriptor sampling.
+//   XFeat.NMS                         modules/xfeat.py:249-263
+//   scores / argsort / top-k          modules/xfeat.py:77-87
+//   InterpolateSparse2d (3 modes)     modules/interpolator.py:17-33  (arithmetic: SURVEY App. A.6)
+//   descriptors                       modules/xfeat.py:70,90-93
+//   extractDense top-k + gather       modules/xfeat.py:362-375
+//
+// Integer results are decided here, so the fp32 arithmetic that feeds a comparison follows the
+// reference's operation order exactly (coordinate normalisation, fused un-normalise, round-
+// half-even for 'nearest').  Ragged per-image lists are kept at fixed capacity with device
+// counts; ordering uses wave ballots + block scans (row-major order is preserved).
+#include "kernels.hpp"
+
+namespace xfh {
+
+// ------------------------------------------------------------------------------------------
+// NMS flags: pixel is kept iff heat > thr and no pixel of its 5x5 window (implicit -inf
+// padding) is larger (== local max; plateaus keep every equal pixel).
+// grid (ceil(WPR/4), H, B): one wave per 64-pixel word.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict__ heat, int H, int W, int WPR, float thr,
+                                                        unsigned long long* __restrict__ mask, int* __restrict__ wcount) {
+    const int lane = threadIdx.x & 63, word = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int y = blockIdx.y, b = blockIdx.z;
+    const int x = word * 64 + lane;
+    const float* hp = heat + (size_t)b * H * W;
+    bool cand = false;
+    if (word < WPR && x < W) {
+        const float v = hp[(size_t)y * W + x];
+        if (v > thr) {
+            float m = v;
+            const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1), x0 = max(x - 2, 0), x1 = min(x + 2, W - 1);
+            for (int yy = y0; yy <= y1; ++yy)
+                for (int xx = x0; xx <= x1; ++xx) m = fmaxf(m, hp[(size_t)yy * W + xx]);
+            cand = (v == m);
+        }
+    }
+    const unsigned long long bal = __ballot(cand);
+    if (lane == 0 && word < WPR) {
+        const size_t o = ((size_t)b * H + y) * WPR + word;
+        mask[o] = bal;
+        wcount[o] = __popcll(bal);
+    }
+}
+
+// block-wide exclusive scan of one int per thread (1024 threads); returns the exclusive
+// prefix, *total = block sum.  lds: >= 16 ints.
+__device__ inline int block_exscan_1024(int v, int* lds, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// grid (B), block 1024: scan the word counts, expand bits in row-major order
+__global__ __launch_bounds__(1024) void nms_compact_kernel(const unsigned long long* __restrict__ mask,
+                                                           const int* __restrict__ wcount, int H, int WPR, int cap,
+                                                           unsigned* __restrict__ cand, int32_t* __restrict__ n_cand) {
+    __shared__ int lds[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int NW = H * WPR;
+    const int per = ceil_div(NW, 1024);
+    const int beg = min(tid * per, NW), end = min(beg + per, NW);
+    const int* wc = wcount + (size_t)b * NW;
+    int local = 0;
+    for (int i = beg; i < end; ++i) local += wc[i];
+    int total;
+    int off = block_exscan_1024(local, lds, &total);
+    const unsigned long long* mk = mask + (size_t)b * NW;
+    unsigned* out = cand + (size_t)b * cap;
+    for (int i = beg; i < end; ++i) {
+        unsigned long long m = mk[i];
+        const int y = i / WPR, xb = (i - y * WPR) * 64;
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (off < cap) out[off] = ((unsigned)y << 16) | (unsigned)(xb + bit);
+            ++off;
+        }
+    }
+    if (tid == 0) n_cand[b] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// sampling coordinate (interpolator.py:17-19 + ATen grid sampler, align_corners=False):
+//   g1 = (2*(p/(S-1)) - 1) + 1   [fp32, reference order]   u = fma(g1, Sm/2, -0.5)
+// ------------------------------------------------------------------------------------------
+__device__ inline float sample_coord(int p, int S, int Sm) {
+    const float q = (float)p / (float)(S - 1);
+    const float g = 2.0f * q - 1.0f;      // 2*q is exact, so contraction cannot change this
+    const float g1 = g + 1.0f;
+    return __fmaf_rn(g1, (float)Sm * 0.5f, -0.5f);
+}
+
+__device__ inline float fetch0(const float* __restrict__ m, int Hm, int Wm, int y, int x) {
+    return (x >= 0 && x < Wm && y >= 0 && y < Hm) ? m[(size_t)y * Wm + x] : 0.f;
+}
+
+// score = nearest(heat) * bilinear(reliability); (0,0) -> -1          (xfeat.py:77-80)
+// key = (~ord(score) << 32) | slot : ascending key == descending score, ties by slot
+__global__ __launch_bounds__(256) void score_keys_kernel(const float* __restrict__ heat, const float* __restrict__ rel,
+                                                         const unsigned* __restrict__ cand,
+                                                         const int32_t* __restrict__ n_cand, int H, int W, int cap,
+                                                         unsigned long long* __restrict__ keys) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(n_cand[b], cap);
+    if (i >= n) return;
+    const unsigned c = cand[(size_t)b * cap + i];
+    const int x = c & 0xffff, y = c >> 16;
+    const int hc = H >> 3, wc = W >> 3;
+    // nearest on the H x W heat map
+    const float nx = sample_coord(x, W, W), ny = sample_coord(y, H, H);
+    const int ix = (int)rintf(nx), iy = (int)rintf(ny);
+    const float sn = fetch0(heat + (size_t)b * H * W, H, W, iy, ix);
+    // bilinear on the (H/8) x (W/8) reliability map
+    const float ux = sample_coord(x, W, wc), uy = sample_coord(y, H, hc);
+    const float fx = floorf(ux), fy = floorf(uy);
+    const float tx = ux - fx, ty = uy - fy;
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float* rp = rel + (size_t)b * hc * wc;
+    const float sb = fetch0(rp, hc, wc, y0, x0) * ((1.f - tx) * (1.f - ty)) + fetch0(rp, hc, wc, y0, x0 + 1) * (tx * (1.f - ty)) +
+                     fetch0(rp, hc, wc, y0 + 1, x0) * ((1.f - tx) * ty) + fetch0(rp, hc, wc, y0 + 1, x0 + 1) * (tx * ty);
+    float score = sn * sb;
+    if (x == 0 && y == 0) score = -1.f;
+    keys[(size_t)b * cap + i] = ((unsigned long long)(~float_ord(score)) << 32) | (unsigned)i;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-image top-k of unique 64-bit keys (ascending): 8-pass radix select of the k-th key,
+// compaction of the keys <= it into LDS, bitonic sort there.  One 1024-thread block per image.
+// dynamic LDS: kpad * 8 bytes.
+// ------------------------------------------------------------------------------------------
+struct TopkOut {            // sparse-path epilogue (all NULL for the plain top-k)
+    const unsigned* cand;   // (B,cap)
+    float* kpts;            // (B,top_k,2)
+    float* scores;          // (B,top_k)
+    int32_t* n_valid;       // (B)
+    float rw, rh;
+};
+
+__global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __restrict__ keys, int key_stride,
+                                                    const int32_t* __restrict__ n_dev, int n_const, int n_cap, int top_k,
+                                                    int kpad, unsigned* __restrict__ sel, int* __restrict__ nsel,
+                                                    TopkOut o) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lk[];
+    __shared__ int hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_kk, s_cnt, s_valid;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    int n = n_dev ? min(n_dev[b], n_cap) : n_const;
+    const int k = min(top_k, n);
+    const unsigned long long* kp = keys + (size_t)b * key_stride;
+
+    unsigned long long T = ~0ull;
+    if (n > k && k > 0) {
+        if (tid == 0) { s_prefix = 0; s_kk = k; }
+        for (int pass = 0; pass < 8; ++pass) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            const int shift = 56 - 8 * pass;
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned long long key = kp[i];
+                const bool match = (pass == 0) || ((key >> (shift + 8)) == prefix);
+                if (match) atomicAdd(&hist[(int)((key >> shift) & 255)], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int kk = s_kk, d = 0;
+                for (; d < 256; ++d) {
+                    if (hist[d] >= kk) break;
+                    kk -= hist[d];
+                }
+                s_kk = kk;
+                s_prefix = (prefix << 8) | (unsigned long long)d;
+            }
+            __syncthreads();
+        }
+        T = s_prefix;
+    }
+    if (tid == 0) { s_cnt = 0; s_valid = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned long long key = kp[i];
+        if (key <= T) {
+            const int slot = atomicAdd(&s_cnt, 1);
+            if (slot < kpad) lk[slot] = key;
+        }
+    }
+    for (int i = k + tid; i < kpad; i += 1024) lk[i] = ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= kpad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (kpad >> 1); t += 1024) {
+                const int i = 2 * t - (t & (stride - 1));
+                const int j = i + stride;
+                const bool up = ((i & size) == 0);
+                const unsigned long long a = lk[i], c = lk[j];
+                if ((a > c) == up) { lk[i] = c; lk[j] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    int nv = 0;
+    for (int j = tid; j < top_k; j += 1024) {
+        if (j < k) {
+            const unsigned long long key = lk[j];
+            const unsigned slot = (unsigned)(key & 0xffffffffu);
+            sel[(size_t)b * top_k + j] = slot;
+            if (o.kpts) {
+                const unsigned hi = (unsigned)(key >> 32);
+                const float score = ord_float(~hi);
+                const unsigned c = o.cand[(size_t)b * n_cap + slot];
+                o.kpts[((size_t)b * top_k + j) * 2 + 0] = (float)(c & 0xffff) * o.rw;
+                o.kpts[((size_t)b * top_k + j) * 2 + 1] = (float)(c >> 16) * o.rh;
+                o.scores[(size_t)b * top_k + j] = score;
+                if (score > 0.f) ++nv;
+            }
+        } else {
+            sel[(size_t)b * top_k + j] = 0;
+            if (o.kpts) {
+                o.kpts[((size_t)b * top_k + j) * 2 + 0] = 0.f;
+                o.kpts[((size_t)b * top_k + j) * 2 + 1] = 0.f;
+                o.scores[(size_t)b * top_k + j] = 0.f;
+            }
+        }
+    }
+    if (o.kpts) {
+        nv = wave_sum_i(nv);
+        if ((tid & 63) == 0 && nv) atomicAdd(&s_valid, nv);
+        __syncthreads();
+        if (tid == 0) o.n_valid[b] = s_valid;
+    }
+    if (tid == 0) nsel[b] = k;
+}
+
+static int next_pow2(int v) {
+    int p = 2;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+static void run_topk(const unsigned long long* keys, int key_stride, const int32_t* n_dev, int n_const, int n_cap,
+                     int top_k, int B, unsigned* sel, int* nsel, const TopkOut& o, hipStream_t st) {
+    const int kpad = next_pow2(top_k);
+    const size_t lds = (size_t)kpad * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            16384 * 8);
+        attr_set = true;
+    }
+    topk_kernel<<<B, 1024, lds, st>>>(keys, key_stride, n_dev, n_const, n_cap, top_k, kpad, sel, nsel, o);
+}
+
+// ------------------------------------------------------------------------------------------
+// 1 / max(||feats[pixel,:]||, 1e-12)   (F.normalize(M1, dim=1), xfeat.py:70), feats NHWC
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void invnorm_kernel(const float* __restrict__ feats, int npix, float* __restrict__ inv) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int pix = g >> 4, part = g & 15;
+    float s = 0.f;
+    if (pix < npix) {
+        const float4 v = *reinterpret_cast<const float4*>(feats + (size_t)pix * 64 + part * 4);
+        s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 1, 64);
+    if (pix < npix && part == 0) inv[pix] = 1.f / fmaxf(sqrtf(s), 1e-12f);
+}
+
+// Keys cubic-convolution weights, A = -0.75 (ATen get_cubic_upsample_coefficients)
+__device__ inline void cubic_w(float t, float w[4]) {
+    const float A = -0.75f;
+    float x = t + 1.f;
+    w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+    x = t;
+    w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 1.f - t;
+    w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    x = 2.f - t;
+    w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+
+// one wave per selected key-point, lane = descriptor channel:
+//   desc = normalize( bicubic( normalize(M1, dim=1) ) )                   (xfeat.py:70,90-93)
+__global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict__ feats, const float* __restrict__ inv,
+                                                         const unsigned* __restrict__ cand, const unsigned* __restrict__ sel,
+                                                         const int* __restrict__ nsel, int H, int W, int cap, int top_k,
+                                                         float* __restrict__ desc) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (j >= top_k) return;
+    float* dp = desc + ((size_t)b * top_k + j) * 64;
+    if (j >= nsel[b]) { dp[lane] = 0.f; return; }
+    const unsigned c = cand[(size_t)b * cap + sel[(size_t)b * top_k + j]];
+    const int x = c & 0xffff, y = c >> 16;
+    const int hc = H >> 3, wc = W >> 3;
+    const float ux = sample_coord(x, W, wc), uy = sample_coord(y, H, hc);
+    const float fx = floorf(ux), fy = floorf(uy);
+    float wx[4], wy[4];
+    cubic_w(ux - fx, wx);
+    cubic_w(uy - fy, wy);
+    const int x0 = (int)fx - 1, y0 = (int)fy - 1;
+    const float* fb = feats + (size_t)b * hc * wc * 64;
+    const float* ib = inv + (size_t)b * hc * wc;
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int yy = y0 + r;
+        float row = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int xx = x0 + i;
+            float v = 0.f;
+            if (xx >= 0 && xx < wc && yy >= 0 && yy < hc) {
+                const int pix = yy * wc + xx;
+                v = fb[(size_t)pix * 64 + lane] * ib[pix];
+            }
+            row += v * wx[i];
+        }
+        acc += row * wy[r];
+    }
+    const float n2 = wave_sum(acc * acc);
+    dp[lane] = acc / fmaxf(sqrtf(n2), 1e-12f);
+}
+
+void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, int B, int H, int W,
+                   float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
+                   int32_t* n_valid, int32_t* n_cand, hipStream_t st) {
+    const int WPR = ceil_div(W, 64);
+    const int hc = H / 8, wc = W / 8;
+    nms_flags_kernel<<<dim3(ceil_div(WPR, 4), H, B), 256, 0, st>>>(heat, H, W, WPR, thr, ws.mask, ws.wcount);
+    nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
+    score_keys_kernel<<<dim3(ceil_div(cap, 256), B), 256, 0, st>>>(heat, reliab, ws.cand, n_cand, H, W, cap, ws.keys);
+    TopkOut o{ws.cand, kpts, scores, n_valid, rw, rh};
+    run_topk(ws.keys, cap, n_cand, 0, cap, top_k, B, ws.sel, ws.nsel, o, st);
+    invnorm_kernel<<<ceil_div(B * hc * wc * 16, 256), 256, 0, st>>>(feats, B * hc * wc, ws.invnorm);
+    descriptor_kernel<<<dim3(ceil_div(top_k, 4), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.sel, ws.nsel, H, W, cap,
+                                                                 top_k, desc);
+}
+
+// stand-alone NMS (XFeat.NMS): flags + compaction + int64 (x,y) list, zero padded
+__global__ __launch_bounds__(256) void cand_to_xy_kernel(const unsigned* __restrict__ cand, const int32_t* __restrict__ n_cand,
+                                                         int cap, int64_t* __restrict__ xy) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    int64_t x = 0, y = 0;
+    if (i < min(n_cand[b], cap)) {
+        const unsigned c = cand[(size_t)b * cap + i];
+        x = c & 0xffff; y = c >> 16;
+    }
+    xy[((size_t)b * cap + i) * 2 + 0] = x;
+    xy[((size_t)b * cap + i) * 2 + 1] = y;
+}
+
+void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int cap, int64_t* xy,
+                     int32_t* n_cand, hipStream_t st) {
+    const int WPR = ceil_div(W, 64);
+    nms_flags_kernel<<<dim3(ceil_div(WPR, 4), H, B), 256, 0, st>>>(heat, H, W, WPR, thr, ws.mask, ws.wcount);
+    nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
+    cand_to_xy_kernel<<<dim3(ceil_div(cap, 256), B), 256, 0, st>>>(ws.cand, n_cand, cap, xy);
+}
+
+// ------------------------------------------------------------------------------------------
+// plain top-k (descending values, ties: lower index first) for extractDense (xfeat.py:371)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void value_keys_kernel(const float* __restrict__ vals, int n,
+                                                         unsigned long long* __restrict__ keys) {
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    keys[(size_t)b * n + i] = ((unsigned long long)(~float_ord(vals[(size_t)b * n + i])) << 32) | (unsigned)i;
+}
+
+void launch_topk_desc(const float* vals, int B, int n, int k, unsigned long long* keys, unsigned* sel, int* nsel,
+                      hipStream_t st) {
+    value_keys_kernel<<<dim3(ceil_div(n, 256), B), 256, 0, st>>>(vals, n, keys);
+    TopkOut o{nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
+    run_topk(keys, n, nullptr, n, n, k, B, sel, nsel, o, st);
+}
+
+// wave per selected cell: raw features + corner coordinates                (xfeat.py:366-375,388)
+__global__ __launch_bounds__(256) void dense_gather_kernel(const float* __restrict__ feats, const unsigned* __restrict__ sel,
+                                                           int hc, int wc, int k, float rw, float rh, float scale_div,
+                                                           float* __restrict__ kpts, float* __restrict__ desc,
+                                                           int32_t* __restrict__ cell_index) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (j >= k) return;
+    const unsigned cell = sel[(size_t)b * k + j];
+    desc[((size_t)b * k + j) * 64 + lane] = feats[((size_t)b * hc * wc + cell) * 64 + lane];
+    if (lane == 0) {
+        const int ci = cell / wc, cj = cell - ci * wc;
+        kpts[((size_t)b * k + j) * 2 + 0] = ((float)(cj * 8) * rw) / scale_div;
+        kpts[((size_t)b * k + j) * 2 + 1] = ((float)(ci * 8) * rh) / scale_div;
+        if (cell_index) cell_index[(size_t)b * k + j] = (int32_t)cell;
+    }
+}
+
+void launch_dense_gather(const float* feats, const unsigned* sel, int B, int hc, int wc, int k, float rw, float rh,
+                         float scale_div, float* kpts, float* desc, int32_t* cell_index, hipStream_t st) {
+    dense_gather_kernel<<<dim3(ceil_div(k, 4), B), 256, 0, st>>>(feats, sel, hc, wc, k, rw, rh, scale_div, kpts, desc,
+                                                                 cell_index);
+}
+
+}  // namespace xfh

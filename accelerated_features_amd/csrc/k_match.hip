@@ -1,0 +1,219 @@
+// Mutual-nearest-neighbour matching on the f32 matrix cores.
+//   XFeat.match        modules/xfeat.py:327-348     XFeat.batch_match  modules/xfeat.py:265-290
+//
+// The reference materialises S = D1.D2^T AND S^T (two GEMMs, 2 x 67 MB at 4096 points) and
+// arg-maxes both.  Here S is produced tile by tile by v_mfma_f32_32x32x2_f32 and never leaves
+// registers: every workgroup owns 256 rows of D1 (A fragments stationary in VGPRs, K = 64 is
+// only 32 MFMA steps) and sweeps all columns of D2 staged through LDS, keeping a running
+// row max/arg-max per lane and emitting per-row-block column maxima as packed 64-bit keys
+// (ord(sim) << 32 | ~index), so that ties resolve to the LOWEST index like torch.max.
+// A second small kernel reduces the column partials, applies the mutual test (+ optional
+// min_cossim) and compacts the surviving pairs in ascending row order.
+#include "kernels.hpp"
+
+namespace xfh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MT_ROWS = 256;   // rows of D1 per workgroup (4 waves x 64)
+constexpr int MT_COLS = 128;   // columns of D2 per LDS fill
+constexpr int MT_DS = 68;      // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
+
+int match_row_blocks(int N1) { return ceil_div(N1, MT_ROWS); }
+
+__device__ inline int pair_count(const int32_t* n, int idx, int cap) {
+    if (!n) return cap;
+    const int v = n[idx];
+    return v < 0 ? 0 : (v > cap ? cap : v);
+}
+
+__global__ __launch_bounds__(256) void mnn_sim_kernel(const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2,
+                                                      size_t ps2, const int32_t* __restrict__ n1p,
+                                                      const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1,
+                                                      int N2, int nrb, int* __restrict__ match12,
+                                                      float* __restrict__ rowmax, unsigned long long* __restrict__ colpart) {
+    __shared__ __attribute__((aligned(16))) float Dl[MT_COLS * MT_DS];
+    __shared__ unsigned long long colbest[4][MT_COLS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int p = blockIdx.y, rb = blockIdx.x;
+    const int n1 = pair_count(n1p, p * n_stride, N1);
+    const int n2 = pair_count(n2p, p * n_stride + n_off2, N2);
+    const int row0 = rb * MT_ROWS;
+    if (n1 <= 0 || n2 <= 0 || row0 >= n1) return;
+    const float* A = d1 + (size_t)p * ps1;
+    const float* Bm = d2 + (size_t)p * ps2;
+
+    // stationary A fragments: step s uses k = s (lanes 0-31) / k = 32+s (lanes 32-63)
+    float a[2][32];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int row = min(row0 + wave * 64 + rt * 32 + l31, n1 - 1);
+        const float4* src = reinterpret_cast<const float4*>(A + (size_t)row * 64 + 32 * half);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 v = src[q];
+            a[rt][4 * q + 0] = v.x; a[rt][4 * q + 1] = v.y; a[rt][4 * q + 2] = v.z; a[rt][4 * q + 3] = v.w;
+        }
+    }
+    float bv[2][16];
+    int bc[2][16];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { bv[rt][r] = -INFINITY; bc[rt][r] = 0; }
+
+    for (int c0 = 0; c0 < n2; c0 += MT_COLS) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = tid + i * 256;
+            const int col = e >> 4, q = e & 15;
+            const int gc = min(c0 + col, n2 - 1);
+            const float4 v = *reinterpret_cast<const float4*>(Bm + (size_t)gc * 64 + 4 * q);
+            *reinterpret_cast<float4*>(Dl + col * MT_DS + 4 * q) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int ct = 0; ct < MT_COLS / 32; ++ct) {
+            const int cbase = c0 + ct * 32;
+            if (cbase >= n2) break;
+            float bf[32];
+            const float4* bp = reinterpret_cast<const float4*>(Dl + (ct * 32 + l31) * MT_DS + 32 * half);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = bp[q];
+                bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
+            }
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s], bf[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s], bf[s], acc1, 0, 0, 0);
+            }
+            // D[i=row][j=col]: this lane holds column cbase+l31, rows (r&3)+8*(r>>2)+4*half
+            const int col = cbase + l31;
+            const bool cvalid = col < n2;
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float v0 = acc0[r], v1 = acc1[r];
+                if (cvalid && v0 > bv[0][r]) { bv[0][r] = v0; bc[0][r] = col; }
+                if (cvalid && v1 > bv[1][r]) { bv[1][r] = v1; bc[1][r] = col; }
+                const int rowa = row0 + wave * 64 + rl, rowb = rowa + 32;
+                if (rowa < n1) best = u64_max(best, ((unsigned long long)float_ord(v0) << 32) | (0xffffffffu - (unsigned)rowa));
+                if (rowb < n1) best = u64_max(best, ((unsigned long long)float_ord(v1) << 32) | (0xffffffffu - (unsigned)rowb));
+            }
+            best = u64_max(best, shfl_xor_u64(best, 32));
+            if (half == 0) colbest[wave][ct * 32 + l31] = best;
+        }
+        __syncthreads();
+        if (tid < MT_COLS) {
+            const int col = c0 + tid;
+            if (col < n2) {
+                const unsigned long long k = u64_max(u64_max(colbest[0][tid], colbest[1][tid]),
+                                                     u64_max(colbest[2][tid], colbest[3][tid]));
+                colpart[((size_t)p * nrb + rb) * N2 + col] = k;
+            }
+        }
+    }
+
+    // row arg-max: reduce the per-lane running maxima over the 32 lanes that share the rows
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            unsigned long long key = ((unsigned long long)float_ord(bv[rt][r]) << 32) | (0xffffffffu - (unsigned)bc[rt][r]);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) key = u64_max(key, shfl_xor_u64(key, o));
+            const int row = row0 + wave * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (l31 == 0 && row < n1) {
+                match12[(size_t)p * N1 + row] = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+                rowmax[(size_t)p * N1 + row] = ord_float((unsigned)(key >> 32));
+            }
+        }
+}
+
+// grid (P), block 1024, dynamic LDS = N2 ints
+__global__ __launch_bounds__(1024) void mnn_finalize_kernel(const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p,
+                                                            int n_stride, int n_off2, int N1, int N2, int nrb,
+                                                            const int* __restrict__ match12, const float* __restrict__ rowmax,
+                                                            const unsigned long long* __restrict__ colpart, float min_cossim,
+                                                            int64_t* __restrict__ idx0, int64_t* __restrict__ idx1,
+                                                            int32_t* __restrict__ n_matches) {
+    extern __shared__ int m21[];
+    __shared__ int wsum[16];
+    __shared__ int s_base;
+    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n1 = pair_count(n1p, p * n_stride, N1);
+    const int n2 = pair_count(n2p, p * n_stride + n_off2, N2);
+    if (n1 <= 0 || n2 <= 0) {
+        if (tid == 0) n_matches[p] = 0;
+        return;
+    }
+    const int nrbp = ceil_div(n1, MT_ROWS);
+    for (int col = tid; col < n2; col += 1024) {
+        unsigned long long best = 0ull;
+        for (int rb = 0; rb < nrbp; ++rb) best = u64_max(best, colpart[((size_t)p * nrb + rb) * N2 + col]);
+        m21[col] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
+    }
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const int* m12 = match12 + (size_t)p * N1;
+    const float* rm = rowmax + (size_t)p * N1;
+    for (int base = 0; base < n1; base += 1024) {
+        const int row = base + tid;
+        bool keep = false;
+        int m = 0;
+        if (row < n1) {
+            m = m12[row];
+            keep = (m21[m] == row) && (min_cossim <= 0.f || rm[row] > min_cossim);
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int s = wsum[w];
+            if (w < wave) off += s;
+            tot += s;
+        }
+        if (keep) {
+            idx0[(size_t)p * N1 + off + before] = row;
+            idx1[(size_t)p * N1 + off + before] = m;
+        }
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) n_matches[p] = s_base;
+}
+
+void prof_begin(Profiler* p, int which, hipStream_t st);
+void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
+
+void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
+                  const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim, int64_t* idx0,
+                  int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof) {
+    const int nrb = match_row_blocks(N1);
+    prof_begin(prof, 2, st);
+    mnn_sim_kernel<<<dim3(nrb, P), 256, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, ws.match12,
+                                                 ws.rowmax, ws.colpart);
+    prof_end(prof, 2, st, 2.0 * P * (double)N1 * N2 * 64, (double)P * (N1 + N2) * 64 * 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnn_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            16384 * 4);
+        attr_set = true;
+    }
+    mnn_finalize_kernel<<<P, 1024, (size_t)N2 * sizeof(int), st>>>(n1, n2, n_stride, n_off2, N1, N2, nrb, ws.match12,
+                                                                  ws.rowmax, ws.colpart, min_cossim, idx0, idx1,
+                                                                  n_matches);
+}
+
+}  // namespace xfh

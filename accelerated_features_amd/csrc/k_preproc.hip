@@ -1,0 +1,152 @@
+// Pre-processing kernels: channel-mean + InstanceNorm2d(1), bilinear resize, pyramid sum.
+// All HBM-bound streaming kernels: float4 rows, 64-lane wave reductions, fp64 statistics.
+#include "kernels.hpp"
+
+namespace xfh {
+
+// ------------------------------------------------------------------------------------------
+// gray = mean over C ; per-image mean / biased variance in fp64     (model.py:135-136)
+// grid (GS_CHUNKS, B), block 256.  part[b][chunk][2] = {sum, sum of squares}
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gray_stats_kernel(const float* __restrict__ img, int C, int HW,
+                                                         double* __restrict__ part) {
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int n4 = HW >> 2;
+    const int per = ceil_div(n4, GS_CHUNKS);
+    const int beg = ch * per, end = min(beg + per, n4);
+    const float4* base = reinterpret_cast<const float4*>(img + (size_t)b * C * HW);
+    const float fC = (float)C;
+    double s = 0.0, q = 0.0;
+    for (int i = beg + tid; i < end; i += 256) {
+        float4 a = base[i];
+        for (int c = 1; c < C; ++c) {
+            float4 v = base[(size_t)c * n4 + i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        a.x /= fC; a.y /= fC; a.z /= fC; a.w /= fC;
+        s += (double)a.x + (double)a.y + (double)a.z + (double)a.w;
+        q += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    __shared__ double sm[8];
+    if ((tid & 63) == 0) { sm[(tid >> 6) * 2] = s; sm[(tid >> 6) * 2 + 1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        part[((size_t)b * GS_CHUNKS + ch) * 2 + 0] = sm[0] + sm[2] + sm[4] + sm[6];
+        part[((size_t)b * GS_CHUNKS + ch) * 2 + 1] = sm[1] + sm[3] + sm[5] + sm[7];
+    }
+}
+
+// out = gray * invstd + (-mean * invstd)     grid (ceil(HW/4/256), B)
+__global__ __launch_bounds__(256) void gray_norm_kernel(const float* __restrict__ img, int C, int HW,
+                                                        const double* __restrict__ part, float eps,
+                                                        float* __restrict__ out) {
+    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ float sm[2];
+    if (tid < 64) {
+        double s = part[((size_t)b * GS_CHUNKS + tid) * 2 + 0];
+        double q = part[((size_t)b * GS_CHUNKS + tid) * 2 + 1];
+        s = wave_sum(s);
+        q = wave_sum(q);
+        if (tid == 0) {
+            double mean = s / HW;
+            double var = q / HW - mean * mean;
+            if (var < 0) var = 0;
+            float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            sm[0] = invstd;
+            sm[1] = -(float)mean * invstd;
+        }
+    }
+    __syncthreads();
+    const float alpha = sm[0], beta = sm[1];
+    const int n4 = HW >> 2;
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= n4) return;
+    const float4* base = reinterpret_cast<const float4*>(img + (size_t)b * C * HW);
+    const float fC = (float)C;
+    float4 a = base[i];
+    for (int c = 1; c < C; ++c) {
+        float4 v = base[(size_t)c * n4 + i];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    a.x = fmaf(a.x / fC, alpha, beta);
+    a.y = fmaf(a.y / fC, alpha, beta);
+    a.z = fmaf(a.z / fC, alpha, beta);
+    a.w = fmaf(a.w / fC, alpha, beta);
+    reinterpret_cast<float4*>(out + (size_t)b * HW)[i] = a;
+}
+
+void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, hipStream_t st) {
+    const int HW = H * W;
+    gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, part);
+    gray_norm_kernel<<<dim3(ceil_div(HW / 4, 256), B), 256, 0, st>>>(img, C, HW, part, 1e-5f, gray);
+}
+
+// ------------------------------------------------------------------------------------------
+// bilinear, align_corners=False (ATen area_pixel_compute_source_index, cubic=false):
+//   src = max(scale*(dst+0.5)-0.5, 0) ; i0=(int)src ; i1=min(i0+1,in-1) ; l1=src-i0 ; l0=1-l1
+//   out = wy0*(wx0*v00+wx1*v01) + wy1*(wx0*v10+wx1*v11)
+// ------------------------------------------------------------------------------------------
+__device__ inline void lin_coef(float scale, int dst, int in, int& i0, int& i1, float& l0, float& l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = min(i0 + 1, in - 1);
+    l1 = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
+    l0 = 1.f - l1;
+}
+__device__ inline float bilerp(const float* __restrict__ p, int Win, int y0, int y1, int x0, int x1,
+                               float wy0, float wy1, float wx0, float wx1) {
+    const float v00 = p[y0 * Win + x0], v01 = p[y0 * Win + x1];
+    const float v10 = p[y1 * Win + x0], v11 = p[y1 * Win + x1];
+    return wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ src, int Hin, int Win,
+                                                              float* __restrict__ dst, int Hout, int Wout,
+                                                              float sh, float sw) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int pl = blockIdx.z;
+    if (ox >= Wout || oy >= Hout) return;
+    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+    lin_coef(sh, oy, Hin, y0, y1, wy0, wy1);
+    lin_coef(sw, ox, Win, x0, x1, wx0, wx1);
+    const float* p = src + (size_t)pl * Hin * Win;
+    dst[((size_t)pl * Hout + oy) * Wout + ox] = bilerp(p, Win, y0, y1, x0, x1, wy0, wy1, wx0, wx1);
+}
+
+void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,
+                            float sh, float sw, hipStream_t st) {
+    resize_bilinear_kernel<<<dim3(ceil_div(Wout, 64), ceil_div(Hout, 4), planes), 256, 0, st>>>(
+        src, Hin, Win, dst, Hout, Wout, sh, sw);
+}
+
+// out = x3 + up(x4 -> x3 size) + up(x5 -> x3 size)      (model.py:146-148), NCHW planes
+__global__ __launch_bounds__(256) void pyramid_sum_kernel(const float* __restrict__ x3, const float* __restrict__ x4,
+                                                          const float* __restrict__ x5, float* __restrict__ out,
+                                                          int H3, int W3, int H4, int W4, int H5, int W5) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int pl = blockIdx.z;
+    if (ox >= W3 || oy >= H3) return;
+    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+    lin_coef((float)H4 / (float)H3, oy, H4, y0, y1, wy0, wy1);
+    lin_coef((float)W4 / (float)W3, ox, W4, x0, x1, wx0, wx1);
+    const float u4 = bilerp(x4 + (size_t)pl * H4 * W4, W4, y0, y1, x0, x1, wy0, wy1, wx0, wx1);
+    lin_coef((float)H5 / (float)H3, oy, H5, y0, y1, wy0, wy1);
+    lin_coef((float)W5 / (float)W3, ox, W5, x0, x1, wx0, wx1);
+    const float u5 = bilerp(x5 + (size_t)pl * H5 * W5, W5, y0, y1, x0, x1, wy0, wy1, wx0, wx1);
+    const size_t o = ((size_t)pl * H3 + oy) * W3 + ox;
+    out[o] = (x3[o] + u4) + u5;
+}
+
+void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int planes,
+                        int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st) {
+    pyramid_sum_kernel<<<dim3(ceil_div(W3, 64), ceil_div(H3, 4), planes), 256, 0, st>>>(
+        x3, x4, x5, out, H3, W3, H4, W4, H5, W5);
+}
+
+}  // namespace xfh

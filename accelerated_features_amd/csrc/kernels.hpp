@@ -1,0 +1,126 @@
+// Internal declarations shared by the kernel translation units and api.hip.
+#pragma once
+#include "common.hpp"
+
+namespace xfh {
+
+constexpr int GS_CHUNKS = 64;   // partial-sum chunks per image in gray_stats_kernel
+
+// Index of every conv in execution order == accelerated_features_amd/spec.py::CONVS.
+enum Layer {
+    L_SKIP1 = 0, L_BLOCK1_0, L_BLOCK1_1, L_BLOCK1_2, L_BLOCK1_3, L_BLOCK2_0, L_BLOCK2_1,
+    L_BLOCK3_0, L_BLOCK3_1, L_BLOCK3_2, L_BLOCK4_0, L_BLOCK4_1, L_BLOCK4_2,
+    L_BLOCK5_0, L_BLOCK5_1, L_BLOCK5_2, L_BLOCK5_3, L_FUSION_0, L_FUSION_1, L_FUSION_2,
+    L_HEAT_0, L_HEAT_1, L_HEAT_2, L_KP_0, L_KP_1, L_KP_2, L_KP_3, L_NUM
+};
+
+struct ConvW {
+    int cin, cout, ks, stride, relu, cout_pad;   // cout_pad = cout rounded up to 32
+    const float* w_oihw;   // (cout,cin,k,k)  BN folded
+    const float* w_kc;     // [(ci*kk+tap)][cout]      BN folded (block1 direct kernels)
+    const float* w_kcp;    // [(ci*kk+tap)][cout_pad]  BN folded, zero padded (MFMA kernels)
+    const float* bias;     // [cout_pad] folded BN shift or conv bias, zero padded
+};
+
+struct LinW {             // fine_matcher layer: y = relu?(x W^T + b), BN folded
+    int k, n, n_pad, relu;
+    const float* w_kn;    // [k][n_pad]
+    const float* bias;    // [n_pad]
+};
+
+struct NetWeights {
+    ConvW conv[L_NUM];
+    LinW fine[5];
+};
+
+struct Profiler;   // api.hip
+
+// ---- k_preproc.hip ----------------------------------------------------------------------
+void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, hipStream_t st);
+void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,
+                            float sh, float sw, hipStream_t st);
+void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int planes,
+                        int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st);
+
+// ---- k_conv_direct.hip ------------------------------------------------------------------
+void launch_block1(const NetWeights& nw, const float* gray, int B, int H, int W, float* t0, float* t1, float* t2,
+                   float* x1, hipStream_t st);
+int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B, int Hin, int Win, float* out,
+                        hipStream_t st);
+void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, hipStream_t st);
+
+// ---- k_conv_mfma.hip --------------------------------------------------------------------
+// 3x3 / 1x1 convolution as an implicit GEMM on f32 MFMA.  in NCHW; out NCHW or NHWC.
+// Returns 0, or -1 when no instantiation exists for the layer shape.
+int launch_conv_mfma(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, bool nhwc_out,
+                     hipStream_t st);
+double conv_flops(const ConvW& c, int B, int Hout, int Wout);
+
+// ---- k_linear_mfma.hip ------------------------------------------------------------------
+enum LinLoader { LOAD_ROWMAJOR = 0, LOAD_UNFOLD8 = 1, LOAD_GATHER2 = 2 };
+struct LinSrc {
+    const float* x;        // ROWMAJOR: (M,K) ; UNFOLD8: normalised gray (B,H,W) ; GATHER2: desc0 (P,N,64)
+    int ldx;               // ROWMAJOR: row stride in floats
+    int H, W;              // UNFOLD8: image size (M = B*(H/8)*(W/8))
+    const float* x2;       // GATHER2: desc1 (P,N,64)
+    const int64_t* idx0;   // GATHER2: (P,N)
+    const int64_t* idx1;
+    const int32_t* rowmap; // GATHER2: compact row -> p*N + r
+    int N;                 // GATHER2: capacity per pair
+};
+// y (M,n) row-major with leading dimension ldy.  m_dev (optional) = device int32 with the live
+// row count (<= M): workgroups past it exit.
+int launch_linear_mfma(const float* w_kn, const float* bias, int K, int N, int n_pad, bool relu,
+                       LinLoader loader, const LinSrc& src, int M, const int32_t* m_dev,
+                       float* y, int ldy, hipStream_t st);
+// reliability = sigmoid(x . w + b) per row of x (M,64)                     (model.py:82-83)
+void launch_dot_sigmoid(const float* x, int M, const float* w, const float* b, float* out, hipStream_t st);
+// heat (B,H,W) <- softmax over 65 logits per cell, depth-to-space 8x8       (xfeat.py:242-247)
+void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat, hipStream_t st);
+
+// ---- k_detect.hip -----------------------------------------------------------------------
+struct DetectWs {          // carved from the caller's workspace by api.hip
+    unsigned long long* mask;   // (B, H, WPR) NMS flags, one bit per pixel
+    int* wcount;                // (B, H*WPR)  popcounts
+    unsigned* cand;             // (B, cap)    (y<<16)|x in row-major order
+    unsigned long long* keys;   // (B, cap)    sort keys
+    unsigned* sel;              // (B, top_k)  sorted candidate slots
+    int* nsel;                  // (B)         min(n_candidates, cap, top_k)
+    float* invnorm;             // (B, hc*wc)  1/max(||feats||,1e-12)
+};
+void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, int B, int H, int W,
+                   float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
+                   int32_t* n_valid, int32_t* n_cand, hipStream_t st);
+void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int cap, int64_t* xy,
+                     int32_t* n_cand, hipStream_t st);
+// top-k of a (B,n) float array, descending (ties: lower index first).  keys scratch (B,n) u64,
+// sel (B,k) u32 receives the indices.
+void launch_topk_desc(const float* vals, int B, int n, int k, unsigned long long* keys, unsigned* sel, int* nsel,
+                      hipStream_t st);
+void launch_dense_gather(const float* feats, const unsigned* sel, int B, int hc, int wc, int k, float rw, float rh,
+                         float scale_div, float* kpts, float* desc, int32_t* cell_index, hipStream_t st);
+
+// ---- k_match.hip ------------------------------------------------------------------------
+struct MatchWs {
+    int* match12;                  // (P,N1)
+    float* rowmax;                 // (P,N1)
+    unsigned long long* colpart;   // (P, nrb, N2) packed (ord(sim)<<32 | ~row)
+};
+void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
+                  const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim,
+                  int64_t* idx0, int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof);
+int match_row_blocks(int N1);
+
+// ---- k_refine.hip -----------------------------------------------------------------------
+void launch_refine_rowmap(const int32_t* n_matches, int P, int N, int32_t* offs, int32_t* rowmap, int32_t* total,
+                          hipStream_t st);
+void launch_refine_finish(const float* o /*(T,64)*/, const int32_t* rowmap, const int32_t* offs, const int32_t* total,
+                          const float* kp0, const float* kp1, const float* scale0, const int64_t* idx0,
+                          const int64_t* idx1, int P, int N, float fine_conf, float* out, int32_t* n_out,
+                          float* rows_tmp, unsigned char* keep_tmp, hipStream_t st);
+
+// ---- profiling hooks (api.hip) ------------------------------------------------------------
+void prof_begin(Profiler* p, int which, hipStream_t st);
+void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
+
+}  // namespace xfh

@@ -1,0 +1,564 @@
+"""MI355X-native XFeat inference, drop-in for the reference's ``modules/xfeat.py::XFeat``.
+
+Same class name, method names, argument names/defaults and return types as the reference
+(/root/reference/modules/xfeat.py:17-403, hubconf.py:5-15), so existing callers only change
+the import.  All arithmetic runs in hand-written HIP kernels for gfx950 reached through the
+C ABI of ``libxfeat_hip.so`` (include/xfeat_hip.h); PyTorch is used for device memory, streams
+and the tensors handed back to the caller.  There is no second backend: without a GPU, or
+without the shared library, every inference call raises.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .spec import CONVS, FINE
+
+__all__ = ["XFeat", "XFeatModel"]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Group(nn.Module):
+    """Bare container so parameter names match the reference's nested Sequential modules."""
+
+
+def _attach(root, dotted, tensor, buffer):
+    mod = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        if not hasattr(mod, p):
+            mod.add_module(p, _Group())
+        mod = getattr(mod, p)
+    if buffer:
+        mod.register_buffer(parts[-1], tensor)
+    else:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class _FineMatcher(_Group):
+    """``net.fine_matcher(x)``: (n,128) -> (n,64)   (reference: modules/model.py:97-111)."""
+
+    def forward(self, x):
+        return self._owner()._fine_matcher(x)
+
+
+class XFeatModel(nn.Module):
+    """Parameter container with the reference's ``state_dict`` keys (modules/model.py:33-111);
+    ``forward`` runs the HIP backbone and returns the same triple as the reference:
+    feats (B,64,H/8,W/8), keypoint logits (B,65,H/8,W/8), reliability (B,1,H/8,W/8).
+    feats and logits are channels-last in memory (same shape/values, different strides)."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(0)
+        for c in CONVS:
+            fan_in = c.cin * c.k * c.k
+            bound = 1.0 / math.sqrt(fan_in)
+            w = (torch.rand((c.cout, c.cin, c.k, c.k), generator=g) * 2 - 1) * bound
+            if c.kind == "bn":
+                _attach(self, f"{c.name}.layer.0.weight", w, False)
+                _attach(self, f"{c.name}.layer.1.running_mean", torch.zeros(c.cout), True)
+                _attach(self, f"{c.name}.layer.1.running_var", torch.ones(c.cout), True)
+                _attach(self, f"{c.name}.layer.1.num_batches_tracked", torch.tensor(0, dtype=torch.long), True)
+            else:
+                _attach(self, f"{c.name}.weight", w, False)
+                _attach(self, f"{c.name}.bias", (torch.rand(c.cout, generator=g) * 2 - 1) * bound, False)
+        self.add_module("fine_matcher", _FineMatcher())
+        for li, fin, fout, bi in FINE:
+            bound = 1.0 / math.sqrt(fin)
+            _attach(self, f"fine_matcher.{li}.weight", (torch.rand((fout, fin), generator=g) * 2 - 1) * bound, False)
+            _attach(self, f"fine_matcher.{li}.bias", (torch.rand(fout, generator=g) * 2 - 1) * bound, False)
+            if bi is not None:
+                _attach(self, f"fine_matcher.{bi}.running_mean", torch.zeros(fout), True)
+                _attach(self, f"fine_matcher.{bi}.running_var", torch.ones(fout), True)
+                _attach(self, f"fine_matcher.{bi}.num_batches_tracked", torch.tensor(0, dtype=torch.long), True)
+        me = self
+        self.fine_matcher._owner = lambda: me          # not a registered submodule cycle
+        self._handle = None
+        self._handle_device = None
+        self._ws = {}
+
+    # -- weights -> C handle -------------------------------------------------------------------
+    def weight_arrays(self):
+        """The fp32 host arrays in the canonical order of include/xfeat_hip.h (xfh_create)."""
+        sd = self.state_dict()
+        out = []
+        for c in CONVS:
+            if c.kind == "bn":
+                keys = [f"{c.name}.layer.0.weight", f"{c.name}.layer.1.running_mean", f"{c.name}.layer.1.running_var"]
+            else:
+                keys = [f"{c.name}.weight", f"{c.name}.bias"]
+            out += [sd[k] for k in keys]
+        for li, fin, fout, bi in FINE:
+            out += [sd[f"fine_matcher.{li}.weight"], sd[f"fine_matcher.{li}.bias"]]
+            if bi is not None:
+                out += [sd[f"fine_matcher.{bi}.running_mean"], sd[f"fine_matcher.{bi}.running_var"]]
+        return [np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy()) for t in out]
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._drop_handle()
+        return r
+
+    def _drop_handle(self):
+        if getattr(self, "_handle", None):
+            _lib.load().xfh_destroy(self._handle)
+        self._handle = None
+
+    def __del__(self):
+        try:
+            self._drop_handle()
+        except Exception:
+            pass
+
+    def handle(self):
+        if not torch.cuda.is_available():
+            raise _lib.XFeatHipError("accelerated_features_amd needs an AMD MI355X (gfx950) GPU: "
+                                     "torch.cuda.is_available() is False and there is no CPU fallback")
+        dev = torch.cuda.current_device()
+        if self._handle is not None and self._handle_device == dev:
+            return self._handle
+        self._drop_handle()
+        lib = _lib.load()
+        arrs = self.weight_arrays()
+        n = lib.xfh_num_weight_arrays()
+        if len(arrs) != n:
+            raise _lib.XFeatHipError(f"weight table has {len(arrs)} arrays, library expects {n}")
+        for i, a in enumerate(arrs):
+            if a.size != lib.xfh_weight_array_floats(i):
+                raise _lib.XFeatHipError(f"weight array {i} has {a.size} floats, expected {lib.xfh_weight_array_floats(i)}")
+        ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        h = C.c_void_p()
+        _lib.check(lib.xfh_create(ptrs, n, dev, C.byref(h)), "xfh_create")
+        self._handle, self._handle_device = h, dev
+        return h
+
+    def workspace(self, name, nbytes):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = self._ws.get(name)
+        if t is None or t.numel() < nbytes or t.device != dev:
+            t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=dev)
+            self._ws[name] = t
+        off = (-t.data_ptr()) % 256
+        return t[off:], int(nbytes)
+
+    # -- the network -----------------------------------------------------------------------------
+    def backbone(self, x, want_logits=True, want_heat=False):
+        """x (B,C,H,W) float32 CUDA, H%32==W%32==0 -> (feats_cl (B,h,w,64), logits_cl|None, heat|None, rel (B,h,w))."""
+        if x.dim() != 4:
+            raise RuntimeError("Input tensor needs to be in (B,C,H,W) format")
+        lib = _lib.load()
+        h = self.handle()
+        x = x.contiguous().float()
+        B, Cc, H, W = x.shape
+        hc, wc = H // 8, W // 8
+        dev = x.device
+        feats = torch.empty((B, hc, wc, 64), dtype=torch.float32, device=dev)
+        rel = torch.empty((B, hc, wc), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, hc, wc, 65), dtype=torch.float32, device=dev) if want_logits else None
+        heat = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_heat else None
+        ws, n = self.workspace("backbone", lib.xfh_backbone_workspace_bytes(B, Cc, H, W))
+        _lib.check(lib.xfh_backbone(h, _ptr(x), B, Cc, H, W, _ptr(feats), _ptr(logits), _ptr(heat), _ptr(rel),
+                                    _ptr(ws), n, _stream()), "xfh_backbone")
+        return feats, logits, heat, rel
+
+    def forward(self, x):
+        feats, logits, _, rel = self.backbone(x, want_logits=True, want_heat=False)
+        return feats.permute(0, 3, 1, 2), logits.permute(0, 3, 1, 2), rel[:, None]
+
+    def _fine_matcher(self, x):
+        lib = _lib.load()
+        h = self.handle()
+        x = x.contiguous().float()
+        n = x.shape[0]
+        out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
+        if n == 0:
+            return out
+        ws, nb = self.workspace("refine", lib.xfh_refine_workspace_bytes(1, n))
+        _lib.check(lib.xfh_fine_matcher(h, _ptr(x), n, _ptr(out), _ptr(ws), nb, _stream()), "xfh_fine_matcher")
+        return out
+
+
+class XFeat(nn.Module):
+    """
+        Implements the inference module for XFeat (sparse and semi-dense extraction & matching)
+        on MI355X.  Mirrors /root/reference/modules/xfeat.py::XFeat.
+    """
+
+    def __init__(self, weights=os.path.abspath(os.path.dirname(__file__)) + '/../weights/xfeat.pt', top_k=4096,
+                 detection_threshold=0.05):
+        super().__init__()
+        self.dev = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        self.net = XFeatModel().eval()
+        self.top_k = top_k
+        self.detection_threshold = detection_threshold
+
+        if weights is not None:
+            if isinstance(weights, str):
+                print('loading weights from: ' + weights)
+                self.net.load_state_dict(torch.load(weights, map_location='cpu'))
+            else:
+                self.net.load_state_dict(weights)
+
+        self.interpolator = None           # reference attribute (InterpolateSparse2d); sampling is fused in HIP
+        self.kornia_available = False
+        self.lighterglue = None
+
+    # ------------------------------------------------------------------------------------------
+    # sparse
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def detectAndCompute(self, x, top_k=None, detection_threshold=None):
+        """
+            Compute sparse keypoints & descriptors. Supports batched mode.
+
+            input:
+                x -> torch.Tensor(B, C, H, W): grayscale or rgb image
+                top_k -> int: keep best k features
+            return:
+                List[Dict]:
+                    'keypoints'    ->   torch.Tensor(N, 2): keypoints (x,y)
+                    'scores'       ->   torch.Tensor(N,): keypoint scores
+                    'descriptors'  ->   torch.Tensor(N, 64): local features
+        """
+        cap = None
+        while True:
+            kpts, scores, desc, n_valid, n_cand, cap, hw = self._detect_device(x, top_k, detection_threshold, cap)
+            cnt = torch.stack([n_valid, n_cand]).cpu()           # the one read-back per batch
+            ncmax = int(cnt[1].max())
+            if cap >= hw or ncmax <= cap:
+                break
+            cap = min(hw, max(ncmax, 2 * cap))                   # plateau image: exact re-run with room
+        nv = cnt[0].tolist()
+        return [{'keypoints': kpts[b, :nv[b]], 'scores': scores[b, :nv[b]], 'descriptors': desc[b, :nv[b]]}
+                for b in range(len(nv))]
+
+    def _detect_device(self, x, top_k=None, detection_threshold=None, cap=None):
+        """Fixed-capacity device results, no read-back: kpts (B,top_k,2), scores (B,top_k),
+        desc (B,top_k,64), n_valid (B) int32, n_cand (B) int32, the NMS capacity used, H*W.
+        If n_cand.max() > capacity the candidate list was truncated (caller re-runs)."""
+        if top_k is None: top_k = self.top_k
+        if detection_threshold is None: detection_threshold = self.detection_threshold
+        x, rh1, rw1 = self.preprocess_tensor(x)
+        B, _, H, W = x.shape
+        feats, _, heat, rel = self.net.backbone(x, want_logits=False, want_heat=True)
+        if cap is None:
+            cap = min(H * W, max(int(top_k), (H * W) // 8))
+        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1)
+        return out[0], out[1], out[2], out[3], out[4], cap, H * W
+
+    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh):
+        lib = _lib.load()
+        dev = feats.device
+        kpts = torch.empty((B, top_k, 2), dtype=torch.float32, device=dev)
+        scores = torch.empty((B, top_k), dtype=torch.float32, device=dev)
+        desc = torch.empty((B, top_k, 64), dtype=torch.float32, device=dev)
+        n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
+        n_cand = torch.empty((B,), dtype=torch.int32, device=dev)
+        ws, n = self.net.workspace("detect", lib.xfh_detect_workspace_bytes(B, H, W, top_k, cap))
+        _lib.check(lib.xfh_detect_sparse(self.net.handle(), _ptr(heat), _ptr(rel), _ptr(feats), B, H, W, float(thr), top_k, cap,
+                                         float(rw), float(rh), _ptr(kpts), _ptr(scores), _ptr(desc), _ptr(n_valid),
+                                         _ptr(n_cand), _ptr(ws), n, _stream()), "xfh_detect_sparse")
+        return kpts, scores, desc, n_valid, n_cand
+
+    # ------------------------------------------------------------------------------------------
+    # semi-dense
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def detectAndComputeDense(self, x, top_k=None, multiscale=True):
+        """
+            Compute dense *and coarse* descriptors. Supports batched mode.
+            return: features sorted by their reliability score -- from most to least
+                Dict:
+                    'keypoints'    ->   torch.Tensor(B, top_k, 2): coarse keypoints
+                    'scales'       ->   torch.Tensor(B, top_k): extraction scale
+                    'descriptors'  ->   torch.Tensor(B, top_k, 64): coarse local features
+        """
+        if top_k is None: top_k = self.top_k
+        if multiscale:
+            mkpts, sc, feats = self.extract_dualscale(x, top_k)
+        else:
+            mkpts, feats = self.extractDense(x, top_k)
+            sc = torch.ones(mkpts.shape[:2], device=mkpts.device)
+        return {'keypoints': mkpts, 'descriptors': feats, 'scales': sc}
+
+    @torch.inference_mode()
+    def match_lighterglue(self, d0, d1, min_conf=0.1):
+        """LighterGlue (modules/lighterglue.py -> kornia LightGlue) is not part of this build
+        (next component; kornia is absent, parity unpinned)."""
+        raise RuntimeError('We rely on kornia for LightGlue. Install with: pip install kornia '
+                           '(match_lighterglue is not implemented in accelerated_features_amd yet)')
+
+    @torch.inference_mode()
+    def match_xfeat(self, img1, img2, top_k=None, min_cossim=-1):
+        """
+            Simple extractor and MNN matcher (B=1).
+            returns:
+                mkpts_0, mkpts_1 -> np.ndarray (N,2) xy coordinate matches from image1 to image2
+        """
+        if top_k is None: top_k = self.top_k
+        img1 = self.parse_input(img1)
+        img2 = self.parse_input(img2)
+
+        out1 = self.detectAndCompute(img1, top_k=top_k)[0]
+        out2 = self.detectAndCompute(img2, top_k=top_k)[0]
+
+        idxs0, idxs1 = self.match(out1['descriptors'], out2['descriptors'], min_cossim=min_cossim)
+
+        return out1['keypoints'][idxs0].cpu().numpy(), out2['keypoints'][idxs1].cpu().numpy()
+
+    @torch.inference_mode()
+    def match_xfeat_star(self, im_set1, im_set2, top_k=None):
+        """
+            Extracts coarse feats, then match pairs and finally refine matches (batched).
+            returns:
+                matches -> List[torch.Tensor(N, 4)]: List of size B of pairwise matches (x1,y1,x2,y2);
+                           for B == 1 a tuple of two numpy (N,2) arrays, like the reference.
+        """
+        if top_k is None: top_k = self.top_k
+        im_set1 = self.parse_input(im_set1)
+        im_set2 = self.parse_input(im_set2)
+
+        out1 = self.detectAndComputeDense(im_set1, top_k=top_k)
+        out2 = self.detectAndComputeDense(im_set2, top_k=top_k)
+
+        idx0, idx1, n_matches = self._batch_match_device(out1['descriptors'], out2['descriptors'], -1)
+        out, n_out = self._refine_device(out1, out2, idx0, idx1, n_matches, 0.25)
+        counts = n_out.cpu().tolist()               # the one read-back
+        matches = [out[b, :counts[b]] for b in range(len(counts))]
+        B = len(im_set1)
+        return matches if B > 1 else (matches[0][:, :2].cpu().numpy(), matches[0][:, 2:].cpu().numpy())
+
+    # ------------------------------------------------------------------------------------------
+    # pre-processing
+    # ------------------------------------------------------------------------------------------
+    def preprocess_tensor(self, x):
+        """ Guarantee that image is divisible by 32 to avoid aliasing artifacts. """
+        if isinstance(x, np.ndarray):
+            if len(x.shape) == 3:
+                x = torch.tensor(x).permute(2, 0, 1)[None]
+            elif len(x.shape) == 2:
+                x = torch.tensor(x[..., None]).permute(2, 0, 1)[None]
+            else:
+                raise RuntimeError('For numpy arrays, only (H,W) or (H,W,C) format is supported.')
+
+        if len(x.shape) != 4:
+            raise RuntimeError('Input tensor needs to be in (B,C,H,W) format')
+
+        self._require_gpu()
+        x = x.to(self.dev).float().contiguous()
+
+        H, W = x.shape[-2:]
+        _H, _W = (H // 32) * 32, (W // 32) * 32
+        if _H == 0 or _W == 0:
+            raise RuntimeError('Input image must be at least 32x32 pixels')
+        rh, rw = H / _H, W / _W
+        if (_H, _W) != (H, W):
+            x = self._resize(x, _H, _W, np.float32(H) / np.float32(_H), np.float32(W) / np.float32(_W))
+        return x, rh, rw
+
+    def _resize(self, x, Hout, Wout, scale_h, scale_w):
+        """bilinear, align_corners=False, with the source step PyTorch would use."""
+        lib = _lib.load()
+        B, Cc, H, W = x.shape
+        out = torch.empty((B, Cc, Hout, Wout), dtype=torch.float32, device=x.device)
+        _lib.check(lib.xfh_resize_bilinear(_ptr(x), B * Cc, H, W, _ptr(out), Hout, Wout, float(scale_h), float(scale_w),
+                                           _stream()), "xfh_resize_bilinear")
+        return out
+
+    def _require_gpu(self):
+        if self.dev.type != 'cuda':
+            raise _lib.XFeatHipError("accelerated_features_amd needs an AMD MI355X (gfx950) GPU; no CPU fallback exists")
+
+    # ------------------------------------------------------------------------------------------
+    # helper methods of the reference surface
+    # ------------------------------------------------------------------------------------------
+    def get_kpts_heatmap(self, kpts, softmax_temp=1.0):
+        """kpts (B,65,h,w) logits -> (B,1,8h,8w) heat map (xfeat.py:242-247)."""
+        self._require_gpu()
+        if softmax_temp != 1.0:
+            kpts = kpts * softmax_temp
+        lib = _lib.load()
+        B, Cc, h, w = kpts.shape
+        if Cc != 65:
+            raise RuntimeError('keypoint logits must have 65 channels')
+        cl = kpts.to(self.dev).float().permute(0, 2, 3, 1).contiguous()
+        heat = torch.empty((B, 1, h * 8, w * 8), dtype=torch.float32, device=cl.device)
+        _lib.check(lib.xfh_kpts_heatmap(_ptr(cl), B, h, w, _ptr(heat), _stream()), "xfh_kpts_heatmap")
+        return heat
+
+    def NMS(self, x, threshold=0.05, kernel_size=5):
+        """x (B,1,H,W) -> (B,Nmax,2) int64 (x,y), zero padded (xfeat.py:249-263)."""
+        if kernel_size != 5:
+            raise NotImplementedError('only kernel_size=5 (the value the reference uses) is implemented')
+        self._require_gpu()
+        lib = _lib.load()
+        x = x.to(self.dev).float().contiguous()
+        B, _, H, W = x.shape
+        cap = min(H * W, max(4096, (H * W) // 8))
+        while True:
+            xy = torch.empty((B, cap, 2), dtype=torch.int64, device=x.device)
+            nc = torch.empty((B,), dtype=torch.int32, device=x.device)
+            ws, n = self.net.workspace("detect", lib.xfh_detect_workspace_bytes(B, H, W, 1, cap))
+            _lib.check(lib.xfh_nms(self.net.handle(), _ptr(x), B, H, W, float(threshold), cap, _ptr(xy), _ptr(nc), _ptr(ws), n,
+                                   _stream()), "xfh_nms")
+            nmax = int(nc.max().item())
+            if nmax <= cap:
+                return xy[:, :nmax]
+            cap = min(H * W, max(nmax, 2 * cap))
+
+    @torch.inference_mode()
+    def batch_match(self, feats1, feats2, min_cossim=-1):
+        idx0, idx1, n = self._batch_match_device(feats1, feats2, min_cossim)
+        counts = n.cpu().tolist()
+        return [(idx0[b, :counts[b]], idx1[b, :counts[b]]) for b in range(len(counts))]
+
+    def _batch_match_device(self, feats1, feats2, min_cossim):
+        self._require_gpu()
+        lib = _lib.load()
+        f1 = feats1.to(self.dev).float().contiguous()
+        f2 = feats2.to(self.dev).float().contiguous()
+        P, N1, D = f1.shape
+        _, N2, _ = f2.shape
+        if D != 64 or f2.shape[0] != P or f2.shape[2] != 64:
+            raise RuntimeError('descriptors must be (B,N,64)')
+        idx0 = torch.empty((P, N1), dtype=torch.int64, device=f1.device)
+        idx1 = torch.empty((P, N1), dtype=torch.int64, device=f1.device)
+        n = torch.empty((P,), dtype=torch.int32, device=f1.device)
+        ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, N1, N2))
+        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(f1), N1 * 64, _ptr(f2), N2 * 64, None, None, 0, 0, P, N1, N2,
+                                     float(min_cossim), _ptr(idx0), _ptr(idx1), _ptr(n), _ptr(ws), nb, _stream()),
+                   "xfh_match_mnn")
+        return idx0, idx1, n
+
+    def match_pairs_device(self, desc, n_valid, min_cossim=-1):
+        """Match consecutive frames (2i, 2i+1) of one detection batch without any read-back.
+        desc (B,top_k,64), n_valid (B) int32 as returned by _detect_device; B even.
+        Returns idx0, idx1 (B/2, top_k) int64 and n_matches (B/2) int32, all on the device."""
+        self._require_gpu()
+        lib = _lib.load()
+        B, K, D = desc.shape
+        assert B % 2 == 0 and D == 64 and desc.is_contiguous()
+        P = B // 2
+        idx0 = torch.empty((P, K), dtype=torch.int64, device=desc.device)
+        idx1 = torch.empty((P, K), dtype=torch.int64, device=desc.device)
+        n = torch.empty((P,), dtype=torch.int32, device=desc.device)
+        ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, K, K))
+        d2 = desc[1]
+        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(desc), 2 * K * 64, _ptr(d2), 2 * K * 64, _ptr(n_valid), _ptr(n_valid),
+                                     2, 1, P, K, K, float(min_cossim), _ptr(idx0), _ptr(idx1), _ptr(n), _ptr(ws), nb,
+                                     _stream()), "xfh_match_mnn")
+        return idx0, idx1, n
+
+    def subpix_softmax2d(self, heatmaps, temp=3):
+        """(N,8,8) -> (N,2) expected offset under softmax(temp*heatmaps) (xfeat.py:292-304).
+        Helper kept for API compatibility; refine_matches fuses this step in HIP."""
+        N, H, W = heatmaps.shape
+        p = torch.softmax(temp * heatmaps.reshape(-1, H * W), -1)
+        idx = torch.arange(H * W, device=heatmaps.device)
+        gx = (idx % W - W // 2).to(p.dtype)
+        gy = (idx // W - H // 2).to(p.dtype)
+        return torch.stack([(p * gx).sum(1), (p * gy).sum(1)], -1)
+
+    def refine_matches(self, d0, d1, matches, batch_idx, fine_conf=0.25):
+        idx0, idx1 = matches[batch_idx]
+        sub0 = {k: v[batch_idx:batch_idx + 1] for k, v in d0.items()}
+        sub1 = {k: v[batch_idx:batch_idx + 1] for k, v in d1.items()}
+        N = sub0['keypoints'].shape[1]
+        dev = sub0['keypoints'].device
+        n = len(idx0)
+        i0 = torch.zeros((1, N), dtype=torch.int64, device=dev)
+        i1 = torch.zeros((1, N), dtype=torch.int64, device=dev)
+        if n > N:
+            raise RuntimeError('more matches than key-points')
+        i0[0, :n] = idx0.to(dev)
+        i1[0, :n] = idx1.to(dev)
+        nm = torch.tensor([n], dtype=torch.int32, device=dev)
+        out, n_out = self._refine_device(sub0, sub1, i0, i1, nm, fine_conf)
+        return out[0, :int(n_out.item())]
+
+    def _refine_device(self, d0, d1, idx0, idx1, n_matches, fine_conf):
+        self._require_gpu()
+        lib = _lib.load()
+        f0 = d0['descriptors'].float().contiguous()
+        f1 = d1['descriptors'].float().contiguous()
+        k0 = d0['keypoints'].float().contiguous()
+        k1 = d1['keypoints'].float().contiguous()
+        s0 = d0['scales'].float().contiguous()
+        P, N, _ = f0.shape
+        if f1.shape[1] != N:
+            raise RuntimeError('refine_matches needs the same number of key-points in both sets')
+        out = torch.empty((P, N, 4), dtype=torch.float32, device=f0.device)
+        n_out = torch.empty((P,), dtype=torch.int32, device=f0.device)
+        ws, nb = self.net.workspace("refine", lib.xfh_refine_workspace_bytes(P, N))
+        _lib.check(lib.xfh_refine_matches(self.net.handle(), _ptr(f0), _ptr(f1), _ptr(k0), _ptr(k1), _ptr(s0),
+                                          _ptr(idx0.contiguous()), _ptr(idx1.contiguous()), _ptr(n_matches.contiguous()), P, N, float(fine_conf),
+                                          _ptr(out), _ptr(n_out), _ptr(ws), nb, _stream()), "xfh_refine_matches")
+        return out, n_out
+
+    @torch.inference_mode()
+    def match(self, feats1, feats2, min_cossim=0.82):
+        if len(feats1) == 0 or len(feats2) == 0:
+            e = torch.empty((0,), dtype=torch.int64, device=self.dev)
+            return e, e.clone()
+        idx0, idx1, n = self._batch_match_device(feats1[None], feats2[None], min_cossim)
+        k = int(n.item())
+        return idx0[0, :k], idx1[0, :k]
+
+    def create_xy(self, h, w, dev):
+        y, x = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing='ij')
+        xy = torch.cat([x[..., None], y[..., None]], -1).reshape(-1, 2)
+        return xy
+
+    def extractDense(self, x, top_k=8_000, _scale_div=1.0):
+        if top_k < 1:
+            top_k = 100_000_000
+        x, rh1, rw1 = self.preprocess_tensor(x)
+        lib = _lib.load()
+        B, _, H, W = x.shape
+        hc, wc = H // 8, W // 8
+        feats, _, heat, rel = self.net.backbone(x, want_logits=True, want_heat=False)
+        k = min(hc * wc, int(top_k))
+        mkpts = torch.empty((B, k, 2), dtype=torch.float32, device=x.device)
+        desc = torch.empty((B, k, 64), dtype=torch.float32, device=x.device)
+        ws, n = self.net.workspace("dense", lib.xfh_dense_workspace_bytes(B, hc, wc, k))
+        _lib.check(lib.xfh_extract_dense(self.net.handle(), _ptr(rel), _ptr(feats), B, hc, wc, k, float(rw1), float(rh1),
+                                         float(_scale_div), _ptr(mkpts), _ptr(desc), None, _ptr(ws), n, _stream()),
+                   "xfh_extract_dense")
+        return mkpts, desc
+
+    def extract_dualscale(self, x, top_k, s1=0.6, s2=1.3):
+        self._require_gpu()
+        x = x.to(self.dev).float().contiguous()
+        B, _, H, W = x.shape
+        outs = []
+        for s, frac in ((s1, 0.20), (s2, 0.80)):
+            Ho, Wo = int(math.floor(H * s)), int(math.floor(W * s))
+            xs = self._resize(x, Ho, Wo, np.float32(1.0 / s), np.float32(1.0 / s))
+            mk, ft = self.extractDense(xs, int(top_k * frac), _scale_div=s)
+            sc = torch.ones(mk.shape[:2], device=mk.device) * (1 / s)
+            outs.append((mk, sc, ft))
+        mkpts = torch.cat([outs[0][0], outs[1][0]], dim=1)
+        sc = torch.cat([outs[0][1], outs[1][1]], dim=1)
+        feats = torch.cat([outs[0][2], outs[1][2]], dim=1)
+        return mkpts, sc, feats
+
+    def parse_input(self, x):
+        if len(x.shape) == 3:
+            x = x[None, ...]
+
+        if isinstance(x, np.ndarray):
+            x = torch.tensor(x).permute(0, 3, 1, 2) / 255
+
+        return x

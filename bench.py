@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the XFeat hot path on MI355X: BASELINE.json's metric
+"frames/sec detectAndCompute+match (VGA, top_k=4096)" on its config[1]
+(VGA 640x480 sparse, top_k=4096, batch 64 per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch: detectAndCompute on B synthetic VGA
+frames already resident in HBM, then the MNN match of the B/2 consecutive frame pairs
+(2i, 2i+1) (`match_xfeat` semantics, min_cossim=-1), then the ONE host read-back of the
+per-image counts that the ragged results need.  Multi-GPU: every rank is a replica with its
+own batch (weak scaling, no data-path collective; RCCL only for the barrier / max-time).
+
+Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s.
+`roofline` is measured live with HIP events around the dominant kernel family
+(conv_mfma_kernel<64,64,3,1,..>, the 64->64 3x3 convolutions) inside the timed region;
+`cpu_baseline` times the CPU oracle (a port of the reference's CPU path) on the host cores
+for a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
+H, W, TOP_K = 480, 640, 4096
+
+
+def make_frames(B, seed):
+    """B VGA frames, consecutive frames (2i, 2i+1) related by a known shift + noise."""
+    import fixtures
+    nb = max(1, min(8, B // 2))
+    base = fixtures.texture_images(nb, H, W, seed=seed)
+    rs = np.random.RandomState(seed + 1)
+    frames = []
+    for i in range(B // 2):
+        a = torch.roll(base[i % nb], shifts=(3 * (i // nb), 5 * (i // nb)), dims=(1, 2))
+        if (i // nb) % 2:
+            a = a.flip(2)
+        b = torch.roll(a, shifts=(16, 24), dims=(1, 2)) + torch.from_numpy((0.02 * rs.randn(3, H, W)).astype(np.float32))
+        frames += [a, b]
+    if B % 2:
+        frames.append(base[0])
+    return torch.stack(frames)
+
+
+def cpu_baseline(seconds):
+    """Oracle (port of the reference CPU path) on the host cores: same workload shape,
+    bounded sample: batches of 4 VGA frames + their 2 pair matches, repeated ~`seconds`."""
+    import fixtures
+    from oracle import xfeat_oracle as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    sd = fixtures.synthetic_state_dict(0)
+    x = make_frames(4, seed=77)
+    frames, t_used, iters = 0, 0.0, 0
+    O.detect_and_compute(sd, x[:1], top_k=TOP_K)            # warm-up
+    while t_used < seconds or iters < 1:
+        t0 = time.perf_counter()
+        out = O.detect_and_compute(sd, x, top_k=TOP_K)
+        for p in range(2):
+            O.match_mnn(out[2 * p]["descriptors"], out[2 * p + 1]["descriptors"], -1)
+        t_used += time.perf_counter() - t0
+        frames += 4
+        iters += 1
+    return {"value": round(frames / t_used, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} x (detect_and_compute on 4 VGA frames, top_k={TOP_K} + 2 MNN matches) "
+                      f"= {frames} frames in {t_used:.1f} s, torch CPU threads={threads}"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("conv_mfma_64_64_s1_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config: 64)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import fixtures
+    from accelerated_features_amd import XFeat, _lib
+    xf = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05)
+    lib = _lib.load()
+    B = args.batch
+    x = make_frames(B, seed=1000 + rank).cuda()           # inputs resident in HBM before the timed region
+    handle = xf.net.handle()
+
+    def step():
+        kp, sc, de, nv, nc, cap, hw = xf._detect_device(x, TOP_K, 0.05)
+        i0, i1, nm = xf.match_pairs_device(de, nv, -1)
+        counts = torch.cat([nv, nc, nm]).cpu()             # the one read-back (ragged results)
+        return counts, cap
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        counts, cap = step()
+    assert int(counts[B:2 * B].max()) <= cap, "NMS capacity overflow in the benchmark workload"
+    lib.xfh_profile_select(handle, _lib.PROF_CONV_64_64_S1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts, cap = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    n_l, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+    lib.xfh_profile_read(handle, C.byref(n_l), C.byref(ms), C.byref(fl), C.byref(by))
+    lib.xfh_profile_select(handle, _lib.PROF_NONE)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    if rank == 0:
+        n_valid = counts[:B].tolist()
+        n_match = counts[2 * B:].tolist()
+        achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        out = {
+            "metric": "frames/sec detectAndCompute+match (VGA, top_k=4096)",
+            "value": round(world * B * args.steps / dt_max, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "VGA 640x480 sparse top_k=4096, batch=64 per GPU: detectAndCompute + MNN match of "
+                                   "the 32 consecutive frame pairs (BASELINE configs[1])",
+                       "batch_per_gpu": B, "height": H, "width": W, "top_k": TOP_K, "weights": "synthetic (tests/fixtures.py)",
+                       "parallelism": f"replicas x{world}, no collective",
+                       "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel<64,64,3,1,..> (64->64 3x3 s1 convs, f32 MFMA)",
+                         "achieved": round(achieved, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
+                         "launches": n_l.value, "avg_launch_us": round(1e3 * ms.value / max(n_l.value, 1), 2),
+                         "flops_per_launch_avg": fl.value / max(n_l.value, 1),
+                         "traffic": load_pmc_traffic()},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

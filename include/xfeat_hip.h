@@ -1,0 +1,207 @@
+/*
+ * xfeat_hip.h -- C ABI of libxfeat_hip.so: the XFeat inference hot path on MI355X (gfx950).
+ *
+ * The reference (verlab/accelerated_features) is pure Python on PyTorch and has NO native
+ * boundary; its drop-in boundary is the Python class modules/xfeat.py::XFeat.  This header
+ * is the native boundary that class is re-hosted on: one entry point per block of ATen work
+ * the reference's methods execute.  Each declaration cites the reference code it replaces.
+ * A host in any language binds these symbols (ctypes stub: accelerated_features_amd/_lib.py,
+ * other hosts: INTEGRATION.md).
+ *
+ * Conventions
+ *   - Plain C types only.  All tensor pointers are DEVICE pointers (HBM) unless the name
+ *     starts with host_.  Layouts are dense, row-major in the index order written.
+ *   - The library never allocates in the hot path: the caller provides a workspace of
+ *     xfh_*_workspace_bytes() bytes (256-byte aligned).  Only xfh_create allocates (weights).
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream).  No hidden synchronisation, no global mutable state besides the
+ *     thread-local error string.
+ *   - Return value: XFH_OK (0) or a negative XFH_ERR_* code; xfh_last_error() gives a
+ *     message for the calling thread.  No C++ exception crosses the boundary.
+ *   - A handle is immutable after xfh_create and may be shared by threads/streams, provided
+ *     each concurrent call uses its own workspace.
+ *   - Ragged results use fixed capacity + device-side counts: the host reads the counts back
+ *     once per batch (the reference synchronises B times per batch: xfeat.py:254-261,99-103).
+ */
+#ifndef XFEAT_HIP_H
+#define XFEAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XFH_VERSION 100          /* major*10000 + minor*100 + patch */
+
+enum {
+    XFH_OK = 0,
+    XFH_ERR_ARG = -1,            /* bad shape / null pointer / unsupported size          */
+    XFH_ERR_WEIGHTS = -2,        /* weight table malformed                               */
+    XFH_ERR_WORKSPACE = -3,      /* workspace too small or misaligned                    */
+    XFH_ERR_UNSUPPORTED = -4,    /* valid request outside what this build implements     */
+    XFH_ERR_HIP = -5,            /* a HIP runtime call failed (message has the hipError) */
+    XFH_ERR_DEVICE = -6          /* not a gfx950 device / no device                      */
+};
+
+typedef struct xfh_context* xfh_handle;
+typedef void* xfh_stream;        /* hipStream_t */
+
+int xfh_version(void);
+const char* xfh_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Weights.  Replaces XFeat.__init__ / net.load_state_dict (modules/xfeat.py:23-35) and the
+ * parameter containers of XFeatModel (modules/model.py:33-111).
+ *
+ * host_arrays: HOST pointers to the fp32 arrays of a reference state_dict in the canonical
+ * order below (n_arrays must equal xfh_num_weight_arrays()).  Eval-mode BatchNorm
+ * (affine=False, eps 1e-5) is folded into the preceding conv / linear at create time.
+ *
+ *   for each conv in execution order (accelerated_features_amd/spec.py::CONVS):
+ *       BasicLayer : <name>.layer.0.weight (Cout,Cin,k,k), .layer.1.running_mean, .layer.1.running_var
+ *       plain conv : <name>.weight (Cout,Cin,k,k), <name>.bias
+ *   then fine_matcher: for L in 0,3,6,9: L.weight (out,in), L.bias, (L+1).running_mean, (L+1).running_var
+ *                      then 12.weight, 12.bias
+ * ---------------------------------------------------------------------------------------- */
+int xfh_num_weight_arrays(void);
+/* number of floats the i-th array must hold (for host-side validation) */
+size_t xfh_weight_array_floats(int i);
+int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_handle* out);
+void xfh_destroy(xfh_handle h);
+
+/* ------------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=False, NCHW planes.  Replaces F.interpolate in
+ * preprocess_tensor (modules/xfeat.py:239, size given => scale = in/out) and in
+ * extract_dualscale (modules/xfeat.py:380-381, scale_factor given => scale = 1/scale_factor).
+ * src (planes,Hin,Win) -> dst (planes,Hout,Wout); scale_h/scale_w are the source-per-
+ * destination steps PyTorch would use.
+ * ---------------------------------------------------------------------------------------- */
+int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,
+                        float scale_h, float scale_w, xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone.  Replaces XFeatModel.forward (modules/model.py:123-154) plus
+ * XFeat.get_kpts_heatmap (modules/xfeat.py:242-247).
+ *
+ *   img      (B,C,H,W) fp32, H%32==0, W%32==0, C>=1
+ *   feats    (B,H/8,W/8,64)  "M1", channels-last (a (B,64,h,w) tensor in channels_last memory format)
+ *   logits   (B,H/8,W/8,65)  "K1", channels-last; may be NULL (then not written)
+ *   heat     (B,H,W)         softmax(K1)[:64] depth-to-space 8x8; may be NULL (then logits must not be)
+ *   reliab   (B,H/8,W/8)     "H1" after the sigmoid
+ * ---------------------------------------------------------------------------------------- */
+size_t xfh_backbone_workspace_bytes(int B, int C, int H, int W);
+int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W,
+                 float* feats, float* logits, float* heat, float* reliab,
+                 void* workspace, size_t workspace_bytes, xfh_stream stream);
+
+/* One conv layer of the network in isolation (parity tests against per-layer oracle
+ * activations).  layer = index into spec.CONVS; in (B,Cin,Hin,Win) NCHW, out (B,Cout,Hout,Wout)
+ * NCHW with the layer's own stride/padding, folded BN and ReLU where the reference has them.
+ * variant: 0 = the kernel the backbone uses for this layer, 1 = the generic direct kernel. */
+int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out,
+                   int variant, xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sparse detection.  Replaces XFeat.NMS (modules/xfeat.py:249-263), the score / top-k /
+ * descriptor block of detectAndCompute (modules/xfeat.py:70-103) and the three
+ * InterpolateSparse2d calls (modules/interpolator.py:21-33).
+ *
+ *   heat (B,H,W), reliab (B,H/8,W/8), feats (B,H/8,W/8,64) as produced by xfh_backbone
+ *   threshold        detection threshold (strict >)
+ *   top_k            <= 16384
+ *   nms_capacity     capacity of the candidate list per image.  If n_candidates[b] comes back
+ *                    larger, candidates were dropped in row-major order: re-run with a
+ *                    capacity >= max(n_candidates) (H*W is always enough).
+ *   rw, rh           original/processed size ratios (key-points are returned multiplied by them)
+ * outputs (fixed capacity, entries past n_valid[b] are zero-filled):
+ *   kpts (B,top_k,2) fp32 (x,y) ; scores (B,top_k) descending ; desc (B,top_k,64) unit norm
+ *   n_valid (B) int32       = number of returned points with score > 0 (they form a prefix)
+ *   n_candidates (B) int32  = NMS candidates found (uncapped)
+ * ---------------------------------------------------------------------------------------- */
+size_t xfh_detect_workspace_bytes(int B, int H, int W, int top_k, int nms_capacity);
+int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats,
+                      int B, int H, int W, float threshold, int top_k, int nms_capacity, float rw, float rh,
+                      float* kpts, float* scores, float* desc, int32_t* n_valid, int32_t* n_candidates,
+                      void* workspace, size_t workspace_bytes, xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Semi-dense extraction.  Replaces XFeat.extractDense after the backbone
+ * (modules/xfeat.py:362-375): top-k of the reliability map (descending), RAW 64-D features of
+ * those cells and their corner coordinates (8*(j,i)*(rw,rh)) / scale_div (scale_div = s of
+ * extract_dualscale, modules/xfeat.py:388; 1 otherwise).
+ *   kpts (B,k,2), desc (B,k,64), cell_index (B,k) int32 (may be NULL); k <= min(h*w, 16384)
+ * ---------------------------------------------------------------------------------------- */
+size_t xfh_dense_workspace_bytes(int B, int h, int w, int k);
+int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int B, int hc, int wc, int k,
+                      float rw, float rh, float scale_div, float* kpts, float* desc, int32_t* cell_index,
+                      void* workspace, size_t workspace_bytes, xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Mutual nearest neighbour matching.  Replaces XFeat.match (modules/xfeat.py:327-348) and
+ * XFeat.batch_match (modules/xfeat.py:265-290) for P independent pairs.
+ *
+ *   pair p uses d1 + p*pair_stride1 (N1 x 64, row-major) and d2 + p*pair_stride2 (N2 x 64)
+ *   n1/n2: DEVICE int32 arrays; pair p uses n1[p*n_stride] rows and n2[p*n_stride+n_offset2]
+ *          rows (so the n_valid array of xfh_detect_sparse can be passed for consecutive
+ *          frame pairs with n_stride=2, n_offset2=1).  NULL => all N1 / N2 rows.
+ *   min_cossim <= 0 disables the similarity test (reference: `if min_cossim > 0`).
+ *   pair_stride1/2 are in floats.
+ * outputs: idx0, idx1 (P,N1) int64 (idx0 ascending), n_matches (P) int32.
+ * Arg-max ties resolve to the lowest index, like torch.max / torch.argmax.
+ * ---------------------------------------------------------------------------------------- */
+size_t xfh_match_workspace_bytes(int P, int N1, int N2);
+int xfh_match_mnn(xfh_handle h /* may be NULL */, const float* d1, size_t pair_stride1, const float* d2, size_t pair_stride2,
+                  const int32_t* n1, const int32_t* n2, int n_stride, int n_offset2,
+                  int P, int N1, int N2, float min_cossim,
+                  int64_t* idx0, int64_t* idx1, int32_t* n_matches,
+                  void* workspace, size_t workspace_bytes, xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Match refinement.  Replaces XFeat.refine_matches (modules/xfeat.py:306-325),
+ * XFeat.subpix_softmax2d (modules/xfeat.py:292-304) and XFeatModel.fine_matcher
+ * (modules/model.py:97-111) for P pairs at once.
+ *
+ *   desc0/desc1 (P,N,64), kp0/kp1 (P,N,2), scale0 (P,N)  -- detectAndComputeDense outputs
+ *   idx0/idx1 (P,N) int64 with n_matches (P) int32 (device) -- xfh_match_mnn outputs
+ *   out (P,N,4) fp32 rows (x0,y0,x1,y1) of the matches with conf > fine_conf, order kept;
+ *   n_out (P) int32.
+ * ---------------------------------------------------------------------------------------- */
+size_t xfh_refine_workspace_bytes(int P, int N);
+int xfh_refine_matches(xfh_handle h, const float* desc0, const float* desc1, const float* kp0, const float* kp1,
+                       const float* scale0, const int64_t* idx0, const int64_t* idx1, const int32_t* n_matches,
+                       int P, int N, float fine_conf, float* out, int32_t* n_out,
+                       void* workspace, size_t workspace_bytes, xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Stand-alone helpers behind the reference's public helper methods.
+ *   xfh_kpts_heatmap : XFeat.get_kpts_heatmap (modules/xfeat.py:242-247); logits (B,h,w,65)
+ *                      channels-last -> heat (B,8h,8w).
+ *   xfh_nms          : XFeat.NMS (modules/xfeat.py:249-263), kernel_size 5.  xy (B,capacity,2)
+ *                      int64 (x,y) in row-major order, zero padded; n_candidates (B) int32
+ *                      uncapped.  workspace: xfh_detect_workspace_bytes(B,H,W,1,capacity).
+ *   xfh_fine_matcher : XFeatModel.fine_matcher (modules/model.py:97-111): x (n,128) -> out (n,64).
+ *                      workspace: xfh_refine_workspace_bytes(1, n).
+ * ---------------------------------------------------------------------------------------- */
+int xfh_kpts_heatmap(const float* logits, int B, int hc, int wc, float* heat, xfh_stream stream);
+int xfh_nms(xfh_handle h, const float* heat, int B, int H, int W, float threshold, int capacity, int64_t* xy,
+            int32_t* n_candidates, void* workspace, size_t workspace_bytes, xfh_stream stream);
+int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* workspace, size_t workspace_bytes,
+                     xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel timing hooks for bench.py (HIP events recorded around one kernel family on the
+ * launch stream).  which: see XFH_PROF_* ; xfh_profile_read synchronises the recorded events
+ * and returns the number of launches and their summed duration in milliseconds.
+ * ---------------------------------------------------------------------------------------- */
+enum { XFH_PROF_NONE = 0, XFH_PROF_CONV_MFMA = 1, XFH_PROF_MATCH = 2, XFH_PROF_BLOCK1 = 3, XFH_PROF_HEADS = 4,
+       XFH_PROF_CONV_64_64_S1 = 5 /* launches of conv_mfma_kernel<64,64,3,1,..>: the 64->64 3x3 stride-1 layers */,
+       XFH_PROF_CONV_LAYER0 = 100 /* + index into spec.CONVS: one MFMA conv layer only */ };
+int xfh_profile_select(xfh_handle h, int which);
+int xfh_profile_read(xfh_handle h, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFEAT_HIP_H */

@@ -1,0 +1,146 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, the Python
+surface mirrors the reference's, host-side planning functions work without a GPU, and the
+product path refuses to run without one (no fallback)."""
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import fixtures
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from accelerated_features_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from accelerated_features_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "xfeat_hip.h")).read()
+    declared = set(re.findall(r"\b(xfh_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    for s in declared:
+        assert hasattr(lib, s), f"{s} declared but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes prototype"
+    assert set(_lib.SIGNATURES) <= declared
+    assert lib.xfh_version() == int(re.search(r"#define XFH_VERSION (\d+)", hdr).group(1))
+
+
+def test_weight_table_matches_spec_and_reference_keys(lib):
+    from accelerated_features_amd import XFeat
+    from accelerated_features_amd.spec import state_dict_keys
+    sd = fixtures.synthetic_state_dict(0)
+    xf = XFeat(weights=sd)
+    mine = xf.net.state_dict()
+    assert list(mine.keys()) == list(sd.keys()) or set(mine.keys()) == set(sd.keys())
+    assert len(mine) == 122                                   # key count of the reference XFeatModel
+    for k, shape in state_dict_keys().items():
+        assert tuple(mine[k].shape) == tuple(shape), k
+        assert torch.equal(mine[k], sd[k]), k
+    arrs = xf.net.weight_arrays()
+    assert len(arrs) == lib.xfh_num_weight_arrays() == 95
+    for i, a in enumerate(arrs):
+        assert a.dtype == np.float32 and a.size == lib.xfh_weight_array_floats(i)
+    assert sum(a.size for a in arrs if True) > 1_544_758      # params + BN statistics
+
+
+def test_public_surface_mirrors_reference():
+    """Names, argument names and defaults of modules/xfeat.py::XFeat."""
+    from accelerated_features_amd import XFeat
+    expect = {
+        "detectAndCompute": ["x", "top_k", "detection_threshold"],
+        "detectAndComputeDense": ["x", "top_k", "multiscale"],
+        "match_lighterglue": ["d0", "d1", "min_conf"],
+        "match_xfeat": ["img1", "img2", "top_k", "min_cossim"],
+        "match_xfeat_star": ["im_set1", "im_set2", "top_k"],
+        "preprocess_tensor": ["x"],
+        "get_kpts_heatmap": ["kpts", "softmax_temp"],
+        "NMS": ["x", "threshold", "kernel_size"],
+        "batch_match": ["feats1", "feats2", "min_cossim"],
+        "subpix_softmax2d": ["heatmaps", "temp"],
+        "refine_matches": ["d0", "d1", "matches", "batch_idx", "fine_conf"],
+        "match": ["feats1", "feats2", "min_cossim"],
+        "create_xy": ["h", "w", "dev"],
+        "extract_dualscale": ["x", "top_k", "s1", "s2"],
+        "parse_input": ["x"],
+    }
+    for name, args in expect.items():
+        sig = inspect.signature(getattr(XFeat, name))
+        assert list(sig.parameters)[1:1 + len(args)] == args, (name, list(sig.parameters))
+    d = {n: p.default for n, p in inspect.signature(XFeat.__init__).parameters.items()}
+    assert d["top_k"] == 4096 and d["detection_threshold"] == 0.05 and d["weights"].endswith("/../weights/xfeat.pt")
+    assert inspect.signature(XFeat.match).parameters["min_cossim"].default == 0.82
+    assert inspect.signature(XFeat.match_xfeat).parameters["min_cossim"].default == -1
+    assert inspect.signature(XFeat.refine_matches).parameters["fine_conf"].default == 0.25
+    assert inspect.signature(XFeat.extract_dualscale).parameters["s1"].default == 0.6
+    assert inspect.signature(XFeat.extractDense).parameters["top_k"].default == 8_000
+    import hubconf
+    hs = inspect.signature(hubconf.XFeat).parameters
+    assert [hs[k].default for k in ("pretrained", "top_k", "detection_threshold")] == [True, 4096, 0.05]
+
+
+def test_host_helpers_match_reference_semantics():
+    from accelerated_features_amd import XFeat
+    xf = XFeat(weights=None)
+    img = (np.random.RandomState(0).rand(20, 30, 3) * 255).astype(np.uint8)
+    t = xf.parse_input(img)
+    assert t.shape == (1, 3, 20, 30) and t.dtype == torch.float32 and float(t.max()) <= 1.0
+    assert xf.parse_input(torch.zeros(3, 8, 8)).shape == (1, 3, 8, 8)
+    xy = xf.create_xy(2, 3, "cpu")
+    assert xy.tolist() == [[0, 0], [1, 0], [2, 0], [0, 1], [1, 1], [2, 1]]
+    o = torch.full((1, 8, 8), -50.0)
+    o[0, 2, 5] = 50.0
+    assert torch.allclose(xf.subpix_softmax2d(o), torch.tensor([[1.0, -2.0]]))
+    assert xf.top_k == 4096 and xf.detection_threshold == 0.05 and hasattr(xf.net, "fine_matcher")
+
+
+def test_workspace_planning_is_host_only(lib):
+    a = lib.xfh_backbone_workspace_bytes(64, 3, 480, 640)
+    b = lib.xfh_backbone_workspace_bytes(1, 3, 480, 640)
+    assert a > 60 * b > 0 and a % 256 == 0
+    assert lib.xfh_backbone_workspace_bytes(0, 3, 480, 640) == 0
+    assert lib.xfh_detect_workspace_bytes(64, 480, 640, 4096, 38400) > 64 * 38400 * 12
+    assert lib.xfh_match_workspace_bytes(32, 4096, 4096) >= 32 * 16 * 4096 * 8
+    assert lib.xfh_refine_workspace_bytes(2, 511) > 2 * 511 * 512 * 4 * 2
+    assert lib.xfh_dense_workspace_bytes(2, 20, 24, 100) > 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    from accelerated_features_amd import XFeat, _lib
+    xf = XFeat(weights=fixtures.synthetic_state_dict(0))
+    with pytest.raises(_lib.XFeatHipError):
+        xf.detectAndCompute(torch.rand(1, 3, 64, 64))
+    with pytest.raises(_lib.XFeatHipError):
+        xf.match(torch.rand(10, 64), torch.rand(10, 64))
+    with pytest.raises(_lib.XFeatHipError):
+        xf.match_xfeat_star(torch.rand(2, 3, 64, 64), torch.rand(2, 3, 64, 64))
+    with pytest.raises(_lib.XFeatHipError):
+        xf.net(torch.rand(1, 3, 64, 64))
+    with pytest.raises(RuntimeError):
+        xf.match_lighterglue({}, {})
+    # the C ABI itself refuses to create a context without a device
+    import ctypes as C
+    arrs = xf.net.weight_arrays()
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    h = C.c_void_p()
+    rc = lib.xfh_create(ptrs, len(arrs), 0, C.byref(h))
+    assert rc != 0 and b"device" in lib.xfh_last_error().lower()
+    assert lib.xfh_create(ptrs, 3, 0, C.byref(h)) == -2       # malformed weight table
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "accelerated_features_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("no CPU fallback", ""), f"{f} mentions the oracle"
+                assert "/root/reference" not in src or f.endswith(".py") and "import" not in src.split("/root/reference")[0][-40:], f
