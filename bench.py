@@ -60,12 +60,25 @@ def cpu_baseline(seconds):
     bounded sample: batches of 4 VGA frames + their 2 pair matches, repeated ~`seconds`."""
     import fixtures
     from oracle import xfeat_oracle as O
-    threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
     sd = fixtures.synthetic_state_dict(0)
     x = make_frames(4, seed=77)
+    ncpu = os.cpu_count() or 1
+    # torch's CPU conv path does not scale to hundreds of threads on these small maps (it gets
+    # slower): pick the fastest thread count from a short calibration and report it.
+    best = None
+    for t in sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu}):
+        torch.set_num_threads(t)
+        O.detect_and_compute(sd, x[:1], top_k=TOP_K)
+        t0 = time.perf_counter()
+        O.detect_and_compute(sd, x[:2], top_k=TOP_K)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[1]:
+            best = (t, dt)
+        if dt > 3 * best[1]:
+            break
+    threads = best[0]
+    torch.set_num_threads(threads)
     frames, t_used, iters = 0, 0.0, 0
-    O.detect_and_compute(sd, x[:1], top_k=TOP_K)            # warm-up
     while t_used < seconds or iters < 1:
         t0 = time.perf_counter()
         out = O.detect_and_compute(sd, x, top_k=TOP_K)
