@@ -106,6 +106,7 @@ void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes
 }  // namespace xfh
 
 struct xfh_context {
+    long long* trace = nullptr;   // debug: conv kernel phase stamps
     int device;
     float* blob;          // device weights
     NetWeights nw;
@@ -243,6 +244,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
 
     std::vector<float> blob;
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
+    const size_t zoff = reserve(256);
     struct Off { size_t oihw, kc, kcp, bias; } coff[L_NUM];
     struct FOff { size_t w, b; } foff[5];
     int ai = 0;
@@ -322,6 +324,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.w_kcp = ctx->blob + coff[li].kcp;
         w.bias = ctx->blob + coff[li].bias;
     }
+    ctx->nw.zeros = ctx->blob + zoff;
     for (int fi = 0; fi < 5; ++fi) {
         LinW& l = ctx->nw.fine[fi];
         l.k = kFine[fi].k; l.n = kFine[fi].n; l.n_pad = (kFine[fi].n + 63) / 64 * 64; l.relu = kFine[fi].bn;
@@ -363,18 +366,22 @@ size_t xfh_backbone_workspace_bytes(int B, int C, int H, int W) {
     return carve_backbone(nullptr, B, H, W, o);
 }
 
-static int conv_mfma_checked(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out, bool nhwc,
-                             hipStream_t st) {
+static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const float* in, int B, int Hin, int Win, float* out,
+                             bool nhwc, hipStream_t st) {
     const ConvW& c = h->nw.conv[layer];
+    const ConvW* c2 = fused_layer >= 0 ? &h->nw.conv[fused_layer] : nullptr;
     const int pad = c.ks / 2;
     const int Hout = (Hin + 2 * pad - c.ks) / c.stride + 1, Wout = (Win + 2 * pad - c.ks) / c.stride + 1;
     // which >= 100 selects one layer (100 + layer index), otherwise the whole family
     int pid = h->prof.which >= 100 ? 100 + layer : XFH_PROF_CONV_MFMA;
     if (h->prof.which == XFH_PROF_CONV_64_64_S1 && c.cin == 64 && c.cout == 64 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_64_64_S1;
     prof_begin(&h->prof, pid, st);
-    const int rc = launch_conv_mfma(c, in, B, Hin, Win, out, nhwc, st);
-    const double bytes = 4.0 * ((double)B * c.cin * Hin * Win + (double)B * c.cout * Hout * Wout + (double)c.cin * c.cout * c.ks * c.ks);
-    prof_end(&h->prof, pid, st, conv_flops(c, B, Hout, Wout), bytes);
+    const int rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
+    const int cl = c2 ? c2->cout : c.cout;
+    double bytes = 4.0 * ((double)B * c.cin * Hin * Win + (double)B * cl * Hout * Wout + (double)c.cin * c.cout * c.ks * c.ks);
+    double flops = conv_flops(c, B, Hout, Wout);
+    if (c2) { flops += conv_flops(*c2, B, Hout, Wout); bytes += 4.0 * c2->cin * c2->cout; }
+    prof_end(&h->prof, pid, st, flops, bytes);
     if (rc) return fail(XFH_ERR_UNSUPPORTED, "no MFMA conv instantiation for layer %d (%d->%d k%d s%d) at %dx%d", layer, c.cin, c.cout, c.ks, c.stride, Hin, Win);
     return XFH_OK;
 }
@@ -396,24 +403,21 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, flo
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
     launch_block1(nw, w.gray, B, H, W, w.t0, w.t1, w.t2, w.x1, st);
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 0, 0);
-#define CONV(layer, in, hin, win, out, nhwc) \
-    if ((rc = conv_mfma_checked(h, layer, in, B, hin, win, out, nhwc, st))) return rc
-    CONV(L_BLOCK2_0, w.x1, H4, W4, w.x2a, false);
-    CONV(L_BLOCK2_1, w.x2a, H4, W4, w.x2b, false);
-    CONV(L_BLOCK3_0, w.x2b, H4, W4, w.x3a, false);
-    CONV(L_BLOCK3_1, w.x3a, H8, W8, w.x3b, false);
-    CONV(L_BLOCK3_2, w.x3b, H8, W8, w.x3c, false);
-    CONV(L_BLOCK4_0, w.x3c, H8, W8, w.x4a, false);
-    CONV(L_BLOCK4_1, w.x4a, H16, W16, w.x4b, false);
-    CONV(L_BLOCK4_2, w.x4b, H16, W16, w.x4c, false);
-    CONV(L_BLOCK5_0, w.x4c, H16, W16, w.x5a, false);
-    CONV(L_BLOCK5_1, w.x5a, H32, W32, w.x5b, false);
-    CONV(L_BLOCK5_2, w.x5b, H32, W32, w.x5c, false);
-    CONV(L_BLOCK5_3, w.x5c, H32, W32, w.x5d, false);
+#define CONV(layer, fused, in, hin, win, out, nhwc) \
+    if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st))) return rc
+    CONV(L_BLOCK2_0, -1, w.x1, H4, W4, w.x2a, false);
+    CONV(L_BLOCK2_1, -1, w.x2a, H4, W4, w.x2b, false);
+    CONV(L_BLOCK3_0, -1, w.x2b, H4, W4, w.x3a, false);
+    CONV(L_BLOCK3_1, L_BLOCK3_2, w.x3a, H8, W8, w.x3c, false);        // 3x3 + fused 1x1
+    CONV(L_BLOCK4_0, -1, w.x3c, H8, W8, w.x4a, false);
+    CONV(L_BLOCK4_1, -1, w.x4a, H16, W16, w.x4b, false);
+    CONV(L_BLOCK4_2, -1, w.x4b, H16, W16, w.x4c, false);
+    CONV(L_BLOCK5_0, -1, w.x4c, H16, W16, w.x5a, false);
+    CONV(L_BLOCK5_1, -1, w.x5a, H32, W32, w.x5b, false);
+    CONV(L_BLOCK5_2, L_BLOCK5_3, w.x5b, H32, W32, w.x5d, false);      // 3x3 + fused 1x1 (128->64)
     launch_pyramid_sum(w.x3c, w.x4c, w.x5d, w.pyr, B * 64, H8, W8, H16, W16, H32, W32, st);
-    CONV(L_FUSION_0, w.pyr, H8, W8, w.f0, false);
-    CONV(L_FUSION_1, w.f0, H8, W8, w.f1, false);
-    CONV(L_FUSION_2, w.f1, H8, W8, feats, true);     // -> channels-last M1
+    CONV(L_FUSION_0, -1, w.pyr, H8, W8, w.f0, false);
+    CONV(L_FUSION_1, L_FUSION_2, w.f0, H8, W8, feats, true);          // 3x3 + fused 1x1 -> channels-last M1
 #undef CONV
 
     // heads on channels-last rows
@@ -464,7 +468,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
     }
     if (layer == L_SKIP1 || layer >= L_HEAT_0)
         return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: layer %d runs fused / channels-last in the backbone; use variant 1", layer);
-    int rc = conv_mfma_checked(h, layer, in, B, Hin, Win, out, false, st);
+    int rc = conv_mfma_checked(h, layer, -1, in, B, Hin, Win, out, false, st);
     if (rc) return rc;
     return check_launch("xfh_conv_layer(mfma)");
 }
@@ -622,6 +626,12 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
     bad |= launch_linear_mfma(f[4].w_kn, f[4].bias, 512, f[4].n, f[4].n_pad, false, LOAD_ROWMAJOR, r, n, nullptr, out, 64, st);
     if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_fine_matcher: missing linear kernel instantiation");
     return check_launch("xfh_fine_matcher");
+}
+
+int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
+    if (!h) return fail(XFH_ERR_ARG, "xfh_debug_trace: NULL handle");
+    h->trace = device_buffer;
+    return XFH_OK;
 }
 
 int xfh_profile_select(xfh_handle h, int which) {

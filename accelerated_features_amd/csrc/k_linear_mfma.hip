@@ -62,13 +62,15 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
         }
     }
 
-    f32x16 acc[RB][NBLK];
+    f32x16 acc[RB][NBLK];      // start at the bias (loaded before any store so the loads batch)
 #pragma unroll
-    for (int a = 0; a < RB; ++a)
+    for (int c = 0; c < NBLK; ++c) {
+        const float bs = bias[n0 + c * 32 + l31];           // bias is padded to n_pad
 #pragma unroll
-        for (int c = 0; c < NBLK; ++c)
+        for (int a = 0; a < RB; ++a)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = bs;
+    }
 
     float4 xreg[8];
     float4 wreg[WV];
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
                 for (int c = 0; c < NBLK; ++c) {
                     const int col = n0 + c * 32 + l31;
                     if (col < N) {
-                        float v = acc[rb][c][r] + bias[col];
+                        float v = acc[rb][c][r];
                         if (relu) v = fmaxf(v, 0.f);
                         y[(size_t)row * ldy + col] = v;
                     }

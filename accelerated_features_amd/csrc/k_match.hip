@@ -15,7 +15,7 @@ namespace xfh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int MT_ROWS = 256;   // rows of D1 per workgroup (4 waves x 64)
+constexpr int MT_ROWS = 256;   // rows of D1 per workgroup (8 waves x 32)
 constexpr int MT_COLS = 128;   // columns of D2 per LDS fill
 constexpr int MT_DS = 68;      // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
 
@@ -27,15 +27,18 @@ __device__ inline int pair_count(const int32_t* n, int idx, int cap) {
     return v < 0 ? 0 : (v > cap ? cap : v);
 }
 
-__global__ __launch_bounds__(256) void mnn_sim_kernel(const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2,
+// 512 threads = 8 waves, 32 rows of D1 each (two waves per SIMD: while one wave runs its VALU
+// arg-max epilogue the other keeps the matrix pipe busy).
+__global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2,
                                                       size_t ps2, const int32_t* __restrict__ n1p,
                                                       const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1,
                                                       int N2, int nrb, int* __restrict__ match12,
                                                       float* __restrict__ rowmax, unsigned long long* __restrict__ colpart) {
     __shared__ __attribute__((aligned(16))) float Dl[MT_COLS * MT_DS];
-    __shared__ unsigned long long colbest[4][MT_COLS];
+    __shared__ unsigned long long colbest[8][MT_COLS];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = blockIdx.y, rb = blockIdx.x;
     const int n1 = pair_count(n1p, p * n_stride, N1);
     const int n2 = pair_count(n2p, p * n_stride + n_off2, N2);
@@ -43,31 +46,29 @@ __global__ __launch_bounds__(256) void mnn_sim_kernel(const float* __restrict__ 
     if (n1 <= 0 || n2 <= 0 || row0 >= n1) return;
     const float* A = d1 + (size_t)p * ps1;
     const float* Bm = d2 + (size_t)p * ps2;
+    const int wrow0 = row0 + wave * 32;
 
-    // stationary A fragments: step s uses k = s (lanes 0-31) / k = 32+s (lanes 32-63)
-    float a[2][32];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int row = min(row0 + wave * 64 + rt * 32 + l31, n1 - 1);
+    // stationary A fragment (32 rows x K=64): step s uses k = s (lanes 0-31) / k = 32+s (lanes 32-63)
+    float a[32];
+    {
+        const int row = min(wrow0 + l31, n1 - 1);
         const float4* src = reinterpret_cast<const float4*>(A + (size_t)row * 64 + 32 * half);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float4 v = src[q];
-            a[rt][4 * q + 0] = v.x; a[rt][4 * q + 1] = v.y; a[rt][4 * q + 2] = v.z; a[rt][4 * q + 3] = v.w;
+            a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
         }
     }
-    float bv[2][16];
-    int bc[2][16];
+    float bv[16];
+    int bc[16];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { bv[rt][r] = -INFINITY; bc[rt][r] = 0; }
+    for (int r = 0; r < 16; ++r) { bv[r] = -INFINITY; bc[r] = 0; }
 
     for (int c0 = 0; c0 < n2; c0 += MT_COLS) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int e = tid + i * 256;
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 512;
             const int col = e >> 4, q = e & 15;
             const int gc = min(c0 + col, n2 - 1);
             const float4 v = *reinterpret_cast<const float4*>(Bm + (size_t)gc * 64 + 4 * q);
@@ -78,35 +79,48 @@ __global__ __launch_bounds__(256) void mnn_sim_kernel(const float* __restrict__ 
         for (int ct = 0; ct < MT_COLS / 32; ++ct) {
             const int cbase = c0 + ct * 32;
             if (cbase >= n2) break;
-            float bf[32];
+            // B fragment in two halves of 16 k-steps: 16 VGPRs live instead of 32 (the other three
+            // waves of the SIMD cover the second half's LDS latency)
             const float4* bp = reinterpret_cast<const float4*>(Dl + (ct * 32 + l31) * MT_DS + 32 * half);
+            f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 v = bp[q];
-                bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
-            }
-            f32x16 acc0, acc1;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            for (int hq = 0; hq < 2; ++hq) {
+                float bf[16];
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s], bf[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s], bf[s], acc1, 0, 0, 0);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = bp[hq * 4 + q];
+                    bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[hq * 16 + s], bf[s], acc, 0, 0, 0);
             }
             // D[i=row][j=col]: this lane holds column cbase+l31, rows (r&3)+8*(r>>2)+4*half
             const int col = cbase + l31;
             const bool cvalid = col < n2;
-            unsigned long long best = 0ull;
+            // row direction: running max per (lane,row); strict > keeps the earliest column
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rl = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float v0 = acc0[r], v1 = acc1[r];
-                if (cvalid && v0 > bv[0][r]) { bv[0][r] = v0; bc[0][r] = col; }
-                if (cvalid && v1 > bv[1][r]) { bv[1][r] = v1; bc[1][r] = col; }
-                const int rowa = row0 + wave * 64 + rl, rowb = rowa + 32;
-                if (rowa < n1) best = u64_max(best, ((unsigned long long)float_ord(v0) << 32) | (0xffffffffu - (unsigned)rowa));
-                if (rowb < n1) best = u64_max(best, ((unsigned long long)float_ord(v1) << 32) | (0xffffffffu - (unsigned)rowb));
+                const float v = acc[r];
+                if (cvalid && v > bv[r]) { bv[r] = v; bc[r] = col; }
             }
+            // column direction: float max over this lane's 16 rows, then the FIRST row attaining it
+            // (rows ascend with r), rows >= n1 excluded; one packed key per lane per tile
+            float cm = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                cm = fmaxf(cm, row < n1 ? acc[r] : -INFINITY);
+            }
+            int crow = 0x7fffffff;
+#pragma unroll
+            for (int r = 15; r >= 0; --r) {
+                const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < n1 && acc[r] == cm) crow = row;
+            }
+            unsigned long long best = crow == 0x7fffffff ? 0ull
+                                                         : (((unsigned long long)float_ord(cm) << 32) | (0xffffffffu - (unsigned)crow));
             best = u64_max(best, shfl_xor_u64(best, 32));
             if (half == 0) colbest[wave][ct * 32 + l31] = best;
         }
@@ -114,8 +128,9 @@ __global__ __launch_bounds__(256) void mnn_sim_kernel(const float* __restrict__ 
         if (tid < MT_COLS) {
             const int col = c0 + tid;
             if (col < n2) {
-                const unsigned long long k = u64_max(u64_max(colbest[0][tid], colbest[1][tid]),
-                                                     u64_max(colbest[2][tid], colbest[3][tid]));
+                unsigned long long k = colbest[0][tid];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) k = u64_max(k, colbest[w][tid]);
                 colpart[((size_t)p * nrb + rb) * N2 + col] = k;
             }
         }
@@ -123,18 +138,16 @@ __global__ __launch_bounds__(256) void mnn_sim_kernel(const float* __restrict__ 
 
     // row arg-max: reduce the per-lane running maxima over the 32 lanes that share the rows
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int r = 0; r < 16; ++r) {
+        unsigned long long key = ((unsigned long long)float_ord(bv[r]) << 32) | (0xffffffffu - (unsigned)bc[r]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            unsigned long long key = ((unsigned long long)float_ord(bv[rt][r]) << 32) | (0xffffffffu - (unsigned)bc[rt][r]);
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) key = u64_max(key, shfl_xor_u64(key, o));
-            const int row = row0 + wave * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (l31 == 0 && row < n1) {
-                match12[(size_t)p * N1 + row] = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-                rowmax[(size_t)p * N1 + row] = ord_float((unsigned)(key >> 32));
-            }
+        for (int o = 16; o > 0; o >>= 1) key = u64_max(key, shfl_xor_u64(key, o));
+        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (l31 == 0 && row < n1) {
+            match12[(size_t)p * N1 + row] = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+            rowmax[(size_t)p * N1 + row] = ord_float((unsigned)(key >> 32));
         }
+    }
 }
 
 // grid (P), block 1024, dynamic LDS = N2 ints
@@ -202,7 +215,7 @@ void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d
                   int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof) {
     const int nrb = match_row_blocks(N1);
     prof_begin(prof, 2, st);
-    mnn_sim_kernel<<<dim3(nrb, P), 256, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, ws.match12,
+    mnn_sim_kernel<<<dim3(nrb, P), 512, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, ws.match12,
                                                  ws.rowmax, ws.colpart);
     prof_end(prof, 2, st, 2.0 * P * (double)N1 * N2 * 64, (double)P * (N1 + N2) * 64 * 4);
     static bool attr_set = false;

@@ -31,6 +31,7 @@ struct LinW {             // fine_matcher layer: y = relu?(x W^T + b), BN folded
 struct NetWeights {
     ConvW conv[L_NUM];
     LinW fine[5];
+    const float* zeros;   // 1 KiB of zeros (padding source of the LDS-DMA loaders)
 };
 
 struct Profiler;   // api.hip
@@ -52,8 +53,9 @@ void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Wi
 // ---- k_conv_mfma.hip --------------------------------------------------------------------
 // 3x3 / 1x1 convolution as an implicit GEMM on f32 MFMA.  in NCHW; out NCHW or NHWC.
 // Returns 0, or -1 when no instantiation exists for the layer shape.
-int launch_conv_mfma(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, bool nhwc_out,
-                     hipStream_t st);
+// fused1x1 (optional): the 1x1 conv that follows, computed in the same kernel.  zeros: >= 256 B.
+int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, const float* in, int B, int Hin, int Win,
+                     float* out, bool nhwc_out, hipStream_t st, long long* trace = nullptr);
 double conv_flops(const ConvW& c, int B, int Hout, int Wout);
 
 // ---- k_linear_mfma.hip ------------------------------------------------------------------

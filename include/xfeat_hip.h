@@ -199,6 +199,8 @@ enum { XFH_PROF_NONE = 0, XFH_PROF_CONV_MFMA = 1, XFH_PROF_MATCH = 2, XFH_PROF_B
        XFH_PROF_CONV_64_64_S1 = 5 /* launches of conv_mfma_kernel<64,64,3,1,..>: the 64->64 3x3 stride-1 layers */,
        XFH_PROF_CONV_LAYER0 = 100 /* + index into spec.CONVS: one MFMA conv layer only */ };
 int xfh_profile_select(xfh_handle h, int which);
+/* debug: 24 int64 s_memtime stamps per MFMA-conv workgroup are written to device_buffer (NULL = off) */
+int xfh_debug_trace(xfh_handle h, long long* device_buffer);
 int xfh_profile_read(xfh_handle h, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);
 
 #ifdef __cplusplus
