@@ -401,7 +401,7 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, flo
 
     launch_gray_norm(img, B, C, H, W, w.part, w.gray, st);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
-    launch_block1(nw, w.gray, B, H, W, w.t0, w.t1, w.t2, w.x1, st);
+    launch_block1_fused(nw, w.gray, B, H, W, w.x1, st);
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 0, 0);
 #define CONV(layer, fused, in, hin, win, out, nhwc) \
     if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st))) return rc

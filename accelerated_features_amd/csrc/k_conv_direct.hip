@@ -100,6 +100,201 @@ int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B,
 }
 
 // ------------------------------------------------------------------------------------------
+// block1 fused: gray (B,1,H,W) -> x1 = block1(gray) + skip1(gray)  (B,24,H/4,W/4)
+//   (modules/model.py:40-48,140).  One workgroup = 8 x 16 output pixels.  The four
+//   low-channel layers run back to back on LDS-resident tiles (halo recomputed per tile,
+//   ~15 % extra FMAs), so the 4/8/8-channel full- and half-resolution activations
+//   (19.7 MB/frame written and re-read by the layer-at-a-time version) never reach HBM:
+//   the kernel reads the gray tile once and writes x1 once.
+//
+//   tile extents (rows x cols), origin in its own map:
+//     out  8 x 16  at (Y4, X4)            [H/4 x W/4]
+//     c3  17 x 33  at (2Y4-1, 2X4-1)      [H/2 x W/2]   conv3 8->8 s1
+//     c2  19 x 35  at (2Y4-2, 2X4-2)      [H/2 x W/2]   conv2 4->8 s2
+//     c1  39 x 71  at (4Y4-5, 4X4-5)      [H x W]       conv1 1->4 s1
+//     g   41 x 73  at (4Y4-6, 4X4-6)      [H x W]       normalised gray
+//   Positions outside a map are stored as 0 = the next conv's zero padding.
+//   Weights are read with wave-uniform addresses (scalar loads, SGPR operands of v_fmac).
+// ------------------------------------------------------------------------------------------
+namespace b1 {
+constexpr int OH = 8, OW = 16;
+constexpr int C3H = 17, C3W = 33, C2H = 19, C2W = 35, C1H = 39, C1W = 71, GH = 41, GW = 73;
+constexpr int G_OFF = 0, G_SZ = GH * GW;                  // 2993
+constexpr int C1_OFF = G_OFF + G_SZ, C1_SZ = 4 * C1H * C1W;  // 11076
+constexpr int C2_OFF = C1_OFF + C1_SZ, C2_SZ = 8 * C2H * C2W;  // 5320
+constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead once c2 exists)
+constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19389 floats = 77.6 KB
+}  // namespace b1
+
+__global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restrict__ gray, float* __restrict__ x1, int H, int W,
+                                                           const float* __restrict__ w1, const float* __restrict__ bb1,
+                                                           const float* __restrict__ w2, const float* __restrict__ bb2,
+                                                           const float* __restrict__ w3, const float* __restrict__ bb3,
+                                                           const float* __restrict__ w4, const float* __restrict__ bb4,
+                                                           const float* __restrict__ skw, const float* __restrict__ skb) {
+    using namespace b1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* G = lds + G_OFF;
+    float* C1 = lds + C1_OFF;
+    float* C2 = lds + C2_OFF;
+    float* C3 = lds + C3_OFF;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, Y4 = blockIdx.y * OH, X4 = blockIdx.x * OW;
+    const int H2 = H >> 1, W2 = W >> 1, H4 = H >> 2, W4 = W >> 2;
+    const float* gb = gray + (size_t)b * H * W;
+
+    // ---- stage 0: gray tile ----------------------------------------------------------------
+    for (int e = tid; e < G_SZ; e += 256) {
+        const int r = e / GW, c = e - r * GW;
+        const int gy = 4 * Y4 - 6 + r, gx = 4 * X4 - 6 + c;
+        G[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gb[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- stage 1: conv1 1->4, s1 --------------------------------------------------------------
+    for (int e = tid; e < C1H * C1W; e += 256) {
+        const int r = e / C1W, c = e - r * C1W;
+        const int gy = 4 * Y4 - 5 + r, gx = 4 * X4 - 5 + c;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+#pragma unroll
+            for (int co = 0; co < 4; ++co) acc[co] = bb1[co];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float v = G[(r + dy) * GW + c + dx];
+                    const float* w = w1 + (dy * 3 + dx) * 4;
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) acc[co] = fmaf(v, w[co], acc[co]);
+                }
+#pragma unroll
+            for (int co = 0; co < 4; ++co) acc[co] = fmaxf(acc[co], 0.f);
+        }
+#pragma unroll
+        for (int co = 0; co < 4; ++co) C1[co * (C1H * C1W) + e] = acc[co];
+    }
+    __syncthreads();
+
+    // ---- stage 2: conv2 4->8, s2 --------------------------------------------------------------
+    for (int e = tid; e < C2H * C2W; e += 256) {
+        const int r = e / C2W, c = e - r * C2W;
+        const int gy = 2 * Y4 - 2 + r, gx = 2 * X4 - 2 + c;
+        float acc[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) acc[co] = 0.f;
+        if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[co] = bb2[co];
+#pragma unroll 1
+            for (int ci = 0; ci < 4; ++ci) {
+                const float* src = C1 + ci * (C1H * C1W) + (2 * r) * C1W + 2 * c;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = src[dy * C1W + dx];
+                        const float* w = w2 + ((ci * 9) + dy * 3 + dx) * 8;
+#pragma unroll
+                        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, w[co], acc[co]);
+                    }
+            }
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[co] = fmaxf(acc[co], 0.f);
+        }
+#pragma unroll
+        for (int co = 0; co < 8; ++co) C2[co * (C2H * C2W) + e] = acc[co];
+    }
+    __syncthreads();
+
+    // ---- stage 3: conv3 8->8, s1 (writes over the dead c1 tile) ----------------------------------
+    for (int e = tid; e < C3H * C3W; e += 256) {
+        const int r = e / C3W, c = e - r * C3W;
+        const int gy = 2 * Y4 - 1 + r, gx = 2 * X4 - 1 + c;
+        float acc[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) acc[co] = 0.f;
+        if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[co] = bb3[co];
+#pragma unroll 1
+            for (int ci = 0; ci < 8; ++ci) {
+                const float* src = C2 + ci * (C2H * C2W) + r * C2W + c;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float v = src[dy * C2W + dx];
+                        const float* w = w3 + ((ci * 9) + dy * 3 + dx) * 8;
+#pragma unroll
+                        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, w[co], acc[co]);
+                    }
+            }
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[co] = fmaxf(acc[co], 0.f);
+        }
+#pragma unroll
+        for (int co = 0; co < 8; ++co) C3[co * (C3H * C3W) + e] = acc[co];
+    }
+    __syncthreads();
+
+    // ---- stage 4: conv4 8->24, s2 + skip1 + residual add; thread = (pixel, 12 of 24 couts) ------
+    {
+        const int p = tid & 127, r = p >> 4, c = p & 15;
+        const int g = __builtin_amdgcn_readfirstlane(tid >> 7);      // waves 0,1 -> couts 0-11 ; 2,3 -> 12-23
+        const int oy = Y4 + r, ox = X4 + c;
+        float acc[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc[j] = bb4[g * 12 + j];
+#pragma unroll 1
+        for (int ci = 0; ci < 8; ++ci) {
+            const float* src = C3 + ci * (C3H * C3W) + (2 * r) * C3W + 2 * c;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float v = src[dy * C3W + dx];
+                    const float* w = w4 + ((ci * 9) + dy * 3 + dx) * 24 + g * 12;
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) acc[j] = fmaf(v, w[j], acc[j]);
+                }
+        }
+        // skip1: 4x4 average of the gray tile (AvgPool2d(4,4)), then 1x1 conv 1->24 with bias
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += G[(4 * r + 6 + i) * GW + 4 * c + 6 + j];
+        const float sk = s * 0.0625f;
+        if (oy < H4 && ox < W4) {
+            float* op = x1 + (((size_t)b * 24 + g * 12) * H4 + oy) * W4 + ox;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const float v = fmaxf(acc[j], 0.f) + fmaf(sk, skw[g * 12 + j], skb[g * 12 + j]);
+                op[(size_t)j * H4 * W4] = v;
+            }
+        }
+    }
+}
+
+void launch_block1_fused(const NetWeights& nw, const float* gray, int B, int H, int W, float* x1, hipStream_t st) {
+    const ConvW& c0 = nw.conv[L_BLOCK1_0];
+    const ConvW& c1 = nw.conv[L_BLOCK1_1];
+    const ConvW& c2 = nw.conv[L_BLOCK1_2];
+    const ConvW& c3 = nw.conv[L_BLOCK1_3];
+    const ConvW& sk = nw.conv[L_SKIP1];
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block1_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  b1::LDS_FLOATS * 4);
+        attr = true;
+    }
+    const int H4 = H / 4, W4 = W / 4;
+    block1_fused_kernel<<<dim3(ceil_div(W4, b1::OW), ceil_div(H4, b1::OH), B), 256, b1::LDS_FLOATS * 4, st>>>(
+        gray, x1, H, W, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
+}
+
+// ------------------------------------------------------------------------------------------
 // generic direct conv: thread = (pixel, 8 output channels); weights in (Cout,Cin,k,k) order
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_direct_generic_kernel(const float* __restrict__ in, const float* __restrict__ w,

@@ -16,30 +16,46 @@ namespace xfh {
 // ------------------------------------------------------------------------------------------
 // NMS flags: pixel is kept iff heat > thr and no pixel of its 5x5 window (implicit -inf
 // padding) is larger (== local max; plateaus keep every equal pixel).
-// grid (ceil(WPR/4), H, B): one wave per 64-pixel word.
+// One workgroup = 64 x 32 pixels: the (64+4) x (32+4) tile is staged in LDS once, every lane
+// owns one column and slides a 5-row window of horizontal 5-maxima down its 8 rows
+// (5 LDS reads per row instead of 25 global loads).  grid (WPR, H/32, B).
 // ------------------------------------------------------------------------------------------
+constexpr int NMS_TW = 64, NMS_TH = 32, NMS_LW = NMS_TW + 4, NMS_LH = NMS_TH + 4;
 __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict__ heat, int H, int W, int WPR, float thr,
                                                         unsigned long long* __restrict__ mask, int* __restrict__ wcount) {
-    const int lane = threadIdx.x & 63, word = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int y = blockIdx.y, b = blockIdx.z;
-    const int x = word * 64 + lane;
+    __shared__ float tile[NMS_LH * NMS_LW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int word = blockIdx.x, y0 = blockIdx.y * NMS_TH, b = blockIdx.z;
+    const int x0 = word * 64;
     const float* hp = heat + (size_t)b * H * W;
-    bool cand = false;
-    if (word < WPR && x < W) {
-        const float v = hp[(size_t)y * W + x];
-        if (v > thr) {
-            float m = v;
-            const int y0 = max(y - 2, 0), y1 = min(y + 2, H - 1), x0 = max(x - 2, 0), x1 = min(x + 2, W - 1);
-            for (int yy = y0; yy <= y1; ++yy)
-                for (int xx = x0; xx <= x1; ++xx) m = fmaxf(m, hp[(size_t)yy * W + xx]);
-            cand = (v == m);
-        }
+    for (int e = tid; e < NMS_LH * NMS_LW; e += 256) {
+        const int r = e / NMS_LW, c = e - r * NMS_LW;
+        const int gy = y0 - 2 + r, gx = x0 - 2 + c;
+        tile[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? hp[(size_t)gy * W + gx] : -INFINITY;
     }
-    const unsigned long long bal = __ballot(cand);
-    if (lane == 0 && word < WPR) {
-        const size_t o = ((size_t)b * H + y) * WPR + word;
-        mask[o] = bal;
-        wcount[o] = __popcll(bal);
+    __syncthreads();
+    // this wave: rows y0 + 8*wave .. +7 ; lane: column x0 + lane
+    const int rbase = 8 * wave;           // tile row of (first output row - 2)
+    float hm[5];
+    auto hmax = [&](int trow) {
+        const float* t = tile + trow * NMS_LW + lane;
+        return fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), t[4]);
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hm[k] = hmax(rbase + k);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        hm[(r + 4) % 5] = hmax(rbase + r + 4);
+        const float m = fmaxf(fmaxf(fmaxf(hm[0], hm[1]), fmaxf(hm[2], hm[3])), hm[4]);
+        const float v = tile[(rbase + r + 2) * NMS_LW + lane + 2];
+        const int y = y0 + 8 * wave + r, x = x0 + lane;
+        const bool cand = (y < H) && (x < W) && (v > thr) && (v == m);
+        const unsigned long long bal = __ballot(cand);
+        if (lane == 0 && y < H) {
+            const size_t o = ((size_t)b * H + y) * WPR + word;
+            mask[o] = bal;
+            wcount[o] = __popcll(bal);
+        }
     }
 }
 
@@ -299,17 +315,18 @@ __device__ inline void cubic_w(float t, float w[4]) {
     w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
 }
 
-// one wave per selected key-point, lane = descriptor channel:
+// 16 lanes per selected key-point (4 channels each as one float4), 4 key-points per wave:
 //   desc = normalize( bicubic( normalize(M1, dim=1) ) )                   (xfeat.py:70,90-93)
+// The 16 taps are 16 independent 256-B row reads per key-point (1 KiB per wave-instruction).
 __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict__ feats, const float* __restrict__ inv,
                                                          const unsigned* __restrict__ cand, const unsigned* __restrict__ sel,
                                                          const int* __restrict__ nsel, int H, int W, int cap, int top_k,
                                                          float* __restrict__ desc) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    const int sub = threadIdx.x & 15;
+    const int j = blockIdx.x * 16 + (threadIdx.x >> 4), b = blockIdx.y;
     if (j >= top_k) return;
-    float* dp = desc + ((size_t)b * top_k + j) * 64;
-    if (j >= nsel[b]) { dp[lane] = 0.f; return; }
+    float4* dp = reinterpret_cast<float4*>(desc + ((size_t)b * top_k + j) * 64) + sub;
+    if (j >= nsel[b]) { *dp = make_float4(0.f, 0.f, 0.f, 0.f); return; }
     const unsigned c = cand[(size_t)b * cap + sel[(size_t)b * top_k + j]];
     const int x = c & 0xffff, y = c >> 16;
     const int hc = H >> 3, wc = W >> 3;
@@ -319,27 +336,33 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     cubic_w(ux - fx, wx);
     cubic_w(uy - fy, wy);
     const int x0 = (int)fx - 1, y0 = (int)fy - 1;
-    const float* fb = feats + (size_t)b * hc * wc * 64;
+    const float4* fb = reinterpret_cast<const float4*>(feats + (size_t)b * hc * wc * 64) + sub;
     const float* ib = inv + (size_t)b * hc * wc;
-    float acc = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int yy = y0 + r;
-        float row = 0.f;
+        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int xx = x0 + i;
-            float v = 0.f;
             if (xx >= 0 && xx < wc && yy >= 0 && yy < hc) {
                 const int pix = yy * wc + xx;
-                v = fb[(size_t)pix * 64 + lane] * ib[pix];
+                const float4 v = fb[(size_t)pix * 16];
+                const float sc = ib[pix];
+                row.x += (v.x * sc) * wx[i]; row.y += (v.y * sc) * wx[i];
+                row.z += (v.z * sc) * wx[i]; row.w += (v.w * sc) * wx[i];
             }
-            row += v * wx[i];
         }
-        acc += row * wy[r];
+        acc.x += row.x * wy[r]; acc.y += row.y * wy[r]; acc.z += row.z * wy[r]; acc.w += row.w * wy[r];
     }
-    const float n2 = wave_sum(acc * acc);
-    dp[lane] = acc / fmaxf(sqrtf(n2), 1e-12f);
+    float n2 = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+    n2 += __shfl_xor(n2, 8, 64);
+    n2 += __shfl_xor(n2, 4, 64);
+    n2 += __shfl_xor(n2, 2, 64);
+    n2 += __shfl_xor(n2, 1, 64);
+    const float d = fmaxf(sqrtf(n2), 1e-12f);
+    *dp = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
 }
 
 void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, int B, int H, int W,
@@ -347,13 +370,13 @@ void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, c
                    int32_t* n_valid, int32_t* n_cand, hipStream_t st) {
     const int WPR = ceil_div(W, 64);
     const int hc = H / 8, wc = W / 8;
-    nms_flags_kernel<<<dim3(ceil_div(WPR, 4), H, B), 256, 0, st>>>(heat, H, W, WPR, thr, ws.mask, ws.wcount);
+    nms_flags_kernel<<<dim3(WPR, ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, H, W, WPR, thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
     score_keys_kernel<<<dim3(ceil_div(cap, 256), B), 256, 0, st>>>(heat, reliab, ws.cand, n_cand, H, W, cap, ws.keys);
     TopkOut o{ws.cand, kpts, scores, n_valid, rw, rh};
     run_topk(ws.keys, cap, n_cand, 0, cap, top_k, B, ws.sel, ws.nsel, o, st);
     invnorm_kernel<<<ceil_div(B * hc * wc * 16, 256), 256, 0, st>>>(feats, B * hc * wc, ws.invnorm);
-    descriptor_kernel<<<dim3(ceil_div(top_k, 4), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.sel, ws.nsel, H, W, cap,
+    descriptor_kernel<<<dim3(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.sel, ws.nsel, H, W, cap,
                                                                  top_k, desc);
 }
 
@@ -374,7 +397,7 @@ __global__ __launch_bounds__(256) void cand_to_xy_kernel(const unsigned* __restr
 void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int cap, int64_t* xy,
                      int32_t* n_cand, hipStream_t st) {
     const int WPR = ceil_div(W, 64);
-    nms_flags_kernel<<<dim3(ceil_div(WPR, 4), H, B), 256, 0, st>>>(heat, H, W, WPR, thr, ws.mask, ws.wcount);
+    nms_flags_kernel<<<dim3(WPR, ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, H, W, WPR, thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
     cand_to_xy_kernel<<<dim3(ceil_div(cap, 256), B), 256, 0, st>>>(ws.cand, n_cand, cap, xy);
 }

@@ -124,29 +124,61 @@ void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, floa
         src, Hin, Win, dst, Hout, Wout, sh, sw);
 }
 
-// out = x3 + up(x4 -> x3 size) + up(x5 -> x3 size)      (model.py:146-148), NCHW planes
+// out = x3 + up(x4 -> x3 size) + up(x5 -> x3 size)      (model.py:146-148), NCHW planes.
+// One workgroup per plane: the small x4 / x5 source planes are staged in LDS (coalesced), the
+// x3 / out streams are float4.  Falls back to direct gathers when the planes exceed LDS.
+__device__ inline float bilerp_at(const float* __restrict__ p, int Hs, int Ws, float sy, float sx, int oy, int ox) {
+    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
+    lin_coef(sy, oy, Hs, y0, y1, wy0, wy1);
+    lin_coef(sx, ox, Ws, x0, x1, wx0, wx1);
+    return bilerp(p, Ws, y0, y1, x0, x1, wy0, wy1, wx0, wx1);
+}
+
+template <bool USE_LDS>
 __global__ __launch_bounds__(256) void pyramid_sum_kernel(const float* __restrict__ x3, const float* __restrict__ x4,
                                                           const float* __restrict__ x5, float* __restrict__ out,
                                                           int H3, int W3, int H4, int W4, int H5, int W5) {
-    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int pl = blockIdx.z;
-    if (ox >= W3 || oy >= H3) return;
-    int y0, y1, x0, x1; float wy0, wy1, wx0, wx1;
-    lin_coef((float)H4 / (float)H3, oy, H4, y0, y1, wy0, wy1);
-    lin_coef((float)W4 / (float)W3, ox, W4, x0, x1, wx0, wx1);
-    const float u4 = bilerp(x4 + (size_t)pl * H4 * W4, W4, y0, y1, x0, x1, wy0, wy1, wx0, wx1);
-    lin_coef((float)H5 / (float)H3, oy, H5, y0, y1, wy0, wy1);
-    lin_coef((float)W5 / (float)W3, ox, W5, x0, x1, wx0, wx1);
-    const float u5 = bilerp(x5 + (size_t)pl * H5 * W5, W5, y0, y1, x0, x1, wy0, wy1, wx0, wx1);
-    const size_t o = ((size_t)pl * H3 + oy) * W3 + ox;
-    out[o] = (x3[o] + u4) + u5;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int pl = blockIdx.x, tid = threadIdx.x;
+    const float* p4 = x4 + (size_t)pl * H4 * W4;
+    const float* p5 = x5 + (size_t)pl * H5 * W5;
+    if (USE_LDS) {
+        for (int e = tid; e < H4 * W4; e += 256) sm[e] = p4[e];
+        for (int e = tid; e < H5 * W5; e += 256) sm[H4 * W4 + e] = p5[e];
+        __syncthreads();
+        p4 = sm;
+        p5 = sm + H4 * W4;
+    }
+    const float s4y = (float)H4 / (float)H3, s4x = (float)W4 / (float)W3;
+    const float s5y = (float)H5 / (float)H3, s5x = (float)W5 / (float)W3;
+    const size_t base = (size_t)pl * H3 * W3;
+    const int n = H3 * W3;
+    if ((W3 & 3) == 0) {
+        for (int e4 = tid; e4 < n / 4; e4 += 256) {
+            const int e = e4 * 4, oy = e / W3, ox = e - oy * W3;
+            const float4 v = *reinterpret_cast<const float4*>(x3 + base + e);
+            float4 r;
+            r.x = (v.x + bilerp_at(p4, H4, W4, s4y, s4x, oy, ox)) + bilerp_at(p5, H5, W5, s5y, s5x, oy, ox);
+            r.y = (v.y + bilerp_at(p4, H4, W4, s4y, s4x, oy, ox + 1)) + bilerp_at(p5, H5, W5, s5y, s5x, oy, ox + 1);
+            r.z = (v.z + bilerp_at(p4, H4, W4, s4y, s4x, oy, ox + 2)) + bilerp_at(p5, H5, W5, s5y, s5x, oy, ox + 2);
+            r.w = (v.w + bilerp_at(p4, H4, W4, s4y, s4x, oy, ox + 3)) + bilerp_at(p5, H5, W5, s5y, s5x, oy, ox + 3);
+            *reinterpret_cast<float4*>(out + base + e) = r;
+        }
+    } else {
+        for (int e = tid; e < n; e += 256) {
+            const int oy = e / W3, ox = e - oy * W3;
+            out[base + e] = (x3[base + e] + bilerp_at(p4, H4, W4, s4y, s4x, oy, ox)) + bilerp_at(p5, H5, W5, s5y, s5x, oy, ox);
+        }
+    }
 }
 
 void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int planes,
                         int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st) {
-    pyramid_sum_kernel<<<dim3(ceil_div(W3, 64), ceil_div(H3, 4), planes), 256, 0, st>>>(
-        x3, x4, x5, out, H3, W3, H4, W4, H5, W5);
+    const size_t lds = ((size_t)H4 * W4 + (size_t)H5 * W5) * sizeof(float);
+    if (lds <= 64 * 1024)
+        pyramid_sum_kernel<true><<<planes, 256, lds, st>>>(x3, x4, x5, out, H3, W3, H4, W4, H5, W5);
+    else
+        pyramid_sum_kernel<false><<<planes, 256, 0, st>>>(x3, x4, x5, out, H3, W3, H4, W4, H5, W5);
 }
 
 }  // namespace xfh

@@ -46,6 +46,7 @@ void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float
 // ---- k_conv_direct.hip ------------------------------------------------------------------
 void launch_block1(const NetWeights& nw, const float* gray, int B, int H, int W, float* t0, float* t1, float* t2,
                    float* x1, hipStream_t st);
+void launch_block1_fused(const NetWeights& nw, const float* gray, int B, int H, int W, float* x1, hipStream_t st);
 int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B, int Hin, int Win, float* out,
                         hipStream_t st);
 void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, hipStream_t st);
