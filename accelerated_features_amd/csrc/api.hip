@@ -131,17 +131,14 @@ struct Carver {
 
 struct BackboneWs {
     double* part;
-    float *gray, *t0, *t1, *t2, *x1, *x2a, *x2b, *x3a, *x3b, *x3c, *x4a, *x4b, *x4c, *x5a, *x5b, *x5c, *x5d;
-    float *pyr, *f0, *f1, *hh0, *hh1, *kh0, *kh1, *kh2, *logits;
+    float *gray, *x1, *x2a, *x2b, *x3a, *x3b, *x3c, *x4a, *x4b, *x4c, *x5a, *x5b, *x5c, *x5d;
+    float *pyr, *f0, *heat_tmp;
 };
 static size_t carve_backbone(void* ws, int B, int H, int W, BackboneWs& o) {
     Carver c(ws);
     const size_t HW = (size_t)H * W, b = B;
     o.part = c.take<double>(b * GS_CHUNKS * 2);
     o.gray = c.take<float>(b * HW);
-    o.t0 = c.take<float>(b * 4 * HW);
-    o.t1 = c.take<float>(b * 8 * HW / 4);
-    o.t2 = c.take<float>(b * 8 * HW / 4);
     o.x1 = c.take<float>(b * 24 * HW / 16);
     o.x2a = c.take<float>(b * 24 * HW / 16);
     o.x2b = c.take<float>(b * 24 * HW / 16);
@@ -157,13 +154,7 @@ static size_t carve_backbone(void* ws, int B, int H, int W, BackboneWs& o) {
     o.x5d = c.take<float>(b * 64 * HW / 1024);
     o.pyr = c.take<float>(b * 64 * HW / 64);
     o.f0 = c.take<float>(b * 64 * HW / 64);
-    o.f1 = c.take<float>(b * 64 * HW / 64);
-    o.hh0 = c.take<float>(b * 64 * HW / 64);
-    o.hh1 = c.take<float>(b * 64 * HW / 64);
-    o.kh0 = c.take<float>(b * 64 * HW / 64);
-    o.kh1 = c.take<float>(b * 64 * HW / 64);
-    o.kh2 = c.take<float>(b * 64 * HW / 64);
-    o.logits = c.take<float>(b * 65 * HW / 64);
+    o.heat_tmp = c.take<float>(b * HW);
     return align_up(c.off, 256);
 }
 
@@ -420,33 +411,10 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, flo
     CONV(L_FUSION_1, L_FUSION_2, w.f0, H8, W8, feats, true);          // 3x3 + fused 1x1 -> channels-last M1
 #undef CONV
 
-    // heads on channels-last rows
-    const int M = B * H8 * W8;
+    // fused heads: reliability from the channels-last features, key-point head from the gray image
     prof_begin(&h->prof, XFH_PROF_HEADS, st);
-    LinSrc rm{};
-    rm.ldx = 64;
-    auto lin = [&](int layer, const float* x, float* y, int ldy) {
-        const ConvW& c = nw.conv[layer];
-        LinSrc s = rm;
-        s.x = x;
-        return launch_linear_mfma(c.w_kcp, c.bias, 64, c.cout, c.cout_pad, c.relu != 0, LOAD_ROWMAJOR, s, M, nullptr, y, ldy, st);
-    };
-    int bad = 0;
-    bad |= lin(L_HEAT_0, feats, w.hh0, 64);
-    bad |= lin(L_HEAT_1, w.hh0, w.hh1, 64);
-    launch_dot_sigmoid(w.hh1, M, nw.conv[L_HEAT_2].w_oihw, nw.conv[L_HEAT_2].bias, reliab, st);
-    {
-        const ConvW& c = nw.conv[L_KP_0];
-        LinSrc s{};
-        s.x = w.gray; s.H = H; s.W = W;
-        bad |= launch_linear_mfma(c.w_kcp, c.bias, 64, c.cout, c.cout_pad, true, LOAD_UNFOLD8, s, M, nullptr, w.kh0, 64, st);
-    }
-    bad |= lin(L_KP_1, w.kh0, w.kh1, 64);
-    bad |= lin(L_KP_2, w.kh1, w.kh2, 64);
-    float* lg = logits ? logits : w.logits;
-    bad |= lin(L_KP_3, w.kh2, lg, 65);
-    if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_backbone: missing linear kernel instantiation");
-    if (heat) launch_softmax_heat(lg, B, H8, W8, heat, st);
+    launch_rel_head(nw, feats, B * H8 * W8, reliab, st);
+    launch_kp_head(nw, w.gray, B, H, W, heat ? heat : w.heat_tmp, logits, st);
     prof_end(&h->prof, XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }

@@ -126,7 +126,7 @@ constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead o
 constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19389 floats = 77.6 KB
 }  // namespace b1
 
-__global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restrict__ gray, float* __restrict__ x1, int H, int W,
+__global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, float* __restrict__ x1, int H, int W,
                                                            const float* __restrict__ w1, const float* __restrict__ bb1,
                                                            const float* __restrict__ w2, const float* __restrict__ bb2,
                                                            const float* __restrict__ w3, const float* __restrict__ bb3,
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restri
     const float* gb = gray + (size_t)b * H * W;
 
     // ---- stage 0: gray tile ----------------------------------------------------------------
-    for (int e = tid; e < G_SZ; e += 256) {
+    for (int e = tid; e < G_SZ; e += 512) {
         const int r = e / GW, c = e - r * GW;
         const int gy = 4 * Y4 - 6 + r, gx = 4 * X4 - 6 + c;
         G[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gb[(size_t)gy * W + gx] : 0.f;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restri
     __syncthreads();
 
     // ---- stage 1: conv1 1->4, s1 --------------------------------------------------------------
-    for (int e = tid; e < C1H * C1W; e += 256) {
+    for (int e = tid; e < C1H * C1W; e += 512) {
         const int r = e / C1W, c = e - r * C1W;
         const int gy = 4 * Y4 - 5 + r, gx = 4 * X4 - 5 + c;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restri
     __syncthreads();
 
     // ---- stage 2: conv2 4->8, s2 --------------------------------------------------------------
-    for (int e = tid; e < C2H * C2W; e += 256) {
+    for (int e = tid; e < C2H * C2W; e += 512) {
         const int r = e / C2W, c = e - r * C2W;
         const int gy = 2 * Y4 - 2 + r, gx = 2 * X4 - 2 + c;
         float acc[8];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restri
     __syncthreads();
 
     // ---- stage 3: conv3 8->8, s1 (writes over the dead c1 tile) ----------------------------------
-    for (int e = tid; e < C3H * C3W; e += 256) {
+    for (int e = tid; e < C3H * C3W; e += 512) {
         const int r = e / C3W, c = e - r * C3W;
         const int gy = 2 * Y4 - 1 + r, gx = 2 * X4 - 1 + c;
         float acc[8];
@@ -238,14 +238,14 @@ __global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restri
     }
     __syncthreads();
 
-    // ---- stage 4: conv4 8->24, s2 + skip1 + residual add; thread = (pixel, 12 of 24 couts) ------
+    // ---- stage 4: conv4 8->24, s2 + skip1 + residual add; thread = (pixel, 6 of 24 couts) -------
     {
         const int p = tid & 127, r = p >> 4, c = p & 15;
-        const int g = __builtin_amdgcn_readfirstlane(tid >> 7);      // waves 0,1 -> couts 0-11 ; 2,3 -> 12-23
+        const int g = __builtin_amdgcn_readfirstlane(tid >> 7);      // wave pair -> couts 6g .. 6g+5
         const int oy = Y4 + r, ox = X4 + c;
-        float acc[12];
+        float acc[6];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) acc[j] = bb4[g * 12 + j];
+        for (int j = 0; j < 6; ++j) acc[j] = bb4[g * 6 + j];
 #pragma unroll 1
         for (int ci = 0; ci < 8; ++ci) {
             const float* src = C3 + ci * (C3H * C3W) + (2 * r) * C3W + 2 * c;
@@ -254,9 +254,9 @@ __global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restri
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const float v = src[dy * C3W + dx];
-                    const float* w = w4 + ((ci * 9) + dy * 3 + dx) * 24 + g * 12;
+                    const float* w = w4 + ((ci * 9) + dy * 3 + dx) * 24 + g * 6;
 #pragma unroll
-                    for (int j = 0; j < 12; ++j) acc[j] = fmaf(v, w[j], acc[j]);
+                    for (int j = 0; j < 6; ++j) acc[j] = fmaf(v, w[j], acc[j]);
                 }
         }
         // skip1: 4x4 average of the gray tile (AvgPool2d(4,4)), then 1x1 conv 1->24 with bias
@@ -267,10 +267,10 @@ __global__ __launch_bounds__(256) void block1_fused_kernel(const float* __restri
             for (int j = 0; j < 4; ++j) s += G[(4 * r + 6 + i) * GW + 4 * c + 6 + j];
         const float sk = s * 0.0625f;
         if (oy < H4 && ox < W4) {
-            float* op = x1 + (((size_t)b * 24 + g * 12) * H4 + oy) * W4 + ox;
+            float* op = x1 + (((size_t)b * 24 + g * 6) * H4 + oy) * W4 + ox;
 #pragma unroll
-            for (int j = 0; j < 12; ++j) {
-                const float v = fmaxf(acc[j], 0.f) + fmaf(sk, skw[g * 12 + j], skb[g * 12 + j]);
+            for (int j = 0; j < 6; ++j) {
+                const float v = fmaxf(acc[j], 0.f) + fmaf(sk, skw[g * 6 + j], skb[g * 6 + j]);
                 op[(size_t)j * H4 * W4] = v;
             }
         }
@@ -290,7 +290,7 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, int B, int H, 
         attr = true;
     }
     const int H4 = H / 4, W4 = W / 4;
-    block1_fused_kernel<<<dim3(ceil_div(W4, b1::OW), ceil_div(H4, b1::OH), B), 256, b1::LDS_FLOATS * 4, st>>>(
+    block1_fused_kernel<<<dim3(ceil_div(W4, b1::OW), ceil_div(H4, b1::OH), B), 512, b1::LDS_FLOATS * 4, st>>>(
         gray, x1, H, W, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
 }
 

@@ -1,0 +1,263 @@
+// Fused network heads on the f32 matrix cores (persistent kernels).
+//
+//   keypoint head  (modules/model.py:87-92,152 + modules/xfeat.py:242-247):
+//       8x8 unfold of the normalised gray image -> 3 x [1x1 conv 64->64 + BN + ReLU] ->
+//       1x1 conv 64->65 + bias -> softmax over the 65 logits -> drop dustbin ->
+//       depth-to-space 8x8 -> heat (B,H,W)            [optionally also the raw logits]
+//   reliability head (modules/model.py:79-84):
+//       feats (channels-last) -> 2 x [1x1 conv 64->64 + BN + ReLU] -> 1x1 conv 64->1 -> sigmoid
+//
+// One unit of work = a tile of 256 cells (one workgroup of 8 waves, 32 cells per wave).
+// Orientation as in k_conv_mfma.hip: D[feature][cell] (A = weights, B = activations), so a
+// layer's ReLU'd accumulator registers ARE the next layer's B operand when the K pairing is
+// chosen as channels (c, c+4): the whole chain lives in registers.  Only the first layer reads
+// activations from LDS ([cell][65] floats, conflict-free), filled by the global->LDS DMA
+// (one 64-lane dword copy per cell: the 8x8 unfold is just the DMA's source addressing).
+// The kernels are persistent: grid = #CUs, the head's weights are copied to LDS once per
+// workgroup, and the next tile's activations are in flight while layers 2..4 run.
+#include "kernels.hpp"
+
+namespace xfh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int HD_CELLS = 256;    // cells per tile
+constexpr int HD_XS = 65;        // LDS row stride of the activation tile
+
+struct HeadArgs {
+    const float* src;        // KP: normalised gray (B,H,W) ; REL: feats (B*hc*wc, 64)
+    const float* zeros;
+    const float* w[4];       // [64][n_pad] per layer (BN folded)
+    const float* bias[4];
+    float* out;              // KP: heat (B,H,W) ; REL: reliability (B*hc*wc)
+    float* logits;           // KP only, optional: (B*hc*wc, 65)
+    int H, W, hc, wc, ncell, ntiles;
+};
+
+// one chained 64 -> 32*MBO layer: out = bias + W^T relu(in)   (in/out in D[feature][cell] layout)
+template <int MBO>
+__device__ inline void chain_layer(const float* __restrict__ Wl, int npad, const float* __restrict__ bias,
+                                   const f32x16 (&in)[2], f32x16 (&out)[MBO], int l31, int half) {
+#pragma unroll
+    for (int m = 0; m < MBO; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[m][r] = bias[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+    const float* wb = Wl + (4 * half) * npad + l31;     // this lane's channel offset (c or c+4)
+    float av[2][MBO];
+    auto ld = [&](int st, float (&ao)[MBO]) {
+        const int m = st >> 4, r = st & 15;
+        const int k0 = m * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int mo = 0; mo < MBO; ++mo) ao[mo] = wb[k0 * npad + mo * 32];
+    };
+    ld(0, av[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, MBO, 0);
+#pragma unroll
+    for (int st = 0; st < 32; ++st) {
+        if (st + 1 < 32) ld(st + 1, av[(st + 1) & 1]);
+        const float y = fmaxf(in[st >> 4][st & 15], 0.f);
+#pragma unroll
+        for (int mo = 0; mo < MBO; ++mo)
+            out[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][mo], y, out[mo], 0, 0, 0);
+        if (st + 1 < 32) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MBO, 0);
+            if (MBO > 1) __builtin_amdgcn_sched_group_barrier(0x008, MBO - 1, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, MBO, 0);
+        }
+    }
+}
+
+template <bool KP>
+__global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
+    constexpr int NL = KP ? 4 : 3;
+    constexpr int W_FLOATS = KP ? (3 * 64 * 64 + 64 * 96) : (2 * 64 * 64 + 64);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wl = smem;
+    float* Xl = smem + W_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = a.hc * a.wc;
+
+    // all weights of this head -> LDS, once
+    {
+        int off = 0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int n = (KP && l == 3) ? 64 * 96 : ((!KP && l == 2) ? 64 : 64 * 64);
+            if (n >= 256) {
+                for (int j = wave; j < n / 256; j += 8)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(a.w[l] + j * 256 + lane * 4), (lptr_t)(Wl + off + j * 256), 16, 0, 0);
+            } else if (wave == 0) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(a.w[l] + lane), (lptr_t)(Wl + off), 4, 0, 0);
+            }
+            off += n;
+        }
+    }
+    // activation tile of `tile` -> LDS [cell][65]: one 64-lane dword DMA per cell
+    auto issue_x = [&](int tile) {
+#pragma unroll 4
+        for (int cc = 0; cc < 32; ++cc) {
+            const int cl = wave * 32 + cc;
+            const int g = tile * HD_CELLS + cl;             // wave-uniform
+            const float* p = a.zeros + lane;
+            if (g < a.ncell) {
+                if (KP) {
+                    const int b = g / hw, rem = g - b * hw;
+                    const int ci = rem / a.wc, cj = rem - ci * a.wc;
+                    p = a.src + (size_t)b * a.H * a.W + (size_t)(8 * ci + (lane >> 3)) * a.W + 8 * cj + (lane & 7);
+                } else {
+                    p = a.src + (size_t)g * 64 + lane;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)(Xl + cl * HD_XS), 4, 0, 0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < a.ntiles) issue_x(tile);
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        __syncthreads();                                   // tile (and the weights) landed
+        // ---- layer 1: B operand from LDS ------------------------------------------------------
+        f32x16 accA[2], accB[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accA[m][r] = a.bias[0][m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+        {
+            const float* xb = Xl + (wave * 32 + l31) * HD_XS + half;
+            const float* wb = Wl + half * 64 + l31;
+            float av[2][2], bv[2];
+            auto ld = [&](int p, float (&ao)[2], float& bo) {
+                ao[0] = wb[(2 * p) * 64];
+                ao[1] = wb[(2 * p) * 64 + 32];
+                bo = xb[2 * p];
+            };
+            ld(0, av[0], bv[0]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+            for (int p = 0; p < 32; ++p) {
+                if (p + 1 < 32) ld(p + 1, av[(p + 1) & 1], bv[(p + 1) & 1]);
+                accA[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][0], bv[p & 1], accA[0], 0, 0, 0);
+                accA[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][1], bv[p & 1], accA[1], 0, 0, 0);
+                if (p + 1 < 32) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+            }
+        }
+        __syncthreads();                                   // every wave is done with the X tile
+        if (tile + (int)gridDim.x < a.ntiles) issue_x(tile + gridDim.x);   // next tile flies during layers 2..
+
+        const int gcell = tile * HD_CELLS + wave * 32 + l31;            // this lane's cell
+        if (KP) {
+            chain_layer<2>(Wl + 64 * 64, 64, a.bias[1], accA, accB, l31, half);
+            chain_layer<2>(Wl + 2 * 64 * 64, 64, a.bias[2], accB, accA, l31, half);
+            f32x16 lg[3];
+            chain_layer<3>(Wl + 3 * 64 * 64, 96, a.bias[3], accA, lg, l31, half);
+            // lane (l31,half) holds logits c = 32m + (r&3) + 8(r>>2) + 4*half of its cell; c == 64 (dustbin) is m=2,r=0,half=0
+            float mx = -INFINITY;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, lg[m][r]);
+            if (half == 0) mx = fmaxf(mx, lg[2][0]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+            f32x16 e[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { e[m][r] = expf(lg[m][r] - mx); sum += e[m][r]; }
+            if (half == 0) sum += expf(lg[2][0] - mx);
+            sum += __shfl_xor(sum, 32, 64);
+            if (gcell < a.ncell) {
+                const int b = gcell / hw, rem = gcell - b * hw;
+                const int ci = rem / a.wc, cj = rem - ci * a.wc;
+                float* o = a.out + (size_t)b * a.H * a.W + (size_t)(8 * ci) * a.W + 8 * cj + 4 * half;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {          // dy = q + 4m, dx = 4*half .. +3
+                        const float4 v = make_float4(e[m][4 * q] / sum, e[m][4 * q + 1] / sum, e[m][4 * q + 2] / sum, e[m][4 * q + 3] / sum);
+                        *reinterpret_cast<float4*>(o + (size_t)(q + 4 * m) * a.W) = v;
+                    }
+                if (a.logits) {
+                    float* lp = a.logits + (size_t)gcell * 65;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) lp[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = lg[m][r];
+                    if (half == 0) lp[64] = lg[2][0];
+                }
+            }
+        } else {
+            chain_layer<2>(Wl + 64 * 64, 64, a.bias[1], accA, accB, l31, half);
+            // final 64 -> 1: dot over this lane's 32 channels, other half via one shuffle
+            const float* w3 = Wl + 2 * 64 * 64;
+            float s = 0.f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    s = fmaf(fmaxf(accB[m][r], 0.f), w3[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half], s);
+            s += __shfl_xor(s, 32, 64);
+            if (half == 0 && gcell < a.ncell) a.out[gcell] = 1.f / (1.f + expf(-(s + a.bias[2][0])));
+        }
+    }
+}
+
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+void launch_kp_head(const NetWeights& nw, const float* gray, int B, int H, int W, float* heat, float* logits, hipStream_t st) {
+    HeadArgs a{};
+    a.src = gray; a.zeros = nw.zeros; a.out = heat; a.logits = logits;
+    a.H = H; a.W = W; a.hc = H / 8; a.wc = W / 8;
+    a.ncell = B * a.hc * a.wc;
+    a.ntiles = ceil_div(a.ncell, HD_CELLS);
+    const int L[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3};
+    for (int i = 0; i < 4; ++i) { a.w[i] = nw.conv[L[i]].w_kcp; a.bias[i] = nw.conv[L[i]].bias; }
+    const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    head_fused_kernel<true><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
+}
+
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, hipStream_t st) {
+    HeadArgs a{};
+    a.src = feats; a.zeros = nw.zeros; a.out = reliab; a.logits = nullptr;
+    a.hc = 1; a.wc = 1; a.H = 8; a.W = 8;
+    a.ncell = ncell;
+    a.ntiles = ceil_div(ncell, HD_CELLS);
+    a.w[0] = nw.conv[L_HEAT_0].w_kcp; a.bias[0] = nw.conv[L_HEAT_0].bias;
+    a.w[1] = nw.conv[L_HEAT_1].w_kcp; a.bias[1] = nw.conv[L_HEAT_1].bias;
+    a.w[2] = nw.conv[L_HEAT_2].w_oihw; a.bias[2] = nw.conv[L_HEAT_2].bias;
+    const size_t lds = (size_t)(2 * 64 * 64 + 64 + HD_CELLS * HD_XS) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    head_fused_kernel<false><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
+}
+
+}  // namespace xfh

@@ -81,6 +81,12 @@ void launch_dot_sigmoid(const float* x, int M, const float* w, const float* b, f
 // heat (B,H,W) <- softmax over 65 logits per cell, depth-to-space 8x8       (xfeat.py:242-247)
 void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat, hipStream_t st);
 
+// ---- k_heads.hip -------------------------------------------------------------------------
+// fused heads (persistent, weights LDS-resident): key-point head -> heat (+ optional logits (M,65)),
+// reliability head -> sigmoid map
+void launch_kp_head(const NetWeights& nw, const float* gray, int B, int H, int W, float* heat, float* logits, hipStream_t st);
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, hipStream_t st);
+
 // ---- k_detect.hip -----------------------------------------------------------------------
 struct DetectWs {          // carved from the caller's workspace by api.hip
     unsigned long long* mask;   // (B, H, WPR) NMS flags, one bit per pixel

@@ -128,7 +128,8 @@ def test_backbone_fused_heat_equals_helper(xf):
     x = fixtures.texture_images(2, 96, 128, seed=11).cuda()
     feats, logits, heat, rel = xf.net.backbone(x, want_logits=True, want_heat=True)
     h2 = xf.get_kpts_heatmap(logits.permute(0, 3, 1, 2))
-    assert torch.equal(heat, h2[:, 0])
+    # same logits, two softmax evaluations (fused epilogue vs helper kernel): summation order differs
+    assert float((heat - h2[:, 0]).abs().max()) <= 5e-7
 
 
 def test_nms_helper_matches_oracle(xf, sd):
