@@ -50,4 +50,25 @@ __device__ inline float ord_float(unsigned o) {
     return __uint_as_float(u);
 }
 
+// XCD-aware work mapping (MI355X: 8 XCDs, private L2s; workgroup b runs on XCD b % 8).
+// A 1-D grid of n_groups_padded * per_group workgroups is remapped so that all `per_group`
+// workgroups of a group (an image, a descriptor pair) run on ONE XCD and share its L2:
+// group g lives on XCD g % 8.  Placement only affects speed, never results.
+// Returns false for the padding workgroups (group >= n_groups).
+// The remap is used only when n_groups is a multiple of 8 (otherwise XCDs would be loaded
+// unevenly, or idle for tiny batches) -- both sides of the launch use the same rule.
+__host__ __device__ inline bool xcd_swizzled(int n_groups) { return n_groups >= 8 && (n_groups & 7) == 0; }
+__device__ inline bool xcd_group_map(int id, int per_group, int n_groups, int& group, int& item) {
+    if (!xcd_swizzled(n_groups)) {
+        group = id / per_group;
+        item = id - group * per_group;
+        return group < n_groups;
+    }
+    const int xcd = id & 7, slot = id >> 3;
+    group = (slot / per_group) * 8 + xcd;
+    item = slot % per_group;
+    return group < n_groups;
+}
+__host__ inline int xcd_grid_size(int per_group, int n_groups) { return per_group * n_groups; }
+
 }  // namespace xfh

@@ -38,7 +38,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct ConvGeom {
     int Hin, Win, Hout, Wout;
-    int TW, TH, tiles_x;
+    int TW, TH, tiles_x, tiles, B;
     int IWt, plane, PS;     // input tile width, elements, plane stride in LDS (multiple of 64)
 };
 
@@ -74,8 +74,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const ConvGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y;
-    const int tyi = blockIdx.x / g.tiles_x, txi = blockIdx.x % g.tiles_x;
+    int b, tile;                      // all tiles of an image on one XCD (halo rows + weights hit its L2)
+    if (!xcd_group_map(blockIdx.x, g.tiles, g.B, b, tile)) return;
+    const int tyi = tile / g.tiles_x, txi = tile % g.tiles_x;
     const int oy0 = tyi * g.TH, ox0 = txi * g.TW;
     const int npix = g.TH * g.TW;
     const int PS = g.PS;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const size_t HWin = (size_t)g.Hin * g.Win;
     const float* inb = a.in + (size_t)b * CIN * HWin;
 
-    long long* tr = a.trace ? a.trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 24 : nullptr;
+    long long* tr = a.trace ? a.trace + (size_t)blockIdx.x * 24 : nullptr;
     if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memtime();
     // fused 1x1 weights: one DMA at kernel start into their own LDS region
     if (COUT2 > 0) {
@@ -369,6 +370,7 @@ static int run(const ConvW& c, const ConvW* c2, const float* zeros, const float*
     a.trace = trace;
     a.wk2 = c2 ? c2->w_kcp : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     const int tiles = g.tiles_x * ceil_div(g.Hout, g.TH);
+    g.tiles = tiles; g.B = B;
     const size_t lds = ((size_t)2 * (WCH + CK * g.PS) + (size_t)COUT * COUT2_PAD * (COUT2 > 0)) * sizeof(float);
     if (lds > 160 * 1024) return -1;
     static bool attr_done = false;     // one static per instantiation of run<>
@@ -379,8 +381,8 @@ static int run(const ConvW& c, const ConvW* c2, const float* zeros, const float*
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (nhwc) conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, true, COUT2><<<dim3(tiles, B), 256, lds, st>>>(a);
-    else conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, false, COUT2><<<dim3(tiles, B), 256, lds, st>>>(a);
+    if (nhwc) conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, true, COUT2><<<xcd_grid_size(tiles, B), 256, lds, st>>>(a);
+    else conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, false, COUT2><<<xcd_grid_size(tiles, B), 256, lds, st>>>(a);
     return 0;
 }
 

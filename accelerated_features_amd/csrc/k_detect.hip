@@ -321,9 +321,11 @@ __device__ inline void cubic_w(float t, float w[4]) {
 __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict__ feats, const float* __restrict__ inv,
                                                          const unsigned* __restrict__ cand, const unsigned* __restrict__ sel,
                                                          const int* __restrict__ nsel, int H, int W, int cap, int top_k,
-                                                         float* __restrict__ desc) {
+                                                         int B, int blocks_per_img, float* __restrict__ desc) {
     const int sub = threadIdx.x & 15;
-    const int j = blockIdx.x * 16 + (threadIdx.x >> 4), b = blockIdx.y;
+    int b, blk;                       // all key-points of an image on one XCD: its feats stay in that L2
+    if (!xcd_group_map(blockIdx.x, blocks_per_img, B, b, blk)) return;
+    const int j = blk * 16 + (threadIdx.x >> 4);
     if (j >= top_k) return;
     float4* dp = reinterpret_cast<float4*>(desc + ((size_t)b * top_k + j) * 64) + sub;
     if (j >= nsel[b]) { *dp = make_float4(0.f, 0.f, 0.f, 0.f); return; }
@@ -376,8 +378,8 @@ void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, c
     TopkOut o{ws.cand, kpts, scores, n_valid, rw, rh};
     run_topk(ws.keys, cap, n_cand, 0, cap, top_k, B, ws.sel, ws.nsel, o, st);
     invnorm_kernel<<<ceil_div(B * hc * wc * 16, 256), 256, 0, st>>>(feats, B * hc * wc, ws.invnorm);
-    descriptor_kernel<<<dim3(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.sel, ws.nsel, H, W, cap,
-                                                                 top_k, desc);
+    descriptor_kernel<<<xcd_grid_size(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.sel, ws.nsel, H, W,
+                                                                            cap, top_k, B, ceil_div(top_k, 16), desc);
 }
 
 // stand-alone NMS (XFeat.NMS): flags + compaction + int64 (x,y) list, zero padded

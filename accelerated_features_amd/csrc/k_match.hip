@@ -32,14 +32,16 @@ __device__ inline int pair_count(const int32_t* n, int idx, int cap) {
 __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2,
                                                       size_t ps2, const int32_t* __restrict__ n1p,
                                                       const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1,
-                                                      int N2, int nrb, int* __restrict__ match12,
+                                                      int N2, int nrb, int P, int* __restrict__ match12,
                                                       float* __restrict__ rowmax, unsigned long long* __restrict__ colpart) {
     __shared__ __attribute__((aligned(16))) float Dl[MT_COLS * MT_DS];
     __shared__ unsigned long long colbest[8][MT_COLS];
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = blockIdx.y, rb = blockIdx.x;
+    // all row blocks of a pair on one XCD: its D2 (1 MB at 4096 points) stays in that XCD's L2
+    int p, rb;
+    if (!xcd_group_map(blockIdx.x, nrb, P, p, rb)) return;
     const int n1 = pair_count(n1p, p * n_stride, N1);
     const int n2 = pair_count(n2p, p * n_stride + n_off2, N2);
     const int row0 = rb * MT_ROWS;
@@ -215,7 +217,7 @@ void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d
                   int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof) {
     const int nrb = match_row_blocks(N1);
     prof_begin(prof, 2, st);
-    mnn_sim_kernel<<<dim3(nrb, P), 512, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, ws.match12,
+    mnn_sim_kernel<<<xcd_grid_size(nrb, P), 512, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.match12,
                                                  ws.rowmax, ws.colpart);
     prof_end(prof, 2, st, 2.0 * P * (double)N1 * N2 * 64, (double)P * (N1 + N2) * 64 * 4);
     static bool attr_set = false;

@@ -21,7 +21,7 @@ def from_db(path):
 def main():
     path = sys.argv[1]
     if os.path.isdir(path):
-        path = sorted(glob.glob(os.path.join(path, "**", "*.db"), recursive=True))[-1]
+        path = max(glob.glob(os.path.join(path, "**", "*.db"), recursive=True), key=os.path.getmtime)
     rows = from_db(path)
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else None
     tot = sum(r[2] for r in rows)
