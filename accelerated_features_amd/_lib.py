@@ -42,6 +42,7 @@ SIGNATURES = {
     "xfh_fine_matcher": (_i, [_p, _p, _i, _p, _p, _sz, _p]),
     "xfh_profile_select": (_i, [_p, _i]),
     "xfh_debug_trace": (_i, [_p, _p]),
+    "xfh_debug_match_occupancy": (_i, []),
     "xfh_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

@@ -596,6 +596,8 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
     return check_launch("xfh_fine_matcher");
 }
 
+int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
+
 int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
     if (!h) return fail(XFH_ERR_ARG, "xfh_debug_trace: NULL handle");
     h->trace = device_buffer;

@@ -29,6 +29,7 @@
 // (c, c+4) makes those registers THE B operand of the 1x1 GEMM: no LDS round trip, no
 // shuffles; only the 1x1 weights [K][COUT2] sit in LDS.
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace xfh {
 
@@ -55,17 +56,17 @@ struct ConvArgs {
     ConvGeom g;
 };
 
-template <int CIN, int COUT, int KS, int STRIDE, int CK, int NSEG, bool NHWC, int COUT2>
+template <int CIN, int COUT, int KS, int STRIDE, int CK, int NSEG, bool NHWC, int COUT2, int NBO = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     constexpr int COUT_PAD = (COUT + 31) / 32 * 32;
     constexpr int MB = COUT_PAD / 32;
-    constexpr int NB = MB == 1 ? 4 : (MB == 2 ? 2 : 1);
+    constexpr int NB = NBO > 0 ? NBO : (MB == 1 ? 4 : (MB == 2 ? 2 : 1));
     constexpr int KK = KS * KS;
     constexpr int PAD = KS / 2;
     constexpr int NCH = CIN / CK;
     static_assert(CIN % CK == 0 && CK % 2 == 0, "CIN must be a multiple of the (even) channel chunk");
     constexpr int WCH = CK * KK * COUT_PAD;          // floats per weight chunk
-    static_assert(WCH % 256 == 0, "weight chunk must be whole 1 KiB DMA pieces");
+    static_assert(WCH % 4 == 0, "weight chunk must be whole 16-byte DMA elements");
     constexpr int COUT2_PAD = (COUT2 + 31) / 32 * 32;
     constexpr int MB2 = COUT2_PAD / 32;
     static_assert(COUT2 == 0 || COUT == COUT_PAD, "fused 1x1 needs a 32-multiple channel count");
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const float* inb = a.in + (size_t)b * CIN * HWin;
 
     long long* tr = a.trace ? a.trace + (size_t)blockIdx.x * 24 : nullptr;
-    if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memtime();
+    if (tr && tid == 0) { tr[0] = __builtin_amdgcn_s_memtime(); tr[19] = __builtin_amdgcn_s_memrealtime(); }
     // fused 1x1 weights: one DMA at kernel start into their own LDS region
     if (COUT2 > 0) {
         float* W2l = smem + 2 * SB;
@@ -116,10 +117,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         const float* wsrc = a.wk + (size_t)ch * WCH;
 #pragma unroll
         for (int jj = 0; jj < (WCH / 256 + 3) / 4; ++jj) {
-            const int j = wave + 4 * jj;
+            const int j = wave + 4 * jj;               // whole 1 KiB pieces: wave-uniform condition
             if (j < WCH / 256)
                 __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + j * 256 + lane * 4), (lptr_t)(Wd + j * 256), 16, 0, 0);
         }
+        if (WCH % 256 != 0 && wave == (WCH / 256) % 4 && lane * 4 < WCH % 256)      // partial last piece
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + (WCH / 256) * 256 + lane * 4), (lptr_t)(Wd + (WCH / 256) * 256), 16, 0, 0);
 #pragma unroll
         for (int s = 0; s < NSEG; ++s) {
             const int seg = wave + 4 * s;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memtime();
     for (int ch = 0; ch < NCH; ++ch) {
         __syncthreads();   // chunk ch has landed (vmcnt(0) + barrier); buffer (ch+1)&1 is free again
-        if (tr && tid == 0 && ch < 18) tr[2 + ch] = __builtin_amdgcn_s_memtime();
+        if (tr && tid == 0 && ch < 17) tr[2 + ch] = __builtin_amdgcn_s_memtime();
         if (ch + 1 < NCH) issue(ch + 1, (ch + 1) & 1);
         const float* S = smem + (ch & 1) * SB;
         // software pipeline over the NS = (CK/2)*k*k MFMA steps of this chunk: the operands of
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                     }
                 }
         }
-        if (tr && tid == 0) { tr[21] = __builtin_amdgcn_s_memtime(); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); tr[22] = ((long long)xcc << 32) | hwid; }
+        if (tr && tid == 0) { tr[21] = __builtin_amdgcn_s_memtime(); tr[23] = __builtin_amdgcn_s_memrealtime(); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); tr[22] = ((long long)xcc << 32) | hwid; }
         return;
     }
 
@@ -352,12 +355,12 @@ static bool choose_tile(int Hout, int Wout, int tile_pix, int S, int KS, int nse
     return true;
 }
 
-template <int CIN, int COUT, int KS, int STRIDE, int CK, int NSEG, int COUT2>
+template <int CIN, int COUT, int KS, int STRIDE, int CK, int NSEG, int COUT2, int NBO = 0>
 static int run(const ConvW& c, const ConvW* c2, const float* zeros, const float* in, int B, int Hin, int Win, float* out,
                bool nhwc, hipStream_t st, long long* trace) {
     constexpr int COUT_PAD = (COUT + 31) / 32 * 32;
     constexpr int MB = COUT_PAD / 32;
-    constexpr int NB = MB == 1 ? 4 : (MB == 2 ? 2 : 1);
+    constexpr int NB = NBO > 0 ? NBO : (MB == 1 ? 4 : (MB == 2 ? 2 : 1));
     constexpr int WCH = CK * KS * KS * COUT_PAD;
     constexpr int COUT2_PAD = (COUT2 + 31) / 32 * 32;
     ConvArgs a;
@@ -375,14 +378,14 @@ static int run(const ConvW& c, const ConvW* c2, const float* zeros, const float*
     if (lds > 160 * 1024) return -1;
     static bool attr_done = false;     // one static per instantiation of run<>
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, true, COUT2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, true, COUT2, NBO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, false, COUT2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, false, COUT2, NBO>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    if (nhwc) conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, true, COUT2><<<xcd_grid_size(tiles, B), 256, lds, st>>>(a);
-    else conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, false, COUT2><<<xcd_grid_size(tiles, B), 256, lds, st>>>(a);
+    if (nhwc) conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, true, COUT2, NBO><<<xcd_grid_size(tiles, B), 256, lds, st>>>(a);
+    else conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, false, COUT2, NBO><<<xcd_grid_size(tiles, B), 256, lds, st>>>(a);
     return 0;
 }
 
@@ -391,17 +394,27 @@ int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, 
     const int key = c.cin * 1000000 + c.cout * 1000 + c.ks * 10 + c.stride;
     if (fused1x1) {
         if (fused1x1->ks != 1 || fused1x1->cin != c.cout) return -1;
-        if (key == 64 * 1000000 + 64 * 1000 + 31 && fused1x1->cout == 64)
+        if (key == 64 * 1000000 + 64 * 1000 + 31 && fused1x1->cout == 64) {
+            if (getenv("XFH_CONV_NB1")) return run<64, 64, 3, 1, 4, 1, 64, 1>(c, fused1x1, zeros, in, B, Hin, Win, out, nhwc, st, trace);
             return run<64, 64, 3, 1, 8, 2, 64>(c, fused1x1, zeros, in, B, Hin, Win, out, nhwc, st, trace);
+        }
         if (key == 128 * 1000000 + 128 * 1000 + 31 && fused1x1->cout == 64)
             return run<128, 128, 3, 1, 4, 1, 64>(c, fused1x1, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         return -1;
     }
+    // small maps: 128-pixel tiles (one pixel block per wave) give 2x the workgroups, each half as
+    // heavy -> less tail and more co-resident workgroups on the 30x40 / 15x20 maps
+    const int Hout = (Hin + 2 * (c.ks / 2) - c.ks) / c.stride + 1, Wout = (Win + 2 * (c.ks / 2) - c.ks) / c.stride + 1;
+    const bool small_map = (long)B * Hout * Wout <= 160L * 1024;
     switch (key) {
-        case 24 * 1000000 + 24 * 1000 + 31:   return run<24, 24, 3, 1, 8, 3, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
+        case 24 * 1000000 + 24 * 1000 + 31:   return run<24, 24, 3, 1, 4, 3, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         case 24 * 1000000 + 64 * 1000 + 32:   return run<24, 64, 3, 2, 4, 5, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
-        case 64 * 1000000 + 64 * 1000 + 31:   return run<64, 64, 3, 1, 8, 2, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
-        case 64 * 1000000 + 64 * 1000 + 32:   return run<64, 64, 3, 2, 4, 5, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
+        case 64 * 1000000 + 64 * 1000 + 31:
+            if (small_map || getenv("XFH_CONV_NB1")) return run<64, 64, 3, 1, 4, 1, 0, 1>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
+            return run<64, 64, 3, 1, 8, 2, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
+        case 64 * 1000000 + 64 * 1000 + 32:
+            if (small_map) return run<64, 64, 3, 2, 4, 3, 0, 1>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
+            return run<64, 64, 3, 2, 4, 5, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         case 64 * 1000000 + 128 * 1000 + 32:  return run<64, 128, 3, 2, 4, 3, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         case 128 * 1000000 + 128 * 1000 + 31: return run<128, 128, 3, 1, 4, 1, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         case 64 * 1000000 + 64 * 1000 + 11:   return run<64, 64, 1, 1, 32, 1, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);

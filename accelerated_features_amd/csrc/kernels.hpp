@@ -119,6 +119,7 @@ void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim,
                   int64_t* idx0, int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof);
 int match_row_blocks(int N1);
+int match_debug_occupancy();
 
 // ---- k_refine.hip -----------------------------------------------------------------------
 void launch_refine_rowmap(const int32_t* n_matches, int P, int N, int32_t* offs, int32_t* rowmap, int32_t* total,

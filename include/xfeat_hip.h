@@ -201,6 +201,8 @@ enum { XFH_PROF_NONE = 0, XFH_PROF_CONV_MFMA = 1, XFH_PROF_MATCH = 2, XFH_PROF_B
 int xfh_profile_select(xfh_handle h, int which);
 /* debug: 24 int64 s_memtime stamps per MFMA-conv workgroup are written to device_buffer (NULL = off) */
 int xfh_debug_trace(xfh_handle h, long long* device_buffer);
+/* debug: resident workgroups per CU the runtime reports for mnn_sim_kernel */
+int xfh_debug_match_occupancy(void);
 int xfh_profile_read(xfh_handle h, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);
 
 #ifdef __cplusplus

@@ -411,3 +411,40 @@ def test_full_size_vga_batch64_properties(xf):
     # image 56 is a copy of image 0: the mutual matches are exactly the identity
     j0, j1 = xf.match(de[0, :nvl[0]], de[56, :nvl[56]], min_cossim=-1)
     assert len(j0) >= nvl[0] - 4 and torch.equal(j0, j1), (len(j0), nvl[0])
+
+
+def test_full_size_dense_1024_batch_properties(xf, sd):
+    """BASELINE configs[2] shape: match_xfeat_star on 1024x1024 pairs, top_k=4096 (batch reduced to 8 pairs
+    to keep the test short; bench.py --workload dense runs the full batch of 32)."""
+    B = 8
+    base = fixtures.texture_images(2, 1024, 1024, seed=55)
+    a = torch.cat([base, base.flip(3), base.flip(2), base.flip(2).flip(3)]).cuda()
+    b = torch.roll(a, (16, 24), (2, 3)).contiguous()
+    da = xf.detectAndComputeDense(a, top_k=4096)
+    assert da["keypoints"].shape == (B, 4095, 2) and da["descriptors"].shape == (B, 4095, 64) and da["scales"].shape == (B, 4095)
+    sc = da["scales"][0].cpu()
+    assert torch.allclose(sc[:819], torch.full((819,), 1 / 0.6)) and torch.allclose(sc[819:], torch.full((3276,), 1 / 1.3))
+    # image 0 of the batch against the oracle (reliability top-k is a set up to ties; compare sorted coordinates)
+    o0 = O.detect_and_compute_dense(sd, base[:1], top_k=4096)
+    kt = sorted(map(tuple, da["keypoints"][0].cpu().numpy().round(3).tolist()))
+    kr = sorted(map(tuple, o0["keypoints"][0].numpy().round(3).tolist()))
+    assert len(set(kt) ^ set(kr)) <= 8, len(set(kt) ^ set(kr))
+    # descriptors of coinciding coordinates agree
+    idx_r = {tuple(np.round(k, 3)): i for i, k in enumerate(o0["keypoints"][0].numpy())}
+    rows = [(i, idx_r[tuple(np.round(k, 3))]) for i, k in enumerate(da["keypoints"][0].cpu().numpy()) if tuple(np.round(k, 3)) in idx_r]
+    ii = torch.tensor([r[0] for r in rows]); jj = torch.tensor([r[1] for r in rows])
+    # the two scales can emit the same coordinate: only compare rows whose descriptor matches one of the candidates
+    d = (da["descriptors"][0].cpu()[ii] - o0["descriptors"][0][jj]).abs().max(dim=1)[0]
+    assert float((d < 2e-4).float().mean()) > 0.98
+    res = xf.match_xfeat_star(a, b, top_k=4096)
+    assert isinstance(res, list) and len(res) == B
+    for r in res:
+        assert r.dim() == 2 and r.shape[1] == 4 and r.dtype == torch.float32 and torch.isfinite(r).all()
+    # batch-position independence: pairs 0 and (flipped twice) are different, but re-running gives identical output
+    res2 = xf.match_xfeat_star(a, b, top_k=4096)
+    for r, r2 in zip(res, res2):
+        assert torch.equal(r, r2)
+    # B == 1 returns the numpy tuple like the reference
+    m0, m1 = xf.match_xfeat_star(a[:1], b[:1], top_k=4096)
+    assert isinstance(m0, np.ndarray) and m0.shape == m1.shape and m0.shape[1] == 2
+    assert np.allclose(np.concatenate([m0, m1], 1), res[0].cpu().numpy())

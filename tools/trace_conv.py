@@ -29,7 +29,7 @@ span = (t[:, 21].max() - t0)
 print("kernel span ticks", span, "=> us at 100MHz:", span / 100)
 start = (t[:, 0] - t0); end = (t[:, 21] - t0)
 dur = end - start
-nch = int((t[0, 2:20] != 0).sum())
+nch = int((t[0, 2:19] != 0).sum())
 print("chunks", nch)
 pro = t[:, 2] - t[:, 0]; main = t[:, 20] - t[:, 2]; epi = t[:, 21] - t[:, 20]
 per = np.diff(t[:, 2:2 + nch], axis=1)
@@ -39,6 +39,8 @@ print("per-chunk mean", per.mean(axis=0).round(1))
 order = np.argsort(start)
 print("start times (sorted, every 64th):", start[order][::64][:30])
 print("end   times (sorted, every 64th):", np.sort(end)[::64][:30])
+rt = (t[:, 23] - t[:, 19]).astype(np.float64); st = (t[:, 21] - t[:, 0]).astype(np.float64)
+print("shader clock estimate (s_memtime / s_memrealtime@100MHz): median %.3f GHz" % (np.median(st / rt) * 0.1))
 xcc = t[:, 22] >> 32; hw = t[:, 22] & 0xffffffff
 cu = (hw >> 8) & 0xf; se = (hw >> 13) & 0x7
 key = xcc * 1000 + se * 16 + cu
