@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxfeat_hip.so")
+LIB_PATH = os.environ.get("XFH_LIB_PATH") or os.path.join(_HERE, "libxfeat_hip.so")   # override: A/B builds only
 
 XFH_OK = 0
 PROF_NONE, PROF_CONV_MFMA, PROF_MATCH, PROF_BLOCK1, PROF_HEADS, PROF_CONV_64_64_S1, PROF_CONV_LAYER0 = 0, 1, 2, 3, 4, 5, 100
