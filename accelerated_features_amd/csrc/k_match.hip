@@ -10,7 +10,6 @@
 // A second small kernel reduces the column partials, applies the mutual test (+ optional
 // min_cossim) and compacts the surviving pairs in ascending row order.
 #include "kernels.hpp"
-#include <cstdlib>
 
 namespace xfh {
 
@@ -18,6 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int MT_ROWS = 256;   // rows of D1 per workgroup (8 waves x 32)
 constexpr int MT_COLS = 128;   // columns of D2 per LDS fill
+constexpr int MT_DS = 68;      // LDS row stride in floats: 16-B aligned rows, conflict-free ds_read_b128
 
 int match_row_blocks(int N1) { return ceil_div(N1, MT_ROWS); }
 
@@ -28,18 +28,14 @@ __device__ inline int pair_count(const int32_t* n, int idx, int cap) {
 }
 
 // 512 threads = 8 waves, 32 rows of D1 each (two waves per SIMD: while one wave runs its VALU
-// arg-max epilogue the other keeps the matrix pipe busy).  The 128-column tiles of D2 reach LDS
-// through the DMA path into two buffers (copy of tile t+1 flies during tile t, ONE barrier per
-// tile).  The DMA image is lane-linear, so rows are unpadded (256 B) and bank conflicts of the
-// ds_read_b128 fragment loads are avoided with an XOR swizzle applied on the SOURCE side:
-// physical 16-B chunk = logical chunk ^ (row & 15)  (same permutation on the read).
+// arg-max epilogue the other keeps the matrix pipe busy).
 __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2,
                                                       size_t ps2, const int32_t* __restrict__ n1p,
                                                       const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1,
                                                       int N2, int nrb, int P, int* __restrict__ match12,
-                                                      float* __restrict__ rowmax, unsigned long long* __restrict__ colpart, int mode) {
-    __shared__ __attribute__((aligned(16))) float Dl[2][MT_COLS * 64];
-    __shared__ unsigned long long colbest[2][8][MT_COLS];
+                                                      float* __restrict__ rowmax, unsigned long long* __restrict__ colpart) {
+    __shared__ __attribute__((aligned(16))) float Dl[MT_COLS * MT_DS];
+    __shared__ unsigned long long colbest[8][MT_COLS];
 
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,20 +50,6 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
     const float* Bm = d2 + (size_t)p * ps2;
     const int wrow0 = row0 + wave * 32;
 
-    // DMA of one 128-column tile: 32 pieces of 1 KiB (4 rows each); wave w copies pieces w, w+8, ..
-    auto issue = [&](int c0, int bsel) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int piece = wave + 8 * k;
-            const int rloc = piece * 4 + (lane >> 4);               // row inside the tile
-            const int gc = min(c0 + rloc, n2 - 1);
-            const int chunk = (lane & 15) ^ (rloc & 15);            // logical chunk stored at physical slot lane&15
-            __builtin_amdgcn_global_load_lds((__attribute__((address_space(1))) const void*)(Bm + (size_t)gc * 64 + chunk * 4),
-                                             (__attribute__((address_space(3))) void*)(&Dl[bsel][piece * 256]), 16, 0, 0);
-        }
-    };
-    issue(0, 0);
-
     // stationary A fragment (32 rows x K=64): step s uses k = s (lanes 0-31) / k = 32+s (lanes 32-63)
     float a[32];
     {
@@ -81,35 +63,27 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
     }
     float bv[16];
     int bc[16];
-    unsigned rvalid = 0;              // bit r: this lane's r-th row exists (row < n1)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        bv[r] = -INFINITY; bc[r] = 0;
-        if (wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half < n1) rvalid |= 1u << r;
-    }
+    for (int r = 0; r < 16; ++r) { bv[r] = -INFINITY; bc[r] = 0; }
 
-    int it = 0;
-    for (int c0 = 0; c0 < n2; c0 += MT_COLS, ++it) {
-        const int cur = it & 1;
-        __syncthreads();      // tile `it` landed; everyone finished tile it-1 (its colbest is complete)
-        if (c0 + MT_COLS < n2) issue(c0 + MT_COLS, cur ^ 1);
-        if (it > 0 && tid < MT_COLS) {     // column partials of the previous tile
-            const int col = c0 - MT_COLS + tid;
-            if (col < n2) {
-                unsigned long long k = colbest[cur ^ 1][0][tid];
+    for (int c0 = 0; c0 < n2; c0 += MT_COLS) {
+        __syncthreads();
 #pragma unroll
-                for (int w = 1; w < 8; ++w) k = u64_max(k, colbest[cur ^ 1][w][tid]);
-                colpart[((size_t)p * nrb + rb) * N2 + col] = k;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 512;
+            const int col = e >> 4, q = e & 15;
+            const int gc = min(c0 + col, n2 - 1);
+            const float4 v = *reinterpret_cast<const float4*>(Bm + (size_t)gc * 64 + 4 * q);
+            *reinterpret_cast<float4*>(Dl + col * MT_DS + 4 * q) = v;
         }
+        __syncthreads();
 #pragma unroll 1
         for (int ct = 0; ct < MT_COLS / 32; ++ct) {
             const int cbase = c0 + ct * 32;
             if (cbase >= n2) break;
             // B fragment in two halves of 16 k-steps: 16 VGPRs live instead of 32 (the other three
             // waves of the SIMD cover the second half's LDS latency)
-            const int rloc = ct * 32 + l31;
-            const float* brow = &Dl[cur][rloc * 64];
+            const float4* bp = reinterpret_cast<const float4*>(Dl + (ct * 32 + l31) * MT_DS + 32 * half);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -118,19 +92,12 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
                 float bf[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int chunk = (8 * half + hq * 4 + q) ^ (rloc & 15);
-                    const float4 v = *reinterpret_cast<const float4*>(brow + chunk * 4);
+                    const float4 v = bp[hq * 4 + q];
                     bf[4 * q + 0] = v.x; bf[4 * q + 1] = v.y; bf[4 * q + 2] = v.z; bf[4 * q + 3] = v.w;
                 }
-                if (mode != 2) {
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[hq * 16 + s], bf[s], acc, 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 16; ++s) acc[s] += bf[s] * a[hq * 16 + s];
-                }
+                for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[hq * 16 + s], bf[s], acc, 0, 0, 0);
             }
-            if (mode == 1) { bv[0] = fmaxf(bv[0], acc[0] + acc[7] + acc[15]); continue; }
             // D[i=row][j=col]: this lane holds column cbase+l31, rows (r&3)+8*(r>>2)+4*half
             const int col = cbase + l31;
             const bool cvalid = col < n2;
@@ -144,29 +111,30 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
             // (rows ascend with r), rows >= n1 excluded; one packed key per lane per tile
             float cm = -INFINITY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cm = fmaxf(cm, ((rvalid >> r) & 1u) ? acc[r] : -INFINITY);
-            int cr = -1;
-#pragma unroll
-            for (int r = 15; r >= 0; --r)
-                if (((rvalid >> r) & 1u) && acc[r] == cm) cr = r;
-            unsigned long long best = 0ull;
-            if (cr >= 0) {
-                const int crow = wrow0 + (cr & 3) + 8 * (cr >> 2) + 4 * half;
-                best = ((unsigned long long)float_ord(cm) << 32) | (0xffffffffu - (unsigned)crow);
+            for (int r = 0; r < 16; ++r) {
+                const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                cm = fmaxf(cm, row < n1 ? acc[r] : -INFINITY);
             }
-            best = u64_max(best, shfl_xor_u64(best, 32));
-            if (half == 0) colbest[cur][wave][ct * 32 + l31] = best;
-        }
-    }
-    __syncthreads();
-    if (tid < MT_COLS) {                   // column partials of the last tile
-        const int last = it - 1;
-        const int col = last * MT_COLS + tid;
-        if (col < n2) {
-            unsigned long long k = colbest[last & 1][0][tid];
+            int crow = 0x7fffffff;
 #pragma unroll
-            for (int w = 1; w < 8; ++w) k = u64_max(k, colbest[last & 1][w][tid]);
-            colpart[((size_t)p * nrb + rb) * N2 + col] = k;
+            for (int r = 15; r >= 0; --r) {
+                const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < n1 && acc[r] == cm) crow = row;
+            }
+            unsigned long long best = crow == 0x7fffffff ? 0ull
+                                                         : (((unsigned long long)float_ord(cm) << 32) | (0xffffffffu - (unsigned)crow));
+            best = u64_max(best, shfl_xor_u64(best, 32));
+            if (half == 0) colbest[wave][ct * 32 + l31] = best;
+        }
+        __syncthreads();
+        if (tid < MT_COLS) {
+            const int col = c0 + tid;
+            if (col < n2) {
+                unsigned long long k = colbest[0][tid];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) k = u64_max(k, colbest[w][tid]);
+                colpart[((size_t)p * nrb + rb) * N2 + col] = k;
+            }
         }
     }
 
@@ -241,12 +209,6 @@ __global__ __launch_bounds__(1024) void mnn_finalize_kernel(const int32_t* __res
     if (tid == 0) n_matches[p] = s_base;
 }
 
-static int match_debug_mode() {
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("XFH_MATCH_MODE"); m = e ? atoi(e) : 0; }
-    return m;
-}
-
 int match_debug_occupancy() {
     int n = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(mnn_sim_kernel), 512, 0);
@@ -262,7 +224,7 @@ void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d
     const int nrb = match_row_blocks(N1);
     prof_begin(prof, 2, st);
     mnn_sim_kernel<<<xcd_grid_size(nrb, P), 512, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.match12,
-                                                 ws.rowmax, ws.colpart, match_debug_mode());
+                                                 ws.rowmax, ws.colpart);
     prof_end(prof, 2, st, 2.0 * P * (double)N1 * N2 * 64, (double)P * (N1 + N2) * 64 * 4);
     static bool attr_set = false;
     if (!attr_set) {
