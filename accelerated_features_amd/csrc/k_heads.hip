@@ -181,11 +181,12 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
                 const int b = gcell / hw, rem = gcell - b * hw;
                 const int ci = rem / a.wc, cj = rem - ci * a.wc;
                 float* o = a.out + (size_t)b * a.H * a.W + (size_t)(8 * ci) * a.W + 8 * cj + 4 * half;
+                const float rs = 1.f / sum;                // one correctly-rounded divide, then 64 multiplies
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {          // dy = q + 4m, dx = 4*half .. +3
-                        const float4 v = make_float4(e[m][4 * q] / sum, e[m][4 * q + 1] / sum, e[m][4 * q + 2] / sum, e[m][4 * q + 3] / sum);
+                        const float4 v = make_float4(e[m][4 * q] * rs, e[m][4 * q + 1] * rs, e[m][4 * q + 2] * rs, e[m][4 * q + 3] * rs);
                         *reinterpret_cast<float4*>(o + (size_t)(q + 4 * m) * a.W) = v;
                     }
                 if (a.logits) {

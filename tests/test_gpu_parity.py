@@ -307,6 +307,25 @@ def test_detect_edge_cases(xf, sd):
             assert float(o["scores"].min()) > 0
 
 
+def test_batch_sizes_cover_both_workgroup_mappings(xf):
+    """Batches that are / are not multiples of 8 take different workgroup->work mappings (XCD-aware vs
+    plain); per-image results must be bit-identical in all of them, for the sparse path and the matcher."""
+    u = fixtures.texture_images(5, 96, 160, seed=23).cuda()
+    ref = [xf.detectAndCompute(u[i:i + 1], top_k=300)[0] for i in range(5)]
+    for B in (2, 8, 9, 16, 24):
+        idx = [i % 5 for i in range(B)]
+        out = xf.detectAndCompute(u[idx], top_k=300)
+        for j, i in enumerate(idx):
+            for k in ("keypoints", "scores", "descriptors"):
+                assert torch.equal(out[j][k], ref[i][k]), (B, j, k)
+    d = torch.nn.functional.normalize(torch.randn(24, 700, 64, device="cuda"), dim=-1)
+    single = [xf.match(d[p], d[(p + 1) % 24], min_cossim=-1) for p in range(24)]
+    for P in (3, 8, 16, 24):
+        bm = xf.batch_match(d[:P], torch.roll(d, -1, 0)[:P])
+        for p in range(P):
+            assert torch.equal(bm[p][0], single[p][0]) and torch.equal(bm[p][1], single[p][1]), (P, p)
+
+
 def test_batch_composition_and_determinism(xf):
     """An image's result does not depend on its batch neighbours, and reruns are bit-identical."""
     x = fixtures.texture_images(5, 96, 160, seed=17).cuda()

@@ -3,7 +3,7 @@
 #   tools/ab.sh            # compares accelerated_features_amd/libxfeat_hip.so (new) with gpurun_ab_old.so (old)
 # Build the "old" side first with tools/build_ab_old.sh <git-rev>.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-for i in 1 2 3; do
+for i in 1 2; do
   for L in "" "$PWD/gpurun_ab_old.so"; do
     XFH_LIB_PATH=$L python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | python -c "
 import sys, json
