@@ -50,6 +50,16 @@ __device__ inline float ord_float(unsigned o) {
     return __uint_as_float(u);
 }
 
+// Barrier that covers global->LDS DMA (global_load_lds) issued by ANY wave of the workgroup.
+// The explicit asm wait is mandatory: hipcc (ROCm 7.2) was observed to omit the vmcnt(0) in
+// front of s_barrier on a loop back-edge when the DMA sits in exec-masked blocks (the 24->24
+// conv instantiation: ~7 % of launches consumed a staging buffer before it had landed).
+// Inline asm is invisible to the waitcnt pass, so it cannot be dropped.
+__device__ inline void lds_dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // XCD-aware work mapping (MI355X: 8 XCDs, private L2s; workgroup b runs on XCD b % 8).
 // A 1-D grid of n_groups_padded * per_group workgroups is remapped so that all `per_group`
 // workgroups of a group (an image, a descriptor pair) run on ONE XCD and share its L2:

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     issue(0, 0);
     if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memtime();
     for (int ch = 0; ch < NCH; ++ch) {
-        __syncthreads();   // chunk ch has landed (vmcnt(0) + barrier); buffer (ch+1)&1 is free again
+        lds_dma_barrier();   // chunk ch has landed (explicit vmcnt(0) + barrier); buffer (ch+1)&1 is free again
         if (tr && tid == 0 && ch < 17) tr[2 + ch] = __builtin_amdgcn_s_memtime();
         if (ch + 1 < NCH) issue(ch + 1, (ch + 1) & 1);
         const float* S = smem + (ch & 1) * SB;

@@ -171,7 +171,7 @@ struct TopkOut {            // sparse-path epilogue (all NULL for the plain top-
 
 __global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __restrict__ keys, int key_stride,
                                                     const int32_t* __restrict__ n_dev, int n_const, int n_cap, int top_k,
-                                                    int kpad, unsigned* __restrict__ sel, int* __restrict__ nsel,
+                                                    int kpad, int kc_cap, unsigned* __restrict__ sel, int* __restrict__ nsel,
                                                     TopkOut o) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lk[];
     __shared__ int hist[256];
@@ -181,6 +181,13 @@ __global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __
     int n = n_dev ? min(n_dev[b], n_cap) : n_const;
     const int k = min(top_k, n);
     const unsigned long long* kp = keys + (size_t)b * key_stride;
+    // keys are read 9 times (8 radix passes + the final compaction): keep them in LDS when they fit
+    unsigned long long* kc = lk + kpad;
+    const bool cached = n <= kc_cap;
+    if (cached) {
+        for (int i = tid; i < n; i += 1024) kc[i] = kp[i];
+        __syncthreads();
+    }
 
     unsigned long long T = ~0ull;
     if (n > k && k > 0) {
@@ -191,19 +198,28 @@ __global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __
             const unsigned long long prefix = s_prefix;
             const int shift = 56 - 8 * pass;
             for (int i = tid; i < n; i += 1024) {
-                const unsigned long long key = kp[i];
+                const unsigned long long key = cached ? kc[i] : kp[i];
                 const bool match = (pass == 0) || ((key >> (shift + 8)) == prefix);
                 if (match) atomicAdd(&hist[(int)((key >> shift) & 255)], 1);
             }
             __syncthreads();
-            if (tid == 0) {
-                int kk = s_kk, d = 0;
-                for (; d < 256; ++d) {
-                    if (hist[d] >= kk) break;
-                    kk -= hist[d];
+            if (tid < 64) {     // wave 0 finds the digit whose cumulative count crosses kk (4 bins per lane + wave scan)
+                const int kk = s_kk;
+                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                const int mine = h0 + h1 + h2 + h3;
+                int inc = mine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(inc, o, 64);
+                    if (tid >= o) inc += t;
                 }
-                s_kk = kk;
-                s_prefix = (prefix << 8) | (unsigned long long)d;
+                const int before = inc - mine;
+                if (before < kk && kk <= inc) {           // exactly one lane
+                    int rem = kk - before, d = 4 * tid;
+                    if (rem > h0) { rem -= h0; ++d; if (rem > h1) { rem -= h1; ++d; if (rem > h2) { rem -= h2; ++d; } } }
+                    s_kk = rem;
+                    s_prefix = (prefix << 8) | (unsigned long long)d;
+                }
             }
             __syncthreads();
         }
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __
     if (tid == 0) { s_cnt = 0; s_valid = 0; }
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
-        const unsigned long long key = kp[i];
+        const unsigned long long key = cached ? kc[i] : kp[i];
         if (key <= T) {
             const int slot = atomicAdd(&s_cnt, 1);
             if (slot < kpad) lk[slot] = key;
@@ -274,14 +290,18 @@ static int next_pow2(int v) {
 static void run_topk(const unsigned long long* keys, int key_stride, const int32_t* n_dev, int n_const, int n_cap,
                      int top_k, int B, unsigned* sel, int* nsel, const TopkOut& o, hipStream_t st) {
     const int kpad = next_pow2(top_k);
-    const size_t lds = (size_t)kpad * 8;
+    // LDS: the sort buffer (kpad keys) + a cache of all candidate keys when it fits (up to 12288 keys)
+    int kc_cap = (int)((150 * 1024) / 8) - kpad;
+    if (kc_cap > 12288) kc_cap = 12288;
+    if (kc_cap < 0) kc_cap = 0;
+    const size_t lds = (size_t)(kpad + kc_cap) * 8;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            16384 * 8);
+                                  152 * 1024);
         attr_set = true;
     }
-    topk_kernel<<<B, 1024, lds, st>>>(keys, key_stride, n_dev, n_const, n_cap, top_k, kpad, sel, nsel, o);
+    topk_kernel<<<B, 1024, lds, st>>>(keys, key_stride, n_dev, n_const, n_cap, top_k, kpad, kc_cap, sel, nsel, o);
 }
 
 // ------------------------------------------------------------------------------------------

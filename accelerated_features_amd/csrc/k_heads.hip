@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
     int tile = blockIdx.x;
     if (tile < a.ntiles) issue_x(tile);
     for (; tile < a.ntiles; tile += gridDim.x) {
-        __syncthreads();                                   // tile (and the weights) landed
+        lds_dma_barrier();                                 // tile (and the weights) landed
         // ---- layer 1: B operand from LDS ------------------------------------------------------
         f32x16 accA[2], accB[2];
 #pragma unroll
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
                 }
             }
         }
-        __syncthreads();                                   // every wave is done with the X tile
+        lds_dma_barrier();                                 // every wave is done with the X tile
         if (tile + (int)gridDim.x < a.ntiles) issue_x(tile + gridDim.x);   // next tile flies during layers 2..
 
         const int gcell = tile * HD_CELLS + wave * 32 + l31;            // this lane's cell

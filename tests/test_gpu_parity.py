@@ -468,3 +468,43 @@ def test_full_size_dense_1024_batch_properties(xf, sd):
     m0, m1 = xf.match_xfeat_star(a[:1], b[:1], top_k=4096)
     assert isinstance(m0, np.ndarray) and m0.shape == m1.shape and m0.shape[1] == 2
     assert np.allclose(np.concatenate([m0, m1], 1), res[0].cpu().numpy())
+
+
+def test_repeated_launches_every_mfma_layer_no_intermittent_errors(xf):
+    """Race screen: every MFMA conv layer, 25 launches each at two scales, every launch checked against the
+    generic direct kernel on the device (an LDS-DMA / barrier race shows up as rare wrong tiles)."""
+    from accelerated_features_amd.spec import CONVS, CONV_INDEX
+    lib = _lib().load()
+    h = xf.net.handle()
+    div = {"block2.0": 4, "block2.1": 4, "block3.0": 4, "block3.1": 8, "block3.2": 8, "block4.0": 8, "block4.1": 16, "block4.2": 16,
+           "block5.0": 16, "block5.1": 32, "block5.2": 32, "block5.3": 32, "block_fusion.0": 8, "block_fusion.1": 8, "block_fusion.2": 8}
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for (B, H, W) in ((64, 480, 640), (8, 1312, 1312)):
+        for name, d in div.items():
+            c = next(c for c in CONVS if c.name == name)
+            hin, win = H // d, W // d
+            hout, wout = (hin - 1) // c.stride + 1, (win - 1) // c.stride + 1
+            x = torch.randn(B, c.cin, hin, win, device="cuda", generator=g)
+            ref = torch.empty(B, c.cout, hout, wout, device="cuda")
+            assert lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(ref.data_ptr()), 1, None) == 0
+            for rep in range(25):
+                y = torch.full_like(ref, float("nan"))
+                assert lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(y.data_ptr()), 0, None) == 0
+                err = float((y - ref).abs().nan_to_num(1e9).max())
+                assert err <= 2e-4, (name, (B, hin, win), rep, err)
+
+
+def test_repeated_backbone_and_sparse_path_bit_identical(xf):
+    """30 repetitions of the full sparse step at the BASELINE batch: results must be bit-identical every time."""
+    x = fixtures.texture_images(8, 480, 640, seed=77)
+    x = torch.cat([x] * 8).cuda()
+    kp0, sc0, de0, nv0, nc0, cap, hw = xf._detect_device(x, 4096, 0.05)
+    i00, i10, nm0 = xf.match_pairs_device(de0, nv0, -1)
+    n0 = nm0.cpu().tolist()
+    for rep in range(30):
+        kp, sc, de, nv, nc, cap, hw = xf._detect_device(x, 4096, 0.05)
+        i0, i1, nm = xf.match_pairs_device(de, nv, -1)
+        assert torch.equal(kp, kp0) and torch.equal(sc, sc0) and torch.equal(de, de0) and torch.equal(nv, nv0), rep
+        assert nm.cpu().tolist() == n0, rep
+        for p in (0, 7, 31):
+            assert torch.equal(i0[p, :n0[p]], i00[p, :n0[p]]) and torch.equal(i1[p, :n0[p]], i10[p, :n0[p]]), (rep, p)

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""ISA audit: in every kernel that uses the global->LDS DMA (global_load_lds*), every s_barrier must be
+directly preceded by an s_waitcnt with vmcnt(0) -- hipcc was observed to drop it (see common.hpp
+lds_dma_barrier).  Exit code 1 and a listing on violation.   python tools/check_dma_barriers.py"""
+import glob
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def audit(src):
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on",
+                            "-save-temps", "-c", src, "-o", os.path.join(td, "o.o")], cwd=td, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(r.stderr)
+        asm = open(glob.glob(os.path.join(td, "*gfx950.s"))[0]).read()
+    bad, n_kern, n_bar = [], 0, 0
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if "global_load_lds" not in body:
+            continue
+        n_kern += 1
+        ins = [l.strip() for l in body.splitlines() if l.startswith("\t") and not l.strip().startswith((";", "."))]
+        for i, l in enumerate(ins):
+            if l.startswith("s_barrier"):
+                n_bar += 1
+                # walk back: a vmcnt(0) wait must come before any vector-memory instruction does
+                ok, j = False, i - 1
+                while j >= 0 and i - j < 64:
+                    p = ins[j]
+                    if "s_waitcnt" in p and "vmcnt(0)" in p:
+                        ok = True
+                        break
+                    if p.startswith(("global_", "buffer_", "flat_", "scratch_", "s_barrier", "s_cbranch", "s_branch")):
+                        break
+                    j -= 1
+                if not ok:
+                    bad.append((name, ins[max(0, i - 4):i]))
+    return n_kern, n_bar, bad
+
+
+def main():
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip")))
+             if "global_load_lds" in open(f).read()]
+    total_bad = 0
+    for f in files:
+        nk, nb, bad = audit(f)
+        print(f"{os.path.basename(f)}: {nk} DMA kernels, {nb} barriers, {len(bad)} without vmcnt(0)")
+        for name, prev in bad[:10]:
+            print("   ", name[:90], "<-", " | ".join(prev))
+        total_bad += len(bad)
+    return 1 if total_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
