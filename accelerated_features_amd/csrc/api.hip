@@ -236,7 +236,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     std::vector<float> blob;
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
     const size_t zoff = reserve(256);
-    struct Off { size_t oihw, kc, kcp, bias; } coff[L_NUM];
+    struct Off { size_t oihw, kc, kcp, bias, wino; bool has_wino; } coff[L_NUM];
     struct FOff { size_t w, b; } foff[5];
     int ai = 0;
     for (int li = 0; li < L_NUM; ++li) {
@@ -269,6 +269,24 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                     blob[coff[li].kcp + ((size_t)i * kk + t) * cpad + o] = v;
                 }
             blob[coff[li].bias + o] = (float)shift[o];
+        }
+        // Winograd F(2x2,3x3): U = G g G^T of the FOLDED fp32 weights, in fp64, rounded once.
+        // layout [cin/4][pos = 4*xi + nu][half = ci & 1][cout_pad][p = (ci >> 1) & 1]  (k_conv_wino.hip)
+        coff[li].has_wino = c.ks == 3 && c.stride == 1 && c.cin % 8 == 0 && c.cin >= 24;
+        if (coff[li].has_wino) {
+            coff[li].wino = reserve((size_t)c.cin * 16 * cpad);
+            static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+            for (int o = 0; o < c.cout; ++o)
+                for (int i = 0; i < c.cin; ++i) {
+                    const float* gk = &blob[coff[li].oihw + ((size_t)o * c.cin + i) * 9];
+                    for (int xi = 0; xi < 4; ++xi)
+                        for (int nu = 0; nu < 4; ++nu) {
+                            double u = 0;
+                            for (int r = 0; r < 3; ++r)
+                                for (int s2 = 0; s2 < 3; ++s2) u += G[xi][r] * (double)gk[r * 3 + s2] * G[nu][s2];
+                            blob[coff[li].wino + ((((size_t)(i / 4) * 16 + xi * 4 + nu) * 2 + (i & 1)) * cpad + o) * 2 + ((i >> 1) & 1)] = (float)u;
+                        }
+                }
         }
     }
     for (int fi = 0; fi < 5; ++fi) {
@@ -314,6 +332,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.w_kc = ctx->blob + coff[li].kc;
         w.w_kcp = ctx->blob + coff[li].kcp;
         w.bias = ctx->blob + coff[li].bias;
+        w.w_wino = coff[li].has_wino ? ctx->blob + coff[li].wino : nullptr;
     }
     ctx->nw.zeros = ctx->blob + zoff;
     for (int fi = 0; fi < 5; ++fi) {
@@ -367,7 +386,12 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     int pid = h->prof.which >= 100 ? 100 + layer : XFH_PROF_CONV_MFMA;
     if (h->prof.which == XFH_PROF_CONV_64_64_S1 && c.cin == 64 && c.cout == 64 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_64_64_S1;
     prof_begin(&h->prof, pid, st);
-    const int rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
+    // 3x3/s1 layers with >= 24 channels: Winograd F(2x2,3x3) (k_conv_wino.hip); XFH_WINO=0 forces the direct kernel (A/B runs)
+    static int use_wino = -1;
+    if (use_wino < 0) { const char* e = getenv("XFH_WINO"); use_wino = e ? atoi(e) : 1; }
+    int rc = -1;
+    if (use_wino && !c2 && !nhwc && c.w_wino) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace);
+    if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
     const int cl = c2 ? c2->cout : c.cout;
     double bytes = 4.0 * ((double)B * c.cin * Hin * Win + (double)B * cl * Hout * Wout + (double)c.cin * c.cout * c.ks * c.ks);
     double flops = conv_flops(c, B, Hout, Wout);
@@ -429,6 +453,11 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
     if (variant == 1) {
         launch_conv_generic(c, in, B, Hin, Win, out, st);
         return check_launch("xfh_conv_layer(generic)");
+    }
+    if (variant >= 2) {
+        if (launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, variant - 1, h->trace))
+            return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no Winograd instantiation for layer %d", layer);
+        return check_launch("xfh_conv_layer(winograd)");
     }
     if (layer >= L_BLOCK1_0 && layer <= L_BLOCK1_3) {
         launch_block1_layer(h->nw, layer, in, B, Hin, Win, out, st);

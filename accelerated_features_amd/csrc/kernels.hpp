@@ -20,6 +20,7 @@ struct ConvW {
     const float* w_kc;     // [(ci*kk+tap)][cout]      BN folded (block1 direct kernels)
     const float* w_kcp;    // [(ci*kk+tap)][cout_pad]  BN folded, zero padded (MFMA kernels)
     const float* bias;     // [cout_pad] folded BN shift or conv bias, zero padded
+    const float* w_wino;   // [cin/4][16][2][cout_pad][2] Winograd F(2x2,3x3) G g G^T (3x3/s1 layers, cin >= 24), else NULL
 };
 
 struct LinW {             // fine_matcher layer: y = relu?(x W^T + b), BN folded
@@ -55,6 +56,8 @@ void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Wi
 // 3x3 / 1x1 convolution as an implicit GEMM on f32 MFMA.  in NCHW; out NCHW or NHWC.
 // Returns 0, or -1 when no instantiation exists for the layer shape.
 // fused1x1 (optional): the 1x1 conv that follows, computed in the same kernel.  zeros: >= 256 B.
+// Winograd F(2x2,3x3) MFMA path for 3x3/s1 layers (k_conv_wino.hip); -1 if no instantiation
+int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B, int H, int W, float* out, hipStream_t st, int cfg = 0, long long* trace = nullptr);
 int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, const float* in, int B, int Hin, int Win,
                      float* out, bool nhwc_out, hipStream_t st, long long* trace = nullptr);
 double conv_flops(const ConvW& c, int B, int Hout, int Wout);

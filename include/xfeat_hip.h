@@ -99,7 +99,8 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W,
 /* One conv layer of the network in isolation (parity tests against per-layer oracle
  * activations).  layer = index into spec.CONVS; in (B,Cin,Hin,Win) NCHW, out (B,Cout,Hout,Wout)
  * NCHW with the layer's own stride/padding, folded BN and ReLU where the reference has them.
- * variant: 0 = the kernel the backbone uses for this layer, 1 = the generic direct kernel. */
+ * variant: 0 = the kernel the backbone uses for this layer, 1 = the generic direct kernel,
+ * >= 2 = explicit Winograd configurations of the 3x3/s1 layers (tuning; XFH_ERR_UNSUPPORTED elsewhere). */
 int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out,
                    int variant, xfh_stream stream);
 

@@ -156,8 +156,8 @@ def test_every_barrier_in_dma_kernels_waits_for_the_dma():
     spec.loader.exec_module(mod)
     import glob
     files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip")))
-             if "global_load_lds" in open(f).read()]
-    assert len(files) >= 2
+             if re.search(r"global_load_lds|buffer_load[^\n]* lds", open(f).read())]
+    assert len(files) >= 3
     for f in files:
         nk, nb, bad = mod.audit(f)
         assert nk > 0 and nb > 0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""ISA audit: in every kernel that uses the global->LDS DMA (global_load_lds*), every s_barrier must be
-directly preceded by an s_waitcnt with vmcnt(0) -- hipcc was observed to drop it (see common.hpp
+"""ISA audit: in every kernel that uses the global->LDS DMA (global_load_lds* / buffer_load* ... lds), every
+s_barrier must be directly preceded by an s_waitcnt with vmcnt(0) -- hipcc was observed to drop it (see common.hpp
 lds_dma_barrier).  Exit code 1 and a listing on violation.   python tools/check_dma_barriers.py"""
 import glob
 import os
@@ -22,7 +22,7 @@ def audit(src):
     bad, n_kern, n_bar = [], 0, 0
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
         name, body = m.group(1), m.group(2)
-        if "global_load_lds" not in body:
+        if "global_load_lds" not in body and not re.search(r"buffer_load_dword\w*[^\n]* lds", body):
             continue
         n_kern += 1
         ins = [l.strip() for l in body.splitlines() if l.startswith("\t") and not l.strip().startswith((";", "."))]
@@ -46,7 +46,7 @@ def audit(src):
 
 def main():
     files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip")))
-             if "global_load_lds" in open(f).read()]
+             if re.search(r"global_load_lds|buffer_load[^\n]* lds", open(f).read())]
     total_bad = 0
     for f in files:
         nk, nb, bad = audit(f)

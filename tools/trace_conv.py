@@ -9,7 +9,8 @@ from accelerated_features_amd import XFeat, _lib
 from accelerated_features_amd.spec import CONVS, CONV_INDEX
 name = sys.argv[1] if len(sys.argv) > 1 else "block3.1"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-DIV = {"block2.0": 4, "block3.0": 4, "block3.1": 8, "block4.0": 8, "block4.1": 16, "block5.0": 16, "block5.1": 32, "block_fusion.0": 8}
+VAR = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+DIV = {"block2.0": 4, "block3.0": 4, "block3.1": 8, "block4.0": 8, "block4.1": 16, "block5.0": 16, "block5.1": 32, "block_fusion.0": 8, "block2.1": 4, "block4.2": 16, "block5.2": 32}
 xf = XFeat(weights=fixtures.synthetic_state_dict(0)); lib = _lib.load(); h = xf.net.handle()
 c = next(c for c in CONVS if c.name == name); d = DIV[name]
 hin, win = 480 // d, 640 // d
@@ -17,7 +18,7 @@ hout, wout = (hin - 1) // c.stride + 1, (win - 1) // c.stride + 1
 x = torch.randn(B, c.cin, hin, win, device="cuda"); y = torch.empty(B, c.cout, hout, wout, device="cuda")
 tr = torch.zeros(24 * 40000, dtype=torch.int64, device="cuda")
 def run():
-    assert lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(y.data_ptr()), 0, None) == 0
+    assert lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(y.data_ptr()), VAR, None) == 0
 for _ in range(3): run()
 torch.cuda.synchronize()
 lib.xfh_debug_trace(h, C.c_void_p(tr.data_ptr())); run(); torch.cuda.synchronize(); lib.xfh_debug_trace(h, None)
@@ -36,6 +37,9 @@ per = np.diff(t[:, 2:2 + nch], axis=1)
 print("per-WG duration: mean %.1f  min %.1f  max %.1f ticks" % (dur.mean(), dur.min(), dur.max()))
 print("prologue (to first barrier passed) mean %.1f max %.1f | main mean %.1f | epilogue mean %.1f max %.1f" % (pro.mean(), pro.max(), main.mean(), epi.mean(), epi.max()))
 print("per-chunk mean", per.mean(axis=0).round(1))
+if VAR >= 2:
+    d = t[:, [20, 10, 11, 12, 13, 21]].astype(np.float64)
+    print("epilogue (wave 0): wait for all waves %.0f | T + X writes %.0f | barrier %.0f | X reads + sums %.0f | stores %.0f" % tuple(np.diff(d, axis=1).mean(axis=0)))
 order = np.argsort(start)
 print("start times (sorted, every 64th):", start[order][::64][:30])
 print("end   times (sorted, every 64th):", np.sort(end)[::64][:30])
