@@ -386,11 +386,12 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     int pid = h->prof.which >= 100 ? 100 + layer : XFH_PROF_CONV_MFMA;
     if (h->prof.which == XFH_PROF_CONV_64_64_S1 && c.cin == 64 && c.cout == 64 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_64_64_S1;
     prof_begin(&h->prof, pid, st);
-    // 3x3/s1 layers with >= 24 channels: Winograd F(2x2,3x3) (k_conv_wino.hip); XFH_WINO=0 forces the direct kernel (A/B runs)
+    // 3x3/s1 layers with >= 24 channels: Winograd F(2x2,3x3) (k_conv_wino.hip), including the 3x3 + fused 1x1 pairs.
+    // A/B runs: XFH_WINO=0 forces the direct kernel, XFH_WINO=1 keeps the fused pairs on the direct kernel.
     static int use_wino = -1;
-    if (use_wino < 0) { const char* e = getenv("XFH_WINO"); use_wino = e ? atoi(e) : 1; }
+    if (use_wino < 0) { const char* e = getenv("XFH_WINO"); use_wino = e ? atoi(e) : 2; }
     int rc = -1;
-    if (use_wino && !c2 && !nhwc && c.w_wino) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace);
+    if (use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
     const int cl = c2 ? c2->cout : c.cout;
     double bytes = 4.0 * ((double)B * c.cin * Hin * Win + (double)B * cl * Hout * Wout + (double)c.cin * c.cout * c.ks * c.ks);

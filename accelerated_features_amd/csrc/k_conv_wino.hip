@@ -47,7 +47,9 @@ struct WinoArgs {
     const float* wu;          // [CIN/4][16 pos][2 half][COUT_PAD][2 p]   channel = 4*chunk + 2*p + half
     const float* bias;        // [COUT_PAD]
     float* out;
-    int relu;
+    const float* wk2;         // fused 1x1: [COUT][COUT2_PAD]
+    const float* bias2;       // [COUT2_PAD]
+    int relu, relu2;
     int H, W, B;              // input == output size (stride 1, pad 1)
     int tiles_x, tiles;       // workgroups per image
     long long* trace;         // debug: per-workgroup s_memtime stamps (NULL in production)
@@ -70,7 +72,7 @@ constexpr int wino_pick_hwp(int ttw) {
     return ttw + 1;
 }
 
-template <int CB, int TBG, int NCBW, int NTBW, int TTH_, int TTW_>
+template <int CB, int TBG, int NCBW, int NTBW, int TTH_, int TTW_, int COUT2 = 0>
 struct WinoCfg {
     static constexpr int CK = 4, TTH = TTH_, TTW = TTW_;
     static constexpr int NG = (CB / NCBW) * (TBG / NTBW), NW = 4 * NG, NTHR = 64 * NW;
@@ -80,16 +82,21 @@ struct WinoCfg {
     static constexpr int UCH = 16 * CK * COUT_PAD, UPW = UCH / 256 / NW;
     static constexpr int RING = 2 * UCH + 2 * CK * PS;           // floats: two slots each
     static constexpr int XCH = NW * 4 * 16 * 64;                 // floats: output-transform exchange
-    static constexpr int LDS_FLOATS = RING > XCH ? RING : XCH;
+    static constexpr int COUT2_PAD = (COUT2 + 31) / 32 * 32;
+    static constexpr int W2_OFF = RING > XCH ? RING : XCH;      // fused 1x1 weights live behind the ring / exchange area
+    static constexpr int LDS_FLOATS = W2_OFF + 32 * CB * COUT2_PAD;
     static_assert(NCBW * NTBW == 2 && CB % NCBW == 0 && TBG % NTBW == 0, "two 32x32 blocks per wave");
     static_assert(TTH * TTW <= NT && TTH * TTW > NT - 32, "region must fill the tile blocks");
     static_assert((UCH / 256) % NW == 0, "every wave issues the same number of weight DMAs");
 };
 
-template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW>
+template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2, bool NHWC>
 __global__ __launch_bounds__(256 * (CB / NCBW) * (TBG / NTBW)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino_kernel(WinoArgs a) {
-    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW>;
+    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
+    constexpr int COUT2_PAD = Cfg::COUT2_PAD, MB2 = COUT2_PAD / 32;
+    static_assert(COUT2 == 0 || (COUT == 32 * CB && NCBW == 2 && MB2 == 2), "fused 1x1: full cout blocks, two per wave, 64 outputs");
+    static_assert(COUT2 > 0 || !NHWC, "channels-last output only with the fused 1x1");
     constexpr int CK = Cfg::CK, NW = Cfg::NW, COUT_PAD = Cfg::COUT_PAD, HWP = Cfg::HWP, ROWS = Cfg::ROWS;
     constexpr int PS = Cfg::PS, NSEG = Cfg::NSEG, UCH = Cfg::UCH, UPW = Cfg::UPW, NCH = CIN / CK;
     static_assert(CIN % (2 * CK) == 0, "the main loop is unrolled by two chunks");
@@ -115,7 +122,11 @@ void conv_wino_kernel(WinoArgs a) {
     auto make_rsrc = [](const void* p, unsigned bytes) {
         const unsigned long long ba = (unsigned long long)p;
         i32x4 r;
-        r.x = (int)(unsigned)ba; r.y = (int)((unsigned)(ba >> 32) & 0xffffu); r.z = (int)bytes; r.w = 0x00020000;
+        // readfirstlane: the "s" asm constraint needs values the compiler KNOWS to be wave-uniform
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ba);
+        r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ba >> 32) & 0xffffu));
+        r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+        r.w = 0x00020000;
         return r;
     };
     const i32x4 rs_in = make_rsrc(a.in + (size_t)b * CIN * HW, (unsigned)(CIN * HW * sizeof(float)));
@@ -149,6 +160,14 @@ void conv_wino_kernel(WinoArgs a) {
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(m0v), "v"(xvoff[s]), "s"(rs_in), "s"(soff) : "memory");
             }
     };
+    if constexpr (COUT2 > 0) {       // fused 1x1 weights: one DMA, covered by the first barrier
+        const i32x4 rs_w2 = make_rsrc(a.wk2, (unsigned)(COUT * COUT2_PAD * sizeof(float)));
+        for (int j = wave; j < COUT * COUT2_PAD / 256; j += NW) {
+            const unsigned m0v = lds_addr(smem + Cfg::W2_OFF + j * 256);
+            const int soff = j * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(uvoff), "s"(rs_w2), "s"(soff) : "memory");
+        }
+    }
     auto dma_barrier = [&]() {       // everything this workgroup has in flight has landed, for every wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -315,16 +334,103 @@ void conv_wino_kernel(WinoArgs a) {
             }
         }
         if (tr && tid == 0) tr[13] = __builtin_amdgcn_s_memtime();
-        if (ok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            y0[r] += bs[r]; y1[r] += bs[r];
+            if (a.relu) { y0[r] = fmaxf(y0[r], 0.f); y1[r] = fmaxf(y1[r], 0.f); }
+        }
+        if constexpr (COUT2 == 0) {
+            if (ok) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < COUT) {
+                        float* o = op + (size_t)co * HW;
+                        if (pair && al8) *reinterpret_cast<float2*>(o) = make_float2(y0[r], y1[r]);
+                        else { o[0] = y0[r]; if (pair) o[1] = y1[r]; }
+                    }
+                }
+            }
+        } else {
+            // ---- fused trailing 1x1 (block3.1+3.2, block5.2+5.3, block_fusion.1+.2) --------------------
+            // Register r of y holds, for this lane's tile, channel cbk*32 + (r&3)+8(r>>2) + 4*half: pairing
+            // channels (c, c+4) makes y[r] THE B operand (A for channels-last) of the 1x1 GEMM -- no LDS
+            // round trip for the activations.  This wave covers the K slice of its cout block cbk; the
+            // KW = CB waves sharing (output row, tile block) add their partial sums through LDS.
+            const float* W2l = smem + Cfg::W2_OFF;
+            f32x16 acc2[2][2];         // [m2][pixel column j]
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[m2][j][r] = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v0 = y0[r] + bs[r], v1 = y1[r] + bs[r];
-                if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                if (co < COUT) {
-                    float* o = op + (size_t)co * HW;
-                    if (pair && al8) *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
-                    else { o[0] = v0; if (pair) o[1] = v1; }
+                const int kc = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float w0 = W2l[kc * COUT2_PAD + l31], w1 = W2l[kc * COUT2_PAD + 32 + l31];
+                if (NHWC) {
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0[r], w0, acc2[0][0], 0, 0, 0);
+                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1[r], w0, acc2[0][1], 0, 0, 0);
+                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0[r], w1, acc2[1][0], 0, 0, 0);
+                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1[r], w1, acc2[1][1], 0, 0, 0);
+                } else {
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, y0[r], acc2[0][0], 0, 0, 0);
+                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, y1[r], acc2[0][1], 0, 0, 0);
+                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, y0[r], acc2[1][0], 0, 0, 0);
+                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, y1[r], acc2[1][1], 0, 0, 0);
+                }
+            }
+            // K-split reduction: KW waves (kw = index of this wave's cout block) hold partial sums of the same
+            // outputs.  Vector v = m2*2 + j is finished by wave kw = v*KW/4 (KW = 2: one m2, both columns).
+            constexpr int KW = CB, VPW = 4 / KW;
+            static_assert(KW == 2 || KW == 4, "K split over 2 or 4 waves");
+            const int kw = cbk;                         // 0 .. KW-1
+            dma_barrier();                              // every wave has finished reading the first exchange
+            float* X2 = smem;                           // [wave][v][16 r][64 lanes]
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (v / VPW == kw) continue;            // wave-uniform: own vectors stay in registers
+#pragma unroll
+                for (int r = 0; r < 16; ++r) X2[((wave * 4 + v) * 16 + r) * 64 + lane] = acc2[v >> 1][v & 1][r];
+            }
+            dma_barrier();
+            float bs2[16];
+            const int m2o = (kw * VPW) >> 1;            // the m2 block this wave finishes
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bs2[r] = NHWC ? a.bias2[m2o * 32 + l31] : a.bias2[m2o * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+            for (int vv = 0; vv < VPW; ++vv) {
+                const int v = kw * VPW + vv;            // wave-uniform
+                f32x16 sum;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+#pragma unroll
+                for (int k2 = 0; k2 < KW; ++k2) {        // peers: same output row oi and tile block, cout block k2
+                    const int pw = NCBW == 2 && CB == 2 ? (g * 4 + oi + 2 * k2) : ((tb0 / NTBW * (CB / NCBW) + (k2 >> 1)) * 4 + oi + 2 * (k2 & 1));
+                    if (k2 == kw) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum[r] += (v == 0 ? acc2[0][0][r] : v == 1 ? acc2[0][1][r] : v == 2 ? acc2[1][0][r] : acc2[1][1][r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum[r] += X2[((pw * 4 + v) * 16 + r) * 64 + lane];
+                    }
+                }
+                const int jcol = v & 1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float o2 = sum[r] + bs2[r];
+                    if (a.relu2) o2 = fmaxf(o2, 0.f);
+                    if (!NHWC) {
+                        const int c2 = m2o * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (ok && c2 < COUT2 && ox + jcol < a.W) a.out[(((size_t)b * COUT2 + c2) * a.H + oy) * a.W + ox + jcol] = o2;
+                    } else {
+                        const int t2 = tbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // D rows are tiles
+                        const int ty2 = t2 / TTW, tx2 = t2 - ty2 * TTW;
+                        const int oy2 = oy0 + 2 * ty2 + oi, ox2 = ox0 + 2 * tx2 + jcol;
+                        const int c2 = m2o * 32 + l31;
+                        if (t2 < TTH * TTW && oy2 < a.H && ox2 < a.W && c2 < COUT2) a.out[(((size_t)b * a.H + oy2) * a.W + ox2) * COUT2 + c2] = o2;
+                    }
                 }
             }
         }
@@ -338,33 +444,50 @@ void conv_wino_kernel(WinoArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW>
-static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
-    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW>;
+template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2 = 0, bool NHWC = false>
+static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2 = nullptr) {
+    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
     if ((size_t)c.cin * H * W * sizeof(float) >= 0x7fffffffu) return -1;     // buffer-resource range
     WinoArgs a;
     a.in = in; a.wu = c.w_wino; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    a.wk2 = c2 ? c2->w_kcp : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
+    if ((COUT2 > 0) != (c2 != nullptr)) return -1;
     a.tiles_x = ceil_div(ceil_div(W, 2), TTW);
     a.tiles = a.tiles_x * ceil_div(ceil_div(H, 2), TTH);
     const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
     static_assert(Cfg::LDS_FLOATS * sizeof(float) <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW><<<xcd_grid_size(a.tiles, B), Cfg::NTHR, lds, st>>>(a);
+    conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC><<<xcd_grid_size(a.tiles, B), Cfg::NTHR, lds, st>>>(a);
     return 0;
 }
 
 static long wino_groups(int H, int W, int tth, int ttw) { return (long)ceil_div(ceil_div(H, 2), tth) * ceil_div(ceil_div(W, 2), ttw); }
 
 int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B, int H, int W, float* out, hipStream_t st, int cfg,
-                     long long* trace) {
+                     long long* trace, const ConvW* c2, bool nhwc) {
     (void)zeros;
     if (c.ks != 3 || c.stride != 1 || !c.w_wino) return -1;
     const int key = c.cin * 1000 + c.cout;
+    if (c2) {      // 3x3 + fused 1x1
+        if (c2->ks != 1 || c2->cin != c.cout || c2->cout != 64) return -1;
+        const bool tall = wino_groups(H, W, 8, 4) < wino_groups(H, W, 4, 8);
+        if (key == 64 * 1000 + 64) {
+            if (nhwc) return tall ? run_wino<64, 64, 2, 1, 2, 1, 8, 4, 64, true>(c, in, B, H, W, out, st, trace, c2)
+                                  : run_wino<64, 64, 2, 1, 2, 1, 4, 8, 64, true>(c, in, B, H, W, out, st, trace, c2);
+            return tall ? run_wino<64, 64, 2, 1, 2, 1, 8, 4, 64, false>(c, in, B, H, W, out, st, trace, c2)
+                        : run_wino<64, 64, 2, 1, 2, 1, 4, 8, 64, false>(c, in, B, H, W, out, st, trace, c2);
+        }
+        if (key == 128 * 1000 + 128 && !nhwc)
+            return tall ? run_wino<128, 128, 4, 1, 2, 1, 8, 4, 64, false>(c, in, B, H, W, out, st, trace, c2)
+                        : run_wino<128, 128, 4, 1, 2, 1, 4, 8, 64, false>(c, in, B, H, W, out, st, trace, c2);
+        return -1;
+    }
+    if (nhwc) return -1;
     // cfg 0 = the production choice; cfg >= 1 = explicit variants (xfh_conv_layer variant 2, 3, ... for tuning)
     switch (key) {
         case 24 * 1000 + 24:     // 1 cout block: waves hold 2 tile blocks each

@@ -57,7 +57,8 @@ void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Wi
 // Returns 0, or -1 when no instantiation exists for the layer shape.
 // fused1x1 (optional): the 1x1 conv that follows, computed in the same kernel.  zeros: >= 256 B.
 // Winograd F(2x2,3x3) MFMA path for 3x3/s1 layers (k_conv_wino.hip); -1 if no instantiation
-int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B, int H, int W, float* out, hipStream_t st, int cfg = 0, long long* trace = nullptr);
+int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B, int H, int W, float* out, hipStream_t st, int cfg = 0, long long* trace = nullptr,
+                     const ConvW* fused1x1 = nullptr, bool nhwc = false);
 int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, const float* in, int B, int Hin, int Win,
                      float* out, bool nhwc_out, hipStream_t st, long long* trace = nullptr);
 double conv_flops(const ConvW& c, int B, int Hout, int Wout);
