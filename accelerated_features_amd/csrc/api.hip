@@ -131,6 +131,7 @@ struct Carver {
 
 struct BackboneWs {
     double* part;
+    float* coef;          // per-image instance-norm {alpha, beta}
     float *gray, *x1, *x2a, *x2b, *x3a, *x3b, *x3c, *x4a, *x4b, *x4c, *x5a, *x5b, *x5c, *x5d;
     float *pyr, *f0, *heat_tmp;
 };
@@ -138,6 +139,7 @@ static size_t carve_backbone(void* ws, int B, int H, int W, BackboneWs& o) {
     Carver c(ws);
     const size_t HW = (size_t)H * W, b = B;
     o.part = c.take<double>(b * GS_CHUNKS * 2);
+    o.coef = c.take<float>(b * 2);
     o.gray = c.take<float>(b * HW);
     o.x1 = c.take<float>(b * 24 * HW / 16);
     o.x2a = c.take<float>(b * 24 * HW / 16);
@@ -415,9 +417,9 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, flo
     const NetWeights& nw = h->nw;
     const int H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
 
-    launch_gray_norm(img, B, C, H, W, w.part, w.gray, st);
+    launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
-    launch_block1_fused(nw, w.gray, B, H, W, w.x1, st);
+    launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st);
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 0, 0);
 #define CONV(layer, fused, in, hin, win, out, nhwc) \
     if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st))) return rc
@@ -439,7 +441,7 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, flo
     // fused heads: reliability from the channels-last features, key-point head from the gray image
     prof_begin(&h->prof, XFH_PROF_HEADS, st);
     launch_rel_head(nw, feats, B * H8 * W8, reliab, st);
-    launch_kp_head(nw, w.gray, B, H, W, heat ? heat : w.heat_tmp, logits, st);
+    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st);
     prof_end(&h->prof, XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }

@@ -126,7 +126,7 @@ constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead o
 constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19389 floats = 77.6 KB
 }  // namespace b1
 
-__global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, float* __restrict__ x1, int H, int W,
+__global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int H, int W,
                                                            const float* __restrict__ w1, const float* __restrict__ bb1,
                                                            const float* __restrict__ w2, const float* __restrict__ bb2,
                                                            const float* __restrict__ w3, const float* __restrict__ bb3,
@@ -143,11 +143,12 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     const int H2 = H >> 1, W2 = W >> 1, H4 = H >> 2, W4 = W >> 2;
     const float* gb = gray + (size_t)b * H * W;
 
-    // ---- stage 0: gray tile ----------------------------------------------------------------
+    // ---- stage 0: gray tile, instance-normalised on the way in (zero padding stays zero) -------
+    const float alpha = coef[2 * b], beta = coef[2 * b + 1];
     for (int e = tid; e < G_SZ; e += 512) {
         const int r = e / GW, c = e - r * GW;
         const int gy = 4 * Y4 - 6 + r, gx = 4 * X4 - 6 + c;
-        G[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gb[(size_t)gy * W + gx] : 0.f;
+        G[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? fmaf(gb[(size_t)gy * W + gx], alpha, beta) : 0.f;
     }
     __syncthreads();
 
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     }
 }
 
-void launch_block1_fused(const NetWeights& nw, const float* gray, int B, int H, int W, float* x1, hipStream_t st) {
+void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st) {
     const ConvW& c0 = nw.conv[L_BLOCK1_0];
     const ConvW& c1 = nw.conv[L_BLOCK1_1];
     const ConvW& c2 = nw.conv[L_BLOCK1_2];
@@ -291,7 +292,7 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, int B, int H, 
     }
     const int H4 = H / 4, W4 = W / 4;
     block1_fused_kernel<<<dim3(ceil_div(W4, b1::OW), ceil_div(H4, b1::OH), B), 512, b1::LDS_FLOATS * 4, st>>>(
-        gray, x1, H, W, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
+        gray, coef, x1, H, W, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -27,7 +27,8 @@ constexpr int HD_CELLS = 256;    // cells per tile
 constexpr int HD_XS = 65;        // LDS row stride of the activation tile
 
 struct HeadArgs {
-    const float* src;        // KP: normalised gray (B,H,W) ; REL: feats (B*hc*wc, 64)
+    const float* src;        // KP: raw gray (B,H,W) ; REL: feats (B*hc*wc, 64)
+    const float* coef;       // KP: per-image instance-norm {alpha, beta}
     const float* zeros;
     const float* w[4];       // [64][n_pad] per layer (BN folded)
     const float* bias[4];
@@ -130,6 +131,13 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
         {
             const float* xb = Xl + (wave * 32 + l31) * HD_XS + half;
             const float* wb = Wl + half * 64 + l31;
+            // key-point head: the tile holds RAW gray; this lane's cell belongs to image cb -> x = fmaf(g, alpha, beta)
+            float nalpha = 1.f, nbeta = 0.f;
+            if (KP) {
+                const int cg = min(tile * HD_CELLS + wave * 32 + l31, a.ncell - 1);
+                const int cb = cg / hw;
+                nalpha = a.coef[2 * cb]; nbeta = a.coef[2 * cb + 1];
+            }
             float av[2][2], bv[2];
             auto ld = [&](int p, float (&ao)[2], float& bo) {
                 ao[0] = wb[(2 * p) * 64];
@@ -141,8 +149,9 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
 #pragma unroll
             for (int p = 0; p < 32; ++p) {
                 if (p + 1 < 32) ld(p + 1, av[(p + 1) & 1], bv[(p + 1) & 1]);
-                accA[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][0], bv[p & 1], accA[0], 0, 0, 0);
-                accA[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][1], bv[p & 1], accA[1], 0, 0, 0);
+                const float xv = KP ? fmaf(bv[p & 1], nalpha, nbeta) : bv[p & 1];
+                accA[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][0], xv, accA[0], 0, 0, 0);
+                accA[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][1], xv, accA[1], 0, 0, 0);
                 if (p + 1 < 32) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
@@ -225,9 +234,9 @@ static int num_cus() {
     return n;
 }
 
-void launch_kp_head(const NetWeights& nw, const float* gray, int B, int H, int W, float* heat, float* logits, hipStream_t st) {
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st) {
     HeadArgs a{};
-    a.src = gray; a.zeros = nw.zeros; a.out = heat; a.logits = logits;
+    a.src = gray; a.coef = coef; a.zeros = nw.zeros; a.out = heat; a.logits = logits;
     a.H = H; a.W = W; a.hc = H / 8; a.wc = W / 8;
     a.ncell = B * a.hc * a.wc;
     a.ntiles = ceil_div(a.ncell, HD_CELLS);

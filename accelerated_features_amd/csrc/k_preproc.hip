@@ -9,7 +9,7 @@ namespace xfh {
 // grid (GS_CHUNKS, B), block 256.  part[b][chunk][2] = {sum, sum of squares}
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gray_stats_kernel(const float* __restrict__ img, int C, int HW,
-                                                         double* __restrict__ part) {
+                                                         double* __restrict__ part, float* __restrict__ gray) {
     const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
     const int n4 = HW >> 2;
     const int per = ceil_div(n4, GS_CHUNKS);
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void gray_stats_kernel(const float* __restrict
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         a.x /= fC; a.y /= fC; a.z /= fC; a.w /= fC;
+        reinterpret_cast<float4*>(gray + (size_t)b * HW)[i] = a;      // raw channel mean; consumers apply the per-image (alpha, beta)
         s += (double)a.x + (double)a.y + (double)a.z + (double)a.w;
         q += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
     }
@@ -38,49 +39,31 @@ __global__ __launch_bounds__(256) void gray_stats_kernel(const float* __restrict
     }
 }
 
-// out = gray * invstd + (-mean * invstd)     grid (ceil(HW/4/256), B)
-__global__ __launch_bounds__(256) void gray_norm_kernel(const float* __restrict__ img, int C, int HW,
-                                                        const double* __restrict__ part, float eps,
-                                                        float* __restrict__ out) {
-    const int b = blockIdx.y, tid = threadIdx.x;
-    __shared__ float sm[2];
-    if (tid < 64) {
-        double s = part[((size_t)b * GS_CHUNKS + tid) * 2 + 0];
-        double q = part[((size_t)b * GS_CHUNKS + tid) * 2 + 1];
-        s = wave_sum(s);
-        q = wave_sum(q);
-        if (tid == 0) {
-            double mean = s / HW;
-            double var = q / HW - mean * mean;
-            if (var < 0) var = 0;
-            float invstd = (float)(1.0 / sqrt(var + (double)eps));
-            sm[0] = invstd;
-            sm[1] = -(float)mean * invstd;
-        }
+// InstanceNorm2d(1) as a per-image affine map: x = fmaf(gray, alpha, beta), alpha = 1/sqrt(var+eps), beta = -mean*alpha.
+// The map is applied by the two consumers of the image (block1 tile load, key-point head operand load) instead of
+// a separate pass over the image (one read + one write of the RGB / gray planes less per frame).
+// grid (B), block 64.   coef[b] = {alpha, beta}
+__global__ __launch_bounds__(64) void gray_coef_kernel(const double* __restrict__ part, int HW, float eps, float* __restrict__ coef) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double s = part[((size_t)b * GS_CHUNKS + tid) * 2 + 0];
+    double q = part[((size_t)b * GS_CHUNKS + tid) * 2 + 1];
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (tid == 0) {
+        const double mean = s / HW;
+        double var = q / HW - mean * mean;
+        if (var < 0) var = 0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        coef[2 * b] = invstd;
+        coef[2 * b + 1] = -(float)mean * invstd;
     }
-    __syncthreads();
-    const float alpha = sm[0], beta = sm[1];
-    const int n4 = HW >> 2;
-    const int i = blockIdx.x * 256 + tid;
-    if (i >= n4) return;
-    const float4* base = reinterpret_cast<const float4*>(img + (size_t)b * C * HW);
-    const float fC = (float)C;
-    float4 a = base[i];
-    for (int c = 1; c < C; ++c) {
-        float4 v = base[(size_t)c * n4 + i];
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    a.x = fmaf(a.x / fC, alpha, beta);
-    a.y = fmaf(a.y / fC, alpha, beta);
-    a.z = fmaf(a.z / fC, alpha, beta);
-    a.w = fmaf(a.w / fC, alpha, beta);
-    reinterpret_cast<float4*>(out + (size_t)b * HW)[i] = a;
 }
 
-void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, hipStream_t st) {
+void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, float* coef, hipStream_t st) {
+    static_assert(GS_CHUNKS == 64, "gray_coef_kernel reduces one wave of partial sums");
     const int HW = H * W;
-    gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, part);
-    gray_norm_kernel<<<dim3(ceil_div(HW / 4, 256), B), 256, 0, st>>>(img, C, HW, part, 1e-5f, gray);
+    gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, part, gray);
+    gray_coef_kernel<<<B, 64, 0, st>>>(part, HW, 1e-5f, coef);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -38,7 +38,8 @@ struct NetWeights {
 struct Profiler;   // api.hip
 
 // ---- k_preproc.hip ----------------------------------------------------------------------
-void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, hipStream_t st);
+// gray = channel mean (raw), coef[b] = {alpha, beta} of the instance norm x = fmaf(gray, alpha, beta)
+void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, float* coef, hipStream_t st);
 void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,
                             float sh, float sw, hipStream_t st);
 void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int planes,
@@ -47,7 +48,7 @@ void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float
 // ---- k_conv_direct.hip ------------------------------------------------------------------
 void launch_block1(const NetWeights& nw, const float* gray, int B, int H, int W, float* t0, float* t1, float* t2,
                    float* x1, hipStream_t st);
-void launch_block1_fused(const NetWeights& nw, const float* gray, int B, int H, int W, float* x1, hipStream_t st);
+void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st);
 int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B, int Hin, int Win, float* out,
                         hipStream_t st);
 void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, hipStream_t st);
@@ -88,7 +89,7 @@ void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat
 // ---- k_heads.hip -------------------------------------------------------------------------
 // fused heads (persistent, weights LDS-resident): key-point head -> heat (+ optional logits (M,65)),
 // reliability head -> sigmoid map
-void launch_kp_head(const NetWeights& nw, const float* gray, int B, int H, int W, float* heat, float* logits, hipStream_t st);
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st);
 void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, hipStream_t st);
 
 // ---- k_detect.hip -----------------------------------------------------------------------
