@@ -247,7 +247,8 @@ def main():
                          "flops_per_launch": fl.value / max(n_l.value, 1),
                          "algorithmic": "2*pairs*N1*N2*64 FLOP per launch (32 pairs x 4096 x 4096)",
                          "traffic": load_pmc_traffic()},
-            "roofline_conv_family": {"bound": "mfma", "kernel": "conv_mfma_kernel<...> (all 13 MFMA conv launches per step)",
+            "roofline_conv_family": {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> (all 12 MFMA conv launches per step; FLOPs of the "
+                                                                  "direct form -- the 3x3/s1 layers execute 2.25x fewer as Winograd F(2x2,3x3))",
                                      "achieved": round((cfl.value / 1e12) / (cms.value / 1e3), 3) if cms.value > 0 else None,
                                      "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                                      "us_per_step": round(1e3 * cms.value / 3, 1)},
