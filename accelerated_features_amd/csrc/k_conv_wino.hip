@@ -72,7 +72,7 @@ constexpr int wino_pick_hwp(int ttw) {
     return ttw + 1;
 }
 
-template <int CB, int TBG, int NCBW, int NTBW, int TTH_, int TTW_, int COUT2 = 0>
+template <int CB, int TBG, int NCBW, int NTBW, int TTH_, int TTW_, int COUT2 = 0, bool PERSIST = false>
 struct WinoCfg {
     static constexpr int CK = 4, TTH = TTH_, TTW = TTW_;
     static constexpr int NG = (CB / NCBW) * (TBG / NTBW), NW = 4 * NG, NTHR = 64 * NW;
@@ -83,17 +83,20 @@ struct WinoCfg {
     static constexpr int RING = 2 * UCH + 2 * CK * PS;           // floats: two slots each
     static constexpr int XCH = NW * 4 * 16 * 64;                 // floats: output-transform exchange
     static constexpr int COUT2_PAD = (COUT2 + 31) / 32 * 32;
-    static constexpr int W2_OFF = RING > XCH ? RING : XCH;      // fused 1x1 weights live behind the ring / exchange area
+    // persistent workgroups: the exchange / deferred-store area (64 KiB) must not overlay the DMA ring
+    static constexpr int XS_OFF = PERSIST ? RING : 0, XS_FLOATS = 16384;
+    static constexpr int W2_OFF = PERSIST ? RING + XS_FLOATS : (RING > XCH ? RING : XCH);      // fused 1x1 weights live behind the ring / exchange area
     static constexpr int LDS_FLOATS = W2_OFF + 32 * CB * COUT2_PAD;
     static_assert(NCBW * NTBW == 2 && CB % NCBW == 0 && TBG % NTBW == 0, "two 32x32 blocks per wave");
     static_assert(TTH * TTW <= NT && TTH * TTW > NT - 32, "region must fill the tile blocks");
     static_assert((UCH / 256) % NW == 0, "every wave issues the same number of weight DMAs");
 };
 
-template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2, bool NHWC>
+template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2, bool NHWC, bool PERSIST>
 __global__ __launch_bounds__(256 * (CB / NCBW) * (TBG / NTBW)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino_kernel(WinoArgs a) {
-    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
+    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, PERSIST>;
+    static_assert(!PERSIST || (COUT2 == 0 && Cfg::NW == 8 && 32 * CB * 4 * Cfg::NT == Cfg::XS_FLOATS), "persistent variant: unfused, 8 waves, 64 KiB of outputs per tile");
     constexpr int COUT2_PAD = Cfg::COUT2_PAD, MB2 = COUT2_PAD / 32;
     static_assert(COUT2 == 0 || (COUT == 32 * CB && NCBW == 2 && MB2 == 2), "fused 1x1: full cout blocks, two per wave, 64 outputs");
     static_assert(COUT2 > 0 || !NHWC, "channels-last output only with the fused 1x1");
@@ -109,10 +112,8 @@ void conv_wino_kernel(WinoArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nu = wave & 3, g = wave >> 2;          // waves w and w+4 share a SIMD: same nu, different group
     const int cb0 = (g % (CB / NCBW)) * NCBW, tb0 = (g / (CB / NCBW)) * NTBW;
-    int b, tile;
-    if (!xcd_group_map(blockIdx.x, a.tiles, a.B, b, tile)) return;
-    const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
-    const int oy0 = 2 * tyi * TTH, ox0 = 2 * txi * TTW;
+    // per-tile state (a persistent workgroup walks virtual ids blockIdx.x, + gridDim.x, ...)
+    int b = 0, oy0 = 0, ox0 = 0;
     const size_t HW = (size_t)a.H * a.W;
     const int HWb = (int)(HW * sizeof(float));
     long long* tr = a.trace ? a.trace + (size_t)blockIdx.x * 24 : nullptr;
@@ -129,18 +130,27 @@ void conv_wino_kernel(WinoArgs a) {
         r.w = 0x00020000;
         return r;
     };
-    const i32x4 rs_in = make_rsrc(a.in + (size_t)b * CIN * HW, (unsigned)(CIN * HW * sizeof(float)));
+    i32x4 rs_in;
     const i32x4 rs_u = make_rsrc(a.wu, (unsigned)((size_t)CIN * 16 * COUT_PAD * sizeof(float)));
     // raw plane element e of a channel = (row r, column parity q, half column h): source pixel (r, 2h+q)
     int xvoff[NSEG];
+    auto set_tile = [&](int vid) {       // false for the padding ids of the XCD-swizzled grid
+        int tile;
+        if (!xcd_group_map(vid, a.tiles, a.B, b, tile)) return false;
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        oy0 = 2 * tyi * TTH; ox0 = 2 * txi * TTW;
+        rs_in = make_rsrc(a.in + (size_t)b * CIN * HW, (unsigned)(CIN * HW * sizeof(float)));
 #pragma unroll
-    for (int s = 0; s < NSEG; ++s) {
-        const int e = (wave + NW * s) * 64 + lane;
-        const int r = e / (2 * HWP), rem = e - r * (2 * HWP), q = rem / HWP, h = rem - q * HWP;
-        const int gy = oy0 - 1 + r, gx = ox0 - 1 + 2 * h + q;
-        const bool ok = r < ROWS && h <= TTW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        xvoff[s] = ok ? (gy * a.W + gx) * 4 : (int)0x80000000;
-    }
+        for (int s = 0; s < NSEG; ++s) {
+            const int e = (wave + NW * s) * 64 + lane;
+            const int r = e / (2 * HWP), rem = e - r * (2 * HWP), q = rem / HWP, h = rem - q * HWP;
+            const int gy = oy0 - 1 + r, gx = ox0 - 1 + 2 * h + q;
+            const bool ok = r < ROWS && h <= TTW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            xvoff[s] = ok ? (gy * a.W + gx) * 4 : (int)0x80000000;
+        }
+        return true;
+    };
+    if (!set_tile(blockIdx.x)) return;
     const int uvoff = lane * 16;
     auto lds_addr = [](const float* p) { return (unsigned)(size_t)(lptr_t)p; };
     auto issue = [&](int ch, int slot) {
@@ -151,13 +161,16 @@ void conv_wino_kernel(WinoArgs a) {
             const int soff = (ch * UCH + j * 256) * 4;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(uvoff), "s"(rs_u), "s"(soff) : "memory");
         }
+        i32x4 rin;                     // per-tile resource: re-assert uniformity where the "s" operand is formed
+        rin.x = __builtin_amdgcn_readfirstlane(rs_in.x); rin.y = __builtin_amdgcn_readfirstlane(rs_in.y);
+        rin.z = __builtin_amdgcn_readfirstlane(rs_in.z); rin.w = 0x00020000;
 #pragma unroll
         for (int s = 0; s < NSEG; ++s)
 #pragma unroll
             for (int c = 0; c < CK; ++c) {
                 const unsigned m0v = lds_addr(Rl + (slot * CK + c) * PS + (wave + NW * s) * 64);
                 const int soff = (ch * CK + c) * HWb;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(m0v), "v"(xvoff[s]), "s"(rs_in), "s"(soff) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(m0v), "v"(xvoff[s]), "s"(rin), "s"(soff) : "memory");
             }
     };
     if constexpr (COUT2 > 0) {       // fused 1x1 weights: one DMA, covered by the first barrier
@@ -226,6 +239,52 @@ void conv_wino_kernel(WinoArgs a) {
 
     auto body = [&](auto SCHED) {
         constexpr int SV = decltype(SCHED)::value;
+        // Wave nu finishes output row oi = nu&1 of block blk = nu>>1 (both columns j: float2).
+        const int oi = nu & 1, blk = nu >> 1;
+        const int cbk = NCBW == 2 ? cb0 + blk : cb0, tbk = NTBW == 2 ? tb0 + blk : tb0;
+        // ---- persistent mode: outputs of tile k wait in LDS (SB = [cout][2*TTH][2*TTW]) and are stored
+        // slice by slice under the MFMAs of tile k+1, so no CU ever sits in a pure store phase.
+        bool have_prev = false;
+        int pb = 0, poy0 = 0, pox0 = 0;
+        constexpr int RH = 2 * TTH, RW = 2 * TTW;
+        constexpr int PPC = RH * RW / 2;                          // float2 elements per channel plane of SB
+        constexpr int CPC = (COUT_PAD + NCH - 1) / NCH;           // channels stored per chunk
+        constexpr int NIT = (CPC * PPC + Cfg::NTHR - 1) / Cfg::NTHR;
+        float* SBl = smem + Cfg::XS_OFF;
+        // lane constants of the deferred store: element w = it*NTHR + tid of a slice -> (channel cw, row py, column px),
+        // packed into one register per it
+        int st_c[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int w = it * Cfg::NTHR + tid;
+            const int cw = w < CPC * PPC ? w / PPC : 0x7fff;      // out of range -> never stored
+            const int rem = w % PPC;
+            st_c[it] = (cw << 16) | ((rem / (RW / 2)) << 8) | (2 * (rem % (RW / 2)));
+        }
+        // Branch-free (it sits inside the pinned MFMA schedule): buffer stores drop lanes whose offset is out of
+        // range, so "nothing to store" (first tile, image border, padded channels) is just an invalid offset.
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((size_t)a.B * COUT * HW * sizeof(float)), 0x00020000);
+        float2 st_v;
+        int st_o0, st_o1;
+        auto slice_load = [&](int i, int it) {
+            const int py = (st_c[it] >> 8) & 0xff, px = st_c[it] & 0xff;
+            const int co = i * CPC + (st_c[it] >> 16);
+            const int oy = poy0 + py, ox = pox0 + px;
+            const bool ok = have_prev && co < COUT && oy < a.H && ox < a.W;
+            const int off = (((pb * COUT + co) * a.H + oy) * a.W + ox) * 4;
+            st_o0 = ok ? off : (int)0x80000000;
+            st_o1 = ok && ox + 1 < a.W ? off + 4 : (int)0x80000000;
+            const int cl = co < COUT_PAD ? co : 0;
+            st_v = *reinterpret_cast<const float2*>(SBl + ((cl * RH + py) * RW + px));
+        };
+        auto slice_store = [&]() {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(st_v.x), rs_out, st_o0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(st_v.y), rs_out, st_o1, 0, 0);
+        };
+
+        issue(0, 0);
+        issue(1, 1);
+        for (int vid = blockIdx.x;;) {
         f32x16 acc[4][2];          // [xi][block], block = cout-block-major
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi)
@@ -233,9 +292,6 @@ void conv_wino_kernel(WinoArgs a) {
             for (int k = 0; k < 2; ++k)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[xi][k][r] = 0.f;
-
-        issue(0, 0);
-        issue(1, 1);
         dma_barrier();
         if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memtime();
         Ops ops[2];
@@ -260,11 +316,13 @@ void conv_wino_kernel(WinoArgs a) {
 #define P_A   { load_a(NXT, ops[NXT]); }
 #define P_BR(p) { read_b(NXT, p, d); }
 #define P_BV(p) { make_b(p, d, ops[NXT]); }
+#define P_SL(it) { if constexpr (PERSIST && (it) < NIT) slice_load(i, (it) < NIT ? (it) : 0); }      /* outputs of the previous tile leave under this tile's MFMAs */
+#define P_SS(it) { if constexpr (PERSIST && (it) < NIT) slice_store(); }
             if (SV == 0) {
                 M(0) P_DMA M(1) P_A P_BR(0) M(2) M(3) M(4) P_BV(0) M(5) P_BR(1) M(6) M(7) M(8) P_BV(1)
-                M(9) M(10) M(11) M(12) M(13) M(14) M(15)
+                M(9) P_SL(0) M(10) M(11) P_SS(0) P_SL(1) M(12) M(13) P_SS(1) P_SL(2) M(14) M(15) P_SS(2)
             } else {
-                M(0) M(1) M(2) M(3) M(4) M(5) M(6) P_DMA M(7) P_A P_BR(0) M(8) M(9) M(10) P_BV(0) M(11) P_BR(1)
+                M(0) P_SL(0) M(1) M(2) P_SS(0) P_SL(1) M(3) M(4) P_SS(1) P_SL(2) M(5) M(6) P_SS(2) P_DMA M(7) P_A P_BR(0) M(8) M(9) M(10) P_BV(0) M(11) P_BR(1)
                 M(12) M(13) M(14) P_BV(1) M(15)
             }
 #undef M
@@ -272,6 +330,8 @@ void conv_wino_kernel(WinoArgs a) {
 #undef P_A
 #undef P_BR
 #undef P_BV
+#undef P_SL
+#undef P_SS
         };
         for (int i = 0; i < NCH; i += 2) {
             chunk(i, std::integral_constant<int, 0>{});
@@ -282,159 +342,228 @@ void conv_wino_kernel(WinoArgs a) {
 
         // ---- output transform --------------------------------------------------------------------
         // T[i][blk] = sum_xi At[i][xi] M[xi]   (lane-local);  Y[i][j] = sum_nu T_nu[i] A[nu][j].
-        // Wave nu finishes output row oi = nu&1 of block blk = nu>>1 (both columns j: float2 stores):
-        // it keeps its own T[oi][blk] in registers and publishes the other three vectors.
-        const int oi = nu & 1, blk = nu >> 1;
-        const int cbk = NCBW == 2 ? cb0 + blk : cb0, tbk = NTBW == 2 ? tb0 + blk : tb0;
-        float bs[16];
+        float bs[16];                // bias: loaded here, in flight under the exchange
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bs[r] = a.bias[cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];      // in flight under the exchange
-        dma_barrier();               // all waves done with the rings (and the dummy tail DMA has landed)
-        if (tr && tid == 0) tr[10] = __builtin_amdgcn_s_memtime();
-        float* X = smem;             // [wave][i*2+k][16 r][64 lanes]
-        f32x16 own;
+        for (int r = 0; r < 16; ++r) bs[r] = a.bias[cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+        if constexpr (PERSIST) {
+            dma_barrier();           // all waves done with the rings (and the dummy tail DMA has landed)
+            const int cur_b = b, cur_oy0 = oy0, cur_ox0 = ox0;
+            const int nvid = vid + (int)gridDim.x;
+            const bool has_next = nvid < a.tiles * a.B && set_tile(nvid);
+            if (has_next) { issue(0, 0); issue(1, 1); }       // first DMA of the next tile flies under this output transform
+            float* X = smem + Cfg::XS_OFF;                    // one pass: [wave][k][16 r][64 lanes]
+            float y0[16], y1[16];
+            f32x16 T[2][2];                                   // [output row i][block]; the accumulators die here
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const f32x16 t0 = acc[0][k] + acc[1][k] + acc[2][k];
-            const f32x16 t1 = acc[1][k] - acc[2][k] - acc[3][k];
-            if (k == blk) own = oi ? t1 : t0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (!(k == blk && oi == 0)) X[((wave * 4 + 0 + k) * 16 + r) * 64 + lane] = t0[r];
-                if (!(k == blk && oi == 1)) X[((wave * 4 + 2 + k) * 16 + r) * 64 + lane] = t1[r];
+            for (int k = 0; k < 2; ++k) {
+                T[0][k] = acc[0][k] + acc[1][k] + acc[2][k];
+                T[1][k] = acc[1][k] - acc[2][k] - acc[3][k];
             }
-        }
-        if (tr && tid == 0) tr[11] = __builtin_amdgcn_s_memtime();
-        dma_barrier();
-        if (tr && tid == 0) tr[12] = __builtin_amdgcn_s_memtime();
-        const float* Xg = X + ((g * 4) * 4 + oi * 2 + blk) * 16 * 64 + lane;      // + nu' * 4*16*64
-        const int t = tbk * 32 + l31;
-        const int ty = t / TTW, tx = t - ty * TTW;
-        const int oy = oy0 + 2 * ty + oi, ox = ox0 + 2 * tx;
-        const bool ok = t < TTH * TTW && oy < a.H && ox < a.W;
-        const bool pair = ox + 1 < a.W;
-        float* op = a.out + ((size_t)b * COUT * a.H + oy) * a.W + ox;
-        const bool al8 = ((a.W & 1) == 0);          // ox is even: rows are 8-byte aligned iff W is even
-        // coefficients of T_nu in (Y[.][0], Y[.][1]): nu 0: (1,0)  1: (1,1)  2: (1,-1)  3: (0,-1)
-        float y0[16], y1[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            y0[r] = nu == 3 ? 0.f : own[r];
-            y1[r] = nu == 0 ? 0.f : (nu == 1 ? own[r] : -own[r]);
-        }
+            for (int pass = 0; pass < 2; ++pass) {            // pass = output row i
+                const f32x16 (&tv)[2] = T[pass];
 #pragma unroll
-        for (int n2 = 0; n2 < 4; ++n2) {
-            if (n2 == nu) continue;          // wave-uniform
+                for (int k = 0; k < 2; ++k) {
+                    if (oi == pass && k == blk) continue;     // wave-uniform: the vector this wave finishes itself
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = Xg[(n2 * 64 + r) * 64];
-                if (n2 != 3) y0[r] += v;
-                if (n2 == 1) y1[r] += v;
-                if (n2 >= 2) y1[r] -= v;
+                    for (int r = 0; r < 16; ++r) X[((wave * 2 + k) * 16 + r) * 64 + lane] = tv[k][r];
+                }
+                dma_barrier();
+                if (oi == pass) {
+                    const f32x16 own = blk ? tv[1] : tv[0];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        y0[r] = nu == 3 ? 0.f : own[r];
+                        y1[r] = nu == 0 ? 0.f : (nu == 1 ? own[r] : -own[r]);
+                    }
+#pragma unroll
+                    for (int n2 = 0; n2 < 4; ++n2) {
+                        if (n2 == nu) continue;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float v = X[(((g * 4 + n2) * 2 + blk) * 16 + r) * 64 + lane];
+                            if (n2 != 3) y0[r] += v;
+                            if (n2 == 1) y1[r] += v;
+                            if (n2 >= 2) y1[r] -= v;
+                        }
+                    }
+                }
+                dma_barrier();       // the exchange area is free again (next pass / the store buffer)
             }
-        }
-        if (tr && tid == 0) tr[13] = __builtin_amdgcn_s_memtime();
+            // finished outputs -> store buffer (the previous tile's slices all left during the main loop)
+            {
+                const int t = tbk * 32 + l31;
+                const int ty = t / TTW, tx = t - ty * TTW;
+                if (t < TTH * TTW) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            y0[r] += bs[r]; y1[r] += bs[r];
-            if (a.relu) { y0[r] = fmaxf(y0[r], 0.f); y1[r] = fmaxf(y1[r], 0.f); }
-        }
-        if constexpr (COUT2 == 0) {
-            if (ok) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (co < COUT) {
-                        float* o = op + (size_t)co * HW;
-                        if (pair && al8) *reinterpret_cast<float2*>(o) = make_float2(y0[r], y1[r]);
-                        else { o[0] = y0[r]; if (pair) o[1] = y1[r]; }
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float v0 = y0[r] + bs[r], v1 = y1[r] + bs[r];
+                        if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                        *reinterpret_cast<float2*>(SBl + (co * RH + 2 * ty + oi) * RW + 2 * tx) = make_float2(v0, v1);
                     }
                 }
             }
+            have_prev = true; pb = cur_b; poy0 = cur_oy0; pox0 = cur_ox0;
+            if (!has_next) break;
+            vid = nvid;
+            continue;
         } else {
-            // ---- fused trailing 1x1 (block3.1+3.2, block5.2+5.3, block_fusion.1+.2) --------------------
-            // Register r of y holds, for this lane's tile, channel cbk*32 + (r&3)+8(r>>2) + 4*half: pairing
-            // channels (c, c+4) makes y[r] THE B operand (A for channels-last) of the 1x1 GEMM -- no LDS
-            // round trip for the activations.  This wave covers the K slice of its cout block cbk; the
-            // KW = CB waves sharing (output row, tile block) add their partial sums through LDS.
-            const float* W2l = smem + Cfg::W2_OFF;
-            f32x16 acc2[2][2];         // [m2][pixel column j]
+            dma_barrier();               // all waves done with the rings (and the dummy tail DMA has landed)
+            if (tr && tid == 0) tr[10] = __builtin_amdgcn_s_memtime();
+            float* X = smem;             // [wave][i*2+k][16 r][64 lanes]
+            f32x16 own;
 #pragma unroll
-            for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc2[m2][j][r] = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kc = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float w0 = W2l[kc * COUT2_PAD + l31], w1 = W2l[kc * COUT2_PAD + 32 + l31];
-                if (NHWC) {
-                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0[r], w0, acc2[0][0], 0, 0, 0);
-                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1[r], w0, acc2[0][1], 0, 0, 0);
-                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0[r], w1, acc2[1][0], 0, 0, 0);
-                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1[r], w1, acc2[1][1], 0, 0, 0);
-                } else {
-                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, y0[r], acc2[0][0], 0, 0, 0);
-                    acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, y1[r], acc2[0][1], 0, 0, 0);
-                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, y0[r], acc2[1][0], 0, 0, 0);
-                    acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, y1[r], acc2[1][1], 0, 0, 0);
-                }
-            }
-            // K-split reduction: KW waves (kw = index of this wave's cout block) hold partial sums of the same
-            // outputs.  Vector v = m2*2 + j is finished by wave kw = v*KW/4 (KW = 2: one m2, both columns).
-            constexpr int KW = CB, VPW = 4 / KW;
-            static_assert(KW == 2 || KW == 4, "K split over 2 or 4 waves");
-            const int kw = cbk;                         // 0 .. KW-1
-            dma_barrier();                              // every wave has finished reading the first exchange
-            float* X2 = smem;                           // [wave][v][16 r][64 lanes]
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                if (v / VPW == kw) continue;            // wave-uniform: own vectors stay in registers
-#pragma unroll
-                for (int r = 0; r < 16; ++r) X2[((wave * 4 + v) * 16 + r) * 64 + lane] = acc2[v >> 1][v & 1][r];
-            }
-            dma_barrier();
-            float bs2[16];
-            const int m2o = (kw * VPW) >> 1;            // the m2 block this wave finishes
-#pragma unroll
-            for (int r = 0; r < 16; ++r) bs2[r] = NHWC ? a.bias2[m2o * 32 + l31] : a.bias2[m2o * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-#pragma unroll
-            for (int vv = 0; vv < VPW; ++vv) {
-                const int v = kw * VPW + vv;            // wave-uniform
-                f32x16 sum;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sum[r] = 0.f;
-#pragma unroll
-                for (int k2 = 0; k2 < KW; ++k2) {        // peers: same output row oi and tile block, cout block k2
-                    const int pw = NCBW == 2 && CB == 2 ? (g * 4 + oi + 2 * k2) : ((tb0 / NTBW * (CB / NCBW) + (k2 >> 1)) * 4 + oi + 2 * (k2 & 1));
-                    if (k2 == kw) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sum[r] += (v == 0 ? acc2[0][0][r] : v == 1 ? acc2[0][1][r] : v == 2 ? acc2[1][0][r] : acc2[1][1][r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) sum[r] += X2[((pw * 4 + v) * 16 + r) * 64 + lane];
-                    }
-                }
-                const int jcol = v & 1;
+            for (int k = 0; k < 2; ++k) {
+                const f32x16 t0 = acc[0][k] + acc[1][k] + acc[2][k];
+                const f32x16 t1 = acc[1][k] - acc[2][k] - acc[3][k];
+                if (k == blk) own = oi ? t1 : t0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float o2 = sum[r] + bs2[r];
-                    if (a.relu2) o2 = fmaxf(o2, 0.f);
-                    if (!NHWC) {
-                        const int c2 = m2o * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (ok && c2 < COUT2 && ox + jcol < a.W) a.out[(((size_t)b * COUT2 + c2) * a.H + oy) * a.W + ox + jcol] = o2;
+                    if (!(k == blk && oi == 0)) X[((wave * 4 + 0 + k) * 16 + r) * 64 + lane] = t0[r];
+                    if (!(k == blk && oi == 1)) X[((wave * 4 + 2 + k) * 16 + r) * 64 + lane] = t1[r];
+                }
+            }
+            if (tr && tid == 0) tr[11] = __builtin_amdgcn_s_memtime();
+            dma_barrier();
+            if (tr && tid == 0) tr[12] = __builtin_amdgcn_s_memtime();
+            const float* Xg = X + ((g * 4) * 4 + oi * 2 + blk) * 16 * 64 + lane;      // + nu' * 4*16*64
+            const int t = tbk * 32 + l31;
+            const int ty = t / TTW, tx = t - ty * TTW;
+            const int oy = oy0 + 2 * ty + oi, ox = ox0 + 2 * tx;
+            const bool ok = t < TTH * TTW && oy < a.H && ox < a.W;
+            const bool pair = ox + 1 < a.W;
+            float* op = a.out + ((size_t)b * COUT * a.H + oy) * a.W + ox;
+            const bool al8 = ((a.W & 1) == 0);          // ox is even: rows are 8-byte aligned iff W is even
+            // coefficients of T_nu in (Y[.][0], Y[.][1]): nu 0: (1,0)  1: (1,1)  2: (1,-1)  3: (0,-1)
+            float y0[16], y1[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y0[r] = nu == 3 ? 0.f : own[r];
+                y1[r] = nu == 0 ? 0.f : (nu == 1 ? own[r] : -own[r]);
+            }
+#pragma unroll
+            for (int n2 = 0; n2 < 4; ++n2) {
+                if (n2 == nu) continue;          // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = Xg[(n2 * 64 + r) * 64];
+                    if (n2 != 3) y0[r] += v;
+                    if (n2 == 1) y1[r] += v;
+                    if (n2 >= 2) y1[r] -= v;
+                }
+            }
+            if (tr && tid == 0) tr[13] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                y0[r] += bs[r]; y1[r] += bs[r];
+                if (a.relu) { y0[r] = fmaxf(y0[r], 0.f); y1[r] = fmaxf(y1[r], 0.f); }
+            }
+            if constexpr (COUT2 == 0) {
+                if (ok) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (co < COUT) {
+                            float* o = op + (size_t)co * HW;
+                            if (pair && al8) *reinterpret_cast<float2*>(o) = make_float2(y0[r], y1[r]);
+                            else { o[0] = y0[r]; if (pair) o[1] = y1[r]; }
+                        }
+                    }
+                }
+            } else {
+                // ---- fused trailing 1x1 (block3.1+3.2, block5.2+5.3, block_fusion.1+.2) --------------------
+                // Register r of y holds, for this lane's tile, channel cbk*32 + (r&3)+8(r>>2) + 4*half: pairing
+                // channels (c, c+4) makes y[r] THE B operand (A for channels-last) of the 1x1 GEMM -- no LDS
+                // round trip for the activations.  This wave covers the K slice of its cout block cbk; the
+                // KW = CB waves sharing (output row, tile block) add their partial sums through LDS.
+                const float* W2l = smem + Cfg::W2_OFF;
+                f32x16 acc2[2][2];         // [m2][pixel column j]
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[m2][j][r] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kc = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float w0 = W2l[kc * COUT2_PAD + l31], w1 = W2l[kc * COUT2_PAD + 32 + l31];
+                    if (NHWC) {
+                        acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0[r], w0, acc2[0][0], 0, 0, 0);
+                        acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1[r], w0, acc2[0][1], 0, 0, 0);
+                        acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(y0[r], w1, acc2[1][0], 0, 0, 0);
+                        acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(y1[r], w1, acc2[1][1], 0, 0, 0);
                     } else {
-                        const int t2 = tbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // D rows are tiles
-                        const int ty2 = t2 / TTW, tx2 = t2 - ty2 * TTW;
-                        const int oy2 = oy0 + 2 * ty2 + oi, ox2 = ox0 + 2 * tx2 + jcol;
-                        const int c2 = m2o * 32 + l31;
-                        if (t2 < TTH * TTW && oy2 < a.H && ox2 < a.W && c2 < COUT2) a.out[(((size_t)b * a.H + oy2) * a.W + ox2) * COUT2 + c2] = o2;
+                        acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, y0[r], acc2[0][0], 0, 0, 0);
+                        acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, y1[r], acc2[0][1], 0, 0, 0);
+                        acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, y0[r], acc2[1][0], 0, 0, 0);
+                        acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, y1[r], acc2[1][1], 0, 0, 0);
+                    }
+                }
+                // K-split reduction: KW waves (kw = index of this wave's cout block) hold partial sums of the same
+                // outputs.  Vector v = m2*2 + j is finished by wave kw = v*KW/4 (KW = 2: one m2, both columns).
+                constexpr int KW = CB, VPW = 4 / KW;
+                static_assert(KW == 2 || KW == 4, "K split over 2 or 4 waves");
+                const int kw = cbk;                         // 0 .. KW-1
+                dma_barrier();                              // every wave has finished reading the first exchange
+                float* X2 = smem;                           // [wave][v][16 r][64 lanes]
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    if (v / VPW == kw) continue;            // wave-uniform: own vectors stay in registers
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) X2[((wave * 4 + v) * 16 + r) * 64 + lane] = acc2[v >> 1][v & 1][r];
+                }
+                dma_barrier();
+                float bs2[16];
+                const int m2o = (kw * VPW) >> 1;            // the m2 block this wave finishes
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bs2[r] = NHWC ? a.bias2[m2o * 32 + l31] : a.bias2[m2o * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+#pragma unroll
+                for (int vv = 0; vv < VPW; ++vv) {
+                    const int v = kw * VPW + vv;            // wave-uniform
+                    f32x16 sum;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+#pragma unroll
+                    for (int k2 = 0; k2 < KW; ++k2) {        // peers: same output row oi and tile block, cout block k2
+                        const int pw = NCBW == 2 && CB == 2 ? (g * 4 + oi + 2 * k2) : ((tb0 / NTBW * (CB / NCBW) + (k2 >> 1)) * 4 + oi + 2 * (k2 & 1));
+                        if (k2 == kw) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sum[r] += (v == 0 ? acc2[0][0][r] : v == 1 ? acc2[0][1][r] : v == 2 ? acc2[1][0][r] : acc2[1][1][r]);
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) sum[r] += X2[((pw * 4 + v) * 16 + r) * 64 + lane];
+                        }
+                    }
+                    const int jcol = v & 1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float o2 = sum[r] + bs2[r];
+                        if (a.relu2) o2 = fmaxf(o2, 0.f);
+                        if (!NHWC) {
+                            const int c2 = m2o * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (ok && c2 < COUT2 && ox + jcol < a.W) a.out[(((size_t)b * COUT2 + c2) * a.H + oy) * a.W + ox + jcol] = o2;
+                        } else {
+                            const int t2 = tbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;      // D rows are tiles
+                            const int ty2 = t2 / TTW, tx2 = t2 - ty2 * TTW;
+                            const int oy2 = oy0 + 2 * ty2 + oi, ox2 = ox0 + 2 * tx2 + jcol;
+                            const int c2 = m2o * 32 + l31;
+                            if (t2 < TTH * TTW && oy2 < a.H && ox2 < a.W && c2 < COUT2) a.out[(((size_t)b * a.H + oy2) * a.W + ox2) * COUT2 + c2] = o2;
+                        }
                     }
                 }
             }
+            if (tr && tid == 0) { tr[21] = __builtin_amdgcn_s_memtime(); tr[23] = __builtin_amdgcn_s_memrealtime(); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); tr[22] = ((long long)xcc << 32) | hwid; }
+            break;
         }
-        if (tr && tid == 0) { tr[21] = __builtin_amdgcn_s_memtime(); tr[23] = __builtin_amdgcn_s_memrealtime(); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); tr[22] = ((long long)xcc << 32) | hwid; }
+        }   // tile loop
+        if constexpr (PERSIST) {     // drain the last tile's outputs
+            dma_barrier();
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) { slice_load(i, it); slice_store(); }       // NCH * CPC >= COUT_PAD: every channel leaves
+        }
     };
     // the two waves of a SIMD (g even / odd) run complementary schedules
     if ((g & 1) == 0) body(std::integral_constant<int, 0>{});
@@ -444,9 +573,9 @@ void conv_wino_kernel(WinoArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2 = 0, bool NHWC = false>
+template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2 = 0, bool NHWC = false, bool PERSIST = false>
 static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2 = nullptr) {
-    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
+    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, PERSIST>;
     if ((size_t)c.cin * H * W * sizeof(float) >= 0x7fffffffu) return -1;     // buffer-resource range
     WinoArgs a;
     a.in = in; a.wu = c.w_wino; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
@@ -458,11 +587,13 @@ static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float*
     static_assert(Cfg::LDS_FLOATS * sizeof(float) <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC, PERSIST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC><<<xcd_grid_size(a.tiles, B), Cfg::NTHR, lds, st>>>(a);
+    int grid = xcd_grid_size(a.tiles, B);
+    if (PERSIST && grid > 256) grid = 256;          // one workgroup per CU walks the tiles (256 % 8 == 0 keeps the XCD mapping)
+    conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC, PERSIST><<<grid, Cfg::NTHR, lds, st>>>(a);
     return 0;
 }
 
@@ -473,6 +604,8 @@ int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B,
     (void)zeros;
     if (c.ks != 3 || c.stride != 1 || !c.w_wino) return -1;
     const int key = c.cin * 1000 + c.cout;
+    static int tune = -1;          // XFH_WINO_TUNE (A/B runs) bit 0: persistent 64-channel variant, bit 1: 4-wave 24-channel variant
+    if (tune < 0) { const char* e = getenv("XFH_WINO_TUNE"); tune = e ? atoi(e) : 0; }
     if (c2) {      // 3x3 + fused 1x1
         if (c2->ks != 1 || c2->cin != c.cout || c2->cout != 64) return -1;
         const bool tall = wino_groups(H, W, 8, 4) < wino_groups(H, W, 4, 8);
@@ -491,10 +624,13 @@ int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B,
     // cfg 0 = the production choice; cfg >= 1 = explicit variants (xfh_conv_layer variant 2, 3, ... for tuning)
     switch (key) {
         case 24 * 1000 + 24:     // 1 cout block: waves hold 2 tile blocks each
-            if (cfg == 2) return run_wino<24, 24, 1, 2, 1, 2, 8, 8>(c, in, B, H, W, out, st, trace);        // 4-wave workgroups, 64 tiles
+            if (cfg == 2 || (cfg == 0 && (tune & 2))) return run_wino<24, 24, 1, 2, 1, 2, 8, 8>(c, in, B, H, W, out, st, trace);   // 4-wave workgroups, 64 tiles, two per CU
             return run_wino<24, 24, 1, 4, 1, 2, 8, 16>(c, in, B, H, W, out, st, trace);                      // 8 waves, 128 tiles
         case 64 * 1000 + 64:     // waves hold both cout blocks of one tile block
             if (cfg == 2) return run_wino<64, 64, 2, 2, 2, 1, 8, 8>(c, in, B, H, W, out, st, trace);        // 8 waves, 64 tiles
+            // persistent 8-wave workgroups (stores of tile k leave under the MFMAs of tile k+1): -11 % back to back on a hot
+            // cache, -2 % inside the real step (tools/layer_insitu.py) -> not the default; XFH_WINO_TUNE=1 selects it
+            if (cfg == 5 || (cfg == 0 && (tune & 1) && wino_groups(H, W, 8, 8) * B >= 1024)) return run_wino<64, 64, 2, 2, 2, 1, 8, 8, 0, false, true>(c, in, B, H, W, out, st, trace);
             if (cfg == 3) return run_wino<64, 64, 2, 2, 2, 1, 16, 4>(c, in, B, H, W, out, st, trace);
             if (cfg == 4 || (cfg == 0 && wino_groups(H, W, 8, 4) < wino_groups(H, W, 4, 8)))
                 return run_wino<64, 64, 2, 1, 2, 1, 8, 4>(c, in, B, H, W, out, st, trace);

@@ -508,3 +508,27 @@ def test_repeated_backbone_and_sparse_path_bit_identical(xf):
         assert nm.cpu().tolist() == n0, rep
         for p in (0, 7, 31):
             assert torch.equal(i0[p, :n0[p]], i00[p, :n0[p]]) and torch.equal(i1[p, :n0[p]], i10[p, :n0[p]]), (rep, p)
+
+
+def test_winograd_configurations_match_generic_kernel(xf):
+    """Every Winograd configuration of xfh_conv_layer (variants 2..6: workgroup shapes, 4/8 waves, persistent) against the
+    generic direct kernel, on odd / small / non-multiple-of-8 shapes (scalar-store path, clipped regions, B not a multiple of 8)."""
+    from accelerated_features_amd.spec import CONVS, CONV_INDEX
+    lib = _lib().load()
+    h = xf.net.handle()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n_checked = 0
+    for name in ("block2.0", "block3.1", "block5.1"):
+        c = next(c for c in CONVS if c.name == name)
+        for (B, hh, ww) in ((3, 41, 41), (2, 60, 80), (9, 30, 40), (8, 15, 20), (1, 6, 10)):
+            x = torch.randn(B, c.cin, hh, ww, device="cuda", generator=g)
+            ref = torch.empty(B, c.cout, hh, ww, device="cuda")
+            assert lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(ref.data_ptr()), 1, None) == 0
+            for variant in (0, 2, 3, 4, 5, 6):
+                y = torch.full_like(ref, float("nan"))
+                rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
+                assert rc == 0, (name, variant, lib.xfh_last_error())
+                err = float((y - ref).abs().nan_to_num(1e9).max())
+                assert err <= 2e-4, (name, (B, hh, ww), variant, err)
+                n_checked += 1
+    assert n_checked == 3 * 5 * 6

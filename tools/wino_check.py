@@ -26,7 +26,7 @@ for (B, H, W) in ((64, 480, 640), (8, 1312, 1312), (3, 480, 640)):
         t = {}
         errs = {2: err}
         if os.environ.get('XFH_WINO', '1') != '0': print('note: variant 0 is the Winograd path unless XFH_WINO=0', end=' ')
-        for v in (0, 2, 3, 4, 5):
+        for v in (0, 2, 3, 4, 5, 6):
             if v > 2:
                 y.fill_(float("nan"))
                 if lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(y.data_ptr()), v, None):
