@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XFH_LIB_PATH") or os.path.join(_HERE, "libxfeat_hip.so")   # override: A/B builds only
 
 XFH_OK = 0
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 PROF_NONE, PROF_CONV_MFMA, PROF_MATCH, PROF_BLOCK1, PROF_HEADS, PROF_CONV_64_64_S1, PROF_CONV_LAYER0 = 0, 1, 2, 3, 4, 5, 100
 
 # name -> (restype, argtypes); mirrors include/xfeat_hip.h one to one
@@ -28,6 +29,7 @@ SIGNATURES = {
     "xfh_resize_bilinear": (_i, [_p, _i, _i, _i, _p, _i, _i, _f, _f, _p]),
     "xfh_backbone_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "xfh_backbone": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "xfh_backbone_u8": (_i, [_p, _p, _i, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "xfh_conv_layer": (_i, [_p, _i, _p, _i, _i, _i, _p, _i, _p]),
     "xfh_detect_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "xfh_detect_sparse": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),

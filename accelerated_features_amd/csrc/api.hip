@@ -404,9 +404,10 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     return XFH_OK;
 }
 
-int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, float* feats, float* logits, float* heat,
-                 float* reliab, void* workspace, size_t workspace_bytes, xfh_stream stream) {
-    if (!h || !img || !feats || !reliab) return fail(XFH_ERR_ARG, "xfh_backbone: NULL argument");
+static int backbone_impl(xfh_handle h, const float* img, const unsigned char* img_u8, int u8_layout, float u8_divisor, int B, int C, int H,
+                         int W, float* feats, float* logits, float* heat, float* reliab, void* workspace, size_t workspace_bytes,
+                         xfh_stream stream) {
+    if (!h || (!img && !img_u8) || !feats || !reliab) return fail(XFH_ERR_ARG, "xfh_backbone: NULL argument");
     if (!logits && !heat) return fail(XFH_ERR_ARG, "xfh_backbone: logits and heat are both NULL");
     int rc = check_img("xfh_backbone", B, C, H, W);
     if (rc) return rc;
@@ -417,7 +418,8 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, flo
     const NetWeights& nw = h->nw;
     const int H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
 
-    launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
+    if (img_u8) launch_gray_norm_u8(img_u8, u8_layout == XFH_LAYOUT_NHWC, u8_divisor, B, C, H, W, w.part, w.gray, w.coef, st);
+    else launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
     launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st);
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 0, 0);
@@ -444,6 +446,18 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, flo
     launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st);
     prof_end(&h->prof, XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
+}
+
+int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, float* feats, float* logits, float* heat,
+                 float* reliab, void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    return backbone_impl(h, img, nullptr, 0, 1.f, B, C, H, W, feats, logits, heat, reliab, workspace, workspace_bytes, stream);
+}
+
+int xfh_backbone_u8(xfh_handle h, const uint8_t* img, int layout, float divisor, int B, int C, int H, int W, float* feats,
+                    float* logits, float* heat, float* reliab, void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    if (layout != XFH_LAYOUT_NCHW && layout != XFH_LAYOUT_NHWC) return fail(XFH_ERR_ARG, "xfh_backbone_u8: layout must be XFH_LAYOUT_NCHW or XFH_LAYOUT_NHWC");
+    if (!(divisor > 0.f)) return fail(XFH_ERR_ARG, "xfh_backbone_u8: divisor must be positive");
+    return backbone_impl(h, nullptr, img, layout, divisor, B, C, H, W, feats, logits, heat, reliab, workspace, workspace_bytes, stream);
 }
 
 int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out, int variant,

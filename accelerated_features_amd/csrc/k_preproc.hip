@@ -39,6 +39,54 @@ __global__ __launch_bounds__(256) void gray_stats_kernel(const float* __restrict
     }
 }
 
+// uint8 ingest (XFeat.parse_input / .float(): modules/xfeat.py:396-403, 232): the same statistics + raw gray from
+// (B,C,H,W) or (B,H,W,C) bytes.  Per channel v = float(u8) / divisor (IEEE division, divisor 255 for parse_input's
+// numpy path, 1 for a uint8 tensor handed to detectAndCompute), then the channel mean exactly as the fp32 kernel does
+// (sequential sum, one division) -- bit-identical to converting on the host, with a quarter of the bytes moved.
+template <bool NHWC>
+__global__ __launch_bounds__(256) void gray_stats_u8_kernel(const unsigned char* __restrict__ img, int C, int HW, float divisor,
+                                                            double* __restrict__ part, float* __restrict__ gray) {
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int n4 = HW >> 2;
+    const int per = ceil_div(n4, GS_CHUNKS);
+    const int beg = ch * per, end = min(beg + per, n4);
+    const unsigned char* base = img + (size_t)b * C * HW;
+    const float fC = (float)C;
+    double s = 0.0, q = 0.0;
+    for (int i = beg + tid; i < end; i += 256) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (NHWC) {
+            const unsigned char* p = base + (size_t)i * 4 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float acc = (float)p[k * C] / divisor;
+                for (int c = 1; c < C; ++c) acc += (float)p[k * C + c] / divisor;
+                a[k] = acc;
+            }
+        } else {
+            uchar4 v = reinterpret_cast<const uchar4*>(base)[i];
+            a[0] = (float)v.x / divisor; a[1] = (float)v.y / divisor; a[2] = (float)v.z / divisor; a[3] = (float)v.w / divisor;
+            for (int c = 1; c < C; ++c) {
+                v = reinterpret_cast<const uchar4*>(base + (size_t)c * HW)[i];
+                a[0] += (float)v.x / divisor; a[1] += (float)v.y / divisor; a[2] += (float)v.z / divisor; a[3] += (float)v.w / divisor;
+            }
+        }
+        float4 g4 = make_float4(a[0] / fC, a[1] / fC, a[2] / fC, a[3] / fC);
+        reinterpret_cast<float4*>(gray + (size_t)b * HW)[i] = g4;
+        s += (double)g4.x + (double)g4.y + (double)g4.z + (double)g4.w;
+        q += (double)g4.x * g4.x + (double)g4.y * g4.y + (double)g4.z * g4.z + (double)g4.w * g4.w;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    __shared__ double sm[8];
+    if ((tid & 63) == 0) { sm[(tid >> 6) * 2] = s; sm[(tid >> 6) * 2 + 1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        part[((size_t)b * GS_CHUNKS + ch) * 2 + 0] = sm[0] + sm[2] + sm[4] + sm[6];
+        part[((size_t)b * GS_CHUNKS + ch) * 2 + 1] = sm[1] + sm[3] + sm[5] + sm[7];
+    }
+}
+
 // InstanceNorm2d(1) as a per-image affine map: x = fmaf(gray, alpha, beta), alpha = 1/sqrt(var+eps), beta = -mean*alpha.
 // The map is applied by the two consumers of the image (block1 tile load, key-point head operand load) instead of
 // a separate pass over the image (one read + one write of the RGB / gray planes less per frame).
@@ -63,6 +111,14 @@ void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part
     static_assert(GS_CHUNKS == 64, "gray_coef_kernel reduces one wave of partial sums");
     const int HW = H * W;
     gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, part, gray);
+    gray_coef_kernel<<<B, 64, 0, st>>>(part, HW, 1e-5f, coef);
+}
+
+void launch_gray_norm_u8(const unsigned char* img, bool nhwc, float divisor, int B, int C, int H, int W, double* part, float* gray,
+                         float* coef, hipStream_t st) {
+    const int HW = H * W;
+    if (nhwc) gray_stats_u8_kernel<true><<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, divisor, part, gray);
+    else gray_stats_u8_kernel<false><<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, divisor, part, gray);
     gray_coef_kernel<<<B, 64, 0, st>>>(part, HW, 1e-5f, coef);
 }
 

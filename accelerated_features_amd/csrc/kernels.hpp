@@ -40,6 +40,8 @@ struct Profiler;   // api.hip
 // ---- k_preproc.hip ----------------------------------------------------------------------
 // gray = channel mean (raw), coef[b] = {alpha, beta} of the instance norm x = fmaf(gray, alpha, beta)
 void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, float* coef, hipStream_t st);
+void launch_gray_norm_u8(const unsigned char* img, bool nhwc, float divisor, int B, int C, int H, int W, double* part, float* gray,
+                         float* coef, hipStream_t st);
 void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,
                             float sh, float sw, hipStream_t st);
 void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int planes,

@@ -53,6 +53,18 @@ class _FineMatcher(_Group):
         return self._owner()._fine_matcher(x)
 
 
+class _U8Image:
+    """uint8 pixels on the device plus the divisor the reference applies on the host (255 in parse_input, 1 for .float()).
+    Internal: lets match_xfeat / match_xfeat_star keep numpy images as bytes all the way into xfh_backbone_u8."""
+
+    def __init__(self, data, divisor):
+        self.data, self.divisor = data, divisor
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+
 class XFeatModel(nn.Module):
     """Parameter container with the reference's ``state_dict`` keys (modules/model.py:33-111);
     ``forward`` runs the HIP backbone and returns the same triple as the reference:
@@ -156,11 +168,17 @@ class XFeatModel(nn.Module):
     # -- the network -----------------------------------------------------------------------------
     def backbone(self, x, want_logits=True, want_heat=False):
         """x (B,C,H,W) float32 CUDA, H%32==W%32==0 -> (feats_cl (B,h,w,64), logits_cl|None, heat|None, rel (B,h,w))."""
-        if x.dim() != 4:
+        if len(x.shape) != 4:
             raise RuntimeError("Input tensor needs to be in (B,C,H,W) format")
         lib = _lib.load()
         h = self.handle()
-        x = x.contiguous().float()
+        u8_div = None
+        if isinstance(x, _U8Image):
+            x, u8_div = x.data, x.divisor
+        elif x.dtype == torch.uint8:
+            u8_div = 1.0                    # reference: x.float() (modules/xfeat.py:232), no scaling
+        if u8_div is None:
+            x = x.contiguous().float()
         B, Cc, H, W = x.shape
         hc, wc = H // 8, W // 8
         dev = x.device
@@ -169,6 +187,16 @@ class XFeatModel(nn.Module):
         logits = torch.empty((B, hc, wc, 65), dtype=torch.float32, device=dev) if want_logits else None
         heat = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_heat else None
         ws, n = self.workspace("backbone", lib.xfh_backbone_workspace_bytes(B, Cc, H, W))
+        if u8_div is not None:
+            # uint8 pixels go to the device as they are (a quarter of the bytes); numpy HWC images arrive as a permuted
+            # view whose memory is (B,H,W,C): no host-side transpose either
+            if x.permute(0, 2, 3, 1).is_contiguous() and not x.is_contiguous():
+                layout, xb = _lib.LAYOUT_NHWC, x
+            else:
+                layout, xb = _lib.LAYOUT_NCHW, x.contiguous()
+            _lib.check(lib.xfh_backbone_u8(h, _ptr(xb), layout, float(u8_div), B, Cc, H, W, _ptr(feats), _ptr(logits), _ptr(heat),
+                                           _ptr(rel), _ptr(ws), n, _stream()), "xfh_backbone_u8")
+            return feats, logits, heat, rel
         _lib.check(lib.xfh_backbone(h, _ptr(x), B, Cc, H, W, _ptr(feats), _ptr(logits), _ptr(heat), _ptr(rel),
                                     _ptr(ws), n, _stream()), "xfh_backbone")
         return feats, logits, heat, rel
@@ -308,8 +336,8 @@ class XFeat(nn.Module):
                 mkpts_0, mkpts_1 -> np.ndarray (N,2) xy coordinate matches from image1 to image2
         """
         if top_k is None: top_k = self.top_k
-        img1 = self.parse_input(img1)
-        img2 = self.parse_input(img2)
+        img1 = self._parse_input_fast(img1)
+        img2 = self._parse_input_fast(img2)
 
         out1 = self.detectAndCompute(img1, top_k=top_k)[0]
         out2 = self.detectAndCompute(img2, top_k=top_k)[0]
@@ -327,7 +355,7 @@ class XFeat(nn.Module):
                            for B == 1 a tuple of two numpy (N,2) arrays, like the reference.
         """
         if top_k is None: top_k = self.top_k
-        im_set1 = self.parse_input(im_set1)
+        im_set1 = self.parse_input(im_set1)          # the dual-scale path resizes first: it needs the float image
         im_set2 = self.parse_input(im_set2)
 
         out1 = self.detectAndComputeDense(im_set1, top_k=top_k)
@@ -357,13 +385,19 @@ class XFeat(nn.Module):
             raise RuntimeError('Input tensor needs to be in (B,C,H,W) format')
 
         self._require_gpu()
-        x = x.to(self.dev).float().contiguous()
-
         H, W = x.shape[-2:]
         _H, _W = (H // 32) * 32, (W // 32) * 32
         if _H == 0 or _W == 0:
             raise RuntimeError('Input image must be at least 32x32 pixels')
         rh, rw = H / _H, W / _W
+        if (_H, _W) == (H, W) and (isinstance(x, _U8Image) or x.dtype == torch.uint8):
+            # bytes stay bytes: the conversion (and parse_input's /255) happens inside xfh_backbone_u8
+            if isinstance(x, _U8Image):
+                return _U8Image(x.data.to(self.dev), x.divisor), rh, rw
+            return x.to(self.dev), rh, rw
+        if isinstance(x, _U8Image):
+            x = x.data / x.divisor                              # resize path: convert like the reference, then interpolate
+        x = x.to(self.dev).float().contiguous()
         if (_H, _W) != (H, W):
             x = self._resize(x, _H, _W, np.float32(H) / np.float32(_H), np.float32(W) / np.float32(_W))
         return x, rh, rw
@@ -562,3 +596,11 @@ class XFeat(nn.Module):
             x = torch.tensor(x).permute(0, 3, 1, 2) / 255
 
         return x
+
+    def _parse_input_fast(self, x):
+        """parse_input for the matchers: a uint8 numpy image keeps its bytes (the /255 moves into the ingest kernel)."""
+        if isinstance(x, np.ndarray) and x.dtype == np.uint8 and len(x.shape) in (3, 4):
+            if len(x.shape) == 3:
+                x = x[None, ...]
+            return _U8Image(torch.from_numpy(np.ascontiguousarray(x)).permute(0, 3, 1, 2), 255.0)
+        return self.parse_input(x)

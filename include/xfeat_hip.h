@@ -96,6 +96,16 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W,
                  float* feats, float* logits, float* heat, float* reliab,
                  void* workspace, size_t workspace_bytes, xfh_stream stream);
 
+/* Same network from uint8 pixels: replaces the host-side conversion in front of it --
+ * XFeat.parse_input's `torch.tensor(x).permute(0,3,1,2) / 255` for numpy images (modules/xfeat.py:396-403, divisor 255,
+ * layout XFH_LAYOUT_NHWC) and preprocess_tensor's `x.float()` for uint8 tensors (modules/xfeat.py:232, divisor 1,
+ * layout XFH_LAYOUT_NCHW).  Per channel v = float(u8) / divisor; results are bit-identical to converting first. */
+#define XFH_LAYOUT_NCHW 0
+#define XFH_LAYOUT_NHWC 1
+int xfh_backbone_u8(xfh_handle h, const uint8_t* img, int layout, float divisor, int B, int C, int H, int W,
+                    float* feats, float* logits, float* heat, float* reliab,
+                    void* workspace, size_t workspace_bytes, xfh_stream stream);
+
 /* One conv layer of the network in isolation (parity tests against per-layer oracle
  * activations).  layer = index into spec.CONVS; in (B,Cin,Hin,Win) NCHW, out (B,Cout,Hout,Wout)
  * NCHW with the layer's own stride/padding, folded BN and ReLU where the reference has them.

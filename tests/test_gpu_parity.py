@@ -532,3 +532,29 @@ def test_winograd_configurations_match_generic_kernel(xf):
                 assert err <= 2e-4, (name, (B, hh, ww), variant, err)
                 n_checked += 1
     assert n_checked == 3 * 5 * 6
+
+
+def test_uint8_ingest_is_bit_identical_to_host_conversion(xf):
+    """xfh_backbone_u8: uint8 pixels, NCHW tensor (divisor 1, `.float()`) and numpy HWC image (divisor 255,
+    parse_input) against the fp32 entry fed with the host-converted image: bit-identical network outputs and key-points."""
+    rs = np.random.RandomState(5)
+    img = (fixtures.texture_images(3, 96, 128, seed=21) * 255).round().clamp(0, 255).to(torch.uint8)      # (3,3,96,128) u8
+    # (a) uint8 tensor: the reference calls x.float()
+    f_a, l_a, h_a, r_a = xf.net.backbone(img.cuda(), want_logits=True, want_heat=True)
+    f_b, l_b, h_b, r_b = xf.net.backbone(img.float().cuda(), want_logits=True, want_heat=True)
+    for u, v in ((f_a, f_b), (l_a, l_b), (h_a, h_b), (r_a, r_b)):
+        assert torch.equal(u, v)
+    # (b) numpy HWC uint8 through match_xfeat's parse path vs the public parse_input (/255 on the host)
+    hwc = np.ascontiguousarray(img[0].permute(1, 2, 0).numpy())
+    fast = xf._parse_input_fast(hwc)
+    slow = xf.parse_input(hwc)
+    o_fast = xf.detectAndCompute(fast, top_k=512)[0]
+    o_slow = xf.detectAndCompute(slow, top_k=512)[0]
+    for k in ("keypoints", "scores", "descriptors"):
+        assert torch.equal(o_fast[k], o_slow[k]), k
+    # (c) gray-scale (H,W) numpy image handed to detectAndCompute (no /255 there, modules/xfeat.py:221-225)
+    g = rs.randint(0, 256, size=(64, 96)).astype(np.uint8)
+    o_u8 = xf.detectAndCompute(g, top_k=256)[0]
+    o_f = xf.detectAndCompute(torch.from_numpy(g)[None, None].float(), top_k=256)[0]
+    for k in ("keypoints", "scores", "descriptors"):
+        assert torch.equal(o_u8[k], o_f[k]), k
