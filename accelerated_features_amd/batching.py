@@ -1,0 +1,88 @@
+"""Batched pair matching for evaluation runners.
+
+The reference's benchmarks call `matcher_fn(img0, img1)` one pair at a time
+(modules/eval/megadepth1500.py:199-237, scannet1500.py:255-300).  On an MI355X a single VGA pair
+leaves the device almost idle; this runner takes the whole list of pairs, groups it by image size,
+pushes each group through `XFeat._detect_device` + `XFeat.match_pairs_device` in batches of up to
+`max_pairs`, and reads back one small tensor of counts per batch.  The results are exactly what
+`XFeat.match_xfeat` returns pair by pair (results do not depend on batch composition; checked by
+tests/test_gpu_parity.py), in the original order.
+"""
+import numpy as np
+import torch
+
+from .sharding import shard_range
+
+
+def _as_nchw(img):
+    """One image -> (C,H,W) tensor and the divisor parse_input would apply (255 for uint8 numpy HWC)."""
+    if isinstance(img, np.ndarray):
+        if img.ndim == 2:
+            img = img[..., None]
+        if img.ndim != 3:
+            raise RuntimeError('For numpy arrays, only (H,W) or (H,W,C) format is supported.')
+        t = torch.from_numpy(np.ascontiguousarray(img)).permute(2, 0, 1)
+        return (t, 255.0) if img.dtype == np.uint8 else (t / 255, None)
+    if img.dim() == 4 and img.shape[0] == 1:
+        img = img[0]
+    if img.dim() != 3:
+        raise RuntimeError('Input tensor needs to be in (C,H,W) or (1,C,H,W) format')
+    return img, None
+
+
+def match_pairs(xfeat, pairs, top_k=None, min_cossim=-1, max_pairs=32, rank=0, world=1):
+    """pairs: sequence of (img0, img1), each a numpy (H,W[,C]) image (scaled by 1/255 like
+    XFeat.parse_input) or a (C,H,W) / (1,C,H,W) tensor.  Returns a list (same order, only this rank's
+    shard when world > 1) of (mkpts0, mkpts1) numpy float32 (N,2) arrays -- XFeat.match_xfeat's result.
+    """
+    from .xfeat import _U8Image
+    if top_k is None:
+        top_k = xfeat.top_k
+    lo, hi = shard_range(len(pairs), rank, world)
+    items = []
+    for i in range(lo, hi):
+        a, da = _as_nchw(pairs[i][0])
+        b, db = _as_nchw(pairs[i][1])
+        items.append((i, a, da, b, db))
+    groups = {}
+    for it in items:
+        key = (tuple(it[1].shape), tuple(it[3].shape), it[1].dtype, it[3].dtype, it[2], it[4])
+        groups.setdefault(key, []).append(it)
+    out = {}
+    for key, members in groups.items():
+        same_shape = key[0] == key[1] and key[2] == key[3] and key[4] == key[5]
+        for s in range(0, len(members), max_pairs):
+            chunk = members[s:s + max_pairs]
+            if same_shape:
+                frames = torch.stack([t for it in chunk for t in (it[1], it[3])])        # (2P,C,H,W): frames 2i, 2i+1 = pair i
+                x = _U8Image(frames, key[4]) if key[4] is not None else frames
+                res = _detect_exact(xfeat, x, top_k)
+                kpts, desc, nv = res
+                idx0, idx1, nm = xfeat.match_pairs_device(desc, nv, min_cossim)
+                nm = nm.cpu().tolist()
+                for p, it in enumerate(chunk):
+                    k0 = kpts[2 * p][idx0[p, :nm[p]]]
+                    k1 = kpts[2 * p + 1][idx1[p, :nm[p]]]
+                    out[it[0]] = (k0.cpu().numpy(), k1.cpu().numpy())
+            else:                                   # the two images of a pair differ in size: two batches + per-pair match
+                xa = torch.stack([it[1] for it in chunk])
+                xb = torch.stack([it[3] for it in chunk])
+                xa = _U8Image(xa, key[4]) if key[4] is not None else xa
+                xb = _U8Image(xb, key[5]) if key[5] is not None else xb
+                oa = xfeat.detectAndCompute(xa, top_k=top_k)
+                ob = xfeat.detectAndCompute(xb, top_k=top_k)
+                for p, it in enumerate(chunk):
+                    i0, i1 = xfeat.match(oa[p]['descriptors'], ob[p]['descriptors'], min_cossim=min_cossim)
+                    out[it[0]] = (oa[p]['keypoints'][i0].cpu().numpy(), ob[p]['keypoints'][i1].cpu().numpy())
+    return [out[i] for i in range(lo, hi)]
+
+
+def _detect_exact(xfeat, x, top_k):
+    """_detect_device with the capacity re-run of detectAndCompute (plateau images), results still on the device."""
+    cap = None
+    while True:
+        kpts, scores, desc, n_valid, n_cand, cap, hw = xfeat._detect_device(x, top_k, None, cap)
+        ncmax = int(n_cand.max())
+        if cap >= hw or ncmax <= cap:
+            return kpts, desc, n_valid
+        cap = min(hw, max(ncmax, 2 * cap))

@@ -558,3 +558,33 @@ def test_uint8_ingest_is_bit_identical_to_host_conversion(xf):
     o_f = xf.detectAndCompute(torch.from_numpy(g)[None, None].float(), top_k=256)[0]
     for k in ("keypoints", "scores", "descriptors"):
         assert torch.equal(o_u8[k], o_f[k]), k
+
+
+def test_batched_pair_runner_equals_pairwise_match_xfeat(xf):
+    """accelerated_features_amd.batching.match_pairs: mixed sizes / dtypes in one list, same results and order
+    as XFeat.match_xfeat pair by pair."""
+    from accelerated_features_amd.batching import match_pairs
+    rs = np.random.RandomState(11)
+    def u8(h, w, seed):
+        t = fixtures.texture_images(2, h, w, seed=seed)
+        return [np.ascontiguousarray((t[i] * 255).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()) for i in range(2)]
+    pairs = []
+    for seed, (h, w) in enumerate([(96, 128), (64, 96), (96, 128), (96, 128), (64, 96)]):
+        a, b = u8(h, w, 30 + seed)
+        pairs.append((a, b))
+    a, _ = u8(96, 128, 77); _, b = u8(64, 96, 78)
+    pairs.append((a, b))                                                  # the two images of this pair differ in size
+    pairs.append((fixtures.texture_images(1, 64, 64, seed=5)[0], fixtures.texture_images(1, 64, 64, seed=6)[0]))   # float tensors
+    got = match_pairs(xf, pairs, top_k=512, max_pairs=2)
+    assert len(got) == len(pairs)
+    for (m0, m1), (a, b) in zip(got, pairs):
+        if isinstance(a, torch.Tensor):
+            r0, r1 = xf.match_xfeat(a[None], b[None], top_k=512)
+        else:
+            r0, r1 = xf.match_xfeat(a, b, top_k=512)
+        assert m0.shape == r0.shape and np.array_equal(m0, r0) and np.array_equal(m1, r1)
+    # sharded: rank 1 of 2 gets the second half, same values
+    half = match_pairs(xf, pairs, top_k=512, max_pairs=2, rank=1, world=2)
+    lo = len(pairs) - len(half)
+    for (m0, m1), (r0, r1) in zip(half, got[lo:]):
+        assert np.array_equal(m0, r0) and np.array_equal(m1, r1)
