@@ -588,3 +588,21 @@ def test_batched_pair_runner_equals_pairwise_match_xfeat(xf):
     lo = len(pairs) - len(half)
     for (m0, m1), (r0, r1) in zip(half, got[lo:]):
         assert np.array_equal(m0, r0) and np.array_equal(m1, r1)
+
+
+def test_hipgraph_captured_pipeline_equals_eager(xf):
+    """accelerated_features_amd.graphs.CapturedSparsePipeline: one hipGraph replay per call, same kernels, bit-identical
+    key-points / descriptors / matches; replays stay correct when the input changes."""
+    from accelerated_features_amd.graphs import CapturedSparsePipeline
+    pipe = CapturedSparsePipeline(xf, batch=2, height=96, width=128, top_k=512, match=True)
+    for seed in (41, 42, 43):
+        x = fixtures.texture_images(2, 96, 128, seed=seed).cuda()
+        o = pipe(x)
+        e = xf.detectAndCompute(x, top_k=512)
+        for b in range(2):
+            n = o['n_valid'][b]
+            assert n == e[b]['keypoints'].shape[0]
+            assert torch.equal(o['keypoints'][b, :n], e[b]['keypoints']) and torch.equal(o['scores'][b, :n], e[b]['scores'])
+            assert torch.equal(o['descriptors'][b, :n], e[b]['descriptors'])
+        i0, i1 = xf.match(e[0]['descriptors'], e[1]['descriptors'], min_cossim=-1)
+        assert torch.equal(o['matches'][0][0], i0) and torch.equal(o['matches'][0][1], i1)
