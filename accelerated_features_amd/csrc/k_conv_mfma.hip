@@ -395,7 +395,6 @@ int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, 
     if (fused1x1) {
         if (fused1x1->ks != 1 || fused1x1->cin != c.cout) return -1;
         if (key == 64 * 1000000 + 64 * 1000 + 31 && fused1x1->cout == 64) {
-            if (getenv("XFH_CONV_NB1")) return run<64, 64, 3, 1, 4, 1, 64, 1>(c, fused1x1, zeros, in, B, Hin, Win, out, nhwc, st, trace);
             return run<64, 64, 3, 1, 8, 2, 64>(c, fused1x1, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         }
         if (key == 128 * 1000000 + 128 * 1000 + 31 && fused1x1->cout == 64)
@@ -406,18 +405,14 @@ int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, 
     // heavy -> less tail and more co-resident workgroups on the 30x40 / 15x20 maps
     const int Hout = (Hin + 2 * (c.ks / 2) - c.ks) / c.stride + 1, Wout = (Win + 2 * (c.ks / 2) - c.ks) / c.stride + 1;
     const bool small_map = (long)B * Hout * Wout <= 160L * 1024;
-    static int exp_bits = -1;
-    if (exp_bits < 0) { const char* e = getenv("XFH_EXP"); exp_bits = e ? atoi(e) : 0; }
     switch (key) {
         case 24 * 1000000 + 24 * 1000 + 31:
             // 256-pixel tiles (2 pixel blocks per wave): A/B measured 1 % faster than 512-pixel tiles
-            if (exp_bits & 2) return run<24, 24, 3, 1, 4, 3, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
             return run<24, 24, 3, 1, 4, 2, 0, 2>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         case 24 * 1000000 + 64 * 1000 + 32:
-            if (exp_bits & 1) return run<24, 64, 3, 2, 4, 3, 0, 1>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
             return run<24, 64, 3, 2, 4, 5, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         case 64 * 1000000 + 64 * 1000 + 31:
-            if (small_map || getenv("XFH_CONV_NB1")) return run<64, 64, 3, 1, 4, 1, 0, 1>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
+            if (small_map) return run<64, 64, 3, 1, 4, 1, 0, 1>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
             return run<64, 64, 3, 1, 8, 2, 0>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
         case 64 * 1000000 + 64 * 1000 + 32:
             if (small_map) return run<64, 64, 3, 2, 4, 3, 0, 1>(c, nullptr, zeros, in, B, Hin, Win, out, nhwc, st, trace);
