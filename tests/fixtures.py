@@ -111,3 +111,51 @@ def shifted_pair(B, H, W, seed=7, shift=(16, 24), noise=0.02):
     b = torch.roll(a, shifts=shift, dims=(2, 3)) + torch.from_numpy(
         (noise * rs.randn(B, 3, H, W)).astype(np.float32))
     return a, b
+
+
+# ------------------------------------------------------------------------------------------------------------
+# LighterGlue: synthetic weights in the key layout kornia's LightGlue has after the reference's loader
+# (modules/lighterglue.py:41-48); the trained xfeat-lighterglue.pt is not in the snapshot.
+# ------------------------------------------------------------------------------------------------------------
+def lighterglue_state_dict(seed=0):
+    import numpy as np
+    import torch
+    from oracle.lighterglue_oracle import state_dict_keys
+    rs = np.random.RandomState(1000 + seed)
+    sd = {}
+    for name, shape in state_dict_keys():
+        if name.endswith("ffn.1.weight"):                       # LayerNorm gain
+            v = 1.0 + 0.1 * rs.randn(*shape)
+        elif name.endswith("ffn.1.bias"):
+            v = 0.1 * rs.randn(*shape)
+        elif name == "posenc.Wr.weight":                        # frequencies: a few radians over the image
+            v = 2.0 * rs.randn(*shape)
+        elif name.endswith("matchability.bias"):
+            v = 0.5 + 0.1 * rs.randn(*shape)                    # most points stay matchable: pruning removes a minority
+        elif name.endswith(".bias"):
+            v = 0.05 * rs.randn(*shape)
+        elif name.endswith("matchability.weight") or name.endswith("token.0.weight"):
+            v = rs.randn(*shape) * (1.5 / np.sqrt(shape[-1]))
+        else:                                                   # Linear weights (out, in)
+            v = rs.randn(*shape) * (1.0 / np.sqrt(shape[-1]))
+        sd[name] = torch.from_numpy(v.astype(np.float32))
+    return sd
+
+
+def lighterglue_inputs(n0, n1, seed=0, size0=(640, 480), size1=(640, 480)):
+    """Two sets of key-points (pixels) with unit-norm 64-D descriptors; a third of set 1 are noisy copies of set 0."""
+    import numpy as np
+    import torch
+    rs = np.random.RandomState(2000 + seed)
+    k0 = np.stack([rs.uniform(0, size0[0] - 1, n0), rs.uniform(0, size0[1] - 1, n0)], -1).astype(np.float32)
+    k1 = np.stack([rs.uniform(0, size1[0] - 1, n1), rs.uniform(0, size1[1] - 1, n1)], -1).astype(np.float32)
+    d0 = rs.randn(n0, 64).astype(np.float32)
+    d1 = rs.randn(n1, 64).astype(np.float32)
+    m = min(n0, n1) // 3
+    perm = rs.permutation(n1)[:m]
+    d1[perm] = d0[:m] + 0.05 * rs.randn(m, 64).astype(np.float32)
+    k1[perm] = np.clip(k0[:m] + rs.randn(m, 2).astype(np.float32) * 3, 0, [size1[0] - 1, size1[1] - 1])
+    d0 /= np.linalg.norm(d0, axis=1, keepdims=True)
+    d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    return (torch.from_numpy(k0), torch.from_numpy(d0), torch.tensor(size0, dtype=torch.float32),
+            torch.from_numpy(k1), torch.from_numpy(d1), torch.tensor(size1, dtype=torch.float32))
