@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("XFH_LIB_PATH") or os.path.join(_HERE, "libxfeat_hip.s
 
 XFH_OK = 0
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+LG_NO_PRUNING = 1 << 30
 PROF_NONE, PROF_CONV_MFMA, PROF_MATCH, PROF_BLOCK1, PROF_HEADS, PROF_CONV_64_64_S1, PROF_CONV_LAYER0 = 0, 1, 2, 3, 4, 5, 100
 
 # name -> (restype, argtypes); mirrors include/xfeat_hip.h one to one
@@ -42,6 +43,12 @@ SIGNATURES = {
     "xfh_kpts_heatmap": (_i, [_p, _i, _i, _i, _p, _p]),
     "xfh_nms": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _sz, _p]),
     "xfh_fine_matcher": (_i, [_p, _p, _i, _p, _p, _sz, _p]),
+    "xfh_lg_num_weight_arrays": (_i, []),
+    "xfh_lg_weight_array_floats": (_sz, [_i]),
+    "xfh_lg_create": (_i, [C.POINTER(_p), _i, _i, C.POINTER(_p)]),
+    "xfh_lg_destroy": (None, [_p]),
+    "xfh_lg_workspace_bytes": (_sz, [_i, _i]),
+    "xfh_lg_match": (_i, [_p, _p, _p, _i, _f, _f, _p, _p, _i, _f, _f, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "xfh_profile_select": (_i, [_p, _i]),
     "xfh_debug_trace": (_i, [_p, _p]),
     "xfh_debug_match_occupancy": (_i, []),

@@ -22,6 +22,16 @@ static int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+// for the other translation units of the library (api_lg.hip)
+int xfh_set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    return fail(code, "%s", buf);
+}
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \

@@ -140,4 +140,19 @@ void launch_refine_finish(const float* o /*(T,64)*/, const int32_t* rowmap, cons
 void prof_begin(Profiler* p, int which, hipStream_t st);
 void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
 
+// ---- LighterGlue (k_lighterglue.hip) ----
+void launch_lg_encode(const float* kpts, int N, float W, float H, const float* wr, float* cs, float* sn, hipStream_t st);
+void launch_lg_rotary(float* qkv, int ld, const int32_t* n_dev, int cap, const float* cs, const float* sn, hipStream_t st);
+void launch_lg_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, const int32_t* nq_dev,
+                         const int32_t* nk_dev, int qcap, int kcap, float scale, hipStream_t st);
+void launch_lg_ln_gelu(float* x, int ld, const int32_t* n_dev, int cap, const float* gamma, const float* beta, hipStream_t st);
+void launch_lg_add(float* x, int ldx, const float* y, int ldy, const int32_t* n_dev, int cap, hipStream_t st);
+void launch_lg_dot(const float* x, int ld, const int32_t* n_dev, int cap, const float* w, const float* b, float* z, hipStream_t st);
+void launch_lg_prune(const float* z, float thr, int min_kpts, const int32_t* n_in, int cap, int32_t* map, int32_t* n_out, const float* x, int ldx, float* xo,
+                     const float* cs, float* cso, const float* sn, float* sno, const int32_t* ind, int32_t* indo, hipStream_t st);
+void launch_lg_transpose(const float* x, int ld, const int32_t* n_dev, int cap, float* xt, int npad, hipStream_t st);
+void launch_lg_assign(const float* sim, int ld, const int32_t* n0_dev, int cap0, const int32_t* n1_dev, int cap1, const float* z0, const float* z1,
+                      float* rlse, float* clse, int32_t* m0, int32_t* m1, float* best0, const int32_t* ind0, const int32_t* ind1, float thr,
+                      int64_t* matches, float* scores, int32_t* n_out, hipStream_t st);
+
 }  // namespace xfh

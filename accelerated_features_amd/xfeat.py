@@ -323,10 +323,24 @@ class XFeat(nn.Module):
 
     @torch.inference_mode()
     def match_lighterglue(self, d0, d1, min_conf=0.1):
-        """LighterGlue (modules/lighterglue.py -> kornia LightGlue) is not part of this build
-        (next component; kornia is absent, parity unpinned)."""
-        raise RuntimeError('We rely on kornia for LightGlue. Install with: pip install kornia '
-                           '(match_lighterglue is not implemented in accelerated_features_amd yet)')
+        """
+            Match XFeat sparse features with LightGlue (smaller version) -- one pair per call, like the reference
+            (/root/reference/modules/xfeat.py:131-162).
+            input:
+                d0, d1: Dict('keypoints', 'scores, 'descriptors', 'image_size (Width, Height)')
+            output:
+                mkpts_0, mkpts_1 -> np.ndarray (N,2) xy coordinate matches from image1 to image2
+                idx              -> np.ndarray (N,2) the indices of the matching features
+        """
+        self._require_gpu()
+        if self.lighterglue is None:
+            from .lighterglue import LighterGlue
+            self.lighterglue = LighterGlue()
+        m, _, c = self.lighterglue.match_device(d0['keypoints'], d0['descriptors'], d0['image_size'], d1['keypoints'],
+                                                d1['descriptors'], d1['image_size'], min_conf)
+        idxs = m[:int(c.item())]
+        k0, k1 = d0['keypoints'].to(idxs.device), d1['keypoints'].to(idxs.device)
+        return k0[idxs[:, 0]].cpu().numpy(), k1[idxs[:, 1]].cpu().numpy(), idxs.cpu().numpy()
 
     @torch.inference_mode()
     def match_xfeat(self, img1, img2, top_k=None, min_cossim=-1):

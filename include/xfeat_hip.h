@@ -202,6 +202,36 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
                      xfh_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * LighterGlue: the attention matcher of XFeat.match_lighterglue (modules/xfeat.py:131-162), i.e.
+ * kornia.feature.lightglue.LightGlue.forward under the configuration of modules/lighterglue.py:12-27 (input 64-D,
+ * d = 96, one head, 6 layers, no early stop, width pruning 0.95, filter threshold = min_conf), for ONE pair
+ * (the reference asserts B = 1).  Its own checkpoint (weights/xfeat-lighterglue.pt) -> its own handle.
+ *
+ *   host_arrays : fp32 arrays in kornia's module order after the reference loader's renaming
+ *                 (modules/lighterglue.py:41-46): input_proj.{weight,bias}, posenc.Wr.weight, per layer
+ *                 transformers.i.self_attn.{Wqkv,out_proj,ffn.0,ffn.1,ffn.3}.{weight,bias},
+ *                 transformers.i.cross_attn.{to_qk,to_v,to_out,ffn.0,ffn.1,ffn.3}.{weight,bias}, then
+ *                 log_assignment.i.{matchability,final_proj}.{weight,bias}, then token_confidence.i.token.0.{weight,bias}
+ *                 (xfh_lg_num_weight_arrays() = 169; sizes from xfh_lg_weight_array_floats).
+ *   xfh_lg_match: kpts (N,2) pixel coordinates, desc (N,64), image size (W,H) per image.  prune_min_kpts: after every
+ *                 layer but the last, a set that still has MORE than this many key-points drops those whose
+ *                 matchability is <= 1 - width_confidence (the published pruning_keypoint_thresholds: -1 on CPU =
+ *                 always, 1024 on CUDA, 1536 on CUDA with flash attention); XFH_LG_NO_PRUNING disables it.  Output: matches (<= min(N0,N1), 2) int64 indices into the input
+ *                 lists, ascending in column 0; scores; n_matches (1) int32 -- all device memory, asynchronous.
+ * ---------------------------------------------------------------------------------------- */
+#define XFH_LG_NO_PRUNING (1 << 30)
+typedef struct xfh_lg_context* xfh_lg_handle;
+int xfh_lg_num_weight_arrays(void);
+size_t xfh_lg_weight_array_floats(int index);
+int xfh_lg_create(const float* const* host_arrays, int n_arrays, int device, xfh_lg_handle* out);
+void xfh_lg_destroy(xfh_lg_handle h);
+size_t xfh_lg_workspace_bytes(int N0, int N1);
+int xfh_lg_match(xfh_lg_handle h, const float* kpts0, const float* desc0, int N0, float W0, float H0,
+                 const float* kpts1, const float* desc1, int N1, float W1, float H1, float min_conf, int prune_min_kpts,
+                 int64_t* matches, float* scores, int32_t* n_matches, void* workspace, size_t workspace_bytes,
+                 xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * Kernel timing hooks for bench.py (HIP events recorded around one kernel family on the
  * launch stream).  which: see XFH_PROF_* ; xfh_profile_read synchronises the recorded events
  * and returns the number of launches and their summed duration in milliseconds.

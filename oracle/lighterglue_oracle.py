@@ -148,11 +148,12 @@ def filter_matches(scores, th):
 # ------------------------------------------------------------------------------------------------------------
 # the matcher (kornia LightGlue.forward under the reference's conf; one pair)
 # ------------------------------------------------------------------------------------------------------------
-def lighterglue_forward(sd, kpts0, desc0, size0, kpts1, desc1, size1, min_conf=0.1, conf=CONF, prune=True, trace=None):
+def lighterglue_forward(sd, kpts0, desc0, size0, kpts1, desc1, size1, min_conf=0.1, conf=CONF, prune=True, trace=None, prune_min_kpts=-1):
     """kpts (N,2) pixel coordinates, desc (N,64), size (2,) = (W,H).
     Returns matches (S,2) int64 (indices into the ORIGINAL key-point lists, ascending in column 0) and scores (S,).
-    `prune=True` is the CPU behaviour of the published code: width pruning (matchability > 1 - width_confidence) after
-    every layer but the last, whatever the number of key-points."""
+    `prune=True`: width pruning (matchability > 1 - width_confidence) after every layer but the last, applied to a set
+    while it holds more than `prune_min_kpts` points (published pruning_keypoint_thresholds: cpu -1 = always,
+    cuda 1024, flash 1536)."""
     n_layers = conf["n_layers"]
     k0, k1 = normalize_keypoints(kpts0, size0), normalize_keypoints(kpts1, size1)
     d0 = F.linear(desc0, sd["input_proj.weight"], sd["input_proj.bias"])
@@ -167,14 +168,17 @@ def lighterglue_forward(sd, kpts0, desc0, size0, kpts1, desc1, size1, min_conf=0
         if i == n_layers - 1:
             continue
         # depth_confidence = -1: no early stop, hence no token confidences in the pruning rule
-        if do_prune:
+        if do_prune and d0.shape[0] > prune_min_kpts:
             keep0 = torch.where(matchability(sd, i, d0) > 1 - conf["width_confidence"])[0]
             ind0, d0, e0 = ind0[keep0], d0[keep0], (e0[0][keep0], e0[1][keep0])
+        if do_prune and d1.shape[0] > prune_min_kpts:
             keep1 = torch.where(matchability(sd, i, d1) > 1 - conf["width_confidence"])[0]
             ind1, d1, e1 = ind1[keep1], d1[keep1], (e1[0][keep1], e1[1][keep1])
     if d0.shape[0] == 0 or d1.shape[0] == 0:
         return torch.zeros((0, 2), dtype=torch.int64), torch.zeros((0,))
     scores = log_assignment(sd, n_layers - 1, d0, d1)
+    if isinstance(trace, list):
+        trace.append((scores, None, ind0.clone(), ind1.clone()))          # last entry: the (M+1, N+1) log assignment
     m0, ms0 = filter_matches(scores, min_conf)
     valid = m0 > -1
     a = torch.where(valid)[0]
