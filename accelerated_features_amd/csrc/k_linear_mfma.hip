@@ -157,8 +157,7 @@ int launch_linear_mfma(const float* w_kn, const float* bias, int K, int N, int n
     if (K == 64 && loader == LOAD_ROWMAJOR && nt64) { XFH_LIN(64, 64, LOAD_ROWMAJOR); return 0; }
     if (K == 64 && loader == LOAD_ROWMAJOR && !nt64) { XFH_LIN(64, 32, LOAD_ROWMAJOR); return 0; }
     if (K == 64 && loader == LOAD_UNFOLD8 && nt64) { XFH_LIN(64, 64, LOAD_UNFOLD8); return 0; }
-    if (K == 96 && loader == LOAD_ROWMAJOR && nt64) { XFH_LIN(96, 64, LOAD_ROWMAJOR); return 0; }       // LighterGlue (d = 96)
-    if (K == 192 && loader == LOAD_ROWMAJOR && nt64) { XFH_LIN(192, 64, LOAD_ROWMAJOR); return 0; }
+    if (K == 96 && loader == LOAD_ROWMAJOR && nt64) { XFH_LIN(96, 64, LOAD_ROWMAJOR); return 0; }       // LighterGlue similarity matrix (d = 96)
     if (K == 128 && loader == LOAD_GATHER2 && nt64) { XFH_LIN(128, 64, LOAD_GATHER2); return 0; }
     if (K == 128 && loader == LOAD_ROWMAJOR && nt64) { XFH_LIN(128, 64, LOAD_ROWMAJOR); return 0; }
     if (K == 512 && loader == LOAD_ROWMAJOR && nt64) { XFH_LIN(512, 64, LOAD_ROWMAJOR); return 0; }

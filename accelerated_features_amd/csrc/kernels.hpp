@@ -140,19 +140,28 @@ void launch_refine_finish(const float* o /*(T,64)*/, const int32_t* rowmap, cons
 void prof_begin(Profiler* p, int which, hipStream_t st);
 void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
 
-// ---- LighterGlue (k_lighterglue.hip) ----
+// ---- LighterGlue (k_lighterglue.hip): every per-set launcher takes the two images of the pair as `sides` ----
+enum { LG_EPI_STORE = 0, LG_EPI_RESIDUAL = 1, LG_EPI_ROTARY = 2, LG_EPI_LNGELU = 3 };
+struct LgLinSide { const float* x; int ldx; float* y; int ldy; const int32_t* n; int cap; const float* cs; const float* sn; };
+struct LgAttSide { const float* Q; const float* K; const float* V; float* O; float* part; const int32_t* nq; const int32_t* nk; int qcap, kcap, nsplit; };
+struct LgRowSide { const float* x; float* z; const int32_t* n; int cap; };
+struct LgPruneSide {
+    const float* z; const int32_t* n_in; int cap; int32_t* map; int32_t* n_out;
+    const float* x; float* xo; const float* cs; float* cso; const float* sn; float* sno; const int32_t* ind; int32_t* indo;
+};
 void launch_lg_encode(const float* kpts, int N, float W, float H, const float* wr, float* cs, float* sn, hipStream_t st);
-void launch_lg_rotary(float* qkv, int ld, const int32_t* n_dev, int cap, const float* cs, const float* sn, hipStream_t st);
-void launch_lg_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo, const int32_t* nq_dev,
-                         const int32_t* nk_dev, int qcap, int kcap, float scale, hipStream_t st);
-void launch_lg_ln_gelu(float* x, int ld, const int32_t* n_dev, int cap, const float* gamma, const float* beta, hipStream_t st);
-void launch_lg_add(float* x, int ldx, const float* y, int ldy, const int32_t* n_dev, int cap, hipStream_t st);
-void launch_lg_dot(const float* x, int ld, const int32_t* n_dev, int cap, const float* w, const float* b, float* z, hipStream_t st);
-void launch_lg_prune(const float* z, float thr, int min_kpts, const int32_t* n_in, int cap, int32_t* map, int32_t* n_out, const float* x, int ldx, float* xo,
-                     const float* cs, float* cso, const float* sn, float* sno, const int32_t* ind, int32_t* indo, hipStream_t st);
+// wp: weights in operand order [N/32][2][K/8][32][4] (api_lg.hip packs them), bias (N).  Returns -1 if (K, epi) has no instantiation.
+int launch_lg_linear(const float* wp, const float* bias, int K, int N, int epi, const LgLinSide* sides, int nsides, const float* gamma,
+                     const float* beta, hipStream_t st);
+size_t lg_attention_partial_floats(int qcap, int kcap);
+// scratch: sum over sides of lg_attention_partial_floats(qcap, kcap) floats
+void launch_lg_attention(LgAttSide* sides, int nsides, int ldq, int ldk, int ldv, int ldo, float* scratch, float scale, hipStream_t st);
+void launch_lg_dot(const LgRowSide* sides, int nsides, int ld, const float* w, const float* b, hipStream_t st);
+void launch_lg_prune(const LgPruneSide* sides, int nsides, float thr, int min_kpts, int ldx, hipStream_t st);
 void launch_lg_transpose(const float* x, int ld, const int32_t* n_dev, int cap, float* xt, int npad, hipStream_t st);
+size_t lg_assign_scratch_bytes(int cap1);
 void launch_lg_assign(const float* sim, int ld, const int32_t* n0_dev, int cap0, const int32_t* n1_dev, int cap1, const float* z0, const float* z1,
                       float* rlse, float* clse, int32_t* m0, int32_t* m1, float* best0, const int32_t* ind0, const int32_t* ind1, float thr,
-                      int64_t* matches, float* scores, int32_t* n_out, hipStream_t st);
+                      int64_t* matches, float* scores, int32_t* n_out, void* scratch, hipStream_t st);
 
 }  // namespace xfh
