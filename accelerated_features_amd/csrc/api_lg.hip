@@ -197,12 +197,16 @@ size_t carve_lg(void* ws, int N0, int N1, LgWs& w) {
     w.ascratch = c.take<char>(lg_assign_scratch_bytes(N1));
     return (c.off + 255) / 256 * 256;
 }
-__global__ void lg_init_kernel(int32_t* ind0, int n0, int32_t* count0, int32_t* ind1, int n1, int32_t* count1, float* zeros, int nz) {
+__global__ void lg_init_kernel(int32_t* ind0, int n0, int32_t* count0, int32_t* ind1, int n1, int32_t* count1, float* zeros, int nz,
+                               const int32_t* live0, const int32_t* live1) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g < n0) ind0[g] = g;
     if (g < n1) ind1[g] = g;
     if (g < nz) zeros[g] = 0.f;
-    if (g == 0) { *count0 = n0; *count1 = n1; }
+    if (g == 0) {
+        *count0 = live0 ? max(0, min(n0, *live0)) : n0;
+        *count1 = live1 ? max(0, min(n1, *live1)) : n1;
+    }
 }
 }  // namespace
 
@@ -212,22 +216,18 @@ size_t xfh_lg_workspace_bytes(int N0, int N1) {
     return carve_lg(nullptr, N0, N1, w);
 }
 
-int xfh_lg_match(xfh_lg_handle h, const float* kpts0, const float* desc0, int N0, float W0, float H0, const float* kpts1, const float* desc1,
-                 int N1, float W1, float H1, float min_conf, int prune_min_kpts, int64_t* matches, float* scores, int32_t* n_matches,
-                 void* workspace, size_t workspace_bytes, xfh_stream stream) {
-    if (!h || !kpts0 || !desc0 || !kpts1 || !desc1 || !matches || !scores || !n_matches) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match: NULL argument");
-    if (N0 <= 0 || N1 <= 0 || N0 > 16384 || N1 > 16384) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match: key-point counts must be in 1..16384");
-    if (((size_t)desc0 | (size_t)desc1) & 15) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match: descriptors must be 16-byte aligned");
+// one pair; live0/live1 (optional, device): number of valid rows (<= N0 / N1) when the lists are zero-padded to a capacity
+static int lg_match_impl(xfh_lg_handle h, const float* kpts0, const float* desc0, int N0, const int32_t* live0, float W0, float H0,
+                         const float* kpts1, const float* desc1, int N1, const int32_t* live1, float W1, float H1, float min_conf,
+                         int prune_min_kpts, int64_t* matches, float* scores, int32_t* n_matches, void* workspace, hipStream_t st) {
     LgWs w;
-    const size_t need = carve_lg(workspace, N0, N1, w);
-    if (!workspace || workspace_bytes < need || ((size_t)workspace & 255)) return xfh_set_error(XFH_ERR_WORKSPACE, "xfh_lg_match: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
-    hipStream_t st = (hipStream_t)stream;
+    carve_lg(workspace, N0, N1, w);
     const int N[2] = {N0, N1};
     int bad = 0;
     // current (x, cos, sin, ind, n) of each set
     float *x[2], *cs[2], *sn[2]; int32_t *ind[2], *nn[2];
     for (int s = 0; s < 2; ++s) { LgSet& S = w.s[s]; x[s] = S.xa; cs[s] = S.csa; sn[s] = S.sna; ind[s] = S.inda; nn[s] = S.na; }
-    lg_init_kernel<<<ceil_div(std::max(std::max(N0, N1), w.n1pad), 256), 256, 0, st>>>(ind[0], N0, nn[0], ind[1], N1, nn[1], w.zeros, w.n1pad);
+    lg_init_kernel<<<ceil_div(std::max(std::max(N0, N1), w.n1pad), 256), 256, 0, st>>>(ind[0], N0, nn[0], ind[1], N1, nn[1], w.zeros, w.n1pad, live0, live1);
     launch_lg_encode(kpts0, N0, W0, H0, h->wr, cs[0], sn[0], st);
     launch_lg_encode(kpts1, N1, W1, H1, h->wr, cs[1], sn[1], st);
     // both images per launch: y[s] = epi(x_in[s] . W^T + b)
@@ -305,5 +305,35 @@ int xfh_lg_match(xfh_lg_handle h, const float* kpts0, const float* desc0, int N0
     if (bad) return xfh_set_error(XFH_ERR_UNSUPPORTED, "xfh_lg_match: missing linear kernel instantiation");
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xfh_set_error(XFH_ERR_HIP, "xfh_lg_match: %s", hipGetErrorString(e));
+    return XFH_OK;
+}
+
+int xfh_lg_match(xfh_lg_handle h, const float* kpts0, const float* desc0, int N0, float W0, float H0, const float* kpts1, const float* desc1,
+                 int N1, float W1, float H1, float min_conf, int prune_min_kpts, int64_t* matches, float* scores, int32_t* n_matches,
+                 void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    if (!h || !kpts0 || !desc0 || !kpts1 || !desc1 || !matches || !scores || !n_matches) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match: NULL argument");
+    if (N0 <= 0 || N1 <= 0 || N0 > 16384 || N1 > 16384) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match: key-point counts must be in 1..16384");
+    if (((size_t)desc0 | (size_t)desc1) & 15) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match: descriptors must be 16-byte aligned");
+    const size_t need = xfh_lg_workspace_bytes(N0, N1);
+    if (!workspace || workspace_bytes < need || ((size_t)workspace & 255)) return xfh_set_error(XFH_ERR_WORKSPACE, "xfh_lg_match: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+    return lg_match_impl(h, kpts0, desc0, N0, nullptr, W0, H0, kpts1, desc1, N1, nullptr, W1, H1, min_conf, prune_min_kpts, matches, scores,
+                         n_matches, workspace, (hipStream_t)stream);
+}
+
+int xfh_lg_match_pairs(xfh_lg_handle h, const float* kpts, const float* desc, const int32_t* counts, int P, int cap, float W, float H,
+                       float min_conf, int prune_min_kpts, int64_t* matches, float* scores, int32_t* n_matches, void* workspace,
+                       size_t workspace_bytes, xfh_stream stream) {
+    if (!h || !kpts || !desc || !counts || !matches || !scores || !n_matches) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match_pairs: NULL argument");
+    if (P <= 0 || cap <= 0 || cap > 16384) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match_pairs: need P > 0 and 1 <= cap <= 16384");
+    if ((size_t)desc & 15) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_match_pairs: descriptors must be 16-byte aligned");
+    const size_t need = xfh_lg_workspace_bytes(cap, cap);
+    if (!workspace || workspace_bytes < need || ((size_t)workspace & 255)) return xfh_set_error(XFH_ERR_WORKSPACE, "xfh_lg_match_pairs: workspace too small or misaligned (%zu < %zu)", workspace_bytes, need);
+    for (int p = 0; p < P; ++p) {           // pairs run back to back on the stream and share the workspace
+        const size_t f0 = 2 * (size_t)p, f1 = f0 + 1;
+        const int rc = lg_match_impl(h, kpts + f0 * cap * 2, desc + f0 * cap * 64, cap, counts + f0, W, H, kpts + f1 * cap * 2, desc + f1 * cap * 64,
+                                     cap, counts + f1, W, H, min_conf, prune_min_kpts, matches + (size_t)p * cap * 2, scores + (size_t)p * cap,
+                                     n_matches + p, workspace, (hipStream_t)stream);
+        if (rc != XFH_OK) return rc;
+    }
     return XFH_OK;
 }

@@ -159,6 +159,32 @@ class LighterGlue(nn.Module):
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream)), "xfh_lg_match")
         return matches, scores, count
 
+    def match_pairs_device(self, kpts, desc, counts, size, min_conf=0.1, prune_min_kpts=None):
+        """Fixed-capacity batch (the layout XFeat._detect_device produces): kpts (2P,cap,2), desc (2P,cap,64), counts (2P,)
+        int32 on the GPU; frames (2p, 2p+1) form pair p; size = (W,H) of every image.  Returns device tensors
+        matches (P,cap,2) int64, scores (P,cap), n (P,) int32 without reading the counts back."""
+        h = self.handle()
+        lib = _lib.load()
+        dev = kpts.device
+        B, cap = kpts.shape[0], kpts.shape[1]
+        if B % 2 or desc.shape != (B, cap, 64) or counts.shape != (B,) or counts.dtype != torch.int32:
+            raise ValueError("expected kpts (2P,cap,2), desc (2P,cap,64), counts (2P,) int32")
+        kpts, desc = kpts.to(torch.float32).contiguous(), desc.to(torch.float32).contiguous()
+        P = B // 2
+        matches = torch.empty((P, cap, 2), dtype=torch.int64, device=dev)
+        scores = torch.empty((P, cap), dtype=torch.float32, device=dev)
+        n = torch.zeros((P,), dtype=torch.int32, device=dev)
+        need = lib.xfh_lg_workspace_bytes(cap, cap)
+        if self._ws is None or self._ws.numel() < need + 256 or self._ws.device != dev:
+            self._ws = torch.empty(int(need) + 256, dtype=torch.uint8, device=dev)
+        ws = self._ws[(-self._ws.data_ptr()) % 256:]
+        p = lambda t: C.c_void_p(t.data_ptr())
+        pm = self.prune_min_kpts if prune_min_kpts is None else prune_min_kpts
+        _lib.check(lib.xfh_lg_match_pairs(h, p(kpts), p(desc), p(counts), P, cap, float(size[0]), float(size[1]), float(min_conf), int(pm),
+                                          p(matches), p(scores), p(n), p(ws), need,
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "xfh_lg_match_pairs")
+        return matches, scores, n
+
     @torch.inference_mode()
     def forward(self, data, min_conf=0.1):
         """data: keypoints0/1 (1,N,2), descriptors0/1 (1,N,64), image_size0/1 (1,2) as in the reference.

@@ -145,6 +145,59 @@ def bench_dense(args, xf, rank, world, dist):
         dist.destroy_process_group()
 
 
+def bench_lighterglue(args, xf, rank, world, dist):
+    """BASELINE configs[4]: XFeat + LighterGlue on VGA pairs, batch 64 frames = 32 pairs per GPU.
+    One step = detectAndCompute of the 64 frames + the attention matcher on the 32 consecutive pairs (fixed-capacity
+    key-point lists with device-side counts: one read-back per step)."""
+    import fixtures
+    from accelerated_features_amd.lighterglue import LighterGlue
+    lg = LighterGlue(weights=fixtures.lighterglue_state_dict(0))
+    B = args.batch
+    x = make_frames(B, seed=1000 + rank).cuda()
+
+    def step():
+        kp, sc, de, nv, nc, cap, hw = xf._detect_device(x, TOP_K, 0.05)
+        m, s, n = lg.match_pairs_device(kp, de, nv, (W, H), 0.0)     # synthetic matcher weights: keep every mutual assignment
+        return torch.cat([nv, n]).cpu()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        counts = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        nv, nm = counts[:B].tolist(), counts[B:].tolist()
+        kpt = float(np.mean(nv))
+        # algorithmic FLOPs of one pair at n key-points per image (no pruning credit): 6 layers x (4 attentions of
+        # 4 n^2 d + linears 2 x 2 n (3dd + dd + 4dd + 2dd + 2dd + dd + 4dd + 2dd)) + the similarity matrix 2 n^2 d
+        d = 96
+        flops_pair = 6 * (4 * 4 * kpt * kpt * d + 2 * 2 * kpt * 19 * d * d) + 2 * kpt * kpt * d
+        out = {"metric": "frames/sec detectAndCompute + LighterGlue (VGA, top_k=4096)", "value": round(world * B * args.steps / float(tmax.item()), 2),
+               "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * float(tmax.item()) / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "XFeat + LighterGlue attention matcher on VGA pairs, batch=64 frames (32 pairs) per GPU (BASELINE configs[4])",
+                          "batch_per_gpu": B, "top_k": TOP_K, "weights": "synthetic (tests/fixtures.py; parity of the matcher unpinned vs kornia, see DESIGN.md)",
+                          "mean_keypoints": round(kpt, 1), "mean_matches": round(float(np.mean(nm)), 1),
+                          "prune_min_kpts": lg.prune_min_kpts, "gflop_per_pair_unpruned": round(flops_pair / 1e9, 1)}}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +205,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config: 64)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--workload", default="sparse", choices=["sparse", "dense"],
+    ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "lighterglue"],
                     help="sparse = BASELINE configs[1] (the contract metric); dense = configs[2], match_xfeat_star on 1024^2 pairs, batch 32")
     args = ap.parse_args()
 
@@ -176,6 +229,8 @@ def main():
     lib = _lib.load()
     if args.workload == "dense":
         return bench_dense(args, xf, rank, world, dist)
+    if args.workload == "lighterglue":
+        return bench_lighterglue(args, xf, rank, world, dist)
     B = args.batch
     x = make_frames(B, seed=1000 + rank).cuda()           # inputs resident in HBM before the timed region
     handle = xf.net.handle()

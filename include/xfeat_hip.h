@@ -231,6 +231,14 @@ int xfh_lg_match(xfh_lg_handle h, const float* kpts0, const float* desc0, int N0
                  int64_t* matches, float* scores, int32_t* n_matches, void* workspace, size_t workspace_bytes,
                  xfh_stream stream);
 
+/* The batch form used with xfh_detect_sparse's fixed-capacity outputs: frames (2p, 2p+1) of kpts (2P,cap,2) /
+ * desc (2P,cap,64) / counts (2P) int32 (all device memory) form pair p; every image has size (W,H).  No host
+ * read-back of the counts; pairs run back to back on `stream` and share one workspace of
+ * xfh_lg_workspace_bytes(cap, cap).  Outputs: matches (P,cap,2) int64, scores (P,cap), n_matches (P) int32. */
+int xfh_lg_match_pairs(xfh_lg_handle h, const float* kpts, const float* desc, const int32_t* counts, int P, int cap,
+                       float W, float H, float min_conf, int prune_min_kpts, int64_t* matches, float* scores,
+                       int32_t* n_matches, void* workspace, size_t workspace_bytes, xfh_stream stream);
+
 /* ------------------------------------------------------------------------------------------
  * Kernel timing hooks for bench.py (HIP events recorded around one kernel family on the
  * launch stream).  which: see XFH_PROF_* ; xfh_profile_read synchronises the recorded events

@@ -115,6 +115,29 @@ def test_lighterglue_class_surface_and_determinism(lg, sd):
     assert np.array_equal(a, k0.numpy()[idx[:, 0]]) and np.array_equal(b, k1.numpy()[idx[:, 1]])
 
 
+def test_lighterglue_pair_batch_with_device_counts_equals_single_pairs(lg):
+    """xfh_lg_match_pairs on zero-padded fixed-capacity lists == xfh_lg_match on the ragged lists."""
+    cap, sizes = 512, [(500, 512), (37, 300), (512, 0), (130, 131)]
+    kp = torch.zeros(2 * len(sizes), cap, 2)
+    de = torch.zeros(2 * len(sizes), cap, 64)
+    cnt = torch.zeros(2 * len(sizes), dtype=torch.int32)
+    singles = []
+    for p, (n0, n1) in enumerate(sizes):
+        k0, d0, s0, k1, d1, s1 = fixtures.lighterglue_inputs(max(n0, 1), max(n1, 1), seed=40 + p)
+        kp[2 * p, :n0], de[2 * p, :n0], kp[2 * p + 1, :n1], de[2 * p + 1, :n1] = k0[:n0], d0[:n0], k1[:n1], d1[:n1]
+        cnt[2 * p], cnt[2 * p + 1] = n0, n1
+        if n0 and n1:
+            singles.append(_run(lg, (k0, d0, s0, k1, d1, s1), 0.02, -1))
+        else:
+            singles.append((np.zeros((0, 2), np.int64), np.zeros((0,), np.float32)))
+    m, s, n = lg.match_pairs_device(kp.cuda(), de.cuda(), cnt.cuda(), (640, 480), 0.02, -1)
+    n = n.cpu().tolist()
+    for p in range(len(sizes)):
+        assert n[p] == len(singles[p][0]), (p, n[p], len(singles[p][0]))
+        assert np.array_equal(m[p, :n[p]].cpu().numpy(), singles[p][0])
+        np.testing.assert_allclose(s[p, :n[p]].cpu().numpy(), singles[p][1], rtol=1e-4, atol=1e-7)      # the key-split count follows the capacity: summation order differs
+
+
 def test_lighterglue_rejects_bad_arguments(lg):
     from accelerated_features_amd import _lib as L
     lib = L.load()
