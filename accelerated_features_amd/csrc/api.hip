@@ -414,9 +414,11 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     return XFH_OK;
 }
 
+struct ResizeSpec { int Hin, Win, Hm, Wm; float s1h, s1w, s2h, s2w; };      // xfh_backbone_resized: img is (B,C,Hin,Win)
+
 static int backbone_impl(xfh_handle h, const float* img, const unsigned char* img_u8, int u8_layout, float u8_divisor, int B, int C, int H,
                          int W, float* feats, float* logits, float* heat, float* reliab, void* workspace, size_t workspace_bytes,
-                         xfh_stream stream) {
+                         xfh_stream stream, const ResizeSpec* rs = nullptr) {
     if (!h || (!img && !img_u8) || !feats || !reliab) return fail(XFH_ERR_ARG, "xfh_backbone: NULL argument");
     if (!logits && !heat) return fail(XFH_ERR_ARG, "xfh_backbone: logits and heat are both NULL");
     int rc = check_img("xfh_backbone", B, C, H, W);
@@ -428,7 +430,11 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     const NetWeights& nw = h->nw;
     const int H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
 
-    if (img_u8) launch_gray_norm_u8(img_u8, u8_layout == XFH_LAYOUT_NHWC, u8_divisor, B, C, H, W, w.part, w.gray, w.coef, st);
+    if (rs) {
+        if (launch_gray_norm_resized(img, B, C, rs->Hin, rs->Win, rs->Hm, rs->Wm, rs->s1h, rs->s1w, H, W, rs->s2h, rs->s2w, w.part, w.gray,
+                                     w.coef, st))
+            return fail(XFH_ERR_UNSUPPORTED, "xfh_backbone_resized: second resize step (%g, %g) must be below 2", rs->s2h, rs->s2w);
+    } else if (img_u8) launch_gray_norm_u8(img_u8, u8_layout == XFH_LAYOUT_NHWC, u8_divisor, B, C, H, W, w.part, w.gray, w.coef, st);
     else launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
     launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st);
@@ -468,6 +474,15 @@ int xfh_backbone_u8(xfh_handle h, const uint8_t* img, int layout, float divisor,
     if (layout != XFH_LAYOUT_NCHW && layout != XFH_LAYOUT_NHWC) return fail(XFH_ERR_ARG, "xfh_backbone_u8: layout must be XFH_LAYOUT_NCHW or XFH_LAYOUT_NHWC");
     if (!(divisor > 0.f)) return fail(XFH_ERR_ARG, "xfh_backbone_u8: divisor must be positive");
     return backbone_impl(h, nullptr, img, layout, divisor, B, C, H, W, feats, logits, heat, reliab, workspace, workspace_bytes, stream);
+}
+
+int xfh_backbone_resized(xfh_handle h, const float* img, int B, int C, int Hin, int Win, int Hmid, int Wmid, float scale1_h, float scale1_w,
+                         int Hout, int Wout, float scale2_h, float scale2_w, float* feats, float* logits, float* heat, float* reliab,
+                         void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    if (Hin <= 0 || Win <= 0 || Hmid <= 0 || Wmid <= 0 || !(scale1_h > 0.f) || !(scale1_w > 0.f))
+        return fail(XFH_ERR_ARG, "xfh_backbone_resized: bad source / intermediate size");
+    const ResizeSpec rs{Hin, Win, Hmid, Wmid, scale1_h, scale1_w, scale2_h, scale2_w};
+    return backbone_impl(h, img, nullptr, 0, 1.f, B, C, Hout, Wout, feats, logits, heat, reliab, workspace, workspace_bytes, stream, &rs);
 }
 
 int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out, int variant,

@@ -163,6 +163,99 @@ void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, floa
         src, Hin, Win, dst, Hout, Wout, sh, sw);
 }
 
+// ------------------------------------------------------------------------------------------
+// Two successive bilinear resizes + channel mean + statistics without materialising either resized image:
+//   F.interpolate(x, scale_factor=s)  (modules/xfeat.py:379-381)  ->  (Hm,Wm)
+//   preprocess_tensor's resize to multiples of 32 (modules/xfeat.py:234-238)  ->  (Ho,Wo)
+//   x.mean(dim=1) + InstanceNorm statistics (modules/model.py:135-136)
+// The dual-scale dense path (1024^2 -> 614^2 -> 608^2 and -> 1331^2 -> 1312^2) otherwise writes and re-reads ~4 GB per
+// 32-image batch.  Per 64x16 output tile and channel: stage 1 (input -> intermediate grid) lands in LDS rounded to fp32
+// exactly as the materialised image would be, stage 2 interpolates from LDS with the same expression as
+// resize_bilinear_kernel, the channel sum runs in gray_stats_kernel's order: the gray plane is bit-identical to the
+// three-kernel path.  grid (GS_CHUNKS, B): workgroup `ch` walks tiles ch, ch+64, ... and writes ONE partial sum, so
+// gray_coef_kernel and the run-to-run determinism are unchanged.
+// ------------------------------------------------------------------------------------------
+constexpr int R2_TW = 64, R2_TH = 16, R2_RW = 2 * R2_TW + 2, R2_RH = 2 * R2_TH + 2;      // LDS region for stage-2 steps < 2
+__global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __restrict__ img, int C, int Hin, int Win, int Hm, int Wm,
+                                                                 float s1h, float s1w, int Ho, int Wo, float s2h, float s2w,
+                                                                 double* __restrict__ part, float* __restrict__ gray) {
+    __shared__ float mid[R2_RH * R2_RW];
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int tiles_x = ceil_div(Wo, R2_TW), tiles = tiles_x * ceil_div(Ho, R2_TH);
+    const float fC = (float)C;
+    const int lx = (tid & 15) * 4, ly = tid >> 4;                  // this thread: 4 consecutive output pixels of tile row ly
+    double s = 0.0, q = 0.0;
+    for (int t = ch; t < tiles; t += GS_CHUNKS) {
+        const int oy0 = (t / tiles_x) * R2_TH, ox0 = (t % tiles_x) * R2_TW;
+        const int oy1 = min(oy0 + R2_TH, Ho) - 1, ox1 = min(ox0 + R2_TW, Wo) - 1;
+        int ym0, ym1, xm0, xm1, d0, d1; float f0, f1;
+        lin_coef(s2h, oy0, Hm, ym0, d1, f0, f1);
+        lin_coef(s2h, oy1, Hm, d0, ym1, f0, f1);
+        lin_coef(s2w, ox0, Wm, xm0, d1, f0, f1);
+        lin_coef(s2w, ox1, Wm, d0, xm1, f0, f1);
+        const int rh = ym1 - ym0 + 1, rw = xm1 - xm0 + 1;          // <= R2_RH x R2_RW (host checks the steps)
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        int y0 = 0, y1 = 0; float wy0 = 0.f, wy1 = 0.f;
+        int x0[4], x1[4]; float wx0[4], wx1[4];
+        if (oy <= oy1) lin_coef(s2h, oy, Hm, y0, y1, wy0, wy1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            x0[k] = x1[k] = xm0; wx0[k] = wx1[k] = 0.f;
+            if (ox + k <= ox1) lin_coef(s2w, ox + k, Wm, x0[k], x1[k], wx0[k], wx1[k]);
+        }
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            const float* p = img + ((size_t)b * C + c) * Hin * Win;
+            __syncthreads();                                        // previous channel's / tile's readers are done
+            for (int e = tid; e < rh * rw; e += 256) {
+                const int ry = e / rw, rx = e - ry * rw;
+                int iy0, iy1, ix0, ix1; float vy0, vy1, vx0, vx1;
+                lin_coef(s1h, ym0 + ry, Hin, iy0, iy1, vy0, vy1);
+                lin_coef(s1w, xm0 + rx, Win, ix0, ix1, vx0, vx1);
+                mid[ry * R2_RW + rx] = bilerp(p, Win, iy0, iy1, ix0, ix1, vy0, vy1, vx0, vx1);
+            }
+            __syncthreads();
+            if (oy <= oy1) {
+                const float* m = mid - ym0 * R2_RW - xm0;           // index with intermediate-grid coordinates
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v = bilerp(m, R2_RW, y0, y1, x0[k], x1[k], wy0, wy1, wx0[k], wx1[k]);
+                    a[k] = c == 0 ? v : a[k] + v;
+                }
+            }
+        }
+        if (oy <= oy1) {
+            float* g = gray + ((size_t)b * Ho + oy) * Wo + ox;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ox + k <= ox1) {
+                    const float v = a[k] / fC;
+                    g[k] = v;
+                    s += (double)v;
+                    q += (double)v * v;
+                }
+        }
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    __shared__ double sm[8];
+    if ((tid & 63) == 0) { sm[(tid >> 6) * 2] = s; sm[(tid >> 6) * 2 + 1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        part[((size_t)b * GS_CHUNKS + ch) * 2 + 0] = sm[0] + sm[2] + sm[4] + sm[6];
+        part[((size_t)b * GS_CHUNKS + ch) * 2 + 1] = sm[1] + sm[3] + sm[5] + sm[7];
+    }
+}
+
+// returns -1 when the stage-2 step is too large for the LDS region (callers then materialise the images)
+int launch_gray_norm_resized(const float* img, int B, int C, int Hin, int Win, int Hm, int Wm, float s1h, float s1w, int Ho, int Wo,
+                             float s2h, float s2w, double* part, float* gray, float* coef, hipStream_t st) {
+    if (!(s2h > 0.f) || !(s2w > 0.f) || s2h * (R2_TH - 1) + 3.f > (float)R2_RH || s2w * (R2_TW - 1) + 3.f > (float)R2_RW) return -1;
+    resize2_gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, Hin, Win, Hm, Wm, s1h, s1w, Ho, Wo, s2h, s2w, part, gray);
+    gray_coef_kernel<<<B, 64, 0, st>>>(part, Ho * Wo, 1e-5f, coef);
+    return 0;
+}
+
 // out = x3 + up(x4 -> x3 size) + up(x5 -> x3 size)      (model.py:146-148), NCHW planes.
 // One workgroup per plane: the small x4 / x5 source planes are staged in LDS (coalesced), the
 // x3 / out streams are float4.  Falls back to direct gathers when the planes exceed LDS.

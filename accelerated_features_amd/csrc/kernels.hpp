@@ -40,6 +40,8 @@ struct Profiler;   // api.hip
 // ---- k_preproc.hip ----------------------------------------------------------------------
 // gray = channel mean (raw), coef[b] = {alpha, beta} of the instance norm x = fmaf(gray, alpha, beta)
 void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, float* coef, hipStream_t st);
+int launch_gray_norm_resized(const float* img, int B, int C, int Hin, int Win, int Hm, int Wm, float s1h, float s1w, int Ho, int Wo,
+                             float s2h, float s2w, double* part, float* gray, float* coef, hipStream_t st);
 void launch_gray_norm_u8(const unsigned char* img, bool nhwc, float divisor, int B, int C, int H, int W, double* part, float* gray,
                          float* coef, hipStream_t st);
 void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,

@@ -65,6 +65,24 @@ class _U8Image:
         return self.data.shape
 
 
+class _LazyResize:
+    """A bilinear resize that has not happened yet: `data` (B,C,Hin,Win) fp32 to be interpolated to (Hm,Wm) with source
+    steps (s1h,s1w), optionally followed by preprocess_tensor's resize to (Ho,Wo).  Internal: lets extract_dualscale hand
+    both resizes to xfh_backbone_resized instead of materialising two images per scale."""
+
+    def __init__(self, data, Hm, Wm, s1h, s1w, Ho=None, Wo=None, s2h=1.0, s2w=1.0):
+        self.data, self.mid, self.s1 = data, (Hm, Wm), (s1h, s1w)
+        self.out, self.s2 = (Hm if Ho is None else Ho, Wm if Wo is None else Wo), (s2h, s2w)
+
+    @property
+    def shape(self):
+        return (self.data.shape[0], self.data.shape[1]) + tuple(self.out)
+
+    @property
+    def device(self):
+        return self.data.device
+
+
 class XFeatModel(nn.Module):
     """Parameter container with the reference's ``state_dict`` keys (modules/model.py:33-111);
     ``forward`` runs the HIP backbone and returns the same triple as the reference:
@@ -173,6 +191,19 @@ class XFeatModel(nn.Module):
         lib = _lib.load()
         h = self.handle()
         u8_div = None
+        if isinstance(x, _LazyResize):
+            B, Cc, H, W = x.shape
+            hc, wc = H // 8, W // 8
+            dev = x.device
+            feats = torch.empty((B, hc, wc, 64), dtype=torch.float32, device=dev)
+            rel = torch.empty((B, hc, wc), dtype=torch.float32, device=dev)
+            logits = torch.empty((B, hc, wc, 65), dtype=torch.float32, device=dev) if want_logits else None
+            heat = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_heat else None
+            ws, n = self.workspace("backbone", lib.xfh_backbone_workspace_bytes(B, Cc, H, W))
+            _lib.check(lib.xfh_backbone_resized(h, _ptr(x.data), B, Cc, x.data.shape[2], x.data.shape[3], x.mid[0], x.mid[1],
+                                                float(x.s1[0]), float(x.s1[1]), H, W, float(x.s2[0]), float(x.s2[1]), _ptr(feats),
+                                                _ptr(logits), _ptr(heat), _ptr(rel), _ptr(ws), n, _stream()), "xfh_backbone_resized")
+            return feats, logits, heat, rel
         if isinstance(x, _U8Image):
             x, u8_div = x.data, x.divisor
         elif x.dtype == torch.uint8:
@@ -404,6 +435,11 @@ class XFeat(nn.Module):
         if _H == 0 or _W == 0:
             raise RuntimeError('Input image must be at least 32x32 pixels')
         rh, rw = H / _H, W / _W
+        if isinstance(x, _LazyResize):
+            s2h, s2w = np.float32(H) / np.float32(_H), np.float32(W) / np.float32(_W)
+            if max(s2h, s2w) < 1.9:
+                return _LazyResize(x.data, x.mid[0], x.mid[1], x.s1[0], x.s1[1], _H, _W, s2h, s2w), rh, rw
+            x = self._resize(x.data, x.mid[0], x.mid[1], x.s1[0], x.s1[1])      # tiny images: materialise
         if (_H, _W) == (H, W) and (isinstance(x, _U8Image) or x.dtype == torch.uint8):
             # bytes stay bytes: the conversion (and parse_input's /255) happens inside xfh_backbone_u8
             if isinstance(x, _U8Image):
@@ -593,7 +629,7 @@ class XFeat(nn.Module):
         outs = []
         for s, frac in ((s1, 0.20), (s2, 0.80)):
             Ho, Wo = int(math.floor(H * s)), int(math.floor(W * s))
-            xs = self._resize(x, Ho, Wo, np.float32(1.0 / s), np.float32(1.0 / s))
+            xs = _LazyResize(x, Ho, Wo, np.float32(1.0 / s), np.float32(1.0 / s))       # both resizes run inside xfh_backbone_resized
             mk, ft = self.extractDense(xs, int(top_k * frac), _scale_div=s)
             sc = torch.ones(mk.shape[:2], device=mk.device) * (1 / s)
             outs.append((mk, sc, ft))

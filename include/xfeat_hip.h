@@ -106,6 +106,17 @@ int xfh_backbone_u8(xfh_handle h, const uint8_t* img, int layout, float divisor,
                     float* feats, float* logits, float* heat, float* reliab,
                     void* workspace, size_t workspace_bytes, xfh_stream stream);
 
+/* The dual-scale dense path (XFeat.extract_dualscale, modules/xfeat.py:379-394): F.interpolate(x, scale_factor=s) to
+ * (Hmid,Wmid), then preprocess_tensor's resize to multiples of 32 (modules/xfeat.py:234-238) to (Hout,Wout), then the
+ * network.  Identical to xfh_resize_bilinear(img -> mid, scale1) + xfh_resize_bilinear(mid -> out, scale2) +
+ * xfh_backbone(out) -- the gray plane the network consumes is bit-identical -- without writing either resized image.
+ * img: (B,C,Hin,Win) fp32; workspace: xfh_backbone_workspace_bytes(B, C, Hout, Wout).  scale2 must be < 2
+ * (XFH_ERR_UNSUPPORTED otherwise: materialise the images with xfh_resize_bilinear). */
+int xfh_backbone_resized(xfh_handle h, const float* img, int B, int C, int Hin, int Win, int Hmid, int Wmid,
+                         float scale1_h, float scale1_w, int Hout, int Wout, float scale2_h, float scale2_w,
+                         float* feats, float* logits, float* heat, float* reliab, void* workspace,
+                         size_t workspace_bytes, xfh_stream stream);
+
 /* One conv layer of the network in isolation (parity tests against per-layer oracle
  * activations).  layer = index into spec.CONVS; in (B,Cin,Hin,Win) NCHW, out (B,Cout,Hout,Wout)
  * NCHW with the layer's own stride/padding, folded BN and ReLU where the reference has them.

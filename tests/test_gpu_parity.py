@@ -606,3 +606,28 @@ def test_hipgraph_captured_pipeline_equals_eager(xf):
             assert torch.equal(o['descriptors'][b, :n], e[b]['descriptors'])
         i0, i1 = xf.match(e[0]['descriptors'], e[1]['descriptors'], min_cossim=-1)
         assert torch.equal(o['matches'][0][0], i0) and torch.equal(o['matches'][0][1], i1)
+
+
+def test_fused_two_stage_resize_backbone_is_bit_identical_to_materialised_resizes(xf):
+    """xfh_backbone_resized (extract_dualscale's F.interpolate + preprocess_tensor resize + network, modules/xfeat.py:379-381,
+    234-238) against xfh_resize_bilinear x2 + xfh_backbone: same gray plane => same features, bit for bit."""
+    from accelerated_features_amd.xfeat import _LazyResize
+    x = fixtures.texture_images(2, 200, 328, seed=11).cuda()
+    for s in (0.6, 1.3, 1.0):
+        Hm, Wm = int(np.floor(200 * s)), int(np.floor(328 * s))
+        s1 = np.float32(1.0 / s)
+        lazy, rh, rw = xf.preprocess_tensor(_LazyResize(x, Hm, Wm, s1, s1))
+        assert isinstance(lazy, _LazyResize) and lazy.shape[2] % 32 == 0 and lazy.shape[3] % 32 == 0
+        f1, l1, _, r1 = xf.net.backbone(lazy)
+        mat, rh2, rw2 = xf.preprocess_tensor(xf._resize(x, Hm, Wm, s1, s1))
+        assert (rh, rw) == (rh2, rw2) and tuple(mat.shape) == tuple(lazy.shape)
+        f2, l2, _, r2 = xf.net.backbone(mat)
+        assert torch.equal(f1, f2) and torch.equal(l1, l2) and torch.equal(r1, r2), s
+    # the dense entry point takes the fused route and still matches the oracle (covered by the dense parity test above);
+    # here: both scales of a ragged size agree with the per-scale materialised extraction
+    mk, sc, ft = xf.extract_dualscale(x, 1000)
+    outs = []
+    for s, frac in ((0.6, 0.20), (1.3, 0.80)):
+        xs = xf._resize(x, int(np.floor(200 * s)), int(np.floor(328 * s)), np.float32(1.0 / s), np.float32(1.0 / s))
+        outs.append(xf.extractDense(xs, int(1000 * frac), _scale_div=s))
+    assert torch.equal(mk, torch.cat([outs[0][0], outs[1][0]], 1)) and torch.equal(ft, torch.cat([outs[0][1], outs[1][1]], 1))
