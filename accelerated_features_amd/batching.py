@@ -86,3 +86,35 @@ def _detect_exact(xfeat, x, top_k):
         if cap >= hw or ncmax <= cap:
             return kpts, desc, n_valid
         cap = min(hw, max(ncmax, 2 * cap))
+
+
+def match_pairs_star(xfeat, pairs, top_k=None, max_pairs=16, rank=0, world=1):
+    """The semi-dense matcher (`--matcher xfeat-star`, modules/eval/megadepth1500.py:265-269) over a list of pairs:
+    pairs whose two images share one size are grouped by that size and pushed through XFeat.match_xfeat_star in batches
+    of up to `max_pairs`; the rest go pair by pair.  Returns, in order, what match_xfeat_star(img0, img1) returns for one
+    pair: (mkpts0, mkpts1) numpy float32 (N,2)."""
+    lo, hi = shard_range(len(pairs), rank, world)
+    items, groups, out = [], {}, {}
+    for i in range(lo, hi):
+        a, da = _as_nchw(pairs[i][0])
+        b, db = _as_nchw(pairs[i][1])
+        a = a / da if da is not None else a            # the dense path interpolates first: convert like parse_input
+        b = b / db if db is not None else b
+        items.append((i, a.float(), b.float()))
+    for it in items:
+        key = (tuple(it[1].shape), tuple(it[2].shape))
+        groups.setdefault(key, []).append(it)
+    for key, members in groups.items():
+        step = max_pairs if key[0] == key[1] else 1
+        for s in range(0, len(members), step):
+            chunk = members[s:s + step]
+            xa = torch.stack([it[1] for it in chunk])
+            xb = torch.stack([it[2] for it in chunk])
+            res = xfeat.match_xfeat_star(xa, xb, top_k=top_k)
+            if len(chunk) == 1:
+                out[chunk[0][0]] = res                 # B == 1: already the (mkpts0, mkpts1) numpy tuple
+            else:
+                for it, m in zip(chunk, res):
+                    m = m.cpu().numpy()
+                    out[it[0]] = (m[:, :2], m[:, 2:])
+    return [out[i] for i in range(lo, hi)]

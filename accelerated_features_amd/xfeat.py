@@ -580,9 +580,15 @@ class XFeat(nn.Module):
         k0 = d0['keypoints'].float().contiguous()
         k1 = d1['keypoints'].float().contiguous()
         s0 = d0['scales'].float().contiguous()
-        P, N, _ = f0.shape
-        if f1.shape[1] != N:
-            raise RuntimeError('refine_matches needs the same number of key-points in both sets')
+        P = f0.shape[0]
+        N = max(f0.shape[1], f1.shape[1])
+
+        def pad(t):            # sets of different size (small images): zero rows up to the common capacity, never indexed
+            if t.shape[1] == N:
+                return t
+            z = torch.zeros((t.shape[0], N - t.shape[1]) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+            return torch.cat([t, z], 1).contiguous()
+        f0, f1, k0, k1, s0, idx0, idx1 = pad(f0), pad(f1), pad(k0), pad(k1), pad(s0), pad(idx0), pad(idx1)
         out = torch.empty((P, N, 4), dtype=torch.float32, device=f0.device)
         n_out = torch.empty((P,), dtype=torch.int32, device=f0.device)
         ws, nb = self.net.workspace("refine", lib.xfh_refine_workspace_bytes(P, N))

@@ -590,6 +590,30 @@ def test_batched_pair_runner_equals_pairwise_match_xfeat(xf):
         assert np.array_equal(m0, r0) and np.array_equal(m1, r1)
 
 
+def test_batched_star_runner_equals_pairwise_match_xfeat_star(xf):
+    """batching.match_pairs_star: size-grouped batches of the semi-dense matcher == match_xfeat_star pair by pair."""
+    from accelerated_features_amd.batching import match_pairs_star
+    pairs = []
+    for seed, (h, w) in enumerate([(160, 192), (128, 160), (160, 192), (160, 192)]):
+        t = fixtures.texture_images(2, h, w, seed=50 + seed)
+        pairs.append((t[0], torch.roll(t[0], (3, 5), (1, 2)) + 0.01 * t[1]))
+    big = fixtures.texture_images(1, 160, 192, seed=60)[0]
+    pairs.append((big, big[:, 16:144, 16:176].contiguous()))                  # sizes differ: a crop of the same content
+    got = match_pairs_star(xf, pairs, top_k=1024, max_pairs=2)
+    assert len(got) == len(pairs)
+    for (m0, m1), (a, b) in zip(got, pairs):
+        r0, r1 = xf.match_xfeat_star(a[None], b[None], top_k=1024)
+        assert m0.shape == r0.shape and np.array_equal(m0, r0) and np.array_equal(m1, r1)
+    # the pair whose images differ in size (different numbers of dense key-points per set) against the oracle:
+    # rows are (x0,y0,x1,y1); every GPU row must be an oracle row up to 2e-3 px, counts equal up to threshold ties
+    a, b = pairs[-1]
+    ref = O.match_xfeat_star(fixtures.synthetic_state_dict(0), a[None], b[None], top_k=1024)[0].numpy()
+    mine = np.concatenate(got[-1], 1)
+    assert abs(len(ref) - len(mine)) <= 2 and len(ref) >= 1      # (synthetic fine_matcher weights keep few rows)
+    hits = sum(bool((np.abs(ref - row).max(1) < 2e-3).any()) for row in mine)
+    assert hits >= len(mine) - 2, (hits, len(mine))
+
+
 def test_hipgraph_captured_pipeline_equals_eager(xf):
     """accelerated_features_amd.graphs.CapturedSparsePipeline: one hipGraph replay per call, same kernels, bit-identical
     key-points / descriptors / matches; replays stay correct when the input changes."""
