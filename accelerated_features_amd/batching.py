@@ -64,16 +64,17 @@ def match_pairs(xfeat, pairs, top_k=None, min_cossim=-1, max_pairs=32, rank=0, w
                     k0 = kpts[2 * p][idx0[p, :nm[p]]]
                     k1 = kpts[2 * p + 1][idx1[p, :nm[p]]]
                     out[it[0]] = (k0.cpu().numpy(), k1.cpu().numpy())
-            else:                                   # the two images of a pair differ in size: two batches + per-pair match
+            else:                                   # the two images of a pair differ in size: one batch per side
                 xa = torch.stack([it[1] for it in chunk])
                 xb = torch.stack([it[3] for it in chunk])
                 xa = _U8Image(xa, key[4]) if key[4] is not None else xa
                 xb = _U8Image(xb, key[5]) if key[5] is not None else xb
-                oa = xfeat.detectAndCompute(xa, top_k=top_k)
-                ob = xfeat.detectAndCompute(xb, top_k=top_k)
+                ka, da, na = _detect_exact(xfeat, xa, top_k)
+                kb, db, nb = _detect_exact(xfeat, xb, top_k)
+                idx0, idx1, nm = xfeat.match_sets_device(da, na, db, nb, min_cossim)
+                nm = nm.cpu().tolist()
                 for p, it in enumerate(chunk):
-                    i0, i1 = xfeat.match(oa[p]['descriptors'], ob[p]['descriptors'], min_cossim=min_cossim)
-                    out[it[0]] = (oa[p]['keypoints'][i0].cpu().numpy(), ob[p]['keypoints'][i1].cpu().numpy())
+                    out[it[0]] = (ka[p][idx0[p, :nm[p]]].cpu().numpy(), kb[p][idx1[p, :nm[p]]].cpu().numpy())
     return [out[i] for i in range(lo, hi)]
 
 

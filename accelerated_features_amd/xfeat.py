@@ -545,6 +545,24 @@ class XFeat(nn.Module):
                                      _stream()), "xfh_match_mnn")
         return idx0, idx1, n
 
+    def match_sets_device(self, desc_a, n_a, desc_b, n_b, min_cossim=-1):
+        """Pair p = (desc_a[p], desc_b[p]): two detection batches (P,K,64) with their n_valid (P) int32 (images of different
+        size go through _detect_device separately).  Same outputs as match_pairs_device, no read-back."""
+        self._require_gpu()
+        lib = _lib.load()
+        P, K, D = desc_a.shape
+        assert desc_b.shape == desc_a.shape and D == 64 and desc_a.is_contiguous() and desc_b.is_contiguous()
+        idx0 = torch.empty((P, K), dtype=torch.int64, device=desc_a.device)
+        idx1 = torch.empty((P, K), dtype=torch.int64, device=desc_a.device)
+        n = torch.empty((P,), dtype=torch.int32, device=desc_a.device)
+        ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, K, K))
+        # one count array so that a single (stride, offset) addresses both sides
+        nv = torch.cat([n_a.to(torch.int32), n_b.to(torch.int32)]).contiguous()
+        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(desc_a), K * 64, _ptr(desc_b), K * 64, _ptr(nv), _ptr(nv),
+                                     1, P, P, K, K, float(min_cossim), _ptr(idx0), _ptr(idx1), _ptr(n), _ptr(ws), nb,
+                                     _stream()), "xfh_match_mnn")
+        return idx0, idx1, n
+
     def subpix_softmax2d(self, heatmaps, temp=3):
         """(N,8,8) -> (N,2) expected offset under softmax(temp*heatmaps) (xfeat.py:292-304).
         Helper kept for API compatibility; refine_matches fuses this step in HIP."""

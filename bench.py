@@ -93,6 +93,21 @@ def cpu_baseline(seconds):
                       f"= {frames} frames in {t_used:.1f} s, torch CPU threads={threads}"}
 
 
+def cpu_sample(seconds, fn, unit, units_per_call, what):
+    """Bounded CPU-oracle sample for the secondary workloads: repeat fn() for about `seconds`."""
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)
+    torch.set_num_threads(threads)
+    n, used = 0, 0.0
+    while used < seconds or n < 1:
+        t0 = time.perf_counter()
+        fn()
+        used += time.perf_counter() - t0
+        n += 1
+    return {"value": round(n * units_per_call / used, 4), "unit": unit, "cores": threads, "kind": "port",
+            "sample": f"{n} x ({what}) in {used:.1f} s, torch CPU threads={threads}"}
+
+
 def load_pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -133,7 +148,15 @@ def bench_dense(args, xf, rank, world, dist):
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            from oracle import xfeat_oracle as O
+            sd = fixtures.synthetic_state_dict(0)
+            ca, cb = a[:1].cpu(), b[:1].cpu()
+            cpu = cpu_sample(args.cpu_seconds, lambda: O.match_xfeat_star(sd, ca, cb, top_k=TOP_K), "pairs/s", 1,
+                             "oracle match_xfeat_star on one 1024x1024 pair")
         print(json.dumps({
+            "cpu_baseline": cpu,
             "metric": "image pairs/sec match_xfeat_star (1024x1024, top_k=4096)", "value": round(world * P * args.steps / float(tmax.item()), 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * float(tmax.item()) / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -192,7 +215,93 @@ def bench_lighterglue(args, xf, rank, world, dist):
                           "batch_per_gpu": B, "top_k": TOP_K, "weights": "synthetic (tests/fixtures.py; parity of the matcher unpinned vs kornia, see DESIGN.md)",
                           "mean_keypoints": round(kpt, 1), "mean_matches": round(float(np.mean(nm)), 1),
                           "prune_min_kpts": lg.prune_min_kpts, "gflop_per_pair_unpruned": round(flops_pair / 1e9, 1)}}
+        if world == 1 and args.cpu_seconds > 0:
+            from oracle import lighterglue_oracle as LGO
+            sdl = fixtures.lighterglue_state_dict(0)
+            kp, sc, de, nv, nc, cap, hw = xf._detect_device(x[:2], TOP_K, 0.05)
+            n0, n1 = int(nv[0]), int(nv[1])
+            k0, d0, k1, d1 = kp[0, :n0].cpu(), de[0, :n0].cpu(), kp[1, :n1].cpu(), de[1, :n1].cpu()
+            size = torch.tensor([float(W), float(H)])
+            out["cpu_baseline"] = cpu_sample(args.cpu_seconds, lambda: LGO.lighterglue_forward(sdl, k0, d0, size, k1, d1, size, min_conf=0.0,
+                                                                                               prune=True, prune_min_kpts=lg.prune_min_kpts),
+                                             "frames/s", 2, f"oracle LighterGlue on one pair of {n0} x {n1} key-points; extraction excluded")
         print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_megadepth(args, xf, rank, world, dist):
+    """BASELINE configs[3]: the MegaDepth-1500 pair list at long side 1600, sharded across the GPUs (no collective).
+    Image sizes follow the reference's pair list (tests/golden/megadepth1500_sizes.json, generated from
+    assets/megadepth_1500.json), scaled x1600/1184 and floored to multiples of 32; pixels are synthetic
+    uint8 textures resident in HBM.  One step = the whole job: this rank's contiguous shard of the 1500 pairs through
+    accelerated_features_amd.batching.match_pairs (size-grouped batches, match_xfeat's results per pair)."""
+    import fixtures
+    from accelerated_features_amd.batching import match_pairs
+    from accelerated_features_amd.sharding import shard_range
+    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "megadepth1500_sizes.json")))
+    up = lambda v: max(32, int(v * 1600 / 1184) // 32 * 32)
+    sizes = []
+    for h0, w0, h1, w1, n in rows:
+        sizes += [((up(h0), up(w0)), (up(h1), up(w1)))] * n
+    order = np.random.RandomState(15).permutation(len(sizes))          # the dataset interleaves scenes; fixed pseudo-random order
+    sizes = [sizes[i] for i in order]
+    lo, hi = shard_range(len(sizes), rank, world)
+    bank = {}
+
+    def image(hw, variant):
+        if hw not in bank:
+            t = fixtures.texture_images(2, hw[0], hw[1], seed=(hw[0] * 7 + hw[1]) % 1000)
+            bank[hw] = (t * 255).round().clamp(0, 255).to(torch.uint8).cuda()
+        return bank[hw][variant]
+
+    pairs = []
+    for i in range(lo, hi):
+        a, b = sizes[i]
+        pairs.append((image(a, i % 2), image(b, (i + 1) % 2) if a != b else torch.roll(image(a, i % 2), (8 + i % 5, 16), (1, 2))))
+
+    def step():
+        return match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        t = float(tmax.item())
+        mpix = sum(a[0] * a[1] + b[0] * b[1] for a, b in sizes) / 1e6
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            from oracle import xfeat_oracle as O
+            sd = fixtures.synthetic_state_dict(0)
+            ca, cb = pairs[0][0][None].cpu().float(), pairs[0][1][None].cpu().float()
+            cpu = cpu_sample(args.cpu_seconds, lambda: O.match_xfeat(sd, ca, cb, top_k=TOP_K), "pairs/s", 1,
+                             f"oracle match_xfeat on one pair of {tuple(ca.shape[2:])} / {tuple(cb.shape[2:])} images")
+        print(json.dumps({
+            "cpu_baseline": cpu,
+            "metric": "image pairs/sec match_xfeat over the MegaDepth-1500 pair list (long side 1600, top_k=4096)",
+            "value": round(len(sizes) * args.steps / t, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * t / args.steps, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MegaDepth-1500 pair list, sizes scaled to long side 1600 and /32, sharded contiguously across the GPUs "
+                                   "(BASELINE configs[3]); one step = all 1500 pairs",
+                       "pairs": len(sizes), "pairs_this_rank": hi - lo, "distinct_size_pairs": len(rows), "megapixels_per_pass": round(mpix, 1),
+                       "top_k": TOP_K, "input": "uint8 tensors in HBM", "mean_matches_rank0": round(float(np.mean([len(r[0]) for r in res])), 1),
+                       "parallelism": f"pairs sharded x{world}, no collective"}}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -205,8 +314,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config: 64)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "lighterglue"],
-                    help="sparse = BASELINE configs[1] (the contract metric); dense = configs[2], match_xfeat_star on 1024^2 pairs, batch 32")
+    ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "lighterglue", "megadepth"],
+                    help="sparse = BASELINE configs[1] (the contract metric); dense = configs[2], match_xfeat_star on 1024^2 pairs, batch 32; "
+                         "megadepth = configs[3], the MegaDepth-1500 pair list sharded across the GPUs; lighterglue = configs[4]")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -231,6 +341,8 @@ def main():
         return bench_dense(args, xf, rank, world, dist)
     if args.workload == "lighterglue":
         return bench_lighterglue(args, xf, rank, world, dist)
+    if args.workload == "megadepth":
+        return bench_megadepth(args, xf, rank, world, dist)
     B = args.batch
     x = make_frames(B, seed=1000 + rank).cuda()           # inputs resident in HBM before the timed region
     handle = xf.net.handle()
