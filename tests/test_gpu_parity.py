@@ -655,3 +655,14 @@ def test_fused_two_stage_resize_backbone_is_bit_identical_to_materialised_resize
         xs = xf._resize(x, int(np.floor(200 * s)), int(np.floor(328 * s)), np.float32(1.0 / s), np.float32(1.0 / s))
         outs.append(xf.extractDense(xs, int(1000 * frac), _scale_div=s))
     assert torch.equal(mk, torch.cat([outs[0][0], outs[1][0]], 1)) and torch.equal(ft, torch.cat([outs[0][1], outs[1][1]], 1))
+
+
+def test_reference_minimal_example_runs_unchanged():
+    """examples/minimal_example.py = the reference's minimal_example.py with only the import changed."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "minimal_example.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "keypoints:  torch.Size([" in r.stdout and "descriptors:  torch.Size([" in r.stdout and "match_xfeat:" in r.stdout
+    assert "torch.Size([" in r.stdout.strip().splitlines()[-1] and ", 4])" in r.stdout.strip().splitlines()[-1]
