@@ -94,6 +94,24 @@ def test_lighterglue_with_width_pruning_vs_oracle(lg, sd, min_kpts):
     assert sizes[-1] < 700, "the fixture weights must prune something, otherwise this test checks nothing"
 
 
+def test_lighterglue_full_size_4096_vs_oracle(lg, sd):
+    """BASELINE size (top_k = 4096 key-points per image), the pruning threshold the class uses on a GPU (1536)."""
+    inp = fixtures.lighterglue_inputs(4096, 4096, seed=9)
+    got_m, got_s = _run(lg, inp, 0.01, 1536)
+    _compare(got_m, got_s, sd, inp, 0.01, prune=True, prune_min_kpts=1536, tol=2e-4)
+
+
+def test_lighterglue_8192_properties(lg):
+    """Beyond the oracle's comfortable size: one-to-one, ascending, thresholded, bit-identical when repeated."""
+    inp = fixtures.lighterglue_inputs(8192, 6000, seed=10)
+    m1, s1 = _run(lg, inp, 0.02, 1536)
+    m2, s2 = _run(lg, inp, 0.02, 1536)
+    assert np.array_equal(m1, m2) and np.array_equal(s1, s2)
+    assert len(m1) > 0 and np.all(np.diff(m1[:, 0]) > 0)
+    assert len(np.unique(m1[:, 1])) == len(m1) and m1[:, 0].max() < 8192 and m1[:, 1].max() < 6000 and m1.min() >= 0
+    assert float(s1.min()) > 0.02 and float(s1.max()) <= 1.0 + 1e-6
+
+
 def test_lighterglue_class_surface_and_determinism(lg, sd):
     from accelerated_features_amd import XFeat
     inp = fixtures.lighterglue_inputs(400, 380, seed=5)
