@@ -666,3 +666,16 @@ def test_reference_minimal_example_runs_unchanged():
     assert r.returncode == 0, r.stderr[-2000:]
     assert "keypoints:  torch.Size([" in r.stdout and "descriptors:  torch.Size([" in r.stdout and "match_xfeat:" in r.stdout
     assert "torch.Size([" in r.stdout.strip().splitlines()[-1] and ", 4])" in r.stdout.strip().splitlines()[-1]
+
+
+def test_large_frame_2160x3840_vs_oracle(xf, sd):
+    """A 4K frame (8.3 MP: 27x the VGA planes, preprocess_tensor resizes 2160 -> 2144) through the sparse path: index
+    arithmetic, workspace carving and the NMS capacity logic at a size far from the benchmark configuration."""
+    x = fixtures.texture_images(1, 2160, 3840, seed=21)
+    out = xf.detectAndCompute(x.cuda(), top_k=4096)[0]
+    ref, st = O.detect_and_compute(sd, x, top_k=4096, keep=True)
+    rep = parity.compare_keypoints(out, ref[0], heat=st["heat"][0, 0], rw=1.0, rh=2160 / 2144)
+    print("4K", rep)
+    assert rep["n_test"] == 4096
+    kp = out["keypoints"].cpu().numpy()
+    assert kp[:, 0].max() <= 3840 and kp[:, 1].max() <= 2160 and kp.min() >= 0
