@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(LgAttSide sa, LgAt
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mnew = fmaxf(mrun, tmax);     // finite: every tile holds at least one live key
         if (__any(mnew != mrun)) {
-            const float corr = exp2f(mrun - mnew);           // exp2(-inf) = 0 on the first tile
+            const float corr = __builtin_amdgcn_exp2f(mrun - mnew);           // raw v_exp_f32; exp2(-inf) = 0 on the first tile
             lrun *= corr;
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(LgAttSide sa, LgAt
         }
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mrun); psum += s[r]; }
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mrun); psum += s[r]; }      // (exp2f() costs 6 VALU ops for the denormal range: p < 2^-126 may flush to 0 here)
         lrun += psum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
