@@ -183,7 +183,7 @@ size_t carve_lg(void* ws, int N0, int N1, LgWs& w) {
         S.xa = c.take<float>(n * 192); S.xb = c.take<float>(n * 192);
         S.csa = c.take<float>(n * 96); S.csb = c.take<float>(n * 96); S.sna = c.take<float>(n * 96); S.snb = c.take<float>(n * 96);
         S.inda = c.take<int32_t>(n); S.indb = c.take<int32_t>(n); S.map = c.take<int32_t>(n); S.na = c.take<int32_t>(1); S.nb = c.take<int32_t>(1);
-        S.qkv = c.take<float>(n * 288); S.hid = c.take<float>(n * 192); S.att = c.take<float>(n * 96); S.z = c.take<float>(n); S.md = c.take<float>(n * 96);
+        S.qkv = c.take<float>(n * 288); S.hid = c.take<float>(n * 192); S.att = c.take<float>(n * 96); S.z = c.take<float>(n + 64); S.md = c.take<float>(n * 96);
     }
     w.n1pad = (N1 + 63) / 64 * 64;
     w.md1t = c.take<float>((size_t)96 * w.n1pad);

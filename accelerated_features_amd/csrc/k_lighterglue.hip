@@ -471,7 +471,7 @@ void launch_lg_transpose(const float* x, int ld, const int32_t* n_dev, int cap, 
 // ------------------------------------------------------------------------------------------
 __device__ inline float lg_logsigmoid(float z) { return fminf(z, 0.f) - log1pf(expf(-fabsf(z))); }
 
-// one wave per row
+// one wave per row, float4 per lane (ld is a multiple of 64 floats: rows are 16-byte aligned)
 __global__ __launch_bounds__(256) void lg_row_lse_kernel(const float* __restrict__ sim, int ld, const int32_t* __restrict__ n0_dev, int cap0,
                                                          const int32_t* __restrict__ n1_dev, int cap1, float* __restrict__ lse) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -479,10 +479,22 @@ __global__ __launch_bounds__(256) void lg_row_lse_kernel(const float* __restrict
     if (row >= n0) return;
     const float* p = sim + (size_t)row * ld;
     float m = -INFINITY;
-    for (int j = lane; j < n1; j += 64) m = fmaxf(m, p[j]);
+    for (int j = 4 * lane; j < n1; j += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + j);
+        m = fmaxf(m, v.x);
+        if (j + 1 < n1) m = fmaxf(m, v.y);
+        if (j + 2 < n1) m = fmaxf(m, v.z);
+        if (j + 3 < n1) m = fmaxf(m, v.w);
+    }
     m = wave_max(m);
     float s = 0.f;
-    for (int j = lane; j < n1; j += 64) s += expf(p[j] - m);
+    for (int j = 4 * lane; j < n1; j += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(p + j);
+        s += expf(v.x - m);
+        if (j + 1 < n1) s += expf(v.y - m);
+        if (j + 2 < n1) s += expf(v.z - m);
+        if (j + 3 < n1) s += expf(v.w - m);
+    }
     s = wave_sum(s);
     if (lane == 0) lse[row] = m + logf(s);
 }
@@ -527,8 +539,15 @@ __global__ __launch_bounds__(256) void lg_col_lse_final_kernel(const float2* __r
     for (int k = 0; k < LG_RSPLIT; ++k) t += p[k].y > 0.f ? p[k].y * expf(p[k].x - mm) : 0.f;
     lse[col] = mm + logf(t);
 }
+// z -> logsigmoid(z) in place, once per key-point (the score kernels would otherwise evaluate it per matrix element)
+__global__ __launch_bounds__(256) void lg_logsigmoid_kernel(float* __restrict__ z0, const int32_t* __restrict__ n0_dev, int cap0, float* __restrict__ z1,
+                                                           const int32_t* __restrict__ n1_dev, int cap1) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    float* z = blockIdx.y ? z1 : z0;
+    if (g < (blockIdx.y ? lg_live(n1_dev, cap1) : lg_live(n0_dev, cap0))) z[g] = lg_logsigmoid(z[g]);
+}
 __device__ inline float lg_score(float v, float rl, float cl, float a, float b) { return ((v - rl) + (v - cl)) + (a + b); }
-// row arg-max (first index on ties) of the core scores; one wave per row
+// row arg-max (first index on ties) of the core scores; one wave per row, float4 per lane
 __global__ __launch_bounds__(256) void lg_row_best_kernel(const float* __restrict__ sim, int ld, const int32_t* __restrict__ n0_dev, int cap0,
                                                           const int32_t* __restrict__ n1_dev, int cap1, const float* __restrict__ rlse,
                                                           const float* __restrict__ clse, const float* __restrict__ z0,
@@ -537,12 +556,19 @@ __global__ __launch_bounds__(256) void lg_row_best_kernel(const float* __restric
     const int n0 = lg_live(n0_dev, cap0), n1 = lg_live(n1_dev, cap1);
     if (row >= n0) return;
     const float* p = sim + (size_t)row * ld;
-    const float rl = rlse[row], a = lg_logsigmoid(z0[row]);
+    const float rl = rlse[row], a = z0[row];
     float bv = -INFINITY;
     int bj = 0x7fffffff;
-    for (int j = lane; j < n1; j += 64) {
-        const float v = lg_score(p[j], rl, clse[j], a, lg_logsigmoid(z1[j]));
-        if (v > bv) { bv = v; bj = j; }
+    for (int j = 4 * lane; j < n1; j += 256) {           // ascending j within the lane: strict > keeps the first maximum
+        const float4 sv = *reinterpret_cast<const float4*>(p + j);
+        const float4 cl = *reinterpret_cast<const float4*>(clse + j);      // (clse / z1 hold n1pad entries; the tail is masked below)
+        const float4 zb = *reinterpret_cast<const float4*>(z1 + j);
+        const float s4[4] = {sv.x, sv.y, sv.z, sv.w}, c4[4] = {cl.x, cl.y, cl.z, cl.w}, b4[4] = {zb.x, zb.y, zb.z, zb.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = lg_score(s4[e], rl, c4[e], a, b4[e]);
+            if (j + e < n1 && v > bv) { bv = v; bj = j + e; }
+        }
     }
     unsigned long long key = bj == 0x7fffffff ? 0ull : (((unsigned long long)float_ord(bv) << 32) | (0xffffffffu - (unsigned)bj));
 #pragma unroll
@@ -564,9 +590,9 @@ __global__ __launch_bounds__(256) void lg_col_best_part_kernel(const float* __re
     const int chunk = ceil_div(n0, LG_RSPLIT), r0 = blockIdx.y * chunk, r1 = min(n0, r0 + chunk);
     unsigned long long key = 0ull;
     if (col < n1) {
-        const float cl = clse[col], b = lg_logsigmoid(z1[col]);
+        const float cl = clse[col], b = z1[col];
         for (int i = r0 + wave; i < r1; i += 4) {
-            const float v = lg_score(sim[(size_t)i * ld + col], rlse[i], cl, lg_logsigmoid(z0[i]), b);
+            const float v = lg_score(sim[(size_t)i * ld + col], rlse[i], cl, z0[i], b);
             key = u64_max(key, ((unsigned long long)float_ord(v) << 32) | (0xffffffffu - (unsigned)i));
         }
     }
@@ -630,11 +656,13 @@ __global__ __launch_bounds__(1024) void lg_mutual_kernel(const int32_t* __restri
     if (tid == 0) *n_out = s_base;
 }
 size_t lg_assign_scratch_bytes(int cap1) { return (size_t)LG_RSPLIT * ((cap1 + 63) / 64 * 64) * 8; }
+// z0 / z1: matchability logits, overwritten with their logsigmoid.
 // `scratch`: lg_assign_scratch_bytes(cap1) bytes (8-byte aligned), used for the column partials of both passes
-void launch_lg_assign(const float* sim, int ld, const int32_t* n0_dev, int cap0, const int32_t* n1_dev, int cap1, const float* z0, const float* z1,
+void launch_lg_assign(const float* sim, int ld, const int32_t* n0_dev, int cap0, const int32_t* n1_dev, int cap1, float* z0, float* z1,
                       float* rlse, float* clse, int32_t* m0, int32_t* m1, float* best0, const int32_t* ind0, const int32_t* ind1, float thr,
                       int64_t* matches, float* scores, int32_t* n_out, void* scratch, hipStream_t st) {
     const int npad = (cap1 + 63) / 64 * 64;
+    lg_logsigmoid_kernel<<<dim3(ceil_div(max(cap0, cap1), 256), 2), 256, 0, st>>>(z0, n0_dev, cap0, z1, n1_dev, cap1);
     lg_row_lse_kernel<<<ceil_div(cap0, 4), 256, 0, st>>>(sim, ld, n0_dev, cap0, n1_dev, cap1, rlse);
     lg_col_lse_part_kernel<<<dim3(npad / 64, LG_RSPLIT), 256, 0, st>>>(sim, ld, n0_dev, cap0, n1_dev, cap1, (float2*)scratch, npad);
     lg_col_lse_final_kernel<<<ceil_div(cap1, 256), 256, 0, st>>>((const float2*)scratch, npad, n1_dev, cap1, clse);

@@ -162,7 +162,7 @@ void launch_lg_dot(const LgRowSide* sides, int nsides, int ld, const float* w, c
 void launch_lg_prune(const LgPruneSide* sides, int nsides, float thr, int min_kpts, int ldx, hipStream_t st);
 void launch_lg_transpose(const float* x, int ld, const int32_t* n_dev, int cap, float* xt, int npad, hipStream_t st);
 size_t lg_assign_scratch_bytes(int cap1);
-void launch_lg_assign(const float* sim, int ld, const int32_t* n0_dev, int cap0, const int32_t* n1_dev, int cap1, const float* z0, const float* z1,
+void launch_lg_assign(const float* sim, int ld, const int32_t* n0_dev, int cap0, const int32_t* n1_dev, int cap1, float* z0, float* z1,
                       float* rlse, float* clse, int32_t* m0, int32_t* m1, float* best0, const int32_t* ind0, const int32_t* ind1, float thr,
                       int64_t* matches, float* scores, int32_t* n_out, void* scratch, hipStream_t st);
 
