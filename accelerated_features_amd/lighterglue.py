@@ -188,8 +188,10 @@ class LighterGlue(nn.Module):
     @torch.inference_mode()
     def forward(self, data, min_conf=0.1):
         """data: keypoints0/1 (1,N,2), descriptors0/1 (1,N,64), image_size0/1 (1,2) as in the reference.
-        Returns the keys XFeat.match_lighterglue and typical callers read: 'matches' (list of (S,2) int64 tensors) and
-        'scores' (list of (S,) tensors).  (kornia additionally returns matches0/1, matching_scores0/1, stop, prune.)"""
+        Returns kornia's result keys: 'matches' (list of (S,2) int64), 'scores' (list of (S,)) -- what
+        XFeat.match_lighterglue reads -- plus 'matches0' (1,M) / 'matches1' (1,N) with -1 for unmatched points,
+        'matching_scores0/1' (score of the accepted match, 0 elsewhere; kornia also reports mutual-but-below-threshold
+        scores there) and 'stop' (= n_layers: early stopping is disabled by the reference's configuration)."""
         self.conf["filter_threshold"] = min_conf
         if data['keypoints0'].shape[0] != 1:
             raise ValueError("LighterGlue supports one pair per call (B = 1), like the reference")
@@ -197,4 +199,13 @@ class LighterGlue(nn.Module):
         m, s, c = self.match_device(data['keypoints0'][0], data['descriptors0'][0], sz(data['image_size0']), data['keypoints1'][0],
                                     data['descriptors1'][0], sz(data['image_size1']), min_conf)
         n = int(c.item())
-        return {'matches': [m[:n]], 'scores': [s[:n]]}
+        m, s = m[:n], s[:n]
+        n0, n1 = data['keypoints0'].shape[1], data['keypoints1'].shape[1]
+        m0 = torch.full((1, n0), -1, dtype=torch.int64, device=m.device)
+        m1 = torch.full((1, n1), -1, dtype=torch.int64, device=m.device)
+        s0 = torch.zeros((1, n0), dtype=torch.float32, device=m.device)
+        s1 = torch.zeros((1, n1), dtype=torch.float32, device=m.device)
+        m0[0, m[:, 0]], m1[0, m[:, 1]] = m[:, 1], m[:, 0]
+        s0[0, m[:, 0]], s1[0, m[:, 1]] = s, s
+        return {'matches0': m0, 'matches1': m1, 'matching_scores0': s0, 'matching_scores1': s1, 'stop': self.conf["n_layers"],
+                'matches': [m], 'scores': [s]}

@@ -123,6 +123,9 @@ def test_lighterglue_class_surface_and_determinism(lg, sd):
     assert torch.equal(out['matches'][0], out2['matches'][0]) and torch.equal(out['scores'][0], out2['scores'][0])
     assert out['matches'][0].dtype == torch.int64 and out['matches'][0].shape[1] == 2
     assert float(out['scores'][0].min()) > 0.05
+    mm = out['matches'][0]
+    assert torch.equal(out['matches0'][0, mm[:, 0]], mm[:, 1]) and torch.equal(out['matches1'][0, mm[:, 1]], mm[:, 0])
+    assert int((out['matches0'] >= 0).sum()) == len(mm) and torch.equal(out['matching_scores0'][0, mm[:, 0]], out['scores'][0])
     # the XFeat-level wrapper (modules/xfeat.py:131-162): numpy (S,2), (S,2), (S,2)
     xf = XFeat(weights=fixtures.synthetic_state_dict(0))
     xf.lighterglue = lg
