@@ -98,31 +98,27 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
 #pragma unroll
                 for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[hq * 16 + s], bf[s], acc, 0, 0, 0);
             }
-            // D[i=row][j=col]: this lane holds column cbase+l31, rows (r&3)+8*(r>>2)+4*half
+            // D[i=row][j=col]: this lane holds column cbase+l31, rows (r&3)+8*(r>>2)+4*half.
+            // No validity masks in this loop: rows >= n1 and columns >= n2 were loaded as copies of the last valid row /
+            // column, so they tie with it and lose every first-index tie-break (their indices are larger); the writes
+            // of match12 / colpart skip them.
             const int col = cbase + l31;
-            const bool cvalid = col < n2;
             // row direction: running max per (lane,row); strict > keeps the earliest column
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[r];
-                if (cvalid && v > bv[r]) { bv[r] = v; bc[r] = col; }
+                if (v > bv[r]) { bv[r] = v; bc[r] = col; }
             }
             // column direction: float max over this lane's 16 rows, then the FIRST row attaining it
-            // (rows ascend with r), rows >= n1 excluded; one packed key per lane per tile
-            float cm = -INFINITY;
+            // (rows ascend with r); one packed key per lane per tile
+            float cm = acc[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                cm = fmaxf(cm, row < n1 ? acc[r] : -INFINITY);
-            }
+            for (int r = 1; r < 16; ++r) cm = fmaxf(cm, acc[r]);
             int crow = 0x7fffffff;
 #pragma unroll
-            for (int r = 15; r >= 0; --r) {
-                const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < n1 && acc[r] == cm) crow = row;
-            }
-            unsigned long long best = crow == 0x7fffffff ? 0ull
-                                                         : (((unsigned long long)float_ord(cm) << 32) | (0xffffffffu - (unsigned)crow));
+            for (int r = 15; r >= 0; --r)
+                if (acc[r] == cm) crow = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            unsigned long long best = ((unsigned long long)float_ord(cm) << 32) | (0xffffffffu - (unsigned)crow);
             best = u64_max(best, shfl_xor_u64(best, 32));
             if (half == 0) colbest[wave][ct * 32 + l31] = best;
         }
