@@ -38,6 +38,17 @@ __device__ inline unsigned long long shfl_xor_u64(unsigned long long v, int o) {
     hi = __shfl_xor(hi, o, 64);
     return ((unsigned long long)hi << 32) | lo;
 }
+// Value held by the lane 32 positions away (lane ^ 32), without the LDS crossbar: v_permlane32_swap_b32 (gfx950) swaps
+// the upper half of one register with the lower half of another in a single VALU op; __shfl_xor(v, 32) costs two
+// address ops, a ds_bpermute and an lgkmcnt wait.
+__device__ inline unsigned xhalf_u32(unsigned v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);      // r[0] = {v.lo, v.lo}, r[1] = {v.hi, v.hi}
+    return (threadIdx.x & 32) ? r[0] : r[1];
+}
+__device__ inline float xhalf(float v) { return __uint_as_float(xhalf_u32(__float_as_uint(v))); }
+__device__ inline unsigned long long xhalf_u64(unsigned long long v) {
+    return ((unsigned long long)xhalf_u32((unsigned)(v >> 32)) << 32) | xhalf_u32((unsigned)v);
+}
 __device__ inline unsigned long long u64_max(unsigned long long a, unsigned long long b) { return a > b ? a : b; }
 
 // Monotone map float -> uint32: a < b  <=>  ord(a) < ord(b)   (NaN not expected on this path).

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, lg[m][r]);
             if (half == 0) mx = fmaxf(mx, lg[2][0]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = fmaxf(mx, xhalf(mx));
             float sum = 0.f;
             f32x16 e[2];
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { e[m][r] = expf(lg[m][r] - mx); sum += e[m][r]; }
             if (half == 0) sum += expf(lg[2][0] - mx);
-            sum += __shfl_xor(sum, 32, 64);
+            sum += xhalf(sum);
             if (gcell < a.ncell) {
                 const int b = gcell / hw, rem = gcell - b * hw;
                 const int ci = rem / a.wc, cj = rem - ci * a.wc;

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void lg_attention_kernel(LgAttSide sa, LgAt
         float tmax = s[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        tmax = fmaxf(tmax, xhalf(tmax));
         const float mnew = fmaxf(mrun, tmax);     // finite: every tile holds at least one live key
         if (__any(mnew != mrun)) {
             const float corr = __builtin_amdgcn_exp2f(mrun - mnew);           // raw v_exp_f32; exp2(-inf) = 0 on the first tile

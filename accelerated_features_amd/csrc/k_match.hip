@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
             for (int r = 15; r >= 0; --r)
                 if (acc[r] == cm) crow = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
             unsigned long long best = ((unsigned long long)float_ord(cm) << 32) | (0xffffffffu - (unsigned)crow);
-            best = u64_max(best, shfl_xor_u64(best, 32));
+            best = u64_max(best, xhalf_u64(best));
             if (half == 0) colbest[wave][ct * 32 + l31] = best;
         }
         __syncthreads();
