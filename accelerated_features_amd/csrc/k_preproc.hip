@@ -176,13 +176,16 @@ void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, floa
 // gray_coef_kernel and the run-to-run determinism are unchanged.
 // ------------------------------------------------------------------------------------------
 constexpr int R2_TW = 64, R2_TH = 16, R2_RW = 2 * R2_TW + 2, R2_RH = 2 * R2_TH + 2;      // LDS region for stage-2 steps < 2
+constexpr int R2_MAXC = 4;
 __global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __restrict__ img, int C, int Hin, int Win, int Hm, int Wm,
                                                                  float s1h, float s1w, int Ho, int Wo, float s2h, float s2w,
                                                                  double* __restrict__ part, float* __restrict__ gray) {
-    __shared__ float mid[R2_RH * R2_RW];
+    extern __shared__ float mid[];                                 // [C][rh * rw] of the current tile (rw-strided rows)
     const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
     const int tiles_x = ceil_div(Wo, R2_TW), tiles = tiles_x * ceil_div(Ho, R2_TH);
     const float fC = (float)C;
+    const size_t plane = (size_t)Hin * Win;
+    const float* base = img + (size_t)b * C * plane;
     const int lx = (tid & 15) * 4, ly = tid >> 4;                  // this thread: 4 consecutive output pixels of tile row ly
     double s = 0.0, q = 0.0;
     for (int t = ch; t < tiles; t += GS_CHUNKS) {
@@ -193,38 +196,37 @@ __global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __
         lin_coef(s2h, oy1, Hm, d0, ym1, f0, f1);
         lin_coef(s2w, ox0, Wm, xm0, d1, f0, f1);
         lin_coef(s2w, ox1, Wm, d0, xm1, f0, f1);
-        const int rh = ym1 - ym0 + 1, rw = xm1 - xm0 + 1;          // <= R2_RH x R2_RW (host checks the steps)
-        const int oy = oy0 + ly, ox = ox0 + lx;
-        int y0 = 0, y1 = 0; float wy0 = 0.f, wy1 = 0.f;
-        int x0[4], x1[4]; float wx0[4], wx1[4];
-        if (oy <= oy1) lin_coef(s2h, oy, Hm, y0, y1, wy0, wy1);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            x0[k] = x1[k] = xm0; wx0[k] = wx1[k] = 0.f;
-            if (ox + k <= ox1) lin_coef(s2w, ox + k, Wm, x0[k], x1[k], wx0[k], wx1[k]);
+        const int rh = ym1 - ym0 + 1, rw = xm1 - xm0 + 1, rsz = rh * rw;      // <= R2_RH x R2_RW (host checks the steps)
+        __syncthreads();                                            // the previous tile's readers are done
+        // stage 1: input -> intermediate grid, all channels of one region pixel per thread (coefficients computed once)
+        for (int e = tid; e < rsz; e += 256) {
+            const int ry = e / rw, rx = e - ry * rw;
+            int iy0, iy1, ix0, ix1; float vy0, vy1, vx0, vx1;
+            lin_coef(s1h, ym0 + ry, Hin, iy0, iy1, vy0, vy1);
+            lin_coef(s1w, xm0 + rx, Win, ix0, ix1, vx0, vx1);
+            for (int c = 0; c < C; ++c) mid[c * rsz + e] = bilerp(base + c * plane, Win, iy0, iy1, ix0, ix1, vy0, vy1, vx0, vx1);
         }
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < C; ++c) {
-            const float* p = img + ((size_t)b * C + c) * Hin * Win;
-            __syncthreads();                                        // previous channel's / tile's readers are done
-            for (int e = tid; e < rh * rw; e += 256) {
-                const int ry = e / rw, rx = e - ry * rw;
-                int iy0, iy1, ix0, ix1; float vy0, vy1, vx0, vx1;
-                lin_coef(s1h, ym0 + ry, Hin, iy0, iy1, vy0, vy1);
-                lin_coef(s1w, xm0 + rx, Win, ix0, ix1, vx0, vx1);
-                mid[ry * R2_RW + rx] = bilerp(p, Win, iy0, iy1, ix0, ix1, vy0, vy1, vx0, vx1);
-            }
-            __syncthreads();
-            if (oy <= oy1) {
-                const float* m = mid - ym0 * R2_RW - xm0;           // index with intermediate-grid coordinates
+        __syncthreads();
+        // stage 2: intermediate -> output grid from LDS, channel mean in gray_stats_kernel's order
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        if (oy <= oy1 && ox <= ox1) {
+            int y0, y1; float wy0, wy1;
+            lin_coef(s2h, oy, Hm, y0, y1, wy0, wy1);
+            y0 -= ym0; y1 -= ym0;
+            float a[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float v = bilerp(m, R2_RW, y0, y1, x0[k], x1[k], wy0, wy1, wx0[k], wx1[k]);
-                    a[k] = c == 0 ? v : a[k] + v;
+            for (int k = 0; k < 4; ++k) {
+                a[k] = 0.f;
+                if (ox + k <= ox1) {
+                    int x0, x1; float wx0, wx1;
+                    lin_coef(s2w, ox + k, Wm, x0, x1, wx0, wx1);
+                    x0 -= xm0; x1 -= xm0;
+                    for (int c = 0; c < C; ++c) {
+                        const float v = bilerp(mid + c * rsz, rw, y0, y1, x0, x1, wy0, wy1, wx0, wx1);
+                        a[k] = c == 0 ? v : a[k] + v;
+                    }
                 }
             }
-        }
-        if (oy <= oy1) {
             float* g = gray + ((size_t)b * Ho + oy) * Wo + ox;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -250,8 +252,14 @@ __global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __
 // returns -1 when the stage-2 step is too large for the LDS region (callers then materialise the images)
 int launch_gray_norm_resized(const float* img, int B, int C, int Hin, int Win, int Hm, int Wm, float s1h, float s1w, int Ho, int Wo,
                              float s2h, float s2w, double* part, float* gray, float* coef, hipStream_t st) {
-    if (!(s2h > 0.f) || !(s2w > 0.f) || s2h * (R2_TH - 1) + 3.f > (float)R2_RH || s2w * (R2_TW - 1) + 3.f > (float)R2_RW) return -1;
-    resize2_gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, Hin, Win, Hm, Wm, s1h, s1w, Ho, Wo, s2h, s2w, part, gray);
+    if (!(s2h > 0.f) || !(s2w > 0.f) || s2h * (R2_TH - 1) + 3.f > (float)R2_RH || s2w * (R2_TW - 1) + 3.f > (float)R2_RW || C > R2_MAXC) return -1;
+    // LDS: C planes of the largest intermediate region this (s2h, s2w) can need
+    const int rh = (int)(s2h * (R2_TH - 1)) + 3, rw = (int)(s2w * (R2_TW - 1)) + 3;
+    const size_t lds = (size_t)C * rh * rw * sizeof(float);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resize2_gray_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); attr = true; }
+    if (lds > 72 * 1024) return -1;
+    resize2_gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, lds, st>>>(img, C, Hin, Win, Hm, Wm, s1h, s1w, Ho, Wo, s2h, s2w, part, gray);
     gray_coef_kernel<<<B, 64, 0, st>>>(part, Ho * Wo, 1e-5f, coef);
     return 0;
 }
