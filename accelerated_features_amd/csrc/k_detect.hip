@@ -161,6 +161,85 @@ __global__ __launch_bounds__(256) void score_keys_kernel(const float* __restrict
 // compaction of the keys <= it into LDS, bitonic sort there.  One 1024-thread block per image.
 // dynamic LDS: kpad * 8 bytes.
 // ------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------
+// Ascending bitonic sort of n (power of two) 64-bit keys in LDS by a 1024-thread workgroup.  Every wave owns aligned
+// blocks of 256 keys (4 consecutive keys per lane): all compare-exchange steps with stride < 256 stay inside the wave
+// (registers for stride 1-2, v_permlane / ds_bpermute exchanges for 4..128) and need no workgroup barrier; only the
+// strides >= 256 of the last log2(n/256) merge phases go through LDS with a barrier each (18 barriers at n = 4096
+// instead of 78).
+// ------------------------------------------------------------------------------------------
+__device__ inline void cswap(unsigned long long& a, unsigned long long& b, bool up) {
+    if ((a > b) == up) { const unsigned long long t = a; a = b; b = t; }
+}
+// strides min(size/2, 128) .. 1 of the merge phase `size` on the wave's 4 keys per lane (block base index `base`)
+__device__ inline void bitonic_wave_steps(unsigned long long (&v)[4], int base, int lane, int size) {
+    for (int stride = min(size >> 1, 128); stride >= 4; stride >>= 1) {
+        const int ls = stride >> 2;                                // partner lane distance
+        const bool lower = (lane & ls) == 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = base + 4 * lane + e;
+            const bool up = (i & size) == 0;
+            const unsigned long long other = shfl_xor_u64(v[e], ls);
+            // the lower index of the pair keeps the smaller key when the run ascends
+            const bool keep_min = lower == up;
+            v[e] = keep_min ? (v[e] < other ? v[e] : other) : (v[e] > other ? v[e] : other);
+        }
+    }
+    const bool up = ((base + 4 * lane) & size) == 0;               // the 4 keys of a lane share the direction for size >= 4
+    if (size >= 4) { cswap(v[0], v[2], up); cswap(v[1], v[3], up); }
+    if (size >= 4) { cswap(v[0], v[1], up); cswap(v[2], v[3], up); }
+    else { cswap(v[0], v[1], true); cswap(v[2], v[3], false); }    // size == 2: pairs alternate direction inside the lane
+}
+__device__ inline void bitonic_sort_lds(unsigned long long* lk, int n) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n < 256) {                                                  // tiny sorts: plain network (top_k < 256)
+        for (int size = 2; size <= n; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (n >> 1); t += 1024) {
+                    const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                    const unsigned long long a = lk[i], c = lk[j];
+                    if ((a > c) == ((i & size) == 0)) { lk[i] = c; lk[j] = a; }
+                }
+                __syncthreads();
+            }
+        return;
+    }
+    const int nblk = n >> 8;
+    // phase 1: every 256-block fully sorted inside one wave (merge phases 2..256), direction by block parity
+    for (int blk = wave; blk < nblk; blk += 16) {
+        const int base = blk << 8;
+        unsigned long long v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = lk[base + 4 * lane + e];
+        for (int size = 2; size <= 256; size <<= 1) bitonic_wave_steps(v, base, lane, size);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lk[base + 4 * lane + e] = v[e];
+    }
+    __syncthreads();
+    // phase 2: merge phases 512 .. n: strides >= 256 through LDS, the rest inside the waves
+    for (int size = 512; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride >= 256; stride >>= 1) {
+            for (int t = tid; t < (n >> 1); t += 1024) {
+                const int i = 2 * t - (t & (stride - 1)), j = i + stride;
+                const unsigned long long a = lk[i], c = lk[j];
+                if ((a > c) == ((i & size) == 0)) { lk[i] = c; lk[j] = a; }
+            }
+            __syncthreads();
+        }
+        for (int blk = wave; blk < nblk; blk += 16) {
+            const int base = blk << 8;
+            unsigned long long v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = lk[base + 4 * lane + e];
+            bitonic_wave_steps(v, base, lane, size);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lk[base + 4 * lane + e] = v[e];
+        }
+        __syncthreads();
+    }
+}
+
 struct TopkOut {            // sparse-path epilogue (all NULL for the plain top-k)
     const unsigned* cand;   // (B,cap)
     float* kpts;            // (B,top_k,2)
@@ -197,10 +276,21 @@ __global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __
             __syncthreads();
             const unsigned long long prefix = s_prefix;
             const int shift = 56 - 8 * pass;
-            for (int i = tid; i < n; i += 1024) {
-                const unsigned long long key = cached ? kc[i] : kp[i];
-                const bool match = (pass == 0) || ((key >> (shift + 8)) == prefix);
-                if (match) atomicAdd(&hist[(int)((key >> shift) & 255)], 1);
+            for (int i0 = 0; i0 < n; i0 += 1024) {             // (uniform trip count: the ballots below need whole waves)
+                const int i = i0 + tid;
+                const unsigned long long key = i < n ? (cached ? kc[i] : kp[i]) : 0ull;
+                const bool match = i < n && ((pass == 0) || ((key >> (shift + 8)) == prefix));
+                const int d = (int)((key >> shift) & 255);
+                // scores share their leading bytes: in the first passes a whole wave hits ONE bin -- add its population once
+                const unsigned long long mm = __ballot(match);
+                if (mm) {
+                    const int d0 = __builtin_amdgcn_readlane(d, __builtin_ctzll(mm));
+                    if (__ballot(match && d != d0) == 0ull) {
+                        if ((tid & 63) == __builtin_ctzll(mm)) atomicAdd(&hist[d0], __popcll(mm));
+                    } else if (match) {
+                        atomicAdd(&hist[d], 1);
+                    }
+                }
             }
             __syncthreads();
             if (tid < 64) {     // wave 0 finds the digit whose cumulative count crosses kk (4 bins per lane + wave scan)
@@ -227,27 +317,23 @@ __global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __
     }
     if (tid == 0) { s_cnt = 0; s_valid = 0; }
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        const unsigned long long key = cached ? kc[i] : kp[i];
-        if (key <= T) {
-            const int slot = atomicAdd(&s_cnt, 1);
-            if (slot < kpad) lk[slot] = key;
+    for (int i0 = 0; i0 < n; i0 += 1024) {                 // one LDS atomic per wave, not per key (k of them hit one counter)
+        const int i = i0 + tid;
+        const unsigned long long key = i < n ? (cached ? kc[i] : kp[i]) : ~0ull;
+        const bool take = i < n && key <= T;
+        const unsigned long long mm = __ballot(take);
+        if (mm) {
+            const int lane = tid & 63, first = __builtin_ctzll(mm);
+            int base = 0;
+            if (lane == first) base = atomicAdd(&s_cnt, __popcll(mm));
+            base = __builtin_amdgcn_readlane(base, first);
+            const int slot = base + __popcll(mm & ((1ull << lane) - 1ull));
+            if (take && slot < kpad) lk[slot] = key;
         }
     }
     for (int i = k + tid; i < kpad; i += 1024) lk[i] = ~0ull;
     __syncthreads();
-    for (int size = 2; size <= kpad; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (kpad >> 1); t += 1024) {
-                const int i = 2 * t - (t & (stride - 1));
-                const int j = i + stride;
-                const bool up = ((i & size) == 0);
-                const unsigned long long a = lk[i], c = lk[j];
-                if ((a > c) == up) { lk[i] = c; lk[j] = a; }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_lds(lk, kpad);
     int nv = 0;
     for (int j = tid; j < top_k; j += 1024) {
         if (j < k) {
