@@ -18,14 +18,18 @@ namespace xfh {
 // padding) is larger (== local max; plateaus keep every equal pixel).
 // One workgroup = 64 x 32 pixels: the (64+4) x (32+4) tile is staged in LDS once, every lane
 // owns one column and slides a 5-row window of horizontal 5-maxima down its 8 rows
-// (5 LDS reads per row instead of 25 global loads).  grid (WPR, H/32, B).
+// (5 LDS reads per row instead of 25 global loads).  1-D grid, XCD-grouped by image.
 // ------------------------------------------------------------------------------------------
 constexpr int NMS_TW = 64, NMS_TH = 32, NMS_LW = NMS_TW + 4, NMS_LH = NMS_TH + 4;
-__global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict__ heat, int H, int W, int WPR, float thr,
+__global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict__ heat, int B, int H, int W, int WPR, int HT, float thr,
                                                         unsigned long long* __restrict__ mask, int* __restrict__ wcount) {
     __shared__ float tile[NMS_LH * NMS_LW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int word = blockIdx.x, y0 = blockIdx.y * NMS_TH, b = blockIdx.z;
+    // all tiles of an image on one XCD: the 2-pixel halos of neighbouring tiles hit that XCD's L2 (PMC: the plain
+    // (x, y, image) grid fetched every heat map twice)
+    int b, item;
+    if (!xcd_group_map(blockIdx.x, WPR * HT, B, b, item)) return;
+    const int word = item % WPR, y0 = (item / WPR) * NMS_TH;
     const int x0 = word * 64;
     const float* hp = heat + (size_t)b * H * W;
     for (int e = tid; e < NMS_LH * NMS_LW; e += 256) {
@@ -478,7 +482,7 @@ void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, c
                    int32_t* n_valid, int32_t* n_cand, hipStream_t st) {
     const int WPR = ceil_div(W, 64);
     const int hc = H / 8, wc = W / 8;
-    nms_flags_kernel<<<dim3(WPR, ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, H, W, WPR, thr, ws.mask, ws.wcount);
+    nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
     score_keys_kernel<<<dim3(ceil_div(cap, 256), B), 256, 0, st>>>(heat, reliab, ws.cand, n_cand, H, W, cap, ws.keys);
     TopkOut o{ws.cand, kpts, scores, n_valid, rw, rh};
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(256) void cand_to_xy_kernel(const unsigned* __restr
 void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int cap, int64_t* xy,
                      int32_t* n_cand, hipStream_t st) {
     const int WPR = ceil_div(W, 64);
-    nms_flags_kernel<<<dim3(WPR, ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, H, W, WPR, thr, ws.mask, ws.wcount);
+    nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
     cand_to_xy_kernel<<<dim3(ceil_div(cap, 256), B), 256, 0, st>>>(ws.cand, n_cand, cap, xy);
 }
