@@ -126,7 +126,8 @@ constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead o
 constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19389 floats = 77.6 KB
 }  // namespace b1
 
-__global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int H, int W,
+__global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int B, int H, int W,
+                                                           int tiles_x, int tiles_y,
                                                            const float* __restrict__ w1, const float* __restrict__ bb1,
                                                            const float* __restrict__ w2, const float* __restrict__ bb2,
                                                            const float* __restrict__ w3, const float* __restrict__ bb3,
@@ -139,7 +140,10 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     float* C2 = lds + C2_OFF;
     float* C3 = lds + C3_OFF;
     const int tid = threadIdx.x;
-    const int b = blockIdx.z, Y4 = blockIdx.y * OH, X4 = blockIdx.x * OW;
+    // the tiles of an image run on one XCD: the 4-pixel gray halos of neighbouring tiles hit its L2
+    int b, item;
+    if (!xcd_group_map(blockIdx.x, tiles_x * tiles_y, B, b, item)) return;
+    const int Y4 = (item / tiles_x) * OH, X4 = (item % tiles_x) * OW;
     const int H2 = H >> 1, W2 = W >> 1, H4 = H >> 2, W4 = W >> 2;
     const float* gb = gray + (size_t)b * H * W;
 
@@ -291,8 +295,9 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
         attr = true;
     }
     const int H4 = H / 4, W4 = W / 4;
-    block1_fused_kernel<<<dim3(ceil_div(W4, b1::OW), ceil_div(H4, b1::OH), B), 512, b1::LDS_FLOATS * 4, st>>>(
-        gray, coef, x1, H, W, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
+    const int tx = ceil_div(W4, b1::OW), ty = ceil_div(H4, b1::OH);
+    block1_fused_kernel<<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(
+        gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
 }
 
 // ------------------------------------------------------------------------------------------
