@@ -17,7 +17,8 @@ for rep in range(3):
     print("backbone608", [bool(torch.equal(x, y)) for x, y in zip(fe[0], fe[1])])
     d2 = xf.detectAndComputeDense(b, top_k=4096)
     m = [xf._batch_match_device(d1[0]["descriptors"], d2["descriptors"], -1) for _ in range(2)]
-    print("match", [bool(torch.equal(x, y)) for x, y in zip(m[0], m[1])], m[0][2].tolist())
+    nmv = m[0][2].tolist()      # idx buffers are torch.empty beyond n_matches: compare the valid prefixes only
+    print("match", bool(torch.equal(m[0][2], m[1][2])) and all(bool(torch.equal(m[0][q][p, :nmv[p]], m[1][q][p, :nmv[p]])) for q in (0, 1) for p in range(len(nmv))), nmv)
     r = [xf._refine_device(d1[0], d2, m[0][0], m[0][1], m[0][2], 0.25) for _ in range(2)]
     n = r[0][1].tolist()
     print("refine n_out", n, r[1][1].tolist(), "rows equal", [bool(torch.equal(r[0][0][p, :n[p]], r[1][0][p, :n[p]])) for p in range(len(n))])
