@@ -14,8 +14,9 @@ this file restates that published algorithm, with the state_dict key names the r
 PARITY STATUS: **unpinned against kornia 0.7.2** (absent).  What IS pinned: every building block (rotary
 self-attention block, bidirectional cross-attention block, FFN, match assignment, mutual filter, key-point
 normalisation, positional encoding) against the independent HuggingFace port
-(`transformers/models/lightglue/modeling_lightglue.py`) with tied weights -- see
-tests/golden/make_golden_lighterglue.py and tests/test_oracle_lighterglue.py.  Not pinned by anything on disk:
+(`transformers/models/lightglue/modeling_lightglue.py`) with tied weights, AND the whole matcher end to end without
+width pruning against that port's own `LightGlueForKeypointMatching._match_image_pair` (identical match list, scores
+within 2e-5) -- see tests/golden/make_golden_lighterglue.py and tests/test_oracle_lighterglue.py.  Not pinned by anything on disk:
 the width-pruning rule and its CPU threshold (`pruning_keypoint_thresholds['cpu'] = -1`, i.e. pruning is always
 on for CPU tensors), restated from the published implementation.
 """

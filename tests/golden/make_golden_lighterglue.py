@@ -84,6 +84,31 @@ def main():
              mscores0=mscores[0].numpy(), matchability0=ma.get_matchability(d0[None])[0].numpy())
     print("wrote lg_posenc.npz lg_layer.npz lg_assign.npz;", int((matches[0] > -1).sum()), "matches of", N)
 
+    # (4) END TO END without width pruning: the port's own LightGlueForKeypointMatching._match_image_pair (input projection,
+    #     positional encoding, 6 layers, assignment of the last layer, mutual filter) with every weight tied to ours.
+    #     (Its pruning path is not used: it needs early stopping enabled and also prunes after the last layer, which is not
+    #     what kornia does; pruning stays pinned only through get_matchability in (3).)
+    from transformers import SuperPointConfig
+    cfg2 = LightGlueConfig(keypoint_detector_config=SuperPointConfig(descriptor_decoder_dim=64), descriptor_dim=96, num_hidden_layers=6,
+                           num_attention_heads=1, depth_confidence=-1.0, width_confidence=-1.0, filter_threshold=0.05)
+    cfg2._attn_implementation = "eager"
+    model = M.LightGlueForKeypointMatching(cfg2).eval()
+    model.input_projection.load_state_dict({"weight": sd["input_proj.weight"].clone(), "bias": sd["input_proj.bias"].clone()})
+    model.positional_encoder.load_state_dict({"projector.weight": sd["posenc.Wr.weight"].clone()})
+    for i in range(6):
+        model.transformer_layers[i].load_state_dict(hf_layer(cfg2, sd, i).state_dict())
+        model.match_assignment_layers[i].load_state_dict({
+            "final_projection.weight": sd[f"log_assignment.{i}.final_proj.weight"].clone(), "final_projection.bias": sd[f"log_assignment.{i}.final_proj.bias"].clone(),
+            "matchability.weight": sd[f"log_assignment.{i}.matchability.weight"].clone(), "matchability.bias": sd[f"log_assignment.{i}.matchability.bias"].clone()})
+    N2 = 211
+    k0, desc0, size0, k1, desc1, size1 = fixtures.lighterglue_inputs(N2, N2, seed=4, size0=(640, 480), size1=(640, 480))
+    m, ms, _, _, _ = model._match_image_pair(torch.stack([k0, k1])[None], torch.stack([desc0, desc1])[None], int(size0[1]), int(size0[0]),
+                                             mask=torch.ones((1, 2, N2), dtype=torch.int))
+    m, ms = m.reshape(2, N2), ms.reshape(2, N2)
+    np.savez(os.path.join(HERE, "lg_e2e.npz"), k0=k0.numpy(), desc0=desc0.numpy(), size0=size0.numpy(), k1=k1.numpy(), desc1=desc1.numpy(),
+             size1=size1.numpy(), matches0=m[0].numpy(), matches1=m[1].numpy(), mscores0=ms[0].numpy(), mscores1=ms[1].numpy(), threshold=np.float32(0.05))
+    print("wrote lg_e2e.npz;", int((m[0] > -1).sum()), "matches of", N2)
+
 
 if __name__ == "__main__":
     main()

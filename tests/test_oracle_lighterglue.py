@@ -65,3 +65,19 @@ def test_full_matcher_runs_prunes_and_is_consistent():
     assert sizes[0] == 300 and sizes[-1] <= sizes[0]                        # width pruning only ever removes points
     m2, _ = lg.lighterglue_forward(SD, k0, d0, s0, k1, d1, s1, min_conf=0.1, prune=False)
     assert m2.shape[1] == 2                                                  # un-pruned variant (what a CUDA run below the threshold does)
+
+
+def test_end_to_end_without_pruning_matches_the_hf_port():
+    """The whole matcher (input projection, encoding, 6 layers, last-layer assignment, mutual filter) against the HuggingFace
+    port's own LightGlueForKeypointMatching._match_image_pair with tied weights (tests/golden/lg_e2e.npz)."""
+    g = np.load(os.path.join(fixtures.GOLDEN_DIR, "lg_e2e.npz"))
+    t = lambda k: torch.from_numpy(g[k])
+    m, sc = lg.lighterglue_forward(SD, t("k0"), t("desc0"), t("size0"), t("k1"), t("desc1"), t("size1"), min_conf=float(g["threshold"]), prune=False)
+    m0 = g["matches0"]
+    want = [(i, int(j)) for i, j in enumerate(m0) if j > -1]
+    assert len(want) >= 5
+    assert [tuple(r) for r in m.tolist()] == want
+    np.testing.assert_allclose(sc.numpy(), g["mscores0"][m0 > -1], rtol=2e-5, atol=1e-7)
+    # the port's matches1 is the same assignment seen from image 1
+    m1 = g["matches1"]
+    assert all(int(m1[j]) == i for i, j in want) and int((m1 > -1).sum()) == len(want)
