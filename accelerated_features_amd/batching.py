@@ -59,11 +59,7 @@ def match_pairs(xfeat, pairs, top_k=None, min_cossim=-1, max_pairs=32, rank=0, w
                 res = _detect_exact(xfeat, x, top_k)
                 kpts, desc, nv = res
                 idx0, idx1, nm = xfeat.match_pairs_device(desc, nv, min_cossim)
-                nm = nm.cpu().tolist()
-                for p, it in enumerate(chunk):
-                    k0 = kpts[2 * p][idx0[p, :nm[p]]]
-                    k1 = kpts[2 * p + 1][idx1[p, :nm[p]]]
-                    out[it[0]] = (k0.cpu().numpy(), k1.cpu().numpy())
+                _collect(out, chunk, kpts[0::2], kpts[1::2], idx0, idx1, nm)
             else:                                   # the two images of a pair differ in size: one batch per side
                 xa = torch.stack([it[1] for it in chunk])
                 xb = torch.stack([it[3] for it in chunk])
@@ -72,10 +68,21 @@ def match_pairs(xfeat, pairs, top_k=None, min_cossim=-1, max_pairs=32, rank=0, w
                 ka, da, na = _detect_exact(xfeat, xa, top_k)
                 kb, db, nb = _detect_exact(xfeat, xb, top_k)
                 idx0, idx1, nm = xfeat.match_sets_device(da, na, db, nb, min_cossim)
-                nm = nm.cpu().tolist()
-                for p, it in enumerate(chunk):
-                    out[it[0]] = (ka[p][idx0[p, :nm[p]]].cpu().numpy(), kb[p][idx1[p, :nm[p]]].cpu().numpy())
+                _collect(out, chunk, ka, kb, idx0, idx1, nm)
     return [out[i] for i in range(lo, hi)]
+
+
+def _collect(out, chunk, kp0, kp1, idx0, idx1, nm):
+    """Matched coordinates of a whole chunk in three device->host copies (not two per pair): gather on the device into
+    fixed-capacity arrays, slice by the match counts on the host.  Entries past a pair's count index row 0 (harmless)."""
+    n = nm.to(torch.int64)
+    keep = torch.arange(idx0.shape[1], device=idx0.device)[None] < n[:, None]
+    g0 = torch.gather(kp0, 1, torch.where(keep, idx0, 0)[..., None].expand(-1, -1, 2))
+    g1 = torch.gather(kp1, 1, torch.where(keep, idx1, 0)[..., None].expand(-1, -1, 2))
+    packed = torch.cat([g0, g1], -1).cpu().numpy()                 # (P, cap, 4)
+    counts = nm.cpu().tolist()
+    for p, it in enumerate(chunk):
+        out[it[0]] = (packed[p, :counts[p], :2].copy(), packed[p, :counts[p], 2:].copy())
 
 
 def _detect_exact(xfeat, x, top_k):
