@@ -177,6 +177,9 @@ void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, floa
 // ------------------------------------------------------------------------------------------
 constexpr int R2_TW = 64, R2_TH = 16, R2_RW = 2 * R2_TW + 2, R2_RH = 2 * R2_TH + 2;      // LDS region for stage-2 steps < 2
 constexpr int R2_MAXC = 4;
+__device__ inline float buffer_load_f32(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
 __global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __restrict__ img, int C, int Hin, int Win, int Hm, int Wm,
                                                                  float s1h, float s1w, int Ho, int Wo, float s2h, float s2w,
                                                                  double* __restrict__ part, float* __restrict__ gray) {
@@ -186,6 +189,8 @@ __global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __
     const float fC = (float)C;
     const size_t plane = (size_t)Hin * Win;
     const float* base = img + (size_t)b * C * plane;
+    // buffer resource of this image (C planes; < 2 GiB, checked by the host): 32-bit offsets, channel plane as scalar offset
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((size_t)C * plane * 4), 0x00020000);
     const int lx = (tid & 15) * 4, ly = tid >> 4;                  // this thread: 4 consecutive output pixels of tile row ly
     double s = 0.0, q = 0.0;
     for (int t = ch; t < tiles; t += GS_CHUNKS) {
@@ -204,7 +209,15 @@ __global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __
             int iy0, iy1, ix0, ix1; float vy0, vy1, vx0, vx1;
             lin_coef(s1h, ym0 + ry, Hin, iy0, iy1, vy0, vy1);
             lin_coef(s1w, xm0 + rx, Win, ix0, ix1, vx0, vx1);
-            for (int c = 0; c < C; ++c) mid[c * rsz + e] = bilerp(base + c * plane, Win, iy0, iy1, ix0, ix1, vy0, vy1, vx0, vx1);
+            // the four tap offsets once per region pixel (32-bit, bytes); the channel plane goes into the scalar offset of
+            // the buffer load instead of 64-bit pointer arithmetic per tap and channel
+            const int o00 = (iy0 * Win + ix0) * 4, o01 = (iy0 * Win + ix1) * 4, o10 = (iy1 * Win + ix0) * 4, o11 = (iy1 * Win + ix1) * 4;
+            for (int c = 0; c < C; ++c) {
+                const int so = c * (int)(plane * 4);
+                const float v00 = buffer_load_f32(rs, o00, so), v01 = buffer_load_f32(rs, o01, so);
+                const float v10 = buffer_load_f32(rs, o10, so), v11 = buffer_load_f32(rs, o11, so);
+                mid[c * rsz + e] = vy0 * (vx0 * v00 + vx1 * v01) + vy1 * (vx0 * v10 + vx1 * v11);
+            }
         }
         __syncthreads();
         // stage 2: intermediate -> output grid from LDS, channel mean in gray_stats_kernel's order
@@ -252,7 +265,7 @@ __global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __
 // returns -1 when the stage-2 step is too large for the LDS region (callers then materialise the images)
 int launch_gray_norm_resized(const float* img, int B, int C, int Hin, int Win, int Hm, int Wm, float s1h, float s1w, int Ho, int Wo,
                              float s2h, float s2w, double* part, float* gray, float* coef, hipStream_t st) {
-    if (!(s2h > 0.f) || !(s2w > 0.f) || s2h * (R2_TH - 1) + 3.f > (float)R2_RH || s2w * (R2_TW - 1) + 3.f > (float)R2_RW || C > R2_MAXC) return -1;
+    if (!(s2h > 0.f) || !(s2w > 0.f) || s2h * (R2_TH - 1) + 3.f > (float)R2_RH || s2w * (R2_TW - 1) + 3.f > (float)R2_RW || C > R2_MAXC || (size_t)C * Hin * Win * 4 >= (1ull << 31)) return -1;
     // LDS: C planes of the largest intermediate region this (s2h, s2w) can need
     const int rh = (int)(s2h * (R2_TH - 1)) + 3, rw = (int)(s2w * (R2_TW - 1)) + 3;
     const size_t lds = (size_t)C * rh * rw * sizeof(float);
