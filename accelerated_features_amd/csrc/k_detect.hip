@@ -448,23 +448,28 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     cubic_w(ux - fx, wx);
     cubic_w(uy - fy, wy);
     const int x0 = (int)fx - 1, y0 = (int)fy - 1;
-    const float4* fb = reinterpret_cast<const float4*>(feats + (size_t)b * hc * wc * 64) + sub;
-    const float* ib = inv + (size_t)b * hc * wc;
+    // buffer loads: 32-bit offsets, and taps outside the map read 0 through the range check of the resource (rows above /
+    // below fall outside image b's buffer; columns left / right get an out-of-range offset) -- no per-tap branches or
+    // 64-bit pointer arithmetic.  A zero tap adds +-0 to the sums: the value a skipped tap leaves.
+    const int npix = hc * wc;
+    const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feats + (size_t)b * npix * 64), 0, npix * 256, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inv + (size_t)b * npix), 0, npix * 4, 0x00020000);
+    int cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cx[i] = (x0 + i >= 0 && x0 + i < wc) ? x0 + i : 0x00800000;      // 2^23 pixels = byte offset 2^31: outside any map, no 32-bit wrap
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int yy = y0 + r;
+        const int rowpix = (y0 + r) * wc;
         float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int xx = x0 + i;
-            if (xx >= 0 && xx < wc && yy >= 0 && yy < hc) {
-                const int pix = yy * wc + xx;
-                const float4 v = fb[(size_t)pix * 16];
-                const float sc = ib[pix];
-                row.x += (v.x * sc) * wx[i]; row.y += (v.y * sc) * wx[i];
-                row.z += (v.z * sc) * wx[i]; row.w += (v.w * sc) * wx[i];
-            }
+            const int pix = rowpix + cx[i];
+            const uint4 u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rf, pix * 256 + sub * 16, 0, 0));
+            const float4 v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+            const float sc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ri, pix * 4, 0, 0));
+            row.x += (v.x * sc) * wx[i]; row.y += (v.y * sc) * wx[i];
+            row.z += (v.z * sc) * wx[i]; row.w += (v.w * sc) * wx[i];
         }
         acc.x += row.x * wy[r]; acc.y += row.y * wy[r]; acc.z += row.z * wy[r]; acc.w += row.w * wy[r];
     }
