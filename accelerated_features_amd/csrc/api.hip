@@ -527,6 +527,8 @@ int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, cons
     int rc = check_img("xfh_detect_sparse", B, 1, H, W);
     if (rc) return rc;
     if (top_k <= 0 || top_k > 16384) return fail(XFH_ERR_UNSUPPORTED, "xfh_detect_sparse: top_k %d outside 1..16384", top_k);
+    if ((long)(H / 8) * (W / 8) >= (1L << 22))      // descriptor_kernel addresses the feature map with 32-bit byte offsets
+        return fail(XFH_ERR_UNSUPPORTED, "xfh_detect_sparse: %dx%d is beyond 2^22 feature cells (about 16k x 16k pixels)", H, W);
     if (nms_capacity <= 0 || (long)nms_capacity > (long)H * W) return fail(XFH_ERR_ARG, "xfh_detect_sparse: nms_capacity %d outside 1..H*W", nms_capacity);
     DetectWs w;
     const size_t need = carve_detect(workspace, B, H, W, top_k, nms_capacity, w);
