@@ -50,6 +50,8 @@ SIGNATURES = {
     "xfh_lg_destroy": (None, [_p]),
     "xfh_lg_workspace_bytes": (_sz, [_i, _i]),
     "xfh_lg_match": (_i, [_p, _p, _p, _i, _f, _f, _p, _p, _i, _f, _f, _f, _i, _p, _p, _p, _p, _sz, _p]),
+    "xfh_lg_profile": (_i, [_p, _i]),
+    "xfh_lg_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "xfh_lg_match_pairs": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "xfh_profile_select": (_i, [_p, _i]),
     "xfh_debug_trace": (_i, [_p, _p]),

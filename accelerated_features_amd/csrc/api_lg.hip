@@ -30,6 +30,11 @@ struct LgLayer {
 struct xfh_lg_context {
     int device;
     float* blob;
+    // bench hook (xfh_lg_profile): HIP events around every attention launch + its algorithmic FLOPs at the capacities
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    size_t prof_used = 0;
+    double prof_flops = 0;
     LgLin input_proj, final_proj;     // final_proj = log_assignment[5].final_proj / 96^(1/4)
     const float* wr;                  // posenc.Wr (48,2)
     LgLayer layer[LG_LAYERS];
@@ -150,8 +155,34 @@ int xfh_lg_create(const float* const* host_arrays, int n_arrays, int device, xfh
     return XFH_OK;
 }
 
+int xfh_lg_profile(xfh_lg_handle h, int enable) {
+    if (!h) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_profile: NULL handle");
+    h->prof_on = enable != 0;
+    h->prof_used = 0;
+    h->prof_flops = 0;
+    return XFH_OK;
+}
+
+int xfh_lg_profile_read(xfh_lg_handle h, int* n_launches, double* total_ms, double* total_flops) {
+    if (!h) return xfh_set_error(XFH_ERR_ARG, "xfh_lg_profile_read: NULL handle");
+    double ms = 0;
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        float t = 0;
+        if (hipEventSynchronize(h->prof_ev[i + 1]) != hipSuccess || hipEventElapsedTime(&t, h->prof_ev[i], h->prof_ev[i + 1]) != hipSuccess)
+            return xfh_set_error(XFH_ERR_HIP, "xfh_lg_profile_read: event query failed");
+        ms += t;
+    }
+    if (n_launches) *n_launches = (int)(h->prof_used / 2);
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = h->prof_flops;
+    h->prof_used = 0;
+    h->prof_flops = 0;
+    return XFH_OK;
+}
+
 void xfh_lg_destroy(xfh_lg_handle h) {
     if (!h) return;
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->blob) (void)hipFree(h->blob);
     delete h;
 }
@@ -254,7 +285,20 @@ static int lg_match_impl(xfh_lg_handle h, const float* kpts0, const float* desc0
             const float* kv = w.s[t].qkv;
             sd[s] = LgAttSide{w.s[s].qkv, cross ? kv : kv + 96, cross ? kv + 96 : kv + 192, w.s[s].att, nullptr, nn[s], nn[t], N[s], N[t], 1};
         }
+        if (h->prof_on) {
+            if (h->prof_used + 2 > h->prof_ev.size()) {
+                hipEvent_t a, b;
+                (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+                h->prof_ev.push_back(a); h->prof_ev.push_back(b);
+            }
+            (void)hipEventRecord(h->prof_ev[h->prof_used], st);
+        }
         launch_lg_attention(sd, 2, 288, 288, 288, 96, w.part, scale, st);
+        if (h->prof_on) {
+            (void)hipEventRecord(h->prof_ev[h->prof_used + 1], st);
+            h->prof_used += 2;
+            for (int s = 0; s < 2; ++s) h->prof_flops += 4.0 * N[s] * N[cross ? s ^ 1 : s] * LG_D;      // Q.K^T and P.V at the capacities
+        }
     };
     const float self_scale = 1.0f / std::sqrt((float)LG_D);
     for (int i = 0; i < LG_LAYERS; ++i) {

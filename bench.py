@@ -174,6 +174,7 @@ def bench_lighterglue(args, xf, rank, world, dist):
     key-point lists with device-side counts: one read-back per step)."""
     import fixtures
     from accelerated_features_amd.lighterglue import LighterGlue
+    from accelerated_features_amd import _lib as _lib_mod
     lg = LighterGlue(weights=fixtures.lighterglue_state_dict(0))
     B = args.batch
     x = make_frames(B, seed=1000 + rank).cuda()
@@ -215,6 +216,21 @@ def bench_lighterglue(args, xf, rank, world, dist):
                           "batch_per_gpu": B, "top_k": TOP_K, "weights": "synthetic (tests/fixtures.py; parity of the matcher unpinned vs kornia, see DESIGN.md)",
                           "mean_keypoints": round(kpt, 1), "mean_matches": round(float(np.mean(nm)), 1),
                           "prune_min_kpts": lg.prune_min_kpts, "gflop_per_pair_unpruned": round(flops_pair / 1e9, 1)}}
+        # roofline of the dominant kernel (lg_attention_kernel, 60 % of a pair): untimed pass of 3 pairs without width pruning
+        # (so that the live key-point counts equal the capacities the FLOPs are counted at), HIP events on the launch stream
+        lib = _lib_mod.load()
+        lib.xfh_lg_profile(lg.handle(), 1)
+        kp, sc, de, nv, nc, cap, hw = xf._detect_device(x[:6], TOP_K, 0.05)
+        lg.match_pairs_device(kp, de, nv, (W, H), 0.0, _lib_mod.LG_NO_PRUNING)
+        torch.cuda.synchronize()
+        n_l, ms, fl = C.c_int(), C.c_double(), C.c_double()
+        lib.xfh_lg_profile_read(lg.handle(), C.byref(n_l), C.byref(ms), C.byref(fl))
+        lib.xfh_lg_profile(lg.handle(), 0)
+        ach = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        out["roofline"] = {"bound": "mfma", "kernel": "lg_attention_kernel (flash-style softmax(QK^T)V on v_mfma_f32_32x32x2_f32, both images per launch)",
+                           "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+                           "launches": n_l.value, "avg_launch_us": round(1e3 * ms.value / max(n_l.value, 1), 2),
+                           "algorithmic": "4*Nq*Nk*96 FLOP per image and launch (4096 x 4096 key-points, pruning off for this pass)", "traffic": None}
         if world == 1 and args.cpu_seconds > 0:
             from oracle import lighterglue_oracle as LGO
             sdl = fixtures.lighterglue_state_dict(0)

@@ -242,6 +242,12 @@ int xfh_lg_match(xfh_lg_handle h, const float* kpts0, const float* desc0, int N0
                  int64_t* matches, float* scores, int32_t* n_matches, void* workspace, size_t workspace_bytes,
                  xfh_stream stream);
 
+/* bench.py hook: HIP events on the launch stream around every attention launch of this handle (lg_attention_kernel, both
+ * images per launch) while enabled; xfh_lg_profile_read returns their number, summed duration and algorithmic FLOPs
+ * (4 N_q N_k 96 per image and launch, at the key-point capacities -- run with XFH_LG_NO_PRUNING for exact figures) and resets. */
+int xfh_lg_profile(xfh_lg_handle h, int enable);
+int xfh_lg_profile_read(xfh_lg_handle h, int* n_launches, double* total_ms, double* total_flops);
+
 /* The batch form used with xfh_detect_sparse's fixed-capacity outputs: frames (2p, 2p+1) of kpts (2P,cap,2) /
  * desc (2P,cap,64) / counts (2P) int32 (all device memory) form pair p; every image has size (W,H).  No host
  * read-back of the counts; pairs run back to back on `stream` and share one workspace of
