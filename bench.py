@@ -108,6 +108,25 @@ def cpu_sample(seconds, fn, unit, units_per_call, what):
             "sample": f"{n} x ({what}) in {used:.1f} s, torch CPU threads={threads}"}
 
 
+def conv_family_roofline(xf, step_fn, n=2):
+    """Secondary, untimed pass shared by the dense / megadepth workloads: HIP events (xfh_profile_select) around every MFMA
+    convolution launch (Winograd + direct) of `n` steps -> achieved TFLOP/s with the direct form's algorithmic FLOPs."""
+    from accelerated_features_amd import _lib
+    lib, handle = _lib.load(), xf.net.handle()
+    lib.xfh_profile_select(handle, _lib.PROF_CONV_MFMA)
+    for _ in range(n):
+        step_fn()
+    torch.cuda.synchronize()
+    cn, cms, cfl, cby = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+    lib.xfh_profile_read(handle, C.byref(cn), C.byref(cms), C.byref(cfl), C.byref(cby))
+    lib.xfh_profile_select(handle, _lib.PROF_NONE)
+    ach = (cfl.value / 1e12) / (cms.value / 1e3) if cms.value > 0 else 0.0
+    return {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> (every MFMA convolution launch of the step; FLOPs of the direct "
+                                       "form -- the 3x3/s1 layers execute 2.25x fewer as Winograd F(2x2,3x3))",
+            "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+            "launches": cn.value, "ms_per_step": round(cms.value / n, 3), "traffic": None}
+
+
 def load_pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -156,7 +175,7 @@ def bench_dense(args, xf, rank, world, dist):
             cpu = cpu_sample(args.cpu_seconds, lambda: O.match_xfeat_star(sd, ca, cb, top_k=TOP_K), "pairs/s", 1,
                              "oracle match_xfeat_star on one 1024x1024 pair")
         print(json.dumps({
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "roofline": conv_family_roofline(xf, step),
             "metric": "image pairs/sec match_xfeat_star (1024x1024, top_k=4096)", "value": round(world * P * args.steps / float(tmax.item()), 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * float(tmax.item()) / args.steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -308,7 +327,7 @@ def bench_megadepth(args, xf, rank, world, dist):
             cpu = cpu_sample(args.cpu_seconds, lambda: O.match_xfeat(sd, ca, cb, top_k=TOP_K), "pairs/s", 1,
                              f"oracle match_xfeat on one pair of {tuple(ca.shape[2:])} / {tuple(cb.shape[2:])} images")
         print(json.dumps({
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "roofline": conv_family_roofline(xf, step, 1),
             "metric": "image pairs/sec match_xfeat over the MegaDepth-1500 pair list (long side 1600, top_k=4096)",
             "value": round(len(sizes) * args.steps / t, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * t / args.steps, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
