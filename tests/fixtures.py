@@ -9,6 +9,11 @@ parity is checked on synthetic weights and images (SURVEY.md finding 3/5, App. B
   layer's pre-activation is roughly zero-mean/unit-variance like a trained net, and committed
   as ``tests/golden/bn_stats.npz`` (they cannot be regenerated bit-exactly on another
   machine because they depend on the CPU conv summation order);
+* ``block_fusion.2`` (the plain 1x1 conv that emits the 64-D descriptors) is composed with a
+  ZCA whitening of its own output, calibrated by the same script and committed in the same
+  file: whitened descriptors make the raw-dot-product mutual-NN of the semi-dense matcher find
+  thousands of matches on a noisy copy of an image (plain random weights: ~1 of 4095, SURVEY
+  App. B.3), so ``match_xfeat_star`` has real rows to refine and compare;
 * ``keypoint_head.3.weight`` is sharpened so the heat map clears the 0.05 detection
   threshold (default init gives zero keypoints), ``fine_matcher.12.weight`` likewise so the
   refinement confidences clear 0.25.
@@ -30,7 +35,7 @@ GOLDEN_DIR = os.path.join(_HERE, "golden")
 BN_STATS = os.path.join(GOLDEN_DIR, "bn_stats.npz")
 
 KEYPOINT_SHARPEN = 6.0
-FINE_SHARPEN = 0.5
+FINE_SHARPEN = 1.0
 
 
 def raw_state_dict(seed=0):
@@ -111,6 +116,13 @@ def shifted_pair(B, H, W, seed=7, shift=(16, 24), noise=0.02):
     b = torch.roll(a, shifts=shift, dims=(2, 3)) + torch.from_numpy(
         (noise * rs.randn(B, 3, H, W)).astype(np.float32))
     return a, b
+
+
+def star_pair(B, H, W, seed=41, noise=0.005):
+    """(a, b): b = a + small noise.  The pair the semi-dense tests use: the dual-scale path resizes by 0.6 and 1.3 and
+    the backbone strides by 32, so no non-trivial shift keeps both scales cell-aligned; a noisy copy gives thousands
+    of mutual matches whose refinement (fine_matcher offsets, confidence filter) is real work to compare."""
+    return shifted_pair(B, H, W, seed=seed, shift=(0, 0), noise=noise)
 
 
 # ------------------------------------------------------------------------------------------------------------

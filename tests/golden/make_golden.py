@@ -28,7 +28,31 @@ import fixtures  # noqa: E402
 from modules.xfeat import XFeat  # noqa: E402  (the reference)
 
 
+WHITEN_FLOOR = 0.1          # eigenvalue floor of the descriptor whitening: amplification <= 1/sqrt(0.1) = 3.2x
+
+
+def _dense_feats(net, xf, imgs, scales=(0.6, 1.0, 1.3)):
+    """Raw dense features (n,64) of `imgs` at the scales the semi-dense path works on."""
+    out = []
+    for s in scales:
+        x = torch.nn.functional.interpolate(imgs, scale_factor=s, align_corners=False, mode="bilinear")
+        x, _, _ = xf.preprocess_tensor(x)
+        f, _, _ = net(x)
+        out.append(f.permute(0, 2, 3, 1).reshape(-1, 64))
+    return torch.cat(out)
+
+
 def calibrate():
+    """Fixture calibration (all of it with the reference's own modules, CPU):
+    1. BatchNorm2d running statistics of the backbone + heads: one train-mode forward (momentum=None).
+    2. block_fusion.2 (the plain 1x1 conv that emits the descriptors) is composed with a ZCA whitening of the dense
+       features it produces on seeded textures (eigenvalues floored at WHITEN_FLOOR).  Reason: with plain random
+       weights the raw descriptors share one dominant direction and have heavy-tailed norms, so the raw-dot-product
+       mutual-NN of the semi-dense matcher (xfeat.py:265-290) finds ~1 match per 4095 and
+       match_xfeat_star has nothing to refine.  Whitened descriptors behave like a trained net's: a noisy copy of an
+       image yields thousands of mutual matches.
+    3. BatchNorm1d statistics of fine_matcher on MATCHED pairs of those descriptors (what refine_matches feeds it).
+    Everything lands in bn_stats.npz (the conv summation order of the calibrating machine is baked in)."""
     torch.manual_seed(0)
     sd = fixtures.raw_state_dict(0)
     xf = XFeat(weights=sd)
@@ -38,24 +62,41 @@ def calibrate():
             m.momentum = None
             m.reset_running_stats()
     imgs = fixtures.texture_images(4, 256, 320, seed=123)
-    # backbone + heads: one train-mode forward accumulates batch statistics
     net.train()
     with torch.no_grad():
-        for mod in (net.fine_matcher,):
-            mod.eval()
-        feats, _, _ = net(imgs)
+        net.fine_matcher.eval()
+        net(imgs)
     net.eval()
-    # fine matcher: pairs of raw dense features, as refine_matches feeds it
-    with torch.no_grad():
-        feats, _, _ = net(imgs)
-        f = feats.permute(0, 2, 3, 1).reshape(-1, 64)
-        g = torch.Generator().manual_seed(5)
-        i0 = torch.randperm(len(f), generator=g)[:4096]
-        i1 = torch.randperm(len(f), generator=g)[:4096]
-        net.fine_matcher.train()
-        net.fine_matcher(torch.cat([f[i0], f[i1]], -1))
-        net.eval()
     out = {}
+    with torch.no_grad():
+        # -- 2. whitening of the descriptor layer
+        cal = fixtures.texture_images(2, 512, 512, seed=124)
+        f = _dense_feats(net, xf, cal).double()
+        mu = f.mean(0)
+        ev, V = torch.linalg.eigh(torch.cov(f.T))
+        Wh = V @ torch.diag(ev.clamp_min(WHITEN_FLOOR).rsqrt()) @ V.T
+        conv = net.block_fusion[2]
+        W0, b0 = conv.weight[:, :, 0, 0].double(), conv.bias.double()
+        conv.weight.copy_((Wh @ W0).float()[:, :, None, None])
+        conv.bias.copy_((Wh @ (b0 - mu)).float())
+        out["block_fusion.2.weight"] = conv.weight.numpy().copy()
+        out["block_fusion.2.bias"] = conv.bias.numpy().copy()
+        print("whitening: eigenvalues %.2e .. %.2e, %d floored" % (float(ev[0]), float(ev[-1]), int((ev < WHITEN_FLOOR).sum())))
+        # the heat-map head reads the descriptors: re-calibrate its BatchNorms on the whitened features
+        for m in net.heatmap_head.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+                m.train()
+        net(imgs)
+        net.eval()
+        # -- 3. fine matcher on matched pairs: descriptors of an image and of a noisy copy, same cells
+        g = torch.Generator().manual_seed(5)
+        noisy = cal + 0.01 * torch.randn(cal.shape, generator=g)
+        fa, fb = _dense_feats(net, xf, cal), _dense_feats(net, xf, noisy)
+        sel = torch.randperm(len(fa), generator=g)[:8192]
+        net.fine_matcher.train()
+        net.fine_matcher(torch.cat([fa[sel], fb[sel]], -1))
+        net.eval()
     for k, v in net.state_dict().items():
         if k.endswith("running_mean") or k.endswith("running_var"):
             out[k] = v.numpy().astype(np.float32)
@@ -88,7 +129,8 @@ def main():
     oa = xf.detectAndCompute(a)[0]
     ob = xf.detectAndCompute(b)[0]
     i0, i1 = xf.match(oa["descriptors"], ob["descriptors"], min_cossim=-1)
-    j0, j1 = xf.match(oa["descriptors"], ob["descriptors"], min_cossim=0.82)
+    j0, j1 = xf.match(oa["descriptors"], ob["descriptors"], min_cossim=0.82)   # the reference's default: (nearly) empty on this fixture
+    h0, h1 = xf.match(oa["descriptors"], ob["descriptors"], min_cossim=0.55)   # about half of the mutual matches pass
     s = oa["descriptors"] @ ob["descriptors"].t()
     top2 = torch.topk(s, 2, dim=1)[0]
     g2 = {}
@@ -100,9 +142,10 @@ def main():
         g2[f"desc_{tag}_rowsum"] = o["descriptors"].double().sum(1).numpy()
     g2.update(idx0=i0.numpy().astype(np.int32), idx1=i1.numpy().astype(np.int32),
               idx0_082=j0.numpy().astype(np.int32), idx1_082=j1.numpy().astype(np.int32),
+              idx0_055=h0.numpy().astype(np.int32), idx1_055=h1.numpy().astype(np.int32),
               row_gap=(top2[:, 0] - top2[:, 1]).numpy())
     np.savez_compressed(os.path.join(HERE, "g2_vga_pair.npz"), **g2)
-    print("g2: kpts", len(oa["keypoints"]), len(ob["keypoints"]), "matches", len(i0), "matches@0.82", len(j0))
+    print("g2: kpts", len(oa["keypoints"]), len(ob["keypoints"]), "matches", len(i0), "matches@0.82", len(j0), "matches@0.55", len(h0))
 
     # ---- G3: non-/32 input through match_xfeat (numpy uint8 HWC, 200x300 -> 192x288) ----
     rs = np.random.RandomState(3)
@@ -133,6 +176,40 @@ def main():
           "refine0": ref0.numpy(), "refine1": ref1.numpy()}
     np.savez_compressed(os.path.join(HERE, "g4_dense.npz"), **g4)
     print("g4: star", [len(r) for r in res], "forced refine", len(ref0), len(ref1), "of", n)
+
+    # ---- G5: BASELINE configs[0]: assets/ref.png <-> tgt.png (600x800 RGB uint8; preprocess resizes 600 -> 576) ----
+    from PIL import Image
+    im0 = np.asarray(Image.open("/root/reference/assets/ref.png").convert("RGB"))
+    im1 = np.asarray(Image.open("/root/reference/assets/tgt.png").convert("RGB"))
+    assert im0.shape == (600, 800, 3) and im1.shape == (600, 800, 3) and im0.dtype == np.uint8
+    m0, m1 = xf.match_xfeat(im0, im1, top_k=4096)
+    # what minimal_example / the notebooks do: detectAndCompute on the parsed image, then match()
+    o0 = xf.detectAndCompute(xf.parse_input(im0), top_k=4096)[0]
+    o1 = xf.detectAndCompute(xf.parse_input(im1), top_k=4096)[0]
+    i0, i1 = xf.match(o0["descriptors"], o1["descriptors"], min_cossim=0.5)
+    s0, s1 = xf.match_xfeat_star(im0, im1, top_k=4096)
+    g5 = {"img0": im0, "img1": im1, "m0": m0, "m1": m1, "idx0_050": i0.numpy().astype(np.int32),
+          "idx1_050": i1.numpy().astype(np.int32), "star0": s0, "star1": s1}
+    for t, o in (("0", o0), ("1", o1)):
+        g5[f"kp{t}"] = o["keypoints"].numpy()
+        g5[f"sc{t}"] = o["scores"].numpy()
+        g5[f"desc{t}_every8"] = o["descriptors"][::8].numpy()
+    np.savez_compressed(os.path.join(HERE, "g5_assets.npz"), **g5)
+    print("g5: kpts", len(o0["keypoints"]), len(o1["keypoints"]), "match_xfeat", m0.shape, "match@0.5", len(i0), "star", s0.shape)
+
+    # ---- G6: match_xfeat_star with MANY refined rows: noisy copy pair, 320x384, B=2, top_k=2048 ----------------
+    sa, sb = fixtures.star_pair(2, 320, 384, seed=41)
+    res = xf.match_xfeat_star(sa, sb, top_k=2048)
+    d0 = xf.detectAndComputeDense(sa, top_k=2048)
+    d1 = xf.detectAndComputeDense(sb, top_k=2048)
+    bm = xf.batch_match(d0["descriptors"], d1["descriptors"])
+    g6 = {"star0": res[0].numpy(), "star1": res[1].numpy(),
+          "kp_a": d0["keypoints"].numpy(), "kp_b": d1["keypoints"].numpy(),
+          "desc_a_every8": d0["descriptors"][:, ::8].numpy(),
+          "bm0_idx0": bm[0][0].numpy().astype(np.int32), "bm0_idx1": bm[0][1].numpy().astype(np.int32),
+          "bm1_idx0": bm[1][0].numpy().astype(np.int32), "bm1_idx1": bm[1][1].numpy().astype(np.int32)}
+    np.savez_compressed(os.path.join(HERE, "g6_star.npz"), **g6)
+    print("g6: mutual", [len(b[0]) for b in bm], "refined rows", [len(r) for r in res])
 
 
 if __name__ == "__main__":

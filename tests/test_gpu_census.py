@@ -1,0 +1,188 @@
+"""GPU parity at the BASELINE shapes, against the CPU oracle and the reference's golden vectors:
+
+* configs[0]: assets/ref.png <-> tgt.png (600x800 uint8, real-resize branch) -- golden g5_assets.npz
+* configs[1]: a CENSUS of the exact bench.py batch (B=64 VGA frames, top_k=4096, 32 pairs): 16 frames and 8 pairs
+  against the oracle, exception histogram printed and asserted
+* configs[2]: match_xfeat_star with thousands of refined rows (golden g6_star.npz at 320x384; one 1024x1024 pair of a
+  batch against the oracle)
+
+Bars: key-point sets / match pairs identical except items whose deciding margin on the ORACLE's own maps is below the
+tie epsilon (tests/parity.py), every exception counted; scores / descriptors within 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fixtures
+import parity
+from oracle import xfeat_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = fixtures.GOLDEN_DIR
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return fixtures.synthetic_state_dict(0)
+
+
+@pytest.fixture(scope="module")
+def xf(sd):
+    from accelerated_features_amd import XFeat
+    return XFeat(weights=sd, top_k=4096, detection_threshold=0.05)
+
+
+def _threads():
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+
+
+# ----------------------------------------------------------------------------------------------
+# configs[0]
+# ----------------------------------------------------------------------------------------------
+def test_config0_assets_pair_vs_reference_golden(xf, sd):
+    _threads()
+    g = np.load(os.path.join(G, "g5_assets.npz"))
+    im0, im1 = g["img0"], g["img1"]
+    assert im0.shape == (600, 800, 3) and im0.dtype == np.uint8
+    # detectAndCompute on the parsed images (what minimal_example / the notebooks do), vs golden and oracle
+    outs, orcs = [], []
+    for t, im in (("0", im0), ("1", im1)):
+        hip = xf.detectAndCompute(xf.parse_input(im), top_k=4096)[0]
+        orc, st = O.detect_and_compute(sd, O.parse_input(im), top_k=4096, keep=True)
+        rep = parity.compare_keypoints(hip, orc[0], heat=st["heat"][0, 0], rw=st["rw"], rh=st["rh"])
+        gk = g[f"kp{t}"]
+        gold = {"keypoints": gk, "scores": g[f"sc{t}"], "descriptors": np.zeros((len(gk), 64), np.float32)}
+        tst = {"keypoints": hip["keypoints"], "scores": hip["scores"], "descriptors": torch.zeros(len(hip["keypoints"]), 64)}
+        rep2 = parity.compare_keypoints(tst, gold, heat=st["heat"][0, 0], rw=st["rw"], rh=st["rh"])
+        print("config0 image", t, "vs oracle", rep, "vs golden", rep2)
+        assert rep["n_test"] == 4096 == rep2["n_ref"]
+        key = {(float(x), float(y)): i for i, (x, y) in enumerate(hip["keypoints"].cpu().numpy())}
+        rows = [(key[(float(x), float(y))], j) for j, (x, y) in enumerate(gk[::8]) if (float(x), float(y)) in key]
+        d = np.abs(hip["descriptors"].cpu().numpy()[[r[0] for r in rows]] - g[f"desc{t}_every8"][[r[1] for r in rows]]).max()
+        assert len(rows) >= 508 and d <= 1e-4, (len(rows), d)
+        outs.append(hip); orcs.append(orc[0])
+    ctx = {"kp0": orcs[0]["keypoints"], "kp1": orcs[1]["keypoints"], "d0": orcs[0]["descriptors"], "d1": orcs[1]["descriptors"]}
+    # match_xfeat on the raw uint8 numpy images (the uint8 ingest + resize path)
+    m0, m1 = xf.match_xfeat(im0, im1, top_k=4096)
+    rep = parity.compare_matches(m0, m1, g["m0"], g["m1"], ctx)
+    print("config0 match_xfeat", rep)
+    assert rep["n_ref"] == len(g["m0"]) and rep["n_test"] >= 500
+    # match() with a similarity cut
+    i0, i1 = xf.match(outs[0]["descriptors"], outs[1]["descriptors"], min_cossim=0.5)
+    k0, k1 = outs[0]["keypoints"].cpu(), outs[1]["keypoints"].cpu()
+    rep = parity.compare_matches(k0[i0.cpu()], k1[i1.cpu()], g["kp0"][g["idx0_050"]], g["kp1"][g["idx1_050"]], ctx)
+    print("config0 match@0.5", rep)
+    # match_xfeat_star (B == 1 -> tuple of numpy arrays)
+    s0, s1 = xf.match_xfeat_star(im0, im1, top_k=4096)
+    assert isinstance(s0, np.ndarray) and s0.shape == s1.shape
+    d0 = O.detect_and_compute_dense(sd, O.parse_input(im0), 4096)
+    d1 = O.detect_and_compute_dense(sd, O.parse_input(im1), 4096)
+    rep = parity.compare_star_rows(np.concatenate([s0, s1], 1), np.concatenate([g["star0"], g["star1"]], 1),
+                                   {"sd": sd, "d0": d0, "d1": d1, "b": 0})
+    print("config0 star", rep)
+
+
+# ----------------------------------------------------------------------------------------------
+# configs[1]: census of the bench batch
+# ----------------------------------------------------------------------------------------------
+def test_config1_census_of_the_bench_batch_vs_oracle(xf, sd):
+    """The exact batch bench.py times (make_frames(64, seed=1000), rank 0) through the exact calls bench.py makes
+    (_detect_device + match_pairs_device); frames of pairs 0,4,...,28 (16 frames, 8 pairs) against the oracle."""
+    _threads()
+    import bench
+    x = bench.make_frames(64, seed=1000)
+    kp, sc, de, nv, nc, cap, hw = xf._detect_device(x.cuda(), 4096, 0.05)
+    i0, i1, nm = xf.match_pairs_device(de, nv, -1)
+    assert int(nc.max()) <= cap
+    nvl, nml = nv.cpu().tolist(), nm.cpu().tolist()
+    kp, sc, de, i0, i1 = kp.cpu(), sc.cpu(), de.cpu(), i0.cpu(), i1.cpu()
+    hist = {"frames": 0, "pairs": 0, "kpts": 0, "kpt_exceptions": 0, "rank_moved": 0, "worst_rank_gap": 0.0,
+            "score_maxdiff": 0.0, "desc_maxdiff": 0.0, "match_rows": 0, "match_differing": 0}
+    for p in range(0, 32, 4):
+        fr = [2 * p, 2 * p + 1]
+        ref, st = O.detect_and_compute(sd, x[fr], top_k=4096, keep=True)
+        for j, f in enumerate(fr):
+            hip = {"keypoints": kp[f, :nvl[f]], "scores": sc[f, :nvl[f]], "descriptors": de[f, :nvl[f]]}
+            rep = parity.compare_keypoints(hip, ref[j], heat=st["heat"][j, 0])
+            hist["frames"] += 1
+            hist["kpts"] += rep["n_ref"]
+            hist["kpt_exceptions"] += rep["exceptions"]
+            hist["rank_moved"] += rep.get("rank_moved", 0)
+            hist["worst_rank_gap"] = max(hist["worst_rank_gap"], rep.get("rank_moved_maxgap", 0.0))
+            hist["score_maxdiff"] = max(hist["score_maxdiff"], rep.get("score_maxdiff", 0.0))
+            hist["desc_maxdiff"] = max(hist["desc_maxdiff"], rep.get("desc_maxdiff", 0.0))
+            assert rep["n_test"] == 4096
+        o0, o1 = O.match_mnn(ref[0]["descriptors"], ref[1]["descriptors"], -1)
+        ctx = {"kp0": ref[0]["keypoints"], "kp1": ref[1]["keypoints"], "d0": ref[0]["descriptors"], "d1": ref[1]["descriptors"]}
+        a, b = i0[p, :nml[p]], i1[p, :nml[p]]
+        assert torch.all(a[1:] > a[:-1])
+        rep = parity.compare_matches(kp[fr[0]][a], kp[fr[1]][b], ref[0]["keypoints"][o0], ref[1]["keypoints"][o1], ctx)
+        hist["pairs"] += 1
+        hist["match_rows"] += rep["n_ref"]
+        hist["match_differing"] += rep["differing_rows"]
+    print("CENSUS", hist)
+    assert hist["frames"] == 16 and hist["pairs"] == 8 and hist["kpts"] == 16 * 4096
+    assert hist["kpt_exceptions"] <= 16 and hist["match_differing"] <= 8, hist      # <= 0.025 % / 0.1 %, each one explained above
+    assert hist["score_maxdiff"] <= 1e-4 and hist["desc_maxdiff"] <= 1e-4, hist
+
+
+# ----------------------------------------------------------------------------------------------
+# configs[2]
+# ----------------------------------------------------------------------------------------------
+def test_star_many_rows_vs_reference_golden_and_oracle(xf, sd):
+    _threads()
+    g = np.load(os.path.join(G, "g6_star.npz"))
+    sa, sb = fixtures.star_pair(2, 320, 384, seed=41)
+    da = xf.detectAndComputeDense(sa.cuda(), top_k=2048)
+    db = xf.detectAndComputeDense(sb.cuda(), top_k=2048)
+    oa = O.detect_and_compute_dense(sd, sa, top_k=2048)
+    ob = O.detect_and_compute_dense(sd, sb, top_k=2048)
+    res = xf.match_xfeat_star(sa.cuda(), sb.cuda(), top_k=2048)
+    ref = O.match_xfeat_star(sd, sa, sb, top_k=2048)
+    # batch_match on the oracle's descriptors: index lists identical to the reference's
+    bm = xf.batch_match(oa["descriptors"].cuda(), ob["descriptors"].cuda())
+    for b in range(2):
+        r1 = parity.compare_dense(da, oa, b)
+        r2 = parity.compare_dense(db, ob, b)
+        assert np.array_equal(bm[b][0].cpu().numpy(), g[f"bm{b}_idx0"]) and np.array_equal(bm[b][1].cpu().numpy(), g[f"bm{b}_idx1"])
+        ctx = {"sd": sd, "d0": oa, "d1": ob, "b": b}
+        dense = (da["keypoints"][b], db["keypoints"][b])
+        rep = parity.compare_star_rows(res[b], ref[b], ctx, test_dense=dense)
+        rep2 = parity.compare_star_rows(res[b], g[f"star{b}"], ctx, test_dense=dense)
+        print("star320", b, r1, r2, rep, rep2)
+        assert rep2["n_ref"] >= 1000 and rep["paired"] >= 1000
+
+
+def test_star_1024_batch_pair_vs_oracle(xf, sd):
+    """BASELINE configs[2] shape: match_xfeat_star on 1024x1024 pairs, top_k=4096 (batch of 4 pairs here; bench.py
+    --workload dense runs 32); pair 0 against the oracle: dense sets, descriptors, every refined row."""
+    _threads()
+    base = fixtures.texture_images(2, 1024, 1024, seed=55)
+    a = torch.cat([base, base.flip(3)])
+    rs = np.random.RandomState(56)
+    b = a + torch.from_numpy((0.005 * rs.randn(*a.shape)).astype(np.float32))
+    da = xf.detectAndComputeDense(a.cuda(), top_k=4096)
+    db = xf.detectAndComputeDense(b.cuda(), top_k=4096)
+    assert da["keypoints"].shape == (4, 4095, 2) and da["descriptors"].shape == (4, 4095, 64) and da["scales"].shape == (4, 4095)
+    sc = da["scales"][0].cpu()
+    assert torch.allclose(sc[:819], torch.full((819,), 1 / 0.6)) and torch.allclose(sc[819:], torch.full((3276,), 1 / 1.3))
+    res = xf.match_xfeat_star(a.cuda(), b.cuda(), top_k=4096)
+    assert isinstance(res, list) and len(res) == 4
+    oa = O.detect_and_compute_dense(sd, a[:1], top_k=4096)
+    ob = O.detect_and_compute_dense(sd, b[:1], top_k=4096)
+    r1, r2 = parity.compare_dense(da, oa, 0), parity.compare_dense(db, ob, 0)
+    ref = O.match_xfeat_star(sd, a[:1], b[:1], top_k=4096)[0]
+    rep = parity.compare_star_rows(res[0], ref, {"sd": sd, "d0": oa, "d1": ob, "b": 0},
+                                   test_dense=(da["keypoints"][0], db["keypoints"][0]))
+    print("star1024", r1, r2, rep)
+    assert rep["n_ref"] >= 2000 and rep["paired"] >= 2000
+    for r in res:
+        assert r.dim() == 2 and r.shape[1] == 4 and r.dtype == torch.float32 and torch.isfinite(r).all()
+    res2 = xf.match_xfeat_star(a.cuda(), b.cuda(), top_k=4096)          # run-to-run bit determinism
+    for r, r2_ in zip(res, res2):
+        assert torch.equal(r, r2_)
+    m0, m1 = xf.match_xfeat_star(a[:1].cuda(), b[:1].cuda(), top_k=4096)     # B == 1: the numpy tuple, like the reference
+    assert isinstance(m0, np.ndarray) and m0.shape == m1.shape and m0.shape[1] == 2
+    assert np.allclose(np.concatenate([m0, m1], 1), res[0].cpu().numpy())

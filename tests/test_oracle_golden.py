@@ -64,8 +64,9 @@ def test_g2_vga_pair_detect_and_match():
     i0, i1 = O.match_mnn(outs["a"]["descriptors"], outs["b"]["descriptors"], -1)
     assert torch.all(i0[1:] > i0[:-1])
     parity.compare_matches(ka[i0], kb[i1], ga[g["idx0"]], gb[g["idx1"]], orc)
-    j0, j1 = O.match_mnn(outs["a"]["descriptors"], outs["b"]["descriptors"], 0.82)
-    parity.compare_matches(ka[j0], kb[j1], ga[g["idx0_082"]], gb[g["idx1_082"]], orc)
+    for mc, tag in ((0.82, "082"), (0.55, "055")):     # the reference default (empty on this fixture) and a cut through the middle
+        j0, j1 = O.match_mnn(outs["a"]["descriptors"], outs["b"]["descriptors"], mc)
+        parity.compare_matches(ka[j0], kb[j1], ga[g[f"idx0_{tag}"]], gb[g[f"idx1_{tag}"]], orc)
     assert len(i0) > 1000 and len(j0) > 100
 
 
@@ -100,3 +101,52 @@ def test_g4_dense_and_refine():
     for b in range(2):
         assert res[b].shape == g[f"star{b}"].shape
         parity.assert_close(res[b], g[f"star{b}"], 2e-4, "star")
+
+
+def test_g5_baseline_config0_assets_pair():
+    """BASELINE configs[0]: assets/ref.png <-> tgt.png (600x800 uint8 RGB, real-resize branch 600 -> 576) through the
+    reference's match_xfeat / detectAndCompute / match / match_xfeat_star (make_golden.py G5)."""
+    g = np.load(os.path.join(G, "g5_assets.npz"))
+    sd = _sd()
+    im0, im1 = g["img0"], g["img1"]
+    assert im0.shape == (600, 800, 3) and im0.dtype == np.uint8
+    outs, heats = [], []
+    for t, im in (("0", im0), ("1", im1)):
+        o, st = O.detect_and_compute(sd, O.parse_input(im), top_k=4096, keep=True)
+        o = o[0]
+        gk = g[f"kp{t}"]
+        full_ref = {"keypoints": gk, "scores": g[f"sc{t}"], "descriptors": np.zeros((len(gk), 64), np.float32)}
+        full = {"keypoints": o["keypoints"], "scores": o["scores"], "descriptors": torch.zeros(len(o["keypoints"]), 64)}
+        rep = parity.compare_keypoints(full, full_ref, heat=st["heat"][0, 0], rw=st["rw"], rh=st["rh"])
+        assert rep["n_test"] == 4096 and rep["exceptions"] == 0, rep
+        key = {(float(x), float(y)): i for i, (x, y) in enumerate(o["keypoints"].numpy())}
+        rows = [key[(float(x), float(y))] for x, y in gk[::8]]
+        parity.assert_close(o["descriptors"][rows], g[f"desc{t}_every8"], 1e-5, "desc")
+        outs.append(o)
+    orc = {"kp0": outs[0]["keypoints"], "kp1": outs[1]["keypoints"], "d0": outs[0]["descriptors"], "d1": outs[1]["descriptors"]}
+    k0, k1, _, _ = O.match_xfeat(sd, im0, im1, top_k=4096)
+    rep = parity.compare_matches(k0, k1, g["m0"], g["m1"], orc)
+    assert rep["n_test"] == len(g["m0"]) >= 500 and rep["differing_rows"] == 0, rep
+    j0, j1 = O.match_mnn(outs[0]["descriptors"], outs[1]["descriptors"], 0.5)
+    parity.compare_matches(outs[0]["keypoints"][j0], outs[1]["keypoints"][j1], g["kp0"][g["idx0_050"]], g["kp1"][g["idx1_050"]], orc)
+    star = O.match_xfeat_star(sd, im0, im1, top_k=4096)[0]
+    rep = parity.compare_star_rows(star, np.concatenate([g["star0"], g["star1"]], 1))
+    assert rep["exceptions"] == 0, rep
+
+
+def test_g6_match_xfeat_star_many_refined_rows():
+    """match_xfeat_star on a noisy-copy pair: > 1000 refined rows per pair, compared row by row with the reference's."""
+    g = np.load(os.path.join(G, "g6_star.npz"))
+    sd = _sd()
+    sa, sb = fixtures.star_pair(2, 320, 384, seed=41)
+    d0 = O.detect_and_compute_dense(sd, sa, top_k=2048)
+    d1 = O.detect_and_compute_dense(sd, sb, top_k=2048)
+    parity.assert_close(d0["keypoints"], g["kp_a"], 1e-4, "dense kp a")
+    parity.assert_close(d1["keypoints"], g["kp_b"], 1e-4, "dense kp b")
+    parity.assert_close(d0["descriptors"][:, ::8], g["desc_a_every8"], 5e-5, "dense desc")
+    bm = O.batch_match(d0["descriptors"], d1["descriptors"])
+    res = O.match_xfeat_star(sd, sa, sb, top_k=2048)
+    for b in range(2):
+        assert np.array_equal(bm[b][0].numpy(), g[f"bm{b}_idx0"]) and np.array_equal(bm[b][1].numpy(), g[f"bm{b}_idx1"])
+        rep = parity.compare_star_rows(res[b], g[f"star{b}"], {"sd": sd, "d0": d0, "d1": d1, "b": b})
+        assert rep["n_ref"] >= 1000 and rep["exceptions"] == 0, rep
