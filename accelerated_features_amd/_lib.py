@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("XFH_LIB_PATH") or os.path.join(_HERE, "libxfeat_hip.s
 XFH_OK = 0
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 LG_NO_PRUNING = 1 << 30
+SAMPLE_MODES = {'nearest': 0, 'bilinear': 1, 'bicubic': 2}
 PROF_NONE, PROF_CONV_MFMA, PROF_MATCH, PROF_BLOCK1, PROF_HEADS, PROF_CONV_64_64_S1, PROF_CONV_LAYER0 = 0, 1, 2, 3, 4, 5, 100
 
 # name -> (restype, argtypes); mirrors include/xfeat_hip.h one to one
@@ -42,7 +43,8 @@ SIGNATURES = {
     "xfh_refine_workspace_bytes": (_sz, [_i, _i]),
     "xfh_refine_matches": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
     "xfh_kpts_heatmap": (_i, [_p, _i, _i, _i, _p, _p]),
-    "xfh_nms": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _p, _p, _sz, _p]),
+    "xfh_nms": (_i, [_p, _p, _i, _i, _i, _f, _i, _i, _p, _p, _p, _sz, _p]),
+    "xfh_sample_sparse": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p]),
     "xfh_fine_matcher": (_i, [_p, _p, _i, _p, _p, _sz, _p]),
     "xfh_lg_num_weight_arrays": (_i, []),
     "xfh_lg_weight_array_floats": (_sz, [_i]),

@@ -631,17 +631,29 @@ int xfh_kpts_heatmap(const float* logits, int B, int hc, int wc, float* heat, xf
     return check_launch("xfh_kpts_heatmap");
 }
 
-int xfh_nms(xfh_handle h, const float* heat, int B, int H, int W, float threshold, int capacity, int64_t* xy,
+int xfh_sample_sparse(const float* x, const float* pos, int B, int C, int Hm, int Wm, int N, int H, int W, int mode, float* out,
+                      xfh_stream stream) {
+    if (!x || !pos || !out) return fail(XFH_ERR_ARG, "xfh_sample_sparse: NULL argument");
+    if (B <= 0 || C <= 0 || Hm <= 0 || Wm <= 0 || N < 0 || H <= 1 || W <= 1) return fail(XFH_ERR_ARG, "xfh_sample_sparse: bad shape");
+    if (mode < XFH_SAMPLE_NEAREST || mode > XFH_SAMPLE_BICUBIC) return fail(XFH_ERR_ARG, "xfh_sample_sparse: mode %d", mode);
+    if ((double)B * N * C >= 4294967296.0 * 256) return fail(XFH_ERR_UNSUPPORTED, "xfh_sample_sparse: too many samples");
+    if (N == 0) return XFH_OK;
+    launch_sample_sparse(x, pos, B, C, Hm, Wm, N, H, W, mode, out, (hipStream_t)stream);
+    return check_launch("xfh_sample_sparse");
+}
+
+int xfh_nms(xfh_handle h, const float* heat, int B, int H, int W, float threshold, int kernel_size, int capacity, int64_t* xy,
             int32_t* n_candidates, void* workspace, size_t workspace_bytes, xfh_stream stream) {
     (void)h;
     if (!heat || !xy || !n_candidates) return fail(XFH_ERR_ARG, "xfh_nms: NULL argument");
+    if (kernel_size < 1 || !(kernel_size & 1) || kernel_size > 255) return fail(XFH_ERR_ARG, "xfh_nms: kernel_size %d must be odd, 1..255", kernel_size);
     if (B <= 0 || H <= 0 || W <= 0 || H >= 65536 || W >= 65536 || B > 65535) return fail(XFH_ERR_ARG, "xfh_nms: bad shape");
     if (capacity <= 0 || (long)capacity > (long)H * W) return fail(XFH_ERR_ARG, "xfh_nms: capacity outside 1..H*W");
     DetectWs w;
     const size_t need = carve_detect(workspace, B, H, W, 1, capacity, w);
     int rc = check_ws(workspace, workspace_bytes, need);
     if (rc) return rc;
-    launch_nms_only(w, heat, B, H, W, threshold, capacity, xy, n_candidates, (hipStream_t)stream);
+    launch_nms_only(w, heat, B, H, W, threshold, kernel_size, capacity, xy, n_candidates, (hipStream_t)stream);
     return check_launch("xfh_nms");
 }
 

@@ -63,6 +63,38 @@ __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict_
     }
 }
 
+// Any odd window (XFeat.NMS(kernel_size=k), xfeat.py:249-252: max_pool2d(k, stride 1, padding k/2)): one wave per 64-pixel mask
+// word, every lane scans its own k x k window in global memory (helper API, not on the hot path which always uses 5).
+__global__ __launch_bounds__(256) void nms_flags_generic_kernel(const float* __restrict__ heat, int B, int H, int W, int WPR, int rad, float thr,
+                                                                unsigned long long* __restrict__ mask, int* __restrict__ wcount) {
+    const int lane = threadIdx.x & 63;
+    const size_t wid = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (size_t)B * H * WPR) return;
+    const int word = (int)(wid % WPR);
+    const int y = (int)((wid / WPR) % H), b = (int)(wid / ((size_t)WPR * H));
+    const int x = word * 64 + lane;
+    const float* hp = heat + (size_t)b * H * W;
+    bool cand = false;
+    if (x < W) {
+        const float v = hp[(size_t)y * W + x];
+        float m = v;
+        for (int dy = -rad; dy <= rad; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= H) continue;
+            for (int dx = -rad; dx <= rad; ++dx) {
+                const int xx = x + dx;
+                if (xx >= 0 && xx < W) m = fmaxf(m, hp[(size_t)yy * W + xx]);
+            }
+        }
+        cand = (v > thr) && (v == m);
+    }
+    const unsigned long long bal = __ballot(cand);
+    if (lane == 0) {
+        mask[wid] = bal;
+        wcount[wid] = __popcll(bal);
+    }
+}
+
 // block-wide exclusive scan of one int per thread (1024 threads); returns the exclusive
 // prefix, *total = block sum.  lds: >= 16 ints.
 __device__ inline int block_exscan_1024(int v, int* lds, int* total) {
@@ -511,10 +543,13 @@ __global__ __launch_bounds__(256) void cand_to_xy_kernel(const unsigned* __restr
     xy[((size_t)b * cap + i) * 2 + 1] = y;
 }
 
-void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int cap, int64_t* xy,
+void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int kernel_size, int cap, int64_t* xy,
                      int32_t* n_cand, hipStream_t st) {
     const int WPR = ceil_div(W, 64);
-    nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
+    if (kernel_size == 5)
+        nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
+    else
+        nms_flags_generic_kernel<<<(unsigned)(((size_t)B * H * WPR + 3) / 4), 256, 0, st>>>(heat, B, H, W, WPR, kernel_size / 2, thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
     cand_to_xy_kernel<<<dim3(ceil_div(cap, 256), B), 256, 0, st>>>(ws.cand, n_cand, cap, xy);
 }

@@ -109,8 +109,11 @@ struct DetectWs {          // carved from the caller's workspace by api.hip
 void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, int B, int H, int W,
                    float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
                    int32_t* n_valid, int32_t* n_cand, hipStream_t st);
-void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int cap, int64_t* xy,
+void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int kernel_size, int cap, int64_t* xy,
                      int32_t* n_cand, hipStream_t st);
+// k_sampler.hip: InterpolateSparse2d as a stand-alone op; mode 0 nearest, 1 bilinear, 2 bicubic
+void launch_sample_sparse(const float* x, const float* pos, int B, int C, int Hm, int Wm, int N, int H, int W, int mode, float* out,
+                          hipStream_t st);
 // top-k of a (B,n) float array, descending (ties: lower index first).  keys scratch (B,n) u64,
 // sel (B,k) u32 receives the indices.
 void launch_topk_desc(const float* vals, int B, int n, int k, unsigned long long* keys, unsigned* sel, int* nsel,

@@ -11,6 +11,13 @@ one graph launch instead of ~25 kernel launches, the same kernels, bit-identical
 
 Plateau images that overflow the captured NMS capacity are detected after the replay (the candidate counts are
 part of the read-back) and re-run eagerly through `xfeat.detectAndCompute`, so results stay exact.
+
+Buffer lifetime: a captured graph bakes in raw device pointers (workspaces, the packed weight blob).  The pipeline
+therefore owns a PRIVATE replica of the model (`XFeat(weights=xfeat.net.state_dict())`: own C handle, own workspaces)
+that nothing else calls, so no eager call on the user's `xfeat` -- a larger image, the plateau re-run, a
+`load_state_dict` -- can reallocate or free memory the graph still references; the eager fallback runs on the
+user's object.  Weights are snapshotted at construction: build a new pipeline after changing them.  As a second
+line of defence every replay checks the replica's allocation epoch and re-captures if it ever moved.
 """
 import torch
 
@@ -23,13 +30,19 @@ class CapturedSparsePipeline:
         if match and batch % 2:
             raise RuntimeError('matching consecutive frames needs an even batch')
         xfeat._require_gpu()
-        self.xf, self.B, self.match = xfeat, batch, match
+        self.user_xf = xfeat                                    # eager fallback only
+        self.xf = type(xfeat)(weights=xfeat.net.state_dict(), top_k=xfeat.top_k, detection_threshold=xfeat.detection_threshold)
+        self.B, self.match = batch, match
         self.top_k = xfeat.top_k if top_k is None else top_k
         self.thr = xfeat.detection_threshold if detection_threshold is None else detection_threshold
         self.min_cossim = min_cossim
         dev = xfeat.dev
         self.x = torch.zeros((batch, channels, height, width), dtype=dtype, device=dev)
         self.hw = height * width
+        self._capture()
+
+    def _capture(self):
+        dev = self.xf.dev
         # warm-up on a side stream (allocates workspaces, sets kernel attributes), then capture
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
@@ -41,6 +54,7 @@ class CapturedSparsePipeline:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._body()
+        self._epoch = self.xf.net._ws_epoch
 
     def _body(self):
         kp, sc, de, nv, nc, cap, hw = self.xf._detect_device(self.x, self.top_k, self.thr)
@@ -55,6 +69,8 @@ class CapturedSparsePipeline:
     def __call__(self, frames):
         """frames: (B,C,H,W) tensor of the captured shape/dtype.  Returns a dict of device tensors (views of the
         static buffers: valid until the next call) plus the host-side counts."""
+        if self.xf.net._ws_epoch != self._epoch:                # somebody used the private replica directly: pointers are stale
+            self._capture()
         self.x.copy_(frames, non_blocking=True)
         self.graph.replay()
         c = self.counts.cpu()                                   # the one read-back
@@ -70,7 +86,7 @@ class CapturedSparsePipeline:
         return out
 
     def _eager(self, frames):
-        res = self.xf.detectAndCompute(frames, top_k=self.top_k, detection_threshold=self.thr)
+        res = self.user_xf.detectAndCompute(frames, top_k=self.top_k, detection_threshold=self.thr)
         K = self.top_k
         dev = self.xf.dev
         kp = torch.zeros((self.B, K, 2), device=dev); sc = torch.zeros((self.B, K), device=dev); de = torch.zeros((self.B, K, 64), device=dev)
@@ -80,7 +96,7 @@ class CapturedSparsePipeline:
             kp[b, :n], sc[b, :n], de[b, :n] = r['keypoints'], r['scores'], r['descriptors']
         out = {'keypoints': kp, 'scores': sc, 'descriptors': de, 'n_valid': nv}
         if self.match:
-            ms = [self.xf.match(res[2 * p]['descriptors'], res[2 * p + 1]['descriptors'], min_cossim=self.min_cossim) for p in range(self.B // 2)]
+            ms = [self.user_xf.match(res[2 * p]['descriptors'], res[2 * p + 1]['descriptors'], min_cossim=self.min_cossim) for p in range(self.B // 2)]
             out['matches'] = ms
             out['n_matches'] = [len(m[0]) for m in ms]
         return out

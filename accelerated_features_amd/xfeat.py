@@ -118,6 +118,7 @@ class XFeatModel(nn.Module):
         self._handle = None
         self._handle_device = None
         self._ws = {}
+        self._ws_epoch = 0
 
     # -- weights -> C handle -------------------------------------------------------------------
     def weight_arrays(self):
@@ -141,9 +142,16 @@ class XFeatModel(nn.Module):
         self._drop_handle()
         return r
 
+    def _load_from_state_dict(self, *args, **kw):
+        # reached when a PARENT module (XFeat.load_state_dict) loads weights: the packed device copy is stale.
+        # (In-place edits of a parameter tensor are not tracked: call load_state_dict, or net._drop_handle().)
+        self._drop_handle()
+        return super()._load_from_state_dict(*args, **kw)
+
     def _drop_handle(self):
         if getattr(self, "_handle", None):
             _lib.load().xfh_destroy(self._handle)
+            self._ws_epoch = getattr(self, "_ws_epoch", 0) + 1
         self._handle = None
 
     def __del__(self):
@@ -177,9 +185,10 @@ class XFeatModel(nn.Module):
     def workspace(self, name, nbytes):
         dev = torch.device("cuda", torch.cuda.current_device())
         t = self._ws.get(name)
-        if t is None or t.numel() < nbytes or t.device != dev:
+        if t is None or t.device != dev or t.numel() - ((-t.data_ptr()) % 256) < nbytes:
             t = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=dev)
             self._ws[name] = t
+            self._ws_epoch += 1                # hipGraphs captured on the old buffer are stale (graphs.py checks this)
         off = (-t.data_ptr()) % 256
         return t[off:], int(nbytes)
 
@@ -191,6 +200,10 @@ class XFeatModel(nn.Module):
         lib = _lib.load()
         h = self.handle()
         u8_div = None
+        probe = x.data if isinstance(x, (_LazyResize, _U8Image)) else x
+        if not probe.is_cuda:
+            raise _lib.XFeatHipError("XFeatModel runs on the GPU: got a CPU tensor (move the input with .cuda(); the XFeat.* "
+                                     "methods do that themselves)")
         if isinstance(x, _LazyResize):
             B, Cc, H, W = x.shape
             hc, wc = H // 8, W // 8
@@ -239,6 +252,8 @@ class XFeatModel(nn.Module):
     def _fine_matcher(self, x):
         lib = _lib.load()
         h = self.handle()
+        if not x.is_cuda:
+            raise _lib.XFeatHipError("fine_matcher runs on the GPU: got a CPU tensor")
         x = x.contiguous().float()
         n = x.shape[0]
         out = torch.empty((n, 64), dtype=torch.float32, device=x.device)
@@ -270,9 +285,16 @@ class XFeat(nn.Module):
             else:
                 self.net.load_state_dict(weights)
 
-        self.interpolator = None           # reference attribute (InterpolateSparse2d); sampling is fused in HIP
+        from .interpolator import InterpolateSparse2d
+        self.interpolator = InterpolateSparse2d('bicubic')      # reference attribute (xfeat.py:37); the hot path fuses its sampling
+        # kornia probe like the reference (xfeat.py:39-46): informational here -- match_lighterglue runs on the HIP matcher
         self.kornia_available = False
         self.lighterglue = None
+        try:
+            import importlib.util
+            self.kornia_available = importlib.util.find_spec("kornia") is not None
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------------------------------
     # sparse
@@ -437,7 +459,7 @@ class XFeat(nn.Module):
         rh, rw = H / _H, W / _W
         if isinstance(x, _LazyResize):
             s2h, s2w = np.float32(H) / np.float32(_H), np.float32(W) / np.float32(_W)
-            if max(s2h, s2w) < 1.9:
+            if max(s2h, s2w) < 1.9 and x.data.shape[1] <= 4 and x.data[0].numel() * 4 < 2 ** 31:
                 return _LazyResize(x.data, x.mid[0], x.mid[1], x.s1[0], x.s1[1], _H, _W, s2h, s2w), rh, rw
             x = self._resize(x.data, x.mid[0], x.mid[1], x.s1[0], x.s1[1])      # tiny images: materialise
         if (_H, _W) == (H, W) and (isinstance(x, _U8Image) or x.dtype == torch.uint8):
@@ -484,8 +506,8 @@ class XFeat(nn.Module):
 
     def NMS(self, x, threshold=0.05, kernel_size=5):
         """x (B,1,H,W) -> (B,Nmax,2) int64 (x,y), zero padded (xfeat.py:249-263)."""
-        if kernel_size != 5:
-            raise NotImplementedError('only kernel_size=5 (the value the reference uses) is implemented')
+        if kernel_size < 1 or kernel_size % 2 == 0:
+            raise RuntimeError('NMS kernel_size must be odd (the reference pads kernel_size//2 on both sides)')
         self._require_gpu()
         lib = _lib.load()
         x = x.to(self.dev).float().contiguous()
@@ -495,8 +517,8 @@ class XFeat(nn.Module):
             xy = torch.empty((B, cap, 2), dtype=torch.int64, device=x.device)
             nc = torch.empty((B,), dtype=torch.int32, device=x.device)
             ws, n = self.net.workspace("detect", lib.xfh_detect_workspace_bytes(B, H, W, 1, cap))
-            _lib.check(lib.xfh_nms(self.net.handle(), _ptr(x), B, H, W, float(threshold), cap, _ptr(xy), _ptr(nc), _ptr(ws), n,
-                                   _stream()), "xfh_nms")
+            _lib.check(lib.xfh_nms(self.net.handle(), _ptr(x), B, H, W, float(threshold), int(kernel_size), cap, _ptr(xy), _ptr(nc),
+                                   _ptr(ws), n, _stream()), "xfh_nms")
             nmax = int(nc.max().item())
             if nmax <= cap:
                 return xy[:, :nmax]

@@ -34,8 +34,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+from accelerated_features_amd import sharding  # noqa: E402  (shard ranges + the barrier / max-over-ranks timing protocol)
+
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 H, W, TOP_K = 480, 640, 4096
+# SURVEY.md 8(d), per VGA frame of this workload: layer-granular compulsory bytes, algorithmic FLOPs (extraction 2.622 GFLOP +
+# half a 4096x4096x64 match), and the roofline time sum_k max(bytes_k / 8 TB/s, flops_k / 157.3 TF) = 20.1 us + 6.83 us
+ALGO_BYTES_PER_FRAME = 78.6e6
+ALGO_FLOPS_PER_FRAME = 2.622e9 + 2.147e9 / 2
+T_ROOF_US_PER_FRAME = 26.9
 
 
 def make_frames(B, seed):
@@ -79,18 +86,31 @@ def cpu_baseline(seconds):
             break
     threads = best[0]
     torch.set_num_threads(threads)
-    frames, t_used, iters = 0, 0.0, 0
-    while t_used < seconds or iters < 1:
+
+    def one_batch(xb):
         t0 = time.perf_counter()
-        out = O.detect_and_compute(sd, x, top_k=TOP_K)
-        for p in range(2):
+        out = O.detect_and_compute(sd, xb, top_k=TOP_K)
+        for p in range(len(xb) // 2):
             O.match_mnn(out[2 * p]["descriptors"], out[2 * p + 1]["descriptors"], -1)
-        t_used += time.perf_counter() - t0
+        return time.perf_counter() - t0
+
+    frames, t_used, iters = 0, 0.0, 0
+    while t_used < 0.7 * seconds or iters < 1:                  # the B = 4 sample is the reported value
+        t_used += one_batch(x)
         frames += 4
         iters += 1
-    return {"value": round(frames / t_used, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{iters} x (detect_and_compute on 4 VGA frames, top_k={TOP_K} + 2 MNN matches) "
-                      f"= {frames} frames in {t_used:.1f} s, torch CPU threads={threads}"}
+    # the CPU path at B in {1, 4, 64} (B = 1: extraction of one frame; B = 64: ONE pass of the benchmark batch)
+    by_batch = {"4": round(frames / t_used, 3)}
+    n1, t1 = 0, 0.0
+    while t1 < 0.1 * seconds or n1 < 1:
+        t1 += one_batch(x[:1]); n1 += 1
+    by_batch["1"] = round(n1 / t1, 3)
+    if seconds >= 10:
+        by_batch["64"] = round(64 / one_batch(make_frames(64, seed=77)), 3)
+    return {"value": round(frames / t_used, 3), "unit": "frames/s", "cores": threads, "kind": "port", "frames_per_s_by_batch": by_batch,
+            "sample": f"CPU ORACLE (oracle/xfeat_oracle.py, a port of the reference's CPU path with hand-written samplers; /root/reference "
+                      f"itself is not on the GPU box): {iters} x (detect_and_compute on 4 VGA frames, top_k={TOP_K} + 2 MNN matches) "
+                      f"= {frames} frames in {t_used:.1f} s, torch CPU threads={threads}; by_batch: B=1 extraction only, B=64 one pass"}
 
 
 def cpu_sample(seconds, fn, unit, units_per_call, what):
@@ -128,14 +148,16 @@ def conv_family_roofline(xf, step_fn, n=2):
 
 
 def load_pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (PMC passes cannot run inside
+    this process: the figure is a constant of the committed profile, stamped with its source)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get("mnn_sim_kernel_hbm_bytes_per_launch")
+            d = json.load(open(p))
+            return d.get("mnn_sim_kernel_hbm_bytes_per_launch"), f"profiles/pmc_traffic.json ({d.get('collected', 'rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes')}); not re-measured in this run"
         except Exception:
-            return None
-    return None
+            return None, None
+    return None, None
 
 
 def bench_dense(args, xf, rank, world, dist):
@@ -144,28 +166,17 @@ def bench_dense(args, xf, rank, world, dist):
     P = 32 if args.batch == 64 else args.batch
     base = fixtures.texture_images(4, 1024, 1024, seed=2000 + rank)
     a = torch.cat([torch.roll(base, (7 * i, 5 * i), (2, 3)) for i in range(P // 4)])[:P].cuda()
-    b = (torch.roll(a, (16, 24), (2, 3)) + 0.02 * torch.randn_like(a)).contiguous()
+    # pair image = a noisy copy (fixtures.star_pair's recipe): the dual-scale path resizes by 0.6 / 1.3 and the backbone strides by 32,
+    # so no non-trivial shift keeps the cells of both scales aligned; a noisy copy gives >= 2000 mutual matches per pair, i.e.
+    # refine_matches (fine_matcher MLP on MFMA + subpixel softmax + confidence filter) does its full work inside the timed region
+    g = torch.Generator(device="cuda").manual_seed(7 + rank)
+    b = (a + 0.005 * torch.randn(a.shape, device="cuda", generator=g)).contiguous()
 
     def step():
         return xf.match_xfeat_star(a, b, top_k=TOP_K)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    secs, res = sharding.timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
+    tmax = torch.tensor([secs], dtype=torch.float64)
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
@@ -181,7 +192,8 @@ def bench_dense(args, xf, rank, world, dist):
             "ms_per_step": round(1e3 * float(tmax.item()) / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "match_xfeat_star semi-dense on 1024x1024 pairs, batch=32 pairs per GPU (BASELINE configs[2])",
-                       "pairs_per_gpu": P, "top_k": TOP_K, "mean_refined_matches": round(float(np.mean([len(r) for r in res])), 1)}}))
+                       "pairs_per_gpu": P, "top_k": TOP_K, "pair": "image + 0.005*noise (see bench_dense)",
+                       "mean_refined_matches": round(float(np.mean([len(r) for r in res])), 1)}}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -203,23 +215,8 @@ def bench_lighterglue(args, xf, rank, world, dist):
         m, s, n = lg.match_pairs_device(kp, de, nv, (W, H), 0.0)     # synthetic matcher weights: keep every mutual assignment
         return torch.cat([nv, n]).cpu()
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        counts = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    secs, counts = sharding.timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
+    tmax = torch.tensor([secs], dtype=torch.float64)
     if rank == 0:
         nv, nm = counts[:B].tolist(), counts[B:].tolist()
         kpt = float(np.mean(nv))
@@ -274,14 +271,8 @@ def bench_megadepth(args, xf, rank, world, dist):
     accelerated_features_amd.batching.match_pairs (size-grouped batches, match_xfeat's results per pair)."""
     import fixtures
     from accelerated_features_amd.batching import match_pairs
-    from accelerated_features_amd.sharding import shard_range
-    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "megadepth1500_sizes.json")))
-    up = lambda v: max(32, int(v * 1600 / 1184) // 32 * 32)
-    sizes = []
-    for h0, w0, h1, w1, n in rows:
-        sizes += [((up(h0), up(w0)), (up(h1), up(w1)))] * n
-    order = np.random.RandomState(15).permutation(len(sizes))          # the dataset interleaves scenes; fixed pseudo-random order
-    sizes = [sizes[i] for i in order]
+    shard_range = sharding.shard_range
+    sizes, n_distinct = sharding.megadepth_pair_sizes()
     lo, hi = shard_range(len(sizes), rank, world)
     bank = {}
 
@@ -299,23 +290,8 @@ def bench_megadepth(args, xf, rank, world, dist):
     def step():
         return match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    secs, res = sharding.timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
+    tmax = torch.tensor([secs], dtype=torch.float64)
     if rank == 0:
         t = float(tmax.item())
         mpix = sum(a[0] * a[1] + b[0] * b[1] for a, b in sizes) / 1e6
@@ -334,7 +310,7 @@ def bench_megadepth(args, xf, rank, world, dist):
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "MegaDepth-1500 pair list, sizes scaled to long side 1600 and /32, sharded contiguously across the GPUs "
                                    "(BASELINE configs[3]); one step = all 1500 pairs",
-                       "pairs": len(sizes), "pairs_this_rank": hi - lo, "distinct_size_pairs": len(rows), "megapixels_per_pass": round(mpix, 1),
+                       "pairs": len(sizes), "pairs_this_rank": hi - lo, "distinct_size_pairs": n_distinct, "megapixels_per_pass": round(mpix, 1),
                        "top_k": TOP_K, "input": "uint8 tensors in HBM", "mean_matches_rank0": round(float(np.mean([len(r[0]) for r in res])), 1),
                        "parallelism": f"pairs sharded x{world}, no collective"}}))
     if dist is not None:
@@ -349,14 +325,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config: 64)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-side-passes", action="store_true", help="skip the extraction-only / with-H2D side figures (profiling runs)")
     ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "lighterglue", "megadepth"],
                     help="sparse = BASELINE configs[1] (the contract metric); dense = configs[2], match_xfeat_star on 1024^2 pairs, batch 32; "
                          "megadepth = configs[3], the MegaDepth-1500 pair list sharded across the GPUs; lighterglue = configs[4]")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = sharding.rank_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -364,9 +339,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("XFH_BENCH_FORCE_DIST") == "1":      # (the env switch exercises the RCCL path with one rank)
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist = sharding.init_process_group("nccl", rank, world)      # backend "nccl" IS RCCL on ROCm
 
     import fixtures
     from accelerated_features_amd import XFeat, _lib
@@ -379,7 +352,8 @@ def main():
     if args.workload == "megadepth":
         return bench_megadepth(args, xf, rank, world, dist)
     B = args.batch
-    x = make_frames(B, seed=1000 + rank).cuda()           # inputs resident in HBM before the timed region
+    x_host = make_frames(B, seed=1000 + rank)
+    x = x_host.cuda()                                      # inputs resident in HBM before the timed region
     handle = xf.net.handle()
 
     def step():
@@ -388,22 +362,11 @@ def main():
         counts = torch.cat([nv, nc, nm]).cpu()             # the one read-back (ragged results)
         return counts, cap
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def arm(last):
+        assert int(last[0][B:2 * B].max()) <= last[1], "NMS capacity overflow in the benchmark workload"
+        lib.xfh_profile_select(handle, _lib.PROF_MATCH)
 
-    for _ in range(args.warmup):
-        counts, cap = step()
-    assert int(counts[B:2 * B].max()) <= cap, "NMS capacity overflow in the benchmark workload"
-    lib.xfh_profile_select(handle, _lib.PROF_MATCH)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts, cap = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    dt_max, (counts, cap) = sharding.timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
     n_l, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
     lib.xfh_profile_read(handle, C.byref(n_l), C.byref(ms), C.byref(fl), C.byref(by))
     # secondary (untimed) pass: the MFMA convolution family, same events mechanism
@@ -415,18 +378,45 @@ def main():
     lib.xfh_profile_read(handle, C.byref(cn), C.byref(cms), C.byref(cfl), C.byref(cby))
     lib.xfh_profile_select(handle, _lib.PROF_NONE)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+    # SURVEY 8(d) side figures, each its own short pass OUTSIDE the timed region above (rank-local, per GPU)
+    def rate(fn, n=5):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return B * n / (time.perf_counter() - t0)
+
+    def extract_only():
+        kp, sc, de, nv, nc, cap_, hw = xf._detect_device(x, TOP_K, 0.05)
+        return torch.cat([nv, nc]).cpu()
+
+    side = {}
+    if rank == 0 and not args.no_side_passes:
+        side["extraction_only_fps"] = round(rate(extract_only), 1)
+        xh32 = x_host.pin_memory()
+        xh8 = (x_host * 255).round().clamp(0, 255).to(torch.uint8).pin_memory()
+
+        def with_h2d(src):
+            def f():
+                xd = src.cuda(non_blocking=True)
+                kp, sc, de, nv, nc, cap_, hw = xf._detect_device(xd, TOP_K, 0.05)
+                i0, i1, nm = xf.match_pairs_device(de, nv, -1)
+                return torch.cat([nv, nc, nm]).cpu()
+            return f
+        side["with_h2d_fp32_fps"] = round(rate(with_h2d(xh32)), 1)
+        side["with_h2d_uint8_fps"] = round(rate(with_h2d(xh8)), 1)
 
     if rank == 0:
         n_valid = counts[:B].tolist()
         n_match = counts[2 * B:].tolist()
         achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        fps = sharding.aggregate_rate(B, args.steps, world, dt_max, "weak")
+        fps_gpu = fps / world
+        traffic, traffic_src = load_pmc_traffic()
         out = {
             "metric": "frames/sec detectAndCompute+match (VGA, top_k=4096)",
-            "value": round(world * B * args.steps / dt_max, 2),
+            "value": round(fps, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -448,18 +438,27 @@ def main():
                          "launches": n_l.value, "avg_launch_us": round(1e3 * ms.value / max(n_l.value, 1), 2),
                          "flops_per_launch": fl.value / max(n_l.value, 1),
                          "algorithmic": "2*pairs*N1*N2*64 FLOP per launch (32 pairs x 4096 x 4096)",
-                         "traffic": load_pmc_traffic()},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_algorithmic": 32 * (2 * 4096 * 64 * 4 + 2 * 4096 * 8 + 4096 * 4)},
+            # whole path against the sum over kernels of max(bytes/8 TB/s, flops/157.3 TF) = 26.9 us per frame
+            "roofline_path": {"t_roof_us_per_frame": T_ROOF_US_PER_FRAME, "fps_at_roof": round(1e6 / T_ROOF_US_PER_FRAME, 1),
+                              "frac": round(fps_gpu * T_ROOF_US_PER_FRAME / 1e6, 4),
+                              "hbm_fraction": round(ALGO_BYTES_PER_FRAME * fps_gpu / 8.0e12, 4),
+                              "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME, "algorithmic_flops_per_frame": ALGO_FLOPS_PER_FRAME,
+                              "note": "per GPU; 78.6 MB and 2.622 + 1.074 GFLOP per frame (SURVEY 8d); the pure-HBM line (8 TB/s / 78.6 MB = "
+                                      "102 k fps) is above the fp32 compute bound of the backbone alone, so frac is taken against T_roof"},
             "roofline_conv_family": {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> (all 12 MFMA conv launches per step; FLOPs of the "
                                                                   "direct form -- the 3x3/s1 layers execute 2.25x fewer as Winograd F(2x2,3x3))",
                                      "achieved": round((cfl.value / 1e12) / (cms.value / 1e3), 3) if cms.value > 0 else None,
                                      "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                                      "us_per_step": round(1e3 * cms.value / 3, 1)},
         }
+        out.update(side)
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
-        dist.barrier()
+        sharding.sync_barrier(dist)
         dist.destroy_process_group()
 
 

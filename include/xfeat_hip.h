@@ -200,15 +200,23 @@ int xfh_refine_matches(xfh_handle h, const float* desc0, const float* desc1, con
  * Stand-alone helpers behind the reference's public helper methods.
  *   xfh_kpts_heatmap : XFeat.get_kpts_heatmap (modules/xfeat.py:242-247); logits (B,h,w,65)
  *                      channels-last -> heat (B,8h,8w).
- *   xfh_nms          : XFeat.NMS (modules/xfeat.py:249-263), kernel_size 5.  xy (B,capacity,2)
- *                      int64 (x,y) in row-major order, zero padded; n_candidates (B) int32
+ *   xfh_nms          : XFeat.NMS (modules/xfeat.py:249-263), any odd kernel_size (the reference's generic
+ *                      max_pool2d(k, 1, k/2) window; 5 is what the hot path uses and has the tiled kernel).
+ *                      xy (B,capacity,2) int64 (x,y) in row-major order, zero padded; n_candidates (B) int32
  *                      uncapped.  workspace: xfh_detect_workspace_bytes(B,H,W,1,capacity).
+ *   xfh_sample_sparse: InterpolateSparse2d.forward (modules/interpolator.py:10-33; the XFeat.interpolator attribute,
+ *                      modules/xfeat.py:37): x (B,C,Hm,Wm) NCHW, pos (B,N,2) fp32 (x,y) in an H x W frame ->
+ *                      out (B,N,C); grid_sample semantics (align_corners=False, zeros padding) with the reference's
+ *                      fp32 coordinate arithmetic.  The hot path fuses its three sampling sites and does not call this.
  *   xfh_fine_matcher : XFeatModel.fine_matcher (modules/model.py:97-111): x (n,128) -> out (n,64).
  *                      workspace: xfh_refine_workspace_bytes(1, n).
  * ---------------------------------------------------------------------------------------- */
 int xfh_kpts_heatmap(const float* logits, int B, int hc, int wc, float* heat, xfh_stream stream);
-int xfh_nms(xfh_handle h, const float* heat, int B, int H, int W, float threshold, int capacity, int64_t* xy,
+int xfh_nms(xfh_handle h, const float* heat, int B, int H, int W, float threshold, int kernel_size, int capacity, int64_t* xy,
             int32_t* n_candidates, void* workspace, size_t workspace_bytes, xfh_stream stream);
+enum { XFH_SAMPLE_NEAREST = 0, XFH_SAMPLE_BILINEAR = 1, XFH_SAMPLE_BICUBIC = 2 };
+int xfh_sample_sparse(const float* x, const float* pos, int B, int C, int Hm, int Wm, int N, int H, int W, int mode, float* out,
+                      xfh_stream stream);
 int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* workspace, size_t workspace_bytes,
                      xfh_stream stream);
 

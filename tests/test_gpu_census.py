@@ -141,12 +141,18 @@ def test_star_many_rows_vs_reference_golden_and_oracle(xf, sd):
     ob = O.detect_and_compute_dense(sd, sb, top_k=2048)
     res = xf.match_xfeat_star(sa.cuda(), sb.cuda(), top_k=2048)
     ref = O.match_xfeat_star(sd, sa, sb, top_k=2048)
-    # batch_match on the oracle's descriptors: index lists identical to the reference's
+    # batch_match on the oracle's descriptors: index lists identical to the oracle's on the same inputs; against the
+    # reference's golden lists through coordinates (the order inside reliability ties of the top-k is free, so raw
+    # indices are only comparable between runs on the same machine / thread count)
     bm = xf.batch_match(oa["descriptors"].cuda(), ob["descriptors"].cuda())
+    bo = O.batch_match(oa["descriptors"], ob["descriptors"])
     for b in range(2):
         r1 = parity.compare_dense(da, oa, b)
         r2 = parity.compare_dense(db, ob, b)
-        assert np.array_equal(bm[b][0].cpu().numpy(), g[f"bm{b}_idx0"]) and np.array_equal(bm[b][1].cpu().numpy(), g[f"bm{b}_idx1"])
+        assert torch.equal(bm[b][0].cpu(), bo[b][0]) and torch.equal(bm[b][1].cpu(), bo[b][1]), b
+        pt = set(zip(map(tuple, oa["keypoints"][b][bm[b][0].cpu()].tolist()), map(tuple, ob["keypoints"][b][bm[b][1].cpu()].tolist())))
+        pg = set(zip(map(tuple, g["kp_a"][b][g[f"bm{b}_idx0"]].tolist()), map(tuple, g["kp_b"][b][g[f"bm{b}_idx1"]].tolist())))
+        assert len(pt ^ pg) <= 2 and len(pg) >= 1500, (len(pt), len(pg), len(pt ^ pg))
         ctx = {"sd": sd, "d0": oa, "d1": ob, "b": b}
         dense = (da["keypoints"][b], db["keypoints"][b])
         rep = parity.compare_star_rows(res[b], ref[b], ctx, test_dense=dense)

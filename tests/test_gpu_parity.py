@@ -642,3 +642,92 @@ def test_large_frame_2160x3840_vs_oracle(xf, sd):
     assert rep["n_test"] == 4096
     kp = out["keypoints"].cpu().numpy()
     assert kp[:, 0].max() <= 3840 and kp[:, 1].max() <= 2160 and kp.min() >= 0
+
+
+# ----------------------------------------------------------------------------------------------
+# reference surface: helper modules / attributes (boundary nits)
+# ----------------------------------------------------------------------------------------------
+def test_interpolator_attribute_is_the_reference_module(xf, sd):
+    """XFeat.interpolator = InterpolateSparse2d('bicubic') like modules/xfeat.py:37; all three modes against the oracle's explicit
+    samplers (pinned to F.grid_sample in tests/test_oracle_sampling.py) and against torch's grid_sample on the host."""
+    from accelerated_features_amd.interpolator import InterpolateSparse2d
+    assert isinstance(xf.interpolator, InterpolateSparse2d) and xf.interpolator.mode == 'bicubic'
+    g = torch.Generator().manual_seed(4)
+    H, W = 96, 128
+    for (C_, Hm, Wm) in ((64, 12, 16), (1, 96, 128), (3, 12, 16)):
+        m = torch.randn(2, C_, Hm, Wm, generator=g)
+        pos = torch.stack([torch.randint(0, W, (2, 300), generator=g), torch.randint(0, H, (2, 300), generator=g)], -1)
+        pos[0, 0] = torch.tensor([0, 0]); pos[0, 1] = torch.tensor([W - 1, H - 1]); pos[0, 2] = torch.tensor([W - 2, H - 2])
+        for mode, fn in (("nearest", O.sample_nearest), ("bilinear", O.sample_bilinear), ("bicubic", O.sample_bicubic)):
+            mod = InterpolateSparse2d(mode)
+            got = mod(m.cuda(), pos.cuda(), H, W).cpu()                     # int64 positions, as detectAndCompute passes them
+            assert got.shape == (2, 300, C_)
+            for b in range(2):
+                parity.assert_close(got[b], fn(m[b], pos[b], H, W), 2e-6, f"{mode} vs oracle")
+            grid = (2. * (pos / torch.tensor([W - 1, H - 1])) - 1.).unsqueeze(-2)
+            ref = torch.nn.functional.grid_sample(m, grid, mode=mode, align_corners=False).permute(0, 2, 3, 1).squeeze(-2)
+            parity.assert_close(got, ref, 1e-5, f"{mode} vs grid_sample")
+            fpos = pos.float() + 0.37                                           # fractional positions
+            got = mod(m.cuda(), fpos.cuda(), H, W).cpu()
+            grid = (2. * (fpos / torch.tensor([W - 1., H - 1.])) - 1.).unsqueeze(-2)
+            ref = torch.nn.functional.grid_sample(m, grid, mode=mode, align_corners=False).permute(0, 2, 3, 1).squeeze(-2)
+            if mode != "nearest":                                               # (nearest at x.5 ties: compared on integers above)
+                parity.assert_close(got, ref, 1e-5, f"{mode} fractional vs grid_sample")
+    assert isinstance(xf.kornia_available, bool)
+
+
+def test_nms_any_odd_kernel_size(xf, sd):
+    x = fixtures.texture_images(2, 96, 128, seed=11)
+    _, logits, _ = O.backbone(sd, x)
+    heat = O.kpts_heatmap(logits)
+    for ks in (1, 3, 5, 7, 9):
+        ref = O.pad_keypoints(O.nms(heat, 0.02, ks))
+        got = xf.NMS(heat.cuda(), threshold=0.02, kernel_size=ks).cpu()
+        assert got.shape == ref.shape and torch.equal(got, ref), ks
+    with pytest.raises(RuntimeError):
+        xf.NMS(heat.cuda(), kernel_size=4)
+
+
+def test_state_dict_reload_and_cpu_inputs(xf, sd):
+    """XFeat.load_state_dict (the parent module) must invalidate the packed device weights; CPU tensors handed to the bare network
+    raise instead of faulting the GPU."""
+    from accelerated_features_amd import XFeat
+    from accelerated_features_amd._lib import XFeatHipError
+    m = XFeat(weights=sd, top_k=256)
+    x = fixtures.texture_images(1, 96, 128, seed=3).cuda()
+    a = m.detectAndCompute(x)[0]
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["block_fusion.2.bias"] = sd2["block_fusion.2.bias"] + 0.25
+    m.load_state_dict({"net." + k: v for k, v in sd2.items()})          # through the PARENT module
+    b = m.detectAndCompute(x)[0]
+    ref = XFeat(weights=sd2, top_k=256).detectAndCompute(x)[0]
+    assert not torch.equal(a["descriptors"], b["descriptors"])
+    assert torch.equal(b["descriptors"], ref["descriptors"]) and torch.equal(b["keypoints"], ref["keypoints"])
+    with pytest.raises(XFeatHipError):
+        m.net(x.cpu())
+    with pytest.raises(XFeatHipError):
+        m.net.fine_matcher(torch.zeros(4, 128))
+
+
+def test_hipgraph_survives_workspace_growth_and_weight_reload_of_the_user_model(sd):
+    """The captured graph must not reference memory the user's XFeat can reallocate or free (graphs.py): eager calls with
+    larger shapes / a forced larger NMS capacity / load_state_dict on the user's model, then replay."""
+    from accelerated_features_amd import XFeat
+    from accelerated_features_amd.graphs import CapturedSparsePipeline
+    m = XFeat(weights=sd, top_k=512)
+    pipe = CapturedSparsePipeline(m, batch=2, height=96, width=128, top_k=512, match=True)
+    x = fixtures.texture_images(2, 96, 128, seed=41).cuda()
+    first = pipe(x)
+    k0, d0 = first['keypoints'].clone(), first['descriptors'].clone()
+    m.detectAndCompute(fixtures.texture_images(3, 480, 640, seed=5).cuda())          # user's workspaces grow
+    m._detect_device(x, 512, 0.05, cap=96 * 128)                                      # larger NMS capacity
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]    # recycle whatever the allocator got back
+    m.load_state_dict({"net." + k: v for k, v in sd.items()})                         # user's weight blob freed and rebuilt
+    m.detectAndCompute(x)
+    again = pipe(x)
+    assert torch.equal(again['keypoints'], k0) and torch.equal(again['descriptors'], d0)
+    e = m.detectAndCompute(x, top_k=512)
+    for b in range(2):
+        n = again['n_valid'][b]
+        assert torch.equal(again['keypoints'][b, :n], e[b]['keypoints']) and torch.equal(again['descriptors'][b, :n], e[b]['descriptors'])
+    del junk

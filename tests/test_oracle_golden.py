@@ -147,6 +147,8 @@ def test_g6_match_xfeat_star_many_refined_rows():
     bm = O.batch_match(d0["descriptors"], d1["descriptors"])
     res = O.match_xfeat_star(sd, sa, sb, top_k=2048)
     for b in range(2):
-        assert np.array_equal(bm[b][0].numpy(), g[f"bm{b}_idx0"]) and np.array_equal(bm[b][1].numpy(), g[f"bm{b}_idx1"])
+        pt = set(zip(map(tuple, d0["keypoints"][b][bm[b][0]].tolist()), map(tuple, d1["keypoints"][b][bm[b][1]].tolist())))
+        pg = set(zip(map(tuple, g["kp_a"][b][g[f"bm{b}_idx0"]].tolist()), map(tuple, g["kp_b"][b][g[f"bm{b}_idx1"]].tolist())))
+        assert pt == pg and len(pg) >= 1500          # as coordinates: the index order inside reliability ties is free
         rep = parity.compare_star_rows(res[b], g[f"star{b}"], {"sd": sd, "d0": d0, "d1": d1, "b": b})
         assert rep["n_ref"] >= 1000 and rep["exceptions"] == 0, rep

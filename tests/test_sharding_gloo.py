@@ -1,14 +1,15 @@
-"""Multi-GPU path on CPU: one process per 'GPU' over gloo (world size 2).  The data path has no
-collective (frames shard embarrassingly); what is checked is that the shards are
-disjoint, cover every frame pair, and that the benchmark's barrier + max-over-ranks timing
-protocol works."""
+"""Multi-GPU path on CPU: one process per 'GPU' over gloo (world size 2).  The data path has no collective (frames shard
+embarrassingly); what is checked is the code bench.py itself runs -- accelerated_features_amd.sharding:
+shard_range / megadepth shards (disjoint, complete, balanced), sync_barrier + timed_steps (exactly K timed steps,
+MAX over ranks), aggregate_rate."""
 import os
 import socket
+import time
 
 import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from accelerated_features_amd import sharding
 from accelerated_features_amd.sharding import shard_range
 
 
@@ -24,24 +25,42 @@ def test_shard_range_properties():
         assert max(sizes) - min(sizes) <= m
 
 
+def test_megadepth_shards_are_balanced_in_megapixels():
+    """BASELINE configs[3] (strong scaling): contiguous chunks of the permuted 1500-pair list; the megapixels per rank --
+    the load -- differ by at most 5 % at 2, 4 and 8 ranks."""
+    sizes, n_distinct = sharding.megadepth_pair_sizes()
+    assert len(sizes) == 1500 and n_distinct >= 10
+    assert all(h % 32 == 0 and w % 32 == 0 and max(h, w) <= 1600 for p in sizes for (h, w) in p)
+    for world in (1, 2, 4, 8):
+        mp_ = sharding.shard_megapixels(sizes, world)
+        assert len(mp_) == world and abs(sum(mp_) - sharding.shard_megapixels(sizes, 1)[0]) < 1e-6
+        assert (max(mp_) - min(mp_)) / (sum(mp_) / world) <= 0.05, (world, mp_)
+
+
 def _worker(rank, world, port, n_frames, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist = sharding.init_process_group("gloo", rank, world)            # 127.0.0.1 rendezvous, like bench.py
     b, e = shard_range(n_frames, rank, world, multiple=2)
     owned = torch.zeros(n_frames, dtype=torch.int32)
     owned[b:e] = 1
-    # "process" the shard: a per-frame checksum that only the owner computes
     frames = torch.arange(n_frames, dtype=torch.float64)
-    local = (frames[b:e] ** 2).sum()
-    dist.barrier()
-    t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)      # pretend per-rank elapsed time
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    calls = {"n": 0, "armed": 0}
+
+    def step():                                     # "process" the shard; rank 1 is slower
+        calls["n"] += 1
+        time.sleep(0.02 * (rank + 1))
+        return (frames[b:e] ** 2).sum()
+
+    def arm(_):
+        calls["armed"] = calls["n"]
+
+    secs, last = sharding.timed_steps(step, steps=3, warmup=2, dist=dist, device_sync=None, device="cpu", before_timed=arm)
     dist.all_reduce(owned, op=dist.ReduceOp.SUM)
-    tot = local.clone()
+    tot = last.clone()
     dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    q.put((rank, owned.tolist(), float(t), float(tot)))
-    dist.barrier()
+    rate = sharding.aggregate_rate(e - b, 3, world, secs, "weak")
+    q.put((rank, owned.tolist(), secs, float(tot), calls["n"], calls["armed"], rate))
+    sharding.sync_barrier(dist)
     dist.destroy_process_group()
 
 
@@ -60,7 +79,11 @@ def test_two_process_gloo_sharding_and_timing_protocol():
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    for rank, owned, tmax, tot in res:
+    secs = [r[2] for r in res]
+    assert secs[0] == secs[1]                        # both ranks hold the MAX over ranks
+    assert 3 * 0.04 <= secs[0] < 3 * 0.04 + 0.5      # = the slow rank's three timed steps (rank 0 alone would be 0.06 s)
+    for rank, owned, tmax, tot, n_calls, armed, rate in res:
         assert owned == [1] * n                      # disjoint and complete
-        assert abs(tmax - 0.2) < 1e-12               # max over ranks
         assert tot == float(sum(i * i for i in range(n)))
+        assert n_calls == 5 and armed == 2           # exactly warmup + steps calls; the hook ran between them
+        assert abs(rate - 32 * 3 * 2 / tmax) < 1e-9  # whole-job units / max time
