@@ -196,7 +196,7 @@ static size_t carve_match(void* ws, int P, int N1, int N2, MatchWs& o) {
     Carver c(ws);
     o.match12 = c.take<int>((size_t)P * N1);
     o.rowmax = c.take<float>((size_t)P * N1);
-    o.colpart = c.take<unsigned long long>((size_t)P * match_row_blocks(N1) * N2);
+    o.colbest = c.take<unsigned long long>((size_t)P * N2);
     return align_up(c.off, 256);
 }
 
@@ -526,7 +526,7 @@ int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, cons
         return fail(XFH_ERR_ARG, "xfh_detect_sparse: NULL argument");
     int rc = check_img("xfh_detect_sparse", B, 1, H, W);
     if (rc) return rc;
-    if (top_k <= 0 || top_k > 16384) return fail(XFH_ERR_UNSUPPORTED, "xfh_detect_sparse: top_k %d outside 1..16384", top_k);
+    if (top_k <= 0) return fail(XFH_ERR_ARG, "xfh_detect_sparse: top_k %d must be positive", top_k);
     if ((long)(H / 8) * (W / 8) >= (1L << 22))      // descriptor_kernel addresses the feature map with 32-bit byte offsets
         return fail(XFH_ERR_UNSUPPORTED, "xfh_detect_sparse: %dx%d is beyond 2^22 feature cells (about 16k x 16k pixels)", H, W);
     if (nms_capacity <= 0 || (long)nms_capacity > (long)H * W) return fail(XFH_ERR_ARG, "xfh_detect_sparse: nms_capacity %d outside 1..H*W", nms_capacity);
@@ -550,7 +550,6 @@ int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int
     if (!h || !reliab || !feats || !kpts || !desc) return fail(XFH_ERR_ARG, "xfh_extract_dense: NULL argument");
     if (B <= 0 || hc <= 0 || wc <= 0 || B > 65535) return fail(XFH_ERR_ARG, "xfh_extract_dense: bad shape");
     if (k <= 0 || k > hc * wc) return fail(XFH_ERR_ARG, "xfh_extract_dense: k %d outside 1..h*w", k);
-    if (k > 16384) return fail(XFH_ERR_UNSUPPORTED, "xfh_extract_dense: k %d > 16384", k);
     if (!(scale_div > 0.f)) return fail(XFH_ERR_ARG, "xfh_extract_dense: scale_div must be positive");
     DenseWs w;
     const size_t need = carve_dense(workspace, B, hc, wc, k, w);
@@ -574,7 +573,7 @@ int xfh_match_mnn(xfh_handle h, const float* d1, size_t pair_stride1, const floa
                   size_t workspace_bytes, xfh_stream stream) {
     if (!d1 || !d2 || !idx0 || !idx1 || !n_matches) return fail(XFH_ERR_ARG, "xfh_match_mnn: NULL argument");
     if (P <= 0 || N1 <= 0 || N2 <= 0 || P > 65535) return fail(XFH_ERR_ARG, "xfh_match_mnn: bad shape");
-    if (N2 > 16384) return fail(XFH_ERR_UNSUPPORTED, "xfh_match_mnn: N2 %d > 16384", N2);
+    if ((long)P * ((N1 + 1023) / 1024) > 0x7fffffffL / 1024) return fail(XFH_ERR_ARG, "xfh_match_mnn: P * N1 too large");
     if ((pair_stride1 & 3) || (pair_stride2 & 3)) return fail(XFH_ERR_ARG, "xfh_match_mnn: pair strides must be multiples of 4 floats");
     MatchWs w;
     const size_t need = carve_match(workspace, P, N1, N2, w);

@@ -71,6 +71,17 @@ __device__ inline void lds_dma_barrier() {
     __syncthreads();
 }
 
+// Raise a kernel's dynamic-LDS limit once per device.  `mask` is a static of the call site (bit d = done on device d): function
+// attributes are per device, so a process that drives several GPUs must set them on each (a per-process "done" flag would leave
+// every device but the first at the 64 KB default).  Racing threads at worst repeat the idempotent call.
+inline void set_max_dynamic_lds(const void* fn, int bytes, unsigned& mask) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 32 && ((mask >> dev) & 1u)) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (dev >= 0 && dev < 32) mask |= 1u << dev;
+}
+
 // XCD-aware work mapping (MI355X: 8 XCDs, private L2s; workgroup b runs on XCD b % 8).
 // A 1-D grid of n_groups_padded * per_group workgroups is remapped so that all `per_group`
 // workgroups of a group (an image, a descriptor pair) run on ONE XCD and share its L2:

@@ -288,12 +288,8 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     const ConvW& c2 = nw.conv[L_BLOCK1_2];
     const ConvW& c3 = nw.conv[L_BLOCK1_3];
     const ConvW& sk = nw.conv[L_SKIP1];
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(block1_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  b1::LDS_FLOATS * 4);
-        attr = true;
-    }
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel), b1::LDS_FLOATS * 4, attr);
     const int H4 = H / 4, W4 = W / 4;
     const int tx = ceil_div(W4, b1::OW), ty = ceil_div(H4, b1::OH);
     block1_fused_kernel<<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(

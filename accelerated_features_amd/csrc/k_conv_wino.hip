@@ -585,12 +585,8 @@ static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float*
     a.tiles = a.tiles_x * ceil_div(ceil_div(H, 2), TTH);
     const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
     static_assert(Cfg::LDS_FLOATS * sizeof(float) <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC, PERSIST>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static unsigned attr_done = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC, PERSIST>), 160 * 1024, attr_done);
     int grid = xcd_grid_size(a.tiles, B);
     if (PERSIST && grid > 256) grid = 256;          // one workgroup per CU walks the tiles (256 % 8 == 0 keeps the XCD mapping)
     conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC, PERSIST><<<grid, Cfg::NTHR, lds, st>>>(a);

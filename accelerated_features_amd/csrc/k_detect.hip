@@ -165,37 +165,43 @@ __device__ inline float fetch0(const float* __restrict__ m, int Hm, int Wm, int 
 
 // score = nearest(heat) * bilinear(reliability); (0,0) -> -1          (xfeat.py:77-80)
 // key = (~ord(score) << 32) | slot : ascending key == descending score, ties by slot
-__global__ __launch_bounds__(256) void score_keys_kernel(const float* __restrict__ heat, const float* __restrict__ rel,
-                                                         const unsigned* __restrict__ cand,
-                                                         const int32_t* __restrict__ n_cand, int H, int W, int cap,
-                                                         unsigned long long* __restrict__ keys) {
-    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    const int n = min(n_cand[b], cap);
-    if (i >= n) return;
-    const unsigned c = cand[(size_t)b * cap + i];
+struct ScoreSrc {
+    const float* heat;      // (B,H,W)
+    const float* rel;       // (B,H/8,W/8)
+    const unsigned* cand;   // (B,cap)
+    int H, W;
+};
+__device__ inline unsigned long long score_key(const ScoreSrc& s, int b, int cap, int i) {
+    const unsigned c = s.cand[(size_t)b * cap + i];
     const int x = c & 0xffff, y = c >> 16;
-    const int hc = H >> 3, wc = W >> 3;
+    const int H = s.H, W = s.W, hc = H >> 3, wc = W >> 3;
     // nearest on the H x W heat map
     const float nx = sample_coord(x, W, W), ny = sample_coord(y, H, H);
     const int ix = (int)rintf(nx), iy = (int)rintf(ny);
-    const float sn = fetch0(heat + (size_t)b * H * W, H, W, iy, ix);
+    const float sn = fetch0(s.heat + (size_t)b * H * W, H, W, iy, ix);
     // bilinear on the (H/8) x (W/8) reliability map
     const float ux = sample_coord(x, W, wc), uy = sample_coord(y, H, hc);
     const float fx = floorf(ux), fy = floorf(uy);
     const float tx = ux - fx, ty = uy - fy;
     const int x0 = (int)fx, y0 = (int)fy;
-    const float* rp = rel + (size_t)b * hc * wc;
+    const float* rp = s.rel + (size_t)b * hc * wc;
     const float sb = fetch0(rp, hc, wc, y0, x0) * ((1.f - tx) * (1.f - ty)) + fetch0(rp, hc, wc, y0, x0 + 1) * (tx * (1.f - ty)) +
                      fetch0(rp, hc, wc, y0 + 1, x0) * ((1.f - tx) * ty) + fetch0(rp, hc, wc, y0 + 1, x0 + 1) * (tx * ty);
     float score = sn * sb;
     if (x == 0 && y == 0) score = -1.f;
-    keys[(size_t)b * cap + i] = ((unsigned long long)(~float_ord(score)) << 32) | (unsigned)i;
+    return ((unsigned long long)(~float_ord(score)) << 32) | (unsigned)i;
 }
 
 // ------------------------------------------------------------------------------------------
-// per-image top-k of unique 64-bit keys (ascending): 8-pass radix select of the k-th key,
-// compaction of the keys <= it into LDS, bitonic sort there.  One 1024-thread block per image.
-// dynamic LDS: kpad * 8 bytes.
+// per-image top-k of unique 64-bit keys (ascending) = argsort(-scores)[:top_k] (xfeat.py:83-87) / topk (xfeat.py:371),
+// spread over the whole chip:
+//   1. topk_sort_runs_kernel: workgroup (image, q) builds the keys of candidates [2048 q, 2048 q + 2048) (the score
+//      sampling of xfeat.py:77-80 is fused here) and sorts them in LDS -> the key array of an image is a sequence of
+//      sorted runs.  ~4 workgroups per VGA image instead of one.
+//   2. topk_rank_merge_kernel: the final position of a key is its rank = its position in its own run + the number of
+//      smaller keys in every other run (binary searches; all runs of the image sit in LDS when they fit, n <= 16384,
+//      otherwise they are searched in global memory).  A key with rank < k is written straight to slot `rank` of the
+//      outputs: no radix select, no global merge passes, any n and any top_k.
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // Ascending bitonic sort of n (power of two) 64-bit keys in LDS by a 1024-thread workgroup.  Every wave owns aligned
@@ -284,108 +290,68 @@ struct TopkOut {            // sparse-path epilogue (all NULL for the plain top-
     float rw, rh;
 };
 
-__global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __restrict__ keys, int key_stride,
-                                                    const int32_t* __restrict__ n_dev, int n_const, int n_cap, int top_k,
-                                                    int kpad, int kc_cap, unsigned* __restrict__ sel, int* __restrict__ nsel,
-                                                    TopkOut o) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long lk[];
-    __shared__ int hist[256];
-    __shared__ unsigned long long s_prefix;
-    __shared__ int s_kk, s_cnt, s_valid;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    int n = n_dev ? min(n_dev[b], n_cap) : n_const;
-    const int k = min(top_k, n);
-    const unsigned long long* kp = keys + (size_t)b * key_stride;
-    // keys are read 9 times (8 radix passes + the final compaction): keep them in LDS when they fit
-    unsigned long long* kc = lk + kpad;
-    const bool cached = n <= kc_cap;
-    if (cached) {
-        for (int i = tid; i < n; i += 1024) kc[i] = kp[i];
-        __syncthreads();
-    }
+constexpr int TK_CH = 2048;          // keys per sorted run
+constexpr int TK_LDS_RUNS = 8;       // runs of one image kept in LDS by the rank kernel (128 KB)
 
-    unsigned long long T = ~0ull;
-    if (n > k && k > 0) {
-        if (tid == 0) { s_prefix = 0; s_kk = k; }
-        for (int pass = 0; pass < 8; ++pass) {
-            if (tid < 256) hist[tid] = 0;
-            __syncthreads();
-            const unsigned long long prefix = s_prefix;
-            const int shift = 56 - 8 * pass;
-            for (int i0 = 0; i0 < n; i0 += 1024) {             // (uniform trip count: the ballots below need whole waves)
-                const int i = i0 + tid;
-                const unsigned long long key = i < n ? (cached ? kc[i] : kp[i]) : 0ull;
-                const bool match = i < n && ((pass == 0) || ((key >> (shift + 8)) == prefix));
-                const int d = (int)((key >> shift) & 255);
-                // scores share their leading bytes: in the first passes a whole wave hits ONE bin -- add its population once
-                const unsigned long long mm = __ballot(match);
-                if (mm) {
-                    const int d0 = __builtin_amdgcn_readlane(d, __builtin_ctzll(mm));
-                    if (__ballot(match && d != d0) == 0ull) {
-                        if ((tid & 63) == __builtin_ctzll(mm)) atomicAdd(&hist[d0], __popcll(mm));
-                    } else if (match) {
-                        atomicAdd(&hist[d], 1);
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid < 64) {     // wave 0 finds the digit whose cumulative count crosses kk (4 bins per lane + wave scan)
-                const int kk = s_kk;
-                const int h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-                const int mine = h0 + h1 + h2 + h3;
-                int inc = mine;
+// MODE 0: keys = score keys of the NMS candidates (ScoreSrc); MODE 1: keys = (~ord(vals[i]) << 32 | i)
+template <int MODE>
+__global__ __launch_bounds__(1024) void topk_sort_runs_kernel(ScoreSrc src, const float* __restrict__ vals, const int32_t* __restrict__ n_dev,
+                                                              int n_const, int n_cap, int top_k, int qmax, int B,
+                                                              unsigned long long* __restrict__ runs, int* __restrict__ nsel,
+                                                              int32_t* __restrict__ n_valid) {
+    __shared__ __attribute__((aligned(16))) unsigned long long lk[TK_CH];
+    int b, q;
+    if (!xcd_group_map(blockIdx.x, qmax, B, b, q)) return;
+    const int tid = threadIdx.x;
+    const int n = n_dev ? min(n_dev[b], n_cap) : n_const;
+    if (q == 0 && tid == 0) {
+        nsel[b] = min(top_k, n);
+        if (n_valid) n_valid[b] = 0;
+    }
+    const int base = q * TK_CH;
+    if (base >= n) return;
+    const int csz = min(TK_CH, n - base);
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(inc, o, 64);
-                    if (tid >= o) inc += t;
-                }
-                const int before = inc - mine;
-                if (before < kk && kk <= inc) {           // exactly one lane
-                    int rem = kk - before, d = 4 * tid;
-                    if (rem > h0) { rem -= h0; ++d; if (rem > h1) { rem -= h1; ++d; if (rem > h2) { rem -= h2; ++d; } } }
-                    s_kk = rem;
-                    s_prefix = (prefix << 8) | (unsigned long long)d;
-                }
-            }
-            __syncthreads();
+    for (int e = 0; e < 2; ++e) {
+        const int j = tid + e * 1024, i = base + j;
+        unsigned long long key = ~0ull;
+        if (j < csz) {
+            if constexpr (MODE == 0) key = score_key(src, b, n_cap, i);
+            else key = ((unsigned long long)(~float_ord(vals[(size_t)b * n_cap + i])) << 32) | (unsigned)i;
         }
-        T = s_prefix;
+        lk[j] = key;
     }
-    if (tid == 0) { s_cnt = 0; s_valid = 0; }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 1024) {                 // one LDS atomic per wave, not per key (k of them hit one counter)
-        const int i = i0 + tid;
-        const unsigned long long key = i < n ? (cached ? kc[i] : kp[i]) : ~0ull;
-        const bool take = i < n && key <= T;
-        const unsigned long long mm = __ballot(take);
-        if (mm) {
-            const int lane = tid & 63, first = __builtin_ctzll(mm);
-            int base = 0;
-            if (lane == first) base = atomicAdd(&s_cnt, __popcll(mm));
-            base = __builtin_amdgcn_readlane(base, first);
-            const int slot = base + __popcll(mm & ((1ull << lane) - 1ull));
-            if (take && slot < kpad) lk[slot] = key;
-        }
+    // short runs sort a smaller power of two (the padding keys ~0 sort last and are not written back)
+    int npad = 256;
+    while (npad < csz) npad <<= 1;
+    bitonic_sort_lds(lk, npad);
+    unsigned long long* out = runs + (size_t)b * n_cap + base;
+    for (int j = tid; j < csz; j += 1024) out[j] = lk[j];
+}
+
+// number of keys < x in the ascending run a[0..len), len <= TK_CH
+__device__ inline int run_lower_bound(const unsigned long long* a, int len, unsigned long long x) {
+    int pos = 0;
+#pragma unroll
+    for (int step = TK_CH; step > 0; step >>= 1) {
+        const int t = pos + step;
+        if (t <= len && a[t - 1] < x) pos = t;
     }
-    for (int i = k + tid; i < kpad; i += 1024) lk[i] = ~0ull;
-    __syncthreads();
-    bitonic_sort_lds(lk, kpad);
-    int nv = 0;
-    for (int j = tid; j < top_k; j += 1024) {
-        if (j < k) {
-            const unsigned long long key = lk[j];
-            const unsigned slot = (unsigned)(key & 0xffffffffu);
-            sel[(size_t)b * top_k + j] = slot;
-            if (o.kpts) {
-                const unsigned hi = (unsigned)(key >> 32);
-                const float score = ord_float(~hi);
-                const unsigned c = o.cand[(size_t)b * n_cap + slot];
-                o.kpts[((size_t)b * top_k + j) * 2 + 0] = (float)(c & 0xffff) * o.rw;
-                o.kpts[((size_t)b * top_k + j) * 2 + 1] = (float)(c >> 16) * o.rh;
-                o.scores[(size_t)b * top_k + j] = score;
-                if (score > 0.f) ++nv;
-            }
-        } else {
+    return pos;
+}
+
+__global__ __launch_bounds__(1024) void topk_rank_merge_kernel(const unsigned long long* __restrict__ runs, const int32_t* __restrict__ n_dev,
+                                                               int n_const, int n_cap, int top_k, int qmax, int B, int lds_runs,
+                                                               unsigned* __restrict__ sel, TopkOut o) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lr[];
+    int b, q;
+    if (!xcd_group_map(blockIdx.x, qmax, B, b, q)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = n_dev ? min(n_dev[b], n_cap) : n_const;
+    const int k = min(top_k, n);
+    if (q == 0) {                                        // fixed-capacity outputs: entries past k are zero
+        for (int j = k + tid; j < top_k; j += 1024) {
             sel[(size_t)b * top_k + j] = 0;
             if (o.kpts) {
                 o.kpts[((size_t)b * top_k + j) * 2 + 0] = 0.f;
@@ -394,36 +360,59 @@ __global__ __launch_bounds__(1024) void topk_kernel(const unsigned long long* __
             }
         }
     }
+    const int base = q * TK_CH;
+    if (base >= n) return;
+    const int nruns = ceil_div(n, TK_CH);
+    const unsigned long long* gr = runs + (size_t)b * n_cap;
+    const bool in_lds = nruns <= lds_runs;
+    if (in_lds) {
+        for (int i = tid; i < n; i += 1024) lr[i] = gr[i];
+        __syncthreads();
+    }
+    int nv = 0;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int j = tid + e * 1024, i = base + j;
+        if (i < n) {
+            const unsigned long long key = in_lds ? lr[i] : gr[i];
+            int rank = j;
+            for (int r = 0; r < nruns; ++r) {
+                if (r == q) continue;
+                const int len = min(TK_CH, n - r * TK_CH);
+                rank += in_lds ? run_lower_bound(lr + r * TK_CH, len, key) : run_lower_bound(gr + r * TK_CH, len, key);
+            }
+            if (rank < k) {
+                const unsigned slot = (unsigned)(key & 0xffffffffu);
+                sel[(size_t)b * top_k + rank] = slot;
+                if (o.kpts) {
+                    const float score = ord_float(~(unsigned)(key >> 32));
+                    const unsigned c = o.cand[(size_t)b * n_cap + slot];
+                    o.kpts[((size_t)b * top_k + rank) * 2 + 0] = (float)(c & 0xffff) * o.rw;
+                    o.kpts[((size_t)b * top_k + rank) * 2 + 1] = (float)(c >> 16) * o.rh;
+                    o.scores[(size_t)b * top_k + rank] = score;
+                    if (score > 0.f) ++nv;
+                }
+            }
+        }
+    }
     if (o.kpts) {
         nv = wave_sum_i(nv);
-        if ((tid & 63) == 0 && nv) atomicAdd(&s_valid, nv);
-        __syncthreads();
-        if (tid == 0) o.n_valid[b] = s_valid;
+        if (lane == 0 && nv) atomicAdd(&o.n_valid[b], nv);
     }
-    if (tid == 0) nsel[b] = k;
 }
 
-static int next_pow2(int v) {
-    int p = 2;
-    while (p < v) p <<= 1;
-    return p;
-}
-
-static void run_topk(const unsigned long long* keys, int key_stride, const int32_t* n_dev, int n_const, int n_cap,
+// keys/runs: (B, n_cap) u64 scratch.  Either `src` (sparse path) or `vals` (B, n_cap floats) feeds the keys.
+static void run_topk(const ScoreSrc* src, const float* vals, unsigned long long* runs, const int32_t* n_dev, int n_const, int n_cap,
                      int top_k, int B, unsigned* sel, int* nsel, const TopkOut& o, hipStream_t st) {
-    const int kpad = next_pow2(top_k);
-    // LDS: the sort buffer (kpad keys) + a cache of all candidate keys when it fits (up to 12288 keys)
-    int kc_cap = (int)((150 * 1024) / 8) - kpad;
-    if (kc_cap > 12288) kc_cap = 12288;
-    if (kc_cap < 0) kc_cap = 0;
-    const size_t lds = (size_t)(kpad + kc_cap) * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  152 * 1024);
-        attr_set = true;
-    }
-    topk_kernel<<<B, 1024, lds, st>>>(keys, key_stride, n_dev, n_const, n_cap, top_k, kpad, kc_cap, sel, nsel, o);
+    const int qmax = ceil_div(n_cap, TK_CH);
+    if (src)
+        topk_sort_runs_kernel<0><<<xcd_grid_size(qmax, B), 1024, 0, st>>>(*src, nullptr, n_dev, n_const, n_cap, top_k, qmax, B, runs, nsel, o.n_valid);
+    else
+        topk_sort_runs_kernel<1><<<xcd_grid_size(qmax, B), 1024, 0, st>>>(ScoreSrc{}, vals, n_dev, n_const, n_cap, top_k, qmax, B, runs, nsel, nullptr);
+    const int lds_runs = min(qmax, TK_LDS_RUNS);
+    static unsigned attr_mask = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(topk_rank_merge_kernel), TK_LDS_RUNS * TK_CH * 8, attr_mask);
+    topk_rank_merge_kernel<<<xcd_grid_size(qmax, B), 1024, (size_t)lds_runs * TK_CH * 8, st>>>(runs, n_dev, n_const, n_cap, top_k, qmax, B, lds_runs, sel, o);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -521,9 +510,9 @@ void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, c
     const int hc = H / 8, wc = W / 8;
     nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
-    score_keys_kernel<<<dim3(ceil_div(cap, 256), B), 256, 0, st>>>(heat, reliab, ws.cand, n_cand, H, W, cap, ws.keys);
     TopkOut o{ws.cand, kpts, scores, n_valid, rw, rh};
-    run_topk(ws.keys, cap, n_cand, 0, cap, top_k, B, ws.sel, ws.nsel, o, st);
+    const ScoreSrc src{heat, reliab, ws.cand, H, W};
+    run_topk(&src, nullptr, ws.keys, n_cand, 0, cap, top_k, B, ws.sel, ws.nsel, o, st);
     invnorm_kernel<<<ceil_div(B * hc * wc * 16, 256), 256, 0, st>>>(feats, B * hc * wc, ws.invnorm);
     descriptor_kernel<<<xcd_grid_size(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.sel, ws.nsel, H, W,
                                                                             cap, top_k, B, ceil_div(top_k, 16), desc);
@@ -557,18 +546,10 @@ void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W,
 // ------------------------------------------------------------------------------------------
 // plain top-k (descending values, ties: lower index first) for extractDense (xfeat.py:371)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void value_keys_kernel(const float* __restrict__ vals, int n,
-                                                         unsigned long long* __restrict__ keys) {
-    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    keys[(size_t)b * n + i] = ((unsigned long long)(~float_ord(vals[(size_t)b * n + i])) << 32) | (unsigned)i;
-}
-
 void launch_topk_desc(const float* vals, int B, int n, int k, unsigned long long* keys, unsigned* sel, int* nsel,
                       hipStream_t st) {
-    value_keys_kernel<<<dim3(ceil_div(n, 256), B), 256, 0, st>>>(vals, n, keys);
     TopkOut o{nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
-    run_topk(keys, n, nullptr, n, n, k, B, sel, nsel, o, st);
+    run_topk(nullptr, vals, keys, nullptr, n, n, k, B, sel, nsel, o, st);
 }
 
 // wave per selected cell: raw features + corner coordinates                (xfeat.py:366-375,388)

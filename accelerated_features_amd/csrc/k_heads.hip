@@ -243,12 +243,8 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
     const int L[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3};
     for (int i = 0; i < 4; ++i) { a.w[i] = nw.conv[L[i]].w_kcp; a.bias[i] = nw.conv[L[i]].bias; }
     const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<true>), 160 * 1024, attr);
     head_fused_kernel<true><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 
@@ -262,11 +258,8 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
     a.w[1] = nw.conv[L_HEAT_1].w_kcp; a.bias[1] = nw.conv[L_HEAT_1].bias;
     a.w[2] = nw.conv[L_HEAT_2].w_oihw; a.bias[2] = nw.conv[L_HEAT_2].bias;
     const size_t lds = (size_t)(2 * 64 * 64 + 64 + HD_CELLS * HD_XS) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<false>), 160 * 1024, attr);
     head_fused_kernel<false><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 

@@ -5,10 +5,11 @@
 // arg-maxes both.  Here S is produced tile by tile by v_mfma_f32_32x32x2_f32 and never leaves
 // registers: every workgroup owns 256 rows of D1 (A fragments stationary in VGPRs, K = 64 is
 // only 32 MFMA steps) and sweeps all columns of D2 staged through LDS, keeping a running
-// row max/arg-max per lane and emitting per-row-block column maxima as packed 64-bit keys
-// (ord(sim) << 32 | ~index), so that ties resolve to the LOWEST index like torch.max.
-// A second small kernel reduces the column partials, applies the mutual test (+ optional
-// min_cossim) and compacts the surviving pairs in ascending row order.
+// row max/arg-max per lane and folding the column maxima of its rows into one packed 64-bit key
+// per column (ord(sim) << 32 | ~index, ties resolve to the LOWEST index like torch.max) with a
+// fire-and-forget 64-bit atomic max in L2 (the 16 row blocks of a pair meet there; no per-row-block
+// partial array, no reduction pass).  A second small kernel applies the mutual test (+ optional
+// min_cossim) and compacts the surviving pairs in ascending row order, 1024 rows per workgroup.
 #include "kernels.hpp"
 
 namespace xfh {
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
                                                       size_t ps2, const int32_t* __restrict__ n1p,
                                                       const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1,
                                                       int N2, int nrb, int P, int* __restrict__ match12,
-                                                      float* __restrict__ rowmax, unsigned long long* __restrict__ colpart) {
+                                                      float* __restrict__ rowmax, unsigned long long* __restrict__ colbest_g) {
     __shared__ __attribute__((aligned(16))) float Dl[MT_COLS * MT_DS];
     __shared__ unsigned long long colbest[8][MT_COLS];
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
                 unsigned long long k = colbest[0][tid];
 #pragma unroll
                 for (int w = 1; w < 8; ++w) k = u64_max(k, colbest[w][tid]);
-                colpart[((size_t)p * nrb + rb) * N2 + col] = k;
+                atomicMax(&colbest_g[(size_t)p * N2 + col], k);            // no return value: global_atomic_umax_x2, asynchronous
             }
         }
     }
@@ -148,61 +149,67 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
     }
 }
 
-// grid (P), block 1024, dynamic LDS = N2 ints
+// grid (P * chunks), block 1024: workgroup (p, q) owns rows [1024 q, 1024 q + 1024) of pair p.  The output position of
+// a kept row is the number of kept rows before it: the workgroup recounts the rows of the chunks in front of its own
+// (<= 3 cheap passes at N1 = 4096: two 4-byte loads and one 8-byte gather per row) instead of waiting for them.
+__device__ inline bool mutual_keep(const int* __restrict__ m12, const float* __restrict__ rm,
+                                   const unsigned long long* __restrict__ cb, int row, float min_cossim, int& m) {
+    m = m12[row];
+    const int back = (int)(0xffffffffu - (unsigned)(cb[m] & 0xffffffffu));        // arg-max row of column m
+    return (back == row) && (min_cossim <= 0.f || rm[row] > min_cossim);
+}
+
 __global__ __launch_bounds__(1024) void mnn_finalize_kernel(const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p,
-                                                            int n_stride, int n_off2, int N1, int N2, int nrb,
+                                                            int n_stride, int n_off2, int N1, int N2, int chunks,
                                                             const int* __restrict__ match12, const float* __restrict__ rowmax,
-                                                            const unsigned long long* __restrict__ colpart, float min_cossim,
+                                                            const unsigned long long* __restrict__ colbest_g, float min_cossim,
                                                             int64_t* __restrict__ idx0, int64_t* __restrict__ idx1,
                                                             int32_t* __restrict__ n_matches) {
-    extern __shared__ int m21[];
     __shared__ int wsum[16];
-    __shared__ int s_base;
-    const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_before;
+    const int p = blockIdx.x / chunks, q = blockIdx.x - p * chunks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = pair_count(n1p, p * n_stride, N1);
     const int n2 = pair_count(n2p, p * n_stride + n_off2, N2);
     if (n1 <= 0 || n2 <= 0) {
-        if (tid == 0) n_matches[p] = 0;
+        if (q == 0 && tid == 0) n_matches[p] = 0;
         return;
     }
-    const int nrbp = ceil_div(n1, MT_ROWS);
-    for (int col = tid; col < n2; col += 1024) {
-        unsigned long long best = 0ull;
-        for (int rb = 0; rb < nrbp; ++rb) best = u64_max(best, colpart[((size_t)p * nrb + rb) * N2 + col]);
-        m21[col] = (int)(0xffffffffu - (unsigned)(best & 0xffffffffu));
-    }
-    if (tid == 0) s_base = 0;
-    __syncthreads();
+    if (q * 1024 >= n1) return;
     const int* m12 = match12 + (size_t)p * N1;
     const float* rm = rowmax + (size_t)p * N1;
-    for (int base = 0; base < n1; base += 1024) {
-        const int row = base + tid;
-        bool keep = false;
-        int m = 0;
-        if (row < n1) {
-            m = m12[row];
-            keep = (m21[m] == row) && (min_cossim <= 0.f || rm[row] > min_cossim);
-        }
-        const unsigned long long bal = __ballot(keep);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int off = s_base, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int s = wsum[w];
-            if (w < wave) off += s;
-            tot += s;
-        }
-        if (keep) {
-            idx0[(size_t)p * N1 + off + before] = row;
-            idx1[(size_t)p * N1 + off + before] = m;
-        }
-        __syncthreads();
-        if (tid == 0) s_base += tot;
-        __syncthreads();
+    const unsigned long long* cb = colbest_g + (size_t)p * N2;
+    // kept rows in the chunks before this one
+    int cnt = 0;
+    for (int row = tid; row < q * 1024; row += 1024) {
+        int m;
+        cnt += mutual_keep(m12, rm, cb, row, min_cossim, m) ? 1 : 0;
     }
-    if (tid == 0) n_matches[p] = s_base;
+    cnt = wave_sum_i(cnt);
+    if (tid == 0) s_before = 0;
+    __syncthreads();
+    if (lane == 0 && cnt) atomicAdd(&s_before, cnt);
+    __syncthreads();
+    // own chunk: ordered compaction
+    const int row = q * 1024 + tid;
+    int m = 0;
+    const bool keep = row < n1 && mutual_keep(m12, rm, cb, row, min_cossim, m);
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_before, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int sv = wsum[w];
+        if (w < wave) off += sv;
+        tot += sv;
+    }
+    if (keep) {
+        const int o = off + __popcll(bal & ((1ull << lane) - 1ull));
+        idx0[(size_t)p * N1 + o] = row;
+        idx1[(size_t)p * N1 + o] = m;
+    }
+    if (tid == 0 && (q + 1) * 1024 >= n1) n_matches[p] = s_before + tot;       // the pair's last chunk knows the total
 }
 
 int match_debug_occupancy() {
@@ -218,19 +225,14 @@ void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim, int64_t* idx0,
                   int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof) {
     const int nrb = match_row_blocks(N1);
+    (void)hipMemsetAsync(ws.colbest, 0, (size_t)P * N2 * sizeof(unsigned long long), st);      // 0 = below every key
     prof_begin(prof, 2, st);
     mnn_sim_kernel<<<xcd_grid_size(nrb, P), 512, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.match12,
-                                                 ws.rowmax, ws.colpart);
+                                                 ws.rowmax, ws.colbest);
     prof_end(prof, 2, st, 2.0 * P * (double)N1 * N2 * 64, (double)P * (N1 + N2) * 64 * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnn_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            16384 * 4);
-        attr_set = true;
-    }
-    mnn_finalize_kernel<<<P, 1024, (size_t)N2 * sizeof(int), st>>>(n1, n2, n_stride, n_off2, N1, N2, nrb, ws.match12,
-                                                                  ws.rowmax, ws.colpart, min_cossim, idx0, idx1,
-                                                                  n_matches);
+    const int chunks = ceil_div(N1, 1024);
+    mnn_finalize_kernel<<<P * chunks, 1024, 0, st>>>(n1, n2, n_stride, n_off2, N1, N2, chunks, ws.match12, ws.rowmax, ws.colbest,
+                                                     min_cossim, idx0, idx1, n_matches);
 }
 
 }  // namespace xfh

@@ -125,7 +125,7 @@ void launch_dense_gather(const float* feats, const unsigned* sel, int B, int hc,
 struct MatchWs {
     int* match12;                  // (P,N1)
     float* rowmax;                 // (P,N1)
-    unsigned long long* colpart;   // (P, nrb, N2) packed (ord(sim)<<32 | ~row)
+    unsigned long long* colbest;   // (P, N2) packed (ord(sim)<<32 | ~row): column arg-max, folded by 64-bit atomic max
 };
 void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim,

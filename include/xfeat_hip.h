@@ -132,7 +132,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
  *
  *   heat (B,H,W), reliab (B,H/8,W/8), feats (B,H/8,W/8,64) as produced by xfh_backbone
  *   threshold        detection threshold (strict >)
- *   top_k            <= 16384
+ *   top_k            any positive value (fewer candidates than top_k => shorter lists, like the reference)
  *   nms_capacity     capacity of the candidate list per image.  If n_candidates[b] comes back
  *                    larger, candidates were dropped in row-major order: re-run with a
  *                    capacity >= max(n_candidates) (H*W is always enough).
@@ -153,7 +153,7 @@ int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, cons
  * (modules/xfeat.py:362-375): top-k of the reliability map (descending), RAW 64-D features of
  * those cells and their corner coordinates (8*(j,i)*(rw,rh)) / scale_div (scale_div = s of
  * extract_dualscale, modules/xfeat.py:388; 1 otherwise).
- *   kpts (B,k,2), desc (B,k,64), cell_index (B,k) int32 (may be NULL); k <= min(h*w, 16384)
+ *   kpts (B,k,2), desc (B,k,64), cell_index (B,k) int32 (may be NULL); k <= h*w
  * ---------------------------------------------------------------------------------------- */
 size_t xfh_dense_workspace_bytes(int B, int h, int w, int k);
 int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int B, int hc, int wc, int k,
