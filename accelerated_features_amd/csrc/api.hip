@@ -177,17 +177,17 @@ static size_t carve_detect(void* ws, int B, int H, int W, int top_k, int cap, De
     o.wcount = c.take<int>(b * H * WPR);
     o.cand = c.take<unsigned>(b * cap);
     o.keys = c.take<unsigned long long>(b * cap);
-    o.sel = c.take<unsigned>(b * top_k);
+    o.skeys = c.take<unsigned long long>(b * top_k);
     o.nsel = c.take<int>(b);
     o.invnorm = c.take<float>(b * (H / 8) * (W / 8));
     return align_up(c.off, 256);
 }
 
-struct DenseWs { unsigned long long* keys; unsigned* sel; int* nsel; };
+struct DenseWs { unsigned long long* keys; unsigned long long* skeys; int* nsel; };
 static size_t carve_dense(void* ws, int B, int hc, int wc, int k, DenseWs& o) {
     Carver c(ws);
     o.keys = c.take<unsigned long long>((size_t)B * hc * wc);
-    o.sel = c.take<unsigned>((size_t)B * k);
+    o.skeys = c.take<unsigned long long>((size_t)B * k);
     o.nsel = c.take<int>(B);
     return align_up(c.off, 256);
 }
@@ -556,8 +556,8 @@ int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int
     int rc = check_ws(workspace, workspace_bytes, need);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    launch_topk_desc(reliab, B, hc * wc, k, w.keys, w.sel, w.nsel, st);
-    launch_dense_gather(feats, w.sel, B, hc, wc, k, rw, rh, scale_div, kpts, desc, cell_index, st);
+    launch_topk_desc(reliab, B, hc * wc, k, w.keys, w.skeys, w.nsel, st);
+    launch_dense_gather(feats, w.skeys, B, hc, wc, k, rw, rh, scale_div, kpts, desc, cell_index, st);
     return check_launch("xfh_extract_dense");
 }
 

@@ -82,6 +82,18 @@ inline void set_max_dynamic_lds(const void* fn, int bytes, unsigned& mask) {
     if (dev >= 0 && dev < 32) mask |= 1u << dev;
 }
 
+// compute units of the current device (256 on MI355X); persistent kernels size their grids with it
+inline int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 // XCD-aware work mapping (MI355X: 8 XCDs, private L2s; workgroup b runs on XCD b % 8).
 // A 1-D grid of n_groups_padded * per_group workgroups is remapped so that all `per_group`
 // workgroups of a group (an image, a descriptor pair) run on ONE XCD and share its L2:

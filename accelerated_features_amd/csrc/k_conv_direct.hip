@@ -149,10 +149,23 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
 
     // ---- stage 0: gray tile, instance-normalised on the way in (zero padding stays zero) -------
     const float alpha = coef[2 * b], beta = coef[2 * b + 1];
-    for (int e = tid; e < G_SZ; e += 512) {
-        const int r = e / GW, c = e - r * GW;
-        const int gy = 4 * Y4 - 6 + r, gx = 4 * X4 - 6 + c;
-        G[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? fmaf(gb[(size_t)gy * W + gx], alpha, beta) : 0.f;
+    {   // all six loads of a thread in flight together (as a rolled loop hipcc waits for each one: six exposed round trips per tile)
+        constexpr int NL = (G_SZ + 511) / 512;
+        float raw[NL];
+        bool in[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int e = tid + k * 512;
+            const int r = e / GW, c = e - r * GW;
+            const int gy = 4 * Y4 - 6 + r, gx = 4 * X4 - 6 + c;
+            in[k] = e < G_SZ && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            raw[k] = in[k] ? gb[(size_t)gy * W + gx] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int e = tid + k * 512;
+            if (e < G_SZ) G[e] = in[k] ? fmaf(raw[k], alpha, beta) : 0.f;
+        }
     }
     __syncthreads();
 
@@ -282,6 +295,16 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     }
 }
 
+// Measured on MI355X, B = 64 VGA (round 2, tools/bench_src/pk_fma_chain.hip + in-kernel s_memtime stamps):
+//   * v_pk_fma_f32 (broadcast A, SGPR-pair B, the form hipcc emits here) issues at the full packed rate (115-123 TFLOP/s chip-wide
+//     at 8 or 16 waves per CU); two v_fma_f32 doing the same work run at 70: everything below must stay SLP-packable.
+//   * this kernel: 292 us = 48 TFLOP/s.  With the weight loads AND the LDS reads made loop-invariant (hoisted) it still takes
+//     258 us: neither scalar-cache latency nor LDS conflicts bound it.  A persistent variant (next tile's gray prefetched into
+//     registers, column-parity de-interleaved c1/c3 tiles = no bank conflicts, two columns per thread in conv1) measured 343 us
+//     with bit-identical results and was dropped: per tile 1.1 k cycles stage 0, 8.6 k conv1, 6.1 k conv2, 9.9 k conv3, 6.2 k conv4,
+//     2.4 k barriers -- the SIMDs issue FMAs ~45 % of the time; the rest is the lock-step stage structure (9 and 11 wave-loads
+//     on 8 waves, two barriers per stage, two workgroups per CU to cover each other).  Unrolling the channel loops made it slower
+//     (x2: +4 %, x8: +20 %).  What helped: issuing the six gray loads of a thread together (311 -> 292 us).
 void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st) {
     const ConvW& c0 = nw.conv[L_BLOCK1_0];
     const ConvW& c1 = nw.conv[L_BLOCK1_1];

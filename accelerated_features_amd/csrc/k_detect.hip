@@ -199,9 +199,10 @@ __device__ inline unsigned long long score_key(const ScoreSrc& s, int b, int cap
 //      sampling of xfeat.py:77-80 is fused here) and sorts them in LDS -> the key array of an image is a sequence of
 //      sorted runs.  ~4 workgroups per VGA image instead of one.
 //   2. topk_rank_merge_kernel: the final position of a key is its rank = its position in its own run + the number of
-//      smaller keys in every other run (binary searches; all runs of the image sit in LDS when they fit, n <= 16384,
-//      otherwise they are searched in global memory).  A key with rank < k is written straight to slot `rank` of the
-//      outputs: no radix select, no global merge passes, any n and any top_k.
+//      smaller keys in every other run (binary searches; the first 4 runs of the image -- n <= 8192 -- sit in LDS, later
+//      runs are searched in global memory).  A key with rank < k is written straight to slot `rank` of the outputs: no
+//      radix select, no global merge passes, any n and any top_k.  Both kernels launch 5 workgroups per image that stride
+//      over the runs (a grid sized for the worst case n = H*W/8 costs more in empty 1024-thread workgroups than the work).
 // ------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------
 // Ascending bitonic sort of n (power of two) 64-bit keys in LDS by a 1024-thread workgroup.  Every wave owns aligned
@@ -282,16 +283,9 @@ __device__ inline void bitonic_sort_lds(unsigned long long* lk, int n) {
     }
 }
 
-struct TopkOut {            // sparse-path epilogue (all NULL for the plain top-k)
-    const unsigned* cand;   // (B,cap)
-    float* kpts;            // (B,top_k,2)
-    float* scores;          // (B,top_k)
-    int32_t* n_valid;       // (B)
-    float rw, rh;
-};
-
 constexpr int TK_CH = 2048;          // keys per sorted run
-constexpr int TK_LDS_RUNS = 8;       // runs of one image kept in LDS by the rank kernel (128 KB)
+constexpr int TK_LDS_RUNS = 4;       // runs of one image kept in LDS by the rank kernel (64 KB: two workgroups per CU); later runs are searched in global memory
+constexpr int TK_WG_PER_IMAGE = 5;   // workgroups launched per image; each walks runs q, q + 5, ... (n <= 10240 is one run each)
 
 // MODE 0: keys = score keys of the NMS candidates (ScoreSrc); MODE 1: keys = (~ord(vals[i]) << 32 | i)
 template <int MODE>
@@ -300,34 +294,36 @@ __global__ __launch_bounds__(1024) void topk_sort_runs_kernel(ScoreSrc src, cons
                                                               unsigned long long* __restrict__ runs, int* __restrict__ nsel,
                                                               int32_t* __restrict__ n_valid) {
     __shared__ __attribute__((aligned(16))) unsigned long long lk[TK_CH];
-    int b, q;
-    if (!xcd_group_map(blockIdx.x, qmax, B, b, q)) return;
+    int b, q0;
+    if (!xcd_group_map(blockIdx.x, qmax, B, b, q0)) return;
     const int tid = threadIdx.x;
     const int n = n_dev ? min(n_dev[b], n_cap) : n_const;
-    if (q == 0 && tid == 0) {
+    if (q0 == 0 && tid == 0) {
         nsel[b] = min(top_k, n);
         if (n_valid) n_valid[b] = 0;
     }
-    const int base = q * TK_CH;
-    if (base >= n) return;
-    const int csz = min(TK_CH, n - base);
+    for (int q = q0; q * TK_CH < n; q += qmax) {
+        const int base = q * TK_CH;
+        const int csz = min(TK_CH, n - base);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int j = tid + e * 1024, i = base + j;
-        unsigned long long key = ~0ull;
-        if (j < csz) {
-            if constexpr (MODE == 0) key = score_key(src, b, n_cap, i);
-            else key = ((unsigned long long)(~float_ord(vals[(size_t)b * n_cap + i])) << 32) | (unsigned)i;
+        for (int e = 0; e < 2; ++e) {
+            const int j = tid + e * 1024, i = base + j;
+            unsigned long long key = ~0ull;
+            if (j < csz) {
+                if constexpr (MODE == 0) key = score_key(src, b, n_cap, i);
+                else key = ((unsigned long long)(~float_ord(vals[(size_t)b * n_cap + i])) << 32) | (unsigned)i;
+            }
+            lk[j] = key;
         }
-        lk[j] = key;
+        __syncthreads();
+        // short runs sort a smaller power of two (the padding keys ~0 sort last and are not written back)
+        int npad = 256;
+        while (npad < csz) npad <<= 1;
+        bitonic_sort_lds(lk, npad);
+        unsigned long long* out = runs + (size_t)b * n_cap + base;
+        for (int j = tid; j < csz; j += 1024) out[j] = lk[j];
+        __syncthreads();
     }
-    __syncthreads();
-    // short runs sort a smaller power of two (the padding keys ~0 sort last and are not written back)
-    int npad = 256;
-    while (npad < csz) npad <<= 1;
-    bitonic_sort_lds(lk, npad);
-    unsigned long long* out = runs + (size_t)b * n_cap + base;
-    for (int j = tid; j < csz; j += 1024) out[j] = lk[j];
 }
 
 // number of keys < x in the ascending run a[0..len), len <= TK_CH
@@ -341,78 +337,63 @@ __device__ inline int run_lower_bound(const unsigned long long* a, int len, unsi
     return pos;
 }
 
+// Workgroup (image, q0) ranks the keys of runs q0, q0 + nq, ... and writes each key with rank < k to slot `rank` of the sorted
+// key list `skeys` (ONE 8-byte scattered store per key; a first version scattered sel / kpts / scores rows from here and spent
+// 13 of its 25 us on those partial-line writes -- the consumers, which walk the list in rank order, now derive them).
 __global__ __launch_bounds__(1024) void topk_rank_merge_kernel(const unsigned long long* __restrict__ runs, const int32_t* __restrict__ n_dev,
-                                                               int n_const, int n_cap, int top_k, int qmax, int B, int lds_runs,
-                                                               unsigned* __restrict__ sel, TopkOut o) {
+                                                               int n_const, int n_cap, int top_k, int nq, int B, int lds_runs,
+                                                               unsigned long long* __restrict__ skeys) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lr[];
-    int b, q;
-    if (!xcd_group_map(blockIdx.x, qmax, B, b, q)) return;
-    const int tid = threadIdx.x, lane = tid & 63;
+    int b, q0;
+    if (!xcd_group_map(blockIdx.x, nq, B, b, q0)) return;
+    const int tid = threadIdx.x;
     const int n = n_dev ? min(n_dev[b], n_cap) : n_const;
     const int k = min(top_k, n);
-    if (q == 0) {                                        // fixed-capacity outputs: entries past k are zero
-        for (int j = k + tid; j < top_k; j += 1024) {
-            sel[(size_t)b * top_k + j] = 0;
-            if (o.kpts) {
-                o.kpts[((size_t)b * top_k + j) * 2 + 0] = 0.f;
-                o.kpts[((size_t)b * top_k + j) * 2 + 1] = 0.f;
-                o.scores[(size_t)b * top_k + j] = 0.f;
-            }
-        }
-    }
-    const int base = q * TK_CH;
-    if (base >= n) return;
+    if (q0 * TK_CH >= n) return;
     const int nruns = ceil_div(n, TK_CH);
     const unsigned long long* gr = runs + (size_t)b * n_cap;
-    const bool in_lds = nruns <= lds_runs;
-    if (in_lds) {
-        for (int i = tid; i < n; i += 1024) lr[i] = gr[i];
-        __syncthreads();
-    }
-    int nv = 0;
+    const int nl = min(n, lds_runs * TK_CH);              // keys [0, nl) = the first lds_runs runs live in LDS
+    {
+        unsigned long long t[8];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int j = tid + e * 1024, i = base + j;
-        if (i < n) {
-            const unsigned long long key = in_lds ? lr[i] : gr[i];
-            int rank = j;
-            for (int r = 0; r < nruns; ++r) {
-                if (r == q) continue;
-                const int len = min(TK_CH, n - r * TK_CH);
-                rank += in_lds ? run_lower_bound(lr + r * TK_CH, len, key) : run_lower_bound(gr + r * TK_CH, len, key);
-            }
-            if (rank < k) {
-                const unsigned slot = (unsigned)(key & 0xffffffffu);
-                sel[(size_t)b * top_k + rank] = slot;
-                if (o.kpts) {
-                    const float score = ord_float(~(unsigned)(key >> 32));
-                    const unsigned c = o.cand[(size_t)b * n_cap + slot];
-                    o.kpts[((size_t)b * top_k + rank) * 2 + 0] = (float)(c & 0xffff) * o.rw;
-                    o.kpts[((size_t)b * top_k + rank) * 2 + 1] = (float)(c >> 16) * o.rh;
-                    o.scores[(size_t)b * top_k + rank] = score;
-                    if (score > 0.f) ++nv;
+        for (int u = 0; u < 8; ++u) { const int i = tid + u * 1024; t[u] = i < nl ? gr[i] : 0ull; }       // independent loads in flight
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = tid + u * 1024; if (i < nl) lr[i] = t[u]; }
+        for (int i = tid + 8192; i < nl; i += 1024) lr[i] = gr[i];
+    }
+    __syncthreads();
+    for (int q = q0; q * TK_CH < n; q += nq) {
+        const int base = q * TK_CH;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = tid + e * 1024, i = base + j;
+            if (i < n && j < k) {                          // rank >= position in the own run
+                const unsigned long long key = i < nl ? lr[i] : gr[i];
+                int rank = j;
+                for (int r = 0; r < nruns && rank < k; ++r) {
+                    if (r == q) continue;
+                    const int len = min(TK_CH, n - r * TK_CH);
+                    rank += r < lds_runs ? run_lower_bound(lr + r * TK_CH, len, key) : run_lower_bound(gr + r * TK_CH, len, key);
                 }
+                if (rank < k) skeys[(size_t)b * top_k + rank] = key;
             }
         }
-    }
-    if (o.kpts) {
-        nv = wave_sum_i(nv);
-        if (lane == 0 && nv) atomicAdd(&o.n_valid[b], nv);
     }
 }
 
 // keys/runs: (B, n_cap) u64 scratch.  Either `src` (sparse path) or `vals` (B, n_cap floats) feeds the keys.
+// Result: skeys (B, top_k) ascending keys (entries [nsel[b], top_k) are left untouched), nsel (B) = min(top_k, n).
 static void run_topk(const ScoreSrc* src, const float* vals, unsigned long long* runs, const int32_t* n_dev, int n_const, int n_cap,
-                     int top_k, int B, unsigned* sel, int* nsel, const TopkOut& o, hipStream_t st) {
-    const int qmax = ceil_div(n_cap, TK_CH);
+                     int top_k, int B, unsigned long long* skeys, int* nsel, int32_t* n_valid, hipStream_t st) {
+    const int qmax = min(ceil_div(n_cap, TK_CH), TK_WG_PER_IMAGE);          // workgroups per image (each strides over the runs)
     if (src)
-        topk_sort_runs_kernel<0><<<xcd_grid_size(qmax, B), 1024, 0, st>>>(*src, nullptr, n_dev, n_const, n_cap, top_k, qmax, B, runs, nsel, o.n_valid);
+        topk_sort_runs_kernel<0><<<xcd_grid_size(qmax, B), 1024, 0, st>>>(*src, nullptr, n_dev, n_const, n_cap, top_k, qmax, B, runs, nsel, n_valid);
     else
-        topk_sort_runs_kernel<1><<<xcd_grid_size(qmax, B), 1024, 0, st>>>(ScoreSrc{}, vals, n_dev, n_const, n_cap, top_k, qmax, B, runs, nsel, nullptr);
-    const int lds_runs = min(qmax, TK_LDS_RUNS);
+        topk_sort_runs_kernel<1><<<xcd_grid_size(qmax, B), 1024, 0, st>>>(ScoreSrc{}, vals, n_dev, n_const, n_cap, top_k, qmax, B, runs, nsel, n_valid);
+    const int lds_runs = min(ceil_div(n_cap, TK_CH), TK_LDS_RUNS);
     static unsigned attr_mask = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(topk_rank_merge_kernel), TK_LDS_RUNS * TK_CH * 8, attr_mask);
-    topk_rank_merge_kernel<<<xcd_grid_size(qmax, B), 1024, (size_t)lds_runs * TK_CH * 8, st>>>(runs, n_dev, n_const, n_cap, top_k, qmax, B, lds_runs, sel, o);
+    topk_rank_merge_kernel<<<xcd_grid_size(qmax, B), 1024, (size_t)lds_runs * TK_CH * 8, st>>>(runs, n_dev, n_const, n_cap, top_k, qmax, B, lds_runs, skeys);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -449,19 +430,40 @@ __device__ inline void cubic_w(float t, float w[4]) {
 // 16 lanes per selected key-point (4 channels each as one float4), 4 key-points per wave:
 //   desc = normalize( bicubic( normalize(M1, dim=1) ) )                   (xfeat.py:70,90-93)
 // The 16 taps are 16 independent 256-B row reads per key-point (1 KiB per wave-instruction).
+// Also the epilogue of the top-k (xfeat.py:83-87,96-103): key-point j of the sorted key list -> kpts (x*rw, y*rh), score, and
+// n_valid = number of returned points with score > 0 (a prefix, the list is sorted).
 __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict__ feats, const float* __restrict__ inv,
-                                                         const unsigned* __restrict__ cand, const unsigned* __restrict__ sel,
+                                                         const unsigned* __restrict__ cand, const unsigned long long* __restrict__ skeys,
                                                          const int* __restrict__ nsel, int H, int W, int cap, int top_k,
-                                                         int B, int blocks_per_img, float* __restrict__ desc) {
+                                                         int B, int blocks_per_img, float rw, float rh, float* __restrict__ kpts,
+                                                         float* __restrict__ scores, int32_t* __restrict__ n_valid, float* __restrict__ desc) {
     const int sub = threadIdx.x & 15;
     int b, blk;                       // all key-points of an image on one XCD: its feats stay in that L2
     if (!xcd_group_map(blockIdx.x, blocks_per_img, B, b, blk)) return;
     const int j = blk * 16 + (threadIdx.x >> 4);
     if (j >= top_k) return;
     float4* dp = reinterpret_cast<float4*>(desc + ((size_t)b * top_k + j) * 64) + sub;
-    if (j >= nsel[b]) { *dp = make_float4(0.f, 0.f, 0.f, 0.f); return; }
-    const unsigned c = cand[(size_t)b * cap + sel[(size_t)b * top_k + j]];
+    const int k = nsel[b];
+    if (j >= k) {                     // fixed-capacity outputs: rows past the list are zero
+        *dp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sub == 0) {
+            *reinterpret_cast<float2*>(kpts + ((size_t)b * top_k + j) * 2) = make_float2(0.f, 0.f);
+            scores[(size_t)b * top_k + j] = 0.f;
+        }
+        return;
+    }
+    const unsigned long long key = skeys[(size_t)b * top_k + j];
+    const unsigned c = cand[(size_t)b * cap + (unsigned)(key & 0xffffffffu)];
     const int x = c & 0xffff, y = c >> 16;
+    if (sub == 0) {
+        const float score = ord_float(~(unsigned)(key >> 32));
+        *reinterpret_cast<float2*>(kpts + ((size_t)b * top_k + j) * 2) = make_float2((float)x * rw, (float)y * rh);
+        scores[(size_t)b * top_k + j] = score;
+        if (score > 0.f) {            // the last positive score ends the valid prefix (n_valid was zeroed by the sort kernel)
+            const bool last = (j + 1 >= k) || !(ord_float(~(unsigned)(skeys[(size_t)b * top_k + j + 1] >> 32)) > 0.f);
+            if (last) n_valid[b] = j + 1;
+        }
+    }
     const int hc = H >> 3, wc = W >> 3;
     const float ux = sample_coord(x, W, wc), uy = sample_coord(y, H, hc);
     const float fx = floorf(ux), fy = floorf(uy);
@@ -510,12 +512,11 @@ void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, c
     const int hc = H / 8, wc = W / 8;
     nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
-    TopkOut o{ws.cand, kpts, scores, n_valid, rw, rh};
     const ScoreSrc src{heat, reliab, ws.cand, H, W};
-    run_topk(&src, nullptr, ws.keys, n_cand, 0, cap, top_k, B, ws.sel, ws.nsel, o, st);
+    run_topk(&src, nullptr, ws.keys, n_cand, 0, cap, top_k, B, ws.skeys, ws.nsel, n_valid, st);
     invnorm_kernel<<<ceil_div(B * hc * wc * 16, 256), 256, 0, st>>>(feats, B * hc * wc, ws.invnorm);
-    descriptor_kernel<<<xcd_grid_size(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.sel, ws.nsel, H, W,
-                                                                            cap, top_k, B, ceil_div(top_k, 16), desc);
+    descriptor_kernel<<<xcd_grid_size(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.skeys, ws.nsel, H, W,
+                                                                            cap, top_k, B, ceil_div(top_k, 16), rw, rh, kpts, scores, n_valid, desc);
 }
 
 // stand-alone NMS (XFeat.NMS): flags + compaction + int64 (x,y) list, zero padded
@@ -546,21 +547,20 @@ void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W,
 // ------------------------------------------------------------------------------------------
 // plain top-k (descending values, ties: lower index first) for extractDense (xfeat.py:371)
 // ------------------------------------------------------------------------------------------
-void launch_topk_desc(const float* vals, int B, int n, int k, unsigned long long* keys, unsigned* sel, int* nsel,
+void launch_topk_desc(const float* vals, int B, int n, int k, unsigned long long* keys, unsigned long long* skeys, int* nsel,
                       hipStream_t st) {
-    TopkOut o{nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
-    run_topk(nullptr, vals, keys, nullptr, n, n, k, B, sel, nsel, o, st);
+    run_topk(nullptr, vals, keys, nullptr, n, n, k, B, skeys, nsel, nullptr, st);
 }
 
 // wave per selected cell: raw features + corner coordinates                (xfeat.py:366-375,388)
-__global__ __launch_bounds__(256) void dense_gather_kernel(const float* __restrict__ feats, const unsigned* __restrict__ sel,
+__global__ __launch_bounds__(256) void dense_gather_kernel(const float* __restrict__ feats, const unsigned long long* __restrict__ skeys,
                                                            int hc, int wc, int k, float rw, float rh, float scale_div,
                                                            float* __restrict__ kpts, float* __restrict__ desc,
                                                            int32_t* __restrict__ cell_index) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
     if (j >= k) return;
-    const unsigned cell = sel[(size_t)b * k + j];
+    const unsigned cell = (unsigned)(skeys[(size_t)b * k + j] & 0xffffffffu);
     desc[((size_t)b * k + j) * 64 + lane] = feats[((size_t)b * hc * wc + cell) * 64 + lane];
     if (lane == 0) {
         const int ci = cell / wc, cj = cell - ci * wc;
@@ -570,9 +570,9 @@ __global__ __launch_bounds__(256) void dense_gather_kernel(const float* __restri
     }
 }
 
-void launch_dense_gather(const float* feats, const unsigned* sel, int B, int hc, int wc, int k, float rw, float rh,
+void launch_dense_gather(const float* feats, const unsigned long long* skeys, int B, int hc, int wc, int k, float rw, float rh,
                          float scale_div, float* kpts, float* desc, int32_t* cell_index, hipStream_t st) {
-    dense_gather_kernel<<<dim3(ceil_div(k, 4), B), 256, 0, st>>>(feats, sel, hc, wc, k, rw, rh, scale_div, kpts, desc,
+    dense_gather_kernel<<<dim3(ceil_div(k, 4), B), 256, 0, st>>>(feats, skeys, hc, wc, k, rw, rh, scale_div, kpts, desc,
                                                                  cell_index);
 }
 

@@ -223,16 +223,6 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
     }
 }
 
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
 
 void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st) {
     HeadArgs a{};

@@ -102,7 +102,7 @@ struct DetectWs {          // carved from the caller's workspace by api.hip
     int* wcount;                // (B, H*WPR)  popcounts
     unsigned* cand;             // (B, cap)    (y<<16)|x in row-major order
     unsigned long long* keys;   // (B, cap)    sort keys
-    unsigned* sel;              // (B, top_k)  sorted candidate slots
+    unsigned long long* skeys;  // (B, top_k)  sorted keys (~ord(score) << 32 | candidate slot)
     int* nsel;                  // (B)         min(n_candidates, cap, top_k)
     float* invnorm;             // (B, hc*wc)  1/max(||feats||,1e-12)
 };
@@ -115,10 +115,10 @@ void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W,
 void launch_sample_sparse(const float* x, const float* pos, int B, int C, int Hm, int Wm, int N, int H, int W, int mode, float* out,
                           hipStream_t st);
 // top-k of a (B,n) float array, descending (ties: lower index first).  keys scratch (B,n) u64,
-// sel (B,k) u32 receives the indices.
-void launch_topk_desc(const float* vals, int B, int n, int k, unsigned long long* keys, unsigned* sel, int* nsel,
+// skeys (B,k) u64 receives the sorted keys (index = low 32 bits).
+void launch_topk_desc(const float* vals, int B, int n, int k, unsigned long long* keys, unsigned long long* skeys, int* nsel,
                       hipStream_t st);
-void launch_dense_gather(const float* feats, const unsigned* sel, int B, int hc, int wc, int k, float rw, float rh,
+void launch_dense_gather(const float* feats, const unsigned long long* skeys, int B, int hc, int wc, int k, float rw, float rh,
                          float scale_div, float* kpts, float* desc, int32_t* cell_index, hipStream_t st);
 
 // ---- k_match.hip ------------------------------------------------------------------------

@@ -663,7 +663,7 @@ def test_interpolator_attribute_is_the_reference_module(xf, sd):
             got = mod(m.cuda(), pos.cuda(), H, W).cpu()                     # int64 positions, as detectAndCompute passes them
             assert got.shape == (2, 300, C_)
             for b in range(2):
-                parity.assert_close(got[b], fn(m[b], pos[b], H, W), 2e-6, f"{mode} vs oracle")
+                parity.assert_close(got[b], fn(m[b], pos[b], H, W), 5e-6, f"{mode} vs oracle")
             grid = (2. * (pos / torch.tensor([W - 1, H - 1])) - 1.).unsqueeze(-2)
             ref = torch.nn.functional.grid_sample(m, grid, mode=mode, align_corners=False).permute(0, 2, 3, 1).squeeze(-2)
             parity.assert_close(got, ref, 1e-5, f"{mode} vs grid_sample")

@@ -107,7 +107,7 @@ def test_workspace_planning_is_host_only(lib):
     assert a > 60 * b > 0 and a % 256 == 0
     assert lib.xfh_backbone_workspace_bytes(0, 3, 480, 640) == 0
     assert lib.xfh_detect_workspace_bytes(64, 480, 640, 4096, 38400) > 64 * 38400 * 12
-    assert lib.xfh_match_workspace_bytes(32, 4096, 4096) >= 32 * 16 * 4096 * 8
+    assert lib.xfh_match_workspace_bytes(32, 4096, 4096) >= 32 * 4096 * (8 + 4 + 4)     # column keys + row arg-max + row max
     assert lib.xfh_refine_workspace_bytes(2, 511) > 2 * 511 * 512 * 4 * 2
     assert lib.xfh_dense_workspace_bytes(2, 20, 24, 100) > 0
 
