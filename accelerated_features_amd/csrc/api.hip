@@ -194,9 +194,21 @@ static size_t carve_dense(void* ws, int B, int hc, int wc, int k, DenseWs& o) {
 
 static size_t carve_match(void* ws, int P, int N1, int N2, MatchWs& o) {
     Carver c(ws);
-    o.match12 = c.take<int>((size_t)P * N1);
-    o.rowmax = c.take<float>((size_t)P * N1);
-    o.colbest = c.take<unsigned long long>((size_t)P * N2);
+    const size_t z0 = c.off;
+    o.rowkey = c.take<unsigned long long>((size_t)P * N1);
+    o.colkey = c.take<unsigned long long>((size_t)P * N2);
+    o.colmaxh = c.take<unsigned>((size_t)P * N2);
+    o.nmax = c.take<unsigned>((size_t)2 * P);
+    o.cnt = c.take<int>(P);
+    o.zeroed = ws ? (char*)ws + z0 : nullptr;
+    o.zeroed_bytes = c.off - z0;
+    o.a16 = c.take<unsigned short>((size_t)P * N1 * 64);
+    o.b16 = c.take<unsigned short>((size_t)P * N2 * 64);
+    o.na = c.take<float>((size_t)P * N1);
+    o.nb = c.take<float>((size_t)P * N2);
+    o.rowmaxh = c.take<float>((size_t)P * N1);
+    o.cand_cap = 4 * (N1 + N2);                        // ~1.3 candidates per row and per column are typical
+    o.cand = c.take<unsigned long long>((size_t)P * o.cand_cap);
     return align_up(c.off, 256);
 }
 

@@ -123,9 +123,19 @@ void launch_dense_gather(const float* feats, const unsigned long long* skeys, in
 
 // ---- k_match.hip ------------------------------------------------------------------------
 struct MatchWs {
-    int* match12;                  // (P,N1)
-    float* rowmax;                 // (P,N1)
-    unsigned long long* colbest;   // (P, N2) packed (ord(sim)<<32 | ~row): column arg-max, folded by 64-bit atomic max
+    // zero-initialised per call (one memset): [rowkey | colkey | colmaxh | nmax | cnt]
+    void* zeroed; size_t zeroed_bytes;
+    unsigned long long* rowkey;    // (P,N1) packed (ord(sim)<<32 | ~col): row arg-max
+    unsigned long long* colkey;    // (P,N2) packed (ord(sim)<<32 | ~row): column arg-max, folded by 64-bit atomic max
+    unsigned* colmaxh;             // (P,N2) ord(column maximum of the bf16 product)
+    unsigned* nmax;                // (2,P)  bit patterns of max |d1_i|, max |d2_j|
+    int* cnt;                      // (P)    candidates found (may exceed cand_cap: overflow)
+    // filter-and-refine scratch
+    unsigned short *a16, *b16;     // (P,N1,64), (P,N2,64) bf16 copies
+    float *na, *nb;                // (P,N1), (P,N2) fp32 norms
+    float* rowmaxh;                // (P,N1) row maximum of the bf16 product
+    unsigned long long* cand;      // (P,cand_cap) (row << 32 | col)
+    int cand_cap;
 };
 void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim,

@@ -731,3 +731,48 @@ def test_hipgraph_survives_workspace_growth_and_weight_reload_of_the_user_model(
         n = again['n_valid'][b]
         assert torch.equal(again['keypoints'][b, :n], e[b]['keypoints']) and torch.equal(again['descriptors'][b, :n], e[b]['descriptors'])
     del junk
+
+
+def test_match_filter_and_refine_equals_exact_kernel(xf):
+    """xfh_match_mnn's shipped path (bf16 MFMA filter with a rigorous error window + exact fp32 refine, k_match_bf16.hip) against the
+    exact f32 MFMA kernel (XFH_MATCH=f32) on identical inputs: identical index lists -- unit descriptors, raw dense features of
+    magnitude ~10, ragged sizes, exact duplicate rows / columns (ties -> lowest index), a similarity cut, and degenerate inputs
+    (all-equal / all-zero descriptors) that overflow the candidate list and take the in-kernel fallback."""
+    g = torch.Generator().manual_seed(12)
+
+    def both(d1, d2, mc):
+        os.environ.pop("XFH_MATCH", None)
+        a = xf.match(d1.cuda(), d2.cuda(), min_cossim=mc)
+        os.environ["XFH_MATCH"] = "f32"
+        try:
+            b = xf.match(d1.cuda(), d2.cuda(), min_cossim=mc)
+        finally:
+            os.environ.pop("XFH_MATCH", None)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (d1.shape, d2.shape, mc, len(a[0]), len(b[0]))
+        return a
+
+    for n1, n2 in ((4096, 4096), (1000, 31), (33, 257), (1, 1), (2500, 4000), (5000, 300)):
+        d1 = torch.nn.functional.normalize(torch.randn(n1, 64, generator=g), dim=-1)
+        d2 = torch.nn.functional.normalize(torch.randn(n2, 64, generator=g), dim=-1)
+        m = min(n1, n2) // 2
+        d2[:m] = torch.nn.functional.normalize(d1[:m] + 0.2 * torch.randn(m, 64, generator=g), dim=-1)     # genuine matches
+        if n1 >= 300 and n2 >= 300:
+            d2[7] = d1[5]; d2[8] = d1[5]; d1[100] = d1[101]
+        for mc in (-1, 0.5):
+            i0, _ = both(d1, d2, mc)
+        assert len(i0) >= m // 4 or n1 < 50
+        both(d1 * 11.0, d2 * 7.0 + 0.3, -1)                                   # raw (un-normalised, shifted) features
+    # degenerate: every descriptor identical -> all n2 columns tie in every row (candidate overflow -> exact kernel inside the call)
+    same = torch.nn.functional.normalize(torch.ones(600, 64), dim=-1)
+    i0, i1 = both(same, same.clone(), -1)
+    assert i0.tolist() == [0] and i1.tolist() == [0]
+    z = torch.zeros(300, 64)
+    both(z, torch.randn(200, 64, generator=g), -1)
+    # batched, device-side counts (the bench path), against per-pair calls
+    d = torch.nn.functional.normalize(torch.randn(16, 700, 64, generator=g), dim=-1).cuda()
+    nv = torch.tensor([700, 650, 1, 700, 0, 700, 333, 700] * 2, dtype=torch.int32, device="cuda")
+    i0, i1, nm = xf.match_pairs_device(d, nv, -1)
+    for p in range(8):
+        a, b = int(nv[2 * p]), int(nv[2 * p + 1])
+        s0, s1 = xf.match(d[2 * p, :a], d[2 * p + 1, :b], min_cossim=-1)
+        assert int(nm[p]) == len(s0) and torch.equal(i0[p, :len(s0)], s0) and torch.equal(i1[p, :len(s0)], s1), p
