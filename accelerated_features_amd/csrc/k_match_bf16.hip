@@ -168,21 +168,28 @@ __global__ __launch_bounds__(512) void mnn_bf16_kernel(const unsigned short* __r
                 cm = fmaxf(cm, xhalf(cm));
                 if (half == 0) colx[wave][ct * 32 + l31] = cm;
             } else {
+                // hit masks straight out of the compares (v_cmp -> SGPR pair, OR-ed on the scalar unit): two VALU ops per element
                 const float cthr = colx[0][ct * 32 + l31];
-                unsigned hit = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hit |= (acc[r] >= fminf(bv[r], cthr)) ? (1u << r) : 0u;
                 const int col = cbase + l31;
-                if (col >= n2) hit = 0;                      // padding columns are copies: not candidates
-                if (__ballot(hit != 0)) {
-                    while (hit) {
-                        const int r = __builtin_ctz(hit);
-                        hit &= hit - 1;
-                        const int row = wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (row < n1) {
-                            const int idx = atomicAdd(&lcnt, 1);
-                            if (idx < LCAND) lcand[idx] = ((unsigned long long)(unsigned)row << 32) | (unsigned)col;
-                        }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {             // rows in groups of four: ~0.6 candidates per tile, most groups skip on a scalar branch
+                    unsigned long long mk[4], any = 0ull;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 4 * g4 + q;
+                        mk[q] = __ballot(acc[r] >= bv[r]) | __ballot(acc[r] >= cthr);
+                        any |= mk[q];
+                    }
+                    if (any) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (((mk[q] >> lane) & 1ull) && col < n2) {           // padding columns are copies: not candidates
+                                const int row = wrow0 + q + 8 * g4 + 4 * half;    // (r&3) + 8*(r>>2) + 4*half with r = 4*g4 + q
+                                if (row < n1) {
+                                    const int idx = atomicAdd(&lcnt, 1);
+                                    if (idx < LCAND) lcand[idx] = ((unsigned long long)(unsigned)row << 32) | (unsigned)col;
+                                }
+                            }
                     }
                 }
             }
