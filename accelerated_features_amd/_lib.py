@@ -14,7 +14,7 @@ XFH_OK = 0
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 LG_NO_PRUNING = 1 << 30
 SAMPLE_MODES = {'nearest': 0, 'bilinear': 1, 'bicubic': 2}
-PROF_NONE, PROF_CONV_MFMA, PROF_MATCH, PROF_BLOCK1, PROF_HEADS, PROF_CONV_64_64_S1, PROF_CONV_LAYER0 = 0, 1, 2, 3, 4, 5, 100
+PROF_NONE, PROF_CONV_MFMA, PROF_MATCH, PROF_BLOCK1, PROF_HEADS, PROF_CONV_64_64_S1, PROF_CONV_24_24, PROF_CONV_LAYER0 = 0, 1, 2, 3, 4, 5, 6, 100
 
 # name -> (restype, argtypes); mirrors include/xfeat_hip.h one to one
 _p = C.c_void_p

@@ -409,6 +409,7 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     // which >= 100 selects one layer (100 + layer index), otherwise the whole family
     int pid = h->prof.which >= 100 ? 100 + layer : XFH_PROF_CONV_MFMA;
     if (h->prof.which == XFH_PROF_CONV_64_64_S1 && c.cin == 64 && c.cout == 64 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_64_64_S1;
+    if (h->prof.which == XFH_PROF_CONV_24_24 && c.cin == 24 && c.cout == 24 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_24_24;
     prof_begin(&h->prof, pid, st);
     // 3x3/s1 layers with >= 24 channels: Winograd F(2x2,3x3) (k_conv_wino.hip), including the 3x3 + fused 1x1 pairs.
     // A/B runs: XFH_WINO=0 forces the direct kernel, XFH_WINO=1 keeps the fused pairs on the direct kernel.
@@ -450,7 +451,8 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     else launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
     launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st);
-    prof_end(&h->prof, XFH_PROF_BLOCK1, st, 0, 0);
+    // block1 + skip1 per input pixel: conv1 9*4*2 + conv2 36*8*2/4 + conv3 72*8*2/4 + conv4 72*24*2/16 = 720 FLOP; gray in, x1 out: 10 bytes
+    prof_end(&h->prof, XFH_PROF_BLOCK1, st, 720.0 * B * H * W, 10.0 * B * H * W);
 #define CONV(layer, fused, in, hin, win, out, nhwc) \
     if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st))) return rc
     CONV(L_BLOCK2_0, -1, w.x1, H4, W4, w.x2a, false);

@@ -14,9 +14,10 @@ per-image counts that the ragged results need.  Multi-GPU: every rank is a repli
 own batch (weak scaling, no data-path collective; RCCL only for the barrier / max-time).
 
 Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s.
-`roofline` is measured live with HIP events around the dominant kernel (mnn_sim_kernel, the
-f32-MFMA similarity GEMM with fused arg-max -- the largest single entry of the rocprofv3
-kernel stats) inside the timed region; the MFMA convolution family is reported next to it;
+`roofline` is measured live with HIP events around the dominant kernel (the largest single
+entry of the rocprofv3 kernel stats: conv_wino_kernel<24,24>, the two 24->24 Winograd
+convolutions of block2) inside the timed region; the match, block1 and the whole MFMA
+convolution family are reported next to it from short untimed passes of the same step;
 `cpu_baseline` times the CPU oracle (a port of the reference's CPU path) on the host cores
 for a bounded sample.
 """
@@ -154,7 +155,7 @@ def load_pmc_traffic():
     if os.path.exists(p):
         try:
             d = json.load(open(p))
-            return d.get("mnn_sim_kernel_hbm_bytes_per_launch"), f"profiles/pmc_traffic.json ({d.get('collected', 'rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes')}); not re-measured in this run"
+            return d.get("dominant_kernel_hbm_bytes_per_launch"), f"profiles/pmc_traffic.json ({d.get('collected', 'rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes')}); not re-measured in this run"
         except Exception:
             return None, None
     return None, None
@@ -364,19 +365,28 @@ def main():
 
     def arm(last):
         assert int(last[0][B:2 * B].max()) <= last[1], "NMS capacity overflow in the benchmark workload"
-        lib.xfh_profile_select(handle, _lib.PROF_MATCH)
+        lib.xfh_profile_select(handle, _lib.PROF_CONV_24_24)
 
     dt_max, (counts, cap) = sharding.timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
-    n_l, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
-    lib.xfh_profile_read(handle, C.byref(n_l), C.byref(ms), C.byref(fl), C.byref(by))
-    # secondary (untimed) pass: the MFMA convolution family, same events mechanism
-    lib.xfh_profile_select(handle, _lib.PROF_CONV_MFMA)
-    for _ in range(3):
-        step()
-    torch.cuda.synchronize()
-    cn, cms, cfl, cby = C.c_int(), C.c_double(), C.c_double(), C.c_double()
-    lib.xfh_profile_read(handle, C.byref(cn), C.byref(cms), C.byref(cfl), C.byref(cby))
-    lib.xfh_profile_select(handle, _lib.PROF_NONE)
+
+    def read_prof():
+        n_, ms_, fl_, by_ = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        lib.xfh_profile_read(handle, C.byref(n_), C.byref(ms_), C.byref(fl_), C.byref(by_))
+        return n_.value, ms_.value, fl_.value, by_.value
+
+    def side_prof(which, n=3):            # secondary (untimed) pass: same events mechanism on another kernel family
+        lib.xfh_profile_select(handle, which)
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        r = read_prof()
+        lib.xfh_profile_select(handle, _lib.PROF_NONE)
+        return r
+
+    n_l, ms, fl, by = read_prof()
+    m_n, m_ms, m_fl, m_by = side_prof(_lib.PROF_MATCH)
+    b_n, b_ms, b_fl, b_by = side_prof(_lib.PROF_BLOCK1)
+    cn, cms, cfl, cby = side_prof(_lib.PROF_CONV_MFMA)
 
     # SURVEY 8(d) side figures, each its own short pass OUTSIDE the timed region above (rank-local, per GPU)
     def rate(fn, n=5):
@@ -410,7 +420,7 @@ def main():
     if rank == 0:
         n_valid = counts[:B].tolist()
         n_match = counts[2 * B:].tolist()
-        achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
         fps = sharding.aggregate_rate(B, args.steps, world, dt_max, "weak")
         fps_gpu = fps / world
         traffic, traffic_src = load_pmc_traffic()
@@ -432,14 +442,25 @@ def main():
                        "batch_per_gpu": B, "height": H, "width": W, "top_k": TOP_K, "weights": "synthetic (tests/fixtures.py)",
                        "parallelism": f"replicas x{world}, no collective",
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
-            "roofline": {"bound": "mfma", "kernel": "mnn_sim_kernel (D1.D2^T on v_mfma_f32_32x32x2_f32 with fused row/column arg-max)",
+            "roofline": {"bound": "mfma", "kernel": "conv_wino_kernel<24,24,...> (block2.0 / block2.1: 3x3 24->24 at 120x160 as Winograd F(2x2,3x3) on "
+                                                    "v_mfma_f32_32x32x2_f32; two launches per step)",
                          "achieved": round(achieved, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
-                         "launches": n_l.value, "avg_launch_us": round(1e3 * ms.value / max(n_l.value, 1), 2),
-                         "flops_per_launch": fl.value / max(n_l.value, 1),
-                         "algorithmic": "2*pairs*N1*N2*64 FLOP per launch (32 pairs x 4096 x 4096)",
+                         "launches": n_l, "avg_launch_us": round(1e3 * ms / max(n_l, 1), 2),
+                         "flops_per_launch": fl / max(n_l, 1),
+                         "algorithmic": "2*B*H/4*W/4*24*24*9 FLOP per launch (direct form; the kernel executes 2.25x fewer multiplies as Winograd, "
+                                        "with Cout padded 24 -> 32 on the 32x32 MFMA tile)",
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_algorithmic": 32 * (2 * 4096 * 64 * 4 + 2 * 4096 * 8 + 4096 * 4)},
+                         "traffic_algorithmic": int(by / max(n_l, 1))},
+            # the former dominant kernel.  xfh_match_mnn = bf16 MFMA filter (rigorous error window) + exact fp32 refine of ~1.3 candidates
+            # per row; identical match lists to the exact f32 MFMA kernel (tests); XFH_MATCH=f32 selects the latter.  "achieved" prices the
+            # ALGORITHMIC fp32 work of D1.D2^T against the f32 MFMA peak: above 1 means the filter beat an exact f32 GEMM at its peak.
+            "roofline_match": {"bound": "mfma", "kernels": "mnn_prep + mnn_bf16_kernel<1> + mnn_bf16_kernel<2> + mnn_exact (+ empty mnn_sim fallback)",
+                               "us_per_step": round(1e3 * m_ms / 3, 1), "algorithmic_f32_tflops": round((m_fl / 1e12) / (m_ms / 1e3), 2) if m_ms > 0 else None,
+                               "executed": "2 x 2*P*N1*N2*64 FLOP on v_mfma_f32_32x32x16_bf16 (two sweeps) + ~1.3 exact fp32 dot products per row and column",
+                               "executed_bf16_tflops": round((2 * m_fl / 1e12) / (m_ms / 1e3), 2) if m_ms > 0 else None, "peak_bf16_tflops": 2500.0},
+            "roofline_block1": {"bound": "valu", "kernel": "block1_fused_kernel (block1 x4 + skip1, LDS-tiled fp32 VALU)", "us_per_step": round(1e3 * b_ms / 3, 1),
+                                "achieved": round((b_fl / 1e12) / (b_ms / 1e3), 2) if b_ms > 0 else None, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s"},
             # whole path against the sum over kernels of max(bytes/8 TB/s, flops/157.3 TF) = 26.9 us per frame
             "roofline_path": {"t_roof_us_per_frame": T_ROOF_US_PER_FRAME, "fps_at_roof": round(1e6 / T_ROOF_US_PER_FRAME, 1),
                               "frac": round(fps_gpu * T_ROOF_US_PER_FRAME / 1e6, 4),
@@ -449,9 +470,9 @@ def main():
                                       "102 k fps) is above the fp32 compute bound of the backbone alone, so frac is taken against T_roof"},
             "roofline_conv_family": {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> (all 12 MFMA conv launches per step; FLOPs of the "
                                                                   "direct form -- the 3x3/s1 layers execute 2.25x fewer as Winograd F(2x2,3x3))",
-                                     "achieved": round((cfl.value / 1e12) / (cms.value / 1e3), 3) if cms.value > 0 else None,
+                                     "achieved": round((cfl / 1e12) / (cms / 1e3), 3) if cms > 0 else None,
                                      "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                                     "us_per_step": round(1e3 * cms.value / 3, 1)},
+                                     "us_per_step": round(1e3 * cms / 3, 1)},
         }
         out.update(side)
         if world == 1 and args.cpu_seconds > 0:

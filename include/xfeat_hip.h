@@ -271,6 +271,7 @@ int xfh_lg_match_pairs(xfh_lg_handle h, const float* kpts, const float* desc, co
  * ---------------------------------------------------------------------------------------- */
 enum { XFH_PROF_NONE = 0, XFH_PROF_CONV_MFMA = 1, XFH_PROF_MATCH = 2, XFH_PROF_BLOCK1 = 3, XFH_PROF_HEADS = 4,
        XFH_PROF_CONV_64_64_S1 = 5 /* launches of conv_mfma_kernel<64,64,3,1,..>: the 64->64 3x3 stride-1 layers */,
+       XFH_PROF_CONV_24_24 = 6 /* the two 24->24 3x3 stride-1 layers (block2.0 / block2.1): one kernel instantiation, two launches per step */,
        XFH_PROF_CONV_LAYER0 = 100 /* + index into spec.CONVS: one MFMA conv layer only */ };
 int xfh_profile_select(xfh_handle h, int which);
 /* debug: 24 int64 s_memtime stamps per MFMA-conv workgroup are written to device_buffer (NULL = off) */

@@ -12,6 +12,6 @@ tail -40 gpurun_out/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 gpurun_out/smoke.log
 if [ "$1" != "nobench" ]; then
 echo "== bench"; timeout 900 python bench.py --steps 10 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -3 gpurun_out/bench.log
-echo "== rocprof"; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --cpu-seconds 0 > "$OLDPWD/gpurun_out/rocprof.log" 2>&1); echo "rocprof rc=$?"
+echo "== rocprof"; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r02 --output-format csv -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --cpu-seconds 0 > "$OLDPWD/gpurun_out/rocprof.log" 2>&1); echo "rocprof rc=$?"
 find gpurun_out/prof -name "*stats*" | head
 fi
