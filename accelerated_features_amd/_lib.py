@@ -30,12 +30,12 @@ SIGNATURES = {
     "xfh_destroy": (None, [_p]),
     "xfh_resize_bilinear": (_i, [_p, _i, _i, _i, _p, _i, _i, _f, _f, _p]),
     "xfh_backbone_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "xfh_backbone": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
-    "xfh_backbone_u8": (_i, [_p, _p, _i, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
-    "xfh_backbone_resized": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f, _f, _p, _p, _p, _p, _p, _sz, _p]),
+    "xfh_backbone": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "xfh_backbone_u8": (_i, [_p, _p, _i, _f, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "xfh_backbone_resized": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "xfh_conv_layer": (_i, [_p, _i, _p, _i, _i, _i, _p, _i, _p]),
     "xfh_detect_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "xfh_detect_sparse": (_i, [_p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "xfh_detect_sparse": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "xfh_dense_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "xfh_extract_dense": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _sz, _p]),
     "xfh_match_workspace_bytes": (_sz, [_i, _i, _i]),

@@ -430,7 +430,7 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
 struct ResizeSpec { int Hin, Win, Hm, Wm; float s1h, s1w, s2h, s2w; };      // xfh_backbone_resized: img is (B,C,Hin,Win)
 
 static int backbone_impl(xfh_handle h, const float* img, const unsigned char* img_u8, int u8_layout, float u8_divisor, int B, int C, int H,
-                         int W, float* feats, float* logits, float* heat, float* reliab, void* workspace, size_t workspace_bytes,
+                         int W, float* feats, float* logits, float* heat, float* reliab, float* invnorm, void* workspace, size_t workspace_bytes,
                          xfh_stream stream, const ResizeSpec* rs = nullptr) {
     if (!h || (!img && !img_u8) || !feats || !reliab) return fail(XFH_ERR_ARG, "xfh_backbone: NULL argument");
     if (!logits && !heat) return fail(XFH_ERR_ARG, "xfh_backbone: logits and heat are both NULL");
@@ -472,31 +472,31 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
 
     // fused heads: reliability from the channels-last features, key-point head from the gray image
     prof_begin(&h->prof, XFH_PROF_HEADS, st);
-    launch_rel_head(nw, feats, B * H8 * W8, reliab, st);
+    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st);
     launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st);
     prof_end(&h->prof, XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }
 
 int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W, float* feats, float* logits, float* heat,
-                 float* reliab, void* workspace, size_t workspace_bytes, xfh_stream stream) {
-    return backbone_impl(h, img, nullptr, 0, 1.f, B, C, H, W, feats, logits, heat, reliab, workspace, workspace_bytes, stream);
+                 float* reliab, float* invnorm, void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    return backbone_impl(h, img, nullptr, 0, 1.f, B, C, H, W, feats, logits, heat, reliab, invnorm, workspace, workspace_bytes, stream);
 }
 
 int xfh_backbone_u8(xfh_handle h, const uint8_t* img, int layout, float divisor, int B, int C, int H, int W, float* feats,
-                    float* logits, float* heat, float* reliab, void* workspace, size_t workspace_bytes, xfh_stream stream) {
+                    float* logits, float* heat, float* reliab, float* invnorm, void* workspace, size_t workspace_bytes, xfh_stream stream) {
     if (layout != XFH_LAYOUT_NCHW && layout != XFH_LAYOUT_NHWC) return fail(XFH_ERR_ARG, "xfh_backbone_u8: layout must be XFH_LAYOUT_NCHW or XFH_LAYOUT_NHWC");
     if (!(divisor > 0.f)) return fail(XFH_ERR_ARG, "xfh_backbone_u8: divisor must be positive");
-    return backbone_impl(h, nullptr, img, layout, divisor, B, C, H, W, feats, logits, heat, reliab, workspace, workspace_bytes, stream);
+    return backbone_impl(h, nullptr, img, layout, divisor, B, C, H, W, feats, logits, heat, reliab, invnorm, workspace, workspace_bytes, stream);
 }
 
 int xfh_backbone_resized(xfh_handle h, const float* img, int B, int C, int Hin, int Win, int Hmid, int Wmid, float scale1_h, float scale1_w,
-                         int Hout, int Wout, float scale2_h, float scale2_w, float* feats, float* logits, float* heat, float* reliab,
+                         int Hout, int Wout, float scale2_h, float scale2_w, float* feats, float* logits, float* heat, float* reliab, float* invnorm,
                          void* workspace, size_t workspace_bytes, xfh_stream stream) {
     if (Hin <= 0 || Win <= 0 || Hmid <= 0 || Wmid <= 0 || !(scale1_h > 0.f) || !(scale1_w > 0.f))
         return fail(XFH_ERR_ARG, "xfh_backbone_resized: bad source / intermediate size");
     const ResizeSpec rs{Hin, Win, Hmid, Wmid, scale1_h, scale1_w, scale2_h, scale2_w};
-    return backbone_impl(h, img, nullptr, 0, 1.f, B, C, Hout, Wout, feats, logits, heat, reliab, workspace, workspace_bytes, stream, &rs);
+    return backbone_impl(h, img, nullptr, 0, 1.f, B, C, Hout, Wout, feats, logits, heat, reliab, invnorm, workspace, workspace_bytes, stream, &rs);
 }
 
 int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out, int variant,
@@ -532,7 +532,7 @@ size_t xfh_detect_workspace_bytes(int B, int H, int W, int top_k, int nms_capaci
     return carve_detect(nullptr, B, H, W, top_k, nms_capacity, o);
 }
 
-int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats, int B, int H, int W,
+int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                       float threshold, int top_k, int nms_capacity, float rw, float rh, float* kpts, float* scores,
                       float* desc, int32_t* n_valid, int32_t* n_candidates, void* workspace, size_t workspace_bytes,
                       xfh_stream stream) {
@@ -547,7 +547,7 @@ int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, cons
     DetectWs w;
     const size_t need = carve_detect(workspace, B, H, W, top_k, nms_capacity, w);
     if ((rc = check_ws(workspace, workspace_bytes, need))) return rc;
-    launch_detect(w, heat, reliab, feats, B, H, W, threshold, top_k, nms_capacity, rw, rh, kpts, scores, desc, n_valid,
+    launch_detect(w, heat, reliab, feats, invnorm, B, H, W, threshold, top_k, nms_capacity, rw, rh, kpts, scores, desc, n_valid,
                   n_candidates, (hipStream_t)stream);
     return check_launch("xfh_detect_sparse");
 }

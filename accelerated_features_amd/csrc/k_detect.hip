@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     *dp = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
 }
 
-void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, int B, int H, int W,
+void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                    float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
                    int32_t* n_valid, int32_t* n_cand, hipStream_t st) {
     const int WPR = ceil_div(W, 64);
@@ -514,8 +514,11 @@ void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, c
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
     const ScoreSrc src{heat, reliab, ws.cand, H, W};
     run_topk(&src, nullptr, ws.keys, n_cand, 0, cap, top_k, B, ws.skeys, ws.nsel, n_valid, st);
-    invnorm_kernel<<<ceil_div(B * hc * wc * 16, 256), 256, 0, st>>>(feats, B * hc * wc, ws.invnorm);
-    descriptor_kernel<<<xcd_grid_size(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, ws.invnorm, ws.cand, ws.skeys, ws.nsel, H, W,
+    if (!invnorm) {           // not handed over by the backbone call: one pass over the feature maps
+        invnorm_kernel<<<ceil_div(B * hc * wc * 16, 256), 256, 0, st>>>(feats, B * hc * wc, ws.invnorm);
+        invnorm = ws.invnorm;
+    }
+    descriptor_kernel<<<xcd_grid_size(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, invnorm, ws.cand, ws.skeys, ws.nsel, H, W,
                                                                             cap, top_k, B, ceil_div(top_k, 16), rw, rh, kpts, scores, n_valid, desc);
 }
 

@@ -34,6 +34,7 @@ struct HeadArgs {
     const float* bias[4];
     float* out;              // KP: heat (B,H,W) ; REL: reliability (B*hc*wc)
     float* logits;           // KP only, optional: (B*hc*wc, 65)
+    float* inv;              // REL only, optional: 1 / max(||feats[cell,:]||, 1e-12)  (F.normalize(M1, dim=1), xfeat.py:70)
     int H, W, hc, wc, ncell, ntiles;
 };
 
@@ -146,10 +147,12 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
             };
             ld(0, av[0], bv[0]);
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            float nrm2 = 0.f;          // REL: this lane walks 32 of its cell's 64 channels anyway -> squared norm for free
 #pragma unroll
             for (int p = 0; p < 32; ++p) {
                 if (p + 1 < 32) ld(p + 1, av[(p + 1) & 1], bv[(p + 1) & 1]);
                 const float xv = KP ? fmaf(bv[p & 1], nalpha, nbeta) : bv[p & 1];
+                if (!KP) nrm2 = fmaf(xv, xv, nrm2);
                 accA[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][0], xv, accA[0], 0, 0, 0);
                 accA[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][1], xv, accA[1], 0, 0, 0);
                 if (p + 1 < 32) {
@@ -159,6 +162,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
                 } else {
                     __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 }
+            }
+            if (!KP && a.inv) {
+                nrm2 += xhalf(nrm2);                       // the other 32 channels sit in the other half-wave
+                const int gc = tile * HD_CELLS + wave * 32 + l31;
+                if (half == 0 && gc < a.ncell) a.inv[gc] = 1.f / fmaxf(sqrtf(nrm2), 1e-12f);
             }
         }
         lds_dma_barrier();                                 // every wave is done with the X tile
@@ -238,9 +246,9 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
     head_fused_kernel<true><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, hipStream_t st) {
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st) {
     HeadArgs a{};
-    a.src = feats; a.zeros = nw.zeros; a.out = reliab; a.logits = nullptr;
+    a.src = feats; a.zeros = nw.zeros; a.out = reliab; a.logits = nullptr; a.inv = invnorm;
     a.hc = 1; a.wc = 1; a.H = 8; a.W = 8;
     a.ncell = ncell;
     a.ntiles = ceil_div(ncell, HD_CELLS);

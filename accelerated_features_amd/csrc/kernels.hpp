@@ -94,7 +94,8 @@ void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat
 // fused heads (persistent, weights LDS-resident): key-point head -> heat (+ optional logits (M,65)),
 // reliability head -> sigmoid map
 void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st);
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, hipStream_t st);
+// invnorm (optional): 1 / max(||feats[cell,:]||, 1e-12) per cell, a by-product of the layer-1 operand loads
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st);
 
 // ---- k_detect.hip -----------------------------------------------------------------------
 struct DetectWs {          // carved from the caller's workspace by api.hip
@@ -106,7 +107,7 @@ struct DetectWs {          // carved from the caller's workspace by api.hip
     int* nsel;                  // (B)         min(n_candidates, cap, top_k)
     float* invnorm;             // (B, hc*wc)  1/max(||feats||,1e-12)
 };
-void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, int B, int H, int W,
+void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                    float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
                    int32_t* n_valid, int32_t* n_cand, hipStream_t st);
 void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int kernel_size, int cap, int64_t* xy,

@@ -193,8 +193,10 @@ class XFeatModel(nn.Module):
         return t[off:], int(nbytes)
 
     # -- the network -----------------------------------------------------------------------------
-    def backbone(self, x, want_logits=True, want_heat=False):
-        """x (B,C,H,W) float32 CUDA, H%32==W%32==0 -> (feats_cl (B,h,w,64), logits_cl|None, heat|None, rel (B,h,w))."""
+    def backbone(self, x, want_logits=True, want_heat=False, want_invnorm=False):
+        """x (B,C,H,W) float32 CUDA, H%32==W%32==0 -> (feats_cl (B,h,w,64), logits_cl|None, heat|None, rel (B,h,w)); with
+        want_invnorm a fifth element: 1/max(||feats[b,i,j,:]||, 1e-12) (B,h,w), the reliability head's by-product that
+        xfh_detect_sparse would otherwise recompute (F.normalize(M1, dim=1), xfeat.py:70)."""
         if len(x.shape) != 4:
             raise RuntimeError("Input tensor needs to be in (B,C,H,W) format")
         lib = _lib.load()
@@ -212,11 +214,12 @@ class XFeatModel(nn.Module):
             rel = torch.empty((B, hc, wc), dtype=torch.float32, device=dev)
             logits = torch.empty((B, hc, wc, 65), dtype=torch.float32, device=dev) if want_logits else None
             heat = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_heat else None
+            inv = torch.empty((B, hc, wc), dtype=torch.float32, device=dev) if want_invnorm else None
             ws, n = self.workspace("backbone", lib.xfh_backbone_workspace_bytes(B, Cc, H, W))
             _lib.check(lib.xfh_backbone_resized(h, _ptr(x.data), B, Cc, x.data.shape[2], x.data.shape[3], x.mid[0], x.mid[1],
                                                 float(x.s1[0]), float(x.s1[1]), H, W, float(x.s2[0]), float(x.s2[1]), _ptr(feats),
-                                                _ptr(logits), _ptr(heat), _ptr(rel), _ptr(ws), n, _stream()), "xfh_backbone_resized")
-            return feats, logits, heat, rel
+                                                _ptr(logits), _ptr(heat), _ptr(rel), _ptr(inv), _ptr(ws), n, _stream()), "xfh_backbone_resized")
+            return (feats, logits, heat, rel, inv) if want_invnorm else (feats, logits, heat, rel)
         if isinstance(x, _U8Image):
             x, u8_div = x.data, x.divisor
         elif x.dtype == torch.uint8:
@@ -230,6 +233,8 @@ class XFeatModel(nn.Module):
         rel = torch.empty((B, hc, wc), dtype=torch.float32, device=dev)
         logits = torch.empty((B, hc, wc, 65), dtype=torch.float32, device=dev) if want_logits else None
         heat = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_heat else None
+        inv = torch.empty((B, hc, wc), dtype=torch.float32, device=dev) if want_invnorm else None
+        ret = (feats, logits, heat, rel, inv) if want_invnorm else (feats, logits, heat, rel)
         ws, n = self.workspace("backbone", lib.xfh_backbone_workspace_bytes(B, Cc, H, W))
         if u8_div is not None:
             # uint8 pixels go to the device as they are (a quarter of the bytes); numpy HWC images arrive as a permuted
@@ -239,11 +244,11 @@ class XFeatModel(nn.Module):
             else:
                 layout, xb = _lib.LAYOUT_NCHW, x.contiguous()
             _lib.check(lib.xfh_backbone_u8(h, _ptr(xb), layout, float(u8_div), B, Cc, H, W, _ptr(feats), _ptr(logits), _ptr(heat),
-                                           _ptr(rel), _ptr(ws), n, _stream()), "xfh_backbone_u8")
-            return feats, logits, heat, rel
-        _lib.check(lib.xfh_backbone(h, _ptr(x), B, Cc, H, W, _ptr(feats), _ptr(logits), _ptr(heat), _ptr(rel),
+                                           _ptr(rel), _ptr(inv), _ptr(ws), n, _stream()), "xfh_backbone_u8")
+            return ret
+        _lib.check(lib.xfh_backbone(h, _ptr(x), B, Cc, H, W, _ptr(feats), _ptr(logits), _ptr(heat), _ptr(rel), _ptr(inv),
                                     _ptr(ws), n, _stream()), "xfh_backbone")
-        return feats, logits, heat, rel
+        return ret
 
     def forward(self, x):
         feats, logits, _, rel = self.backbone(x, want_logits=True, want_heat=False)
@@ -333,13 +338,13 @@ class XFeat(nn.Module):
         if detection_threshold is None: detection_threshold = self.detection_threshold
         x, rh1, rw1 = self.preprocess_tensor(x)
         B, _, H, W = x.shape
-        feats, _, heat, rel = self.net.backbone(x, want_logits=False, want_heat=True)
+        feats, _, heat, rel, inv = self.net.backbone(x, want_logits=False, want_heat=True, want_invnorm=True)
         if cap is None:
             cap = min(H * W, max(int(top_k), (H * W) // 8))
-        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1)
+        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1, inv)
         return out[0], out[1], out[2], out[3], out[4], cap, H * W
 
-    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh):
+    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh, inv=None):
         lib = _lib.load()
         dev = feats.device
         kpts = torch.empty((B, top_k, 2), dtype=torch.float32, device=dev)
@@ -348,7 +353,7 @@ class XFeat(nn.Module):
         n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
         n_cand = torch.empty((B,), dtype=torch.int32, device=dev)
         ws, n = self.net.workspace("detect", lib.xfh_detect_workspace_bytes(B, H, W, top_k, cap))
-        _lib.check(lib.xfh_detect_sparse(self.net.handle(), _ptr(heat), _ptr(rel), _ptr(feats), B, H, W, float(thr), top_k, cap,
+        _lib.check(lib.xfh_detect_sparse(self.net.handle(), _ptr(heat), _ptr(rel), _ptr(feats), _ptr(inv), B, H, W, float(thr), top_k, cap,
                                          float(rw), float(rh), _ptr(kpts), _ptr(scores), _ptr(desc), _ptr(n_valid),
                                          _ptr(n_cand), _ptr(ws), n, _stream()), "xfh_detect_sparse")
         return kpts, scores, desc, n_valid, n_cand

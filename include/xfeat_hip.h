@@ -90,10 +90,12 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   logits   (B,H/8,W/8,65)  "K1", channels-last; may be NULL (then not written)
  *   heat     (B,H,W)         softmax(K1)[:64] depth-to-space 8x8; may be NULL (then logits must not be)
  *   reliab   (B,H/8,W/8)     "H1" after the sigmoid
+ *   invnorm  (B,H/8,W/8)     optional (may be NULL): 1 / max(||feats[b,i,j,:]||, 1e-12), the per-cell factor of F.normalize(M1, dim=1)
+ *                            (modules/xfeat.py:70) -- a by-product of the reliability head; hand it to xfh_detect_sparse to save that pass
  * ---------------------------------------------------------------------------------------- */
 size_t xfh_backbone_workspace_bytes(int B, int C, int H, int W);
 int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W,
-                 float* feats, float* logits, float* heat, float* reliab,
+                 float* feats, float* logits, float* heat, float* reliab, float* invnorm,
                  void* workspace, size_t workspace_bytes, xfh_stream stream);
 
 /* Same network from uint8 pixels: replaces the host-side conversion in front of it --
@@ -103,7 +105,7 @@ int xfh_backbone(xfh_handle h, const float* img, int B, int C, int H, int W,
 #define XFH_LAYOUT_NCHW 0
 #define XFH_LAYOUT_NHWC 1
 int xfh_backbone_u8(xfh_handle h, const uint8_t* img, int layout, float divisor, int B, int C, int H, int W,
-                    float* feats, float* logits, float* heat, float* reliab,
+                    float* feats, float* logits, float* heat, float* reliab, float* invnorm,
                     void* workspace, size_t workspace_bytes, xfh_stream stream);
 
 /* The dual-scale dense path (XFeat.extract_dualscale, modules/xfeat.py:379-394): F.interpolate(x, scale_factor=s) to
@@ -114,7 +116,7 @@ int xfh_backbone_u8(xfh_handle h, const uint8_t* img, int layout, float divisor,
  * (XFH_ERR_UNSUPPORTED otherwise: materialise the images with xfh_resize_bilinear). */
 int xfh_backbone_resized(xfh_handle h, const float* img, int B, int C, int Hin, int Win, int Hmid, int Wmid,
                          float scale1_h, float scale1_w, int Hout, int Wout, float scale2_h, float scale2_w,
-                         float* feats, float* logits, float* heat, float* reliab, void* workspace,
+                         float* feats, float* logits, float* heat, float* reliab, float* invnorm, void* workspace,
                          size_t workspace_bytes, xfh_stream stream);
 
 /* One conv layer of the network in isolation (parity tests against per-layer oracle
@@ -131,6 +133,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
  * InterpolateSparse2d calls (modules/interpolator.py:21-33).
  *
  *   heat (B,H,W), reliab (B,H/8,W/8), feats (B,H/8,W/8,64) as produced by xfh_backbone
+ *   invnorm          (B,H/8,W/8) from the same xfh_backbone call, or NULL (then computed here in one extra pass over feats)
  *   threshold        detection threshold (strict >)
  *   top_k            any positive value (fewer candidates than top_k => shorter lists, like the reference)
  *   nms_capacity     capacity of the candidate list per image.  If n_candidates[b] comes back
@@ -143,7 +146,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
  *   n_candidates (B) int32  = NMS candidates found (uncapped)
  * ---------------------------------------------------------------------------------------- */
 size_t xfh_detect_workspace_bytes(int B, int H, int W, int top_k, int nms_capacity);
-int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats,
+int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats, const float* invnorm,
                       int B, int H, int W, float threshold, int top_k, int nms_capacity, float rw, float rh,
                       float* kpts, float* scores, float* desc, int32_t* n_valid, int32_t* n_candidates,
                       void* workspace, size_t workspace_bytes, xfh_stream stream);

@@ -776,3 +776,17 @@ def test_match_filter_and_refine_equals_exact_kernel(xf):
         a, b = int(nv[2 * p]), int(nv[2 * p + 1])
         s0, s1 = xf.match(d[2 * p, :a], d[2 * p + 1, :b], min_cossim=-1)
         assert int(nm[p]) == len(s0) and torch.equal(i0[p, :len(s0)], s0) and torch.equal(i1[p, :len(s0)], s1), p
+
+
+def test_invnorm_by_product_of_the_reliability_head(xf):
+    """xfh_backbone's optional invnorm output (reliability head by-product) against 1/max(||feats||, 1e-12) in torch, and the sparse
+    results with it handed to xfh_detect_sparse against the internal invnorm pass (NULL): same key-points, descriptors within 1e-6."""
+    x = fixtures.texture_images(3, 96, 160, seed=29).cuda()
+    feats, _, heat, rel, inv = xf.net.backbone(x, want_logits=False, want_heat=True, want_invnorm=True)
+    ref = 1.0 / feats.norm(dim=-1).clamp_min(1e-12)
+    assert inv.shape == ref.shape and float(((inv - ref).abs() / ref).max()) <= 1e-6
+    B, H, W = 3, 96, 160
+    a = xf._detect_call(feats, heat, rel, B, H, W, 0.05, 300, H * W // 8, 1.0, 1.0, inv)
+    b = xf._detect_call(feats, heat, rel, B, H, W, 0.05, 300, H * W // 8, 1.0, 1.0, None)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
+    assert float((a[2] - b[2]).abs().max()) <= 1e-6
