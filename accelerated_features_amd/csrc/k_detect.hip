@@ -23,7 +23,7 @@ namespace xfh {
 constexpr int NMS_TW = 64, NMS_TH = 32, NMS_LW = NMS_TW + 4, NMS_LH = NMS_TH + 4;
 __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict__ heat, int B, int H, int W, int WPR, int HT, float thr,
                                                         unsigned long long* __restrict__ mask, int* __restrict__ wcount) {
-    __shared__ float tile[NMS_LH * NMS_LW];
+    __shared__ __attribute__((aligned(8))) float tile[NMS_LH * NMS_LW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // all tiles of an image on one XCD: the 2-pixel halos of neighbouring tiles hit that XCD's L2 (PMC: the plain
     // (x, y, image) grid fetched every heat map twice)
@@ -32,10 +32,23 @@ __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict_
     const int word = item % WPR, y0 = (item / WPR) * NMS_TH;
     const int x0 = word * 64;
     const float* hp = heat + (size_t)b * H * W;
-    for (int e = tid; e < NMS_LH * NMS_LW; e += 256) {
-        const int r = e / NMS_LW, c = e - r * NMS_LW;
-        const int gy = y0 - 2 + r, gx = x0 - 2 + c;
-        tile[e] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? hp[(size_t)gy * W + gx] : -INFINITY;
+    {   // the tile as 8-byte column pairs (x0 - 2 and W are even: a pair never straddles the image border), all five loads of a thread
+        // in flight together -- as a rolled loop of dword loads hipcc waited for each of the ten round trips in turn
+        constexpr int PW = NMS_LW / 2, NP = NMS_LH * PW, NL = (NP + 255) / 256;
+        float2 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int e = tid + k * 256;
+            const int r = e / PW, c = e - r * PW;
+            const int gy = y0 - 2 + r, gx = x0 - 2 + 2 * c;
+            v[k] = (e < NP && gy >= 0 && gy < H && gx >= 0 && gx < W) ? *reinterpret_cast<const float2*>(hp + (size_t)gy * W + gx)
+                                                                      : make_float2(-INFINITY, -INFINITY);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int e = tid + k * 256;
+            if (e < NP) reinterpret_cast<float2*>(tile)[e] = v[k];
+        }
     }
     __syncthreads();
     // this wave: rows y0 + 8*wave .. +7 ; lane: column x0 + lane
