@@ -790,3 +790,30 @@ def test_invnorm_by_product_of_the_reliability_head(xf):
     b = xf._detect_call(feats, heat, rel, B, H, W, 0.05, 300, H * W // 8, 1.0, 1.0, None)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[3], b[3])
     assert float((a[2] - b[2]).abs().max()) <= 1e-6
+
+
+def test_sizes_beyond_the_round1_limits(xf, sd):
+    """top_k, dense k and descriptor-set sizes above 16384 (round 1 refused them; the reference has no such limits): the run-sorted top-k
+    with global-memory rank searches, extractDense(top_k < 1) = every cell of a 1056 x 1312 image (21 648 cells), a 20 000-row match."""
+    x = fixtures.texture_images(1, 1056, 1312, seed=33)
+    out = xf.detectAndCompute(x.cuda(), top_k=20000, detection_threshold=0.01)[0]
+    ref, st = O.detect_and_compute(sd, x, top_k=20000, detection_threshold=0.01, keep=True)
+    rep = parity.compare_keypoints(out, ref[0], heat=st["heat"][0, 0], thr=0.01)
+    print("top_k 20000:", rep)
+    assert rep["n_ref"] > 16384, rep["n_ref"]
+    mk, ft = xf.extractDense(x.cuda(), top_k=-1)
+    rk, rf, _ = O.extract_dense(sd, x, -1)
+    assert mk.shape == rk.shape and mk.shape[1] == 132 * 164 > 16384
+    a = {tuple(p): i for i, p in enumerate(mk[0].cpu().numpy().tolist())}
+    b = {tuple(p): i for i, p in enumerate(rk[0].numpy().tolist())}
+    assert set(a) == set(b)
+    ia = torch.tensor([a[k] for k in b]); ib = torch.tensor([b[k] for k in b])
+    parity.assert_close(ft[0].cpu()[ia], rf[0][ib], 2e-4, "dense features, all cells")
+    g = torch.Generator().manual_seed(8)
+    d1 = torch.nn.functional.normalize(torch.randn(300, 64, generator=g), dim=-1)
+    d2 = torch.nn.functional.normalize(torch.randn(20000, 64, generator=g), dim=-1)
+    d2[17000] = d1[5]; d2[123] = d1[7]
+    for a_, b_ in ((d1, d2), (d2, d1)):
+        i0, i1 = xf.match(a_.cuda(), b_.cuda(), min_cossim=-1)
+        o0, o1 = O.match_mnn(a_, b_, -1)
+        assert torch.equal(i0.cpu(), o0) and torch.equal(i1.cpu(), o1)
