@@ -417,6 +417,34 @@ def main():
         side["with_h2d_fp32_fps"] = round(rate(with_h2d(xh32)), 1)
         side["with_h2d_uint8_fps"] = round(rate(with_h2d(xh8)), 1)
 
+        def pipelined(src, n=6):
+            """the upload of batch i+1 on a copy stream under the step of batch i (two device buffers): what a feeding loop would do"""
+            cs, main = torch.cuda.Stream(), torch.cuda.current_stream()
+            dev = [torch.empty(src.shape, dtype=src.dtype, device="cuda") for _ in range(2)]
+            ready = [torch.cuda.Event() for _ in range(2)]
+            free = [torch.cuda.Event() for _ in range(2)]
+
+            def upload(i):
+                with torch.cuda.stream(cs):
+                    if i >= 2:
+                        cs.wait_event(free[i % 2])
+                    dev[i % 2].copy_(src, non_blocking=True)
+                    ready[i % 2].record(cs)
+            upload(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                upload(i + 1)
+                main.wait_event(ready[i % 2])
+                kp, sc, de, nv, nc, cap_, hw = xf._detect_device(dev[i % 2], TOP_K, 0.05)
+                i0, i1, nm = xf.match_pairs_device(de, nv, -1)
+                free[i % 2].record(main)
+                torch.cat([nv, nc, nm]).cpu()
+            torch.cuda.synchronize()
+            return B * n / (time.perf_counter() - t0)
+        side["with_h2d_fp32_pipelined_fps"] = round(pipelined(xh32), 1)
+        side["with_h2d_uint8_pipelined_fps"] = round(pipelined(xh8), 1)
+
     if rank == 0:
         n_valid = counts[:B].tolist()
         n_match = counts[2 * B:].tolist()
