@@ -35,11 +35,11 @@ SIGNATURES = {
     "xfh_backbone_resized": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _f, _f, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "xfh_conv_layer": (_i, [_p, _i, _p, _i, _i, _i, _p, _i, _p]),
     "xfh_detect_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "xfh_detect_sparse": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "xfh_detect_sparse": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _f, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "xfh_dense_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "xfh_extract_dense": (_i, [_p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p, _p, _p, _p, _sz, _p]),
     "xfh_match_workspace_bytes": (_sz, [_i, _i, _i]),
-    "xfh_match_mnn": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
+    "xfh_match_mnn": (_i, [_p, _p, _sz, _p, _sz, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _sz, _p]),
     "xfh_refine_workspace_bytes": (_sz, [_i, _i]),
     "xfh_refine_matches": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _p, _p, _sz, _p]),
     "xfh_kpts_heatmap": (_i, [_p, _i, _i, _i, _p, _p]),

@@ -534,7 +534,7 @@ size_t xfh_detect_workspace_bytes(int B, int H, int W, int top_k, int nms_capaci
 
 int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                       float threshold, int top_k, int nms_capacity, float rw, float rh, float* kpts, float* scores,
-                      float* desc, int32_t* n_valid, int32_t* n_candidates, void* workspace, size_t workspace_bytes,
+                      float* desc, uint16_t* desc_bf16, int32_t* n_valid, int32_t* n_candidates, void* workspace, size_t workspace_bytes,
                       xfh_stream stream) {
     if (!h || !heat || !reliab || !feats || !kpts || !scores || !desc || !n_valid || !n_candidates)
         return fail(XFH_ERR_ARG, "xfh_detect_sparse: NULL argument");
@@ -548,7 +548,7 @@ int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, cons
     const size_t need = carve_detect(workspace, B, H, W, top_k, nms_capacity, w);
     if ((rc = check_ws(workspace, workspace_bytes, need))) return rc;
     launch_detect(w, heat, reliab, feats, invnorm, B, H, W, threshold, top_k, nms_capacity, rw, rh, kpts, scores, desc, n_valid,
-                  n_candidates, (hipStream_t)stream);
+                  n_candidates, (hipStream_t)stream, desc_bf16);
     return check_launch("xfh_detect_sparse");
 }
 
@@ -582,6 +582,7 @@ size_t xfh_match_workspace_bytes(int P, int N1, int N2) {
 }
 
 int xfh_match_mnn(xfh_handle h, const float* d1, size_t pair_stride1, const float* d2, size_t pair_stride2,
+                  const uint16_t* d1_bf16, const uint16_t* d2_bf16,
                   const int32_t* n1, const int32_t* n2, int n_stride, int n_offset2, int P, int N1, int N2,
                   float min_cossim, int64_t* idx0, int64_t* idx1, int32_t* n_matches, void* workspace,
                   size_t workspace_bytes, xfh_stream stream) {
@@ -589,12 +590,14 @@ int xfh_match_mnn(xfh_handle h, const float* d1, size_t pair_stride1, const floa
     if (P <= 0 || N1 <= 0 || N2 <= 0 || P > 65535) return fail(XFH_ERR_ARG, "xfh_match_mnn: bad shape");
     if ((long)P * ((N1 + 1023) / 1024) > 0x7fffffffL / 1024) return fail(XFH_ERR_ARG, "xfh_match_mnn: P * N1 too large");
     if ((pair_stride1 & 3) || (pair_stride2 & 3)) return fail(XFH_ERR_ARG, "xfh_match_mnn: pair strides must be multiples of 4 floats");
+    if ((d1_bf16 == nullptr) != (d2_bf16 == nullptr)) return fail(XFH_ERR_ARG, "xfh_match_mnn: pass both bf16 copies or neither");
+    if (d1_bf16 && ((pair_stride1 & 7) || (pair_stride2 & 7))) return fail(XFH_ERR_ARG, "xfh_match_mnn: bf16 copies need pair strides that are multiples of 8");
     MatchWs w;
     const size_t need = carve_match(workspace, P, N1, N2, w);
     int rc = check_ws(workspace, workspace_bytes, need);
     if (rc) return rc;
     launch_match(w, d1, pair_stride1, d2, pair_stride2, n1, n2, n_stride, n_offset2, P, N1, N2, min_cossim, idx0, idx1,
-                 n_matches, (hipStream_t)stream, h ? &h->prof : nullptr);
+                 n_matches, (hipStream_t)stream, h ? &h->prof : nullptr, d1_bf16, d2_bf16);
     return check_launch("xfh_match_mnn");
 }
 

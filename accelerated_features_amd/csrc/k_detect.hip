@@ -449,7 +449,8 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
                                                          const unsigned* __restrict__ cand, const unsigned long long* __restrict__ skeys,
                                                          const int* __restrict__ nsel, int H, int W, int cap, int top_k,
                                                          int B, int blocks_per_img, float rw, float rh, float* __restrict__ kpts,
-                                                         float* __restrict__ scores, int32_t* __restrict__ n_valid, float* __restrict__ desc) {
+                                                         float* __restrict__ scores, int32_t* __restrict__ n_valid, float* __restrict__ desc,
+                                                         uint16_t* __restrict__ desc16) {
     const int sub = threadIdx.x & 15;
     int b, blk;                       // all key-points of an image on one XCD: its feats stay in that L2
     if (!xcd_group_map(blockIdx.x, blocks_per_img, B, b, blk)) return;
@@ -457,8 +458,10 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     if (j >= top_k) return;
     float4* dp = reinterpret_cast<float4*>(desc + ((size_t)b * top_k + j) * 64) + sub;
     const int k = nsel[b];
+    ushort4* dp16 = desc16 ? reinterpret_cast<ushort4*>(desc16 + ((size_t)b * top_k + j) * 64) + sub : nullptr;
     if (j >= k) {                     // fixed-capacity outputs: rows past the list are zero
         *dp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dp16) *dp16 = make_ushort4(0, 0, 0, 0);
         if (sub == 0) {
             *reinterpret_cast<float2*>(kpts + ((size_t)b * top_k + j) * 2) = make_float2(0.f, 0.f);
             scores[(size_t)b * top_k + j] = 0.f;
@@ -515,12 +518,17 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     n2 += __shfl_xor(n2, 2, 64);
     n2 += __shfl_xor(n2, 1, 64);
     const float d = fmaxf(sqrtf(n2), 1e-12f);
-    *dp = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+    const float4 o = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+    *dp = o;
+    if (dp16) {                       // bf16 (round-to-nearest-even) copy for the matcher's filter sweeps: saves its conversion pass
+        auto rne = [](float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); };
+        *dp16 = make_ushort4(rne(o.x), rne(o.y), rne(o.z), rne(o.w));
+    }
 }
 
 void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                    float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
-                   int32_t* n_valid, int32_t* n_cand, hipStream_t st) {
+                   int32_t* n_valid, int32_t* n_cand, hipStream_t st, uint16_t* desc16) {
     const int WPR = ceil_div(W, 64);
     const int hc = H / 8, wc = W / 8;
     nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
@@ -532,7 +540,7 @@ void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, c
         invnorm = ws.invnorm;
     }
     descriptor_kernel<<<xcd_grid_size(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, invnorm, ws.cand, ws.skeys, ws.nsel, H, W,
-                                                                            cap, top_k, B, ceil_div(top_k, 16), rw, rh, kpts, scores, n_valid, desc);
+                                                                            cap, top_k, B, ceil_div(top_k, 16), rw, rh, kpts, scores, n_valid, desc, desc16);
 }
 
 // stand-alone NMS (XFeat.NMS): flags + compaction + int64 (x,y) list, zero padded

@@ -222,18 +222,18 @@ int match_debug_occupancy() {
 void prof_begin(Profiler* p, int which, hipStream_t st);
 void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
 
-void launch_match_bf16(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1, const int32_t* n2,
-                       int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st);
+void launch_match_bf16(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const uint16_t* d1_16, const uint16_t* d2_16,
+                       const int32_t* n1, const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st);
 
 void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim, int64_t* idx0,
-                  int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof) {
+                  int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof, const uint16_t* d1_16, const uint16_t* d2_16) {
     const int nrb = match_row_blocks(N1);
     const char* mode = getenv("XFH_MATCH");
     const bool exact_only = mode && mode[0] == 'f';            // XFH_MATCH=f32: the exact MFMA kernel for every pair (A/B runs)
     (void)hipMemsetAsync(ws.zeroed, 0, ws.zeroed_bytes, st);   // keys / maxima / counters: 0 = below everything
     prof_begin(prof, 2, st);
-    if (!exact_only) launch_match_bf16(ws, d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, P, N1, N2, st);
+    if (!exact_only) launch_match_bf16(ws, d1, ps1, d2, ps2, d1_16, d2_16, n1, n2, n_stride, n_off2, P, N1, N2, st);
     // exact kernel: every pair (exact_only), or only the pairs whose candidate list overflowed (its workgroups exit at once otherwise)
     mnn_sim_kernel<<<xcd_grid_size(nrb, P), 512, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.rowkey, ws.colkey,
                                                  exact_only ? nullptr : ws.cnt, ws.cand_cap);

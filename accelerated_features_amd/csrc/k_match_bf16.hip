@@ -95,7 +95,8 @@ __device__ inline f32x16 bf16_tile(const bf16x8 (&a)[4], const unsigned short* b
 
 // PASS 1: row / column maxima of S^.  PASS 2: candidates.  Same tiling as mnn_sim_kernel: a workgroup owns 256 rows, sweeps the columns.
 template <int PASS>
-__global__ __launch_bounds__(512) void mnn_bf16_kernel(const unsigned short* __restrict__ a16, const unsigned short* __restrict__ b16,
+__global__ __launch_bounds__(512) void mnn_bf16_kernel(const unsigned short* __restrict__ a16, size_t sa16, const unsigned short* __restrict__ b16, size_t sb16,
+                                                       float unit_bound /* > 0: prepared unit-norm inputs, every |d| <= unit_bound (na / nb / nmax unused) */,
                                                        const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
                                                        int N1, int N2, int nrb, int P, const float* __restrict__ na, const float* __restrict__ nb,
                                                        const unsigned* __restrict__ nmax, float* __restrict__ rowmaxh, unsigned* __restrict__ colmaxh,
@@ -114,8 +115,8 @@ __global__ __launch_bounds__(512) void mnn_bf16_kernel(const unsigned short* __r
     const int n2 = bpair_count(n2p, p * n_stride + n_off2, N2);
     const int row0 = rb * BT_ROWS;
     if (n1 <= 0 || n2 <= 0 || row0 >= n1) return;
-    const unsigned short* A = a16 + (size_t)p * N1 * 64;
-    const unsigned short* Bm = b16 + (size_t)p * N2 * 64;
+    const unsigned short* A = a16 + (size_t)p * sa16;
+    const unsigned short* Bm = b16 + (size_t)p * sb16;
     const int wrow0 = row0 + wave * 32;
 
     bf16x8 a[4];
@@ -129,14 +130,14 @@ __global__ __launch_bounds__(512) void mnn_bf16_kernel(const unsigned short* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) bv[r] = -INFINITY;
     } else {
-        const float e2 = 2.f * BF_C * __uint_as_float(nmax[P + p]);          // 2 c max|d2|
+        const float e2 = 2.f * BF_C * (unit_bound > 0.f ? unit_bound : __uint_as_float(nmax[P + p]));          // 2 c max|d2|
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = min(wrow0 + (r & 3) + 8 * (r >> 2) + 4 * half, n1 - 1);
-            bv[r] = rowmaxh[(size_t)p * N1 + row] - e2 * na[(size_t)p * N1 + row];
+            bv[r] = rowmaxh[(size_t)p * N1 + row] - e2 * (unit_bound > 0.f ? unit_bound : na[(size_t)p * N1 + row]);
         }
     }
-    const float e2c = PASS == 2 ? 2.f * BF_C * __uint_as_float(nmax[p]) : 0.f;      // 2 c max|d1|
+    const float e2c = PASS == 2 ? 2.f * BF_C * (unit_bound > 0.f ? unit_bound : __uint_as_float(nmax[p])) : 0.f;      // 2 c max|d1|
 
     for (int c0 = 0; c0 < n2; c0 += BT_COLS) {
         __syncthreads();
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(512) void mnn_bf16_kernel(const unsigned short* __r
             }
             if (PASS == 2 && tid < BT_COLS) {
                 const int gc = min(c0 + tid, n2 - 1);
-                colx[0][tid] = ord_float(colmaxh[(size_t)p * N2 + gc]) - e2c * nb[(size_t)p * N2 + gc];
+                colx[0][tid] = ord_float(colmaxh[(size_t)p * N2 + gc]) - e2c * (unit_bound > 0.f ? unit_bound : nb[(size_t)p * N2 + gc]);
             }
         }
         __syncthreads();
@@ -263,14 +264,22 @@ __global__ __launch_bounds__(256) void mnn_exact_kernel(const float* __restrict_
     }
 }
 
-void launch_match_bf16(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1, const int32_t* n2,
-                       int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st) {
+// d1_16 / d2_16 (optional, both or neither): bf16 RNE copies the caller already holds (xfh_detect_sparse's desc_bf16), laid out like d1 / d2
+// (same pair strides in elements), rows L2-normalised: |d| <= 1.00001.  They replace the prep pass.
+void launch_match_bf16(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const uint16_t* d1_16, const uint16_t* d2_16,
+                       const int32_t* n1, const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st) {
     const int nrb = ceil_div(N1, BT_ROWS);
-    mnn_prep_kernel<<<dim3(ceil_div(N1 > N2 ? N1 : N2, 256), P, 2), 256, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, ws.a16, ws.b16,
-                                                                               ws.na, ws.nb, ws.nmax);
-    mnn_bf16_kernel<1><<<xcd_grid_size(nrb, P), 512, 0, st>>>(ws.a16, ws.b16, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.na, ws.nb, ws.nmax,
+    const bool prepared = d1_16 && d2_16;
+    const unsigned short* a16 = prepared ? d1_16 : ws.a16;
+    const unsigned short* b16 = prepared ? d2_16 : ws.b16;
+    const size_t sa = prepared ? ps1 : (size_t)N1 * 64, sb = prepared ? ps2 : (size_t)N2 * 64;
+    const float ub = prepared ? 1.00001f : 0.f;
+    if (!prepared)
+        mnn_prep_kernel<<<dim3(ceil_div(N1 > N2 ? N1 : N2, 256), P, 2), 256, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, ws.a16, ws.b16,
+                                                                                    ws.na, ws.nb, ws.nmax);
+    mnn_bf16_kernel<1><<<xcd_grid_size(nrb, P), 512, 0, st>>>(a16, sa, b16, sb, ub, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.na, ws.nb, ws.nmax,
                                                              ws.rowmaxh, ws.colmaxh, ws.cand, ws.cand_cap, ws.cnt);
-    mnn_bf16_kernel<2><<<xcd_grid_size(nrb, P), 512, 0, st>>>(ws.a16, ws.b16, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.na, ws.nb, ws.nmax,
+    mnn_bf16_kernel<2><<<xcd_grid_size(nrb, P), 512, 0, st>>>(a16, sa, b16, sb, ub, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.na, ws.nb, ws.nmax,
                                                              ws.rowmaxh, ws.colmaxh, ws.cand, ws.cand_cap, ws.cnt);
     mnn_exact_kernel<<<dim3(64, P), 256, 0, st>>>(d1, ps1, d2, ps2, ws.cand, ws.cand_cap, ws.cnt, N1, N2, ws.rowkey, ws.colkey);
 }

@@ -109,7 +109,7 @@ struct DetectWs {          // carved from the caller's workspace by api.hip
 };
 void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                    float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
-                   int32_t* n_valid, int32_t* n_cand, hipStream_t st);
+                   int32_t* n_valid, int32_t* n_cand, hipStream_t st, uint16_t* desc16 = nullptr);
 void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int kernel_size, int cap, int64_t* xy,
                      int32_t* n_cand, hipStream_t st);
 // k_sampler.hip: InterpolateSparse2d as a stand-alone op; mode 0 nearest, 1 bilinear, 2 bicubic
@@ -140,7 +140,7 @@ struct MatchWs {
 };
 void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim,
-                  int64_t* idx0, int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof);
+                  int64_t* idx0, int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof, const uint16_t* d1_16 = nullptr, const uint16_t* d2_16 = nullptr);
 int match_row_blocks(int N1);
 int match_debug_occupancy();
 

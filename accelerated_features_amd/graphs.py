@@ -57,10 +57,11 @@ class CapturedSparsePipeline:
         self._epoch = self.xf.net._ws_epoch
 
     def _body(self):
-        kp, sc, de, nv, nc, cap, hw = self.xf._detect_device(self.x, self.top_k, self.thr)
+        kp, sc, de, nv, nc, cap, hw, d16 = self.xf._detect_device(self.x, self.top_k, self.thr, want_bf16=self.match)[:8] if self.match else \
+            self.xf._detect_device(self.x, self.top_k, self.thr) + (None,)
         self.kpts, self.scores, self.desc, self.n_valid, self.n_cand, self.cap = kp, sc, de, nv, nc, cap
         if self.match:
-            self.idx0, self.idx1, self.n_match = self.xf.match_pairs_device(de, nv, self.min_cossim)
+            self.idx0, self.idx1, self.n_match = self.xf.match_pairs_device(de, nv, self.min_cossim, d16)
             self.counts = torch.cat([nv, nc, self.n_match])
         else:
             self.counts = torch.cat([nv, nc])

@@ -330,9 +330,10 @@ class XFeat(nn.Module):
         return [{'keypoints': kpts[b, :nv[b]], 'scores': scores[b, :nv[b]], 'descriptors': desc[b, :nv[b]]}
                 for b in range(len(nv))]
 
-    def _detect_device(self, x, top_k=None, detection_threshold=None, cap=None):
+    def _detect_device(self, x, top_k=None, detection_threshold=None, cap=None, want_bf16=False):
         """Fixed-capacity device results, no read-back: kpts (B,top_k,2), scores (B,top_k),
-        desc (B,top_k,64), n_valid (B) int32, n_cand (B) int32, the NMS capacity used, H*W.
+        desc (B,top_k,64), n_valid (B) int32, n_cand (B) int32, the NMS capacity used, H*W
+        (+ with want_bf16 an eighth element: the descriptors rounded to bf16, (B,top_k,64) int16, for match_pairs_device).
         If n_cand.max() > capacity the candidate list was truncated (caller re-runs)."""
         if top_k is None: top_k = self.top_k
         if detection_threshold is None: detection_threshold = self.detection_threshold
@@ -341,10 +342,12 @@ class XFeat(nn.Module):
         feats, _, heat, rel, inv = self.net.backbone(x, want_logits=False, want_heat=True, want_invnorm=True)
         if cap is None:
             cap = min(H * W, max(int(top_k), (H * W) // 8))
-        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1, inv)
+        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1, inv, want_bf16)
+        if want_bf16:
+            return out[0], out[1], out[2], out[3], out[4], cap, H * W, out[5]
         return out[0], out[1], out[2], out[3], out[4], cap, H * W
 
-    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh, inv=None):
+    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh, inv=None, want_bf16=False):
         lib = _lib.load()
         dev = feats.device
         kpts = torch.empty((B, top_k, 2), dtype=torch.float32, device=dev)
@@ -352,11 +355,12 @@ class XFeat(nn.Module):
         desc = torch.empty((B, top_k, 64), dtype=torch.float32, device=dev)
         n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
         n_cand = torch.empty((B,), dtype=torch.int32, device=dev)
+        d16 = torch.empty((B, top_k, 64), dtype=torch.int16, device=dev) if want_bf16 else None
         ws, n = self.net.workspace("detect", lib.xfh_detect_workspace_bytes(B, H, W, top_k, cap))
         _lib.check(lib.xfh_detect_sparse(self.net.handle(), _ptr(heat), _ptr(rel), _ptr(feats), _ptr(inv), B, H, W, float(thr), top_k, cap,
-                                         float(rw), float(rh), _ptr(kpts), _ptr(scores), _ptr(desc), _ptr(n_valid),
+                                         float(rw), float(rh), _ptr(kpts), _ptr(scores), _ptr(desc), _ptr(d16), _ptr(n_valid),
                                          _ptr(n_cand), _ptr(ws), n, _stream()), "xfh_detect_sparse")
-        return kpts, scores, desc, n_valid, n_cand
+        return kpts, scores, desc, n_valid, n_cand, d16
 
     # ------------------------------------------------------------------------------------------
     # semi-dense
@@ -548,14 +552,15 @@ class XFeat(nn.Module):
         idx1 = torch.empty((P, N1), dtype=torch.int64, device=f1.device)
         n = torch.empty((P,), dtype=torch.int32, device=f1.device)
         ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, N1, N2))
-        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(f1), N1 * 64, _ptr(f2), N2 * 64, None, None, 0, 0, P, N1, N2,
+        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(f1), N1 * 64, _ptr(f2), N2 * 64, None, None, None, None, 0, 0, P, N1, N2,
                                      float(min_cossim), _ptr(idx0), _ptr(idx1), _ptr(n), _ptr(ws), nb, _stream()),
                    "xfh_match_mnn")
         return idx0, idx1, n
 
-    def match_pairs_device(self, desc, n_valid, min_cossim=-1):
+    def match_pairs_device(self, desc, n_valid, min_cossim=-1, desc_bf16=None):
         """Match consecutive frames (2i, 2i+1) of one detection batch without any read-back.
-        desc (B,top_k,64), n_valid (B) int32 as returned by _detect_device; B even.
+        desc (B,top_k,64), n_valid (B) int32 as returned by _detect_device; B even.  desc_bf16: the bf16 copy the same
+        _detect_device(want_bf16=True) call returned (saves the matcher's conversion pass; results identical).
         Returns idx0, idx1 (B/2, top_k) int64 and n_matches (B/2) int32, all on the device."""
         self._require_gpu()
         lib = _lib.load()
@@ -567,7 +572,11 @@ class XFeat(nn.Module):
         n = torch.empty((P,), dtype=torch.int32, device=desc.device)
         ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, K, K))
         d2 = desc[1]
-        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(desc), 2 * K * 64, _ptr(d2), 2 * K * 64, _ptr(n_valid), _ptr(n_valid),
+        b1 = b2 = None
+        if desc_bf16 is not None:
+            assert desc_bf16.shape == desc.shape and desc_bf16.dtype == torch.int16 and desc_bf16.is_contiguous()
+            b1, b2 = desc_bf16, desc_bf16[1]
+        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(desc), 2 * K * 64, _ptr(d2), 2 * K * 64, _ptr(b1), _ptr(b2), _ptr(n_valid), _ptr(n_valid),
                                      2, 1, P, K, K, float(min_cossim), _ptr(idx0), _ptr(idx1), _ptr(n), _ptr(ws), nb,
                                      _stream()), "xfh_match_mnn")
         return idx0, idx1, n
@@ -585,7 +594,7 @@ class XFeat(nn.Module):
         ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, K, K))
         # one count array so that a single (stride, offset) addresses both sides
         nv = torch.cat([n_a.to(torch.int32), n_b.to(torch.int32)]).contiguous()
-        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(desc_a), K * 64, _ptr(desc_b), K * 64, _ptr(nv), _ptr(nv),
+        _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(desc_a), K * 64, _ptr(desc_b), K * 64, None, None, _ptr(nv), _ptr(nv),
                                      1, P, P, K, K, float(min_cossim), _ptr(idx0), _ptr(idx1), _ptr(n), _ptr(ws), nb,
                                      _stream()), "xfh_match_mnn")
         return idx0, idx1, n

@@ -142,13 +142,14 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
  *   rw, rh           original/processed size ratios (key-points are returned multiplied by them)
  * outputs (fixed capacity, entries past n_valid[b] are zero-filled):
  *   kpts (B,top_k,2) fp32 (x,y) ; scores (B,top_k) descending ; desc (B,top_k,64) unit norm
+ *   desc_bf16 (B,top_k,64) optional (may be NULL): the same descriptors rounded to bf16 (nearest-even), for xfh_match_mnn's filter sweeps
  *   n_valid (B) int32       = number of returned points with score > 0 (they form a prefix)
  *   n_candidates (B) int32  = NMS candidates found (uncapped)
  * ---------------------------------------------------------------------------------------- */
 size_t xfh_detect_workspace_bytes(int B, int H, int W, int top_k, int nms_capacity);
 int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats, const float* invnorm,
                       int B, int H, int W, float threshold, int top_k, int nms_capacity, float rw, float rh,
-                      float* kpts, float* scores, float* desc, int32_t* n_valid, int32_t* n_candidates,
+                      float* kpts, float* scores, float* desc, uint16_t* desc_bf16, int32_t* n_valid, int32_t* n_candidates,
                       void* workspace, size_t workspace_bytes, xfh_stream stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -171,6 +172,9 @@ int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int
  *   n1/n2: DEVICE int32 arrays; pair p uses n1[p*n_stride] rows and n2[p*n_stride+n_offset2]
  *          rows (so the n_valid array of xfh_detect_sparse can be passed for consecutive
  *          frame pairs with n_stride=2, n_offset2=1).  NULL => all N1 / N2 rows.
+ *   d1_bf16/d2_bf16: optional (both or neither): bf16 round-to-nearest-even copies of d1 / d2 with the same pair strides (in elements, multiples
+ *          of 8), valid ONLY for L2-normalised rows (|row| <= 1.00001) -- what xfh_detect_sparse's desc_bf16 holds.  They spare the call its
+ *          conversion pass; every decision is still taken on exact fp32 dot products of d1 / d2 (results identical with or without them).
  *   min_cossim <= 0 disables the similarity test (reference: `if min_cossim > 0`).
  *   pair_stride1/2 are in floats.
  * outputs: idx0, idx1 (P,N1) int64 (idx0 ascending), n_matches (P) int32.
@@ -178,6 +182,7 @@ int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int
  * ---------------------------------------------------------------------------------------- */
 size_t xfh_match_workspace_bytes(int P, int N1, int N2);
 int xfh_match_mnn(xfh_handle h /* may be NULL */, const float* d1, size_t pair_stride1, const float* d2, size_t pair_stride2,
+                  const uint16_t* d1_bf16, const uint16_t* d2_bf16,
                   const int32_t* n1, const int32_t* n2, int n_stride, int n_offset2,
                   int P, int N1, int N2, float min_cossim,
                   int64_t* idx0, int64_t* idx1, int32_t* n_matches,

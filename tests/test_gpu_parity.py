@@ -817,3 +817,21 @@ def test_sizes_beyond_the_round1_limits(xf, sd):
         i0, i1 = xf.match(a_.cuda(), b_.cuda(), min_cossim=-1)
         o0, o1 = O.match_mnn(a_, b_, -1)
         assert torch.equal(i0.cpu(), o0) and torch.equal(i1.cpu(), o1)
+
+
+def test_match_with_bf16_copies_from_the_descriptor_kernel(xf):
+    """xfh_detect_sparse's optional desc_bf16 output handed to xfh_match_mnn (no conversion pass inside the matcher): bit pattern = RNE of the
+    fp32 descriptors, match lists identical to the plain call."""
+    x = fixtures.texture_images(4, 192, 256, seed=61).cuda()
+    kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x, 1024, 0.05, want_bf16=True)
+    ref16 = de.to(torch.bfloat16).view(torch.int16)
+    assert d16.dtype == torch.int16 and torch.equal(d16, ref16)
+    a = xf.match_pairs_device(de, nv, -1)
+    b = xf.match_pairs_device(de, nv, -1, d16)
+    c = xf.match_pairs_device(de, nv, 0.5, d16)
+    d = xf.match_pairs_device(de, nv, 0.5)
+    for u, v in ((a, b), (c, d)):
+        assert torch.equal(u[2], v[2])
+        for p in range(2):
+            n = int(u[2][p])
+            assert n > 50 and torch.equal(u[0][p, :n], v[0][p, :n]) and torch.equal(u[1][p, :n], v[1][p, :n])
