@@ -227,21 +227,48 @@ __device__ inline unsigned long long score_key(const ScoreSrc& s, int b, int cap
 __device__ inline void cswap(unsigned long long& a, unsigned long long& b, bool up) {
     if ((a > b) == up) { const unsigned long long t = a; a = b; b = t; }
 }
+// Value of lane (lane ^ LS) without the LDS crossbar round trip of ds_bpermute (__shfl_xor): DPP quad permutes / row shifts / row rotate for
+// 1, 2, 4, 8, the gfx950 permlane swaps for 16 and 32 -- plain VALU moves, no address register, no lgkmcnt wait.
+template <int LS>
+__device__ inline unsigned xchg_u32(unsigned v, int lane) {
+    if constexpr (LS == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+    else if constexpr (LS == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+    else if constexpr (LS == 4) {
+        const unsigned up = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, true);               // row_shl:4: lane i <- i + 4
+        const unsigned dn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);               // row_shr:4: lane i <- i - 4
+        return (lane & 4) ? dn : up;
+    } else if constexpr (LS == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+    else if constexpr (LS == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);      // r[0] = rows {0,0,2,2}, r[1] = rows {1,1,3,3}
+        return (lane & 16) ? r[0] : r[1];
+    } else return xhalf_u32(v);
+}
+template <int LS>
+__device__ inline unsigned long long xchg_u64(unsigned long long v, int lane) {
+    return ((unsigned long long)xchg_u32<LS>((unsigned)(v >> 32), lane) << 32) | xchg_u32<LS>((unsigned)v, lane);
+}
+template <int LS>
+__device__ inline void bitonic_lane_step(unsigned long long (&v)[4], int base, int lane, int size) {
+    const bool lower = (lane & LS) == 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = base + 4 * lane + e;
+        const bool up = (i & size) == 0;
+        const unsigned long long other = xchg_u64<LS>(v[e], lane);
+        // the lower index of the pair keeps the smaller key when the run ascends
+        const bool keep_min = lower == up;
+        v[e] = keep_min ? (v[e] < other ? v[e] : other) : (v[e] > other ? v[e] : other);
+    }
+}
 // strides min(size/2, 128) .. 1 of the merge phase `size` on the wave's 4 keys per lane (block base index `base`)
 __device__ inline void bitonic_wave_steps(unsigned long long (&v)[4], int base, int lane, int size) {
-    for (int stride = min(size >> 1, 128); stride >= 4; stride >>= 1) {
-        const int ls = stride >> 2;                                // partner lane distance
-        const bool lower = (lane & ls) == 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int i = base + 4 * lane + e;
-            const bool up = (i & size) == 0;
-            const unsigned long long other = shfl_xor_u64(v[e], ls);
-            // the lower index of the pair keeps the smaller key when the run ascends
-            const bool keep_min = lower == up;
-            v[e] = keep_min ? (v[e] < other ? v[e] : other) : (v[e] > other ? v[e] : other);
-        }
-    }
+    const int top = min(size >> 1, 128);                           // partner lane distance = stride / 4
+    if (top >= 128) bitonic_lane_step<32>(v, base, lane, size);
+    if (top >= 64) bitonic_lane_step<16>(v, base, lane, size);
+    if (top >= 32) bitonic_lane_step<8>(v, base, lane, size);
+    if (top >= 16) bitonic_lane_step<4>(v, base, lane, size);
+    if (top >= 8) bitonic_lane_step<2>(v, base, lane, size);
+    if (top >= 4) bitonic_lane_step<1>(v, base, lane, size);
     const bool up = ((base + 4 * lane) & size) == 0;               // the 4 keys of a lane share the direction for size >= 4
     if (size >= 4) { cswap(v[0], v[2], up); cswap(v[1], v[3], up); }
     if (size >= 4) { cswap(v[0], v[1], up); cswap(v[2], v[3], up); }
