@@ -233,6 +233,19 @@ static int check_ws(const void* ws, size_t have, size_t need) {
     return XFH_OK;
 }
 
+static uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 // ------------------------------------------------------------------------------------------
 // exported functions
 // ------------------------------------------------------------------------------------------
@@ -260,7 +273,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     std::vector<float> blob;
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
     const size_t zoff = reserve(256);
-    struct Off { size_t oihw, kc, kcp, bias, wino; bool has_wino; } coff[L_NUM];
+    struct Off { size_t oihw, kc, kcp, bias, wino, bx; bool has_wino, has_bx; } coff[L_NUM];
     struct FOff { size_t w, b; } foff[5];
     int ai = 0;
     for (int li = 0; li < L_NUM; ++li) {
@@ -312,6 +325,28 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                         }
                 }
         }
+        // bf16 MFMA path with three-way split operands (k_conv_bx.hip): w = wh + wm + wl, each bf16 (round to nearest even), in
+        // operand order [step][split][lane = half * 32 + cout][8]: K group kg = 2 step + half = (tap, 8-channel group)
+        coff[li].has_bx = c.ks == 3 && c.stride == 1 && c.cin == 24 && c.cout <= 32;
+        if (coff[li].has_bx) {
+            const int cg = c.cin / 8, nstep = bx_steps(c.cin);
+            coff[li].bx = reserve((size_t)nstep * 3 * 64 * 4);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
+            for (int s = 0; s < nstep; ++s)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int o = lane & 31, kg = 2 * s + (lane >> 5);
+                    for (int i = 0; i < 8; ++i) {
+                        float v = 0.f;
+                        if (o < c.cout && kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
+                        const uint16_t h = bf16_rne(v);
+                        const float r1 = v - bf16_float(h);
+                        const uint16_t m = bf16_rne(r1);
+                        const float r2 = r1 - bf16_float(m);
+                        const uint16_t q[3] = {h, m, bf16_rne(r2)};
+                        for (int sp = 0; sp < 3; ++sp) dst[(((size_t)s * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                    }
+                }
+        }
     }
     for (int fi = 0; fi < 5; ++fi) {
         const FineSpec& f = kFine[fi];
@@ -357,6 +392,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.w_kcp = ctx->blob + coff[li].kcp;
         w.bias = ctx->blob + coff[li].bias;
         w.w_wino = coff[li].has_wino ? ctx->blob + coff[li].wino : nullptr;
+        w.w_bx = coff[li].has_bx ? ctx->blob + coff[li].bx : nullptr;
     }
     ctx->nw.zeros = ctx->blob + zoff;
     for (int fi = 0; fi < 5; ++fi) {
@@ -415,8 +451,12 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     // A/B runs: XFH_WINO=0 forces the direct kernel, XFH_WINO=1 keeps the fused pairs on the direct kernel.
     static int use_wino = -1;
     if (use_wino < 0) { const char* e = getenv("XFH_WINO"); use_wino = e ? atoi(e) : 2; }
+    // 24-channel 3x3/s1 layers: bf16 MFMAs on three-way split operands (k_conv_bx.hip); XFH_BX=0 keeps them on the Winograd kernel
+    static int use_bx = -1;
+    if (use_bx < 0) { const char* e = getenv("XFH_BX"); use_bx = e ? atoi(e) : 1; }
     int rc = -1;
-    if (use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
+    if (use_bx && c.w_bx && !c2 && !nhwc) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);
+    if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
     const int cl = c2 ? c2->cout : c.cout;
     double bytes = 4.0 * ((double)B * c.cin * Hin * Win + (double)B * cl * Hout * Wout + (double)c.cin * c.cout * c.ks * c.ks);
@@ -509,6 +549,10 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
     if (variant == 1) {
         launch_conv_generic(c, in, B, Hin, Win, out, st);
         return check_launch("xfh_conv_layer(generic)");
+    }
+    if (variant == 10) {
+        if (launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no split-bf16 instantiation for layer %d", layer);
+        return check_launch("xfh_conv_layer(split bf16)");
     }
     if (variant >= 2) {
         if (launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, variant - 1, h->trace))

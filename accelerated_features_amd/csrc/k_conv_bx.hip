@@ -1,0 +1,287 @@
+// 3x3 stride-1 convolution of the 24-channel layers (block2.0 / block2.1; modules/model.py:56-59) on the bf16 matrix cores
+// with three-way split operands -- fp32 arithmetic carried by bf16 MFMAs.
+//
+// Why: gfx950 issues v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) at 16x the rate of v_mfma_f32_32x32x2_f32 (64 cycles, K = 2).
+// An fp32 number is the exact sum of three bf16 numbers up to 2^-27 relative:  x = xh + xm + xl  with  xh = bf16(x),
+// xm = bf16(x - xh), xl = bf16(x - xh - xm)  (round to nearest even; both subtractions are exact in fp32).  A product
+//     w x  =  wh xh + (wh xm + wm xh) + (wh xl + wl xh + wm xm)  +  O(2^-25 |w x|)
+// needs six bf16 MFMAs; every bf16 x bf16 product is exact in the fp32 accumulator, so the result carries the rounding of an fp32
+// dot product (the three dropped cross terms are below one fp32 ulp of the product).  Six K=16 MFMAs cost 192 pipe cycles against
+// 512 for the same K on the f32 instruction -- as a direct convolution that is 0.84x the matrix time of Winograd F(2x2,3x3) on f32
+// MFMAs, with no input / output transforms, no cross-wave exchange and one barrier pair per tile.
+//
+// Layout: a persistent workgroup (4 waves, two workgroups per CU) walks 8x32-pixel output tiles.
+//   * staging: thread (pixel, 8-channel group) loads its 8 raw fp32 values from the NCHW planes (32 loads in flight per thread),
+//     splits them and writes three 16-byte rows into LDS:  [pixel of the 10x34 halo tile][split][24 channels] bf16 (144 B per pixel:
+//     the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots);
+//   * GEMM: M = cout (A = weights), N = 32 pixels of one output row (B), K = (tap, channel) in 8-channel groups, two groups per
+//     K=16 step (lane half 0 / 1), 27 groups + 1 zero group = 14 steps.  The split weights of ALL steps live in registers in operand
+//     order (168 VGPRs, loaded once per workgroup); a wave owns two output rows (two accumulators), reads three 16-byte B rows per
+//     row and step and issues 6 MFMAs on them: 48 B of LDS per 192 pipe cycles per wave = half the LDS bandwidth of a CU;
+//   * D: lane (pixel, half) holds couts (r&3) + 8 (r>>2) + 4 half: bias, ReLU, one coalesced 128-byte store per cout and half-wave.
+#include "kernels.hpp"
+#include <cstdlib>
+
+namespace xfh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct BxArgs {
+    const float* in;
+    const uint4* wfrag;        // [step][split][64 lanes] 8 bf16 each (api.hip: pack_bx_weights)
+    const float* bias;
+    float* out;
+    int relu, H, W, B, tiles_x, tiles;
+    int lag;                   // first-tile delay of the second workgroup of a CU, in units of 512 cycles
+    long long* trace;          // debug: 6 s_memtime stamps per tile, 10 tiles, per workgroup (NULL in production)
+};
+
+__device__ inline unsigned pk_bf16_rne(float a, float b) {      // v_cvt_pk_bf16_f32: a -> low half
+    const f32x2 v = {a, b};
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(unsigned, r);
+}
+// (a, b) -> packed bf16 pairs h, m, l with a = ah + am + al (+ 2^-27 |a|)
+__device__ inline void split3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16_rne(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pk_bf16_rne(ra, rb);
+    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+    l = pk_bf16_rne(sa, sb);
+}
+
+template <int CIN, int COUT>
+struct BxCfg {
+    static constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
+    static constexpr int CG = CIN / 8, PIXB = 3 * CIN * 2, SPLB = CIN * 2;      // bytes per pixel / per split row
+    static constexpr int KG = 9 * CG, NSTEP = (KG + 1) / 2;
+    static constexpr int NITEM = NPIX * CG, NIT = (NITEM + 255) / 256;
+    static constexpr bool WM_LDS = true;
+    static constexpr int TILE_BYTES = NPIX * PIXB, WL_BYTES = NSTEP * 64 * 16;
+    static constexpr int BIAS_OFF = TILE_BYTES + (WM_LDS ? 2 : 1) * WL_BYTES, LDS_BYTES = BIAS_OFF + 32 * 4;
+    static_assert(CIN % 8 == 0 && COUT <= 32, "one cout block, 8-channel groups");
+    // byte offset of K group kg (tap, channel group) relative to the lane's own pixel
+    static constexpr int koff(int kg) {
+        const int g = kg < KG ? kg : KG - 1;       // the zero group re-reads the last one (finite values x zero weights)
+        const int tap = g / CG, cg = g % CG;
+        return ((tap / 3) * IW + tap % 3) * PIXB + cg * 16;
+    }
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_bx_kernel(BxArgs a) {
+    using Cfg = BxCfg<CIN, COUT>;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, IW = Cfg::IW, NPIX = Cfg::NPIX, CG = Cfg::CG, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB;
+    constexpr int NSTEP = Cfg::NSTEP, NIT = Cfg::NIT;
+    constexpr bool WM_LDS = Cfg::WM_LDS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t HW = (size_t)a.H * a.W;
+
+    // split weights in operand order: lane (cout l31, half) holds K group 2 s + half of every step.  wh (3 uses per step and row)
+    // stays in registers for the whole kernel; wm (2 uses) and wl (1) are read from LDS once per step: all three in registers (168)
+    // leave hipcc two fragment buffers and an lgkmcnt(0) in front of every MFMA group, and no room for the prefetched next tile
+    bf16x8 wf[NSTEP][WM_LDS ? 1 : 2];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+        for (int q = 0; q < (WM_LDS ? 1 : 2); ++q) wf[s][q] = __builtin_bit_cast(bf16x8, a.wfrag[(s * 3 + q) * 64 + lane]);
+    unsigned char* wl_lds = smem_bx + Cfg::TILE_BYTES;            // [step][lane] 16 B
+    unsigned char* wm_lds = wl_lds + Cfg::WL_BYTES;
+    for (int s = wave; s < NSTEP; s += 4) {
+        *reinterpret_cast<uint4*>(wl_lds + (s * 64 + lane) * 16) = a.wfrag[(s * 3 + 2) * 64 + lane];
+        if (WM_LDS) *reinterpret_cast<uint4*>(wm_lds + (s * 64 + lane) * 16) = a.wfrag[(s * 3 + 1) * 64 + lane];
+    }
+    // pin the wait for the weight loads here: hipcc otherwise keeps an s_waitcnt vmcnt(32 + k) in front of each step's first use INSIDE
+    // the tile loop, where the counter also holds the previous tile's stores (the MFMA loop would wait for their write acks)
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+        for (int q = 0; q < (WM_LDS ? 1 : 2); ++q) asm volatile("" : "+v"(wf[s][q]));
+    // the bias lives in LDS too: a global load in the epilogue would wait (vmcnt counts in order) for the stores issued before it
+    float* bias_lds = reinterpret_cast<float*>(smem_bx + Cfg::BIAS_OFF);
+    if (tid < 32) bias_lds[tid] = a.bias[tid];
+
+    // staging items of this thread: item = cg * NPIX + pixel -> (tile row, tile column, LDS byte offset); cg >= CG: no item
+    int it_rc[NIT], it_lds[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int item = tid + 256 * i;
+        const int cg = item / NPIX, pix = item - cg * NPIX;
+        const int r = pix / IW, c = pix - r * IW;
+        it_rc[i] = cg < CG ? (cg << 16) | (r << 8) | c : -1;
+        it_lds[i] = pix * PIXB + cg * 16;
+    }
+    const int lane_off = (2 * wave * IW + l31) * PIXB;
+    const int total = a.tiles * a.B;
+    long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
+    int tix = 0;
+#define BX_STAMP(k) { if (tr && tix < 10) tr[tix * 6 + (k)] = __builtin_amdgcn_s_memtime(); }
+
+    auto tile_of = [&](int vid, int& b, int& oy0, int& ox0) {
+        int tile;
+        xcd_group_map(vid, a.tiles, a.B, b, tile);          // vid < tiles * B: never a padding id
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        oy0 = tyi * TH; ox0 = txi * TW;
+    };
+    // raw fp32 values of a tile: 8 channels of one pixel per item, all loads of a thread in flight together; out-of-image pixels
+    // carry an out-of-range offset (the buffer load returns the zero padding)
+    float v[NIT][8];
+    auto issue_loads = [&](int vid) {
+        int b, oy0, ox0;
+        tile_of(vid, b, oy0, ox0);
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * CIN * HW), 0, (int)(CIN * HW * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int cg = it_rc[i] >> 16, gy = oy0 - 1 + ((it_rc[i] >> 8) & 0xff), gx = ox0 - 1 + (it_rc[i] & 0xff);
+            const bool ok = it_rc[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int voff = ok ? (int)((((size_t)cg * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[i][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)(k * HW * 4), 0));
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            uint4 h, m, l;
+            split3(v[i][0], v[i][1], h.x, m.x, l.x);
+            split3(v[i][2], v[i][3], h.y, m.y, l.y);
+            split3(v[i][4], v[i][5], h.z, m.z, l.z);
+            split3(v[i][6], v[i][7], h.w, m.w, l.w);
+            if (it_rc[i] >= 0) {
+                unsigned char* p = smem_bx + it_lds[i];
+                *reinterpret_cast<uint4*>(p) = h;
+                *reinterpret_cast<uint4*>(p + SPLB) = m;
+                *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+            }
+        }
+    };
+
+    int vid = blockIdx.x;
+    if (vid >= total) return;
+    // Two workgroups share a CU and keep whatever phase lag they start with (a lag x between their MFMA phases is preserved from
+    // tile to tile: period = 2 M + O - x for M cycles of MFMA and O cycles of staging + stores per tile).  Launched together they
+    // run in phase: both on the matrix pipe, then both off it.  The workgroup that was allocated second on its CU (LDS base != 0)
+    // starts half a period late, so one stages / stores while the other one multiplies.
+    {
+        unsigned lds_alloc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc));
+        if (tr) tr[62] = lds_alloc;
+        if ((lds_alloc & 0xffu) != 0)
+            for (int i = 0; i < a.lag; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+    issue_loads(vid);
+    for (;;) {
+        int b, oy0, ox0;
+        tile_of(vid, b, oy0, ox0);
+        BX_STAMP(0)
+        stage_write();
+        BX_STAMP(1)
+        __syncthreads();
+        BX_STAMP(2)
+        const int nvid = vid + (int)gridDim.x;
+        if (nvid < total) issue_loads(nvid);          // the next tile's loads fly under this tile's MFMAs
+        // ---- 14 K steps x 2 rows x 6 MFMAs ---------------------------------------------------------------------------
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // operands of step s+1 are read while the MFMAs of step s issue (two register sets, pinned: left alone hipcc sinks the reads
+        // in front of their first use).  The K groups of the two lane halves differ by one of three byte deltas -> three base registers.
+        struct Frag { bf16x8 x[2][3]; bf16x8 wl, wm; };
+        Frag f[2];
+        auto load = [&](int s, Frag& o) {
+            const int k0 = Cfg::koff(2 * s), dk = Cfg::koff(2 * s + 1) - k0;
+            const unsigned char* p = smem_bx + (lane_off + half * dk) + k0;
+            o.wl = *reinterpret_cast<const bf16x8*>(wl_lds + (s * 64 + lane) * 16);
+            if (WM_LDS) o.wm = *reinterpret_cast<const bf16x8*>(wm_lds + (s * 64 + lane) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) o.x[j][q] = *reinterpret_cast<const bf16x8*>(p + j * IW * PIXB + q * SPLB);
+        };
+        load(0, f[0]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const Frag& c = f[s & 1];
+            if (s + 1 < NSTEP) load(s + 1, f[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 wh = wf[s][0], wm = WM_LDS ? c.wm : wf[s][WM_LDS ? 0 : 1];
+            // small terms first; the two rows alternate (independent accumulators)
+#define BX_MM(A, Q) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c.x[0][Q], acc[0], 0, 0, 0); acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c.x[1][Q], acc[1], 0, 0, 0); }
+            BX_MM(c.wl, 0) BX_MM(wh, 2) BX_MM(wm, 1) BX_MM(wm, 0) BX_MM(wh, 1) BX_MM(wh, 0)
+#undef BX_MM
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        BX_STAMP(3)
+        // ---- bias, ReLU, store ------------------------------------------------------------------------------------------
+        const int ox = ox0 + l31;
+        float bs[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 t = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * half);
+            bs[4 * g4] = t.x; bs[4 * g4 + 1] = t.y; bs[4 * g4 + 2] = t.z; bs[4 * g4 + 3] = t.w;
+        }
+        // buffer stores: one address dword per lane instead of two (a store's issue time is its VGPR traffic); lanes outside the image
+        // carry an out-of-range offset and are dropped
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * COUT * HW), 0, (int)(COUT * HW * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oy = oy0 + 2 * wave + j;
+            const int voff = oy < a.H && ox < a.W ? (int)(((size_t)(4 * half) * HW + (size_t)oy * a.W + ox) * 4) : (int)0x80000000;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co0 = (r & 3) + 8 * (r >> 2);          // cout of lane half 0; half 1 holds co0 + 4
+                if (co0 < COUT) {                                // compile-time (r < 12 for 24 channels)
+                    float y = acc[j][r] + bs[r];
+                    if (a.relu) y = fmaxf(y, 0.f);
+                    const bool okc = COUT % 8 == 0 || co0 + 4 * half < COUT;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, okc ? voff : (int)0x80000000, (int)(co0 * HW * 4), 0);
+                }
+            }
+        }
+        BX_STAMP(4)
+        if (nvid >= total) break;
+        __syncthreads();         // every wave is done with the tile before the next one is staged
+        BX_STAMP(5)
+        ++tix;
+        vid = nvid;
+    }
+#undef BX_STAMP
+}
+
+template <int CIN, int COUT>
+static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
+    using Cfg = BxCfg<CIN, COUT>;
+    if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
+    BxArgs a;
+    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    static int lag = -1;
+    if (lag < 0) { const char* e = getenv("XFH_BX_LAG"); lag = e ? atoi(e) : 11; }
+    a.lag = lag;
+    a.tiles_x = ceil_div(W, Cfg::TW);
+    a.tiles = a.tiles_x * ceil_div(H, Cfg::TH);
+    static unsigned attr_done = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx_kernel<CIN, COUT>), Cfg::LDS_BYTES, attr_done);
+    const int total = xcd_grid_size(a.tiles, B);
+    int grid = 2 * num_cus();            // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
+    if (grid > total) grid = total;
+    conv_bx_kernel<CIN, COUT><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+    return 0;
+}
+
+int bx_steps(int cin) { return (9 * (cin / 8) + 1) / 2; }
+
+int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
+    if (c.ks != 3 || c.stride != 1 || !c.w_bx) return -1;
+    if (c.cin == 24 && c.cout == 24) return run_bx<24, 24>(c, in, B, H, W, out, st, trace);
+    return -1;
+}
+
+}  // namespace xfh

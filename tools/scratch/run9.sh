@@ -1,4 +1,3 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-python bench.py --steps 20 --warmup 5 --cpu-seconds 6 2>&1 | grep "^{" > gpurun_out/bench_r02.json; cut -c1-3000 gpurun_out/bench_r02.json
-bash tools/gpu_traffic.sh > gpurun_out/traffic.log 2>&1; tail -40 gpurun_out/traffic.log
+for d in 0 1 2 4 8 3 5 6 10 12 14 15; do XFH_BX_DBG=$d timeout 100 python tools/bx_time.py 2>&1 | grep DBG; done
