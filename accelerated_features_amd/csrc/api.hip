@@ -327,8 +327,16 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         }
         // bf16 MFMA path with three-way split operands (k_conv_bx.hip): w = wh + wm + wl, each bf16 (round to nearest even), in
         // operand order [step][split][lane = half * 32 + cout][8]: K group kg = 2 step + half = (tap, 8-channel group)
-        coff[li].has_bx = c.ks == 3 && c.stride == 1 && c.cin == 24 && c.cout <= 32;
-        if (coff[li].has_bx) {
+        auto split3 = [&](float v, uint16_t (&q)[3]) {
+            q[0] = bf16_rne(v);
+            const float r1 = v - bf16_float(q[0]);
+            q[1] = bf16_rne(r1);
+            q[2] = bf16_rne(r1 - bf16_float(q[1]));
+        };
+        const bool bx24 = c.ks == 3 && c.stride == 1 && c.cin == 24 && c.cout <= 32;
+        const bool bx64 = c.ks == 3 && c.stride == 1 && c.cin == 64 && c.cout == 64;
+        coff[li].has_bx = bx24 || bx64;
+        if (bx24) {
             const int cg = c.cin / 8, nstep = bx_steps(c.cin);
             coff[li].bx = reserve((size_t)nstep * 3 * 64 * 4);
             uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
@@ -338,14 +346,26 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                     for (int i = 0; i < 8; ++i) {
                         float v = 0.f;
                         if (o < c.cout && kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
-                        const uint16_t h = bf16_rne(v);
-                        const float r1 = v - bf16_float(h);
-                        const uint16_t m = bf16_rne(r1);
-                        const float r2 = r1 - bf16_float(m);
-                        const uint16_t q[3] = {h, m, bf16_rne(r2)};
+                        uint16_t q[3];
+                        split3(v, q);
                         for (int sp = 0; sp < 3; ++sp) dst[(((size_t)s * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                     }
                 }
+        }
+        if (bx64) {      // [cin/16][dy][dx][cout block][split][lane = half * 32 + cout][8]: channel = 16 chunk + 8 half + i
+            const int nch = c.cin / 16;
+            coff[li].bx = reserve((size_t)nch * 9 * 2 * 3 * 64 * 4);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
+            for (int ch = 0; ch < nch; ++ch)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int cb = 0; cb < 2; ++cb)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 8; ++i) {
+                                const int o = cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
+                                uint16_t q[3];
+                                split3(blob[coff[li].oihw + ((size_t)o * c.cin + ci) * 9 + tap], q);
+                                for (int sp = 0; sp < 3; ++sp) dst[(((((size_t)ch * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                            }
         }
     }
     for (int fi = 0; fi < 5; ++fi) {
@@ -455,7 +475,10 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     static int use_bx = -1;
     if (use_bx < 0) { const char* e = getenv("XFH_BX"); use_bx = e ? atoi(e) : 1; }
     int rc = -1;
-    if (use_bx && c.w_bx && !c2 && !nhwc) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);
+    if (use_bx && c.w_bx && !c2 && !nhwc) {
+        if (c.cin == 24) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);
+        else if (use_bx & 2) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);
+    }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
     const int cl = c2 ? c2->cout : c.cout;
@@ -551,7 +574,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
         return check_launch("xfh_conv_layer(generic)");
     }
     if (variant == 10) {
-        if (launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no split-bf16 instantiation for layer %d", layer);
+        if (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace) : launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no split-bf16 instantiation for layer %d", layer);
         return check_launch("xfh_conv_layer(split bf16)");
     }
     if (variant >= 2) {

@@ -20,14 +20,10 @@
 //     row and step and issues 6 MFMAs on them: 48 B of LDS per 192 pipe cycles per wave = half the LDS bandwidth of a CU;
 //   * D: lane (pixel, half) holds couts (r&3) + 8 (r>>2) + 4 half: bias, ReLU, one coalesced 128-byte store per cout and half-wave.
 #include "kernels.hpp"
+#include "bx_split.hpp"
 #include <cstdlib>
 
 namespace xfh {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct BxArgs {
     const float* in;
@@ -38,20 +34,6 @@ struct BxArgs {
     int lag;                   // first-tile delay of the second workgroup of a CU, in units of 512 cycles
     long long* trace;          // debug: 6 s_memtime stamps per tile, 10 tiles, per workgroup (NULL in production)
 };
-
-__device__ inline unsigned pk_bf16_rne(float a, float b) {      // v_cvt_pk_bf16_f32: a -> low half
-    const f32x2 v = {a, b};
-    const bf16x2 r = __builtin_convertvector(v, bf16x2);
-    return __builtin_bit_cast(unsigned, r);
-}
-// (a, b) -> packed bf16 pairs h, m, l with a = ah + am + al (+ 2^-27 |a|)
-__device__ inline void split3(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-    h = pk_bf16_rne(a, b);
-    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-    m = pk_bf16_rne(ra, rb);
-    const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
-    l = pk_bf16_rne(sa, sb);
-}
 
 template <int CIN, int COUT>
 struct BxCfg {

@@ -1,0 +1,314 @@
+// 3x3 stride-1 convolution, 64 (or 128) -> 64 channels, on the bf16 matrix cores with three-way split operands (see k_conv_bx.hip for
+// the arithmetic: six v_mfma_f32_32x32x16_bf16 per K=16 carry an fp32 product sum).     block3.1, block4.1/.2, block_fusion.0/.1
+//
+// The 24-channel kernel keeps its weights in registers; here the split weights are 216 KiB, so both operands come from LDS:
+//   * a wave owns 2 pixel blocks x 2 cout blocks (four 32x32 accumulators): per K step 6 + 6 ds_read_b128 feed 24 MFMAs;
+//   * pixel block = 2 rows x 16 columns (lane l31 -> row l31 >> 4, column l31 & 15); a workgroup (4 waves) owns a 16x16 tile, or an
+//     8x16 "half tile" (one pixel block per wave).  The work list is cut in units of half tiles, so that every workgroup of the
+//     persistent grid gets the same number of units (VGA batch 64 at 1/8 scale: 2560 units = 5 per workgroup = two tiles and a half
+//     tile; whole tiles only would be 2.5 per workgroup: three rounds for half of the chip);
+//   * the input channels go through LDS in chunks of 16 = one K step per tap: [18 halo rows, 2048 B apart][18 pixels, 112 B apart]
+//     [split h, m, l][16 channels] bf16 -- 112 B = 7 x 16 B keeps the 16 lanes of every ds_read_b128 group on distinct banks, the
+//     256-B-multiple row pitch does the same for the second row of a pixel block.  Raw fp32 values are prefetched into registers one
+//     chunk ahead (also across tiles), split on the way into LDS;
+//   * the weights stream through a two-slot LDS ring by LDS-DMA, one slot = one tap row of one chunk (3 K steps, 18 KiB, in operand
+//     order [tap][cout block][split][lane]); the DMA of row r+1 is issued behind the barrier that opens row r;
+//   * two workgroups per CU (74 KiB of LDS each) overlap each other's barriers, staging and stores.
+#include "kernels.hpp"
+#include "bx_split.hpp"
+#include <cstdlib>
+#include <type_traits>
+
+namespace xfh {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct Bx64Args {
+    const float* in;
+    const void* wq;            // [cin/16][3 dy][3 dx][2 cout blocks][3 splits][64 lanes][8 bf16]   (api.hip)
+    const float* bias;
+    float* out;
+    int relu, H, W, B;
+    int ncols, nhr, upi;       // 16-column strips, 8-row half tiles per strip, units per image
+    long long* trace;
+};
+
+namespace bx64 {
+constexpr int XROWB = 2048, PIXB = 112, SPLB = 32, IW = 18, IH = 18;
+constexpr int X_BYTES = IH * XROWB;                    // 36864
+constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;      // 6 KiB per K step, 18 per slot
+constexpr int RING_OFF = X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, LDS_BYTES = BIAS_OFF + 64 * 4;
+constexpr int NQ = 6;                                   // aligned 4-pixel quads per halo row
+static_assert(IH * NQ * 2 <= 256, "one (row, quad, 8-channel group) item per thread");
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_bx64_kernel(Bx64Args a) {
+    using namespace bx64;
+    constexpr int NCH = CIN / 16, NROW = NCH * 3, COUT = 64;
+    static_assert(NROW % 2 == 0, "the ring slot of a row must not depend on the tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b64[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t HW = (size_t)a.H * a.W;
+    float* bias_lds = reinterpret_cast<float*>(smem_b64 + BIAS_OFF);
+    if (tid < 64) bias_lds[tid] = a.bias[tid];
+
+    // ---- this workgroup's units -----------------------------------------------------------------------------------------
+    // unit u of an image list = (image, 16-column strip, half-tile row), strips and rows fastest.  With a batch that is a multiple of
+    // 8 the images of XCD x are x, x + 8, ... (workgroup id & 7 = XCD): a strip's neighbours share an L2.
+    int u0, u1, img0, img_step;
+    {
+        const int G = (int)gridDim.x, g = (int)blockIdx.x;
+        if (xcd_swizzled(a.B) && (G & 7) == 0) {
+            const long long U = (long long)(a.B >> 3) * a.upi;
+            const int slot = g >> 3, nslot = G >> 3;
+            u0 = (int)(U * slot / nslot); u1 = (int)(U * (slot + 1) / nslot);
+            img0 = g & 7; img_step = 8;
+        } else {
+            const long long U = (long long)a.B * a.upi;
+            u0 = (int)(U * g / G); u1 = (int)(U * (g + 1) / G);
+            img0 = 0; img_step = 1;
+        }
+    }
+    if (u0 >= u1) return;
+    struct Tile { int b, y0, x0, full; };
+    auto tile_at = [&](int u, Tile& t) {      // returns the units consumed (2 = a full 16-row tile)
+        const int im = u / a.upi, rem = u - im * a.upi;
+        const int col = rem / a.nhr, hr = rem - col * a.nhr;
+        t.b = img0 + img_step * im; t.y0 = hr * 8; t.x0 = col * 16;
+        t.full = (u + 1 < u1 && hr + 1 < a.nhr) ? 1 : 0;
+        return 1 + t.full;
+    };
+
+    // ---- LDS-DMA of the weight stream (inline asm: hipcc would make every LDS read wait for all DMA it can see) -------------
+    auto make_rsrc = [](const void* p, unsigned bytes) {
+        const unsigned long long ba = (unsigned long long)p;
+        i32x4 r;
+        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ba);
+        r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ba >> 32) & 0xffffu));
+        r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+        r.w = 0x00020000;
+        return r;
+    };
+    const i32x4 rs_w = make_rsrc(a.wq, (unsigned)(NROW * SLOT_BYTES));
+    const int dma_voff = lane * 16;
+    auto lds_addr = [](const unsigned char* p) { return (unsigned)(size_t)(lptr_t)p; };
+    auto issue_row = [&](int r) __attribute__((always_inline)) {             // weights of row r (chunk r / 3, tap row r % 3) -> slot r & 1
+        for (int j = wave; j < NPIECE; j += 4) {
+            const unsigned m0v = lds_addr(smem_b64 + RING_OFF + (r & 1) * SLOT_BYTES + j * 1024);
+            const int soff = r * SLOT_BYTES + j * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(dma_voff), "s"(rs_w), "s"(soff) : "memory");
+        }
+    };
+    auto dma_barrier = [&]() {                // everything this workgroup has in flight has landed, for every wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // ---- raw fp32 values of one 16-channel chunk of a tile.  Item of a thread = 4 consecutive pixels x 8 channels: eight
+    // buffer_load_dwordx4 (one per channel plane) instead of 32 dword loads -- the texture addresser takes ~16 cycles per wave
+    // instruction whatever its width, and eight waves loading dword by dword kept it busy for 3 k cycles per chunk.  The halo row
+    // [x0 - 1, x0 + 17) is covered by the six aligned quads [x0 - 4, x0 + 20); W % 4 == 0 keeps every quad entirely inside or outside.
+    const bool has_item = tid < IH * NQ * 2;
+    const int it_g8 = tid / (IH * NQ), it_row = (tid - it_g8 * (IH * NQ)) / NQ, it_quad = tid % NQ;
+    float v[8][4];
+    int v_gx = 0;                             // first column of the quad in flight (the tail of a quad that straddles the right border is masked
+                                              // when it is consumed: touching the values where they are loaded would park a vmcnt(0) there)
+    auto issue_loads = [&](const Tile& t, int chunk) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.b * CIN * HW), 0, (int)(CIN * HW * sizeof(float)), 0x00020000);
+        const int nrow = t.full ? 18 : 10;
+        const int gy = t.y0 - 1 + it_row, gx = t.x0 - 4 + 4 * it_quad;
+        const bool ok = has_item && it_row < nrow && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        v_gx = gx;
+        const int voff = ok ? (int)((((size_t)it_g8 * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, (int)((chunk * 16 + k) * HW * 4), 0);
+            v[k][0] = __uint_as_float(q[0]); v[k][1] = __uint_as_float(q[1]); v[k][2] = __uint_as_float(q[2]); v[k][3] = __uint_as_float(q[3]);
+        }
+    };
+    // split3 works on the two neighbouring PIXELS of a loaded quad (adjacent registers of one dwordx4: pairing channels instead made
+    // hipcc re-arrange all 32 values with moves right behind the loads -- and wait for them there); v_perm_b32 then gathers the
+    // channel pairs of each pixel: 16 + 16 bits from two registers in one op.
+    auto stage_write = [&]() __attribute__((always_inline)) {
+        if (!has_item) return;
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            unsigned H[8], M[8], L[8];                     // {pixel 2 pp, pixel 2 pp + 1} of channel k
+            // beyond the right border (W % 4 != 0 only) the quad's tail holds the next row's first pixels: zero them as values, not in v
+            // (conditional stores into the array sent it to scratch memory)
+            const bool z0 = (a.W & 3) && v_gx + 2 * pp >= a.W, z1 = (a.W & 3) && v_gx + 2 * pp + 1 >= a.W;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float x0 = v[k][2 * pp], x1 = v[k][2 * pp + 1];
+                if (a.W & 3) { x0 = z0 ? 0.f : x0; x1 = z1 ? 0.f : x1; }
+                split3(x0, x1, H[k], M[k], L[k]);
+            }
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+                const int cc = 4 * it_quad + 2 * pp + e2 - 3;          // halo column of this pixel
+                if (cc < 0 || cc >= IW) continue;                     // (quad 0: its last pixel only; quad 5: its first only)
+                const unsigned sel = e2 ? 0x07060302u : 0x05040100u;
+                uint4 h, m, l;
+                h.x = __builtin_amdgcn_perm(H[1], H[0], sel); h.y = __builtin_amdgcn_perm(H[3], H[2], sel);
+                h.z = __builtin_amdgcn_perm(H[5], H[4], sel); h.w = __builtin_amdgcn_perm(H[7], H[6], sel);
+                m.x = __builtin_amdgcn_perm(M[1], M[0], sel); m.y = __builtin_amdgcn_perm(M[3], M[2], sel);
+                m.z = __builtin_amdgcn_perm(M[5], M[4], sel); m.w = __builtin_amdgcn_perm(M[7], M[6], sel);
+                l.x = __builtin_amdgcn_perm(L[1], L[0], sel); l.y = __builtin_amdgcn_perm(L[3], L[2], sel);
+                l.z = __builtin_amdgcn_perm(L[5], L[4], sel); l.w = __builtin_amdgcn_perm(L[7], L[6], sel);
+                unsigned char* p = smem_b64 + it_row * XROWB + cc * PIXB + it_g8 * 16;
+                *reinterpret_cast<uint4*>(p) = h;
+                *reinterpret_cast<uint4*>(p + SPLB) = m;
+                *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+            }
+        }
+    };
+
+    long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
+    int tix = 0;
+#define BX_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }      /* second tile of the workgroup: [0] start, per row r: [1+4r] staged / row start, [2+4r] barrier passed, [3+4r] DMA + loads issued, [4+4r] MFMAs issued; [50] stores issued, [51] end barrier */
+    struct Frag { bf16x8 x[2][3]; bf16x8 w[2][3]; };
+    const int lane_px = (l31 >> 4) * XROWB + (l31 & 15) * PIXB + half * 16;
+
+    // ---- one tile: NPB pixel blocks per wave (2 = 16x16 tile, 1 = 8x16 half tile).  Two instantiations of the whole tile body:
+    // accumulators that live across a branch between two tap-row variants were given a second register set and 64 moves per row.
+    auto do_tile = [&](auto NPBC, const Tile& cur, const Tile& nxt, bool has_next) __attribute__((always_inline)) {
+        constexpr int NPB = decltype(NPBC)::value;
+        f32x16 acc[NPB][2];                   // [pixel block][cout block]
+#pragma unroll
+        for (int j = 0; j < NPB; ++j)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][cb][r] = 0.f;
+        // block rows of this wave: full tile 2 w, 2 w + 1 ; half tile w
+        const int br0 = NPB == 2 ? 2 * wave : wave, br1 = 2 * wave + 1;
+        const int xb[2] = {2 * br0 * XROWB + lane_px, 2 * br1 * XROWB + lane_px};
+        for (int c = 0; c < NCH; ++c) {
+            if (c > 0) __syncthreads();        // every wave has finished the previous chunk's last tap row (the tile loop ends on a barrier)
+            stage_write();
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = c * 3 + dy;
+                BX_STAMP(1 + 4 * r)
+                dma_barrier();
+                BX_STAMP(2 + 4 * r)                 // row r's weights landed; (dy = 0) the chunk is staged; (dy > 0) row r - 1 is finished
+                BX_STAMP(3 + 4 * r)
+                // ---- one tap row: 3 K steps x (NPB pixel blocks x 2 cout blocks) x 6 MFMAs; operands of step s+1 read under step s
+                const unsigned char* wslot = smem_b64 + RING_OFF + (r & 1) * SLOT_BYTES + lane * 16;
+                const unsigned char* xrow = smem_b64 + dy * XROWB;
+                Frag f[2];
+                auto load = [&](int s, Frag& o) {
+#pragma unroll
+                    for (int j = 0; j < NPB; ++j)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) o.x[j][q] = *reinterpret_cast<const bf16x8*>(xrow + xb[j] + s * PIXB + q * SPLB);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) o.w[cb][q] = *reinterpret_cast<const bf16x8*>(wslot + s * STEP_BYTES + (cb * 3 + q) * 1024);
+                };
+                load(0, f[0]);
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const Frag& cf = f[s & 1];
+                    if (s + 1 < 3) load(s + 1, f[(s + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); independent accumulators
+#define BX_MM(WQ, XQ) { _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int j = 0; j < NPB; ++j) \
+                        acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.x[j][XQ], cf.w[cb][WQ], acc[j][cb], 0, 0, 0); }
+                    BX_MM(2, 0) BX_MM(0, 2) BX_MM(1, 1) BX_MM(1, 0) BX_MM(0, 1) BX_MM(0, 0)
+#undef BX_MM
+                    __builtin_amdgcn_sched_barrier(0);
+                    // memory instructions go BETWEEN the MFMA groups: their issue (~100 cycles per LDS-DMA piece or load with the CU's
+                    // eight waves at it) overlaps the matrix pipe's backlog instead of preceding it
+                    if (s == 0) issue_row(r + 1 < NROW ? r + 1 : 0);          // next row (of the next tile after the last one: the stream is cyclic)
+                    if (s == 1 && dy == 0) {   // raw values of the next chunk (or the next tile's first) fly under this chunk's MFMAs
+                        // (ONE load site: two sites load into two register sets and merge them with moves -- behind a wait for the loads)
+                        const bool same = c + 1 < NCH;
+                        Tile lt;
+                        lt.b = same ? cur.b : nxt.b; lt.y0 = same ? cur.y0 : nxt.y0; lt.x0 = same ? cur.x0 : nxt.x0; lt.full = same ? cur.full : nxt.full;
+                        if (same || has_next) issue_loads(lt, same ? c + 1 : 0);
+                    }
+                }
+                BX_STAMP(4 + 4 * r)
+            }
+        }
+        // ---- bias, ReLU, stores.  A = pixels, B = couts: lane (cout l31, half) holds pixels m = (r & 3) + 8 (r >> 2) + 4 half of the block
+        // (row m >> 4, column m & 15): four consecutive pixels per register quad = one buffer_store_dwordx4 into the cout's plane.
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * COUT * HW), 0, (int)(COUT * HW * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const float bsv = bias_lds[cb * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < NPB; ++j)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int oy = cur.y0 + 2 * (j ? br1 : br0) + (g4 >> 1), ox = cur.x0 + 8 * (g4 & 1) + 4 * half;
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        y[e] = acc[j][cb][4 * g4 + e] + bsv;
+                        if (a.relu) y[e] = fmaxf(y[e], 0.f);
+                    }
+                    const size_t eoff = ((size_t)(cb * 32 + l31) * HW + (size_t)oy * a.W + ox) * 4;
+                    if ((a.W & 3) == 0) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 q = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(q, rs_out, oy < a.H && ox < a.W ? (int)eoff : (int)0x80000000, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[e]), rs_out, oy < a.H && ox + e < a.W ? (int)eoff + 4 * e : (int)0x80000000, 0, 0);
+                    }
+                }
+        }
+    };
+
+    Tile cur, nxt;
+    int u = u0;
+    u += tile_at(u, cur);
+    nxt = cur;
+    issue_row(0);
+    issue_loads(cur, 0);
+    for (;;) {
+        const bool has_next = u < u1;
+        if (has_next) u += tile_at(u, nxt);
+        BX_STAMP(0)
+        if (cur.full) do_tile(std::integral_constant<int, 2>{}, cur, nxt, has_next);
+        else do_tile(std::integral_constant<int, 1>{}, cur, nxt, has_next);
+        BX_STAMP(50)
+        if (!has_next) break;
+        __syncthreads();                       // every wave is done with the tile's last tap row before the next chunk is staged
+        BX_STAMP(51)
+        ++tix;
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the cyclic stream's last DMA must not outlive the workgroup's LDS
+#undef BX_STAMP
+}
+
+template <int CIN>
+static int run_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
+    if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
+    Bx64Args a;
+    a.in = in; a.wq = c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    a.ncols = ceil_div(W, 16); a.nhr = ceil_div(H, 8); a.upi = a.ncols * a.nhr;
+    static unsigned attr_done = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN>), bx64::LDS_BYTES, attr_done);
+    const long long units = (long long)B * a.upi;
+    int grid = 2 * num_cus();                  // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
+    if (units < grid) grid = (int)units;       // (small inputs: one unit per workgroup; the XCD mapping then needs grid % 8 == 0 or is skipped)
+    conv_bx64_kernel<CIN><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
+    return 0;
+}
+
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
+    if (c.ks != 3 || c.stride != 1 || !c.w_bx || c.cout != 64) return -1;
+    if (c.cin == 64) return run_bx64<64>(c, in, B, H, W, out, st, trace);
+    return -1;
+}
+
+}  // namespace xfh

@@ -21,7 +21,8 @@ struct ConvW {
     const float* w_kcp;    // [(ci*kk+tap)][cout_pad]  BN folded, zero padded (MFMA kernels)
     const float* bias;     // [cout_pad] folded BN shift or conv bias, zero padded
     const float* w_wino;   // [cin/4][16][2][cout_pad][2] Winograd F(2x2,3x3) G g G^T (3x3/s1 layers, cin >= 24), else NULL
-    const void* w_bx;      // [step][split h,m,l][64 lanes][8] bf16: three-way split weights in MFMA operand order (k_conv_bx.hip), else NULL
+    const void* w_bx;      // three-way split bf16 weights in MFMA operand order, else NULL: cin 24: [step][split h,m,l][64 lanes][8] (k_conv_bx.hip);
+                           // cin 64 -> 64: [cin/16][dy][dx][cout block][split][64 lanes][8] (k_conv_bx64.hip)
 };
 
 struct LinW {             // fine_matcher layer: y = relu?(x W^T + b), BN folded
@@ -69,6 +70,7 @@ int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, 
                      float* out, bool nhwc_out, hipStream_t st, long long* trace = nullptr);
 // 3x3/s1 on bf16 MFMAs with three-way split operands (fp32-equivalent; k_conv_bx.hip); -1 if no instantiation
 int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
 int bx_steps(int cin);      // K steps of 16 = 2 groups of 8 channels of one tap
 double conv_flops(const ConvW& c, int B, int Hout, int Wout);
 
