@@ -218,7 +218,7 @@ void conv_bx64_kernel(Bx64Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                     // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); independent accumulators
 #define BX_MM(WQ, XQ) { _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int j = 0; j < NPB; ++j) \
-                        acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.x[j][XQ], cf.w[cb][WQ], acc[j][cb], 0, 0, 0); }
+                        acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.w[cb][WQ], cf.x[j][XQ], acc[j][cb], 0, 0, 0); }
                     BX_MM(2, 0) BX_MM(0, 2) BX_MM(1, 1) BX_MM(1, 0) BX_MM(0, 1) BX_MM(0, 0)
 #undef BX_MM
                     __builtin_amdgcn_sched_barrier(0);
@@ -236,34 +236,31 @@ void conv_bx64_kernel(Bx64Args a) {
                 BX_STAMP(4 + 4 * r)
             }
         }
-        // ---- bias, ReLU, stores.  A = pixels, B = couts: lane (cout l31, half) holds pixels m = (r & 3) + 8 (r >> 2) + 4 half of the block
-        // (row m >> 4, column m & 15): four consecutive pixels per register quad = one buffer_store_dwordx4 into the cout's plane.
+        // ---- bias, ReLU, buffer stores (lanes outside the image carry an out-of-range offset).  A = weights, B = pixels: lane (pixel,
+        // half) holds couts (r & 3) + 8 (r >> 2) + 4 half; a store instruction writes four 64-byte row segments.  (The transposed
+        // product -- lane = cout, four consecutive pixels per register quad, dwordx4 stores -- has a quarter of the instructions but
+        // every lane in its own cache line: 64 lines per instruction instead of 4, and was slower: the addresser works per line.)
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * COUT * HW), 0, (int)(COUT * HW * sizeof(float)), 0x00020000);
+        const int ox = cur.x0 + (l31 & 15);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const float bsv = bias_lds[cb * 32 + l31];
+        for (int j = 0; j < NPB; ++j) {
+            const int oy = cur.y0 + 2 * (j ? br1 : br0) + (l31 >> 4);
+            const int voff = oy < a.H && ox < a.W ? (int)(((size_t)(4 * half) * HW + (size_t)oy * a.W + ox) * 4) : (int)0x80000000;
 #pragma unroll
-            for (int j = 0; j < NPB; ++j)
+            for (int cb = 0; cb < 2; ++cb) {
+                float bs[16];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int oy = cur.y0 + 2 * (j ? br1 : br0) + (g4 >> 1), ox = cur.x0 + 8 * (g4 & 1) + 4 * half;
-                    float y[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        y[e] = acc[j][cb][4 * g4 + e] + bsv;
-                        if (a.relu) y[e] = fmaxf(y[e], 0.f);
-                    }
-                    const size_t eoff = ((size_t)(cb * 32 + l31) * HW + (size_t)oy * a.W + ox) * 4;
-                    if ((a.W & 3) == 0) {
-                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                        const u32x4 q = {__float_as_uint(y[0]), __float_as_uint(y[1]), __float_as_uint(y[2]), __float_as_uint(y[3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(q, rs_out, oy < a.H && ox < a.W ? (int)eoff : (int)0x80000000, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[e]), rs_out, oy < a.H && ox + e < a.W ? (int)eoff + 4 * e : (int)0x80000000, 0, 0);
-                    }
+                    const float4 t = *reinterpret_cast<const float4*>(bias_lds + cb * 32 + 8 * g4 + 4 * half);
+                    bs[4 * g4] = t.x; bs[4 * g4 + 1] = t.y; bs[4 * g4 + 2] = t.z; bs[4 * g4 + 3] = t.w;
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float y = acc[j][cb][r] + bs[r];
+                    if (a.relu) y = fmaxf(y, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((cb * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
+                }
+            }
         }
     };
 
