@@ -368,6 +368,45 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                             }
         }
     }
+    // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].
+    // K order: the first layer takes its channels in natural order (16 t + 8 half + i); a chained layer takes the previous layer's D
+    // registers, i.e. feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).
+    size_t head_off[2] = {0, 0}, head_boff[2] = {0, 0};
+    float head_b_last = 0.f;
+    {
+        const int kp[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3}, rel[2] = {L_HEAT_0, L_HEAT_1};
+        for (int hd = 0; hd < 2; ++hd) {
+            const int nl = hd == 0 ? 4 : 2;
+            const int* ls = hd == 0 ? kp : rel;
+            size_t words = 0, nbias = 0;
+            for (int p = 0; p < nl; ++p) { const int mbo = (kConvs[ls[p]].cout + 31) / 32; words += (size_t)4 * mbo * 3 * 64 * 4; nbias += 32 * mbo; }
+            head_off[hd] = reserve(words);
+            head_boff[hd] = reserve(nbias);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[head_off[hd]]);
+            size_t bo = head_boff[hd];
+            for (int p = 0; p < nl; ++p) {
+                const ConvSpec& c = kConvs[ls[p]];
+                const int mbo = (c.cout + 31) / 32;
+                for (int t = 0; t < 4; ++t)
+                    for (int mb = 0; mb < mbo; ++mb)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 8; ++i) {
+                                const int o = mb * 32 + (lane & 31), hf = lane >> 5;
+                                const int ch = p == 0 ? 16 * t + 8 * hf + i : 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
+                                const float v = o < c.cout ? blob[coff[ls[p]].oihw + (size_t)o * 64 + ch] : 0.f;
+                                const uint16_t q0 = bf16_rne(v);
+                                const float r1 = v - bf16_float(q0);
+                                const uint16_t q1 = bf16_rne(r1);
+                                const uint16_t q[3] = {q0, q1, bf16_rne(r1 - bf16_float(q1))};
+                                for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * mbo + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                            }
+                dst += (size_t)4 * mbo * 3 * 64 * 8;
+                for (int o = 0; o < 32 * mbo; ++o) blob[bo + o] = o < c.cout ? blob[coff[ls[p]].bias + o] : 0.f;
+                bo += 32 * mbo;
+            }
+        }
+        head_b_last = blob[coff[L_HEAT_2].bias];
+    }
     for (int fi = 0; fi < 5; ++fi) {
         const FineSpec& f = kFine[fi];
         const int npad = (f.n + 63) / 64 * 64;
@@ -415,6 +454,8 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.w_bx = coff[li].has_bx ? ctx->blob + coff[li].bx : nullptr;
     }
     ctx->nw.zeros = ctx->blob + zoff;
+    for (int hd = 0; hd < 2; ++hd) { ctx->nw.head_bx[hd] = ctx->blob + head_off[hd]; ctx->nw.head_bx_bias[hd] = ctx->blob + head_boff[hd]; }
+    ctx->nw.head_rel_b_last = head_b_last;
     for (int fi = 0; fi < 5; ++fi) {
         LinW& l = ctx->nw.fine[fi];
         l.k = kFine[fi].k; l.n = kFine[fi].n; l.n_pad = (kFine[fi].n + 63) / 64 * 64; l.relu = kFine[fi].bn;

@@ -224,6 +224,8 @@ void conv_bx64_kernel(Bx64Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                     // memory instructions go BETWEEN the MFMA groups: their issue (~100 cycles per LDS-DMA piece or load with the CU's
                     // eight waves at it) overlaps the matrix pipe's backlog instead of preceding it
+                    // (and idle slots first: VALU address arithmetic right behind an MFMA may land in operand lanes it has not read yet)
+                    if (s < 2) { asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
                     if (s == 0) issue_row(r + 1 < NROW ? r + 1 : 0);          // next row (of the next tile after the last one: the stream is cyclic)
                     if (s == 1 && dy == 0) {   // raw values of the next chunk (or the next tile's first) fly under this chunk's MFMAs
                         // (ONE load site: two sites load into two register sets and merge them with moves -- behind a wait for the loads)
@@ -233,6 +235,8 @@ void conv_bx64_kernel(Bx64Args a) {
                         if (same || has_next) issue_loads(lt, same ? c + 1 : 0);
                     }
                 }
+                asm volatile("s_nop 7\n\ts_nop 7");
+                __builtin_amdgcn_sched_barrier(0);
                 BX_STAMP(4 + 4 * r)
             }
         }

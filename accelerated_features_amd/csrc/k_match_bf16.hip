@@ -81,17 +81,20 @@ __global__ __launch_bounds__(256) void mnn_prep_kernel(const float* __restrict__
 }
 
 // One 32x32 tile of S^ on four bf16 MFMAs.  a: this lane's A fragment (row l31, k = 16 kk + 8 half .. +7), bp: this lane's B row in LDS.
-__device__ inline f32x16 bf16_tile(const bf16x8 (&a)[4], const unsigned short* bp) {
+// The B fragments are handed back: the caller keeps them alive (an empty asm use) until its epilogue is over -- a VALU result written
+// a few cycles after a K = 16 MFMA was issued can land in operand lanes the matrix core has not read yet, and hipcc reuses a dead
+// fragment register for address arithmetic right behind the last MFMA (tools/check_mfma_war.py audits the generated code).
+__device__ inline f32x16 bf16_tile(const bf16x8 (&a)[4], const unsigned short* bp, bf16x8 (&bfrag)[4]) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(bp + kk * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bfrag, acc, 0, 0, 0);
-    }
+    for (int kk = 0; kk < 4; ++kk) bfrag[kk] = *reinterpret_cast<const bf16x8*>(bp + kk * 16);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[kk], bfrag[kk], acc, 0, 0, 0);
     return acc;
 }
+#define XFH_KEEP_FRAGS(f) asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]))
 
 // PASS 1: row / column maxima of S^.  PASS 2: candidates.  Same tiling as mnn_sim_kernel: a workgroup owns 256 rows, sweeps the columns.
 template <int PASS>
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(512) void mnn_bf16_kernel(const unsigned short* __r
         for (int ct = 0; ct < BT_COLS / 32; ++ct) {
             const int cbase = c0 + ct * 32;
             if (cbase >= n2) break;
-            const f32x16 acc = bf16_tile(a, Dl + (ct * 32 + l31) * BT_DS + half * 8);
+            bf16x8 bfrag[4];
+            const f32x16 acc = bf16_tile(a, Dl + (ct * 32 + l31) * BT_DS + half * 8, bfrag);
             // D[i=row][j=col]: this lane holds column cbase+l31, rows (r&3)+8*(r>>2)+4*half
             if (PASS == 1) {
                 float cm = acc[0];
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(512) void mnn_bf16_kernel(const unsigned short* __r
                     }
                 }
             }
+            XFH_KEEP_FRAGS(bfrag);
         }
         if (PASS == 1) {
             __syncthreads();

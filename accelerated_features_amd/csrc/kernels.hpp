@@ -35,6 +35,10 @@ struct NetWeights {
     ConvW conv[L_NUM];
     LinW fine[5];
     const float* zeros;   // 1 KiB of zeros (padding source of the LDS-DMA loaders)
+    // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): [0] key-point head, [1] reliability head
+    const void* head_bx[2];          // per layer [K step 4][cout block][split 3][64 lanes][8] bf16
+    const float* head_bx_bias[2];    // biases padded to the cout blocks (KP 64,64,64,96 ; REL 64,64)
+    float head_rel_b_last;           // bias of the final 64 -> 1 layer of the reliability head
 };
 
 struct Profiler;   // api.hip
