@@ -188,7 +188,7 @@ void conv_bx64_kernel(Bx64Args a) {
         const int br0 = NPB == 2 ? 2 * wave : wave, br1 = 2 * wave + 1;
         const int xb[2] = {2 * br0 * XROWB + lane_px, 2 * br1 * XROWB + lane_px};
         for (int c = 0; c < NCH; ++c) {
-            if (c > 0) __syncthreads();        // every wave has finished the previous chunk's last tap row (the tile loop ends on a barrier)
+            if (c > 0) dma_barrier();          // every wave has finished the previous chunk's last tap row (the tile loop ends on a barrier)
             stage_write();
             for (int dy = 0; dy < 3; ++dy) {
                 const int r = c * 3 + dy;
@@ -282,7 +282,7 @@ void conv_bx64_kernel(Bx64Args a) {
         else do_tile(std::integral_constant<int, 1>{}, cur, nxt, has_next);
         BX_STAMP(50)
         if (!has_next) break;
-        __syncthreads();                       // every wave is done with the tile's last tap row before the next chunk is staged
+        dma_barrier();                         // every wave is done with the tile's last tap row before the next chunk is staged
         BX_STAMP(51)
         ++tix;
         cur = nxt;
