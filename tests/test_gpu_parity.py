@@ -6,6 +6,7 @@ tests/parity.py), descriptors / scores within 1e-4 fp32.  Run with `pytest -m gp
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -17,6 +18,7 @@ from oracle import xfeat_oracle as O
 
 pytestmark = pytest.mark.gpu
 G = fixtures.GOLDEN_DIR
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL_ACT = 5e-5      # activations are O(1); fp32 summation-order noise is ~1e-6
 
 
@@ -122,6 +124,31 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["feats_vs_oracle"] <= 1e-4 and errs["feats_vs_golden"] <= 1e-4, errs
     assert errs["logits_vs_oracle"] <= 5e-4 and errs["logits_vs_golden"] <= 5e-4, errs   # logits are O(50)
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
+
+
+@pytest.mark.parametrize("env", [{"XFH_HEADS": "f32", "XFH_BX": "0"}, {"XFH_BX": "3"}])
+def test_backbone_alternative_kernels_same_results(env):
+    """The A/B switches select other kernels for the same layers (heads on f32 MFMAs, 24->24 layers on Winograd; 64->64 layers on the
+    split-bf16 kernel): the switches are read once per process, so each setting runs the small golden backbone case in its own process."""
+    import subprocess
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))\n"
+        "import fixtures\n"
+        "from accelerated_features_amd import XFeat\n"
+        "g = np.load(os.path.join(%r, 'g1_small.npz'))\n"
+        "xf = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=4096)\n"
+        "x = fixtures.texture_images(2, 96, 128, seed=11)\n"
+        "feats, logits, rel = xf.net(x.cuda())\n"
+        "heat = xf.get_kpts_heatmap(logits)\n"
+        "e = [float(np.abs(feats.cpu().numpy() - g['feats']).max()), float(np.abs(logits.cpu().numpy() - g['logits']).max()),\n"
+        "     float(np.abs(rel.cpu().numpy() - g['reliability']).max()), float(np.abs(heat.cpu().numpy() - g['heat']).max())]\n"
+        "print('ERRS', *e)\n"
+        "assert e[0] <= 1e-4 and e[1] <= 5e-4 and e[2] <= 1e-5 and e[3] <= 1e-5, e\n" % G
+    )
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-1500:])
+    assert "ERRS" in r.stdout
 
 
 def test_backbone_fused_heat_equals_helper(xf):
@@ -506,7 +533,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
     h = xf.net.handle()
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 0
-    for name in ("block2.0", "block2.1"):
+    for name in ("block2.0", "block2.1", "block_fusion.0", "block4.1"):       # the last two: conv_bx64_kernel (opt-in XFH_BX=3)
         c = next(c for c in CONVS if c.name == name)
         w = sd[f"{name}.layer.0.weight"].double().cuda()
         rm, rv = sd[f"{name}.layer.1.running_mean"].double().cuda(), sd[f"{name}.layer.1.running_var"].double().cuda()
@@ -525,7 +552,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
                     err[variant] = float((y.double() - truth).abs().nan_to_num(1e9).max()) / ref
                 assert err[10] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
                 n += 1
-    assert n == 2 * 8 * 3
+    assert n == 4 * 8 * 3
 
 
 def test_uint8_ingest_is_bit_identical_to_host_conversion(xf):
