@@ -142,7 +142,7 @@ def conv_family_roofline(xf, step_fn, n=2):
     lib.xfh_profile_read(handle, C.byref(cn), C.byref(cms), C.byref(cfl), C.byref(cby))
     lib.xfh_profile_select(handle, _lib.PROF_NONE)
     ach = (cfl.value / 1e12) / (cms.value / 1e3) if cms.value > 0 else 0.0
-    return {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> (every MFMA convolution launch of the step; FLOPs of the direct "
+    return {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> + conv_bx_kernel<24,24> (every MFMA convolution launch of the step; FLOPs of the direct "
                                        "form -- the 3x3/s1 layers execute 2.25x fewer as Winograd F(2x2,3x3))",
             "achieved": round(ach, 2), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4),
             "launches": cn.value, "ms_per_step": round(cms.value / n, 3), "traffic": None}
@@ -504,7 +504,7 @@ def main():
                               "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME, "algorithmic_flops_per_frame": ALGO_FLOPS_PER_FRAME,
                               "note": "per GPU; 78.6 MB and 2.622 + 1.074 GFLOP per frame (SURVEY 8d); the pure-HBM line (8 TB/s / 78.6 MB = "
                                       "102 k fps) is above the fp32 compute bound of the backbone alone, so frac is taken against T_roof"},
-            "roofline_conv_family": {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> (all 12 MFMA conv launches per step; FLOPs of the "
+            "roofline_conv_family": {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> + conv_bx_kernel<24,24> (all 12 MFMA conv launches per step; FLOPs of the "
                                                                   "direct form -- the 3x3/s1 layers execute 2.25x fewer as Winograd F(2x2,3x3))",
                                      "achieved": round((cfl / 1e12) / (cms / 1e3), 3) if cms > 0 else None,
                                      "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
