@@ -335,7 +335,8 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         };
         const bool bx24 = c.ks == 3 && c.stride == 1 && c.cin == 24 && c.cout <= 32;
         const bool bx64 = c.ks == 3 && c.stride == 1 && c.cin == 64 && c.cout == 64;
-        coff[li].has_bx = bx24 || bx64;
+        const bool bx24s2 = c.ks == 3 && c.stride == 2 && c.cin == 24 && c.cout == 64;
+        coff[li].has_bx = bx24 || bx64 || bx24s2;
         if (bx24) {
             const int cg = c.cin / 8, nstep = bx_steps(c.cin);
             coff[li].bx = reserve((size_t)nstep * 3 * 64 * 4);
@@ -351,6 +352,23 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                         for (int sp = 0; sp < 3; ++sp) dst[(((size_t)s * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                     }
                 }
+        }
+        if (bx24s2) {     // the stride-2 sibling: [cout block][step][split][lane][8], same K order as bx24
+            const int cg = c.cin / 8, nstep = bx_steps(c.cin);
+            coff[li].bx = reserve((size_t)2 * nstep * 3 * 64 * 4);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
+            for (int cb = 0; cb < 2; ++cb)
+                for (int s = 0; s < nstep; ++s)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int o = cb * 32 + (lane & 31), kg = 2 * s + (lane >> 5);
+                        for (int i = 0; i < 8; ++i) {
+                            float v = 0.f;
+                            if (kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
+                            uint16_t q[3];
+                            split3(v, q);
+                            for (int sp = 0; sp < 3; ++sp) dst[((((size_t)cb * nstep + s) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                        }
+                    }
         }
         if (bx64) {      // [cin/16][dy][dx][cout block][split][lane = half * 32 + cout][8]: channel = 16 chunk + 8 half + i
             const int nch = c.cin / 16;
@@ -512,12 +530,12 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     // A/B runs: XFH_WINO=0 forces the direct kernel, XFH_WINO=1 keeps the fused pairs on the direct kernel.
     static int use_wino = -1;
     if (use_wino < 0) { const char* e = getenv("XFH_WINO"); use_wino = e ? atoi(e) : 2; }
-    // 24-channel 3x3/s1 layers: bf16 MFMAs on three-way split operands (k_conv_bx.hip); XFH_BX=0 keeps them on the Winograd kernel
+    // 24-channel 3x3 layers (block2.0/.1 s1, block3.0 s2): bf16 MFMAs on three-way split operands (k_conv_bx.hip); XFH_BX=0 keeps them on the f32-MFMA kernels
     static int use_bx = -1;
     if (use_bx < 0) { const char* e = getenv("XFH_BX"); use_bx = e ? atoi(e) : 1; }
     int rc = -1;
     if (use_bx && c.w_bx && !c2 && !nhwc) {
-        if (c.cin == 24) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);
+        if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);      // (XFH_BX=9: block3.0 stays on the f32 kernel)
         else if (use_bx & 2) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);
     }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);

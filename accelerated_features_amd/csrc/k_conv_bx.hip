@@ -201,6 +201,8 @@ void conv_bx_kernel(BxArgs a) {
 #undef BX_MM
             __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("s_nop 7\n\ts_nop 7");      // idle slots: the epilogue's VALU code must not land in operand registers of the last MFMAs
+        __builtin_amdgcn_sched_barrier(0);
         BX_STAMP(3)
         // ---- bias, ReLU, store ------------------------------------------------------------------------------------------
         const int ox = ox0 + l31;
@@ -238,6 +240,199 @@ void conv_bx_kernel(BxArgs a) {
 #undef BX_STAMP
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The stride-2 sibling: block3.0 (3x3 / s2, 24 -> 64; modules/model.py:62) on the same staging.  The 10x34 halo tile around an 8x32
+// block of INPUT pixels feeds a 4x16 block of outputs (one 32-pixel MFMA block per two output rows); wave (pb, cb) owns pixel block pb
+// and cout block cb.  The tile is stored with even and odd columns apart ([row][column parity][column / 2], 2496 B per parity row: a
+// multiple of 64 B, so that the second row of a pixel block lands on the same banks as the first): the lanes of a fragment read step by
+// two input pixels and would otherwise collide pairwise.  wh and wm of the wave's cout block live in registers, wl in LDS.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int CIN>
+struct BxS2Cfg {
+    static constexpr int IH = 10, IW = 34, NPIX = IH * IW, CG = CIN / 8, PIXB = 3 * CIN * 2, SPLB = CIN * 2;
+    static constexpr int ROWQ = ((IW / 2) * PIXB + 63) / 64 * 64;          // bytes per (row, column parity)
+    static constexpr int KG = 9 * CG, NSTEP = (KG + 1) / 2;
+    static constexpr int NIT = (NPIX * CG + 255) / 256;
+    static constexpr int TILE_BYTES = IH * 2 * ROWQ, WL_BYTES = 2 * NSTEP * 64 * 16;
+    static constexpr int BIAS_OFF = TILE_BYTES + WL_BYTES, LDS_BYTES = BIAS_OFF + 64 * 4;
+    static_assert((4 * ROWQ) % 256 == 0, "two output rows = four parity rows must be a multiple of the 64 banks");
+    static constexpr int koff(int kg) {
+        const int g = kg < KG ? kg : KG - 1;
+        const int tap = g / CG, cg = g % CG, dy = tap / 3, dx = tap % 3;
+        return (dy * 2 + (dx & 1)) * ROWQ + (dx >> 1) * PIXB + cg * 16;
+    }
+};
+
+struct BxS2Args {
+    const float* in;
+    const uint4* wfrag;        // [cout block 2][step][split][64 lanes] 8 bf16 each
+    const float* bias;
+    float* out;
+    int relu, H, W, Ho, Wo, B, tiles_x, tiles;
+};
+
+template <int CIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_bxs2_kernel(BxS2Args a) {
+    using Cfg = BxS2Cfg<CIN>;
+    constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, CG = Cfg::CG, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB, ROWQ = Cfg::ROWQ;
+    constexpr int NSTEP = Cfg::NSTEP, NIT = Cfg::NIT, COUT = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = wave >> 1, cb = wave & 1;
+    const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
+
+    bf16x8 wf[NSTEP][2];                       // wh, wm of this wave's cout block
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) wf[s][q] = __builtin_bit_cast(bf16x8, a.wfrag[((cb * NSTEP + s) * 3 + q) * 64 + lane]);
+    unsigned char* wl_lds = smem_bx + Cfg::TILE_BYTES;            // [cout block][step][lane] 16 B
+    for (int j = wave; j < 2 * NSTEP; j += 4)
+        *reinterpret_cast<uint4*>(wl_lds + (j * 64 + lane) * 16) = a.wfrag[(((j / NSTEP) * NSTEP + j % NSTEP) * 3 + 2) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) asm volatile("" : "+v"(wf[s][q]));      // the wait for the weight loads belongs here, not into the tile loop
+    float* bias_lds = reinterpret_cast<float*>(smem_bx + Cfg::BIAS_OFF);
+    if (tid < 64) bias_lds[tid] = a.bias[tid];
+
+    int it_rc[NIT], it_lds[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int item = tid + 256 * i;
+        const int cg = item / NPIX, pix = item - cg * NPIX;
+        const int r = pix / IW, c = pix - r * IW;
+        it_rc[i] = cg < CG ? (cg << 16) | (r << 8) | c : -1;
+        it_lds[i] = (r * 2 + (c & 1)) * ROWQ + (c >> 1) * PIXB + cg * 16;
+    }
+    const int orow = 2 * pb + (l31 >> 4), ocol = l31 & 15;
+    const int lane_off = 4 * orow * ROWQ + ocol * PIXB;
+    // this lane's wl fragments: ONE address register, the step in the instruction's offset field (an address computed per step is a VALU
+    // write that hipcc put into a fragment register the step's last MFMA had just read)
+    const unsigned char* wl_lane = wl_lds + (cb * NSTEP * 64 + lane) * 16;
+    const int total = a.tiles * a.B;
+
+    auto tile_of = [&](int vid, int& b, int& iy0, int& ix0) {
+        int tile;
+        xcd_group_map(vid, a.tiles, a.B, b, tile);
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        iy0 = tyi * 8; ix0 = txi * 32;
+    };
+    float v[NIT][8];
+    auto issue_loads = [&](int vid) __attribute__((always_inline)) {
+        int b, iy0, ix0;
+        tile_of(vid, b, iy0, ix0);
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * CIN * HW), 0, (int)(CIN * HW * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int cg = it_rc[i] >> 16, gy = iy0 - 1 + ((it_rc[i] >> 8) & 0xff), gx = ix0 - 1 + (it_rc[i] & 0xff);
+            const bool ok = it_rc[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int voff = ok ? (int)((((size_t)cg * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[i][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)(k * HW * 4), 0));
+        }
+    };
+    auto stage_write = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            uint4 h, m, l;
+            split3(v[i][0], v[i][1], h.x, m.x, l.x);
+            split3(v[i][2], v[i][3], h.y, m.y, l.y);
+            split3(v[i][4], v[i][5], h.z, m.z, l.z);
+            split3(v[i][6], v[i][7], h.w, m.w, l.w);
+            if (it_rc[i] >= 0) {
+                unsigned char* p = smem_bx + it_lds[i];
+                *reinterpret_cast<uint4*>(p) = h;
+                *reinterpret_cast<uint4*>(p + SPLB) = m;
+                *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+            }
+        }
+    };
+
+    int vid = blockIdx.x;
+    if (vid >= total) return;
+    issue_loads(vid);
+    for (;;) {
+        int b, iy0, ix0;
+        tile_of(vid, b, iy0, ix0);
+        stage_write();
+        __syncthreads();
+        const int nvid = vid + (int)gridDim.x;
+        if (nvid < total) issue_loads(nvid);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        struct Frag { bf16x8 x[3]; bf16x8 wl; };
+        Frag f[2];
+        auto load = [&](int s, Frag& o) {
+            const int k0 = Cfg::koff(2 * s), dk = Cfg::koff(2 * s + 1) - k0;
+            const unsigned char* p = smem_bx + (lane_off + half * dk) + k0;
+            o.wl = *reinterpret_cast<const bf16x8*>(wl_lane + s * 1024);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) o.x[q] = *reinterpret_cast<const bf16x8*>(p + q * SPLB);
+        };
+        load(0, f[0]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const Frag& c = f[s & 1];
+            if (s + 1 < NSTEP) load(s + 1, f[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.wl, c.x[0], acc, 0, 0, 0);          // small terms first
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], c.x[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], c.x[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], c.x[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], c.x[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], c.x[0], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // idle slots before the epilogue's address arithmetic: it must not land in operand registers of the last MFMAs
+        asm volatile("s_nop 7\n\ts_nop 7");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- bias, ReLU, buffer stores: lane (pixel, half) holds couts 32 cb + (r & 3) + 8 (r >> 2) + 4 half ----------------------------
+        {
+            float bs[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const float4 t = *reinterpret_cast<const float4*>(bias_lds + cb * 32 + 8 * g4 + 4 * half);
+                bs[4 * g4] = t.x; bs[4 * g4 + 1] = t.y; bs[4 * g4 + 2] = t.z; bs[4 * g4 + 3] = t.w;
+            }
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * COUT * HWo), 0, (int)(COUT * HWo * sizeof(float)), 0x00020000);
+            const int oy = (iy0 >> 1) + orow, ox = (ix0 >> 1) + ocol;
+            const int voff = oy < a.Ho && ox < a.Wo ? (int)(((size_t)(4 * half) * HWo + (size_t)oy * a.Wo + ox) * 4) : (int)0x80000000;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float y = acc[r] + bs[r];
+                if (a.relu) y = fmaxf(y, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((cb * 32 + (r & 3) + 8 * (r >> 2)) * HWo * 4), 0);
+            }
+        }
+        if (nvid >= total) break;
+        __syncthreads();
+        vid = nvid;
+    }
+}
+
+template <int CIN>
+static int run_bxs2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st) {
+    using Cfg = BxS2Cfg<CIN>;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * Ho * Wo * sizeof(float) >= 0x7fffffffu) return -1;
+    BxS2Args a;
+    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu;
+    a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B;
+    a.tiles_x = ceil_div(W, 32);
+    a.tiles = a.tiles_x * ceil_div(H, 8);
+    static unsigned attr_done = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN>), Cfg::LDS_BYTES, attr_done);
+    const int total = xcd_grid_size(a.tiles, B);
+    int grid = 2 * num_cus();
+    if (grid > total) grid = total;
+    conv_bxs2_kernel<CIN><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+    return 0;
+}
+
 template <int CIN, int COUT>
 static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
     using Cfg = BxCfg<CIN, COUT>;
@@ -261,8 +456,9 @@ static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* o
 int bx_steps(int cin) { return (9 * (cin / 8) + 1) / 2; }
 
 int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
-    if (c.ks != 3 || c.stride != 1 || !c.w_bx) return -1;
-    if (c.cin == 24 && c.cout == 24) return run_bx<24, 24>(c, in, B, H, W, out, st, trace);
+    if (c.ks != 3 || !c.w_bx) return -1;
+    if (c.stride == 1 && c.cin == 24 && c.cout == 24) return run_bx<24, 24>(c, in, B, H, W, out, st, trace);
+    if (c.stride == 2 && c.cin == 24 && c.cout == 64) return run_bxs2<24>(c, in, B, H, W, out, st);
     return -1;
 }
 

@@ -525,7 +525,7 @@ def test_winograd_configurations_match_generic_kernel(xf):
 
 
 def test_split_bf16_conv_is_fp32_accurate(xf, sd):
-    """The 24-channel 3x3 layers run on bf16 MFMAs with three-way split operands (k_conv_bx.hip, xfh_conv_layer variant 10): against an
+    """The 24-channel 3x3 layers (stride 1 and 2) run on bf16 MFMAs with three-way split operands (k_conv_bx.hip, xfh_conv_layer variant 10): against an
     fp64 convolution of the same folded weights the error must stay at the level of the fp32 direct kernel (variant 1), on odd / small /
     clipped shapes, large magnitudes, and batches that are not a multiple of 8."""
     from accelerated_features_amd.spec import CONVS, CONV_INDEX, BN_EPS
@@ -533,7 +533,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
     h = xf.net.handle()
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 0
-    for name in ("block2.0", "block2.1", "block_fusion.0", "block4.1"):       # the last two: conv_bx64_kernel (opt-in XFH_BX=3)
+    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1"):       # block3.0: the stride-2 kernel; the last two: conv_bx64_kernel (opt-in XFH_BX=3)
         c = next(c for c in CONVS if c.name == name)
         w = sd[f"{name}.layer.0.weight"].double().cuda()
         rm, rv = sd[f"{name}.layer.1.running_mean"].double().cuda(), sd[f"{name}.layer.1.running_var"].double().cuda()
@@ -542,17 +542,17 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
         for (B, hh, ww) in ((2, 24, 32), (3, 41, 41), (1, 6, 10), (9, 30, 40), (8, 120, 160), (2, 7, 70), (1, 1, 1), (16, 9, 33)):
             for scale in (1.0, 1e-3, 300.0):
                 x = torch.randn(B, c.cin, hh, ww, device="cuda", generator=g) * scale
-                truth = torch.relu(torch.nn.functional.conv2d(x.double(), wf, bf, padding=1))
+                truth = torch.relu(torch.nn.functional.conv2d(x.double(), wf, bf, stride=c.stride, padding=1))
                 ref = float(truth.abs().max())
                 err = {}
                 for variant in (1, 10):
-                    y = torch.full((B, c.cout, hh, ww), float("nan"), device="cuda")
+                    y = torch.full(tuple(truth.shape), float("nan"), device="cuda")
                     rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
                     assert rc == 0, (name, variant, lib.xfh_last_error())
                     err[variant] = float((y.double() - truth).abs().nan_to_num(1e9).max()) / ref
                 assert err[10] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
                 n += 1
-    assert n == 4 * 8 * 3
+    assert n == 5 * 8 * 3
 
 
 def test_uint8_ingest_is_bit_identical_to_host_conversion(xf):

@@ -29,7 +29,7 @@ def truth64(name, x):
 def run(name, x, variant):
     c = next(c for c in CONVS if c.name == name)
     B, _, hh, ww = x.shape
-    y = torch.full((B, c.cout, hh, ww), float("nan"), device="cuda")
+    y = torch.full((B, c.cout, (hh - 1) // c.stride + 1, (ww - 1) // c.stride + 1), float("nan"), device="cuda")
     rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
     assert rc == 0, (name, variant, lib.xfh_last_error())
     torch.cuda.synchronize()
@@ -43,13 +43,15 @@ for name in names:
             x = torch.randn(B, c.cin, hh, ww, device="cuda", generator=g) * scale
             t = truth64(name, x)
             ref = float(t.abs().max())
-            errs = {v: float((run(name, x, v).double() - t).abs().nan_to_num(1e9).max()) / ref for v in (1, 2, 10)}
-            print(f"{name} B={B} {hh}x{ww} scale {scale:4.0f}: max|err|/max|y|  generic {errs[1]:.2e}  winograd {errs[2]:.2e}  split-bf16 {errs[10]:.2e}", flush=True)
+            vs = (1, 2, 10) if c.stride == 1 else (1, 10)
+            errs = {v: float((run(name, x, v).double() - t).abs().nan_to_num(1e9).max()) / ref for v in vs}
+            print(f"{name} B={B} {hh}x{ww} scale {scale:4.0f}: max|err|/max|y|  generic {errs[1]:.2e}  " + (f"winograd {errs[2]:.2e}  " if 2 in errs else "") + f"split-bf16 {errs[10]:.2e}", flush=True)
 for (B, H, W) in ((64, 480, 640), (8, 1312, 1312)):
     for name in names:
         c = next(c for c in CONVS if c.name == name)
         d = DIV[name]; hin, win = H // d, W // d
         x = torch.randn(B, c.cin, hin, win, device="cuda", generator=g)
-        y = torch.empty(B, c.cout, hin, win, device="cuda")
-        t = {v: time_fn(lambda: lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(y.data_ptr()), v, None)) for v in (2, 10)}
-        print(f"{name} B={B} {hin}x{win}: winograd {t[2]:7.1f} us   split-bf16 {t[10]:7.1f} us", flush=True)
+        y = torch.empty(B, c.cout, (hin - 1) // c.stride + 1, (win - 1) // c.stride + 1, device="cuda")
+        # variant 0 = the production dispatch: run with XFH_BX=0 to time the f32-MFMA kernel of a stride-2 layer there
+        t = {v: time_fn(lambda: lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(y.data_ptr()), v, None)) for v in ((2, 10) if c.stride == 1 else (0, 10))}
+        print(f"{name} B={B} {hin}x{win}: " + (f"winograd {t[2]:7.1f} us" if 2 in t else f"dispatch (XFH_BX={os.environ.get('XFH_BX', '1')}) {t[0]:7.1f} us") + f"   split-bf16 {t[10]:7.1f} us", flush=True)

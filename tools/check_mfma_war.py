@@ -13,7 +13,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DIST = 8          # issue slots: every instruction counts one, s_nop N counts N + 1
+DIST = 8          # issue slots: every instruction counts one, s_nop N counts N + 1, an MFMA counts 8 (the pipe takes one at a time, 8 passes each)
 sys.path.insert(0, ROOT)
 
 
@@ -49,6 +49,7 @@ def audit(src):
             if t[0].startswith("v_mfma") and "bf16" in t[0]:
                 recent = (recent + [(n, _regs(args[1]) | _regs(args[2]))])[-6:]
                 n_mfma += 1
+                n += 7
             elif t[0] == "s_nop" and args:
                 n += int(args[0], 0)
             elif t[0].startswith("v_") and args:
