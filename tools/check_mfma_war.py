@@ -62,7 +62,7 @@ def audit(src):
 
 
 def main():
-    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if "mfma_f32_32x32x16_bf16(" in open(f).read()]
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_bf16\(", open(f).read())]
     total = 0
     for f in files:
         nk, nm, bad = audit(f)
