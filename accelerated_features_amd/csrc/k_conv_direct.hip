@@ -611,6 +611,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef B1_STAMP
 }
 
+// A variant with ONLY conv4 on the matrix cores (same tiles and LDS budget as the kernel below, one tile per workgroup, nothing held in
+// registers across stages) was no better: conv4 6.2 k -> 7.2 k cycles as written (its 36 MFMAs per wave are two dependent accumulator chains:
+// ~150 cycles per v_mfma_f32_16x16x32_bf16 with the operand reads in between; four chains would bring it to ~3 k) while conv3's epilogue pays
+// 2.6 k for splitting its outputs into bf16 rows -- a wash at best.  Removed.
 // block1_bx_kernel (opt-in): per tile 5.3 k cycles gray + 7.4 k conv1 + 7.5 k conv2 (+ split) + 9-10 k conv3 + 4-10 k conv4 = 34-41 k against
 // 32.9 k for the kernel below (325-371 us against 294).  conv3 / conv4 need 90 + 36 MFMAs per wave (~2 k cycles of the pipe) but at 128 VGPRs
 // and ~100 SGPRs (two workgroups of 8 waves per CU, the VALU stages' scalar weight streams, a persistent loop, 14 pointer arguments) hipcc
@@ -649,10 +653,10 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     const ConvW& c2 = nw.conv[L_BLOCK1_2];
     const ConvW& c3 = nw.conv[L_BLOCK1_3];
     const ConvW& sk = nw.conv[L_SKIP1];
-    static unsigned attr = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel), b1::LDS_FLOATS * 4, attr);
     const int H4 = H / 4, W4 = W / 4;
     const int tx = ceil_div(W4, b1::OW), ty = ceil_div(H4, b1::OH);
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel), b1::LDS_FLOATS * 4, attr);
     block1_fused_kernel<<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(
         gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
 }

@@ -15,6 +15,7 @@ lib.xfh_debug_trace(h, C.c_void_p(tr.data_ptr())); xf.net(x); torch.cuda.synchro
 t = tr[(1 << 21):].cpu().numpy().reshape(-1, 16).astype(np.float64); t = t[(t[:, 0] != 0) & (t[:, 6] != 0)]
 print("workgroups", len(t))
 d = np.diff(t[:, :7], axis=1)
-for k, nm in enumerate(("stage 0 gray", "stage 1 conv1 (VALU) + skip avg", "stage 2 conv2 (VALU) + split", "stage 3 conv3 (MFMA)", "stage 4 conv4 (MFMA) + stores", "end barrier")):
+for k, nm in enumerate(("stage 0 gray", "stage 1 conv1 (VALU) + skip avg", "stage 2 conv2 (VALU) + split", "stage 3 conv3", "stage 4 conv4 (MFMA) + stores", "end")):
     print(f"{nm:34s} mean {d[:, k].mean():8.0f}  p10 {np.percentile(d[:, k], 10):8.0f}  p90 {np.percentile(d[:, k], 90):8.0f}")
 print("tile mean %.0f" % (t[:, 6] - t[:, 0]).mean())
+
