@@ -269,6 +269,15 @@ class XFeatModel(nn.Module):
         return out
 
 
+def _counts_pair(n_valid, n_cand):
+    """(2,B) tensor of the two count rows: the buffer they are views of (as _detect_call allocates them) or a stacked copy."""
+    base = getattr(n_valid, "_base", None)
+    if base is not None and base is getattr(n_cand, "_base", None) and base.dim() == 2 and base.shape[0] >= 2 and base.is_contiguous() \
+            and n_valid.data_ptr() == base.data_ptr() and n_cand.data_ptr() == base[1].data_ptr():
+        return base[:2]
+    return torch.stack([n_valid, n_cand])
+
+
 class XFeat(nn.Module):
     """
         Implements the inference module for XFeat (sparse and semi-dense extraction & matching)
@@ -321,7 +330,7 @@ class XFeat(nn.Module):
         cap = None
         while True:
             kpts, scores, desc, n_valid, n_cand, cap, hw = self._detect_device(x, top_k, detection_threshold, cap)
-            cnt = torch.stack([n_valid, n_cand]).cpu()           # the one read-back per batch
+            cnt = _counts_pair(n_valid, n_cand).cpu()            # the one read-back per batch
             ncmax = int(cnt[1].max())
             if cap >= hw or ncmax <= cap:
                 break
@@ -330,11 +339,13 @@ class XFeat(nn.Module):
         return [{'keypoints': kpts[b, :nv[b]], 'scores': scores[b, :nv[b]], 'descriptors': desc[b, :nv[b]]}
                 for b in range(len(nv))]
 
-    def _detect_device(self, x, top_k=None, detection_threshold=None, cap=None, want_bf16=False):
+    def _detect_device(self, x, top_k=None, detection_threshold=None, cap=None, want_bf16=False, counts_out=None):
         """Fixed-capacity device results, no read-back: kpts (B,top_k,2), scores (B,top_k),
         desc (B,top_k,64), n_valid (B) int32, n_cand (B) int32, the NMS capacity used, H*W
         (+ with want_bf16 an eighth element: the descriptors rounded to bf16, (B,top_k,64) int16, for match_pairs_device).
-        If n_cand.max() > capacity the candidate list was truncated (caller re-runs)."""
+        If n_cand.max() > capacity the candidate list was truncated (caller re-runs).
+        n_valid / n_cand are the two rows of ONE (2,B) tensor (counts_out if given: a caller that also matches can keep all its counts
+        in one buffer and read them back with one copy, without a concatenation kernel)."""
         if top_k is None: top_k = self.top_k
         if detection_threshold is None: detection_threshold = self.detection_threshold
         x, rh1, rw1 = self.preprocess_tensor(x)
@@ -342,19 +353,20 @@ class XFeat(nn.Module):
         feats, _, heat, rel, inv = self.net.backbone(x, want_logits=False, want_heat=True, want_invnorm=True)
         if cap is None:
             cap = min(H * W, max(int(top_k), (H * W) // 8))
-        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1, inv, want_bf16)
+        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1, inv, want_bf16, counts_out)
         if want_bf16:
             return out[0], out[1], out[2], out[3], out[4], cap, H * W, out[5]
         return out[0], out[1], out[2], out[3], out[4], cap, H * W
 
-    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh, inv=None, want_bf16=False):
+    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh, inv=None, want_bf16=False, counts_out=None):
         lib = _lib.load()
         dev = feats.device
         kpts = torch.empty((B, top_k, 2), dtype=torch.float32, device=dev)
         scores = torch.empty((B, top_k), dtype=torch.float32, device=dev)
         desc = torch.empty((B, top_k, 64), dtype=torch.float32, device=dev)
-        n_valid = torch.empty((B,), dtype=torch.int32, device=dev)
-        n_cand = torch.empty((B,), dtype=torch.int32, device=dev)
+        cnt = counts_out if counts_out is not None else torch.empty((2, B), dtype=torch.int32, device=dev)
+        assert cnt.shape == (2, B) and cnt.dtype == torch.int32 and cnt[0].is_contiguous() and cnt[1].is_contiguous()
+        n_valid, n_cand = cnt[0], cnt[1]
         d16 = torch.empty((B, top_k, 64), dtype=torch.int16, device=dev) if want_bf16 else None
         ws, n = self.net.workspace("detect", lib.xfh_detect_workspace_bytes(B, H, W, top_k, cap))
         _lib.check(lib.xfh_detect_sparse(self.net.handle(), _ptr(heat), _ptr(rel), _ptr(feats), _ptr(inv), B, H, W, float(thr), top_k, cap,
@@ -557,11 +569,11 @@ class XFeat(nn.Module):
                    "xfh_match_mnn")
         return idx0, idx1, n
 
-    def match_pairs_device(self, desc, n_valid, min_cossim=-1, desc_bf16=None):
+    def match_pairs_device(self, desc, n_valid, min_cossim=-1, desc_bf16=None, n_out=None):
         """Match consecutive frames (2i, 2i+1) of one detection batch without any read-back.
         desc (B,top_k,64), n_valid (B) int32 as returned by _detect_device; B even.  desc_bf16: the bf16 copy the same
         _detect_device(want_bf16=True) call returned (saves the matcher's conversion pass; results identical).
-        Returns idx0, idx1 (B/2, top_k) int64 and n_matches (B/2) int32, all on the device."""
+        Returns idx0, idx1 (B/2, top_k) int64 and n_matches (B/2) int32 (n_out if given), all on the device."""
         self._require_gpu()
         lib = _lib.load()
         B, K, D = desc.shape
@@ -569,7 +581,8 @@ class XFeat(nn.Module):
         P = B // 2
         idx0 = torch.empty((P, K), dtype=torch.int64, device=desc.device)
         idx1 = torch.empty((P, K), dtype=torch.int64, device=desc.device)
-        n = torch.empty((P,), dtype=torch.int32, device=desc.device)
+        n = n_out if n_out is not None else torch.empty((P,), dtype=torch.int32, device=desc.device)
+        assert n.shape == (P,) and n.dtype == torch.int32 and n.is_contiguous()
         ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, K, K))
         d2 = desc[1]
         b1 = b2 = None
