@@ -90,6 +90,7 @@ static size_t array_floats(int idx) {
 // ------------------------------------------------------------------------------------------
 namespace xfh {
 extern long long* g_block1_trace;      // k_conv_direct.hip
+extern long long* g_head_trace;        // k_heads.hip
 struct Profiler {
     int which = 0;
     std::vector<hipEvent_t> ev;   // pairs
@@ -857,7 +858,8 @@ int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
 int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
     if (!h) return fail(XFH_ERR_ARG, "xfh_debug_trace: NULL handle");
     h->trace = device_buffer;
-    g_block1_trace = device_buffer ? device_buffer + (1 << 21) : nullptr;      // block1's stamps live 2 Mi entries into the buffer (the conv kernels use the front)
+    g_block1_trace = device_buffer ? device_buffer + (1 << 21) : nullptr;
+    g_head_trace = device_buffer ? device_buffer + (1 << 21) + (1 << 16) : nullptr;      // (and the key-point head's 64 Ki entries further)      // block1's stamps live 2 Mi entries into the buffer (the conv kernels use the front)
     return XFH_OK;
 }
 

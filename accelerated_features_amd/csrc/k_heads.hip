@@ -261,6 +261,7 @@ struct HeadBxArgs {
     float* logits;           // KP only, optional: (B*hc*wc, 65)
     float* inv;              // REL only, optional: 1 / max(||feats[cell,:]||, 1e-12)
     int H, W, hc, wc, ncell, ntiles;
+    long long* trace;        // debug: s_memtime stamps of wave 0's second tile, 16 per workgroup
 };
 
 __device__ inline unsigned hb_pk_bf16(float a, float b) {
@@ -387,8 +388,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int tile = blockIdx.x;
     if (tile < a.ntiles) issue_x(tile);
     lds_dma_barrier();                                                // the weights (and biases) have landed; no barrier from here on
-    for (; tile < a.ntiles; tile += gridDim.x) {
+    long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
+    int tix = 0;
+#define HB_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }
+    for (; tile < a.ntiles; tile += gridDim.x, ++tix) {
         const int gcell = tile * HD_CELLS + wave * 32 + l31;          // this lane's cell
+        HB_STAMP(0)
         f32x16 accA[2], accB[2];
         float nrm2 = 0.f;
         {
@@ -405,6 +410,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             nrm2 += xhalf(nrm2);                                      // the other 32 channels sit in the other half-wave
             if (half == 0 && gcell < a.ncell) a.inv[gcell] = 1.f / fmaxf(sqrtf(nrm2), 1e-12f);
         }
+        HB_STAMP(1)
         if (tile + (int)gridDim.x < a.ntiles) issue_x(tile + gridDim.x);      // the next tile's input flies during the chained layers
         // chained layers: K step t = register quads 8 (t & 1), 8 (t & 1) + 4 of block t >> 1, ReLU'd
         auto chain = [](const f32x16 (&in)[2]) {
@@ -415,9 +421,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         };
         if (KP) {
             head_bx_layer<2>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half);
+            HB_STAMP(2)
             head_bx_layer<2>(smem_h + 2 * L_BYTES, bias_lds + 128, chain(accB), accA, lane, half);
+            HB_STAMP(3)
             f32x16 lg[3];
             head_bx_layer<3>(smem_h + 3 * L_BYTES, bias_lds + 192, chain(accA), lg, lane, half);
+            HB_STAMP(4)
             // lane (l31,half) holds logits c = 32m + (r&3) + 8(r>>2) + 4*half of its cell; c == 64 (dustbin) is m=2,r=0,half=0
             float mx = -INFINITY;
 #pragma unroll
@@ -455,6 +464,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (half == 0) lp[64] = lg[2][0];
                 }
             }
+            HB_STAMP(5)
         } else {
             head_bx_layer<2>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half);
             // final 64 -> 1: dot over this lane's 32 channels, other half via one shuffle
@@ -468,7 +478,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (half == 0 && gcell < a.ncell) a.out[gcell] = 1.f / (1.f + expf(-(s + a.b_last)));
         }
     }
+#undef HB_STAMP
 }
+
+long long* g_head_trace = nullptr;        // debug (xfh_debug_trace): stamps of head_bx_kernel<true>
 
 static bool heads_use_bx() {
     static int v = -1;
@@ -483,6 +496,7 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
         h.H = H; h.W = W; h.hc = H / 8; h.wc = W / 8;
         h.ncell = B * h.hc * h.wc;
         h.ntiles = ceil_div(h.ncell, HD_CELLS);
+        h.trace = g_head_trace;
         const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float);
         static unsigned attr = 0;
         set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true>), 160 * 1024, attr);
