@@ -146,6 +146,9 @@ void conv_bx_kernel(BxArgs a) {
 
     int vid = blockIdx.x;
     if (vid >= total) return;
+    // (Also tried: ONE 8-wave workgroup per CU whose two halves own different tiles / LDS buffers and swap roles at a barrier per slot --
+    // one half on the matrix pipe while the other stores and stages.  102 us against 93: a lone MFMA wave per SIMD has nobody to cover
+    // its LDS latency, a slot took 10.8 k cycles instead of the 5.5 k of its 168 MFMAs.)
     // Two workgroups share a CU and keep whatever phase lag they start with (a lag x between their MFMA phases is preserved from
     // tile to tile: period = 2 M + O - x for M cycles of MFMA and O cycles of staging + stores per tile).  Launched together they
     // run in phase: both on the matrix pipe, then both off it.  The workgroup that was allocated second on its CU (LDS base != 0)
