@@ -562,11 +562,11 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     if (use_wino < 0) { const char* e = getenv("XFH_WINO"); use_wino = e ? atoi(e) : 2; }
     // 24-channel 3x3 layers (block2.0/.1 s1, block3.0 s2): bf16 MFMAs on three-way split operands (k_conv_bx.hip); XFH_BX=0 keeps them on the f32-MFMA kernels
     static int use_bx = -1;
-    if (use_bx < 0) { const char* e = getenv("XFH_BX"); use_bx = e ? atoi(e) : 1; }
+    if (use_bx < 0) { const char* e = getenv("XFH_BX"); use_bx = e ? atoi(e) : 5; }      // 1: 24-channel layers; 4: unfused 64 -> 64 layers on large maps (2: on every map); 8: not block3.0
     int rc = -1;
     if (use_bx && c.w_bx && !c2 && !nhwc) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);      // (XFH_BX=9: block3.0 stays on the f32 kernel)
-        else if (use_bx & 2) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);
+        else if ((use_bx & 2) || ((use_bx & 4) && (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 2048)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);      // (XFH_BX=5: large maps only)
     }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
