@@ -338,7 +338,22 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         const bool bx24 = c.ks == 3 && c.stride == 1 && c.cin == 24 && c.cout <= 32;
         const bool bx64 = c.ks == 3 && c.stride == 1 && c.cin == 64 && c.cout == 64;
         const bool bx24s2 = c.ks == 3 && c.stride == 2 && c.cin == 24 && c.cout == 64;
-        coff[li].has_bx = bx24 || bx64 || bx24s2;
+        const bool bx1x1 = c.ks == 1 && c.cin == 64 && c.cout == 64 && li > 0 && kConvs[li - 1].ks == 3 && kConvs[li - 1].cout == 64 && kConvs[li - 1].cin == 64;      // block3.2, block_fusion.2
+        coff[li].has_bx = bx24 || bx64 || bx24s2 || bx1x1;
+        if (bx1x1) {      // trailing 1x1 fused into conv_bx64_kernel: K order of the 3x3's D registers (as the heads' chained layers): [K step 4][cout block 2][split 3][lane][8]
+            coff[li].bx = reserve((size_t)4 * 2 * 3 * 64 * 4);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
+            for (int t = 0; t < 4; ++t)
+                for (int mb = 0; mb < 2; ++mb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const int o = mb * 32 + (lane & 31), hf = lane >> 5;
+                            const int ch = 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
+                            uint16_t q[3];
+                            split3(blob[coff[li].oihw + (size_t)o * 64 + ch], q);
+                            for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * 2 + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                        }
+        }
         if (bx24) {
             const int cg = c.cin / 8, nstep = bx_steps(c.cin);
             coff[li].bx = reserve((size_t)nstep * 3 * 64 * 4);
@@ -564,9 +579,12 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     static int use_bx = -1;
     if (use_bx < 0) { const char* e = getenv("XFH_BX"); use_bx = e ? atoi(e) : 5; }      // 1: 24-channel layers; 4: unfused 64 -> 64 layers on large maps (2: on every map); 8: not block3.0
     int rc = -1;
-    if (use_bx && c.w_bx && !c2 && !nhwc) {
+    const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 2048;
+    if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
+        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc);      // 3x3 + trailing 1x1 in one split-bf16 kernel
+    if (rc && use_bx && c.w_bx && !c2 && !nhwc) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);      // (XFH_BX=9: block3.0 stays on the f32 kernel)
-        else if ((use_bx & 2) || ((use_bx & 4) && (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 2048)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);      // (XFH_BX=5: large maps only)
+        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);      // (XFH_BX=5: large maps only)
     }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);

@@ -32,18 +32,23 @@ struct Bx64Args {
     int relu, H, W, B;
     int ncols, nhr, upi;       // 16-column strips, 8-row half tiles per strip, units per image
     long long* trace;
+    // fused trailing 1x1 (64 -> 64): split weights in the K order of the 3x3's D registers, [K step 4][cout block 2][split 3][64 lanes] 8 bf16
+    const uint4* wq2;
+    const float* bias2;
+    int relu2;
 };
 
 namespace bx64 {
 constexpr int XROWB = 2048, PIXB = 112, SPLB = 32, IW = 18, IH = 18;
 constexpr int X_BYTES = IH * XROWB;                    // 36864
 constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;      // 6 KiB per K step, 18 per slot
-constexpr int RING_OFF = X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, LDS_BYTES = BIAS_OFF + 64 * 4;
+constexpr int RING_OFF = X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, LDS_BYTES = BIAS_OFF + 128 * 4;      // bias of the 3x3, bias of the fused 1x1
 constexpr int NQ = 6;                                   // aligned 4-pixel quads per halo row
 static_assert(IH * NQ * 2 <= 256, "one (row, quad, 8-channel group) item per thread");
 }
 
-template <int CIN>
+// FUSE: 0 = the 3x3 alone; 1 = + trailing 1x1 (64 -> 64), NCHW output; 2 = the same with channels-last output
+template <int CIN, int FUSE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64_kernel(Bx64Args a) {
     using namespace bx64;
@@ -55,6 +60,7 @@ void conv_bx64_kernel(Bx64Args a) {
     const size_t HW = (size_t)a.H * a.W;
     float* bias_lds = reinterpret_cast<float*>(smem_b64 + BIAS_OFF);
     if (tid < 64) bias_lds[tid] = a.bias[tid];
+    if (FUSE && tid >= 64 && tid < 128) bias_lds[tid] = a.bias2[tid - 64];
 
     // ---- this workgroup's units -----------------------------------------------------------------------------------------
     // unit u of an image list = (image, 16-column strip, half-tile row), strips and rows fastest.  With a batch that is a multiple of
@@ -240,29 +246,132 @@ void conv_bx64_kernel(Bx64Args a) {
                 BX_STAMP(4 + 4 * r)
             }
         }
-        // ---- bias, ReLU, buffer stores (lanes outside the image carry an out-of-range offset).  A = weights, B = pixels: lane (pixel,
-        // half) holds couts (r & 3) + 8 (r >> 2) + 4 half; a store instruction writes four 64-byte row segments.  (The transposed
-        // product -- lane = cout, four consecutive pixels per register quad, dwordx4 stores -- has a quarter of the instructions but
-        // every lane in its own cache line: 64 lines per instruction instead of 4, and was slower: the addresser works per line.)
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * COUT * HW), 0, (int)(COUT * HW * sizeof(float)), 0x00020000);
-        const int ox = cur.x0 + (l31 & 15);
-#pragma unroll
-        for (int j = 0; j < NPB; ++j) {
-            const int oy = cur.y0 + 2 * (j ? br1 : br0) + (l31 >> 4);
-            const int voff = oy < a.H && ox < a.W ? (int)(((size_t)(4 * half) * HW + (size_t)oy * a.W + ox) * 4) : (int)0x80000000;
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                float bs[16];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const float4 t = *reinterpret_cast<const float4*>(bias_lds + cb * 32 + 8 * g4 + 4 * half);
-                    bs[4 * g4] = t.x; bs[4 * g4 + 1] = t.y; bs[4 * g4 + 2] = t.z; bs[4 * g4 + 3] = t.w;
+        if constexpr (FUSE == 0) {
+            // ---- bias, ReLU, buffer stores (lanes outside the image carry an out-of-range offset).  A = weights, B = pixels: lane (pixel,
+            // half) holds couts (r & 3) + 8 (r >> 2) + 4 half; a store instruction writes four 64-byte row segments.  (The transposed
+            // product -- lane = cout, four consecutive pixels per register quad, dwordx4 stores -- has a quarter of the instructions but
+            // every lane in its own cache line: 64 lines per instruction instead of 4, and was slower: the addresser works per line.)
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * COUT * HW), 0, (int)(COUT * HW * sizeof(float)), 0x00020000);
+            const int ox = cur.x0 + (l31 & 15);
+    #pragma unroll
+            for (int j = 0; j < NPB; ++j) {
+                const int oy = cur.y0 + 2 * (j ? br1 : br0) + (l31 >> 4);
+                const int voff = oy < a.H && ox < a.W ? (int)(((size_t)(4 * half) * HW + (size_t)oy * a.W + ox) * 4) : (int)0x80000000;
+    #pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    float bs[16];
+    #pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 t = *reinterpret_cast<const float4*>(bias_lds + cb * 32 + 8 * g4 + 4 * half);
+                        bs[4 * g4] = t.x; bs[4 * g4 + 1] = t.y; bs[4 * g4 + 2] = t.z; bs[4 * g4 + 3] = t.w;
+                    }
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float y = acc[j][cb][r] + bs[r];
+                        if (a.relu) y = fmaxf(y, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((cb * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
+                    }
                 }
+            }
+        } else {
+            // ---- fused trailing 1x1 (block3.2 / block_fusion.2) on the same matrix cores: the 3x3's D registers (lane = pixel, registers =
+            // couts (r & 3) + 8 (r >> 2) + 4 half), biased and ReLU'd, ARE the 1x1's pixel-side fragments once split: K step t of lane half h
+            // takes the register quads 8 (t & 1), 8 (t & 1) + 4 of cout block t >> 1 (the weights are packed in that K order, as for the
+            // heads' chained layers).  Weight fragments come straight from L2 (24 KiB, the same for every wave; no LDS left for them),
+            // one K step per load batch; the split fragments are double-buffered and kept alive as in head_bx_layer (MFMA operand hazard).
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float y = acc[j][cb][r] + bs[r];
-                    if (a.relu) y = fmaxf(y, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((cb * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
+            for (int j = 0; j < NPB; ++j)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 t = *reinterpret_cast<const float4*>(bias_lds + cb * 32 + 8 * g4 + 4 * half);
+                        const float bq[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float y = acc[j][cb][4 * g4 + e] + bq[e];
+                            if (a.relu) y = fmaxf(y, 0.f);
+                            acc[j][cb][4 * g4 + e] = y;
+                        }
+                    }
+            // one pixel block at a time (its two 1x1 accumulators, stores included): both blocks at once do not fit into 256 registers next to
+            // the 3x3's results and the next tile's prefetched input
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
+            bf16x8 w2[2][3], xf[2][3];
+            auto ldw2 = [&](int t) {
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) w2[m2][q] = __builtin_bit_cast(bf16x8, a.wq2[((t * 2 + m2) * 3 + q) * 64 + lane]);
+            };
+#pragma unroll
+            for (int j = 0; j < NPB; ++j) {
+                f32x16 acc2[2];                   // [cout block of the 1x1]
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)      // FUSE 1: D2 rows = couts ; FUSE 2 (transposed product): D2 columns = couts
+                        acc2[m2][r] = FUSE == 1 ? bias_lds[64 + m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] : bias_lds[64 + m2 * 32 + l31];
+                auto split_step = [&](int t, bf16x8 (&o)[3]) {
+                    uint4 uh, um, ul;
+                    unsigned* ph = &uh.x; unsigned* pm = &um.x; unsigned* pl = &ul.x;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) split3(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pm[i], pl[i]);
+                    o[0] = __builtin_bit_cast(bf16x8, uh); o[1] = __builtin_bit_cast(bf16x8, um); o[2] = __builtin_bit_cast(bf16x8, ul);
+                };
+                asm volatile("" ::: "memory");
+                ldw2(0);
+                split_step(0, xf[0]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int sb = t & 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    // products (weight split, input split), small terms first; FUSE 2 swaps the operands (rows = pixels, lane = cout)
+#define BX_MM2(WQ, XQ) { _Pragma("unroll") for (int m2 = 0; m2 < 2; ++m2) acc2[m2] = FUSE == 1 \
+                        ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[m2][WQ], xf[sb][XQ], acc2[m2], 0, 0, 0) \
+                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[sb][XQ], w2[m2][WQ], acc2[m2], 0, 0, 0); }
+                    BX_MM2(2, 0) BX_MM2(0, 2) BX_MM2(1, 1) BX_MM2(1, 0) BX_MM2(0, 1) BX_MM2(0, 0)
+#undef BX_MM2
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < 4) {
+                        split_step(t + 1, xf[sb ^ 1]);
+                        // the new fragments pass through an asm that uses the old ones and this step's weights: their registers stay occupied
+                        // while the split's results and temporaries are written
+                        asm volatile("" : "+v"(xf[sb ^ 1][0]), "+v"(xf[sb ^ 1][1]), "+v"(xf[sb ^ 1][2])
+                                        : "v"(xf[sb][0]), "v"(xf[sb][1]), "v"(xf[sb][2]), "v"(w2[0][0]), "v"(w2[0][1]), "v"(w2[0][2]), "v"(w2[1][0]), "v"(w2[1][1]), "v"(w2[1][2]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        ldw2(t + 1);                  // (the loads land hundreds of cycles after the last MFMA read these registers)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");      // idle slots before the VALU code of the stores
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (FUSE == 1) {
+                    const int ox = cur.x0 + (l31 & 15);
+                    const int oy = cur.y0 + 2 * (j ? br1 : br0) + (l31 >> 4);
+                    const int voff = oy < a.H && ox < a.W ? (int)(((size_t)(4 * half) * HW + (size_t)oy * a.W + ox) * 4) : (int)0x80000000;
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float y = acc2[m2][r];
+                            if (a.relu2) y = fmaxf(y, 0.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((m2 * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
+                        }
+                } else {
+                    // channels-last: lane (cout l31, half) holds pixels (r & 3) + 8 (r >> 2) + 4 half of the block: 32 lanes = 128 contiguous bytes
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pm = (r & 3) + 8 * (r >> 2) + 4 * half;          // pixel of the block: row pm >> 4, column pm & 15
+                        const int oy = cur.y0 + 2 * (j ? br1 : br0) + (pm >> 4), ox = cur.x0 + (pm & 15);
+                        const int voff = oy < a.H && ox < a.W ? (int)((((size_t)oy * a.W + ox) * 64 + l31) * 4) : (int)0x80000000;
+#pragma unroll
+                        for (int m2 = 0; m2 < 2; ++m2) {
+                            float y = acc2[m2][r];
+                            if (a.relu2) y = fmaxf(y, 0.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, m2 * 128, 0);
+                        }
+                    }
                 }
             }
         }
@@ -291,25 +400,27 @@ void conv_bx64_kernel(Bx64Args a) {
 #undef BX_STAMP
 }
 
-template <int CIN>
-static int run_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
+template <int CIN, int FUSE>
+static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     Bx64Args a;
     a.in = in; a.wq = c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    a.wq2 = c2 ? reinterpret_cast<const uint4*>(c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     a.ncols = ceil_div(W, 16); a.nhr = ceil_div(H, 8); a.upi = a.ncols * a.nhr;
     static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN>), bx64::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE>), bx64::LDS_BYTES, attr_done);
     const long long units = (long long)B * a.upi;
     int grid = 2 * num_cus();                  // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
     if (units < grid) grid = (int)units;       // (small inputs: one unit per workgroup; the XCD mapping then needs grid % 8 == 0 or is skipped)
-    conv_bx64_kernel<CIN><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
+    conv_bx64_kernel<CIN, FUSE><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
     return 0;
 }
 
-int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
-    if (c.ks != 3 || c.stride != 1 || !c.w_bx || c.cout != 64) return -1;
-    if (c.cin == 64) return run_bx64<64>(c, in, B, H, W, out, st, trace);
-    return -1;
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc) {
+    if (c.ks != 3 || c.stride != 1 || !c.w_bx || c.cout != 64 || c.cin != 64) return -1;
+    if (!c2) return nhwc ? -1 : run_bx64<64, 0>(c, nullptr, in, B, H, W, out, st, trace);
+    if (c2->ks != 1 || c2->cin != 64 || c2->cout != 64 || !c2->w_bx) return -1;
+    return nhwc ? run_bx64<64, 2>(c, c2, in, B, H, W, out, st, trace) : run_bx64<64, 1>(c, c2, in, B, H, W, out, st, trace);
 }
 
 }  // namespace xfh

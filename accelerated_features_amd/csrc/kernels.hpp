@@ -75,7 +75,8 @@ int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, 
                      float* out, bool nhwc_out, hipStream_t st, long long* trace = nullptr);
 // 3x3/s1 on bf16 MFMAs with three-way split operands (fp32-equivalent; k_conv_bx.hip); -1 if no instantiation
 int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
-int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr,
+                     const ConvW* fused1x1 = nullptr, bool nhwc = false);
 int bx_steps(int cin);      // K steps of 16 = 2 groups of 8 channels of one tap
 double conv_flops(const ConvW& c, int B, int Hout, int Wout);
 

@@ -151,6 +151,33 @@ def test_backbone_alternative_kernels_same_results(env):
     assert "ERRS" in r.stdout
 
 
+def test_split_bf16_backbone_equals_f32_mfma_backbone_at_bench_shape(xf, tmp_path):
+    """At the benchmark shape (B=64 VGA) the default path runs the 24-channel layers, the three 64 -> 64 layers at 1/8 scale (two of them with
+    their trailing 1x1 fused, one writing channels-last) and both heads on split-bf16 MFMAs.  Same network outputs as with every one of
+    them on the f32-MFMA kernels (XFH_BX=0, XFH_HEADS=f32: read once per process, so that side runs in its own process)."""
+    import subprocess
+    ref_path = str(tmp_path / "ref.npz")
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))\n"
+        "import fixtures\n"
+        "from accelerated_features_amd import XFeat\n"
+        "xf = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=4096)\n"
+        "x = torch.cat([fixtures.texture_images(8, 480, 640, seed=s) for s in range(8)]).cuda()\n"
+        "feats, logits, rel = xf.net(x)\n"
+        f"np.savez({ref_path!r}, feats=feats[::8].cpu().numpy(), logits=logits[::8].cpu().numpy(), rel=rel.cpu().numpy())\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "XFH_BX": "0", "XFH_HEADS": "f32"}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-400:], r.stderr[-1500:])
+    ref = np.load(ref_path)
+    x = torch.cat([fixtures.texture_images(8, 480, 640, seed=s) for s in range(8)]).cuda()
+    feats, logits, rel = xf.net(x)
+    e = {"feats": float(np.abs(feats[::8].cpu().numpy() - ref["feats"]).max()), "logits": float(np.abs(logits[::8].cpu().numpy() - ref["logits"]).max()),
+         "rel": float(np.abs(rel.cpu().numpy() - ref["rel"]).max())}
+    print(e, "feats absmax", float(np.abs(ref["feats"]).max()), "logits absmax", float(np.abs(ref["logits"]).max()))
+    assert e["feats"] <= 1e-4 and e["logits"] <= 5e-4 and e["rel"] <= 3e-5, e      # two fp32-accurate computations of a 20-layer network
+
+
 def test_backbone_fused_heat_equals_helper(xf):
     x = fixtures.texture_images(2, 96, 128, seed=11).cuda()
     feats, logits, heat, rel = xf.net.backbone(x, want_logits=True, want_heat=True)
