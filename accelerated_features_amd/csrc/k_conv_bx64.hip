@@ -298,11 +298,14 @@ void conv_bx64_kernel(Bx64Args a) {
             // the 3x3's results and the next tile's prefetched input
             const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
             bf16x8 w2[2][3], xf[2][3];
+            // (buffer loads: ONE address register per lane, the fragment in the scalar offset -- as global loads the 24 fragment addresses were
+            // 48 registers, spilled, and re-read from scratch in front of every load)
+            const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wq2, 0, 4 * 2 * 3 * 1024, 0x00020000);
             auto ldw2 = [&](int t) {
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) w2[m2][q] = __builtin_bit_cast(bf16x8, a.wq2[((t * 2 + m2) * 3 + q) * 64 + lane]);
+                    for (int q = 0; q < 3; ++q) w2[m2][q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, lane * 16, ((t * 2 + m2) * 3 + q) * 1024, 0));
             };
 #pragma unroll
             for (int j = 0; j < NPB; ++j) {
