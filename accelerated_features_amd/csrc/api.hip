@@ -579,7 +579,7 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     static int use_bx = -1;
     if (use_bx < 0) { const char* e = getenv("XFH_BX"); use_bx = e ? atoi(e) : 5; }      // 1: 24-channel layers; 4: unfused 64 -> 64 layers on large maps (2: on every map); 8: not block3.0
     int rc = -1;
-    const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 2048;
+    const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 1024;      // >= 2 half-tile units per workgroup of the persistent grid (B=8 164x164: 92 vs 124 us stand-alone)
     if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc);      // 3x3 + trailing 1x1 in one split-bf16 kernel
     if (rc && use_bx && c.w_bx && !c2 && !nhwc) {
