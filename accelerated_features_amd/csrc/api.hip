@@ -89,7 +89,6 @@ static size_t array_floats(int idx) {
 // profiler: HIP events around one kernel family, on the launch stream
 // ------------------------------------------------------------------------------------------
 namespace xfh {
-extern long long* g_block1_trace;      // k_conv_direct.hip
 extern long long* g_head_trace;        // k_heads.hip
 struct Profiler {
     int which = 0;
@@ -403,33 +402,6 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                             }
         }
     }
-    // block1.2 (8 -> 8) and block1.3 (8 -> 24, s2) on split-bf16 MFMAs (k_conv_direct.hip: block1_bx_kernel), operand order of
-    // v_mfma_f32_16x16x32_bf16: lane (cout = lane & 15, tap group kg = lane >> 4) holds tap 4 s + kg of K step s (taps 9..11 zero), channels 0..7.
-    // conv3: [step 3][split 3][64 lanes][8] ; conv4: [cout block 2][step 3][split 3][64 lanes][8]
-    size_t b1bx_off = 0;
-    {
-        b1bx_off = reserve((size_t)(9 + 18) * 64 * 4);
-        uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[b1bx_off]);
-        const int ls[2] = {L_BLOCK1_2, L_BLOCK1_3};
-        size_t frag = 0;
-        for (int p = 0; p < 2; ++p) {
-            const ConvSpec& c = kConvs[ls[p]];
-            for (int cb = 0; cb < (p ? 2 : 1); ++cb)
-                for (int s = 0; s < 3; ++s) {
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int i = 0; i < 8; ++i) {
-                            const int o = 16 * cb + (lane & 15), tap = 4 * s + (lane >> 4);
-                            const float v = (o < c.cout && tap < 9) ? blob[coff[ls[p]].oihw + ((size_t)o * c.cin + i) * 9 + tap] : 0.f;
-                            const uint16_t q0 = bf16_rne(v);
-                            const float r1 = v - bf16_float(q0);
-                            const uint16_t q1 = bf16_rne(r1);
-                            const uint16_t q[3] = {q0, q1, bf16_rne(r1 - bf16_float(q1))};
-                            for (int sp = 0; sp < 3; ++sp) dst[((frag + sp) * 64 + lane) * 8 + i] = q[sp];
-                        }
-                    frag += 3;
-                }
-        }
-    }
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].
     // K order: the first layer takes its channels in natural order (16 t + 8 half + i); a chained layer takes the previous layer's D
     // registers, i.e. feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).
@@ -518,7 +490,6 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     ctx->nw.zeros = ctx->blob + zoff;
     for (int hd = 0; hd < 2; ++hd) { ctx->nw.head_bx[hd] = ctx->blob + head_off[hd]; ctx->nw.head_bx_bias[hd] = ctx->blob + head_boff[hd]; }
     ctx->nw.head_rel_b_last = head_b_last;
-    ctx->nw.block1_bx = ctx->blob + b1bx_off;
     for (int fi = 0; fi < 5; ++fi) {
         LinW& l = ctx->nw.fine[fi];
         l.k = kFine[fi].k; l.n = kFine[fi].n; l.n_pad = (kFine[fi].n + 63) / 64 * 64; l.relu = kFine[fi].bn;
@@ -876,8 +847,7 @@ int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
 int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
     if (!h) return fail(XFH_ERR_ARG, "xfh_debug_trace: NULL handle");
     h->trace = device_buffer;
-    g_block1_trace = device_buffer ? device_buffer + (1 << 21) : nullptr;
-    g_head_trace = device_buffer ? device_buffer + (1 << 21) + (1 << 16) : nullptr;      // (and the key-point head's 64 Ki entries further)      // block1's stamps live 2 Mi entries into the buffer (the conv kernels use the front)
+    g_head_trace = device_buffer ? device_buffer + (1 << 21) + (1 << 16) : nullptr;      // the key-point head's stamps live 2 Mi + 64 Ki entries into the buffer (the conv kernels use the front)
     return XFH_OK;
 }
 

@@ -72,7 +72,7 @@ constexpr int wino_pick_hwp(int ttw) {
     return ttw + 1;
 }
 
-template <int CB, int TBG, int NCBW, int NTBW, int TTH_, int TTW_, int COUT2 = 0, bool PERSIST = false>
+template <int CB, int TBG, int NCBW, int NTBW, int TTH_, int TTW_, int COUT2 = 0>
 struct WinoCfg {
     static constexpr int CK = 4, TTH = TTH_, TTW = TTW_;
     static constexpr int NG = (CB / NCBW) * (TBG / NTBW), NW = 4 * NG, NTHR = 64 * NW;
@@ -83,20 +83,17 @@ struct WinoCfg {
     static constexpr int RING = 2 * UCH + 2 * CK * PS;           // floats: two slots each
     static constexpr int XCH = NW * 4 * 16 * 64;                 // floats: output-transform exchange
     static constexpr int COUT2_PAD = (COUT2 + 31) / 32 * 32;
-    // persistent workgroups: the exchange / deferred-store area (64 KiB) must not overlay the DMA ring
-    static constexpr int XS_OFF = PERSIST ? RING : 0, XS_FLOATS = 16384;
-    static constexpr int W2_OFF = PERSIST ? RING + XS_FLOATS : (RING > XCH ? RING : XCH);      // fused 1x1 weights live behind the ring / exchange area
+    static constexpr int W2_OFF = RING > XCH ? RING : XCH;      // fused 1x1 weights live behind the ring / exchange area
     static constexpr int LDS_FLOATS = W2_OFF + 32 * CB * COUT2_PAD;
     static_assert(NCBW * NTBW == 2 && CB % NCBW == 0 && TBG % NTBW == 0, "two 32x32 blocks per wave");
     static_assert(TTH * TTW <= NT && TTH * TTW > NT - 32, "region must fill the tile blocks");
     static_assert((UCH / 256) % NW == 0, "every wave issues the same number of weight DMAs");
 };
 
-template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2, bool NHWC, bool PERSIST>
+template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2, bool NHWC>
 __global__ __launch_bounds__(256 * (CB / NCBW) * (TBG / NTBW)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino_kernel(WinoArgs a) {
-    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, PERSIST>;
-    static_assert(!PERSIST || (COUT2 == 0 && Cfg::NW == 8 && 32 * CB * 4 * Cfg::NT == Cfg::XS_FLOATS), "persistent variant: unfused, 8 waves, 64 KiB of outputs per tile");
+    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
     constexpr int COUT2_PAD = Cfg::COUT2_PAD, MB2 = COUT2_PAD / 32;
     static_assert(COUT2 == 0 || (COUT == 32 * CB && NCBW == 2 && MB2 == 2), "fused 1x1: full cout blocks, two per wave, 64 outputs");
     static_assert(COUT2 > 0 || !NHWC, "channels-last output only with the fused 1x1");
@@ -112,7 +109,7 @@ void conv_wino_kernel(WinoArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nu = wave & 3, g = wave >> 2;          // waves w and w+4 share a SIMD: same nu, different group
     const int cb0 = (g % (CB / NCBW)) * NCBW, tb0 = (g / (CB / NCBW)) * NTBW;
-    // per-tile state (a persistent workgroup walks virtual ids blockIdx.x, + gridDim.x, ...)
+    // per-tile state
     int b = 0, oy0 = 0, ox0 = 0;
     const size_t HW = (size_t)a.H * a.W;
     const int HWb = (int)(HW * sizeof(float));
@@ -242,49 +239,9 @@ void conv_wino_kernel(WinoArgs a) {
         // Wave nu finishes output row oi = nu&1 of block blk = nu>>1 (both columns j: float2).
         const int oi = nu & 1, blk = nu >> 1;
         const int cbk = NCBW == 2 ? cb0 + blk : cb0, tbk = NTBW == 2 ? tb0 + blk : tb0;
-        // ---- persistent mode: outputs of tile k wait in LDS (SB = [cout][2*TTH][2*TTW]) and are stored
-        // slice by slice under the MFMAs of tile k+1, so no CU ever sits in a pure store phase.
-        bool have_prev = false;
-        int pb = 0, poy0 = 0, pox0 = 0;
-        constexpr int RH = 2 * TTH, RW = 2 * TTW;
-        constexpr int PPC = RH * RW / 2;                          // float2 elements per channel plane of SB
-        constexpr int CPC = (COUT_PAD + NCH - 1) / NCH;           // channels stored per chunk
-        constexpr int NIT = (CPC * PPC + Cfg::NTHR - 1) / Cfg::NTHR;
-        float* SBl = smem + Cfg::XS_OFF;
-        // lane constants of the deferred store: element w = it*NTHR + tid of a slice -> (channel cw, row py, column px),
-        // packed into one register per it
-        int st_c[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int w = it * Cfg::NTHR + tid;
-            const int cw = w < CPC * PPC ? w / PPC : 0x7fff;      // out of range -> never stored
-            const int rem = w % PPC;
-            st_c[it] = (cw << 16) | ((rem / (RW / 2)) << 8) | (2 * (rem % (RW / 2)));
-        }
-        // Branch-free (it sits inside the pinned MFMA schedule): buffer stores drop lanes whose offset is out of
-        // range, so "nothing to store" (first tile, image border, padded channels) is just an invalid offset.
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((size_t)a.B * COUT * HW * sizeof(float)), 0x00020000);
-        float2 st_v;
-        int st_o0, st_o1;
-        auto slice_load = [&](int i, int it) {
-            const int py = (st_c[it] >> 8) & 0xff, px = st_c[it] & 0xff;
-            const int co = i * CPC + (st_c[it] >> 16);
-            const int oy = poy0 + py, ox = pox0 + px;
-            const bool ok = have_prev && co < COUT && oy < a.H && ox < a.W;
-            const int off = (((pb * COUT + co) * a.H + oy) * a.W + ox) * 4;
-            st_o0 = ok ? off : (int)0x80000000;
-            st_o1 = ok && ox + 1 < a.W ? off + 4 : (int)0x80000000;
-            const int cl = co < COUT_PAD ? co : 0;
-            st_v = *reinterpret_cast<const float2*>(SBl + ((cl * RH + py) * RW + px));
-        };
-        auto slice_store = [&]() {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(st_v.x), rs_out, st_o0, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(st_v.y), rs_out, st_o1, 0, 0);
-        };
-
         issue(0, 0);
         issue(1, 1);
-        for (int vid = blockIdx.x;;) {
+        {
         f32x16 acc[4][2];          // [xi][block], block = cout-block-major
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi)
@@ -316,13 +273,11 @@ void conv_wino_kernel(WinoArgs a) {
 #define P_A   { load_a(NXT, ops[NXT]); }
 #define P_BR(p) { read_b(NXT, p, d); }
 #define P_BV(p) { make_b(p, d, ops[NXT]); }
-#define P_SL(it) { if constexpr (PERSIST && (it) < NIT) slice_load(i, (it) < NIT ? (it) : 0); }      /* outputs of the previous tile leave under this tile's MFMAs */
-#define P_SS(it) { if constexpr (PERSIST && (it) < NIT) slice_store(); }
             if (SV == 0) {
                 M(0) P_DMA M(1) P_A P_BR(0) M(2) M(3) M(4) P_BV(0) M(5) P_BR(1) M(6) M(7) M(8) P_BV(1)
-                M(9) P_SL(0) M(10) M(11) P_SS(0) P_SL(1) M(12) M(13) P_SS(1) P_SL(2) M(14) M(15) P_SS(2)
+                M(9) M(10) M(11) M(12) M(13) M(14) M(15)
             } else {
-                M(0) P_SL(0) M(1) M(2) P_SS(0) P_SL(1) M(3) M(4) P_SS(1) P_SL(2) M(5) M(6) P_SS(2) P_DMA M(7) P_A P_BR(0) M(8) M(9) M(10) P_BV(0) M(11) P_BR(1)
+                M(0) M(1) M(2) M(3) M(4) M(5) M(6) P_DMA M(7) P_A P_BR(0) M(8) M(9) M(10) P_BV(0) M(11) P_BR(1)
                 M(12) M(13) M(14) P_BV(1) M(15)
             }
 #undef M
@@ -330,8 +285,6 @@ void conv_wino_kernel(WinoArgs a) {
 #undef P_A
 #undef P_BR
 #undef P_BV
-#undef P_SL
-#undef P_SS
         };
         for (int i = 0; i < NCH; i += 2) {
             chunk(i, std::integral_constant<int, 0>{});
@@ -345,70 +298,7 @@ void conv_wino_kernel(WinoArgs a) {
         float bs[16];                // bias: loaded here, in flight under the exchange
 #pragma unroll
         for (int r = 0; r < 16; ++r) bs[r] = a.bias[cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-        if constexpr (PERSIST) {
-            dma_barrier();           // all waves done with the rings (and the dummy tail DMA has landed)
-            const int cur_b = b, cur_oy0 = oy0, cur_ox0 = ox0;
-            const int nvid = vid + (int)gridDim.x;
-            const bool has_next = nvid < a.tiles * a.B && set_tile(nvid);
-            if (has_next) { issue(0, 0); issue(1, 1); }       // first DMA of the next tile flies under this output transform
-            float* X = smem + Cfg::XS_OFF;                    // one pass: [wave][k][16 r][64 lanes]
-            float y0[16], y1[16];
-            f32x16 T[2][2];                                   // [output row i][block]; the accumulators die here
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                T[0][k] = acc[0][k] + acc[1][k] + acc[2][k];
-                T[1][k] = acc[1][k] - acc[2][k] - acc[3][k];
-            }
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {            // pass = output row i
-                const f32x16 (&tv)[2] = T[pass];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (oi == pass && k == blk) continue;     // wave-uniform: the vector this wave finishes itself
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) X[((wave * 2 + k) * 16 + r) * 64 + lane] = tv[k][r];
-                }
-                dma_barrier();
-                if (oi == pass) {
-                    const f32x16 own = blk ? tv[1] : tv[0];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        y0[r] = nu == 3 ? 0.f : own[r];
-                        y1[r] = nu == 0 ? 0.f : (nu == 1 ? own[r] : -own[r]);
-                    }
-#pragma unroll
-                    for (int n2 = 0; n2 < 4; ++n2) {
-                        if (n2 == nu) continue;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float v = X[(((g * 4 + n2) * 2 + blk) * 16 + r) * 64 + lane];
-                            if (n2 != 3) y0[r] += v;
-                            if (n2 == 1) y1[r] += v;
-                            if (n2 >= 2) y1[r] -= v;
-                        }
-                    }
-                }
-                dma_barrier();       // the exchange area is free again (next pass / the store buffer)
-            }
-            // finished outputs -> store buffer (the previous tile's slices all left during the main loop)
-            {
-                const int t = tbk * 32 + l31;
-                const int ty = t / TTW, tx = t - ty * TTW;
-                if (t < TTH * TTW) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int co = cbk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float v0 = y0[r] + bs[r], v1 = y1[r] + bs[r];
-                        if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                        *reinterpret_cast<float2*>(SBl + (co * RH + 2 * ty + oi) * RW + 2 * tx) = make_float2(v0, v1);
-                    }
-                }
-            }
-            have_prev = true; pb = cur_b; poy0 = cur_oy0; pox0 = cur_ox0;
-            if (!has_next) break;
-            vid = nvid;
-            continue;
-        } else {
+        {
             dma_barrier();               // all waves done with the rings (and the dummy tail DMA has landed)
             if (tr && tid == 0) tr[10] = __builtin_amdgcn_s_memtime();
             float* X = smem;             // [wave][i*2+k][16 r][64 lanes]
@@ -555,14 +445,7 @@ void conv_wino_kernel(WinoArgs a) {
                 }
             }
             if (tr && tid == 0) { tr[21] = __builtin_amdgcn_s_memtime(); tr[23] = __builtin_amdgcn_s_memrealtime(); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); tr[22] = ((long long)xcc << 32) | hwid; }
-            break;
         }
-        }   // tile loop
-        if constexpr (PERSIST) {     // drain the last tile's outputs
-            dma_barrier();
-            for (int i = 0; i < NCH; ++i)
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) { slice_load(i, it); slice_store(); }       // NCH * CPC >= COUT_PAD: every channel leaves
         }
     };
     // the two waves of a SIMD (g even / odd) run complementary schedules
@@ -573,9 +456,9 @@ void conv_wino_kernel(WinoArgs a) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2 = 0, bool NHWC = false, bool PERSIST = false>
+template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2 = 0, bool NHWC = false>
 static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2 = nullptr) {
-    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, PERSIST>;
+    using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
     if ((size_t)c.cin * H * W * sizeof(float) >= 0x7fffffffu) return -1;     // buffer-resource range
     WinoArgs a;
     a.in = in; a.wu = c.w_wino; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
@@ -586,10 +469,9 @@ static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float*
     const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
     static_assert(Cfg::LDS_FLOATS * sizeof(float) <= 160 * 1024, "LDS budget");
     static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC, PERSIST>), 160 * 1024, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC>), 160 * 1024, attr_done);
     int grid = xcd_grid_size(a.tiles, B);
-    if (PERSIST && grid > 256) grid = 256;          // one workgroup per CU walks the tiles (256 % 8 == 0 keeps the XCD mapping)
-    conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC, PERSIST><<<grid, Cfg::NTHR, lds, st>>>(a);
+    conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC><<<grid, Cfg::NTHR, lds, st>>>(a);
     return 0;
 }
 
@@ -600,7 +482,7 @@ int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B,
     (void)zeros;
     if (c.ks != 3 || c.stride != 1 || !c.w_wino) return -1;
     const int key = c.cin * 1000 + c.cout;
-    static int tune = -1;          // XFH_WINO_TUNE (A/B runs) bit 0: persistent 64-channel variant, bit 1: 4-wave 24-channel variant
+    static int tune = -1;          // XFH_WINO_TUNE (A/B runs) bit 1: 4-wave 24-channel variant
     if (tune < 0) { const char* e = getenv("XFH_WINO_TUNE"); tune = e ? atoi(e) : 0; }
     if (c2) {      // 3x3 + fused 1x1
         if (c2->ks != 1 || c2->cin != c.cout || c2->cout != 64) return -1;
@@ -624,9 +506,8 @@ int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B,
             return run_wino<24, 24, 1, 4, 1, 2, 8, 16>(c, in, B, H, W, out, st, trace);                      // 8 waves, 128 tiles
         case 64 * 1000 + 64:     // waves hold both cout blocks of one tile block
             if (cfg == 2) return run_wino<64, 64, 2, 2, 2, 1, 8, 8>(c, in, B, H, W, out, st, trace);        // 8 waves, 64 tiles
-            // persistent 8-wave workgroups (stores of tile k leave under the MFMAs of tile k+1): -11 % back to back on a hot
-            // cache, -2 % inside the real step (tools/layer_insitu.py) -> not the default; XFH_WINO_TUNE=1 selects it
-            if (cfg == 5 || (cfg == 0 && (tune & 1) && wino_groups(H, W, 8, 8) * B >= 1024)) return run_wino<64, 64, 2, 2, 2, 1, 8, 8, 0, false, true>(c, in, B, H, W, out, st, trace);
+            // (a persistent 8-wave variant -- outputs of tile k parked in LDS and stored under the MFMAs of tile k+1 -- measured -11 % back to back
+            // on a hot cache but -0.5 ... -2 % inside the real step, needed 256 VGPRs + 28 B of scratch, and was removed: DESIGN 3.2)
             if (cfg == 3) return run_wino<64, 64, 2, 2, 2, 1, 16, 4>(c, in, B, H, W, out, st, trace);
             if (cfg == 4 || (cfg == 0 && wino_groups(H, W, 8, 4) < wino_groups(H, W, 4, 8)))
                 return run_wino<64, 64, 2, 1, 2, 1, 8, 4>(c, in, B, H, W, out, st, trace);

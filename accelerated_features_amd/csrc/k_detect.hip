@@ -274,7 +274,7 @@ __device__ inline void bitonic_wave_steps(unsigned long long (&v)[4], int base, 
     if (size >= 4) { cswap(v[0], v[1], up); cswap(v[2], v[3], up); }
     else { cswap(v[0], v[1], true); cswap(v[2], v[3], false); }    // size == 2: pairs alternate direction inside the lane
 }
-__device__ inline void bitonic_sort_lds(unsigned long long* lk, int n) {
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* lk, int n) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (n < 256) {                                                  // tiny sorts: plain network (top_k < 256)
         for (int size = 2; size <= n; size <<= 1)

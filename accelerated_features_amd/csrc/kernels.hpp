@@ -39,7 +39,6 @@ struct NetWeights {
     const void* head_bx[2];          // per layer [K step 4][cout block][split 3][64 lanes][8] bf16
     const float* head_bx_bias[2];    // biases padded to the cout blocks (KP 64,64,64,96 ; REL 64,64)
     float head_rel_b_last;           // bias of the final 64 -> 1 layer of the reliability head
-    const void* block1_bx;           // block1.2 / block1.3 on split-bf16 MFMAs: [layer 2][tap pair 5][split 3][64 lanes][8] bf16 (k_conv_direct.hip)
 };
 
 struct Profiler;   // api.hip

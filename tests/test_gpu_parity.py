@@ -126,10 +126,10 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
 
 
-@pytest.mark.parametrize("env", [{"XFH_HEADS": "f32", "XFH_BX": "0"}, {"XFH_BX": "3", "XFH_BLOCK1": "bx"}])
+@pytest.mark.parametrize("env", [{"XFH_HEADS": "f32", "XFH_BX": "0"}, {"XFH_BX": "3"}])
 def test_backbone_alternative_kernels_same_results(env):
-    """The A/B switches select other kernels for the same layers (heads on f32 MFMAs, 24->24 layers on Winograd; 64->64 layers and
-    block1's 8-channel layers on the split-bf16 kernels): the switches are read once per process, so each setting runs the small golden backbone case in its own process."""
+    """The A/B switches select other kernels for the same layers (heads on f32 MFMAs, 24->24 layers on Winograd; every unfused 64->64 layer on the
+    split-bf16 kernel): the switches are read once per process, so each setting runs the small golden backbone case in its own process."""
     import subprocess
     code = (
         "import os, sys, numpy as np, torch\n"
@@ -528,7 +528,7 @@ def test_repeated_backbone_and_sparse_path_bit_identical(xf):
 
 
 def test_winograd_configurations_match_generic_kernel(xf):
-    """Every Winograd configuration of xfh_conv_layer (variants 2..6: workgroup shapes, 4/8 waves, persistent) against the
+    """Every Winograd configuration of xfh_conv_layer (variants 2..6: workgroup shapes, 4/8 waves) against the
     generic direct kernel, on odd / small / non-multiple-of-8 shapes (scalar-store path, clipped regions, B not a multiple of 8)."""
     from accelerated_features_amd.spec import CONVS, CONV_INDEX
     lib = _lib().load()

@@ -179,3 +179,29 @@ def test_no_valu_write_lands_in_a_freshly_read_bf16_mfma_operand():
         nk, nm, bad = mod.audit(f)
         assert nk > 0 and nm > 0
         assert not bad, (os.path.basename(f), bad[:3])
+
+
+def test_no_kernel_in_the_library_uses_scratch(tmp_path):
+    """Code-object metadata of the built libxfeat_hip.so: no kernel has a private segment (scratch) or spills vector registers
+    (a scratch reload parks a vmcnt(0) wherever it lands; the variants that needed scratch were measured slower and removed)."""
+    import shutil
+    import subprocess
+    import yaml
+    from accelerated_features_amd import build
+    lib = build.LIB
+    assert os.path.exists(lib), "build the library first (python -m accelerated_features_amd.build)"
+    llvm = "/opt/rocm/lib/llvm/bin"
+    so = shutil.copy(lib, tmp_path / "lib.so")
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", os.path.basename(so)], cwd=tmp_path, check=True, capture_output=True)
+    objs = sorted(p for p in os.listdir(tmp_path) if p.endswith("gfx950"))
+    assert objs, "no gfx950 code objects in the library"
+    n = 0
+    for o in objs:
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", o], cwd=tmp_path, check=True, capture_output=True, text=True).stdout
+        if "amdhsa.kernels" not in notes:
+            continue
+        doc = notes[notes.index("---"):notes.rindex("...")]
+        for k in yaml.safe_load(doc)["amdhsa.kernels"]:
+            n += 1
+            assert k[".private_segment_fixed_size"] == 0 and k[".vgpr_spill_count"] == 0, (k[".name"], k[".private_segment_fixed_size"], k[".vgpr_spill_count"])
+    assert n >= 100
