@@ -786,6 +786,32 @@ int xfh_refine_matches(xfh_handle h, const float* desc0, const float* desc1, con
     return check_launch("xfh_refine_matches");
 }
 
+size_t xfh_homography_workspace_bytes(int P, int max_iters) {
+    if (P <= 0 || max_iters <= 0) return 0;
+    return xfh::homography_workspace_bytes(P, max_iters);
+}
+
+int xfh_find_homography(const float* pts0, const float* pts1, const int32_t* counts, int n_const, int P, int cap, double ransac_thr,
+                        int max_iters, double confidence, uint64_t seed, double* H, uint8_t* mask, int32_t* info, void* workspace,
+                        size_t workspace_bytes, xfh_stream stream) {
+    if (!pts0 || !pts1 || !H || !mask || !info) return fail(XFH_ERR_ARG, "xfh_find_homography: NULL argument");
+    if (P <= 0 || P > 65535 || cap <= 0 || cap > (1 << 24) || (!counts && (n_const < 0 || n_const > cap)))
+        return fail(XFH_ERR_ARG, "xfh_find_homography: bad shape (P %d, cap %d, n %d)", P, cap, n_const);
+    if (!(ransac_thr > 0.0) || !(confidence > 0.0 && confidence < 1.0)) return fail(XFH_ERR_ARG, "xfh_find_homography: threshold %g / confidence %g", ransac_thr, confidence);
+    if (max_iters < 1 || max_iters > 4096) return fail(XFH_ERR_UNSUPPORTED, "xfh_find_homography: max_iters %d outside [1, 4096]", max_iters);
+    int rc = check_ws(workspace, workspace_bytes, xfh::homography_workspace_bytes(P, max_iters));
+    if (rc) return rc;
+    if (launch_find_homography(pts0, pts1, counts, n_const, P, cap, ransac_thr, max_iters, confidence, seed, H, mask, info, workspace, (hipStream_t)stream))
+        return fail(XFH_ERR_UNSUPPORTED, "xfh_find_homography: unsupported configuration");
+    return check_launch("xfh_find_homography");
+}
+
+int xfh_homography_tables(double ransac_thr, uint32_t* score_table, double* weight_table, xfh_stream stream) {
+    if (!score_table || !weight_table || !(ransac_thr > 0.0)) return fail(XFH_ERR_ARG, "xfh_homography_tables: bad argument");
+    launch_homography_tables(ransac_thr, score_table, weight_table, (hipStream_t)stream);
+    return check_launch("xfh_homography_tables");
+}
+
 int xfh_kpts_heatmap(const float* logits, int B, int hc, int wc, float* heat, xfh_stream stream) {
     if (!logits || !heat || B <= 0 || hc <= 0 || wc <= 0) return fail(XFH_ERR_ARG, "xfh_kpts_heatmap: bad argument");
     launch_softmax_heat(logits, B, hc, wc, heat, (hipStream_t)stream);

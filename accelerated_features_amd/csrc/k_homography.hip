@@ -1,0 +1,471 @@
+// Robust homography from the match lists: the device side of
+//     H, inliers = cv2.findHomography(points1, points2, cv2.USAC_MAGSAC, ransac_thr, maxIters=700, confidence=0.995)
+// (realtime_demo.py:225 of the reference).  OpenCV is not available offline; what is implemented is the published algorithm behind
+// USAC_MAGSAC -- RANSAC with the MAGSAC++ quality and sigma-consensus++ weights (Barath, Noskova, Ivashechkin, Matas, CVPR 2020) -- with
+// the call's arguments (threshold, maxIters, confidence).  The specification (the test suite holds an independent numpy
+// restatement of it):
+//   * minimal sample: 4 distinct correspondences; draw d of hypothesis `it` of pair p is the upper half of
+//     splitmix64-finaliser(seed + golden * (((p << 20) + it) * 16 + d + 1)) scaled to [0, n); duplicates are redrawn (16 draws at most);
+//   * 4-point homography H = B adj(A), A / B the projective bases through the first three source / target points that send (1,1,1) to
+//     the fourth (3x3 adjugates, no pivoting); a sample is rejected unless its four point triples all keep or all flip their orientation;
+//   * residual = squared forward transfer error; quality = sum over residuals below (2 thr)^2 of 1 - rho(r) / rho(k sigma_max), rho the
+//     MAGSAC++ loss for n = 4 degrees of freedom, k = 3.64, sigma_max = 2 thr / k, from a 4096-bin table over r^2 in 20-bit fixed point;
+//   * termination: hypotheses in order, a strictly better quality updates the bound log(1 - confidence) / log(1 - w^4), w = inlier ratio at thr;
+//   * refinement of the winner: up to 5 re-weighted least-squares steps (Hartley-normalised inhomogeneous DLT, weights w(r) / w(0) from the
+//     same bins), each kept only if it raises the quality; mask = residual < thr^2 under the final model; found = at least 4 inliers.
+//
+// What makes it a device algorithm: hypothesis `it` is a function of (seed, pair, it) alone, so ALL maxIters hypotheses are built and
+// scored at once -- thread = hypothesis, workgroups over (256 hypotheses) x (512 correspondences) x pairs -- and the sequential loop's
+// stopping rule is applied afterwards to the score list, exactly as the loop would have applied it.  A score is a sum of integers
+// (u64 atomics: no summation order), the geometry is fp64 with every product and sum rounded once (fp contraction off in this file), so
+// the winning hypothesis, the iteration count and the inlier mask are reproducible bit for bit by any IEEE implementation of the
+// specification; only the least-squares refinement carries a (1e-9) tolerance, from the order of its fp64 reductions.
+//
+// Three launches per call, fp64 VALU + latency bound (one pair with 1000 matches and 700 hypotheses is 0.7 M residuals of ~45 fp64 ops):
+//   homog_tables_kernel : loss / weight tables of this threshold (closed forms of the incomplete gamma functions for n = 4), scores zeroed
+//   homog_score_kernel  : hypotheses + MAGSAC++ quality + inlier counts
+//   homog_select_kernel : one workgroup per pair: stopping rule, refinement (23 weighted sums -> 8x8 Cholesky), mask
+#include "kernels.hpp"
+
+#pragma clang fp contract(off)
+
+namespace xfh {
+namespace hg {
+constexpr int NBINS = 4096, SCORE_ONE = 1 << 20, LO_ITERS = 5, MAX_DRAWS = 16;
+constexpr int HYP_PER_WG = 256, PTS_PER_WG = 512, MAX_ITERS = 4096;
+constexpr double K_QUANTILE = 3.64, MAX_THR_FACTOR = 2.0;
+constexpr int NSUM = 23;
+}  // namespace hg
+
+struct HgArgs {
+    const float* p0;
+    const float* p1;
+    const int32_t* counts;
+    int n_const, P, cap, iters, iters_pad;
+    double thr2, tmax2, bin_scale, log1mc;
+    unsigned long long seed;
+    unsigned* stab;
+    double* wtab;
+    unsigned long long* hscore;
+    unsigned* hcnt;
+    double* H;
+    unsigned char* mask;
+    int32_t* info;
+};
+
+// ---- tables -----------------------------------------------------------------------------------------------------------------------------
+// Gamma(3/2, x) = sqrt(pi)/2 erfc(sqrt x) + sqrt x e^-x ;  gamma(5/2, x) = 3/4 sqrt(pi) erf(sqrt x) - e^-x sqrt x (3/2 + x)
+__device__ inline double upper_gamma_3_2(double sx) { return 0.88622692545275801365 * erfc(sx) + sx * exp(-sx * sx); }
+__device__ inline double lower_gamma_5_2(double sx) { return 1.32934038817913702047 * erf(sx) - exp(-sx * sx) * sx * (1.5 + sx * sx); }
+
+__global__ __launch_bounds__(256) void homog_tables_kernel(double thr, unsigned* __restrict__ stab, double* __restrict__ wtab,
+                                                           unsigned long long* __restrict__ hscore, unsigned* __restrict__ hcnt, int nhyp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < hg::NBINS && stab) {
+        const double t_max = hg::MAX_THR_FACTOR * thr, sigma = t_max / hg::K_QUANTILE;
+        const double bin_scale = hg::NBINS / (t_max * t_max);
+        const double r = sqrt((i + 0.5) / bin_scale);
+        const double sx = r / (sigma * 1.41421356237309504880), sk = hg::K_QUANTILE / 1.41421356237309504880;
+        const double gk = upper_gamma_3_2(sk);
+        const double diff = upper_gamma_3_2(sx) - gk;
+        const double half_s2 = 0.5 * sigma * sigma;
+        const double loss = half_s2 * lower_gamma_5_2(sx) + 0.25 * r * r * diff;          // common factor C 2^(5/2) / sigma dropped
+        const double loss_out = half_s2 * lower_gamma_5_2(sk);
+        double q = 1.0 - loss / loss_out;
+        q = q < 0.0 ? 0.0 : (q > 1.0 ? 1.0 : q);
+        stab[i] = (unsigned)floor(q * hg::SCORE_ONE + 0.5);
+        wtab[i] = diff / (0.88622692545275801365 - gk);                                    // w(r) / w(0)
+    }
+    for (int j = i; j < nhyp; j += gridDim.x * 256) { hscore[j] = 0ull; hcnt[j] = 0u; }
+}
+
+// ---- hypotheses -------------------------------------------------------------------------------------------------------------------------
+__device__ inline unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ inline int draw_index(unsigned long long seed, int pair, int it, int draw, int n) {
+    const unsigned long long counter = ((unsigned long long)pair * (1ull << 20) + (unsigned long long)it) * hg::MAX_DRAWS + (unsigned long long)draw;
+    const unsigned long long h = mix64(seed + 0x9e3779b97f4a7c15ull * (counter + 1ull));
+    return (int)(((h >> 32) * (unsigned long long)n) >> 32);
+}
+__device__ inline double orient(double ax, double ay, double bx, double by, double cx, double cy) {
+    return (bx - ax) * (cy - ay) - (by - ay) * (cx - ax);
+}
+// columns lambda_j (x_j, y_j, 1) of the projective basis through points 0..2 that sends (1,1,1) to D * point 3; d[4] = triple orientations
+__device__ inline void basis(const double (&x)[4], const double (&y)[4], double (&m)[3][3], double (&d)[4]) {
+    const double l0 = orient(x[3], y[3], x[1], y[1], x[2], y[2]);
+    const double l1 = orient(x[0], y[0], x[3], y[3], x[2], y[2]);
+    const double l2 = orient(x[0], y[0], x[1], y[1], x[3], y[3]);
+    d[0] = orient(x[0], y[0], x[1], y[1], x[2], y[2]); d[1] = l0; d[2] = l1; d[3] = l2;
+    const double lam[3] = {l0, l1, l2};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { m[0][j] = lam[j] * x[j]; m[1][j] = lam[j] * y[j]; m[2][j] = lam[j]; }
+}
+// hypothesis `it` of pair `pair`: false when the draws ran out or the sample does not keep the orientation of its triples
+__device__ inline bool make_hypothesis(const float* __restrict__ p0, const float* __restrict__ p1, int n, unsigned long long seed, int pair, int it,
+                                       double (&h)[9]) {
+    int i0 = -1, i1 = -1, i2 = -1, i3 = -1, slot = 0;
+#pragma unroll
+    for (int d = 0; d < hg::MAX_DRAWS; ++d) {
+        const int c = draw_index(seed, pair, it, d, n);
+        const bool dup = (slot > 0 && c == i0) || (slot > 1 && c == i1) || (slot > 2 && c == i2);
+        if (slot < 4 && !dup) {
+            i0 = slot == 0 ? c : i0; i1 = slot == 1 ? c : i1; i2 = slot == 2 ? c : i2; i3 = slot == 3 ? c : i3;
+            ++slot;
+        }
+    }
+    if (slot < 4) return false;
+    const int idx[4] = {i0, i1, i2, i3};
+    double x0[4], y0[4], x1[4], y1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float2 a = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)idx[k]);
+        const float2 b = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)idx[k]);
+        x0[k] = a.x; y0[k] = a.y; x1[k] = b.x; y1[k] = b.y;
+    }
+    double A[3][3], Bm[3][3], da[4], db[4];
+    basis(x0, y0, A, da);
+    basis(x1, y1, Bm, db);
+    double adj[3][3];
+    adj[0][0] = A[1][1] * A[2][2] - A[1][2] * A[2][1];
+    adj[0][1] = A[0][2] * A[2][1] - A[0][1] * A[2][2];
+    adj[0][2] = A[0][1] * A[1][2] - A[0][2] * A[1][1];
+    adj[1][0] = A[1][2] * A[2][0] - A[1][0] * A[2][2];
+    adj[1][1] = A[0][0] * A[2][2] - A[0][2] * A[2][0];
+    adj[1][2] = A[0][2] * A[1][0] - A[0][0] * A[1][2];
+    adj[2][0] = A[1][0] * A[2][1] - A[1][1] * A[2][0];
+    adj[2][1] = A[0][1] * A[2][0] - A[0][0] * A[2][1];
+    adj[2][2] = A[0][0] * A[1][1] - A[0][1] * A[1][0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) h[3 * i + j] = (Bm[i][0] * adj[0][j] + Bm[i][1] * adj[1][j]) + Bm[i][2] * adj[2][j];
+    const double q0 = da[0] * db[0], q1 = da[1] * db[1], q2 = da[2] * db[2], q3 = da[3] * db[3];
+    return (q0 > 0 && q1 > 0 && q2 > 0 && q3 > 0) || (q0 < 0 && q1 < 0 && q2 < 0 && q3 < 0);
+}
+// squared forward transfer error
+__device__ inline double residual_sq(const double (&h)[9], double x, double y, double u1, double v1) {
+    const double w = (h[6] * x + h[7] * y) + h[8];
+    const double u = (h[0] * x + h[1] * y) + h[2];
+    const double v = (h[3] * x + h[4] * y) + h[5];
+    const double iw = 1.0 / w;
+    const double dx = u1 - u * iw, dy = v1 - v * iw;
+    return dx * dx + dy * dy;
+}
+__device__ inline int bin_of(double r2, double bin_scale) {
+    const int b = (int)(r2 * bin_scale);
+    return b < hg::NBINS - 1 ? b : hg::NBINS - 1;
+}
+
+__global__ __launch_bounds__(256) void homog_score_kernel(HgArgs a) {
+    __shared__ unsigned stab[hg::NBINS];
+    const int pair = blockIdx.z, tid = threadIdx.x;
+    const int n = a.counts ? min(a.counts[pair], a.cap) : a.n_const;
+    const int c0 = blockIdx.y * hg::PTS_PER_WG;
+    if (n < 4 || c0 >= n) return;
+#pragma unroll
+    for (int k = 0; k < hg::NBINS / 256; ++k) stab[tid + 256 * k] = a.stab[tid + 256 * k];
+    __syncthreads();
+    const int it = blockIdx.x * hg::HYP_PER_WG + tid;
+    if (it >= a.iters) return;
+    const float* __restrict__ p0 = a.p0 + (size_t)pair * a.cap * 2;
+    const float* __restrict__ p1 = a.p1 + (size_t)pair * a.cap * 2;
+    double h[9];
+    if (!make_hypothesis(p0, p1, n, a.seed, pair, it, h)) return;
+    const int c1 = min(c0 + hg::PTS_PER_WG, n);
+    unsigned long long s = 0;
+    unsigned c = 0;
+    for (int i = c0; i < c1; ++i) {                       // the same correspondence in every lane: scalar loads
+        const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
+        const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+        const double r2 = residual_sq(h, q0.x, q0.y, q1.x, q1.y);
+        if (r2 < a.tmax2) s += stab[bin_of(r2, a.bin_scale)];
+        c += r2 < a.thr2 ? 1u : 0u;
+    }
+    atomicAdd(a.hscore + (size_t)pair * a.iters_pad + it, s);
+    atomicAdd(a.hcnt + (size_t)pair * a.iters_pad + it, c);
+}
+
+// ---- selection, refinement, mask --------------------------------------------------------------------------------------------------------
+// totals over the workgroup (4 waves), every thread gets them; the order of the additions is fixed
+template <int N>
+__device__ inline void block_sums(double (&v)[N], double* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    __syncthreads();                                       // red free (previous use)
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < N; ++k) red[wave * N + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[N + k]) + red[2 * N + k]) + red[3 * N + k];
+}
+
+// Solve the 8x8 normal equations of the weighted inhomogeneous DLT (unknowns h00 h01 h02 h10 h11 h12 h20 h21, h22 = 1) from the 23 sums.
+__device__ inline bool solve_dlt(const double (&s)[hg::NSUM], double (&hn)[9]) {
+    // sums: 0 xx 1 xy 2 x 3 yy 4 y 5 1 | 6 uxx 7 uxy 8 uyy 9 ux 10 uy 11 u | 12 vxx 13 vxy 14 vyy 15 vx 16 vy 17 v | 18 qxx 19 qxy 20 qyy 21 qx 22 qy (q = u^2+v^2)
+    double m[8][8], g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[i][j] = 0.0;
+    const double P[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { m[i][j] = P[i][j]; m[3 + i][3 + j] = P[i][j]; }
+    const double Cu[3][2] = {{-s[6], -s[7]}, {-s[7], -s[8]}, {-s[9], -s[10]}};
+    const double Cv[3][2] = {{-s[12], -s[13]}, {-s[13], -s[14]}, {-s[15], -s[16]}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int l = 0; l < 2; ++l) { m[i][6 + l] = Cu[i][l]; m[6 + l][i] = Cu[i][l]; m[3 + i][6 + l] = Cv[i][l]; m[6 + l][3 + i] = Cv[i][l]; }
+    m[6][6] = s[18]; m[6][7] = s[19]; m[7][6] = s[19]; m[7][7] = s[20];
+    g[0] = s[9]; g[1] = s[10]; g[2] = s[11]; g[3] = s[15]; g[4] = s[16]; g[5] = s[17]; g[6] = -s[21]; g[7] = -s[22];
+    // Cholesky (lower), in place
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        double d = m[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= m[j][k] * m[j][k];
+        ok = ok && d > 0.0;                                // also false for NaN
+        const double l = sqrt(d), il = 1.0 / l;
+        m[j][j] = l;
+#pragma unroll
+        for (int i = j + 1; i < 8; ++i) {
+            double v = m[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) v -= m[i][k] * m[j][k];
+            m[i][j] = v * il;
+        }
+    }
+    double yv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        double v = g[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= m[i][k] * yv[k];
+        yv[i] = v / m[i][i];
+    }
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        double v = yv[i];
+#pragma unroll
+        for (int k = i + 1; k < 8; ++k) v -= m[k][i] * hn[k];
+        hn[i] = v / m[i][i];
+    }
+    hn[8] = 1.0;
+    bool fin = true;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fin = fin && (hn[i] - hn[i] == 0.0);
+    return ok && fin;
+}
+
+__global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    __shared__ double red[4 * hg::NSUM];
+    __shared__ double hsh[9];
+    __shared__ int sel[4];
+    __shared__ unsigned long long sc_sh;
+    __shared__ unsigned cnt_sh;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int n = a.counts ? min(a.counts[pair], a.cap) : a.n_const;
+    const float* __restrict__ p0 = a.p0 + (size_t)pair * a.cap * 2;
+    const float* __restrict__ p1 = a.p1 + (size_t)pair * a.cap * 2;
+    unsigned char* mask = a.mask + (size_t)pair * a.cap;
+    int32_t* info = a.info + pair * 8;
+    double* Hout = a.H + pair * 9;
+
+    // ---- the stopping rule of the sequential loop, on the score list
+    unsigned long long* hs = reinterpret_cast<unsigned long long*>(lds_raw);
+    unsigned* hc = reinterpret_cast<unsigned*>(lds_raw + (size_t)a.iters_pad * 8);
+    for (int i = tid; i < a.iters; i += 256) { hs[i] = a.hscore[(size_t)pair * a.iters_pad + i]; hc[i] = a.hcnt[(size_t)pair * a.iters_pad + i]; }
+    __syncthreads();
+    if (tid == 0) {
+        int best = -1, k_stop = a.iters, it = 0;
+        unsigned long long best_s = 0;
+        if (n >= 4) {
+            for (; it < a.iters && it < k_stop; ++it) {
+                if (hs[it] > best_s) {
+                    best = it; best_s = hs[it];
+                    const double w = (double)hc[it] / (double)n;
+                    const double p = 1.0 - w * w * w * w;
+                    int need;
+                    if (p <= 0.0) need = 1;
+                    else if (p >= 1.0) need = a.iters;
+                    else { const double k = ceil(a.log1mc / log(p)); need = k < (double)a.iters ? (int)k : a.iters; }
+                    k_stop = need < k_stop ? need : k_stop;
+                }
+            }
+        }
+        sel[0] = best; sel[1] = it;
+        double h[9];
+        if (best >= 0) {
+            make_hypothesis(p0, p1, n, a.seed, pair, best, h);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) hsh[k] = h[k];
+        }
+    }
+    __syncthreads();
+    const int best = sel[0], iters_run = sel[1];
+    if (best < 0) {
+        for (int i = tid; i < a.cap; i += 256) mask[i] = 0;
+        if (tid < 9) Hout[tid] = 0.0;
+        if (tid < 8) info[tid] = tid == 2 ? iters_run : (tid == 1 ? -1 : (tid == 5 ? n : 0));
+        return;
+    }
+    // ---- Hartley normalisation of both point sets (conditioning of the normal equations only)
+    double c[4] = {0, 0, 0, 0};
+    for (int i = tid; i < n; i += 256) {
+        const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
+        const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+        c[0] += q0.x; c[1] += q0.y; c[2] += q1.x; c[3] += q1.y;
+    }
+    block_sums(c, red);
+    const double cx0 = c[0] / n, cy0 = c[1] / n, cx1 = c[2] / n, cy1 = c[3] / n;
+    double dd[2] = {0, 0};
+    for (int i = tid; i < n; i += 256) {
+        const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
+        const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+        const double ax = q0.x - cx0, ay = q0.y - cy0, bx = q1.x - cx1, by = q1.y - cy1;
+        dd[0] += sqrt(ax * ax + ay * ay); dd[1] += sqrt(bx * bx + by * by);
+    }
+    block_sums(dd, red);
+    const double s0 = dd[0] > 0 ? 1.41421356237309504880 / (dd[0] / n) : 1.0, s1 = dd[1] > 0 ? 1.41421356237309504880 / (dd[1] / n) : 1.0;
+
+    // ---- sigma-consensus++: re-weighted least squares while the quality rises
+    double hcur[9], hbest[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { hcur[k] = hsh[k]; hbest[k] = hsh[k]; }
+    unsigned long long s_best = 0;
+    int lo_accepted = 0;
+    for (int step = 0; step <= hg::LO_ITERS; ++step) {
+        if (tid == 0) { sc_sh = 0ull; cnt_sh = 0u; }
+        __syncthreads();
+        double sm[hg::NSUM];
+#pragma unroll
+        for (int k = 0; k < hg::NSUM; ++k) sm[k] = 0.0;
+        unsigned long long sc = 0;
+        for (int i = tid; i < n; i += 256) {
+            const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
+            const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+            const double r2 = residual_sq(hcur, q0.x, q0.y, q1.x, q1.y);
+            if (r2 < a.tmax2) {
+                const int b = bin_of(r2, a.bin_scale);
+                sc += a.stab[b];
+                const double w = a.wtab[b];
+                const double x = (q0.x - cx0) * s0, y = (q0.y - cy0) * s0, u = (q1.x - cx1) * s1, v = (q1.y - cy1) * s1;
+                const double wx = w * x, wy = w * y, wxx = wx * x, wxy = wx * y, wyy = wy * y, q = u * u + v * v;
+                sm[0] += wxx; sm[1] += wxy; sm[2] += wx; sm[3] += wyy; sm[4] += wy; sm[5] += w;
+                sm[6] += u * wxx; sm[7] += u * wxy; sm[8] += u * wyy; sm[9] += u * wx; sm[10] += u * wy; sm[11] += u * w;
+                sm[12] += v * wxx; sm[13] += v * wxy; sm[14] += v * wyy; sm[15] += v * wx; sm[16] += v * wy; sm[17] += v * w;
+                sm[18] += q * wxx; sm[19] += q * wxy; sm[20] += q * wyy; sm[21] += q * wx; sm[22] += q * wy;
+            }
+        }
+        atomicAdd(&sc_sh, sc);
+        block_sums(sm, red);                               // (its barriers also publish sc_sh)
+        const unsigned long long s_now = sc_sh;
+        if (s_now <= s_best) break;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hbest[k] = hcur[k];
+        s_best = s_now;
+        lo_accepted = step;
+        if (step == hg::LO_ITERS) break;
+        double hn[9];
+        if (!solve_dlt(sm, hn)) break;
+        // H = T1^-1 Hn T0
+        double t[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            t[3 * r + 0] = hn[3 * r + 0] * s0;
+            t[3 * r + 1] = hn[3 * r + 1] * s0;
+            t[3 * r + 2] = hn[3 * r + 2] - (hn[3 * r + 0] * s0 * cx0 + hn[3 * r + 1] * s0 * cy0);
+        }
+        const double is1 = 1.0 / s1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            hcur[k] = t[k] * is1 + cx1 * t[6 + k];
+            hcur[3 + k] = t[3 + k] * is1 + cy1 * t[6 + k];
+            hcur[6 + k] = t[6 + k];
+        }
+        bool fin = true;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fin = fin && (hcur[k] - hcur[k] == 0.0);
+        if (!fin) break;
+        __syncthreads();                                   // sc_sh read by everybody before it is cleared again
+    }
+    // ---- inlier mask under the final model
+    __syncthreads();
+    if (tid == 0) cnt_sh = 0u;
+    __syncthreads();
+    unsigned cn = 0;
+    for (int i = tid; i < a.cap; i += 256) {
+        unsigned char mk = 0;
+        if (i < n) {
+            const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
+            const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+            mk = residual_sq(hbest, q0.x, q0.y, q1.x, q1.y) < a.thr2 ? 1 : 0;
+        }
+        mask[i] = mk;
+        cn += mk;
+    }
+    atomicAdd(&cnt_sh, cn);
+    __syncthreads();
+    const int n_in = (int)cnt_sh;
+    if (tid == 0) {
+        const bool found = n_in >= 4;
+        double nrm = hbest[8];
+        if (!(fabs(nrm) > 1e-300)) {
+            nrm = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) nrm += hbest[k] * hbest[k];
+            nrm = sqrt(nrm);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Hout[k] = found ? hbest[k] / nrm : 0.0;
+        info[0] = found ? 1 : 0; info[1] = best; info[2] = iters_run; info[3] = n_in; info[4] = lo_accepted; info[5] = n;
+        info[6] = (int)(s_best & 0xffffffffull); info[7] = (int)(s_best >> 32);
+    }
+}
+
+size_t homography_workspace_bytes(int P, int max_iters) {
+    const size_t pad = (size_t)ceil_div(max_iters, 256) * 256;
+    return (size_t)hg::NBINS * 4 + (size_t)hg::NBINS * 8 + (size_t)P * pad * 12 + 256;
+}
+
+void launch_homography_tables(double thr, unsigned* stab, double* wtab, hipStream_t st) {
+    homog_tables_kernel<<<hg::NBINS / 256, 256, 0, st>>>(thr, stab, wtab, nullptr, nullptr, 0);
+}
+
+int launch_find_homography(const float* p0, const float* p1, const int32_t* counts, int n_const, int P, int cap, double thr, int max_iters,
+                           double confidence, unsigned long long seed, double* H, unsigned char* mask, int32_t* info, void* ws, hipStream_t st) {
+    if (max_iters < 1 || max_iters > hg::MAX_ITERS || P > 65535) return -1;
+    HgArgs a;
+    a.p0 = p0; a.p1 = p1; a.counts = counts; a.n_const = n_const; a.P = P; a.cap = cap; a.iters = max_iters;
+    a.iters_pad = ceil_div(max_iters, 256) * 256;
+    const double t_max = hg::MAX_THR_FACTOR * thr;
+    a.thr2 = thr * thr; a.tmax2 = t_max * t_max; a.bin_scale = hg::NBINS / (t_max * t_max); a.log1mc = log(1.0 - confidence);
+    a.seed = seed;
+    unsigned char* w = static_cast<unsigned char*>(ws);
+    a.wtab = reinterpret_cast<double*>(w); w += (size_t)hg::NBINS * 8;
+    a.hscore = reinterpret_cast<unsigned long long*>(w); w += (size_t)P * a.iters_pad * 8;
+    a.stab = reinterpret_cast<unsigned*>(w); w += (size_t)hg::NBINS * 4;
+    a.hcnt = reinterpret_cast<unsigned*>(w);
+    a.H = H; a.mask = mask; a.info = info;
+    const int nhyp = P * a.iters_pad;
+    int tg = ceil_div(nhyp, 256);
+    tg = tg < hg::NBINS / 256 ? hg::NBINS / 256 : (tg > 1024 ? 1024 : tg);
+    homog_tables_kernel<<<tg, 256, 0, st>>>(thr, a.stab, a.wtab, a.hscore, a.hcnt, nhyp);
+    const dim3 grid(ceil_div(max_iters, hg::HYP_PER_WG), ceil_div(cap, hg::PTS_PER_WG), P);
+    homog_score_kernel<<<grid, 256, 0, st>>>(a);
+    homog_select_kernel<<<P, 256, (size_t)a.iters_pad * 12, st>>>(a);
+    return 0;
+}
+
+}  // namespace xfh

@@ -1,0 +1,88 @@
+"""Robust homography from the matches on MI355X: the step after the matcher in the reference's demo.
+
+    self.H, inliers = cv2.findHomography(points1, points2, cv2.USAC_MAGSAC, self.ransac_thr, maxIters=700, confidence=0.995)
+    inliers = inliers.flatten() > 0                                          # /root/reference/realtime_demo.py:225-226
+
+``find_homography`` has that call's arguments and results (H (3,3) float64 with H[2,2] = 1 and an (N,1) uint8 mask, or
+``(None, None)`` when no model with at least four inliers exists); ``find_homography_batch`` is the same estimator over
+P match lists resident in HBM (the output of ``XFeat.match_pairs_device`` / ``batch_match``) without leaving the device.
+The kernels behind ``xfh_find_homography`` (include/xfeat_hip.h, csrc/k_homography.hip) evaluate every hypothesis at once
+and apply RANSAC's stopping rule to the score list afterwards; OpenCV is not a dependency -- the estimator is the published
+MAGSAC++ (Barath et al., CVPR 2020), so H agrees with cv2's as an estimate of the same homography, not in its random stream.
+There is no CPU path: without the HIP library and a gfx950 device these functions raise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+USAC_MAGSAC = 38          # cv2.USAC_MAGSAC: accepted (and required) as ``method`` for signature compatibility
+INFO_FIELDS = ("found", "best_it", "iters", "n_inliers", "lo_accepted", "n", "score_lo", "score_hi")
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _lib.XFeatHipError("find_homography needs an AMD MI355X (gfx950) GPU; no CPU fallback exists")
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def find_homography_batch(pts0, pts1, counts=None, ransac_thr=4.0, max_iters=700, confidence=0.995, seed=0):
+    """P robust homographies in one call.
+
+    pts0, pts1 : (P, cap, 2) float32 CUDA tensors (pixel coordinates of the matched key-points, row i of pts0 matches row i of pts1)
+    counts     : (P,) int32 CUDA tensor, pair p uses its first counts[p] rows; None = all cap rows
+    Returns a dict of CUDA tensors: 'H' (P,3,3) float64, 'inliers' (P,cap) uint8, 'info' (P,8) int32 (INFO_FIELDS).  Asynchronous.
+    """
+    dev = pts0.device if pts0.is_cuda else _device()
+    pts0 = pts0.to(dev).float().contiguous()
+    pts1 = pts1.to(dev).float().contiguous()
+    if pts0.dim() != 3 or pts0.shape[2] != 2 or pts1.shape != pts0.shape:
+        raise RuntimeError('expected two (P, cap, 2) point tensors of the same shape')
+    P, cap = pts0.shape[0], pts0.shape[1]
+    H = torch.zeros((P, 3, 3), dtype=torch.float64, device=dev)
+    mask = torch.zeros((P, cap), dtype=torch.uint8, device=dev)
+    info = torch.zeros((P, 8), dtype=torch.int32, device=dev)
+    if P == 0 or cap == 0:
+        return {'H': H, 'inliers': mask, 'info': info}
+    if counts is not None:
+        counts = counts.to(dev).to(torch.int32).contiguous()
+        if counts.shape != (P,):
+            raise RuntimeError('counts must have one entry per pair')
+    lib = _lib.load()
+    ws = torch.empty(lib.xfh_homography_workspace_bytes(P, int(max_iters)) + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    _lib.check(lib.xfh_find_homography(C.c_void_p(pts0.data_ptr()), C.c_void_p(pts1.data_ptr()),
+                                       C.c_void_p(counts.data_ptr()) if counts is not None else None, cap, P, cap,
+                                       float(ransac_thr), int(max_iters), float(confidence), int(seed) & ((1 << 64) - 1),
+                                       C.c_void_p(H.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(info.data_ptr()),
+                                       C.c_void_p(ws.data_ptr() + off), ws.numel() - off,
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "xfh_find_homography")
+    ws.record_stream(torch.cuda.current_stream(dev))
+    return {'H': H, 'inliers': mask, 'info': info}
+
+
+def find_homography(points1, points2, method=USAC_MAGSAC, ransac_thr=4.0, maxIters=700, confidence=0.995, seed=0, return_info=False):
+    """``cv2.findHomography(points1, points2, cv2.USAC_MAGSAC, ransac_thr, maxIters=..., confidence=...)`` for one pair.
+
+    points1, points2 : (N,2) arrays / tensors (numpy, CPU or CUDA torch), any float type
+    Returns (H, inliers): H (3,3) float64 numpy array, inliers (N,1) uint8 numpy array -- or (None, None) like cv2 when fewer than
+    four correspondences are given or no model is found.
+    """
+    if method != USAC_MAGSAC:
+        raise _lib.XFeatHipError(f"find_homography: only cv2.USAC_MAGSAC ({USAC_MAGSAC}) is implemented, got method={method}")
+    dev = _device()
+    a = torch.as_tensor(np.asarray(points1) if not torch.is_tensor(points1) else points1).reshape(-1, 2)
+    b = torch.as_tensor(np.asarray(points2) if not torch.is_tensor(points2) else points2).reshape(-1, 2)
+    if a.shape != b.shape:
+        raise RuntimeError('points1 and points2 must hold the same number of points')
+    n = a.shape[0]
+    if n < 4:
+        return (None, None, dict.fromkeys(INFO_FIELDS, 0)) if return_info else (None, None)
+    r = find_homography_batch(a.to(dev).float()[None], b.to(dev).float()[None], None, ransac_thr, maxIters, confidence, seed)
+    info = dict(zip(INFO_FIELDS, r['info'][0].cpu().tolist()))
+    if not info['found']:
+        return (None, None, info) if return_info else (None, None)
+    out = (r['H'][0].cpu().numpy(), r['inliers'][0].cpu().numpy().reshape(-1, 1))
+    return out + (info,) if return_info else out

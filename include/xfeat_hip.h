@@ -229,6 +229,26 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
                      xfh_stream stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Robust homography from the matches -- the consumer of the demo:
+ *     H, inliers = cv2.findHomography(points1, points2, cv2.USAC_MAGSAC, ransac_thr, maxIters=700, confidence=0.995)
+ * (realtime_demo.py:225), for P pairs at once.  OpenCV (opencv-contrib-python-headless 4.10.0.84, requirements.txt:1) is not
+ * part of the reference tree: the algorithm is the published one (RANSAC + MAGSAC++ quality and sigma-consensus++ weights,
+ * Barath et al., CVPR 2020) as specified in DESIGN.md 3.7 / csrc/k_homography.hip -- same estimate, not OpenCV's random stream.
+ *   pts0/pts1 (P,cap,2) fp32 pixel coordinates (device), pair p uses its first counts[p] rows (device int32; NULL: n_const
+ *   for all).  All max_iters (<= 4096) hypotheses are scored on the device; the stopping rule (confidence) is then applied
+ *   to the score list as the sequential loop would apply it, so the result is a function of the arguments and `seed` only.
+ *   H (P,9) fp64 row-major with H[8] = 1 (zeros when nothing was found); mask (P,cap) uint8, 1 = forward transfer error
+ *   < ransac_thr; info (P,8) int32: found, winning hypothesis, hypotheses the loop would have run, inliers, accepted
+ *   refinement steps, n, quality (lo, hi word).  Fewer than 4 correspondences / inliers: found = 0 (cv2 returns None).
+ *   xfh_homography_tables: the 4096-entry quality (20-bit fixed point) / weight tables over r^2 in [0, (2 thr)^2).
+ * ---------------------------------------------------------------------------------------- */
+size_t xfh_homography_workspace_bytes(int P, int max_iters);
+int xfh_find_homography(const float* pts0, const float* pts1, const int32_t* counts, int n_const, int P, int cap,
+                        double ransac_thr, int max_iters, double confidence, uint64_t seed,
+                        double* H, uint8_t* mask, int32_t* info, void* workspace, size_t workspace_bytes, xfh_stream stream);
+int xfh_homography_tables(double ransac_thr, uint32_t* score_table, double* weight_table, xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
  * LighterGlue: the attention matcher of XFeat.match_lighterglue (modules/xfeat.py:131-162), i.e.
  * kornia.feature.lightglue.LightGlue.forward under the configuration of modules/lighterglue.py:12-27 (input 64-D,
  * d = 96, one head, 6 layers, no early stop, width pruning 0.95, filter threshold = min_conf), for ONE pair
