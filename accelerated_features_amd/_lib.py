@@ -48,6 +48,7 @@ SIGNATURES = {
     "xfh_fine_matcher": (_i, [_p, _p, _i, _p, _p, _sz, _p]),
     "xfh_homography_workspace_bytes": (_sz, [_i, _i]),
     "xfh_find_homography": (_i, [_p, _p, _p, _i, _i, _i, C.c_double, _i, C.c_double, C.c_uint64, _p, _p, _p, _p, _sz, _p]),
+    "xfh_find_homography_matches": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, C.c_double, _i, C.c_double, C.c_uint64, _p, _p, _p, _p, _sz, _p]),
     "xfh_homography_tables": (_i, [C.c_double, _p, _p, _p]),
     "xfh_lg_num_weight_arrays": (_i, []),
     "xfh_lg_weight_array_floats": (_sz, [_i]),

@@ -791,19 +791,34 @@ size_t xfh_homography_workspace_bytes(int P, int max_iters) {
     return xfh::homography_workspace_bytes(P, max_iters);
 }
 
+static int find_homography_impl(const char* who, const float* pts0, const float* pts1, const int64_t* idx0, const int64_t* idx1, int kcap,
+                                const int32_t* counts, int n_const, int P, int cap, double ransac_thr, int max_iters, double confidence,
+                                uint64_t seed, double* H, uint8_t* mask, int32_t* info, void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    if (!pts0 || !pts1 || !H || !mask || !info) return fail(XFH_ERR_ARG, "%s: NULL argument", who);
+    if (P <= 0 || P > 65535 || cap <= 0 || cap > (1 << 24) || kcap <= 0 || (!counts && (n_const < 0 || n_const > cap)))
+        return fail(XFH_ERR_ARG, "%s: bad shape (P %d, cap %d, n %d)", who, P, cap, n_const);
+    if (!(ransac_thr > 0.0) || !(confidence > 0.0 && confidence < 1.0)) return fail(XFH_ERR_ARG, "%s: threshold %g / confidence %g", who, ransac_thr, confidence);
+    if (max_iters < 1 || max_iters > 4096) return fail(XFH_ERR_UNSUPPORTED, "%s: max_iters %d outside [1, 4096]", who, max_iters);
+    int rc = check_ws(workspace, workspace_bytes, xfh::homography_workspace_bytes(P, max_iters));
+    if (rc) return rc;
+    if (launch_find_homography(pts0, pts1, idx0, idx1, kcap, counts, n_const, P, cap, ransac_thr, max_iters, confidence, seed, H, mask, info, workspace, (hipStream_t)stream))
+        return fail(XFH_ERR_UNSUPPORTED, "%s: unsupported configuration", who);
+    return check_launch(who);
+}
+
 int xfh_find_homography(const float* pts0, const float* pts1, const int32_t* counts, int n_const, int P, int cap, double ransac_thr,
                         int max_iters, double confidence, uint64_t seed, double* H, uint8_t* mask, int32_t* info, void* workspace,
                         size_t workspace_bytes, xfh_stream stream) {
-    if (!pts0 || !pts1 || !H || !mask || !info) return fail(XFH_ERR_ARG, "xfh_find_homography: NULL argument");
-    if (P <= 0 || P > 65535 || cap <= 0 || cap > (1 << 24) || (!counts && (n_const < 0 || n_const > cap)))
-        return fail(XFH_ERR_ARG, "xfh_find_homography: bad shape (P %d, cap %d, n %d)", P, cap, n_const);
-    if (!(ransac_thr > 0.0) || !(confidence > 0.0 && confidence < 1.0)) return fail(XFH_ERR_ARG, "xfh_find_homography: threshold %g / confidence %g", ransac_thr, confidence);
-    if (max_iters < 1 || max_iters > 4096) return fail(XFH_ERR_UNSUPPORTED, "xfh_find_homography: max_iters %d outside [1, 4096]", max_iters);
-    int rc = check_ws(workspace, workspace_bytes, xfh::homography_workspace_bytes(P, max_iters));
-    if (rc) return rc;
-    if (launch_find_homography(pts0, pts1, counts, n_const, P, cap, ransac_thr, max_iters, confidence, seed, H, mask, info, workspace, (hipStream_t)stream))
-        return fail(XFH_ERR_UNSUPPORTED, "xfh_find_homography: unsupported configuration");
-    return check_launch("xfh_find_homography");
+    return find_homography_impl("xfh_find_homography", pts0, pts1, nullptr, nullptr, cap, counts, n_const, P, cap, ransac_thr, max_iters, confidence, seed,
+                                H, mask, info, workspace, workspace_bytes, stream);
+}
+
+int xfh_find_homography_matches(const float* kpts0, const float* kpts1, int kpt_cap, const int64_t* idx0, const int64_t* idx1,
+                                const int32_t* n_matches, int P, int cap, double ransac_thr, int max_iters, double confidence, uint64_t seed,
+                                double* H, uint8_t* mask, int32_t* info, void* workspace, size_t workspace_bytes, xfh_stream stream) {
+    if (!idx0 || !idx1 || !n_matches) return fail(XFH_ERR_ARG, "xfh_find_homography_matches: NULL argument");
+    return find_homography_impl("xfh_find_homography_matches", kpts0, kpts1, idx0, idx1, kpt_cap, n_matches, 0, P, cap, ransac_thr, max_iters, confidence, seed,
+                                H, mask, info, workspace, workspace_bytes, stream);
 }
 
 int xfh_homography_tables(double ransac_thr, uint32_t* score_table, double* weight_table, xfh_stream stream) {

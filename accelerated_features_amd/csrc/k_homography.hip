@@ -21,9 +21,11 @@
 // the winning hypothesis, the iteration count and the inlier mask are reproducible bit for bit by any IEEE implementation of the
 // specification; only the least-squares refinement carries a (1e-9) tolerance, from the order of its fp64 reductions.
 //
-// Three launches per call, fp64 VALU + latency bound (one pair with 1000 matches and 700 hypotheses is 0.7 M residuals of ~45 fp64 ops):
+// Up to five launches per call, fp64 VALU + latency bound (one pair with 1000 matches and 700 hypotheses is 0.7 M residuals of ~45 fp64 ops):
 //   homog_tables_kernel : loss / weight tables of this threshold (closed forms of the incomplete gamma functions for n = 4), scores zeroed
-//   homog_score_kernel  : hypotheses + MAGSAC++ quality + inlier counts
+//   homog_score_kernel  : hypotheses + MAGSAC++ quality + inlier counts; hypotheses 0..255 of every pair first, then homog_bound_kernel
+//                         bounds the index the loop can still reach and the later hypothesis blocks run only below that bound (at 50 %
+//                         inliers the loop needs 83 iterations: the 444 hypotheses beyond the first block are never built)
 //   homog_select_kernel : one workgroup per pair: stopping rule, refinement (23 weighted sums -> 8x8 Cholesky), mask
 #include "kernels.hpp"
 
@@ -38,10 +40,12 @@ constexpr int NSUM = 23;
 }  // namespace hg
 
 struct HgArgs {
-    const float* p0;
+    const float* p0;          // (P, kcap, 2): the correspondences themselves (idx0 == NULL, kcap == cap) or the key-point lists they index
     const float* p1;
+    const int64_t* idx0;      // (P, cap) rows of p0 / p1 of correspondence i, or NULL
+    const int64_t* idx1;
     const int32_t* counts;
-    int n_const, P, cap, iters, iters_pad;
+    int n_const, P, cap, kcap, iters, iters_pad;
     double thr2, tmax2, bin_scale, log1mc;
     unsigned long long seed;
     unsigned* stab;
@@ -79,6 +83,22 @@ __global__ __launch_bounds__(256) void homog_tables_kernel(double thr, unsigned*
     for (int j = i; j < nhyp; j += gridDim.x * 256) { hscore[j] = 0ull; hcnt[j] = 0u; }
 }
 
+// ---- correspondences of one pair ---------------------------------------------------------------------------------------------------------
+struct PairPts {
+    const float* p0;
+    const float* p1;
+    const int64_t* i0;
+    const int64_t* i1;
+    __device__ PairPts(const HgArgs& a, int pair)
+        : p0(a.p0 + (size_t)pair * a.kcap * 2), p1(a.p1 + (size_t)pair * a.kcap * 2), i0(a.idx0 ? a.idx0 + (size_t)pair * a.cap : nullptr),
+          i1(a.idx1 ? a.idx1 + (size_t)pair * a.cap : nullptr) {}
+    __device__ inline void get(int i, float2& q0, float2& q1) const {
+        const size_t r0 = i0 ? (size_t)i0[i] : (size_t)i, r1 = i1 ? (size_t)i1[i] : (size_t)i;
+        q0 = *reinterpret_cast<const float2*>(p0 + 2 * r0);
+        q1 = *reinterpret_cast<const float2*>(p1 + 2 * r1);
+    }
+};
+
 // ---- hypotheses -------------------------------------------------------------------------------------------------------------------------
 __device__ inline unsigned long long mix64(unsigned long long z) {
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
@@ -104,8 +124,7 @@ __device__ inline void basis(const double (&x)[4], const double (&y)[4], double 
     for (int j = 0; j < 3; ++j) { m[0][j] = lam[j] * x[j]; m[1][j] = lam[j] * y[j]; m[2][j] = lam[j]; }
 }
 // hypothesis `it` of pair `pair`: false when the draws ran out or the sample does not keep the orientation of its triples
-__device__ inline bool make_hypothesis(const float* __restrict__ p0, const float* __restrict__ p1, int n, unsigned long long seed, int pair, int it,
-                                       double (&h)[9]) {
+__device__ inline bool make_hypothesis(const PairPts& pts, int n, unsigned long long seed, int pair, int it, double (&h)[9]) {
     int i0 = -1, i1 = -1, i2 = -1, i3 = -1, slot = 0;
 #pragma unroll
     for (int d = 0; d < hg::MAX_DRAWS; ++d) {
@@ -121,8 +140,8 @@ __device__ inline bool make_hypothesis(const float* __restrict__ p0, const float
     double x0[4], y0[4], x1[4], y1[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float2 a = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)idx[k]);
-        const float2 b = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)idx[k]);
+        float2 a, b;
+        pts.get(idx[k], a, b);
         x0[k] = a.x; y0[k] = a.y; x1[k] = b.x; y1[k] = b.y;
     }
     double A[3][3], Bm[3][3], da[4], db[4];
@@ -159,33 +178,73 @@ __device__ inline int bin_of(double r2, double bin_scale) {
     return b < hg::NBINS - 1 ? b : hg::NBINS - 1;
 }
 
-__global__ __launch_bounds__(256) void homog_score_kernel(HgArgs a) {
+// iterations the loop still needs once a model with `inliers` of n is the best one (the standard RANSAC bound)
+__device__ inline int iterations_needed(unsigned inliers, int n, double log1mc, int max_iters) {
+    const double w = (double)inliers / (double)n;
+    const double p = 1.0 - w * w * w * w;
+    if (p <= 0.0) return 1;
+    if (p >= 1.0) return max_iters;
+    const double k = ceil(log1mc / log(p));
+    return k < (double)max_iters ? (int)k : max_iters;
+}
+
+// Hypotheses [256 (blockIdx.x + blk0), + 256) of pair blockIdx.z against correspondences [512 blockIdx.y, + 512).  The first 256 hypotheses of
+// every pair are scored first (blk0 = 0, bound = NULL); the later blocks run only where homog_bound_kernel left a bound above their first index.
+__global__ __launch_bounds__(256) void homog_score_kernel(HgArgs a, int blk0, const int* __restrict__ bound) {
     __shared__ unsigned stab[hg::NBINS];
+    __shared__ float4 spt[hg::PTS_PER_WG];
     const int pair = blockIdx.z, tid = threadIdx.x;
     const int n = a.counts ? min(a.counts[pair], a.cap) : a.n_const;
     const int c0 = blockIdx.y * hg::PTS_PER_WG;
+    const int it0 = (blockIdx.x + blk0) * hg::HYP_PER_WG;
     if (n < 4 || c0 >= n) return;
+    if (bound && bound[pair] <= it0) return;
+    const PairPts pts(a, pair);
+    const int c1 = min(c0 + hg::PTS_PER_WG, n);
 #pragma unroll
     for (int k = 0; k < hg::NBINS / 256; ++k) stab[tid + 256 * k] = a.stab[tid + 256 * k];
+#pragma unroll
+    for (int k = 0; k < hg::PTS_PER_WG / 256; ++k) {      // the chunk's correspondences: fetched (and de-referenced) once per workgroup
+        const int i = c0 + tid + 256 * k;
+        float2 q0 = make_float2(0.f, 0.f), q1 = q0;
+        if (i < c1) pts.get(i, q0, q1);
+        spt[tid + 256 * k] = make_float4(q0.x, q0.y, q1.x, q1.y);
+    }
     __syncthreads();
-    const int it = blockIdx.x * hg::HYP_PER_WG + tid;
+    const int it = it0 + tid;
     if (it >= a.iters) return;
-    const float* __restrict__ p0 = a.p0 + (size_t)pair * a.cap * 2;
-    const float* __restrict__ p1 = a.p1 + (size_t)pair * a.cap * 2;
     double h[9];
-    if (!make_hypothesis(p0, p1, n, a.seed, pair, it, h)) return;
-    const int c1 = min(c0 + hg::PTS_PER_WG, n);
+    if (!make_hypothesis(pts, n, a.seed, pair, it, h)) return;
     unsigned long long s = 0;
     unsigned c = 0;
-    for (int i = c0; i < c1; ++i) {                       // the same correspondence in every lane: scalar loads
-        const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
-        const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
-        const double r2 = residual_sq(h, q0.x, q0.y, q1.x, q1.y);
+    const int m = c1 - c0;
+    for (int i = 0; i < m; ++i) {                         // the same correspondence in every lane: LDS broadcast
+        const float4 q = spt[i];
+        const double r2 = residual_sq(h, q.x, q.y, q.z, q.w);
         if (r2 < a.tmax2) s += stab[bin_of(r2, a.bin_scale)];
         c += r2 < a.thr2 ? 1u : 0u;
     }
     atomicAdd(a.hscore + (size_t)pair * a.iters_pad + it, s);
     atomicAdd(a.hcnt + (size_t)pair * a.iters_pad + it, c);
+}
+
+// After the first 256 hypotheses: an upper bound of the index the sequential loop stops at = min over the records (strict prefix maxima of
+// the quality) among them of iterations_needed.  If the loop stops inside the first 256 the value does not matter (no later hypothesis is
+// visited); if it does not, every record among the first 256 is one the loop sees, so its own bound is <= this one.
+__global__ __launch_bounds__(256) void homog_bound_kernel(HgArgs a, int* __restrict__ bound) {
+    __shared__ unsigned long long sc[256];
+    __shared__ int bmin;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int n = a.counts ? min(a.counts[pair], a.cap) : a.n_const;
+    const unsigned long long mine = tid < a.iters ? a.hscore[(size_t)pair * a.iters_pad + tid] : 0ull;
+    sc[tid] = mine;
+    if (tid == 0) bmin = a.iters;
+    __syncthreads();
+    unsigned long long before = 0;
+    for (int j = 0; j < tid; ++j) before = sc[j] > before ? sc[j] : before;
+    if (n >= 4 && mine > before) atomicMin(&bmin, iterations_needed(a.hcnt[(size_t)pair * a.iters_pad + tid], n, a.log1mc, a.iters));
+    __syncthreads();
+    if (tid == 0) bound[pair] = bmin;
 }
 
 // ---- selection, refinement, mask --------------------------------------------------------------------------------------------------------
@@ -276,8 +335,7 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
     __shared__ unsigned cnt_sh;
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int n = a.counts ? min(a.counts[pair], a.cap) : a.n_const;
-    const float* __restrict__ p0 = a.p0 + (size_t)pair * a.cap * 2;
-    const float* __restrict__ p1 = a.p1 + (size_t)pair * a.cap * 2;
+    const PairPts pts(a, pair);
     unsigned char* mask = a.mask + (size_t)pair * a.cap;
     int32_t* info = a.info + pair * 8;
     double* Hout = a.H + pair * 9;
@@ -294,12 +352,7 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
             for (; it < a.iters && it < k_stop; ++it) {
                 if (hs[it] > best_s) {
                     best = it; best_s = hs[it];
-                    const double w = (double)hc[it] / (double)n;
-                    const double p = 1.0 - w * w * w * w;
-                    int need;
-                    if (p <= 0.0) need = 1;
-                    else if (p >= 1.0) need = a.iters;
-                    else { const double k = ceil(a.log1mc / log(p)); need = k < (double)a.iters ? (int)k : a.iters; }
+                    const int need = iterations_needed(hc[it], n, a.log1mc, a.iters);
                     k_stop = need < k_stop ? need : k_stop;
                 }
             }
@@ -307,7 +360,7 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
         sel[0] = best; sel[1] = it;
         double h[9];
         if (best >= 0) {
-            make_hypothesis(p0, p1, n, a.seed, pair, best, h);
+            make_hypothesis(pts, n, a.seed, pair, best, h);
 #pragma unroll
             for (int k = 0; k < 9; ++k) hsh[k] = h[k];
         }
@@ -323,16 +376,16 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
     // ---- Hartley normalisation of both point sets (conditioning of the normal equations only)
     double c[4] = {0, 0, 0, 0};
     for (int i = tid; i < n; i += 256) {
-        const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
-        const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+        float2 q0, q1;
+        pts.get(i, q0, q1);
         c[0] += q0.x; c[1] += q0.y; c[2] += q1.x; c[3] += q1.y;
     }
     block_sums(c, red);
     const double cx0 = c[0] / n, cy0 = c[1] / n, cx1 = c[2] / n, cy1 = c[3] / n;
     double dd[2] = {0, 0};
     for (int i = tid; i < n; i += 256) {
-        const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
-        const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+        float2 q0, q1;
+        pts.get(i, q0, q1);
         const double ax = q0.x - cx0, ay = q0.y - cy0, bx = q1.x - cx1, by = q1.y - cy1;
         dd[0] += sqrt(ax * ax + ay * ay); dd[1] += sqrt(bx * bx + by * by);
     }
@@ -353,8 +406,8 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
         for (int k = 0; k < hg::NSUM; ++k) sm[k] = 0.0;
         unsigned long long sc = 0;
         for (int i = tid; i < n; i += 256) {
-            const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
-            const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+            float2 q0, q1;
+            pts.get(i, q0, q1);
             const double r2 = residual_sq(hcur, q0.x, q0.y, q1.x, q1.y);
             if (r2 < a.tmax2) {
                 const int b = bin_of(r2, a.bin_scale);
@@ -408,8 +461,8 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
     for (int i = tid; i < a.cap; i += 256) {
         unsigned char mk = 0;
         if (i < n) {
-            const float2 q0 = *reinterpret_cast<const float2*>(p0 + 2 * (size_t)i);
-            const float2 q1 = *reinterpret_cast<const float2*>(p1 + 2 * (size_t)i);
+            float2 q0, q1;
+            pts.get(i, q0, q1);
             mk = residual_sq(hbest, q0.x, q0.y, q1.x, q1.y) < a.thr2 ? 1 : 0;
         }
         mask[i] = mk;
@@ -436,18 +489,18 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
 
 size_t homography_workspace_bytes(int P, int max_iters) {
     const size_t pad = (size_t)ceil_div(max_iters, 256) * 256;
-    return (size_t)hg::NBINS * 4 + (size_t)hg::NBINS * 8 + (size_t)P * pad * 12 + 256;
+    return (size_t)hg::NBINS * 4 + (size_t)hg::NBINS * 8 + (size_t)P * pad * 12 + (size_t)P * 4 + 256;
 }
 
 void launch_homography_tables(double thr, unsigned* stab, double* wtab, hipStream_t st) {
     homog_tables_kernel<<<hg::NBINS / 256, 256, 0, st>>>(thr, stab, wtab, nullptr, nullptr, 0);
 }
 
-int launch_find_homography(const float* p0, const float* p1, const int32_t* counts, int n_const, int P, int cap, double thr, int max_iters,
+int launch_find_homography(const float* p0, const float* p1, const int64_t* idx0, const int64_t* idx1, int kcap, const int32_t* counts, int n_const, int P, int cap, double thr, int max_iters,
                            double confidence, unsigned long long seed, double* H, unsigned char* mask, int32_t* info, void* ws, hipStream_t st) {
     if (max_iters < 1 || max_iters > hg::MAX_ITERS || P > 65535) return -1;
     HgArgs a;
-    a.p0 = p0; a.p1 = p1; a.counts = counts; a.n_const = n_const; a.P = P; a.cap = cap; a.iters = max_iters;
+    a.p0 = p0; a.p1 = p1; a.idx0 = idx0; a.idx1 = idx1; a.kcap = idx0 ? kcap : cap; a.counts = counts; a.n_const = n_const; a.P = P; a.cap = cap; a.iters = max_iters;
     a.iters_pad = ceil_div(max_iters, 256) * 256;
     const double t_max = hg::MAX_THR_FACTOR * thr;
     a.thr2 = thr * thr; a.tmax2 = t_max * t_max; a.bin_scale = hg::NBINS / (t_max * t_max); a.log1mc = log(1.0 - confidence);
@@ -456,14 +509,19 @@ int launch_find_homography(const float* p0, const float* p1, const int32_t* coun
     a.wtab = reinterpret_cast<double*>(w); w += (size_t)hg::NBINS * 8;
     a.hscore = reinterpret_cast<unsigned long long*>(w); w += (size_t)P * a.iters_pad * 8;
     a.stab = reinterpret_cast<unsigned*>(w); w += (size_t)hg::NBINS * 4;
-    a.hcnt = reinterpret_cast<unsigned*>(w);
+    a.hcnt = reinterpret_cast<unsigned*>(w); w += (size_t)P * a.iters_pad * 4;
+    int* bound = reinterpret_cast<int*>(w);
     a.H = H; a.mask = mask; a.info = info;
     const int nhyp = P * a.iters_pad;
     int tg = ceil_div(nhyp, 256);
     tg = tg < hg::NBINS / 256 ? hg::NBINS / 256 : (tg > 1024 ? 1024 : tg);
     homog_tables_kernel<<<tg, 256, 0, st>>>(thr, a.stab, a.wtab, a.hscore, a.hcnt, nhyp);
-    const dim3 grid(ceil_div(max_iters, hg::HYP_PER_WG), ceil_div(cap, hg::PTS_PER_WG), P);
-    homog_score_kernel<<<grid, 256, 0, st>>>(a);
+    const int nblk = ceil_div(max_iters, hg::HYP_PER_WG), nch = ceil_div(cap, hg::PTS_PER_WG);
+    homog_score_kernel<<<dim3(1, nch, P), 256, 0, st>>>(a, 0, nullptr);
+    if (nblk > 1) {
+        homog_bound_kernel<<<P, 256, 0, st>>>(a, bound);
+        homog_score_kernel<<<dim3(nblk - 1, nch, P), 256, 0, st>>>(a, 1, bound);
+    }
     homog_select_kernel<<<P, 256, (size_t)a.iters_pad * 12, st>>>(a);
     return 0;
 }

@@ -80,7 +80,7 @@ int bx_steps(int cin);      // K steps of 16 = 2 groups of 8 channels of one tap
 // ---- k_homography.hip (RANSAC + MAGSAC++ homography from match lists) ----
 size_t homography_workspace_bytes(int P, int max_iters);
 void launch_homography_tables(double thr, unsigned* stab, double* wtab, hipStream_t st);
-int launch_find_homography(const float* p0, const float* p1, const int32_t* counts, int n_const, int P, int cap, double thr, int max_iters,
+int launch_find_homography(const float* p0, const float* p1, const int64_t* idx0, const int64_t* idx1, int kcap, const int32_t* counts, int n_const, int P, int cap, double thr, int max_iters,
                            double confidence, unsigned long long seed, double* H, unsigned char* mask, int32_t* info, void* ws, hipStream_t st);
 double conv_flops(const ConvW& c, int B, int Hout, int Wout);
 

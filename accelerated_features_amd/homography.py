@@ -28,6 +28,22 @@ def _device():
     return torch.device('cuda', torch.cuda.current_device())
 
 
+def _outputs(P, cap, dev):
+    return (torch.zeros((P, 3, 3), dtype=torch.float64, device=dev), torch.zeros((P, cap), dtype=torch.uint8, device=dev),
+            torch.zeros((P, 8), dtype=torch.int32, device=dev))
+
+
+def _workspace(lib, P, max_iters, dev):
+    ws = torch.empty(lib.xfh_homography_workspace_bytes(P, int(max_iters)) + 256, dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    ws.record_stream(torch.cuda.current_stream(dev))
+    return ws, off
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
 def find_homography_batch(pts0, pts1, counts=None, ransac_thr=4.0, max_iters=700, confidence=0.995, seed=0):
     """P robust homographies in one call.
 
@@ -41,9 +57,7 @@ def find_homography_batch(pts0, pts1, counts=None, ransac_thr=4.0, max_iters=700
     if pts0.dim() != 3 or pts0.shape[2] != 2 or pts1.shape != pts0.shape:
         raise RuntimeError('expected two (P, cap, 2) point tensors of the same shape')
     P, cap = pts0.shape[0], pts0.shape[1]
-    H = torch.zeros((P, 3, 3), dtype=torch.float64, device=dev)
-    mask = torch.zeros((P, cap), dtype=torch.uint8, device=dev)
-    info = torch.zeros((P, 8), dtype=torch.int32, device=dev)
+    H, mask, info = _outputs(P, cap, dev)
     if P == 0 or cap == 0:
         return {'H': H, 'inliers': mask, 'info': info}
     if counts is not None:
@@ -51,16 +65,67 @@ def find_homography_batch(pts0, pts1, counts=None, ransac_thr=4.0, max_iters=700
         if counts.shape != (P,):
             raise RuntimeError('counts must have one entry per pair')
     lib = _lib.load()
-    ws = torch.empty(lib.xfh_homography_workspace_bytes(P, int(max_iters)) + 256, dtype=torch.uint8, device=dev)
-    off = (-ws.data_ptr()) % 256
-    _lib.check(lib.xfh_find_homography(C.c_void_p(pts0.data_ptr()), C.c_void_p(pts1.data_ptr()),
-                                       C.c_void_p(counts.data_ptr()) if counts is not None else None, cap, P, cap,
-                                       float(ransac_thr), int(max_iters), float(confidence), int(seed) & ((1 << 64) - 1),
-                                       C.c_void_p(H.data_ptr()), C.c_void_p(mask.data_ptr()), C.c_void_p(info.data_ptr()),
-                                       C.c_void_p(ws.data_ptr() + off), ws.numel() - off,
-                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "xfh_find_homography")
-    ws.record_stream(torch.cuda.current_stream(dev))
+    ws, off = _workspace(lib, P, max_iters, dev)
+    _lib.check(lib.xfh_find_homography(_ptr(pts0), _ptr(pts1), _ptr(counts), cap, P, cap, float(ransac_thr), int(max_iters), float(confidence),
+                                       int(seed) & ((1 << 64) - 1), _ptr(H), _ptr(mask), _ptr(info), C.c_void_p(ws.data_ptr() + off),
+                                       ws.numel() - off, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "xfh_find_homography")
     return {'H': H, 'inliers': mask, 'info': info}
+
+
+def find_homography_matches(kpts0, kpts1, idx0, idx1, n_matches, ransac_thr=4.0, max_iters=700, confidence=0.995, seed=0):
+    """The same estimator straight on the matcher's output (no gathered point lists): correspondence i of pair p is
+    (kpts0[p, idx0[p, i]], kpts1[p, idx1[p, i]]) for i < n_matches[p] -- ``points1 = kpts1[idx0]; points2 = kpts2[idx1]`` of
+    realtime_demo.py:209-211.  kpts (P,K,2) float32, idx (P,cap) int64, n_matches (P,) int32: the CUDA tensors that
+    ``XFeat._detect_device`` and ``XFeat.match_sets_device`` / ``match_pairs_device`` return.  Same result dict as find_homography_batch."""
+    dev = kpts0.device
+    if not kpts0.is_cuda:
+        raise _lib.XFeatHipError("find_homography_matches works on device-resident match lists")
+    P, cap = idx0.shape
+    if kpts0.shape != kpts1.shape or kpts0.shape[0] != P or kpts0.shape[2] != 2 or idx1.shape != idx0.shape or n_matches.shape != (P,):
+        raise RuntimeError('expected kpts (P,K,2), idx (P,cap), n_matches (P,)')
+    for t, dt in ((kpts0, torch.float32), (kpts1, torch.float32), (idx0, torch.int64), (idx1, torch.int64), (n_matches, torch.int32)):
+        if t.dtype != dt or not t.is_contiguous():
+            raise RuntimeError('find_homography_matches: contiguous float32 key-points, int64 indices, int32 counts expected')
+    H, mask, info = _outputs(P, cap, dev)
+    lib = _lib.load()
+    ws, off = _workspace(lib, P, max_iters, dev)
+    _lib.check(lib.xfh_find_homography_matches(_ptr(kpts0), _ptr(kpts1), kpts0.shape[1], _ptr(idx0), _ptr(idx1), _ptr(n_matches), P, cap,
+                                               float(ransac_thr), int(max_iters), float(confidence), int(seed) & ((1 << 64) - 1), _ptr(H),
+                                               _ptr(mask), _ptr(info), C.c_void_p(ws.data_ptr() + off), ws.numel() - off,
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "xfh_find_homography_matches")
+    return {'H': H, 'inliers': mask, 'info': info}
+
+
+class ReferenceTracker:
+    """The XFeat branch of the reference demo's per-frame work (realtime_demo.py:136-142 and 204-231) for B camera streams at once, with
+    everything resident in HBM: reference features are extracted once and cached (``ref_precomp``), every new frame goes through
+    detectAndCompute -> mutual-NN match against the cached descriptors (``min_cossim`` 0.82) -> MAGSAC++ homography
+    (``ransac_thr``, maxIters 700, confidence 0.995); a homography with fewer than ``min_inliers`` inliers is dropped (``self.H = None``)."""
+
+    def __init__(self, xfeat, top_k=4096, min_cossim=0.82, ransac_thr=4.0, min_inliers=50, max_iters=700, confidence=0.995, seed=0):
+        self.xfeat, self.top_k, self.min_cossim = xfeat, top_k, min_cossim
+        self.ransac_thr, self.min_inliers, self.max_iters, self.confidence, self.seed = ransac_thr, min_inliers, max_iters, confidence, seed
+        self.ref = None
+
+    def set_reference(self, frames):
+        """frames (B,C,H,W) (or (B,H,W,C) uint8 like the demo's camera frames): cache their key-points and descriptors."""
+        kp, sc, de, nv, nc, cap, hw = self.xfeat._detect_device(self.xfeat.parse_input(frames), self.top_k)
+        self.ref = (kp, de, nv.clone())
+
+    def track(self, frames):
+        """One step for the B current frames.  Returns CUDA tensors: 'H' (B,3,3) float64, 'valid' (B,) bool (inliers >= min_inliers),
+        'inliers' (B,top_k) uint8 over the match list, 'idx0' / 'idx1' (B,top_k) int64 (rows of the reference / current key-points),
+        'n_matches' (B,) int32, 'keypoints' (B,top_k,2) of the current frames, 'info' (B,8).  No read-back happens here."""
+        if self.ref is None:
+            raise RuntimeError('ReferenceTracker.track: call set_reference first')
+        kp0, de0, nv0 = self.ref
+        kp1, sc, de1, nv1, nc, cap, hw = self.xfeat._detect_device(self.xfeat.parse_input(frames), self.top_k)
+        if kp1.shape != kp0.shape:
+            raise RuntimeError('the current frames must have the batch size of the reference frames')
+        idx0, idx1, n = self.xfeat.match_sets_device(de0, nv0, de1, nv1, self.min_cossim)
+        r = find_homography_matches(kp0, kp1, idx0, idx1, n, self.ransac_thr, self.max_iters, self.confidence, self.seed)
+        r.update(valid=(r['info'][:, 0] > 0) & (r['info'][:, 3] >= self.min_inliers), idx0=idx0, idx1=idx1, n_matches=n, keypoints=kp1)
+        return r
 
 
 def find_homography(points1, points2, method=USAC_MAGSAC, ransac_thr=4.0, maxIters=700, confidence=0.995, seed=0, return_info=False):

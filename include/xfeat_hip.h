@@ -240,12 +240,18 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
  *   H (P,9) fp64 row-major with H[8] = 1 (zeros when nothing was found); mask (P,cap) uint8, 1 = forward transfer error
  *   < ransac_thr; info (P,8) int32: found, winning hypothesis, hypotheses the loop would have run, inliers, accepted
  *   refinement steps, n, quality (lo, hi word).  Fewer than 4 correspondences / inliers: found = 0 (cv2 returns None).
+ *   xfh_find_homography_matches: the same on the matcher's output without materialising the point lists: correspondence i of
+ *   pair p is (kpts0[p][idx0[p][i]], kpts1[p][idx1[p][i]]), kpts (P,kpt_cap,2) fp32, idx (P,cap) int64 and n_matches (P) int32 as
+ *   xfh_match_mnn writes them (realtime_demo.py:209-211: points1 = kpts1[idx0], points2 = kpts2[idx1]).
  *   xfh_homography_tables: the 4096-entry quality (20-bit fixed point) / weight tables over r^2 in [0, (2 thr)^2).
  * ---------------------------------------------------------------------------------------- */
 size_t xfh_homography_workspace_bytes(int P, int max_iters);
 int xfh_find_homography(const float* pts0, const float* pts1, const int32_t* counts, int n_const, int P, int cap,
                         double ransac_thr, int max_iters, double confidence, uint64_t seed,
                         double* H, uint8_t* mask, int32_t* info, void* workspace, size_t workspace_bytes, xfh_stream stream);
+int xfh_find_homography_matches(const float* kpts0, const float* kpts1, int kpt_cap, const int64_t* idx0, const int64_t* idx1,
+                                const int32_t* n_matches, int P, int cap, double ransac_thr, int max_iters, double confidence, uint64_t seed,
+                                double* H, uint8_t* mask, int32_t* info, void* workspace, size_t workspace_bytes, xfh_stream stream);
 int xfh_homography_tables(double ransac_thr, uint32_t* score_table, double* weight_table, xfh_stream stream);
 
 /* ------------------------------------------------------------------------------------------
