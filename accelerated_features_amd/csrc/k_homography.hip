@@ -26,7 +26,7 @@
 //   homog_score_kernel  : hypotheses + MAGSAC++ quality + inlier counts; hypotheses 0..255 of every pair first, then homog_bound_kernel
 //                         bounds the index the loop can still reach and the later hypothesis blocks run only below that bound (at 50 %
 //                         inliers the loop needs 83 iterations: the 444 hypotheses beyond the first block are never built)
-//   homog_select_kernel : one workgroup per pair: stopping rule, refinement (23 weighted sums -> 8x8 Cholesky), mask
+//   homog_select_kernel : one workgroup per pair: stopping rule, refinement (23 weighted sums -> block Cholesky of the 8x8 normal equations), mask
 #include "kernels.hpp"
 
 #pragma clang fp contract(off)
@@ -46,6 +46,7 @@ struct HgArgs {
     const int64_t* idx1;
     const int32_t* counts;
     int n_const, P, cap, kcap, iters, iters_pad;
+    int chunk;                // correspondences per workgroup of homog_score_kernel (64 .. PTS_PER_WG)
     double thr2, tmax2, bin_scale, log1mc;
     unsigned long long seed;
     unsigned* stab;
@@ -188,19 +189,19 @@ __device__ inline int iterations_needed(unsigned inliers, int n, double log1mc, 
     return k < (double)max_iters ? (int)k : max_iters;
 }
 
-// Hypotheses [256 (blockIdx.x + blk0), + 256) of pair blockIdx.z against correspondences [512 blockIdx.y, + 512).  The first 256 hypotheses of
+// Hypotheses [256 (blockIdx.x + blk0), + 256) of pair blockIdx.z against correspondences [chunk blockIdx.y, + chunk).  The first 256 hypotheses of
 // every pair are scored first (blk0 = 0, bound = NULL); the later blocks run only where homog_bound_kernel left a bound above their first index.
 __global__ __launch_bounds__(256) void homog_score_kernel(HgArgs a, int blk0, const int* __restrict__ bound) {
     __shared__ unsigned stab[hg::NBINS];
     __shared__ float4 spt[hg::PTS_PER_WG];
     const int pair = blockIdx.z, tid = threadIdx.x;
     const int n = a.counts ? min(a.counts[pair], a.cap) : a.n_const;
-    const int c0 = blockIdx.y * hg::PTS_PER_WG;
+    const int c0 = blockIdx.y * a.chunk;
     const int it0 = (blockIdx.x + blk0) * hg::HYP_PER_WG;
     if (n < 4 || c0 >= n) return;
     if (bound && bound[pair] <= it0) return;
     const PairPts pts(a, pair);
-    const int c1 = min(c0 + hg::PTS_PER_WG, n);
+    const int c1 = min(c0 + a.chunk, n);
 #pragma unroll
     for (int k = 0; k < hg::NBINS / 256; ++k) stab[tid + 256 * k] = a.stab[tid + 256 * k];
 #pragma unroll
@@ -218,10 +219,13 @@ __global__ __launch_bounds__(256) void homog_score_kernel(HgArgs a, int blk0, co
     unsigned long long s = 0;
     unsigned c = 0;
     const int m = c1 - c0;
-    for (int i = 0; i < m; ++i) {                         // the same correspondence in every lane: LDS broadcast
-        const float4 q = spt[i];
+#pragma unroll 4
+    for (int i = 0; i < m; ++i) {                         // the same correspondence in every lane: LDS broadcast; branch-free, so that the
+        const float4 q = spt[i];                          // scheduler interleaves the fp64 chains of consecutive correspondences
         const double r2 = residual_sq(h, q.x, q.y, q.z, q.w);
-        if (r2 < a.tmax2) s += stab[bin_of(r2, a.bin_scale)];
+        const bool near = r2 < a.tmax2;
+        const unsigned e = stab[bin_of(near ? r2 : 0.0, a.bin_scale)];
+        s += near ? e : 0u;
         c += r2 < a.thr2 ? 1u : 0u;
     }
     atomicAdd(a.hscore + (size_t)pair * a.iters_pad + it, s);
@@ -248,78 +252,93 @@ __global__ __launch_bounds__(256) void homog_bound_kernel(HgArgs a, int* __restr
 }
 
 // ---- selection, refinement, mask --------------------------------------------------------------------------------------------------------
-// totals over the workgroup (4 waves), every thread gets them; the order of the additions is fixed
+// Totals of N per-thread values over the workgroup, every thread gets them; the order of the additions is fixed.  Through LDS as a transpose:
+// thread (k, j) adds 32 of the 256 entries of row k, thread k the 8 partial sums -- ~40 dependent additions and four barriers.  (A butterfly of
+// wave shuffles costs 6 steps x 2 ds_bpermute per value, each waited for: 11 us per pass for the 23 sums of the refinement.)
+constexpr int RED_PITCH = 257;
 template <int N>
-__device__ inline void block_sums(double (&v)[N], double* red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ inline void block_sums(double (&v)[N], double* buf /* N * RED_PITCH + 9 * N doubles */) {
+    static_assert(N * 8 <= 256, "one thread per (row, segment)");
+    const int tid = threadIdx.x;
+    double* part = buf + N * RED_PITCH;
+    double* tot = part + N * 8;
+    __syncthreads();                                       // buf free (previous use)
 #pragma unroll
-    for (int k = 0; k < N; ++k)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
-    __syncthreads();                                       // red free (previous use)
-    if (lane == 0)
-#pragma unroll
-        for (int k = 0; k < N; ++k) red[wave * N + k] = v[k];
+    for (int k = 0; k < N; ++k) buf[k * RED_PITCH + tid] = v[k];
+    __syncthreads();
+    if (tid < N * 8) {
+        const int k = tid >> 3, j = tid & 7;
+        const double* row = buf + k * RED_PITCH + j * 32;
+        double t = 0.0;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) t += row[i];
+        part[tid] = t;
+    }
+    __syncthreads();
+    if (tid < N) {
+        const double* q = part + tid * 8;
+        tot[tid] = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])));
+    }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = ((red[k] + red[N + k]) + red[2 * N + k]) + red[3 * N + k];
+    for (int k = 0; k < N; ++k) v[k] = tot[k];
 }
 
-// Solve the 8x8 normal equations of the weighted inhomogeneous DLT (unknowns h00 h01 h02 h10 h11 h12 h20 h21, h22 = 1) from the 23 sums.
+// Solve the 8x8 normal equations of the weighted inhomogeneous DLT (unknowns a = h00 h01 h02, b = h10 h11 h12, c = h20 h21; h22 = 1) from the 23 sums.
+// The matrix is [[P 0 Cu] [0 P Cv] [Cu' Cv' R]] with one 3x3 block P = sum w p p' for both rows: Cholesky of P once, the 2x2 Schur complement
+// S = R - Xu'Xu - Xv'Xv (X = L^-1 C) for c, back-substitution for a and b -- the block form of the dense 8x8 Cholesky solve (5 square roots
+// instead of 8, ~1/5 of the dependent fp64 chain that every step of the refinement waits for).
 __device__ inline bool solve_dlt(const double (&s)[hg::NSUM], double (&hn)[9]) {
     // sums: 0 xx 1 xy 2 x 3 yy 4 y 5 1 | 6 uxx 7 uxy 8 uyy 9 ux 10 uy 11 u | 12 vxx 13 vxy 14 vyy 15 vx 16 vy 17 v | 18 qxx 19 qxy 20 qyy 21 qx 22 qy (q = u^2+v^2)
-    double m[8][8], g[8];
+    // P = [[xx xy x] [xy yy y] [x y 1]]
+    bool ok = s[0] > 0.0;
+    const double l00 = sqrt(s[0]), i00 = 1.0 / l00;
+    const double l10 = s[1] * i00, l20 = s[2] * i00;
+    const double d1 = s[3] - l10 * l10;
+    ok = ok && d1 > 0.0;
+    const double l11 = sqrt(d1), i11 = 1.0 / l11;
+    const double l21 = (s[4] - l20 * l10) * i11;
+    const double d2 = s[5] - l20 * l20 - l21 * l21;
+    ok = ok && d2 > 0.0;
+    const double l22 = sqrt(d2), i22 = 1.0 / l22;
+    auto fwd = [&](double v0, double v1, double v2, double (&y)[3]) {
+        y[0] = v0 * i00;
+        y[1] = (v1 - l10 * y[0]) * i11;
+        y[2] = (v2 - l20 * y[0] - l21 * y[1]) * i22;
+    };
+    auto bwd = [&](const double (&y)[3], double* x) {
+        x[2] = y[2] * i22;
+        x[1] = (y[1] - l21 * x[2]) * i11;
+        x[0] = (y[0] - l10 * x[1] - l20 * x[2]) * i00;
+    };
+    // columns of Cu = -[[uxx uxy] [uxy uyy] [ux uy]], Cv likewise; right-hand sides gu = [ux uy u], gv = [vx vy v], gr = -[qx qy]
+    double xu0[3], xu1[3], xv0[3], xv1[3], yu[3], yv[3];
+    fwd(-s[6], -s[7], -s[9], xu0);
+    fwd(-s[7], -s[8], -s[10], xu1);
+    fwd(-s[12], -s[13], -s[15], xv0);
+    fwd(-s[13], -s[14], -s[16], xv1);
+    fwd(s[9], s[10], s[11], yu);
+    fwd(s[15], s[16], s[17], yv);
+    auto dot = [](const double (&p)[3], const double (&q)[3]) { return p[0] * q[0] + p[1] * q[1] + p[2] * q[2]; };
+    const double S00 = s[18] - dot(xu0, xu0) - dot(xv0, xv0);
+    const double S01 = s[19] - dot(xu0, xu1) - dot(xv0, xv1);
+    const double S11 = s[20] - dot(xu1, xu1) - dot(xv1, xv1);
+    const double t0 = -s[21] - dot(xu0, yu) - dot(xv0, yv);
+    const double t1 = -s[22] - dot(xu1, yu) - dot(xv1, yv);
+    ok = ok && S00 > 0.0;
+    const double m00 = sqrt(S00), j00 = 1.0 / m00;
+    const double m10 = S01 * j00;
+    const double e1 = S11 - m10 * m10;
+    ok = ok && e1 > 0.0;
+    const double m11 = sqrt(e1), j11 = 1.0 / m11;
+    const double z0 = t0 * j00, z1 = (t1 - m10 * z0) * j11;
+    const double c1 = z1 * j11, c0 = (z0 - m10 * c1) * j00;
+    double ra[3], rb[3];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) m[i][j] = 0.0;
-    const double P[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { m[i][j] = P[i][j]; m[3 + i][3 + j] = P[i][j]; }
-    const double Cu[3][2] = {{-s[6], -s[7]}, {-s[7], -s[8]}, {-s[9], -s[10]}};
-    const double Cv[3][2] = {{-s[12], -s[13]}, {-s[13], -s[14]}, {-s[15], -s[16]}};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int l = 0; l < 2; ++l) { m[i][6 + l] = Cu[i][l]; m[6 + l][i] = Cu[i][l]; m[3 + i][6 + l] = Cv[i][l]; m[6 + l][3 + i] = Cv[i][l]; }
-    m[6][6] = s[18]; m[6][7] = s[19]; m[7][6] = s[19]; m[7][7] = s[20];
-    g[0] = s[9]; g[1] = s[10]; g[2] = s[11]; g[3] = s[15]; g[4] = s[16]; g[5] = s[17]; g[6] = -s[21]; g[7] = -s[22];
-    // Cholesky (lower), in place
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        double d = m[j][j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= m[j][k] * m[j][k];
-        ok = ok && d > 0.0;                                // also false for NaN
-        const double l = sqrt(d), il = 1.0 / l;
-        m[j][j] = l;
-#pragma unroll
-        for (int i = j + 1; i < 8; ++i) {
-            double v = m[i][j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) v -= m[i][k] * m[j][k];
-            m[i][j] = v * il;
-        }
-    }
-    double yv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        double v = g[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) v -= m[i][k] * yv[k];
-        yv[i] = v / m[i][i];
-    }
-#pragma unroll
-    for (int i = 7; i >= 0; --i) {
-        double v = yv[i];
-#pragma unroll
-        for (int k = i + 1; k < 8; ++k) v -= m[k][i] * hn[k];
-        hn[i] = v / m[i][i];
-    }
-    hn[8] = 1.0;
+    for (int k = 0; k < 3; ++k) { ra[k] = yu[k] - (xu0[k] * c0 + xu1[k] * c1); rb[k] = yv[k] - (xv0[k] * c0 + xv1[k] * c1); }
+    bwd(ra, &hn[0]);
+    bwd(rb, &hn[3]);
+    hn[6] = c0; hn[7] = c1; hn[8] = 1.0;
     bool fin = true;
 #pragma unroll
     for (int i = 0; i < 8; ++i) fin = fin && (hn[i] - hn[i] == 0.0);
@@ -328,7 +347,6 @@ __device__ inline bool solve_dlt(const double (&s)[hg::NSUM], double (&hn)[9]) {
 
 __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    __shared__ double red[4 * hg::NSUM];
     __shared__ double hsh[9];
     __shared__ int sel[4];
     __shared__ unsigned long long sc_sh;
@@ -367,6 +385,7 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
     }
     __syncthreads();
     const int best = sel[0], iters_run = sel[1];
+    double* red = reinterpret_cast<double*>(lds_raw);       // the score list is dead: its LDS is the reduction buffer from here on
     if (best < 0) {
         for (int i = tid; i < a.cap; i += 256) mask[i] = 0;
         if (tid < 9) Hout[tid] = 0.0;
@@ -516,13 +535,18 @@ int launch_find_homography(const float* p0, const float* p1, const int64_t* idx0
     int tg = ceil_div(nhyp, 256);
     tg = tg < hg::NBINS / 256 ? hg::NBINS / 256 : (tg > 1024 ? 1024 : tg);
     homog_tables_kernel<<<tg, 256, 0, st>>>(thr, a.stab, a.wtab, a.hscore, a.hcnt, nhyp);
-    const int nblk = ceil_div(max_iters, hg::HYP_PER_WG), nch = ceil_div(cap, hg::PTS_PER_WG);
+    // few pairs: smaller chunks of correspondences, so that one pair still spreads over the chip (integer scores: any split gives the same sums)
+    a.chunk = hg::PTS_PER_WG;
+    while (a.chunk > 64 && (long)P * ceil_div(cap, a.chunk) < 256) a.chunk >>= 1;
+    const int nblk = ceil_div(max_iters, hg::HYP_PER_WG), nch = ceil_div(cap, a.chunk);
     homog_score_kernel<<<dim3(1, nch, P), 256, 0, st>>>(a, 0, nullptr);
     if (nblk > 1) {
         homog_bound_kernel<<<P, 256, 0, st>>>(a, bound);
         homog_score_kernel<<<dim3(nblk - 1, nch, P), 256, 0, st>>>(a, 1, bound);
     }
-    homog_select_kernel<<<P, 256, (size_t)a.iters_pad * 12, st>>>(a);
+    const size_t red_bytes = (size_t)(hg::NSUM * RED_PITCH + 9 * hg::NSUM) * sizeof(double);
+    const size_t lds = (size_t)a.iters_pad * 12 > red_bytes ? (size_t)a.iters_pad * 12 : red_bytes;
+    homog_select_kernel<<<P, 256, lds, st>>>(a);
     return 0;
 }
 

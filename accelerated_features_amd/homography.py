@@ -29,8 +29,9 @@ def _device():
 
 
 def _outputs(P, cap, dev):
-    return (torch.zeros((P, 3, 3), dtype=torch.float64, device=dev), torch.zeros((P, cap), dtype=torch.uint8, device=dev),
-            torch.zeros((P, 8), dtype=torch.int32, device=dev))
+    """H, mask, info: the select kernel writes every element (rows of the mask beyond a pair's count included), so no fill kernels."""
+    return (torch.empty((P, 3, 3), dtype=torch.float64, device=dev), torch.empty((P, cap), dtype=torch.uint8, device=dev),
+            torch.empty((P, 8), dtype=torch.int32, device=dev))
 
 
 def _workspace(lib, P, max_iters, dev):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time xfh_find_homography (three launches) on synthetic match lists: the demo's shape (one pair, ~1000 matches) and the bench batch
-(32 pairs x 4096 rows).   python tools/homography_time.py"""
+(32 pairs x 4096 rows).   python tools/homography_time.py [P,n,maxIters]"""
 import os
 import sys
 import time
@@ -14,7 +14,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from accelerated_features_amd.homography import find_homography_batch  # noqa: E402
 from test_oracle_homography import synthetic_pair  # noqa: E402
 
-for P, n, iters in ((1, 300, 700), (1, 1000, 700), (1, 4096, 700), (32, 1024, 700), (32, 4096, 700), (32, 4096, 4096)):
+CASES = ((1, 300, 700), (1, 1000, 700), (1, 4096, 700), (32, 1024, 700), (32, 4096, 700), (32, 4096, 4096))
+if len(sys.argv) > 1:                      # one case "P,n,iters" (per-kernel profiles: rocprofv3 --kernel-trace --stats -- python tools/homography_time.py 1,1000,700)
+    CASES = (tuple(int(v) for v in sys.argv[1].split(",")),)
+for P, n, iters in CASES:
     p0 = np.zeros((P, n, 2), np.float32)
     p1 = np.zeros_like(p0)
     for p in range(P):
