@@ -129,24 +129,27 @@ class ReferenceTracker:
         return r
 
 
-def find_homography(points1, points2, method=USAC_MAGSAC, ransac_thr=4.0, maxIters=700, confidence=0.995, seed=0, return_info=False):
-    """``cv2.findHomography(points1, points2, cv2.USAC_MAGSAC, ransac_thr, maxIters=..., confidence=...)`` for one pair.
+def find_homography(srcPoints, dstPoints, method=USAC_MAGSAC, ransacReprojThreshold=3.0, mask=None, maxIters=2000, confidence=0.995, *,
+                    seed=0, return_info=False):
+    """``cv2.findHomography(srcPoints, dstPoints, cv2.USAC_MAGSAC, ransacReprojThreshold, maxIters=..., confidence=...)`` for one pair:
+    cv2's parameter names, order and defaults (``mask`` is cv2's optional output argument: accepted and ignored); ``method`` must be
+    ``cv2.USAC_MAGSAC`` (38), the one the reference uses (realtime_demo.py:225).
 
-    points1, points2 : (N,2) arrays / tensors (numpy, CPU or CUDA torch), any float type
+    srcPoints, dstPoints : (N,2) or (N,1,2) arrays / tensors (numpy, CPU or CUDA torch), any float type
     Returns (H, inliers): H (3,3) float64 numpy array, inliers (N,1) uint8 numpy array -- or (None, None) like cv2 when fewer than
-    four correspondences are given or no model is found.
+    four correspondences are given or no model is found.  ``seed`` fixes the sample sequence (same arguments, same bits).
     """
     if method != USAC_MAGSAC:
         raise _lib.XFeatHipError(f"find_homography: only cv2.USAC_MAGSAC ({USAC_MAGSAC}) is implemented, got method={method}")
     dev = _device()
-    a = torch.as_tensor(np.asarray(points1) if not torch.is_tensor(points1) else points1).reshape(-1, 2)
-    b = torch.as_tensor(np.asarray(points2) if not torch.is_tensor(points2) else points2).reshape(-1, 2)
+    a = torch.as_tensor(np.asarray(srcPoints) if not torch.is_tensor(srcPoints) else srcPoints).reshape(-1, 2)
+    b = torch.as_tensor(np.asarray(dstPoints) if not torch.is_tensor(dstPoints) else dstPoints).reshape(-1, 2)
     if a.shape != b.shape:
-        raise RuntimeError('points1 and points2 must hold the same number of points')
+        raise RuntimeError('srcPoints and dstPoints must hold the same number of points')
     n = a.shape[0]
     if n < 4:
         return (None, None, dict.fromkeys(INFO_FIELDS, 0)) if return_info else (None, None)
-    r = find_homography_batch(a.to(dev).float()[None], b.to(dev).float()[None], None, ransac_thr, maxIters, confidence, seed)
+    r = find_homography_batch(a.to(dev).float()[None], b.to(dev).float()[None], None, ransacReprojThreshold, maxIters, confidence, seed)
     info = dict(zip(INFO_FIELDS, r['info'][0].cpu().tolist()))
     if not info['found']:
         return (None, None, info) if return_info else (None, None)

@@ -64,7 +64,7 @@ def test_tables_are_the_oracles():
 def test_single_pair_matches_oracle(n, outliers, noise, thr, iters, conf, seed):
     from accelerated_features_amd.homography import find_homography
     p0, p1, Ht, _ = synthetic_pair(n, outliers, noise, seed=100 + n)
-    H, mask, info = find_homography(p0, p1, ransac_thr=thr, maxIters=iters, confidence=conf, seed=seed, return_info=True)
+    H, mask, info = find_homography(p0, p1, ransacReprojThreshold=thr, maxIters=iters, confidence=conf, seed=seed, return_info=True)
     info["score"] = (info.pop("score_hi") << 32) | (info.pop("score_lo") & 0xffffffff)
     assert H is not None and mask.shape == (n, 1) and mask.dtype == np.uint8 and H.dtype == np.float64
     io = _check_against_oracle(p0, p1, H, mask[:, 0], info, thr, iters, conf, seed)
@@ -72,7 +72,7 @@ def test_single_pair_matches_oracle(n, outliers, noise, thr, iters, conf, seed):
     if noise > 0 and outliers < 0.8:
         assert transfer_error(H, Ht) < 1.0
     # same arguments, same bits
-    H2, mask2 = find_homography(p0, p1, ransac_thr=thr, maxIters=iters, confidence=conf, seed=seed)
+    H2, mask2 = find_homography(p0, p1, ransacReprojThreshold=thr, maxIters=iters, confidence=conf, seed=seed)
     assert np.array_equal(H, H2) and np.array_equal(mask, mask2)
 
 
@@ -106,7 +106,7 @@ def test_degenerate_and_error_behaviour():
     assert find_homography(line, line + 1) == (None, None)                                  # every sample is collinear
     g = np.random.default_rng(0)
     a, b = g.uniform(0, 500, (200, 2)), g.uniform(0, 500, (200, 2))
-    H, mask, info = find_homography(a, b, ransac_thr=1.0, return_info=True)
+    H, mask, info = find_homography(a, b, ransacReprojThreshold=1.0, maxIters=700, return_info=True)
     Ho, mo = ho.find_homography(a, b, 1.0)
     assert (H is None) == (Ho is None) and (H is None or np.array_equal(mask, mo))
     with pytest.raises(L.XFeatHipError):
@@ -134,7 +134,8 @@ def test_demo_pattern_cached_reference_then_match_then_homography():
     assert len(idx0) > 50
     points1 = ref["keypoints"][idx0].cpu().numpy()
     points2 = cur["keypoints"][idx1].cpu().numpy()
-    H, inliers = find_homography(points1, points2, ransac_thr=4.0, maxIters=700, confidence=0.995)
+    from accelerated_features_amd.homography import USAC_MAGSAC
+    H, inliers = find_homography(points1, points2, USAC_MAGSAC, 4.0, maxIters=700, confidence=0.995)      # the demo's call, verbatim
     inliers = inliers.flatten() > 0
     assert inliers.sum() > 0.4 * len(idx0)
     assert np.abs(H - np.array([[1, 0, 64.0], [0, 1, 32.0], [0, 0, 1]])).max() < 0.5 and abs(H[0, 0] - 1) < 5e-3 and abs(H[1, 0]) < 5e-3

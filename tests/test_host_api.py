@@ -205,3 +205,23 @@ def test_no_kernel_in_the_library_uses_scratch(tmp_path):
             n += 1
             assert k[".private_segment_fixed_size"] == 0 and k[".vgpr_spill_count"] == 0, (k[".name"], k[".private_segment_fixed_size"], k[".vgpr_spill_count"])
     assert n >= 100
+
+
+def test_find_homography_has_cv2s_signature_and_no_cpu_path():
+    """cv2.findHomography(srcPoints, dstPoints[, method[, ransacReprojThreshold[, mask[, maxIters[, confidence]]]]]) -- the call of
+    realtime_demo.py:225 binds positionally / by these keywords; without a GPU the function raises (there is no host estimator in the product)."""
+    import inspect
+    import numpy as np
+    import torch
+    from accelerated_features_amd import _lib, homography
+    sig = inspect.signature(homography.find_homography)
+    names = list(sig.parameters)
+    assert names[:7] == ["srcPoints", "dstPoints", "method", "ransacReprojThreshold", "mask", "maxIters", "confidence"]
+    assert sig.parameters["ransacReprojThreshold"].default == 3.0 and sig.parameters["maxIters"].default == 2000 and sig.parameters["confidence"].default == 0.995
+    assert homography.USAC_MAGSAC == 38                         # cv2.USAC_MAGSAC
+    sig.bind(np.zeros((8, 2)), np.zeros((8, 2)), 38, 4.0, maxIters=700, confidence=0.995)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.XFeatHipError):
+            homography.find_homography(np.zeros((8, 2)), np.zeros((8, 2)), 38, 4.0, maxIters=700, confidence=0.995)
+        with pytest.raises(_lib.XFeatHipError):
+            homography.find_homography_batch(torch.zeros(1, 8, 2), torch.zeros(1, 8, 2))
