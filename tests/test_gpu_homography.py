@@ -176,3 +176,33 @@ def test_index_list_entry_equals_gathered_points_and_tracker_runs_the_demo_step(
     Ho, mo, io = ho.find_homography(p0[1, :k].cpu().numpy(), p1[1, :k].cpu().numpy(), 4.0, seed=3, pair=1, return_info=True)
     assert io["best_it"] == int(r["info"][1, 1]) and io["iters"] == int(r["info"][1, 2]) and np.array_equal(mo[:, 0], r["inliers"][1, :k].cpu().numpy())
     assert np.abs(H[1] - Ho).max() <= 1e-8 * np.abs(Ho).max()
+
+
+def test_randomised_sweep_matches_oracle_and_repeats_bit_for_bit():
+    """32 random configurations (list length, outlier share, noise, threshold, maxIters, confidence, seed, degenerate duplicates): every
+    integer output identical to the restatement; then 100 repetitions of one call: identical bits (u64 atomics carry no order)."""
+    from accelerated_features_amd.homography import find_homography, find_homography_batch
+    g = np.random.default_rng(2024)
+    for k in range(32):
+        n = int(g.integers(4, 3000))
+        outl, noise = float(g.uniform(0, 0.75)), float(g.uniform(0, 1.5))
+        thr, iters = float(g.uniform(0.8, 6.0)), int(g.integers(20, 1500))
+        conf, seed = float(g.choice([0.9, 0.99, 0.995, 0.9999])), int(g.integers(0, 2 ** 62))
+        p0, p1, _, _ = synthetic_pair(n, outl, noise, seed=500 + k)
+        if k % 5 == 0:                                   # repeated correspondences: duplicate draws, rank-deficient samples
+            p0[: n // 2] = p0[0]
+            p1[: n // 2] = p1[0]
+        H, mask, info = find_homography(p0, p1, ransacReprojThreshold=thr, maxIters=iters, confidence=conf, seed=seed, return_info=True)
+        info["score"] = (info.pop("score_hi") << 32) | (info.pop("score_lo") & 0xffffffff)
+        if H is None:
+            Ho, mo, io = ho.find_homography(p0, p1, thr, max_iters=iters, confidence=conf, seed=seed, return_info=True)
+            assert Ho is None and info["best_it"] == io["best_it"] and info["iters"] == io["iters"], (k, info, io)
+        else:
+            _check_against_oracle(p0, p1, H, mask[:, 0], info, thr, iters, conf, seed)
+    p0, p1, _, _ = synthetic_pair(2000, 0.5, 0.8, seed=77)
+    a, b = torch.from_numpy(np.stack([p0] * 8)).cuda(), torch.from_numpy(np.stack([p1] * 8)).cuda()
+    first = find_homography_batch(a, b, None, 3.0, 700, 0.995, 5)
+    for _ in range(100):
+        r = find_homography_batch(a, b, None, 3.0, 700, 0.995, 5)
+        assert torch.equal(r["H"], first["H"]) and torch.equal(r["inliers"], first["inliers"]) and torch.equal(r["info"], first["info"])
+    assert len({tuple(first["info"][p, 1:3].tolist()) for p in range(8)}) > 1      # pairs draw different samples (the counter carries the pair index)
