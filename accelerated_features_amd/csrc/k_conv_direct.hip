@@ -321,6 +321,9 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
 //     2.4 k barriers -- the SIMDs issue FMAs ~45 % of the time; the rest is the lock-step stage structure (9 and 11 wave-loads
 //     on 8 waves, two barriers per stage, two workgroups per CU to cover each other).  Unrolling the channel loops made it slower
 //     (x2: +4 %, x8: +20 %).  What helped: issuing the six gray loads of a thread together (311 -> 292 us).
+//   * 7 x 16 output tiles (the conv3 tile = 15 x 33 = 495 pixels = ONE pass of the 512 threads instead of 561 = a full pass + one wave,
+//     conv1 5 passes instead of 6: 11 % fewer issue slots on a workgroup's critical path, 5 % more tiles): 299 us against 288 in
+//     three alternating in-run pairs -- the partial passes are not what the stages wait for; dropped.
 
 void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st) {
     const ConvW& c0 = nw.conv[L_BLOCK1_0];
