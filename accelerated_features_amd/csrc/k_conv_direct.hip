@@ -324,6 +324,8 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
 //   * 7 x 16 output tiles (the conv3 tile = 15 x 33 = 495 pixels = ONE pass of the 512 threads instead of 561 = a full pass + one wave,
 //     conv1 5 passes instead of 6: 11 % fewer issue slots on a workgroup's critical path, 5 % more tiles): 299 us against 288 in
 //     three alternating in-run pairs -- the partial passes are not what the stages wait for; dropped.
+//   * workgroup size (same tiles, conv4 on 24 / (threads / 128) couts per thread): 256 threads 330 us, 512 threads 280 us, 1024 threads
+//     380 us (alternating in-run pairs): with 16 waves conv4 reads its 72 inputs twice as often per FMA, with 4 waves nothing hides the LDS latency.
 
 void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st) {
     const ConvW& c0 = nw.conv[L_BLOCK1_0];
