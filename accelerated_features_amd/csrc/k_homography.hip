@@ -37,6 +37,7 @@ constexpr int NBINS = 4096, SCORE_ONE = 1 << 20, LO_ITERS = 5, MAX_DRAWS = 16;
 constexpr int HYP_PER_WG = 256, PTS_PER_WG = 512, MAX_ITERS = 4096;
 constexpr double K_QUANTILE = 3.64, MAX_THR_FACTOR = 2.0;
 constexpr int NSUM = 23;
+constexpr int SEL_CACHE = 2048;     // correspondences of a pair that homog_select_kernel keeps in LDS
 }  // namespace hg
 
 struct HgArgs {
@@ -46,6 +47,7 @@ struct HgArgs {
     const int64_t* idx1;
     const int32_t* counts;
     int n_const, P, cap, kcap, iters, iters_pad;
+    int sel_cache_off;        // byte offset of homog_select_kernel's correspondence cache in its dynamic LDS
     int chunk;                // correspondences per workgroup of homog_score_kernel (64 .. PTS_PER_WG)
     double thr2, tmax2, bin_scale, log1mc;
     unsigned long long seed;
@@ -392,22 +394,37 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
         if (tid < 8) info[tid] = tid == 2 ? iters_run : (tid == 1 ? -1 : (tid == 5 ? n : 0));
         return;
     }
-    // ---- Hartley normalisation of both point sets (conditioning of the normal equations only)
-    double c[4] = {0, 0, 0, 0};
-    for (int i = tid; i < n; i += 256) {
+    // ---- the first SEL_CACHE correspondences stay in LDS for all passes (every pass otherwise pays the index -> key-point round trip
+    // again: ~1.5 us each, nine passes); longer lists re-read their tail
+    float4* spt = reinterpret_cast<float4*>(lds_raw + a.sel_cache_off);
+    for (int i = tid; i < min(n, hg::SEL_CACHE); i += 256) {
         float2 q0, q1;
         pts.get(i, q0, q1);
-        c[0] += q0.x; c[1] += q0.y; c[2] += q1.x; c[3] += q1.y;
+        spt[i] = make_float4(q0.x, q0.y, q1.x, q1.y);
     }
+    __syncthreads();
+    auto for_each = [&](auto&& f) {                        // f(i, (x0, y0, x1, y1)) for this thread's correspondences tid, tid + 256, ...
+        for (int i = tid; i < n; i += 256) {
+            float4 q;
+            if (i < hg::SEL_CACHE) q = spt[i];
+            else {
+                float2 q0, q1;
+                pts.get(i, q0, q1);
+                q = make_float4(q0.x, q0.y, q1.x, q1.y);
+            }
+            f(i, q);
+        }
+    };
+    // ---- Hartley normalisation of both point sets (conditioning of the normal equations only)
+    double c[4] = {0, 0, 0, 0};
+    for_each([&](int, const float4& q) { c[0] += q.x; c[1] += q.y; c[2] += q.z; c[3] += q.w; });
     block_sums(c, red);
     const double cx0 = c[0] / n, cy0 = c[1] / n, cx1 = c[2] / n, cy1 = c[3] / n;
     double dd[2] = {0, 0};
-    for (int i = tid; i < n; i += 256) {
-        float2 q0, q1;
-        pts.get(i, q0, q1);
-        const double ax = q0.x - cx0, ay = q0.y - cy0, bx = q1.x - cx1, by = q1.y - cy1;
+    for_each([&](int, const float4& q) {
+        const double ax = q.x - cx0, ay = q.y - cy0, bx = q.z - cx1, by = q.w - cy1;
         dd[0] += sqrt(ax * ax + ay * ay); dd[1] += sqrt(bx * bx + by * by);
-    }
+    });
     block_sums(dd, red);
     const double s0 = dd[0] > 0 ? 1.41421356237309504880 / (dd[0] / n) : 1.0, s1 = dd[1] > 0 ? 1.41421356237309504880 / (dd[1] / n) : 1.0;
 
@@ -424,22 +441,20 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
 #pragma unroll
         for (int k = 0; k < hg::NSUM; ++k) sm[k] = 0.0;
         unsigned long long sc = 0;
-        for (int i = tid; i < n; i += 256) {
-            float2 q0, q1;
-            pts.get(i, q0, q1);
-            const double r2 = residual_sq(hcur, q0.x, q0.y, q1.x, q1.y);
+        for_each([&](int, const float4& p) {
+            const double r2 = residual_sq(hcur, p.x, p.y, p.z, p.w);
             if (r2 < a.tmax2) {
                 const int b = bin_of(r2, a.bin_scale);
                 sc += a.stab[b];
                 const double w = a.wtab[b];
-                const double x = (q0.x - cx0) * s0, y = (q0.y - cy0) * s0, u = (q1.x - cx1) * s1, v = (q1.y - cy1) * s1;
+                const double x = (p.x - cx0) * s0, y = (p.y - cy0) * s0, u = (p.z - cx1) * s1, v = (p.w - cy1) * s1;
                 const double wx = w * x, wy = w * y, wxx = wx * x, wxy = wx * y, wyy = wy * y, q = u * u + v * v;
                 sm[0] += wxx; sm[1] += wxy; sm[2] += wx; sm[3] += wyy; sm[4] += wy; sm[5] += w;
                 sm[6] += u * wxx; sm[7] += u * wxy; sm[8] += u * wyy; sm[9] += u * wx; sm[10] += u * wy; sm[11] += u * w;
                 sm[12] += v * wxx; sm[13] += v * wxy; sm[14] += v * wyy; sm[15] += v * wx; sm[16] += v * wy; sm[17] += v * w;
                 sm[18] += q * wxx; sm[19] += q * wxy; sm[20] += q * wyy; sm[21] += q * wx; sm[22] += q * wy;
             }
-        }
+        });
         atomicAdd(&sc_sh, sc);
         block_sums(sm, red);                               // (its barriers also publish sc_sh)
         const unsigned long long s_now = sc_sh;
@@ -477,16 +492,12 @@ __global__ __launch_bounds__(256) void homog_select_kernel(HgArgs a) {
     if (tid == 0) cnt_sh = 0u;
     __syncthreads();
     unsigned cn = 0;
-    for (int i = tid; i < a.cap; i += 256) {
-        unsigned char mk = 0;
-        if (i < n) {
-            float2 q0, q1;
-            pts.get(i, q0, q1);
-            mk = residual_sq(hbest, q0.x, q0.y, q1.x, q1.y) < a.thr2 ? 1 : 0;
-        }
+    for_each([&](int i, const float4& p) {
+        const unsigned char mk = residual_sq(hbest, p.x, p.y, p.z, p.w) < a.thr2 ? 1 : 0;
         mask[i] = mk;
         cn += mk;
-    }
+    });
+    for (int i = (n > 0 ? n : 0) + tid; i < a.cap; i += 256) mask[i] = 0;      // rows beyond the pair's count
     atomicAdd(&cnt_sh, cn);
     __syncthreads();
     const int n_in = (int)cnt_sh;
@@ -523,7 +534,7 @@ int launch_find_homography(const float* p0, const float* p1, const int64_t* idx0
     a.iters_pad = ceil_div(max_iters, 256) * 256;
     const double t_max = hg::MAX_THR_FACTOR * thr;
     a.thr2 = thr * thr; a.tmax2 = t_max * t_max; a.bin_scale = hg::NBINS / (t_max * t_max); a.log1mc = log(1.0 - confidence);
-    a.seed = seed;
+    a.seed = seed; a.sel_cache_off = 0; a.chunk = hg::PTS_PER_WG;
     unsigned char* w = static_cast<unsigned char*>(ws);
     a.wtab = reinterpret_cast<double*>(w); w += (size_t)hg::NBINS * 8;
     a.hscore = reinterpret_cast<unsigned long long*>(w); w += (size_t)P * a.iters_pad * 8;
@@ -545,7 +556,11 @@ int launch_find_homography(const float* p0, const float* p1, const int64_t* idx0
         homog_score_kernel<<<dim3(nblk - 1, nch, P), 256, 0, st>>>(a, 1, bound);
     }
     const size_t red_bytes = (size_t)(hg::NSUM * RED_PITCH + 9 * hg::NSUM) * sizeof(double);
-    const size_t lds = (size_t)a.iters_pad * 12 > red_bytes ? (size_t)a.iters_pad * 12 : red_bytes;
+    const size_t front = ((size_t)a.iters_pad * 12 > red_bytes ? (size_t)a.iters_pad * 12 : red_bytes) + 15 & ~(size_t)15;
+    a.sel_cache_off = (int)front;
+    const size_t lds = front + (size_t)hg::SEL_CACHE * sizeof(float4);
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(homog_select_kernel), 96 * 1024, attr);
     homog_select_kernel<<<P, 256, lds, st>>>(a);
     return 0;
 }
