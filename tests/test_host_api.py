@@ -225,3 +225,37 @@ def test_find_homography_has_cv2s_signature_and_no_cpu_path():
             homography.find_homography(np.zeros((8, 2)), np.zeros((8, 2)), 38, 4.0, maxIters=700, confidence=0.995)
         with pytest.raises(_lib.XFeatHipError):
             homography.find_homography_batch(torch.zeros(1, 8, 2), torch.zeros(1, 8, 2))
+
+
+def _build_c_host(tmp_path):
+    import subprocess
+    from accelerated_features_amd import build
+    exe = str(tmp_path / "c_host_homography")
+    libdir = os.path.dirname(build.LIB)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+           os.path.join(ROOT, "examples", "c_host_homography.c"), "-L", libdir, "-lxfeat_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """include/xfeat_hip.h is the boundary for hosts in any language: it must compile as strict C99 and as C++11 on its own, and a C program
+    that uses only it and the HIP runtime must link against libxfeat_hip.so (examples/c_host_homography.c; the GPU suite runs it)."""
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "xfeat_hip.h"\nint main(void) { return xfh_version() >= 100 ? 0 : 1; }\n')
+    for cc, std in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++11", "-x", "c++"])):
+        r = subprocess.run([cc, *std, "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "t.o")],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    assert os.path.exists(_build_c_host(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_host_runs_the_homography_stage(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "mask differences 0" in r.stdout
