@@ -129,6 +129,7 @@ constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead o
 constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19389 floats = 77.6 KB
 }  // namespace b1
 
+template <bool C1X3>
 __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int B, int H, int W,
                                                            int tiles_x, int tiles_y,
                                                            const float* __restrict__ w1, const float* __restrict__ bb1,
@@ -173,6 +174,43 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     __syncthreads();
 
     // ---- stage 1: conv1 1->4, s1 --------------------------------------------------------------
+    if constexpr (C1X3) {
+        // three adjacent pixels per thread: one index computation and 15 LDS reads for 3 x 36 FMAs (a pixel alone: 9 reads for 36)
+        constexpr int NG = (C1W + 2) / 3;
+        for (int e = tid; e < C1H * NG; e += 512) {
+            const int r = e / NG, c0 = (e - r * NG) * 3;
+            const int gy = 4 * Y4 - 5 + r, gx0 = 4 * X4 - 5 + c0;
+            float acc[3][4];
+#pragma unroll
+            for (int px = 0; px < 3; ++px)
+#pragma unroll
+                for (int co = 0; co < 4; ++co) acc[px][co] = bb1[co];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) v[j] = G[(r + dy) * GW + c0 + j];          // (the last group reads one element past its row: unused pixel)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* w = w1 + (dy * 3 + dx) * 4;
+#pragma unroll
+                    for (int px = 0; px < 3; ++px)
+#pragma unroll
+                        for (int co = 0; co < 4; ++co) acc[px][co] = fmaf(v[px + dx], w[co], acc[px][co]);
+                }
+            }
+            const bool rowok = gy >= 0 && gy < H;
+#pragma unroll
+            for (int px = 0; px < 3; ++px) {
+                const int gx = gx0 + px;
+                const bool ok = rowok && gx >= 0 && gx < W;
+                if (c0 + px < C1W) {
+#pragma unroll
+                    for (int co = 0; co < 4; ++co) C1[co * (C1H * C1W) + r * C1W + c0 + px] = ok ? fmaxf(acc[px][co], 0.f) : 0.f;
+                }
+            }
+        }
+    } else
     for (int e = tid; e < C1H * C1W; e += 512) {
         const int r = e / C1W, c = e - r * C1W;
         const int gy = 4 * Y4 - 5 + r, gx = 4 * X4 - 5 + c;
@@ -335,9 +373,19 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     const ConvW& sk = nw.conv[L_SKIP1];
     const int H4 = H / 4, W4 = W / 4;
     const int tx = ceil_div(W4, b1::OW), ty = ceil_div(H4, b1::OH);
-    static unsigned attr = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel), b1::LDS_FLOATS * 4, attr);
-    block1_fused_kernel<<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(
+    // conv1 on three adjacent pixels per thread: 275 -> 266 us in alternating in-run pairs (PMC: the kernel issues VALU instructions 76 % of the
+    // time and only 54 % of them are FMAs -- index arithmetic, bounds and LDS addresses are the rest, and conv1 has the fewest FMAs per index).
+    static int c1x3 = -1;          // XFH_BLOCK1_C1=1: one pixel per thread (A/B runs)
+    if (c1x3 < 0) { const char* e = getenv("XFH_BLOCK1_C1"); c1x3 = e && atoi(e) == 1 ? 0 : 1; }
+    static unsigned attr = 0, attr3 = 0;
+    if (c1x3) {
+        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<true>), b1::LDS_FLOATS * 4, attr3);
+        block1_fused_kernel<true><<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(
+            gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
+        return;
+    }
+    set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<false>), b1::LDS_FLOATS * 4, attr);
+    block1_fused_kernel<false><<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(
         gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
 }
 
