@@ -140,3 +140,51 @@ def test_degenerate_inputs():
     sq = np.array([[0, 0], [100, 0], [100, 100], [0, 100]], np.float32)
     H, mask = ho.find_homography(sq, sq * 2 + 5, 4.0)                              # exactly four points
     assert mask.sum() == 4 and np.allclose(H, [[2, 0, 5], [0, 2, 5], [0, 0, 1]], atol=1e-9)
+
+
+from sklearn.base import BaseEstimator, RegressorMixin  # noqa: E402
+
+
+class _DltHomography(RegressorMixin, BaseEstimator):
+    """Minimal scikit-learn estimator: X (n,2) -> y (n,2) under a homography fitted by the normalised DLT (SVD).  Shares no code with the oracle."""
+
+    @staticmethod
+    def _norm(p):
+        c = p.mean(0)
+        s = np.sqrt(2) / max(np.linalg.norm(p - c, axis=1).mean(), 1e-12)
+        return np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+
+    def fit(self, X, y):
+        T0, T1 = self._norm(X), self._norm(y)
+        a = np.c_[X, np.ones(len(X))] @ T0.T
+        b = np.c_[y, np.ones(len(y))] @ T1.T
+        rows = []
+        for (x, yy, _), (u, v, _) in zip(a, b):
+            rows.append([x, yy, 1, 0, 0, 0, -u * x, -u * yy, -u])
+            rows.append([0, 0, 0, x, yy, 1, -v * x, -v * yy, -v])
+        h = np.linalg.svd(np.asarray(rows))[2][-1].reshape(3, 3)
+        self.H_ = np.linalg.inv(T1) @ h @ T0
+        return self
+
+    def predict(self, X):
+        q = np.c_[X, np.ones(len(X))] @ self.H_.T
+        return q[:, :2] / q[:, 2:]
+
+    def score(self, X, y):
+        return -float(np.mean(np.sum((self.predict(X) - y) ** 2, axis=1)))
+
+
+@pytest.mark.parametrize("n,outliers,noise", [(400, 0.3, 0.5), (1500, 0.5, 1.0)])
+def test_agrees_with_an_independent_ransac(n, outliers, noise):
+    """scikit-learn's RANSACRegressor around a textbook DLT (different sampler, plain inlier counting, SVD instead of normal equations) finds the
+    same model: inlier sets agree on >= 97 % of the correspondences and the two homographies move the image corners by < 0.5 px apart."""
+    from sklearn.linear_model import RANSACRegressor
+    p0, p1, _, _ = synthetic_pair(n, outliers, noise, seed=900 + n)
+    H, mask = ho.find_homography(p0, p1, 4.0, seed=3)
+    with np.errstate(all="ignore"):
+        rs = RANSACRegressor(_DltHomography(), min_samples=4, residual_threshold=4.0, max_trials=700, random_state=0,
+                             loss=lambda y, yp: np.sqrt(np.sum((y - yp) ** 2, axis=1)))
+        rs.fit(p0.astype(np.float64), p1.astype(np.float64))
+    agree = (rs.inlier_mask_ == (mask[:, 0] > 0)).mean()
+    assert agree >= 0.97, agree
+    assert transfer_error(H, rs.estimator_.H_ / rs.estimator_.H_[2, 2]) < 0.5
