@@ -14,12 +14,15 @@
  *   - The library never allocates in the hot path: the caller provides a workspace of
  *     xfh_*_workspace_bytes() bytes (256-byte aligned).  Only xfh_create allocates (weights).
  *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
- *     default stream).  No hidden synchronisation, no global mutable state besides the
- *     thread-local error string.
+ *     default stream).  No hidden synchronisation.  Process-wide state is limited to: the
+ *     thread-local error string; the XFH_* environment switches (A/B runs; each read once, at the
+ *     first call that consults it); per-device "kernel attribute set" flags (idempotent);
+ *     the debugging hooks xfh_debug_trace / xfh_profile_select (not for concurrent use).
  *   - Return value: XFH_OK (0) or a negative XFH_ERR_* code; xfh_last_error() gives a
  *     message for the calling thread.  No C++ exception crosses the boundary.
- *   - A handle is immutable after xfh_create and may be shared by threads/streams, provided
- *     each concurrent call uses its own workspace.
+ *   - A handle's weights are immutable after xfh_create and it may be shared by threads/streams,
+ *     provided each concurrent call uses its own workspace (the profiling hooks above write
+ *     into the handle: switch them off for concurrent use).
  *   - Ragged results use fixed capacity + device-side counts: the host reads the counts back
  *     once per batch (the reference synchronises B times per batch: xfeat.py:254-261,99-103).
  */
