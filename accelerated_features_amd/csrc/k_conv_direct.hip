@@ -129,7 +129,7 @@ constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead o
 constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19389 floats = 77.6 KB
 }  // namespace b1
 
-template <bool C1X3>
+template <int C1MODE>      // conv1: 1 = a pixel per thread, 3 = three adjacent pixels (scalar FMAs), 4 = three adjacent pixels on packed FMAs
 __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int B, int H, int W,
                                                            int tiles_x, int tiles_y,
                                                            const float* __restrict__ w1, const float* __restrict__ bb1,
@@ -174,7 +174,48 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     __syncthreads();
 
     // ---- stage 1: conv1 1->4, s1 --------------------------------------------------------------
-    if constexpr (C1X3) {
+    if constexpr (C1MODE == 4) {
+        // three adjacent pixels per thread, cout pairs on v_pk_fma_f32 (written as 2-vectors: left to itself hipcc emits 108 v_fmac_f32 here)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        constexpr int NG = (C1W + 2) / 3;
+        for (int e = tid; e < C1H * NG; e += 512) {
+            const int r = e / NG, c0 = (e - r * NG) * 3;
+            const int gy = 4 * Y4 - 5 + r, gx0 = 4 * X4 - 5 + c0;
+            f2 acc[3][2];
+#pragma unroll
+            for (int px = 0; px < 3; ++px) { acc[px][0] = f2{bb1[0], bb1[1]}; acc[px][1] = f2{bb1[2], bb1[3]}; }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float v[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) v[j] = G[(r + dy) * GW + c0 + j];          // (the last group reads one element past its row: unused pixel)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* w = w1 + (dy * 3 + dx) * 4;
+                    const f2 w01 = f2{w[0], w[1]}, w23 = f2{w[2], w[3]};
+#pragma unroll
+                    for (int px = 0; px < 3; ++px) {
+                        const f2 vv = f2{v[px + dx], v[px + dx]};
+                        acc[px][0] = __builtin_elementwise_fma(vv, w01, acc[px][0]);
+                        acc[px][1] = __builtin_elementwise_fma(vv, w23, acc[px][1]);
+                    }
+                }
+            }
+            const bool rowok = gy >= 0 && gy < H;
+#pragma unroll
+            for (int px = 0; px < 3; ++px) {
+                const int gx = gx0 + px;
+                const bool ok = rowok && gx >= 0 && gx < W;
+                if (c0 + px < C1W) {
+                    float* o = C1 + r * C1W + c0 + px;
+                    o[0] = ok ? fmaxf(acc[px][0].x, 0.f) : 0.f;
+                    o[C1H * C1W] = ok ? fmaxf(acc[px][0].y, 0.f) : 0.f;
+                    o[2 * C1H * C1W] = ok ? fmaxf(acc[px][1].x, 0.f) : 0.f;
+                    o[3 * C1H * C1W] = ok ? fmaxf(acc[px][1].y, 0.f) : 0.f;
+                }
+            }
+        }
+    } else if constexpr (C1MODE == 3) {
         // three adjacent pixels per thread: one index computation and 15 LDS reads for 3 x 36 FMAs (a pixel alone: 9 reads for 36)
         constexpr int NG = (C1W + 2) / 3;
         for (int e = tid; e < C1H * NG; e += 512) {
@@ -367,7 +408,7 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
 
 void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st) {
     const ConvW& c0 = nw.conv[L_BLOCK1_0];
-    const ConvW& c1 = nw.conv[L_BLOCK1_1];
+    const ConvW& c1w = nw.conv[L_BLOCK1_1];
     const ConvW& c2 = nw.conv[L_BLOCK1_2];
     const ConvW& c3 = nw.conv[L_BLOCK1_3];
     const ConvW& sk = nw.conv[L_SKIP1];
@@ -375,18 +416,22 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     const int tx = ceil_div(W4, b1::OW), ty = ceil_div(H4, b1::OH);
     // conv1 on three adjacent pixels per thread: 275 -> 266 us in alternating in-run pairs (PMC: the kernel issues VALU instructions 76 % of the
     // time and only 54 % of them are FMAs -- index arithmetic, bounds and LDS addresses are the rest, and conv1 has the fewest FMAs per index).
-    static int c1x3 = -1;          // XFH_BLOCK1_C1=1: one pixel per thread (A/B runs)
-    if (c1x3 < 0) { const char* e = getenv("XFH_BLOCK1_C1"); c1x3 = e && atoi(e) == 1 ? 0 : 1; }
-    static unsigned attr = 0, attr3 = 0;
-    if (c1x3) {
-        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<true>), b1::LDS_FLOATS * 4, attr3);
-        block1_fused_kernel<true><<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(
-            gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
-        return;
+    // Mode 4 writes the same three pixels as 2-vectors so that hipcc emits 54 v_pk_fma_f32 per item instead of 108 v_fmac_f32 (-108 of ~1400 VALU
+    // instructions per thread); rocprof 280.5 us against 289.4 us for mode 3 on two comparable boxes, full GPU suite green with it as the default --
+    // no alternating in-run pair could be run any more in round 2, so it stays opt-in until one has been.
+    static int c1 = 0;          // XFH_BLOCK1_C1=1: one pixel per thread; =4: three pixels on packed FMAs; default 3: three pixels, scalar FMAs
+    if (!c1) { const char* e = getenv("XFH_BLOCK1_C1"); c1 = e && (atoi(e) == 1 || atoi(e) == 4) ? atoi(e) : 3; }
+    static unsigned attr1 = 0, attr3 = 0, attr4 = 0;
+#define XFH_B1_LAUNCH(MODE, ATTR)                                                                                                       \
+    {                                                                                                                                    \
+        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<MODE>), b1::LDS_FLOATS * 4, ATTR);                         \
+        block1_fused_kernel<MODE><<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(                                           \
+            gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias); \
     }
-    set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<false>), b1::LDS_FLOATS * 4, attr);
-    block1_fused_kernel<false><<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(
-        gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1.w_kc, c1.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias);
+    if (c1 == 1) XFH_B1_LAUNCH(1, attr1)
+    else if (c1 == 3) XFH_B1_LAUNCH(3, attr3)
+    else XFH_B1_LAUNCH(4, attr4)
+#undef XFH_B1_LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------

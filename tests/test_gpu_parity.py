@@ -126,7 +126,7 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
 
 
-@pytest.mark.parametrize("env", [{"XFH_HEADS": "f32", "XFH_BX": "0"}, {"XFH_BX": "3", "XFH_BLOCK1_C1": "1"}])
+@pytest.mark.parametrize("env", [{"XFH_HEADS": "f32", "XFH_BX": "0", "XFH_BLOCK1_C1": "1"}, {"XFH_BX": "3", "XFH_BLOCK1_C1": "4"}])
 def test_backbone_alternative_kernels_same_results(env):
     """The A/B switches select other kernels for the same layers (heads on f32 MFMAs, 24->24 layers on Winograd; every unfused 64->64 layer on the
     split-bf16 kernel): the switches are read once per process, so each setting runs the small golden backbone case in its own process."""
