@@ -15,7 +15,7 @@
 //     same bins), each kept only if it raises the quality; mask = residual < thr^2 under the final model; found = at least 4 inliers.
 //
 // What makes it a device algorithm: hypothesis `it` is a function of (seed, pair, it) alone, so ALL maxIters hypotheses are built and
-// scored at once -- thread = hypothesis, workgroups over (256 hypotheses) x (512 correspondences) x pairs -- and the sequential loop's
+// scored at once -- thread = hypothesis, workgroups over (256 hypotheses) x (64-512 correspondences) x pairs -- and the sequential loop's
 // stopping rule is applied afterwards to the score list, exactly as the loop would have applied it.  A score is a sum of integers
 // (u64 atomics: no summation order), the geometry is fp64 with every product and sum rounded once (fp contraction off in this file), so
 // the winning hypothesis, the iteration count and the inlier mask are reproducible bit for bit by any IEEE implementation of the
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void homog_bound_kernel(HgArgs a, int* __restr
 // ---- selection, refinement, mask --------------------------------------------------------------------------------------------------------
 // Totals of N per-thread values over the workgroup, every thread gets them; the order of the additions is fixed.  Through LDS as a transpose:
 // thread (k, j) adds 32 of the 256 entries of row k, thread k the 8 partial sums -- ~40 dependent additions and four barriers.  (A butterfly of
-// wave shuffles costs 6 steps x 2 ds_bpermute per value, each waited for: 11 us per pass for the 23 sums of the refinement.)
+// wave shuffles costs 6 steps x 2 ds_bpermute per value, each waited for: with it the select kernel took 76-84 us instead of 52.)
 constexpr int RED_PITCH = 257;
 template <int N>
 __device__ inline void block_sums(double (&v)[N], double* buf /* N * RED_PITCH + 9 * N doubles */) {
