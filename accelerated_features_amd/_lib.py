@@ -62,6 +62,8 @@ SIGNATURES = {
     "xfh_profile_select": (_i, [_p, _i]),
     "xfh_debug_trace": (_i, [_p, _p]),
     "xfh_debug_match_occupancy": (_i, []),
+    "xfh_set_option": (_i, [_p, C.c_char_p, _i]),
+    "xfh_get_option": (_i, [_p, C.c_char_p, C.POINTER(_i)]),
     "xfh_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

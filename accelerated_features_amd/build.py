@@ -20,9 +20,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
          "-ffp-contract=on"]
 
 
-# per-file additions.  k_match_bf16: without NaN semantics fmaxf is ONE v_max_f32 (else every operand is canonicalised first: 61 instead
-# of 27 max instructions per 32x32 tile of the filter sweeps); descriptors are finite by construction.
-EXTRA_FLAGS = {"k_match_bf16.hip": ["-fno-honor-nans"]}
+# per-file additions.  k_match_f16: without NaN semantics fmaxf(fmaxf(a, b), c) is ONE v_max3_f32 (else every operand is canonicalised
+# first); descriptors are finite by construction.
+EXTRA_FLAGS = {"k_match_f16.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():

@@ -122,6 +122,7 @@ struct xfh_context {
     float* blob;          // device weights
     NetWeights nw;
     Profiler prof;
+    Options opt;          // xfh_set_option
 };
 
 // ------------------------------------------------------------------------------------------
@@ -200,16 +201,15 @@ static size_t carve_match(void* ws, int P, int N1, int N2, MatchWs& o) {
     o.colkey = c.take<unsigned long long>((size_t)P * N2);
     o.colmaxh = c.take<unsigned>((size_t)P * N2);
     o.nmax = c.take<unsigned>((size_t)2 * P);
-    o.cnt = c.take<int>(P);
     o.zeroed = ws ? (char*)ws + z0 : nullptr;
     o.zeroed_bytes = c.off - z0;
-    o.a16 = c.take<unsigned short>((size_t)P * N1 * 64);
-    o.b16 = c.take<unsigned short>((size_t)P * N2 * 64);
+    o.a16 = c.take<_Float16>((size_t)P * N1 * 64);
+    o.b16 = c.take<_Float16>((size_t)P * N2 * 64);
     o.na = c.take<float>((size_t)P * N1);
     o.nb = c.take<float>((size_t)P * N2);
-    o.rowmaxh = c.take<float>((size_t)P * N1);
-    o.cand_cap = 4 * (N1 + N2);                        // ~1.3 candidates per row and per column are typical
-    o.cand = c.take<unsigned long long>((size_t)P * o.cand_cap);
+    o.thr_row = c.take<float>((size_t)P * N1);
+    o.R = c.take<float>((size_t)P * ceil_div(N2, 32) * N1);      // block maxima: 1/32 of the similarity matrix each
+    o.C = c.take<float>((size_t)P * ceil_div(N1, 32) * N2);
     return align_up(c.off, 256);
 }
 
@@ -543,19 +543,17 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     if (h->prof.which == XFH_PROF_CONV_24_24 && c.cin == 24 && c.cout == 24 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_24_24;
     prof_begin(&h->prof, pid, st);
     // 3x3/s1 layers with >= 24 channels: Winograd F(2x2,3x3) (k_conv_wino.hip), including the 3x3 + fused 1x1 pairs.
-    // A/B runs: XFH_WINO=0 forces the direct kernel, XFH_WINO=1 keeps the fused pairs on the direct kernel.
-    static int use_wino = -1;
-    if (use_wino < 0) { const char* e = getenv("XFH_WINO"); use_wino = e ? atoi(e) : 2; }
-    // 24-channel 3x3 layers (block2.0/.1 s1, block3.0 s2): bf16 MFMAs on three-way split operands (k_conv_bx.hip); XFH_BX=0 keeps them on the f32-MFMA kernels
-    static int use_bx = -1;
-    if (use_bx < 0) { const char* e = getenv("XFH_BX"); use_bx = e ? atoi(e) : 5; }      // 1: 24-channel layers; 4: unfused 64 -> 64 layers on large maps (2: on every map); 8: not block3.0
+    // A/B runs (xfh_set_option): wino = 0 forces the direct kernel, 1 keeps the fused pairs on the direct kernel.
+    const int use_wino = h->opt.wino;
+    // 24-channel 3x3 layers (block2.0/.1 s1, block3.0 s2): bf16 MFMAs on three-way split operands (k_conv_bx.hip); bx = 0 keeps them on the f32-MFMA kernels
+    const int use_bx = h->opt.bx;      // 1: 24-channel layers; 4: unfused 64 -> 64 layers on large maps (2: on every map); 8: not block3.0
     int rc = -1;
     const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 1024;      // >= 2 half-tile units per workgroup of the persistent grid (B=8 164x164: 92 vs 124 us stand-alone)
     if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc);      // 3x3 + trailing 1x1 in one split-bf16 kernel
     if (rc && use_bx && c.w_bx && !c2 && !nhwc) {
-        if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);      // (XFH_BX=9: block3.0 stays on the f32 kernel)
-        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);      // (XFH_BX=5: large maps only)
+        if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);      // (bx = 9: block3.0 stays on the f32 kernel)
+        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);      // (bx = 5: large maps only)
     }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
@@ -591,7 +589,7 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     } else if (img_u8) launch_gray_norm_u8(img_u8, u8_layout == XFH_LAYOUT_NHWC, u8_divisor, B, C, H, W, w.part, w.gray, w.coef, st);
     else launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
-    launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st);
+    launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st, h->opt.block1);
     // block1 + skip1 per input pixel: conv1 9*4*2 + conv2 36*8*2/4 + conv3 72*8*2/4 + conv4 72*24*2/16 = 720 FLOP; gray in, x1 out: 10 bytes
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 720.0 * B * H * W, 10.0 * B * H * W);
 #define CONV(layer, fused, in, hin, win, out, nhwc) \
@@ -613,8 +611,8 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
 
     // fused heads: reliability from the channels-last features, key-point head from the gray image
     prof_begin(&h->prof, XFH_PROF_HEADS, st);
-    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st);
-    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st);
+    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32 != 0);
+    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32 != 0);
     prof_end(&h->prof, XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }
@@ -679,7 +677,7 @@ size_t xfh_detect_workspace_bytes(int B, int H, int W, int top_k, int nms_capaci
 
 int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                       float threshold, int top_k, int nms_capacity, float rw, float rh, float* kpts, float* scores,
-                      float* desc, uint16_t* desc_bf16, int32_t* n_valid, int32_t* n_candidates, void* workspace, size_t workspace_bytes,
+                      float* desc, uint16_t* desc_f16, int32_t* n_valid, int32_t* n_candidates, void* workspace, size_t workspace_bytes,
                       xfh_stream stream) {
     if (!h || !heat || !reliab || !feats || !kpts || !scores || !desc || !n_valid || !n_candidates)
         return fail(XFH_ERR_ARG, "xfh_detect_sparse: NULL argument");
@@ -693,7 +691,7 @@ int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, cons
     const size_t need = carve_detect(workspace, B, H, W, top_k, nms_capacity, w);
     if ((rc = check_ws(workspace, workspace_bytes, need))) return rc;
     launch_detect(w, heat, reliab, feats, invnorm, B, H, W, threshold, top_k, nms_capacity, rw, rh, kpts, scores, desc, n_valid,
-                  n_candidates, (hipStream_t)stream, desc_bf16);
+                  n_candidates, (hipStream_t)stream, desc_f16);
     return check_launch("xfh_detect_sparse");
 }
 
@@ -727,7 +725,7 @@ size_t xfh_match_workspace_bytes(int P, int N1, int N2) {
 }
 
 int xfh_match_mnn(xfh_handle h, const float* d1, size_t pair_stride1, const float* d2, size_t pair_stride2,
-                  const uint16_t* d1_bf16, const uint16_t* d2_bf16,
+                  const uint16_t* d1_f16, const uint16_t* d2_f16,
                   const int32_t* n1, const int32_t* n2, int n_stride, int n_offset2, int P, int N1, int N2,
                   float min_cossim, int64_t* idx0, int64_t* idx1, int32_t* n_matches, void* workspace,
                   size_t workspace_bytes, xfh_stream stream) {
@@ -735,14 +733,14 @@ int xfh_match_mnn(xfh_handle h, const float* d1, size_t pair_stride1, const floa
     if (P <= 0 || N1 <= 0 || N2 <= 0 || P > 65535) return fail(XFH_ERR_ARG, "xfh_match_mnn: bad shape");
     if ((long)P * ((N1 + 1023) / 1024) > 0x7fffffffL / 1024) return fail(XFH_ERR_ARG, "xfh_match_mnn: P * N1 too large");
     if ((pair_stride1 & 3) || (pair_stride2 & 3)) return fail(XFH_ERR_ARG, "xfh_match_mnn: pair strides must be multiples of 4 floats");
-    if ((d1_bf16 == nullptr) != (d2_bf16 == nullptr)) return fail(XFH_ERR_ARG, "xfh_match_mnn: pass both bf16 copies or neither");
-    if (d1_bf16 && ((pair_stride1 & 7) || (pair_stride2 & 7))) return fail(XFH_ERR_ARG, "xfh_match_mnn: bf16 copies need pair strides that are multiples of 8");
+    if ((d1_f16 == nullptr) != (d2_f16 == nullptr)) return fail(XFH_ERR_ARG, "xfh_match_mnn: pass both fp16 copies or neither");
+    if (d1_f16 && ((pair_stride1 & 7) || (pair_stride2 & 7))) return fail(XFH_ERR_ARG, "xfh_match_mnn: fp16 copies need pair strides that are multiples of 8");
     MatchWs w;
     const size_t need = carve_match(workspace, P, N1, N2, w);
     int rc = check_ws(workspace, workspace_bytes, need);
     if (rc) return rc;
     launch_match(w, d1, pair_stride1, d2, pair_stride2, n1, n2, n_stride, n_offset2, P, N1, N2, min_cossim, idx0, idx1,
-                 n_matches, (hipStream_t)stream, h ? &h->prof : nullptr, d1_bf16, d2_bf16);
+                 n_matches, (hipStream_t)stream, h ? &h->prof : nullptr, d1_f16, d2_f16, h ? h->opt.match_exact != 0 : false);
     return check_launch("xfh_match_mnn");
 }
 
@@ -884,6 +882,32 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
 }
 
 int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
+
+static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
+    struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
+        {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 15},
+        {"heads_f32", &Options::heads_f32, 0, 1}, {"block1", &Options::block1, 0, 15}, {"pyramid_fused", &Options::pyramid_fused, 0, 1}};
+    for (auto& t : tab)
+        if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
+    return nullptr;
+}
+int xfh_set_option(xfh_handle h, const char* key, int value) {
+    if (!h || !key) return fail(XFH_ERR_ARG, "xfh_set_option: NULL argument");
+    int lo, hi;
+    int* slot = option_slot(h, key, lo, hi);
+    if (!slot) return fail(XFH_ERR_ARG, "xfh_set_option: unknown option '%s'", key);
+    if (value < lo || value > hi) return fail(XFH_ERR_ARG, "xfh_set_option: %s = %d outside [%d, %d]", key, value, lo, hi);
+    *slot = value;
+    return XFH_OK;
+}
+int xfh_get_option(xfh_handle h, const char* key, int* value) {
+    if (!h || !key || !value) return fail(XFH_ERR_ARG, "xfh_get_option: NULL argument");
+    int lo, hi;
+    const int* slot = option_slot(h, key, lo, hi);
+    if (!slot) return fail(XFH_ERR_ARG, "xfh_get_option: unknown option '%s'", key);
+    *value = *slot;
+    return XFH_OK;
+}
 
 int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
     if (!h) return fail(XFH_ERR_ARG, "xfh_debug_trace: NULL handle");

@@ -442,9 +442,7 @@ static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* o
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     BxArgs a;
     a.in = in; a.wfrag = reinterpret_cast<const uint4*>(c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
-    static int lag = -1;
-    if (lag < 0) { const char* e = getenv("XFH_BX_LAG"); lag = e ? atoi(e) : 11; }
-    a.lag = lag;
+    a.lag = 11;
     a.tiles_x = ceil_div(W, Cfg::TW);
     a.tiles = a.tiles_x * ceil_div(H, Cfg::TH);
     static unsigned attr_done = 0;

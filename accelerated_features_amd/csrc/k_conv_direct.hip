@@ -406,7 +406,7 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
 //   * workgroup size (same tiles, conv4 on 24 / (threads / 128) couts per thread): 256 threads 330 us, 512 threads 280 us, 1024 threads
 //     380 us (alternating in-run pairs): with 16 waves conv4 reads its 72 inputs twice as often per FMA, with 4 waves nothing hides the LDS latency.
 
-void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st) {
+void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant) {
     const ConvW& c0 = nw.conv[L_BLOCK1_0];
     const ConvW& c1w = nw.conv[L_BLOCK1_1];
     const ConvW& c2 = nw.conv[L_BLOCK1_2];
@@ -419,8 +419,7 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     // Mode 4 writes the same three pixels as 2-vectors so that hipcc emits 54 v_pk_fma_f32 per item instead of 108 v_fmac_f32 (-108 of ~1400 VALU
     // instructions per thread); rocprof 280.5 us against 289.4 us for mode 3 on two comparable boxes, full GPU suite green with it as the default --
     // no alternating in-run pair could be run any more in round 2, so it stays opt-in until one has been.
-    static int c1 = 0;          // XFH_BLOCK1_C1=1: one pixel per thread; =4: three pixels on packed FMAs; default 3: three pixels, scalar FMAs
-    if (!c1) { const char* e = getenv("XFH_BLOCK1_C1"); c1 = e && (atoi(e) == 1 || atoi(e) == 4) ? atoi(e) : 3; }
+    const int c1 = (variant == 1 || variant == 4) ? variant : 3;      // option "block1": 1 = one pixel per thread; 4 = three pixels on packed FMAs; default 3: three pixels, scalar FMAs
     static unsigned attr1 = 0, attr3 = 0, attr4 = 0;
 #define XFH_B1_LAUNCH(MODE, ATTR)                                                                                                       \
     {                                                                                                                                    \

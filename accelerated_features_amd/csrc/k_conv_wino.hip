@@ -482,8 +482,6 @@ int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B,
     (void)zeros;
     if (c.ks != 3 || c.stride != 1 || !c.w_wino) return -1;
     const int key = c.cin * 1000 + c.cout;
-    static int tune = -1;          // XFH_WINO_TUNE (A/B runs) bit 1: 4-wave 24-channel variant
-    if (tune < 0) { const char* e = getenv("XFH_WINO_TUNE"); tune = e ? atoi(e) : 0; }
     if (c2) {      // 3x3 + fused 1x1
         if (c2->ks != 1 || c2->cin != c.cout || c2->cout != 64) return -1;
         const bool tall = wino_groups(H, W, 8, 4) < wino_groups(H, W, 4, 8);
@@ -502,7 +500,7 @@ int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B,
     // cfg 0 = the production choice; cfg >= 1 = explicit variants (xfh_conv_layer variant 2, 3, ... for tuning)
     switch (key) {
         case 24 * 1000 + 24:     // 1 cout block: waves hold 2 tile blocks each
-            if (cfg == 2 || (cfg == 0 && (tune & 2))) return run_wino<24, 24, 1, 2, 1, 2, 8, 8>(c, in, B, H, W, out, st, trace);   // 4-wave workgroups, 64 tiles, two per CU
+            if (cfg == 2) return run_wino<24, 24, 1, 2, 1, 2, 8, 8>(c, in, B, H, W, out, st, trace);   // 4-wave workgroups, 64 tiles, two per CU
             return run_wino<24, 24, 1, 4, 1, 2, 8, 16>(c, in, B, H, W, out, st, trace);                      // 8 waves, 128 tiles
         case 64 * 1000 + 64:     // waves hold both cout blocks of one tile block
             if (cfg == 2) return run_wino<64, 64, 2, 2, 2, 1, 8, 8>(c, in, B, H, W, out, st, trace);        // 8 waves, 64 tiles

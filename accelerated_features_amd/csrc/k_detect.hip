@@ -547,9 +547,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     const float d = fmaxf(sqrtf(n2), 1e-12f);
     const float4 o = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
     *dp = o;
-    if (dp16) {                       // bf16 (round-to-nearest-even) copy for the matcher's filter sweeps: saves its conversion pass
-        auto rne = [](float f) { unsigned u = __float_as_uint(f); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); };
-        *dp16 = make_ushort4(rne(o.x), rne(o.y), rne(o.z), rne(o.w));
+    if (dp16) {                       // fp16 copy of 256 * row (round-to-nearest-even) for the matcher's filter sweep: saves its conversion passes
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 q;
+        q[0] = (_Float16)(o.x * 256.f); q[1] = (_Float16)(o.y * 256.f); q[2] = (_Float16)(o.z * 256.f); q[3] = (_Float16)(o.w * 256.f);
+        *dp16 = __builtin_bit_cast(ushort4, q);
     }
 }
 
@@ -587,7 +589,9 @@ __global__ __launch_bounds__(256) void cand_to_xy_kernel(const unsigned* __restr
 void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int kernel_size, int cap, int64_t* xy,
                      int32_t* n_cand, hipStream_t st) {
     const int WPR = ceil_div(W, 64);
-    if (kernel_size == 5)
+    // the tiled 5x5 kernel loads 8-byte column pairs: even widths only (an odd W would read the pair at x = W-1 across the row end);
+    // every other window / width goes to the per-pixel kernel
+    if (kernel_size == 5 && (W & 1) == 0)
         nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
     else
         nms_flags_generic_kernel<<<(unsigned)(((size_t)B * H * WPR + 3) / 4), 256, 0, st>>>(heat, B, H, W, WPR, kernel_size / 2, thr, ws.mask, ws.wcount);

@@ -483,14 +483,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 long long* g_head_trace = nullptr;        // debug (xfh_debug_trace): stamps of head_bx_kernel<true>
 
-static bool heads_use_bx() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("XFH_HEADS"); v = e && !strcmp(e, "f32") ? 0 : 1; }
-    return v != 0;
-}
-
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st) {
-    if (heads_use_bx() && nw.head_bx[0]) {
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, bool f32_kernels) {
+    if (!f32_kernels && nw.head_bx[0]) {
         HeadBxArgs h{};
         h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
         h.H = H; h.W = W; h.hc = H / 8; h.wc = W / 8;
@@ -516,8 +510,8 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
     head_fused_kernel<true><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st) {
-    if (heads_use_bx() && nw.head_bx[1]) {
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, bool f32_kernels) {
+    if (!f32_kernels && nw.head_bx[1]) {
         HeadBxArgs h{};
         h.src = feats; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[1]); h.bias = nw.head_bx_bias[1]; h.out = reliab; h.inv = invnorm;
         h.w_last = nw.conv[L_HEAT_2].w_oihw; h.b_last = nw.head_rel_b_last;

@@ -1,5 +1,5 @@
 // Mutual-nearest-neighbour matching on the f32 matrix cores: the EXACT kernel.  xfh_match_mnn runs the filter-and-refine path of
-// k_match_bf16.hip and comes here for the pairs it cannot settle (candidate-list overflow) -- or for every pair under XFH_MATCH=f32;
+// k_match_f16.hip; this kernel is the every-pair reference it is tested against (xfh_set_option(h, "match_exact", 1));
 // the finalize kernel at the bottom is shared by both.
 //   XFeat.match        modules/xfeat.py:327-348     XFeat.batch_match  modules/xfeat.py:265-290
 //
@@ -13,7 +13,6 @@
 // partial array, no reduction pass).  A second small kernel applies the mutual test (+ optional
 // min_cossim) and compacts the surviving pairs in ascending row order, 1024 rows per workgroup.
 #include "kernels.hpp"
-#include <cstdlib>
 
 namespace xfh {
 
@@ -37,7 +36,7 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
                                                       size_t ps2, const int32_t* __restrict__ n1p,
                                                       const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1,
                                                       int N2, int nrb, int P, unsigned long long* __restrict__ rowkey,
-                                                      unsigned long long* __restrict__ colbest_g, const int* __restrict__ only_over, int over_cap) {
+                                                      unsigned long long* __restrict__ colbest_g) {
     __shared__ __attribute__((aligned(16))) float Dl[MT_COLS * MT_DS];
     __shared__ unsigned long long colbest[8][MT_COLS];
 
@@ -46,7 +45,6 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
     // all row blocks of a pair on one XCD: its D2 (1 MB at 4096 points) stays in that XCD's L2
     int p, rb;
     if (!xcd_group_map(blockIdx.x, nrb, P, p, rb)) return;
-    if (only_over && only_over[p] <= over_cap) return;       // this pair was settled by the filter-and-refine path
     const int n1 = pair_count(n1p, p * n_stride, N1);
     const int n2 = pair_count(n2p, p * n_stride + n_off2, N2);
     const int row0 = rb * MT_ROWS;
@@ -153,10 +151,11 @@ __global__ __launch_bounds__(512, 4) void mnn_sim_kernel(const float* __restrict
 // grid (P * chunks), block 1024: workgroup (p, q) owns rows [1024 q, 1024 q + 1024) of pair p.  The output position of
 // a kept row is the number of kept rows before it: the workgroup recounts the rows of the chunks in front of its own
 // (<= 3 cheap passes at N1 = 4096: two 4-byte loads and one 8-byte gather per row) instead of waiting for them.
-__device__ inline bool mutual_keep(const unsigned long long* __restrict__ rk, const unsigned long long* __restrict__ cb, int row,
+__device__ inline bool mutual_keep(const unsigned long long* __restrict__ rk, const unsigned long long* __restrict__ cb, int row, int n2,
                                    float min_cossim, int& m) {
     const unsigned long long key = rk[row];                                        // (ord(row max) << 32) | ~arg-max column
     m = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+    if (key == 0ull || (unsigned)m >= (unsigned)n2) { m = 0; return false; }       // no key was ever folded in (non-finite descriptors): no match, no out-of-range read
     const int back = (int)(0xffffffffu - (unsigned)(cb[m] & 0xffffffffu));        // arg-max row of column m
     return (back == row) && (min_cossim <= 0.f || ord_float((unsigned)(key >> 32)) > min_cossim);
 }
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(1024) void mnn_finalize_kernel(const int32_t* __res
     int cnt = 0;
     for (int row = tid; row < q * 1024; row += 1024) {
         int m;
-        cnt += mutual_keep(rk, cb, row, min_cossim, m) ? 1 : 0;
+        cnt += mutual_keep(rk, cb, row, n2, min_cossim, m) ? 1 : 0;
     }
     cnt = wave_sum_i(cnt);
     if (tid == 0) s_before = 0;
@@ -194,7 +193,7 @@ __global__ __launch_bounds__(1024) void mnn_finalize_kernel(const int32_t* __res
     // own chunk: ordered compaction
     const int row = q * 1024 + tid;
     int m = 0;
-    const bool keep = row < n1 && mutual_keep(rk, cb, row, min_cossim, m);
+    const bool keep = row < n1 && mutual_keep(rk, cb, row, n2, min_cossim, m);
     const unsigned long long bal = __ballot(keep);
     if (lane == 0) wsum[wave] = __popcll(bal);
     __syncthreads();
@@ -222,21 +221,17 @@ int match_debug_occupancy() {
 void prof_begin(Profiler* p, int which, hipStream_t st);
 void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
 
-void launch_match_bf16(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const uint16_t* d1_16, const uint16_t* d2_16,
-                       const int32_t* n1, const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st);
+void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const uint16_t* d1_16, const uint16_t* d2_16,
+                      const int32_t* n1, const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st);
 
 void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim, int64_t* idx0,
-                  int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof, const uint16_t* d1_16, const uint16_t* d2_16) {
+                  int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof, const uint16_t* d1_16, const uint16_t* d2_16, bool exact_only) {
     const int nrb = match_row_blocks(N1);
-    const char* mode = getenv("XFH_MATCH");
-    const bool exact_only = mode && mode[0] == 'f';            // XFH_MATCH=f32: the exact MFMA kernel for every pair (A/B runs)
-    (void)hipMemsetAsync(ws.zeroed, 0, ws.zeroed_bytes, st);   // keys / maxima / counters: 0 = below everything
+    (void)hipMemsetAsync(ws.zeroed, 0, ws.zeroed_bytes, st);   // keys / maxima: 0 = below everything
     prof_begin(prof, 2, st);
-    if (!exact_only) launch_match_bf16(ws, d1, ps1, d2, ps2, d1_16, d2_16, n1, n2, n_stride, n_off2, P, N1, N2, st);
-    // exact kernel: every pair (exact_only), or only the pairs whose candidate list overflowed (its workgroups exit at once otherwise)
-    mnn_sim_kernel<<<xcd_grid_size(nrb, P), 512, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.rowkey, ws.colkey,
-                                                 exact_only ? nullptr : ws.cnt, ws.cand_cap);
+    if (!exact_only) launch_match_f16(ws, d1, ps1, d2, ps2, d1_16, d2_16, n1, n2, n_stride, n_off2, P, N1, N2, st);
+    else mnn_sim_kernel<<<xcd_grid_size(nrb, P), 512, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.rowkey, ws.colkey);
     prof_end(prof, 2, st, 2.0 * P * (double)N1 * N2 * 64, (double)P * (N1 + N2) * 64 * 4);
     const int chunks = ceil_div(N1, 1024);
     mnn_finalize_kernel<<<P * chunks, 1024, 0, st>>>(n1, n2, n_stride, n_off2, N1, N2, chunks, ws.rowkey, ws.colkey,

@@ -43,6 +43,17 @@ struct NetWeights {
 
 struct Profiler;   // api.hip
 
+// Per-handle variant switches (xfh_set_option): which of several equivalent kernels a call uses.  They exist for A/B measurements and for the
+// parity tests that pin one variant against another; the defaults are the shipped path.  No process-wide state: a handle carries its own copy.
+struct Options {
+    int match_exact = 0;    // 1: xfh_match_mnn runs the exact f32-MFMA kernel for every pair (no filter)
+    int wino = 2;           // 0: 3x3/s1 layers never use Winograd; 1: only unfused layers; 2: fused 3x3 + 1x1 pairs too
+    int bx = 5;             // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0
+    int heads_f32 = 0;      // 1: heads on the f32-MFMA kernels
+    int block1 = 0;         // block1 variant: 0 = shipped, see launch_block1_fused
+    int pyramid_fused = 1;  // 1: x3 + up(x4) + up(x5) is formed inside block_fusion.0's tile staging (no pyramid_sum pass)
+};
+
 // ---- k_preproc.hip ----------------------------------------------------------------------
 // gray = channel mean (raw), coef[b] = {alpha, beta} of the instance norm x = fmaf(gray, alpha, beta)
 void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, float* coef, hipStream_t st);
@@ -58,7 +69,7 @@ void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float
 // ---- k_conv_direct.hip ------------------------------------------------------------------
 void launch_block1(const NetWeights& nw, const float* gray, int B, int H, int W, float* t0, float* t1, float* t2,
                    float* x1, hipStream_t st);
-void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st);
+void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant = 0);
 int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B, int Hin, int Win, float* out,
                         hipStream_t st);
 void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, hipStream_t st);
@@ -109,9 +120,9 @@ void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat
 // ---- k_heads.hip -------------------------------------------------------------------------
 // fused heads (persistent, weights LDS-resident): key-point head -> heat (+ optional logits (M,65)),
 // reliability head -> sigmoid map
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st);
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, bool f32_kernels = false);
 // invnorm (optional): 1 / max(||feats[cell,:]||, 1e-12) per cell, a by-product of the layer-1 operand loads
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st);
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, bool f32_kernels = false);
 
 // ---- k_detect.hip -----------------------------------------------------------------------
 struct DetectWs {          // carved from the caller's workspace by api.hip
@@ -140,23 +151,22 @@ void launch_dense_gather(const float* feats, const unsigned long long* skeys, in
 
 // ---- k_match.hip ------------------------------------------------------------------------
 struct MatchWs {
-    // zero-initialised per call (one memset): [rowkey | colkey | colmaxh | nmax | cnt]
+    // zero-initialised per call (one memset): [rowkey | colkey | colmaxh | nmax]
     void* zeroed; size_t zeroed_bytes;
-    unsigned long long* rowkey;    // (P,N1) packed (ord(sim)<<32 | ~col): row arg-max
-    unsigned long long* colkey;    // (P,N2) packed (ord(sim)<<32 | ~row): column arg-max, folded by 64-bit atomic max
-    unsigned* colmaxh;             // (P,N2) ord(column maximum of the bf16 product)
+    unsigned long long* rowkey;    // (P,N1) packed (ord(sim)<<32 | ~col): row arg-max, folded by 64-bit atomic max
+    unsigned long long* colkey;    // (P,N2) packed (ord(sim)<<32 | ~row): column arg-max
+    unsigned* colmaxh;             // (P,N2) ord(column maximum of the fp16 product)
     unsigned* nmax;                // (2,P)  bit patterns of max |d1_i|, max |d2_j|
-    int* cnt;                      // (P)    candidates found (may exceed cand_cap: overflow)
-    // filter-and-refine scratch
-    unsigned short *a16, *b16;     // (P,N1,64), (P,N2,64) bf16 copies
+    // filter-and-refine scratch (k_match_f16.hip)
+    _Float16 *a16, *b16;           // (P,N1,64), (P,N2,64) scaled fp16 copies
     float *na, *nb;                // (P,N1), (P,N2) fp32 norms
-    float* rowmaxh;                // (P,N1) row maximum of the bf16 product
-    unsigned long long* cand;      // (P,cand_cap) (row << 32 | col)
-    int cand_cap;
+    float* thr_row;                // (P,N1) row maximum of the fp16 product - 2 E
+    float *R, *C;                  // (P,ceil(N2/32),N1) / (P,ceil(N1/32),N2) block maxima of the fp16 product
 };
 void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim,
-                  int64_t* idx0, int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof, const uint16_t* d1_16 = nullptr, const uint16_t* d2_16 = nullptr);
+                  int64_t* idx0, int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof, const uint16_t* d1_16 = nullptr, const uint16_t* d2_16 = nullptr,
+                  bool exact_only = false);
 int match_row_blocks(int N1);
 int match_debug_occupancy();
 

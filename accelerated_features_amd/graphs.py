@@ -57,7 +57,7 @@ class CapturedSparsePipeline:
         self._epoch = self.xf.net._ws_epoch
 
     def _body(self):
-        kp, sc, de, nv, nc, cap, hw, d16 = self.xf._detect_device(self.x, self.top_k, self.thr, want_bf16=self.match)[:8] if self.match else \
+        kp, sc, de, nv, nc, cap, hw, d16 = self.xf._detect_device(self.x, self.top_k, self.thr, want_f16=self.match)[:8] if self.match else \
             self.xf._detect_device(self.x, self.top_k, self.thr) + (None,)
         self.kpts, self.scores, self.desc, self.n_valid, self.n_cand, self.cap = kp, sc, de, nv, nc, cap
         if self.match:

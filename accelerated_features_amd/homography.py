@@ -112,6 +112,7 @@ class ReferenceTracker:
         """frames (B,C,H,W) (or (B,H,W,C) uint8 like the demo's camera frames): cache their key-points and descriptors."""
         kp, sc, de, nv, nc, cap, hw = self.xfeat._detect_device(self.xfeat.parse_input(frames), self.top_k)
         self.ref = (kp, de, nv.clone())
+        self.ref_overflow = (nc, cap)          # device counts: see `overflowed`
 
     def track(self, frames):
         """One step for the B current frames.  Returns CUDA tensors: 'H' (B,3,3) float64, 'valid' (B,) bool (inliers >= min_inliers),
@@ -125,8 +126,16 @@ class ReferenceTracker:
             raise RuntimeError('the current frames must have the batch size of the reference frames')
         idx0, idx1, n = self.xfeat.match_sets_device(de0, nv0, de1, nv1, self.min_cossim)
         r = find_homography_matches(kp0, kp1, idx0, idx1, n, self.ransac_thr, self.max_iters, self.confidence, self.seed)
-        r.update(valid=(r['info'][:, 0] > 0) & (r['info'][:, 3] >= self.min_inliers), idx0=idx0, idx1=idx1, n_matches=n, keypoints=kp1)
+        r.update(valid=(r['info'][:, 0] > 0) & (r['info'][:, 3] >= self.min_inliers), idx0=idx0, idx1=idx1, n_matches=n, keypoints=kp1,
+                 n_candidates=nc, nms_capacity=cap)
         return r
+
+    @staticmethod
+    def overflowed(n_candidates, nms_capacity):
+        """True if an image of the batch had more NMS candidates than the fixed capacity (plateau images): its candidate list was cut in
+        row-major order, unlike detectAndCompute, which re-runs with room.  One read-back; check it when exactness on such images matters
+        (``track()`` returns both values, ``set_reference`` leaves them in ``ref_overflow``)."""
+        return bool((n_candidates > nms_capacity).any().item())
 
 
 def find_homography(srcPoints, dstPoints, method=USAC_MAGSAC, ransacReprojThreshold=3.0, mask=None, maxIters=2000, confidence=0.995, *,

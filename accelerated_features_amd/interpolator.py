@@ -21,8 +21,7 @@ class InterpolateSparse2d(nn.Module):
         super().__init__()
         if mode not in _lib.SAMPLE_MODES:
             raise ValueError(f"mode must be one of {sorted(_lib.SAMPLE_MODES)}")
-        if align_corners:
-            raise _lib.XFeatHipError("InterpolateSparse2d: align_corners=True is not implemented (the reference never uses it)")
+        # like the reference (interpolator.py:11-14,32): the flag is stored and IGNORED -- forward() always samples with align_corners=False
         self.mode = mode
         self.align_corners = align_corners
 

@@ -117,6 +117,7 @@ class XFeatModel(nn.Module):
         self.fine_matcher._owner = lambda: me          # not a registered submodule cycle
         self._handle = None
         self._handle_device = None
+        self._options = {}
         self._ws = {}
         self._ws_epoch = 0
 
@@ -180,7 +181,20 @@ class XFeatModel(nn.Module):
         h = C.c_void_p()
         _lib.check(lib.xfh_create(ptrs, n, dev, C.byref(h)), "xfh_create")
         self._handle, self._handle_device = h, dev
+        for k, v in self._options.items():
+            _lib.check(lib.xfh_set_option(h, k.encode(), int(v)), f"xfh_set_option({k})")
         return h
+
+    def set_option(self, key, value):
+        """Kernel-variant switch of this model's handle (include/xfeat_hip.h: xfh_set_option) -- A/B runs and variant-vs-variant tests.
+        Remembered across handle re-creation (load_state_dict, device change).  value None restores the default."""
+        if value is None:
+            if self._options.pop(key, None) is not None:
+                self._drop_handle()                    # a fresh handle starts from the defaults
+            return
+        self._options[key] = int(value)
+        if self._handle is not None:
+            _lib.check(_lib.load().xfh_set_option(self._handle, key.encode(), int(value)), f"xfh_set_option({key})")
 
     def workspace(self, name, nbytes):
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -310,6 +324,10 @@ class XFeat(nn.Module):
         except Exception:
             pass
 
+    def set_option(self, key, value):
+        """Kernel-variant switch (xfh_set_option; see XFeatModel.set_option)."""
+        self.net.set_option(key, value)
+
     # ------------------------------------------------------------------------------------------
     # sparse
     # ------------------------------------------------------------------------------------------
@@ -339,10 +357,10 @@ class XFeat(nn.Module):
         return [{'keypoints': kpts[b, :nv[b]], 'scores': scores[b, :nv[b]], 'descriptors': desc[b, :nv[b]]}
                 for b in range(len(nv))]
 
-    def _detect_device(self, x, top_k=None, detection_threshold=None, cap=None, want_bf16=False, counts_out=None):
+    def _detect_device(self, x, top_k=None, detection_threshold=None, cap=None, want_f16=False, counts_out=None):
         """Fixed-capacity device results, no read-back: kpts (B,top_k,2), scores (B,top_k),
         desc (B,top_k,64), n_valid (B) int32, n_cand (B) int32, the NMS capacity used, H*W
-        (+ with want_bf16 an eighth element: the descriptors rounded to bf16, (B,top_k,64) int16, for match_pairs_device).
+        (+ with want_f16 an eighth element: 256 * descriptors rounded to fp16, (B,top_k,64) float16, for match_pairs_device).
         If n_cand.max() > capacity the candidate list was truncated (caller re-runs).
         n_valid / n_cand are the two rows of ONE (2,B) tensor (counts_out if given: a caller that also matches can keep all its counts
         in one buffer and read them back with one copy, without a concatenation kernel)."""
@@ -353,12 +371,12 @@ class XFeat(nn.Module):
         feats, _, heat, rel, inv = self.net.backbone(x, want_logits=False, want_heat=True, want_invnorm=True)
         if cap is None:
             cap = min(H * W, max(int(top_k), (H * W) // 8))
-        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1, inv, want_bf16, counts_out)
-        if want_bf16:
+        out = self._detect_call(feats, heat, rel, B, H, W, detection_threshold, int(top_k), cap, rw1, rh1, inv, want_f16, counts_out)
+        if want_f16:
             return out[0], out[1], out[2], out[3], out[4], cap, H * W, out[5]
         return out[0], out[1], out[2], out[3], out[4], cap, H * W
 
-    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh, inv=None, want_bf16=False, counts_out=None):
+    def _detect_call(self, feats, heat, rel, B, H, W, thr, top_k, cap, rw, rh, inv=None, want_f16=False, counts_out=None):
         lib = _lib.load()
         dev = feats.device
         kpts = torch.empty((B, top_k, 2), dtype=torch.float32, device=dev)
@@ -367,7 +385,7 @@ class XFeat(nn.Module):
         cnt = counts_out if counts_out is not None else torch.empty((2, B), dtype=torch.int32, device=dev)
         assert cnt.shape == (2, B) and cnt.dtype == torch.int32 and cnt[0].is_contiguous() and cnt[1].is_contiguous()
         n_valid, n_cand = cnt[0], cnt[1]
-        d16 = torch.empty((B, top_k, 64), dtype=torch.int16, device=dev) if want_bf16 else None
+        d16 = torch.empty((B, top_k, 64), dtype=torch.float16, device=dev) if want_f16 else None
         ws, n = self.net.workspace("detect", lib.xfh_detect_workspace_bytes(B, H, W, top_k, cap))
         _lib.check(lib.xfh_detect_sparse(self.net.handle(), _ptr(heat), _ptr(rel), _ptr(feats), _ptr(inv), B, H, W, float(thr), top_k, cap,
                                          float(rw), float(rh), _ptr(kpts), _ptr(scores), _ptr(desc), _ptr(d16), _ptr(n_valid),
@@ -569,10 +587,10 @@ class XFeat(nn.Module):
                    "xfh_match_mnn")
         return idx0, idx1, n
 
-    def match_pairs_device(self, desc, n_valid, min_cossim=-1, desc_bf16=None, n_out=None):
+    def match_pairs_device(self, desc, n_valid, min_cossim=-1, desc_f16=None, n_out=None):
         """Match consecutive frames (2i, 2i+1) of one detection batch without any read-back.
-        desc (B,top_k,64), n_valid (B) int32 as returned by _detect_device; B even.  desc_bf16: the bf16 copy the same
-        _detect_device(want_bf16=True) call returned (saves the matcher's conversion pass; results identical).
+        desc (B,top_k,64), n_valid (B) int32 as returned by _detect_device; B even.  desc_f16: the fp16 copy the same
+        _detect_device(want_f16=True) call returned (saves the matcher's conversion passes; results identical).
         Returns idx0, idx1 (B/2, top_k) int64 and n_matches (B/2) int32 (n_out if given), all on the device."""
         self._require_gpu()
         lib = _lib.load()
@@ -586,9 +604,9 @@ class XFeat(nn.Module):
         ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, K, K))
         d2 = desc[1]
         b1 = b2 = None
-        if desc_bf16 is not None:
-            assert desc_bf16.shape == desc.shape and desc_bf16.dtype == torch.int16 and desc_bf16.is_contiguous()
-            b1, b2 = desc_bf16, desc_bf16[1]
+        if desc_f16 is not None:
+            assert desc_f16.shape == desc.shape and desc_f16.dtype == torch.float16 and desc_f16.is_contiguous()
+            b1, b2 = desc_f16, desc_f16[1]
         _lib.check(lib.xfh_match_mnn(self.net.handle(), _ptr(desc), 2 * K * 64, _ptr(d2), 2 * K * 64, _ptr(b1), _ptr(b2), _ptr(n_valid), _ptr(n_valid),
                                      2, 1, P, K, K, float(min_cossim), _ptr(idx0), _ptr(idx1), _ptr(n), _ptr(ws), nb,
                                      _stream()), "xfh_match_mnn")

@@ -438,7 +438,7 @@ def main():
     def step():
         # (the descriptor kernel also emits the bf16 copy the matcher's filter sweeps read: no separate conversion pass; all counts
         # land in one buffer: one read-back, no concatenation kernel)
-        kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x, TOP_K, 0.05, want_bf16=True, counts_out=cnt_dev[:2])
+        kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x, TOP_K, 0.05, want_f16=True, counts_out=cnt_dev[:2])
         i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16, n_out=cnt_dev[2, :B // 2])
         c = cnt_dev.cpu()                                  # the one read-back (ragged results)
         return torch.cat([c[0], c[1], c[2, :B // 2]]), cap
@@ -490,7 +490,7 @@ def main():
         def with_h2d(src):
             def f():
                 xd = src.cuda(non_blocking=True)
-                kp, sc, de, nv, nc, cap_, hw, d16 = xf._detect_device(xd, TOP_K, 0.05, want_bf16=True)
+                kp, sc, de, nv, nc, cap_, hw, d16 = xf._detect_device(xd, TOP_K, 0.05, want_f16=True)
                 i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16)
                 return torch.cat([nv, nc, nm]).cpu()
             return f
@@ -516,7 +516,7 @@ def main():
             for i in range(n):
                 upload(i + 1)
                 main.wait_event(ready[i % 2])
-                kp, sc, de, nv, nc, cap_, hw, d16 = xf._detect_device(dev[i % 2], TOP_K, 0.05, want_bf16=True)
+                kp, sc, de, nv, nc, cap_, hw, d16 = xf._detect_device(dev[i % 2], TOP_K, 0.05, want_f16=True)
                 i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16)
                 free[i % 2].record(main)
                 torch.cat([nv, nc, nm]).cpu()

@@ -15,9 +15,9 @@
  *     xfh_*_workspace_bytes() bytes (256-byte aligned).  Only xfh_create allocates (weights).
  *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream).  No hidden synchronisation.  Process-wide state is limited to: the
- *     thread-local error string; the XFH_* environment switches (A/B runs; each read once, at the
- *     first call that consults it); per-device "kernel attribute set" flags (idempotent);
- *     the debugging hooks xfh_debug_trace / xfh_profile_select (not for concurrent use).
+ *     thread-local error string and per-device "kernel attribute set" flags (idempotent).  The library reads
+ *     no environment variables; kernel-variant switches are per handle (xfh_set_option), and so are the
+ *     debugging hooks xfh_debug_trace / xfh_profile_select (not for concurrent use on one handle).
  *   - Return value: XFH_OK (0) or a negative XFH_ERR_* code; xfh_last_error() gives a
  *     message for the calling thread.  No C++ exception crosses the boundary.
  *   - A handle's weights are immutable after xfh_create and it may be shared by threads/streams,
@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define XFH_VERSION 100          /* major*10000 + minor*100 + patch */
+#define XFH_VERSION 101          /* major*10000 + minor*100 + patch */
 
 enum {
     XFH_OK = 0,
@@ -83,6 +83,21 @@ void xfh_destroy(xfh_handle h);
  * ---------------------------------------------------------------------------------------- */
 int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,
                         float scale_h, float scale_w, xfh_stream stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Kernel-variant switches of ONE handle (A/B measurements, variant-against-variant parity tests).  Results of every variant satisfy the
+ * same parity contract; the defaults are the shipped path.  Not for concurrent use with calls on the same handle.
+ *   "match_exact"   0 | 1   1: xfh_match_mnn computes every similarity on the f32 matrix cores (no fp16 filter)
+ *   "wino"          0..2    3x3/s1 layers: 0 never Winograd, 1 unfused layers only, 2 (default) also the 3x3 + 1x1 pairs
+ *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
+ *                           8 not block3.0 (default 5)
+ *   "heads_f32"     0 | 1   1: both heads on the f32-MFMA kernels
+ *   "block1"        0..     block1 kernel variant (0 = shipped)
+ *   "pyramid_fused" 0 | 1   0: x3 + up(x4) + up(x5) as its own pass before block_fusion.0 (default 1: formed in that layer's tile staging)
+ * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.
+ * ---------------------------------------------------------------------------------------- */
+int xfh_set_option(xfh_handle h, const char* key, int value);
+int xfh_get_option(xfh_handle h, const char* key, int* value);
 
 /* ------------------------------------------------------------------------------------------
  * Backbone.  Replaces XFeatModel.forward (modules/model.py:123-154) plus
@@ -145,14 +160,14 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
  *   rw, rh           original/processed size ratios (key-points are returned multiplied by them)
  * outputs (fixed capacity, entries past n_valid[b] are zero-filled):
  *   kpts (B,top_k,2) fp32 (x,y) ; scores (B,top_k) descending ; desc (B,top_k,64) unit norm
- *   desc_bf16 (B,top_k,64) optional (may be NULL): the same descriptors rounded to bf16 (nearest-even), for xfh_match_mnn's filter sweeps
+ *   desc_f16 (B,top_k,64) optional (may be NULL): fp16 (round-to-nearest-even) of 256 * desc, the operand of xfh_match_mnn's filter sweep
  *   n_valid (B) int32       = number of returned points with score > 0 (they form a prefix)
  *   n_candidates (B) int32  = NMS candidates found (uncapped)
  * ---------------------------------------------------------------------------------------- */
 size_t xfh_detect_workspace_bytes(int B, int H, int W, int top_k, int nms_capacity);
 int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, const float* feats, const float* invnorm,
                       int B, int H, int W, float threshold, int top_k, int nms_capacity, float rw, float rh,
-                      float* kpts, float* scores, float* desc, uint16_t* desc_bf16, int32_t* n_valid, int32_t* n_candidates,
+                      float* kpts, float* scores, float* desc, uint16_t* desc_f16, int32_t* n_valid, int32_t* n_candidates,
                       void* workspace, size_t workspace_bytes, xfh_stream stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -175,9 +190,11 @@ int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int
  *   n1/n2: DEVICE int32 arrays; pair p uses n1[p*n_stride] rows and n2[p*n_stride+n_offset2]
  *          rows (so the n_valid array of xfh_detect_sparse can be passed for consecutive
  *          frame pairs with n_stride=2, n_offset2=1).  NULL => all N1 / N2 rows.
- *   d1_bf16/d2_bf16: optional (both or neither): bf16 round-to-nearest-even copies of d1 / d2 with the same pair strides (in elements, multiples
- *          of 8), valid ONLY for L2-normalised rows (|row| <= 1.00001) -- what xfh_detect_sparse's desc_bf16 holds.  They spare the call its
- *          conversion pass; every decision is still taken on exact fp32 dot products of d1 / d2 (results identical with or without them).
+ *   d1_f16/d2_f16: optional (both or neither): fp16 round-to-nearest-even copies of 256 * d1 / 256 * d2 with the same pair strides (in elements,
+ *          multiples of 8), valid ONLY for L2-normalised rows (|row| <= 1.00001) -- what xfh_detect_sparse's desc_f16 holds.  They spare the call its
+ *          two conversion passes; every decision is still taken on exact fp32 dot products of d1 / d2 (results identical with or without them).
+ *   The fp16 product only selects which 32-wide blocks of a row / column can hold its arg-max (window derived in k_match_f16.hip); the arg-max
+ *   itself, ties included, comes from fp32 dot products of d1 / d2 in a fixed summation order.
  *   min_cossim <= 0 disables the similarity test (reference: `if min_cossim > 0`).
  *   pair_stride1/2 are in floats.
  * outputs: idx0, idx1 (P,N1) int64 (idx0 ascending), n_matches (P) int32.
@@ -185,7 +202,7 @@ int xfh_extract_dense(xfh_handle h, const float* reliab, const float* feats, int
  * ---------------------------------------------------------------------------------------- */
 size_t xfh_match_workspace_bytes(int P, int N1, int N2);
 int xfh_match_mnn(xfh_handle h /* may be NULL */, const float* d1, size_t pair_stride1, const float* d2, size_t pair_stride2,
-                  const uint16_t* d1_bf16, const uint16_t* d2_bf16,
+                  const uint16_t* d1_f16, const uint16_t* d2_f16,
                   const int32_t* n1, const int32_t* n2, int n_stride, int n_offset2,
                   int P, int N1, int N2, float min_cossim,
                   int64_t* idx0, int64_t* idx1, int32_t* n_matches,

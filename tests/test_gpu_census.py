@@ -93,8 +93,9 @@ def test_config1_census_of_the_bench_batch_vs_oracle(xf, sd):
     _threads()
     import bench
     x = bench.make_frames(64, seed=1000)
-    kp, sc, de, nv, nc, cap, hw = xf._detect_device(x.cuda(), 4096, 0.05)
-    i0, i1, nm = xf.match_pairs_device(de, nv, -1)
+    cnt_dev = torch.empty((3, 64), dtype=torch.int32, device="cuda")          # bench.py's one read-back buffer
+    kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x.cuda(), 4096, 0.05, want_f16=True, counts_out=cnt_dev[:2])
+    i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16, n_out=cnt_dev[2, :32])
     assert int(nc.max()) <= cap
     nvl, nml = nv.cpu().tolist(), nm.cpu().tolist()
     kp, sc, de, i0, i1 = kp.cpu(), sc.cpu(), de.cpu(), i0.cpu(), i1.cpu()

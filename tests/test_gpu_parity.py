@@ -126,51 +126,40 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
 
 
-@pytest.mark.parametrize("env", [{"XFH_HEADS": "f32", "XFH_BX": "0", "XFH_BLOCK1_C1": "1"}, {"XFH_BX": "3", "XFH_BLOCK1_C1": "4"}])
-def test_backbone_alternative_kernels_same_results(env):
-    """The A/B switches select other kernels for the same layers (heads on f32 MFMAs, 24->24 layers on Winograd; every unfused 64->64 layer on the
-    split-bf16 kernel): the switches are read once per process, so each setting runs the small golden backbone case in its own process."""
-    import subprocess
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))\n"
-        "import fixtures\n"
-        "from accelerated_features_amd import XFeat\n"
-        "g = np.load(os.path.join(%r, 'g1_small.npz'))\n"
-        "xf = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=4096)\n"
-        "x = fixtures.texture_images(2, 96, 128, seed=11)\n"
-        "feats, logits, rel = xf.net(x.cuda())\n"
-        "heat = xf.get_kpts_heatmap(logits)\n"
-        "e = [float(np.abs(feats.cpu().numpy() - g['feats']).max()), float(np.abs(logits.cpu().numpy() - g['logits']).max()),\n"
-        "     float(np.abs(rel.cpu().numpy() - g['reliability']).max()), float(np.abs(heat.cpu().numpy() - g['heat']).max())]\n"
-        "print('ERRS', *e)\n"
-        "assert e[0] <= 1e-4 and e[1] <= 5e-4 and e[2] <= 1e-5 and e[3] <= 1e-5, e\n" % G
-    )
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, (env, r.stdout[-400:], r.stderr[-1500:])
-    assert "ERRS" in r.stdout
+@pytest.mark.parametrize("opts", [{"heads_f32": 1, "bx": 0, "block1": 1}, {"bx": 3, "block1": 4}, {"wino": 0, "pyramid_fused": 0}, {"block1": 0, "pyramid_fused": 1}])
+def test_backbone_alternative_kernels_same_results(opts, sd):
+    """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on f32 MFMAs, 24->24 layers on Winograd; every
+    unfused 64->64 layer on the split-bf16 kernel; direct implicit GEMM instead of Winograd; the pyramid sum as its own pass): the small golden
+    backbone case on a model of its own with each setting."""
+    from accelerated_features_amd import XFeat
+    g = np.load(os.path.join(G, "g1_small.npz"))
+    xf2 = XFeat(weights=sd, top_k=4096)
+    for k, v in opts.items():
+        xf2.set_option(k, v)
+    x = fixtures.texture_images(2, 96, 128, seed=11)
+    feats, logits, rel = xf2.net(x.cuda())
+    heat = xf2.get_kpts_heatmap(logits)
+    e = [float(np.abs(feats.cpu().numpy() - g["feats"]).max()), float(np.abs(logits.cpu().numpy() - g["logits"]).max()),
+         float(np.abs(rel.cpu().numpy() - g["reliability"]).max()), float(np.abs(heat.cpu().numpy() - g["heat"]).max())]
+    print("ERRS", opts, e)
+    assert e[0] <= 1e-4 and e[1] <= 5e-4 and e[2] <= 1e-5 and e[3] <= 1e-5, (opts, e)
+    with pytest.raises(Exception):
+        xf2.set_option("no_such_option", 1)
+    with pytest.raises(Exception):
+        xf2.set_option("wino", 7)
 
 
-def test_split_bf16_backbone_equals_f32_mfma_backbone_at_bench_shape(xf, tmp_path):
+def test_split_bf16_backbone_equals_f32_mfma_backbone_at_bench_shape(xf, sd):
     """At the benchmark shape (B=64 VGA) the default path runs the 24-channel layers, the three 64 -> 64 layers at 1/8 scale (two of them with
     their trailing 1x1 fused, one writing channels-last) and both heads on split-bf16 MFMAs.  Same network outputs as with every one of
-    them on the f32-MFMA kernels (XFH_BX=0, XFH_HEADS=f32: read once per process, so that side runs in its own process)."""
-    import subprocess
-    ref_path = str(tmp_path / "ref.npz")
-    code = (
-        "import os, sys, numpy as np, torch\n"
-        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))\n"
-        "import fixtures\n"
-        "from accelerated_features_amd import XFeat\n"
-        "xf = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=4096)\n"
-        "x = torch.cat([fixtures.texture_images(8, 480, 640, seed=s) for s in range(8)]).cuda()\n"
-        "feats, logits, rel = xf.net(x)\n"
-        f"np.savez({ref_path!r}, feats=feats[::8].cpu().numpy(), logits=logits[::8].cpu().numpy(), rel=rel.cpu().numpy())\n"
-    )
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "XFH_BX": "0", "XFH_HEADS": "f32"}, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-400:], r.stderr[-1500:])
-    ref = np.load(ref_path)
+    them on the f32-MFMA kernels (a second model with bx = 0, heads_f32 = 1, the pyramid sum as its own pass)."""
+    from accelerated_features_amd import XFeat
+    xr = XFeat(weights=sd, top_k=4096)
+    xr.set_option("bx", 0); xr.set_option("heads_f32", 1); xr.set_option("pyramid_fused", 0)
     x = torch.cat([fixtures.texture_images(8, 480, 640, seed=s) for s in range(8)]).cuda()
+    f_, l_, r_ = xr.net(x)
+    ref = {"feats": f_[::8].cpu().numpy(), "logits": l_[::8].cpu().numpy(), "rel": r_.cpu().numpy()}
+    del xr, f_, l_, r_
     feats, logits, rel = xf.net(x)
     e = {"feats": float(np.abs(feats[::8].cpu().numpy() - ref["feats"]).max()), "logits": float(np.abs(logits[::8].cpu().numpy() - ref["logits"]).max()),
          "rel": float(np.abs(rel.cpu().numpy() - ref["rel"]).max())}
@@ -771,6 +760,15 @@ def test_nms_any_odd_kernel_size(xf, sd):
         assert got.shape == ref.shape and torch.equal(got, ref), ks
     with pytest.raises(RuntimeError):
         xf.NMS(heat.cuda(), kernel_size=4)
+    # odd widths (the tiled 5x5 kernel loads column pairs and must not see them), incl. maxima on the last column / row
+    for Hh, Ww in ((33, 67), (40, 129), (17, 63)):
+        g = torch.Generator().manual_seed(Hh * Ww)
+        hm = torch.rand(2, 1, Hh, Ww, generator=g)
+        hm[0, 0, 5, Ww - 1] = 2.0; hm[1, 0, Hh - 1, Ww - 1] = 3.0; hm[1, 0, 0, 0] = 2.5
+        for ks in (3, 5):
+            ref = O.pad_keypoints(O.nms(hm, 0.5, ks))
+            got = xf.NMS(hm.cuda(), threshold=0.5, kernel_size=ks).cpu()
+            assert got.shape == ref.shape and torch.equal(got, ref), (Hh, Ww, ks)
 
 
 def test_state_dict_reload_and_cpu_inputs(xf, sd):
@@ -819,20 +817,19 @@ def test_hipgraph_survives_workspace_growth_and_weight_reload_of_the_user_model(
 
 
 def test_match_filter_and_refine_equals_exact_kernel(xf):
-    """xfh_match_mnn's shipped path (bf16 MFMA filter with a rigorous error window + exact fp32 refine, k_match_bf16.hip) against the
-    exact f32 MFMA kernel (XFH_MATCH=f32) on identical inputs: identical index lists -- unit descriptors, raw dense features of
-    magnitude ~10, ragged sizes, exact duplicate rows / columns (ties -> lowest index), a similarity cut, and degenerate inputs
-    (all-equal / all-zero descriptors) that overflow the candidate list and take the in-kernel fallback."""
+    """xfh_match_mnn's shipped path (fp16 MFMA filter with a derived error window + exact fp32 refine of the flagged 32-wide blocks,
+    k_match_f16.hip) against the exact f32 MFMA kernel (option match_exact) on identical inputs: identical index lists -- unit descriptors,
+    raw dense features of magnitude ~10, ragged sizes, exact duplicate rows / columns (ties -> lowest index), a similarity cut, and
+    degenerate inputs (all-equal / all-zero descriptors: every block is flagged)."""
     g = torch.Generator().manual_seed(12)
 
     def both(d1, d2, mc):
-        os.environ.pop("XFH_MATCH", None)
         a = xf.match(d1.cuda(), d2.cuda(), min_cossim=mc)
-        os.environ["XFH_MATCH"] = "f32"
+        xf.set_option("match_exact", 1)
         try:
             b = xf.match(d1.cuda(), d2.cuda(), min_cossim=mc)
         finally:
-            os.environ.pop("XFH_MATCH", None)
+            xf.set_option("match_exact", 0)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (d1.shape, d2.shape, mc, len(a[0]), len(b[0]))
         return a
 
@@ -847,7 +844,7 @@ def test_match_filter_and_refine_equals_exact_kernel(xf):
             i0, _ = both(d1, d2, mc)
         assert len(i0) >= m // 4 or n1 < 50
         both(d1 * 11.0, d2 * 7.0 + 0.3, -1)                                   # raw (un-normalised, shifted) features
-    # degenerate: every descriptor identical -> all n2 columns tie in every row (candidate overflow -> exact kernel inside the call)
+    # degenerate: every descriptor identical -> all n2 columns tie in every row (every block flagged, still exact)
     same = torch.nn.functional.normalize(torch.ones(600, 64), dim=-1)
     i0, i1 = both(same, same.clone(), -1)
     assert i0.tolist() == [0] and i1.tolist() == [0]
@@ -904,13 +901,13 @@ def test_sizes_beyond_the_round1_limits(xf, sd):
         assert torch.equal(i0.cpu(), o0) and torch.equal(i1.cpu(), o1)
 
 
-def test_match_with_bf16_copies_from_the_descriptor_kernel(xf):
-    """xfh_detect_sparse's optional desc_bf16 output handed to xfh_match_mnn (no conversion pass inside the matcher): bit pattern = RNE of the
-    fp32 descriptors, match lists identical to the plain call."""
+def test_match_with_f16_copies_from_the_descriptor_kernel(xf):
+    """xfh_detect_sparse's optional desc_f16 output handed to xfh_match_mnn (no conversion passes inside the matcher): bit pattern = fp16 RNE of
+    256 * the fp32 descriptors, match lists identical to the plain call."""
     x = fixtures.texture_images(4, 192, 256, seed=61).cuda()
-    kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x, 1024, 0.05, want_bf16=True)
-    ref16 = de.to(torch.bfloat16).view(torch.int16)
-    assert d16.dtype == torch.int16 and torch.equal(d16, ref16)
+    kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x, 1024, 0.05, want_f16=True)
+    ref16 = (de * 256.0).to(torch.float16)
+    assert d16.dtype == torch.float16 and torch.equal(d16.view(torch.int16), ref16.view(torch.int16))
     a = xf.match_pairs_device(de, nv, -1)
     b = xf.match_pairs_device(de, nv, -1, d16)
     c = xf.match_pairs_device(de, nv, 0.5, d16)
@@ -920,3 +917,44 @@ def test_match_with_bf16_copies_from_the_descriptor_kernel(xf):
         for p in range(2):
             n = int(u[2][p])
             assert n > 50 and torch.equal(u[0][p, :n], v[0][p, :n]) and torch.equal(u[1][p, :n], v[1][p, :n])
+
+
+def test_match_on_rounding_aligned_adversarial_sets(xf):
+    """The filter window against descriptor sets whose fp16 rounding errors are ALIGNED (tests/adversarial.py: components a hair below / above
+    rounding midpoints, the true best match losing 1.9u in the rounded product to a competitor in another 32-wide block -- half the window loses
+    every one of them, tests/test_match_filter_window.py).  Default path == exact f32-MFMA kernel == oracle, through xfh_match_mnn with its own
+    conversion passes and -- for the unit-norm sets -- with caller-provided fp16 copies (the bench path), both directions, with and without a cut."""
+    import adversarial as A
+    total = 0
+    for name, d1, d2, unit in A.sets():
+        t1, t2 = A.as_torch(d1), A.as_torch(d2)
+        o0, o1 = O.match_mnn(t1, t2, -1)
+        n_strict = A.check_mnn_fp64(d1, d2, o0.numpy(), o1.numpy())             # the oracle itself against float64 (tie allowance 2e-6)
+        for mc in (-1, 0.3):
+            a = xf.match(t1.cuda(), t2.cuda(), min_cossim=mc)
+            xf.set_option("match_exact", 1)
+            try:
+                b = xf.match(t1.cuda(), t2.cuda(), min_cossim=mc)
+            finally:
+                xf.set_option("match_exact", 0)
+            for got in (a, b):
+                A.check_mnn_fp64(d1, d2, got[0].cpu().numpy(), got[1].cpu().numpy(), mc)
+            if "all_equal" not in name:               # (all-equal rows: every pair is a tie, any consistent answer passes the check above)
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (name, mc, len(a[0]), len(b[0]))
+                if mc < 0:
+                    assert torch.equal(a[0].cpu(), o0) and torch.equal(a[1].cpu(), o1), (name, len(a[0]), len(o0))
+            total += len(a[0])
+        if unit:
+            # caller-provided copies: one pair (frames 0 and 1 of a "batch"), rows padded to a common capacity with device-side counts
+            K = max(len(d1), len(d2))
+            de = torch.zeros(2, K, 64); de[0, :len(d1)] = t1; de[1, :len(d2)] = t2
+            de = de.cuda()
+            nv = torch.tensor([len(d1), len(d2)], dtype=torch.int32, device="cuda")
+            d16 = (de * 256.0).to(torch.float16)
+            i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16)
+            n = int(nm[0])
+            A.check_mnn_fp64(d1, d2, i0[0, :n].cpu().numpy(), i1[0, :n].cpu().numpy())
+            if "all_equal" not in name:
+                assert n == len(o0) and torch.equal(i0[0, :n].cpu(), o0) and torch.equal(i1[0, :n].cpu(), o1), name
+        print(name, d1.shape, d2.shape, "strict mutual matches", n_strict, "reported", len(o0))
+    assert total > 1500

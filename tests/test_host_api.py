@@ -173,7 +173,7 @@ def test_no_valu_write_lands_in_a_freshly_read_bf16_mfma_operand():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     import glob
-    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_bf16\(", open(f).read())]
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_(bf16|f16)\(", open(f).read())]
     assert len(files) >= 4
     for f in files:
         nk, nm, bad = mod.audit(f)

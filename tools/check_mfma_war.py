@@ -37,7 +37,7 @@ def audit(src):
     n_kern, n_mfma, bad = 0, 0, []
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
         name, body = m.group(1), m.group(2)
-        if "_bf16" not in body or "v_mfma" not in body:
+        if not re.search(r"v_mfma_f32_\d+x\d+x\d+_(bf16|f16)", body):
             continue
         n_kern += 1
         recent, n = [], 0
@@ -46,7 +46,7 @@ def audit(src):
             if not t or not l.startswith("\t") or t[0].startswith((";", ".")):
                 continue
             args = [a.strip(",") for a in t[1:]]
-            if t[0].startswith("v_mfma") and "bf16" in t[0]:
+            if t[0].startswith("v_mfma") and ("bf16" in t[0] or t[0].endswith("_f16")):
                 recent = (recent + [(n, _regs(args[1]) | _regs(args[2]))])[-6:]
                 n_mfma += 1
                 n += 7
@@ -62,7 +62,7 @@ def audit(src):
 
 
 def main():
-    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_bf16\(", open(f).read())]
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_(bf16|f16)\(", open(f).read())]
     total = 0
     for f in files:
         nk, nm, bad = audit(f)
