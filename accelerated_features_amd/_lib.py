@@ -15,6 +15,7 @@ LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 LG_NO_PRUNING = 1 << 30
 SAMPLE_MODES = {'nearest': 0, 'bilinear': 1, 'bicubic': 2}
 PROF_NONE, PROF_CONV_MFMA, PROF_MATCH, PROF_BLOCK1, PROF_HEADS, PROF_CONV_64_64_S1, PROF_CONV_24_24, PROF_CONV_LAYER0 = 0, 1, 2, 3, 4, 5, 6, 100
+PROF_ALL = 1000
 
 # name -> (restype, argtypes); mirrors include/xfeat_hip.h one to one
 _p = C.c_void_p
@@ -64,6 +65,7 @@ SIGNATURES = {
     "xfh_debug_match_occupancy": (_i, []),
     "xfh_set_option": (_i, [_p, C.c_char_p, _i]),
     "xfh_get_option": (_i, [_p, C.c_char_p, C.POINTER(_i)]),
+    "xfh_profile_read_spans": (_i, [_p, C.POINTER(_i), C.POINTER(C.c_double), _i, C.POINTER(_i)]),
     "xfh_profile_read": (_i, [_p, C.POINTER(_i), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

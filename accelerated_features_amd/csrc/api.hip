@@ -93,11 +93,16 @@ extern long long* g_head_trace;        // k_heads.hip
 struct Profiler {
     int which = 0;
     std::vector<hipEvent_t> ev;   // pairs
+    std::vector<int> ids;         // span id of each pair (XFH_PROF_ALL)
     size_t used = 0;
     double flops = 0, bytes = 0;
 };
+// XFH_PROF_ALL records the leaf spans only (block1, one conv layer, the XFH_SPAN_* ids): the family ids bracket several of them and do not nest
+static inline bool prof_on(const Profiler* p, int which) {
+    return p && (p->which == which || (p->which == XFH_PROF_ALL && (which == XFH_PROF_BLOCK1 || which >= XFH_PROF_CONV_LAYER0)));
+}
 void prof_begin(Profiler* p, int which, hipStream_t st) {
-    if (!p || p->which != which) return;
+    if (!prof_on(p, which)) return;
     if (p->used + 2 > p->ev.size()) {
         hipEvent_t a, b;
         (void)hipEventCreate(&a);
@@ -105,10 +110,12 @@ void prof_begin(Profiler* p, int which, hipStream_t st) {
         p->ev.push_back(a);
         p->ev.push_back(b);
     }
+    if (p->ids.size() < p->ev.size() / 2) p->ids.resize(p->ev.size() / 2);
+    p->ids[p->used / 2] = which;
     (void)hipEventRecord(p->ev[p->used], st);
 }
 void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes) {
-    if (!p || p->which != which) return;
+    if (!prof_on(p, which)) return;
     (void)hipEventRecord(p->ev[p->used + 1], st);
     p->used += 2;
     p->flops += flops;
@@ -199,7 +206,7 @@ static size_t carve_match(void* ws, int P, int N1, int N2, MatchWs& o) {
     const size_t z0 = c.off;
     o.rowkey = c.take<unsigned long long>((size_t)P * N1);
     o.colkey = c.take<unsigned long long>((size_t)P * N2);
-    o.colmaxh = c.take<unsigned>((size_t)P * N2);
+    o.rowmaxh = c.take<unsigned>((size_t)P * N1);
     o.nmax = c.take<unsigned>((size_t)2 * P);
     o.zeroed = ws ? (char*)ws + z0 : nullptr;
     o.zeroed_bytes = c.off - z0;
@@ -208,6 +215,7 @@ static size_t carve_match(void* ws, int P, int N1, int N2, MatchWs& o) {
     o.na = c.take<float>((size_t)P * N1);
     o.nb = c.take<float>((size_t)P * N2);
     o.thr_row = c.take<float>((size_t)P * N1);
+    o.thr_col = c.take<float>((size_t)P * N2);
     o.R = c.take<float>((size_t)P * ceil_div(N2, 32) * N1);      // block maxima: 1/32 of the similarity matrix each
     o.C = c.take<float>((size_t)P * ceil_div(N1, 32) * N2);
     return align_up(c.off, 256);
@@ -538,7 +546,7 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     const int pad = c.ks / 2;
     const int Hout = (Hin + 2 * pad - c.ks) / c.stride + 1, Wout = (Win + 2 * pad - c.ks) / c.stride + 1;
     // which >= 100 selects one layer (100 + layer index), otherwise the whole family
-    int pid = h->prof.which >= 100 ? 100 + layer : XFH_PROF_CONV_MFMA;
+    int pid = h->prof.which >= 100 ? 100 + layer : XFH_PROF_CONV_MFMA;      // (XFH_PROF_ALL = 1000: one span per layer)
     if (h->prof.which == XFH_PROF_CONV_64_64_S1 && c.cin == 64 && c.cout == 64 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_64_64_S1;
     if (h->prof.which == XFH_PROF_CONV_24_24 && c.cin == 24 && c.cout == 24 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_24_24;
     prof_begin(&h->prof, pid, st);
@@ -582,12 +590,14 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     const NetWeights& nw = h->nw;
     const int H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
 
+    prof_begin(&h->prof, XFH_SPAN_GRAY, st);
     if (rs) {
         if (launch_gray_norm_resized(img, B, C, rs->Hin, rs->Win, rs->Hm, rs->Wm, rs->s1h, rs->s1w, H, W, rs->s2h, rs->s2w, w.part, w.gray,
                                      w.coef, st))
             return fail(XFH_ERR_UNSUPPORTED, "xfh_backbone_resized: second resize step (%g, %g) must be below 2", rs->s2h, rs->s2w);
     } else if (img_u8) launch_gray_norm_u8(img_u8, u8_layout == XFH_LAYOUT_NHWC, u8_divisor, B, C, H, W, w.part, w.gray, w.coef, st);
     else launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
+    prof_end(&h->prof, XFH_SPAN_GRAY, st, 0, 0);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
     launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st, h->opt.block1);
     // block1 + skip1 per input pixel: conv1 9*4*2 + conv2 36*8*2/4 + conv3 72*8*2/4 + conv4 72*24*2/16 = 720 FLOP; gray in, x1 out: 10 bytes
@@ -604,16 +614,20 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     CONV(L_BLOCK5_0, -1, w.x4c, H16, W16, w.x5a, false);
     CONV(L_BLOCK5_1, -1, w.x5a, H32, W32, w.x5b, false);
     CONV(L_BLOCK5_2, L_BLOCK5_3, w.x5b, H32, W32, w.x5d, false);      // 3x3 + fused 1x1 (128->64)
+    prof_begin(&h->prof, XFH_SPAN_PYRAMID, st);
     launch_pyramid_sum(w.x3c, w.x4c, w.x5d, w.pyr, B * 64, H8, W8, H16, W16, H32, W32, st);
+    prof_end(&h->prof, XFH_SPAN_PYRAMID, st, 0, 0);
     CONV(L_FUSION_0, -1, w.pyr, H8, W8, w.f0, false);
     CONV(L_FUSION_1, L_FUSION_2, w.f0, H8, W8, feats, true);          // 3x3 + fused 1x1 -> channels-last M1
 #undef CONV
 
     // fused heads: reliability from the channels-last features, key-point head from the gray image
-    prof_begin(&h->prof, XFH_PROF_HEADS, st);
+    const bool all = h->prof.which == XFH_PROF_ALL;      // one span per head instead of one for both
+    prof_begin(&h->prof, all ? XFH_SPAN_HEAD_REL : XFH_PROF_HEADS, st);
     launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32 != 0);
+    if (all) { prof_end(&h->prof, XFH_SPAN_HEAD_REL, st, 0, 0); prof_begin(&h->prof, XFH_SPAN_HEAD_KP, st); }
     launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32 != 0);
-    prof_end(&h->prof, XFH_PROF_HEADS, st, 0, 0);
+    prof_end(&h->prof, all ? XFH_SPAN_HEAD_KP : XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }
 
@@ -691,7 +705,7 @@ int xfh_detect_sparse(xfh_handle h, const float* heat, const float* reliab, cons
     const size_t need = carve_detect(workspace, B, H, W, top_k, nms_capacity, w);
     if ((rc = check_ws(workspace, workspace_bytes, need))) return rc;
     launch_detect(w, heat, reliab, feats, invnorm, B, H, W, threshold, top_k, nms_capacity, rw, rh, kpts, scores, desc, n_valid,
-                  n_candidates, (hipStream_t)stream, desc_f16);
+                  n_candidates, (hipStream_t)stream, desc_f16, &h->prof);
     return check_launch("xfh_detect_sparse");
 }
 
@@ -919,6 +933,22 @@ int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
 int xfh_profile_select(xfh_handle h, int which) {
     if (!h) return fail(XFH_ERR_ARG, "xfh_profile_select: NULL handle");
     h->prof.which = which;
+    h->prof.used = 0;
+    h->prof.flops = h->prof.bytes = 0;
+    return XFH_OK;
+}
+
+int xfh_profile_read_spans(xfh_handle h, int* ids, double* ms, int capacity, int* n_spans) {
+    if (!h || !n_spans) return fail(XFH_ERR_ARG, "xfh_profile_read_spans: NULL argument");
+    const int n = (int)(h->prof.used / 2);
+    for (int i = 0; i < n && i < capacity; ++i) {
+        HIP_TRY(hipEventSynchronize(h->prof.ev[2 * i + 1]));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, h->prof.ev[2 * i], h->prof.ev[2 * i + 1]));
+        if (ids) ids[i] = h->prof.ids[i];
+        if (ms) ms[i] = t;
+    }
+    *n_spans = n;
     h->prof.used = 0;
     h->prof.flops = h->prof.bytes = 0;
     return XFH_OK;

@@ -9,6 +9,7 @@
 // reference's operation order exactly (coordinate normalisation, fused un-normalise, round-
 // half-even for 'nearest').  Ragged per-image lists are kept at fixed capacity with device
 // counts; ordering uses wave ballots + block scans (row-major order is preserved).
+#include "../../include/xfeat_hip.h"
 #include "kernels.hpp"
 
 namespace xfh {
@@ -555,21 +556,35 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     }
 }
 
+void prof_begin(Profiler* p, int which, hipStream_t st);
+void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
+
 void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                    float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
-                   int32_t* n_valid, int32_t* n_cand, hipStream_t st, uint16_t* desc16) {
+                   int32_t* n_valid, int32_t* n_cand, hipStream_t st, uint16_t* desc16, Profiler* prof) {
     const int WPR = ceil_div(W, 64);
     const int hc = H / 8, wc = W / 8;
-    nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
+    prof_begin(prof, XFH_SPAN_NMS_FLAGS, st);
+    if ((W & 1) == 0)
+        nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
+    else        // (the tiled kernel loads 8-byte column pairs: even widths only)
+        nms_flags_generic_kernel<<<(unsigned)(((size_t)B * H * WPR + 3) / 4), 256, 0, st>>>(heat, B, H, W, WPR, 2, thr, ws.mask, ws.wcount);
+    prof_end(prof, XFH_SPAN_NMS_FLAGS, st, 0, 0);
+    prof_begin(prof, XFH_SPAN_NMS_COMPACT, st);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
+    prof_end(prof, XFH_SPAN_NMS_COMPACT, st, 0, 0);
     const ScoreSrc src{heat, reliab, ws.cand, H, W};
+    prof_begin(prof, XFH_SPAN_TOPK, st);
     run_topk(&src, nullptr, ws.keys, n_cand, 0, cap, top_k, B, ws.skeys, ws.nsel, n_valid, st);
+    prof_end(prof, XFH_SPAN_TOPK, st, 0, 0);
+    prof_begin(prof, XFH_SPAN_DESCRIPTOR, st);
     if (!invnorm) {           // not handed over by the backbone call: one pass over the feature maps
         invnorm_kernel<<<ceil_div(B * hc * wc * 16, 256), 256, 0, st>>>(feats, B * hc * wc, ws.invnorm);
         invnorm = ws.invnorm;
     }
     descriptor_kernel<<<xcd_grid_size(ceil_div(top_k, 16), B), 256, 0, st>>>(feats, invnorm, ws.cand, ws.skeys, ws.nsel, H, W,
                                                                             cap, top_k, B, ceil_div(top_k, 16), rw, rh, kpts, scores, n_valid, desc, desc16);
+    prof_end(prof, XFH_SPAN_DESCRIPTOR, st, 0, 0);
 }
 
 // stand-alone NMS (XFeat.NMS): flags + compaction + int64 (x,y) list, zero padded

@@ -10,8 +10,8 @@
 //             same register layout, so the transposed tile costs four more MFMAs and no loads -- which turns both reductions into
 //             in-lane v_max3 trees (8 ops for 16 values):
 //               C[rb][j] = max of S^ over the 32 rows of row block rb, column j       R[cb][i] = max over the 32 columns of block cb, row i
-//             plus the row maxima (running, one op per tile) and the column maxima (LDS across the waves, one atomic per column and
-//             workgroup).  8 MFMAs (256 pipe cycles) and ~28 VALU ops per tile: the matrix pipe is the bound.
+//             plus the column maxima (running in registers; the workgroup sees whole columns) and the row maxima (one 32-bit atomic
+//             per row and workgroup).  8 MFMAs (256 pipe cycles) and ~28 VALU ops per tile: the matrix pipe is the bound.
 //   refine    for every row i: the column blocks with R[cb][i] >= rowmax^_i - 2 E_i are the only ones that can hold the exact arg-max
 //             of row i (or an exact tie with it); all 32 of their fp32 dot products are computed (fixed summation order) and folded
 //             into the row key (ord(S) << 32 | ~j) with a 64-bit atomic max -- ties to the lowest index like torch.max.  Columns
@@ -34,16 +34,20 @@
 // flagged -- the same for every exact tie with j* and, with the roles swapped, for columns.  (Round 2 shipped a bf16 filter whose window
 // assumed u = 2^-9; bf16 RNE has u = 2^-8, so that window was a factor 2 short of a proof.  fp16 on unit-norm rows is 8x tighter than
 // bf16 and the window above is derived, and tested on rounding-aligned adversarial rows: tests/test_gpu_parity.py.)
+#include "../../include/xfeat_hip.h"
 #include "kernels.hpp"
 
 namespace xfh {
+
+void prof_begin(Profiler* p, int which, hipStream_t st);
+void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int FT_ROWS = 256;     // rows of D1 per workgroup (8 waves x 32)
-constexpr int FT_COLS = 128;     // columns of D2 per LDS fill
+
+constexpr int FT_COLS = 256;     // columns of D2 per LDS fill
 constexpr int FT_DS = 72;        // LDS row stride in fp16 elements (144 bytes): the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots
 constexpr float F16_C = 1.03f * 0.0009765625f;       // c = 1.03 * 2^-10
 constexpr float F16_KAPPA = 1.0e-5f;
@@ -139,6 +143,9 @@ __device__ inline PairWindow pair_window(float unit_bound, const unsigned* __res
         w.two_c = 2.f * F16_C * ss * (row_side ? mb : ma);          // times |x|
         w.two_k = 2.f * F16_KAPPA * ss * ma * mb;
     }
+    // wave-uniform by construction: keep them in scalar registers
+    w.two_c = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(w.two_c)));
+    w.two_k = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(w.two_k)));
     return w;
 }
 
@@ -147,217 +154,349 @@ __device__ inline PairWindow pair_window(float unit_bound, const unsigned* __res
 // for address arithmetic right behind the last MFMA (tools/check_mfma_war.py audits the generated code).
 #define XFH_KEEP_FRAGS(f) asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]))
 
-// A workgroup owns 256 rows of D1 and sweeps the columns of D2 (staged 128 at a time through LDS).
-//   thr_row (P,N1)      : rowmax^_i - 2 E_i          (scaled units; the workgroup sees whole rows)
-//   colmaxh (P,N2) u32  : ord(column maximum), 32-bit atomic max across the row-block workgroups (zeroed by the caller)
+// Sweep.  A workgroup keeps 256 columns (rows of D2) in LDS for its whole life and streams the 32-row blocks of D1 past them: no barrier
+// inside the loop -- the waves take row blocks from a shared counter, so a wave the scheduler favours simply does more of them.  Per block
+// the A fragments come straight from global memory into registers, one block ahead.  Per 32x32 tile the two orientations run one after the
+// other on 16 accumulator registers each, and the VALU epilogue of one hides in the issue gaps of the other's MFMAs (a K = 16 MFMA holds
+// the pipe for 32 cycles = room for ~5 other instructions of the same wave; with the epilogues AFTER all eight MFMAs the kernel measured
+// MFMA time + VALU time, the pipe 53 % busy: profiles/r03_*):
+//     A:  acc  = a . b            (lane = column)                        |  B:  accT = b . a  (lane = row)  ||  column epilogue of acc
+//     then the fragments of the next tile leave LDS                       ||  row epilogue of accT
+//   thr_col (P,N2)      : colmax^_j - 2 E'_j         (scaled units; the workgroup sees whole columns)
+//   rowmaxh (P,N1) u32  : ord(row maximum), 32-bit atomic max across the column-chunk workgroups (zeroed by the caller)
 //   R (P, ceil(N2/32), N1), C (P, ceil(N1/32), N2) : block maxima
+constexpr int FT_TILES = FT_COLS / 32;
 __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __restrict__ a16, size_t sa16, const _Float16* __restrict__ b16, size_t sb16,
                                                             float unit_bound /* > 0: caller-provided copies of unit-norm rows (na / nb / nmax unused) */,
                                                             const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
-                                                            int N1, int N2, int nrb, int P, const float* __restrict__ na, const unsigned* __restrict__ nmax,
-                                                            float* __restrict__ thr_row, unsigned* __restrict__ colmaxh,
+                                                            int N1, int N2, int ncc, int P, const float* __restrict__ nb, const unsigned* __restrict__ nmax,
+                                                            float* __restrict__ thr_col, unsigned* __restrict__ rowmaxh,
                                                             float* __restrict__ R, float* __restrict__ C) {
-    __shared__ __attribute__((aligned(16))) _Float16 Dl[FT_COLS * FT_DS];
-    __shared__ float colx[8][FT_COLS];                    // per-wave column maxima of the current 128 columns
+    __shared__ __attribute__((aligned(16))) _Float16 Dl[FT_COLS * FT_DS];      // the columns
+    __shared__ float colx[8][FT_COLS];                                          // per wave: running column maxima (ds_max_f32, no return)
+    __shared__ int next_block;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int p, rb;
-    if (!xcd_group_map(blockIdx.x, nrb, P, p, rb)) return;
+    int p, cc;
+    if (!xcd_group_map(blockIdx.x, ncc, P, p, cc)) return;
     const int n1 = fpair_count(n1p, p * n_stride, N1);
     const int n2 = fpair_count(n2p, p * n_stride + n_off2, N2);
-    const int row0 = rb * FT_ROWS;
-    if (n1 <= 0 || n2 <= 0 || row0 >= n1) return;
+    const int c0 = cc * FT_COLS;
+    if (n1 <= 0 || n2 <= 0 || c0 >= n2) return;
     const _Float16* A = a16 + (size_t)p * sa16;
     const _Float16* Bm = b16 + (size_t)p * sb16;
-    const int wrow0 = row0 + wave * 32;
-    const bool wave_live = wrow0 < n1;                    // waves past the last row still stage and meet the barriers
-    const int myrow = wrow0 + l31;
     const int ncb32 = ceil_div(N2, 32), nrb32 = ceil_div(N1, 32);
-    float* Cw = C + ((size_t)p * nrb32 + (wrow0 >> 5)) * N2;
-    float* Rw = R + (size_t)p * ncb32 * N1 + myrow;
-
-    f16x8 a[4];
-    {
-        const int row = min(myrow, n1 - 1);               // rows >= n1: copies of the last valid row (never reported)
+    const int ntile = min(FT_TILES, ceil_div(n2 - c0, 32));
+    const int nblock = ceil_div(n1, 32);
+    if (tid == 0) next_block = 8;                          // blocks 0..7: one per wave to start with
+    {   // 256 columns x 64 fp16 = 2048 16-byte pieces, four per thread, all in flight; columns >= n2: copies of the last valid column
+        uint4 v[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a[kk] = *reinterpret_cast<const f16x8*>(A + (size_t)row * 64 + kk * 16 + half * 8);
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 512;
+            v[i] = *reinterpret_cast<const uint4*>(Bm + (size_t)min(c0 + (e >> 3), n2 - 1) * 64 + (e & 7) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 512;
+            *reinterpret_cast<uint4*>(Dl + (e >> 3) * FT_DS + (e & 7) * 8) = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) (&colx[0][0])[tid + i * 512] = -INFINITY;
     }
-    float rowrun = -INFINITY;
-
-    for (int c0 = 0; c0 < n2; c0 += FT_COLS) {
-        __syncthreads();
-        {   // 128 columns x 64 fp16 = 1024 16-byte pieces, two per thread
+    f16x8 a[4], an[4];
+    int blk = wave, nxt;
+    if (blk < nblock) {
+        const int row = min(blk * 32 + l31, n1 - 1);       // rows >= n1: copies of the last valid row (never reported)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int e = tid + i * 512;
-                const int col = e >> 3, q = e & 7;
-                const int gc = min(c0 + col, n2 - 1);      // columns >= n2: copies of the last valid column
-                const uint4 v = *reinterpret_cast<const uint4*>(Bm + (size_t)gc * 64 + q * 8);
-                *reinterpret_cast<uint4*>(Dl + col * FT_DS + q * 8) = v;
-            }
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int ct = 0; ct < FT_COLS / 32; ++ct) {
-            const int cbase = c0 + ct * 32;
-            if (cbase >= n2) break;
-            f16x8 bfrag[4];
-            const _Float16* bp = Dl + (ct * 32 + l31) * FT_DS + half * 8;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) bfrag[kk] = *reinterpret_cast<const f16x8*>(bp + kk * 16);
-            f32x16 acc, accT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; accT[r] = 0.f; }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], bfrag[kk], acc, 0, 0, 0);      // lane: column cbase + l31, 16 of the wave's rows
-                accT = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[kk], a[kk], accT, 0, 0, 0);    // lane: row wrow0 + l31, 16 of the tile's columns
-            }
-            float cm = max16(acc), rm = max16(accT);
-            cm = fmaxf(cm, xhalf(cm));
-            rm = fmaxf(rm, xhalf(rm));
-            rowrun = fmaxf(rowrun, rm);
-            if (half == 0) {
-                colx[wave][ct * 32 + l31] = cm;
-                if (wave_live && cbase + l31 < n2) Cw[cbase + l31] = cm;
-            } else if (myrow < n1) {
-                Rw[(size_t)(cbase >> 5) * N1] = rm;
-            }
-            XFH_KEEP_FRAGS(bfrag);
-        }
-        __syncthreads();
-        if (tid < FT_COLS) {
-            const int col = c0 + tid;
-            if (col < n2) {
-                float k = colx[0][tid];
-#pragma unroll
-                for (int w = 1; w < 8; ++w) k = fmaxf(k, colx[w][tid]);
-                atomicMax(&colmaxh[(size_t)p * N2 + col], float_ord(k));
-            }
-        }
+        for (int kk = 0; kk < 4; ++kk) an[kk] = *reinterpret_cast<const f16x8*>(A + (size_t)row * 64 + kk * 16 + half * 8);
     }
-    if (half == 0 && myrow < n1) {
-        const PairWindow w = pair_window(unit_bound, nmax, P, p, true);
-        const float nx = unit_bound > 0.f ? unit_bound : na[(size_t)p * N1 + myrow];
-        thr_row[(size_t)p * N1 + myrow] = rowrun - fmaf(w.two_c, nx, w.two_k);
+    __syncthreads();
+    float* mycolx = &colx[wave][l31];
+    const _Float16* bp0 = Dl + l31 * FT_DS + half * 8;
+    while (blk < nblock) {
+        {   // the next block of this wave, and its fragments on their way under this block's MFMAs
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&next_block, 1);
+            nxt = __builtin_amdgcn_readfirstlane(t);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
+        if (nxt < nblock) {
+            const int row = min(nxt * 32 + l31, n1 - 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) an[kk] = *reinterpret_cast<const f16x8*>(A + (size_t)row * 64 + kk * 16 + half * 8);
+        }
+        const int myrow = blk * 32 + l31;
+        // branch-free stores (a branch would end the basic block and with it the MFMA / VALU interleave below): buffer stores, lanes that
+        // must not store carry an out-of-range offset and the hardware drops them; the C row's range check also drops columns >= n2
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)p * nrb32 + blk) * N2 + c0, 0, (min(n2, c0 + FT_COLS) - c0) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(R + ((size_t)p * ncb32 + (c0 >> 5)) * N1, 0, FT_TILES * N1 * 4, 0x00020000);
+        const int offC = half == 0 ? l31 * 4 : (int)0x80000000;
+        const int offR = (half == 1 && myrow < n1) ? myrow * 4 : (int)0x80000000;
+        float rowrun = -INFINITY;
+        f16x8 bfrag[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bfrag[0][kk] = *reinterpret_cast<const f16x8*>(bp0 + kk * 16);
+        f32x16 acc, accT;
+        // Software pipeline over the tiles (uniform control flow only: every tile is one basic block, so the scheduler can interleave):
+        //   A(ct): acc  = a . b[ct]   ||  row epilogue of accT(ct - 1)
+        //   B(ct): accT = b[ct] . a   ||  column epilogue of acc(ct)
+        // with the fragments of tile ct + 1 leaving LDS meanwhile (second register set).
+#define XFH_ROW_EPILOGUE(CT)                                                                              \
+        {                                                                                                 \
+            float rm = max16(accT);                                                                       \
+            rm = fmaxf(rm, xhalf(rm));                                                                    \
+            rowrun = fmaxf(rowrun, rm);                                                                   \
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rm), rR, offR, (CT) * N1 * 4, 0);       \
+        }
+#define XFH_INTERLEAVE_4x5()                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+#pragma unroll
+        for (int ct = 0; ct < FT_TILES; ++ct) {
+            if (ct < ntile) {                               // (uniform)
+                if (ct + 1 < FT_TILES) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) bfrag[(ct + 1) & 1][kk] = *reinterpret_cast<const f16x8*>(bp0 + (ct + 1) * 32 * FT_DS + kk * 16);
+                }
+                // ---- A: lane = column c0 + 32 ct + l31, registers = 16 of the block's rows
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk], bfrag[ct & 1][kk], acc, 0, 0, 0);
+                if (ct > 0) XFH_ROW_EPILOGUE(ct - 1)
+                XFH_INTERLEAVE_4x5()
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- B: lane = row myrow, registers = 16 of the tile's columns
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accT[r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) accT = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][kk], a[kk], accT, 0, 0, 0);
+                {
+                    float cm = max16(acc);
+                    cm = fmaxf(cm, xhalf(cm));
+                    __hip_atomic_fetch_max(mycolx + ct * 32, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (both half-waves hold cm)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cm), rC, offC + ct * 128, 0, 0);
+                }
+                XFH_INTERLEAVE_4x5()
+                __builtin_amdgcn_sched_barrier(0);
+                XFH_KEEP_FRAGS(bfrag[ct & 1]);
+            }
+        }
+        XFH_ROW_EPILOGUE(ntile - 1)
+#undef XFH_ROW_EPILOGUE
+#undef XFH_INTERLEAVE_4x5
+        if (half == 0 && myrow < n1) atomicMax(&rowmaxh[(size_t)p * N1 + myrow], float_ord(rowrun));      // (no return value: fire and forget)
+        blk = nxt;
+    }
+    // column maxima: across the 8 waves, then the thresholds
+    __syncthreads();
+    if (tid < FT_COLS && c0 + tid < n2) {
+        float k = colx[0][tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) k = fmaxf(k, colx[w][tid]);
+        const PairWindow w = pair_window(unit_bound, nmax, P, p, false);
+        const float nx = unit_bound > 0.f ? unit_bound : nb[(size_t)p * N2 + c0 + tid];
+        thr_col[(size_t)p * N2 + c0 + tid] = k - fmaf(w.two_c, nx, w.two_k);
     }
 }
 
-// Exact refine.  Workgroup (pair, side, yb): the 32 rows yb*32.. of the OTHER set (Y) sit in LDS; every x of the own set whose block
-// maximum reaches its threshold gets the 32 exact dot products with them, folded into key[x] = max (ord(S) << 32 | ~y).
-//   side 0: x = rows of D1 (keys: row arg-max), Y = D2, block maxima R, thresholds thr_row
-//   side 1: x = rows of D2 (keys: column arg-max), Y = D1, block maxima C, thresholds from colmaxh (complete only now)
-// The dot product is the one the round-2 refine used, bit for bit: four chains of 16 channels, (s0 + s1) + (s2 + s3).
-constexpr int RF_LIST = 2048;
-constexpr int RF_YS = 68;          // LDS row stride in floats (272 bytes = 17 x 16: the lanes of a ds_read_b128 group hit distinct slots)
-__global__ __launch_bounds__(256) void mnn_f16_refine_kernel(const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2, size_t ps2,
-                                                             float unit_bound, const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p,
-                                                             int n_stride, int n_off2, int N1, int N2, int nyb_max, int P,
-                                                             const float* __restrict__ na, const float* __restrict__ nb, const unsigned* __restrict__ nmax,
-                                                             const float* __restrict__ thr_row, const unsigned* __restrict__ colmaxh,
-                                                             const float* __restrict__ R, const float* __restrict__ C,
-                                                             unsigned long long* __restrict__ rowkey, unsigned long long* __restrict__ colkey) {
-    __shared__ __attribute__((aligned(16))) float Ys[32 * RF_YS];
-    __shared__ unsigned short list[RF_LIST];
-    __shared__ int lcnt;
+// Exact refine.  ONE WAVE per (pair, side, yb), no barriers.  Phase 1: the wave walks its block maxima against their thresholds, 512 per
+// round with the next round's loads in flight, and queues the x whose block maximum reaches its threshold (wave-private LDS queue).
+// Phase 2: the queued x, 32 at a time, against the 32 rows yb*32.. of the OTHER set (Y) on v_mfma_f32_32x32x2_f32 -- an exact fp32 fma
+// chain per similarity, in the channel order of the exact kernel (k_match.hip), so both paths produce the same bits -- folded into
+// key[x] = max (ord(S) << 32 | ~y), ties to the lowest y.
+//   side 0: x = rows of D1 (keys: row arg-max), Y = D2, block maxima R, thresholds from rowmaxh
+//   side 1: x = rows of D2 (keys: column arg-max), Y = D1, block maxima C, thresholds thr_col
+// Workgroups of four such waves only share the launch.  What was measured on the way (B = 64 VGA bench, 32 pairs of 4096 x 4096):
+// a workgroup per yb with barriers between its phases 102 us; a wave per yb with the dot products on the vector ALUs (two x per step, one
+// per half-wave, 64 FMAs + a DPP arg-max each) 84 us -- 24 M vector instructions per launch, issue-bound; on the matrix cores the same
+// ~280 k x 32 similarities are 32 MFMAs per 32 x: 60 us, of which the scan is 27 (latency: two rounds of 16-byte loads in flight per
+// wave), the row gathers / LDS transposes / epilogues 22 and the MFMA chains 11 (ablation builds, profiles/README.md).
+constexpr int RF_ROUND = 512;      // x per scan round
+constexpr int RF_CHUNK = 4096;     // x per queue fill
+// thresholds of the row side, once the row maxima are complete: thr_row = rowmax^ - 2 E (scaled units)
+__global__ __launch_bounds__(256) void mnn_f16_thr_row_kernel(float unit_bound, const int32_t* __restrict__ n1p, int n_stride, int N1, int P,
+                                                              const float* __restrict__ na, const unsigned* __restrict__ nmax,
+                                                              const unsigned* __restrict__ rowmaxh, float* __restrict__ thr_row) {
+    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= fpair_count(n1p, p * n_stride, N1)) return;
+    const PairWindow w = pair_window(unit_bound, nmax, P, p, true);
+    const float nx = unit_bound > 0.f ? unit_bound : na[(size_t)p * N1 + i];
+    thr_row[(size_t)p * N1 + i] = ord_float(rowmaxh[(size_t)p * N1 + i]) - fmaf(w.two_c, nx, w.two_k);
+}
+
+constexpr int RF_QUEUE = 1024;     // queue capacity per wave; it is drained before a scan round (<= 512 new entries) could overflow it
+constexpr int RF_XS = 68;          // LDS row stride of the 32 x 64 tile in floats (272 bytes = 17 x 16: conflict-free 16-byte reads down a column of rows)
+constexpr int RF_WAVES = 2;        // waves (= Y blocks) per workgroup
+__global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void mnn_f16_refine_kernel(
+    const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2, size_t ps2, const int32_t* __restrict__ n1p,
+    const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1, int N2, int nyb_max, int P,
+    const float* __restrict__ thr_row, const float* __restrict__ thr_col, const float* __restrict__ R,
+    const float* __restrict__ C, unsigned long long* __restrict__ rowkey, unsigned long long* __restrict__ colkey) {
+    __shared__ unsigned short queue[RF_WAVES][RF_QUEUE];                       // per wave: flagged x (offsets into the current chunk)
+    __shared__ __attribute__((aligned(16))) float tile[RF_WAVES][32 * RF_XS];   // per wave: 32 rows x 64 channels on their way into MFMA operand order
+    const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int p, item;
-    if (!xcd_group_map(blockIdx.x, 2 * nyb_max, P, p, item)) return;
-    const int side = item / nyb_max, yb = item - side * nyb_max;
+    if (!xcd_group_map(blockIdx.x, 2 * (nyb_max / RF_WAVES), P, p, item)) return;      // nyb_max is a multiple of RF_WAVES
+    const int side = item / (nyb_max / RF_WAVES), yb = (item - side * (nyb_max / RF_WAVES)) * RF_WAVES + wv;
     const int n1 = fpair_count(n1p, p * n_stride, N1);
     const int n2 = fpair_count(n2p, p * n_stride + n_off2, N2);
     if (n1 <= 0 || n2 <= 0) return;
     const int nX = side ? n2 : n1, nY = side ? n1 : n2, NX = side ? N2 : N1;
-    if (yb * 32 >= nY) return;
+    if (yb * 32 >= nY) return;                              // (whole waves leave: nothing below synchronises across waves)
     const float* X = side ? d2 + (size_t)p * ps2 : d1 + (size_t)p * ps1;
     const float* Y = side ? d1 + (size_t)p * ps1 : d2 + (size_t)p * ps2;
     const float* M = (side ? C + (size_t)p * ceil_div(N1, 32) * N2 : R + (size_t)p * ceil_div(N2, 32) * N1) + (size_t)yb * NX;
+    const float* T = side ? thr_col + (size_t)p * N2 : thr_row + (size_t)p * N1;
     unsigned long long* key = side ? colkey + (size_t)p * N2 : rowkey + (size_t)p * N1;
-    const int tid = threadIdx.x;
-    {   // 32 rows x 64 floats = 512 float4, two per thread; rows past nY: zeros (their keys are never written)
+    const bool vec_ok = (NX & 3) == 0;                      // 16-byte loads need 16-byte aligned rows of M / thresholds
+    unsigned short* q = queue[wv];
+    float* xt = tile[wv];
+    // buffer resources (uniform bases in SGPRs, 32-bit lane offsets; reads past the end return 0): one address register per lane instead of
+    // a 64-bit pointer per array
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, nX * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(T), 0, nX * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, nX * 256, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Y), 0, nY * 256, 0x00020000);
+
+    // 32 rows of 256 bytes -> LDS -> this lane's 32 channels (32 half ..) of row l31: the global reads are coalesced (16 lanes per row, four
+    // rows per instruction); a lane reading its own row straight from memory is a 64-line gather per instruction, and those gathers were
+    // what the matrix-core version of this kernel waited for
+    const int trow = lane >> 4, tq = lane & 15;
+    auto rows_to_operand = [&](const __amdgpu_buffer_rsrc_t& rs, auto row_of, float (&reg)[32]) {
+        uint4 v[8];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = tid + i * 256;
-            const int r = e >> 4, q = e & 15;
-            const int gy = yb * 32 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < nY) v = *reinterpret_cast<const float4*>(Y + (size_t)gy * 64 + q * 4);
-            *reinterpret_cast<float4*>(Ys + r * RF_YS + q * 4) = v;
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, row_of(4 * i + trow) * 256 + tq * 16, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(xt + (4 * i + trow) * RF_XS + tq * 4) = v[i];
+        // (wave-synchronous: LDS operations of one wave execute in order)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float4 f = *reinterpret_cast<const float4*>(xt + l31 * RF_XS + half * 32 + t * 4);
+            reg[4 * t] = f.x; reg[4 * t + 1] = f.y; reg[4 * t + 2] = f.z; reg[4 * t + 3] = f.w;
         }
-    }
-    const PairWindow w = pair_window(unit_bound, nmax, P, p, side == 0);
-    const float* nx = side ? nb + (size_t)p * N2 : na + (size_t)p * N1;
-    const int grp = tid >> 5, l31 = tid & 31;
-    const int gy = yb * 32 + l31;
-    for (int x0 = 0; x0 < nX; x0 += RF_LIST) {
-        if (tid == 0) lcnt = 0;
-        __syncthreads();                                   // (also covers the Ys fill the first time round)
-        {   // scan: RF_LIST block maxima against their thresholds, all loads of a thread in flight together
-            constexpr int NL = RF_LIST / 256;
-            float m[NL], t[NL];
+    };
+    float yreg[32];                                         // Y row yb*32 + l31, channels 32 half .. ; rows past nY read 0 and are masked below
+    rows_to_operand(rY, [&](int r) { return yb * 32 + r; }, yreg);
+    const bool ragged = yb * 32 + 32 > nY;                  // (uniform) the last block of Y: rows past nY must not win
+
+    for (int xc = 0; xc < nX; xc += RF_CHUNK) {
+        int cnt = 0;
+        // ---- phase 2 (called when the queue fills up, and after the scan): up to 32 queued x per pass against the 32 rows of the Y block
+        //      on the f32 matrix cores, with the operand roles and the K order of the exact kernel (k_match.hip): step s multiplies channels
+        //      s (lanes 0-31) and 32 + s (lanes 32-63) -- the same fma chain, so the refine's similarities are the exact kernel's, bit for
+        //      bit.  A = Y rows (i = y), B = x rows (j = queue entry): a lane ends up with 16 of the 32 similarities of ITS entry; maximum
+        //      and first index in-lane, the other half by permlane32.
+        auto drain = [&]() {
+            for (int e0 = 0; e0 < cnt; e0 += 32) {
+                float xreg[32];
+                rows_to_operand(rX, [&](int r) { return xc + (int)q[min(e0 + r, cnt - 1)]; }, xreg);      // (entries past the queue: copies of the last one, not reported)
+                f32x16 acc;
 #pragma unroll
-            for (int k = 0; k < NL; ++k) {
-                const int x = x0 + tid + k * 256;
-                m[k] = -INFINITY; t[k] = INFINITY;
-                if (x < nX) {
-                    m[k] = M[x];
-                    if (side == 0) t[k] = thr_row[(size_t)p * N1 + x];
-                    else t[k] = ord_float(colmaxh[(size_t)p * N2 + x]) - fmaf(w.two_c, unit_bound > 0.f ? unit_bound : nx[x], w.two_k);
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s_ = 0; s_ < 32; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yreg[s_], xreg[s_], acc, 0, 0, 0);
+                // acc[r] = S(x of entry l31, y = yb*32 + (r&3) + 8*(r>>2) + 4*half): y ascends with r
+                if (ragged) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (yb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= nY) acc[r] = -INFINITY;
+                }
+                const float m = max16(acc);
+                int ry = 0;
+#pragma unroll
+                for (int r = 15; r >= 0; --r)
+                    if (acc[r] == m) ry = (r & 3) + 8 * (r >> 2);                  // the FIRST r attaining the maximum: the lowest y of this half
+                unsigned long long k = ((unsigned long long)float_ord(m) << 32) | (0xffffffffu - (unsigned)(yb * 32 + ry + 4 * half));
+                k = u64_max(k, xhalf_u64(k));                                        // ties between the halves: the larger ~y = the lower y
+                const int e = e0 + l31;
+                if (half == 0 && e < cnt) atomicMax(&key[xc + q[e]], k);
+            }
+            cnt = 0;
+        };
+        // ---- phase 1: scan.  Eight block maxima per lane and round (two 16-byte loads of each array); the next round is in flight while
+        //      this one is tested: one compare per element, the queue bookkeeping only for the (rare) hits.
+        const int nround = ceil_div(min(RF_CHUNK, nX - xc), RF_ROUND);
+        float4 ma0, ma1, ta0, ta1, mb0, mb1, tb0, tb1;         // two rounds in flight: set a (even rounds), set b (odd rounds)
+        auto issue = [&](int r, float4& m0, float4& m1, float4& t0, float4& t1) {
+            const int xb = xc + r * RF_ROUND + lane * 8;
+            if (vec_ok) {
+                m0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rM, xb * 4, 0, 0));
+                m1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rM, xb * 4 + 16, 0, 0));
+                t0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rT, xb * 4, 0, 0));
+                t1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rT, xb * 4 + 16, 0, 0));
+            } else {
+                float mm[8], tt[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    mm[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rM, (xb + j) * 4, 0, 0));
+                    tt[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (xb + j) * 4, 0, 0));
+                }
+                m0 = make_float4(mm[0], mm[1], mm[2], mm[3]); m1 = make_float4(mm[4], mm[5], mm[6], mm[7]);
+                t0 = make_float4(tt[0], tt[1], tt[2], tt[3]); t1 = make_float4(tt[4], tt[5], tt[6], tt[7]);
+            }
+        };
+        auto test = [&](int r, const float4& m0, const float4& m1, const float4& t0, const float4& t1) {
+            if (cnt > RF_QUEUE - RF_ROUND) drain();          // (uniform; identical descriptor sets get here)
+            const int xl = r * RF_ROUND + lane * 8;
+            const int left = nX - (xc + xl);                 // elements of this lane that exist (entries past nX read 0 >= 0: mask them)
+            const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+            const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            // ordered compaction into the wave's queue: ballot per j, prefix by popcount
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long bal = __ballot(mv[j] >= tv[j] && j < left);
+                if (bal) {                                   // (uniform)
+                    if ((bal >> lane) & 1ull) q[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(xl + j);
+                    cnt += __popcll(bal);
                 }
             }
-#pragma unroll
-            for (int k = 0; k < NL; ++k)
-                if (m[k] >= t[k]) list[atomicAdd(&lcnt, 1)] = (unsigned short)(tid + k * 256);
-        }
-        __syncthreads();
-        const int cnt = lcnt;
-        for (int e = grp; e < cnt; e += 8) {               // a half-wave per flagged x: lane = row of the Y block
-            const int x = x0 + list[e];
-            const float4* xp = reinterpret_cast<const float4*>(X + (size_t)x * 64);      // one address per half-wave: a broadcast load
-            const float4* yp = reinterpret_cast<const float4*>(Ys + l31 * RF_YS);
-            float s[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 xv[4], yv[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) { xv[t] = xp[q * 4 + t]; yv[t] = yp[q * 4 + t]; }
-                float c = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    c = fmaf(xv[t].x, yv[t].x, c); c = fmaf(xv[t].y, yv[t].y, c);
-                    c = fmaf(xv[t].z, yv[t].z, c); c = fmaf(xv[t].w, yv[t].w, c);
-                }
-                s[q] = c;
+        };
+        issue(0, ma0, ma1, ta0, ta1);
+        for (int r = 0; r < nround; r += 2) {
+            if (r + 1 < nround) issue(r + 1, mb0, mb1, tb0, tb1);
+            test(r, ma0, ma1, ta0, ta1);
+            if (r + 1 < nround) {
+                if (r + 2 < nround) issue(r + 2, ma0, ma1, ta0, ta1);
+                test(r + 1, mb0, mb1, tb0, tb1);
             }
-            const float dot = (s[0] + s[1]) + (s[2] + s[3]);
-            unsigned long long k = gy < nY ? ((unsigned long long)float_ord(dot) << 32) | (0xffffffffu - (unsigned)gy) : 0ull;
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) k = u64_max(k, shfl_xor_u64(k, o));
-            if (l31 == 0) atomicMax(&key[x], k);
         }
-        __syncthreads();
+        drain();
     }
 }
 
 // d1_16 / d2_16 (optional, both or neither): fp16 copies the caller already holds (xfh_detect_sparse's desc_f16 = RNE(256 * row)), laid out
 // like d1 / d2 (same pair strides in elements), rows L2-normalised: |row| <= 1.00001.  They replace the prep passes.
 void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const uint16_t* d1_16, const uint16_t* d2_16,
-                      const int32_t* n1, const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st) {
-    const int nrb = ceil_div(N1, FT_ROWS);
+                      const int32_t* n1, const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st, Profiler* prof) {
     const bool prepared = d1_16 && d2_16;
     const _Float16* a16 = prepared ? reinterpret_cast<const _Float16*>(d1_16) : ws.a16;
     const _Float16* b16 = prepared ? reinterpret_cast<const _Float16*>(d2_16) : ws.b16;
     const size_t sa = prepared ? ps1 : (size_t)N1 * 64, sb = prepared ? ps2 : (size_t)N2 * 64;
     const float ub = prepared ? 1.00001f : 0.f;
     if (!prepared) {
+        prof_begin(prof, XFH_SPAN_MATCH_PREP, st);
         const dim3 g(ceil_div(N1 > N2 ? N1 : N2, 256), P, 2);
         mnn_prep_kernel<false><<<g, 256, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, ws.a16, ws.b16, ws.na, ws.nb, ws.nmax);
         mnn_prep_kernel<true><<<g, 256, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, ws.a16, ws.b16, ws.na, ws.nb, ws.nmax);
+        prof_end(prof, XFH_SPAN_MATCH_PREP, st, 0, 0);
     }
-    mnn_f16_sweep_kernel<<<xcd_grid_size(nrb, P), 512, 0, st>>>(a16, sa, b16, sb, ub, n1, n2, n_stride, n_off2, N1, N2, nrb, P, ws.na, ws.nmax,
-                                                               ws.thr_row, ws.colmaxh, ws.R, ws.C);
-    const int nyb = ceil_div(N1 > N2 ? N1 : N2, 32);
-    mnn_f16_refine_kernel<<<xcd_grid_size(2 * nyb, P), 256, 0, st>>>(d1, ps1, d2, ps2, ub, n1, n2, n_stride, n_off2, N1, N2, nyb, P, ws.na, ws.nb, ws.nmax,
-                                                                    ws.thr_row, ws.colmaxh, ws.R, ws.C, ws.rowkey, ws.colkey);
+    prof_begin(prof, XFH_SPAN_MATCH_SWEEP, st);
+    const int ncc = ceil_div(N2, FT_COLS);
+    mnn_f16_sweep_kernel<<<xcd_grid_size(ncc, P), 512, 0, st>>>(a16, sa, b16, sb, ub, n1, n2, n_stride, n_off2, N1, N2, ncc, P, ws.nb, ws.nmax,
+                                                               ws.thr_col, ws.rowmaxh, ws.R, ws.C);
+    prof_end(prof, XFH_SPAN_MATCH_SWEEP, st, 0, 0);
+    const int nyb = ceil_div(ceil_div(N1 > N2 ? N1 : N2, 32), RF_WAVES) * RF_WAVES;
+    prof_begin(prof, XFH_SPAN_MATCH_REFINE, st);
+    mnn_f16_thr_row_kernel<<<dim3(ceil_div(N1, 256), P), 256, 0, st>>>(ub, n1, n_stride, N1, P, ws.na, ws.nmax, ws.rowmaxh, ws.thr_row);
+    mnn_f16_refine_kernel<<<xcd_grid_size(2 * (nyb / RF_WAVES), P), 64 * RF_WAVES, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nyb, P,
+                                                                          ws.thr_row, ws.thr_col, ws.R, ws.C, ws.rowkey, ws.colkey);
+    prof_end(prof, XFH_SPAN_MATCH_REFINE, st, 0, 0);
 }
 
 }  // namespace xfh

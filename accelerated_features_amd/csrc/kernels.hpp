@@ -136,7 +136,7 @@ struct DetectWs {          // carved from the caller's workspace by api.hip
 };
 void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                    float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
-                   int32_t* n_valid, int32_t* n_cand, hipStream_t st, uint16_t* desc16 = nullptr);
+                   int32_t* n_valid, int32_t* n_cand, hipStream_t st, uint16_t* desc16 = nullptr, Profiler* prof = nullptr);
 void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int kernel_size, int cap, int64_t* xy,
                      int32_t* n_cand, hipStream_t st);
 // k_sampler.hip: InterpolateSparse2d as a stand-alone op; mode 0 nearest, 1 bilinear, 2 bicubic
@@ -151,16 +151,16 @@ void launch_dense_gather(const float* feats, const unsigned long long* skeys, in
 
 // ---- k_match.hip ------------------------------------------------------------------------
 struct MatchWs {
-    // zero-initialised per call (one memset): [rowkey | colkey | colmaxh | nmax]
+    // zero-initialised per call (one memset): [rowkey | colkey | rowmaxh | nmax]
     void* zeroed; size_t zeroed_bytes;
     unsigned long long* rowkey;    // (P,N1) packed (ord(sim)<<32 | ~col): row arg-max, folded by 64-bit atomic max
     unsigned long long* colkey;    // (P,N2) packed (ord(sim)<<32 | ~row): column arg-max
-    unsigned* colmaxh;             // (P,N2) ord(column maximum of the fp16 product)
+    unsigned* rowmaxh;             // (P,N1) ord(row maximum of the fp16 product), 32-bit atomic max across the column-chunk workgroups
     unsigned* nmax;                // (2,P)  bit patterns of max |d1_i|, max |d2_j|
     // filter-and-refine scratch (k_match_f16.hip)
     _Float16 *a16, *b16;           // (P,N1,64), (P,N2,64) scaled fp16 copies
     float *na, *nb;                // (P,N1), (P,N2) fp32 norms
-    float* thr_row;                // (P,N1) row maximum of the fp16 product - 2 E
+    float *thr_row, *thr_col;      // (P,N1), (P,N2) row / column maximum of the fp16 product - 2 E
     float *R, *C;                  // (P,ceil(N2/32),N1) / (P,ceil(N1/32),N2) block maxima of the fp16 product
 };
 void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,

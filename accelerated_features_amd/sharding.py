@@ -34,6 +34,34 @@ def rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(script, argv, n_ranks, visible_devices=None, python=None):
+    """`python bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): re-run the same command line as N ranks under
+    torch.distributed.run (one process per GPU, 127.0.0.1 rendezvous on a free port) and return its exit code.  Refuses -- loudly --
+    when fewer than N devices are visible, so a line with n_gpus != the request can never be printed.
+    visible_devices: the device count to check against (None: do not check -- CPU / gloo self-tests)."""
+    import subprocess
+    import sys
+    if "WORLD_SIZE" in os.environ:
+        raise RuntimeError("self_launch called inside a torch.distributed.run worker")
+    if visible_devices is not None and visible_devices < n_ranks:
+        raise SystemExit(f"--gpus {n_ranks} requested but only {visible_devices} GPU(s) are visible to this process: refusing to run "
+                         f"(a benchmark line must never report fewer GPUs than were asked for)")
+    cmd = [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on these hosts
+    return subprocess.call(cmd, env=env)
+
+
 def init_process_group(backend, rank, world):
     """Rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
     import torch.distributed as dist
@@ -84,12 +112,12 @@ def aggregate_rate(units_per_rank_step, steps, world, seconds, scaling="weak"):
 # ------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[3]: the MegaDepth-1500 pair list (sizes only), long side 1600, sharded contiguously
 # ------------------------------------------------------------------------------------------------------------------
-_SIZES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "megadepth1500_sizes.json")
+_SIZES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "megadepth1500_sizes.json")
 
 
 def megadepth_pair_sizes(path=_SIZES, long_side=1600, seed=15):
     """[((h0,w0),(h1,w1)), ...] for the 1500 pairs of the reference's assets/megadepth_1500.json (sizes committed as
-    tests/golden/megadepth1500_sizes.json), scaled x long_side/1184 and floored to multiples of 32, in a fixed
+    accelerated_features_amd/data/megadepth1500_sizes.json by tests/golden/make_megadepth_sizes.py), scaled x long_side/1184 and floored to multiples of 32, in a fixed
     pseudo-random order (the dataset interleaves scenes; a permuted list also balances the contiguous shards)."""
     rows = json.load(open(path))
     up = lambda v: max(32, int(v * long_side / 1184) // 32 * 32)

@@ -326,8 +326,16 @@ int xfh_lg_match_pairs(xfh_lg_handle h, const float* kpts, const float* desc, co
 enum { XFH_PROF_NONE = 0, XFH_PROF_CONV_MFMA = 1, XFH_PROF_MATCH = 2, XFH_PROF_BLOCK1 = 3, XFH_PROF_HEADS = 4,
        XFH_PROF_CONV_64_64_S1 = 5 /* launches of conv_mfma_kernel<64,64,3,1,..>: the 64->64 3x3 stride-1 layers */,
        XFH_PROF_CONV_24_24 = 6 /* the two 24->24 3x3 stride-1 layers (block2.0 / block2.1): one kernel instantiation, two launches per step */,
-       XFH_PROF_CONV_LAYER0 = 100 /* + index into spec.CONVS: one MFMA conv layer only */ };
+       XFH_PROF_CONV_LAYER0 = 100 /* + index into spec.CONVS: one MFMA conv layer only */,
+       XFH_PROF_ALL = 1000 /* every kernel (or tight kernel group) of xfh_backbone / xfh_detect_sparse / xfh_match_mnn as its own span: read with xfh_profile_read_spans */ };
+/* span ids reported under XFH_PROF_ALL (next to XFH_PROF_BLOCK1 and XFH_PROF_CONV_LAYER0 + layer) */
+enum { XFH_SPAN_GRAY = 200, XFH_SPAN_PYRAMID = 201, XFH_SPAN_HEAD_REL = 202, XFH_SPAN_HEAD_KP = 203,
+       XFH_SPAN_NMS_FLAGS = 210, XFH_SPAN_NMS_COMPACT = 211, XFH_SPAN_TOPK = 212, XFH_SPAN_DESCRIPTOR = 213,
+       XFH_SPAN_MATCH_ZERO = 220, XFH_SPAN_MATCH_PREP = 221, XFH_SPAN_MATCH_SWEEP = 222, XFH_SPAN_MATCH_REFINE = 223, XFH_SPAN_MATCH_FINALIZE = 224,
+       XFH_SPAN_MATCH_EXACT = 225 };
 int xfh_profile_select(xfh_handle h, int which);
+/* the spans recorded since the last read, in launch order: ids[i], ms[i] for i < min(*n_spans, capacity); synchronises; resets */
+int xfh_profile_read_spans(xfh_handle h, int* ids, double* ms, int capacity, int* n_spans);
 /* debug: 24 int64 s_memtime stamps per MFMA-conv workgroup are written to device_buffer (NULL = off) */
 int xfh_debug_trace(xfh_handle h, long long* device_buffer);
 /* debug: resident workgroups per CU the runtime reports for mnn_sim_kernel */

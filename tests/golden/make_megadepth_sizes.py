@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Size histogram of the MegaDepth-1500 pair list (BASELINE configs[3]) -> tests/golden/megadepth1500_sizes.json.
+"""Size histogram of the MegaDepth-1500 pair list (BASELINE configs[3]) -> accelerated_features_amd/data/megadepth1500_sizes.json.
 
 Reads /root/reference/assets/megadepth_1500.json (1500 pairs; only `size0_hw` / `size1_hw` are used -- the images
 themselves are not in the repository) and writes [[h0, w0, h1, w1, count], ...] sorted by count.  bench.py
@@ -10,7 +10,7 @@ import json
 import os
 
 SRC = "/root/reference/assets/megadepth_1500.json"
-DST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "megadepth1500_sizes.json")
+DST = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "accelerated_features_amd", "data", "megadepth1500_sizes.json")
 
 if __name__ == "__main__":
     d = json.load(open(SRC))

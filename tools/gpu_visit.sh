@@ -7,7 +7,16 @@ mkdir -p gpurun_out/$TAG
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider "$@" > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -30 gpurun_out/$TAG/pytest_gpu.log | grep -v amdgpu.ids
 timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | grep -v amdgpu.ids | tee gpurun_out/$TAG/bench.log | tail -3
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/$TAG/prof" -o it -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --cpu-seconds 0 > "$OLDPWD/gpurun_out/$TAG/rocprof.log" 2>&1); echo "rocprof rc=$?"
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/$TAG/prof" -o it --output-format csv -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --cpu-seconds 0 > "$OLDPWD/gpurun_out/$TAG/rocprof.log" 2>&1); echo "rocprof rc=$?"
 find gpurun_out/$TAG/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$TAG/kernel_stats.csv
-head -32 gpurun_out/$TAG/kernel_stats.csv | cut -c1-200
-find gpurun_out/$TAG/prof -type f ! -name "*stats*" -delete
+python - <<PY
+import csv
+rows = list(csv.DictReader(open("gpurun_out/$TAG/kernel_stats.csv")))
+n = 14.0       # steps + warmup + side passes of the profiled command: 10 + 3 + 1 (arm)...; per-step figures use Calls of block1
+calls = next((int(r["Calls"]) for r in rows if "block1" in r["Name"]), 1)
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print(f"kernel time per step (block1 launches = {calls}): {tot / calls / 1e3:.1f} us")
+for r in rows[:34]:
+    print(f'{r["Name"].replace("xfh::", "").replace("void ", "")[:70]:70s} {int(r["Calls"]) / calls:5.1f}/step {float(r["TotalDurationNs"]) / calls / 1e3:8.1f} us/step  avg {float(r["AverageNs"]) / 1e3:8.1f} us  {r["Percentage"]}%')
+PY
+rm -rf gpurun_out/$TAG/prof
