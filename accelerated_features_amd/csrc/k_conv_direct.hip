@@ -122,11 +122,12 @@ int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B,
 namespace b1 {
 constexpr int OH = 8, OW = 16;
 constexpr int C3H = 17, C3W = 33, C2H = 19, C2W = 35, C1H = 39, C1W = 71, GH = 41, GW = 73;
-constexpr int G_OFF = 0, G_SZ = GH * GW;                  // 2993
-constexpr int C1_OFF = G_OFF + G_SZ, C1_SZ = 4 * C1H * C1W;  // 11076
+constexpr int G_OFF = 0, G_SZ = GH * GW;                  // 2993 (+ 1: rows are loaded as column pairs, the last pair of the last row spills one element)
+constexpr int SK_OFF = G_OFF + G_SZ + 1, SK_SZ = OH * OW; // 4 x 4 averages of the gray tile (skip1's AvgPool2d), one per output pixel
+constexpr int C1_OFF = SK_OFF + SK_SZ, C1_SZ = 4 * C1H * C1W;  // 11076
 constexpr int C2_OFF = C1_OFF + C1_SZ, C2_SZ = 8 * C2H * C2W;  // 5320
 constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead once c2 exists)
-constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19389 floats = 77.6 KB
+constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19518 floats = 78.1 KB
 }  // namespace b1
 
 template <int C1MODE>      // conv1: 1 = a pixel per thread, 3 = three adjacent pixels (scalar FMAs), 4 = three adjacent pixels on packed FMAs
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     using namespace b1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* G = lds + G_OFF;
+    float* SK = lds + SK_OFF;
     float* C1 = lds + C1_OFF;
     float* C2 = lds + C2_OFF;
     float* C3 = lds + C3_OFF;
@@ -153,22 +155,29 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
 
     // ---- stage 0: gray tile, instance-normalised on the way in (zero padding stays zero) -------
     const float alpha = coef[2 * b], beta = coef[2 * b + 1];
-    {   // all six loads of a thread in flight together (as a rolled loop hipcc waits for each one: six exposed round trips per tile)
-        constexpr int NL = (G_SZ + 511) / 512;
-        float raw[NL];
+    {   // the tile as 8-byte column pairs (its origin 4 X4 - 6 and W are even: a pair never straddles the image border), all three loads of a
+        // thread in flight together (a rolled loop waits for each one); half the index arithmetic of the dword version (PMC: the kernel is bound
+        // by the number of vector instructions it issues, and 46 % of them are not FMAs)
+        constexpr int PW = (GW + 1) / 2, NP = GH * PW, NL = (NP + 511) / 512;      // 37 pairs per row (the last one holds column 72 and a spill)
+        float2 raw[NL];
         bool in[NL];
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int e = tid + k * 512;
-            const int r = e / GW, c = e - r * GW;
+            const int r = e / PW, c = 2 * (e - r * PW);
             const int gy = 4 * Y4 - 6 + r, gx = 4 * X4 - 6 + c;
-            in[k] = e < G_SZ && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            raw[k] = in[k] ? gb[(size_t)gy * W + gx] : 0.f;
+            in[k] = e < NP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            raw[k] = in[k] ? *reinterpret_cast<const float2*>(gb + (size_t)gy * W + gx) : make_float2(0.f, 0.f);
         }
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int e = tid + k * 512;
-            if (e < G_SZ) G[e] = in[k] ? fmaf(raw[k], alpha, beta) : 0.f;
+            if (e < NP) {
+                const int r = e / PW, c = 2 * (e - r * PW);
+                float* g = G + r * GW + c;                   // (row pitch 73: odd rows are only 4-byte aligned -> two dword stores)
+                g[0] = in[k] ? fmaf(raw[k].x, alpha, beta) : 0.f;
+                if (c + 1 < GW || r + 1 == GH) g[1] = in[k] ? fmaf(raw[k].y, alpha, beta) : 0.f;      // (column 73 of rows 0..39 is column 0 of the next row: its own pair writes it)
+            }
         }
     }
     __syncthreads();
@@ -274,6 +283,16 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
 #pragma unroll
         for (int co = 0; co < 4; ++co) C1[co * (C1H * C1W) + e] = acc[co];
     }
+    if (tid >= 384) {       // skip1's 4 x 4 averages, once per output pixel (the second pass of conv1 occupies threads 0..410: these 128 are the least loaded;
+                            // round 2 had each of stage 4's four cout groups recompute them: 16 LDS reads + 16 adds per thread)
+        const int p = tid - 384, r = p >> 4, c = p & 15;
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) sm += G[(4 * r + 6 + i) * GW + 4 * c + 6 + jj];
+        SK[p] = sm * 0.0625f;
+    }
     __syncthreads();
 
     // ---- stage 2: conv2 4->8, s2 --------------------------------------------------------------
@@ -359,13 +378,8 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
                     for (int j = 0; j < 6; ++j) acc[j] = fmaf(v, w[j], acc[j]);
                 }
         }
-        // skip1: 4x4 average of the gray tile (AvgPool2d(4,4)), then 1x1 conv 1->24 with bias
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s += G[(4 * r + 6 + i) * GW + 4 * c + 6 + j];
-        const float sk = s * 0.0625f;
+        // skip1: 4x4 average of the gray tile (AvgPool2d(4,4), computed once in stage 1), then 1x1 conv 1->24 with bias
+        const float sk = SK[p];
         if (oy < H4 && ox < W4) {
             float* op = x1 + (((size_t)b * 24 + g * 6) * H4 + oy) * W4 + ox;
 #pragma unroll
@@ -417,9 +431,17 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     // conv1 on three adjacent pixels per thread: 275 -> 266 us in alternating in-run pairs (PMC: the kernel issues VALU instructions 76 % of the
     // time and only 54 % of them are FMAs -- index arithmetic, bounds and LDS addresses are the rest, and conv1 has the fewest FMAs per index).
     // Mode 4 writes the same three pixels as 2-vectors so that hipcc emits 54 v_pk_fma_f32 per item instead of 108 v_fmac_f32 (-108 of ~1400 VALU
-    // instructions per thread); rocprof 280.5 us against 289.4 us for mode 3 on two comparable boxes, full GPU suite green with it as the default --
-    // no alternating in-run pair could be run any more in round 2, so it stays opt-in until one has been.
-    const int c1 = (variant == 1 || variant == 4) ? variant : 3;      // option "block1": 1 = one pixel per thread; 4 = three pixels on packed FMAs; default 3: three pixels, scalar FMAs
+    // instructions per thread); rocprof 280.5 us against 289.4 us for mode 3 on two comparable boxes in round 2; the default since round 3.
+    //
+    // Round 3, measured and removed: conv3 + conv4 (70 % of the FLOPs, 5.8 k of the kernel's 12.1 k vector wave-instructions per tile) on
+    // v_mfma_f32_16x16x4_f32 -- conv3 as N = 16 = two adjacent pixels x 8 couts over the union of their windows (K = 8 x 3 x 4 = 96, 72 used),
+    // conv4 as two 16-wide cout blocks with K = 72; every A operand one ds_read_b32 at base(lane) + constant(step), B operands packed per step
+    // and lane by the host, results back through LDS.  Parity-green on the first run (backbone / census tests), and 330 us against 283: an f32 MFMA
+    // has the FLOP rate of the packed vector FMA, so the matrix stages take the cycles the vector stages took (6.0 k vs 5.8 k per SIMD and tile, 19
+    // blocks on 8 waves), the two workgroups of a CU run their stages in phase (no matrix / vector overlap to collect), and the extra barrier
+    // and LDS round trip come on top.  What the vector pipe is short of is issue slots (PMC: 116 M vector instructions, 54 % FMAs, inner loops
+    // already 95 % v_pk_fma_f32) -- the remaining lever is the per-item prologue / epilogue arithmetic of the stages, not another pipe.
+    const int c1 = (variant == 1 || variant == 3) ? variant : 4;      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; default (0 / 4): three pixels on packed FMAs
     static unsigned attr1 = 0, attr3 = 0, attr4 = 0;
 #define XFH_B1_LAUNCH(MODE, ATTR)                                                                                                       \
     {                                                                                                                                    \
