@@ -87,3 +87,34 @@ def test_two_process_gloo_sharding_and_timing_protocol():
         assert tot == float(sum(i * i for i in range(n)))
         assert n_calls == 5 and armed == 2           # exactly warmup + steps calls; the hook ran between them
         assert abs(rate - 32 * 3 * 2 / tmax) < 1e-9  # whole-job units / max time
+
+
+def test_bench_launches_its_own_ranks_and_never_underreports(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher re-runs itself as two ranks under torch.distributed.run (it used to run one
+    rank and print n_gpus = 1).  --launch-selftest swaps RCCL / the hot path for gloo / a sleep so that the launch path itself runs here;
+    without it, on a box with fewer GPUs than asked for, the command must refuse loudly instead of printing a line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]                      # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["selftest"] is True
+    assert d["ms_per_step"] >= 19.0                               # the slow rank (20 ms sleeps) sets the time: MAX over ranks
+    # the real workload on this GPU-less box: refuse, do not report
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        return                                                    # (a multi-GPU box would really run it)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "refusing to run" in (r.stderr + r.stdout)
+    # a launcher whose world size disagrees with --gpus is an error too
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-selftest"], capture_output=True, text=True, timeout=120,
+                       env={**env, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, cwd=str(tmp_path))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
