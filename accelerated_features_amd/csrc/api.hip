@@ -207,6 +207,7 @@ static size_t carve_match(void* ws, int P, int N1, int N2, MatchWs& o) {
     o.rowkey = c.take<unsigned long long>((size_t)P * N1);
     o.colkey = c.take<unsigned long long>((size_t)P * N2);
     o.rowmaxh = c.take<unsigned>((size_t)P * N1);
+    o.colmaxh = c.take<unsigned>((size_t)P * N2);
     o.nmax = c.take<unsigned>((size_t)2 * P);
     o.zeroed = ws ? (char*)ws + z0 : nullptr;
     o.zeroed_bytes = c.off - z0;

@@ -162,23 +162,23 @@ __device__ inline PairWindow pair_window(float unit_bound, const unsigned* __res
 // MFMA time + VALU time, the pipe 53 % busy: profiles/r03_*):
 //     A:  acc  = a . b            (lane = column)                        |  B:  accT = b . a  (lane = row)  ||  column epilogue of acc
 //     then the fragments of the next tile leave LDS                       ||  row epilogue of accT
-//   thr_col (P,N2)      : colmax^_j - 2 E'_j         (scaled units; the workgroup sees whole columns)
+//   colmaxh (P,N2) u32  : ord(column maximum), 32-bit atomic max across the row shares (zeroed by the caller)
 //   rowmaxh (P,N1) u32  : ord(row maximum), 32-bit atomic max across the column-chunk workgroups (zeroed by the caller)
 //   R (P, ceil(N2/32), N1), C (P, ceil(N1/32), N2) : block maxima
 constexpr int FT_TILES = FT_COLS / 32;
 __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __restrict__ a16, size_t sa16, const _Float16* __restrict__ b16, size_t sb16,
-                                                            float unit_bound /* > 0: caller-provided copies of unit-norm rows (na / nb / nmax unused) */,
                                                             const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
-                                                            int N1, int N2, int ncc, int P, const float* __restrict__ nb, const unsigned* __restrict__ nmax,
-                                                            float* __restrict__ thr_col, unsigned* __restrict__ rowmaxh,
+                                                            int N1, int N2, int ncc, int nsplit, int P,
+                                                            unsigned* __restrict__ colmaxh, unsigned* __restrict__ rowmaxh,
                                                             float* __restrict__ R, float* __restrict__ C) {
     __shared__ __attribute__((aligned(16))) _Float16 Dl[FT_COLS * FT_DS];      // the columns
     __shared__ float colx[8][FT_COLS];                                          // per wave: running column maxima (ds_max_f32, no return)
     __shared__ int next_block;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int p, cc;
-    if (!xcd_group_map(blockIdx.x, ncc, P, p, cc)) return;
+    int p, item;
+    if (!xcd_group_map(blockIdx.x, ncc * nsplit, P, p, item)) return;
+    const int cc = item / nsplit, rs = item - cc * nsplit;     // column chunk, and which share of the row blocks (few pairs: more workgroups)
     const int n1 = fpair_count(n1p, p * n_stride, N1);
     const int n2 = fpair_count(n2p, p * n_stride + n_off2, N2);
     const int c0 = cc * FT_COLS;
@@ -187,8 +187,10 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
     const _Float16* Bm = b16 + (size_t)p * sb16;
     const int ncb32 = ceil_div(N2, 32), nrb32 = ceil_div(N1, 32);
     const int ntile = min(FT_TILES, ceil_div(n2 - c0, 32));
-    const int nblock = ceil_div(n1, 32);
-    if (tid == 0) next_block = 8;                          // blocks 0..7: one per wave to start with
+    const int bps = ceil_div(ceil_div(n1, 32), nsplit);     // row blocks per share
+    const int blk_lo = rs * bps, nblock = min(ceil_div(n1, 32), blk_lo + bps);
+    if (blk_lo >= nblock) return;
+    if (tid == 0) next_block = blk_lo + 8;                 // the first eight blocks: one per wave to start with
     {   // 256 columns x 64 fp16 = 2048 16-byte pieces, four per thread, all in flight; columns >= n2: copies of the last valid column
         uint4 v[4];
 #pragma unroll
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
         for (int i = 0; i < 4; ++i) (&colx[0][0])[tid + i * 512] = -INFINITY;
     }
     f16x8 a[4], an[4];
-    int blk = wave, nxt;
+    int blk = blk_lo + wave, nxt;
     if (blk < nblock) {
         const int row = min(blk * 32 + l31, n1 - 1);       // rows >= n1: copies of the last valid row (never reported)
 #pragma unroll
@@ -292,43 +294,31 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
         if (half == 0 && myrow < n1) atomicMax(&rowmaxh[(size_t)p * N1 + myrow], float_ord(rowrun));      // (no return value: fire and forget)
         blk = nxt;
     }
-    // column maxima: across the 8 waves, then the thresholds
+    // column maxima: across the 8 waves, then across the row shares by 32-bit atomic max (the thresholds follow in mnn_f16_thr_kernel)
     __syncthreads();
     if (tid < FT_COLS && c0 + tid < n2) {
         float k = colx[0][tid];
 #pragma unroll
         for (int w = 1; w < 8; ++w) k = fmaxf(k, colx[w][tid]);
-        const PairWindow w = pair_window(unit_bound, nmax, P, p, false);
-        const float nx = unit_bound > 0.f ? unit_bound : nb[(size_t)p * N2 + c0 + tid];
-        thr_col[(size_t)p * N2 + c0 + tid] = k - fmaf(w.two_c, nx, w.two_k);
+        atomicMax(&colmaxh[(size_t)p * N2 + c0 + tid], float_ord(k));
     }
 }
 
-// Exact refine.  ONE WAVE per (pair, side, yb), no barriers.  Phase 1: the wave walks its block maxima against their thresholds, 512 per
-// round with the next round's loads in flight, and queues the x whose block maximum reaches its threshold (wave-private LDS queue).
-// Phase 2: the queued x, 32 at a time, against the 32 rows yb*32.. of the OTHER set (Y) on v_mfma_f32_32x32x2_f32 -- an exact fp32 fma
-// chain per similarity, in the channel order of the exact kernel (k_match.hip), so both paths produce the same bits -- folded into
-// key[x] = max (ord(S) << 32 | ~y), ties to the lowest y.
-//   side 0: x = rows of D1 (keys: row arg-max), Y = D2, block maxima R, thresholds from rowmaxh
-//   side 1: x = rows of D2 (keys: column arg-max), Y = D1, block maxima C, thresholds thr_col
-// Workgroups of four such waves only share the launch.  What was measured on the way (B = 64 VGA bench, 32 pairs of 4096 x 4096):
-// a workgroup per yb with barriers between its phases 102 us; a wave per yb with the dot products on the vector ALUs (two x per step, one
-// per half-wave, 64 FMAs + a DPP arg-max each) 84 us -- 24 M vector instructions per launch, issue-bound; on the matrix cores the same
-// ~280 k x 32 similarities are 32 MFMAs per 32 x: 60 us, of which the scan is 27 (latency: two rounds of 16-byte loads in flight per
-// wave), the row gathers / LDS transposes / epilogues 22 and the MFMA chains 11 (ablation builds, profiles/README.md).
-constexpr int RF_ROUND = 512;      // x per scan round
-constexpr int RF_CHUNK = 4096;     // x per queue fill
-// thresholds of the row side, once the row maxima are complete: thr_row = rowmax^ - 2 E (scaled units)
-__global__ __launch_bounds__(256) void mnn_f16_thr_row_kernel(float unit_bound, const int32_t* __restrict__ n1p, int n_stride, int N1, int P,
-                                                              const float* __restrict__ na, const unsigned* __restrict__ nmax,
-                                                              const unsigned* __restrict__ rowmaxh, float* __restrict__ thr_row) {
-    const int p = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= fpair_count(n1p, p * n_stride, N1)) return;
-    const PairWindow w = pair_window(unit_bound, nmax, P, p, true);
-    const float nx = unit_bound > 0.f ? unit_bound : na[(size_t)p * N1 + i];
-    thr_row[(size_t)p * N1 + i] = ord_float(rowmaxh[(size_t)p * N1 + i]) - fmaf(w.two_c, nx, w.two_k);
+// thresholds, once the maxima are complete: thr = max^ - 2 E (scaled units).  grid (ceil(max(N1,N2)/256), P, 2 sides)
+__global__ __launch_bounds__(256) void mnn_f16_thr_kernel(float unit_bound, const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
+                                                          int N1, int N2, int P, const float* __restrict__ na, const float* __restrict__ nb,
+                                                          const unsigned* __restrict__ nmax, const unsigned* __restrict__ rowmaxh, const unsigned* __restrict__ colmaxh,
+                                                          float* __restrict__ thr_row, float* __restrict__ thr_col) {
+    const int p = blockIdx.y, side = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+    const int N = side ? N2 : N1;
+    if (i >= (side ? fpair_count(n2p, p * n_stride + n_off2, N2) : fpair_count(n1p, p * n_stride, N1))) return;
+    const PairWindow w = pair_window(unit_bound, nmax, P, p, side == 0);
+    const float nx = unit_bound > 0.f ? unit_bound : (side ? nb : na)[(size_t)p * N + i];
+    (side ? thr_col : thr_row)[(size_t)p * N + i] = ord_float((side ? colmaxh : rowmaxh)[(size_t)p * N + i]) - fmaf(w.two_c, nx, w.two_k);
 }
 
+constexpr int RF_ROUND = 512;      // x per scan round
+constexpr int RF_CHUNK = 4096;     // x per pass over the block maxima
 constexpr int RF_QUEUE = 1024;     // queue capacity per wave; it is drained before a scan round (<= 512 new entries) could overflow it
 constexpr int RF_XS = 68;          // LDS row stride of the 32 x 64 tile in floats (272 bytes = 17 x 16: conflict-free 16-byte reads down a column of rows)
 constexpr int RF_WAVES = 2;        // waves (= Y blocks) per workgroup
@@ -488,12 +478,15 @@ void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const floa
     }
     prof_begin(prof, XFH_SPAN_MATCH_SWEEP, st);
     const int ncc = ceil_div(N2, FT_COLS);
-    mnn_f16_sweep_kernel<<<xcd_grid_size(ncc, P), 512, 0, st>>>(a16, sa, b16, sb, ub, n1, n2, n_stride, n_off2, N1, N2, ncc, P, ws.nb, ws.nmax,
-                                                               ws.thr_col, ws.rowmaxh, ws.R, ws.C);
+    // two workgroups per CU fill the chip; with few pairs the row blocks of a column chunk are shared out over more workgroups (>= 8 blocks each)
+    const int nsplit = max(1, min(ceil_div(2 * num_cus(), ncc * P), ceil_div(N1, 256)));
+    mnn_f16_sweep_kernel<<<xcd_grid_size(ncc * nsplit, P), 512, 0, st>>>(a16, sa, b16, sb, n1, n2, n_stride, n_off2, N1, N2, ncc, nsplit, P,
+                                                                        ws.colmaxh, ws.rowmaxh, ws.R, ws.C);
     prof_end(prof, XFH_SPAN_MATCH_SWEEP, st, 0, 0);
     const int nyb = ceil_div(ceil_div(N1 > N2 ? N1 : N2, 32), RF_WAVES) * RF_WAVES;
     prof_begin(prof, XFH_SPAN_MATCH_REFINE, st);
-    mnn_f16_thr_row_kernel<<<dim3(ceil_div(N1, 256), P), 256, 0, st>>>(ub, n1, n_stride, N1, P, ws.na, ws.nmax, ws.rowmaxh, ws.thr_row);
+    mnn_f16_thr_kernel<<<dim3(ceil_div(N1 > N2 ? N1 : N2, 256), P, 2), 256, 0, st>>>(ub, n1, n2, n_stride, n_off2, N1, N2, P, ws.na, ws.nb, ws.nmax, ws.rowmaxh, ws.colmaxh,
+                                                                                        ws.thr_row, ws.thr_col);
     mnn_f16_refine_kernel<<<xcd_grid_size(2 * (nyb / RF_WAVES), P), 64 * RF_WAVES, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nyb, P,
                                                                           ws.thr_row, ws.thr_col, ws.R, ws.C, ws.rowkey, ws.colkey);
     prof_end(prof, XFH_SPAN_MATCH_REFINE, st, 0, 0);

@@ -151,11 +151,11 @@ void launch_dense_gather(const float* feats, const unsigned long long* skeys, in
 
 // ---- k_match.hip ------------------------------------------------------------------------
 struct MatchWs {
-    // zero-initialised per call (one memset): [rowkey | colkey | rowmaxh | nmax]
+    // zero-initialised per call (one memset): [rowkey | colkey | rowmaxh | colmaxh | nmax]
     void* zeroed; size_t zeroed_bytes;
     unsigned long long* rowkey;    // (P,N1) packed (ord(sim)<<32 | ~col): row arg-max, folded by 64-bit atomic max
     unsigned long long* colkey;    // (P,N2) packed (ord(sim)<<32 | ~row): column arg-max
-    unsigned* rowmaxh;             // (P,N1) ord(row maximum of the fp16 product), 32-bit atomic max across the column-chunk workgroups
+    unsigned *rowmaxh, *colmaxh;   // (P,N1), (P,N2) ord(row / column maximum of the fp16 product), 32-bit atomic max across the sweep's workgroups
     unsigned* nmax;                // (2,P)  bit patterns of max |d1_i|, max |d2_j|
     // filter-and-refine scratch (k_match_f16.hip)
     _Float16 *a16, *b16;           // (P,N1,64), (P,N2,64) scaled fp16 copies
