@@ -524,6 +524,11 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     int cx[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) cx[i] = (x0 + i >= 0 && x0 + i < wc) ? x0 + i : 0x00800000;      // 2^23 pixels = byte offset 2^31: outside any map, no 32-bit wrap
+    // 1 / |feats| of the 16 taps: lane `sub` fetches tap `sub`'s factor (ONE load instruction per key-point group instead of sixteen
+    // broadcast loads: the kernel is bound by the number of vector-memory instructions the texture addresser has to walk, not by misses --
+    // visiting the key-points in spatial instead of score order left its time unchanged), handed round by ds_bpermute below
+    const float inv_mine = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ri, ((y0 + (sub >> 2)) * wc + cx[sub & 3]) * 4, 0, 0));
+    const int lane_base = (threadIdx.x & 63) & ~15;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -534,7 +539,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
             const int pix = rowpix + cx[i];
             const uint4 u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rf, pix * 256 + sub * 16, 0, 0));
             const float4 v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-            const float sc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ri, pix * 4, 0, 0));
+            const float sc = __shfl(inv_mine, lane_base + 4 * r + i, 64);
             row.x += (v.x * sc) * wx[i]; row.y += (v.y * sc) * wx[i];
             row.z += (v.z * sc) * wx[i]; row.w += (v.w * sc) * wx[i];
         }

@@ -193,3 +193,44 @@ def test_star_1024_batch_pair_vs_oracle(xf, sd):
     m0, m1 = xf.match_xfeat_star(a[:1].cuda(), b[:1].cuda(), top_k=4096)     # B == 1: the numpy tuple, like the reference
     assert isinstance(m0, np.ndarray) and m0.shape == m1.shape and m0.shape[1] == 2
     assert np.allclose(np.concatenate([m0, m1], 1), res[0].cpu().numpy())
+
+
+# ----------------------------------------------------------------------------------------------
+# configs[3]: the MegaDepth-1500 sizes at long side 1600 (modules/eval/megadepth1500.py:49-56)
+# ----------------------------------------------------------------------------------------------
+def test_config3_megadepth_sizes_through_match_pairs_vs_oracle(xf, sd):
+    """The three most frequent size pairs of the MegaDepth-1500 list at long side 1600 -- (1152,1600)x2 (229 pairs), (1184,1600)x2 (166),
+    (1152,1600)/(1184,1600) (121) -- plus the most frequent pair with a 1024-row image (104), as uint8 images through
+    accelerated_features_amd.batching.match_pairs (the call `bench.py --workload megadepth` times), against the oracle's match_xfeat pair by
+    pair: key-points with their exception accounting, match pairs as coordinates with explained ties only."""
+    _threads()
+    from accelerated_features_amd import sharding
+    from accelerated_features_amd.batching import match_pairs
+    sizes, _ = sharding.megadepth_pair_sizes()
+    from collections import Counter
+    top = [p for p, _n in Counter(sizes).most_common(5)]
+    want = top[:3] + [p for p in top if 1024 in (p[0][0], p[1][0])][:1]
+    assert ((1152, 1600), (1152, 1600)) in want and len(want) >= 3
+    big = (fixtures.texture_images(2, 1600, 1600, seed=31) * 255).round().clamp(0, 255).to(torch.uint8)
+    pairs = []
+    for i, (a, b) in enumerate(want):
+        ia = big[0, :, :a[0], :a[1]].contiguous()
+        ib = torch.roll(big[0], (8 + 3 * i, 16), (1, 2))[:, :b[0], :b[1]].contiguous()      # the same texture shifted: genuine matches
+        pairs.append((ia, ib))
+    got = match_pairs(xf, [(a.cuda(), b.cuda()) for a, b in pairs], top_k=4096, min_cossim=-1, max_pairs=16)
+    hist = {"pairs": 0, "rows": 0, "differing": 0, "kpt_exceptions": 0}
+    for (m0, m1), (ia, ib) in zip(got, pairs):
+        r0, r1, _i0, _i1 = O.match_xfeat(sd, ia[None], ib[None], top_k=4096)
+        oa, sta = O.detect_and_compute(sd, ia[None].float(), top_k=4096, keep=True)
+        ob, stb = O.detect_and_compute(sd, ib[None].float(), top_k=4096, keep=True)
+        for img, (orc, st) in ((ia, (oa, sta)), (ib, (ob, stb))):
+            mine = xf.detectAndCompute(img[None].cuda(), top_k=4096)[0]
+            rep = parity.compare_keypoints(mine, orc[0], heat=st["heat"][0, 0])
+            hist["kpt_exceptions"] += rep["exceptions"]
+            assert rep["n_test"] == 4096 and rep["n_ref"] == 4096
+        ctx = {"kp0": oa[0]["keypoints"], "kp1": ob[0]["keypoints"], "d0": oa[0]["descriptors"], "d1": ob[0]["descriptors"]}
+        rep = parity.compare_matches(m0, m1, r0, r1, ctx)
+        hist["pairs"] += 1; hist["rows"] += rep["n_ref"]; hist["differing"] += rep["differing_rows"]
+        assert rep["n_ref"] > 300, rep
+    print("MEGADEPTH SIZES", [tuple(p) for p in want], hist)
+    assert hist["pairs"] == len(want) and hist["differing"] <= 2 * len(want) and hist["kpt_exceptions"] <= 2 * len(want), hist

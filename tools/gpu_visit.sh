@@ -6,8 +6,8 @@ TAG=${1:-visit}; shift
 mkdir -p gpurun_out/$TAG
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider "$@" > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 tail -30 gpurun_out/$TAG/pytest_gpu.log | grep -v amdgpu.ids
-timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 2>&1 | grep -v amdgpu.ids | tee gpurun_out/$TAG/bench.log | tail -3
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/$TAG/prof" -o it --output-format csv -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --cpu-seconds 0 > "$OLDPWD/gpurun_out/$TAG/rocprof.log" 2>&1); echo "rocprof rc=$?"
+timeout 600 python bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-side-passes 2>&1 | grep -v amdgpu.ids | tee gpurun_out/$TAG/bench.log | tail -3
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/$TAG/prof" -o it --output-format csv -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --cpu-seconds 0 --no-side-passes > "$OLDPWD/gpurun_out/$TAG/rocprof.log" 2>&1); echo "rocprof rc=$?"
 find gpurun_out/$TAG/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/$TAG/kernel_stats.csv
 python - <<PY
 import csv
