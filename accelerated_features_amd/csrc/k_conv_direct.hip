@@ -128,9 +128,13 @@ constexpr int C1_OFF = SK_OFF + SK_SZ, C1_SZ = 4 * C1H * C1W;  // 11076
 constexpr int C2_OFF = C1_OFF + C1_SZ, C2_SZ = 8 * C2H * C2W;  // 5320
 constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead once c2 exists)
 constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19518 floats = 78.1 KB
+// mode 5 (conv1 recomputed inside conv2, no c1 tile): g | sk | c2 | c3 = 51.7 KB -> three workgroups per CU.  (c3 over the dead gray tile
+// = 39.7 KB = four per CU measured 0.947 of mode 4's time against 0.924 for three: more waves than the LDS pipe and L1 feed.)
+constexpr int F_SK_OFF = SK_OFF, F_C2_OFF = SK_OFF + SK_SZ, F_C3_OFF = F_C2_OFF + C2_SZ, F_LDS_FLOATS = F_C3_OFF + 8 * C3H * C3W;      // 12930 floats
 }  // namespace b1
 
-template <int C1MODE>      // conv1: 1 = a pixel per thread, 3 = three adjacent pixels (scalar FMAs), 4 = three adjacent pixels on packed FMAs
+template <int C1MODE>      // conv1: 1 = a pixel per thread, 3 = three adjacent pixels (scalar FMAs), 4 = three adjacent pixels on packed FMAs,
+                           // 5 = recomputed from the gray tile inside conv2 (no c1 tile in LDS)
 __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int B, int H, int W,
                                                            int tiles_x, int tiles_y,
                                                            const float* __restrict__ w1, const float* __restrict__ bb1,
@@ -141,10 +145,10 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     using namespace b1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* G = lds + G_OFF;
-    float* SK = lds + SK_OFF;
+    float* SK = lds + (C1MODE == 5 ? F_SK_OFF : SK_OFF);
     float* C1 = lds + C1_OFF;
-    float* C2 = lds + C2_OFF;
-    float* C3 = lds + C3_OFF;
+    float* C2 = lds + (C1MODE == 5 ? F_C2_OFF : C2_OFF);
+    float* C3 = lds + (C1MODE == 5 ? F_C3_OFF : C3_OFF);
     const int tid = threadIdx.x;
     // the tiles of an image run on one XCD: the 4-pixel gray halos of neighbouring tiles hit its L2
     int b, item;
@@ -183,7 +187,9 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
     __syncthreads();
 
     // ---- stage 1: conv1 1->4, s1 --------------------------------------------------------------
-    if constexpr (C1MODE == 4) {
+    if constexpr (C1MODE == 5) {
+        // (no c1 tile: stage 2 recomputes the nine c1 pixels of its window from the gray tile)
+    } else if constexpr (C1MODE == 4) {
         // three adjacent pixels per thread, cout pairs on v_pk_fma_f32 (written as 2-vectors: left to itself hipcc emits 108 v_fmac_f32 here)
         typedef float f2 __attribute__((ext_vector_type(2)));
         constexpr int NG = (C1W + 2) / 3;
@@ -293,9 +299,67 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
             for (int jj = 0; jj < 4; ++jj) sm += G[(4 * r + 6 + i) * GW + 4 * c + 6 + jj];
         SK[p] = sm * 0.0625f;
     }
-    __syncthreads();
+    if constexpr (C1MODE != 5) __syncthreads();
 
     // ---- stage 2: conv2 4->8, s2 --------------------------------------------------------------
+    if constexpr (C1MODE == 5) {
+        // conv1 inside conv2: a c2 pixel needs the 3 x 3 c1 pixels (2r + py, 2c + px), each a 3 x 3 window of the gray tile: 25 LDS reads
+        // and 9 x 36 FMAs in registers instead of 36 reads of a c1 tile that first had to be computed, written (44 KB of LDS, the largest
+        // tile of the kernel) and waited for behind a barrier.  2.25x the conv1 FLOPs (+ 12 % of the kernel's), one stage and 26 KB less.
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        for (int e = tid; e < C2H * C2W; e += 512) {
+            const int r = e / C2W, c = e - r * C2W;
+            const int gy = 2 * Y4 - 2 + r, gx = 2 * X4 - 2 + c;
+            float acc[8];
+#pragma unroll
+            for (int co = 0; co < 8; ++co) acc[co] = 0.f;
+            if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
+                float g[5][5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) g[i][j] = G[(2 * r + i) * GW + 2 * c + j];
+                // c1[py][px][ch]: ReLU(conv1), zero outside the full-resolution map (= conv2's zero padding)
+                f2 c1v[3][3][2];
+#pragma unroll
+                for (int py = 0; py < 3; ++py)
+#pragma unroll
+                    for (int px = 0; px < 3; ++px) {
+                        f2 a01 = f2{bb1[0], bb1[1]}, a23 = f2{bb1[2], bb1[3]};
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const float* w = w1 + (dy * 3 + dx) * 4;
+                                const f2 vv = f2{g[py + dy][px + dx], g[py + dy][px + dx]};
+                                a01 = __builtin_elementwise_fma(vv, f2{w[0], w[1]}, a01);
+                                a23 = __builtin_elementwise_fma(vv, f2{w[2], w[3]}, a23);
+                            }
+                        const int y1 = 4 * Y4 - 5 + 2 * r + py, x1 = 4 * X4 - 5 + 2 * c + px;
+                        const bool ok = y1 >= 0 && y1 < H && x1 >= 0 && x1 < W;
+                        c1v[py][px][0] = ok ? f2{fmaxf(a01.x, 0.f), fmaxf(a01.y, 0.f)} : f2{0.f, 0.f};
+                        c1v[py][px][1] = ok ? f2{fmaxf(a23.x, 0.f), fmaxf(a23.y, 0.f)} : f2{0.f, 0.f};
+                    }
+#pragma unroll
+                for (int co = 0; co < 8; ++co) acc[co] = bb2[co];
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+                    for (int py = 0; py < 3; ++py)
+#pragma unroll
+                        for (int px = 0; px < 3; ++px) {
+                            const float v = ci & 1 ? c1v[py][px][ci >> 1].y : c1v[py][px][ci >> 1].x;
+                            const float* w = w2 + ((ci * 9) + py * 3 + px) * 8;
+#pragma unroll
+                            for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, w[co], acc[co]);
+                        }
+#pragma unroll
+                for (int co = 0; co < 8; ++co) acc[co] = fmaxf(acc[co], 0.f);
+            }
+#pragma unroll
+            for (int co = 0; co < 8; ++co) C2[co * (C2H * C2W) + e] = acc[co];
+        }
+    } else
     for (int e = tid; e < C2H * C2W; e += 512) {
         const int r = e / C2W, c = e - r * C2W;
         const int gy = 2 * Y4 - 2 + r, gx = 2 * X4 - 2 + c;
@@ -431,7 +495,10 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     // conv1 on three adjacent pixels per thread: 275 -> 266 us in alternating in-run pairs (PMC: the kernel issues VALU instructions 76 % of the
     // time and only 54 % of them are FMAs -- index arithmetic, bounds and LDS addresses are the rest, and conv1 has the fewest FMAs per index).
     // Mode 4 writes the same three pixels as 2-vectors so that hipcc emits 54 v_pk_fma_f32 per item instead of 108 v_fmac_f32 (-108 of ~1400 VALU
-    // instructions per thread); rocprof 280.5 us against 289.4 us for mode 3 on two comparable boxes in round 2; the default since round 3.
+    // instructions per thread); rocprof 280.5 us against 289.4 us for mode 3 on two comparable boxes in round 2.
+    // Mode 5 (the default since round 3) drops the c1 tile altogether: conv2 recomputes its nine c1 pixels from 25 gray values in registers.
+    // + 12 % FLOPs, but one stage, one barrier and 26 KB of LDS less: three workgroups per CU instead of two.  In-run A/B (tools/ab_option.py,
+    // alternating rounds on one box): 264.5 / 262.9 / 262.3 -> 244.8 / 241.8 / 242.7 us, step 1.788 -> 1.753 ms.
     //
     // Round 3, measured and removed: conv3 + conv4 (70 % of the FLOPs, 5.8 k of the kernel's 12.1 k vector wave-instructions per tile) on
     // v_mfma_f32_16x16x4_f32 -- conv3 as N = 16 = two adjacent pixels x 8 couts over the union of their windows (K = 8 x 3 x 4 = 96, 72 used),
@@ -441,16 +508,18 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     // blocks on 8 waves), the two workgroups of a CU run their stages in phase (no matrix / vector overlap to collect), and the extra barrier
     // and LDS round trip come on top.  What the vector pipe is short of is issue slots (PMC: 116 M vector instructions, 54 % FMAs, inner loops
     // already 95 % v_pk_fma_f32) -- the remaining lever is the per-item prologue / epilogue arithmetic of the stages, not another pipe.
-    const int c1 = (variant == 1 || variant == 3) ? variant : 4;      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; default (0 / 4): three pixels on packed FMAs
-    static unsigned attr1 = 0, attr3 = 0, attr4 = 0;
+    const int c1 = (variant == 1 || variant == 3 || variant == 4) ? variant : 5;      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; default (0 / 4): three pixels on packed FMAs
+    static unsigned attr1 = 0, attr3 = 0, attr4 = 0, attr5 = 0;
 #define XFH_B1_LAUNCH(MODE, ATTR)                                                                                                       \
     {                                                                                                                                    \
-        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<MODE>), b1::LDS_FLOATS * 4, ATTR);                         \
-        block1_fused_kernel<MODE><<<xcd_grid_size(tx * ty, B), 512, b1::LDS_FLOATS * 4, st>>>(                                           \
+        constexpr int lds_floats = MODE == 5 ? b1::F_LDS_FLOATS : b1::LDS_FLOATS;                                                        \
+        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<MODE>), lds_floats * 4, ATTR);                             \
+        block1_fused_kernel<MODE><<<xcd_grid_size(tx * ty, B), 512, lds_floats * 4, st>>>(                                               \
             gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias); \
     }
     if (c1 == 1) XFH_B1_LAUNCH(1, attr1)
     else if (c1 == 3) XFH_B1_LAUNCH(3, attr3)
+    else if (c1 == 5) XFH_B1_LAUNCH(5, attr5)
     else XFH_B1_LAUNCH(4, attr4)
 #undef XFH_B1_LAUNCH
 }

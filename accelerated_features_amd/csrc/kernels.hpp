@@ -50,7 +50,7 @@ struct Options {
     int wino = 2;           // 0: 3x3/s1 layers never use Winograd; 1: only unfused layers; 2: fused 3x3 + 1x1 pairs too
     int bx = 5;             // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0
     int heads_f32 = 0;      // 1: heads on the f32-MFMA kernels
-    int block1 = 0;         // block1's conv1: 0 = shipped (three adjacent pixels per thread on packed FMAs = 4); 1 = one pixel per thread; 3 = three pixels, scalar FMAs
+    int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs
     int pyramid_fused = 1;  // 1: x3 + up(x4) + up(x5) is formed inside block_fusion.0's tile staging (no pyramid_sum pass)
 };
 

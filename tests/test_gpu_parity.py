@@ -126,7 +126,7 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
 
 
-@pytest.mark.parametrize("opts", [{"heads_f32": 1, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0, "pyramid_fused": 0}, {"block1": 0, "pyramid_fused": 1}])
+@pytest.mark.parametrize("opts", [{"heads_f32": 1, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0, "pyramid_fused": 0}, {"block1": 4, "pyramid_fused": 1}])
 def test_backbone_alternative_kernels_same_results(opts, sd):
     """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on f32 MFMAs, 24->24 layers on Winograd; every
     unfused 64->64 layer on the split-bf16 kernel; direct implicit GEMM instead of Winograd; the pyramid sum as its own pass): the small golden
