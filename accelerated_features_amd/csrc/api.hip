@@ -901,7 +901,7 @@ int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 15},
-        {"heads_f32", &Options::heads_f32, 0, 1}, {"block1", &Options::block1, 0, 15}, {"pyramid_fused", &Options::pyramid_fused, 0, 1}};
+        {"heads_f32", &Options::heads_f32, 0, 1}, {"block1", &Options::block1, 0, 15}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

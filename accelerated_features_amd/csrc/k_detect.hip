@@ -17,57 +17,60 @@ namespace xfh {
 // ------------------------------------------------------------------------------------------
 // NMS flags: pixel is kept iff heat > thr and no pixel of its 5x5 window (implicit -inf
 // padding) is larger (== local max; plateaus keep every equal pixel).
-// One workgroup = 64 x 32 pixels: the (64+4) x (32+4) tile is staged in LDS once, every lane
-// owns one column and slides a 5-row window of horizontal 5-maxima down its 8 rows
-// (5 LDS reads per row instead of 25 global loads).  1-D grid, XCD-grouped by image.
+// 1-D grid, XCD-grouped by image.
 // ------------------------------------------------------------------------------------------
-constexpr int NMS_TW = 64, NMS_TH = 32, NMS_LW = NMS_TW + 4, NMS_LH = NMS_TH + 4;
+// Round 3: no LDS tile, no barrier.  A WAVE owns 64 columns x NMS_RB rows: every lane loads its column of the NMS_RB + 4 input rows (all loads in
+// flight at once), lanes 0..3 the four halo columns; the 5 x 5 maximum is a vertical v_max3 pair per row and a horizontal pass through
+// whole-wave DPP shifts (wave_shr / wave_shl by one lane, twice), the halo maxima entering at lanes 0 / 63 as the shifts' `old` operand.
+// ~22 vector instructions per 64 pixels; the LDS version (36 x 68 tile, five LDS reads per horizontal maximum, a barrier per tile) ran at
+// 2.5 TB/s.  Any width (scalar loads).
+constexpr int NMS_RB = 16, NMS_TH = NMS_RB;
+__device__ inline float dpp_wave_shr1(float v, float old) {      // lane i <- lane i - 1, lane 0 <- old
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ inline float dpp_wave_shl1(float v, float old) {      // lane i <- lane i + 1, lane 63 <- old
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
 __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict__ heat, int B, int H, int W, int WPR, int HT, float thr,
                                                         unsigned long long* __restrict__ mask, int* __restrict__ wcount) {
-    __shared__ __attribute__((aligned(8))) float tile[NMS_LH * NMS_LW];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // all tiles of an image on one XCD: the 2-pixel halos of neighbouring tiles hit that XCD's L2 (PMC: the plain
-    // (x, y, image) grid fetched every heat map twice)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // all strips of an image on one XCD: the 2-pixel halos of neighbouring strips hit that XCD's L2
     int b, item;
-    if (!xcd_group_map(blockIdx.x, WPR * HT, B, b, item)) return;
-    const int word = item % WPR, y0 = (item / WPR) * NMS_TH;
-    const int x0 = word * 64;
-    const float* hp = heat + (size_t)b * H * W;
-    {   // the tile as 8-byte column pairs (x0 - 2 and W are even: a pair never straddles the image border), all five loads of a thread
-        // in flight together -- as a rolled loop of dword loads hipcc waited for each of the ten round trips in turn
-        constexpr int PW = NMS_LW / 2, NP = NMS_LH * PW, NL = (NP + 255) / 256;
-        float2 v[NL];
+    if (!xcd_group_map(blockIdx.x, ceil_div(WPR * HT, 4), B, b, item)) return;
+    const int unit = item * 4 + wave;
+    if (unit >= WPR * HT) return;
+    const int word = unit % WPR, y0 = (unit / WPR) * NMS_RB;
+    const int x = word * 64 + lane;
+    // halo columns: lane 0 -> x0 - 2, 1 -> x0 - 1, 2 -> x0 + 64, 3 -> x0 + 65 (other lanes: out of range = -inf)
+    const int hx = lane < 2 ? word * 64 - 2 + lane : (lane < 4 ? word * 64 + 62 + lane : -1);
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(heat + (size_t)b * H * W), 0, H * W * 4, 0x00020000);
+    const bool xin = x < W, hin = hx >= 0 && hx < W;
+    float v[NMS_RB + 4], h[NMS_RB + 4];
 #pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            const int e = tid + k * 256;
-            const int r = e / PW, c = e - r * PW;
-            const int gy = y0 - 2 + r, gx = x0 - 2 + 2 * c;
-            v[k] = (e < NP && gy >= 0 && gy < H && gx >= 0 && gx < W) ? *reinterpret_cast<const float2*>(hp + (size_t)gy * W + gx)
-                                                                      : make_float2(-INFINITY, -INFINITY);
-        }
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            const int e = tid + k * 256;
-            if (e < NP) reinterpret_cast<float2*>(tile)[e] = v[k];
-        }
+    for (int r = 0; r < NMS_RB + 4; ++r) {
+        const int gy = y0 - 2 + r;
+        const bool yin = gy >= 0 && gy < H;
+        // (out-of-image: an out-of-range offset would read 0, the padding value is -inf: select after the load)
+        const float a = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, (yin && xin) ? (gy * W + x) * 4 : 0, 0, 0));
+        const float c = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, (yin && hin) ? (gy * W + hx) * 4 : 0, 0, 0));
+        v[r] = (yin && xin) ? a : -INFINITY;
+        h[r] = (yin && hin) ? c : -INFINITY;
     }
-    __syncthreads();
-    // this wave: rows y0 + 8*wave .. +7 ; lane: column x0 + lane
-    const int rbase = 8 * wave;           // tile row of (first output row - 2)
-    float hm[5];
-    auto hmax = [&](int trow) {
-        const float* t = tile + trow * NMS_LW + lane;
-        return fmaxf(fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3])), t[4]);
-    };
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hm[k] = hmax(rbase + k);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        hm[(r + 4) % 5] = hmax(rbase + r + 4);
-        const float m = fmaxf(fmaxf(fmaxf(hm[0], hm[1]), fmaxf(hm[2], hm[3])), hm[4]);
-        const float v = tile[(rbase + r + 2) * NMS_LW + lane + 2];
-        const int y = y0 + 8 * wave + r, x = x0 + lane;
-        const bool cand = (y < H) && (x < W) && (v > thr) && (v == m);
+    for (int r = 0; r < NMS_RB; ++r) {
+        const int y = y0 + r;
+        const float vm = fmaxf(fmaxf(fmaxf(v[r], v[r + 1]), v[r + 2]), fmaxf(v[r + 3], v[r + 4]));
+        const float hm = fmaxf(fmaxf(fmaxf(h[r], h[r + 1]), h[r + 2]), fmaxf(h[r + 3], h[r + 4]));      // lanes 0..3: the halo columns' vertical maxima
+        const float h1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hm), 1)), h2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hm), 2)),
+                    h3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hm), 3));
+        const float l1 = dpp_wave_shr1(vm, h1);            // column x - 1 (lane 0: x0 - 1)
+        const float l2 = dpp_wave_shr1(l1, hm);            // column x - 2 (lane 0: x0 - 2 = its own halo value; lane 1: x0 - 1 via l1's lane 0)
+        const float r1 = dpp_wave_shl1(vm, h2);            // column x + 1 (lane 63: x0 + 64)
+        const float r2 = dpp_wave_shl1(r1, h3);            // column x + 2 (lane 63: x0 + 65; lane 62: x0 + 64 via r1's lane 63)
+        const float m = fmaxf(fmaxf(fmaxf(vm, l1), l2), fmaxf(r1, r2));
+        const float c = v[r + 2];
+        const bool cand = (y < H) && xin && (c > thr) && (c == m);
         const unsigned long long bal = __ballot(cand);
         if (lane == 0 && y < H) {
             const size_t o = ((size_t)b * H + y) * WPR + word;
@@ -570,10 +573,7 @@ void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, c
     const int WPR = ceil_div(W, 64);
     const int hc = H / 8, wc = W / 8;
     prof_begin(prof, XFH_SPAN_NMS_FLAGS, st);
-    if ((W & 1) == 0)
-        nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
-    else        // (the tiled kernel loads 8-byte column pairs: even widths only)
-        nms_flags_generic_kernel<<<(unsigned)(((size_t)B * H * WPR + 3) / 4), 256, 0, st>>>(heat, B, H, W, WPR, 2, thr, ws.mask, ws.wcount);
+    nms_flags_kernel<<<xcd_grid_size(ceil_div(WPR * ceil_div(H, NMS_TH), 4), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
     prof_end(prof, XFH_SPAN_NMS_FLAGS, st, 0, 0);
     prof_begin(prof, XFH_SPAN_NMS_COMPACT, st);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
@@ -609,10 +609,9 @@ __global__ __launch_bounds__(256) void cand_to_xy_kernel(const unsigned* __restr
 void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W, float thr, int kernel_size, int cap, int64_t* xy,
                      int32_t* n_cand, hipStream_t st) {
     const int WPR = ceil_div(W, 64);
-    // the tiled 5x5 kernel loads 8-byte column pairs: even widths only (an odd W would read the pair at x = W-1 across the row end);
-    // every other window / width goes to the per-pixel kernel
-    if (kernel_size == 5 && (W & 1) == 0)
-        nms_flags_kernel<<<xcd_grid_size(WPR * ceil_div(H, NMS_TH), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
+    // 5 x 5 (the hot path's window): the register / DPP kernel, any width; every other window goes to the per-pixel kernel
+    if (kernel_size == 5)
+        nms_flags_kernel<<<xcd_grid_size(ceil_div(WPR * ceil_div(H, NMS_TH), 4), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
     else
         nms_flags_generic_kernel<<<(unsigned)(((size_t)B * H * WPR + 3) / 4), 256, 0, st>>>(heat, B, H, W, WPR, kernel_size / 2, thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);

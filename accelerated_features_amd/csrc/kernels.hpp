@@ -51,7 +51,6 @@ struct Options {
     int bx = 5;             // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0
     int heads_f32 = 0;      // 1: heads on the f32-MFMA kernels
     int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs
-    int pyramid_fused = 1;  // 1: x3 + up(x4) + up(x5) is formed inside block_fusion.0's tile staging (no pyramid_sum pass)
 };
 
 // ---- k_preproc.hip ----------------------------------------------------------------------

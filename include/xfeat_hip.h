@@ -92,8 +92,7 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
  *                           8 not block3.0 (default 5)
  *   "heads_f32"     0 | 1   1: both heads on the f32-MFMA kernels
- *   "block1"        0..     block1 kernel variant (0 = shipped)
- *   "pyramid_fused" 0 | 1   0: x3 + up(x4) + up(x5) as its own pass before block_fusion.0 (default 1: formed in that layer's tile staging)
+ *   "block1"        0..5    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile
  * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.
  * ---------------------------------------------------------------------------------------- */
 int xfh_set_option(xfh_handle h, const char* key, int value);

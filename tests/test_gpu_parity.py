@@ -126,10 +126,10 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
 
 
-@pytest.mark.parametrize("opts", [{"heads_f32": 1, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0, "pyramid_fused": 0}, {"block1": 4, "pyramid_fused": 1}])
+@pytest.mark.parametrize("opts", [{"heads_f32": 1, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}])
 def test_backbone_alternative_kernels_same_results(opts, sd):
     """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on f32 MFMAs, 24->24 layers on Winograd; every
-    unfused 64->64 layer on the split-bf16 kernel; direct implicit GEMM instead of Winograd; the pyramid sum as its own pass): the small golden
+    unfused 64->64 layer on the split-bf16 kernel; direct implicit GEMM instead of Winograd; block1 with a c1 tile): the small golden
     backbone case on a model of its own with each setting."""
     from accelerated_features_amd import XFeat
     g = np.load(os.path.join(G, "g1_small.npz"))
@@ -152,10 +152,10 @@ def test_backbone_alternative_kernels_same_results(opts, sd):
 def test_split_bf16_backbone_equals_f32_mfma_backbone_at_bench_shape(xf, sd):
     """At the benchmark shape (B=64 VGA) the default path runs the 24-channel layers, the three 64 -> 64 layers at 1/8 scale (two of them with
     their trailing 1x1 fused, one writing channels-last) and both heads on split-bf16 MFMAs.  Same network outputs as with every one of
-    them on the f32-MFMA kernels (a second model with bx = 0, heads_f32 = 1, the pyramid sum as its own pass)."""
+    them on the f32-MFMA kernels (a second model with bx = 0, heads_f32 = 1)."""
     from accelerated_features_amd import XFeat
     xr = XFeat(weights=sd, top_k=4096)
-    xr.set_option("bx", 0); xr.set_option("heads_f32", 1); xr.set_option("pyramid_fused", 0)
+    xr.set_option("bx", 0); xr.set_option("heads_f32", 1)
     x = torch.cat([fixtures.texture_images(8, 480, 640, seed=s) for s in range(8)]).cuda()
     f_, l_, r_ = xr.net(x)
     ref = {"feats": f_[::8].cpu().numpy(), "logits": l_[::8].cpu().numpy(), "rel": r_.cpu().numpy()}
