@@ -52,6 +52,6 @@ for (B, H, W) in ((64, 480, 640), (8, 1312, 1312)):
         d = DIV[name]; hin, win = H // d, W // d
         x = torch.randn(B, c.cin, hin, win, device="cuda", generator=g)
         y = torch.empty(B, c.cout, (hin - 1) // c.stride + 1, (win - 1) // c.stride + 1, device="cuda")
-        # variant 0 = the production dispatch: run with XFH_BX=0 to time the f32-MFMA kernel of a stride-2 layer there
+        # variant 0 = the production dispatch (xf.set_option('bx', 0) times the f32-MFMA kernel of a stride-2 layer there)
         t = {v: time_fn(lambda: lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(y.data_ptr()), v, None)) for v in ((2, 10) if c.stride == 1 else (0, 10))}
-        print(f"{name} B={B} {hin}x{win}: " + (f"winograd {t[2]:7.1f} us" if 2 in t else f"dispatch (XFH_BX={os.environ.get('XFH_BX', '1')}) {t[0]:7.1f} us") + f"   split-bf16 {t[10]:7.1f} us", flush=True)
+        print(f"{name} B={B} {hin}x{win}: " + (f"winograd {t[2]:7.1f} us" if 2 in t else f"dispatch {t[0]:7.1f} us") + f"   split-bf16 {t[10]:7.1f} us", flush=True)

@@ -25,7 +25,7 @@ for (B, H, W) in ((64, 480, 640), (8, 1312, 1312), (3, 480, 640)):
         err = float((y - ref).abs().nan_to_num(1e9).max())
         t = {}
         errs = {2: err}
-        if os.environ.get('XFH_WINO', '1') != '0': print('note: variant 0 is the Winograd path unless XFH_WINO=0', end=' ')
+        print('note: variant 0 is the Winograd path unless the handle option wino is 0', end=' ')
         for v in (0, 2, 3, 4, 5, 6):
             if v > 2:
                 y.fill_(float("nan"))
