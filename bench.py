@@ -677,9 +677,35 @@ def main():
         kp, sc, de, nv, nc, cap_, hw = xf._detect_device(x, TOP_K, 0.05)
         return torch.cat([nv, nc]).cpu()
 
+    def pipelined_readback(n=20):
+        """The same step with its read-back one step deep: the counts of step i travel to pinned host memory asynchronously and are waited for
+        after step i + 1 has been queued, so the GPU never idles on the host round trip (what a consumer loop would do; the contract value above
+        keeps the synchronous read-back inside every step)."""
+        host = [torch.empty((3, B), dtype=torch.int32).pin_memory() for _ in range(2)]
+        dev = [torch.zeros((3, B), dtype=torch.int32, device="cuda") for _ in range(2)]
+        ev = [torch.cuda.Event() for _ in range(2)]
+
+        def queue(i):
+            d = dev[i % 2]
+            kp, sc, de, nv, nc, cap_, hw, d16 = xf._detect_device(x, TOP_K, 0.05, want_f16=True, counts_out=d[:2])
+            xf.match_pairs_device(de, nv, -1, d16, n_out=d[2, :B // 2])
+            host[i % 2].copy_(d, non_blocking=True)
+            ev[i % 2].record()
+        queue(0); ev[0].synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        queue(0)
+        for i in range(1, n):
+            queue(i)
+            ev[(i - 1) % 2].synchronize()               # step i - 1's ragged counts are on the host now
+        ev[(n - 1) % 2].synchronize()
+        torch.cuda.synchronize()
+        return B * n / (time.perf_counter() - t0)
+
     side = {}
     if rank == 0 and not args.no_side_passes:
         side["extraction_only_fps"] = round(rate(extract_only), 1)
+        side["pipelined_readback_fps"] = round(pipelined_readback(), 1)
         xh32 = x_host.pin_memory()
         xh8 = (x_host * 255).round().clamp(0, 255).to(torch.uint8).pin_memory()
 
