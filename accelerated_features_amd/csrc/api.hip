@@ -347,7 +347,8 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         const bool bx64 = c.ks == 3 && c.stride == 1 && c.cin == 64 && c.cout == 64;
         const bool bx24s2 = c.ks == 3 && c.stride == 2 && c.cin == 24 && c.cout == 64;
         const bool bx1x1 = c.ks == 1 && c.cin == 64 && c.cout == 64 && li > 0 && kConvs[li - 1].ks == 3 && kConvs[li - 1].cout == 64 && kConvs[li - 1].cin == 64;      // block3.2, block_fusion.2
-        coff[li].has_bx = bx24 || bx64 || bx24s2 || bx1x1;
+        const bool bx64s2 = c.ks == 3 && c.stride == 2 && c.cin == 64 && (c.cout == 64 || c.cout == 128);      // block4.0, block5.0
+        coff[li].has_bx = bx24 || bx64 || bx24s2 || bx1x1 || bx64s2;
         if (bx1x1) {      // trailing 1x1 fused into conv_bx64_kernel: K order of the 3x3's D registers (as the heads' chained layers): [K step 4][cout block 2][split 3][lane][8]
             coff[li].bx = reserve((size_t)4 * 2 * 3 * 64 * 4);
             uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
@@ -395,20 +396,21 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                         }
                     }
         }
-        if (bx64) {      // [cin/16][dy][dx][cout block][split][lane = half * 32 + cout][8]: channel = 16 chunk + 8 half + i
-            const int nch = c.cin / 16;
-            coff[li].bx = reserve((size_t)nch * 9 * 2 * 3 * 64 * 4);
+        if (bx64 || bx64s2) {      // [cout half][cin/16][dy][dx][cout block][split][lane = half * 32 + cout][8]: channel = 16 chunk + 8 half + i
+            const int nch = c.cin / 16, nhf = c.cout / 64;
+            coff[li].bx = reserve((size_t)nhf * nch * 9 * 2 * 3 * 64 * 4);
             uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
-            for (int ch = 0; ch < nch; ++ch)
-                for (int tap = 0; tap < 9; ++tap)
-                    for (int cb = 0; cb < 2; ++cb)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int i = 0; i < 8; ++i) {
-                                const int o = cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
-                                uint16_t q[3];
-                                split3(blob[coff[li].oihw + ((size_t)o * c.cin + ci) * 9 + tap], q);
-                                for (int sp = 0; sp < 3; ++sp) dst[(((((size_t)ch * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                            }
+            for (int hf = 0; hf < nhf; ++hf)
+                for (int ch = 0; ch < nch; ++ch)
+                    for (int tap = 0; tap < 9; ++tap)
+                        for (int cb = 0; cb < 2; ++cb)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int i = 0; i < 8; ++i) {
+                                    const int o = hf * 64 + cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
+                                    uint16_t q[3];
+                                    split3(blob[coff[li].oihw + ((size_t)o * c.cin + ci) * 9 + tap], q);
+                                    for (int sp = 0; sp < 3; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                                }
         }
     }
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].
@@ -560,7 +562,8 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 1024;      // >= 2 half-tile units per workgroup of the persistent grid (B=8 164x164: 92 vs 124 us stand-alone)
     if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc);      // 3x3 + trailing 1x1 in one split-bf16 kernel
-    if (rc && use_bx && c.w_bx && !c2 && !nhwc) {
+    if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
+    if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);      // (bx = 9: block3.0 stays on the f32 kernel)
         else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);      // (bx = 5: large maps only)
     }
@@ -665,7 +668,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
         return check_launch("xfh_conv_layer(generic)");
     }
     if (variant == 10) {
-        if (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace) : launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no split-bf16 instantiation for layer %d", layer);
+        if (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace) : c.stride == 2 ? launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace) : launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no split-bf16 instantiation for layer %d", layer);
         return check_launch("xfh_conv_layer(split bf16)");
     }
     if (variant >= 2) {
@@ -900,7 +903,7 @@ int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
-        {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 15},
+        {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
         {"heads_f32", &Options::heads_f32, 0, 1}, {"block1", &Options::block1, 0, 15}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }

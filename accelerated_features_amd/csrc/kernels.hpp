@@ -86,6 +86,8 @@ int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, 
 int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
 int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr,
                      const ConvW* fused1x1 = nullptr, bool nhwc = false);
+// 3x3/s2, 64 -> 64 | 128 (block4.0, block5.0; k_conv_bx64s2.hip); -1 if no instantiation
+int launch_conv_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
 int bx_steps(int cin);      // K steps of 16 = 2 groups of 8 channels of one tap
 // ---- k_homography.hip (RANSAC + MAGSAC++ homography from match lists) ----
 size_t homography_workspace_bytes(int P, int max_iters);

@@ -549,7 +549,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
     h = xf.net.handle()
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 0
-    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1"):       # block3.0: the stride-2 kernel; the last two: conv_bx64_kernel (opt-in XFH_BX=3)
+    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1", "block4.0", "block5.0"):       # block3.0: the 24-channel stride-2 kernel; block_fusion.0 / block4.1: conv_bx64_kernel; the last two: conv_bx64s2_kernel (64 / 128 couts)
         c = next(c for c in CONVS if c.name == name)
         w = sd[f"{name}.layer.0.weight"].double().cuda()
         rm, rv = sd[f"{name}.layer.1.running_mean"].double().cuda(), sd[f"{name}.layer.1.running_var"].double().cuda()
@@ -568,7 +568,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
                     err[variant] = float((y.double() - truth).abs().nan_to_num(1e9).max()) / ref
                 assert err[10] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
                 n += 1
-    assert n == 5 * 8 * 3
+    assert n == 7 * 8 * 3
 
 
 def test_uint8_ingest_is_bit_identical_to_host_conversion(xf):
