@@ -24,4 +24,15 @@ __device__ inline void split3(float a, float b, unsigned& h, unsigned& m, unsign
     l = pk_bf16_rne(sa, sb);
 }
 
+// The same by truncation: h, m = the leading 8 + 8 significant bits, l = the remaining 8 -- a + b + c is EXACT (fp32 has 24), every op is a
+// plain and / sub / v_perm_b32 (which packs the two high halves).  |m| < 2^-7 |a|,
+// |l| < 2^-15 |a|: with RNE-split weights (|wm| <= 2^-9, |wl| <= 2^-18) the three dropped cross terms stay below 2^-23 of the product, zero-mean.
+__device__ inline void split3_trunc(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    h = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+    const float ra = a - __uint_as_float(__float_as_uint(a) & 0xffff0000u), rb = b - __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+    m = __builtin_amdgcn_perm(__float_as_uint(rb), __float_as_uint(ra), 0x07060302u);
+    const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+
 }  // namespace xfh

@@ -6,17 +6,21 @@
 // outputs per VGA frame), so the kernel is shaped by balance, not by reuse:
 //   * unit = (cout half, image, 16-column strip, 8-row tile): 8x16 output pixels x 64 couts.  VGA batch 64: 768 units for block4.0
 //     (three per CU), 512 for block5.0 (two per CU: the second cout half of an image is another unit, not another accumulator);
-//   * ONE workgroup of 8 waves per CU: wave (pb, cb) owns pixel block pb (2 output rows x 16 columns) and cout block cb: one 32x32
-//     accumulator, per K step 3 + 3 ds_read_b128 for 6 MFMAs (half of the LDS read rate with two waves per SIMD);
+//   * ONE workgroup of 8 waves per CU (all of its LDS): wave (pb, cb) owns pixel block pb (2 output rows x 16 columns) and cout block
+//     cb: one 32x32 accumulator, per K step 3 + 3 ds_read_b128 for 6 MFMAs (half of the LDS read rate with two waves per SIMD);
 //   * the 17x33 input halo of a tile goes through LDS in chunks of 16 channels with EVEN and ODD columns apart
 //     ([17 rows, 3712 B apart][parity, 1904 B apart][17 / 16 pixels, 112 B apart][split h, m, l][16 channels] bf16): the 16 lanes of a
 //     ds_read_b128 group step by two input pixels and would collide pairwise in one plane; 112 B keeps them on distinct banks;
-//   * raw fp32 values are prefetched into registers one chunk ahead (also across units) as dwordx4 loads of pixel quads, split on
-//     the way into LDS;
-//   * the split weights (216 KiB per cout half) stream through a three-slot LDS ring by LDS-DMA, one slot = one tap row of one chunk
-//     (3 K steps, 18 KiB); the DMA of row r + 2 is issued behind the barrier that opens row r.
+//   * TWO such buffers: chunk g + 1 is split and written while chunk g is multiplied.  With all eight waves of a CU in one workgroup
+//     nobody else covers a staging phase (first version: 13 k of a unit's 42 k cycles were split3 + ds_write between two barriers, all
+//     matrix pipes idle), and a wave's vector work only hides in the issue gaps of its OWN MFMAs: every wave splits half an item (two
+//     pixels x 8 channels) inside each of a chunk's first two tap rows, in the same basic block as that row's 18 MFMAs (no branch: lanes
+//     without an item write to a dump slot).  Raw fp32 values are loaded two chunks ahead (two register sets), also across units;
+//   * the split weights (216 KiB per cout half) stream through a two-slot LDS ring by LDS-DMA, one slot = one tap row of one chunk
+//     (3 K steps, 18 KiB); the DMA of row r + 1 is issued behind the barrier that opens row r.  One barrier per tap row, none per chunk.
 #include "kernels.hpp"
 #include "bx_split.hpp"
+#include <type_traits>
 
 namespace xfh {
 
@@ -39,19 +43,19 @@ constexpr int PARB = NEVEN * PIXB;                      // odd columns of a row 
 constexpr int XROWB = 3712;                             // >= (17 + 16) * 112
 constexpr int X_BYTES = IH * XROWB;                     // 63104
 constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;
-constexpr int NSLOT = 3;                                // ring depth: row r + 2 is in flight while row r is multiplied
-constexpr int RING_OFF = X_BYTES, BIAS_OFF = RING_OFF + NSLOT * SLOT_BYTES, LDS_BYTES = BIAS_OFF + 128 * 4;
-constexpr int NQ = 9;                                   // aligned 4-pixel quads [2 ox0 - 4, 2 ox0 + 32) per halo row
+constexpr int RING_OFF = 2 * X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, DUMP_OFF = BIAS_OFF + 128 * 4, LDS_BYTES = DUMP_OFF + 256;
+constexpr int NQ = 9;                                   // 4-pixel quads [2 ox0 - 4, 2 ox0 + 32) per halo row
 constexpr int NITEM = IH * NQ * 2;                      // (row, quad, 8-channel group)
-static_assert(NITEM <= 512 && RING_OFF % 64 == 0, "one staging item per thread");
+static_assert(NITEM <= 512 && RING_OFF % 64 == 0 && LDS_BYTES <= 160 * 1024, "one staging item per thread; all of a CU's LDS");
 }
 
-template <int NCO>          // cout halves: 1 (64 couts) or 2 (128)
+// NCO: cout halves, 1 (64 couts) or 2 (128).  W4: W % 4 == 0 (no quad straddles the right border: no masking of its tail)
+template <int NCO, bool W4>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64s2_kernel(Bx64S2Args a) {
     using namespace bx64s2;
     constexpr int CIN = 64, NCH = CIN / 16, NROW = NCH * 3, COUT = 64 * NCO;
-    static_assert(NROW % NSLOT == 0, "the ring slot of a row must not depend on the unit");
+    static_assert(NROW % 2 == 0 && NCH % 2 == 0, "ring slot, X buffer and register set of a chunk must not depend on the unit");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,136 +105,177 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
     const i32x4 rs_w = make_rsrc(a.wq, (unsigned)(NCO * NROW * SLOT_BYTES));
     const int dma_voff = lane * 16;
     auto lds_addr = [](const unsigned char* p) { return (unsigned)(size_t)(lptr_t)p; };
-    auto issue_row = [&](int r, int hf) __attribute__((always_inline)) {      // weights of row r (chunk r / 3, tap row r % 3) of cout half hf -> slot r % 3
+    auto issue_row = [&](int r, int hf) __attribute__((always_inline)) {      // weights of row r (chunk r / 3, tap row r % 3) of cout half hf -> slot r & 1
         for (int j = wave; j < NPIECE; j += 8) {
-            const unsigned m0v = lds_addr(smem_s2 + RING_OFF + (r % NSLOT) * SLOT_BYTES + j * 1024);
+            const unsigned m0v = lds_addr(smem_s2 + RING_OFF + (r & 1) * SLOT_BYTES + j * 1024);
             const int soff = (hf * NROW + r) * SLOT_BYTES + j * 1024;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(dma_voff), "s"(rs_w), "s"(soff) : "memory");
         }
     };
-    // Barrier that opens a row: everything but the DMA pieces of the row issued LAST has landed, for every wave.  vmcnt counts in issue
-    // order, so "at most n outstanding" with n = this wave's pieces per row (3 for waves 0 and 1, 2 for the others) leaves only the newest
-    // row in flight -- or less, if loads / stores were issued behind it (conservative).  (Measured: 72 -> 70 us for block4.0 against the
-    // two-slot ring with a wait for everything.)
-    auto dma_barrier = [&]() {
-        if (wave < 2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __syncthreads();
-    };
 
     // ---- raw fp32 values of one 16-channel chunk of a tile: item of a thread = 4 consecutive pixels x 8 channels (eight dwordx4 loads,
-    // one per channel plane).  Halo column c = 0 .. 32 is image column 2 ox0 - 1 + c; the quads start at 2 ox0 - 4.
+    // one per channel plane).  Halo column c = 0 .. 32 is image column 2 ox0 - 1 + c; the quads start at 2 ox0 - 4.  Two register sets:
+    // chunk g + 2 is loaded (set g & 1) while chunk g + 1 is split (set (g + 1) & 1) and chunk g is multiplied.
     const bool has_item = tid < NITEM;
     const int it_g8 = tid / (IH * NQ), it_row = (tid - it_g8 * (IH * NQ)) / NQ, it_quad = tid % NQ;
-    float v[8][4];
-    int v_gx = 0;                             // first column of the quad in flight (W % 4 != 0: the tail of a quad that straddles the right border is
-                                              // masked where it is consumed, k_conv_bx64.hip)
-    auto issue_loads = [&](const Tile& t, int chunk) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.b * CIN * HW), 0, (int)(CIN * HW * sizeof(float)), 0x00020000);
+    float v[2][8][4];
+    int v_gx[2] = {0, 0};                     // first column of the quad (W % 4 != 0: the tail of a quad that straddles the right border is masked)
+    // (32-bit offsets, selects instead of branches: the loads sit inside the MFMA block of a row)
+    struct LoadAddr { __amdgpu_buffer_rsrc_t rs; int voff; };
+    auto load_addr = [&](auto SETC, const Tile& t, bool en) __attribute__((always_inline)) {
+        constexpr int S = decltype(SETC)::value;
+        LoadAddr la;
+        la.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.b * CIN * HW), 0, (int)(CIN * HW * sizeof(float)), 0x00020000);
         const int gy = 2 * t.oy0 - 1 + it_row, gx = 2 * t.ox0 - 4 + 4 * it_quad;
-        const bool ok = has_item && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        v_gx = gx;
-        const int voff = ok ? (int)((((size_t)it_g8 * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, (int)((chunk * 16 + k) * HW * 4), 0);
-            v[k][0] = __uint_as_float(q[0]); v[k][1] = __uint_as_float(q[1]); v[k][2] = __uint_as_float(q[2]); v[k][3] = __uint_as_float(q[3]);
-        }
+        const bool ok = en && has_item && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        v_gx[S] = gx;
+        const int off = (it_g8 * 8 * (int)HW + gy * a.W + gx) * 4;
+        la.voff = ok ? off : (int)0x80000000;      // (out of range: zeros)
+        return la;
     };
-    // split3 works on the two neighbouring PIXELS of a loaded quad; v_perm_b32 then gathers the channel pairs of each pixel (k_conv_bx64.hip)
-    auto stage_write = [&]() __attribute__((always_inline)) {
-        if (!has_item) return;
-        unsigned char* row_base = smem_s2 + it_row * XROWB + it_g8 * 16 + 2 * it_quad * PIXB;
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            unsigned H[8], M[8], L[8];                     // {pixel 2 pp, pixel 2 pp + 1} of channel k
-            const bool z0 = (a.W & 3) && v_gx + 2 * pp >= a.W, z1 = (a.W & 3) && v_gx + 2 * pp + 1 >= a.W;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float x0 = v[k][2 * pp], x1 = v[k][2 * pp + 1];
-                if (a.W & 3) { x0 = z0 ? 0.f : x0; x1 = z1 ? 0.f : x1; }
-                split3(x0, x1, H[k], M[k], L[k]);
-            }
-#pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-                const int e = 2 * pp + e2;                               // pixel of the quad: halo column c = 4 quad + e - 3
-                if (it_quad == 0 && e < 3) continue;                     // (c < 0: left of the halo)
-                const int par = (e + 1) & 1;                             // c & 1
-                const int idx = e == 0 ? -2 : e == 3 ? 0 : -1;           // (c >> 1) - 2 quad
-                const unsigned sel = e2 ? 0x07060302u : 0x05040100u;
-                uint4 h, m, l;
-                h.x = __builtin_amdgcn_perm(H[1], H[0], sel); h.y = __builtin_amdgcn_perm(H[3], H[2], sel);
-                h.z = __builtin_amdgcn_perm(H[5], H[4], sel); h.w = __builtin_amdgcn_perm(H[7], H[6], sel);
-                m.x = __builtin_amdgcn_perm(M[1], M[0], sel); m.y = __builtin_amdgcn_perm(M[3], M[2], sel);
-                m.z = __builtin_amdgcn_perm(M[5], M[4], sel); m.w = __builtin_amdgcn_perm(M[7], M[6], sel);
-                l.x = __builtin_amdgcn_perm(L[1], L[0], sel); l.y = __builtin_amdgcn_perm(L[3], L[2], sel);
-                l.z = __builtin_amdgcn_perm(L[5], L[4], sel); l.w = __builtin_amdgcn_perm(L[7], L[6], sel);
-                unsigned char* p = row_base + par * PARB + idx * PIXB;
-                *reinterpret_cast<uint4*>(p) = h;
-                *reinterpret_cast<uint4*>(p + SPLB) = m;
-                *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
-            }
-        }
+    auto load_plane = [&](auto SETC, auto KC, const LoadAddr& la, int chunk) __attribute__((always_inline)) {
+        constexpr int S = decltype(SETC)::value, k = decltype(KC)::value;
+        const auto q = __builtin_amdgcn_raw_buffer_load_b128(la.rs, la.voff, (chunk * 16 + k) * (int)HW * 4, 0);
+        v[S][k][0] = __uint_as_float(q[0]); v[S][k][1] = __uint_as_float(q[1]); v[S][k][2] = __uint_as_float(q[2]); v[S][k][3] = __uint_as_float(q[3]);
     };
+    // Half an item (pixels 2 PP, 2 PP + 1 of the quad x 8 channels) of a register set -> an X buffer, as micro-steps that a tap row places
+    // behind its MFMAs (S2_A1 ... S2_P below): split3_trunc of a channel pair of one pixel (h, residual, m, residual, l), ds_write_b128 of a pixel's rows.  Branch-free: a lane without a pixel to
+    // write (no item, left of the halo, nothing to stage) writes to the dump slot.
+    const int row_base = it_row * XROWB + it_g8 * 16 + 2 * it_quad * PIXB;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 qH[2], qM[2], qL[2];                         // [pixel of the half] h / m / l rows: word j = channels 2 j, 2 j + 1
+    float xa[8], xb[8];                                // a unit's two values, then their residuals
 
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
     int tix = 0;
-#define S2_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }      /* [0] unit start; row r: [1+4r] start, [2+4r] barrier passed, [3+4r] MFMAs issued; [50] stores issued, [51] end barrier */
+#define S2_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }      /* [0] unit start; row r: [1+4r] start, [2+4r] barrier passed, [3+4r] MFMAs issued; [50] stores issued */
     struct Frag { bf16x8 x[3]; bf16x8 w[3]; };
     // lane (pixel l31 of block pb): output row 2 pb + (l31 >> 4), column l31 & 15 -> input row 2 * that (+ dy), even column index = column (+ dx >> 1)
     const int lane_px = 2 * (2 * pb + (l31 >> 4)) * XROWB + (l31 & 15) * PIXB + half * 16;
+    f32x16 acc, acc2;
 
-    auto do_tile = [&](const Tile& cur, const Tile& nxt, bool has_next) __attribute__((always_inline)) {
-        f32x16 acc;
+    // ---- one tap row (chunk C, tap row DY) of a unit: barrier, DMA of the next row, (DY = 0) loads of chunk C + 2, then ONE basic block of
+    // 18 MFMAs with the fragment reads of the later steps and (DY < 2) the split of half an item of chunk C + 1 in their issue gaps.
+    // vmcnt counts in issue order: "at most n outstanding" leaves the n youngest operations in flight -- the eight raw loads behind the
+    // DMA of row (C, 1), the sixteen stores of the previous unit behind the DMA of row (0, 0) -- and guarantees the row's own DMA.
+    auto row = [&](auto CC, auto DYC, auto STGC, const Tile& cur, const Tile& nxt, bool has_next, bool first_unit) __attribute__((always_inline)) {
+        constexpr int C = decltype(CC)::value, DY = decltype(DYC)::value, r = C * 3 + DY, P = C & 1;
+        constexpr int MODE = decltype(STGC)::value;      // 0: this wave only multiplies (waves 5 - 7); 1: it also loads and splits an item (waves 0 - 4), half in each of a chunk's
+        constexpr bool STG = MODE != 0;                  // first two rows.  (Wave 4 -- the last 50 items, on wave 0's SIMD -- doing both halves in the third row instead: slower.)
+        S2_STAMP(1 + 4 * r)
+        if (DY == 1 && STG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (r == 0 && !first_unit) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        S2_STAMP(4 + 4 * r)
+        __syncthreads();
+        S2_STAMP(2 + 4 * r)
+        issue_row(r + 1 < NROW ? r + 1 : 0, r + 1 < NROW ? cur.hf : nxt.hf);          // (the stream is cyclic over the units)
+        const unsigned char* wslot = smem_s2 + RING_OFF + (r & 1) * SLOT_BYTES + cb * 3 * 1024 + lane * 16;
+        const unsigned char* xrow = smem_s2 + P * X_BYTES + lane_px + DY * XROWB;
+        Frag f[2];                             // steps 0 and 1; step 2 is read into f[0] behind the last MFMA of step 0 (slot 6)
+        auto load = [&](int s, Frag& o) {          // tap column s: parity s & 1, pixel index + (s >> 1)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int c = 0; c < NCH; ++c) {
-            if (c > 0) dma_barrier();          // every wave has finished the previous chunk's last tap row (the unit loop ends on a barrier)
-            stage_write();
-            for (int dy = 0; dy < 3; ++dy) {
-                const int r = c * 3 + dy;
-                S2_STAMP(1 + 4 * r)
-                dma_barrier();                 // row r's weights landed; (dy = 0) the chunk is staged; (dy > 0) row r - 1 is finished
-                S2_STAMP(2 + 4 * r)
-                const unsigned char* wslot = smem_s2 + RING_OFF + (r % NSLOT) * SLOT_BYTES + cb * 3 * 1024 + lane * 16;
-                const unsigned char* xrow = smem_s2 + lane_px + dy * XROWB;
-                Frag f[2];
-                auto load = [&](int s, Frag& o) {          // tap column s: parity s & 1, pixel index + (s >> 1)
+            for (int q = 0; q < 3; ++q) o.x[q] = *reinterpret_cast<const bf16x8*>(xrow + (s & 1) * PARB + (s >> 1) * PIXB + q * SPLB);
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) o.x[q] = *reinterpret_cast<const bf16x8*>(xrow + (s & 1) * PARB + (s >> 1) * PIXB + q * SPLB);
+            for (int q = 0; q < 3; ++q) o.w[q] = *reinterpret_cast<const bf16x8*>(wslot + s * STEP_BYTES + q * 1024);
+        };
+        load(0, f[0]);
+        load(1, f[1]);
+        // (DY = 0) raw values of chunk C + 2 (of the next unit for C >= 2) -> set P, free since chunk C - 1 staged it
+        constexpr bool same2 = C + 2 < NCH;
+        constexpr int SS = P ^ 1;              // (DY < 2) chunk C + 1: set P ^ 1 (loaded during chunk C - 1) -> X buffer P ^ 1 (free since chunk C - 1 was multiplied)
+        Tile lt;
+        lt.b = same2 ? cur.b : nxt.b; lt.oy0 = same2 ? cur.oy0 : nxt.oy0; lt.ox0 = same2 ? cur.ox0 : nxt.ox0; lt.hf = 0;
+        LoadAddr la;
+        if constexpr (STG && DY == 0) la = load_addr(std::integral_constant<int, P>{}, lt, same2 || has_next);
+        const bool en = C + 1 < NCH || has_next;
+        if (r == 0) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) o.w[q] = *reinterpret_cast<const bf16x8*>(wslot + s * STEP_BYTES + q * 1024);
-                };
-                load(0, f[0]);
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const Frag& cf = f[s & 1];
-                    if (s + 1 < 3) load(s + 1, f[(s + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.w[2], cf.x[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.w[0], cf.x[2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.w[1], cf.x[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.w[1], cf.x[0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.w[0], cf.x[1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.w[0], cf.x[0], acc, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // memory instructions BETWEEN the MFMA groups, behind idle slots (VALU address arithmetic right behind an MFMA may land in
-                    // operand lanes it has not read yet)
-                    if (s < 2) { asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
-                    if (s == 0) issue_row(r + 2 < NROW ? r + 2 : r + 2 - NROW, r + 2 < NROW ? cur.hf : nxt.hf);      // (the stream is cyclic over the units)
-                    if (s == 1 && dy == 0) {   // raw values of the next chunk (or the next unit's first) fly under this chunk's MFMAs (ONE load site)
-                        const bool same = c + 1 < NCH;
-                        Tile lt;
-                        lt.b = same ? cur.b : nxt.b; lt.oy0 = same ? cur.oy0 : nxt.oy0; lt.ox0 = same ? cur.ox0 : nxt.ox0; lt.hf = 0;
-                        if (same || has_next) issue_loads(lt, same ? c + 1 : 0);
-                    }
-                }
-                asm volatile("s_nop 7\n\ts_nop 7");
-                __builtin_amdgcn_sched_barrier(0);
-                S2_STAMP(3 + 4 * r)
-            }
+            for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // 18 fenced slots of { 1 MFMA, ~7 vector ops of the staging, (DY = 0) one plane of raw loads }: a wave's vector work hides in the
+        // issue gaps of its OWN MFMAs only, and only if no slot holds more of it than an MFMA takes (11 ops in eight slots: + 500 cycles
+        // per row).  Products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); two accumulators take
+        // turns: a dependent MFMA stalls at issue until its predecessor has left the pipe, and blocks the ops behind it.
+#define S2_MF(I) { if constexpr ((I) == 6) { S2_KEEP(f[0]) load(2, f[0]); } constexpr int s_ = ((I) / 6) & 1, j_ = (I) % 6, wq_ = j_ == 0 ? 2 : (j_ == 2 || j_ == 3) ? 1 : 0, xq_ = j_ == 1 ? 2 : (j_ == 2 || j_ == 4) ? 1 : 0; \
+        if constexpr (j_ & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s_].w[wq_], f[s_].x[xq_], acc2, 0, 0, 0); \
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s_].w[wq_], f[s_].x[xq_], acc, 0, 0, 0); }
+#define S2_FENCE __builtin_amdgcn_sched_barrier(0);
+        // a fragment's registers stay occupied until every MFMA of its step has long been issued: they are not handed to the staging's results
+        // while an MFMA may still be reading them (tools/check_mfma_war.py)
+#define S2_KEEP(F) asm volatile("" :: "v"(F.x[0]), "v"(F.x[1]), "v"(F.x[2]), "v"(F.w[0]), "v"(F.w[1]), "v"(F.w[2]));
+#define S2_HI(A, B) __builtin_amdgcn_perm(__float_as_uint(B), __float_as_uint(A), 0x07060302u)      /* split3_trunc, step by step */
+#define S2_ON(PP) if constexpr (MODE == 1 && DY == (PP))
+        // unit U = (pixel e2 of the half, channel pair j): channels 2 j, 2 j + 1 of ONE pixel -> word j of the pixel's h / m / l rows.  (Pairs of
+        // pixels, as k_conv_bx64 splits them, need four more v_perm_b32 per row to gather the channel pairs; v_perm_b32 -- unlike the
+        // packed conversion -- takes any two registers, so pairing channels costs no moves here.)
+#define S2_A1(PP, U) S2_ON(PP) { constexpr int e2_ = (U) >> 2, j_ = (U) & 3; xa[U] = v[SS][2 * j_][2 * (PP) + e2_]; xb[U] = v[SS][2 * j_ + 1][2 * (PP) + e2_]; \
+        if (!W4) { const bool z_ = v_gx[SS] + 2 * (PP) + e2_ >= a.W; xa[U] = z_ ? 0.f : xa[U]; xb[U] = z_ ? 0.f : xb[U]; } qH[e2_][j_] = S2_HI(xa[U], xb[U]); }
+#define S2_A2(PP, U) S2_ON(PP) { xa[U] -= __uint_as_float(__float_as_uint(xa[U]) & 0xffff0000u); }
+#define S2_A3(PP, U) S2_ON(PP) { xb[U] -= __uint_as_float(__float_as_uint(xb[U]) & 0xffff0000u); }
+#define S2_B1(PP, U) S2_ON(PP) { qM[(U) >> 2][(U) & 3] = S2_HI(xa[U], xb[U]); }
+#define S2_B2(PP, U) S2_ON(PP) { xa[U] -= __uint_as_float(__float_as_uint(xa[U]) & 0xffff0000u); }
+#define S2_B3(PP, U) S2_ON(PP) { xb[U] -= __uint_as_float(__float_as_uint(xb[U]) & 0xffff0000u); }
+#define S2_C1(PP, U) S2_ON(PP) { qL[(U) >> 2][(U) & 3] = S2_HI(xa[U], xb[U]); }
+        // pixel e = 2 PP + e2 of the quad: halo column c = 4 quad + e - 3 (c < 0: left of the halo), parity c & 1, index (c >> 1) - 2 quad
+#define S2_P(PP, E2, Q) S2_ON(PP) { constexpr int e_ = 2 * (PP) + (E2), par_ = (e_ + 1) & 1, idx_ = e_ == 0 ? -2 : e_ == 3 ? 0 : -1; \
+        const bool wr_ = en && has_item && !(it_quad == 0 && e_ < 3); \
+        *reinterpret_cast<u32x4*>(smem_s2 + (wr_ ? SS * X_BYTES + row_base + par_ * PARB + idx_ * PIXB + (Q) * SPLB : DUMP_OFF)) = (Q) == 0 ? qH[E2] : (Q) == 1 ? qM[E2] : qL[E2]; }
+#define S2_LD(k) if constexpr (STG && DY == 0) load_plane(std::integral_constant<int, P>{}, std::integral_constant<int, k>{}, la, same2 ? C + 2 : C + 2 - NCH);
+        {
+            constexpr int PP1 = DY & 1;
+            S2_MF(0) S2_A1(PP1, 0) S2_A2(PP1, 0) S2_A3(PP1, 0) S2_B1(PP1, 0) S2_FENCE
+            S2_MF(1) S2_B2(PP1, 0) S2_B3(PP1, 0) S2_C1(PP1, 0) S2_FENCE
+            S2_MF(2) S2_A1(PP1, 1) S2_A2(PP1, 1) S2_A3(PP1, 1) S2_B1(PP1, 1) S2_FENCE
+            S2_MF(3) S2_B2(PP1, 1) S2_B3(PP1, 1) S2_C1(PP1, 1) S2_FENCE
+            S2_MF(4) S2_A1(PP1, 2) S2_A2(PP1, 2) S2_A3(PP1, 2) S2_B1(PP1, 2) S2_FENCE
+            S2_MF(5) S2_B2(PP1, 2) S2_B3(PP1, 2) S2_C1(PP1, 2) S2_FENCE
+            S2_MF(6) S2_A1(PP1, 3) S2_A2(PP1, 3) S2_A3(PP1, 3) S2_B1(PP1, 3) S2_FENCE
+            S2_MF(7) S2_B2(PP1, 3) S2_B3(PP1, 3) S2_C1(PP1, 3) S2_FENCE
+            S2_MF(8) S2_A1(PP1, 4) S2_A2(PP1, 4) S2_A3(PP1, 4) S2_B1(PP1, 4) S2_P(PP1, 0, 0) S2_FENCE
+            S2_MF(9) S2_B2(PP1, 4) S2_B3(PP1, 4) S2_C1(PP1, 4) S2_P(PP1, 0, 1) S2_LD(0) S2_FENCE
+            S2_MF(10) S2_A1(PP1, 5) S2_A2(PP1, 5) S2_A3(PP1, 5) S2_B1(PP1, 5) S2_P(PP1, 0, 2) S2_LD(1) S2_FENCE
+            S2_MF(11) S2_B2(PP1, 5) S2_B3(PP1, 5) S2_C1(PP1, 5) S2_LD(2) S2_FENCE
+            S2_MF(12) S2_A1(PP1, 6) S2_A2(PP1, 6) S2_A3(PP1, 6) S2_B1(PP1, 6) S2_LD(3) S2_FENCE
+            S2_MF(13) S2_B2(PP1, 6) S2_B3(PP1, 6) S2_C1(PP1, 6) S2_LD(4) S2_FENCE
+            S2_MF(14) S2_A1(PP1, 7) S2_A2(PP1, 7) S2_A3(PP1, 7) S2_B1(PP1, 7) S2_LD(5) S2_FENCE
+            S2_MF(15) S2_B2(PP1, 7) S2_B3(PP1, 7) S2_C1(PP1, 7) S2_LD(6) S2_FENCE
+            S2_MF(16) S2_P(PP1, 1, 0) S2_P(PP1, 1, 1) S2_LD(7) S2_FENCE
+            S2_MF(17) S2_P(PP1, 1, 2) S2_FENCE
+        }
+#undef S2_MF
+#undef S2_FENCE
+#undef S2_ON
+#undef S2_HI
+#undef S2_A1
+#undef S2_A2
+#undef S2_A3
+#undef S2_B1
+#undef S2_B2
+#undef S2_B3
+#undef S2_C1
+#undef S2_P
+#undef S2_LD
+        S2_KEEP(f[0]) S2_KEEP(f[1])
+#undef S2_KEEP
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7\n\ts_nop 7");      // idle slots: whatever follows must not land in operand registers of the last MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        S2_STAMP(3 + 4 * r)
+    };
+
+    auto do_unit = [&](const Tile& cur, const Tile& nxt, bool has_next, bool first_unit) __attribute__((always_inline)) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        auto rows = [&](auto STGC) __attribute__((always_inline)) {
+            row(I0{}, I0{}, STGC, cur, nxt, has_next, first_unit); row(I0{}, I1{}, STGC, cur, nxt, has_next, first_unit); row(I0{}, I2{}, STGC, cur, nxt, has_next, first_unit);
+            row(I1{}, I0{}, STGC, cur, nxt, has_next, first_unit); row(I1{}, I1{}, STGC, cur, nxt, has_next, first_unit); row(I1{}, I2{}, STGC, cur, nxt, has_next, first_unit);
+            row(I2{}, I0{}, STGC, cur, nxt, has_next, first_unit); row(I2{}, I1{}, STGC, cur, nxt, has_next, first_unit); row(I2{}, I2{}, STGC, cur, nxt, has_next, first_unit);
+            row(I3{}, I0{}, STGC, cur, nxt, has_next, first_unit); row(I3{}, I1{}, STGC, cur, nxt, has_next, first_unit); row(I3{}, I2{}, STGC, cur, nxt, has_next, first_unit);
+        };
+        if (wave * 64 < NITEM) rows(std::integral_constant<int, 1>{});          // (wave-uniform: two copies of the unit's code, no exec masking)
+        else rows(std::integral_constant<int, 0>{});
         // ---- bias, ReLU, buffer stores: lane (pixel, half) holds couts 64 hf + 32 cb + (r & 3) + 8 (r >> 2) + 4 half --------------------
         float bs[16];
 #pragma unroll
@@ -244,7 +289,7 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         const int voff = oy < a.Ho && ox < a.Wo ? (int)(((size_t)(4 * half) * HWo + (size_t)oy * a.Wo + ox) * 4) : (int)0x80000000;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float y = acc[r] + bs[r];
+            float y = (acc[r] + acc2[r]) + bs[r];
             if (a.relu) y = fmaxf(y, 0.f);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)(((r & 3) + 8 * (r >> 2)) * HWo * 4), 0);
         }
@@ -254,18 +299,49 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
     int u = u0;
     tile_at(u++, cur);
     nxt = cur;
+    // prologue: chunk 0 of the first unit is staged with every pipe idle (once per workgroup); chunk 1 waits in set 1
     issue_row(0, cur.hf);
-    issue_row(1, cur.hf);
-    issue_loads(cur, 0);
+    {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        const LoadAddr l0 = load_addr(I0{}, cur, true);
+        load_plane(I0{}, std::integral_constant<int, 0>{}, l0, 0); load_plane(I0{}, std::integral_constant<int, 1>{}, l0, 0);
+        load_plane(I0{}, std::integral_constant<int, 2>{}, l0, 0); load_plane(I0{}, std::integral_constant<int, 3>{}, l0, 0);
+        load_plane(I0{}, std::integral_constant<int, 4>{}, l0, 0); load_plane(I0{}, std::integral_constant<int, 5>{}, l0, 0);
+        load_plane(I0{}, std::integral_constant<int, 6>{}, l0, 0); load_plane(I0{}, std::integral_constant<int, 7>{}, l0, 0);
+        const LoadAddr l1 = load_addr(I1{}, cur, true);
+        load_plane(I1{}, std::integral_constant<int, 0>{}, l1, 1); load_plane(I1{}, std::integral_constant<int, 1>{}, l1, 1);
+        load_plane(I1{}, std::integral_constant<int, 2>{}, l1, 1); load_plane(I1{}, std::integral_constant<int, 3>{}, l1, 1);
+        load_plane(I1{}, std::integral_constant<int, 4>{}, l1, 1); load_plane(I1{}, std::integral_constant<int, 5>{}, l1, 1);
+        load_plane(I1{}, std::integral_constant<int, 6>{}, l1, 1); load_plane(I1{}, std::integral_constant<int, 7>{}, l1, 1);
+        // chunk 0 of the first unit: split and written with every pipe idle (once per workgroup)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u32x4 h, m, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x0 = v[0][2 * j][e], x1 = v[0][2 * j + 1][e];
+                if (!W4) { const bool z = v_gx[0] + e >= a.W; x0 = z ? 0.f : x0; x1 = z ? 0.f : x1; }
+                unsigned hh, mm, ll;
+                split3_trunc(x0, x1, hh, mm, ll);
+                h[j] = hh; m[j] = mm; l[j] = ll;
+            }
+            const bool wr = has_item && !(it_quad == 0 && e < 3);
+            const int par = (e + 1) & 1, idx = e == 0 ? -2 : e == 3 ? 0 : -1;
+            unsigned char* p = smem_s2 + (wr ? row_base + par * PARB + idx * PIXB : DUMP_OFF);
+            *reinterpret_cast<u32x4*>(p) = h;
+            *reinterpret_cast<u32x4*>(p + SPLB) = m;
+            *reinterpret_cast<u32x4*>(p + 2 * SPLB) = l;
+        }
+    }
+    bool first_unit = true;
     for (;;) {
         const bool has_next = u < u1;
         if (has_next) tile_at(u++, nxt);
         S2_STAMP(0)
-        do_tile(cur, nxt, has_next);
+        do_unit(cur, nxt, has_next, first_unit);
         S2_STAMP(50)
         if (!has_next) break;
-        dma_barrier();                         // every wave is done with the unit's last tap row before the next chunk is staged
-        S2_STAMP(51)
+        first_unit = false;
         ++tix;
         cur = nxt;
     }
@@ -273,7 +349,7 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
 #undef S2_STAMP
 }
 
-template <int NCO>
+template <int NCO, bool W4>
 static int run_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if ((size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
@@ -281,18 +357,19 @@ static int run_bx64s2(const ConvW& c, const float* in, int B, int H, int W, floa
     a.in = in; a.wq = c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B; a.trace = trace;
     a.nrows = ceil_div(Ho, 8); a.upi = ceil_div(Wo, 16) * a.nrows;
     static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64s2_kernel<NCO>), bx64s2::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64s2_kernel<NCO, W4>), bx64s2::LDS_BYTES, attr_done);
     const long long units = (long long)NCO * B * a.upi;
-    int grid = num_cus();                      // one 8-wave workgroup per CU (100 KiB of LDS); a multiple of 8 keeps a workgroup on its XCD
+    int grid = num_cus();                      // one 8-wave workgroup per CU (all 160 KiB of LDS); a multiple of 8 keeps a workgroup on its XCD
     if (units < grid) grid = (int)units;       // (small inputs: one unit per workgroup; the XCD mapping then needs grid % 8 == 0 or is skipped)
-    conv_bx64s2_kernel<NCO><<<grid, 512, bx64s2::LDS_BYTES, st>>>(a);
+    conv_bx64s2_kernel<NCO, W4><<<grid, 512, bx64s2::LDS_BYTES, st>>>(a);
     return 0;
 }
 
 int launch_conv_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
     if (c.ks != 3 || c.stride != 2 || !c.w_bx || c.cin != 64) return -1;
-    if (c.cout == 64) return run_bx64s2<1>(c, in, B, H, W, out, st, trace);
-    if (c.cout == 128) return run_bx64s2<2>(c, in, B, H, W, out, st, trace);
+    const bool w4 = (W & 3) == 0;
+    if (c.cout == 64) return w4 ? run_bx64s2<1, true>(c, in, B, H, W, out, st, trace) : run_bx64s2<1, false>(c, in, B, H, W, out, st, trace);
+    if (c.cout == 128) return w4 ? run_bx64s2<2, true>(c, in, B, H, W, out, st, trace) : run_bx64s2<2, false>(c, in, B, H, W, out, st, trace);
     return -1;
 }
 

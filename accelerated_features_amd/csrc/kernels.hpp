@@ -48,7 +48,8 @@ struct Profiler;   // api.hip
 struct Options {
     int match_exact = 0;    // 1: xfh_match_mnn runs the exact f32-MFMA kernel for every pair (no filter)
     int wino = 2;           // 0: 3x3/s1 layers never use Winograd; 1: only unfused layers; 2: fused 3x3 + 1x1 pairs too
-    int bx = 5;             // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0
+    int bx = 21;            // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0,
+                            // 16 = the stride-2 64 -> 64 | 128 layers (block4.0, block5.0)
     int heads_f32 = 0;      // 1: heads on the f32-MFMA kernels
     int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs
 };

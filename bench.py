@@ -208,7 +208,10 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K):
     add(100 + ci["block_fusion.0"], "conv_bx64_kernel<64,0> (block_fusion.0)", 4.0 * 128 * px["8"], fl, fl * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
     for n_, cin, cout, sc_in, sc_out in (("block4.0", 64, 64, "8", "16"), ("block5.0", 64, 128, "16", "32")):
         fl = conv_flops(n_, px[sc_out])
-        add(100 + ci[n_], f"conv_mfma_kernel ({n_}, stride 2, direct)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), fl, fl, f32, "f32 mfma")
+        ho, wo = H // int(sc_out), W // int(sc_out)
+        pad = (-(-ho // 8) * 8) * (-(-wo // 16) * 16) / float(ho * wo)          # 8x16-pixel units over the map (1.28 / 1.71 at VGA)
+        add(100 + ci[n_], f"conv_bx64s2_kernel<{cout // 64}> ({n_}, stride 2)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), fl, fl * 6 * pad, PEAK_BF16_TFLOPS,
+            "bf16 mfma x6 (fp32-equivalent)")
     for n_, ch, sc in (("block4.1", 64, "16"), ("block4.2", 64, "16"), ("block5.1", 128, "32")):
         fl = conv_flops(n_, px[sc])
         add(100 + ci[n_], f"conv_wino_kernel ({n_})", 4.0 * 2 * ch * px[sc], fl, fl / 2.25, f32, "f32 mfma, Winograd F(2x2,3x3)")
@@ -774,7 +777,7 @@ def main():
                                    "the 32 consecutive frame pairs (BASELINE configs[1])",
                        "batch_per_gpu": B, "height": H, "width": W, "top_k": TOP_K, "weights": "synthetic (tests/fixtures.py)",
                        "arithmetic": "fp32 results throughout; the >= 24-channel convolutions and the heads compute them on bf16 MFMAs with three-way split "
-                                     "operands (fp32-equivalent, error <= an fp32 direct convolution's), the deep layers as Winograd / direct on f32 MFMAs, the "
+                                     "operands (fp32-equivalent, error <= an fp32 direct convolution's), the stride-1 layers at 1/16 and 1/32 scale as Winograd F(2x2,3x3) on f32 MFMAs, the "
                                      "matcher decides on exact fp32 dot products (fp16 MFMAs only pre-select 32-wide blocks inside a derived error window)",
                        "parallelism": f"replicas x{world}, no collective",
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
