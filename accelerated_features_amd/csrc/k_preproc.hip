@@ -8,6 +8,11 @@ namespace xfh {
 // gray = mean over C ; per-image mean / biased variance in fp64     (model.py:135-136)
 // grid (GS_CHUNKS, B), block 256.  part[b][chunk][2] = {sum, sum of squares}
 // ------------------------------------------------------------------------------------------
+// CT: channel count known at compile time (1 or 3; 0 = any).  A thread's loads of GS_UNROLL rows x CT channels are issued before any
+// of them is used (the runtime channel loop waited for every load on its own: one float4 in flight per thread, 4.4 TB/s at full
+// occupancy); the arithmetic and its order are unchanged (channel sum c = 0, 1, ..., one division; fp64 sums in row order).
+constexpr int GS_UNROLL = 5;          // VGA: 1200 float4 per chunk = 4.7 rows of 256 threads
+template <int CT>
 __global__ __launch_bounds__(256) void gray_stats_kernel(const float* __restrict__ img, int C, int HW,
                                                          double* __restrict__ part, float* __restrict__ gray) {
     const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
@@ -15,18 +20,41 @@ __global__ __launch_bounds__(256) void gray_stats_kernel(const float* __restrict
     const int per = ceil_div(n4, GS_CHUNKS);
     const int beg = ch * per, end = min(beg + per, n4);
     const float4* base = reinterpret_cast<const float4*>(img + (size_t)b * C * HW);
+    float4* gout = reinterpret_cast<float4*>(gray + (size_t)b * HW);
     const float fC = (float)C;
     double s = 0.0, q = 0.0;
-    for (int i = beg + tid; i < end; i += 256) {
-        float4 a = base[i];
-        for (int c = 1; c < C; ++c) {
-            float4 v = base[(size_t)c * n4 + i];
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
+    auto finish = [&](float4 a, int i) {
         a.x /= fC; a.y /= fC; a.z /= fC; a.w /= fC;
-        reinterpret_cast<float4*>(gray + (size_t)b * HW)[i] = a;      // raw channel mean; consumers apply the per-image (alpha, beta)
+        gout[i] = a;      // raw channel mean; consumers apply the per-image (alpha, beta)
         s += (double)a.x + (double)a.y + (double)a.z + (double)a.w;
         q += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+    };
+    if constexpr (CT > 0) {
+        for (int i0 = beg + tid; i0 < end; i0 += 256 * GS_UNROLL) {
+            float4 v[GS_UNROLL][CT];
+#pragma unroll
+            for (int u = 0; u < GS_UNROLL; ++u) {
+                const int i = min(i0 + 256 * u, end - 1);          // (rows beyond the chunk re-read its last element and are dropped below)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) v[u][c] = base[(size_t)c * n4 + i];
+            }
+#pragma unroll
+            for (int u = 0; u < GS_UNROLL; ++u) {
+                float4 a = v[u][0];
+#pragma unroll
+                for (int c = 1; c < CT; ++c) { a.x += v[u][c].x; a.y += v[u][c].y; a.z += v[u][c].z; a.w += v[u][c].w; }
+                if (i0 + 256 * u < end) finish(a, i0 + 256 * u);
+            }
+        }
+    } else {
+        for (int i = beg + tid; i < end; i += 256) {
+            float4 a = base[i];
+            for (int c = 1; c < C; ++c) {
+                float4 v = base[(size_t)c * n4 + i];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            finish(a, i);
+        }
     }
     s = wave_sum(s);
     q = wave_sum(q);
@@ -110,7 +138,9 @@ __global__ __launch_bounds__(64) void gray_coef_kernel(const double* __restrict_
 void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, float* coef, hipStream_t st) {
     static_assert(GS_CHUNKS == 64, "gray_coef_kernel reduces one wave of partial sums");
     const int HW = H * W;
-    gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, part, gray);
+    if (C == 3) gray_stats_kernel<3><<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, part, gray);
+    else if (C == 1) gray_stats_kernel<1><<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, part, gray);
+    else gray_stats_kernel<0><<<dim3(GS_CHUNKS, B), 256, 0, st>>>(img, C, HW, part, gray);
     gray_coef_kernel<<<B, 64, 0, st>>>(part, HW, 1e-5f, coef);
 }
 
@@ -287,6 +317,8 @@ __device__ inline float bilerp_at(const float* __restrict__ p, int Hs, int Ws, f
     return bilerp(p, Ws, y0, y1, x0, x1, wy0, wy1, wx0, wx1);
 }
 
+struct __attribute__((aligned(16))) PyrCoef { int i0, i1; float l0, l1; };
+
 template <bool USE_LDS>
 __global__ __launch_bounds__(256) void pyramid_sum_kernel(const float* __restrict__ x3, const float* __restrict__ x4,
                                                           const float* __restrict__ x5, float* __restrict__ out,
@@ -326,9 +358,42 @@ __global__ __launch_bounds__(256) void pyramid_sum_kernel(const float* __restric
                 if (e < H4 * W4 + H5 * W5) sm[e] = t[k];
             }
         }
+        // interpolation coefficients of every output column / row, once per plane instead of once per pixel (the kernel was bound by
+        // its vector ops -- ten lin_coef per float4 -- not by HBM): tab[level][W3 columns | H3 rows] = {i0, i1, l0, l1}, the values
+        // lin_coef returns, so that bilerp sees the same operands as before
+        PyrCoef* tab = reinterpret_cast<PyrCoef*>(sm + ((H4 * W4 + H5 * W5 + 3) & ~3));
+        for (int e = tid; e < 2 * (W3 + H3); e += 256) {
+            const int lv = e >= W3 + H3, r = e - lv * (W3 + H3);
+            PyrCoef c;
+            if (r < W3) lin_coef(lv ? s5x : s4x, r, lv ? W5 : W4, c.i0, c.i1, c.l0, c.l1);
+            else lin_coef(lv ? s5y : s4y, r - W3, lv ? H5 : H4, c.i0, c.i1, c.l0, c.l1);
+            tab[e] = c;
+        }
         __syncthreads();
         p4 = sm;
         p5 = sm + H4 * W4;
+        if (vec) {
+            auto emit = [&](int e4, const float4 v) {
+                const int e = e4 * 4, oy = e / W3, ox = e - oy * W3;
+                const PyrCoef y4 = tab[W3 + oy], y5 = tab[W3 + H3 + W3 + oy];
+                const float vin[4] = {v.x, v.y, v.z, v.w};
+                float r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const PyrCoef c4 = tab[ox + k], c5 = tab[W3 + H3 + ox + k];
+                    r[k] = (vin[k] + bilerp(p4, W4, y4.i0, y4.i1, c4.i0, c4.i1, y4.l0, y4.l1, c4.l0, c4.l1))
+                         + bilerp(p5, W5, y5.i0, y5.i1, c5.i0, c5.i1, y5.l0, y5.l1, c5.l0, c5.l1);
+                }
+                *reinterpret_cast<float4*>(out + base + e) = make_float4(r[0], r[1], r[2], r[3]);
+            };
+#pragma unroll
+            for (int k = 0; k < NPRE; ++k) {
+                const int e4 = tid + k * 256;
+                if (e4 < n / 4) emit(e4, pre[k]);
+            }
+            for (int e4 = tid + NPRE * 256; e4 < n / 4; e4 += 256) emit(e4, *reinterpret_cast<const float4*>(x3 + base + 4 * (size_t)e4));
+            return;
+        }
     }
     if (vec) {
         auto emit = [&](int e4, const float4 v) {
@@ -356,7 +421,7 @@ __global__ __launch_bounds__(256) void pyramid_sum_kernel(const float* __restric
 
 void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int planes,
                         int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st) {
-    const size_t lds = ((size_t)H4 * W4 + (size_t)H5 * W5) * sizeof(float);
+    const size_t lds = ((((size_t)H4 * W4 + (size_t)H5 * W5 + 3) & ~(size_t)3) * sizeof(float)) + 2 * (size_t)(W3 + H3) * sizeof(PyrCoef);      // planes + coefficient tables
     if (lds <= 64 * 1024)
         pyramid_sum_kernel<true><<<planes, 256, lds, st>>>(x3, x4, x5, out, H3, W3, H4, W4, H5, W5);
     else
