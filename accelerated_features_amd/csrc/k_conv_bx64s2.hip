@@ -166,7 +166,6 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         if (DY == 1 && STG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (r == 0 && !first_unit) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        S2_STAMP(4 + 4 * r)
         __syncthreads();
         S2_STAMP(2 + 4 * r)
         issue_row(r + 1 < NROW ? r + 1 : 0, r + 1 < NROW ? cur.hf : nxt.hf);          // (the stream is cyclic over the units)

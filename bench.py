@@ -560,6 +560,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (BASELINE config: 64)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (accelerated_features_amd.streaming.FrameStream: one handle + HIP stream each); "
+                                                         "1 = every step waits for its own read-back")
     ap.add_argument("--no-side-passes", action="store_true", help="skip the extraction-only / with-H2D side figures (profiling runs)")
     ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "lighterglue", "megadepth", "demo"],
                     help="sparse = BASELINE configs[1] (the contract metric); dense = configs[2], match_xfeat_star on 1024^2 pairs, batch 32; "
@@ -610,23 +612,55 @@ def main():
     cnt_dev = torch.zeros((3, B), dtype=torch.int32, device="cuda")      # rows: n_valid, n_candidates, n_matches (first B/2 entries)
 
     def step():
-        # (the descriptor kernel also emits the bf16 copy the matcher's filter sweeps read: no separate conversion pass; all counts
+        # ONE batch, synchronously, on this handle (the profiled / side passes below; with --lanes 1 also the timed step):
+        # (the descriptor kernel also emits the fp16 copy the matcher's filter sweep reads: no separate conversion pass; all counts
         # land in one buffer: one read-back, no concatenation kernel)
         kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x, TOP_K, 0.05, want_f16=True, counts_out=cnt_dev[:2])
         i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16, n_out=cnt_dev[2, :B // 2])
         c = cnt_dev.cpu()                                  # the one read-back (ragged results)
         return torch.cat([c[0], c[1], c[2, :B // 2]]), cap
 
+    # The timed step: the same batch through accelerated_features_amd.streaming.FrameStream -- `lanes` batches in flight, one handle + HIP stream
+    # each; a call queues one batch and retires the oldest one once every lane is busy (its ragged counts arrive by an asynchronous copy).  The
+    # latency-bound tail of one batch (NMS compaction, top-k, refine scan, finalize, read-back) fills with the convolutions of the next.
+    from accelerated_features_amd.streaming import FrameStream
+    lanes = max(1, args.lanes)
+    lane_xf = [xf] + [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(lanes - 1)]
+    handles = [l.net.handle() for l in lane_xf]
+    fs = FrameStream(xfeats=lane_xf, top_k=TOP_K, detection_threshold=0.05, min_cossim=-1)
+    retired = []
+
+    def lane_step():
+        r = None
+        if fs.in_flight == fs.lanes:
+            r = fs.result()
+            retired.append(r)
+        fs.submit(x)
+        return r
+
     def arm(last):
-        assert int(last[0][B:2 * B].max()) <= last[1], "NMS capacity overflow in the benchmark workload"
-        lib.xfh_profile_select(handle, _lib.PROF_BLOCK1)
+        for r in fs.drain():                               # nothing of the warm-up is in flight when the timed region starts
+            retired.append(r)
+        assert retired and all(int(r["n_candidates"].max()) <= r["nms_capacity"] for r in retired), "NMS capacity overflow in the benchmark workload"
+        retired.clear()
+        for h_ in handles:
+            lib.xfh_profile_select(h_, _lib.PROF_BLOCK1)
 
-    dt_max, (counts, cap) = sharding.timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
+    # (the barrier + torch.cuda.synchronize() that closes the timed region waits for every lane: all `steps` batches complete inside it)
+    dt_max, _ = sharding.timed_steps(lane_step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
+    retired += fs.drain()
+    assert len(retired) == args.steps
+    last = retired[-1]
+    counts = torch.cat([last["n_valid"], last["n_candidates"], last["n_matches"]])
+    cap = last["nms_capacity"]
 
-    def read_prof():
-        n_, ms_, fl_, by_ = C.c_int(), C.c_double(), C.c_double(), C.c_double()
-        lib.xfh_profile_read(handle, C.byref(n_), C.byref(ms_), C.byref(fl_), C.byref(by_))
-        return n_.value, ms_.value, fl_.value, by_.value
+    def read_prof(hs=None):
+        tot = [0, 0.0, 0.0, 0.0]
+        for h_ in (hs or [handle]):
+            n_, ms_, fl_, by_ = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+            lib.xfh_profile_read(h_, C.byref(n_), C.byref(ms_), C.byref(fl_), C.byref(by_))
+            tot = [tot[0] + n_.value, tot[1] + ms_.value, tot[2] + fl_.value, tot[3] + by_.value]
+        return tuple(tot)
 
     def side_prof(which, n=3):            # secondary (untimed) pass: same events mechanism on another kernel family
         lib.xfh_profile_select(handle, which)
@@ -637,7 +671,9 @@ def main():
         lib.xfh_profile_select(handle, _lib.PROF_NONE)
         return r
 
-    n_l, ms, fl, by = read_prof()
+    n_l, ms, fl, by = read_prof(handles)                  # block1 launches of the timed region, every lane (their durations include the other lane's company)
+    for h_ in handles:
+        lib.xfh_profile_select(h_, _lib.PROF_NONE)
     m_n, m_ms, m_fl, m_by = side_prof(_lib.PROF_MATCH)
     b_n, b_ms, b_fl, b_by = side_prof(_lib.PROF_CONV_24_24)
     cn, cms, cfl, cby = side_prof(_lib.PROF_CONV_MFMA)
@@ -663,9 +699,11 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                step()
+                lane_step()
             torch.cuda.synchronize()
             rep_fps.append(B * args.steps / (time.perf_counter() - t0))
+            fs.drain()
+        retired.clear()
 
     # SURVEY 8(d) side figures, each its own short pass OUTSIDE the timed region above (rank-local, per GPU)
     def rate(fn, n=5):
@@ -680,35 +718,10 @@ def main():
         kp, sc, de, nv, nc, cap_, hw = xf._detect_device(x, TOP_K, 0.05)
         return torch.cat([nv, nc]).cpu()
 
-    def pipelined_readback(n=20):
-        """The same step with its read-back one step deep: the counts of step i travel to pinned host memory asynchronously and are waited for
-        after step i + 1 has been queued, so the GPU never idles on the host round trip (what a consumer loop would do; the contract value above
-        keeps the synchronous read-back inside every step)."""
-        host = [torch.empty((3, B), dtype=torch.int32).pin_memory() for _ in range(2)]
-        dev = [torch.zeros((3, B), dtype=torch.int32, device="cuda") for _ in range(2)]
-        ev = [torch.cuda.Event() for _ in range(2)]
-
-        def queue(i):
-            d = dev[i % 2]
-            kp, sc, de, nv, nc, cap_, hw, d16 = xf._detect_device(x, TOP_K, 0.05, want_f16=True, counts_out=d[:2])
-            xf.match_pairs_device(de, nv, -1, d16, n_out=d[2, :B // 2])
-            host[i % 2].copy_(d, non_blocking=True)
-            ev[i % 2].record()
-        queue(0); ev[0].synchronize()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        queue(0)
-        for i in range(1, n):
-            queue(i)
-            ev[(i - 1) % 2].synchronize()               # step i - 1's ragged counts are on the host now
-        ev[(n - 1) % 2].synchronize()
-        torch.cuda.synchronize()
-        return B * n / (time.perf_counter() - t0)
-
     side = {}
     if rank == 0 and not args.no_side_passes:
         side["extraction_only_fps"] = round(rate(extract_only), 1)
-        side["pipelined_readback_fps"] = round(pipelined_readback(), 1)
+        side["single_lane_synchronous_fps"] = round(rate(step, 20), 1)      # one handle, one stream, every step waits for its read-back (the contract value of rounds 1-3a)
         xh32 = x_host.pin_memory()
         xh8 = (x_host * 255).round().clamp(0, 255).to(torch.uint8).pin_memory()
 
@@ -779,7 +792,8 @@ def main():
                        "arithmetic": "fp32 results throughout; the >= 24-channel convolutions and the heads compute them on bf16 MFMAs with three-way split "
                                      "operands (fp32-equivalent, error <= an fp32 direct convolution's), the stride-1 layers at 1/16 and 1/32 scale as Winograd F(2x2,3x3) on f32 MFMAs, the "
                                      "matcher decides on exact fp32 dot products (fp16 MFMAs only pre-select 32-wide blocks inside a derived error window)",
-                       "parallelism": f"replicas x{world}, no collective",
+                       "parallelism": f"replicas x{world}, no collective; {lanes} batches in flight per GPU (FrameStream: one handle + HIP stream per lane, asynchronous read-back of the counts)",
+                       "lanes": lanes,
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
             # block1 x4 + skip1 in one kernel: fp32 FMA work on the vector ALUs (v_pk_fma_f32), LDS-tiled.  Neither HBM nor the matrix
             # cores bound it (1 -> 4 -> 8 -> 8 -> 24 channels: no K for an MFMA); it is priced against the dense fp32 rate of the chip,
@@ -792,7 +806,13 @@ def main():
                          "flops_per_launch": fl / max(n_l, 1),
                          "algorithmic": "720 FLOP per input pixel (2 * (9*4 + 36*8/4 + 72*8/4 + 72*24/16 + 24/16)) x B*H*W pixels per launch",
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "traffic_algorithmic": int(by / max(n_l, 1))},
+                         "traffic_algorithmic": int(by / max(n_l, 1)),
+                         # with more than one lane the kernel shares the chip with the other lane's kernels while its events tick: the duration of
+                         # the timed region above is NOT its speed on the whole chip; `alone` = the same launch in a single-lane pass of this run
+                         "alone": ({"avg_launch_us": round(spans_us[3], 2), "achieved": round(fl / max(n_l, 1) / 1e6 / spans_us[3], 3),
+                                    "frac": round(fl / max(n_l, 1) / 1e6 / spans_us[3] / PEAK_MFMA_F32_TFLOPS, 4),
+                                    "note": "single-lane pass (xfh_profile_select(XFH_PROF_ALL)), nothing else on the GPU"} if spans_us.get(3) else None),
+                         "lanes_in_timed_region": lanes},
             # xfh_match_mnn = fp16 MFMA filter (derived error window, one sweep in both tile orientations) + exact fp32 refine of the flagged
             # 32-wide blocks (~1.07 per row and column) on f32 MFMAs; identical match lists to the exact f32 MFMA kernel (tests; option
             # match_exact selects the latter).  "algorithmic" prices the fp32 work of D1.D2^T against the f32 MFMA peak: above 1 means the
@@ -813,7 +833,9 @@ def main():
             # frac_vs_survey_roof: SURVEY 8(d)'s figure (direct fp32 convolutions at 157.3 TF + one f32 GEMM for the match = 26.9 us per frame): a
             # bound the implementation has left behind (Winograd executes 2.25x fewer FLOPs, the split-bf16 and fp16 kernels run on a 16x faster pipe).
             # hbm_fraction: the north_star's bar (>= 0.8 of the HBM roofline on 78.6 MB per frame) -- NOT met: the path is compute-side bound.
+            # frac_timed: the same sum of floors against the WALL time of a timed step (all lanes, host included): what the chip delivers per step.
             "roofline_path": {"frac": k_sum["frac"], "sum_of_kernel_floors_us_per_step": k_sum["sum_of_floors_us_per_step"], "kernels_us_per_step": k_sum["kernels_us_per_step"],
+                              "frac_timed": round(k_sum["sum_of_floors_us_per_step"] / (1e6 * dt_max / args.steps), 4),
                               "frac_vs_survey_roof": round(fps_gpu * T_ROOF_US_PER_FRAME / 1e6, 4), "t_roof_survey_us_per_frame": T_ROOF_US_PER_FRAME,
                               "hbm_fraction": round(ALGO_BYTES_PER_FRAME * fps_gpu / 8.0e12, 4), "north_star_hbm_bar": 0.8, "north_star_hbm_bar_met": bool(ALGO_BYTES_PER_FRAME * fps_gpu / 8.0e12 >= 0.8),
                               "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME, "algorithmic_flops_per_frame": ALGO_FLOPS_PER_FRAME,

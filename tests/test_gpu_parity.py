@@ -958,3 +958,43 @@ def test_match_on_rounding_aligned_adversarial_sets(xf):
                 assert n == len(o0) and torch.equal(i0[0, :n].cpu(), o0) and torch.equal(i1[0, :n].cpu(), o1), name
         print(name, d1.shape, d2.shape, "strict mutual matches", n_strict, "reported", len(o0))
     assert total > 1500
+
+
+def test_frame_stream_lanes_deliver_the_synchronous_results_in_order(xf, sd):
+    """accelerated_features_amd.streaming.FrameStream: batches on two lanes (two handles, two HIP streams, asynchronous read-back of the ragged counts)
+    give, ticket by ticket, exactly what the synchronous device path gives for the same batch -- key-points, scores, descriptors, match lists, counts."""
+    from accelerated_features_amd.streaming import FrameStream
+    fs = FrameStream(weights=sd, top_k=512, lanes=2)
+    batches = [fixtures.texture_images(4, 96, 128, seed=40 + i).cuda() for i in range(5)]
+    batches[3] = fixtures.texture_images(6, 64, 96, seed=99).cuda()          # another shape / batch size in the middle of the stream
+    want = []
+    for x in batches:
+        kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x, 512, 0.05, want_f16=True)
+        i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16)
+        want.append((kp.clone(), sc.clone(), de.clone(), nv.cpu(), nc.cpu(), i0.clone(), i1.clone(), nm.cpu()))
+    got, tickets = [], []
+    for i, x in enumerate(batches):
+        if fs.in_flight == fs.lanes:
+            got.append(fs.result(tickets[len(got)]))
+        tickets.append(fs.submit(x))
+    with pytest.raises(RuntimeError):
+        fs.result(tickets[-1])                                               # tickets retire in order
+    got += fs.drain()
+    assert [g["ticket"] for g in got] == tickets == list(range(5)) and fs.in_flight == 0
+    for g, w in zip(got, want):
+        kp, sc, de, nv, nc, i0, i1, nm = w
+        assert torch.equal(g["n_valid"], nv) and torch.equal(g["n_candidates"], nc) and torch.equal(g["n_matches"], nm)
+        for b in range(len(nv)):
+            n = int(nv[b])
+            assert torch.equal(g["keypoints"][b, :n], kp[b, :n]) and torch.equal(g["scores"][b, :n], sc[b, :n]) and torch.equal(g["descriptors"][b, :n], de[b, :n])
+        for p_ in range(len(nm)):
+            n = int(nm[p_])
+            assert n > 0 and torch.equal(g["idx0"][p_, :n], i0[p_, :n]) and torch.equal(g["idx1"][p_, :n], i1[p_, :n])
+    with pytest.raises(RuntimeError):
+        fs.result()
+    t = [fs.submit(batches[0]), fs.submit(batches[1])]
+    with pytest.raises(RuntimeError):
+        fs.submit(batches[2])                                                # both lanes busy
+    fs.drain()
+    with pytest.raises(ValueError):
+        fs.submit(batches[0][:3])

@@ -126,6 +126,9 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
         xf.net(torch.rand(1, 3, 64, 64))
     with pytest.raises(RuntimeError):
         xf.match_lighterglue({}, {})
+    from accelerated_features_amd.streaming import FrameStream
+    with pytest.raises(_lib.XFeatHipError):
+        FrameStream(weights=fixtures.synthetic_state_dict(0), lanes=2)
     # the C ABI itself refuses to create a context without a device
     import ctypes as C
     arrs = xf.net.weight_arrays()

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """ISA audit: in every kernel that uses the global->LDS DMA (global_load_lds* / buffer_load* ... lds), every
 s_barrier must be directly preceded by an s_waitcnt with vmcnt(0) -- hipcc was observed to drop it (see common.hpp
-lds_dma_barrier).  Exit code 1 and a listing on violation.   python tools/check_dma_barriers.py"""
+lds_dma_barrier) -- or by an EXPLICIT wait written in inline asm (between ;;#ASMSTART / ;;#ASMEND) with a deliberate count:
+k_conv_bx64s2.hip leaves the n youngest operations in flight (vmcnt counts in issue order; the kernel's comments derive n).
+Exit code 1 and a listing on violation.   python tools/check_dma_barriers.py"""
 import glob
 import os
 import re
@@ -25,7 +27,15 @@ def audit(src):
         if "global_load_lds" not in body and not re.search(r"buffer_load_dword\w*[^\n]* lds", body):
             continue
         n_kern += 1
-        ins = [l.strip() for l in body.splitlines() if l.startswith("\t") and not l.strip().startswith((";", "."))]
+        ins, in_asm = [], False
+        for l in body.splitlines():
+            t = l.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif l.startswith("\t") and not t.startswith((";", ".")):
+                ins.append(("asm:" if in_asm else "") + t)
         for i, l in enumerate(ins):
             if l.startswith("s_barrier"):
                 n_bar += 1
@@ -33,10 +43,10 @@ def audit(src):
                 ok, j = False, i - 1
                 while j >= 0 and i - j < 64:
                     p = ins[j]
-                    if "s_waitcnt" in p and "vmcnt(0)" in p:
+                    if "s_waitcnt" in p and ("vmcnt(0)" in p or (p.startswith("asm:") and "vmcnt(" in p)):
                         ok = True
                         break
-                    if p.startswith(("global_", "buffer_", "flat_", "scratch_", "s_barrier", "s_cbranch", "s_branch")):
+                    if p.replace("asm:", "").startswith(("global_", "buffer_", "flat_", "scratch_", "s_barrier", "s_cbranch", "s_branch")):
                         break
                     j -= 1
                 if not ok:

@@ -27,8 +27,8 @@ t = tr.cpu().numpy().reshape(-1, 64).astype(np.float64); t = t[t[:, 0] != 0]
 print("workgroups with a second unit", len(t))
 rows = t[:, 1:49].reshape(len(t), 12, 4)
 print("unit start -> first row start (zero acc, stage chunk 0): %.0f" % (rows[:, 0, 0] - t[:, 0]).mean())
-print("per row means: vmcnt wait | barrier | DMA issue, fragment reads, MFMAs + staging | to next row start")
+print("per row means: vmcnt wait + barrier | DMA issue, fragment reads, MFMAs + staging | to next row start")
 for r in range(12):
     nxt = rows[:, r + 1, 0] if r < 11 else t[:, 50]
-    print(r, "%.0f %.0f %.0f %.0f" % ((rows[:, r, 3] - rows[:, r, 0]).mean(), (rows[:, r, 1] - rows[:, r, 3]).mean(), (rows[:, r, 2] - rows[:, r, 1]).mean(), (nxt - rows[:, r, 2]).mean()))
+    print(r, "%.0f %.0f %.0f" % ((rows[:, r, 1] - rows[:, r, 0]).mean(), (rows[:, r, 2] - rows[:, r, 1]).mean(), (nxt - rows[:, r, 2]).mean()))
 print("whole unit (start -> stores issued): %.0f ; end barrier %.0f" % ((t[:, 50] - t[:, 0]).mean(), (t[:, 51] - t[:, 50])[t[:, 51] > 0].mean()))
