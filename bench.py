@@ -726,8 +726,10 @@ def main():
         xh8 = (x_host * 255).round().clamp(0, 255).to(torch.uint8).pin_memory()
 
         def with_h2d(src):
+            xd = torch.empty(src.shape, dtype=src.dtype, device="cuda")          # (one device buffer: a fresh 236 MB allocation per step would time the allocator)
+
             def f():
-                xd = src.cuda(non_blocking=True)
+                xd.copy_(src, non_blocking=True)
                 kp, sc, de, nv, nc, cap_, hw, d16 = xf._detect_device(xd, TOP_K, 0.05, want_f16=True)
                 i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16)
                 return torch.cat([nv, nc, nm]).cpu()
