@@ -11,7 +11,13 @@
 One step = one pass of the hot path over one batch: detectAndCompute on B synthetic VGA
 frames already resident in HBM, then the MNN match of the B/2 consecutive frame pairs
 (2i, 2i+1) (`match_xfeat` semantics, min_cossim=-1), then the ONE host read-back of the
-per-image counts that the ragged results need.  Multi-GPU: every rank is a replica with its
+per-image counts that the ragged results need.  The K timed steps go through
+accelerated_features_amd.streaming.FrameStream with `--lanes` (default 2) batches in flight: a step
+queues one batch on the next lane (handle + HIP stream) and retires the oldest one -- its counts
+arrive by an asynchronous copy -- so that one batch's latency-bound tail runs under the other's
+convolutions; nothing is in flight when the timed region starts and the closing synchronize covers
+every lane.  `--lanes 1` = every step waits for its own read-back (`single_lane_synchronous_fps`).
+Multi-GPU: every rank is a replica with its
 own batch (weak scaling, no data-path collective; RCCL only for the barrier / max-time).
 
 Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s.
