@@ -15,8 +15,8 @@ per-image counts that the ragged results need.  The K timed steps go through
 accelerated_features_amd.streaming.FrameStream with `--lanes` (default 2) batches in flight: a step
 queues one batch on the next lane (handle + HIP stream) and retires the oldest one -- its counts
 arrive by an asynchronous copy -- so that one batch's latency-bound tail runs under the other's
-convolutions; nothing is in flight when the timed region starts and the closing synchronize covers
-every lane.  `--lanes 1` = every step waits for its own read-back (`single_lane_synchronous_fps`).
+convolutions; nothing is in flight when the timed region starts and the K-th step retires everything
+still in flight.  `--lanes 1` = every step waits for its own read-back (`single_lane_synchronous_fps`).
 Multi-GPU: every rank is a replica with its
 own batch (weak scaling, no data-path collective; RCCL only for the barrier / max-time).
 
@@ -636,12 +636,18 @@ def main():
     fs = FrameStream(xfeats=lane_xf, top_k=TOP_K, detection_threshold=0.05, min_cossim=-1)
     retired = []
 
+    timed_calls = [None]                                   # calls left in the timed region (None: warm-up)
+
     def lane_step():
         r = None
         if fs.in_flight == fs.lanes:
             r = fs.result()
             retired.append(r)
         fs.submit(x)
+        if timed_calls[0] is not None:
+            timed_calls[0] -= 1
+            if timed_calls[0] == 0:                        # the last timed step also retires what is still in flight: all K results are delivered inside the region
+                retired.extend(fs.drain())
         return r
 
     def arm(last):
@@ -649,13 +655,14 @@ def main():
             retired.append(r)
         assert retired and all(int(r["n_candidates"].max()) <= r["nms_capacity"] for r in retired), "NMS capacity overflow in the benchmark workload"
         retired.clear()
+        timed_calls[0] = args.steps
         for h_ in handles:
             lib.xfh_profile_select(h_, _lib.PROF_BLOCK1)
 
     # (the barrier + torch.cuda.synchronize() that closes the timed region waits for every lane: all `steps` batches complete inside it)
     dt_max, _ = sharding.timed_steps(lane_step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
-    retired += fs.drain()
-    assert len(retired) == args.steps
+    timed_calls[0] = None
+    assert len(retired) == args.steps and fs.in_flight == 0
     last = retired[-1]
     counts = torch.cat([last["n_valid"], last["n_candidates"], last["n_matches"]])
     cap = last["nms_capacity"]
