@@ -287,12 +287,14 @@ def side_workloads(xf, x, B, seconds_cap=90.0):
         return round(P / timed(lambda: xf.match_xfeat_star(a, b, top_k=TOP_K), 4), 1)
 
     def megadepth():
+        from accelerated_features_amd import XFeat
         from accelerated_features_amd.batching import match_pairs
         sizes, _ = sharding.megadepth_pair_sizes()
         big = (fixtures.texture_images(2, 1600, 1600, seed=31) * 255).round().clamp(0, 255).to(torch.uint8).cuda()
         img = lambda hw, v: big[v, :, :hw[0], :hw[1]].contiguous()
         pairs = [(img(a_, i % 2), img(b_, (i + 1) % 2) if a_ != b_ else torch.roll(img(a_, i % 2), (8 + i % 5, 16), (1, 2))) for i, (a_, b_) in enumerate(sizes)]
-        return round(len(pairs) / timed(lambda: match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16), 1), 1)
+        xf2 = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05)      # second lane of the runner
+        return round(len(pairs) / timed(lambda: match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16, xfeat2=xf2), 1), 1)
 
     def lighterglue():
         from accelerated_features_amd.lighterglue import LighterGlue
@@ -442,8 +444,11 @@ def bench_megadepth(args, xf, rank, world, dist):
         a, b = sizes[i]
         pairs.append((image(a, i % 2), image(b, (i + 1) % 2) if a != b else torch.roll(image(a, i % 2), (8 + i % 5, 16), (1, 2))))
 
+    from accelerated_features_amd import XFeat
+    xf2 = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) if args.lanes > 1 else None      # the runner's second lane
+
     def step():
-        return match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16)
+        return match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16, xfeat2=xf2)
 
     secs, res = sharding.timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     tmax = torch.tensor([secs], dtype=torch.float64)

@@ -625,6 +625,13 @@ def test_batched_pair_runner_equals_pairwise_match_xfeat(xf):
     lo = len(pairs) - len(half)
     for (m0, m1), (r0, r1) in zip(half, got[lo:]):
         assert np.array_equal(m0, r0) and np.array_equal(m1, r1)
+    # two lanes (a second handle, two HIP streams, read-back of batch j under batch j + 1): the same lists
+    from accelerated_features_amd import XFeat
+    xf2 = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=512)
+    two = match_pairs(xf, pairs, top_k=512, max_pairs=2, xfeat2=xf2)
+    assert len(two) == len(got)
+    for (m0, m1), (r0, r1) in zip(two, got):
+        assert np.array_equal(m0, r0) and np.array_equal(m1, r1)
 
 
 def test_batched_star_runner_equals_pairwise_match_xfeat_star(xf):
