@@ -337,11 +337,16 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
                             }
                         const int y1 = 4 * Y4 - 5 + 2 * r + py, x1 = 4 * X4 - 5 + 2 * c + px;
                         const bool ok = y1 >= 0 && y1 < H && x1 >= 0 && x1 < W;
-                        c1v[py][px][0] = ok ? f2{fmaxf(a01.x, 0.f), fmaxf(a01.y, 0.f)} : f2{0.f, 0.f};
-                        c1v[py][px][1] = ok ? f2{fmaxf(a23.x, 0.f), fmaxf(a23.y, 0.f)} : f2{0.f, 0.f};
+                        // ReLU and the zero padding in ONE op per value: median(a, 0, hi) = max(a, 0) for hi = +inf, = 0 for hi = 0
+                        const float hi = ok ? __builtin_inff() : 0.f;
+                        c1v[py][px][0] = f2{__builtin_amdgcn_fmed3f(a01.x, 0.f, hi), __builtin_amdgcn_fmed3f(a01.y, 0.f, hi)};
+                        c1v[py][px][1] = f2{__builtin_amdgcn_fmed3f(a23.x, 0.f, hi), __builtin_amdgcn_fmed3f(a23.y, 0.f, hi)};
                     }
+                // conv2 on explicit 2-vectors: hipcc left the scalar form as 288 v_fmac_f32 per pixel (the PMC count of the kernel, 125 M vector
+                // wave-instructions per launch = 93 % of its duration at 4 cycles each, says the kernel IS vector-issue bound: 45 % of them were this stage)
+                f2 q[4];
 #pragma unroll
-                for (int co = 0; co < 8; ++co) acc[co] = bb2[co];
+                for (int j = 0; j < 4; ++j) q[j] = f2{bb2[2 * j], bb2[2 * j + 1]};
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -350,11 +355,12 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
                         for (int px = 0; px < 3; ++px) {
                             const float v = ci & 1 ? c1v[py][px][ci >> 1].y : c1v[py][px][ci >> 1].x;
                             const float* w = w2 + ((ci * 9) + py * 3 + px) * 8;
+                            const f2 vv = f2{v, v};
 #pragma unroll
-                            for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, w[co], acc[co]);
+                            for (int j = 0; j < 4; ++j) q[j] = __builtin_elementwise_fma(vv, f2{w[2 * j], w[2 * j + 1]}, q[j]);
                         }
 #pragma unroll
-                for (int co = 0; co < 8; ++co) acc[co] = fmaxf(acc[co], 0.f);
+                for (int j = 0; j < 4; ++j) { acc[2 * j] = fmaxf(q[j].x, 0.f); acc[2 * j + 1] = fmaxf(q[j].y, 0.f); }
             }
 #pragma unroll
             for (int co = 0; co < 8; ++co) C2[co * (C2H * C2W) + e] = acc[co];
