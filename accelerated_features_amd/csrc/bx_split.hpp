@@ -24,6 +24,10 @@ __device__ inline void split3(float a, float b, unsigned& h, unsigned& m, unsign
     l = pk_bf16_rne(sa, sb);
 }
 
+// (Measured in round 3 and dropped: the residual r = x - h as ONE v_dot2c_f32_bf16 on the packed word with the constant pair (-1, 0) / (0, -1) -- 7 ops per
+// pair instead of 11, exact, all 75 GPU tests green as the split of every split-bf16 kernel -- but no kernel got faster and k_conv_bx64s2, whose split sits inside its
+// MFMA rows, got 10 % slower: the dot instruction does not issue at the rate of an and / sub.  Also: as a literal, hipcc encodes the pair 0x0000bf80 as the inline
+// constant -1.0, which the instruction reads as the fp32 pattern 0xbf800000 = the pair (0, -1).)
 // The same by truncation: h, m = the leading 8 + 8 significant bits, l = the remaining 8 -- a + b + c is EXACT (fp32 has 24), every op is a
 // plain and / sub / v_perm_b32 (which packs the two high halves).  |m| < 2^-7 |a|,
 // |l| < 2^-15 |a|: with RNE-split weights (|wm| <= 2^-9, |wl| <= 2^-18) the three dropped cross terms stay below 2^-23 of the product, zero-mean.
