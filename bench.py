@@ -573,6 +573,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (accelerated_features_amd.streaming.FrameStream: one handle + HIP stream each); "
                                                          "1 = every step waits for its own read-back")
+    ap.add_argument("--wake-ms", type=float, default=200.0, help="untimed steps for this many ms before the profiling passes and the warm-up (a cold GPU's first ~150 ms run 3-4 %% slow); 0 = none")
     ap.add_argument("--no-side-passes", action="store_true", help="skip the extraction-only / with-H2D side figures (profiling runs)")
     ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "lighterglue", "megadepth", "demo"],
                     help="sparse = BASELINE configs[1] (the contract metric); dense = configs[2], match_xfeat_star on 1024^2 pairs, batch 32; "
@@ -664,14 +665,6 @@ def main():
         for h_ in handles:
             lib.xfh_profile_select(h_, _lib.PROF_BLOCK1)
 
-    # (the barrier + torch.cuda.synchronize() that closes the timed region waits for every lane: all `steps` batches complete inside it)
-    dt_max, _ = sharding.timed_steps(lane_step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
-    timed_calls[0] = None
-    assert len(retired) == args.steps and fs.in_flight == 0
-    last = retired[-1]
-    counts = torch.cat([last["n_valid"], last["n_candidates"], last["n_matches"]])
-    cap = last["nms_capacity"]
-
     def read_prof(hs=None):
         tot = [0, 0.0, 0.0, 0.0]
         for h_ in (hs or [handle]):
@@ -689,12 +682,6 @@ def main():
         lib.xfh_profile_select(handle, _lib.PROF_NONE)
         return r
 
-    n_l, ms, fl, by = read_prof(handles)                  # block1 launches of the timed region, every lane (their durations include the other lane's company)
-    for h_ in handles:
-        lib.xfh_profile_select(h_, _lib.PROF_NONE)
-    m_n, m_ms, m_fl, m_by = side_prof(_lib.PROF_MATCH)
-    b_n, b_ms, b_fl, b_by = side_prof(_lib.PROF_CONV_24_24)
-    cn, cms, cfl, cby = side_prof(_lib.PROF_CONV_MFMA)
 
     def span_pass(n=3):                   # every kernel of the step as its own HIP-event span (untimed pass)
         lib.xfh_profile_select(handle, _lib.PROF_ALL)
@@ -709,7 +696,47 @@ def main():
             acc[ids[i]] = acc.get(ids[i], 0.0) + sms[i]
         return {k: 1e3 * v / n for k, v in acc.items()}
 
+    # GPU wake-up BEFORE the warm-up.  A GPU that has just been woken delivers 3-4 % less for its first ~150 ms of work (power state: bench.py --warmup 5 alone
+    # 38.8 k frames/s, --warmup 40 40.2 k, every later window of the same run 40-41.8 k; a kernel span measured cold read 386 us for block1 against 245):
+    # untimed windows of steps (at least --wake-ms, until two windows in a row agree within 1 %) bring it to the state a stream of batches runs in; block1's HIP events are created here (hipEventCreate inside
+    # the timed region cost its first window 1.8 %).  Then the contract's W warm-up steps and K timed steps, back to back.
+    for h_ in handles:
+        lib.xfh_profile_select(h_, _lib.PROF_BLOCK1)
+    t_wake, n_wake, wake_rates = time.perf_counter(), 0, []
+    while args.wake_ms > 0:                                # windows of `steps` untimed steps until two in a row agree within 1 % (and >= wake_ms, <= 8 x wake_ms have passed)
+        torch.cuda.synchronize()
+        t0w = time.perf_counter()
+        for _ in range(args.steps):
+            lane_step()
+        retired.extend(fs.drain())
+        torch.cuda.synchronize()
+        wake_rates.append(B * args.steps / (time.perf_counter() - t0w))
+        n_wake += args.steps
+        el = (time.perf_counter() - t_wake) * 1e3
+        settled = len(wake_rates) >= 2 and abs(wake_rates[-1] / wake_rates[-2] - 1.0) < 0.01
+        if (el >= args.wake_ms and settled) or el >= 8 * args.wake_ms:
+            break
+    retired.clear()
+    for h_ in handles:
+        lib.xfh_profile_select(h_, _lib.PROF_NONE)
+
+    # (the barrier + torch.cuda.synchronize() that closes the timed region waits for every lane: all `steps` batches complete inside it)
+    dt_max, _ = sharding.timed_steps(lane_step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
+    timed_calls[0] = None
+    assert len(retired) == args.steps and fs.in_flight == 0
+    last = retired[-1]
+    counts = torch.cat([last["n_valid"], last["n_candidates"], last["n_matches"]])
+    cap = last["nms_capacity"]
+
+    n_l, ms, fl, by = read_prof(handles)                  # block1 launches of the timed region, every lane (their durations include the other lane's company)
+    for h_ in handles:
+        lib.xfh_profile_select(h_, _lib.PROF_NONE)
+    # untimed profiling passes (12 single-lane steps): every kernel as a span, then three kernel families
     spans_us = span_pass()
+    m_n, m_ms, m_fl, m_by = side_prof(_lib.PROF_MATCH)
+    b_n, b_ms, b_fl, b_by = side_prof(_lib.PROF_CONV_24_24)
+    cn, cms, cfl, cby = side_prof(_lib.PROF_CONV_MFMA)
+
     # five more timed windows of `steps` steps each (same protocol, this rank only): the spread of the headline figure
     rep_fps = []
     if rank == 0 and not args.no_side_passes:
@@ -814,6 +841,8 @@ def main():
                                      "matcher decides on exact fp32 dot products (fp16 MFMAs only pre-select 32-wide blocks inside a derived error window)",
                        "parallelism": f"replicas x{world}, no collective; {lanes} batches in flight per GPU (FrameStream: one handle + HIP stream per lane, asynchronous read-back of the counts)",
                        "lanes": lanes,
+                       "untimed_before_the_timed_region": f"GPU wake-up ({n_wake} steps: windows of {args.steps} until two agree within 1 %, >= {args.wake_ms:.0f} ms; a cold GPU runs its first ~150 ms 3-4 % slow), then the W warm-up steps",
+                       "wake_up_window_fps": [round(r, 1) for r in wake_rates],
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
             # block1 x4 + skip1 in one kernel: fp32 FMA work on the vector ALUs (v_pk_fma_f32), LDS-tiled.  Neither HBM nor the matrix
             # cores bound it (1 -> 4 -> 8 -> 8 -> 24 channels: no K for an MFMA); it is priced against the dense fp32 rate of the chip,
