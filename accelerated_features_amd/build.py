@@ -23,7 +23,9 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 # per-file additions.  k_match_f16: without NaN semantics fmaxf(fmaxf(a, b), c) is ONE v_max3_f32 (else every operand is canonicalised
 # first); descriptors are finite by construction.  No SLP: hipcc paired the refine's four fma chains into v_pk_fma_f32, shuffling the 64
 # registers of the Y row into pairs first (32 more registers: spills).
-EXTRA_FLAGS = {"k_match_f16.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"k_match_f16.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
+               # block1 is vector-issue bound (PMC): with NaN semantics every ReLU is a canonicalising v_max(x, x) + the v_max(x, 0); activations are finite
+               "k_conv_direct.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():
