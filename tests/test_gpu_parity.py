@@ -1005,3 +1005,27 @@ def test_frame_stream_lanes_deliver_the_synchronous_results_in_order(xf, sd):
     fs.drain()
     with pytest.raises(ValueError):
         fs.submit(batches[0][:3])
+
+
+def test_frame_stream_at_the_bench_shape_is_bit_stable_over_many_steps(xf, sd):
+    """Two lanes at BASELINE configs[1] (64 VGA frames, top_k 4096): 40 batches in flight two at a time -- every retired result equals the synchronous one
+    bit for bit (two handles running the same kernels concurrently share nothing but the device)."""
+    from accelerated_features_amd.streaming import FrameStream
+    x = torch.cat([fixtures.texture_images(8, 480, 640, seed=77)] * 8).cuda()
+    kp0, sc0, de0, nv0, nc0, cap, hw, d16 = xf._detect_device(x, 4096, 0.05, want_f16=True)
+    i00, i10, nm0 = xf.match_pairs_device(de0, nv0, -1, d16)
+    nv_h, nm_h = nv0.cpu(), nm0.cpu()
+    fs = FrameStream(weights=sd, top_k=4096, lanes=2)
+    n_checked = 0
+    for step in range(40):
+        if fs.in_flight == fs.lanes:
+            r = fs.result()
+            assert torch.equal(r["n_valid"], nv_h) and torch.equal(r["n_matches"], nm_h), step
+            assert torch.equal(r["keypoints"], kp0) and torch.equal(r["scores"], sc0) and torch.equal(r["descriptors"], de0), step
+            for p in (0, 13, 31):
+                n = int(nm_h[p])
+                assert torch.equal(r["idx0"][p, :n], i00[p, :n]) and torch.equal(r["idx1"][p, :n], i10[p, :n]), (step, p)
+            n_checked += 1
+        fs.submit(x)
+    n_checked += len(fs.drain())
+    assert n_checked == 40
