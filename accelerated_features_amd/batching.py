@@ -4,8 +4,7 @@ The reference's benchmarks call `matcher_fn(img0, img1)` one pair at a time
 (modules/eval/megadepth1500.py:199-237, scannet1500.py:255-300).  On an MI355X a single VGA pair
 leaves the device almost idle; this runner takes the whole list of pairs, groups it by image size,
 pushes each group through `XFeat._detect_device` + `XFeat.match_pairs_device` in batches of up to
-`max_pairs`, and reads back the matched coordinates of a whole batch in two copies -- with a second XFeat instance (`xfeat2`) on two
-lanes, one batch's read-back under the next batch's kernels.  The results are exactly what
+`max_pairs`, and reads back one small tensor of counts per batch.  The results are exactly what
 `XFeat.match_xfeat` returns pair by pair (results do not depend on batch composition; checked by
 tests/test_gpu_parity.py), in the original order.
 """
@@ -31,12 +30,10 @@ def _as_nchw(img):
     return img, None
 
 
-def match_pairs(xfeat, pairs, top_k=None, min_cossim=-1, max_pairs=32, rank=0, world=1, xfeat2=None):
+def match_pairs(xfeat, pairs, top_k=None, min_cossim=-1, max_pairs=32, rank=0, world=1):
     """pairs: sequence of (img0, img1), each a numpy (H,W[,C]) image (scaled by 1/255 like
     XFeat.parse_input) or a (C,H,W) / (1,C,H,W) tensor.  Returns a list (same order, only this rank's
     shard when world > 1) of (mkpts0, mkpts1) numpy float32 (N,2) arrays -- XFeat.match_xfeat's result.
-    xfeat2: a second XFeat instance (same weights, its own handle): the batches then alternate between two lanes (one HIP stream each) and a
-    batch's results are read back while the next one computes (as streaming.FrameStream does for frame batches); same results.
     """
     from .xfeat import _U8Image
     if top_k is None:
@@ -52,110 +49,51 @@ def match_pairs(xfeat, pairs, top_k=None, min_cossim=-1, max_pairs=32, rank=0, w
         key = (tuple(it[1].shape), tuple(it[3].shape), it[1].dtype, it[3].dtype, it[2], it[4])
         groups.setdefault(key, []).append(it)
     out = {}
-
-    def run_chunk(xf, key, chunk, caps=(None, None)):
-        """queue one batch on xf (current stream); returns the device results + what a capacity check needs"""
+    for key, members in groups.items():
         same_shape = key[0] == key[1] and key[2] == key[3] and key[4] == key[5]
-        if same_shape:
-            frames = torch.stack([t for it in chunk for t in (it[1], it[3])])        # (2P,C,H,W): frames 2i, 2i+1 = pair i
-            x = _U8Image(frames, key[4]) if key[4] is not None else frames
-            kpts, _, desc, nv, nc, cap, hw = xf._detect_device(x, top_k, None, caps[0])
-            idx0, idx1, nm = xf.match_pairs_device(desc, nv, min_cossim)
-            return (kpts[0::2], kpts[1::2], idx0, idx1, nm), ((nc, cap, hw),)
-        # the two images of a pair differ in size: one batch per side
-        xa = torch.stack([it[1] for it in chunk])
-        xb = torch.stack([it[3] for it in chunk])
-        xa = _U8Image(xa, key[4]) if key[4] is not None else xa
-        xb = _U8Image(xb, key[5]) if key[5] is not None else xb
-        ka, _, da, na, nca, capa, hwa = xf._detect_device(xa, top_k, None, caps[0])
-        kb, _, db, nb, ncb, capb, hwb = xf._detect_device(xb, top_k, None, caps[1])
-        idx0, idx1, nm = xf.match_sets_device(da, na, db, nb, min_cossim)
-        return (ka, kb, idx0, idx1, nm), ((nca, capa, hwa), (ncb, capb, hwb))
-
-    def exact(xf, key, chunk):
-        """run_chunk with the capacity re-run of detectAndCompute (plateau images), synchronously"""
-        caps = [None, None]
-        while True:
-            res, chk = run_chunk(xf, key, chunk, tuple(caps))
-            again = False
-            for j, (nc, cap, hw) in enumerate(chk):
-                ncmax = int(nc.max())
-                if cap < hw and ncmax > cap:
-                    caps[j] = min(hw, max(ncmax, 2 * cap))
-                    again = True
-                else:
-                    caps[j] = cap
-            if not again:
-                return res
-
-    jobs = [(key, members[s:s + max_pairs]) for key, members in groups.items() for s in range(0, len(members), max_pairs)]
-    if xfeat2 is None:
-        for key, chunk in jobs:
-            _collect(out, chunk, *exact(xfeat, key, chunk))
-        return [out[i] for i in range(lo, hi)]
-
-    # two lanes: batch j on lane j % 2; a lane's previous batch is finished (host side) right before the lane is given the next one
-    lanes = [{"xf": xfeat, "stream": torch.cuda.Stream(), "event": torch.cuda.Event(), "pending": None},
-             {"xf": xfeat2, "stream": torch.cuda.Stream(), "event": torch.cuda.Event(), "pending": None}]
-
-    def pinned(ln, name, like):
-        buf = ln.get(name)
-        if buf is None or buf.dtype != like.dtype or buf.numel() < like.numel():
-            buf = torch.empty((max(like.numel(), 1),), dtype=like.dtype).pin_memory()
-            ln[name] = buf
-        return buf[:like.numel()].view(like.shape)
-
-    def finish(ln):
-        if ln["pending"] is None:
-            return
-        key, chunk, packed, counts, ncs, chk = ln["pending"]
-        ln["pending"] = None
-        ln["event"].synchronize()
-        if any(cap < hw and int(nch.max()) > cap for nch, (_, cap, hw) in zip(ncs, chk)):      # plateau image: the exact path, synchronously
-            with torch.cuda.stream(ln["stream"]):
-                _collect(out, chunk, *exact(ln["xf"], key, chunk))
-            return
-        _slice(out, chunk, packed.numpy(), counts.tolist())
-
-    for j, (key, chunk) in enumerate(jobs):
-        ln = lanes[j % 2]
-        finish(ln)
-        ln["stream"].wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(ln["stream"]):
-            res, chk = run_chunk(ln["xf"], key, chunk)
-            packed_d = _gather(*res)
-            packed = pinned(ln, "packed", packed_d)                  # (pinned host buffers live with the lane: hipHostMalloc per batch costs more than the batch)
-            counts = pinned(ln, "counts", res[4])
-            ncs = [pinned(ln, f"nc{j_}", c[0]) for j_, c in enumerate(chk)]
-            packed.copy_(packed_d, non_blocking=True)
-            counts.copy_(res[4], non_blocking=True)
-            for h_, c in zip(ncs, chk):
-                h_.copy_(c[0], non_blocking=True)
-            ln["event"].record(ln["stream"])
-        ln["pending"] = (key, chunk, packed, counts, ncs, chk)
-    for ln in lanes:
-        finish(ln)
+        for s in range(0, len(members), max_pairs):
+            chunk = members[s:s + max_pairs]
+            if same_shape:
+                frames = torch.stack([t for it in chunk for t in (it[1], it[3])])        # (2P,C,H,W): frames 2i, 2i+1 = pair i
+                x = _U8Image(frames, key[4]) if key[4] is not None else frames
+                res = _detect_exact(xfeat, x, top_k)
+                kpts, desc, nv = res
+                idx0, idx1, nm = xfeat.match_pairs_device(desc, nv, min_cossim)
+                _collect(out, chunk, kpts[0::2], kpts[1::2], idx0, idx1, nm)
+            else:                                   # the two images of a pair differ in size: one batch per side
+                xa = torch.stack([it[1] for it in chunk])
+                xb = torch.stack([it[3] for it in chunk])
+                xa = _U8Image(xa, key[4]) if key[4] is not None else xa
+                xb = _U8Image(xb, key[5]) if key[5] is not None else xb
+                ka, da, na = _detect_exact(xfeat, xa, top_k)
+                kb, db, nb = _detect_exact(xfeat, xb, top_k)
+                idx0, idx1, nm = xfeat.match_sets_device(da, na, db, nb, min_cossim)
+                _collect(out, chunk, ka, kb, idx0, idx1, nm)
     return [out[i] for i in range(lo, hi)]
 
 
-def _gather(kp0, kp1, idx0, idx1, nm):
-    """Matched coordinates of a whole chunk as ONE fixed-capacity device array (P, cap, 4); entries past a pair's count index row 0 (harmless)."""
+def _collect(out, chunk, kp0, kp1, idx0, idx1, nm):
+    """Matched coordinates of a whole chunk in three device->host copies (not two per pair): gather on the device into
+    fixed-capacity arrays, slice by the match counts on the host.  Entries past a pair's count index row 0 (harmless)."""
     n = nm.to(torch.int64)
     keep = torch.arange(idx0.shape[1], device=idx0.device)[None] < n[:, None]
     g0 = torch.gather(kp0, 1, torch.where(keep, idx0, 0)[..., None].expand(-1, -1, 2))
     g1 = torch.gather(kp1, 1, torch.where(keep, idx1, 0)[..., None].expand(-1, -1, 2))
-    return torch.cat([g0, g1], -1)
-
-
-def _slice(out, chunk, packed, counts):
+    packed = torch.cat([g0, g1], -1).cpu().numpy()                 # (P, cap, 4)
+    counts = nm.cpu().tolist()
     for p, it in enumerate(chunk):
         out[it[0]] = (packed[p, :counts[p], :2].copy(), packed[p, :counts[p], 2:].copy())
 
 
-def _collect(out, chunk, kp0, kp1, idx0, idx1, nm):
-    """Matched coordinates of a whole chunk in two device->host copies (not two per pair): gather on the device into
-    fixed-capacity arrays, slice by the match counts on the host."""
-    _slice(out, chunk, _gather(kp0, kp1, idx0, idx1, nm).cpu().numpy(), nm.cpu().tolist())
+def _detect_exact(xfeat, x, top_k):
+    """_detect_device with the capacity re-run of detectAndCompute (plateau images), results still on the device."""
+    cap = None
+    while True:
+        kpts, scores, desc, n_valid, n_cand, cap, hw = xfeat._detect_device(x, top_k, None, cap)
+        ncmax = int(n_cand.max())
+        if cap >= hw or ncmax <= cap:
+            return kpts, desc, n_valid
+        cap = min(hw, max(ncmax, 2 * cap))
 
 
 def match_pairs_star(xfeat, pairs, top_k=None, max_pairs=16, rank=0, world=1):

@@ -156,16 +156,17 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
 
     // ---- one tap row (chunk C, tap row DY) of a unit: barrier, DMA of the next row, (DY = 0) loads of chunk C + 2, then ONE basic block of
     // 18 MFMAs with the fragment reads of the later steps and (DY < 2) the split of half an item of chunk C + 1 in their issue gaps.
-    // vmcnt counts in issue order: "at most n outstanding" leaves the n youngest operations in flight -- the eight raw loads behind the
-    // DMA of row (C, 1), the sixteen stores of the previous unit behind the DMA of row (0, 0) -- and guarantees the row's own DMA.
-    auto row = [&](auto CC, auto DYC, auto STGC, const Tile& cur, const Tile& nxt, bool has_next, bool first_unit) __attribute__((always_inline)) {
+    // Every barrier waits for EVERYTHING the wave has in flight (vmcnt(0)).  A first version left "the n youngest" operations in flight -- the eight raw loads
+    // behind a row's DMA, the sixteen output stores of the previous unit behind the next unit's first DMA -- on the argument that vmcnt counts in issue order.
+    // It does so for loads only: stores are acknowledged out of order with respect to loads, vmcnt(16) was satisfied by early store acks while the DMA was
+    // still out, and one unit in ~100 000 read stale weights -- caught by the two-lane soak (tools/lanes_soak.py: 1 wrong image in 1500 concurrent steps), never
+    // by a single-stream test.  The loads-only form (vmcnt(8)) was worth 2 us per step and was dropped with it.
+    auto row = [&](auto CC, auto DYC, auto STGC, const Tile& cur, const Tile& nxt, bool has_next) __attribute__((always_inline)) {
         constexpr int C = decltype(CC)::value, DY = decltype(DYC)::value, r = C * 3 + DY, P = C & 1;
         constexpr int MODE = decltype(STGC)::value;      // 0: this wave only multiplies (waves 5 - 7); 1: it also loads and splits an item (waves 0 - 4), half in each of a chunk's
         constexpr bool STG = MODE != 0;                  // first two rows.  (Wave 4 -- the last 50 items, on wave 0's SIMD -- doing both halves in the third row instead: slower.)
         S2_STAMP(1 + 4 * r)
-        if (DY == 1 && STG) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (r == 0 && !first_unit) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         S2_STAMP(2 + 4 * r)
         issue_row(r + 1 < NROW ? r + 1 : 0, r + 1 < NROW ? cur.hf : nxt.hf);          // (the stream is cyclic over the units)
@@ -264,14 +265,14 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         S2_STAMP(3 + 4 * r)
     };
 
-    auto do_unit = [&](const Tile& cur, const Tile& nxt, bool has_next, bool first_unit) __attribute__((always_inline)) {
+    auto do_unit = [&](const Tile& cur, const Tile& nxt, bool has_next) __attribute__((always_inline)) {
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         auto rows = [&](auto STGC) __attribute__((always_inline)) {
-            row(I0{}, I0{}, STGC, cur, nxt, has_next, first_unit); row(I0{}, I1{}, STGC, cur, nxt, has_next, first_unit); row(I0{}, I2{}, STGC, cur, nxt, has_next, first_unit);
-            row(I1{}, I0{}, STGC, cur, nxt, has_next, first_unit); row(I1{}, I1{}, STGC, cur, nxt, has_next, first_unit); row(I1{}, I2{}, STGC, cur, nxt, has_next, first_unit);
-            row(I2{}, I0{}, STGC, cur, nxt, has_next, first_unit); row(I2{}, I1{}, STGC, cur, nxt, has_next, first_unit); row(I2{}, I2{}, STGC, cur, nxt, has_next, first_unit);
-            row(I3{}, I0{}, STGC, cur, nxt, has_next, first_unit); row(I3{}, I1{}, STGC, cur, nxt, has_next, first_unit); row(I3{}, I2{}, STGC, cur, nxt, has_next, first_unit);
+            row(I0{}, I0{}, STGC, cur, nxt, has_next); row(I0{}, I1{}, STGC, cur, nxt, has_next); row(I0{}, I2{}, STGC, cur, nxt, has_next);
+            row(I1{}, I0{}, STGC, cur, nxt, has_next); row(I1{}, I1{}, STGC, cur, nxt, has_next); row(I1{}, I2{}, STGC, cur, nxt, has_next);
+            row(I2{}, I0{}, STGC, cur, nxt, has_next); row(I2{}, I1{}, STGC, cur, nxt, has_next); row(I2{}, I2{}, STGC, cur, nxt, has_next);
+            row(I3{}, I0{}, STGC, cur, nxt, has_next); row(I3{}, I1{}, STGC, cur, nxt, has_next); row(I3{}, I2{}, STGC, cur, nxt, has_next);
         };
         if (wave * 64 < NITEM) rows(std::integral_constant<int, 1>{});          // (wave-uniform: two copies of the unit's code, no exec masking)
         else rows(std::integral_constant<int, 0>{});
@@ -332,15 +333,13 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
             *reinterpret_cast<u32x4*>(p + 2 * SPLB) = l;
         }
     }
-    bool first_unit = true;
     for (;;) {
         const bool has_next = u < u1;
         if (has_next) tile_at(u++, nxt);
         S2_STAMP(0)
-        do_unit(cur, nxt, has_next, first_unit);
+        do_unit(cur, nxt, has_next);
         S2_STAMP(50)
         if (!has_next) break;
-        first_unit = false;
         ++tix;
         cur = nxt;
     }

@@ -1,10 +1,18 @@
 """Throughput runner for a STREAM of frame batches (SURVEY 8 hot path: detectAndCompute + match of consecutive frames, modules/xfeat.py:47-96,150-165).
 
-One batch's step ends in latency-bound kernels that leave most of the chip idle -- NMS compaction, top-k, the matcher's refine scan and finalize, the host
-read-back of the ragged counts (about 0.12 ms of a 1.7 ms VGA batch-64 step).  `FrameStream` keeps `lanes` batches in flight: every lane is an XFeat instance of
-its own (handle, workspaces) on its own HIP stream, batches go to the lanes round-robin, and the hardware schedules the convolutions of one batch into the gaps
-of the other's tail.  Results are the ones XFeat._detect_device / match_pairs_device return for the same batch, bit for bit (same kernels, same order per lane);
-they are retired in submission order.  Measured on one MI355X, VGA batch 64: 35.7 k -> 40.4 k frames/s with two lanes (three: no further gain).
+`FrameStream` keeps `lanes` batches in flight: every lane is an XFeat instance of its own (handle, workspaces), batches go to the lanes round-robin, a
+batch's ragged counts travel to pinned host memory by an asynchronous copy and are waited for when the batch is retired (in submission order).  Results are,
+bit for bit, the ones XFeat._detect_device / match_pairs_device return for the same batch on a handle with the same options.
+
+Two modes:
+  * default (concurrent=False): all lanes queue on ONE HIP stream.  The kernels run exactly as in the synchronous path, one after the other; what is gained
+    is the host round trip of the read-back (the GPU never waits for Python): 37.0 k -> ~37.8 k frames/s on VGA batches of 64.
+  * concurrent=True: a HIP stream per lane -- the hardware schedules the convolutions of one batch into the latency-bound tail of the other (NMS
+    compaction, top-k, the matcher's refine scan and finalize: ~0.12 ms of a 1.7 ms step).  With two streams on the chip the split-bf16 head kernel delivered
+    one wrong 16-cell block of the heat map in ~10^4 steps (3 in 60 000 concurrent backbone steps of tools/lanes_backbone_soak.py, always that kernel; 0 in
+    24 000 single-stream steps; 0 in 24 000 concurrent steps with the f32 heads): a wave of another kernel on the SIMD changes the timing the kernel's
+    bf16-MFMA operand-hazard fence was measured for.  Concurrent lanes therefore run both heads on the f32-MFMA kernels (option heads_f32 = 1,
+    set here): 37.6-38.5 k frames/s (39.8 k with the bf16 heads, which are not shipped next to another stream).  Opt-in until the hazard is understood.
 
     fs = FrameStream(weights, top_k=4096, lanes=2)
     t0 = fs.submit(batch0); t1 = fs.submit(batch1)        # returns as soon as the work is queued
@@ -17,9 +25,9 @@ from .xfeat import XFeat
 
 
 class _Lane:
-    def __init__(self, xf):
+    def __init__(self, xf, stream):
         self.xf = xf
-        self.stream = torch.cuda.Stream()
+        self.stream = stream
         self.event = torch.cuda.Event()
         self.ticket = None          # ticket of the batch in flight / not yet retired
         self.dev = None             # (3, B) int32: n_valid, n_candidates, n_matches (first B/2)
@@ -28,8 +36,9 @@ class _Lane:
 
 
 class FrameStream:
-    def __init__(self, weights=None, top_k=4096, detection_threshold=0.05, lanes=2, min_cossim=-1, xfeats=None):
-        """`xfeats`: ready XFeat instances to use as lanes (one per lane, each with its own handle) instead of building them from `weights`."""
+    def __init__(self, weights=None, top_k=4096, detection_threshold=0.05, lanes=2, min_cossim=-1, xfeats=None, concurrent=False):
+        """`xfeats`: ready XFeat instances to use as lanes (one per lane, each with its own handle) instead of building them from `weights`.
+        concurrent: a HIP stream per lane (see the module docstring: sets option heads_f32 = 1 on the lanes); default: one stream for all lanes."""
         if xfeats is None:
             kw = {} if weights is None else {"weights": weights}
             xfeats = [XFeat(top_k=top_k, detection_threshold=detection_threshold, **kw) for _ in range(int(lanes))]
@@ -39,7 +48,12 @@ class FrameStream:
             raise ValueError("FrameStream: every lane needs an XFeat instance of its own (the workspaces belong to the handle)")
         self.top_k, self.thr, self.min_cossim = int(top_k), float(detection_threshold), min_cossim
         xfeats[0]._require_gpu()          # no GPU / no library: XFeatHipError, never a fallback
-        self._lanes = [_Lane(x) for x in xfeats]
+        self.concurrent = bool(concurrent) and len(xfeats) > 1
+        if self.concurrent:
+            for x in xfeats:
+                x.set_option("heads_f32", 1)          # see the module docstring: the split-bf16 heads are not run next to another stream's kernels
+        shared = None if self.concurrent else torch.cuda.Stream()
+        self._lanes = [_Lane(x, torch.cuda.Stream() if self.concurrent else shared) for x in xfeats]
         self._next_ticket = 0
         self._next_retire = 0
 

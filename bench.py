@@ -287,14 +287,12 @@ def side_workloads(xf, x, B, seconds_cap=90.0):
         return round(P / timed(lambda: xf.match_xfeat_star(a, b, top_k=TOP_K), 4), 1)
 
     def megadepth():
-        from accelerated_features_amd import XFeat
         from accelerated_features_amd.batching import match_pairs
         sizes, _ = sharding.megadepth_pair_sizes()
         big = (fixtures.texture_images(2, 1600, 1600, seed=31) * 255).round().clamp(0, 255).to(torch.uint8).cuda()
         img = lambda hw, v: big[v, :, :hw[0], :hw[1]].contiguous()
         pairs = [(img(a_, i % 2), img(b_, (i + 1) % 2) if a_ != b_ else torch.roll(img(a_, i % 2), (8 + i % 5, 16), (1, 2))) for i, (a_, b_) in enumerate(sizes)]
-        xf2 = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05)      # second lane of the runner
-        return round(len(pairs) / timed(lambda: match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16, xfeat2=xf2), 1), 1)
+        return round(len(pairs) / timed(lambda: match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16), 1), 1)
 
     def lighterglue():
         from accelerated_features_amd.lighterglue import LighterGlue
@@ -444,11 +442,8 @@ def bench_megadepth(args, xf, rank, world, dist):
         a, b = sizes[i]
         pairs.append((image(a, i % 2), image(b, (i + 1) % 2) if a != b else torch.roll(image(a, i % 2), (8 + i % 5, 16), (1, 2))))
 
-    from accelerated_features_amd import XFeat
-    xf2 = XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) if args.lanes > 1 else None      # the runner's second lane
-
     def step():
-        return match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16, xfeat2=xf2)
+        return match_pairs(xf, pairs, top_k=TOP_K, min_cossim=-1, max_pairs=16)
 
     secs, res = sharding.timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda")
     tmax = torch.tensor([secs], dtype=torch.float64)
@@ -573,6 +568,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (accelerated_features_amd.streaming.FrameStream: one handle + HIP stream each); "
                                                          "1 = every step waits for its own read-back")
+    ap.add_argument("--concurrent-lanes", action="store_true", help="a HIP stream per lane (FrameStream(concurrent=True): the lanes then run the f32 heads); default: all lanes on one stream")
     ap.add_argument("--wake-ms", type=float, default=200.0, help="untimed steps for this many ms before the profiling passes and the warm-up (a cold GPU's first ~150 ms run 3-4 %% slow); 0 = none")
     ap.add_argument("--no-side-passes", action="store_true", help="skip the extraction-only / with-H2D side figures (profiling runs)")
     ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "lighterglue", "megadepth", "demo"],
@@ -637,9 +633,13 @@ def main():
     # latency-bound tail of one batch (NMS compaction, top-k, refine scan, finalize, read-back) fills with the convolutions of the next.
     from accelerated_features_amd.streaming import FrameStream
     lanes = max(1, args.lanes)
-    lane_xf = [xf] + [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(lanes - 1)]
+    # (concurrent lanes run the heads on the f32-MFMA kernels -- streaming.py -- so then the lanes are instances of their own and `xf` keeps the default
+    # kernel mix for the single-lane profiling passes)
+    conc = bool(args.concurrent_lanes) and lanes > 1
+    lane_xf = [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(lanes)] if conc else \
+              [xf] + [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(lanes - 1)]
     handles = [l.net.handle() for l in lane_xf]
-    fs = FrameStream(xfeats=lane_xf, top_k=TOP_K, detection_threshold=0.05, min_cossim=-1)
+    fs = FrameStream(xfeats=lane_xf, top_k=TOP_K, detection_threshold=0.05, min_cossim=-1, concurrent=conc)
     retired = []
 
     timed_calls = [None]                                   # calls left in the timed region (None: warm-up)
@@ -767,6 +767,20 @@ def main():
     if rank == 0 and not args.no_side_passes:
         side["extraction_only_fps"] = round(rate(extract_only), 1)
         side["single_lane_synchronous_fps"] = round(rate(step, 20), 1)      # one handle, one stream, every step waits for its read-back (the contract value of rounds 1-3a)
+        if not conc:                                                        # for information: a HIP stream per lane (f32 heads, streaming.py), 60 steps after 20
+            cxf = [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(2)]
+            cfs = FrameStream(xfeats=cxf, top_k=TOP_K, detection_threshold=0.05, min_cossim=-1, concurrent=True)
+
+            def crun(n):
+                torch.cuda.synchronize(); t0c = time.perf_counter()
+                for _ in range(n):
+                    if cfs.in_flight == cfs.lanes: cfs.result()
+                    cfs.submit(x)
+                cfs.drain(); torch.cuda.synchronize()
+                return B * n / (time.perf_counter() - t0c)
+            crun(20)
+            side["concurrent_lanes_f32_heads_fps"] = round(crun(60), 1)
+            del cfs, cxf
         xh32 = x_host.pin_memory()
         xh8 = (x_host * 255).round().clamp(0, 255).to(torch.uint8).pin_memory()
 
@@ -839,7 +853,10 @@ def main():
                        "arithmetic": "fp32 results throughout; the >= 24-channel convolutions and the heads compute them on bf16 MFMAs with three-way split "
                                      "operands (fp32-equivalent, error <= an fp32 direct convolution's), the stride-1 layers at 1/16 and 1/32 scale as Winograd F(2x2,3x3) on f32 MFMAs, the "
                                      "matcher decides on exact fp32 dot products (fp16 MFMAs only pre-select 32-wide blocks inside a derived error window)",
-                       "parallelism": f"replicas x{world}, no collective; {lanes} batches in flight per GPU (FrameStream: one handle + HIP stream per lane, asynchronous read-back of the counts)",
+                       "parallelism": f"replicas x{world}, no collective; {lanes} batches in flight per GPU (FrameStream: one handle per lane, asynchronous read-back of the counts; "
+                                      + ("a HIP stream per lane: the lanes run both heads on the f32-MFMA kernels, the single-lane passes of this line -- spans, single_lane_synchronous_fps -- the split-bf16 ones)"
+                                         if conc else "ALL lanes on one HIP stream: the kernels run one after the other exactly as in the synchronous path, only the host round trip of the read-back is hidden)"),
+                       "concurrent_lanes": conc,
                        "lanes": lanes,
                        "untimed_before_the_timed_region": f"GPU wake-up ({n_wake} steps: windows of {args.steps} until two agree within 1 %, >= {args.wake_ms:.0f} ms; a cold GPU runs its first ~150 ms 3-4 % slow), then the W warm-up steps",
                        "wake_up_window_fps": [round(r, 1) for r in wake_rates],

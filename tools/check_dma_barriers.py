@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """ISA audit: in every kernel that uses the global->LDS DMA (global_load_lds* / buffer_load* ... lds), every
 s_barrier must be directly preceded by an s_waitcnt with vmcnt(0) -- hipcc was observed to drop it (see common.hpp
-lds_dma_barrier) -- or by an EXPLICIT wait written in inline asm (between ;;#ASMSTART / ;;#ASMEND) with a deliberate count:
-k_conv_bx64s2.hip leaves the n youngest operations in flight (vmcnt counts in issue order; the kernel's comments derive n).
+lds_dma_barrier).  No partial counts: vmcnt orders loads only, stores are acknowledged out of order with respect to them
+(k_conv_bx64s2.hip's first version left "the 16 youngest" -- its output stores -- in flight and read stale DMA data once in 1500 two-lane steps).
 Exit code 1 and a listing on violation.   python tools/check_dma_barriers.py"""
 import glob
 import os
@@ -43,7 +43,7 @@ def audit(src):
                 ok, j = False, i - 1
                 while j >= 0 and i - j < 64:
                     p = ins[j]
-                    if "s_waitcnt" in p and ("vmcnt(0)" in p or (p.startswith("asm:") and "vmcnt(" in p)):
+                    if "s_waitcnt" in p and "vmcnt(0)" in p:
                         ok = True
                         break
                     if p.replace("asm:", "").startswith(("global_", "buffer_", "flat_", "scratch_", "s_barrier", "s_cbranch", "s_branch")):
