@@ -13,9 +13,9 @@
 //     ds_read_b128 group step by two input pixels and would collide pairwise in one plane; 112 B keeps them on distinct banks;
 //   * TWO such buffers: chunk g + 1 is split and written while chunk g is multiplied.  With all eight waves of a CU in one workgroup
 //     nobody else covers a staging phase (first version: 13 k of a unit's 42 k cycles were split3 + ds_write between two barriers, all
-//     matrix pipes idle), and a wave's vector work only hides in the issue gaps of its OWN MFMAs: every wave splits half an item (two
-//     pixels x 8 channels) inside each of a chunk's first two tap rows, in the same basic block as that row's 18 MFMAs (no branch: lanes
-//     without an item write to a dump slot).  Raw fp32 values are loaded two chunks ahead (two register sets), also across units;
+//     matrix pipes idle), and a wave's vector work only hides in the issue gaps of its OWN MFMAs: the five waves that hold staging items
+//     split half an item (two pixels x 8 channels) inside each of a chunk's first two tap rows, in the same basic block as that row's 18
+//     MFMAs (no branch: lanes without an item write to a dump slot; waves 5 - 7 run a copy of the unit's code without loads and splits).  Raw fp32 values are loaded two chunks ahead (two register sets), also across units;
 //   * the split weights (216 KiB per cout half) stream through a two-slot LDS ring by LDS-DMA, one slot = one tap row of one chunk
 //     (3 K steps, 18 KiB); the DMA of row r + 1 is issued behind the barrier that opens row r.  One barrier per tap row, none per chunk.
 #include "kernels.hpp"

@@ -6,13 +6,13 @@ bit for bit, the ones XFeat._detect_device / match_pairs_device return for the s
 
 Two modes:
   * default (concurrent=False): all lanes queue on ONE HIP stream.  The kernels run exactly as in the synchronous path, one after the other; what is gained
-    is the host round trip of the read-back (the GPU never waits for Python): 37.0 k -> ~37.8 k frames/s on VGA batches of 64.
+    is the host round trip of the read-back (the GPU never waits for Python): 37.6 k -> 38.2 k frames/s on VGA batches of 64 (profiles/r03_i_bench.json).
   * concurrent=True: a HIP stream per lane -- the hardware schedules the convolutions of one batch into the latency-bound tail of the other (NMS
     compaction, top-k, the matcher's refine scan and finalize: ~0.12 ms of a 1.7 ms step).  With two streams on the chip the split-bf16 head kernel delivered
     one wrong 16-cell block of the heat map in ~10^4 steps (3 in 60 000 concurrent backbone steps of tools/lanes_backbone_soak.py, always that kernel; 0 in
     24 000 single-stream steps; 0 in 24 000 concurrent steps with the f32 heads): a wave of another kernel on the SIMD changes the timing the kernel's
     bf16-MFMA operand-hazard fence was measured for.  Concurrent lanes therefore run both heads on the f32-MFMA kernels (option heads_f32 = 1,
-    set here): 37.6-38.5 k frames/s (39.8 k with the bf16 heads, which are not shipped next to another stream).  Opt-in until the hazard is understood.
+    set here): 38.4 k frames/s in the same run (+ 5 % more with the bf16 heads, which are not shipped next to another stream).  Opt-in until the hazard is understood.
 
     fs = FrameStream(weights, top_k=4096, lanes=2)
     t0 = fs.submit(batch0); t1 = fs.submit(batch1)        # returns as soon as the work is queued
