@@ -91,7 +91,8 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   "wino"          0..2    3x3/s1 layers: 0 never Winograd, 1 unfused layers only, 2 (default) also the 3x3 + 1x1 pairs
  *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
  *                           8 not block3.0, 16 the stride-2 64 -> 64 | 128 layers (block4.0, block5.0) (default 21)
- *   "heads_f32"     0 | 1   1: both heads on the f32-MFMA kernels
+ *   "heads_f32"     0 | 1   1: both heads on the f32-MFMA kernels (set it when other kernels run on the GPU CONCURRENTLY with this handle's calls -- a second stream,
+ *                           another process: next to a foreign kernel the split-bf16 key-point head was seen to deliver one wrong 16-cell block in ~10^4 calls)
  *   "block1"        0..5    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile
  * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.
  * ---------------------------------------------------------------------------------------- */
