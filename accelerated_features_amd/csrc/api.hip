@@ -256,6 +256,57 @@ static float bf16_float(uint16_t h) {
     return f;
 }
 
+// fp32 -> fp16, round to nearest even (subnormals kept, overflow -> inf) and back: the host side of the two-term fp16 weights
+static uint16_t f16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));      // NaN / inf
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                       // >= 65520: rounds to inf
+    if (u < 0x38800000u) {                                                                        // < 2^-14: subnormal result, spacing 2^-24
+        if (u < 0x33000000u) return (uint16_t)sign;                                               // < 2^-25: rounds to zero (2^-25 itself ties to even = 0)
+        const int e = (int)(u >> 23);                                                             // biased fp32 exponent, 102 .. 112
+        const uint32_t m = (u & 0x7fffffu) | 0x800000u;                                           // 24-bit significand
+        const int sh = 126 - e;                                                                   // value = m * 2^(e - 150); result units of 2^-24: m >> (126 - e)
+        const uint32_t q = m >> sh, rem = m & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
+        return (uint16_t)(sign | (q + ((rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t v = u - 0x38000000u;                                                           // rebias 127 -> 15
+    return (uint16_t)(sign | ((v + 0xfffu + ((v >> 13) & 1u)) >> 13));
+}
+static float f16_float(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        const float f = (float)m * 5.9604644775390625e-8f;                                        // m * 2^-24, exact
+        memcpy(&u, &f, 4);
+        u |= sign;
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// The three weight fragments of one fp32 weight, per arithmetic of the split-operand MFMA kernels (k_conv_bx*.hip, k_heads.hip):
+//   mode 0: bf16, w = q0 + q1 + q2 (three-way split, round to nearest even)
+//   mode 1: fp16 at scale 2^11 ("fx"): q0 = fp16(2^11 w), q2 = fp16(2^11 w - q0) -- together 22 bits of 2^11 w, multiplied with the activation's high
+//           part -- and q1 = fp16(w), multiplied with the activation's 2^11-scaled low part: all three products carry the factor 2^11
+static void split_weight(float v, int mode, uint16_t (&q)[3]) {
+    if (mode == 0) {
+        q[0] = bf16_rne(v);
+        const float r1 = v - bf16_float(q[0]);
+        q[1] = bf16_rne(r1);
+        q[2] = bf16_rne(r1 - bf16_float(q[1]));
+    } else {
+        const float s = v * 2048.f;                    // exact
+        q[0] = f16_rne(s);
+        q[1] = f16_rne(v);
+        q[2] = f16_rne(s - f16_float(q[0]));            // exact difference
+    }
+}
+constexpr float kFxMaxWeight = 31.f;                   // |w| * 2^11 must stay below the fp16 maximum (65504)
+
 // ------------------------------------------------------------------------------------------
 // exported functions
 // ------------------------------------------------------------------------------------------
@@ -283,7 +334,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     std::vector<float> blob;
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
     const size_t zoff = reserve(256);
-    struct Off { size_t oihw, kc, kcp, bias, wino, bx; bool has_wino, has_bx; } coff[L_NUM];
+    struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx; bool has_wino, has_bx, fx_ok; } coff[L_NUM];
     struct FOff { size_t w, b; } foff[5];
     int ai = 0;
     for (int li = 0; li < L_NUM; ++li) {
@@ -335,99 +386,94 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                         }
                 }
         }
-        // bf16 MFMA path with three-way split operands (k_conv_bx.hip): w = wh + wm + wl, each bf16 (round to nearest even), in
-        // operand order [step][split][lane = half * 32 + cout][8]: K group kg = 2 step + half = (tap, 8-channel group)
-        auto split3 = [&](float v, uint16_t (&q)[3]) {
-            q[0] = bf16_rne(v);
-            const float r1 = v - bf16_float(q[0]);
-            q[1] = bf16_rne(r1);
-            q[2] = bf16_rne(r1 - bf16_float(q[1]));
-        };
+        // Split-operand MFMA paths (k_conv_bx*.hip): every fp32 weight as three 16-bit fragments in MFMA operand order, in two arithmetics (split_weight):
+        // bf16 three-way split (w_bx), and the fp16 pair at scale 2^11 (w_fx; only if every |w| of the layer stays below kFxMaxWeight).
+        // K group kg = 2 step + half = (tap, 8-channel group) for the 24-channel layers.
         const bool bx24 = c.ks == 3 && c.stride == 1 && c.cin == 24 && c.cout <= 32;
         const bool bx64 = c.ks == 3 && c.stride == 1 && c.cin == 64 && c.cout == 64;
         const bool bx24s2 = c.ks == 3 && c.stride == 2 && c.cin == 24 && c.cout == 64;
         const bool bx1x1 = c.ks == 1 && c.cin == 64 && c.cout == 64 && li > 0 && kConvs[li - 1].ks == 3 && kConvs[li - 1].cout == 64 && kConvs[li - 1].cin == 64;      // block3.2, block_fusion.2
         const bool bx64s2 = c.ks == 3 && c.stride == 2 && c.cin == 64 && (c.cout == 64 || c.cout == 128);      // block4.0, block5.0
         coff[li].has_bx = bx24 || bx64 || bx24s2 || bx1x1 || bx64s2;
-        if (bx1x1) {      // trailing 1x1 fused into conv_bx64_kernel: K order of the 3x3's D registers (as the heads' chained layers): [K step 4][cout block 2][split 3][lane][8]
-            coff[li].bx = reserve((size_t)4 * 2 * 3 * 64 * 4);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
-            for (int t = 0; t < 4; ++t)
-                for (int mb = 0; mb < 2; ++mb)
-                    for (int lane = 0; lane < 64; ++lane)
-                        for (int i = 0; i < 8; ++i) {
-                            const int o = mb * 32 + (lane & 31), hf = lane >> 5;
-                            const int ch = 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
-                            uint16_t q[3];
-                            split3(blob[coff[li].oihw + (size_t)o * 64 + ch], q);
-                            for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * 2 + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                        }
+        coff[li].fx_ok = false;
+        if (coff[li].has_bx) {
+            float wmax = 0.f;
+            for (size_t i = 0; i < (size_t)c.cout * c.cin * kk; ++i) wmax = std::max(wmax, std::fabs(blob[coff[li].oihw + i]));
+            coff[li].fx_ok = wmax < kFxMaxWeight;
         }
-        if (bx24) {
-            const int cg = c.cin / 8, nstep = bx_steps(c.cin);
-            coff[li].bx = reserve((size_t)nstep * 3 * 64 * 4);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
-            for (int s = 0; s < nstep; ++s)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int o = lane & 31, kg = 2 * s + (lane >> 5);
-                    for (int i = 0; i < 8; ++i) {
-                        float v = 0.f;
-                        if (o < c.cout && kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
-                        uint16_t q[3];
-                        split3(v, q);
-                        for (int sp = 0; sp < 3; ++sp) dst[(((size_t)s * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                    }
-                }
-        }
-        if (bx24s2) {     // the stride-2 sibling: [cout block][step][split][lane][8], same K order as bx24
-            const int cg = c.cin / 8, nstep = bx_steps(c.cin);
-            coff[li].bx = reserve((size_t)2 * nstep * 3 * 64 * 4);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
-            for (int cb = 0; cb < 2; ++cb)
-                for (int s = 0; s < nstep; ++s)
+        for (int mode = 0; mode < 2 && coff[li].has_bx; ++mode) {
+            size_t words = 0;
+            const int cg = c.cin / 8, nstep = bx_steps(c.cin), nch = c.cin / 16, nhf = c.cout / 64;
+            if (bx1x1) words = (size_t)4 * 2 * 3 * 64 * 4;
+            if (bx24) words = (size_t)nstep * 3 * 64 * 4;
+            if (bx24s2) words = (size_t)2 * nstep * 3 * 64 * 4;
+            if (bx64 || bx64s2) words = (size_t)nhf * nch * 9 * 2 * 3 * 64 * 4;
+            const size_t off = reserve(words);
+            (mode == 0 ? coff[li].bx : coff[li].fx) = off;
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[off]);
+            uint16_t q[3];
+            if (bx1x1)        // trailing 1x1 fused into conv_bx64_kernel: K order of the 3x3's D registers (as the heads' chained layers): [K step 4][cout block 2][split 3][lane][8]
+                for (int t = 0; t < 4; ++t)
+                    for (int mb = 0; mb < 2; ++mb)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int i = 0; i < 8; ++i) {
+                                const int o = mb * 32 + (lane & 31), hf = lane >> 5;
+                                const int ch = 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
+                                split_weight(blob[coff[li].oihw + (size_t)o * 64 + ch], mode, q);
+                                for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * 2 + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                            }
+            if (bx24)         // [step][split][lane = half * 32 + cout][8]
+                for (int st = 0; st < nstep; ++st)
                     for (int lane = 0; lane < 64; ++lane) {
-                        const int o = cb * 32 + (lane & 31), kg = 2 * s + (lane >> 5);
+                        const int o = lane & 31, kg = 2 * st + (lane >> 5);
                         for (int i = 0; i < 8; ++i) {
                             float v = 0.f;
-                            if (kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
-                            uint16_t q[3];
-                            split3(v, q);
-                            for (int sp = 0; sp < 3; ++sp) dst[((((size_t)cb * nstep + s) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                            if (o < c.cout && kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
+                            split_weight(v, mode, q);
+                            for (int sp = 0; sp < 3; ++sp) dst[(((size_t)st * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                         }
                     }
-        }
-        if (bx64 || bx64s2) {      // [cout half][cin/16][dy][dx][cout block][split][lane = half * 32 + cout][8]: channel = 16 chunk + 8 half + i
-            const int nch = c.cin / 16, nhf = c.cout / 64;
-            coff[li].bx = reserve((size_t)nhf * nch * 9 * 2 * 3 * 64 * 4);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].bx]);
-            for (int hf = 0; hf < nhf; ++hf)
-                for (int ch = 0; ch < nch; ++ch)
-                    for (int tap = 0; tap < 9; ++tap)
-                        for (int cb = 0; cb < 2; ++cb)
-                            for (int lane = 0; lane < 64; ++lane)
-                                for (int i = 0; i < 8; ++i) {
-                                    const int o = hf * 64 + cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
-                                    uint16_t q[3];
-                                    split3(blob[coff[li].oihw + ((size_t)o * c.cin + ci) * 9 + tap], q);
-                                    for (int sp = 0; sp < 3; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                                }
+            if (bx24s2)       // the stride-2 sibling: [cout block][step][split][lane][8], same K order as bx24
+                for (int cb = 0; cb < 2; ++cb)
+                    for (int st = 0; st < nstep; ++st)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int o = cb * 32 + (lane & 31), kg = 2 * st + (lane >> 5);
+                            for (int i = 0; i < 8; ++i) {
+                                float v = 0.f;
+                                if (kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
+                                split_weight(v, mode, q);
+                                for (int sp = 0; sp < 3; ++sp) dst[((((size_t)cb * nstep + st) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                            }
+                        }
+            if (bx64 || bx64s2)      // [cout half][cin/16][dy][dx][cout block][split][lane = half * 32 + cout][8]: channel = 16 chunk + 8 half + i
+                for (int hf = 0; hf < nhf; ++hf)
+                    for (int ch = 0; ch < nch; ++ch)
+                        for (int tap = 0; tap < 9; ++tap)
+                            for (int cb = 0; cb < 2; ++cb)
+                                for (int lane = 0; lane < 64; ++lane)
+                                    for (int i = 0; i < 8; ++i) {
+                                        const int o = hf * 64 + cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
+                                        split_weight(blob[coff[li].oihw + ((size_t)o * c.cin + ci) * 9 + tap], mode, q);
+                                        for (int sp = 0; sp < 3; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                                    }
         }
     }
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].
     // K order: the first layer takes its channels in natural order (16 t + 8 half + i); a chained layer takes the previous layer's D
     // registers, i.e. feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).
-    size_t head_off[2] = {0, 0}, head_boff[2] = {0, 0};
+    size_t head_off[2][2] = {{0, 0}, {0, 0}}, head_boff[2] = {0, 0};      // [arithmetic: 0 = bf16 x3, 1 = fp16 pair][head]
+    bool head_fx_ok[2] = {true, true};
     float head_b_last = 0.f;
-    {
+    for (int mode = 0; mode < 2; ++mode) {
         const int kp[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3}, rel[2] = {L_HEAT_0, L_HEAT_1};
         for (int hd = 0; hd < 2; ++hd) {
             const int nl = hd == 0 ? 4 : 2;
             const int* ls = hd == 0 ? kp : rel;
             size_t words = 0, nbias = 0;
             for (int p = 0; p < nl; ++p) { const int mbo = (kConvs[ls[p]].cout + 31) / 32; words += (size_t)4 * mbo * 3 * 64 * 4; nbias += 32 * mbo; }
-            head_off[hd] = reserve(words);
-            head_boff[hd] = reserve(nbias);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[head_off[hd]]);
+            head_off[mode][hd] = reserve(words);
+            if (mode == 0) head_boff[hd] = reserve(nbias);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[head_off[mode][hd]]);
             size_t bo = head_boff[hd];
             for (int p = 0; p < nl; ++p) {
                 const ConvSpec& c = kConvs[ls[p]];
@@ -439,10 +485,9 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                                 const int o = mb * 32 + (lane & 31), hf = lane >> 5;
                                 const int ch = p == 0 ? 16 * t + 8 * hf + i : 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
                                 const float v = o < c.cout ? blob[coff[ls[p]].oihw + (size_t)o * 64 + ch] : 0.f;
-                                const uint16_t q0 = bf16_rne(v);
-                                const float r1 = v - bf16_float(q0);
-                                const uint16_t q1 = bf16_rne(r1);
-                                const uint16_t q[3] = {q0, q1, bf16_rne(r1 - bf16_float(q1))};
+                                if (!(std::fabs(v) < kFxMaxWeight)) head_fx_ok[hd] = false;
+                                uint16_t q[3];
+                                split_weight(v, mode, q);
                                 for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * mbo + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                             }
                 dst += (size_t)4 * mbo * 3 * 64 * 8;
@@ -497,9 +542,14 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.bias = ctx->blob + coff[li].bias;
         w.w_wino = coff[li].has_wino ? ctx->blob + coff[li].wino : nullptr;
         w.w_bx = coff[li].has_bx ? ctx->blob + coff[li].bx : nullptr;
+        w.w_fx = coff[li].has_bx && coff[li].fx_ok ? ctx->blob + coff[li].fx : nullptr;
     }
     ctx->nw.zeros = ctx->blob + zoff;
-    for (int hd = 0; hd < 2; ++hd) { ctx->nw.head_bx[hd] = ctx->blob + head_off[hd]; ctx->nw.head_bx_bias[hd] = ctx->blob + head_boff[hd]; }
+    for (int hd = 0; hd < 2; ++hd) {
+        ctx->nw.head_bx[hd] = ctx->blob + head_off[0][hd];
+        ctx->nw.head_fx[hd] = head_fx_ok[hd] ? ctx->blob + head_off[1][hd] : nullptr;
+        ctx->nw.head_bx_bias[hd] = ctx->blob + head_boff[hd];
+    }
     ctx->nw.head_rel_b_last = head_b_last;
     for (int fi = 0; fi < 5; ++fi) {
         LinW& l = ctx->nw.fine[fi];
@@ -561,11 +611,11 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     int rc = -1;
     const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 1024;      // >= 2 half-tile units per workgroup of the persistent grid (B=8 164x164: 92 vs 124 us stand-alone)
     if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
-        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc);      // 3x3 + trailing 1x1 in one split-bf16 kernel
+        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) != 0);      // 3x3 + trailing 1x1 in one split-operand kernel
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);      // (bx = 9: block3.0 stays on the f32 kernel)
-        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace);      // (bx = 5: large maps only)
+        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) != 0);      // (bx = 5: large maps only)
     }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
@@ -670,6 +720,10 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
     if (variant == 10) {
         if (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace) : c.stride == 2 ? launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace) : launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no split-bf16 instantiation for layer %d", layer);
         return check_launch("xfh_conv_layer(split bf16)");
+    }
+    if (variant == 11) {      // the split kernel of the layer in the fp16-pair arithmetic
+        if (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, true)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fp16-pair instantiation for layer %d", layer);
+        return check_launch("xfh_conv_layer(fp16 pair)");
     }
     if (variant >= 2) {
         if (launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, variant - 1, h->trace))
@@ -904,7 +958,7 @@ int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 1}, {"block1", &Options::block1, 0, 15}};
+        {"heads_f32", &Options::heads_f32, 0, 1}, {"block1", &Options::block1, 0, 5}, {"fx", &Options::fx, 0, 15}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;
@@ -915,6 +969,7 @@ int xfh_set_option(xfh_handle h, const char* key, int value) {
     int* slot = option_slot(h, key, lo, hi);
     if (!slot) return fail(XFH_ERR_ARG, "xfh_set_option: unknown option '%s'", key);
     if (value < lo || value > hi) return fail(XFH_ERR_ARG, "xfh_set_option: %s = %d outside [%d, %d]", key, value, lo, hi);
+    if (!strcmp(key, "block1") && value == 2) return fail(XFH_ERR_ARG, "xfh_set_option: block1 = 2 names no kernel (0 | 5 = shipped, 1, 3, 4 = earlier forms)");
     *slot = value;
     return XFH_OK;
 }
@@ -932,6 +987,17 @@ int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
     h->trace = device_buffer;
     g_head_trace = device_buffer ? device_buffer + (1 << 21) + (1 << 16) : nullptr;      // the key-point head's stamps live 2 Mi + 64 Ki entries into the buffer (the conv kernels use the front)
     return XFH_OK;
+}
+
+int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int W, float* gray, float* coef, double* part, float* heat, const float* heat_ref,
+                        float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, xfh_stream stream,
+                        float* dbg, const float* dbg_ref, unsigned* rep_dbg) {
+    if (!h || !gray || !coef || !heat) return fail(XFH_ERR_ARG, "xfh_debug_head_soak: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (img) launch_gray_norm(img, B, C, H, W, part, gray, coef, st);      // (first call: the head's inputs)
+    if (head_soak(h->nw, gray, coef, B, H, W, heat, heat_ref, logits, logits_ref, variant, iters, iter0, rep_heat, rep_logits, cap, st, dbg, dbg_ref, rep_dbg))
+        return fail(XFH_ERR_ARG, "xfh_debug_head_soak: unknown variant %d", variant);
+    return check_launch("xfh_debug_head_soak");
 }
 
 int xfh_profile_select(xfh_handle h, int which) {

@@ -8,6 +8,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 
 __device__ inline unsigned pk_bf16_rne(float a, float b) {      // v_cvt_pk_bf16_f32: a -> low half
@@ -38,5 +40,23 @@ __device__ inline void split3_trunc(float a, float b, unsigned& h, unsigned& m, 
     const float sa = ra - __uint_as_float(__float_as_uint(ra) & 0xffff0000u), sb = rb - __uint_as_float(__float_as_uint(rb) & 0xffff0000u);
     l = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
 }
+
+
+// ---- the fp16-pair arithmetic ("fx") ---------------------------------------------------------------------------------------------
+// x = xh + 2^-11 xl up to 2^-22 |x|: xh = fp16(x), xl = fp16(2^11 (x - xh)) (round to nearest even; the residual is exact in fp32 and, scaled, of the size of
+// x / 2: never a subnormal where xh is not).  With the weights as q0 = fp16(2^11 w), q2 = fp16(2^11 w - q0), q1 = fp16(w) (api.hip: split_weight) a product sum
+// takes THREE fp16 MFMAs per K = 16 instead of the six of the bf16 three-way split,
+//     2^11 w x  =  q2 xh + q1 xl + q0 xh   (+ the dropped term 2^-11 (2^11 w - q0 - q2) ... <= 2^-21 |w x| in all),
+// every partial product exact in the fp32 accumulator, ONE accumulator at scale 2^11 (the epilogue multiplies by 2^-11, exactly).  Error of a K = 576 product
+// sum against fp64: 2.7e-7 of max |y| in the numpy restatement (the six-MFMA bf16 form: 5.5e-7; an fp32 fma chain: 7.3e-7) -- fewer roundings of the accumulator.
+// Range: |x| < 65504 (detected: FxRange), |w| < 31 (checked at xfh_create: the layer otherwise stays on the bf16 form).
+__device__ inline void split2_f16(float a, float b, unsigned& h, unsigned& l) {
+    const f32x2 v = {a, b};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);                       // v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x2 r = (v - __builtin_convertvector(hh, f32x2)) * 2048.f;
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+constexpr float FX_SCALE_INV = 1.f / 2048.f;
 
 }  // namespace xfh

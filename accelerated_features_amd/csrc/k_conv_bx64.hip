@@ -39,7 +39,9 @@ struct Bx64Args {
 };
 
 namespace bx64 {
-constexpr int XROWB = 2048, PIXB = 112, SPLB = 32, IW = 18, IH = 18;
+constexpr int XROWB = 2048, SPLB = 32, IW = 18, IH = 18;
+// bytes per staged pixel: 16 channels x (3 bf16 | 2 fp16 fragments) + 16: an ODD multiple of 16 B keeps the 16 lanes of a ds_read_b128 group on distinct banks
+template <bool FX> constexpr int pixb() { return FX ? 80 : 112; }
 constexpr int X_BYTES = IH * XROWB;                    // 36864
 constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;      // 6 KiB per K step, 18 per slot
 constexpr int RING_OFF = X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, LDS_BYTES = BIAS_OFF + 128 * 4;      // bias of the 3x3, bias of the fused 1x1
@@ -48,10 +50,17 @@ static_assert(IH * NQ * 2 <= 256, "one (row, quad, 8-channel group) item per thr
 }
 
 // FUSE: 0 = the 3x3 alone; 1 = + trailing 1x1 (64 -> 64), NCHW output; 2 = the same with channels-last output
-template <int CIN, int FUSE>
+// FX: the fp16-pair arithmetic (bx_split.hpp) -- two input fragments per pixel, three MFMAs per K step and accumulator instead of six
+template <int CIN, int FUSE, bool FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64_kernel(Bx64Args a) {
     using namespace bx64;
+    constexpr int PIXB = pixb<FX>(), NXS = FX ? 2 : 3;
+    using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
+    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {
+        if constexpr (FX) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    };
     constexpr int NCH = CIN / 16, NROW = NCH * 3, COUT = 64;
     static_assert(NROW % 2 == 0, "the ring slot of a row must not depend on the tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b64[];
@@ -151,7 +160,8 @@ void conv_bx64_kernel(Bx64Args a) {
             for (int k = 0; k < 8; ++k) {
                 float x0 = v[k][2 * pp], x1 = v[k][2 * pp + 1];
                 if (a.W & 3) { x0 = z0 ? 0.f : x0; x1 = z1 ? 0.f : x1; }
-                split3(x0, x1, H[k], M[k], L[k]);
+                if constexpr (FX) { split2_f16(x0, x1, H[k], L[k]); M[k] = 0; }
+                else split3(x0, x1, H[k], M[k], L[k]);
             }
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {
@@ -167,8 +177,11 @@ void conv_bx64_kernel(Bx64Args a) {
                 l.z = __builtin_amdgcn_perm(L[5], L[4], sel); l.w = __builtin_amdgcn_perm(L[7], L[6], sel);
                 unsigned char* p = smem_b64 + it_row * XROWB + cc * PIXB + it_g8 * 16;
                 *reinterpret_cast<uint4*>(p) = h;
-                *reinterpret_cast<uint4*>(p + SPLB) = m;
-                *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+                if constexpr (FX) *reinterpret_cast<uint4*>(p + SPLB) = l;
+                else {
+                    *reinterpret_cast<uint4*>(p + SPLB) = m;
+                    *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+                }
             }
         }
     };
@@ -176,7 +189,7 @@ void conv_bx64_kernel(Bx64Args a) {
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
     int tix = 0;
 #define BX_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }      /* second tile of the workgroup: [0] start, per row r: [1+4r] staged / row start, [2+4r] barrier passed, [3+4r] DMA + loads issued, [4+4r] MFMAs issued; [50] stores issued, [51] end barrier */
-    struct Frag { bf16x8 x[2][3]; bf16x8 w[2][3]; };
+    struct Frag { frag_t x[2][NXS]; frag_t w[2][3]; };
     const int lane_px = (l31 >> 4) * XROWB + (l31 & 15) * PIXB + half * 16;
 
     // ---- one tile: NPB pixel blocks per wave (2 = 16x16 tile, 1 = 8x16 half tile).  Two instantiations of the whole tile body:
@@ -210,11 +223,11 @@ void conv_bx64_kernel(Bx64Args a) {
 #pragma unroll
                     for (int j = 0; j < NPB; ++j)
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) o.x[j][q] = *reinterpret_cast<const bf16x8*>(xrow + xb[j] + s * PIXB + q * SPLB);
+                        for (int q = 0; q < NXS; ++q) o.x[j][q] = *reinterpret_cast<const frag_t*>(xrow + xb[j] + s * PIXB + q * SPLB);
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) o.w[cb][q] = *reinterpret_cast<const bf16x8*>(wslot + s * STEP_BYTES + (cb * 3 + q) * 1024);
+                        for (int q = 0; q < 3; ++q) o.w[cb][q] = *reinterpret_cast<const frag_t*>(wslot + s * STEP_BYTES + (cb * 3 + q) * 1024);
                 };
                 load(0, f[0]);
 #pragma unroll
@@ -224,8 +237,9 @@ void conv_bx64_kernel(Bx64Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                     // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); independent accumulators
 #define BX_MM(WQ, XQ) { _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int j = 0; j < NPB; ++j) \
-                        acc[j][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cf.w[cb][WQ], cf.x[j][XQ], acc[j][cb], 0, 0, 0); }
-                    BX_MM(2, 0) BX_MM(0, 2) BX_MM(1, 1) BX_MM(1, 0) BX_MM(0, 1) BX_MM(0, 0)
+                        acc[j][cb] = mfma(cf.w[cb][WQ], cf.x[j][XQ], acc[j][cb]); }
+                    if constexpr (FX) { BX_MM(2, 0) BX_MM(1, 1) BX_MM(0, 0) }      // fp16 pair: (2^11 w - q0) xh, w xl, q0 xh -- all at scale 2^11
+                    else { BX_MM(2, 0) BX_MM(0, 2) BX_MM(1, 1) BX_MM(1, 0) BX_MM(0, 1) BX_MM(0, 0) }
 #undef BX_MM
                     __builtin_amdgcn_sched_barrier(0);
                     // memory instructions go BETWEEN the MFMA groups: their issue (~100 cycles per LDS-DMA piece or load with the CU's
@@ -267,7 +281,7 @@ void conv_bx64_kernel(Bx64Args a) {
                     }
     #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        float y = acc[j][cb][r] + bs[r];
+                        float y = FX ? fmaf(acc[j][cb][r], FX_SCALE_INV, bs[r]) : acc[j][cb][r] + bs[r];
                         if (a.relu) y = fmaxf(y, 0.f);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((cb * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
                     }
@@ -289,7 +303,7 @@ void conv_bx64_kernel(Bx64Args a) {
                         const float bq[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float y = acc[j][cb][4 * g4 + e] + bq[e];
+                            float y = FX ? fmaf(acc[j][cb][4 * g4 + e], FX_SCALE_INV, bq[e]) : acc[j][cb][4 * g4 + e] + bq[e];
                             if (a.relu) y = fmaxf(y, 0.f);
                             acc[j][cb][4 * g4 + e] = y;
                         }
@@ -297,7 +311,7 @@ void conv_bx64_kernel(Bx64Args a) {
             // one pixel block at a time (its two 1x1 accumulators, stores included): both blocks at once do not fit into 256 registers next to
             // the 3x3's results and the next tile's prefetched input
             const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
-            bf16x8 w2[2][3], xf[2][3];
+            frag_t w2[2][3], xf[2][NXS];
             // (buffer loads: ONE address register per lane, the fragment in the scalar offset -- as global loads the 24 fragment addresses were
             // 48 registers, spilled, and re-read from scratch in front of every load)
             const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wq2, 0, 4 * 2 * 3 * 1024, 0x00020000);
@@ -305,7 +319,7 @@ void conv_bx64_kernel(Bx64Args a) {
 #pragma unroll
                 for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) w2[m2][q] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, lane * 16, ((t * 2 + m2) * 3 + q) * 1024, 0));
+                    for (int q = 0; q < 3; ++q) w2[m2][q] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, lane * 16, ((t * 2 + m2) * 3 + q) * 1024, 0));
             };
 #pragma unroll
             for (int j = 0; j < NPB; ++j) {
@@ -314,13 +328,18 @@ void conv_bx64_kernel(Bx64Args a) {
                 for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)      // FUSE 1: D2 rows = couts ; FUSE 2 (transposed product): D2 columns = couts
-                        acc2[m2][r] = FUSE == 1 ? bias_lds[64 + m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] : bias_lds[64 + m2 * 32 + l31];
-                auto split_step = [&](int t, bf16x8 (&o)[3]) {
+                        acc2[m2][r] = (FUSE == 1 ? bias_lds[64 + m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] : bias_lds[64 + m2 * 32 + l31]) * (FX ? 2048.f : 1.f);      // (fx: the accumulator lives at scale 2^11)
+                auto split_step = [&](int t, frag_t (&o)[NXS]) {
                     uint4 uh, um, ul;
                     unsigned* ph = &uh.x; unsigned* pm = &um.x; unsigned* pl = &ul.x;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) split3(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pm[i], pl[i]);
-                    o[0] = __builtin_bit_cast(bf16x8, uh); o[1] = __builtin_bit_cast(bf16x8, um); o[2] = __builtin_bit_cast(bf16x8, ul);
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (FX) split2_f16(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pl[i]);
+                        else split3(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pm[i], pl[i]);
+                    }
+                    o[0] = __builtin_bit_cast(frag_t, uh);
+                    if constexpr (FX) o[1] = __builtin_bit_cast(frag_t, ul);
+                    else { o[1] = __builtin_bit_cast(frag_t, um); o[2] = __builtin_bit_cast(frag_t, ul); }
                 };
                 asm volatile("" ::: "memory");
                 ldw2(0);
@@ -331,17 +350,17 @@ void conv_bx64_kernel(Bx64Args a) {
                     __builtin_amdgcn_sched_barrier(0);
                     // products (weight split, input split), small terms first; FUSE 2 swaps the operands (rows = pixels, lane = cout)
 #define BX_MM2(WQ, XQ) { _Pragma("unroll") for (int m2 = 0; m2 < 2; ++m2) acc2[m2] = FUSE == 1 \
-                        ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[m2][WQ], xf[sb][XQ], acc2[m2], 0, 0, 0) \
-                        : __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[sb][XQ], w2[m2][WQ], acc2[m2], 0, 0, 0); }
-                    BX_MM2(2, 0) BX_MM2(0, 2) BX_MM2(1, 1) BX_MM2(1, 0) BX_MM2(0, 1) BX_MM2(0, 0)
+                        ? mfma(w2[m2][WQ], xf[sb][XQ], acc2[m2]) : mfma(xf[sb][XQ], w2[m2][WQ], acc2[m2]); }
+                    if constexpr (FX) { BX_MM2(2, 0) BX_MM2(1, 1) BX_MM2(0, 0) }
+                    else { BX_MM2(2, 0) BX_MM2(0, 2) BX_MM2(1, 1) BX_MM2(1, 0) BX_MM2(0, 1) BX_MM2(0, 0) }
 #undef BX_MM2
                     __builtin_amdgcn_sched_barrier(0);
                     if (t + 1 < 4) {
                         split_step(t + 1, xf[sb ^ 1]);
                         // the new fragments pass through an asm that uses the old ones and this step's weights: their registers stay occupied
                         // while the split's results and temporaries are written
-                        asm volatile("" : "+v"(xf[sb ^ 1][0]), "+v"(xf[sb ^ 1][1]), "+v"(xf[sb ^ 1][2])
-                                        : "v"(xf[sb][0]), "v"(xf[sb][1]), "v"(xf[sb][2]), "v"(w2[0][0]), "v"(w2[0][1]), "v"(w2[0][2]), "v"(w2[1][0]), "v"(w2[1][1]), "v"(w2[1][2]));
+                        asm volatile("" : "+v"(xf[sb ^ 1][0]), "+v"(xf[sb ^ 1][1]), "+v"(xf[sb ^ 1][NXS - 1])
+                                        : "v"(xf[sb][0]), "v"(xf[sb][1]), "v"(xf[sb][NXS - 1]), "v"(w2[0][0]), "v"(w2[0][1]), "v"(w2[0][2]), "v"(w2[1][0]), "v"(w2[1][1]), "v"(w2[1][2]));
                         __builtin_amdgcn_sched_barrier(0);
                         ldw2(t + 1);                  // (the loads land hundreds of cycles after the last MFMA read these registers)
                     }
@@ -357,7 +376,7 @@ void conv_bx64_kernel(Bx64Args a) {
                     for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            float y = acc2[m2][r];
+                            float y = FX ? acc2[m2][r] * FX_SCALE_INV : acc2[m2][r];
                             if (a.relu2) y = fmaxf(y, 0.f);
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((m2 * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
                         }
@@ -370,7 +389,7 @@ void conv_bx64_kernel(Bx64Args a) {
                         const int voff = oy < a.H && ox < a.W ? (int)((((size_t)oy * a.W + ox) * 64 + l31) * 4) : (int)0x80000000;
 #pragma unroll
                         for (int m2 = 0; m2 < 2; ++m2) {
-                            float y = acc2[m2][r];
+                            float y = FX ? acc2[m2][r] * FX_SCALE_INV : acc2[m2][r];
                             if (a.relu2) y = fmaxf(y, 0.f);
                             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, m2 * 128, 0);
                         }
@@ -403,27 +422,31 @@ void conv_bx64_kernel(Bx64Args a) {
 #undef BX_STAMP
 }
 
-template <int CIN, int FUSE>
+template <int CIN, int FUSE, bool FX>
 static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     Bx64Args a;
-    a.in = in; a.wq = c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
-    a.wq2 = c2 ? reinterpret_cast<const uint4*>(c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
+    a.in = in; a.wq = FX ? c.w_fx : c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    a.wq2 = c2 ? reinterpret_cast<const uint4*>(FX ? c2->w_fx : c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     a.ncols = ceil_div(W, 16); a.nhr = ceil_div(H, 8); a.upi = a.ncols * a.nhr;
     static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE>), bx64::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE, FX>), bx64::LDS_BYTES, attr_done);
     const long long units = (long long)B * a.upi;
     int grid = 2 * num_cus();                  // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
     if (units < grid) grid = (int)units;       // (small inputs: one unit per workgroup; the XCD mapping then needs grid % 8 == 0 or is skipped)
-    conv_bx64_kernel<CIN, FUSE><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
+    conv_bx64_kernel<CIN, FUSE, FX><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
     return 0;
 }
 
-int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc) {
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, bool fx) {
     if (c.ks != 3 || c.stride != 1 || !c.w_bx || c.cout != 64 || c.cin != 64) return -1;
-    if (!c2) return nhwc ? -1 : run_bx64<64, 0>(c, nullptr, in, B, H, W, out, st, trace);
-    if (c2->ks != 1 || c2->cin != 64 || c2->cout != 64 || !c2->w_bx) return -1;
-    return nhwc ? run_bx64<64, 2>(c, c2, in, B, H, W, out, st, trace) : run_bx64<64, 1>(c, c2, in, B, H, W, out, st, trace);
+    if (c2 && (c2->ks != 1 || c2->cin != 64 || c2->cout != 64 || !c2->w_bx)) return -1;
+    if (fx && c.w_fx && (!c2 || c2->w_fx)) {      // the fp16-pair arithmetic: three MFMAs per product instead of six
+        if (!c2) return nhwc ? -1 : run_bx64<64, 0, true>(c, nullptr, in, B, H, W, out, st, trace);
+        return nhwc ? run_bx64<64, 2, true>(c, c2, in, B, H, W, out, st, trace) : run_bx64<64, 1, true>(c, c2, in, B, H, W, out, st, trace);
+    }
+    if (!c2) return nhwc ? -1 : run_bx64<64, 0, false>(c, nullptr, in, B, H, W, out, st, trace);
+    return nhwc ? run_bx64<64, 2, false>(c, c2, in, B, H, W, out, st, trace) : run_bx64<64, 1, false>(c, c2, in, B, H, W, out, st, trace);
 }
 
 }  // namespace xfh

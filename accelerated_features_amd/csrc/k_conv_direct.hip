@@ -514,7 +514,7 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     // blocks on 8 waves), the two workgroups of a CU run their stages in phase (no matrix / vector overlap to collect), and the extra barrier
     // and LDS round trip come on top.  What the vector pipe is short of is issue slots (PMC: 116 M vector instructions, 54 % FMAs, inner loops
     // already 95 % v_pk_fma_f32) -- the remaining lever is the per-item prologue / epilogue arithmetic of the stages, not another pipe.
-    const int c1 = (variant == 1 || variant == 3 || variant == 4) ? variant : 5;      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; default (0 / 4): three pixels on packed FMAs
+    const int c1 = (variant == 1 || variant == 3 || variant == 4) ? variant : 5;      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels on packed FMAs; default (0 / 5): conv1 recomputed inside conv2 (xfh_set_option rejects every other value)
     static unsigned attr1 = 0, attr3 = 0, attr4 = 0, attr5 = 0;
 #define XFH_B1_LAUNCH(MODE, ATTR)                                                                                                       \
     {                                                                                                                                    \

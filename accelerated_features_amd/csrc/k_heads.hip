@@ -262,6 +262,7 @@ struct HeadBxArgs {
     float* inv;              // REL only, optional: 1 / max(||feats[cell,:]||, 1e-12)
     int H, W, hc, wc, ncell, ntiles;
     long long* trace;        // debug: s_memtime stamps of wave 0's second tile, 16 per workgroup
+    float* dbg;              // debug (VAR 10): [layer 0..2][cell][64] outputs of the first three key-point layers
 };
 
 __device__ inline unsigned hb_pk_bf16(float a, float b) {
@@ -285,13 +286,13 @@ __device__ inline void hb_split8(const float (&y)[8], bf16x8& h, bf16x8& m, bf16
 }
 
 // one K = 64 layer: out[mb] = bias + W x, x given per K step by `xs(t, y[8])`; weights of the layer at wl (LDS, operand order)
-template <int MBO, typename XS>
-__device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_lds, XS xs, f32x16 (&out)[MBO], int lane, int half) {
+template <int MBO, int VAR, typename XS, int MBS = MBO, int MB0 = 0>      // (MBS blocks per K step in the weight layout, this call computes blocks MB0 .. MB0 + MBO - 1)
+__device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_lds, XS xs, f32x16 (&out)[MBO], int lane, int half, uint4* sc = nullptr) {
 #pragma unroll
     for (int mb = 0; mb < MBO; ++mb)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 t = *reinterpret_cast<const float4*>(bias_lds + mb * 32 + 8 * g4 + 4 * half);
+            const float4 t = *reinterpret_cast<const float4*>(bias_lds + (MB0 + mb) * 32 + 8 * g4 + 4 * half);
             out[mb][4 * g4] = t.x; out[mb][4 * g4 + 1] = t.y; out[mb][4 * g4 + 2] = t.z; out[mb][4 * g4 + 3] = t.w;
         }
     // (compiler fence: the weights never change, so hipcc hoists every fragment read of every layer out of the persistent tile loop --
@@ -302,7 +303,7 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
 #pragma unroll
         for (int mb = 0; mb < MBO; ++mb)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) o[mb][q] = *reinterpret_cast<const bf16x8*>(wl + (((t * MBO + mb) * 3 + q) * 64 + lane) * 16);
+            for (int q = 0; q < 3; ++q) o[mb][q] = *reinterpret_cast<const bf16x8*>(wl + (((t * MBS + MB0 + mb) * 3 + q) * 64 + lane) * 16);
     };
     ldw(0, w[0]);
     // The B fragments are VALU results, and a VALU write that follows an MFMA by a few cycles can land in that MFMA's A/B registers
@@ -315,11 +316,20 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
         float y[8];
         xs(0, y);
         hb_split8(y, xf[0][0], xf[0][1], xf[0][2]);
+        if (VAR == 4) {
+            uint4* q = sc + lane;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) q[64 * i] = __builtin_bit_cast(uint4, xf[0][i]);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xf[0][i] = __builtin_bit_cast(bf16x8, *(volatile uint4*)(q + 64 * i));
+        }
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (t + 1 < 4) ldw(t + 1, w[(t + 1) & 1]);
         asm volatile("" ::: "memory");
+        if (VAR == 3 || VAR == 8) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(xf[t & 1][0]), "+v"(xf[t & 1][1]), "+v"(xf[t & 1][2])); __builtin_amdgcn_sched_barrier(0); }
         const bf16x8 xh = xf[t & 1][0], xm = xf[t & 1][1], xl = xf[t & 1][2];
         __builtin_amdgcn_sched_barrier(0);      // the MFMAs of a step stay together: left free, hipcc floats the NEXT steps' splits in between them
         // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
@@ -327,10 +337,19 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
         HB_MM(2, xh) HB_MM(0, xl) HB_MM(1, xm) HB_MM(1, xh) HB_MM(0, xm) HB_MM(0, xh)
 #undef HB_MM
         __builtin_amdgcn_sched_barrier(0);
+        if (VAR == 3 || VAR == 8) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
         if (t + 1 < 4) {
             float y[8];
             xs(t + 1, y);
             hb_split8(y, xf[(t + 1) & 1][0], xf[(t + 1) & 1][1], xf[(t + 1) & 1][2]);
+            if (VAR == 4) {      // experiment: the fragments reach their MFMA registers as LDS read results instead of vector-ALU results
+                uint4* q = sc + ((t + 1) & 1) * 192 + lane;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) q[64 * i] = __builtin_bit_cast(uint4, xf[(t + 1) & 1][i]);
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int i = 0; i < 3; ++i) xf[(t + 1) & 1][i] = __builtin_bit_cast(bf16x8, *(volatile uint4*)(q + 64 * i));
+            }
             // the new fragments pass THROUGH the asm that uses the old ones (and this step's weights): it cannot move above the split,
             // so the old registers stay occupied while the split's results and temporaries are written
             asm volatile("" : "+v"(xf[(t + 1) & 1][0]), "+v"(xf[(t + 1) & 1][1]), "+v"(xf[(t + 1) & 1][2])
@@ -347,10 +366,15 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
                  "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");
+    if (VAR == 9) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool KP>
+template <bool KP, int VAR = 0>      // VAR != 0: experiment builds of the soak tool (xfh_debug_head_soak), never launched by the product path
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_bx_kernel(HeadBxArgs a) {
     constexpr int NB = KP ? 288 : 128;                                 // bias floats
     constexpr int W_BYTES = KP ? (3 * 2 + 3) * 4 * 3 * 1024 : 2 * 2 * 4 * 3 * 1024;      // cout blocks x K steps x splits x 1 KiB
@@ -360,6 +384,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hw = a.hc * a.wc;
+    uint4* sc = VAR == 4 ? reinterpret_cast<uint4*>(smem_h + W_BYTES + NB * 4) + wave * 384 : nullptr;      // 6 KiB per wave
+    auto XH = [](float v) { return VAR == 2 ? __shfl_xor(v, 32, 64) : xhalf(v); };
     for (int j = wave; j < W_BYTES / 1024; j += 8)
         __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned char*>(a.wq) + j * 1024 + lane * 16), (lptr_t)(smem_h + j * 1024), 16, 0, 0);
     if (tid < NB) bias_lds[tid] = a.bias[tid];
@@ -392,29 +418,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int tile = blockIdx.x;
     if (tile < a.ntiles) issue_x(tile);
     lds_dma_barrier();                                                // the weights (and biases) have landed; no barrier from here on
+    if (VAR == 7 && wave >= 4) { asm volatile("s_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127"); }      // the second wave of every SIMD starts ~32 k cycles late
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
     int tix = 0;
 #define HB_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }
-    for (; tile < a.ntiles; tile += gridDim.x, ++tix) {
-        const int gcell = tile * HD_CELLS + wave * 32 + l31;          // this lane's cell
+    bool dry = VAR == 13;      // experiment: the first tile computed twice, the first time without stores (instruction cache warm, waves out of the start's lock-step)
+    for (; tile < a.ntiles; tile += (VAR == 13 && dry) ? 0 : (int)gridDim.x, ++tix, dry = (VAR == 13 && dry && tix == 1) ? false : dry) {
+        const int gcell = (VAR == 13 && dry) ? a.ncell : tile * HD_CELLS + wave * 32 + l31;          // this lane's cell (dry pass: nothing is stored)
+        if (VAR == 1 || (VAR >= 5 && VAR <= 10)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (one instruction: 50 x the event rate of VAR 0 in the two-stream soak)
+        if (VAR == 5) asm volatile("s_nop 0");                                                    // code alignment / one issue slot more
+        if (VAR == 6) __syncthreads();                                                            // the waves of a workgroup in lock-step at every tile
         HB_STAMP(0)
         f32x16 accA[2], accB[2];
         float nrm2 = 0.f;
         {
             const float al = nalpha, be = nbeta;
-            head_bx_layer<2>(smem_h, bias_lds, [&](int t, float (&y)[8]) {
+            head_bx_layer<2, VAR>(smem_h, bias_lds, [&](int t, float (&y)[8]) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     y[i] = KP ? fmaf(xin[t][i], al, be) : xin[t][i];
                     if (!KP) nrm2 = fmaf(y[i], y[i], nrm2);
                 }
-            }, accA, lane, half);
+            }, accA, lane, half, sc);
         }
         if (!KP && a.inv) {
-            nrm2 += xhalf(nrm2);                                      // the other 32 channels sit in the other half-wave
+            nrm2 += XH(nrm2);                                      // the other 32 channels sit in the other half-wave
             if (half == 0 && gcell < a.ncell) a.inv[gcell] = 1.f / fmaxf(sqrtf(nrm2), 1e-12f);
         }
         HB_STAMP(1)
+        auto dump = [&](int layer, const f32x16 (&acc)[2]) {
+            if (VAR != 10 || !a.dbg || gcell >= a.ncell) return;
+            float* o = a.dbg + ((size_t)layer * a.ncell + gcell) * 64;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    *reinterpret_cast<float4*>(o + m * 32 + 8 * g4 + 4 * half) = make_float4(acc[m][4 * g4], acc[m][4 * g4 + 1], acc[m][4 * g4 + 2], acc[m][4 * g4 + 3]);
+        };
+        if (KP) dump(0, accA);
+        if (VAR == 13 && dry) issue_x(tile);
+        else
         if (tile + (int)gridDim.x < a.ntiles) issue_x(tile + gridDim.x);      // the next tile's input flies during the chained layers
         // chained layers: K step t = register quads 8 (t & 1), 8 (t & 1) + 4 of block t >> 1, ReLU'd
         auto chain = [](const f32x16 (&in)[2]) {
@@ -424,12 +467,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             };
         };
         if (KP) {
-            head_bx_layer<2>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half);
+            head_bx_layer<2, VAR>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half, sc);
             HB_STAMP(2)
-            head_bx_layer<2>(smem_h + 2 * L_BYTES, bias_lds + 128, chain(accB), accA, lane, half);
+            dump(1, accB);
+            head_bx_layer<2, VAR>(smem_h + 2 * L_BYTES, bias_lds + 128, chain(accB), accA, lane, half, sc);
             HB_STAMP(3)
+            dump(2, accA);
             f32x16 lg[3];
-            head_bx_layer<3>(smem_h + 3 * L_BYTES, bias_lds + 192, chain(accA), lg, lane, half);
+            if constexpr (VAR == 11) {      // experiment: the 64 -> 65 layer as 2 + 1 cout blocks (no 18-MFMA groups, no three-accumulator rotation)
+                f32x16 lga[2], lgb[1];
+                head_bx_layer<2, VAR, decltype(chain(accA)), 3, 0>(smem_h + 3 * L_BYTES, bias_lds + 192, chain(accA), lga, lane, half, sc);
+                head_bx_layer<1, VAR, decltype(chain(accA)), 3, 2>(smem_h + 3 * L_BYTES, bias_lds + 192, chain(accA), lgb, lane, half, sc);
+                lg[0] = lga[0]; lg[1] = lga[1]; lg[2] = lgb[0];
+            } else
+                head_bx_layer<3, VAR>(smem_h + 3 * L_BYTES, bias_lds + 192, chain(accA), lg, lane, half, sc);
             HB_STAMP(4)
             // lane (l31,half) holds logits c = 32m + (r&3) + 8(r>>2) + 4*half of its cell; c == 64 (dustbin) is m=2,r=0,half=0
             float mx = -INFINITY;
@@ -438,7 +489,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, lg[m][r]);
             if (half == 0) mx = fmaxf(mx, lg[2][0]);
-            mx = fmaxf(mx, xhalf(mx));
+            mx = fmaxf(mx, XH(mx));
             float sum = 0.f;
             f32x16 e[2];
 #pragma unroll
@@ -446,7 +497,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { e[m][r] = expf(lg[m][r] - mx); sum += e[m][r]; }
             if (half == 0) sum += expf(lg[2][0] - mx);
-            sum += xhalf(sum);
+            sum += XH(sum);
             if (gcell < a.ncell) {
                 const int b = gcell / hw, rem = gcell - b * hw;
                 const int ci = rem / a.wc, cj = rem - ci * a.wc;
@@ -470,7 +521,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             HB_STAMP(5)
         } else {
-            head_bx_layer<2>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half);
+            head_bx_layer<2, VAR>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half, sc);
             // final 64 -> 1: dot over this lane's 32 channels, other half via one shuffle
             float s = 0.f;
 #pragma unroll
@@ -540,6 +591,68 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
     static unsigned attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<false>), 160 * 1024, attr);
     head_fused_kernel<false><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Debug (xfh_debug_head_soak, tools/head_soak.py): the key-point head alone, launched `iters` times, every result compared on the
+// device with a reference result; differing float4s are counted and the first `cap` of them recorded as {iteration, float4 index,
+// bits got, bits expected} behind a 4-word header {count, 0, 0, 0}.  variant 0 = the shipped split-bf16 kernel, 1..4 = experiment
+// builds of it (VAR above), 100 = the f32-MFMA kernel.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void soak_compare_kernel(const uint4* __restrict__ got, const uint4* __restrict__ ref, size_t n4, int iter, unsigned* rep, unsigned cap) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const uint4 g = got[i], r = ref[i];
+        if (g.x != r.x || g.y != r.y || g.z != r.z || g.w != r.w) {
+            const unsigned k = atomicAdd(rep, 1u);
+            if (k < cap) {
+                unsigned* o = rep + 4 + 4 * (size_t)k;
+                const int c = g.x != r.x ? 0 : g.y != r.y ? 1 : g.z != r.z ? 2 : 3;
+                o[0] = (unsigned)iter; o[1] = (unsigned)i; o[2] = (&g.x)[c]; o[3] = (&r.x)[c];
+            }
+        }
+    }
+}
+
+template <int VAR>
+static void launch_kp_head_var(const HeadBxArgs& h, hipStream_t st) {
+    const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float) + (VAR == 4 ? 8 * 6144 : 0);
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, VAR>), 160 * 1024, attr);
+    head_bx_kernel<true, VAR><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+}
+
+int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, const float* heat_ref, float* logits, const float* logits_ref,
+              int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, hipStream_t st, float* dbg, const float* dbg_ref, unsigned* rep_dbg) {
+    HeadBxArgs h{};
+    h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
+    h.H = H; h.W = W; h.hc = H / 8; h.wc = W / 8;
+    h.ncell = B * h.hc * h.wc;
+    h.ntiles = ceil_div(h.ncell, HD_CELLS);
+    h.dbg = dbg;
+    const size_t n4h = (size_t)B * H * W / 4, n4l = (size_t)h.ncell * 65 / 4, n4d = (size_t)3 * h.ncell * 64 / 4;
+    for (int it = 0; it < iters; ++it) {
+        switch (variant) {
+            case 0: launch_kp_head_var<0>(h, st); break;
+            case 1: launch_kp_head_var<1>(h, st); break;
+            case 2: launch_kp_head_var<2>(h, st); break;
+            case 3: launch_kp_head_var<3>(h, st); break;
+            case 4: launch_kp_head_var<4>(h, st); break;
+            case 5: launch_kp_head_var<5>(h, st); break;
+            case 6: launch_kp_head_var<6>(h, st); break;
+            case 7: launch_kp_head_var<7>(h, st); break;
+            case 8: launch_kp_head_var<8>(h, st); break;
+            case 9: launch_kp_head_var<9>(h, st); break;
+            case 10: launch_kp_head_var<10>(h, st); break;
+            case 11: launch_kp_head_var<11>(h, st); break;
+            case 13: launch_kp_head_var<13>(h, st); break;
+            case 100: launch_kp_head(nw, gray, coef, B, H, W, heat, logits, st, true); break;
+            default: return -1;
+        }
+        if (heat_ref) soak_compare_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const uint4*>(heat), reinterpret_cast<const uint4*>(heat_ref), n4h, iter0 + it, rep_heat, cap);
+        if (logits && logits_ref) soak_compare_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const uint4*>(logits), reinterpret_cast<const uint4*>(logits_ref), n4l, iter0 + it, rep_logits, cap);
+        if (dbg && dbg_ref) soak_compare_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const uint4*>(dbg), reinterpret_cast<const uint4*>(dbg_ref), n4d, iter0 + it, rep_dbg, cap);
+    }
+    return 0;
 }
 
 }  // namespace xfh

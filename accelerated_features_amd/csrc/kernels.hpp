@@ -21,6 +21,7 @@ struct ConvW {
     const float* w_kcp;    // [(ci*kk+tap)][cout_pad]  BN folded, zero padded (MFMA kernels)
     const float* bias;     // [cout_pad] folded BN shift or conv bias, zero padded
     const float* w_wino;   // [cin/4][16][2][cout_pad][2] Winograd F(2x2,3x3) G g G^T (3x3/s1 layers, cin >= 24), else NULL
+    const void* w_fx;      // the same fragments in the fp16-pair arithmetic (api.hip: split_weight mode 1), NULL if the layer has none or a weight is too large for it
     const void* w_bx;      // three-way split bf16 weights in MFMA operand order, else NULL: cin 24: [step][split h,m,l][64 lanes][8] (k_conv_bx.hip);
                            // cin 64 -> 64: [cin/16][dy][dx][cout block][split][64 lanes][8] (k_conv_bx64.hip)
 };
@@ -37,6 +38,7 @@ struct NetWeights {
     const float* zeros;   // 1 KiB of zeros (padding source of the LDS-DMA loaders)
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): [0] key-point head, [1] reliability head
     const void* head_bx[2];          // per layer [K step 4][cout block][split 3][64 lanes][8] bf16
+    const void* head_fx[2];          // the same in the fp16-pair arithmetic (or NULL)
     const float* head_bx_bias[2];    // biases padded to the cout blocks (KP 64,64,64,96 ; REL 64,64)
     float head_rel_b_last;           // bias of the final 64 -> 1 layer of the reliability head
 };
@@ -51,7 +53,8 @@ struct Options {
     int bx = 21;            // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0,
                             // 16 = the stride-2 64 -> 64 | 128 layers (block4.0, block5.0)
     int heads_f32 = 0;      // 1: heads on the f32-MFMA kernels
-    int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs
+    int fx = 0;             // split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six): bit 1 = the 64 -> 64 layers on large maps (conv_bx64_kernel)
+    int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected)
 };
 
 // ---- k_preproc.hip ----------------------------------------------------------------------
@@ -86,7 +89,7 @@ int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, 
 // 3x3/s1 on bf16 MFMAs with three-way split operands (fp32-equivalent; k_conv_bx.hip); -1 if no instantiation
 int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
 int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr,
-                     const ConvW* fused1x1 = nullptr, bool nhwc = false);
+                     const ConvW* fused1x1 = nullptr, bool nhwc = false, bool fx = false);
 // 3x3/s2, 64 -> 64 | 128 (block4.0, block5.0; k_conv_bx64s2.hip); -1 if no instantiation
 int launch_conv_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
 int bx_steps(int cin);      // K steps of 16 = 2 groups of 8 channels of one tap
@@ -122,6 +125,9 @@ void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat
 // ---- k_heads.hip -------------------------------------------------------------------------
 // fused heads (persistent, weights LDS-resident): key-point head -> heat (+ optional logits (M,65)),
 // reliability head -> sigmoid map
+int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, const float* heat_ref, float* logits, const float* logits_ref,
+              int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, hipStream_t st, float* dbg = nullptr, const float* dbg_ref = nullptr,
+              unsigned* rep_dbg = nullptr);      // debug, k_heads.hip
 void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, bool f32_kernels = false);
 // invnorm (optional): 1 / max(||feats[cell,:]||, 1e-12) per cell, a by-product of the layer-1 operand loads
 void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, bool f32_kernels = false);

@@ -180,10 +180,16 @@ class XFeatModel(nn.Module):
         ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
         h = C.c_void_p()
         _lib.check(lib.xfh_create(ptrs, n, dev, C.byref(h)), "xfh_create")
+        try:                                           # every remembered option applies, or the handle is never published
+            for k, v in self._options.items():
+                _lib.check(lib.xfh_set_option(h, k.encode(), int(v)), f"xfh_set_option({k})")
+        except Exception:
+            lib.xfh_destroy(h)
+            raise
         self._handle, self._handle_device = h, dev
-        for k, v in self._options.items():
-            _lib.check(lib.xfh_set_option(h, k.encode(), int(v)), f"xfh_set_option({k})")
         return h
+
+    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 1), "block1": (0, 5), "fx": (0, 15)}      # include/xfeat_hip.h: xfh_set_option
 
     def set_option(self, key, value):
         """Kernel-variant switch of this model's handle (include/xfeat_hip.h: xfh_set_option) -- A/B runs and variant-vs-variant tests.
@@ -192,9 +198,14 @@ class XFeatModel(nn.Module):
             if self._options.pop(key, None) is not None:
                 self._drop_handle()                    # a fresh handle starts from the defaults
             return
-        self._options[key] = int(value)
+        # validated BEFORE it is remembered (a bad entry in _options would fail every later handle creation half-way through the list): against the
+        # live handle when there is one, against the table below (= api.hip: option_slot) otherwise
+        lo, hi = self.OPTION_RANGES.get(key, (None, None))
+        if lo is None or not lo <= int(value) <= hi or (key == "block1" and int(value) == 2):
+            raise _lib.XFeatHipError(f"set_option: unknown option or value out of range: {key} = {value} (options: {self.OPTION_RANGES})")
         if self._handle is not None:
             _lib.check(_lib.load().xfh_set_option(self._handle, key.encode(), int(value)), f"xfh_set_option({key})")
+        self._options[key] = int(value)
 
     def workspace(self, name, nbytes):
         dev = torch.device("cuda", torch.cuda.current_device())

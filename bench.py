@@ -170,6 +170,7 @@ def load_pmc_traffic():
 
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PEAK_BF16_TFLOPS = 2500.0         # dense bf16 / fp16 MFMA
+MATCH_MAXIMA_BYTES_PER_ENTRY = 4.0      # the matcher's block maxima (k_match_f16.hip): fp32
 
 
 def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K):
@@ -188,7 +189,7 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K):
     f32 = PEAK_MFMA_F32_TFLOPS
     rows = []
 
-    def add(span, kernel, by, fl_alg, fl_exec, peak, pipe, note=""):
+    def add(span, kernel, by, fl_alg, fl_exec, peak, pipe, note="", design_bytes=0.0):
         us = spans_us.get(span)
         if us is None or us <= 0:
             return
@@ -196,7 +197,9 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K):
         t_cmp = (fl_exec / 1e12) / peak * 1e6 if peak else 0.0
         rows.append({"kernel": kernel, "us": round(us, 1), "bytes": int(by), "hbm_gbs": round(by / us / 1e3, 1), "flops_algorithmic": fl_alg,
                      "flops_executed": fl_exec, "pipe": pipe, "peak_used_tflops": peak, "bound": "hbm" if t_mem >= t_cmp else pipe,
-                     "floor_us": round(max(t_mem, t_cmp), 1), "frac": round(max(t_mem, t_cmp) / us, 3), **({"note": note} if note else {})})
+                     "floor_us": round(max(t_mem, t_cmp), 1), "frac": round(max(t_mem, t_cmp) / us, 3), **({"note": note} if note else {}),
+                     # traffic the kernel's DESIGN adds on top of the algorithmic bytes (the matcher's block-maxima arrays): in no floor, listed so that it can be seen
+                     **({"filter_design_traffic_bytes": int(design_bytes)} if design_bytes else {})})
 
     ci = {c.name: i for i, c in enumerate(CONVS)}
     add(200, "gray_stats + gray_coef (channel mean, InstanceNorm statistics)", 4.0 * px["1"] * 4, 4.0 * px["1"], 4.0 * px["1"], 0, "valu")
@@ -235,9 +238,10 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K):
         2.0 * 16 * 64 * B * n_kpts, 0, "l1 gather", note="bytes = compulsory HBM traffic; the gather itself moves 4 KB per key-point through L1/L2")
     mm = 2.0 * P * n_kpts * n_kpts * 64
     add(220, "match: memset of keys / maxima", 8.0 * 2 * P * n_kpts + 4.0 * P * n_kpts, 0, 0, 0, "hbm")
-    add(222, "mnn_f16_sweep_kernel (both tile orientations)", 2.0 * 2 * P * n_kpts * 64 * 2 + 4.0 * 2 * P * n_kpts * (n_kpts / 32), mm, 2 * mm, PEAK_BF16_TFLOPS, "fp16 mfma (filter)")
-    add(223, "mnn_f16_thr_row + mnn_f16_refine_kernel (scan of the block maxima, exact fp32 blocks on f32 mfma)", 4.0 * 2 * P * n_kpts * (n_kpts / 32) + 4.0 * 2 * P * n_kpts * 64, 0,
-        2.0 * 2 * P * n_kpts * 1.07 * 32 * 64, f32, "latency + f32 mfma")
+    maxima = MATCH_MAXIMA_BYTES_PER_ENTRY * 2 * P * n_kpts * (n_kpts / 32)      # R (P, N2/32, N1) + C (P, N1/32, N2): written by the sweep, read by the refine's scan
+    add(222, "mnn_f16_sweep_kernel (both tile orientations)", 2.0 * 2 * P * n_kpts * 64, mm, 2 * mm, PEAK_BF16_TFLOPS, "fp16 mfma (filter)", design_bytes=maxima)
+    add(223, "mnn_f16_thr_row + mnn_f16_refine_kernel (scan of the block maxima, exact fp32 blocks on f32 mfma)", 4.0 * 2 * P * n_kpts * 64, 0,
+        2.0 * 2 * P * n_kpts * 1.07 * 32 * 64, f32, "latency + f32 mfma", design_bytes=maxima)
     add(224, "mnn_finalize_kernel", 8.0 * 2 * P * n_kpts + 16.0 * P * n_kpts, 0, 0, 0, "latency")
     rows.sort(key=lambda r: -r["us"])
     tot = sum(r["us"] for r in rows)
@@ -278,6 +282,19 @@ def side_workloads(xf, x, B, seconds_cap=90.0):
             return [xf.match(res[2 * p]['descriptors'], res[2 * p + 1]['descriptors'], min_cossim=-1) for p in range(B // 2)]
         return round(B / timed(step, 3), 1)
 
+    def latency_b1():
+        # the reference demo's per-frame step through the public API (realtime_demo.py:204-209): detectAndCompute on ONE VGA frame, match(descs_ref, descs_cur, 0.82)
+        # against the cached reference frame, the matched coordinates brought to the host; wall clock per frame, one frame in flight (top_k 4096: BASELINE's figure; the demo's own default is 3000)
+        ref = xf.detectAndCompute(x[:1], top_k=TOP_K)[0]
+
+        def step():
+            cur = xf.detectAndCompute(x[1:2], top_k=TOP_K)[0]
+            i0, i1 = xf.match(ref['descriptors'], cur['descriptors'], 0.82)
+            return ref['keypoints'][i0].cpu(), cur['keypoints'][i1].cpu()
+        for _ in range(10):
+            step()
+        return round(1e3 * timed(step, 100), 3)
+
     def dense():
         P = 32
         base = fixtures.texture_images(4, 1024, 1024, seed=2000)
@@ -305,10 +322,12 @@ def side_workloads(xf, x, B, seconds_cap=90.0):
         return round(B / timed(step, 2), 1)
 
     guarded("public_api_fps", public_api)
+    guarded("latency_b1_ms", latency_b1)
     guarded("dense_1024_pairs_per_s", dense)
     guarded("megadepth1600_pairs_per_s", megadepth)
     guarded("lighterglue_frames_per_s", lighterglue)
-    out["side_workloads"] = ("public_api_fps: detectAndCompute (List[Dict]) + 32 x match() on the bench batch; dense_1024: match_xfeat_star on 32 pairs of 1024^2 "
+    out["side_workloads"] = ("public_api_fps: detectAndCompute (List[Dict]) + 32 x match() on the bench batch; latency_b1_ms: ONE VGA frame through detectAndCompute + match(0.82) "
+                             "against a cached reference frame + the matched points on the host, wall clock per frame (the reference demo's step, realtime_demo.py:204-209); dense_1024: match_xfeat_star on 32 pairs of 1024^2 "
                              "(configs[2]); megadepth1600: the 1500 pairs of the MegaDepth-1500 list at long side 1600 through batching.match_pairs, one pass "
                              "(configs[3], crops of one synthetic texture); lighterglue: detect + attention matcher on the bench batch (configs[4]); "
                              "each a short untimed-by-the-contract pass on this GPU, full versions: --workload dense|megadepth|lighterglue")
@@ -553,7 +572,8 @@ def launch_selftest(args, rank, world):
     secs, last = sharding.timed_steps(lambda: time.sleep(0.01 * (rank + 1)) or rank, args.steps, args.warmup, dist, None, "cpu")
     if rank == 0:
         print(json.dumps({"metric": "launch self-test (no GPU work)", "value": round(sharding.aggregate_rate(1, args.steps, world, secs, "weak"), 3), "unit": "steps/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * secs / args.steps, 3), "selftest": True}))
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * secs / args.steps, 3), "selftest": True, "scaling": "weak",
+                          "config": {"workload": "sleep of 10 ms x (rank + 1) per step", "units_per_rank_per_step": 1}}))
     if dist is not None:
         sharding.sync_barrier(dist)
         dist.destroy_process_group()
@@ -886,7 +906,11 @@ def main():
             "roofline_match": {"bound": "mfma", "kernels": "mnn_f16_sweep_kernel + mnn_f16_thr_row + mnn_f16_refine_kernel (the fp16 copies come from the descriptor kernel)",
                                "us_per_step": round(1e3 * m_ms / 3, 1), "algorithmic_f32_tflops": round((m_fl / 1e12) / (m_ms / 1e3), 2) if m_ms > 0 else None,
                                "executed": "2 x 2*P*N1*N2*64 FLOP on v_mfma_f32_32x32x16_f16 (one sweep, both orientations of every tile) + 32 exact fp32 similarities per flagged block",
-                               "executed_f16_tflops_sweep": round((2 * m_fl / 1e12) / (spans_us.get(222, 0) / 1e6), 1) if spans_us.get(222) else None, "peak_f16_tflops": PEAK_BF16_TFLOPS},
+                               # (m_fl = the algorithmic FLOPs of the 3 steps of the side pass; spans_us = us per ONE step)
+                               "executed_f16_tflops_sweep": round((2 * (m_fl / 3) / 1e12) / (spans_us.get(222, 0) / 1e6), 1) if spans_us.get(222) else None, "peak_f16_tflops": PEAK_BF16_TFLOPS,
+                               # the matcher's algorithmic floor: ONE fp16 GEMM per pair (2*N1*N2*64 FLOP) at the 2.5 PF peak, against everything xfh_match_mnn launches
+                               "floor_algorithmic_us": round((m_fl / 3) / PEAK_BF16_TFLOPS / 1e6, 1),
+                               "frac_algorithmic": round(((m_fl / 3) / PEAK_BF16_TFLOPS / 1e6) / (1e3 * m_ms / 3), 3) if m_ms > 0 else None},
             # the two 24 -> 24 convolutions (round 1-2a: the dominant kernel as Winograd on f32 MFMAs, 2 x 151 us): bf16 MFMAs on three-way
             # split operands, fp32-equivalent results.  "achieved" prices the ALGORITHMIC fp32 work against the f32 MFMA peak.
             "roofline_conv24": {"bound": "mfma", "kernel": "conv_bx_kernel<24,24> (block2.0 / block2.1 on v_mfma_f32_32x32x16_bf16, six MFMAs per K = 16)",

@@ -141,7 +141,8 @@ int xfh_backbone_resized(xfh_handle h, const float* img, int B, int C, int Hin, 
  * activations).  layer = index into spec.CONVS; in (B,Cin,Hin,Win) NCHW, out (B,Cout,Hout,Wout)
  * NCHW with the layer's own stride/padding, folded BN and ReLU where the reference has them.
  * variant: 0 = the kernel the backbone uses for this layer, 1 = the generic direct kernel,
- * >= 2 = explicit Winograd configurations of the 3x3/s1 layers (tuning; XFH_ERR_UNSUPPORTED elsewhere). */
+ * 10 = the split-bf16 kernel of the layer, 11 = the same kernel in the fp16-pair arithmetic, other values >= 2 = explicit Winograd
+ * configurations of the 3x3/s1 layers (tuning; XFH_ERR_UNSUPPORTED elsewhere). */
 int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out,
                    int variant, xfh_stream stream);
 
@@ -338,6 +339,13 @@ int xfh_profile_select(xfh_handle h, int which);
 int xfh_profile_read_spans(xfh_handle h, int* ids, double* ms, int capacity, int* n_spans);
 /* debug: 24 int64 s_memtime stamps per MFMA-conv workgroup are written to device_buffer (NULL = off) */
 int xfh_debug_trace(xfh_handle h, long long* device_buffer);
+/* debug (tools/head_soak.py): the key-point head alone, `iters` launches of kernel `variant` (0 = the shipped split-bf16 kernel, 1..4 = experiment
+ * builds of it, 100 = the f32-MFMA kernel), every result compared on the device with heat_ref (and logits_ref); a report buffer holds {count, 0, 0, 0}
+ * followed by up to `cap` records {iteration, float4 index, bits got, bits expected}.  img != NULL: gray / coef are computed from it first
+ * (part: B * 128 doubles of scratch).  dbg (variant 10 only): [3][cells][64] outputs of the first three layers, compared with dbg_ref likewise. */
+int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int W, float* gray, float* coef, double* part, float* heat,
+                        const float* heat_ref, float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat,
+                        unsigned* rep_logits, unsigned cap, xfh_stream stream, float* dbg, const float* dbg_ref, unsigned* rep_dbg);
 /* debug: resident workgroups per CU the runtime reports for mnn_sim_kernel */
 int xfh_debug_match_occupancy(void);
 int xfh_profile_read(xfh_handle h, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);

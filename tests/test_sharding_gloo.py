@@ -106,6 +106,16 @@ def test_bench_launches_its_own_ranks_and_never_underreports(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["selftest"] is True
     assert d["ms_per_step"] >= 19.0                               # the slow rank (20 ms sleeps) sets the time: MAX over ranks
+    # the same at the width of a full node: 8 ranks, one line, n_gpus 8, the slowest rank's time
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--launch-selftest", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["selftest"] is True and d["scaling"] == "weak"
+    assert d["ms_per_step"] >= 79.0                               # rank 7 sleeps 80 ms per step: MAX over ranks
+    assert abs(d["value"] - 8 * d["config"]["units_per_rank_per_step"] / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]      # whole-job units / the slowest rank's time
     # the real workload on this GPU-less box: refuse, do not report
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
