@@ -89,6 +89,7 @@ static size_t array_floats(int idx) {
 // profiler: HIP events around one kernel family, on the launch stream
 // ------------------------------------------------------------------------------------------
 namespace xfh {
+int g_debug_cold = 0;      // debug (xfh_debug_cold_start): process-wide, never set by the product path
 extern long long* g_head_trace;        // k_heads.hip
 struct Profiler {
     int which = 0;
@@ -130,6 +131,7 @@ struct xfh_context {
     NetWeights nw;
     Profiler prof;
     Options opt;          // xfh_set_option
+    int* status = nullptr;      // xfh_set_status_buffer: caller-owned device word the kernels OR status bits into (bit 0: fp16-pair range exceeded)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -611,11 +613,11 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     int rc = -1;
     const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 1024;      // >= 2 half-tile units per workgroup of the persistent grid (B=8 164x164: 92 vs 124 us stand-alone)
     if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
-        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) != 0);      // 3x3 + trailing 1x1 in one split-operand kernel
+        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) != 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
-        if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace);      // (bx = 9: block3.0 stays on the f32 kernel)
-        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) != 0);      // (bx = 5: large maps only)
+        if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, (h->opt.fx & 2) != 0, h->status);      // (bx = 9: block3.0 stays on the f32 kernel)
+        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) != 0, h->status);      // (bx = 5: large maps only)
     }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
@@ -722,7 +724,9 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
         return check_launch("xfh_conv_layer(split bf16)");
     }
     if (variant == 11) {      // the split kernel of the layer in the fp16-pair arithmetic
-        if (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, true)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fp16-pair instantiation for layer %d", layer);
+        if (!c.w_fx || (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, true, h->status)
+                                    : (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, true, h->status))))
+            return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fp16-pair instantiation for layer %d", layer);
         return check_launch("xfh_conv_layer(fp16 pair)");
     }
     if (variant >= 2) {
@@ -954,6 +958,7 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
 }
 
 int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
+int xfh_debug_cold_start(int enable) { xfh::g_debug_cold = enable ? 1 : 0; return XFH_OK; }
 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
@@ -971,6 +976,11 @@ int xfh_set_option(xfh_handle h, const char* key, int value) {
     if (value < lo || value > hi) return fail(XFH_ERR_ARG, "xfh_set_option: %s = %d outside [%d, %d]", key, value, lo, hi);
     if (!strcmp(key, "block1") && value == 2) return fail(XFH_ERR_ARG, "xfh_set_option: block1 = 2 names no kernel (0 | 5 = shipped, 1, 3, 4 = earlier forms)");
     *slot = value;
+    return XFH_OK;
+}
+int xfh_set_status_buffer(xfh_handle h, int32_t* device_word) {
+    if (!h) return fail(XFH_ERR_ARG, "xfh_set_status_buffer: NULL handle");
+    h->status = reinterpret_cast<int*>(device_word);
     return XFH_OK;
 }
 int xfh_get_option(xfh_handle h, const char* key, int* value) {

@@ -58,5 +58,12 @@ __device__ inline void split2_f16(float a, float b, unsigned& h, unsigned& l) {
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 constexpr float FX_SCALE_INV = 1.f / 2048.f;
+// Range guard of the fp16 pair: a kernel keeps the largest |x| it converted (one v_max3 per value pair) and, when it ends, reports |x| >= 65504 -- a value the
+// fp16 high part cannot hold -- by setting bit 0 of the caller's status word (xfh_set_status_buffer; the host re-runs the batch in the bf16 arithmetic).
+constexpr float FX_MAX_INPUT = 65504.f;
+__device__ inline void fx_track(float& amax, float a, float b) { amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b))); }
+__device__ inline void fx_report(float amax, int* status) {
+    if (status && amax >= FX_MAX_INPUT) atomicOr(status, 1);
+}
 
 }  // namespace xfh

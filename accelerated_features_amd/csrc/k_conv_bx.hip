@@ -22,6 +22,7 @@
 #include "kernels.hpp"
 #include "bx_split.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace xfh {
 
@@ -33,12 +34,17 @@ struct BxArgs {
     int relu, H, W, B, tiles_x, tiles;
     int lag;                   // first-tile delay of the second workgroup of a CU, in units of 512 cycles
     long long* trace;          // debug: 6 s_memtime stamps per tile, 10 tiles, per workgroup (NULL in production)
+    int cold;
+    int* status;               // fx: range guard (bx_split.hpp), may be NULL
 };
 
-template <int CIN, int COUT>
+// FX: the fp16-pair arithmetic (bx_split.hpp): two input fragments per pixel (h, l), three MFMAs per K step and accumulator
+template <int CIN, int COUT, bool FX = false>
 struct BxCfg {
     static constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
-    static constexpr int CG = CIN / 8, PIXB = 3 * CIN * 2, SPLB = CIN * 2;      // bytes per pixel / per split row
+    static constexpr int NXS = FX ? 2 : 3;
+    // bytes per pixel / per split row; an ODD multiple of 16 B per pixel keeps the 16 lanes of a ds_read_b128 group on distinct banks (fx: 2 x 48 + 16 of padding)
+    static constexpr int CG = CIN / 8, SPLB = CIN * 2, PIXB = ((NXS * SPLB / 16) | 1) * 16;
     static constexpr int KG = 9 * CG, NSTEP = (KG + 1) / 2;
     static constexpr int NITEM = NPIX * CG, NIT = (NITEM + 255) / 256;
     static constexpr bool WM_LDS = true;
@@ -53,10 +59,17 @@ struct BxCfg {
     }
 };
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx_kernel(BxArgs a) {
-    using Cfg = BxCfg<CIN, COUT>;
+    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    using Cfg = BxCfg<CIN, COUT, FX>;
+    constexpr int NXS = Cfg::NXS;
+    using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
+    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {
+        if constexpr (FX) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    };
     constexpr int TH = Cfg::TH, TW = Cfg::TW, IW = Cfg::IW, NPIX = Cfg::NPIX, CG = Cfg::CG, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB;
     constexpr int NSTEP = Cfg::NSTEP, NIT = Cfg::NIT;
     constexpr bool WM_LDS = Cfg::WM_LDS;
@@ -68,11 +81,11 @@ void conv_bx_kernel(BxArgs a) {
     // split weights in operand order: lane (cout l31, half) holds K group 2 s + half of every step.  wh (3 uses per step and row)
     // stays in registers for the whole kernel; wm (2 uses) and wl (1) are read from LDS once per step: all three in registers (168)
     // leave hipcc two fragment buffers and an lgkmcnt(0) in front of every MFMA group, and no room for the prefetched next tile
-    bf16x8 wf[NSTEP][WM_LDS ? 1 : 2];
+    frag_t wf[NSTEP][WM_LDS ? 1 : 2];
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
-        for (int q = 0; q < (WM_LDS ? 1 : 2); ++q) wf[s][q] = __builtin_bit_cast(bf16x8, a.wfrag[(s * 3 + q) * 64 + lane]);
+        for (int q = 0; q < (WM_LDS ? 1 : 2); ++q) wf[s][q] = __builtin_bit_cast(frag_t, a.wfrag[(s * 3 + q) * 64 + lane]);
     unsigned char* wl_lds = smem_bx + Cfg::TILE_BYTES;            // [step][lane] 16 B
     unsigned char* wm_lds = wl_lds + Cfg::WL_BYTES;
     for (int s = wave; s < NSTEP; s += 4) {
@@ -114,6 +127,7 @@ void conv_bx_kernel(BxArgs a) {
     // raw fp32 values of a tile: 8 channels of one pixel per item, all loads of a thread in flight together; out-of-image pixels
     // carry an out-of-range offset (the buffer load returns the zero padding)
     float v[NIT][8];
+    float amax = 0.f;                         // fx: the largest |x| converted (range guard)
     auto issue_loads = [&](int vid) {
         int b, oy0, ox0;
         tile_of(vid, b, oy0, ox0);
@@ -131,15 +145,24 @@ void conv_bx_kernel(BxArgs a) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             uint4 h, m, l;
-            split3(v[i][0], v[i][1], h.x, m.x, l.x);
-            split3(v[i][2], v[i][3], h.y, m.y, l.y);
-            split3(v[i][4], v[i][5], h.z, m.z, l.z);
-            split3(v[i][6], v[i][7], h.w, m.w, l.w);
+            if constexpr (FX) {
+                fx_track(amax, v[i][0], v[i][1]); fx_track(amax, v[i][2], v[i][3]); fx_track(amax, v[i][4], v[i][5]); fx_track(amax, v[i][6], v[i][7]);
+                split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
+                split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
+            } else {
+                split3(v[i][0], v[i][1], h.x, m.x, l.x);
+                split3(v[i][2], v[i][3], h.y, m.y, l.y);
+                split3(v[i][4], v[i][5], h.z, m.z, l.z);
+                split3(v[i][6], v[i][7], h.w, m.w, l.w);
+            }
             if (it_rc[i] >= 0) {
                 unsigned char* p = smem_bx + it_lds[i];
                 *reinterpret_cast<uint4*>(p) = h;
-                *reinterpret_cast<uint4*>(p + SPLB) = m;
-                *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+                if constexpr (FX) *reinterpret_cast<uint4*>(p + SPLB) = l;
+                else {
+                    *reinterpret_cast<uint4*>(p + SPLB) = m;
+                    *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+                }
             }
         }
     };
@@ -179,17 +202,17 @@ void conv_bx_kernel(BxArgs a) {
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         // operands of step s+1 are read while the MFMAs of step s issue (two register sets, pinned: left alone hipcc sinks the reads
         // in front of their first use).  The K groups of the two lane halves differ by one of three byte deltas -> three base registers.
-        struct Frag { bf16x8 x[2][3]; bf16x8 wl, wm; };
+        struct Frag { frag_t x[2][NXS]; frag_t wl, wm; };
         Frag f[2];
         auto load = [&](int s, Frag& o) {
             const int k0 = Cfg::koff(2 * s), dk = Cfg::koff(2 * s + 1) - k0;
             const unsigned char* p = smem_bx + (lane_off + half * dk) + k0;
-            o.wl = *reinterpret_cast<const bf16x8*>(wl_lds + (s * 64 + lane) * 16);
-            if (WM_LDS) o.wm = *reinterpret_cast<const bf16x8*>(wm_lds + (s * 64 + lane) * 16);
+            o.wl = *reinterpret_cast<const frag_t*>(wl_lds + (s * 64 + lane) * 16);
+            if (WM_LDS) o.wm = *reinterpret_cast<const frag_t*>(wm_lds + (s * 64 + lane) * 16);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) o.x[j][q] = *reinterpret_cast<const bf16x8*>(p + j * IW * PIXB + q * SPLB);
+                for (int q = 0; q < NXS; ++q) o.x[j][q] = *reinterpret_cast<const frag_t*>(p + j * IW * PIXB + q * SPLB);
         };
         load(0, f[0]);
 #pragma unroll
@@ -197,14 +220,17 @@ void conv_bx_kernel(BxArgs a) {
             const Frag& c = f[s & 1];
             if (s + 1 < NSTEP) load(s + 1, f[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 wh = wf[s][0], wm = WM_LDS ? c.wm : wf[s][WM_LDS ? 0 : 1];
+            const frag_t wh = wf[s][0], wm = WM_LDS ? c.wm : wf[s][WM_LDS ? 0 : 1];
             // small terms first; the two rows alternate (independent accumulators)
-#define BX_MM(A, Q) { acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c.x[0][Q], acc[0], 0, 0, 0); acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, c.x[1][Q], acc[1], 0, 0, 0); }
-            BX_MM(c.wl, 0) BX_MM(wh, 2) BX_MM(wm, 1) BX_MM(wm, 0) BX_MM(wh, 1) BX_MM(wh, 0)
+#define BX_MM(A, Q) { acc[0] = mfma(A, c.x[0][Q], acc[0]); acc[1] = mfma(A, c.x[1][Q], acc[1]); }
+            if constexpr (FX) { BX_MM(c.wl, 0) BX_MM(wm, 1) BX_MM(wh, 0) }      // fragments (2^11 w - q0, w, q0 = fp16(2^11 w)) x (xh, xl, xh): all at scale 2^11
+            else { BX_MM(c.wl, 0) BX_MM(wh, 2) BX_MM(wm, 1) BX_MM(wm, 0) BX_MM(wh, 1) BX_MM(wh, 0) }
 #undef BX_MM
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_nop 7\n\ts_nop 7");      // idle slots: the epilogue's VALU code must not land in operand registers of the last MFMAs
+        // idle slots: the epilogue's VALU code must not land in operand registers of the last MFMAs.  Tied to the accumulators: an asm without
+        // operands is no anchor -- hipcc moved it in front of the fx form's last two MFMAs and the epilogue's address arithmetic behind them (ISA audit)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));
         __builtin_amdgcn_sched_barrier(0);
         BX_STAMP(3)
         // ---- bias, ReLU, store ------------------------------------------------------------------------------------------
@@ -226,7 +252,7 @@ void conv_bx_kernel(BxArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co0 = (r & 3) + 8 * (r >> 2);          // cout of lane half 0; half 1 holds co0 + 4
                 if (co0 < COUT) {                                // compile-time (r < 12 for 24 channels)
-                    float y = acc[j][r] + bs[r];
+                    float y = FX ? fmaf(acc[j][r], FX_SCALE_INV, bs[r]) : acc[j][r] + bs[r];
                     if (a.relu) y = fmaxf(y, 0.f);
                     const bool okc = COUT % 8 == 0 || co0 + 4 * half < COUT;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, okc ? voff : (int)0x80000000, (int)(co0 * HW * 4), 0);
@@ -240,6 +266,7 @@ void conv_bx_kernel(BxArgs a) {
         ++tix;
         vid = nvid;
     }
+    if constexpr (FX) fx_report(amax, a.status);
 #undef BX_STAMP
 }
 
@@ -250,9 +277,10 @@ void conv_bx_kernel(BxArgs a) {
 // multiple of 64 B, so that the second row of a pixel block lands on the same banks as the first): the lanes of a fragment read step by
 // two input pixels and would otherwise collide pairwise.  wh and wm of the wave's cout block live in registers, wl in LDS.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int CIN>
+template <int CIN, bool FX = false>
 struct BxS2Cfg {
-    static constexpr int IH = 10, IW = 34, NPIX = IH * IW, CG = CIN / 8, PIXB = 3 * CIN * 2, SPLB = CIN * 2;
+    static constexpr int NXS = FX ? 2 : 3;
+    static constexpr int IH = 10, IW = 34, NPIX = IH * IW, CG = CIN / 8, SPLB = CIN * 2, PIXB = ((NXS * SPLB / 16) | 1) * 16;
     static constexpr int ROWQ = ((IW / 2) * PIXB + 63) / 64 * 64;          // bytes per (row, column parity)
     static constexpr int KG = 9 * CG, NSTEP = (KG + 1) / 2;
     static constexpr int NIT = (NPIX * CG + 255) / 256;
@@ -272,12 +300,21 @@ struct BxS2Args {
     const float* bias;
     float* out;
     int relu, H, W, Ho, Wo, B, tiles_x, tiles;
+    int cold;
+    int* status;
 };
 
-template <int CIN>
+template <int CIN, bool FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bxs2_kernel(BxS2Args a) {
-    using Cfg = BxS2Cfg<CIN>;
+    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    using Cfg = BxS2Cfg<CIN, FX>;
+    constexpr int NXS = Cfg::NXS;
+    using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
+    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {
+        if constexpr (FX) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    };
     constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, CG = Cfg::CG, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB, ROWQ = Cfg::ROWQ;
     constexpr int NSTEP = Cfg::NSTEP, NIT = Cfg::NIT, COUT = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
@@ -286,11 +323,11 @@ void conv_bxs2_kernel(BxS2Args a) {
     const int pb = wave >> 1, cb = wave & 1;
     const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
 
-    bf16x8 wf[NSTEP][2];                       // wh, wm of this wave's cout block
+    frag_t wf[NSTEP][2];                       // wh, wm of this wave's cout block (fx: q0 = fp16(2^11 w), q1 = fp16(w))
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) wf[s][q] = __builtin_bit_cast(bf16x8, a.wfrag[((cb * NSTEP + s) * 3 + q) * 64 + lane]);
+        for (int q = 0; q < 2; ++q) wf[s][q] = __builtin_bit_cast(frag_t, a.wfrag[((cb * NSTEP + s) * 3 + q) * 64 + lane]);
     unsigned char* wl_lds = smem_bx + Cfg::TILE_BYTES;            // [cout block][step][lane] 16 B
     for (int j = wave; j < 2 * NSTEP; j += 4)
         *reinterpret_cast<uint4*>(wl_lds + (j * 64 + lane) * 16) = a.wfrag[(((j / NSTEP) * NSTEP + j % NSTEP) * 3 + 2) * 64 + lane];
@@ -324,6 +361,7 @@ void conv_bxs2_kernel(BxS2Args a) {
         iy0 = tyi * 8; ix0 = txi * 32;
     };
     float v[NIT][8];
+    float amax = 0.f;                         // fx: the largest |x| converted (range guard)
     auto issue_loads = [&](int vid) __attribute__((always_inline)) {
         int b, iy0, ix0;
         tile_of(vid, b, iy0, ix0);
@@ -341,15 +379,24 @@ void conv_bxs2_kernel(BxS2Args a) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             uint4 h, m, l;
-            split3(v[i][0], v[i][1], h.x, m.x, l.x);
-            split3(v[i][2], v[i][3], h.y, m.y, l.y);
-            split3(v[i][4], v[i][5], h.z, m.z, l.z);
-            split3(v[i][6], v[i][7], h.w, m.w, l.w);
+            if constexpr (FX) {
+                fx_track(amax, v[i][0], v[i][1]); fx_track(amax, v[i][2], v[i][3]); fx_track(amax, v[i][4], v[i][5]); fx_track(amax, v[i][6], v[i][7]);
+                split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
+                split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
+            } else {
+                split3(v[i][0], v[i][1], h.x, m.x, l.x);
+                split3(v[i][2], v[i][3], h.y, m.y, l.y);
+                split3(v[i][4], v[i][5], h.z, m.z, l.z);
+                split3(v[i][6], v[i][7], h.w, m.w, l.w);
+            }
             if (it_rc[i] >= 0) {
                 unsigned char* p = smem_bx + it_lds[i];
                 *reinterpret_cast<uint4*>(p) = h;
-                *reinterpret_cast<uint4*>(p + SPLB) = m;
-                *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+                if constexpr (FX) *reinterpret_cast<uint4*>(p + SPLB) = l;
+                else {
+                    *reinterpret_cast<uint4*>(p + SPLB) = m;
+                    *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
+                }
             }
         }
     };
@@ -367,14 +414,14 @@ void conv_bxs2_kernel(BxS2Args a) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        struct Frag { bf16x8 x[3]; bf16x8 wl; };
+        struct Frag { frag_t x[NXS]; frag_t wl; };
         Frag f[2];
         auto load = [&](int s, Frag& o) {
             const int k0 = Cfg::koff(2 * s), dk = Cfg::koff(2 * s + 1) - k0;
             const unsigned char* p = smem_bx + (lane_off + half * dk) + k0;
-            o.wl = *reinterpret_cast<const bf16x8*>(wl_lane + s * 1024);
+            o.wl = *reinterpret_cast<const frag_t*>(wl_lane + s * 1024);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) o.x[q] = *reinterpret_cast<const bf16x8*>(p + q * SPLB);
+            for (int q = 0; q < NXS; ++q) o.x[q] = *reinterpret_cast<const frag_t*>(p + q * SPLB);
         };
         load(0, f[0]);
 #pragma unroll
@@ -382,16 +429,22 @@ void conv_bxs2_kernel(BxS2Args a) {
             const Frag& c = f[s & 1];
             if (s + 1 < NSTEP) load(s + 1, f[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c.wl, c.x[0], acc, 0, 0, 0);          // small terms first
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], c.x[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], c.x[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][1], c.x[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], c.x[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][0], c.x[0], acc, 0, 0, 0);
+            if constexpr (FX) {
+                acc = mfma(c.wl, c.x[0], acc);          // small terms first: (2^11 w - q0) xh, w xl, q0 xh
+                acc = mfma(wf[s][1], c.x[1], acc);
+                acc = mfma(wf[s][0], c.x[0], acc);
+            } else {
+                acc = mfma(c.wl, c.x[0], acc);          // small terms first
+                acc = mfma(wf[s][0], c.x[2], acc);
+                acc = mfma(wf[s][1], c.x[1], acc);
+                acc = mfma(wf[s][1], c.x[0], acc);
+                acc = mfma(wf[s][0], c.x[1], acc);
+                acc = mfma(wf[s][0], c.x[0], acc);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // idle slots before the epilogue's address arithmetic: it must not land in operand registers of the last MFMAs
-        asm volatile("s_nop 7\n\ts_nop 7");
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));      // (tied to the accumulator: see conv_bx_kernel)
         __builtin_amdgcn_sched_barrier(0);
         // ---- bias, ReLU, buffer stores: lane (pixel, half) holds couts 32 cb + (r & 3) + 8 (r >> 2) + 4 half ----------------------------
         {
@@ -406,7 +459,7 @@ void conv_bxs2_kernel(BxS2Args a) {
             const int voff = oy < a.Ho && ox < a.Wo ? (int)(((size_t)(4 * half) * HWo + (size_t)oy * a.Wo + ox) * 4) : (int)0x80000000;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float y = acc[r] + bs[r];
+                float y = FX ? fmaf(acc[r], FX_SCALE_INV, bs[r]) : acc[r] + bs[r];
                 if (a.relu) y = fmaxf(y, 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((cb * 32 + (r & 3) + 8 * (r >> 2)) * HWo * 4), 0);
             }
@@ -415,51 +468,57 @@ void conv_bxs2_kernel(BxS2Args a) {
         __syncthreads();
         vid = nvid;
     }
+    if constexpr (FX) fx_report(amax, a.status);
 }
 
-template <int CIN>
-static int run_bxs2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st) {
-    using Cfg = BxS2Cfg<CIN>;
+template <int CIN, bool FX>
+static int run_bxs2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status) {
+    using Cfg = BxS2Cfg<CIN, FX>;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * Ho * Wo * sizeof(float) >= 0x7fffffffu) return -1;
     BxS2Args a;
-    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu;
+    a.cold = g_debug_cold;
+    a.status = status;
+    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(FX ? c.w_fx : c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu;
     a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B;
     a.tiles_x = ceil_div(W, 32);
     a.tiles = a.tiles_x * ceil_div(H, 8);
     static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN>), Cfg::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN, FX>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();
     if (grid > total) grid = total;
-    conv_bxs2_kernel<CIN><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+    conv_bxs2_kernel<CIN, FX><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
     return 0;
 }
 
-template <int CIN, int COUT>
-static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
-    using Cfg = BxCfg<CIN, COUT>;
+template <int CIN, int COUT, bool FX>
+static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
+    using Cfg = BxCfg<CIN, COUT, FX>;
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     BxArgs a;
-    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    a.cold = g_debug_cold;
+    a.status = status;
+    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(FX ? c.w_fx : c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
     a.lag = 11;
     a.tiles_x = ceil_div(W, Cfg::TW);
     a.tiles = a.tiles_x * ceil_div(H, Cfg::TH);
     static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx_kernel<CIN, COUT>), Cfg::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx_kernel<CIN, COUT, FX>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();            // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
     if (grid > total) grid = total;
-    conv_bx_kernel<CIN, COUT><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+    conv_bx_kernel<CIN, COUT, FX><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
     return 0;
 }
 
 int bx_steps(int cin) { return (9 * (cin / 8) + 1) / 2; }
 
-int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
+int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, bool fx, int* status) {
     if (c.ks != 3 || !c.w_bx) return -1;
-    if (c.stride == 1 && c.cin == 24 && c.cout == 24) return run_bx<24, 24>(c, in, B, H, W, out, st, trace);
-    if (c.stride == 2 && c.cin == 24 && c.cout == 64) return run_bxs2<24>(c, in, B, H, W, out, st);
+    fx = fx && c.w_fx;      // (a layer with a weight too large for the fp16 pair keeps the bf16 form)
+    if (c.stride == 1 && c.cin == 24 && c.cout == 24) return fx ? run_bx<24, 24, true>(c, in, B, H, W, out, st, trace, status) : run_bx<24, 24, false>(c, in, B, H, W, out, st, trace, status);
+    if (c.stride == 2 && c.cin == 24 && c.cout == 64) return fx ? run_bxs2<24, true>(c, in, B, H, W, out, st, status) : run_bxs2<24, false>(c, in, B, H, W, out, st, status);
     return -1;
 }
 

@@ -36,6 +36,8 @@ struct Bx64Args {
     const uint4* wq2;
     const float* bias2;
     int relu2;
+    int cold;
+    int* status;               // fx: range guard (bx_split.hpp), may be NULL
 };
 
 namespace bx64 {
@@ -55,6 +57,7 @@ template <int CIN, int FUSE, bool FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64_kernel(Bx64Args a) {
     using namespace bx64;
+    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
     constexpr int PIXB = pixb<FX>(), NXS = FX ? 2 : 3;
     using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
     auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {
@@ -150,6 +153,7 @@ void conv_bx64_kernel(Bx64Args a) {
     // channel pairs of each pixel: 16 + 16 bits from two registers in one op.
     auto stage_write = [&]() __attribute__((always_inline)) {
         if (!has_item) return;
+        float amax = 0.f;                         // fx: the largest |x| of this item (range guard, bx_split.hpp; a kernel-long register cost the fused forms eight spills)
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             unsigned H[8], M[8], L[8];                     // {pixel 2 pp, pixel 2 pp + 1} of channel k
@@ -160,7 +164,7 @@ void conv_bx64_kernel(Bx64Args a) {
             for (int k = 0; k < 8; ++k) {
                 float x0 = v[k][2 * pp], x1 = v[k][2 * pp + 1];
                 if (a.W & 3) { x0 = z0 ? 0.f : x0; x1 = z1 ? 0.f : x1; }
-                if constexpr (FX) { split2_f16(x0, x1, H[k], L[k]); M[k] = 0; }
+                if constexpr (FX) { fx_track(amax, x0, x1); split2_f16(x0, x1, H[k], L[k]); M[k] = 0; }
                 else split3(x0, x1, H[k], M[k], L[k]);
             }
 #pragma unroll
@@ -184,6 +188,7 @@ void conv_bx64_kernel(Bx64Args a) {
                 }
             }
         }
+        if constexpr (FX) fx_report(amax, a.status);
     };
 
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
@@ -255,7 +260,8 @@ void conv_bx64_kernel(Bx64Args a) {
                         if (same || has_next) issue_loads(lt, same ? c + 1 : 0);
                     }
                 }
-                asm volatile("s_nop 7\n\ts_nop 7");
+                if constexpr (NPB == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));      // (tied to the accumulators: an asm
+                else asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]));                                                            // without operands is no anchor)
                 __builtin_amdgcn_sched_barrier(0);
                 BX_STAMP(4 + 4 * r)
             }
@@ -293,6 +299,7 @@ void conv_bx64_kernel(Bx64Args a) {
             // takes the register quads 8 (t & 1), 8 (t & 1) + 4 of cout block t >> 1 (the weights are packed in that K order, as for the
             // heads' chained layers).  Weight fragments come straight from L2 (24 KiB, the same for every wave; no LDS left for them),
             // one K step per load batch; the split fragments are double-buffered and kept alive as in head_bx_layer (MFMA operand hazard).
+            float amax = 0.f;
 #pragma unroll
             for (int j = 0; j < NPB; ++j)
 #pragma unroll
@@ -305,9 +312,11 @@ void conv_bx64_kernel(Bx64Args a) {
                         for (int e = 0; e < 4; ++e) {
                             float y = FX ? fmaf(acc[j][cb][4 * g4 + e], FX_SCALE_INV, bq[e]) : acc[j][cb][4 * g4 + e] + bq[e];
                             if (a.relu) y = fmaxf(y, 0.f);
+                            if constexpr (FX) amax = fmaxf(amax, fabsf(y));      // range guard of the 1x1's input (tracked here: inside the split it cost eight spilled registers)
                             acc[j][cb][4 * g4 + e] = y;
                         }
                     }
+            if constexpr (FX) fx_report(amax, a.status);
             // one pixel block at a time (its two 1x1 accumulators, stores included): both blocks at once do not fit into 256 registers next to
             // the 3x3's results and the next tile's prefetched input
             const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
@@ -366,7 +375,7 @@ void conv_bx64_kernel(Bx64Args a) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");      // idle slots before the VALU code of the stores
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc2[0]), "+v"(acc2[1]));      // idle slots before the VALU code of the stores
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (FUSE == 1) {
                     const int ox = cur.x0 + (l31 & 15);
@@ -423,9 +432,11 @@ void conv_bx64_kernel(Bx64Args a) {
 }
 
 template <int CIN, int FUSE, bool FX>
-static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
+static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     Bx64Args a;
+    a.cold = g_debug_cold;
+    a.status = status;
     a.in = in; a.wq = FX ? c.w_fx : c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
     a.wq2 = c2 ? reinterpret_cast<const uint4*>(FX ? c2->w_fx : c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     a.ncols = ceil_div(W, 16); a.nhr = ceil_div(H, 8); a.upi = a.ncols * a.nhr;
@@ -438,15 +449,15 @@ static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int
     return 0;
 }
 
-int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, bool fx) {
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, bool fx, int* status) {
     if (c.ks != 3 || c.stride != 1 || !c.w_bx || c.cout != 64 || c.cin != 64) return -1;
     if (c2 && (c2->ks != 1 || c2->cin != 64 || c2->cout != 64 || !c2->w_bx)) return -1;
     if (fx && c.w_fx && (!c2 || c2->w_fx)) {      // the fp16-pair arithmetic: three MFMAs per product instead of six
-        if (!c2) return nhwc ? -1 : run_bx64<64, 0, true>(c, nullptr, in, B, H, W, out, st, trace);
-        return nhwc ? run_bx64<64, 2, true>(c, c2, in, B, H, W, out, st, trace) : run_bx64<64, 1, true>(c, c2, in, B, H, W, out, st, trace);
+        if (!c2) return nhwc ? -1 : run_bx64<64, 0, true>(c, nullptr, in, B, H, W, out, st, trace, status);
+        return nhwc ? run_bx64<64, 2, true>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, true>(c, c2, in, B, H, W, out, st, trace, status);
     }
-    if (!c2) return nhwc ? -1 : run_bx64<64, 0, false>(c, nullptr, in, B, H, W, out, st, trace);
-    return nhwc ? run_bx64<64, 2, false>(c, c2, in, B, H, W, out, st, trace) : run_bx64<64, 1, false>(c, c2, in, B, H, W, out, st, trace);
+    if (!c2) return nhwc ? -1 : run_bx64<64, 0, false>(c, nullptr, in, B, H, W, out, st, trace, status);
+    return nhwc ? run_bx64<64, 2, false>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, false>(c, c2, in, B, H, W, out, st, trace, status);
 }
 
 }  // namespace xfh

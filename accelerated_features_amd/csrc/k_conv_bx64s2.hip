@@ -35,6 +35,7 @@ struct Bx64S2Args {
     int relu, H, W, Ho, Wo, B;
     int nrows, upi;            // 8-row tiles per strip, units per image and cout half
     long long* trace;          // debug: s_memtime stamps of the workgroup's second unit (NULL in production)
+    int cold;
 };
 
 namespace bx64s2 {
@@ -53,6 +54,7 @@ static_assert(NITEM <= 512 && RING_OFF % 64 == 0 && LDS_BYTES <= 160 * 1024, "on
 template <int NCO, bool W4>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64s2_kernel(Bx64S2Args a) {
+    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
     using namespace bx64s2;
     constexpr int CIN = 64, NCH = CIN / 16, NROW = NCH * 3, COUT = 64 * NCO;
     static_assert(NROW % 2 == 0 && NCH % 2 == 0, "ring slot, X buffer and register set of a chunk must not depend on the unit");
@@ -352,6 +354,7 @@ static int run_bx64s2(const ConvW& c, const float* in, int B, int H, int W, floa
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if ((size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     Bx64S2Args a;
+    a.cold = g_debug_cold;
     a.in = in; a.wq = c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B; a.trace = trace;
     a.nrows = ceil_div(Ho, 8); a.upi = ceil_div(Wo, 16) * a.nrows;
     static unsigned attr_done = 0;

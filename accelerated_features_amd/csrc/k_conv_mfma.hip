@@ -54,10 +54,12 @@ struct ConvArgs {
     int relu, relu2;
     long long* trace;       // debug: per-workgroup s_memtime stamps (NULL in production)
     ConvGeom g;
+    int cold;
 };
 
 template <int CIN, int COUT, int KS, int STRIDE, int CK, int NSEG, bool NHWC, int COUT2, int NBO = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
     constexpr int COUT_PAD = (COUT + 31) / 32 * 32;
     constexpr int MB = COUT_PAD / 32;
     constexpr int NB = NBO > 0 ? NBO : (MB == 1 ? 4 : (MB == 2 ? 2 : 1));
@@ -364,6 +366,7 @@ static int run(const ConvW& c, const ConvW* c2, const float* zeros, const float*
     constexpr int WCH = CK * KS * KS * COUT_PAD;
     constexpr int COUT2_PAD = (COUT2 + 31) / 32 * 32;
     ConvArgs a;
+    a.cold = g_debug_cold;
     ConvGeom& g = a.g;
     g.Hin = Hin; g.Win = Win;
     g.Hout = (Hin + 2 * (KS / 2) - KS) / STRIDE + 1;

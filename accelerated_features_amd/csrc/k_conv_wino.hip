@@ -53,6 +53,7 @@ struct WinoArgs {
     int H, W, B;              // input == output size (stride 1, pad 1)
     int tiles_x, tiles;       // workgroups per image
     long long* trace;         // debug: per-workgroup s_memtime stamps (NULL in production)
+    int cold;
 };
 
 // smallest padded half-width >= ttw+1 for which the 32 lanes of a half-wave (tiles t = 0..31, tile
@@ -93,6 +94,7 @@ struct WinoCfg {
 template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2, bool NHWC>
 __global__ __launch_bounds__(256 * (CB / NCBW) * (TBG / NTBW)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino_kernel(WinoArgs a) {
+    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
     using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
     constexpr int COUT2_PAD = Cfg::COUT2_PAD, MB2 = COUT2_PAD / 32;
     static_assert(COUT2 == 0 || (COUT == 32 * CB && NCBW == 2 && MB2 == 2), "fused 1x1: full cout blocks, two per wave, 64 outputs");
@@ -461,6 +463,7 @@ static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float*
     using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
     if ((size_t)c.cin * H * W * sizeof(float) >= 0x7fffffffu) return -1;     // buffer-resource range
     WinoArgs a;
+    a.cold = g_debug_cold;
     a.in = in; a.wu = c.w_wino; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
     a.wk2 = c2 ? c2->w_kcp : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     if ((COUT2 > 0) != (c2 != nullptr)) return -1;

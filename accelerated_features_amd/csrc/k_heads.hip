@@ -38,6 +38,7 @@ struct HeadArgs {
     float* logits;           // KP only, optional: (B*hc*wc, 65)
     float* inv;              // REL only, optional: 1 / max(||feats[cell,:]||, 1e-12)  (F.normalize(M1, dim=1), xfeat.py:70)
     int H, W, hc, wc, ncell, ntiles;
+    int cold;
 };
 
 // one chained 64 -> 32*MBO layer: out = bias + W^T relu(in)   (in/out in D[feature][cell] layout)
@@ -75,8 +76,14 @@ __device__ inline void chain_layer(const float* __restrict__ Wl, int npad, const
     }
 }
 
-template <bool KP>
+// SHIFT (debug, tools/head_soak.py): the kernel body moved by SHIFT x 4 bytes against the 64-byte instruction-cache lines
+template <int N> __device__ inline void code_shift() {
+    if constexpr (N > 0) { asm volatile("s_nop 0"); code_shift<N - 1>(); }
+}
+template <bool KP, int SHIFT = 0>
 __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
+    code_shift<SHIFT>();
+    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
     constexpr int NL = KP ? 4 : 3;
     constexpr int W_FLOATS = KP ? (3 * 64 * 64 + 64 * 96) : (2 * 64 * 64 + 64);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -262,6 +269,7 @@ struct HeadBxArgs {
     float* inv;              // REL only, optional: 1 / max(||feats[cell,:]||, 1e-12)
     int H, W, hc, wc, ncell, ntiles;
     long long* trace;        // debug: s_memtime stamps of wave 0's second tile, 16 per workgroup
+    int cold;
     float* dbg;              // debug (VAR 10): [layer 0..2][cell][64] outputs of the first three key-point layers
 };
 
@@ -287,7 +295,7 @@ __device__ inline void hb_split8(const float (&y)[8], bf16x8& h, bf16x8& m, bf16
 
 // one K = 64 layer: out[mb] = bias + W x, x given per K step by `xs(t, y[8])`; weights of the layer at wl (LDS, operand order)
 template <int MBO, int VAR, typename XS, int MBS = MBO, int MB0 = 0>      // (MBS blocks per K step in the weight layout, this call computes blocks MB0 .. MB0 + MBO - 1)
-__device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_lds, XS xs, f32x16 (&out)[MBO], int lane, int half, uint4* sc = nullptr) {
+__device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_lds, XS xs, f32x16 (&out)[MBO], int lane, int half, uint4* sc = nullptr, uint4* fdump = nullptr, size_t fstride = 0) {
 #pragma unroll
     for (int mb = 0; mb < MBO; ++mb)
 #pragma unroll
@@ -316,6 +324,10 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
         float y[8];
         xs(0, y);
         hb_split8(y, xf[0][0], xf[0][1], xf[0][2]);
+        if (VAR == 26 && fdump) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fdump[(size_t)i * fstride] = __builtin_bit_cast(uint4, xf[0][i]);
+        }
         if (VAR == 4) {
             uint4* q = sc + lane;
 #pragma unroll
@@ -329,7 +341,10 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
     for (int t = 0; t < 4; ++t) {
         if (t + 1 < 4) ldw(t + 1, w[(t + 1) & 1]);
         asm volatile("" ::: "memory");
-        if (VAR == 3 || VAR == 8) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(xf[t & 1][0]), "+v"(xf[t & 1][1]), "+v"(xf[t & 1][2])); __builtin_amdgcn_sched_barrier(0); }
+        if (VAR == 3 || VAR == 8 || VAR == 20 || VAR == 22) { asm volatile("s_nop 7\n\ts_nop 7" : "+v"(xf[t & 1][0]), "+v"(xf[t & 1][1]), "+v"(xf[t & 1][2])); __builtin_amdgcn_sched_barrier(0); }
+        if (VAR == 23) { asm volatile("" : "+v"(xf[t & 1][0]), "+v"(xf[t & 1][1]), "+v"(xf[t & 1][2])); __builtin_amdgcn_sched_barrier(0); }              // the operands pinned, no idle slot
+        if (VAR == 24) { asm volatile("s_nop 0" : "+v"(xf[t & 1][0]), "+v"(xf[t & 1][1]), "+v"(xf[t & 1][2])); __builtin_amdgcn_sched_barrier(0); }       // one idle slot
+        if (VAR == 25) { asm volatile("s_nop 3" : "+v"(xf[t & 1][0]), "+v"(xf[t & 1][1]), "+v"(xf[t & 1][2])); __builtin_amdgcn_sched_barrier(0); }       // four
         const bf16x8 xh = xf[t & 1][0], xm = xf[t & 1][1], xl = xf[t & 1][2];
         __builtin_amdgcn_sched_barrier(0);      // the MFMAs of a step stay together: left free, hipcc floats the NEXT steps' splits in between them
         // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
@@ -337,11 +352,15 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
         HB_MM(2, xh) HB_MM(0, xl) HB_MM(1, xm) HB_MM(1, xh) HB_MM(0, xm) HB_MM(0, xh)
 #undef HB_MM
         __builtin_amdgcn_sched_barrier(0);
-        if (VAR == 3 || VAR == 8) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
+        if (VAR == 3 || VAR == 8 || VAR == 21 || VAR == 22) { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
         if (t + 1 < 4) {
             float y[8];
             xs(t + 1, y);
             hb_split8(y, xf[(t + 1) & 1][0], xf[(t + 1) & 1][1], xf[(t + 1) & 1][2]);
+            if (VAR == 26 && fdump) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) fdump[(size_t)(3 * (t + 1) + i) * fstride] = __builtin_bit_cast(uint4, xf[(t + 1) & 1][i]);
+            }
             if (VAR == 4) {      // experiment: the fragments reach their MFMA registers as LDS read results instead of vector-ALU results
                 uint4* q = sc + ((t + 1) & 1) * 192 + lane;
 #pragma unroll
@@ -374,8 +393,9 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool KP, int VAR = 0>      // VAR != 0: experiment builds of the soak tool (xfh_debug_head_soak), never launched by the product path
+template <bool KP, int VAR = 0, int SHIFT = 0>      // VAR != 0: experiment builds of the soak tool (xfh_debug_head_soak), never launched by the product path
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_bx_kernel(HeadBxArgs a) {
+    code_shift<SHIFT>();
     constexpr int NB = KP ? 288 : 128;                                 // bias floats
     constexpr int W_BYTES = KP ? (3 * 2 + 3) * 4 * 3 * 1024 : 2 * 2 * 4 * 3 * 1024;      // cout blocks x K steps x splits x 1 KiB
     constexpr int L_BYTES = 2 * 4 * 3 * 1024;                         // a 64 -> 64 layer
@@ -415,9 +435,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
+    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start)
     int tile = blockIdx.x;
+    if (VAR == 18 || (VAR >= 20 && VAR <= 29)) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // experiment: every workgroup starts on a cold instruction cache (no foreign kernel needed to evict the code?)
+    if constexpr (VAR == 16) {
+        // experiment: is the data of a load there when `s_waitcnt vmcnt(0)` has passed?  The first tile's loads as asm with the destination registers
+        // pre-filled with a sentinel no gray value equals; after the barrier every lane counts the sentinels it still holds (a.dbg: [0] lanes, [1] waves,
+        // then records {workgroup, wave, lane, register}).
+        const int g = min(tile * HD_CELLS + wave * 32 + l31, a.ncell - 1);
+        const int b = g / hw, rem = g - b * hw;
+        const int ci = rem / a.wc, cj = rem - ci * a.wc;
+        const float* p = a.src + (size_t)b * a.H * a.W + (size_t)(8 * ci + half) * a.W + 8 * cj;
+        nalpha = a.coef[2 * b]; nbeta = a.coef[2 * b + 1];
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        f32x4v u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float s0, s1, s2, s3;
+            asm volatile("v_mov_b32 %0, 0x4640e400\n\tv_mov_b32 %1, 0x4640e400\n\tv_mov_b32 %2, 0x4640e400\n\tv_mov_b32 %3, 0x4640e400" : "=v"(s0), "=v"(s1), "=v"(s2), "=v"(s3));
+            u[k] = f32x4v{s0, s1, s2, s3};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float* q = p + (k >> 1) * 2 * (size_t)a.W + 4 * (k & 1);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(u[k]) : "v"(q) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]) :: "memory");
+        __syncthreads();
+        unsigned bad = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float e[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (__float_as_uint(e[c]) == 0x4640e400u) bad |= 1u << (4 * k + c);
+                xin[k >> 1][4 * (k & 1) + c] = e[c];
+            }
+        }
+        if (bad && a.dbg) {
+            unsigned* d = reinterpret_cast<unsigned*>(a.dbg);
+            const unsigned n = atomicAdd(d, 1u);
+            if (n < 4096) { d[4 + 4 * n] = blockIdx.x; d[5 + 4 * n] = (unsigned)wave; d[6 + 4 * n] = (unsigned)lane; d[7 + 4 * n] = bad; }
+        }
+    } else {
     if (tile < a.ntiles) issue_x(tile);
     lds_dma_barrier();                                                // the weights (and biases) have landed; no barrier from here on
+    if (VAR == 14 && tile < a.ntiles) issue_x(tile);                  // experiment: the first tile's input loaded AGAIN, after the barrier (same values)
+    if (VAR == 15) asm volatile("s_sleep 32");                        // experiment: ~2 k idle cycles between the barrier and the first use of the input
+    }
     if (VAR == 7 && wave >= 4) { asm volatile("s_sleep 127\n\ts_sleep 127\n\ts_sleep 127\n\ts_sleep 127"); }      // the second wave of every SIMD starts ~32 k cycles late
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
     int tix = 0;
@@ -425,9 +490,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     bool dry = VAR == 13;      // experiment: the first tile computed twice, the first time without stores (instruction cache warm, waves out of the start's lock-step)
     for (; tile < a.ntiles; tile += (VAR == 13 && dry) ? 0 : (int)gridDim.x, ++tix, dry = (VAR == 13 && dry && tix == 1) ? false : dry) {
         const int gcell = (VAR == 13 && dry) ? a.ncell : tile * HD_CELLS + wave * 32 + l31;          // this lane's cell (dry pass: nothing is stored)
-        if (VAR == 1 || (VAR >= 5 && VAR <= 10)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (one instruction: 50 x the event rate of VAR 0 in the two-stream soak)
+        if (VAR == 1 || (VAR >= 5 && VAR <= 10) || VAR == 17) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (one instruction: 50 x the event rate of VAR 0 in the two-stream soak)
         if (VAR == 5) asm volatile("s_nop 0");                                                    // code alignment / one issue slot more
-        if (VAR == 6) __syncthreads();                                                            // the waves of a workgroup in lock-step at every tile
+        if (VAR == 6 || VAR == 17) __syncthreads();                                               // the waves of a workgroup in lock-step at every tile
+        if (VAR == 17 && tix == 2) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");              // experiment: the third tile starts on a cold instruction cache too
         HB_STAMP(0)
         f32x16 accA[2], accB[2];
         float nrm2 = 0.f;
@@ -439,7 +505,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     y[i] = KP ? fmaf(xin[t][i], al, be) : xin[t][i];
                     if (!KP) nrm2 = fmaf(y[i], y[i], nrm2);
                 }
-            }, accA, lane, half, sc);
+            }, accA, lane, half, sc, (VAR == 26 && a.dbg && tix == 0) ? reinterpret_cast<uint4*>(a.dbg) + (size_t)blockIdx.x * 512 + tid : nullptr, (size_t)gridDim.x * 512);
+            if (VAR == 26 && a.dbg && tix == 0) {      // ... and the layer's output, [12 fragments][threads] uint4 then [32 registers][threads] float
+                float* o = a.dbg + (size_t)12 * gridDim.x * 512 * 4 + (size_t)blockIdx.x * 512 + tid;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(size_t)(m * 16 + r) * gridDim.x * 512] = accA[m][r];
+            }
         }
         if (!KP && a.inv) {
             nrm2 += XH(nrm2);                                      // the other 32 channels sit in the other half-wave
@@ -541,6 +614,7 @@ long long* g_head_trace = nullptr;        // debug (xfh_debug_trace): stamps of 
 void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, bool f32_kernels) {
     if (!f32_kernels && nw.head_bx[0]) {
         HeadBxArgs h{};
+        h.cold = g_debug_cold;
         h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
         h.H = H; h.W = W; h.hc = H / 8; h.wc = W / 8;
         h.ncell = B * h.hc * h.wc;
@@ -553,6 +627,7 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
         return;
     }
     HeadArgs a{};
+    a.cold = g_debug_cold;
     a.src = gray; a.coef = coef; a.zeros = nw.zeros; a.out = heat; a.logits = logits;
     a.H = H; a.W = W; a.hc = H / 8; a.wc = W / 8;
     a.ncell = B * a.hc * a.wc;
@@ -568,6 +643,7 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
 void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, bool f32_kernels) {
     if (!f32_kernels && nw.head_bx[1]) {
         HeadBxArgs h{};
+        h.cold = g_debug_cold;
         h.src = feats; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[1]); h.bias = nw.head_bx_bias[1]; h.out = reliab; h.inv = invnorm;
         h.w_last = nw.conv[L_HEAT_2].w_oihw; h.b_last = nw.head_rel_b_last;
         h.hc = 1; h.wc = 1; h.H = 8; h.W = 8;
@@ -580,6 +656,7 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
         return;
     }
     HeadArgs a{};
+    a.cold = g_debug_cold;
     a.src = feats; a.zeros = nw.zeros; a.out = reliab; a.logits = nullptr; a.inv = invnorm;
     a.hc = 1; a.wc = 1; a.H = 8; a.W = 8;
     a.ncell = ncell;
@@ -613,24 +690,48 @@ __global__ __launch_bounds__(256) void soak_compare_kernel(const uint4* __restri
     }
 }
 
-template <int VAR>
+template <int VAR, int SHIFT = 0>
 static void launch_kp_head_var(const HeadBxArgs& h, hipStream_t st) {
     const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float) + (VAR == 4 ? 8 * 6144 : 0);
     static unsigned attr = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, VAR>), 160 * 1024, attr);
-    head_bx_kernel<true, VAR><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, VAR, SHIFT>), 160 * 1024, attr);
+    head_bx_kernel<true, VAR, SHIFT><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+}
+template <int SHIFT>
+static void launch_kp_head_f32_shift(const HeadArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<true, SHIFT>), 160 * 1024, attr);
+    head_fused_kernel<true, SHIFT><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
+}
+template <int S>
+static bool launch_shift(int shift, const HeadBxArgs& h, const HeadArgs& a, bool f32, hipStream_t st) {      // shift 0 .. 15 -> the instantiation
+    if (shift == S) { if (f32) launch_kp_head_f32_shift<S>(a, st); else launch_kp_head_var<0, S>(h, st); return true; }
+    if constexpr (S < 15) return launch_shift<S + 1>(shift, h, a, f32, st);
+    return false;
 }
 
 int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, const float* heat_ref, float* logits, const float* logits_ref,
               int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, hipStream_t st, float* dbg, const float* dbg_ref, unsigned* rep_dbg) {
     HeadBxArgs h{};
+    h.cold = g_debug_cold;
     h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
     h.H = H; h.W = W; h.hc = H / 8; h.wc = W / 8;
     h.ncell = B * h.hc * h.wc;
     h.ntiles = ceil_div(h.ncell, HD_CELLS);
     h.dbg = dbg;
-    const size_t n4h = (size_t)B * H * W / 4, n4l = (size_t)h.ncell * 65 / 4, n4d = (size_t)3 * h.ncell * 64 / 4;
+    const size_t n4h = (size_t)B * H * W / 4, n4l = (size_t)h.ncell * 65 / 4, n4d = variant == 26 ? (size_t)(12 * 4 + 32) * 256 * 512 / 4 : (size_t)3 * h.ncell * 64 / 4;
+    HeadArgs fa{};      // the f32-MFMA kernel's arguments (variants 2000 + shift)
+    fa.src = gray; fa.coef = coef; fa.zeros = nw.zeros; fa.out = heat; fa.logits = logits; fa.H = H; fa.W = W; fa.hc = H / 8; fa.wc = W / 8; fa.ncell = h.ncell; fa.ntiles = h.ntiles;
+    {
+        const int L[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3};
+        for (int i = 0; i < 4; ++i) { fa.w[i] = nw.conv[L[i]].w_kcp; fa.bias[i] = nw.conv[L[i]].bias; }
+    }
+    fa.cold = h.cold = (variant >= 1000) ? 1 : g_debug_cold;      // 1000 + shift: the split-bf16 kernel, 2000 + shift: the f32 kernel, both cold-started, code moved by 4 x shift bytes
     for (int it = 0; it < iters; ++it) {
+        if (variant >= 1000) {
+            if (!launch_shift<0>(variant % 1000, h, fa, variant >= 2000, st)) return -1;
+        } else
         switch (variant) {
             case 0: launch_kp_head_var<0>(h, st); break;
             case 1: launch_kp_head_var<1>(h, st); break;
@@ -644,6 +745,18 @@ int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B,
             case 9: launch_kp_head_var<9>(h, st); break;
             case 10: launch_kp_head_var<10>(h, st); break;
             case 11: launch_kp_head_var<11>(h, st); break;
+            case 14: launch_kp_head_var<14>(h, st); break;
+            case 15: launch_kp_head_var<15>(h, st); break;
+            case 16: launch_kp_head_var<16>(h, st); break;
+            case 17: launch_kp_head_var<17>(h, st); break;
+            case 18: launch_kp_head_var<18>(h, st); break;
+            case 20: launch_kp_head_var<20>(h, st); break;
+            case 21: launch_kp_head_var<21>(h, st); break;
+            case 22: launch_kp_head_var<22>(h, st); break;
+            case 23: launch_kp_head_var<23>(h, st); break;
+            case 24: launch_kp_head_var<24>(h, st); break;
+            case 25: launch_kp_head_var<25>(h, st); break;
+            case 26: launch_kp_head_var<26>(h, st); break;
             case 13: launch_kp_head_var<13>(h, st); break;
             case 100: launch_kp_head(nw, gray, coef, B, H, W, heat, logits, st, true); break;
             default: return -1;

@@ -44,6 +44,7 @@ struct NetWeights {
 };
 
 struct Profiler;   // api.hip
+extern int g_debug_cold;      // debug (xfh_debug_cold_start): MFMA kernels invalidate the instruction cache when they start (api.hip)
 
 // Per-handle variant switches (xfh_set_option): which of several equivalent kernels a call uses.  They exist for A/B measurements and for the
 // parity tests that pin one variant against another; the defaults are the shipped path.  No process-wide state: a handle carries its own copy.
@@ -52,8 +53,11 @@ struct Options {
     int wino = 2;           // 0: 3x3/s1 layers never use Winograd; 1: only unfused layers; 2: fused 3x3 + 1x1 pairs too
     int bx = 21;            // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0,
                             // 16 = the stride-2 64 -> 64 | 128 layers (block4.0, block5.0)
-    int heads_f32 = 0;      // 1: heads on the f32-MFMA kernels
-    int fx = 0;             // split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six): bit 1 = the 64 -> 64 layers on large maps (conv_bx64_kernel)
+    int heads_f32 = 1;      // 1 (default since round 4): both heads on the f32-MFMA kernels; 0: the split-bf16 kernels (head_bx_kernel) -- faster (-106 us per 64-frame step), but
+                            // head_bx_kernel<true> delivers a wrong 16-cell block once in 10^3..10^5 launches when a workgroup's first tile runs on instruction-cache
+                            // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
+    int fx = 3;             // split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
+                            // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel); 0 = the bf16 three-way split everywhere
     int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected)
 };
 
@@ -87,9 +91,9 @@ int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B,
 int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, const float* in, int B, int Hin, int Win,
                      float* out, bool nhwc_out, hipStream_t st, long long* trace = nullptr);
 // 3x3/s1 on bf16 MFMAs with three-way split operands (fp32-equivalent; k_conv_bx.hip); -1 if no instantiation
-int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
+int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr, bool fx = false, int* status = nullptr);
 int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr,
-                     const ConvW* fused1x1 = nullptr, bool nhwc = false, bool fx = false);
+                     const ConvW* fused1x1 = nullptr, bool nhwc = false, bool fx = false, int* status = nullptr);
 // 3x3/s2, 64 -> 64 | 128 (block4.0, block5.0; k_conv_bx64s2.hip); -1 if no instantiation
 int launch_conv_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
 int bx_steps(int cin);      // K steps of 16 = 2 groups of 8 channels of one tap

@@ -6,13 +6,15 @@ bit for bit, the ones XFeat._detect_device / match_pairs_device return for the s
 
 Two modes:
   * default (concurrent=False): all lanes queue on ONE HIP stream.  The kernels run exactly as in the synchronous path, one after the other; what is gained
-    is the host round trip of the read-back (the GPU never waits for Python): 37.6 k -> 38.2 k frames/s on VGA batches of 64 (profiles/r03_i_bench.json).
+    is the host round trip of the read-back (the GPU never waits for Python).
   * concurrent=True: a HIP stream per lane -- the hardware schedules the convolutions of one batch into the latency-bound tail of the other (NMS
-    compaction, top-k, the matcher's refine scan and finalize: ~0.12 ms of a 1.7 ms step).  With two streams on the chip the split-bf16 head kernel delivered
-    one wrong 16-cell block of the heat map in ~10^4 steps (3 in 60 000 concurrent backbone steps of tools/lanes_backbone_soak.py, always that kernel; 0 in
-    24 000 single-stream steps; 0 in 24 000 concurrent steps with the f32 heads): a wave of another kernel on the SIMD changes the timing the kernel's
-    bf16-MFMA operand-hazard fence was measured for.  Concurrent lanes therefore run both heads on the f32-MFMA kernels (option heads_f32 = 1,
-    set here): 38.4 k frames/s in the same run (+ 5 % more with the bf16 heads, which are not shipped next to another stream).  Opt-in until the hazard is understood.
+    compaction, top-k, the matcher's refine scan and finalize: ~0.12 ms of a 1.7 ms step).
+  Either way the lanes run the library's default kernel mix.  (Round 3 found the split-bf16 key-point head delivering a wrong 16-cell block once in ~10^4
+  steps with two streams on the chip; round 4 traced it to instruction-cache misses in a workgroup's first tile -- another stream's kernels evict the code --
+  and made the f32-MFMA heads the default of every handle: DESIGN 9.0.  Nothing here depends on it any more.)
+
+  `x` must stay untouched until its ticket is retired: the lane's kernels read it asynchronously (and result() reads it again if a plateau image overflowed the
+  NMS candidate list).  A caller that refills one staging buffer per frame needs as many buffers as lanes.
 
     fs = FrameStream(weights, top_k=4096, lanes=2)
     t0 = fs.submit(batch0); t1 = fs.submit(batch1)        # returns as soon as the work is queued
@@ -30,7 +32,7 @@ class _Lane:
         self.stream = stream
         self.event = torch.cuda.Event()
         self.ticket = None          # ticket of the batch in flight / not yet retired
-        self.dev = None             # (3, B) int32: n_valid, n_candidates, n_matches (first B/2)
+        self.dev = None             # (4, B) int32: n_valid, n_candidates, n_matches (first B/2), [3, 0] = the handle's status word for this batch
         self.host = None            # its pinned host mirror
         self.out = None
 
@@ -38,7 +40,7 @@ class _Lane:
 class FrameStream:
     def __init__(self, weights=None, top_k=4096, detection_threshold=0.05, lanes=2, min_cossim=-1, xfeats=None, concurrent=False):
         """`xfeats`: ready XFeat instances to use as lanes (one per lane, each with its own handle) instead of building them from `weights`.
-        concurrent: a HIP stream per lane (see the module docstring: sets option heads_f32 = 1 on the lanes); default: one stream for all lanes."""
+        concurrent: a HIP stream per lane; default: one stream for all lanes."""
         if xfeats is None:
             kw = {} if weights is None else {"weights": weights}
             xfeats = [XFeat(top_k=top_k, detection_threshold=detection_threshold, **kw) for _ in range(int(lanes))]
@@ -49,9 +51,6 @@ class FrameStream:
         self.top_k, self.thr, self.min_cossim = int(top_k), float(detection_threshold), min_cossim
         xfeats[0]._require_gpu()          # no GPU / no library: XFeatHipError, never a fallback
         self.concurrent = bool(concurrent) and len(xfeats) > 1
-        if self.concurrent:
-            for x in xfeats:
-                x.set_option("heads_f32", 1)          # see the module docstring: the split-bf16 heads are not run next to another stream's kernels
         shared = None if self.concurrent else torch.cuda.Stream()
         self._lanes = [_Lane(x, torch.cuda.Stream() if self.concurrent else shared) for x in xfeats]
         self._next_ticket = 0
@@ -68,7 +67,8 @@ class FrameStream:
     @torch.inference_mode()
     def submit(self, x):
         """Queue detectAndCompute (top_k, detection_threshold) + the MNN match of the frame pairs (2i, 2i+1) of batch x (B even) on the next lane.
-        Returns a ticket at once; at most `lanes` tickets may be outstanding (retire with result())."""
+        Returns a ticket at once; at most `lanes` tickets may be outstanding (retire with result()).  x is read asynchronously: do not modify it before
+        the ticket is retired."""
         ln = self._lanes[self._next_ticket % len(self._lanes)]
         if ln.ticket is not None:
             raise RuntimeError(f"FrameStream: all {len(self._lanes)} lanes are busy; retire ticket {ln.ticket} first (result())")
@@ -78,8 +78,10 @@ class FrameStream:
         ln.stream.wait_stream(torch.cuda.current_stream())          # x may have been produced on the caller's stream
         with torch.cuda.stream(ln.stream):
             if ln.dev is None or ln.dev.shape[1] != B:
-                ln.dev = torch.zeros((3, B), dtype=torch.int32, device=x.device)
-                ln.host = torch.empty((3, B), dtype=torch.int32).pin_memory()
+                ln.dev = torch.zeros((4, B), dtype=torch.int32, device=x.device)
+                ln.host = torch.empty((4, B), dtype=torch.int32).pin_memory()
+            ln.xf.net.set_status_target(ln.dev[3])                  # the backbone's status bits travel with the counts (no extra read-back; re-registered per
+            ln.dev[3, :1].zero_()                                   # call: a handle re-created in between -- load_state_dict -- starts on the model's own word)
             kp, sc, de, nv, nc, cap, hw, d16 = ln.xf._detect_device(x, self.top_k, self.thr, want_f16=True, counts_out=ln.dev[:2])
             i0, i1, nm = ln.xf.match_pairs_device(de, nv, self.min_cossim, d16, n_out=ln.dev[2, :B // 2])
             ln.host.copy_(ln.dev, non_blocking=True)                # the one read-back (ragged results), asynchronous
@@ -103,9 +105,11 @@ class FrameStream:
         cur.wait_event(ln.event)
         kp, sc, de, i0, i1, cap, B, hw, x = ln.out
         ncmax = int(ln.host[1].max())
-        if ncmax > cap:                                             # a plateau image overflowed the NMS candidate list: exact re-run with room (as detectAndCompute)
-            cap = min(hw, max(ncmax, 2 * cap))
+        redo = ln.xf.net.fx_range_exceeded(status=int(ln.host[3, 0]))      # fp16-pair arithmetic out of range (never on images): the lane's model is on the bf16 split now
+        if ncmax > cap or redo:                                     # a plateau image overflowed the NMS candidate list: exact re-run with room (as detectAndCompute)
+            cap = min(hw, max(ncmax, 2 * cap)) if ncmax > cap else cap
             with torch.cuda.stream(ln.stream), torch.inference_mode():
+                ln.dev[3, :1].zero_()
                 kp, sc, de, nv, nc, cap, hw, d16 = ln.xf._detect_device(x, self.top_k, self.thr, cap=cap, want_f16=True, counts_out=ln.dev[:2])
                 i0, i1, nm = ln.xf.match_pairs_device(de, nv, self.min_cossim, d16, n_out=ln.dev[2, :B // 2])
                 ln.host.copy_(ln.dev, non_blocking=True)

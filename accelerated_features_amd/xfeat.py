@@ -18,6 +18,8 @@ import torch.nn as nn
 from . import _lib
 from .spec import CONVS, FINE
 
+DEFAULT_FX = 3          # the library's default of option "fx" (csrc/kernels.hpp: Options; tests/test_gpu_parity.py checks the two agree)
+
 __all__ = ["XFeat", "XFeatModel"]
 
 
@@ -187,6 +189,9 @@ class XFeatModel(nn.Module):
             lib.xfh_destroy(h)
             raise
         self._handle, self._handle_device = h, dev
+        self._status = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", dev))      # the handle's status word (include/xfeat_hip.h: xfh_set_status_buffer)
+        self._status_target = self._status
+        _lib.check(lib.xfh_set_status_buffer(h, C.c_void_p(self._status.data_ptr())), "xfh_set_status_buffer")
         return h
 
     OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 1), "block1": (0, 5), "fx": (0, 15)}      # include/xfeat_hip.h: xfh_set_option
@@ -206,6 +211,37 @@ class XFeatModel(nn.Module):
         if self._handle is not None:
             _lib.check(_lib.load().xfh_set_option(self._handle, key.encode(), int(value)), f"xfh_set_option({key})")
         self._options[key] = int(value)
+
+    def set_status_target(self, t=None):
+        """The device int32 the handle's kernels report into (bit 0: an activation outside the range of the fp16-pair arithmetic, option `fx`): `t` (a caller's
+        tensor, e.g. a slot of the buffer it reads back anyway -- FrameStream) or None for the model's own word.  The caller zeroes / reads its own target."""
+        h = self.handle()
+        self._status_target = self._status if t is None else t
+        assert self._status_target.dtype == torch.int32 and self._status_target.is_cuda
+        _lib.check(_lib.load().xfh_set_status_buffer(h, C.c_void_p(self._status_target.data_ptr())), "xfh_set_status_buffer")
+
+    def take_status(self):
+        """Read and clear the model's own status word (one 4-byte read-back; 0 without a handle)."""
+        if self._handle is None or getattr(self, "_status_target", None) is None:
+            return 0
+        v = int(self._status_target[0].item())
+        if v:
+            self._status_target[:1].zero_()
+        return v
+
+    def fx_range_exceeded(self, status=None):
+        """True if a call since the last check left the range of the fp16-pair arithmetic (|activation| >= 65504; never seen on images): the model then falls
+        back to the bf16 three-way split for good (option fx = 0) and the caller repeats the call -- results are exact either way."""
+        if status is None and not self._options.get("fx", DEFAULT_FX):
+            return False                               # (the bf16 arithmetic has fp32's range: nothing to read back)
+        v = self.take_status() if status is None else int(status)
+        if not (v & 1):
+            return False
+        import warnings
+        warnings.warn("accelerated_features_amd: an activation left the range of the fp16-pair arithmetic (|x| >= 65504); this model falls back to the "
+                      "bf16 three-way split (option fx = 0) and the call is repeated")
+        self.set_option("fx", 0)
+        return True
 
     def workspace(self, name, nbytes):
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -360,6 +396,8 @@ class XFeat(nn.Module):
         while True:
             kpts, scores, desc, n_valid, n_cand, cap, hw = self._detect_device(x, top_k, detection_threshold, cap)
             cnt = _counts_pair(n_valid, n_cand).cpu()            # the one read-back per batch
+            if self.net.fx_range_exceeded():                     # (fp16-pair arithmetic out of range: never on images; exact re-run on the bf16 split)
+                continue
             ncmax = int(cnt[1].max())
             if cap >= hw or ncmax <= cap:
                 break
@@ -416,6 +454,13 @@ class XFeat(nn.Module):
                     'scales'       ->   torch.Tensor(B, top_k): extraction scale
                     'descriptors'  ->   torch.Tensor(B, top_k, 64): coarse local features
         """
+        while True:
+            out = self._dense_device(x, top_k, multiscale)
+            if not self.net.fx_range_exceeded():      # (one 4-byte read-back while the fp16-pair arithmetic is on; see detectAndCompute)
+                return out
+
+    def _dense_device(self, x, top_k=None, multiscale=True):
+        """detectAndComputeDense without the status read-back (match_xfeat_star checks once per call)."""
         if top_k is None: top_k = self.top_k
         if multiscale:
             mkpts, sc, feats = self.extract_dualscale(x, top_k)
@@ -475,12 +520,15 @@ class XFeat(nn.Module):
         im_set1 = self.parse_input(im_set1)          # the dual-scale path resizes first: it needs the float image
         im_set2 = self.parse_input(im_set2)
 
-        out1 = self.detectAndComputeDense(im_set1, top_k=top_k)
-        out2 = self.detectAndComputeDense(im_set2, top_k=top_k)
+        while True:
+            out1 = self._dense_device(im_set1, top_k=top_k)
+            out2 = self._dense_device(im_set2, top_k=top_k)
 
-        idx0, idx1, n_matches = self._batch_match_device(out1['descriptors'], out2['descriptors'], -1)
-        out, n_out = self._refine_device(out1, out2, idx0, idx1, n_matches, 0.25)
-        counts = n_out.cpu().tolist()               # the one read-back
+            idx0, idx1, n_matches = self._batch_match_device(out1['descriptors'], out2['descriptors'], -1)
+            out, n_out = self._refine_device(out1, out2, idx0, idx1, n_matches, 0.25)
+            counts = n_out.cpu().tolist()               # the one read-back
+            if not self.net.fx_range_exceeded():        # (see detectAndCompute)
+                break
         matches = [out[b, :counts[b]] for b in range(len(counts))]
         B = len(im_set1)
         return matches if B > 1 else (matches[0][:, :2].cpu().numpy(), matches[0][:, 2:].cpu().numpy())

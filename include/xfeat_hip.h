@@ -91,13 +91,23 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   "wino"          0..2    3x3/s1 layers: 0 never Winograd, 1 unfused layers only, 2 (default) also the 3x3 + 1x1 pairs
  *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
  *                           8 not block3.0, 16 the stride-2 64 -> 64 | 128 layers (block4.0, block5.0) (default 21)
- *   "heads_f32"     0 | 1   1: both heads on the f32-MFMA kernels (set it when other kernels run on the GPU CONCURRENTLY with this handle's calls -- a second stream,
- *                           another process: next to a foreign kernel the split-bf16 key-point head was seen to deliver one wrong 16-cell block in ~10^4 calls)
+ *   "heads_f32"     0 | 1   1 (default): both heads on the f32-MFMA kernels.  0: the split-bf16 head kernels -- 106 us per 64-frame VGA step faster, and NOT safe: the key-point
+ *                           head was found to deliver one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever the first tile of a workgroup runs on
+ *                           instruction-cache misses, i.e. whenever other kernels (a second stream, another process) evict its code between launches (DESIGN 9.0,
+ *                           profiles/r04_head_hazard/); the f32 kernels are clean under the same torture at every code position.  For A/B measurements only.
+ *   "fx"            bitmask split-operand convolutions in the fp16-pair arithmetic (three MFMAs per product instead of the six of the bf16 three-way split):
+ *                           1 = the 64 -> 64 layers on large maps (conv_bx64_kernel), 2 = the 24-channel layers, 4 = the stride-2 64-channel layers
  *   "block1"        0..5    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile
  * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.
  * ---------------------------------------------------------------------------------------- */
 int xfh_set_option(xfh_handle h, const char* key, int value);
 int xfh_get_option(xfh_handle h, const char* key, int* value);
+/* Status word of a handle's calls: a caller-owned DEVICE int32 (NULL = none) into which kernels OR status bits; the caller zeroes and reads it (e.g. with
+ * the read-back of the key-point counts).  XFH_STATUS_FX_RANGE: a convolution in the fp16-pair arithmetic (option "fx") met an activation of magnitude
+ * >= 65504, which the fp16 high part cannot hold -- the outputs of that call are not valid; repeat it with fx = 0 (the bf16 three-way split has fp32's range).
+ * Set by xfh_backbone*, xfh_conv_layer.  The pointer is read at launch time; it may be changed between calls. */
+enum { XFH_STATUS_FX_RANGE = 1 };
+int xfh_set_status_buffer(xfh_handle h, int32_t* device_word);
 
 /* ------------------------------------------------------------------------------------------
  * Backbone.  Replaces XFeatModel.forward (modules/model.py:123-154) plus
@@ -346,6 +356,10 @@ int xfh_debug_trace(xfh_handle h, long long* device_buffer);
 int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int W, float* gray, float* coef, double* part, float* heat,
                         const float* heat_ref, float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat,
                         unsigned* rep_logits, unsigned cap, xfh_stream stream, float* dbg, const float* dbg_ref, unsigned* rep_dbg);
+/* debug / torture (process-wide, not for production): with enable != 0 every matrix-core kernel of the backbone invalidates the instruction cache when a
+ * workgroup starts, so that its first tile runs on instruction-fetch misses -- the condition under which head_bx_kernel<true> was found to deliver a wrong
+ * 16-cell block; the concurrency / cold-start soaks of tests/test_gpu_parity.py and tools/head_soak.py use it. */
+int xfh_debug_cold_start(int enable);
 /* debug: resident workgroups per CU the runtime reports for mnn_sim_kernel */
 int xfh_debug_match_occupancy(void);
 int xfh_profile_read(xfh_handle h, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);

@@ -12,7 +12,7 @@ from microbench import DIV, time_fn
 sd = fixtures.synthetic_state_dict()
 xf = XFeat(weights=sd, top_k=4096)
 lib = _lib.load(); h = xf.net.handle()
-names = [a for a in sys.argv[1:] if not a.startswith("-")] or ["block3.1", "block_fusion.0"]
+names = [a for a in sys.argv[1:] if not a.startswith("-")] or ["block2.0", "block3.0", "block3.1", "block_fusion.0"]
 g = torch.Generator(device="cuda").manual_seed(5)
 
 
@@ -39,8 +39,8 @@ def run(name, x, variant):
 VARS = {1: "generic fp32", 10: "bf16 x3", 11: "fp16 pair"}
 for name in names:
     c = next(c for c in CONVS if c.name == name)
-    for (B, hh, ww) in ((2, 24, 32), (3, 41, 44), (1, 6, 12), (9, 30, 40), (8, 60, 80)):
-        for scale, kind in ((1.0, "relu-normal"), (30.0, "relu-normal"), (1e-3, "relu-normal"), (1.0, "signed"), (300.0, "signed")):
+    for (B, hh, ww) in ((2, 24, 32), (3, 41, 44), (1, 6, 12), (9, 30, 40)):
+        for scale, kind in ((1.0, "relu-normal"), (30.0, "relu-normal"), (1e-3, "relu-normal"), (300.0, "signed")):
             x = torch.randn(B, c.cin, hh, ww, device="cuda", generator=g) * scale
             if kind == "relu-normal": x = torch.relu(x)
             t = truth64(name, x)
@@ -52,7 +52,7 @@ for name in names:
     B, H, W = 64, 480, 640
     d = DIV[name]; hin, win = H // d, W // d
     x = torch.relu(torch.randn(B, c.cin, hin, win, device="cuda", generator=g))
-    y = torch.empty(B, c.cout, hin, win, device="cuda")
+    y = torch.empty(B, c.cout, (hin - 1) // c.stride + 1, (win - 1) // c.stride + 1, device="cuda")
     for rnd in range(3):
         t = {v: time_fn(lambda: lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hin, win, C.c_void_p(y.data_ptr()), v, None), iters=30) for v in (10, 11)}
         print(f"{name} B={B} {hin}x{win}: bf16 x3 {t[10]:7.1f} us   fp16 pair {t[11]:7.1f} us", flush=True)

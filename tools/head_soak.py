@@ -136,7 +136,8 @@ results = []
 for variant in [int(v) for v in args.variants.split(",")]:
     heat = torch.empty(B, H, W, device="cuda")
     logits = torch.empty(ncell, 65, device="cuda") if args.logits else None
-    dbg = torch.zeros(3, ncell, 64, device="cuda") if variant == 10 else None
+    dbg = torch.zeros(3, ncell, 64, device="cuda") if variant == 10 else torch.zeros(32768, dtype=torch.int32, device="cuda") if variant == 16 else \
+          torch.zeros((12 * 4 + 32) * 256 * 512, device="cuda") if variant == 26 else None
     dbg_ref = rep_d = None
     with torch.cuda.stream(st_a):
         run(variant, st_a, 1, 0, heat, None, logits, None, None, None, img=x, dbg=dbg)
@@ -144,7 +145,7 @@ for variant in [int(v) for v in args.variants.split(",")]:
         heat_ref = heat.clone(); logits_ref = logits.clone() if args.logits else None
         # quiet determinism check
         rep_h = torch.zeros(4 + 4 * CAP, dtype=torch.int32, device="cuda"); rep_l = torch.zeros_like(rep_h)
-        if dbg is not None:
+        if variant in (10, 26):
             dbg_ref = dbg.clone(); rep_d = torch.zeros_like(rep_h)
         run(variant, st_a, 200, 0, heat, heat_ref, logits, logits_ref, rep_h, rep_l, dbg=dbg, dbg_ref=dbg_ref, rep_d=rep_d)
         st_a.synchronize()
@@ -181,11 +182,38 @@ for variant in [int(v) for v in args.variants.split(",")]:
         results.append(line)
         for l in decode(rh, "heat")[:12]: print(l, flush=True)
         for l in decode(rl, "logits")[:12]: print(l, flush=True)
+        if variant == 16:
+            d = dbg.cpu().numpy().view(np.uint32)
+            print(f"    variant 16: {int(d[0])} lanes still held the sentinel in an input register AFTER s_waitcnt vmcnt(0) + the barrier", flush=True)
+            for k in range(min(int(d[0]), 24)):
+                wg, wv, ln, mask = d[4 + 4 * k: 8 + 4 * k]
+                print(f"        workgroup {wg} wave {wv} lane {ln}: registers {mask:#010x}", flush=True)
+            if d[0]:
+                rec = d[4:4 + 4 * min(int(d[0]), 4096)].reshape(-1, 4)
+                print(f"        lanes histogram (lane & 63 // 16): {np.bincount(rec[:, 2] // 16, minlength=4).tolist()}  waves: {np.bincount(rec[:, 1], minlength=8).tolist()}  distinct masks: {[hex(m) for m in np.unique(rec[:, 3])[:16]]}", flush=True)
+            dbg.zero_()
         if rep_d is not None:
             nd = int(rep_d[0])
             rd = rep_d[4:4 + 4 * min(nd, CAP)].cpu().numpy().view(np.uint32).reshape(-1, 4)
             print(f"    layer dumps: {nd} float4 differ", flush=True)
-            for l in decode(rd, "layers")[:12]: print(l, flush=True)
+            if variant == 26:      # [12 fragments (step t, split q)][131072 threads] uint4, then [32 registers][131072 threads] float
+                NT = 256 * 512
+                for it in np.unique(rd[:, 0])[:40]:
+                    r = rd[rd[:, 0] == it]
+                    i4 = r[:, 1].astype(np.int64)
+                    fr = i4[i4 < 12 * NT]; ac = i4[i4 >= 12 * NT] - 12 * NT
+                    msg = f"    iter {it}:"
+                    if len(fr):
+                        frag, thr = fr // NT, fr % NT
+                        msg += f" B FRAGMENTS differ: (step, split) {sorted(set((int(f) // 3, int(f) % 3) for f in frag))} workgroup {np.unique(thr // 512).tolist()} wave {np.unique(thr % 512 // 64).tolist()} lanes {np.unique(thr % 64).tolist()};"
+                    else:
+                        msg += " B fragments identical;"
+                    if len(ac):
+                        f4 = ac * 4; reg, thr = f4 // NT, f4 % NT
+                        msg += f" L1 OUTPUT differs: {len(ac)} float4, registers {np.unique(reg).tolist()} workgroup {np.unique(thr // 512).tolist()} wave {np.unique(thr % 512 // 64).tolist()} lanes {np.unique(thr % 64 // 4 * 4).tolist()} (+0..3)"
+                    print(msg, flush=True)
+            else:
+                for l in decode(rd, "layers")[:12]: print(l, flush=True)
         if nl and nl <= CAP:      # which logits of a wrong cell differ (feature index histogram of the first event)
             it0 = rl[0, 0]; r0 = rl[rl[:, 0] == it0]
             feats = np.unique((r0[:, 1].astype(np.int64) * 4) % 65)
