@@ -680,9 +680,9 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     // fused heads: reliability from the channels-last features, key-point head from the gray image
     const bool all = h->prof.which == XFH_PROF_ALL;      // one span per head instead of one for both
     prof_begin(&h->prof, all ? XFH_SPAN_HEAD_REL : XFH_PROF_HEADS, st);
-    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32 != 0);
+    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32);
     if (all) { prof_end(&h->prof, XFH_SPAN_HEAD_REL, st, 0, 0); prof_begin(&h->prof, XFH_SPAN_HEAD_KP, st); }
-    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32 != 0);
+    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32);
     prof_end(&h->prof, all ? XFH_SPAN_HEAD_KP : XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }
@@ -963,7 +963,7 @@ int xfh_debug_cold_start(int enable) { xfh::g_debug_cold = enable ? 1 : 0; retur
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 1}, {"block1", &Options::block1, 0, 5}, {"fx", &Options::fx, 0, 15}};
+        {"heads_f32", &Options::heads_f32, 0, 2}, {"block1", &Options::block1, 0, 5}, {"fx", &Options::fx, 0, 15}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;
@@ -1000,12 +1000,11 @@ int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
 }
 
 int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int W, float* gray, float* coef, double* part, float* heat, const float* heat_ref,
-                        float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, xfh_stream stream,
-                        float* dbg, const float* dbg_ref, unsigned* rep_dbg) {
+                        float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, xfh_stream stream) {
     if (!h || !gray || !coef || !heat) return fail(XFH_ERR_ARG, "xfh_debug_head_soak: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     if (img) launch_gray_norm(img, B, C, H, W, part, gray, coef, st);      // (first call: the head's inputs)
-    if (head_soak(h->nw, gray, coef, B, H, W, heat, heat_ref, logits, logits_ref, variant, iters, iter0, rep_heat, rep_logits, cap, st, dbg, dbg_ref, rep_dbg))
+    if (head_soak(h->nw, gray, coef, B, H, W, heat, heat_ref, logits, logits_ref, variant, iters, iter0, rep_heat, rep_logits, cap, st))
         return fail(XFH_ERR_ARG, "xfh_debug_head_soak: unknown variant %d", variant);
     return check_launch("xfh_debug_head_soak");
 }

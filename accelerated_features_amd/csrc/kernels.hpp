@@ -53,7 +53,8 @@ struct Options {
     int wino = 2;           // 0: 3x3/s1 layers never use Winograd; 1: only unfused layers; 2: fused 3x3 + 1x1 pairs too
     int bx = 21;            // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0,
                             // 16 = the stride-2 64 -> 64 | 128 layers (block4.0, block5.0)
-    int heads_f32 = 1;      // 1 (default since round 4): both heads on the f32-MFMA kernels; 0: the split-bf16 kernels (head_bx_kernel) -- faster (-106 us per 64-frame step), but
+    int heads_f32 = 2;      // both heads on f32 MFMAs: 2 (default since round 4) = head_f32r_kernel (first-layer input in registers, no barrier per tile), 1 = head_fused_kernel (round 1:
+                            // activation tile in LDS, two barriers per tile; + 33 us per 64-frame step); 0: the split-bf16 kernels (head_bx_kernel) -- 60 us faster than 2, but
                             // head_bx_kernel<true> delivers a wrong 16-cell block once in 10^3..10^5 launches when a workgroup's first tile runs on instruction-cache
                             // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
     int fx = 3;             // split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
@@ -130,11 +131,10 @@ void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat
 // fused heads (persistent, weights LDS-resident): key-point head -> heat (+ optional logits (M,65)),
 // reliability head -> sigmoid map
 int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, const float* heat_ref, float* logits, const float* logits_ref,
-              int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, hipStream_t st, float* dbg = nullptr, const float* dbg_ref = nullptr,
-              unsigned* rep_dbg = nullptr);      // debug, k_heads.hip
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, bool f32_kernels = false);
+              int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, hipStream_t st);      // debug, k_heads.hip
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels = 0);
 // invnorm (optional): 1 / max(||feats[cell,:]||, 1e-12) per cell, a by-product of the layer-1 operand loads
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, bool f32_kernels = false);
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels = 0);
 
 // ---- k_detect.hip -----------------------------------------------------------------------
 struct DetectWs {          // carved from the caller's workspace by api.hip

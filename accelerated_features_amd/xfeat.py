@@ -194,7 +194,7 @@ class XFeatModel(nn.Module):
         _lib.check(lib.xfh_set_status_buffer(h, C.c_void_p(self._status.data_ptr())), "xfh_set_status_buffer")
         return h
 
-    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 1), "block1": (0, 5), "fx": (0, 15)}      # include/xfeat_hip.h: xfh_set_option
+    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 2), "block1": (0, 5), "fx": (0, 15)}      # include/xfeat_hip.h: xfh_set_option
 
     def set_option(self, key, value):
         """Kernel-variant switch of this model's handle (include/xfeat_hip.h: xfh_set_option) -- A/B runs and variant-vs-variant tests.
@@ -405,6 +405,22 @@ class XFeat(nn.Module):
         nv = cnt[0].tolist()
         return [{'keypoints': kpts[b, :nv[b]], 'scores': scores[b, :nv[b]], 'descriptors': desc[b, :nv[b]]}
                 for b in range(len(nv))]
+
+    @torch.inference_mode()
+    def detectAndComputePadded(self, x, top_k=None, detection_threshold=None, counts_out=None, with_f16=True):
+        """detectAndCompute without the ragged lists and without a read-back: the throughput form of the same call (everything stays on the device; pair it with
+        match_pairs_device, or use streaming.FrameStream / batching.match_pairs, which do).  Returns a dict of fixed-capacity tensors
+            'keypoints' (B,top_k,2), 'scores' (B,top_k), 'descriptors' (B,top_k,64), 'n_valid' (B,) int32  -- rows [n_valid[b]:] of image b are unspecified,
+            'n_candidates' (B,) int32 and 'nms_capacity': if n_candidates.max() > nms_capacity a plateau image overflowed the candidate list and the
+            call has to be repeated through detectAndCompute (which does so by itself); never seen on natural or textured images,
+            'descriptors_f16' (with_f16): 256 x the descriptors rounded to fp16, the copy match_pairs_device's filter reads.
+        counts_out: an int32 (2,B) device tensor to receive n_valid / n_candidates (a caller that keeps all its counts in one buffer reads them back with one copy).
+        The status word of the fp16-pair arithmetic (XFeatModel.fx_range_exceeded) is the caller's to check."""
+        out = self._detect_device(x, top_k, detection_threshold, None, with_f16, counts_out)
+        d = {'keypoints': out[0], 'scores': out[1], 'descriptors': out[2], 'n_valid': out[3], 'n_candidates': out[4], 'nms_capacity': out[5]}
+        if with_f16:
+            d['descriptors_f16'] = out[7]
+        return d
 
     def _detect_device(self, x, top_k=None, detection_threshold=None, cap=None, want_f16=False, counts_out=None):
         """Fixed-capacity device results, no read-back: kpts (B,top_k,2), scores (B,top_k),

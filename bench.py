@@ -173,7 +173,7 @@ PEAK_BF16_TFLOPS = 2500.0         # dense bf16 / fp16 MFMA
 MATCH_MAXIMA_BYTES_PER_ENTRY = 4.0      # the matcher's block maxima (k_match_f16.hip): fp32
 
 
-def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K):
+def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2):
     """roofline_kernels: one row per kernel (or tight kernel group) of the step, from the HIP-event spans of an untimed pass
     (xfh_profile_select(XFH_PROF_ALL)).  Per row: us per step; algorithmic HBM bytes (inputs read once + outputs written once) and FLOPs;
     the FLOPs the shipped kernel EXECUTES on the instruction it uses (Winograd: 2.25x fewer than direct; fp32 on bf16 MFMAs: 6 MFMAs per
@@ -204,17 +204,21 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K):
     ci = {c.name: i for i, c in enumerate(CONVS)}
     add(200, "gray_stats + gray_coef (channel mean, InstanceNorm statistics)", 4.0 * px["1"] * 4, 4.0 * px["1"], 4.0 * px["1"], 0, "valu")
     add(3, "block1_fused_kernel (block1.0-.3 + skip1)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32, "fp32 valu (v_pk_fma_f32)")
-    bx24 = 6 * (32 / 24) * (224 / 216)
+    # split-operand convolutions: the fp16-pair arithmetic (option fx, default: 3 MFMAs per product) or the bf16 three-way split (6)
+    nm24, nm64 = (3 if fx & 2 else 6), (3 if fx & 1 else 6)
+    pipe24 = "fp16 mfma x3 (fp16 pair, fp32-equivalent)" if fx & 2 else "bf16 mfma x6 (fp32-equivalent)"
+    pipe64 = "fp16 mfma x3 (fp16 pair, fp32-equivalent)" if fx & 1 else "bf16 mfma x6 (fp32-equivalent)"
+    bx24 = nm24 * (32 / 24) * (224 / 216)
     for n_ in ("block2.0", "block2.1"):
         fl = conv_flops(n_, px["4"])
-        add(100 + ci[n_], f"conv_bx_kernel<24,24> ({n_})", 4.0 * 48 * px["4"], fl, fl * bx24, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
+        add(100 + ci[n_], f"conv_bx_kernel<24,24> ({n_})", 4.0 * 48 * px["4"], fl, fl * bx24, PEAK_BF16_TFLOPS, pipe24)
     fl = conv_flops("block3.0", px["8"])
-    add(100 + ci["block3.0"], "conv_bxs2_kernel<24> (block3.0, stride 2)", 4.0 * (24 * px["4"] + 64 * px["8"]), fl, fl * 6 * (224 / 216), PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
+    add(100 + ci["block3.0"], "conv_bxs2_kernel<24> (block3.0, stride 2)", 4.0 * (24 * px["4"] + 64 * px["8"]), fl, fl * nm24 * (224 / 216), PEAK_BF16_TFLOPS, pipe24)
     for n3, n1, tag in (("block3.1", "block3.2", "conv_bx64_kernel<64,1>"), ("block_fusion.1", "block_fusion.2", "conv_bx64_kernel<64,2> (channels-last out)")):
         fl = conv_flops(n3, px["8"]) + conv_flops(n1, px["8"])
-        add(100 + ci[n3], f"{tag} ({n3} + {n1})", 4.0 * 128 * px["8"], fl, fl * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
+        add(100 + ci[n3], f"{tag} ({n3} + {n1})", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
     fl = conv_flops("block_fusion.0", px["8"])
-    add(100 + ci["block_fusion.0"], "conv_bx64_kernel<64,0> (block_fusion.0)", 4.0 * 128 * px["8"], fl, fl * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
+    add(100 + ci["block_fusion.0"], "conv_bx64_kernel<64,0> (block_fusion.0)", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
     for n_, cin, cout, sc_in, sc_out in (("block4.0", 64, 64, "8", "16"), ("block5.0", 64, 128, "16", "32")):
         fl = conv_flops(n_, px[sc_out])
         ho, wo = H // int(sc_out), W // int(sc_out)
@@ -228,9 +232,15 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K):
     add(100 + ci["block5.2"], "conv_wino_kernel (block5.2 + block5.3)", 4.0 * (128 + 64) * px["32"], fl3 + fl1, fl3 / 2.25 + fl1, f32, "f32 mfma, Winograd F(2x2,3x3)")
     add(201, "pyramid_sum_kernel (x3 + up(x4) + up(x5))", 4.0 * 64 * (2 * px["8"] + px["16"] + px["32"]), 3.0 * 64 * px["8"], 3.0 * 64 * px["8"], 0, "valu")
     fl = 2.0 * (2 * 64 * 64 + 64) * px["8"]
-    add(202, "head_bx_kernel<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl, fl * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
-    fl = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
-    add(203, "head_bx_kernel<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * 96) * px["8"] * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
+    hk = {0: "head_bx_kernel", 1: "head_fused_kernel", 2: "head_f32r_kernel"}[heads_f32]
+    if heads_f32:      # (default) the heads on f32 MFMAs: executed = algorithmic FLOPs (+ the 65 -> 96 padding of the last key-point layer) against the f32 peak
+        add(202, f"{hk}<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl, fl, f32, "f32 mfma")
+        fl = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
+        add(203, f"{hk}<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * 96) * px["8"], f32, "f32 mfma")
+    else:
+        add(202, f"{hk}<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl, fl * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
+        fl = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
+        add(203, f"{hk}<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * 96) * px["8"] * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
     add(210, "nms_flags_kernel", 4.0 * px["1"] + px["1"] / 8, 25.0 * px["1"], 25.0 * px["1"], 0, "valu")
     add(211, "nms_compact_kernel", px["1"] / 8 + 4.0 * px["1"] / 64, 0, 0, 0, "latency")
     add(212, "topk_sort_runs + topk_rank_merge", 4.0 * 3 * B * 2 * n_kpts, 0, 0, 0, "lds sort / latency")
@@ -588,7 +598,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="bound of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--lanes", type=int, default=2, help="batches in flight per GPU (accelerated_features_amd.streaming.FrameStream: one handle + HIP stream each); "
                                                          "1 = every step waits for its own read-back")
-    ap.add_argument("--concurrent-lanes", action="store_true", help="a HIP stream per lane (FrameStream(concurrent=True): the lanes then run the f32 heads); default: all lanes on one stream")
+    ap.add_argument("--concurrent-lanes", type=int, default=1, help="1 (default): a HIP stream per lane (FrameStream(concurrent=True)): one batch's convolutions fill the other's "
+                                                                        "latency-bound tail; 0: all lanes on one stream (the kernels run one after the other as in the synchronous path)")
     ap.add_argument("--wake-ms", type=float, default=200.0, help="untimed steps for this many ms before the profiling passes and the warm-up (a cold GPU's first ~150 ms run 3-4 %% slow); 0 = none")
     ap.add_argument("--no-side-passes", action="store_true", help="skip the extraction-only / with-H2D side figures (profiling runs)")
     ap.add_argument("--workload", default="sparse", choices=["sparse", "dense", "lighterglue", "megadepth", "demo"],
@@ -643,21 +654,19 @@ def main():
         # ONE batch, synchronously, on this handle (the profiled / side passes below; with --lanes 1 also the timed step):
         # (the descriptor kernel also emits the fp16 copy the matcher's filter sweep reads: no separate conversion pass; all counts
         # land in one buffer: one read-back, no concatenation kernel)
-        kp, sc, de, nv, nc, cap, hw, d16 = xf._detect_device(x, TOP_K, 0.05, want_f16=True, counts_out=cnt_dev[:2])
-        i0, i1, nm = xf.match_pairs_device(de, nv, -1, d16, n_out=cnt_dev[2, :B // 2])
+        r = xf.detectAndComputePadded(x, TOP_K, 0.05, counts_out=cnt_dev[:2])          # (public names only: the padded form of detectAndCompute + the pair matcher)
+        i0, i1, nm = xf.match_pairs_device(r['descriptors'], r['n_valid'], -1, r['descriptors_f16'], n_out=cnt_dev[2, :B // 2])
         c = cnt_dev.cpu()                                  # the one read-back (ragged results)
-        return torch.cat([c[0], c[1], c[2, :B // 2]]), cap
+        return torch.cat([c[0], c[1], c[2, :B // 2]]), r['nms_capacity']
 
     # The timed step: the same batch through accelerated_features_amd.streaming.FrameStream -- `lanes` batches in flight, one handle + HIP stream
     # each; a call queues one batch and retires the oldest one once every lane is busy (its ragged counts arrive by an asynchronous copy).  The
     # latency-bound tail of one batch (NMS compaction, top-k, refine scan, finalize, read-back) fills with the convolutions of the next.
     from accelerated_features_amd.streaming import FrameStream
     lanes = max(1, args.lanes)
-    # (concurrent lanes run the heads on the f32-MFMA kernels -- streaming.py -- so then the lanes are instances of their own and `xf` keeps the default
-    # kernel mix for the single-lane profiling passes)
+    # (every lane runs the library's default kernel mix; lane 0 is `xf`, which also serves the single-lane profiling passes after the timed region)
     conc = bool(args.concurrent_lanes) and lanes > 1
-    lane_xf = [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(lanes)] if conc else \
-              [xf] + [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(lanes - 1)]
+    lane_xf = [xf] + [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(lanes - 1)]
     handles = [l.net.handle() for l in lane_xf]
     fs = FrameStream(xfeats=lane_xf, top_k=TOP_K, detection_threshold=0.05, min_cossim=-1, concurrent=conc)
     retired = []
@@ -787,9 +796,9 @@ def main():
     if rank == 0 and not args.no_side_passes:
         side["extraction_only_fps"] = round(rate(extract_only), 1)
         side["single_lane_synchronous_fps"] = round(rate(step, 20), 1)      # one handle, one stream, every step waits for its read-back (the contract value of rounds 1-3a)
-        if not conc:                                                        # for information: a HIP stream per lane (f32 heads, streaming.py), 60 steps after 20
+        if lanes > 1:                                                       # for information: the OTHER lane mode (one stream for all lanes / a stream per lane), 60 steps after 20
             cxf = [XFeat(weights=fixtures.synthetic_state_dict(0), top_k=TOP_K, detection_threshold=0.05) for _ in range(2)]
-            cfs = FrameStream(xfeats=cxf, top_k=TOP_K, detection_threshold=0.05, min_cossim=-1, concurrent=True)
+            cfs = FrameStream(xfeats=cxf, top_k=TOP_K, detection_threshold=0.05, min_cossim=-1, concurrent=not conc)
 
             def crun(n):
                 torch.cuda.synchronize(); t0c = time.perf_counter()
@@ -799,7 +808,7 @@ def main():
                 cfs.drain(); torch.cuda.synchronize()
                 return B * n / (time.perf_counter() - t0c)
             crun(20)
-            side["concurrent_lanes_f32_heads_fps"] = round(crun(60), 1)
+            side["lanes_on_one_stream_fps" if conc else "concurrent_lanes_fps"] = round(crun(60), 1)
             del cfs, cxf
         xh32 = x_host.pin_memory()
         xh8 = (x_host * 255).round().clamp(0, 255).to(torch.uint8).pin_memory()
@@ -849,7 +858,9 @@ def main():
     if rank == 0:
         n_valid = counts[:B].tolist()
         n_match = counts[2 * B:].tolist()
-        k_rows, k_sum = kernel_roofline_table(spans_us, B, B // 2)
+        opt_fx, opt_heads = C.c_int(), C.c_int()
+        lib.xfh_get_option(handle, b"fx", C.byref(opt_fx)); lib.xfh_get_option(handle, b"heads_f32", C.byref(opt_heads))
+        k_rows, k_sum = kernel_roofline_table(spans_us, B, B // 2, fx=opt_fx.value, heads_f32=opt_heads.value)
         achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
         fps = sharding.aggregate_rate(B, args.steps, world, dt_max, "weak")
         fps_gpu = fps / world
@@ -870,11 +881,13 @@ def main():
             "config": {"workload": "VGA 640x480 sparse top_k=4096, batch=64 per GPU: detectAndCompute + MNN match of "
                                    "the 32 consecutive frame pairs (BASELINE configs[1])",
                        "batch_per_gpu": B, "height": H, "width": W, "top_k": TOP_K, "weights": "synthetic (tests/fixtures.py)",
-                       "arithmetic": "fp32 results throughout; the >= 24-channel convolutions and the heads compute them on bf16 MFMAs with three-way split "
-                                     "operands (fp32-equivalent, error <= an fp32 direct convolution's), the stride-1 layers at 1/16 and 1/32 scale as Winograd F(2x2,3x3) on f32 MFMAs, the "
-                                     "matcher decides on exact fp32 dot products (fp16 MFMAs only pre-select 32-wide blocks inside a derived error window)",
+                       "arithmetic": "fp32 results throughout; the 24-channel and the 64 -> 64 convolutions at 1/4 and 1/8 scale compute them on fp16 MFMAs with an fp16 PAIR per "
+                                     "operand (x = xh + 2^-11 xl: three MFMAs per product, error <= an fp32 direct convolution's; range-guarded, bf16 three-way split as fallback), the two "
+                                     "stride-2 64-channel layers on bf16 MFMAs with three-way split operands, the stride-1 layers at 1/16 and 1/32 scale as Winograd F(2x2,3x3) on f32 MFMAs, "
+                                     "both heads on f32 MFMAs, the matcher decides on exact fp32 dot products (fp16 MFMAs only pre-select 32-wide blocks inside a derived error window)",
                        "parallelism": f"replicas x{world}, no collective; {lanes} batches in flight per GPU (FrameStream: one handle per lane, asynchronous read-back of the counts; "
-                                      + ("a HIP stream per lane: the lanes run both heads on the f32-MFMA kernels, the single-lane passes of this line -- spans, single_lane_synchronous_fps -- the split-bf16 ones)"
+                                      + ("a HIP stream per lane: the hardware schedules one batch's convolutions into the other's latency-bound tail -- NMS compaction, top-k, refine scan, finalize;"
+                                         " lanes_on_one_stream_fps = the same with all lanes on one stream)"
                                          if conc else "ALL lanes on one HIP stream: the kernels run one after the other exactly as in the synchronous path, only the host round trip of the read-back is hidden)"),
                        "concurrent_lanes": conc,
                        "lanes": lanes,
@@ -913,11 +926,11 @@ def main():
                                "frac_algorithmic": round(((m_fl / 3) / PEAK_BF16_TFLOPS / 1e6) / (1e3 * m_ms / 3), 3) if m_ms > 0 else None},
             # the two 24 -> 24 convolutions (round 1-2a: the dominant kernel as Winograd on f32 MFMAs, 2 x 151 us): bf16 MFMAs on three-way
             # split operands, fp32-equivalent results.  "achieved" prices the ALGORITHMIC fp32 work against the f32 MFMA peak.
-            "roofline_conv24": {"bound": "mfma", "kernel": "conv_bx_kernel<24,24> (block2.0 / block2.1 on v_mfma_f32_32x32x16_bf16, six MFMAs per K = 16)",
+            "roofline_conv24": {"bound": "mfma", "kernel": "conv_bx_kernel<24,24> (block2.0 / block2.1 on v_mfma_f32_32x32x16_f16, three MFMAs per K = 16: fp16-pair arithmetic)",
                                 "us_per_step": round(1e3 * b_ms / 3, 1), "launches_per_step": 2,
                                 "achieved": round((b_fl / 1e12) / (b_ms / 1e3), 2) if b_ms > 0 else None, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                                "executed_bf16_tflops": round((b_fl * 6 * (32 / 24) * (224 / 216) / 1e12) / (b_ms / 1e3), 1) if b_ms > 0 else None,
-                                "peak_bf16_tflops": 2500.0},
+                                "executed_f16_tflops": round((b_fl * (3 if opt_fx.value & 2 else 6) * (32 / 24) * (224 / 216) / 1e12) / (b_ms / 1e3), 1) if b_ms > 0 else None,
+                                "peak_f16_tflops": 2500.0},
             # Whole path.  frac: against the roofline of the INSTRUCTION MIX THAT SHIPS -- per kernel max(algorithmic bytes / 8 TB/s, executed FLOPs /
             # the peak of the pipe the kernel uses), summed (roofline_kernels) -- i.e. how close the kernels are to their own floors.
             # frac_vs_survey_roof: SURVEY 8(d)'s figure (direct fp32 convolutions at 157.3 TF + one f32 GEMM for the match = 26.9 us per frame): a

@@ -91,10 +91,11 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   "wino"          0..2    3x3/s1 layers: 0 never Winograd, 1 unfused layers only, 2 (default) also the 3x3 + 1x1 pairs
  *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
  *                           8 not block3.0, 16 the stride-2 64 -> 64 | 128 layers (block4.0, block5.0) (default 21)
- *   "heads_f32"     0 | 1   1 (default): both heads on the f32-MFMA kernels.  0: the split-bf16 head kernels -- 106 us per 64-frame VGA step faster, and NOT safe: the key-point
- *                           head was found to deliver one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever the first tile of a workgroup runs on
- *                           instruction-cache misses, i.e. whenever other kernels (a second stream, another process) evict its code between launches (DESIGN 9.0,
- *                           profiles/r04_head_hazard/); the f32 kernels are clean under the same torture at every code position.  For A/B measurements only.
+ *   "heads_f32"     0..2    both heads on f32 MFMAs: 2 (default) the register-input kernels (head_f32r_kernel), 1 the round-1 kernels with an activation tile in LDS
+ *                           (+ 33 us per 64-frame VGA step).  0: the split-bf16 head kernels -- another 60 us faster, and NOT safe: the key-point head was found to deliver
+ *                           one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever the first tile of a workgroup runs on instruction-cache misses,
+ *                           i.e. whenever other kernels (a second stream, another process) evict its code between launches (profiles/r04_head_hazard/);
+ *                           both f32 kernels are clean under the same torture at every code position.  For A/B measurements only.
  *   "fx"            bitmask split-operand convolutions in the fp16-pair arithmetic (three MFMAs per product instead of the six of the bf16 three-way split):
  *                           1 = the 64 -> 64 layers on large maps (conv_bx64_kernel), 2 = the 24-channel layers, 4 = the stride-2 64-channel layers
  *   "block1"        0..5    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile
@@ -349,13 +350,13 @@ int xfh_profile_select(xfh_handle h, int which);
 int xfh_profile_read_spans(xfh_handle h, int* ids, double* ms, int capacity, int* n_spans);
 /* debug: 24 int64 s_memtime stamps per MFMA-conv workgroup are written to device_buffer (NULL = off) */
 int xfh_debug_trace(xfh_handle h, long long* device_buffer);
-/* debug (tools/head_soak.py): the key-point head alone, `iters` launches of kernel `variant` (0 = the shipped split-bf16 kernel, 1..4 = experiment
- * builds of it, 100 = the f32-MFMA kernel), every result compared on the device with heat_ref (and logits_ref); a report buffer holds {count, 0, 0, 0}
- * followed by up to `cap` records {iteration, float4 index, bits got, bits expected}.  img != NULL: gray / coef are computed from it first
- * (part: B * 128 doubles of scratch).  dbg (variant 10 only): [3][cells][64] outputs of the first three layers, compared with dbg_ref likewise. */
+/* debug (tools/head_soak.py): the key-point head alone, `iters` launches of kernel `variant` (0 = the split-bf16 kernel, 100 / 101 = the f32-MFMA kernels with an
+ * activation tile / with register input; 1000 + s, 2000 + s, 3000 + s = the same three cold-started with the code moved by 4 s bytes, s = 0 .. 15), every result
+ * compared on the device with heat_ref (and logits_ref); a report buffer holds {count, 0, 0, 0} followed by up to `cap` records {iteration, float4 index, bits got,
+ * bits expected}.  img != NULL: gray / coef are computed from it first (part: B * 128 doubles of scratch). */
 int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int W, float* gray, float* coef, double* part, float* heat,
                         const float* heat_ref, float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat,
-                        unsigned* rep_logits, unsigned cap, xfh_stream stream, float* dbg, const float* dbg_ref, unsigned* rep_dbg);
+                        unsigned* rep_logits, unsigned cap, xfh_stream stream);
 /* debug / torture (process-wide, not for production): with enable != 0 every matrix-core kernel of the backbone invalidates the instruction cache when a
  * workgroup starts, so that its first tile runs on instruction-fetch misses -- the condition under which head_bx_kernel<true> was found to deliver a wrong
  * 16-cell block; the concurrency / cold-start soaks of tests/test_gpu_parity.py and tools/head_soak.py use it. */

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Soak of the key-point head ALONE (head_bx_kernel<true> and its experiment builds) next to a foreign load on a second HIP stream.
+"""Soak of the key-point head ALONE next to a foreign load on a second HIP stream, and the cold-start code-position scan.
 
 Every launch's heat map (and logits) is compared on the device with the result of a quiet run; differing float4s are recorded
 (iteration, index, bits) and decoded here into (image, cell, workgroup tile, wave, lane) so that a rare wrong block can be placed.
+Variants (xfh_debug_head_soak): 0 = the split-bf16 head, 100 / 101 = the f32-MFMA heads (activation tile in LDS / register input = the default);
+1000 + s, 2000 + s, 3000 + s = the same three started on an invalidated instruction cache with the code moved by 4 s bytes (s = 0 .. 15).
 
-    python tools/head_soak.py --variants 0,100 --foreign backbone,copy,none --iters 100000
+    python tools/head_soak.py --variants 0,101 --foreign backbone,copy,none --max-seconds 45           # two streams
+    python tools/head_soak.py --variants $(seq -s, 1000 1015),$(seq -s, 3000 3015) --foreign none --max-seconds 6 --logits 0      # the scan
+
+(The experiment builds behind profiles/r04_head_hazard/t1..t9 -- variants 1..26: reloads, pads, dumps, a dry first pass -- were removed after commit 9607d16.)
 """
 import argparse
 import ctypes as C
@@ -47,9 +52,9 @@ part = torch.empty(B * 128, dtype=torch.float64, device="cuda")
 ncell = B * (H // 8) * (W // 8)
 
 
-def run(variant, stream, iters, iter0, heat, heat_ref, logits, logits_ref, rep_h, rep_l, img=None, dbg=None, dbg_ref=None, rep_d=None):
+def run(variant, stream, iters, iter0, heat, heat_ref, logits, logits_ref, rep_h, rep_l, img=None):
     rc = lib.xfh_debug_head_soak(h, P(img), B, 3, H, W, P(gray), P(coef), P(part), P(heat), P(heat_ref), P(logits), P(logits_ref),
-                                 variant, iters, iter0, P(rep_h), P(rep_l), CAP, C.c_void_p(stream.cuda_stream), P(dbg), P(dbg_ref), P(rep_d))
+                                 variant, iters, iter0, P(rep_h), P(rep_l), CAP, C.c_void_p(stream.cuda_stream))
     assert rc == 0, lib.xfh_last_error()
 
 
@@ -108,13 +113,6 @@ def decode(rec, what):
             b, rem = idx // (H * W), idx % (H * W)
             yy, xx = rem // W, rem % W
             cell = b * (H // 8) * (W // 8) + (yy // 8) * (W // 8) + xx // 8
-        elif what == "layers":      # [layer][cell][64]
-            layer, rem = idx // (ncell * 64), idx % (ncell * 64)
-            cell, feat = rem // 64, rem % 64
-            for L in np.unique(layer):
-                f = np.unique(feat[layer == L])
-                # a float4 record starts at feature 4 q: features 8 g + 4 half + (0..3): half 0 = {0, 8, 16, ...}, half 1 = {4, 12, ...}
-                extra += f" | layer {L}: {int((layer == L).sum())} float4 in {len(np.unique(cell[layer == L]))} cells, feature groups {f.tolist()}"
         else:
             cell = idx // 65
         cells = np.unique(cell)
@@ -136,23 +134,17 @@ results = []
 for variant in [int(v) for v in args.variants.split(",")]:
     heat = torch.empty(B, H, W, device="cuda")
     logits = torch.empty(ncell, 65, device="cuda") if args.logits else None
-    dbg = torch.zeros(3, ncell, 64, device="cuda") if variant == 10 else torch.zeros(32768, dtype=torch.int32, device="cuda") if variant == 16 else \
-          torch.zeros((12 * 4 + 32) * 256 * 512, device="cuda") if variant == 26 else None
-    dbg_ref = rep_d = None
     with torch.cuda.stream(st_a):
-        run(variant, st_a, 1, 0, heat, None, logits, None, None, None, img=x, dbg=dbg)
+        run(variant, st_a, 1, 0, heat, None, logits, None, None, None, img=x)
         st_a.synchronize()
         heat_ref = heat.clone(); logits_ref = logits.clone() if args.logits else None
         # quiet determinism check
         rep_h = torch.zeros(4 + 4 * CAP, dtype=torch.int32, device="cuda"); rep_l = torch.zeros_like(rep_h)
-        if variant in (10, 26):
-            dbg_ref = dbg.clone(); rep_d = torch.zeros_like(rep_h)
-        run(variant, st_a, 200, 0, heat, heat_ref, logits, logits_ref, rep_h, rep_l, dbg=dbg, dbg_ref=dbg_ref, rep_d=rep_d)
+        run(variant, st_a, 200, 0, heat, heat_ref, logits, logits_ref, rep_h, rep_l)
         st_a.synchronize()
     print(f"variant {variant}: quiet 200 launches: heat mismatches {int(rep_h[0])}, logits {int(rep_l[0])}; heat sum {float(heat_ref.double().sum()):.6f}", flush=True)
     for kind in args.foreign.split(","):
         rep_h.zero_(); rep_l.zero_()
-        if rep_d is not None: rep_d.zero_()
         stop = threading.Event()
         th = None
         if kind != "none":
@@ -162,7 +154,7 @@ for variant in [int(v) for v in args.variants.split(",")]:
         t0 = time.time(); done = 0; seen_h = seen_l = 0
         with torch.cuda.stream(st_a):
             while done < args.iters and time.time() - t0 < args.max_seconds:
-                run(variant, st_a, args.chunk, done, heat, heat_ref, logits, logits_ref, rep_h, rep_l, dbg=dbg, dbg_ref=dbg_ref, rep_d=rep_d)
+                run(variant, st_a, args.chunk, done, heat, heat_ref, logits, logits_ref, rep_h, rep_l)
                 done += args.chunk
                 if (done // args.chunk) % 4 == 0:
                     st_a.synchronize()
@@ -182,38 +174,6 @@ for variant in [int(v) for v in args.variants.split(",")]:
         results.append(line)
         for l in decode(rh, "heat")[:12]: print(l, flush=True)
         for l in decode(rl, "logits")[:12]: print(l, flush=True)
-        if variant == 16:
-            d = dbg.cpu().numpy().view(np.uint32)
-            print(f"    variant 16: {int(d[0])} lanes still held the sentinel in an input register AFTER s_waitcnt vmcnt(0) + the barrier", flush=True)
-            for k in range(min(int(d[0]), 24)):
-                wg, wv, ln, mask = d[4 + 4 * k: 8 + 4 * k]
-                print(f"        workgroup {wg} wave {wv} lane {ln}: registers {mask:#010x}", flush=True)
-            if d[0]:
-                rec = d[4:4 + 4 * min(int(d[0]), 4096)].reshape(-1, 4)
-                print(f"        lanes histogram (lane & 63 // 16): {np.bincount(rec[:, 2] // 16, minlength=4).tolist()}  waves: {np.bincount(rec[:, 1], minlength=8).tolist()}  distinct masks: {[hex(m) for m in np.unique(rec[:, 3])[:16]]}", flush=True)
-            dbg.zero_()
-        if rep_d is not None:
-            nd = int(rep_d[0])
-            rd = rep_d[4:4 + 4 * min(nd, CAP)].cpu().numpy().view(np.uint32).reshape(-1, 4)
-            print(f"    layer dumps: {nd} float4 differ", flush=True)
-            if variant == 26:      # [12 fragments (step t, split q)][131072 threads] uint4, then [32 registers][131072 threads] float
-                NT = 256 * 512
-                for it in np.unique(rd[:, 0])[:40]:
-                    r = rd[rd[:, 0] == it]
-                    i4 = r[:, 1].astype(np.int64)
-                    fr = i4[i4 < 12 * NT]; ac = i4[i4 >= 12 * NT] - 12 * NT
-                    msg = f"    iter {it}:"
-                    if len(fr):
-                        frag, thr = fr // NT, fr % NT
-                        msg += f" B FRAGMENTS differ: (step, split) {sorted(set((int(f) // 3, int(f) % 3) for f in frag))} workgroup {np.unique(thr // 512).tolist()} wave {np.unique(thr % 512 // 64).tolist()} lanes {np.unique(thr % 64).tolist()};"
-                    else:
-                        msg += " B fragments identical;"
-                    if len(ac):
-                        f4 = ac * 4; reg, thr = f4 // NT, f4 % NT
-                        msg += f" L1 OUTPUT differs: {len(ac)} float4, registers {np.unique(reg).tolist()} workgroup {np.unique(thr // 512).tolist()} wave {np.unique(thr % 512 // 64).tolist()} lanes {np.unique(thr % 64 // 4 * 4).tolist()} (+0..3)"
-                    print(msg, flush=True)
-            else:
-                for l in decode(rd, "layers")[:12]: print(l, flush=True)
         if nl and nl <= CAP:      # which logits of a wrong cell differ (feature index histogram of the first event)
             it0 = rl[0, 0]; r0 = rl[rl[:, 0] == it0]
             feats = np.unique((r0[:, 1].astype(np.int64) * 4) % 65)
