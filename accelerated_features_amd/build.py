@@ -52,8 +52,11 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, scan=False):
+    """scan: the torture build libxfeat_hip_scan.so -- the key-point head kernels at 16 code positions (tools/head_soak.py: XFH_LIB_PATH selects it)."""
     hipcc = _hipcc()
+    OBJ = globals()["OBJ"] + ("_scan" if scan else "")
+    LIB = globals()["LIB"].replace(".so", "_scan.so") if scan else globals()["LIB"]
     os.makedirs(OBJ, exist_ok=True)
     hdrs = _deps()
     jobs = []
@@ -64,7 +67,7 @@ def build(force=False, verbose=True):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + (["-DXFH_HEAD_SCAN_SHIFTS=16"] if scan else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 
@@ -89,4 +92,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, scan="--scan" in sys.argv)

@@ -611,7 +611,9 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     // 24-channel 3x3 layers (block2.0/.1 s1, block3.0 s2): bf16 MFMAs on three-way split operands (k_conv_bx.hip); bx = 0 keeps them on the f32-MFMA kernels
     const int use_bx = h->opt.bx;      // 1: 24-channel layers; 4: unfused 64 -> 64 layers on large maps (2: on every map); 8: not block3.0
     int rc = -1;
-    const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= 1024;      // >= 2 half-tile units per workgroup of the persistent grid (B=8 164x164: 92 vs 124 us stand-alone)
+    // "large map" = enough half-tile units for the persistent grid of conv_bx64_kernel (512 workgroups): >= 2 per workgroup in the bf16 arithmetic (B=8 164x164: 92 vs 124 us
+    // stand-alone against Winograd), >= 1.5 in the fp16-pair arithmetic, whose units are a third cheaper (VGA batch 64 at 1/16 scale, 768 units: 45 us against Winograd's 54)
+    const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= ((h->opt.fx & 1) ? 768 : 1024);
     if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) != 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0

@@ -770,10 +770,15 @@ static void launch_kp_head_f32r_shift(const HeadArgs& a, hipStream_t st) {
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<true, SHIFT>), 160 * 1024, attr);
     head_f32r_kernel<true, SHIFT><<<min(a.ntiles, num_cus()), 512, (size_t)(3 * 64 * 64 + 64 * 96) * sizeof(float), st>>>(a);
 }
+// The scan's 3 x 16 instantiations are compiled into the torture build only (python -m accelerated_features_amd.build --scan -> libxfeat_hip_scan.so, defines
+// XFH_HEAD_SCAN_SHIFTS = 16); the production library holds position 0 of each kernel.
+#ifndef XFH_HEAD_SCAN_SHIFTS
+#define XFH_HEAD_SCAN_SHIFTS 1
+#endif
 template <int S>
-static bool launch_shift(int shift, const HeadBxArgs& h, const HeadArgs& a, int kind, hipStream_t st) {      // shift 0 .. 15 -> the instantiation; kind 1 bf16, 2 f32 (LDS tile), 3 f32 (registers)
+static bool launch_shift(int shift, const HeadBxArgs& h, const HeadArgs& a, int kind, hipStream_t st) {      // shift -> the instantiation; kind 1 bf16, 2 f32 (LDS tile), 3 f32 (registers)
     if (shift == S) { if (kind == 2) launch_kp_head_f32_shift<S>(a, st); else if (kind == 3) launch_kp_head_f32r_shift<S>(a, st); else launch_kp_head_bx_shift<S>(h, st); return true; }
-    if constexpr (S < 15) return launch_shift<S + 1>(shift, h, a, kind, st);
+    if constexpr (S + 1 < XFH_HEAD_SCAN_SHIFTS) return launch_shift<S + 1>(shift, h, a, kind, st);
     return false;
 }
 

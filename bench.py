@@ -225,9 +225,13 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2):
         pad = (-(-ho // 8) * 8) * (-(-wo // 16) * 16) / float(ho * wo)          # 8x16-pixel units over the map (1.28 / 1.71 at VGA)
         add(100 + ci[n_], f"conv_bx64s2_kernel<{cout // 64}> ({n_}, stride 2)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), fl, fl * 6 * pad, PEAK_BF16_TFLOPS,
             "bf16 mfma x6 (fp32-equivalent)")
+    units16 = B * (-(-(H // 16) // 8)) * (-(-(W // 16) // 16))          # half-tile units of conv_bx64_kernel at 1/16 scale (api.hip: big_map)
     for n_, ch, sc in (("block4.1", 64, "16"), ("block4.2", 64, "16"), ("block5.1", 128, "32")):
         fl = conv_flops(n_, px[sc])
-        add(100 + ci[n_], f"conv_wino_kernel ({n_})", 4.0 * 2 * ch * px[sc], fl, fl / 2.25, f32, "f32 mfma, Winograd F(2x2,3x3)")
+        if ch == 64 and (fx & 1) and units16 >= 768:      # the 64 -> 64 layers at 1/16 scale join the fp16-pair split kernel when the batch fills its grid
+            add(100 + ci[n_], f"conv_bx64_kernel<64,0> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
+        else:
+            add(100 + ci[n_], f"conv_wino_kernel ({n_})", 4.0 * 2 * ch * px[sc], fl, fl / 2.25, f32, "f32 mfma, Winograd F(2x2,3x3)")
     fl3, fl1 = conv_flops("block5.2", px["32"]), conv_flops("block5.3", px["32"])
     add(100 + ci["block5.2"], "conv_wino_kernel (block5.2 + block5.3)", 4.0 * (128 + 64) * px["32"], fl3 + fl1, fl3 / 2.25 + fl1, f32, "f32 mfma, Winograd F(2x2,3x3)")
     add(201, "pyramid_sum_kernel (x3 + up(x4) + up(x5))", 4.0 * 64 * (2 * px["8"] + px["16"] + px["32"]), 3.0 * 64 * px["8"], 3.0 * 64 * px["8"], 0, "valu")

@@ -1018,9 +1018,7 @@ def test_frame_stream_lanes_deliver_the_synchronous_results_in_order(xf, sd, con
     from accelerated_features_amd.streaming import FrameStream
     from accelerated_features_amd import XFeat
     fs = FrameStream(weights=sd, top_k=512, lanes=2, concurrent=concurrent)
-    xs_ = XFeat(weights=sd, top_k=512)
-    if concurrent:
-        xs_.set_option("heads_f32", 1)                                       # the concurrent lanes' kernel mix (streaming.py: f32 heads next to another stream)
+    xs_ = XFeat(weights=sd, top_k=512)                                        # (the lanes run the library's default kernel mix in both modes)
     batches = [fixtures.texture_images(4, 96, 128, seed=40 + i).cuda() for i in range(5)]
     batches[3] = fixtures.texture_images(6, 64, 96, seed=99).cuda()          # another shape / batch size in the middle of the stream
     want = []
@@ -1064,8 +1062,6 @@ def test_frame_stream_at_the_bench_shape_is_bit_stable_over_many_steps(xf, sd, c
     from accelerated_features_amd import XFeat
     x = torch.cat([fixtures.texture_images(8, 480, 640, seed=77)] * 8).cuda()
     xs_ = XFeat(weights=sd, top_k=4096)
-    if concurrent:
-        xs_.set_option("heads_f32", 1)                                       # the concurrent lanes' kernel mix (streaming.py)
 
     def sync_result():
         kp, sc, de, nv, nc, cap, hw, d16 = xs_._detect_device(x, 4096, 0.05, want_f16=True)
@@ -1099,7 +1095,7 @@ def test_frame_stream_at_the_bench_shape_is_bit_stable_over_many_steps(xf, sd, c
         raise AssertionError(f"{len(bad)} of 40 results differ from the synchronous one (synchronous result reproducible: {ref_stable}): {bad[:6]}")
 
 
-@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"heads_f32": 0}])
+@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 0}])
 def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
     """Time-boxed soak.  The bench-shape backbone + sparse step + match on one HIP stream while a second stream runs foreign kernels (another
     model's backbone = every kernel of this library incl. f32-MFMA and vector-only ones, a large copy, a rocBLAS GEMM), then the same with every matrix-core

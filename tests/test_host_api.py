@@ -161,6 +161,7 @@ def test_every_barrier_in_dma_kernels_waits_for_the_dma():
     files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip")))
              if re.search(r"global_load_lds|buffer_load[^\n]* lds", open(f).read())]
     assert len(files) >= 3
+    mod.isa_asm.prefetch(sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "k_*.hip"))))      # (every kernel file once, in parallel; the audit below shares them)
     for f in files:
         nk, nb, bad = mod.audit(f)
         assert nk > 0 and nb > 0

@@ -12,15 +12,12 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_asm  # noqa: E402
 
 
 def audit(src):
-    with tempfile.TemporaryDirectory() as td:
-        r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on",
-                            "-save-temps", "-c", src, "-o", os.path.join(td, "o.o")], cwd=td, capture_output=True, text=True)
-        if r.returncode:
-            raise RuntimeError(r.stderr)
-        asm = open(glob.glob(os.path.join(td, "*gfx950.s"))[0]).read()
+    asm = isa_asm.asm(src)
     bad, n_kern, n_bar = [], 0, 0
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
         name, body = m.group(1), m.group(2)

@@ -13,6 +13,8 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_asm  # noqa: E402
 DIST = 8          # issue slots: every instruction counts one, s_nop N counts N + 1, an MFMA counts 8 (the pipe takes one at a time, 8 passes each)
 sys.path.insert(0, ROOT)
 
@@ -26,14 +28,7 @@ def _regs(tok):
 
 
 def audit(src):
-    from accelerated_features_amd.build import EXTRA_FLAGS
-    with tempfile.TemporaryDirectory() as td:
-        r = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on"]
-                           + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-save-temps", "-c", src, "-o", os.path.join(td, "o.o")],
-                           cwd=td, capture_output=True, text=True)
-        if r.returncode:
-            raise RuntimeError(r.stderr)
-        asm = open(glob.glob(os.path.join(td, "*gfx950.s"))[0]).read()
+    asm = isa_asm.asm(src)
     n_kern, n_mfma, bad = 0, 0, []
     for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", asm, re.S | re.M):
         name, body = m.group(1), m.group(2)

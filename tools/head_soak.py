@@ -7,7 +7,8 @@ Variants (xfh_debug_head_soak): 0 = the split-bf16 head, 100 / 101 = the f32-MFM
 1000 + s, 2000 + s, 3000 + s = the same three started on an invalidated instruction cache with the code moved by 4 s bytes (s = 0 .. 15).
 
     python tools/head_soak.py --variants 0,101 --foreign backbone,copy,none --max-seconds 45           # two streams
-    python tools/head_soak.py --variants $(seq -s, 1000 1015),$(seq -s, 3000 3015) --foreign none --max-seconds 6 --logits 0      # the scan
+    python -m accelerated_features_amd.build --scan          # (the 3 x 16 scan instantiations live in libxfeat_hip_scan.so only)
+    XFH_LIB_PATH=accelerated_features_amd/libxfeat_hip_scan.so python tools/head_soak.py --variants $(seq -s, 1000 1015),$(seq -s, 3000 3015) --foreign none --max-seconds 6 --logits 0
 
 (The experiment builds behind profiles/r04_head_hazard/t1..t9 -- variants 1..26: reloads, pads, dumps, a dry first pass -- were removed after commit 9607d16.)
 """
