@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define XFH_VERSION 102          /* major*10000 + minor*100 + patch */
+#define XFH_VERSION 103          /* major*10000 + minor*100 + patch */
 
 enum {
     XFH_OK = 0,
