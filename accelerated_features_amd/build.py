@@ -52,11 +52,13 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, scan=False):
-    """scan: the torture build libxfeat_hip_scan.so -- the key-point head kernels at 16 code positions (tools/head_soak.py: XFH_LIB_PATH selects it)."""
+def build(force=False, verbose=True, scan=False, shift=0):
+    """scan: the torture build libxfeat_hip_scan.so -- the key-point head kernels at 16 code positions (tools/head_soak.py: XFH_LIB_PATH selects it).
+    shift = N > 0: libxfeat_hip_shiftN.so -- EVERY matrix-core kernel's body moved by 4 N bytes (common.hpp: XFH_CODE_SHIFT; tools/shift_scan.sh)."""
     hipcc = _hipcc()
-    OBJ = globals()["OBJ"] + ("_scan" if scan else "")
-    LIB = globals()["LIB"].replace(".so", "_scan.so") if scan else globals()["LIB"]
+    tag = "_scan" if scan else (f"_shift{shift}" if shift else "")
+    OBJ = globals()["OBJ"] + tag
+    LIB = globals()["LIB"].replace(".so", tag + ".so")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = _deps()
     jobs = []
@@ -67,7 +69,7 @@ def build(force=False, verbose=True, scan=False):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + (["-DXFH_HEAD_SCAN_SHIFTS=16"] if scan else []) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + (["-DXFH_HEAD_SCAN_SHIFTS=16"] if scan else []) + ([f"-DXFH_CODE_SHIFT={shift}"] if shift else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 
@@ -92,4 +94,4 @@ def build(force=False, verbose=True, scan=False):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, scan="--scan" in sys.argv)
+    build(force="--force" in sys.argv, scan="--scan" in sys.argv, shift=int(sys.argv[sys.argv.index("--shift") + 1]) if "--shift" in sys.argv else 0)

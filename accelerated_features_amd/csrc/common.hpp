@@ -71,6 +71,20 @@ __device__ inline void lds_dma_barrier() {
     __syncthreads();
 }
 
+// Debug hooks at the entry of every matrix-core kernel.  XFH_CODE_SHIFT (build.py --shift N -> libxfeat_hip_shiftN.so): the kernel body moved by 4 N bytes
+// against the 64-byte instruction-cache lines; cold (xfh_debug_cold_start): the workgroup starts on an invalidated instruction cache -- together the
+// code-position scan of DESIGN 9.0 (tools/shift_scan.sh) for the whole library.  The production build has N = 0 and cold = 0: one scalar compare.
+#ifndef XFH_CODE_SHIFT
+#define XFH_CODE_SHIFT 0
+#endif
+template <int N> __device__ inline void code_shift() {
+    if constexpr (N > 0) { asm volatile("s_nop 0"); code_shift<N - 1>(); }
+}
+__device__ inline void kernel_entry_hooks(int cold) {
+    code_shift<XFH_CODE_SHIFT>();
+    if (cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");
+}
+
 // Raise a kernel's dynamic-LDS limit once per device.  `mask` is a static of the call site (bit d = done on device d): function
 // attributes are per device, so a process that drives several GPUs must set them on each (a per-process "done" flag would leave
 // every device but the first at the 64 KB default).  Racing threads at worst repeat the idempotent call.

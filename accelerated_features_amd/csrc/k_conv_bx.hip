@@ -62,7 +62,7 @@ struct BxCfg {
 template <int CIN, int COUT, bool FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx_kernel(BxArgs a) {
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     using Cfg = BxCfg<CIN, COUT, FX>;
     constexpr int NXS = Cfg::NXS;
     using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
@@ -307,7 +307,7 @@ struct BxS2Args {
 template <int CIN, bool FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bxs2_kernel(BxS2Args a) {
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     using Cfg = BxS2Cfg<CIN, FX>;
     constexpr int NXS = Cfg::NXS;
     using frag_t = std::conditional_t<FX, f16x8, bf16x8>;

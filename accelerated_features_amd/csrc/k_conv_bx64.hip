@@ -57,7 +57,7 @@ template <int CIN, int FUSE, bool FX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64_kernel(Bx64Args a) {
     using namespace bx64;
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     constexpr int PIXB = pixb<FX>(), NXS = FX ? 2 : 3;
     using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
     auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {

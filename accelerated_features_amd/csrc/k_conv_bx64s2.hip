@@ -54,7 +54,7 @@ static_assert(NITEM <= 512 && RING_OFF % 64 == 0 && LDS_BYTES <= 160 * 1024, "on
 template <int NCO, bool W4>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64s2_kernel(Bx64S2Args a) {
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     using namespace bx64s2;
     constexpr int CIN = 64, NCH = CIN / 16, NROW = NCH * 3, COUT = 64 * NCO;
     static_assert(NROW % 2 == 0 && NCH % 2 == 0, "ring slot, X buffer and register set of a chunk must not depend on the unit");

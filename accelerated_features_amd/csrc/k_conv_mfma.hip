@@ -59,7 +59,7 @@ struct ConvArgs {
 
 template <int CIN, int COUT, int KS, int STRIDE, int CK, int NSEG, bool NHWC, int COUT2, int NBO = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     constexpr int COUT_PAD = (COUT + 31) / 32 * 32;
     constexpr int MB = COUT_PAD / 32;
     constexpr int NB = NBO > 0 ? NBO : (MB == 1 ? 4 : (MB == 2 ? 2 : 1));

@@ -94,7 +94,7 @@ struct WinoCfg {
 template <int CIN, int COUT, int CB, int TBG, int NCBW, int NTBW, int TTH, int TTW, int COUT2, bool NHWC>
 __global__ __launch_bounds__(256 * (CB / NCBW) * (TBG / NTBW)) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_wino_kernel(WinoArgs a) {
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     using Cfg = WinoCfg<CB, TBG, NCBW, NTBW, TTH, TTW, COUT2>;
     constexpr int COUT2_PAD = Cfg::COUT2_PAD, MB2 = COUT2_PAD / 32;
     static_assert(COUT2 == 0 || (COUT == 32 * CB && NCBW == 2 && MB2 == 2), "fused 1x1: full cout blocks, two per wave, 64 outputs");

@@ -76,14 +76,11 @@ __device__ inline void chain_layer(const float* __restrict__ Wl, int npad, const
     }
 }
 
-// SHIFT (debug, tools/head_soak.py): the kernel body moved by SHIFT x 4 bytes against the 64-byte instruction-cache lines
-template <int N> __device__ inline void code_shift() {
-    if constexpr (N > 0) { asm volatile("s_nop 0"); code_shift<N - 1>(); }
-}
+// SHIFT (debug, tools/head_soak.py; torture build only): the kernel body moved by SHIFT x 4 bytes against the 64-byte instruction-cache lines
 template <bool KP, int SHIFT = 0>
 __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
     code_shift<SHIFT>();
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start): the workgroup starts on a cold instruction cache
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     constexpr int NL = KP ? 4 : 3;
     constexpr int W_FLOATS = KP ? (3 * 64 * 64 + 64 * 96) : (2 * 64 * 64 + 64);
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -253,7 +250,7 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
 template <bool KP, int SHIFT = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_f32r_kernel(HeadArgs a) {
     code_shift<SHIFT>();
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start)
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     constexpr int NL = KP ? 4 : 3;
     extern __shared__ __attribute__((aligned(16))) float smem_r[];
     float* Wl = smem_r;
@@ -520,7 +517,7 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
 template <bool KP, int SHIFT = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_bx_kernel(HeadBxArgs a) {
     code_shift<SHIFT>();
-    if (a.cold) asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7");      // debug (xfh_debug_cold_start)
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     constexpr int NB = KP ? 288 : 128;                                 // bias floats
     constexpr int W_BYTES = KP ? (3 * 2 + 3) * 4 * 3 * 1024 : 2 * 2 * 4 * 3 * 1024;      // cout blocks x K steps x splits x 1 KiB
     constexpr int L_BYTES = 2 * 4 * 3 * 1024;                         // a 64 -> 64 layer

@@ -170,7 +170,14 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
                                                             const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
                                                             int N1, int N2, int ncc, int nsplit, int P,
                                                             unsigned* __restrict__ colmaxh, unsigned* __restrict__ rowmaxh,
-                                                            float* __restrict__ R, float* __restrict__ C) {
+                                                            float* __restrict__ R, float* __restrict__ C
+#if XFH_CODE_SHIFT > 0      // torture builds only (build.py --shift N): the production kernel is, byte for byte, the one the round-4 proof soaks ran
+                                                            , int cold
+#endif
+                                                            ) {
+#if XFH_CODE_SHIFT > 0
+    kernel_entry_hooks(cold);      // debug: code-position shift / cold instruction cache (common.hpp)
+#endif
     __shared__ __attribute__((aligned(16))) _Float16 Dl[FT_COLS * FT_DS];      // the columns
     __shared__ float colx[8][FT_COLS];                                          // per wave: running column maxima (ds_max_f32, no return)
     __shared__ int next_block;
@@ -481,7 +488,11 @@ void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const floa
     // two workgroups per CU fill the chip; with few pairs the row blocks of a column chunk are shared out over more workgroups (>= 8 blocks each)
     const int nsplit = max(1, min(ceil_div(2 * num_cus(), ncc * P), ceil_div(N1, 256)));
     mnn_f16_sweep_kernel<<<xcd_grid_size(ncc * nsplit, P), 512, 0, st>>>(a16, sa, b16, sb, n1, n2, n_stride, n_off2, N1, N2, ncc, nsplit, P,
-                                                                        ws.colmaxh, ws.rowmaxh, ws.R, ws.C);
+                                                                        ws.colmaxh, ws.rowmaxh, ws.R, ws.C
+#if XFH_CODE_SHIFT > 0
+                                                                        , g_debug_cold
+#endif
+                                                                        );
     prof_end(prof, XFH_SPAN_MATCH_SWEEP, st, 0, 0);
     const int nyb = ceil_div(ceil_div(N1 > N2 ? N1 : N2, 32), RF_WAVES) * RF_WAVES;
     prof_begin(prof, XFH_SPAN_MATCH_REFINE, st);
