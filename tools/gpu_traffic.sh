@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 for C in FETCH_SIZE WRITE_SIZE; do
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C -d "$OLDPWD/gpurun_out/pmc_$C" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 3 --warmup 2 --cpu-seconds 0 > "$OLDPWD/gpurun_out/pmc_$C.log" 2>&1; echo "$C rc=$?")
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C -d "$OLDPWD/gpurun_out/pmc_$C" -o pmc --output-format csv -- python "$OLDPWD/bench.py" --steps 3 --warmup 2 --cpu-seconds 0 --no-side-passes --wake-ms 0 --lanes 1 > "$OLDPWD/gpurun_out/pmc_$C.log" 2>&1; echo "$C rc=$?")
 done
 python - <<'PY'
 import csv, collections, json

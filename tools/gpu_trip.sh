@@ -1,3 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 200 python tools/ab_option.py bx 21 23 111 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bx23_ab_block41.log
-timeout 200 python tools/ab_option.py bx 21 23 112 2>&1 | grep -v amdgpu.ids | tee gpurun_out/bx23_ab_block42.log
+V1=$(python -c "print(','.join(str(1000+i) for i in range(16)))")
+V3=$(python -c "print(','.join(str(3000+i) for i in range(16)))")
+XFH_LIB_PATH=accelerated_features_amd/libxfeat_hip_scan.so timeout 500 python tools/head_soak.py --variants $V1,$V3 --foreign none --iters 100000000 --max-seconds 4 --logits 0 2>&1 | grep "^variant.*foreign" | tee gpurun_out/r04_head_scan_same_box.txt | cut -c1-150

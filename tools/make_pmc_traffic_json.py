@@ -18,7 +18,7 @@ for k, v in raw.items():
     table[k] = {"launches": v["launches"], "hbm_read_bytes": int(v["fetch_kib"] * 1024 * corr), "hbm_write_bytes": int(v["write_kib"] * 1024),
                 "hbm_bytes": int(v["fetch_kib"] * 1024 * corr + v["write_kib"] * 1024)}
 b1 = next((k for k in table if k.startswith("block1_fused_kernel")), None)
-out = {"collected": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 2 --cpu-seconds 0`, tools/gpu_traffic.sh, "
+out = {"collected": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 2 --cpu-seconds 0 --no-side-passes --wake-ms 0 --lanes 1` (every launch at the bench shape), tools/gpu_traffic.sh, "
                     f"final build of round 4 ({tag}); raw table profiles/{tag}_pmc_traffic_raw.json; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B): calibration in this run on "
                     f"gray_stats_kernel = {rgb} B of RGB per launch -> measured factor {cal:.3f}" if cal else "no calibration kernel found",
        "read_correction": corr, "read_calibration_on_gray_stats": cal,
