@@ -4,9 +4,9 @@ The reference's benchmarks call `matcher_fn(img0, img1)` one pair at a time
 (modules/eval/megadepth1500.py:199-237, scannet1500.py:255-300).  On an MI355X a single VGA pair
 leaves the device almost idle; this runner takes the whole list of pairs, groups it by image size,
 pushes each group through `XFeat._detect_device` + `XFeat.match_pairs_device` in batches of up to
-`max_pairs`, and reads back one small tensor of counts per batch.  The results are exactly what
-`XFeat.match_xfeat` returns pair by pair (results do not depend on batch composition; checked by
-tests/test_gpu_parity.py), in the original order.
+`max_pairs`, and reads back one small tensor of counts per batch.  The results are what
+`XFeat.match_xfeat` returns pair by pair, in the original order (identical in tests/test_gpu_parity.py at its sizes; in general
+a large batch may run some convolutions on another -- equally fp32-accurate -- kernel than a single pair does, api.hip: big_map).
 """
 import numpy as np
 import torch
@@ -91,6 +91,8 @@ def _detect_exact(xfeat, x, top_k):
     while True:
         kpts, scores, desc, n_valid, n_cand, cap, hw = xfeat._detect_device(x, top_k, None, cap)
         ncmax = int(n_cand.max())
+        if xfeat.net.fx_range_exceeded():            # fp16-pair arithmetic out of range (never on images): exact re-run on the bf16 split, like detectAndCompute
+            continue
         if cap >= hw or ncmax <= cap:
             return kpts, desc, n_valid
         cap = min(hw, max(ncmax, 2 * cap))
