@@ -915,7 +915,11 @@ def main():
                          "alone": ({"avg_launch_us": round(spans_us[3], 2), "achieved": round(fl / max(n_l, 1) / 1e6 / spans_us[3], 3),
                                     "frac": round(fl / max(n_l, 1) / 1e6 / spans_us[3] / PEAK_MFMA_F32_TFLOPS, 4),
                                     "note": "single-lane pass (xfh_profile_select(XFH_PROF_ALL)), nothing else on the GPU"} if spans_us.get(3) else None),
-                         "lanes_in_timed_region": lanes},
+                         "lanes_in_timed_region": lanes,
+                         "note": ("the timed region runs two batches on two HIP streams: this launch duration (HIP events on the launch stream, = rocprofv3's per-dispatch duration in "
+                                  "profiles/*_kernel_stats.csv) includes the time the kernel shares the chip with the other lane's kernels; `alone` is the same kernel with the chip to "
+                                  "itself in a single-lane pass of this run (= profiles/*_kernel_stats_1lane.csv) and is the figure that speaks about the kernel") if conc else
+                                 "all lanes on one HIP stream: the kernels run one after the other, the launch duration is the kernel's own"},
             # xfh_match_mnn = fp16 MFMA filter (derived error window, one sweep in both tile orientations) + exact fp32 refine of the flagged
             # 32-wide blocks (~1.07 per row and column) on f32 MFMAs; identical match lists to the exact f32 MFMA kernel (tests; option
             # match_exact selects the latter).  "algorithmic" prices the fp32 work of D1.D2^T against the f32 MFMA peak: above 1 means the
