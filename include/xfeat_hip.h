@@ -114,7 +114,9 @@ int xfh_set_status_buffer(xfh_handle h, int32_t* device_word);
  * Backbone.  Replaces XFeatModel.forward (modules/model.py:123-154) plus
  * XFeat.get_kpts_heatmap (modules/xfeat.py:242-247).
  *
- *   img      (B,C,H,W) fp32, H%32==0, W%32==0, C>=1
+ *   img      (B,C,H,W) fp32, H%32==0, W%32==0, C>=1; finite values.  A NaN or Inf pixel is NOT propagated the way F.relu / torch.max propagate it in the
+ *            reference: block1's ReLU is a v_med3_f32 (k_conv_direct.hip is compiled with -fno-honor-nans, as is the matcher's maximum search), so a non-finite
+ *            input gives unspecified finite-or-not values in that image (other images of the batch are unaffected).  Validate on the host if the source can produce them.
  *   feats    (B,H/8,W/8,64)  "M1", channels-last (a (B,64,h,w) tensor in channels_last memory format)
  *   logits   (B,H/8,W/8,65)  "K1", channels-last; may be NULL (then not written)
  *   heat     (B,H,W)         softmax(K1)[:64] depth-to-space 8x8; may be NULL (then logits must not be)
