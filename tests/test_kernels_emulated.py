@@ -1,0 +1,136 @@
+"""Two of the shipped kernels compiled for the HOST and run against float64 references without a GPU: block1_fused_kernel<5> (the dominant kernel) and
+head_f32r_kernel<KP> (the default heads).  The kernel source is SLICED out of the product files (csrc/k_conv_direct.hip, csrc/k_heads.hip -- nothing in them is
+changed for this) and compiled with the host clang against tests/emu/emu.hpp: one host thread per work-item, LDS as a buffer (initialised to NaN patterns),
+__syncthreads a barrier, the LDS-DMA a copy, v_mfma_f32_32x32x2_f32 and the lane exchanges emulated.  What it checks: index arithmetic, tile and weight layouts,
+partial tiles, the barrier structure; what it cannot: timing, memory ordering, hardware hazards (the GPU suite and the soaks do that).  The slicing is by markers
+in the source: a change there that moves them fails this test loudly instead of silently testing something else."""
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "accelerated_features_amd", "csrc")
+EMU = os.path.join(ROOT, "tests", "emu")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def _between(text, start, end):
+    a = text.index(start)
+    return text[a:text.index(end, a)]
+
+
+def _must_sub(text, old, new):
+    assert old in text, f"marker not found in the kernel source: {old[:70]!r}"
+    return text.replace(old, new)
+
+
+def _slice_block1():
+    t = open(os.path.join(CSRC, "k_conv_direct.hip")).read()
+    s = _between(t, "namespace b1 {", "// Split-bf16 MFMA variants of block1_fused_kernel")
+    s = _must_sub(s, "__global__ __launch_bounds__(512) void block1_fused_kernel(", "inline void block1_fused_kernel(")
+    s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) float lds[];", "XFH_DYN_LDS(lds);")
+    assert "asm" not in s and "<<<" not in s
+    return s
+
+
+def _slice_heads():
+    t = open(os.path.join(CSRC, "k_heads.hip")).read()
+    head = _between(t, "typedef float f32x16 __attribute__((ext_vector_type(16)));", "// SHIFT (debug, tools/head_soak.py")
+    head = _must_sub(head, "typedef __attribute__((address_space(1))) const void* gptr_t;", "typedef const void* gptr_t;")
+    head = _must_sub(head, "typedef __attribute__((address_space(3))) void* lptr_t;", "typedef void* lptr_t;")
+    k = _between(t, "// The f32-MFMA heads without the activation tile", "// The same heads on the bf16 matrix cores with three-way split operands")
+    k = k[:k.rindex("// ----")]                                                          # (the next section's rule)
+    k = _must_sub(k, "__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_f32r_kernel(HeadArgs a) {", "inline void head_f32r_kernel(HeadArgs a) {")
+    k = _must_sub(k, "    code_shift<SHIFT>();\n", "")
+    k = _must_sub(k, "extern __shared__ __attribute__((aligned(16))) float smem_r[];", "XFH_DYN_LDS(smem_r);")
+    assert "asm" not in head + k and "<<<" not in head + k
+    return head + "\n// " + k
+
+
+@pytest.fixture(scope="module")
+def emu_bins():
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang")
+    td = tempfile.mkdtemp()
+    open(os.path.join(td, "block1_slice.hpp"), "w").write(_slice_block1())
+    open(os.path.join(td, "heads_slice.hpp"), "w").write(_slice_heads())
+    out = {}
+    for name in ("block1_emu", "head_emu"):
+        out[name] = os.path.join(td, name)
+        subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
+    return out
+
+
+def _blob(hdr, arrs):
+    return np.concatenate([np.array(hdr, np.int32).view(np.float32)] + [np.asarray(a, np.float32).reshape(-1) for a in arrs]).tobytes()
+
+
+def test_block1_kernel_on_the_host_is_the_network(emu_bins):
+    F = torch.nn.functional
+    for seed, (B, H, W) in enumerate(((1, 64, 64), (2, 96, 160))):        # 2 x 1 full tiles; 3 x 2.5 tiles per image (a partial last column of tiles)
+        g = torch.Generator().manual_seed(seed)
+        r = lambda *s, k=1.0: (torch.randn(*s, generator=g) * k).float()
+        w = {"w1": r(4, 1, 3, 3, k=0.5), "b1": r(4, k=0.2), "w2": r(8, 4, 3, 3, k=0.25), "b2": r(8, k=0.2), "w3": r(8, 8, 3, 3, k=0.2), "b3": r(8, k=0.2),
+             "w4": r(24, 8, 3, 3, k=0.2), "b4": r(24, k=0.2), "skw": r(24, 1, 1, 1, k=0.5), "skb": r(24, k=0.2)}
+        gray = torch.rand(B, 1, H, W, generator=g).float()
+        coef = torch.stack([0.5 + torch.rand(B, generator=g) * 3, torch.randn(B, generator=g)], 1).float()      # per-image {alpha, beta} of the instance normalisation
+        d = lambda t: t.double()
+        x = d(gray) * d(coef[:, 0]).view(-1, 1, 1, 1) + d(coef[:, 1]).view(-1, 1, 1, 1)
+        a = F.relu(F.conv2d(x, d(w["w1"]), d(w["b1"]), padding=1))
+        a = F.relu(F.conv2d(a, d(w["w2"]), d(w["b2"]), stride=2, padding=1))
+        a = F.relu(F.conv2d(a, d(w["w3"]), d(w["b3"]), padding=1))
+        a = F.relu(F.conv2d(a, d(w["w4"]), d(w["b4"]), stride=2, padding=1))
+        ref = (a + F.conv2d(F.avg_pool2d(x, 4, 4), d(w["skw"]), d(w["skb"]))).numpy()      # modules/model.py:40-48,140
+        kc = lambda t: t.permute(1, 2, 3, 0).reshape(-1).contiguous()          # (cout, cin, 3, 3) -> [(ci * 9 + tap) * cout + co]
+        pad = lambda t: torch.cat([t.reshape(-1), torch.zeros(32 - t.numel())])
+        out = subprocess.run([emu_bins["block1_emu"]], input=_blob([B, H, W, 5], [gray, coef, kc(w["w1"]), w["b1"], kc(w["w2"]), w["b2"], kc(w["w3"]), w["b3"], kc(w["w4"]), pad(w["b4"]),
+                                                                               pad(w["skw"]), pad(w["skb"])]), capture_output=True, check=True, timeout=240).stdout
+        x1 = np.frombuffer(out, np.float32).reshape(B, 24, H // 4, W // 4)
+        dd = np.abs(x1 - ref)
+        print(f"block1 ({B},{H},{W}): max |err| {dd.max():.3g}, max |x1| {np.abs(ref).max():.3g}")
+        assert np.isfinite(x1).all() and dd.max() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_default_heads_on_the_host(emu_bins):
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 96, 136                              # 2 x 12 x 17 = 408 cells: one full tile and a partial one
+    gray = torch.rand(B, H, W, generator=g)
+    coef = torch.stack([1.0 + torch.rand(B, generator=g) * 2, torch.randn(B, generator=g) * 0.5], 1)
+    ws = [torch.randn(64, 64, generator=g) * 0.18 for _ in range(3)] + [torch.randn(65, 64, generator=g) * 0.3]
+    bs = [torch.randn(64, generator=g) * 0.3 for _ in range(3)] + [torch.randn(65, generator=g)]
+    out = subprocess.run([emu_bins["head_emu"]], input=_blob([1, B, H, W], [gray, coef] + ws + bs), capture_output=True, check=True, timeout=240).stdout
+    ncell = B * (H // 8) * (W // 8)
+    heat = np.frombuffer(out[:4 * B * H * W], np.float32).reshape(B, H, W)
+    logits = np.frombuffer(out[4 * B * H * W:], np.float32).reshape(ncell, 65)
+    # 8 x 8 unfold (channel = 8 dy + dx) -> 3 x (linear + ReLU) -> linear -> softmax, dustbin dropped, depth-to-space   (modules/model.py:87-92,152; modules/xfeat.py:242-247)
+    x = gray.double() * coef[:, 0].double().view(-1, 1, 1) + coef[:, 1].double().view(-1, 1, 1)
+    a = x.view(B, H // 8, 8, W // 8, 8).permute(0, 1, 3, 2, 4).reshape(ncell, 64)
+    for w, b in zip(ws[:3], bs[:3]):
+        a = torch.relu(a @ w.double().T + b.double())
+    lg = a @ ws[3].double().T + bs[3].double()
+    href = torch.softmax(lg, 1)[:, :64].view(B, H // 8, W // 8, 8, 8).permute(0, 1, 3, 2, 4).reshape(B, H, W)
+    e_l, e_h = float(np.abs(logits - lg.numpy()).max()), float(np.abs(heat - href.numpy()).max())
+    print(f"key-point head: logits max |err| {e_l:.3g} (max |logit| {float(lg.abs().max()):.3g}), heat max |err| {e_h:.3g}")
+    assert np.isfinite(heat).all() and e_l <= 2e-5 * float(lg.abs().max()) and e_h <= 1e-6
+    # reliability head + 1 / |feats|   (modules/model.py:79-84; modules/xfeat.py:70)
+    n = 300
+    feats = torch.randn(n, 64, generator=g) * 2
+    ws = [torch.randn(64, 64, generator=g) * 0.18 for _ in range(2)]
+    w2 = torch.randn(64, generator=g) * 0.2
+    bs = [torch.randn(64, generator=g) * 0.3 for _ in range(2)]
+    b2 = torch.randn(1, generator=g)
+    out = subprocess.run([emu_bins["head_emu"]], input=_blob([0, n, 0, 0], [feats] + ws + [w2] + bs + [b2]), capture_output=True, check=True, timeout=240).stdout
+    rel, inv = np.frombuffer(out[:4 * n], np.float32), np.frombuffer(out[4 * n:8 * n], np.float32)
+    a = feats.double()
+    for w, b in zip(ws, bs):
+        a = torch.relu(a @ w.double().T + b.double())
+    ref = torch.sigmoid(a @ w2.double() + b2.double())
+    iref = 1.0 / feats.double().norm(dim=1).clamp_min(1e-12)
+    e_r, e_i = float(np.abs(rel - ref.numpy()).max()), float(np.abs(inv / iref.numpy() - 1).max())
+    print(f"reliability head: max |err| {e_r:.3g}, 1 / |feats| max rel err {e_i:.3g}")
+    assert e_r <= 2e-6 and e_i <= 1e-6
