@@ -52,6 +52,36 @@ def _slice_heads():
     return head + "\n// " + k
 
 
+def _slice_conv_bx64():
+    """conv_bx64_kernel: the inline assembly (LDS-DMA by buffer_load ... lds, waits, idle slots, register keep-alives) becomes emulator calls or nothing"""
+    t = open(os.path.join(CSRC, "k_conv_bx64.hip")).read()
+    s = _between(t, "typedef int i32x4 __attribute__((ext_vector_type(4)));", "template <int CIN, int FUSE, bool FX>\nstatic int run_bx64(")
+    s = _must_sub(s, "typedef __attribute__((address_space(3))) void* lptr_t;", "")
+    s = _must_sub(s, "__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))\nvoid conv_bx64_kernel(Bx64Args a) {", "inline void conv_bx64_kernel(Bx64Args a) {")
+    s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) unsigned char smem_b64[];", "XFH_DYN_LDS_BYTES(smem_b64);")
+    s = _must_sub(s, "auto lds_addr = [](const unsigned char* p) { return (unsigned)(size_t)(lptr_t)p; };", "auto lds_addr = [&](const unsigned char* p) { return (unsigned)(p - smem_b64); };")
+    s = _must_sub(s, 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(dma_voff), "s"(rs_w), "s"(soff) : "memory");',
+                  "emu::dma_b128_to_lds(m0v, dma_voff, rs_w, soff);")
+    n0 = s.count("asm volatile")
+    s = s.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', ";")
+    s = re.sub(r'asm volatile\("s_nop 7[^;]*;', ";", s)                                   # idle slots (with or without tied accumulators)
+    s = re.sub(r'asm volatile\("" : "\+v"[^;]*;', ";", s)                                 # register keep-alives of the fused 1x1
+    assert n0 >= 8 and s.count("asm volatile") == s.count('asm volatile("" ::: "memory");'), "an inline-assembly statement of conv_bx64_kernel is not covered"
+    assert "<<<" not in s
+    return s
+
+
+def _slice_weight_split():
+    t = open(os.path.join(CSRC, "api.hip")).read()
+    return _between(t, "static uint16_t bf16_rne(float f) {", "constexpr float kFxMaxWeight")
+
+
+def _slice_bx_split():
+    t = open(os.path.join(CSRC, "bx_split.hpp")).read()
+    s = _between(t, "typedef float f32x16 __attribute__((ext_vector_type(16)));", "}  // namespace xfh")
+    return s
+
+
 @pytest.fixture(scope="module")
 def emu_bins():
     if not os.path.exists(CLANG):
@@ -59,8 +89,11 @@ def emu_bins():
     td = tempfile.mkdtemp()
     open(os.path.join(td, "block1_slice.hpp"), "w").write(_slice_block1())
     open(os.path.join(td, "heads_slice.hpp"), "w").write(_slice_heads())
+    open(os.path.join(td, "conv_bx64_slice.hpp"), "w").write(_slice_conv_bx64())
+    open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
+    open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("block1_emu", "head_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx64_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -134,3 +167,26 @@ def test_default_heads_on_the_host(emu_bins):
     e_r, e_i = float(np.abs(rel - ref.numpy()).max()), float(np.abs(inv / iref.numpy() - 1).max())
     print(f"reliability head: max |err| {e_r:.3g}, 1 / |feats| max rel err {e_i:.3g}")
     assert e_r <= 2e-6 and e_i <= 1e-6
+
+
+@pytest.mark.parametrize("fuse,fx,shape,grid", [(0, 1, (1, 24, 40), 3), (0, 0, (1, 16, 16), 2), (1, 1, (2, 24, 32), 5), (2, 1, (1, 18, 20), 2), (0, 1, (8, 8, 16), 8)])
+def test_conv_bx64_kernel_on_the_host(emu_bins, fuse, fx, shape, grid):
+    """the 64 -> 64 3x3 convolutions on split-operand MFMAs (fp16 pair / bf16 three-way split), alone and with their trailing 1x1 fused, NCHW or channels-last output:
+    full tiles, a half tile, partial strips and rows (24 x 40, 18 x 20), and the XCD mapping of the work list (B = 8 on a grid of 8)"""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(10 * fuse + fx)
+    x = torch.relu(torch.randn(B, 64, H, W, generator=g)) * 2
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b = torch.randn(64, generator=g) * 0.3
+    w2 = torch.randn(64, 64, generator=g) / 8
+    b2 = torch.randn(64, generator=g) * 0.3
+    out = subprocess.run([emu_bins["conv_bx64_emu"]], input=_blob([B, H, W, fuse, fx, 1, 0, grid], [x, w, b] + ([w2, b2] if fuse else [])), capture_output=True, check=True, timeout=240).stdout
+    y = np.frombuffer(out[:-4], np.float32)
+    status = int(np.frombuffer(out[-4:], np.int32)[0])
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if fuse:
+        ref = torch.nn.functional.conv2d(ref, w2.double().view(64, 64, 1, 1), b2.double())
+    y = y.reshape(B, H, W, 64).transpose(0, 3, 1, 2) if fuse == 2 else y.reshape(B, 64, H, W)
+    d = np.abs(y - ref.numpy())
+    print(f"conv_bx64 fuse {fuse} fx {fx} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert status == 0 and np.isfinite(y).all() and d.max() <= 3e-6 * float(ref.abs().max())
