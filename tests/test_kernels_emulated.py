@@ -169,10 +169,11 @@ def test_default_heads_on_the_host(emu_bins):
     assert e_r <= 2e-6 and e_i <= 1e-6
 
 
-@pytest.mark.parametrize("fuse,fx,shape,grid", [(0, 1, (1, 24, 40), 3), (0, 0, (1, 16, 16), 2), (1, 1, (2, 24, 32), 5), (2, 1, (1, 18, 20), 2), (0, 1, (8, 8, 16), 8)])
+@pytest.mark.parametrize("fuse,fx,shape,grid", [(0, 1, (1, 24, 40), 3), (0, 0, (1, 16, 16), 2), (1, 1, (2, 24, 32), 5), (2, 1, (1, 18, 20), 2), (0, 1, (8, 8, 16), 8), (0, 1, (1, 10, 22), 2), (1, 1, (1, 9, 17), 3)])
 def test_conv_bx64_kernel_on_the_host(emu_bins, fuse, fx, shape, grid):
     """the 64 -> 64 3x3 convolutions on split-operand MFMAs (fp16 pair / bf16 three-way split), alone and with their trailing 1x1 fused, NCHW or channels-last output:
-    full tiles, a half tile, partial strips and rows (24 x 40, 18 x 20), and the XCD mapping of the work list (B = 8 on a grid of 8)"""
+    full tiles, a half tile, partial strips and rows (24 x 40, 18 x 20), widths that are no multiple of four (22, 17: the masked tail of a loaded pixel quad), and the XCD
+    mapping of the work list (B = 8 on a grid of 8)"""
     B, H, W = shape
     g = torch.Generator().manual_seed(10 * fuse + fx)
     x = torch.relu(torch.randn(B, 64, H, W, generator=g)) * 2
