@@ -1,4 +1,4 @@
-"""Two of the shipped kernels compiled for the HOST and run against float64 references without a GPU: block1_fused_kernel<5> (the dominant kernel) and
+"""Shipped kernels compiled for the HOST and run against float64 references without a GPU: block1_fused_kernel<5> (the dominant kernel) and
 head_f32r_kernel<KP> (the default heads).  The kernel source is SLICED out of the product files (csrc/k_conv_direct.hip, csrc/k_heads.hip -- nothing in them is
 changed for this) and compiled with the host clang against tests/emu/emu.hpp: one host thread per work-item, LDS as a buffer (initialised to NaN patterns),
 __syncthreads a barrier, the LDS-DMA a copy, v_mfma_f32_32x32x2_f32 and the lane exchanges emulated.  What it checks: index arithmetic, tile and weight layouts,
@@ -71,6 +71,24 @@ def _slice_conv_bx64():
     return s
 
 
+def _slice_conv_bx64s2():
+    """conv_bx64s2_kernel (the stride-2 64 -> 64 | 128 layers: the split of the next chunk hand-placed inside the MFMA rows of the current one): the same substitutions"""
+    t = open(os.path.join(CSRC, "k_conv_bx64s2.hip")).read()
+    s = _between(t, "struct Bx64S2Args {", "template <int NCO, bool W4>\nstatic int run_bx64s2(")
+    s = _must_sub(s, "__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))\nvoid conv_bx64s2_kernel(Bx64S2Args a) {", "inline void conv_bx64s2_kernel(Bx64S2Args a) {")
+    s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];", "XFH_DYN_LDS_BYTES(smem_s2);")
+    s = _must_sub(s, "auto lds_addr = [](const unsigned char* p) { return (unsigned)(size_t)(lptr_t)p; };", "auto lds_addr = [&](const unsigned char* p) { return (unsigned)(p - smem_s2); };")
+    s = _must_sub(s, 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(dma_voff), "s"(rs_w), "s"(soff) : "memory");',
+                  "emu::dma_b128_to_lds(m0v, dma_voff, rs_w, soff);")
+    n0 = s.count("asm volatile")
+    s = s.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', ";")
+    s = re.sub(r'asm volatile\("s_nop 7[^;]*;', ";", s)                                   # idle slots
+    s = re.sub(r'asm volatile\("" :: "v"[^;]*;', ";", s)                                  # S2_KEEP: register keep-alives of the just-read fragments
+    assert n0 == 4 and "asm volatile" not in s, "an inline-assembly statement of conv_bx64s2_kernel is not covered"
+    assert "<<<" not in s
+    return "typedef int i32x4 __attribute__((ext_vector_type(4)));\n" + s
+
+
 def _slice_weight_split():
     t = open(os.path.join(CSRC, "api.hip")).read()
     return _between(t, "static uint16_t bf16_rne(float f) {", "constexpr float kFxMaxWeight")
@@ -90,10 +108,11 @@ def emu_bins():
     open(os.path.join(td, "block1_slice.hpp"), "w").write(_slice_block1())
     open(os.path.join(td, "heads_slice.hpp"), "w").write(_slice_heads())
     open(os.path.join(td, "conv_bx64_slice.hpp"), "w").write(_slice_conv_bx64())
+    open(os.path.join(td, "conv_bx64s2_slice.hpp"), "w").write(_slice_conv_bx64s2())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("block1_emu", "head_emu", "conv_bx64_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -191,3 +210,22 @@ def test_conv_bx64_kernel_on_the_host(emu_bins, fuse, fx, shape, grid):
     d = np.abs(y - ref.numpy())
     print(f"conv_bx64 fuse {fuse} fx {fx} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
     assert status == 0 and np.isfinite(y).all() and d.max() <= 3e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("cout,shape,grid", [(64, (1, 16, 32), 1), (64, (2, 30, 40), 3), (128, (1, 30, 40), 2), (64, (1, 9, 11), 1), (128, (1, 18, 22), 2)])
+def test_conv_bx64s2_kernel_on_the_host(emu_bins, cout, shape, grid):
+    """the stride-2 64 -> 64 | 128 convolutions (block4.0 / block5.0) on bf16 MFMAs with three-way split operands -- the kernel whose barrier waits carried the round-3
+    store-ordering bug (a memory-ordering matter the host cannot see: what runs here is its index arithmetic, the parity-separated input buffers, the split
+    hand-placed in the MFMA rows, the cyclic weight stream across units): one full unit, partial rows and strips with several units per workgroup, two cout halves,
+    odd sizes with W % 4 != 0 (the masked tail of a loaded pixel quad)"""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(cout + H)
+    x = torch.randn(B, 64, H, W, generator=g) * 2
+    w = torch.randn(cout, 64, 3, 3, generator=g) / 24
+    b = torch.randn(cout, generator=g) * 0.3
+    out = subprocess.run([emu_bins["conv_bx64s2_emu"]], input=_blob([B, H, W, cout, 1, grid], [x, w, b]), capture_output=True, check=True, timeout=400).stdout
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    y = np.frombuffer(out, np.float32).reshape(tuple(ref.shape))
+    d = np.abs(y - ref.numpy())
+    print(f"conv_bx64s2 cout {cout} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert np.isfinite(y).all() and d.max() <= 4e-6 * float(ref.abs().max())
