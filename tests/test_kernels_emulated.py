@@ -89,6 +89,23 @@ def _slice_conv_bx64s2():
     return "typedef int i32x4 __attribute__((ext_vector_type(4)));\n" + s
 
 
+def _slice_conv_bx24():
+    """conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0): weights in registers, one staged halo tile per output tile"""
+    t = open(os.path.join(CSRC, "k_conv_bx.hip")).read()
+    s = _between(t, "struct BxArgs {", "template <int CIN, bool FX>\nstatic int run_bxs2(")
+    for name, args in (("conv_bx_kernel", "BxArgs"), ("conv_bxs2_kernel", "BxS2Args")):
+        s = _must_sub(s, f"__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))\nvoid {name}({args} a) {{", f"inline void {name}({args} a) {{")
+    assert s.count("extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];") == 2
+    s = s.replace("extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];", "XFH_DYN_LDS_BYTES(smem_bx);")
+    n0 = s.count("asm volatile")
+    s = _must_sub(s, 'asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc));', "lds_alloc = 0;")      # (which workgroup of a CU this is: a start delay, nothing else)
+    s = re.sub(r'asm volatile\("s_nop 7[^;]*;', ";", s)                                   # idle slots tied to the accumulators
+    s = re.sub(r'asm volatile\("" : "\+v"[^;]*;', ";", s)                                 # "the wait for the weight loads belongs here": register pins
+    assert n0 == 5 and "asm volatile" not in s, "an inline-assembly statement of k_conv_bx.hip is not covered"
+    assert "<<<" not in s
+    return s
+
+
 def _slice_weight_split():
     t = open(os.path.join(CSRC, "api.hip")).read()
     return _between(t, "static uint16_t bf16_rne(float f) {", "constexpr float kFxMaxWeight")
@@ -109,10 +126,11 @@ def emu_bins():
     open(os.path.join(td, "heads_slice.hpp"), "w").write(_slice_heads())
     open(os.path.join(td, "conv_bx64_slice.hpp"), "w").write(_slice_conv_bx64())
     open(os.path.join(td, "conv_bx64s2_slice.hpp"), "w").write(_slice_conv_bx64s2())
+    open(os.path.join(td, "conv_bx24_slice.hpp"), "w").write(_slice_conv_bx24())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu", "conv_bx24_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -229,3 +247,22 @@ def test_conv_bx64s2_kernel_on_the_host(emu_bins, cout, shape, grid):
     d = np.abs(y - ref.numpy())
     print(f"conv_bx64s2 cout {cout} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
     assert np.isfinite(y).all() and d.max() <= 4e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("stride,fx,shape,grid", [(1, 1, (1, 16, 64), 2), (1, 0, (1, 8, 32), 1), (1, 1, (2, 21, 45), 3), (2, 1, (1, 16, 64), 2), (2, 0, (1, 8, 32), 1), (2, 1, (2, 21, 45), 3), (1, 1, (8, 8, 32), 8)])
+def test_conv_bx24_kernels_on_the_host(emu_bins, stride, fx, shape, grid):
+    """the 24-channel layers on split-operand MFMAs with their weights in registers: conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0, stride 2,
+    64 couts), in the shipped fp16-pair arithmetic and the bf16 three-way split: full tiles, partial tiles with odd sizes (21 x 45), several tiles per workgroup, the XCD mapping
+    of the work list (B = 8 on a grid of 8)"""
+    B, H, W = shape
+    cout = 64 if stride == 2 else 24
+    g = torch.Generator().manual_seed(7 * stride + fx + H)
+    x = torch.relu(torch.randn(B, 24, H, W, generator=g)) * 2
+    w = torch.randn(cout, 24, 3, 3, generator=g) / 15
+    b = torch.randn(cout, generator=g) * 0.3
+    out = subprocess.run([emu_bins["conv_bx24_emu"]], input=_blob([B, H, W, stride, fx, 1, grid], [x, w, b]), capture_output=True, check=True, timeout=400).stdout
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1))
+    y = np.frombuffer(out[:-4], np.float32).reshape(tuple(ref.shape))
+    d = np.abs(y - ref.numpy())
+    print(f"conv_bx24 stride {stride} fx {fx} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0 and np.isfinite(y).all() and d.max() <= 3e-6 * float(ref.abs().max())
