@@ -266,3 +266,100 @@ def test_conv_bx24_kernels_on_the_host(emu_bins, stride, fx, shape, grid):
     d = np.abs(y - ref.numpy())
     print(f"conv_bx24 stride {stride} fx {fx} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
     assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0 and np.isfinite(y).all() and d.max() <= 3e-6 * float(ref.abs().max())
+
+
+def test_shipped_block1_and_heads_on_the_host_keep_the_references_key_points(emu_bins):
+    """The three sliced kernels END TO END against the reference-made goldens, without a GPU: block1_fused_kernel<5> and both default heads run in the host emulation on the
+    golden fixtures' images and weights (BatchNorm folded here the way xfh_create folds it), everything between and after them (block2 .. feats; NMS, scores, top-k,
+    descriptors) is the oracle's fp32 restatement, and the key-point lists are compared -- by the GPU suite's own comparator -- with what the UNMODIFIED reference wrote into
+    tests/golden/ (g1_small: 2 x 256 key-points; g2_vga_pair: 2 x 4096 at VGA).  The same key-point SET as the reference; rank moves only among scores a few ulps apart."""
+    import sys
+    import torch.nn.functional as F
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fixtures
+    import parity
+    from oracle import xfeat_oracle as O
+
+    def fold(sd, name):      # conv (no bias) + eval BatchNorm (affine=False, eps 1e-5) -> weight, bias   (modules/model.py:16-22)
+        s_ = 1.0 / torch.sqrt(sd[f"{name}.layer.1.running_var"].double() + 1e-5)
+        return (sd[f"{name}.layer.0.weight"].double() * s_.view(-1, 1, 1, 1)).float(), (-sd[f"{name}.layer.1.running_mean"].double() * s_).float()
+
+    def run_block1(sd, gray, coef):
+        B, H, W = gray.shape
+        (w1, b1), (w2, b2), (w3, b3), (w4, b4) = (fold(sd, f"block1.{i}") for i in range(4))
+        kc = lambda t: t.permute(1, 2, 3, 0).reshape(-1).contiguous()
+        pad = lambda t: torch.cat([t.reshape(-1), torch.zeros(32 - t.numel())])
+        out = subprocess.run([emu_bins["block1_emu"]], input=_blob([B, H, W, 5], [gray, coef, kc(w1), b1, kc(w2), b2, kc(w3), b3, kc(w4), pad(b4), pad(sd["skip1.1.weight"].float()),
+                                                                                   pad(sd["skip1.1.bias"].float())]), capture_output=True, check=True, timeout=600).stdout
+        return torch.from_numpy(np.frombuffer(out, np.float32).reshape(B, 24, H // 4, W // 4).copy())
+
+    def run_kp_head(sd, gray, coef):
+        B, H, W = gray.shape
+        ws, bs = zip(*[(w.view(64, 64), b) for w, b in (fold(sd, f"keypoint_head.{i}") for i in range(3))])
+        ws, bs = list(ws) + [sd["keypoint_head.3.weight"].view(65, 64).float()], list(bs) + [sd["keypoint_head.3.bias"].float()]
+        out = subprocess.run([emu_bins["head_emu"]], input=_blob([1, B, H, W], [gray, coef] + ws + bs), capture_output=True, check=True, timeout=600).stdout
+        return torch.from_numpy(np.frombuffer(out[:4 * B * H * W], np.float32).reshape(B, 1, H, W).copy())
+
+    def run_rel_head(sd, feats):
+        B, _, h, w = feats.shape
+        cl = feats.permute(0, 2, 3, 1).reshape(-1, 64).contiguous()
+        ws, bs = zip(*[(w_.view(64, 64), b_) for w_, b_ in (fold(sd, f"heatmap_head.{i}") for i in range(2))])
+        out = subprocess.run([emu_bins["head_emu"]], input=_blob([0, len(cl), 0, 0], [cl] + list(ws) + [sd["heatmap_head.2.weight"].view(64).float()] + list(bs) +
+                                                                 [sd["heatmap_head.2.bias"].float()]), capture_output=True, check=True, timeout=600).stdout
+        return torch.from_numpy(np.frombuffer(out[:4 * len(cl)], np.float32).reshape(B, 1, h, w).copy())
+
+    def middle(sd, x1):      # block2 .. block_fusion.2 (modules/model.py:141-150), the oracle's own layers
+        a = O._basic(sd, "block2.1", O._basic(sd, "block2.0", x1))
+        x3 = O._basic(sd, "block3.2", O._basic(sd, "block3.1", O._basic(sd, "block3.0", a, 2)), 1, 1)
+        x4 = O._basic(sd, "block4.2", O._basic(sd, "block4.1", O._basic(sd, "block4.0", x3, 2)))
+        x5 = O._basic(sd, "block5.3", O._basic(sd, "block5.2", O._basic(sd, "block5.1", O._basic(sd, "block5.0", x4, 2))), 1, 1)
+        hw = tuple(x3.shape[-2:])
+        f = x3 + F.interpolate(x4, hw, mode="bilinear") + F.interpolate(x5, hw, mode="bilinear")
+        return O._plain(sd, "block_fusion.2", O._basic(sd, "block_fusion.1", O._basic(sd, "block_fusion.0", f)))
+
+    def detect(feats, heat, rel, top_k, H, W):      # modules/xfeat.py:70-96 on given maps, with the oracle's pieces
+        B = feats.shape[0]
+        fn = F.normalize(feats, dim=1)
+        mk = O.pad_keypoints(O.nms(heat, 0.05, 5))
+        scores = torch.stack([O.sample_nearest(heat[b], mk[b], H, W)[:, 0] * O.sample_bilinear(rel[b], mk[b], H, W)[:, 0] for b in range(B)])
+        scores[torch.all(mk == 0, dim=-1)] = -1
+        order = torch.argsort(-scores)
+        mk = torch.gather(mk, 1, order[..., None].expand(-1, -1, 2))[:, :top_k]
+        scores = torch.gather(scores, 1, order)[:, :top_k]
+        desc = F.normalize(torch.stack([O.sample_bicubic(fn[b], mk[b], H, W) for b in range(B)]), dim=-1)
+        return [{"keypoints": mk[b][scores[b] > 0].float(), "scores": scores[b][scores[b] > 0], "descriptors": desc[b][scores[b] > 0]} for b in range(B)]
+
+    sd = fixtures.synthetic_state_dict(0)
+    with torch.inference_mode():
+        for which in ("g1_small", "g2_vga_pair"):
+            g = np.load(os.path.join(ROOT, "tests", "golden", which + ".npz"))
+            if which == "g1_small":
+                x, top_k = fixtures.texture_images(2, 96, 128, seed=11), 256
+                gold = [{k: g[f"{k}{b}"] for k in ("keypoints", "scores", "descriptors")} for b in range(2)]
+            else:
+                x, top_k = torch.cat(fixtures.shifted_pair(1, 480, 640, seed=7)), 4096
+                gold = [{"keypoints": g[f"kp_{t}"].astype(np.float32), "scores": g[f"sc_{t}"]} for t in ("a", "b")]
+            B, _, H, W = x.shape
+            gray = x.mean(1)
+            gd = gray.double()
+            alpha = 1.0 / torch.sqrt(gd.var((1, 2), unbiased=False) + 1e-5)               # InstanceNorm2d(1) as x * alpha + beta   (modules/model.py:35,136)
+            coef = torch.stack([alpha, -gd.mean((1, 2)) * alpha], 1).float()
+            _, _, _, taps = O.backbone(sd, x, keep=True)
+            oheat = O.kpts_heatmap(taps["logits"])
+            x1 = run_block1(sd, gray, coef)
+            feats = middle(sd, x1)
+            rel, heat = run_rel_head(sd, feats), run_kp_head(sd, gray, coef)
+            e = {"x1": float((x1 - taps["x1"]).abs().max()), "feats": float((feats - taps["feats"]).abs().max()),
+                 "rel": float((rel - taps["reliability"]).abs().max()), "heat": float((heat - oheat).abs().max())}
+            print(which, e)
+            assert e["x1"] <= 2e-5 and e["feats"] <= 1e-4 and e["rel"] <= 3e-5 and e["heat"] <= 1e-5, e      # the GPU suite's tolerances against the oracle
+            for b, out in enumerate(detect(feats, heat, rel, top_k, H, W)):
+                gd_, t = dict(gold[b]), dict(out)
+                if "descriptors" not in gd_:      # (g2 holds every 8th descriptor row only: the lists are compared)
+                    gd_["descriptors"] = np.zeros((len(gd_["keypoints"]), 64), np.float32); t["descriptors"] = torch.zeros(len(t["keypoints"]), 64)
+                rep = parity.compare_keypoints(t, gd_, heat=oheat[b, 0])      # raises on anything that is not a tie in the reference's own maps
+                print(which, "image", b, rep)
+                assert rep["common"] == rep["n_ref"] == top_k and rep["exceptions"] == 0, rep
+                assert rep.get("rank_moved", 0) <= 64 and rep.get("rank_moved_maxgap", 0.0) <= 5e-6, rep
+
