@@ -268,11 +268,17 @@ def test_conv_bx24_kernels_on_the_host(emu_bins, stride, fx, shape, grid):
     assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0 and np.isfinite(y).all() and d.max() <= 3e-6 * float(ref.abs().max())
 
 
-def test_shipped_block1_and_heads_on_the_host_keep_the_references_key_points(emu_bins):
+@pytest.mark.parametrize("which,convs", [("g1_small", False), ("g2_vga_pair", False), ("g1_small", True),
+                                         pytest.param("g2_vga_pair", True, marks=pytest.mark.skipif(not os.environ.get("XFH_EMU_VGA"), reason="ten minutes of emulation: XFH_EMU_VGA=1 (log: profiles/r04_emulated_end_to_end_vga.txt)"))])
+def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, which, convs):
     """The three sliced kernels END TO END against the reference-made goldens, without a GPU: block1_fused_kernel<5> and both default heads run in the host emulation on the
     golden fixtures' images and weights (BatchNorm folded here the way xfh_create folds it), everything between and after them (block2 .. feats; NMS, scores, top-k,
     descriptors) is the oracle's fp32 restatement, and the key-point lists are compared -- by the GPU suite's own comparator -- with what the UNMODIFIED reference wrote into
-    tests/golden/ (g1_small: 2 x 256 key-points; g2_vga_pair: 2 x 4096 at VGA).  The same key-point SET as the reference; rank moves only among scores a few ulps apart."""
+    tests/golden/ (g1_small: 2 x 256 key-points; g2_vga_pair: 2 x 4096 at VGA).  The same key-point SET as the reference; rank moves only among scores a few ulps apart.
+    With `convs` the split-operand convolution kernels join in the routing of the bench batch (fp16-pair arithmetic): block2.0 / 2.1 and block3.0 (conv_bx_kernel<24, 24>,
+    conv_bxs2_kernel<24>), block3.1 + 3.2, block4.1, block4.2, block_fusion.0, block_fusion.1 + .2 (conv_bx64_kernel, all three fused forms), block4.0 and block5.0
+    (conv_bx64s2_kernel) -- 14 of the 17 convolution layers of the path plus block1 and the heads as sliced product source; what stays with the oracle is block5.1 - 5.3
+    (Winograd on f32 MFMAs: not under the emulation), the pyramid sum and the detection."""
     import sys
     import torch.nn.functional as F
     sys.path.insert(0, ROOT)
@@ -309,6 +315,32 @@ def test_shipped_block1_and_heads_on_the_host_keep_the_references_key_points(emu
                                                                  [sd["heatmap_head.2.bias"].float()]), capture_output=True, check=True, timeout=600).stdout
         return torch.from_numpy(np.frombuffer(out[:4 * len(cl)], np.float32).reshape(B, 1, h, w).copy())
 
+    def conv_emu(kind, hdr, x, tensors, shape, status=True, cl=False):
+        out = subprocess.run([emu_bins[kind]], input=_blob(hdr, [x] + tensors), capture_output=True, check=True, timeout=3000).stdout
+        if status:
+            assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0, (kind, hdr)
+            out = out[:-4]
+        y = torch.from_numpy(np.frombuffer(out, np.float32).copy())
+        return y.view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2).contiguous() if cl else y.view(shape)
+
+    def middle_emulated(sd, x1):      # the same layers on the sliced kernels; grids chosen so that workgroups walk several tiles / units
+        B, _, H4, W4 = x1.shape
+        H8, W8, H16, W16, H32, W32 = H4 // 2, W4 // 2, H4 // 4, W4 // 4, H4 // 8, W4 // 8
+        a = conv_emu("conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], x1, list(fold(sd, "block2.0")), (B, 24, H4, W4))
+        a = conv_emu("conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], a, list(fold(sd, "block2.1")), (B, 24, H4, W4))
+        x3 = conv_emu("conv_bx24_emu", [B, H4, W4, 2, 1, 1, 5], a, list(fold(sd, "block3.0")), (B, 64, H8, W8))
+        w2, b2 = fold(sd, "block3.2")
+        x3 = conv_emu("conv_bx64_emu", [B, H8, W8, 1, 1, 1, 1, 5], x3, list(fold(sd, "block3.1")) + [w2.view(64, 64), b2], (B, 64, H8, W8))      # + the 1x1 BasicLayer (ReLU) fused
+        x4 = conv_emu("conv_bx64s2_emu", [B, H8, W8, 64, 1, 3], x3, list(fold(sd, "block4.0")), (B, 64, H16, W16), status=False)
+        x4 = conv_emu("conv_bx64_emu", [B, H16, W16, 0, 1, 1, 0, 3], x4, list(fold(sd, "block4.1")), (B, 64, H16, W16))
+        x4 = conv_emu("conv_bx64_emu", [B, H16, W16, 0, 1, 1, 0, 3], x4, list(fold(sd, "block4.2")), (B, 64, H16, W16))
+        x5 = conv_emu("conv_bx64s2_emu", [B, H16, W16, 128, 1, 2], x4, list(fold(sd, "block5.0")), (B, 128, H32, W32), status=False)
+        x5 = O._basic(sd, "block5.3", O._basic(sd, "block5.2", O._basic(sd, "block5.1", x5)), 1, 1)
+        f = x3 + F.interpolate(x4, (H8, W8), mode="bilinear") + F.interpolate(x5, (H8, W8), mode="bilinear")
+        f = conv_emu("conv_bx64_emu", [B, H8, W8, 0, 1, 1, 0, 5], f, list(fold(sd, "block_fusion.0")), (B, 64, H8, W8))
+        return conv_emu("conv_bx64_emu", [B, H8, W8, 2, 1, 1, 0, 5], f, list(fold(sd, "block_fusion.1")) + [sd["block_fusion.2.weight"].view(64, 64).float(), sd["block_fusion.2.bias"].float()],
+                        (B, 64, H8, W8), cl=True)      # + the plain 1x1 fused, channels-last output (= feats as the samplers read them)
+
     def middle(sd, x1):      # block2 .. block_fusion.2 (modules/model.py:141-150), the oracle's own layers
         a = O._basic(sd, "block2.1", O._basic(sd, "block2.0", x1))
         x3 = O._basic(sd, "block3.2", O._basic(sd, "block3.1", O._basic(sd, "block3.0", a, 2)), 1, 1)
@@ -332,7 +364,7 @@ def test_shipped_block1_and_heads_on_the_host_keep_the_references_key_points(emu
 
     sd = fixtures.synthetic_state_dict(0)
     with torch.inference_mode():
-        for which in ("g1_small", "g2_vga_pair"):
+        for which in (which,):
             g = np.load(os.path.join(ROOT, "tests", "golden", which + ".npz"))
             if which == "g1_small":
                 x, top_k = fixtures.texture_images(2, 96, 128, seed=11), 256
@@ -348,11 +380,11 @@ def test_shipped_block1_and_heads_on_the_host_keep_the_references_key_points(emu
             _, _, _, taps = O.backbone(sd, x, keep=True)
             oheat = O.kpts_heatmap(taps["logits"])
             x1 = run_block1(sd, gray, coef)
-            feats = middle(sd, x1)
+            feats = middle_emulated(sd, x1) if convs else middle(sd, x1)
             rel, heat = run_rel_head(sd, feats), run_kp_head(sd, gray, coef)
             e = {"x1": float((x1 - taps["x1"]).abs().max()), "feats": float((feats - taps["feats"]).abs().max()),
                  "rel": float((rel - taps["reliability"]).abs().max()), "heat": float((heat - oheat).abs().max())}
-            print(which, e)
+            print(which, "convolutions emulated" if convs else "convolutions: oracle", e)
             assert e["x1"] <= 2e-5 and e["feats"] <= 1e-4 and e["rel"] <= 3e-5 and e["heat"] <= 1e-5, e      # the GPU suite's tolerances against the oracle
             for b, out in enumerate(detect(feats, heat, rel, top_k, H, W)):
                 gd_, t = dict(gold[b]), dict(out)
