@@ -1,6 +1,7 @@
-"""Shipped kernels compiled for the HOST and run against float64 references without a GPU: block1_fused_kernel<5> (the dominant kernel) and
-head_f32r_kernel<KP> (the default heads).  The kernel source is SLICED out of the product files (csrc/k_conv_direct.hip, csrc/k_heads.hip -- nothing in them is
-changed for this) and compiled with the host clang against tests/emu/emu.hpp: one host thread per work-item, LDS as a buffer (initialised to NaN patterns),
+"""Shipped kernels compiled for the HOST and run against float64 references without a GPU: block1_fused_kernel<5> (the dominant kernel), head_f32r_kernel<KP> (the
+default heads) and every convolution kernel of the default path (conv_bx_kernel<24, 24>, conv_bxs2_kernel<24>, conv_bx64_kernel, conv_bx64s2_kernel, conv_wino_kernel) --
+alone, and chained END TO END against the key-points the unmodified reference wrote into tests/golden/.  The kernel source is SLICED out of the product files (csrc/k_*.hip --
+nothing in them is changed for this) and compiled with the host clang against tests/emu/emu.hpp: one host thread per work-item, LDS as a buffer (initialised to NaN patterns),
 __syncthreads a barrier, the LDS-DMA a copy, v_mfma_f32_32x32x2_f32 and the lane exchanges emulated.  What it checks: index arithmetic, tile and weight layouts,
 partial tiles, the barrier structure; what it cannot: timing, memory ordering, hardware hazards (the GPU suite and the soaks do that).  The slicing is by markers
 in the source: a change there that moves them fails this test loudly instead of silently testing something else."""
@@ -89,6 +90,26 @@ def _slice_conv_bx64s2():
     return "typedef int i32x4 __attribute__((ext_vector_type(4)));\n" + s
 
 
+def _slice_conv_wino():
+    """conv_wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: input planes and transformed weights by LDS-DMA into a two-slot ring, output transform through an LDS
+    exchange, optional trailing 1x1 with a K-split reduction across waves): the three DMA forms become emulator calls, the LDS address a byte offset"""
+    t = open(os.path.join(CSRC, "k_conv_wino.hip")).read()
+    s = _between(t, "struct WinoArgs {", "// ------------------------------------------------------------------------------------------\n// host side")
+    s = _must_sub(s, "__global__ __launch_bounds__(256 * (CB / NCBW) * (TBG / NTBW)) __attribute__((amdgpu_waves_per_eu(2, 2)))\nvoid conv_wino_kernel(WinoArgs a) {", "inline void conv_wino_kernel(WinoArgs a) {")
+    s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) float smem[];", "XFH_DYN_LDS(smem);")
+    s = _must_sub(s, "auto lds_addr = [](const float* p) { return (unsigned)(size_t)(lptr_t)p; };", "auto lds_addr = [&](const float* p) { return (unsigned)((p - smem) * 4); };")
+    n0 = s.count("asm volatile")
+    s = _must_sub(s, 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(uvoff), "s"(rs_u), "s"(soff) : "memory");', "emu::dma_b128_to_lds(m0v, uvoff, rs_u, soff);")
+    s = _must_sub(s, 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(m0v), "v"(xvoff[s]), "s"(rin), "s"(soff) : "memory");', "emu::dma_b32_to_lds(m0v, xvoff[s], rin, soff);")
+    s = _must_sub(s, 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(uvoff), "s"(rs_w2), "s"(soff) : "memory");', "emu::dma_b128_to_lds(m0v, uvoff, rs_w2, soff);")
+    s = s.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', ";")
+    s = re.sub(r'unsigned (\w+); asm volatile\("s_getreg_b32[^;]*;', r"unsigned \1 = 0;", s)      # (the trace's XCC / hardware ids: a.trace is NULL here)
+    assert n0 == 6 and "asm volatile" not in s, "an inline-assembly statement of conv_wino_kernel is not covered"
+    assert "<<<" not in s
+    s = s.replace("#define XFH_PIN __builtin_amdgcn_sched_barrier(0)", "#undef XFH_PIN\n#define XFH_PIN __builtin_amdgcn_sched_barrier(0)")
+    return "typedef float f32x16 __attribute__((ext_vector_type(16)));\ntypedef int i32x4 __attribute__((ext_vector_type(4)));\n#define __builtin_amdgcn_s_memrealtime() 0ll\n" + s
+
+
 def _slice_conv_bx24():
     """conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0): weights in registers, one staged halo tile per output tile"""
     t = open(os.path.join(CSRC, "k_conv_bx.hip")).read()
@@ -127,10 +148,11 @@ def emu_bins():
     open(os.path.join(td, "conv_bx64_slice.hpp"), "w").write(_slice_conv_bx64())
     open(os.path.join(td, "conv_bx64s2_slice.hpp"), "w").write(_slice_conv_bx64s2())
     open(os.path.join(td, "conv_bx24_slice.hpp"), "w").write(_slice_conv_bx24())
+    open(os.path.join(td, "conv_wino_slice.hpp"), "w").write(_slice_conv_wino())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu", "conv_bx24_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu", "conv_bx24_emu", "conv_wino_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -268,6 +290,28 @@ def test_conv_bx24_kernels_on_the_host(emu_bins, stride, fx, shape, grid):
     assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0 and np.isfinite(y).all() and d.max() <= 3e-6 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("cin,fuse,shape,tall", [(64, 0, (1, 8, 16), 0), (64, 1, (2, 9, 13), 1), (64, 2, (1, 16, 8), 1), (128, 0, (1, 6, 10), 0), (128, 1, (2, 15, 20), 0), (128, 0, (1, 15, 20), 1)])
+def test_conv_wino_kernel_on_the_host(emu_bins, cin, fuse, shape, tall):
+    """Winograd F(2x2,3x3) on the f32 matrix cores (block5.1, block5.2 + 5.3 on the default path; every >= 64-channel 3x3/s1 layer under option wino): 64 and 128 channels, alone and
+    with the trailing 1x1 fused (NCHW / channels-last output, the K-split reduction across two or four waves), both tile-region shapes, full and partial regions, odd sizes"""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(cin + fuse)
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g)) * 2
+    w = torch.randn(cin, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cin, generator=g) * 0.3
+    w2 = torch.randn(64, cin, generator=g) / cin ** 0.5
+    b2 = torch.randn(64, generator=g) * 0.3
+    out = subprocess.run([emu_bins["conv_wino_emu"]], input=_blob([B, H, W, cin, fuse, 1, 0, tall], [x, w, b] + ([w2, b2] if fuse else [])), capture_output=True, check=True, timeout=600).stdout
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if fuse:
+        ref = torch.nn.functional.conv2d(ref, w2.double().view(64, cin, 1, 1), b2.double())
+    y = np.frombuffer(out, np.float32)
+    y = y.reshape(B, H, W, 64).transpose(0, 3, 1, 2) if fuse == 2 else y.reshape(tuple(ref.shape))
+    d = np.abs(y - ref.numpy())
+    print(f"conv_wino cin {cin} fuse {fuse} {shape} tall {tall}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert np.isfinite(y).all() and d.max() <= 1e-6 * float(ref.abs().max())      # (Winograd's transforms cost a few ulps: DESIGN 3.2)
+
+
 @pytest.mark.parametrize("which,convs", [("g1_small", False), ("g2_vga_pair", False), ("g1_small", True),
                                          pytest.param("g2_vga_pair", True, marks=pytest.mark.skipif(not os.environ.get("XFH_EMU_VGA"), reason="ten minutes of emulation: XFH_EMU_VGA=1 (log: profiles/r04_emulated_end_to_end_vga.txt)"))])
 def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, which, convs):
@@ -277,8 +321,8 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
     tests/golden/ (g1_small: 2 x 256 key-points; g2_vga_pair: 2 x 4096 at VGA).  The same key-point SET as the reference; rank moves only among scores a few ulps apart.
     With `convs` the split-operand convolution kernels join in the routing of the bench batch (fp16-pair arithmetic): block2.0 / 2.1 and block3.0 (conv_bx_kernel<24, 24>,
     conv_bxs2_kernel<24>), block3.1 + 3.2, block4.1, block4.2, block_fusion.0, block_fusion.1 + .2 (conv_bx64_kernel, all three fused forms), block4.0 and block5.0
-    (conv_bx64s2_kernel) -- 14 of the 17 convolution layers of the path plus block1 and the heads as sliced product source; what stays with the oracle is block5.1 - 5.3
-    (Winograd on f32 MFMAs: not under the emulation), the pyramid sum and the detection."""
+    (conv_bx64s2_kernel), block5.1 and block5.2 + 5.3 (conv_wino_kernel) -- ALL 17 convolution layers of the path behind block1, plus block1 and the heads, as sliced product
+    source; what stays with the oracle is the pyramid sum (bilinear up-sampling + add) and the detection."""
     import sys
     import torch.nn.functional as F
     sys.path.insert(0, ROOT)
@@ -335,7 +379,10 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
         x4 = conv_emu("conv_bx64_emu", [B, H16, W16, 0, 1, 1, 0, 3], x4, list(fold(sd, "block4.1")), (B, 64, H16, W16))
         x4 = conv_emu("conv_bx64_emu", [B, H16, W16, 0, 1, 1, 0, 3], x4, list(fold(sd, "block4.2")), (B, 64, H16, W16))
         x5 = conv_emu("conv_bx64s2_emu", [B, H16, W16, 128, 1, 2], x4, list(fold(sd, "block5.0")), (B, 128, H32, W32), status=False)
-        x5 = O._basic(sd, "block5.3", O._basic(sd, "block5.2", O._basic(sd, "block5.1", x5)), 1, 1)
+        tall = int(-(-((H32 + 1) // 2) // 8) * -(-((W32 + 1) // 2) // 4) < -(-((H32 + 1) // 2) // 4) * -(-((W32 + 1) // 2) // 8))      # launch_conv_wino's choice of the tile region
+        x5 = conv_emu("conv_wino_emu", [B, H32, W32, 128, 0, 1, 0, tall], x5, list(fold(sd, "block5.1")), (B, 128, H32, W32), status=False)
+        w2, b2 = fold(sd, "block5.3")
+        x5 = conv_emu("conv_wino_emu", [B, H32, W32, 128, 1, 1, 1, tall], x5, list(fold(sd, "block5.2")) + [w2.view(64, 128), b2], (B, 64, H32, W32), status=False)      # + block5.3 (1x1 BasicLayer) fused
         f = x3 + F.interpolate(x4, (H8, W8), mode="bilinear") + F.interpolate(x5, (H8, W8), mode="bilinear")
         f = conv_emu("conv_bx64_emu", [B, H8, W8, 0, 1, 1, 0, 5], f, list(fold(sd, "block_fusion.0")), (B, 64, H8, W8))
         return conv_emu("conv_bx64_emu", [B, H8, W8, 2, 1, 1, 0, 5], f, list(fold(sd, "block_fusion.1")) + [sd["block_fusion.2.weight"].view(64, 64).float(), sd["block_fusion.2.bias"].float()],
