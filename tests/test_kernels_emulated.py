@@ -110,6 +110,17 @@ def _slice_conv_wino():
     return "typedef float f32x16 __attribute__((ext_vector_type(16)));\ntypedef int i32x4 __attribute__((ext_vector_type(4)));\n#define __builtin_amdgcn_s_memrealtime() 0ll\n" + s
 
 
+def _slice_pyramid():
+    """pyramid_sum_kernel (x3 + up(x4) + up(x5): source planes and per-plane coefficient tables in LDS) with the interpolation helpers it shares with the resize kernels"""
+    t = open(os.path.join(CSRC, "k_preproc.hip")).read()
+    s = _between(t, "__device__ inline void lin_coef(", "__global__ __launch_bounds__(256) void resize_bilinear_kernel(")
+    s += _between(t, "__device__ inline float bilerp_at(", "void launch_pyramid_sum(")
+    s = _must_sub(s, "__global__ __launch_bounds__(256) void pyramid_sum_kernel(", "inline void pyramid_sum_kernel(")
+    s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) float sm[];", "XFH_DYN_LDS(sm);")
+    assert "asm volatile" not in s and "<<<" not in s
+    return s
+
+
 def _slice_conv_bx24():
     """conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0): weights in registers, one staged halo tile per output tile"""
     t = open(os.path.join(CSRC, "k_conv_bx.hip")).read()
@@ -149,10 +160,11 @@ def emu_bins():
     open(os.path.join(td, "conv_bx64s2_slice.hpp"), "w").write(_slice_conv_bx64s2())
     open(os.path.join(td, "conv_bx24_slice.hpp"), "w").write(_slice_conv_bx24())
     open(os.path.join(td, "conv_wino_slice.hpp"), "w").write(_slice_conv_wino())
+    open(os.path.join(td, "pyramid_slice.hpp"), "w").write(_slice_pyramid())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu", "conv_bx24_emu", "conv_wino_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -312,6 +324,23 @@ def test_conv_wino_kernel_on_the_host(emu_bins, cin, fuse, shape, tall):
     assert np.isfinite(y).all() and d.max() <= 1e-6 * float(ref.abs().max())      # (Winograd's transforms cost a few ulps: DESIGN 3.2)
 
 
+@pytest.mark.parametrize("shape,use_lds", [((3, 12, 16), 1), ((2, 60, 80), 1), ((2, 9, 14), 1), ((2, 12, 16), 0), ((1, 10, 13), 0)])
+def test_pyramid_sum_kernel_on_the_host(emu_bins, shape, use_lds):
+    """x3 + up(x4) + up(x5) (modules/model.py:146-148: F.interpolate bilinear, align_corners=False): planes whose width is / is not a multiple of four (float4 / scalar path),
+    the LDS-staged form with its coefficient tables and the direct-gather fall-back, against ATen in float64"""
+    planes, H3, W3 = shape
+    H4, W4, H5, W5 = (H3 + 1) // 2, (W3 + 1) // 2, (H3 + 3) // 4, (W3 + 3) // 4
+    g = torch.Generator().manual_seed(H3 * W3)
+    x3, x4, x5 = torch.randn(1, planes, H3, W3, generator=g), torch.randn(1, planes, H4, W4, generator=g), torch.randn(1, planes, H5, W5, generator=g)
+    out = subprocess.run([emu_bins["pyramid_emu"]], input=_blob([planes, H3, W3, H4, W4, H5, W5, use_lds], [x3, x4, x5]), capture_output=True, check=True, timeout=240).stdout
+    F = torch.nn.functional
+    ref = x3.double() + F.interpolate(x4.double(), (H3, W3), mode="bilinear") + F.interpolate(x5.double(), (H3, W3), mode="bilinear")
+    y = np.frombuffer(out, np.float32).reshape(1, planes, H3, W3)
+    d = np.abs(y - ref.numpy())
+    print(f"pyramid_sum {shape} lds {use_lds}: max |err| {d.max():.3g}")
+    assert np.isfinite(y).all() and d.max() <= 2e-6
+
+
 @pytest.mark.parametrize("which,convs", [("g1_small", False), ("g2_vga_pair", False), ("g1_small", True),
                                          pytest.param("g2_vga_pair", True, marks=pytest.mark.skipif(not os.environ.get("XFH_EMU_VGA"), reason="ten minutes of emulation: XFH_EMU_VGA=1 (log: profiles/r04_emulated_end_to_end_vga.txt)"))])
 def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, which, convs):
@@ -322,7 +351,7 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
     With `convs` the split-operand convolution kernels join in the routing of the bench batch (fp16-pair arithmetic): block2.0 / 2.1 and block3.0 (conv_bx_kernel<24, 24>,
     conv_bxs2_kernel<24>), block3.1 + 3.2, block4.1, block4.2, block_fusion.0, block_fusion.1 + .2 (conv_bx64_kernel, all three fused forms), block4.0 and block5.0
     (conv_bx64s2_kernel), block5.1 and block5.2 + 5.3 (conv_wino_kernel) -- ALL 17 convolution layers of the path behind block1, plus block1 and the heads, as sliced product
-    source; what stays with the oracle is the pyramid sum (bilinear up-sampling + add) and the detection."""
+    source, and pyramid_sum_kernel between them: the whole network behind the gray image; what stays with the oracle is the detection (NMS, scores, top-k, descriptors)."""
     import sys
     import torch.nn.functional as F
     sys.path.insert(0, ROOT)
@@ -383,7 +412,7 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
         x5 = conv_emu("conv_wino_emu", [B, H32, W32, 128, 0, 1, 0, tall], x5, list(fold(sd, "block5.1")), (B, 128, H32, W32), status=False)
         w2, b2 = fold(sd, "block5.3")
         x5 = conv_emu("conv_wino_emu", [B, H32, W32, 128, 1, 1, 1, tall], x5, list(fold(sd, "block5.2")) + [w2.view(64, 128), b2], (B, 64, H32, W32), status=False)      # + block5.3 (1x1 BasicLayer) fused
-        f = x3 + F.interpolate(x4, (H8, W8), mode="bilinear") + F.interpolate(x5, (H8, W8), mode="bilinear")
+        f = conv_emu("pyramid_emu", [B * 64, H8, W8, H16, W16, H32, W32, 1], x3, [x4, x5], (B, 64, H8, W8), status=False)      # pyramid_sum_kernel (modules/model.py:146-148)
         f = conv_emu("conv_bx64_emu", [B, H8, W8, 0, 1, 1, 0, 5], f, list(fold(sd, "block_fusion.0")), (B, 64, H8, W8))
         return conv_emu("conv_bx64_emu", [B, H8, W8, 2, 1, 1, 0, 5], f, list(fold(sd, "block_fusion.1")) + [sd["block_fusion.2.weight"].view(64, 64).float(), sd["block_fusion.2.bias"].float()],
                         (B, 64, H8, W8), cl=True)      # + the plain 1x1 fused, channels-last output (= feats as the samplers read them)
