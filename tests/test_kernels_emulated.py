@@ -121,6 +121,20 @@ def _slice_pyramid():
     return s
 
 
+def _slice_gray():
+    """gray_stats_kernel<CT> (channel mean + fp64 partial sums per chunk) and gray_coef_kernel (the instance normalisation as {alpha, beta} per image): the 2-D grid becomes a
+    1-D one, the static LDS array a pointer into the emulator's LDS"""
+    t = open(os.path.join(CSRC, "k_preproc.hip")).read()
+    s = _between(t, "constexpr int GS_UNROLL = 5;", "// uint8 ingest (XFeat.parse_input")
+    s += _between(t, "__global__ __launch_bounds__(64) void gray_coef_kernel(", "void launch_gray_norm(")
+    s = _must_sub(s, "__global__ __launch_bounds__(256) void gray_stats_kernel(", "inline void gray_stats_kernel(")
+    s = _must_sub(s, "__global__ __launch_bounds__(64) void gray_coef_kernel(", "inline void gray_coef_kernel(")
+    s = _must_sub(s, "const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;", "const int b = blockIdx.x / GS_CHUNKS, ch = blockIdx.x % GS_CHUNKS, tid = threadIdx.x;")
+    s = _must_sub(s, "__shared__ double sm[8];", "double* sm = reinterpret_cast<double*>(emu::wg->lds_base());")
+    assert "asm volatile" not in s and "<<<" not in s and "blockIdx.y" not in s
+    return s
+
+
 def _slice_conv_bx24():
     """conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0): weights in registers, one staged halo tile per output tile"""
     t = open(os.path.join(CSRC, "k_conv_bx.hip")).read()
@@ -161,10 +175,11 @@ def emu_bins():
     open(os.path.join(td, "conv_bx24_slice.hpp"), "w").write(_slice_conv_bx24())
     open(os.path.join(td, "conv_wino_slice.hpp"), "w").write(_slice_conv_wino())
     open(os.path.join(td, "pyramid_slice.hpp"), "w").write(_slice_pyramid())
+    open(os.path.join(td, "gray_slice.hpp"), "w").write(_slice_gray())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx64_emu", "conv_bx64s2_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu", "gray_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -341,6 +356,23 @@ def test_pyramid_sum_kernel_on_the_host(emu_bins, shape, use_lds):
     assert np.isfinite(y).all() and d.max() <= 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 96, 128), (1, 1, 64, 96), (2, 2, 32, 40), (1, 3, 480, 640)])
+def test_gray_stats_kernels_on_the_host(emu_bins, shape):
+    """x.mean(1) and InstanceNorm2d(1) (modules/model.py:135-136, 35) as the raw gray image + a per-image {alpha, beta}: three, one and "any" channels (the three instantiations),
+    chunks that end inside a 256-thread row, VGA -- against float64"""
+    B, C, H, W = shape
+    x = torch.rand(B, C, H, W, generator=torch.Generator().manual_seed(C * H)) * 3 - 1
+    out = subprocess.run([emu_bins["gray_emu"]], input=_blob([B, C, H, W], [x]), capture_output=True, check=True, timeout=240).stdout
+    gray = np.frombuffer(out[:4 * B * H * W], np.float32).reshape(B, H, W)
+    coef = np.frombuffer(out[4 * B * H * W:], np.float32).reshape(B, 2)
+    gd = x.double().mean(1)
+    alpha = 1.0 / torch.sqrt(gd.var((1, 2), unbiased=False) + 1e-5)
+    ref = torch.stack([alpha, -gd.mean((1, 2)) * alpha], 1).numpy()
+    e_g, e_c = float(np.abs(gray - gd.numpy()).max()), float(np.abs(coef / ref - 1).max())
+    print(f"gray_stats {shape}: gray max |err| {e_g:.3g}, coef max rel err {e_c:.3g}")
+    assert np.isfinite(gray).all() and e_g <= 3e-7 and e_c <= 1e-6      # (gray: an fp32 sum of C values and one division)
+
+
 @pytest.mark.parametrize("which,convs", [("g1_small", False), ("g2_vga_pair", False), ("g1_small", True),
                                          pytest.param("g2_vga_pair", True, marks=pytest.mark.skipif(not os.environ.get("XFH_EMU_VGA"), reason="ten minutes of emulation: XFH_EMU_VGA=1 (log: profiles/r04_emulated_end_to_end_vga.txt)"))])
 def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, which, convs):
@@ -351,7 +383,7 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
     With `convs` the split-operand convolution kernels join in the routing of the bench batch (fp16-pair arithmetic): block2.0 / 2.1 and block3.0 (conv_bx_kernel<24, 24>,
     conv_bxs2_kernel<24>), block3.1 + 3.2, block4.1, block4.2, block_fusion.0, block_fusion.1 + .2 (conv_bx64_kernel, all three fused forms), block4.0 and block5.0
     (conv_bx64s2_kernel), block5.1 and block5.2 + 5.3 (conv_wino_kernel) -- ALL 17 convolution layers of the path behind block1, plus block1 and the heads, as sliced product
-    source, and pyramid_sum_kernel between them: the whole network behind the gray image; what stays with the oracle is the detection (NMS, scores, top-k, descriptors)."""
+    source, pyramid_sum_kernel between them and gray_stats_kernel + gray_coef_kernel in front: the whole network from the image to feats / heat / reliability; what stays with the oracle is the detection (NMS, scores, top-k, descriptors)."""
     import sys
     import torch.nn.functional as F
     sys.path.insert(0, ROOT)
@@ -448,11 +480,16 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
             else:
                 x, top_k = torch.cat(fixtures.shifted_pair(1, 480, 640, seed=7)), 4096
                 gold = [{"keypoints": g[f"kp_{t}"].astype(np.float32), "scores": g[f"sc_{t}"]} for t in ("a", "b")]
-            B, _, H, W = x.shape
-            gray = x.mean(1)
-            gd = gray.double()
-            alpha = 1.0 / torch.sqrt(gd.var((1, 2), unbiased=False) + 1e-5)               # InstanceNorm2d(1) as x * alpha + beta   (modules/model.py:35,136)
-            coef = torch.stack([alpha, -gd.mean((1, 2)) * alpha], 1).float()
+            B, Cc, H, W = x.shape
+            if convs:      # the front of the path too: gray_stats_kernel + gray_coef_kernel
+                o_ = subprocess.run([emu_bins["gray_emu"]], input=_blob([B, Cc, H, W], [x]), capture_output=True, check=True, timeout=600).stdout
+                gray = torch.from_numpy(np.frombuffer(o_[:4 * B * H * W], np.float32).reshape(B, H, W).copy())
+                coef = torch.from_numpy(np.frombuffer(o_[4 * B * H * W:], np.float32).reshape(B, 2).copy())
+            else:
+                gray = x.mean(1)
+                gd = gray.double()
+                alpha = 1.0 / torch.sqrt(gd.var((1, 2), unbiased=False) + 1e-5)               # InstanceNorm2d(1) as x * alpha + beta   (modules/model.py:35,136)
+                coef = torch.stack([alpha, -gd.mean((1, 2)) * alpha], 1).float()
             _, _, _, taps = O.backbone(sd, x, keep=True)
             oheat = O.kpts_heatmap(taps["logits"])
             x1 = run_block1(sd, gray, coef)
