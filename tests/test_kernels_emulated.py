@@ -373,7 +373,7 @@ def test_gray_stats_kernels_on_the_host(emu_bins, shape):
     assert np.isfinite(gray).all() and e_g <= 3e-7 and e_c <= 1e-6      # (gray: an fp32 sum of C values and one division)
 
 
-@pytest.mark.parametrize("which,convs", [("g1_small", False), ("g2_vga_pair", False), ("g1_small", True),
+@pytest.mark.parametrize("which,convs", [("g1_small", False), ("g2_vga_pair", False), ("g1_small", True), ("g1_small", "single"),
                                          pytest.param("g2_vga_pair", True, marks=pytest.mark.skipif(not os.environ.get("XFH_EMU_VGA"), reason="ten minutes of emulation: XFH_EMU_VGA=1 (log: profiles/r04_emulated_end_to_end_vga.txt)"))])
 def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, which, convs):
     """The three sliced kernels END TO END against the reference-made goldens, without a GPU: block1_fused_kernel<5> and both default heads run in the host emulation on the
@@ -383,7 +383,9 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
     With `convs` the split-operand convolution kernels join in the routing of the bench batch (fp16-pair arithmetic): block2.0 / 2.1 and block3.0 (conv_bx_kernel<24, 24>,
     conv_bxs2_kernel<24>), block3.1 + 3.2, block4.1, block4.2, block_fusion.0, block_fusion.1 + .2 (conv_bx64_kernel, all three fused forms), block4.0 and block5.0
     (conv_bx64s2_kernel), block5.1 and block5.2 + 5.3 (conv_wino_kernel) -- ALL 17 convolution layers of the path behind block1, plus block1 and the heads, as sliced product
-    source, pyramid_sum_kernel between them and gray_stats_kernel + gray_coef_kernel in front: the whole network from the image to feats / heat / reliability; what stays with the oracle is the detection (NMS, scores, top-k, descriptors)."""
+    source, pyramid_sum_kernel between them and gray_stats_kernel + gray_coef_kernel in front: the whole network from the image to feats / heat / reliability; what stays with the oracle is the detection (NMS, scores, top-k, descriptors).
+    convs = "single": the routing of a single frame or a small batch (the reference's headline use, realtime_demo.py) -- every 64 -> 64 3x3 layer on conv_wino_kernel (alone, with the
+    trailing 1x1 fused, channels-last) instead of conv_bx64_kernel, everything else as above."""
     import sys
     import torch.nn.functional as F
     sys.path.insert(0, ROOT)
@@ -428,9 +430,29 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
         y = torch.from_numpy(np.frombuffer(out, np.float32).copy())
         return y.view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2).contiguous() if cl else y.view(shape)
 
+    def wino_tall(H_, W_):      # launch_conv_wino's choice of the tile region (8 x 4 instead of 4 x 8 where that needs fewer workgroups)
+        return int(-(-((H_ + 1) // 2) // 8) * -(-((W_ + 1) // 2) // 4) < -(-((H_ + 1) // 2) // 4) * -(-((W_ + 1) // 2) // 8))
+
     def middle_emulated(sd, x1):      # the same layers on the sliced kernels; grids chosen so that workgroups walk several tiles / units
         B, _, H4, W4 = x1.shape
         H8, W8, H16, W16, H32, W32 = H4 // 2, W4 // 2, H4 // 4, W4 // 4, H4 // 8, W4 // 8
+        if convs == "single":      # the routing of a single frame or a small batch (api.hip: conv_mfma_checked with maps below the "large map" mark): every 64 -> 64 layer on Winograd
+            a = conv_emu("conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], x1, list(fold(sd, "block2.0")), (B, 24, H4, W4))
+            a = conv_emu("conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], a, list(fold(sd, "block2.1")), (B, 24, H4, W4))
+            x3 = conv_emu("conv_bx24_emu", [B, H4, W4, 2, 1, 1, 5], a, list(fold(sd, "block3.0")), (B, 64, H8, W8))
+            w2, b2 = fold(sd, "block3.2")
+            x3 = conv_emu("conv_wino_emu", [B, H8, W8, 64, 1, 1, 1, wino_tall(H8, W8)], x3, list(fold(sd, "block3.1")) + [w2.view(64, 64), b2], (B, 64, H8, W8), status=False)
+            x4 = conv_emu("conv_bx64s2_emu", [B, H8, W8, 64, 1, 3], x3, list(fold(sd, "block4.0")), (B, 64, H16, W16), status=False)
+            x4 = conv_emu("conv_wino_emu", [B, H16, W16, 64, 0, 1, 0, wino_tall(H16, W16)], x4, list(fold(sd, "block4.1")), (B, 64, H16, W16), status=False)
+            x4 = conv_emu("conv_wino_emu", [B, H16, W16, 64, 0, 1, 0, wino_tall(H16, W16)], x4, list(fold(sd, "block4.2")), (B, 64, H16, W16), status=False)
+            x5 = conv_emu("conv_bx64s2_emu", [B, H16, W16, 128, 1, 2], x4, list(fold(sd, "block5.0")), (B, 128, H32, W32), status=False)
+            x5 = conv_emu("conv_wino_emu", [B, H32, W32, 128, 0, 1, 0, wino_tall(H32, W32)], x5, list(fold(sd, "block5.1")), (B, 128, H32, W32), status=False)
+            w2, b2 = fold(sd, "block5.3")
+            x5 = conv_emu("conv_wino_emu", [B, H32, W32, 128, 1, 1, 1, wino_tall(H32, W32)], x5, list(fold(sd, "block5.2")) + [w2.view(64, 128), b2], (B, 64, H32, W32), status=False)
+            f = conv_emu("pyramid_emu", [B * 64, H8, W8, H16, W16, H32, W32, 1], x3, [x4, x5], (B, 64, H8, W8), status=False)
+            f = conv_emu("conv_wino_emu", [B, H8, W8, 64, 0, 1, 0, wino_tall(H8, W8)], f, list(fold(sd, "block_fusion.0")), (B, 64, H8, W8), status=False)
+            return conv_emu("conv_wino_emu", [B, H8, W8, 64, 2, 1, 0, wino_tall(H8, W8)], f, list(fold(sd, "block_fusion.1")) + [sd["block_fusion.2.weight"].view(64, 64).float(), sd["block_fusion.2.bias"].float()],
+                            (B, 64, H8, W8), status=False, cl=True)
         a = conv_emu("conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], x1, list(fold(sd, "block2.0")), (B, 24, H4, W4))
         a = conv_emu("conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], a, list(fold(sd, "block2.1")), (B, 24, H4, W4))
         x3 = conv_emu("conv_bx24_emu", [B, H4, W4, 2, 1, 1, 5], a, list(fold(sd, "block3.0")), (B, 64, H8, W8))
@@ -440,7 +462,7 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
         x4 = conv_emu("conv_bx64_emu", [B, H16, W16, 0, 1, 1, 0, 3], x4, list(fold(sd, "block4.1")), (B, 64, H16, W16))
         x4 = conv_emu("conv_bx64_emu", [B, H16, W16, 0, 1, 1, 0, 3], x4, list(fold(sd, "block4.2")), (B, 64, H16, W16))
         x5 = conv_emu("conv_bx64s2_emu", [B, H16, W16, 128, 1, 2], x4, list(fold(sd, "block5.0")), (B, 128, H32, W32), status=False)
-        tall = int(-(-((H32 + 1) // 2) // 8) * -(-((W32 + 1) // 2) // 4) < -(-((H32 + 1) // 2) // 4) * -(-((W32 + 1) // 2) // 8))      # launch_conv_wino's choice of the tile region
+        tall = wino_tall(H32, W32)
         x5 = conv_emu("conv_wino_emu", [B, H32, W32, 128, 0, 1, 0, tall], x5, list(fold(sd, "block5.1")), (B, 128, H32, W32), status=False)
         w2, b2 = fold(sd, "block5.3")
         x5 = conv_emu("conv_wino_emu", [B, H32, W32, 128, 1, 1, 1, tall], x5, list(fold(sd, "block5.2")) + [w2.view(64, 128), b2], (B, 64, H32, W32), status=False)      # + block5.3 (1x1 BasicLayer) fused
@@ -497,7 +519,7 @@ def test_shipped_kernels_on_the_host_keep_the_references_key_points(emu_bins, wh
             rel, heat = run_rel_head(sd, feats), run_kp_head(sd, gray, coef)
             e = {"x1": float((x1 - taps["x1"]).abs().max()), "feats": float((feats - taps["feats"]).abs().max()),
                  "rel": float((rel - taps["reliability"]).abs().max()), "heat": float((heat - oheat).abs().max())}
-            print(which, "convolutions emulated" if convs else "convolutions: oracle", e)
+            print(which, f"convolutions emulated ({convs})" if convs else "convolutions: oracle", e)
             assert e["x1"] <= 2e-5 and e["feats"] <= 1e-4 and e["rel"] <= 3e-5 and e["heat"] <= 1e-5, e      # the GPU suite's tolerances against the oracle
             for b, out in enumerate(detect(feats, heat, rel, top_k, H, W)):
                 gd_, t = dict(gold[b]), dict(out)
