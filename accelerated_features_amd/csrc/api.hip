@@ -2,6 +2,8 @@
 // launch sequences of the hot path.  No compute happens on the host; there is no CPU fallback.
 #include "../../include/xfeat_hip.h"
 #include "kernels.hpp"
+#include "weight_split.hpp"
+#include "block1_fx.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -245,69 +247,6 @@ static int check_ws(const void* ws, size_t have, size_t need) {
     return XFH_OK;
 }
 
-static uint16_t bf16_rne(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static float bf16_float(uint16_t h) {
-    const uint32_t u = (uint32_t)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-
-// fp32 -> fp16, round to nearest even (subnormals kept, overflow -> inf) and back: the host side of the two-term fp16 weights
-static uint16_t f16_rne(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    const uint32_t sign = (u >> 16) & 0x8000u;
-    u &= 0x7fffffffu;
-    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));      // NaN / inf
-    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                       // >= 65520: rounds to inf
-    if (u < 0x38800000u) {                                                                        // < 2^-14: subnormal result, spacing 2^-24
-        if (u < 0x33000000u) return (uint16_t)sign;                                               // < 2^-25: rounds to zero (2^-25 itself ties to even = 0)
-        const int e = (int)(u >> 23);                                                             // biased fp32 exponent, 102 .. 112
-        const uint32_t m = (u & 0x7fffffu) | 0x800000u;                                           // 24-bit significand
-        const int sh = 126 - e;                                                                   // value = m * 2^(e - 150); result units of 2^-24: m >> (126 - e)
-        const uint32_t q = m >> sh, rem = m & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
-        return (uint16_t)(sign | (q + ((rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u)));
-    }
-    const uint32_t v = u - 0x38000000u;                                                           // rebias 127 -> 15
-    return (uint16_t)(sign | ((v + 0xfffu + ((v >> 13) & 1u)) >> 13));
-}
-static float f16_float(uint16_t h) {
-    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
-    uint32_t u;
-    if (e == 0) {
-        const float f = (float)m * 5.9604644775390625e-8f;                                        // m * 2^-24, exact
-        memcpy(&u, &f, 4);
-        u |= sign;
-    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
-    else u = sign | ((e + 112u) << 23) | (m << 13);
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-// The three weight fragments of one fp32 weight, per arithmetic of the split-operand MFMA kernels (k_conv_bx*.hip, k_heads.hip):
-//   mode 0: bf16, w = q0 + q1 + q2 (three-way split, round to nearest even)
-//   mode 1: fp16 at scale 2^11 ("fx"): q0 = fp16(2^11 w), q2 = fp16(2^11 w - q0) -- together 22 bits of 2^11 w, multiplied with the activation's high
-//           part -- and q1 = fp16(w), multiplied with the activation's 2^11-scaled low part: all three products carry the factor 2^11
-static void split_weight(float v, int mode, uint16_t (&q)[3]) {
-    if (mode == 0) {
-        q[0] = bf16_rne(v);
-        const float r1 = v - bf16_float(q[0]);
-        q[1] = bf16_rne(r1);
-        q[2] = bf16_rne(r1 - bf16_float(q[1]));
-    } else {
-        const float s = v * 2048.f;                    // exact
-        q[0] = f16_rne(s);
-        q[1] = f16_rne(v);
-        q[2] = f16_rne(s - f16_float(q[0]));            // exact difference
-    }
-}
-constexpr float kFxMaxWeight = 31.f;                   // |w| * 2^11 must stay below the fp16 maximum (65504)
 
 // ------------------------------------------------------------------------------------------
 // exported functions
@@ -499,6 +438,22 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         }
         head_b_last = blob[coff[L_HEAT_2].bias];
     }
+    // block1.3 (8 -> 24, stride 2) for block1_fused_kernel<6>: the compact fp16-pair image of block1_fx.hpp (only if every |w| stays below kFxMaxWeight)
+    size_t b1fx_off = 0;
+    bool b1fx_ok = true;
+    {
+        const float* wkc = &blob[coff[L_BLOCK1_3].kc];
+        for (int i = 0; i < 8 * 9 * 24; ++i) b1fx_ok = b1fx_ok && std::fabs(wkc[i]) < kFxMaxWeight;
+        b1fx_off = reserve(b1fx::W4_BYTES / 4);
+        b1fx::pack_w4(&blob[coff[L_BLOCK1_3].kc], reinterpret_cast<uint16_t*>(&blob[b1fx_off]), [](float v, uint16_t (&q)[3]) { split_weight(v, 1, q); });
+    }
+    size_t b1fx3_off = 0;      // block1.2 (8 -> 8) for block1_fused_kernel<7>
+    {
+        const float* wkc = &blob[coff[L_BLOCK1_2].kc];
+        for (int i = 0; i < 8 * 9 * 8; ++i) b1fx_ok = b1fx_ok && std::fabs(wkc[i]) < kFxMaxWeight;
+        b1fx3_off = reserve(b1fx::W3_IMAGE_BYTES / 4);
+        b1fx::pack_w3(&blob[coff[L_BLOCK1_2].kc], reinterpret_cast<uint16_t*>(&blob[b1fx3_off]), [](float v, uint16_t (&q)[3]) { split_weight(v, 1, q); });
+    }
     for (int fi = 0; fi < 5; ++fi) {
         const FineSpec& f = kFine[fi];
         const int npad = (f.n + 63) / 64 * 64;
@@ -552,6 +507,8 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         ctx->nw.head_fx[hd] = head_fx_ok[hd] ? ctx->blob + head_off[1][hd] : nullptr;
         ctx->nw.head_bx_bias[hd] = ctx->blob + head_boff[hd];
     }
+    ctx->nw.block1_fx = b1fx_ok ? ctx->blob + b1fx_off : nullptr;
+    ctx->nw.block1_fx3 = b1fx_ok ? ctx->blob + b1fx3_off : nullptr;
     ctx->nw.head_rel_b_last = head_b_last;
     for (int fi = 0; fi < 5; ++fi) {
         LinW& l = ctx->nw.fine[fi];
@@ -657,7 +614,7 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     else launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
     prof_end(&h->prof, XFH_SPAN_GRAY, st, 0, 0);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
-    launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st, h->opt.block1);
+    launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st, h->opt.block1, h->status);
     // block1 + skip1 per input pixel: conv1 9*4*2 + conv2 36*8*2/4 + conv3 72*8*2/4 + conv4 72*24*2/16 = 720 FLOP; gray in, x1 out: 10 bytes
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 720.0 * B * H * W, 10.0 * B * H * W);
 #define CONV(layer, fused, in, hin, win, out, nhwc) \
@@ -961,11 +918,17 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
 
 int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
 int xfh_debug_cold_start(int enable) { xfh::g_debug_cold = enable ? 1 : 0; return XFH_OK; }
+int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, int H, int W, float* x1, xfh_stream stream) {
+    if (!h || !gray || !coef || !x1) return fail(XFH_ERR_ARG, "xfh_debug_block1: NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 3) || (W & 3)) return fail(XFH_ERR_ARG, "xfh_debug_block1: bad shape (%d,%d,%d)", B, H, W);
+    launch_block1_fused(h->nw, gray, coef, B, H, W, x1, (hipStream_t)stream, h->opt.block1, h->status);
+    return check_launch("xfh_debug_block1");
+}
 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 2}, {"block1", &Options::block1, 0, 5}, {"fx", &Options::fx, 0, 15}};
+        {"heads_f32", &Options::heads_f32, 0, 2}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 15}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;
@@ -976,7 +939,7 @@ int xfh_set_option(xfh_handle h, const char* key, int value) {
     int* slot = option_slot(h, key, lo, hi);
     if (!slot) return fail(XFH_ERR_ARG, "xfh_set_option: unknown option '%s'", key);
     if (value < lo || value > hi) return fail(XFH_ERR_ARG, "xfh_set_option: %s = %d outside [%d, %d]", key, value, lo, hi);
-    if (!strcmp(key, "block1") && value == 2) return fail(XFH_ERR_ARG, "xfh_set_option: block1 = 2 names no kernel (0 | 5 = shipped, 1, 3, 4 = earlier forms)");
+    if (!strcmp(key, "block1") && value == 2) return fail(XFH_ERR_ARG, "xfh_set_option: block1 = 2 names no kernel (0 | 5 = shipped, 1, 3, 4 = earlier forms, 6 / 7 = conv4 / conv3 + conv4 on the fp16 matrix cores)");
     *slot = value;
     return XFH_OK;
 }

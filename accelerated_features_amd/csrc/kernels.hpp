@@ -41,6 +41,8 @@ struct NetWeights {
     const void* head_fx[2];          // the same in the fp16-pair arithmetic (or NULL)
     const float* head_bx_bias[2];    // biases padded to the cout blocks (KP 64,64,64,96 ; REL 64,64)
     float head_rel_b_last;           // bias of the final 64 -> 1 layer of the reliability head
+    const void* block1_fx;           // block1.3 in the fp16-pair arithmetic, compact LDS image (block1_fx.hpp), or NULL
+    const void* block1_fx3;          // block1.2 likewise (q0 / q2 fragments)
 };
 
 struct Profiler;   // api.hip
@@ -59,7 +61,7 @@ struct Options {
                             // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
     int fx = 3;             // split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
                             // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel); 0 = the bf16 three-way split everywhere
-    int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected)
+    int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected); 6 = 5 with conv4 on the fp16 matrix cores (fp16-pair arithmetic, block1_fx.hpp), 7 = conv3 too
 };
 
 // ---- k_preproc.hip ----------------------------------------------------------------------
@@ -77,7 +79,7 @@ void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float
 // ---- k_conv_direct.hip ------------------------------------------------------------------
 void launch_block1(const NetWeights& nw, const float* gray, int B, int H, int W, float* t0, float* t1, float* t2,
                    float* x1, hipStream_t st);
-void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant = 0);
+void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant = 0, int* status = nullptr);
 int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B, int Hin, int Win, float* out,
                         hipStream_t st);
 void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, hipStream_t st);

@@ -1,0 +1,72 @@
+// Host side of the split-operand weight formats (api.hip packs every MFMA operand with these; tests/test_block1_fx_model.py compiles them with g++).
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+namespace xfh {
+
+inline uint16_t bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_float(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// fp32 -> fp16, round to nearest even (subnormals kept, overflow -> inf) and back: the host side of the two-term fp16 weights
+inline uint16_t f16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7fffffffu;
+    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));      // NaN / inf
+    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                       // >= 65520: rounds to inf
+    if (u < 0x38800000u) {                                                                        // < 2^-14: subnormal result, spacing 2^-24
+        if (u < 0x33000000u) return (uint16_t)sign;                                               // < 2^-25: rounds to zero (2^-25 itself ties to even = 0)
+        const int e = (int)(u >> 23);                                                             // biased fp32 exponent, 102 .. 112
+        const uint32_t m = (u & 0x7fffffu) | 0x800000u;                                           // 24-bit significand
+        const int sh = 126 - e;                                                                   // value = m * 2^(e - 150); result units of 2^-24: m >> (126 - e)
+        const uint32_t q = m >> sh, rem = m & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
+        return (uint16_t)(sign | (q + ((rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u)));
+    }
+    const uint32_t v = u - 0x38000000u;                                                           // rebias 127 -> 15
+    return (uint16_t)(sign | ((v + 0xfffu + ((v >> 13) & 1u)) >> 13));
+}
+inline float f16_float(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        const float f = (float)m * 5.9604644775390625e-8f;                                        // m * 2^-24, exact
+        memcpy(&u, &f, 4);
+        u |= sign;
+    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+    else u = sign | ((e + 112u) << 23) | (m << 13);
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// The three weight fragments of one fp32 weight, per arithmetic of the split-operand MFMA kernels (k_conv_bx*.hip, k_heads.hip):
+//   mode 0: bf16, w = q0 + q1 + q2 (three-way split, round to nearest even)
+//   mode 1: fp16 at scale 2^11 ("fx"): q0 = fp16(2^11 w), q2 = fp16(2^11 w - q0) -- together 22 bits of 2^11 w, multiplied with the activation's high
+//           part -- and q1 = fp16(w), multiplied with the activation's 2^11-scaled low part: all three products carry the factor 2^11
+inline void split_weight(float v, int mode, uint16_t (&q)[3]) {
+    if (mode == 0) {
+        q[0] = bf16_rne(v);
+        const float r1 = v - bf16_float(q[0]);
+        q[1] = bf16_rne(r1);
+        q[2] = bf16_rne(r1 - bf16_float(q[1]));
+    } else {
+        const float s = v * 2048.f;                    // exact
+        q[0] = f16_rne(s);
+        q[1] = f16_rne(v);
+        q[2] = f16_rne(s - f16_float(q[0]));            // exact difference
+    }
+}
+constexpr float kFxMaxWeight = 31.f;                   // |w| * 2^11 must stay below the fp16 maximum (65504)
+
+}  // namespace xfh

@@ -194,7 +194,7 @@ class XFeatModel(nn.Module):
         _lib.check(lib.xfh_set_status_buffer(h, C.c_void_p(self._status.data_ptr())), "xfh_set_status_buffer")
         return h
 
-    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 2), "block1": (0, 5), "fx": (0, 15)}      # include/xfeat_hip.h: xfh_set_option
+    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 2), "block1": (0, 7), "fx": (0, 15)}      # include/xfeat_hip.h: xfh_set_option
 
     def set_option(self, key, value):
         """Kernel-variant switch of this model's handle (include/xfeat_hip.h: xfh_set_option) -- A/B runs and variant-vs-variant tests.
@@ -232,7 +232,7 @@ class XFeatModel(nn.Module):
     def fx_range_exceeded(self, status=None):
         """True if a call since the last check left the range of the fp16-pair arithmetic (|activation| >= 65504; never seen on images): the model then falls
         back to the bf16 three-way split for good (option fx = 0) and the caller repeats the call -- results are exact either way."""
-        if status is None and not self._options.get("fx", DEFAULT_FX):
+        if status is None and not self._options.get("fx", DEFAULT_FX) and self._options.get("block1", 0) < 6:
             return False                               # (the bf16 arithmetic has fp32's range: nothing to read back)
         v = self.take_status() if status is None else int(status)
         if not (v & 1):
@@ -241,6 +241,8 @@ class XFeatModel(nn.Module):
         warnings.warn("accelerated_features_amd: an activation left the range of the fp16-pair arithmetic (|x| >= 65504); this model falls back to the "
                       "bf16 three-way split (option fx = 0) and the call is repeated")
         self.set_option("fx", 0)
+        if self._options.get("block1", 0) >= 6:        # (block1's matrix-core forms are fp16-pair kernels too)
+            self.set_option("block1", 0)
         return True
 
     def workspace(self, name, nbytes):

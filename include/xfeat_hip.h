@@ -98,7 +98,8 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *                           both f32 kernels are clean under the same torture at every code position.  For A/B measurements only.
  *   "fx"            bitmask split-operand convolutions in the fp16-pair arithmetic (three MFMAs per product instead of the six of the bf16 three-way split):
  *                           1 = the 64 -> 64 layers on large maps (conv_bx64_kernel), 2 = the 24-channel layers, 4 = the stride-2 64-channel layers
- *   "block1"        0..5    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile
+ *   "block1"        0..7    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile;
+ *                           6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too (both set XFH_STATUS_FX_RANGE like "fx")
  * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.
  * ---------------------------------------------------------------------------------------- */
 int xfh_set_option(xfh_handle h, const char* key, int value);
@@ -363,6 +364,9 @@ int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int
  * workgroup starts, so that its first tile runs on instruction-fetch misses -- the condition under which head_bx_kernel<true> was found to deliver a wrong
  * 16-cell block; the concurrency / cold-start soaks of tests/test_gpu_parity.py and tools/head_soak.py use it. */
 int xfh_debug_cold_start(int enable);
+/* debug: block1 + skip1 alone in the form option "block1" selects: gray (B,H,W) raw gray image, coef (B,2) the per-image {alpha, beta} of the instance
+ * normalisation (x -> alpha x + beta), x1 (B,24,H/4,W/4); H % 4 == W % 4 == 0.  For the variant-against-variant tests of tests/test_gpu_parity.py. */
+int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, int H, int W, float* x1, xfh_stream stream);
 /* debug: resident workgroups per CU the runtime reports for mnn_sim_kernel */
 int xfh_debug_match_occupancy(void);
 int xfh_profile_read(xfh_handle h, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);

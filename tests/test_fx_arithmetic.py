@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SPLIT = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "bx_split.hpp")).read()
-API = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "api.hip")).read()
+API = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "api.hip")).read() + open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "weight_split.hpp")).read()
 
 
 def pair(v):

@@ -127,7 +127,7 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
 
 
 @pytest.mark.parametrize("opts", [{"heads_f32": 0, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}, {"fx": 0}, {"fx": 15, "bx": 23},
-                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}])
+                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"block1": 6}, {"block1": 7}])
 def test_backbone_alternative_kernels_same_results(opts, sd):
     """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on the split-bf16 kernels -- opt-in since round 4 --, 24->24
     layers on Winograd; every unfused 64->64 layer on the split kernel; direct implicit GEMM instead of Winograd; block1 with a c1 tile; the split-operand
@@ -148,6 +148,46 @@ def test_backbone_alternative_kernels_same_results(opts, sd):
         xf2.set_option("no_such_option", 1)
     with pytest.raises(Exception):
         xf2.set_option("wino", 7)
+
+
+@pytest.mark.parametrize("mode", [5, 6, 7])
+def test_block1_forms_alone(sd, acts, mode):
+    """block1 + skip1 alone (xfh_debug_block1) in the shipped vector form (5), with block1.3 on the fp16 matrix cores (6) and with block1.2 there too (7; fp16-pair
+    arithmetic, csrc/block1_fx.hpp): against the oracle's x1 on its own normalised gray images, and form against form on shapes whose last tiles are partial
+    (W / 4 = 88: five and a half 16-column tiles; H / 4 = 60: seven and a half 8-row tiles) -- with the position of the largest difference, for whoever has to debug it."""
+    from accelerated_features_amd import XFeat
+    lib = _lib().load()
+    m = XFeat(weights=sd, top_k=512)
+    m.set_option("block1", mode)
+    ref = XFeat(weights=sd, top_k=512)
+    ref.set_option("block1", 5)
+
+    def run(model, gray):
+        B, H, W = gray.shape
+        coef = torch.tensor([[1.0, 0.0]] * B, device="cuda")
+        x1 = torch.full((B, 24, H // 4, W // 4), float("nan"), device="cuda")
+        assert lib.xfh_debug_block1(model.net.handle(), C.c_void_p(gray.data_ptr()), C.c_void_p(coef.data_ptr()), B, H, W, C.c_void_p(x1.data_ptr()), None) == 0, lib.xfh_last_error()
+        torch.cuda.synchronize()
+        return x1
+
+    def where(d):
+        i = int(d.argmax())
+        return tuple(int(v) for v in np.unravel_index(i, tuple(d.shape)))
+    for tag, (x, t) in acts.items():
+        g = t["gray"].cuda().contiguous()[:, 0]
+        got = run(m, g)
+        d = (got.cpu() - t["x1"]).abs()
+        assert bool(torch.isfinite(got).all()) and float(d.max()) <= TOL_ACT, (tag, mode, float(d.max()), where(d))
+    assert m.net.take_status() == 0
+    for B, H, W, seed in ((3, 224, 352, 5), (2, 240, 320, 6), (1, 32, 32, 7)):
+        g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(seed)).cuda()
+        a, b = run(m, g), run(ref, g)
+        d = (a - b).abs().cpu()
+        assert bool(torch.isfinite(a).all()) and float(d.max()) <= 2e-5 * max(1.0, float(b.abs().max())), (mode, (B, H, W), float(d.max()), where(d))
+    if mode >= 6:      # the range guard of the pair: activations beyond 65504 in c2 / c3 are reported
+        g = torch.randn(1, 64, 64, generator=torch.Generator().manual_seed(8)).cuda() * 1.0e7
+        run(m, g)
+        assert m.net.take_status() & 1
 
 
 def test_split_bf16_backbone_equals_f32_mfma_backbone_at_bench_shape(xf, sd):
@@ -1095,7 +1135,7 @@ def test_frame_stream_at_the_bench_shape_is_bit_stable_over_many_steps(xf, sd, c
         raise AssertionError(f"{len(bad)} of 40 results differ from the synchronous one (synchronous result reproducible: {ref_stable}): {bad[:6]}")
 
 
-@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 0}])
+@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 0}, {"block1": 7}])
 def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
     """Time-boxed soak.  The bench-shape backbone + sparse step + match on one HIP stream while a second stream runs foreign kernels (another
     model's backbone = every kernel of this library incl. f32-MFMA and vector-only ones, a large copy, a rocBLAS GEMM), then the same with every matrix-core
