@@ -127,7 +127,7 @@ void conv_bx_kernel(BxArgs a) {
     // raw fp32 values of a tile: 8 channels of one pixel per item, all loads of a thread in flight together; out-of-image pixels
     // carry an out-of-range offset (the buffer load returns the zero padding)
     float v[NIT][8];
-    float amax = 0.f;                         // fx: the largest |x| converted (range guard)
+    unsigned amax = 0;                        // fx: the largest fp16 high parts converted (range guard: bx_split.hpp)
     auto issue_loads = [&](int vid) {
         int b, oy0, ox0;
         tile_of(vid, b, oy0, ox0);
@@ -146,9 +146,9 @@ void conv_bx_kernel(BxArgs a) {
         for (int i = 0; i < NIT; ++i) {
             uint4 h, m, l;
             if constexpr (FX) {
-                fx_track(amax, v[i][0], v[i][1]); fx_track(amax, v[i][2], v[i][3]); fx_track(amax, v[i][4], v[i][5]); fx_track(amax, v[i][6], v[i][7]);
                 split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
                 split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
+                fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);      // (on the high parts: bx_split.hpp)
             } else {
                 split3(v[i][0], v[i][1], h.x, m.x, l.x);
                 split3(v[i][2], v[i][3], h.y, m.y, l.y);
@@ -266,7 +266,7 @@ void conv_bx_kernel(BxArgs a) {
         ++tix;
         vid = nvid;
     }
-    if constexpr (FX) fx_report(amax, a.status);
+    if constexpr (FX) fx_report_h(amax, a.status);
 #undef BX_STAMP
 }
 
@@ -361,7 +361,7 @@ void conv_bxs2_kernel(BxS2Args a) {
         iy0 = tyi * 8; ix0 = txi * 32;
     };
     float v[NIT][8];
-    float amax = 0.f;                         // fx: the largest |x| converted (range guard)
+    unsigned amax = 0;                        // fx: the largest fp16 high parts converted (range guard: bx_split.hpp)
     auto issue_loads = [&](int vid) __attribute__((always_inline)) {
         int b, iy0, ix0;
         tile_of(vid, b, iy0, ix0);
@@ -380,9 +380,9 @@ void conv_bxs2_kernel(BxS2Args a) {
         for (int i = 0; i < NIT; ++i) {
             uint4 h, m, l;
             if constexpr (FX) {
-                fx_track(amax, v[i][0], v[i][1]); fx_track(amax, v[i][2], v[i][3]); fx_track(amax, v[i][4], v[i][5]); fx_track(amax, v[i][6], v[i][7]);
                 split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
                 split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
+                fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);      // (on the high parts: bx_split.hpp)
             } else {
                 split3(v[i][0], v[i][1], h.x, m.x, l.x);
                 split3(v[i][2], v[i][3], h.y, m.y, l.y);
@@ -468,7 +468,7 @@ void conv_bxs2_kernel(BxS2Args a) {
         __syncthreads();
         vid = nvid;
     }
-    if constexpr (FX) fx_report(amax, a.status);
+    if constexpr (FX) fx_report_h(amax, a.status);
 }
 
 template <int CIN, bool FX>

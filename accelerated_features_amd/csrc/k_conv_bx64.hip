@@ -153,7 +153,7 @@ void conv_bx64_kernel(Bx64Args a) {
     // channel pairs of each pixel: 16 + 16 bits from two registers in one op.
     auto stage_write = [&]() __attribute__((always_inline)) {
         if (!has_item) return;
-        float amax = 0.f;                         // fx: the largest |x| of this item (range guard, bx_split.hpp; a kernel-long register cost the fused forms eight spills)
+        unsigned amax = 0;                        // fx: the largest fp16 high parts of this item (range guard, bx_split.hpp; a kernel-long register cost the fused forms eight spills)
 #pragma unroll
         for (int pp = 0; pp < 2; ++pp) {
             unsigned H[8], M[8], L[8];                     // {pixel 2 pp, pixel 2 pp + 1} of channel k
@@ -164,7 +164,7 @@ void conv_bx64_kernel(Bx64Args a) {
             for (int k = 0; k < 8; ++k) {
                 float x0 = v[k][2 * pp], x1 = v[k][2 * pp + 1];
                 if (a.W & 3) { x0 = z0 ? 0.f : x0; x1 = z1 ? 0.f : x1; }
-                if constexpr (FX) { fx_track(amax, x0, x1); split2_f16(x0, x1, H[k], L[k]); M[k] = 0; }
+                if constexpr (FX) { split2_f16(x0, x1, H[k], L[k]); fx_track_h(amax, H[k], true); M[k] = 0; }
                 else split3(x0, x1, H[k], M[k], L[k]);
             }
 #pragma unroll
@@ -188,7 +188,7 @@ void conv_bx64_kernel(Bx64Args a) {
                 }
             }
         }
-        if constexpr (FX) fx_report(amax, a.status);
+        if constexpr (FX) fx_report_h(amax, a.status);
     };
 
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
@@ -299,7 +299,7 @@ void conv_bx64_kernel(Bx64Args a) {
             // takes the register quads 8 (t & 1), 8 (t & 1) + 4 of cout block t >> 1 (the weights are packed in that K order, as for the
             // heads' chained layers).  Weight fragments come straight from L2 (24 KiB, the same for every wave; no LDS left for them),
             // one K step per load batch; the split fragments are double-buffered and kept alive as in head_bx_layer (MFMA operand hazard).
-            float amax = 0.f;
+            float amax2 = 0.f;                    // fx: range guard of the 1x1's input (on the values, not on the split's high parts as the staging does: + 1 register = 8 bytes of scratch in FUSE 2)
 #pragma unroll
             for (int j = 0; j < NPB; ++j)
 #pragma unroll
@@ -312,11 +312,11 @@ void conv_bx64_kernel(Bx64Args a) {
                         for (int e = 0; e < 4; ++e) {
                             float y = FX ? fmaf(acc[j][cb][4 * g4 + e], FX_SCALE_INV, bq[e]) : acc[j][cb][4 * g4 + e] + bq[e];
                             if (a.relu) y = fmaxf(y, 0.f);
-                            if constexpr (FX) amax = fmaxf(amax, fabsf(y));      // range guard of the 1x1's input (tracked here: inside the split it cost eight spilled registers)
+                            if constexpr (FX) amax2 = fmaxf(amax2, fabsf(y));
                             acc[j][cb][4 * g4 + e] = y;
                         }
                     }
-            if constexpr (FX) fx_report(amax, a.status);
+            if constexpr (FX) fx_report(amax2, a.status);
             // one pixel block at a time (its two 1x1 accumulators, stores included): both blocks at once do not fit into 256 registers next to
             // the 3x3's results and the next tile's prefetched input
             const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
@@ -343,7 +343,7 @@ void conv_bx64_kernel(Bx64Args a) {
                     unsigned* ph = &uh.x; unsigned* pm = &um.x; unsigned* pl = &ul.x;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if constexpr (FX) split2_f16(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pl[i]);
+                        if constexpr (FX) { split2_f16(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pl[i]); }
                         else split3(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pm[i], pl[i]);
                     }
                     o[0] = __builtin_bit_cast(frag_t, uh);

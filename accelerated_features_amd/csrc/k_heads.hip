@@ -16,8 +16,10 @@
 // The kernels are persistent: grid = #CUs, the head's weights are copied to LDS once per
 // workgroup, and the next tile's activations are in flight while layers 2..4 run.
 #include "kernels.hpp"
+#include "bx_split.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace xfh {
 
@@ -422,6 +424,7 @@ struct HeadBxArgs {
     int H, W, hc, wc, ncell, ntiles;
     long long* trace;        // debug: s_memtime stamps of wave 0's second tile, 16 per workgroup
     int cold;                // debug (xfh_debug_cold_start)
+    int* status;             // fx: range guard (bx_split.hpp), may be NULL
 };
 
 __device__ inline unsigned hb_pk_bf16(float a, float b) {
@@ -445,24 +448,28 @@ __device__ inline void hb_split8(const float (&y)[8], bf16x8& h, bf16x8& m, bf16
 }
 
 // one K = 64 layer: out[mb] = bias + W x, x given per K step by `xs(t, y[8])`; weights of the layer at wl (LDS, operand order)
-template <int MBO, typename XS>
-__device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_lds, XS xs, f32x16 (&out)[MBO], int lane, int half) {
+// FX: the fp16-pair arithmetic (bx_split.hpp): two input fragments, three MFMAs per K step and accumulator, `out` at scale 2^11 WITHOUT the bias (the consumer
+// applies fma(out, 2^-11, bias)); amax collects the largest |x| converted (range guard)
+template <int MBO, bool FX, bool RELU_IN, typename XS>      // RELU_IN: xs delivers non-negative values (a chained layer): cheaper range tracking
+__device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_lds, XS xs, f32x16 (&out)[MBO], int lane, int half, unsigned& amax) {
+    using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
+    constexpr int NXS = FX ? 2 : 3;
 #pragma unroll
     for (int mb = 0; mb < MBO; ++mb)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 t = *reinterpret_cast<const float4*>(bias_lds + mb * 32 + 8 * g4 + 4 * half);
+            const float4 t = FX ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(bias_lds + mb * 32 + 8 * g4 + 4 * half);
             out[mb][4 * g4] = t.x; out[mb][4 * g4 + 1] = t.y; out[mb][4 * g4 + 2] = t.z; out[mb][4 * g4 + 3] = t.w;
         }
     // (compiler fence: the weights never change, so hipcc hoists every fragment read of every layer out of the persistent tile loop --
     // 432 registers' worth, straight into scratch memory)
     asm volatile("" ::: "memory");
-    bf16x8 w[2][MBO][3];
-    auto ldw = [&](int t, bf16x8 (&o)[MBO][3]) {
+    frag_t w[2][MBO][3];
+    auto ldw = [&](int t, frag_t (&o)[MBO][3]) {
 #pragma unroll
         for (int mb = 0; mb < MBO; ++mb)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) o[mb][q] = *reinterpret_cast<const bf16x8*>(wl + (((t * MBO + mb) * 3 + q) * 64 + lane) * 16);
+            for (int q = 0; q < 3; ++q) o[mb][q] = *reinterpret_cast<const frag_t*>(wl + (((t * MBO + mb) * 3 + q) * 64 + lane) * 16);
     };
     ldw(0, w[0]);
     // The B fragments are VALU results, and a VALU write that follows an MFMA by a few cycles can land in that MFMA's A/B registers
@@ -470,31 +477,45 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
     // of many; hipcc's hazard recogniser only covers SrcC).  So the fragments of step t+1 are built into a second register set while
     // step t's are still alive: the empty asm below is a use of step t's set AFTER the split, which keeps the allocator from handing
     // its registers to the new values; a set is rewritten one full step (12-18 MFMAs) after its last read.
-    bf16x8 xf[2][3];
+    frag_t xf[2][NXS];
+    auto split8 = [&](const float (&y)[8], frag_t (&o)[NXS]) {
+        if constexpr (FX) {
+            uint4 uh, ul;
+            unsigned* ph = &uh.x; unsigned* pl = &ul.x;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { split2_f16(y[2 * i], y[2 * i + 1], ph[i], pl[i]); fx_track_h(amax, ph[i], !RELU_IN); }
+            o[0] = __builtin_bit_cast(frag_t, uh); o[1] = __builtin_bit_cast(frag_t, ul);
+        } else {
+            hb_split8(y, o[0], o[1], o[NXS - 1]);
+        }
+    };
     {
         float y[8];
         xs(0, y);
-        hb_split8(y, xf[0][0], xf[0][1], xf[0][2]);
+        split8(y, xf[0]);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         if (t + 1 < 4) ldw(t + 1, w[(t + 1) & 1]);
         asm volatile("" ::: "memory");
-        const bf16x8 xh = xf[t & 1][0], xm = xf[t & 1][1], xl = xf[t & 1][2];
+        const frag_t x0 = xf[t & 1][0], x1 = xf[t & 1][1], x2 = xf[t & 1][NXS - 1];
         __builtin_amdgcn_sched_barrier(0);      // the MFMAs of a step stay together: left free, hipcc floats the NEXT steps' splits in between them
-        // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-#define HB_MM(WQ, X) { _Pragma("unroll") for (int mb = 0; mb < MBO; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t & 1][mb][WQ], X, out[mb], 0, 0, 0); }
-        HB_MM(2, xh) HB_MM(0, xl) HB_MM(1, xm) HB_MM(1, xh) HB_MM(0, xm) HB_MM(0, xh)
+        // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); fp16 pair: (q2, xh) (q1, xl) (q0, xh)
+#define HB_MM(WQ, X) { _Pragma("unroll") for (int mb = 0; mb < MBO; ++mb) { \
+            if constexpr (FX) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[t & 1][mb][WQ], X, out[mb], 0, 0, 0); \
+            else out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t & 1][mb][WQ], X, out[mb], 0, 0, 0); } }
+        if constexpr (FX) { HB_MM(2, x0) HB_MM(1, x1) HB_MM(0, x0) }
+        else { HB_MM(2, x0) HB_MM(0, x2) HB_MM(1, x1) HB_MM(1, x0) HB_MM(0, x1) HB_MM(0, x0) }
 #undef HB_MM
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < 4) {
             float y[8];
             xs(t + 1, y);
-            hb_split8(y, xf[(t + 1) & 1][0], xf[(t + 1) & 1][1], xf[(t + 1) & 1][2]);
+            split8(y, xf[(t + 1) & 1]);
             // the new fragments pass THROUGH the asm that uses the old ones (and this step's weights): it cannot move above the split,
             // so the old registers stay occupied while the split's results and temporaries are written
-            asm volatile("" : "+v"(xf[(t + 1) & 1][0]), "+v"(xf[(t + 1) & 1][1]), "+v"(xf[(t + 1) & 1][2])
-                            : "v"(xf[t & 1][0]), "v"(xf[t & 1][1]), "v"(xf[t & 1][2]), "v"(w[t & 1][0][0]), "v"(w[t & 1][0][1]), "v"(w[t & 1][0][2]),
+            asm volatile("" : "+v"(xf[(t + 1) & 1][0]), "+v"(xf[(t + 1) & 1][1]), "+v"(xf[(t + 1) & 1][NXS - 1])
+                            : "v"(xf[t & 1][0]), "v"(xf[t & 1][1]), "v"(xf[t & 1][NXS - 1]), "v"(w[t & 1][0][0]), "v"(w[t & 1][0][1]), "v"(w[t & 1][0][2]),
                               "v"(w[t & 1][MBO - 1][0]), "v"(w[t & 1][MBO - 1][1]), "v"(w[t & 1][MBO - 1][2]));
             if (MBO == 3) asm volatile("" : "+v"(xf[(t + 1) & 1][0]) : "v"(w[t & 1][1][0]), "v"(w[t & 1][1][1]), "v"(w[t & 1][1][2]));
             __builtin_amdgcn_sched_barrier(0);
@@ -514,7 +535,9 @@ __device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_
 // xfh_debug_cold_start -- the FIRST tile of a workgroup comes out with the cells of lanes 16..31 of one wave wrong once in 10^3 .. 10^5 launches, depending on
 // where the 64-byte instruction lines fall in the MFMA groups (tools/head_soak.py scans 16 code positions: three fail) and on the chip; not understood at the
 // instruction level (profiles/r04_head_hazard/).  SHIFT moves the body by 4 x SHIFT bytes for that scan.
-template <bool KP, int SHIFT = 0>
+// FX: the fp16-pair arithmetic (bx_split.hpp; weights a.wq = NetWeights::head_fx): three MFMAs per K step and cout block instead of six; a layer's accumulators
+// live at scale 2^11 without the bias, the consumer applies fma(acc, 2^-11, bias) (the chain in front of its ReLU, the epilogues on the logits)
+template <bool KP, int SHIFT = 0, bool FX = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_bx_kernel(HeadBxArgs a) {
     code_shift<SHIFT>();
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
@@ -558,6 +581,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int tile = blockIdx.x;
     if (tile < a.ntiles) issue_x(tile);
     lds_dma_barrier();                                                // the weights (and biases) have landed; no barrier from here on
+    unsigned amax = 0;                                                // fx: the largest fp16 high parts converted, as a pair of 16-bit magnitudes (range guard: bx_split.hpp)
+    const float* bias_v = bias_lds + 4 * half;                        // fx: the lane's view of the bias table.  Opaque to the compiler: otherwise every read of the table gets
+    asm volatile("" : "+v"(bias_v));                                  // an address register of its own (the table sits beyond the 64-KiB reach of an offset field), hoisted out of the tile loop and spilled
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
     int tix = 0;
 #define HB_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }
@@ -568,13 +594,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float nrm2 = 0.f;
         {
             const float al = nalpha, be = nbeta;
-            head_bx_layer<2>(smem_h, bias_lds, [&](int t, float (&y)[8]) {
+            head_bx_layer<2, FX, false>(smem_h, bias_lds, [&](int t, float (&y)[8]) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     y[i] = KP ? fmaf(xin[t][i], al, be) : xin[t][i];
                     if (!KP) nrm2 = fmaf(y[i], y[i], nrm2);
                 }
-            }, accA, lane, half);
+            }, accA, lane, half, amax);
         }
         if (!KP && a.inv) {
             nrm2 += xhalf(nrm2);                                      // the other 32 channels sit in the other half-wave
@@ -583,19 +609,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         HB_STAMP(1)
         if (tile + (int)gridDim.x < a.ntiles) issue_x(tile + gridDim.x);      // the next tile's input flies during the chained layers
         // chained layers: K step t = register quads 8 (t & 1), 8 (t & 1) + 4 of block t >> 1, ReLU'd
-        auto chain = [](const f32x16 (&in)[2]) {
-            return [&in](int t, float (&y)[8]) {
+        // (fx: `in` is at scale 2^11 and without its bias: both applied here -- the biases of the lane's eight features are two float4 of the LDS table)
+        auto chain = [](const f32x16 (&in)[2], const float* bias_in) {      // bias_in: this lane's view of the table (+ 4 half)
+            return [&in, bias_in](int t, float (&y)[8]) {
+                if constexpr (FX) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(bias_in + (t >> 1) * 32 + 16 * (t & 1));
+                    const float4 b1 = *reinterpret_cast<const float4*>(bias_in + (t >> 1) * 32 + 16 * (t & 1) + 8);
+                    const float bq[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) y[i] = fmaxf(in[t >> 1][8 * (t & 1) + i], 0.f);
+                    for (int i = 0; i < 8; ++i) y[i] = fmaxf(fmaf(in[t >> 1][8 * (t & 1) + i], FX_SCALE_INV, bq[i]), 0.f);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = fmaxf(in[t >> 1][8 * (t & 1) + i], 0.f);
+                }
             };
         };
         if (KP) {
-            head_bx_layer<2>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half);
+            head_bx_layer<2, FX, true>(smem_h + L_BYTES, bias_lds + 64, chain(accA, bias_v), accB, lane, half, amax);
             HB_STAMP(2)
-            head_bx_layer<2>(smem_h + 2 * L_BYTES, bias_lds + 128, chain(accB), accA, lane, half);
+            head_bx_layer<2, FX, true>(smem_h + 2 * L_BYTES, bias_lds + 128, chain(accB, bias_v + 64), accA, lane, half, amax);
             HB_STAMP(3)
             f32x16 lg[3];
-            head_bx_layer<3>(smem_h + 3 * L_BYTES, bias_lds + 192, chain(accA), lg, lane, half);
+            head_bx_layer<3, FX, true>(smem_h + 3 * L_BYTES, bias_lds + 192, chain(accA, bias_v + 128), lg, lane, half, amax);
+            if constexpr (FX) {      // logits = 2^-11 acc + bias
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int g4 = 0; g4 < (m < 2 ? 4 : 1); ++g4) {
+                        const float4 bq = *reinterpret_cast<const float4*>(bias_v + 192 + m * 32 + 8 * g4);
+                        lg[m][4 * g4] = fmaf(lg[m][4 * g4], FX_SCALE_INV, bq.x); lg[m][4 * g4 + 1] = fmaf(lg[m][4 * g4 + 1], FX_SCALE_INV, bq.y);
+                        lg[m][4 * g4 + 2] = fmaf(lg[m][4 * g4 + 2], FX_SCALE_INV, bq.z); lg[m][4 * g4 + 3] = fmaf(lg[m][4 * g4 + 3], FX_SCALE_INV, bq.w);
+                    }
+            }
             HB_STAMP(4)
             // lane (l31,half) holds logits c = 32m + (r&3) + 8(r>>2) + 4*half of its cell; c == 64 (dustbin) is m=2,r=0,half=0
             float mx = -INFINITY;
@@ -636,34 +681,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             HB_STAMP(5)
         } else {
-            head_bx_layer<2>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half);
+            head_bx_layer<2, FX, true>(smem_h + L_BYTES, bias_lds + 64, chain(accA, bias_v), accB, lane, half, amax);
             // final 64 -> 1: dot over this lane's 32 channels, other half via one shuffle
             float s = 0.f;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    s = fmaf(fmaxf(accB[m][r], 0.f), a.w_last[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half], s);
+                for (int r = 0; r < 16; ++r) {
+                    const int ch = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float v = FX ? fmaf(accB[m][r], FX_SCALE_INV, bias_v[64 + m * 32 + (r & 3) + 8 * (r >> 2)]) : accB[m][r];
+                    s = fmaf(fmaxf(v, 0.f), a.w_last[ch], s);
+                }
             s += __shfl_xor(s, 32, 64);
             if (half == 0 && gcell < a.ncell) a.out[gcell] = 1.f / (1.f + expf(-(s + a.b_last)));
         }
     }
+    if constexpr (FX) fx_report_h(amax, a.status);
 #undef HB_STAMP
 }
 
 long long* g_head_trace = nullptr;        // debug (xfh_debug_trace): stamps of head_bx_kernel<true>
 
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels) {
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels, bool fx, int* status) {
     if (!f32_kernels && nw.head_bx[0]) {
+        fx = fx && nw.head_fx[0];
         HeadBxArgs h{};
         h.cold = g_debug_cold;
-        h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
+        h.status = status;
+        h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(fx ? nw.head_fx[0] : nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
         h.H = H; h.W = W; h.hc = H / 8; h.wc = W / 8;
         h.ncell = B * h.hc * h.wc;
         h.ntiles = ceil_div(h.ncell, HD_CELLS);
         h.trace = g_head_trace;
         const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float);
-        static unsigned attr = 0;
+        static unsigned attr = 0, attr_fx = 0;
+        if (fx) {
+            set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, 0, true>), 160 * 1024, attr_fx);
+            head_bx_kernel<true, 0, true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+            return;
+        }
         set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true>), 160 * 1024, attr);
         head_bx_kernel<true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
         return;
@@ -688,17 +744,24 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
     head_fused_kernel<true><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels) {
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels, bool fx, int* status) {
     if (!f32_kernels && nw.head_bx[1]) {
+        fx = fx && nw.head_fx[1];
         HeadBxArgs h{};
         h.cold = g_debug_cold;
-        h.src = feats; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[1]); h.bias = nw.head_bx_bias[1]; h.out = reliab; h.inv = invnorm;
+        h.status = status;
+        h.src = feats; h.wq = reinterpret_cast<const uint4*>(fx ? nw.head_fx[1] : nw.head_bx[1]); h.bias = nw.head_bx_bias[1]; h.out = reliab; h.inv = invnorm;
         h.w_last = nw.conv[L_HEAT_2].w_oihw; h.b_last = nw.head_rel_b_last;
         h.hc = 1; h.wc = 1; h.H = 8; h.W = 8;
         h.ncell = ncell;
         h.ntiles = ceil_div(ncell, HD_CELLS);
         const size_t lds = (size_t)2 * 2 * 4 * 3 * 1024 + 128 * sizeof(float);
-        static unsigned attr = 0;
+        static unsigned attr = 0, attr_fx = 0;
+        if (fx) {
+            set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<false, 0, true>), 160 * 1024, attr_fx);
+            head_bx_kernel<false, 0, true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+            return;
+        }
         set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<false>), 160 * 1024, attr);
         head_bx_kernel<false><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
         return;
@@ -728,8 +791,8 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
 // Debug (xfh_debug_head_soak, tools/head_soak.py): the key-point head alone, launched `iters` times, every result compared on the
 // device with a reference result; differing float4s are counted and the first `cap` of them recorded as {iteration, float4 index,
 // bits got, bits expected} behind a 4-word header {count, 0, 0, 0}.  variant: 0 = the split-bf16 kernel, 100 = the f32-MFMA kernel with
-// an activation tile (head_fused_kernel), 101 = the f32-MFMA kernel with register input (head_f32r_kernel, the default head);
-// 1000 + s / 2000 + s / 3000 + s = the same three kernels COLD-STARTED (s_icache_inv per workgroup) with the body moved by 4 s bytes,
+// an activation tile (head_fused_kernel), 101 = the f32-MFMA kernel with register input (head_f32r_kernel, the default head), 102 = the split head in the fp16-pair arithmetic;
+// 1000 + s / 2000 + s / 3000 + s / 4000 + s = the same four kernels COLD-STARTED (s_icache_inv per workgroup) with the body moved by 4 s bytes,
 // s = 0 .. 15: the code-position scan that separates a kernel that trips on instruction-cache refills from one that does not.
 // (The experiment builds of round 4 -- reloads, pads, dumps, dry passes: variants 1 .. 26 of profiles/r04_head_hazard -- lived here until commit 9607d16.)
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -755,6 +818,13 @@ static void launch_kp_head_bx_shift(const HeadBxArgs& h, hipStream_t st) {
     head_bx_kernel<true, SHIFT><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
 }
 template <int SHIFT>
+static void launch_kp_head_fx_shift(const HeadBxArgs& h, hipStream_t st) {
+    const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float);
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, SHIFT, true>), 160 * 1024, attr);
+    head_bx_kernel<true, SHIFT, true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+}
+template <int SHIFT>
 static void launch_kp_head_f32_shift(const HeadArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
     static unsigned attr = 0;
@@ -773,9 +843,13 @@ static void launch_kp_head_f32r_shift(const HeadArgs& a, hipStream_t st) {
 #define XFH_HEAD_SCAN_SHIFTS 1
 #endif
 template <int S>
-static bool launch_shift(int shift, const HeadBxArgs& h, const HeadArgs& a, int kind, hipStream_t st) {      // shift -> the instantiation; kind 1 bf16, 2 f32 (LDS tile), 3 f32 (registers)
-    if (shift == S) { if (kind == 2) launch_kp_head_f32_shift<S>(a, st); else if (kind == 3) launch_kp_head_f32r_shift<S>(a, st); else launch_kp_head_bx_shift<S>(h, st); return true; }
-    if constexpr (S + 1 < XFH_HEAD_SCAN_SHIFTS) return launch_shift<S + 1>(shift, h, a, kind, st);
+static bool launch_shift(int shift, const HeadBxArgs& h, const HeadBxArgs& hx, const HeadArgs& a, int kind, hipStream_t st) {      // shift -> the instantiation; kind 1 bf16, 2 f32 (LDS tile), 3 f32 (registers), 4 fp16 pair
+    if (shift == S) {
+        if (kind == 2) launch_kp_head_f32_shift<S>(a, st); else if (kind == 3) launch_kp_head_f32r_shift<S>(a, st); else if (kind == 4) launch_kp_head_fx_shift<S>(hx, st);
+        else launch_kp_head_bx_shift<S>(h, st);
+        return true;
+    }
+    if constexpr (S + 1 < XFH_HEAD_SCAN_SHIFTS) return launch_shift<S + 1>(shift, h, hx, a, kind, st);
     return false;
 }
 
@@ -793,11 +867,14 @@ int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B,
         for (int i = 0; i < 4; ++i) { fa.w[i] = nw.conv[L[i]].w_kcp; fa.bias[i] = nw.conv[L[i]].bias; }
     }
     fa.cold = h.cold = (variant >= 1000) ? 1 : g_debug_cold;
+    HeadBxArgs hx = h;                     // the fp16-pair head (variants 102, 4000 + s)
+    hx.wq = reinterpret_cast<const uint4*>(nw.head_fx[0]);
     const size_t n4h = (size_t)B * H * W / 4, n4l = (size_t)h.ncell * 65 / 4;
     for (int it = 0; it < iters; ++it) {
         if (variant >= 1000) {
-            if (variant >= 4000 || !launch_shift<0>(variant % 1000, h, fa, variant / 1000, st)) return -1;
+            if (variant >= 5000 || (variant >= 4000 && !nw.head_fx[0]) || !launch_shift<0>(variant % 1000, h, hx, fa, variant / 1000, st)) return -1;
         } else if (variant == 0) launch_kp_head_bx_shift<0>(h, st);
+        else if (variant == 102 && nw.head_fx[0]) launch_kp_head_fx_shift<0>(hx, st);
         else if (variant == 100) launch_kp_head_f32_shift<0>(fa, st);
         else if (variant == 101) launch_kp_head_f32r_shift<0>(fa, st);
         else return -1;
