@@ -1,6 +1,8 @@
 // Three-way bf16 split of fp32 values (shared by the split-operand MFMA convolutions k_conv_bx.hip / k_conv_bx64.hip).
 #pragma once
+#ifndef XFH_HOST_EMU      // (tests/emu/ compiles this header for the host)
 #include "common.hpp"
+#endif
 
 namespace xfh {
 

@@ -1,0 +1,132 @@
+// Host emulation of the few GPU facilities a kernel body of csrc/ needs (tests/emu/*.cpp): one host thread per work-item, a workgroup at a time.
+// LDS is a buffer, __syncthreads a barrier over the workgroup's threads, the LDS-DMA a copy, v_mfma_f32_16x16x32_f16 an exchange among the 64 threads of a wave
+// (exact fp16 products, the accumulator rounded to fp32 once per instruction: what tests/test_block1_fx_model.py assumes of the instruction).
+// Not a model of timing or of memory ordering: it checks index arithmetic, tile layouts and the barrier structure (a missing barrier usually shows as a wrong
+// result here too, since the host threads run at very different paces).
+#pragma once
+#define XFH_HOST_EMU 1
+#include <atomic>
+#include <barrier>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <thread>
+#include <type_traits>
+#include <vector>
+
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+struct emu_dim3 { unsigned x = 0, y = 0, z = 0; };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
+using std::max;
+using std::min;
+
+namespace emu {
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct Workgroup {
+    int nthreads;
+    std::vector<unsigned char> lds;
+    std::barrier<> bar;
+    std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
+    std::vector<h8> opa, opb;      // [thread]
+    Workgroup(int n, size_t lds_bytes) : nthreads(n), lds(lds_bytes + 64, 0xff), bar(n), opa(n), opb(n) {      // (LDS starts as NaN patterns: nothing may rely on zeros)
+        for (int w = 0; w < n / 64; ++w) wave_bar.emplace_back(new std::barrier<>(64));
+    }
+    unsigned char* lds_base() { return reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(lds.data()) + 63) & ~uintptr_t(63)); }
+};
+inline thread_local Workgroup* wg = nullptr;
+inline thread_local emu_dim3 tidx, bidx;
+inline emu_dim3 gdim;
+
+inline f4 mfma16(h8 a, h8 b, f4 c) {
+    const int t = tidx.x, w = t >> 6, l = t & 63;
+    wg->opa[t] = a; wg->opb[t] = b;
+    wg->wave_bar[w]->arrive_and_wait();
+    f4 d = c;
+    const int n = l & 15;                       // this lane's column
+    for (int j = 0; j < 4; ++j) {
+        const int m = 4 * (l >> 4) + j;         // row
+        double s = 0;
+        for (int kb = 0; kb < 4; ++kb)
+            for (int i = 0; i < 8; ++i) s += (double)(float)wg->opa[w * 64 + 16 * kb + m][i] * (double)(float)wg->opb[w * 64 + 16 * kb + n][i];
+        d[j] = (float)((double)c[j] + s);
+    }
+    wg->wave_bar[w]->arrive_and_wait();
+    return d;
+}
+inline void dma16(const void* g, void* l_base) { std::memcpy(static_cast<unsigned char*>(l_base) + 16 * (tidx.x & 63), g, 16); }
+struct Rsrc { unsigned char* base; unsigned bytes; };
+inline float med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
+inline unsigned perm(unsigned hi, unsigned lo, unsigned sel) {
+    const uint64_t v = ((uint64_t)hi << 32) | lo;
+    unsigned r = 0;
+    for (int i = 0; i < 4; ++i) r |= (unsigned)((v >> (8 * ((sel >> (8 * i)) & 7))) & 0xff) << (8 * i);
+    return r;
+}
+
+// run `fn()` as every work-item of `grid` workgroups of `nthreads`, one workgroup at a time
+template <typename F>
+void launch(int grid, int nthreads, size_t lds_bytes, F fn) {
+    Workgroup w(nthreads, lds_bytes);
+    gdim.x = grid;
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t)
+        th.emplace_back([&, t] {
+            wg = &w;
+            tidx.x = t;
+            for (int b = 0; b < grid; ++b) {
+                bidx.x = b;
+                fn();
+                w.bar.arrive_and_wait();        // the next workgroup reuses the LDS
+            }
+        });
+    for (auto& t : th) t.join();
+}
+}  // namespace emu
+
+#define threadIdx emu::tidx
+#define blockIdx emu::bidx
+#define gridDim emu::gdim
+inline void __syncthreads() { emu::wg->bar.arrive_and_wait(); }
+inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+#define XFH_DYN_LDS(name) float* name = reinterpret_cast<float*>(emu::wg->lds_base())
+#define XFH_NOP16_2(a, b) ((void)0)
+#define XFH_NOP16_3(a, b, c) ((void)0)
+#define XFH_PIN(x) ((void)0)
+typedef const void* xfh_gptr_t;
+typedef void* xfh_lptr_t;
+typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
+#define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_fmed3f(a, b, c) emu::med3(a, b, c)
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_perm(hi, lo, sel) emu::perm(hi, lo, sel)
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu::mfma16(a, b, c)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::dma16(g, l)
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{reinterpret_cast<unsigned char*>(p), (unsigned)(bytes)}
+#define __builtin_amdgcn_raw_buffer_store_b32(val, rs, voff, soff, aux)                                                               \
+    do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 4 <= (rs).bytes) { const unsigned v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 4); } } while (0)
+
+namespace xfh {
+inline void kernel_entry_hooks(int) {}
+inline void lds_dma_barrier() { __syncthreads(); }
+inline bool xcd_swizzled(int n_groups) { return n_groups >= 8 && (n_groups & 7) == 0; }
+inline bool xcd_group_map(int id, int per_group, int n_groups, int& group, int& item) {      // (common.hpp)
+    if (!xcd_swizzled(n_groups)) { group = id / per_group; item = id - group * per_group; return group < n_groups; }
+    const int xcd = id & 7, slot = id >> 3;
+    group = (slot / per_group) * 8 + xcd; item = slot % per_group;
+    return group < n_groups;
+}
+}  // namespace xfh
