@@ -419,19 +419,9 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
             for (int p = 0; p < nl; ++p) {
                 const ConvSpec& c = kConvs[ls[p]];
                 const int mbo = (c.cout + 31) / 32;
-                for (int t = 0; t < 4; ++t)
-                    for (int mb = 0; mb < mbo; ++mb)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int i = 0; i < 8; ++i) {
-                                const int o = mb * 32 + (lane & 31), hf = lane >> 5;
-                                const int ch = p == 0 ? 16 * t + 8 * hf + i : 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
-                                const float v = o < c.cout ? blob[coff[ls[p]].oihw + (size_t)o * 64 + ch] : 0.f;
-                                if (!(std::fabs(v) < kFxMaxWeight)) head_fx_ok[hd] = false;
-                                uint16_t q[3];
-                                split_weight(v, mode, q);
-                                for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * mbo + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                            }
-                dst += (size_t)4 * mbo * 3 * 64 * 8;
+                for (size_t i = 0; i < (size_t)c.cout * 64; ++i)
+                    if (!(std::fabs(blob[coff[ls[p]].oihw + i]) < kFxMaxWeight)) head_fx_ok[hd] = false;
+                dst += pack_head_layer(&blob[coff[ls[p]].oihw], c.cout, p == 0, mode, dst);      // (weight_split.hpp)
                 for (int o = 0; o < 32 * mbo; ++o) blob[bo + o] = o < c.cout ? blob[coff[ls[p]].bias + o] : 0.f;
                 bo += 32 * mbo;
             }

@@ -9,9 +9,14 @@
 #define XFH_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
 #define XFH_NOP16_2(a, b) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b))              /* 16 idle slots behind an MFMA group, tied to its accumulators */
 #define XFH_NOP16_3(a, b, c) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c))
+#ifndef XFH_PIN
 #define XFH_PIN(x) asm volatile("" : "+v"(x))                                                 /* the value is computed HERE */
+#endif
+#ifndef XFH_GPTR_DEFINED
+#define XFH_GPTR_DEFINED
 typedef __attribute__((address_space(1))) const void* xfh_gptr_t;
 typedef __attribute__((address_space(3))) void* xfh_lptr_t;
+#endif
 #else
 #include "bx_split.hpp"
 #endif

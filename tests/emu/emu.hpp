@@ -42,7 +42,8 @@ struct Workgroup {
     std::barrier<> bar;
     std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
     std::vector<h8> opa, opb;      // [thread]
-    Workgroup(int n, size_t lds_bytes) : nthreads(n), lds(lds_bytes + 64, 0xff), bar(n), opa(n), opb(n) {      // (LDS starts as NaN patterns: nothing may rely on zeros)
+    std::vector<float> opa32, opb32;      // [thread][8]
+    Workgroup(int n, size_t lds_bytes) : nthreads(n), lds(lds_bytes + 64, 0xff), bar(n), opa(n), opb(n), opa32(8 * n), opb32(8 * n) {      // (LDS starts as NaN patterns: nothing may rely on zeros)
         for (int w = 0; w < n / 64; ++w) wave_bar.emplace_back(new std::barrier<>(64));
     }
     unsigned char* lds_base() { return reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(lds.data()) + 63) & ~uintptr_t(63)); }
@@ -66,6 +67,39 @@ inline f4 mfma16(h8 a, h8 b, f4 c) {
     }
     wg->wave_bar[w]->arrive_and_wait();
     return d;
+}
+// v_mfma_f32_32x32x16_{f16,bf16}: lane l holds A row l & 31 / B column l & 31, K values 8 (l >> 5) .. + 7; D: lane (column l & 31, half l >> 5) holds rows
+// (r & 3) + 8 (r >> 2) + 4 half, r = 0 .. 15
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <typename V8>
+inline f16v mfma32(V8 a, V8 b, f16v c) {
+    const int t = tidx.x, w = t >> 6, l = t & 63;
+    h8 af, bf;      // (as fp32-exact carriers: both fp16 and bf16 convert to float exactly; kept as floats below)
+    static thread_local float fa[8], fb[8];
+    for (int i = 0; i < 8; ++i) { fa[i] = (float)a[i]; fb[i] = (float)b[i]; }
+    std::memcpy(&wg->opa32[t * 8], fa, 32); std::memcpy(&wg->opb32[t * 8], fb, 32);
+    (void)af; (void)bf;
+    wg->wave_bar[w]->arrive_and_wait();
+    f16v d = c;
+    const int n = l & 31, half = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+        double s = 0;
+        for (int kb = 0; kb < 2; ++kb)
+            for (int i = 0; i < 8; ++i) s += (double)wg->opa32[(w * 64 + 32 * kb + m) * 8 + i] * (double)wg->opb32[(w * 64 + 32 * kb + n) * 8 + i];
+        d[r] = (float)((double)c[r] + s);
+    }
+    wg->wave_bar[w]->arrive_and_wait();
+    return d;
+}
+// value of lane ^ mask of the same wave
+inline float shfl_xor(float v, int mask) {
+    const int t = tidx.x, w = t >> 6, l = t & 63;
+    wg->opa32[t * 8] = v;
+    wg->wave_bar[w]->arrive_and_wait();
+    const float r = wg->opa32[(w * 64 + (l ^ mask)) * 8];
+    wg->wave_bar[w]->arrive_and_wait();
+    return r;
 }
 inline void dma16(const void* g, void* l_base) { std::memcpy(static_cast<unsigned char*>(l_base) + 16 * (tidx.x & 63), g, 16); }
 struct Rsrc { unsigned char* base; unsigned bytes; };
@@ -103,6 +137,7 @@ void launch(int grid, int nthreads, size_t lds_bytes, F fn) {
 inline void __syncthreads() { emu::wg->bar.arrive_and_wait(); }
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 #define XFH_DYN_LDS(name) float* name = reinterpret_cast<float*>(emu::wg->lds_base())
+#define XFH_DYN_LDS_BYTES(name) unsigned char* name = emu::wg->lds_base()
 #define XFH_NOP16_2(a, b) ((void)0)
 #define XFH_NOP16_3(a, b, c) ((void)0)
 #define XFH_PIN(x) ((void)0)
@@ -114,12 +149,17 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_perm(hi, lo, sel) emu::perm(hi, lo, sel)
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu::mfma16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma32(a, b, c)
+#define __builtin_amdgcn_s_memtime() 0ll
+#define __shfl_xor(v, mask, width) emu::shfl_xor(v, mask)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::dma16(g, l)
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{reinterpret_cast<unsigned char*>(p), (unsigned)(bytes)}
 #define __builtin_amdgcn_raw_buffer_store_b32(val, rs, voff, soff, aux)                                                               \
     do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 4 <= (rs).bytes) { const unsigned v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 4); } } while (0)
 
 namespace xfh {
+inline float xhalf(float v) { return emu::shfl_xor(v, 32); }      // (common.hpp: v_permlane32_swap)
 inline void kernel_entry_hooks(int) {}
 inline void lds_dma_barrier() { __syncthreads(); }
 inline bool xcd_swizzled(int n_groups) { return n_groups >= 8 && (n_groups & 7) == 0; }

@@ -20,7 +20,7 @@ def emu_bin():
         pytest.skip("no host clang")
     td = tempfile.mkdtemp()
     out = os.path.join(td, "block1_emu")
-    subprocess.run([CLANG, "-O1", "-std=c++20", "-pthread", "-I", os.path.join(ROOT, "accelerated_features_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "emu"),
+    subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", os.path.join(ROOT, "accelerated_features_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "emu"),
                     os.path.join(ROOT, "tests", "emu", "block1_emu.cpp"), "-o", out], check=True)
     return out
 
