@@ -405,23 +405,26 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     size_t head_off[2][2] = {{0, 0}, {0, 0}}, head_boff[2] = {0, 0};      // [arithmetic: 0 = bf16 x3, 1 = fp16 pair][head]
     bool head_fx_ok[2] = {true, true};
     float head_b_last = 0.f;
-    for (int mode = 0; mode < 2; ++mode) {
+    size_t head_fq_off[2] = {0, 0};
+    for (int mode = 0; mode < 3; ++mode) {      // 0: bf16 x3, 1: fp16 pair (three fragments), 2: fp16 pair with q0 / q2 alone
         const int kp[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3}, rel[2] = {L_HEAT_0, L_HEAT_1};
         for (int hd = 0; hd < 2; ++hd) {
             const int nl = hd == 0 ? 4 : 2;
             const int* ls = hd == 0 ? kp : rel;
             size_t words = 0, nbias = 0;
-            for (int p = 0; p < nl; ++p) { const int mbo = (kConvs[ls[p]].cout + 31) / 32; words += (size_t)4 * mbo * 3 * 64 * 4; nbias += 32 * mbo; }
-            head_off[mode][hd] = reserve(words);
+            // (the fp16-pair images hold 64 of keypoint_head.3's 65 outputs: the dustbin logit is a dot product on the vector ALUs there -- head_bx_body.hpp)
+            auto couts = [&](int p) { return mode && hd == 0 && p == 3 ? 64 : kConvs[ls[p]].cout; };
+            for (int p = 0; p < nl; ++p) { words += (size_t)4 * ((couts(p) + 31) / 32) * (mode == 2 ? 2 : 3) * 64 * 4; nbias += 32 * ((kConvs[ls[p]].cout + 31) / 32); }
+            (mode == 2 ? head_fq_off[hd] : head_off[mode][hd]) = reserve(words);
             if (mode == 0) head_boff[hd] = reserve(nbias);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[head_off[mode][hd]]);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[mode == 2 ? head_fq_off[hd] : head_off[mode][hd]]);
             size_t bo = head_boff[hd];
             for (int p = 0; p < nl; ++p) {
                 const ConvSpec& c = kConvs[ls[p]];
                 const int mbo = (c.cout + 31) / 32;
                 for (size_t i = 0; i < (size_t)c.cout * 64; ++i)
                     if (!(std::fabs(blob[coff[ls[p]].oihw + i]) < kFxMaxWeight)) head_fx_ok[hd] = false;
-                dst += pack_head_layer(&blob[coff[ls[p]].oihw], c.cout, p == 0, mode, dst);      // (weight_split.hpp)
+                dst += pack_head_layer(&blob[coff[ls[p]].oihw], couts(p), p == 0, mode ? 1 : 0, dst, mode == 2 ? 2 : 3);      // (weight_split.hpp)
                 for (int o = 0; o < 32 * mbo; ++o) blob[bo + o] = o < c.cout ? blob[coff[ls[p]].bias + o] : 0.f;
                 bo += 32 * mbo;
             }
@@ -495,11 +498,13 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     for (int hd = 0; hd < 2; ++hd) {
         ctx->nw.head_bx[hd] = ctx->blob + head_off[0][hd];
         ctx->nw.head_fx[hd] = head_fx_ok[hd] ? ctx->blob + head_off[1][hd] : nullptr;
+        ctx->nw.head_fq[hd] = head_fx_ok[hd] ? ctx->blob + head_fq_off[hd] : nullptr;
         ctx->nw.head_bx_bias[hd] = ctx->blob + head_boff[hd];
     }
     ctx->nw.block1_fx = b1fx_ok ? ctx->blob + b1fx_off : nullptr;
     ctx->nw.block1_fx3 = b1fx_ok ? ctx->blob + b1fx3_off : nullptr;
     ctx->nw.head_rel_b_last = head_b_last;
+    ctx->nw.head_kp_b_dust = blob[coff[L_KP_3].bias + 64];
     for (int fi = 0; fi < 5; ++fi) {
         LinW& l = ctx->nw.fine[fi];
         l.k = kFine[fi].k; l.n = kFine[fi].n; l.n_pad = (kFine[fi].n + 63) / 64 * 64; l.relu = kFine[fi].bn;
@@ -629,9 +634,9 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     // fused heads: reliability from the channels-last features, key-point head from the gray image
     const bool all = h->prof.which == XFH_PROF_ALL;      // one span per head instead of one for both
     prof_begin(&h->prof, all ? XFH_SPAN_HEAD_REL : XFH_PROF_HEADS, st);
-    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32, (h->opt.fx & 8) != 0, h->status);
+    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32, h->opt.fx, h->status);
     if (all) { prof_end(&h->prof, XFH_SPAN_HEAD_REL, st, 0, 0); prof_begin(&h->prof, XFH_SPAN_HEAD_KP, st); }
-    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32, (h->opt.fx & 8) != 0, h->status);
+    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32, h->opt.fx, h->status);
     prof_end(&h->prof, all ? XFH_SPAN_HEAD_KP : XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }
@@ -918,7 +923,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 2}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 15}};
+        {"heads_f32", &Options::heads_f32, 0, 2}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 63}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

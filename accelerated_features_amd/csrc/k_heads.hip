@@ -396,35 +396,44 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 
 // the split-operand heads: body in head_bx_body.hpp (also compiled for the host by tests/emu/)
-template <bool KP, int SHIFT = 0, bool FX = false>
+template <bool KP, int SHIFT = 0, int FXM = 0>      // FXM: 0 bf16 three-way split, 1 .. 3 the fp16-pair forms (head_bx_body.hpp)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_bx_kernel(HeadBxArgs a) {
     code_shift<SHIFT>();
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    head_bx_body<KP, FX>(a);
+    head_bx_body<KP, FXM>(a);
+}
+// dynamic LDS of a form: weight fragments (1 KiB each), biases, (FXM 3) a 4-KiB slot pair per wave
+static size_t head_bx_lds(bool kp, int fxm) { return (size_t)(kp ? (fxm ? 8 : 9) : 4) * 4 * (fxm == 2 ? 2 : 3) * 1024 + ((kp ? 288 : 128) + 64) * sizeof(float) + (fxm == 3 ? 8 * 4096 : 0); }
+template <bool KP, int SHIFT, int FXM>
+static void launch_head_bx(const HeadBxArgs& h, hipStream_t st) {
+    static unsigned attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<KP, SHIFT, FXM>), 160 * 1024, attr);
+    head_bx_kernel<KP, SHIFT, FXM><<<min(h.ntiles, num_cus()), 512, head_bx_lds(KP, FXM), st>>>(h);
+}
+// option fx -> the form: bit 8 the fp16 pair, + 16 two weight fragments in LDS, + 32 (instead) B through LDS
+static int head_fxm(int fx, const NetWeights& nw, int hd) {
+    if (!(fx & 8) || !nw.head_fx[hd]) return 0;
+    return (fx & 32) ? 3 : (fx & 16) ? 2 : 1;
 }
 
 long long* g_head_trace = nullptr;        // debug (xfh_debug_trace): stamps of head_bx_kernel<true>
 
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels, bool fx, int* status) {
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels, int fx, int* status) {
     if (!f32_kernels && nw.head_bx[0]) {
-        fx = fx && nw.head_fx[0];
+        const int fxm = head_fxm(fx, nw, 0);
         HeadBxArgs h{};
         h.cold = g_debug_cold;
         h.status = status;
-        h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(fx ? nw.head_fx[0] : nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
+        h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(fxm == 2 ? nw.head_fq[0] : fxm ? nw.head_fx[0] : nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
         h.H = H; h.W = W; h.hc = H / 8; h.wc = W / 8;
         h.ncell = B * h.hc * h.wc;
         h.ntiles = ceil_div(h.ncell, HD_CELLS);
         h.trace = g_head_trace;
-        const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float);
-        static unsigned attr = 0, attr_fx = 0;
-        if (fx) {
-            set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, 0, true>), 160 * 1024, attr_fx);
-            head_bx_kernel<true, 0, true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
-            return;
-        }
-        set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true>), 160 * 1024, attr);
-        head_bx_kernel<true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+        h.w_dust = nw.conv[L_KP_3].w_oihw + 64 * 64; h.b_dust = nw.head_kp_b_dust;
+        if (fxm == 3) launch_head_bx<true, 0, 3>(h, st);
+        else if (fxm == 2) launch_head_bx<true, 0, 2>(h, st);
+        else if (fxm == 1) launch_head_bx<true, 0, 1>(h, st);
+        else launch_head_bx<true, 0, 0>(h, st);
         return;
     }
     HeadArgs a{};
@@ -447,26 +456,21 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
     head_fused_kernel<true><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels, bool fx, int* status) {
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels, int fx, int* status) {
     if (!f32_kernels && nw.head_bx[1]) {
-        fx = fx && nw.head_fx[1];
+        const int fxm = head_fxm(fx, nw, 1);
         HeadBxArgs h{};
         h.cold = g_debug_cold;
         h.status = status;
-        h.src = feats; h.wq = reinterpret_cast<const uint4*>(fx ? nw.head_fx[1] : nw.head_bx[1]); h.bias = nw.head_bx_bias[1]; h.out = reliab; h.inv = invnorm;
+        h.src = feats; h.wq = reinterpret_cast<const uint4*>(fxm == 2 ? nw.head_fq[1] : fxm ? nw.head_fx[1] : nw.head_bx[1]); h.bias = nw.head_bx_bias[1]; h.out = reliab; h.inv = invnorm;
         h.w_last = nw.conv[L_HEAT_2].w_oihw; h.b_last = nw.head_rel_b_last;
         h.hc = 1; h.wc = 1; h.H = 8; h.W = 8;
         h.ncell = ncell;
         h.ntiles = ceil_div(ncell, HD_CELLS);
-        const size_t lds = (size_t)2 * 2 * 4 * 3 * 1024 + 128 * sizeof(float);
-        static unsigned attr = 0, attr_fx = 0;
-        if (fx) {
-            set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<false, 0, true>), 160 * 1024, attr_fx);
-            head_bx_kernel<false, 0, true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
-            return;
-        }
-        set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<false>), 160 * 1024, attr);
-        head_bx_kernel<false><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+        if (fxm == 3) launch_head_bx<false, 0, 3>(h, st);
+        else if (fxm == 2) launch_head_bx<false, 0, 2>(h, st);
+        else if (fxm == 1) launch_head_bx<false, 0, 1>(h, st);
+        else launch_head_bx<false, 0, 0>(h, st);
         return;
     }
     HeadArgs a{};
@@ -494,8 +498,8 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
 // Debug (xfh_debug_head_soak, tools/head_soak.py): the key-point head alone, launched `iters` times, every result compared on the
 // device with a reference result; differing float4s are counted and the first `cap` of them recorded as {iteration, float4 index,
 // bits got, bits expected} behind a 4-word header {count, 0, 0, 0}.  variant: 0 = the split-bf16 kernel, 100 = the f32-MFMA kernel with
-// an activation tile (head_fused_kernel), 101 = the f32-MFMA kernel with register input (head_f32r_kernel, the default head), 102 = the split head in the fp16-pair arithmetic;
-// 1000 + s / 2000 + s / 3000 + s / 4000 + s = the same four kernels COLD-STARTED (s_icache_inv per workgroup) with the body moved by 4 s bytes,
+// an activation tile (head_fused_kernel), 101 = the f32-MFMA kernel with register input (head_f32r_kernel, the default head), 102 / 103 / 104 = the split head in the fp16-pair arithmetic (three weight fragments | two | three and B through LDS);
+// 1000 + s / 2000 + s / 3000 + s / 4000 + s / 5000 + s = 0, 100, 101, 102, 104 COLD-STARTED (s_icache_inv per workgroup) with the body moved by 4 s bytes,
 // s = 0 .. 15: the code-position scan that separates a kernel that trips on instruction-cache refills from one that does not.
 // (The experiment builds of round 4 -- reloads, pads, dumps, dry passes: variants 1 .. 26 of profiles/r04_head_hazard -- lived here until commit 9607d16.)
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -514,19 +518,11 @@ __global__ __launch_bounds__(256) void soak_compare_kernel(const uint4* __restri
 }
 
 template <int SHIFT>
-static void launch_kp_head_bx_shift(const HeadBxArgs& h, hipStream_t st) {
-    const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float);
-    static unsigned attr = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, SHIFT>), 160 * 1024, attr);
-    head_bx_kernel<true, SHIFT><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
-}
+static void launch_kp_head_bx_shift(const HeadBxArgs& h, hipStream_t st) { launch_head_bx<true, SHIFT, 0>(h, st); }
 template <int SHIFT>
-static void launch_kp_head_fx_shift(const HeadBxArgs& h, hipStream_t st) {
-    const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float);
-    static unsigned attr = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, SHIFT, true>), 160 * 1024, attr);
-    head_bx_kernel<true, SHIFT, true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
-}
+static void launch_kp_head_fx_shift(const HeadBxArgs& h, hipStream_t st) { launch_head_bx<true, SHIFT, 1>(h, st); }
+template <int SHIFT>
+static void launch_kp_head_fl_shift(const HeadBxArgs& h, hipStream_t st) { launch_head_bx<true, SHIFT, 3>(h, st); }
 template <int SHIFT>
 static void launch_kp_head_f32_shift(const HeadArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
@@ -546,13 +542,14 @@ static void launch_kp_head_f32r_shift(const HeadArgs& a, hipStream_t st) {
 #define XFH_HEAD_SCAN_SHIFTS 1
 #endif
 template <int S>
-static bool launch_shift(int shift, const HeadBxArgs& h, const HeadBxArgs& hx, const HeadArgs& a, int kind, hipStream_t st) {      // shift -> the instantiation; kind 1 bf16, 2 f32 (LDS tile), 3 f32 (registers), 4 fp16 pair
+static bool launch_shift(int shift, const HeadBxArgs& h, const HeadBxArgs& hx, const HeadBxArgs& hq, const HeadArgs& a, int kind, hipStream_t st) {      // shift -> the instantiation; kind 1 bf16, 2 f32 (LDS tile), 3 f32 (registers), 4 fp16 pair, 5 fp16 pair with B through LDS
     if (shift == S) {
         if (kind == 2) launch_kp_head_f32_shift<S>(a, st); else if (kind == 3) launch_kp_head_f32r_shift<S>(a, st); else if (kind == 4) launch_kp_head_fx_shift<S>(hx, st);
+        else if (kind == 5) launch_kp_head_fl_shift<S>(hx, st);
         else launch_kp_head_bx_shift<S>(h, st);
         return true;
     }
-    if constexpr (S + 1 < XFH_HEAD_SCAN_SHIFTS) return launch_shift<S + 1>(shift, h, hx, a, kind, st);
+    if constexpr (S + 1 < XFH_HEAD_SCAN_SHIFTS) return launch_shift<S + 1>(shift, h, hx, hq, a, kind, st);
     return false;
 }
 
@@ -570,14 +567,19 @@ int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B,
         for (int i = 0; i < 4; ++i) { fa.w[i] = nw.conv[L[i]].w_kcp; fa.bias[i] = nw.conv[L[i]].bias; }
     }
     fa.cold = h.cold = (variant >= 1000) ? 1 : g_debug_cold;
+    h.w_dust = nw.conv[L_KP_3].w_oihw + 64 * 64; h.b_dust = nw.head_kp_b_dust;
     HeadBxArgs hx = h;                     // the fp16-pair head (variants 102, 4000 + s)
     hx.wq = reinterpret_cast<const uint4*>(nw.head_fx[0]);
+    HeadBxArgs hq = h;                     // its two-fragment image (variant 103)
+    hq.wq = reinterpret_cast<const uint4*>(nw.head_fq[0]);
     const size_t n4h = (size_t)B * H * W / 4, n4l = (size_t)h.ncell * 65 / 4;
     for (int it = 0; it < iters; ++it) {
         if (variant >= 1000) {
-            if (variant >= 5000 || (variant >= 4000 && !nw.head_fx[0]) || !launch_shift<0>(variant % 1000, h, hx, fa, variant / 1000, st)) return -1;
+            if (variant >= 6000 || (variant >= 4000 && !nw.head_fx[0]) || !launch_shift<0>(variant % 1000, h, hx, hq, fa, variant / 1000, st)) return -1;
         } else if (variant == 0) launch_kp_head_bx_shift<0>(h, st);
         else if (variant == 102 && nw.head_fx[0]) launch_kp_head_fx_shift<0>(hx, st);
+        else if (variant == 103 && nw.head_fx[0]) launch_head_bx<true, 0, 2>(hq, st);
+        else if (variant == 104 && nw.head_fx[0]) launch_kp_head_fl_shift<0>(hx, st);
         else if (variant == 100) launch_kp_head_f32_shift<0>(fa, st);
         else if (variant == 101) launch_kp_head_f32r_shift<0>(fa, st);
         else return -1;

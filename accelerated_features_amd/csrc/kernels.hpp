@@ -39,8 +39,10 @@ struct NetWeights {
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): [0] key-point head, [1] reliability head
     const void* head_bx[2];          // per layer [K step 4][cout block][split 3][64 lanes][8] bf16
     const void* head_fx[2];          // the same in the fp16-pair arithmetic (or NULL)
+    const void* head_fq[2];          // the fp16-pair form with two fragments per weight (q0, q2): [K step][cout block][2][64 lanes][8] (or NULL)
     const float* head_bx_bias[2];    // biases padded to the cout blocks (KP 64,64,64,96 ; REL 64,64)
     float head_rel_b_last;           // bias of the final 64 -> 1 layer of the reliability head
+    float head_kp_b_dust;            // bias of the dustbin logit (output 64 of keypoint_head.3)
     const void* block1_fx;           // block1.3 in the fp16-pair arithmetic, compact LDS image (block1_fx.hpp), or NULL
     const void* block1_fx3;          // block1.2 likewise (q0 / q2 fragments)
 };
@@ -60,7 +62,7 @@ struct Options {
                             // head_bx_kernel<true> delivers a wrong 16-cell block once in 10^3..10^5 launches when a workgroup's first tile runs on instruction-cache
                             // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
     int fx = 3;             // split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
-                            // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel), 8 = the split heads (with heads_f32 = 0: head_bx_kernel<.., true>); 0 = the bf16 three-way split everywhere
+                            // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel), 8 = the split heads (with heads_f32 = 0: head_bx_kernel<.., 1>), + 16 = with two weight fragments in LDS (<.., 2>), + 32 = (instead) the B fragments through LDS (<.., 3>); 0 = the bf16 three-way split everywhere
     int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected); 6 = 5 with conv4 on the fp16 matrix cores (fp16-pair arithmetic, block1_fx.hpp), 7 = conv3 too
 };
 
@@ -134,9 +136,9 @@ void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat
 // reliability head -> sigmoid map
 int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, const float* heat_ref, float* logits, const float* logits_ref,
               int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, hipStream_t st);      // debug, k_heads.hip
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels = 0, bool fx = false, int* status = nullptr);
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels = 0, int fx = 0, int* status = nullptr);
 // invnorm (optional): 1 / max(||feats[cell,:]||, 1e-12) per cell, a by-product of the layer-1 operand loads
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels = 0, bool fx = false, int* status = nullptr);
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels = 0, int fx = 0, int* status = nullptr);
 
 // ---- k_detect.hip -----------------------------------------------------------------------
 struct DetectWs {          // carved from the caller's workspace by api.hip

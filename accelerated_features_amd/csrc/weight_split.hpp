@@ -71,8 +71,9 @@ constexpr float kFxMaxWeight = 31.f;                   // |w| * 2^11 must stay b
 
 // One layer of a split-operand head (head_bx_body.hpp) in operand order: [K step t][cout block][split][lane = half * 32 + cout][8], cout blocks of 32 (zeros above cout).
 // K order: the first layer of a head takes its 64 input channels in natural order (16 t + 8 half + i); a chained layer takes the previous layer's D registers, i.e.
-// feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).  w: (cout, 64) fp32 (BatchNorm folded), mode: split_weight's.  Returns the 16-bit words written.
-inline size_t pack_head_layer(const float* w, int cout, bool first, int mode, uint16_t* dst) {
+// feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).  w: (cout, 64) fp32 (BatchNorm folded), mode: split_weight's.  nfrag = 2 (mode 1 only): q0 and q2 alone
+// ([.. ][2 fragments][lane][8]; the kernel derives q1 = 2^-11 q0).  Returns the 16-bit words written.
+inline size_t pack_head_layer(const float* w, int cout, bool first, int mode, uint16_t* dst, int nfrag = 3) {
     const int mbo = (cout + 31) / 32;
     for (int t = 0; t < 4; ++t)
         for (int mb = 0; mb < mbo; ++mb)
@@ -82,9 +83,10 @@ inline size_t pack_head_layer(const float* w, int cout, bool first, int mode, ui
                     const int ch = first ? 16 * t + 8 * hf + i : 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
                     uint16_t q[3];
                     split_weight(o < cout ? w[(size_t)o * 64 + ch] : 0.f, mode, q);
-                    for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * mbo + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                    if (nfrag == 3) for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * mbo + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                    else for (int sp = 0; sp < 2; ++sp) dst[((((size_t)t * mbo + mb) * 2 + sp) * 64 + lane) * 8 + i] = q[2 * sp];
                 }
-    return (size_t)4 * mbo * 3 * 64 * 8;
+    return (size_t)4 * mbo * nfrag * 64 * 8;
 }
 
 }  // namespace xfh

@@ -138,6 +138,7 @@ inline void __syncthreads() { emu::wg->bar.arrive_and_wait(); }
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 #define XFH_DYN_LDS(name) float* name = reinterpret_cast<float*>(emu::wg->lds_base())
 #define XFH_DYN_LDS_BYTES(name) unsigned char* name = emu::wg->lds_base()
+#define XFH_LDS_VOLATILE(T) volatile T
 #define XFH_NOP16_2(a, b) ((void)0)
 #define XFH_NOP16_3(a, b, c) ((void)0)
 #define XFH_PIN(x) ((void)0)

@@ -23,13 +23,13 @@ int main() {
     std::vector<float> bias;
     auto pack = [&](const std::vector<std::vector<float>>& ws, const std::vector<std::vector<float>>& bs, const std::vector<int>& couts) {
         size_t words = 0;
-        for (int c : couts) words += (size_t)4 * ((c + 31) / 32) * 3 * 64 * 8;
+        for (int c : couts) words += (size_t)4 * ((c + 31) / 32) * (fx == 2 ? 2 : 3) * 64 * 8;
         wq.assign(words, 0);
         uint16_t* dst = wq.data();
         for (size_t p = 0; p < couts.size(); ++p) {
-            dst += xfh::pack_head_layer(ws[p].data(), couts[p], p == 0, fx ? 1 : 0, dst);
-            const int pad = 32 * ((couts[p] + 31) / 32);
-            for (int o = 0; o < pad; ++o) bias.push_back(o < couts[p] ? bs[p][o] : 0.f);
+            dst += xfh::pack_head_layer(ws[p].data(), couts[p], p == 0, fx ? 1 : 0, dst, fx == 2 ? 2 : 3);
+            const int nb = (int)bs[p].size(), pad = 32 * ((nb + 31) / 32);          // (the bias table keeps the layout 64, 64, 64, 96)
+            for (int o = 0; o < pad; ++o) bias.push_back(o < nb ? bs[p][o] : 0.f);
         }
         a.wq = reinterpret_cast<const uint4*>(wq.data());
         a.bias = bias.data();
@@ -37,15 +37,18 @@ int main() {
     if (kp) {
         auto gray = rd((size_t)B * H * W), coef = rd(2 * B);
         std::vector<std::vector<float>> ws = {rd(4096), rd(4096), rd(4096), rd(65 * 64)}, bs = {rd(64), rd(64), rd(64), rd(65)};
-        pack(ws, bs, {64, 64, 64, 65});
+        pack(ws, bs, {64, 64, 64, fx ? 64 : 65});          // (the fp16-pair forms take the dustbin logit as a dot product: w_dust / b_dust)
+        a.w_dust = ws[3].data() + 64 * 64; a.b_dust = bs[3][64];
         a.src = gray.data(); a.coef = coef.data();
         a.H = H; a.W = W; a.hc = H / 8; a.wc = W / 8; a.ncell = B * a.hc * a.wc; a.ntiles = (a.ncell + 255) / 256;
         std::vector<float> heat((size_t)B * H * W, NAN), logits((size_t)a.ncell * 65, NAN);
         a.out = heat.data(); a.logits = logits.data();
-        const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * 4;
+        const size_t lds = (size_t)(fx ? 8 : 9) * 4 * (fx == 2 ? 2 : 3) * 1024 + (288 + 64) * 4 + (fx == 3 ? 8 * 4096 : 0);
         const int grid = std::min(a.ntiles, 2);          // (persistent: each workgroup walks several tiles)
-        if (fx) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, true>(a); });
-        else emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, false>(a); });
+        if (fx == 3) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, 3>(a); });
+        else if (fx == 2) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, 2>(a); });
+        else if (fx == 1) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, 1>(a); });
+        else emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, 0>(a); });
         fwrite(heat.data(), 4, heat.size(), stdout);
         fwrite(logits.data(), 4, logits.size(), stdout);
     } else {
@@ -59,10 +62,12 @@ int main() {
         a.hc = 1; a.wc = 1; a.H = 8; a.W = 8; a.ncell = B; a.ntiles = (B + 255) / 256;
         std::vector<float> rel(B, NAN), inv(B, NAN);
         a.out = rel.data(); a.inv = inv.data();
-        const size_t lds = (size_t)2 * 2 * 4 * 3 * 1024 + 128 * 4;
+        const size_t lds = (size_t)2 * 2 * 4 * (fx == 2 ? 2 : 3) * 1024 + (128 + 64) * 4 + (fx == 3 ? 8 * 4096 : 0);
         const int grid = std::min(a.ntiles, 2);
-        if (fx) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, true>(a); });
-        else emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, false>(a); });
+        if (fx == 3) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, 3>(a); });
+        else if (fx == 2) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, 2>(a); });
+        else if (fx == 1) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, 1>(a); });
+        else emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, 0>(a); });
         fwrite(rel.data(), 4, rel.size(), stdout);
         fwrite(inv.data(), 4, inv.size(), stdout);
     }

@@ -27,7 +27,7 @@ def _blob(hdr, arrs):
     return np.concatenate([np.array(hdr, np.int32).view(np.float32)] + [np.asarray(a, np.float32).reshape(-1) for a in arrs]).tobytes()
 
 
-@pytest.mark.parametrize("fx", [0, 1])
+@pytest.mark.parametrize("fx", [0, 1, 2, 3])
 def test_keypoint_head_on_the_host(emu_bin, fx):
     g = torch.Generator().manual_seed(3 + fx)
     B, H, W = 2, 96, 136                              # 2 x 12 x 17 = 408 cells: one full tile and a partial one
@@ -55,7 +55,7 @@ def test_keypoint_head_on_the_host(emu_bin, fx):
     assert e_l <= 2e-5 * float(lg.abs().max()) and e_h <= 1e-6
 
 
-@pytest.mark.parametrize("fx", [0, 1])
+@pytest.mark.parametrize("fx", [0, 1, 2, 3])
 def test_reliability_head_on_the_host(emu_bin, fx):
     g = torch.Generator().manual_seed(13 + fx)
     n = 300
@@ -77,5 +77,5 @@ def test_reliability_head_on_the_host(emu_bin, fx):
     print(f"fx {fx}: reliability max |err| {e_r:.3g}, 1 / |feats| max rel err {e_i:.3g}")
     assert status == 0 and e_r <= 2e-6 and e_i <= 1e-6
     if fx:      # the range guard: features beyond the fp16 range are reported
-        out = subprocess.run([emu_bin], input=_blob([0, 1, n, 0, 0], [feats * 1.0e5] + ws + [w2] + bs + [b2]), capture_output=True, check=True, timeout=1800).stdout
+        out = subprocess.run([emu_bin], input=_blob([0, fx, n, 0, 0], [feats * 1.0e5] + ws + [w2] + bs + [b2]), capture_output=True, check=True, timeout=1800).stdout
         assert int(np.frombuffer(out[-4:], np.int32)[0]) & 1
