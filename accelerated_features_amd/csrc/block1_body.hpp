@@ -6,7 +6,9 @@
 #include "kernels.hpp"
 #include "bx_split.hpp"
 #include <type_traits>
+#ifndef XFH_DYN_LDS
 #define XFH_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#endif
 #define XFH_NOP16_2(a, b) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b))              /* 16 idle slots behind an MFMA group, tied to its accumulators */
 #define XFH_NOP16_3(a, b, c) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c))
 #ifndef XFH_PIN

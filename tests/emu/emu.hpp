@@ -92,6 +92,22 @@ inline f16v mfma32(V8 a, V8 b, f16v c) {
     wg->wave_bar[w]->arrive_and_wait();
     return d;
 }
+// v_mfma_f32_32x32x2_f32: lane l holds A[row l & 31][k = l >> 5] and B[k = l >> 5][column l & 31]; D as above
+inline f16v mfma32x2(float a, float b, f16v c) {
+    const int t = tidx.x, w = t >> 6, l = t & 63;
+    wg->opa32[t * 8] = a; wg->opb32[t * 8] = b;
+    wg->wave_bar[w]->arrive_and_wait();
+    f16v d = c;
+    const int n = l & 31, half = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+        double s = 0;
+        for (int k = 0; k < 2; ++k) s += (double)wg->opa32[(w * 64 + 32 * k + m) * 8] * (double)wg->opb32[(w * 64 + 32 * k + n) * 8];
+        d[r] = (float)((double)c[r] + s);
+    }
+    wg->wave_bar[w]->arrive_and_wait();
+    return d;
+}
 // value of lane ^ mask of the same wave
 inline float shfl_xor(float v, int mask) {
     const int t = tidx.x, w = t >> 6, l = t & 63;
@@ -101,7 +117,7 @@ inline float shfl_xor(float v, int mask) {
     wg->wave_bar[w]->arrive_and_wait();
     return r;
 }
-inline void dma16(const void* g, void* l_base) { std::memcpy(static_cast<unsigned char*>(l_base) + 16 * (tidx.x & 63), g, 16); }
+inline void dma(const void* g, void* l_base, int size) { std::memcpy(static_cast<unsigned char*>(l_base) + size * (tidx.x & 63), g, size); }      // (M0 base + lane x size)
 struct Rsrc { unsigned char* base; unsigned bytes; };
 inline float med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 inline unsigned perm(unsigned hi, unsigned lo, unsigned sel) {
@@ -153,8 +169,10 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu::mfma32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) emu::mfma32(a, b, c)
 #define __builtin_amdgcn_s_memtime() 0ll
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) emu::mfma32x2(a, b, c)
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __shfl_xor(v, mask, width) emu::shfl_xor(v, mask)
-#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::dma16(g, l)
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::dma(g, l, size)
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{reinterpret_cast<unsigned char*>(p), (unsigned)(bytes)}
 #define __builtin_amdgcn_raw_buffer_store_b32(val, rs, voff, soff, aux)                                                               \
     do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 4 <= (rs).bytes) { const unsigned v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 4); } } while (0)

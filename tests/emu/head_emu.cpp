@@ -1,9 +1,11 @@
-// head_bx_body<KP, FX> (csrc/head_bx_body.hpp) on the host.  stdin: {kp, fx, B, H, W} int32 (REL: B = cells, H = W = 0), then
+// head_bx_body<KP, FXM> (csrc/head_bx_body.hpp; fx = 0 .. 3) and head_f32r_body<KP> (csrc/head_f32r_body.hpp: the default heads; fx = -1) on the host.
+// stdin: {kp, fx, B, H, W} int32 (REL: B = cells, H = W = 0), then
 //   KP : gray (B*H*W), coef (2B), w0..w2 (64x64 each), w3 (65x64), b0..b2 (64 each), b3 (65)         -> stdout heat (B*H*W), logits (cells*65), status
 //   REL: feats (cells*64), w0, w1 (64x64), w2 (64), b0, b1 (64), b2 (1)                               -> stdout reliability (cells), inv (cells), status
 #include "emu.hpp"
 #include "weight_split.hpp"
 #include "head_bx_body.hpp"
+#include "head_f32r_body.hpp"
 #include <cstdio>
 
 static std::vector<float> rd(size_t n) {
@@ -17,6 +19,39 @@ int main() {
     if (fread(hdr, 4, 5, stdin) != 5) return 2;
     const int kp = hdr[0], fx = hdr[1], B = hdr[2], H = hdr[3], W = hdr[4];
     int status = 0;
+    if (fx < 0) {      // the f32-MFMA heads with register input: weights [k][n_pad] (BN folded), n_pad = 64 | 96
+        xfh::HeadArgs f{};
+        auto kcp = [](const std::vector<float>& w, int cout, int npad) { std::vector<float> o((size_t)64 * npad, 0.f); for (int n = 0; n < cout; ++n) for (int k = 0; k < 64; ++k) o[(size_t)k * npad + n] = w[(size_t)n * 64 + k]; return o; };
+        if (kp) {
+            auto gray = rd((size_t)B * H * W), coef = rd(2 * B);
+            std::vector<std::vector<float>> ws = {rd(4096), rd(4096), rd(4096), rd(65 * 64)}, bs = {rd(64), rd(64), rd(64), rd(65)};
+            std::vector<std::vector<float>> wk = {kcp(ws[0], 64, 64), kcp(ws[1], 64, 64), kcp(ws[2], 64, 64), kcp(ws[3], 65, 96)};
+            bs[3].resize(96, 0.f);
+            for (int i = 0; i < 4; ++i) { f.w[i] = wk[i].data(); f.bias[i] = bs[i].data(); }
+            f.src = gray.data(); f.coef = coef.data(); f.H = H; f.W = W; f.hc = H / 8; f.wc = W / 8; f.ncell = B * f.hc * f.wc; f.ntiles = (f.ncell + 255) / 256;
+            std::vector<float> heat((size_t)B * H * W, NAN), logits((size_t)f.ncell * 65, NAN);
+            f.out = heat.data(); f.logits = logits.data();
+            emu::launch(std::min(f.ntiles, 2), 512, (size_t)(3 * 64 * 64 + 64 * 96) * 4, [&] { xfh::head_f32r_body<true>(f); });
+            fwrite(heat.data(), 4, heat.size(), stdout);
+            fwrite(logits.data(), 4, logits.size(), stdout);
+        } else {
+            auto feats = rd((size_t)B * 64);
+            std::vector<std::vector<float>> ws = {rd(4096), rd(4096)};
+            auto w2 = rd(64);
+            std::vector<std::vector<float>> bs = {rd(64), rd(64)};
+            auto b2 = rd(1);
+            std::vector<std::vector<float>> wk = {kcp(ws[0], 64, 64), kcp(ws[1], 64, 64)};
+            f.w[0] = wk[0].data(); f.w[1] = wk[1].data(); f.w[2] = w2.data(); f.bias[0] = bs[0].data(); f.bias[1] = bs[1].data(); f.bias[2] = b2.data();
+            f.src = feats.data(); f.hc = 1; f.wc = 1; f.H = 8; f.W = 8; f.ncell = B; f.ntiles = (B + 255) / 256;
+            std::vector<float> rel(B, NAN), inv(B, NAN);
+            f.out = rel.data(); f.inv = inv.data();
+            emu::launch(std::min(f.ntiles, 2), 512, (size_t)(2 * 64 * 64 + 64) * 4, [&] { xfh::head_f32r_body<false>(f); });
+            fwrite(rel.data(), 4, rel.size(), stdout);
+            fwrite(inv.data(), 4, inv.size(), stdout);
+        }
+        fwrite(&status, 4, 1, stdout);
+        return 0;
+    }
     xfh::HeadBxArgs a{};
     a.status = &status;
     std::vector<uint16_t> wq;

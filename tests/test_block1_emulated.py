@@ -52,7 +52,7 @@ def _run(emu_bin, mode, w, gray, coef):
     pad = lambda t: torch.cat([t.reshape(-1), torch.zeros(32 - t.numel())])
     blob = np.concatenate([np.array([B, H, W, mode], np.int32).view(np.float32)] + [t.numpy().astype(np.float32).reshape(-1) for t in (
         gray, coef, kc(w["w1"]), w["b1"], kc(w["w2"]), w["b2"], kc(w["w3"]), w["b3"], kc(w["w4"]), pad(w["b4"]), pad(w["skw"]), pad(w["skb"]))])
-    out = subprocess.run([emu_bin], input=blob.tobytes(), capture_output=True, check=True, timeout=900).stdout
+    out = subprocess.run([emu_bin], input=blob.tobytes(), capture_output=True, check=True, timeout=240).stdout
     x1 = np.frombuffer(out[:-4], np.float32).reshape(B, 24, H // 4, W // 4)
     return x1, int(np.frombuffer(out[-4:], np.int32)[0])
 

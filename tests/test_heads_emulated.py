@@ -27,15 +27,15 @@ def _blob(hdr, arrs):
     return np.concatenate([np.array(hdr, np.int32).view(np.float32)] + [np.asarray(a, np.float32).reshape(-1) for a in arrs]).tobytes()
 
 
-@pytest.mark.parametrize("fx", [0, 1, 2, 3])
+@pytest.mark.parametrize("fx", [-1, 0, 1, 2, 3])      # -1: the f32-MFMA heads with register input (the default), 0: bf16 three-way split, 1 .. 3: the fp16-pair forms
 def test_keypoint_head_on_the_host(emu_bin, fx):
-    g = torch.Generator().manual_seed(3 + fx)
+    g = torch.Generator().manual_seed(4 + fx)
     B, H, W = 2, 96, 136                              # 2 x 12 x 17 = 408 cells: one full tile and a partial one
     gray = torch.rand(B, H, W, generator=g)
     coef = torch.stack([1.0 + torch.rand(B, generator=g) * 2, torch.randn(B, generator=g) * 0.5], 1)
     ws = [torch.randn(64, 64, generator=g) * 0.18 for _ in range(3)] + [torch.randn(65, 64, generator=g) * 0.3]
     bs = [torch.randn(64, generator=g) * 0.3 for _ in range(3)] + [torch.randn(65, generator=g)]
-    out = subprocess.run([emu_bin], input=_blob([1, fx, B, H, W], [gray, coef] + ws + bs), capture_output=True, check=True, timeout=1800).stdout
+    out = subprocess.run([emu_bin], input=_blob([1, fx, B, H, W], [gray, coef] + ws + bs), capture_output=True, check=True, timeout=240).stdout
     ncell = B * (H // 8) * (W // 8)
     heat = np.frombuffer(out[:4 * B * H * W], np.float32).reshape(B, H, W)
     logits = np.frombuffer(out[4 * B * H * W:4 * B * H * W + 4 * ncell * 65], np.float32).reshape(ncell, 65)
@@ -55,16 +55,16 @@ def test_keypoint_head_on_the_host(emu_bin, fx):
     assert e_l <= 2e-5 * float(lg.abs().max()) and e_h <= 1e-6
 
 
-@pytest.mark.parametrize("fx", [0, 1, 2, 3])
+@pytest.mark.parametrize("fx", [-1, 0, 1, 2, 3])
 def test_reliability_head_on_the_host(emu_bin, fx):
-    g = torch.Generator().manual_seed(13 + fx)
+    g = torch.Generator().manual_seed(14 + fx)
     n = 300
     feats = torch.randn(n, 64, generator=g) * 2
     ws = [torch.randn(64, 64, generator=g) * 0.18 for _ in range(2)]
     w2 = torch.randn(64, generator=g) * 0.2
     bs = [torch.randn(64, generator=g) * 0.3 for _ in range(2)]
     b2 = torch.randn(1, generator=g)
-    out = subprocess.run([emu_bin], input=_blob([0, fx, n, 0, 0], [feats] + ws + [w2] + bs + [b2]), capture_output=True, check=True, timeout=1800).stdout
+    out = subprocess.run([emu_bin], input=_blob([0, fx, n, 0, 0], [feats] + ws + [w2] + bs + [b2]), capture_output=True, check=True, timeout=240).stdout
     rel = np.frombuffer(out[:4 * n], np.float32)
     inv = np.frombuffer(out[4 * n:8 * n], np.float32)
     status = int(np.frombuffer(out[-4:], np.int32)[0])
@@ -76,6 +76,6 @@ def test_reliability_head_on_the_host(emu_bin, fx):
     e_r, e_i = float(np.abs(rel - ref.numpy()).max()), float(np.abs(inv / iref.numpy() - 1).max())
     print(f"fx {fx}: reliability max |err| {e_r:.3g}, 1 / |feats| max rel err {e_i:.3g}")
     assert status == 0 and e_r <= 2e-6 and e_i <= 1e-6
-    if fx:      # the range guard: features beyond the fp16 range are reported
-        out = subprocess.run([emu_bin], input=_blob([0, fx, n, 0, 0], [feats * 1.0e5] + ws + [w2] + bs + [b2]), capture_output=True, check=True, timeout=1800).stdout
+    if fx > 0:      # the range guard: features beyond the fp16 range are reported
+        out = subprocess.run([emu_bin], input=_blob([0, fx, n, 0, 0], [feats * 1.0e5] + ws + [w2] + bs + [b2]), capture_output=True, check=True, timeout=240).stdout
         assert int(np.frombuffer(out[-4:], np.int32)[0]) & 1
