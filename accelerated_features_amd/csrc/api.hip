@@ -923,7 +923,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 2}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 63}};
+        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 63}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

@@ -85,7 +85,7 @@ __device__ inline void chain_layer(const float* __restrict__ Wl, int npad, const
 // After the weights have landed there is no barrier: the waves drift apart and cover each other's epilogues, as in head_bx_kernel -- on the f32
 // instruction (v_mfma_f32_32x32x2_f32, one VGPR per operand), which the cold-instruction-cache torture of tools/head_soak.py does not trip.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <bool KP>
+template <bool KP, bool DUST = true>      // DUST = false: the round-4 form (the dustbin logit as the only real row of a third cout block), kept for A/B (heads_f32 = 3)
 __device__ __forceinline__ void head_f32r_body(const HeadArgs& a) {
     constexpr int NL = KP ? 4 : 3;
     XFH_DYN_LDS(smem_r);
@@ -174,10 +174,16 @@ __device__ __forceinline__ void head_f32r_body(const HeadArgs& a) {
         if (KP) {
             chain_layer<2>(Wl + 64 * 64, 64, a.bias[1], accA, accB, l31, half);
             chain_layer<2>(Wl + 2 * 64 * 64, 64, a.bias[2], accB, accA, l31, half);
-            f32x16 lg[2];
-            float dust;
-            chain_layer<2, true>(Wl + 3 * 64 * 64, 96, a.bias[3], accA, lg, l31, half, &dust);      // (the 64 real outputs on the matrix cores, the dustbin logit as a dot product)
-            const float lgd = dust + xhalf(dust) + a.bias[3][64];
+            f32x16 lg[DUST ? 2 : 3];
+            float lgd;
+            if constexpr (DUST) {
+                float dust;
+                chain_layer<2, true>(Wl + 3 * 64 * 64, 96, a.bias[3], accA, lg, l31, half, &dust);      // (the 64 real outputs on the matrix cores, the dustbin logit as a dot product)
+                lgd = dust + xhalf(dust) + a.bias[3][64];
+            } else {
+                chain_layer<3>(Wl + 3 * 64 * 64, 96, a.bias[3], accA, lg, l31, half);
+                lgd = lg[DUST ? 0 : 2][0];          // (half 0 only: the one place that uses it)
+            }
             // lane (l31,half) holds logits c = 32m + (r&3) + 8(r>>2) + 4*half of its cell; the dustbin logit (c == 64) is lgd, in every lane
             float mx = -INFINITY;
 #pragma unroll

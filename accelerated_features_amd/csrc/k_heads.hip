@@ -194,11 +194,11 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
 
 
 // the default heads: body in head_f32r_body.hpp (also compiled for the host by tests/emu/)
-template <bool KP, int SHIFT = 0>
+template <bool KP, int SHIFT = 0, bool DUST = true>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_f32r_kernel(HeadArgs a) {
     code_shift<SHIFT>();
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    head_f32r_body<KP>(a);
+    head_f32r_body<KP, DUST>(a);
 }
 
 // the split-operand heads: body in head_bx_body.hpp (also compiled for the host by tests/emu/)
@@ -250,8 +250,13 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
     a.ntiles = ceil_div(a.ncell, HD_CELLS);
     const int L[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3};
     for (int i = 0; i < 4; ++i) { a.w[i] = nw.conv[L[i]].w_kcp; a.bias[i] = nw.conv[L[i]].bias; }
-    if (f32_kernels == 2) {      // the register-input form (no activation tile, no barrier per tile)
-        static unsigned attr_r = 0;
+    if (f32_kernels >= 2) {      // the register-input form (no activation tile, no barrier per tile); 3: with the dustbin logit on the matrix cores (round 4)
+        static unsigned attr_r = 0, attr_o = 0;
+        if (f32_kernels == 3) {
+            set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<true, 0, false>), 160 * 1024, attr_o);
+            head_f32r_kernel<true, 0, false><<<min(a.ntiles, num_cus()), 512, (size_t)(3 * 64 * 64 + 64 * 96) * sizeof(float), st>>>(a);
+            return;
+        }
         set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<true>), 160 * 1024, attr_r);
         head_f32r_kernel<true><<<min(a.ntiles, num_cus()), 512, (size_t)(3 * 64 * 64 + 64 * 96) * sizeof(float), st>>>(a);
         return;
@@ -288,7 +293,7 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
     a.w[0] = nw.conv[L_HEAT_0].w_kcp; a.bias[0] = nw.conv[L_HEAT_0].bias;
     a.w[1] = nw.conv[L_HEAT_1].w_kcp; a.bias[1] = nw.conv[L_HEAT_1].bias;
     a.w[2] = nw.conv[L_HEAT_2].w_oihw; a.bias[2] = nw.conv[L_HEAT_2].bias;
-    if (f32_kernels == 2) {
+    if (f32_kernels >= 2) {
         static unsigned attr_r = 0;
         set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<false>), 160 * 1024, attr_r);
         head_f32r_kernel<false><<<min(a.ntiles, num_cus()), 512, (size_t)(2 * 64 * 64 + 64) * sizeof(float), st>>>(a);

@@ -91,7 +91,7 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   "wino"          0..2    3x3/s1 layers: 0 never Winograd, 1 unfused layers only, 2 (default) also the 3x3 + 1x1 pairs
  *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
  *                           8 not block3.0, 16 the stride-2 64 -> 64 | 128 layers (block4.0, block5.0) (default 21)
- *   "heads_f32"     0..2    both heads on f32 MFMAs: 2 (default) the register-input kernels (head_f32r_kernel), 1 the round-1 kernels with an activation tile in LDS
+ *   "heads_f32"     0..3    both heads on f32 MFMAs: 2 (default) the register-input kernels (head_f32r_kernel; 3 = their round-4 form with the dustbin logit on the matrix cores), 1 the round-1 kernels with an activation tile in LDS
  *                           (+ 33 us per 64-frame VGA step).  0: the split-bf16 head kernels -- another 60 us faster, and NOT safe: the key-point head was found to deliver
  *                           one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever the first tile of a workgroup runs on instruction-cache misses,
  *                           i.e. whenever other kernels (a second stream, another process) evict its code between launches (profiles/r04_head_hazard/);
