@@ -55,7 +55,11 @@ constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19518 floats = 78.1
 // mode 5 (conv1 recomputed inside conv2, no c1 tile): g | sk | c2 | c3 = 51.7 KB -> three workgroups per CU.  (c3 over the dead gray tile
 // = 39.7 KB = four per CU measured 0.947 of mode 4's time against 0.924 for three: more waves than the LDS pipe and L1 feed.)
 constexpr int F_SK_OFF = SK_OFF, F_C2_OFF = SK_OFF + SK_SZ, F_C3_OFF = F_C2_OFF + C2_SZ, F_LDS_FLOATS = F_C3_OFF + 8 * C3H * C3W;      // 12930 floats
-static_assert(SK_OFF % 4 == 0 && F_C2_OFF % 4 == 0 && F_C3_OFF % 4 == 0 && F_LDS_FLOATS % 4 == 0, "16-byte aligned tiles: the fp16-pair planes of modes 6 / 7 are read as b128");
+// modes 6, 7 (matrix-core stages): no skip table -- every thread of stage 4 holds its pixel's average in a register -- so the tiles move up by it and conv3's weight image
+// (mode 7) fits behind them in 53 616 bytes: three workgroups per CU also if LDS is handed out in 1280-byte granules (42 of them; 160 KB / 3 = 54 613 bytes)
+constexpr int M_C2_OFF = SK_OFF, M_C3_OFF = M_C2_OFF + C2_SZ, M_LDS_FLOATS = M_C3_OFF + 8 * C3H * C3W;      // 12804 floats
+static_assert(SK_OFF % 4 == 0 && F_C2_OFF % 4 == 0 && F_C3_OFF % 4 == 0 && F_LDS_FLOATS % 4 == 0 && M_C3_OFF % 4 == 0 && M_LDS_FLOATS % 4 == 0,
+              "16-byte aligned tiles: the fp16-pair planes of modes 6 / 7 are read as b128");
 }  // namespace b1
 
 template <int C1MODE>      // conv1: 1 = a pixel per thread, 3 = three adjacent pixels (scalar FMAs), 4 = three adjacent pixels on packed FMAs,
@@ -82,13 +86,13 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln64 = threadIdx.x & 63;
         if (wv < 3 && (wv < 2 || ln64 < (b1fx::W3_BYTES - 2048) / 16))
             __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned char*>(w3fx) + wv * 1024 + ln64 * 16),
-                                             (lptr_t)(reinterpret_cast<unsigned char*>(lds + F_LDS_FLOATS) + wv * 1024), 16, 0, 0);
+                                             (lptr_t)(reinterpret_cast<unsigned char*>(lds + M_LDS_FLOATS) + wv * 1024), 16, 0, 0);
     }
     float* G = lds + G_OFF;
     float* SK = lds + (F5 ? F_SK_OFF : SK_OFF);
     float* C1 = lds + C1_OFF;
-    float* C2 = lds + (F5 ? F_C2_OFF : C2_OFF);
-    float* C3 = lds + (F5 ? F_C3_OFF : C3_OFF);
+    float* C2 = lds + (MX ? M_C2_OFF : F5 ? F_C2_OFF : C2_OFF);
+    float* C3 = lds + (MX ? M_C3_OFF : F5 ? F_C3_OFF : C3_OFF);
     const int tid = threadIdx.x;
     // the tiles of an image run on one XCD: the 4-pixel gray halos of neighbouring tiles hit its L2
     int b, item;
@@ -229,6 +233,16 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
 #pragma unroll
         for (int co = 0; co < 4; ++co) C1[co * (C1H * C1W) + e] = acc[co];
     }
+    float sk_reg = 0.f;     // MX: skip1's 4 x 4 average of THIS thread's stage-4 pixel (wave = output row, lane & 15 = column): the four lanes that share a pixel sum a
+                            // window row each and exchange (two wave shuffles); no table in LDS
+    if constexpr (MX) {
+        const int r = tid >> 6, c = tid & 15, i = (tid >> 4) & 3;
+        const float* g4 = G + (4 * r + 6 + i) * GW + 4 * c + 6;
+        float sm = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        sk_reg = sm * 0.0625f;
+    } else
     if (tid >= 384) {       // skip1's 4 x 4 averages, once per output pixel (the second pass of conv1 occupies threads 0..410: these 128 are the least loaded;
                             // round 2 had each of stage 4's four cout groups recompute them: 16 LDS reads + 16 adds per thread)
         const int p = tid - 384, r = p >> 4, c = p & 15;
@@ -364,7 +378,7 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
         const int lane = tid & 63, ln = lane & 15, kg = lane >> 4;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int dxw = kg - (ln >> 3);                                                                  // rows 8 .. 15: the right pixel, its window starts one column later
-        const unsigned char* wa = reinterpret_cast<const unsigned char*>(lds + F_LDS_FLOATS) + (dxw >= 0 && dxw <= 2 ? b1fx::W3_REC * (8 * dxw + (ln & 7)) : b1fx::W3_ZERO_OFF);
+        const unsigned char* wa = reinterpret_cast<const unsigned char*>(lds + M_LDS_FLOATS) + (dxw >= 0 && dxw <= 2 ? b1fx::W3_REC * (8 * dxw + (ln & 7)) : b1fx::W3_ZERO_OFF);
         const float4 b3q = *reinterpret_cast<const float4*>(bb3 + 4 * (kg & 1));
         const float b3a[4] = {b3q.x, b3q.y, b3q.z, b3q.w};
         // lane constants of the two parity layouts: the c2 pixel (r + s, 2 pc + kg) sits at index pc + kgo of its row (column 35 -> index 34: zero weights and the dropped
@@ -522,7 +536,7 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
         // bias, ReLU, skip1 (1x1 conv of the 4 x 4 average) and the residual add; buffer stores: the lane's part of the address in ONE 32-bit register
         // (out of range = beyond the resource: dropped), the cout plane in the scalar offset
         const int oy = Y4 + orow, ox = X4 + ln;
-        const float sk = SK[orow * 16 + ln];
+        const float sk = sk_reg;
         const int plane = H4 * W4;
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(x1 + (size_t)b * 24 * plane), 0, 24 * plane * (int)sizeof(float), 0x00020000);
         const int voff = oy < H4 && ox < W4 ? (4 * kg * plane + oy * W4 + ox) * 4 : (int)0x80000000;

@@ -187,12 +187,12 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     else if (c1 == 3) XFH_B1_LAUNCH(3, attr3)
     else if (c1 == 5) XFH_B1_LAUNCH(5, attr5)
     else if (c1 == 6) {
-        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_mx_kernel<6>), b1::F_LDS_FLOATS * 4, attr6);
-        block1_mx_kernel<6><<<xcd_grid_size(tx * ty, B), 512, b1::F_LDS_FLOATS * 4, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
+        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_mx_kernel<6>), b1::M_LDS_FLOATS * 4, attr6);
+        block1_mx_kernel<6><<<xcd_grid_size(tx * ty, B), 512, b1::M_LDS_FLOATS * 4, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
                                                                                            c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold);
-    } else if (c1 == 7) {      // (+ conv3's weight image behind the tiles: 54.1 KB, still three workgroups per CU)
-        constexpr int lds7 = b1::F_LDS_FLOATS * 4 + b1fx::W3_BYTES;
-        static_assert(3 * ((lds7 + 511) / 512 * 512) <= 160 * 1024, "three workgroups per CU");
+    } else if (c1 == 7) {      // (+ conv3's weight image behind the tiles: 53.6 KB, still three workgroups per CU)
+        constexpr int lds7 = b1::M_LDS_FLOATS * 4 + b1fx::W3_BYTES;
+        static_assert(3 * ((lds7 + 1279) / 1280 * 1280) <= 160 * 1024, "three workgroups per CU, also with 1280-byte allocation granules");
         set_max_dynamic_lds(reinterpret_cast<const void*>(block1_mx_kernel<7>), lds7, attr7);
         block1_mx_kernel<7><<<xcd_grid_size(tx * ty, B), 512, lds7, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
                                                                            c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold);

@@ -23,7 +23,7 @@ int main() {
     const int H4 = H / 4, W4 = W / 4, tx = (W4 + xfh::b1::OW - 1) / xfh::b1::OW, ty = (H4 + xfh::b1::OH - 1) / xfh::b1::OH;
     std::vector<float> x1((size_t)B * 24 * H4 * W4, NAN);
     int status = 0;
-    const size_t lds = (mode >= 5 ? xfh::b1::F_LDS_FLOATS : xfh::b1::LDS_FLOATS) * 4 + (mode == 7 ? xfh::b1fx::W3_BYTES : 0);
+    const size_t lds = (mode >= 6 ? xfh::b1::M_LDS_FLOATS : mode == 5 ? xfh::b1::F_LDS_FLOATS : xfh::b1::LDS_FLOATS) * 4 + (mode == 7 ? xfh::b1fx::W3_BYTES : 0);
     auto run = [&](auto M) {
         emu::launch(tx * ty * B, 512, lds, [&] {
             xfh::block1_fused_body<decltype(M)::value>(gray.data(), coef.data(), x1.data(), B, H, W, tx, ty, w1.data(), b1.data(), w2.data(), b2.data(), w3.data(), b3.data(),
