@@ -353,16 +353,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
             (mode == 0 ? coff[li].bx : coff[li].fx) = off;
             uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[off]);
             uint16_t q[3];
-            if (bx1x1)        // trailing 1x1 fused into conv_bx64_kernel: K order of the 3x3's D registers (as the heads' chained layers): [K step 4][cout block 2][split 3][lane][8]
-                for (int t = 0; t < 4; ++t)
-                    for (int mb = 0; mb < 2; ++mb)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int i = 0; i < 8; ++i) {
-                                const int o = mb * 32 + (lane & 31), hf = lane >> 5;
-                                const int ch = 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
-                                split_weight(blob[coff[li].oihw + (size_t)o * 64 + ch], mode, q);
-                                for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * 2 + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                            }
+            if (bx1x1) pack_bx1x1(&blob[coff[li].oihw], mode, dst);      // trailing 1x1 fused into conv_bx64_kernel (weight_split.hpp)
             if (bx24)         // [step][split][lane = half * 32 + cout][8]
                 for (int st = 0; st < nstep; ++st)
                     for (int lane = 0; lane < 64; ++lane) {
@@ -386,17 +377,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                                 for (int sp = 0; sp < 3; ++sp) dst[((((size_t)cb * nstep + st) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                             }
                         }
-            if (bx64 || bx64s2)      // [cout half][cin/16][dy][dx][cout block][split][lane = half * 32 + cout][8]: channel = 16 chunk + 8 half + i
-                for (int hf = 0; hf < nhf; ++hf)
-                    for (int ch = 0; ch < nch; ++ch)
-                        for (int tap = 0; tap < 9; ++tap)
-                            for (int cb = 0; cb < 2; ++cb)
-                                for (int lane = 0; lane < 64; ++lane)
-                                    for (int i = 0; i < 8; ++i) {
-                                        const int o = hf * 64 + cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
-                                        split_weight(blob[coff[li].oihw + ((size_t)o * c.cin + ci) * 9 + tap], mode, q);
-                                        for (int sp = 0; sp < 3; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                                    }
+            if (bx64 || bx64s2) pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, mode, dst);      // (weight_split.hpp)
         }
     }
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].

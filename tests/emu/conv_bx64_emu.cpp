@@ -1,0 +1,44 @@
+// conv_bx64_body<64, FUSE, FX> (csrc/conv_bx64_body.hpp) on the host.  stdin: {B, H, W, fuse, fx, relu, relu2, grid} int32, then in (B*64*H*W), w (64*64*9), bias (64),
+// [fuse: w2 (64*64), bias2 (64)] as fp32 (BatchNorm folded); stdout: out (B*64*H*W; fuse 2: channels-last), status (int32).
+#include "emu.hpp"
+#include "weight_split.hpp"
+#include "conv_bx64_body.hpp"
+#include <cstdio>
+
+static std::vector<float> rd(size_t n) {
+    std::vector<float> v(n);
+    if (fread(v.data(), 4, n, stdin) != n) { fprintf(stderr, "short input\n"); exit(2); }
+    return v;
+}
+
+int main() {
+    int hdr[8];
+    if (fread(hdr, 4, 8, stdin) != 8) return 2;
+    const int B = hdr[0], H = hdr[1], W = hdr[2], fuse = hdr[3], fx = hdr[4], relu = hdr[5], relu2 = hdr[6], grid = hdr[7];
+    auto in = rd((size_t)B * 64 * H * W), w = rd(64 * 64 * 9), bias = rd(64);
+    std::vector<float> w2, bias2;
+    if (fuse) { w2 = rd(64 * 64); bias2 = rd(64); }
+    std::vector<uint16_t> wq((size_t)4 * 9 * 2 * 3 * 64 * 8 + 8192), wq2((size_t)4 * 2 * 3 * 64 * 8);
+    xfh::pack_bx64(w.data(), 64, 64, fx ? 1 : 0, wq.data());
+    if (fuse) xfh::pack_bx1x1(w2.data(), fx ? 1 : 0, wq2.data());
+    std::vector<float> out((size_t)B * 64 * H * W, NAN);
+    int status = 0;
+    xfh::Bx64Args a{};
+    a.status = &status;
+    a.in = in.data(); a.wq = wq.data(); a.bias = bias.data(); a.out = out.data(); a.relu = relu; a.H = H; a.W = W; a.B = B;
+    a.wq2 = fuse ? reinterpret_cast<const uint4*>(wq2.data()) : nullptr; a.bias2 = fuse ? bias2.data() : nullptr; a.relu2 = relu2;
+    a.ncols = (W + 15) / 16; a.nhr = (H + 7) / 8; a.upi = a.ncols * a.nhr;
+    const long long units = (long long)B * a.upi;
+    const int g = units < grid ? (int)units : grid;
+    auto run = [&](auto F, auto X) {
+        emu::launch(g, 256, xfh::bx64::LDS_BYTES, [&] { xfh::conv_bx64_body<64, decltype(F)::value, decltype(X)::value>(a); });
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    using T = std::true_type; using Fa = std::false_type;
+    if (fuse == 0) { if (fx) run(I0{}, T{}); else run(I0{}, Fa{}); }
+    else if (fuse == 1) { if (fx) run(I1{}, T{}); else run(I1{}, Fa{}); }
+    else { if (fx) run(I2{}, T{}); else run(I2{}, Fa{}); }
+    fwrite(out.data(), 4, out.size(), stdout);
+    fwrite(&status, 4, 1, stdout);
+    return 0;
+}

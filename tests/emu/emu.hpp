@@ -119,6 +119,20 @@ inline float shfl_xor(float v, int mask) {
 }
 inline void dma(const void* g, void* l_base, int size) { std::memcpy(static_cast<unsigned char*>(l_base) + size * (tidx.x & 63), g, size); }      // (M0 base + lane x size)
 struct Rsrc { unsigned char* base; unsigned bytes; };
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef int i4 __attribute__((ext_vector_type(4)));
+// raw buffer load of 16 bytes: the range check covers the lane's offset (voff), not the scalar offset; out of range reads zeros
+inline u4 buffer_load_b128(Rsrc rs, unsigned voff, unsigned soff) {
+    u4 r = {0u, 0u, 0u, 0u};
+    if ((uint64_t)voff + 16 <= rs.bytes) std::memcpy(&r, rs.base + voff + soff, 16);
+    return r;
+}
+// buffer_load_dwordx4 ... lds with a hand-built resource word (base address in .x/.y, bytes in .z): 16 bytes per lane to the LDS offset m0 + 16 lane
+inline void dma_b128_to_lds(unsigned m0v, unsigned voff, i4 rs, unsigned soff) {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(((uint64_t)((unsigned)rs.y & 0xffffu) << 32) | (unsigned)rs.x);
+    unsigned char* dst = wg->lds_base() + m0v + 16 * (tidx.x & 63);
+    if ((uint64_t)voff + 16 <= (unsigned)rs.z) std::memcpy(dst, base + voff + soff, 16); else std::memset(dst, 0, 16);
+}
 inline float med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 inline unsigned perm(unsigned hi, unsigned lo, unsigned sel) {
     const uint64_t v = ((uint64_t)hi << 32) | lo;
@@ -156,6 +170,12 @@ inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_REL
 #define XFH_DYN_LDS_BYTES(name) unsigned char* name = emu::wg->lds_base()
 #define XFH_LDS_VOLATILE(T) volatile T
 #define XFH_NOP16_2(a, b) ((void)0)
+#define XFH_NOP16() ((void)0)
+#define XFH_NOP16_4(a, b, c, d) ((void)0)
+#define XFH_NOP32_2(a, b) ((void)0)
+#define XFH_WAIT_VMCNT0() ((void)0)
+#define XFH_LDS_ADDR(p, base) ((unsigned)((p) - (base)))
+#define XFH_DMA_B128_TO_LDS(m0v, voff, rsrc, soff) emu::dma_b128_to_lds(m0v, voff, rsrc, soff)
 #define XFH_NOP16_3(a, b, c) ((void)0)
 #define XFH_PIN(x) ((void)0)
 typedef const void* xfh_gptr_t;
@@ -174,6 +194,7 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __shfl_xor(v, mask, width) emu::shfl_xor(v, mask)
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::dma(g, l, size)
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{reinterpret_cast<unsigned char*>(p), (unsigned)(bytes)}
+#define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) emu::buffer_load_b128(rs, (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_store_b32(val, rs, voff, soff, aux)                                                               \
     do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 4 <= (rs).bytes) { const unsigned v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 4); } } while (0)
 
