@@ -158,8 +158,11 @@ def test_every_barrier_in_dma_kernels_waits_for_the_dma():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     import glob
+    def _src_dma(f):      # the file and the kernel-body headers it includes (csrc/*_body.hpp)
+        t = open(f).read()
+        return t + "".join(open(os.path.join(os.path.dirname(f), h)).read() for h in re.findall(r'#include "(\w+_body\.hpp)"', t))
     files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip")))
-             if re.search(r"global_load_lds|buffer_load[^\n]* lds", open(f).read())]
+             if re.search(r"global_load_lds|buffer_load[^\n]* lds", _src_dma(f))]
     assert len(files) >= 3
     mod.isa_asm.prefetch(sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "k_*.hip"))))      # (every kernel file once, in parallel; the audit below shares them)
     for f in files:
@@ -177,7 +180,10 @@ def test_no_valu_write_lands_in_a_freshly_read_bf16_mfma_operand():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     import glob
-    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_(bf16|f16)\(", open(f).read())]
+    def _src(f):      # the file and the kernel-body headers it includes (csrc/*_body.hpp)
+        t = open(f).read()
+        return t + "".join(open(os.path.join(os.path.dirname(f), h)).read() for h in re.findall(r'#include "(\w+_body\.hpp)"', t))
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_(bf16|f16)\(", _src(f))]
     assert len(files) >= 4
     for f in files:
         nk, nm, bad = mod.audit(f)
