@@ -275,7 +275,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     std::vector<float> blob;
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
     const size_t zoff = reserve(256);
-    struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx; bool has_wino, has_bx, fx_ok; } coff[L_NUM];
+    struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx, fq; bool has_wino, has_bx, fx_ok, has_fq; } coff[L_NUM];
     struct FOff { size_t w, b; } foff[5];
     int ai = 0;
     for (int li = 0; li < L_NUM; ++li) {
@@ -379,6 +379,11 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                         }
             if (bx64 || bx64s2) pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, mode, dst);      // (weight_split.hpp)
         }
+        coff[li].has_fq = bx64 && coff[li].fx_ok;
+        if (coff[li].has_fq) {      // two fragments per weight (q0, q2): conv_bx64_body.hpp FXM 2
+            coff[li].fq = reserve((size_t)(c.cin / 16) * 9 * 2 * 2 * 64 * 4);
+            pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, 1, reinterpret_cast<uint16_t*>(&blob[coff[li].fq]), 2);
+        }
     }
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].
     // K order: the first layer takes its channels in natural order (16 t + 8 half + i); a chained layer takes the previous layer's D
@@ -474,6 +479,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.w_wino = coff[li].has_wino ? ctx->blob + coff[li].wino : nullptr;
         w.w_bx = coff[li].has_bx ? ctx->blob + coff[li].bx : nullptr;
         w.w_fx = coff[li].has_bx && coff[li].fx_ok ? ctx->blob + coff[li].fx : nullptr;
+        w.w_fq = coff[li].has_fq ? ctx->blob + coff[li].fq : nullptr;
     }
     ctx->nw.zeros = ctx->blob + zoff;
     for (int hd = 0; hd < 2; ++hd) {
@@ -548,11 +554,11 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     // stand-alone against Winograd), >= 1.5 in the fp16-pair arithmetic, whose units are a third cheaper (VGA batch 64 at 1/16 scale, 768 units: 45 us against Winograd's 54)
     const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= ((h->opt.fx & 1) ? 768 : 1024);
     if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
-        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) != 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
+        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, (h->opt.fx & 2) != 0, h->status);      // (bx = 9: block3.0 stays on the f32 kernel)
-        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) != 0, h->status);      // (bx = 5: large maps only)
+        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // (bx = 5: large maps only)
     }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
@@ -660,7 +666,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
     }
     if (variant == 11) {      // the split kernel of the layer in the fp16-pair arithmetic
         if (!c.w_fx || (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, true, h->status)
-                                    : (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, true, h->status))))
+                                    : (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status))))
             return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fp16-pair instantiation for layer %d", layer);
         return check_launch("xfh_conv_layer(fp16 pair)");
     }

@@ -53,9 +53,14 @@ static_assert(IH * NQ * 2 <= 256, "one (row, quad, 8-channel group) item per thr
 
 // FUSE: 0 = the 3x3 alone; 1 = + trailing 1x1 (64 -> 64), NCHW output; 2 = the same with channels-last output
 // FX: the fp16-pair arithmetic (bx_split.hpp) -- two input fragments per pixel, three MFMAs per K step and accumulator instead of six
-template <int CIN, int FUSE, bool FX>
+// FXM: 0 = bf16 three-way split, 1 = fp16 pair, 2 = fp16 pair with TWO weight fragments per (tap, cout block) in the stream and in LDS (q0, q2; q1 = fp16(w) = 2^-11 q0
+// derived with four v_pk_mul_f16 per cout block and K step): a third less weight DMA, 8 instead of 10 LDS reads per 12 MFMAs
+template <int CIN, int FUSE, int FXM>
 __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
     using namespace bx64;
+    constexpr bool FX = FXM > 0;
+    constexpr int NWF = FXM == 2 ? 2 : 3;
+    constexpr int STEP_B = 2 * NWF * 1024, SLOT_B = 3 * STEP_B, NPC = SLOT_B / 1024;      // (the ring keeps the room of the three-fragment form: bx64::LDS_BYTES)
     constexpr int PIXB = pixb<FX>(), NXS = FX ? 2 : 3;
     using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
     auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {
@@ -109,13 +114,13 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
         r.w = 0x00020000;
         return r;
     };
-    const i32x4 rs_w = make_rsrc(a.wq, (unsigned)(NROW * SLOT_BYTES));
+    const i32x4 rs_w = make_rsrc(a.wq, (unsigned)(NROW * SLOT_B));
     const int dma_voff = lane * 16;
     auto lds_addr = [&](const unsigned char* p) { return XFH_LDS_ADDR(p, smem_b64); };
     auto issue_row = [&](int r) __attribute__((always_inline)) {             // weights of row r (chunk r / 3, tap row r % 3) -> slot r & 1
-        for (int j = wave; j < NPIECE; j += 4) {
-            const unsigned m0v = lds_addr(smem_b64 + RING_OFF + (r & 1) * SLOT_BYTES + j * 1024);
-            const int soff = r * SLOT_BYTES + j * 1024;
+        for (int j = wave; j < NPC; j += 4) {
+            const unsigned m0v = lds_addr(smem_b64 + RING_OFF + (r & 1) * SLOT_B + j * 1024);
+            const int soff = r * SLOT_B + j * 1024;
             XFH_DMA_B128_TO_LDS(m0v, dma_voff, rs_w, soff);
         }
     };
@@ -219,7 +224,7 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
                 BX_STAMP(2 + 4 * r)                 // row r's weights landed; (dy = 0) the chunk is staged; (dy > 0) row r - 1 is finished
                 BX_STAMP(3 + 4 * r)
                 // ---- one tap row: 3 K steps x (NPB pixel blocks x 2 cout blocks) x 6 MFMAs; operands of step s+1 read under step s
-                const unsigned char* wslot = smem_b64 + RING_OFF + (r & 1) * SLOT_BYTES + lane * 16;
+                const unsigned char* wslot = smem_b64 + RING_OFF + (r & 1) * SLOT_B + lane * 16;
                 const unsigned char* xrow = smem_b64 + dy * XROWB;
                 Frag f[2];
                 auto load = [&](int s, Frag& o) {
@@ -230,11 +235,15 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                        for (int q = 0; q < 3; ++q) o.w[cb][q] = *reinterpret_cast<const frag_t*>(wslot + s * STEP_BYTES + (cb * 3 + q) * 1024);
+                        for (int q = 0; q < NWF; ++q) o.w[cb][NWF == 3 ? q : 2 * q] = *reinterpret_cast<const frag_t*>(wslot + s * STEP_B + (cb * NWF + q) * 1024);
                 };
                 load(0, f[0]);
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
+                    if constexpr (NWF == 2) {      // q1 from q0 (the registers it lands in were last read two K steps ago)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb) f[s & 1].w[cb][1] = f[s & 1].w[cb][0] * (_Float16)0.00048828125f;
+                    }
                     const Frag& cf = f[s & 1];
                     if (s + 1 < 3) load(s + 1, f[(s + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);

@@ -23,40 +23,44 @@
 namespace xfh {
 
 // body in conv_bx64_body.hpp (also compiled for the host by tests/emu/)
-template <int CIN, int FUSE, bool FX>
+template <int CIN, int FUSE, int FXM>      // FXM: 0 bf16 three-way split, 1 fp16 pair, 2 fp16 pair with two weight fragments in the stream (conv_bx64_body.hpp)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64_kernel(Bx64Args a) {
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    conv_bx64_body<CIN, FUSE, FX>(a);
+    conv_bx64_body<CIN, FUSE, FXM>(a);
 }
 
-template <int CIN, int FUSE, bool FX>
+template <int CIN, int FUSE, int FXM>
 static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     Bx64Args a;
     a.cold = g_debug_cold;
     a.status = status;
-    a.in = in; a.wq = FX ? c.w_fx : c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
-    a.wq2 = c2 ? reinterpret_cast<const uint4*>(FX ? c2->w_fx : c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
+    a.in = in; a.wq = FXM == 2 ? c.w_fq : FXM ? c.w_fx : c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    a.wq2 = c2 ? reinterpret_cast<const uint4*>(FXM ? c2->w_fx : c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     a.ncols = ceil_div(W, 16); a.nhr = ceil_div(H, 8); a.upi = a.ncols * a.nhr;
     static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE, FX>), bx64::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE, FXM>), bx64::LDS_BYTES, attr_done);
     const long long units = (long long)B * a.upi;
     int grid = 2 * num_cus();                  // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
     if (units < grid) grid = (int)units;       // (small inputs: one unit per workgroup; the XCD mapping then needs grid % 8 == 0 or is skipped)
-    conv_bx64_kernel<CIN, FUSE, FX><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
+    conv_bx64_kernel<CIN, FUSE, FXM><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
     return 0;
 }
 
-int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, bool fx, int* status) {
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, int fx, int* status) {
     if (c.ks != 3 || c.stride != 1 || !c.w_bx || c.cout != 64 || c.cin != 64) return -1;
     if (c2 && (c2->ks != 1 || c2->cin != 64 || c2->cout != 64 || !c2->w_bx)) return -1;
-    if (fx && c.w_fx && (!c2 || c2->w_fx)) {      // the fp16-pair arithmetic: three MFMAs per product instead of six
-        if (!c2) return nhwc ? -1 : run_bx64<64, 0, true>(c, nullptr, in, B, H, W, out, st, trace, status);
-        return nhwc ? run_bx64<64, 2, true>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, true>(c, c2, in, B, H, W, out, st, trace, status);
+    if (fx && c.w_fx && (!c2 || c2->w_fx)) {      // the fp16-pair arithmetic: three MFMAs per product instead of six; fx = 2: two weight fragments in the stream
+        if (fx == 2 && c.w_fq) {
+            if (!c2) return nhwc ? -1 : run_bx64<64, 0, 2>(c, nullptr, in, B, H, W, out, st, trace, status);
+            return nhwc ? run_bx64<64, 2, 2>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, 2>(c, c2, in, B, H, W, out, st, trace, status);
+        }
+        if (!c2) return nhwc ? -1 : run_bx64<64, 0, 1>(c, nullptr, in, B, H, W, out, st, trace, status);
+        return nhwc ? run_bx64<64, 2, 1>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, 1>(c, c2, in, B, H, W, out, st, trace, status);
     }
-    if (!c2) return nhwc ? -1 : run_bx64<64, 0, false>(c, nullptr, in, B, H, W, out, st, trace, status);
-    return nhwc ? run_bx64<64, 2, false>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, false>(c, c2, in, B, H, W, out, st, trace, status);
+    if (!c2) return nhwc ? -1 : run_bx64<64, 0, 0>(c, nullptr, in, B, H, W, out, st, trace, status);
+    return nhwc ? run_bx64<64, 2, 0>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, 0>(c, c2, in, B, H, W, out, st, trace, status);
 }
 
 }  // namespace xfh

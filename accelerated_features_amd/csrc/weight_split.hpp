@@ -91,7 +91,7 @@ inline size_t pack_head_layer(const float* w, int cout, bool first, int mode, ui
 
 // 3x3 convolution weights for conv_bx64_kernel / conv_bx64s2_kernel: [cout half][cin/16][tap 9][cout block 2][split 3][lane = half * 32 + cout][8], channel = 16 chunk + 8 half + i.
 // w: (cout, cin, 3, 3) fp32 (BatchNorm folded), cin % 16 == 0, cout % 64 == 0.  Returns the 16-bit words written.
-inline size_t pack_bx64(const float* w, int cin, int cout, int mode, uint16_t* dst) {
+inline size_t pack_bx64(const float* w, int cin, int cout, int mode, uint16_t* dst, int nfrag = 3) {      // nfrag = 2 (mode 1): q0, q2 alone -- [..][cout block][2][lane][8]
     const int nch = cin / 16, nhf = cout / 64;
     for (int hf = 0; hf < nhf; ++hf)
         for (int ch = 0; ch < nch; ++ch)
@@ -102,9 +102,9 @@ inline size_t pack_bx64(const float* w, int cin, int cout, int mode, uint16_t* d
                             const int o = hf * 64 + cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
                             uint16_t q[3];
                             split_weight(w[((size_t)o * cin + ci) * 9 + tap], mode, q);
-                            for (int sp = 0; sp < 3; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                            for (int sp = 0; sp < nfrag; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * nfrag + sp) * 64 + lane) * 8 + i] = q[nfrag == 3 ? sp : 2 * sp];
                         }
-    return (size_t)nhf * nch * 9 * 2 * 3 * 64 * 8;
+    return (size_t)nhf * nch * 9 * 2 * nfrag * 64 * 8;
 }
 // the 1x1 (64 -> 64) fused behind a 64 -> 64 3x3 in conv_bx64_kernel: K order of the 3x3's D registers (as a chained head layer): [K step 4][cout block 2][split 3][lane][8]
 inline size_t pack_bx1x1(const float* w /* (64, 64) */, int mode, uint16_t* dst) { return pack_head_layer(w, 64, false, mode, dst); }

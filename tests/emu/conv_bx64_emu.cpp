@@ -19,7 +19,7 @@ int main() {
     std::vector<float> w2, bias2;
     if (fuse) { w2 = rd(64 * 64); bias2 = rd(64); }
     std::vector<uint16_t> wq((size_t)4 * 9 * 2 * 3 * 64 * 8 + 8192), wq2((size_t)4 * 2 * 3 * 64 * 8);
-    xfh::pack_bx64(w.data(), 64, 64, fx ? 1 : 0, wq.data());
+    xfh::pack_bx64(w.data(), 64, 64, fx ? 1 : 0, wq.data(), fx == 2 ? 2 : 3);
     if (fuse) xfh::pack_bx1x1(w2.data(), fx ? 1 : 0, wq2.data());
     std::vector<float> out((size_t)B * 64 * H * W, NAN);
     int status = 0;
@@ -34,10 +34,8 @@ int main() {
         emu::launch(g, 256, xfh::bx64::LDS_BYTES, [&] { xfh::conv_bx64_body<64, decltype(F)::value, decltype(X)::value>(a); });
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    using T = std::true_type; using Fa = std::false_type;
-    if (fuse == 0) { if (fx) run(I0{}, T{}); else run(I0{}, Fa{}); }
-    else if (fuse == 1) { if (fx) run(I1{}, T{}); else run(I1{}, Fa{}); }
-    else { if (fx) run(I2{}, T{}); else run(I2{}, Fa{}); }
+    auto runf = [&](auto F) { if (fx == 2) run(F, I2{}); else if (fx == 1) run(F, I1{}); else run(F, I0{}); };
+    if (fuse == 0) runf(I0{}); else if (fuse == 1) runf(I1{}); else runf(I2{});
     fwrite(out.data(), 4, out.size(), stdout);
     fwrite(&status, 4, 1, stdout);
     return 0;

@@ -23,7 +23,7 @@ def emu_bin():
     return out
 
 
-@pytest.mark.parametrize("fuse,fx,shape,grid", [(0, 1, (1, 24, 40), 3), (0, 0, (1, 16, 16), 2), (1, 1, (2, 24, 32), 5), (2, 1, (1, 18, 20), 2), (0, 1, (8, 8, 16), 8)])
+@pytest.mark.parametrize("fuse,fx,shape,grid", [(0, 1, (1, 24, 40), 3), (0, 0, (1, 16, 16), 2), (1, 1, (2, 24, 32), 5), (2, 1, (1, 18, 20), 2), (0, 1, (8, 8, 16), 8), (0, 2, (1, 24, 40), 3), (1, 2, (1, 16, 32), 2), (2, 2, (1, 18, 20), 2)])
 def test_conv_bx64_body_on_the_host(emu_bin, fuse, fx, shape, grid):
     B, H, W = shape                                   # (24 x 40: full tiles, a half tile and a partial strip; 18 x 20: rows and columns beyond the map; B = 8, grid 8: the XCD mapping)
     g = torch.Generator().manual_seed(10 * fuse + fx)
