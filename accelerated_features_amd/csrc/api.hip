@@ -534,7 +534,7 @@ size_t xfh_backbone_workspace_bytes(int B, int C, int H, int W) {
 }
 
 static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const float* in, int B, int Hin, int Win, float* out,
-                             bool nhwc, hipStream_t st) {
+                             bool nhwc, hipStream_t st, bool in_backbone = false) {      // in_backbone: the layer's neighbours are this call's (the split-format link may be used)
     const ConvW& c = h->nw.conv[layer];
     const ConvW* c2 = fused_layer >= 0 ? &h->nw.conv[fused_layer] : nullptr;
     const int pad = c.ks / 2;
@@ -553,7 +553,13 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     // "large map" = enough half-tile units for the persistent grid of conv_bx64_kernel (512 workgroups): >= 2 per workgroup in the bf16 arithmetic (B=8 164x164: 92 vs 124 us
     // stand-alone against Winograd), >= 1.5 in the fp16-pair arithmetic, whose units are a third cheaper (VGA batch 64 at 1/16 scale, 768 units: 45 us against Winograd's 54)
     const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= ((h->opt.fx & 1) ? 768 : 1024);
-    if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
+    // the split-format link (fx bit 64; conv_bx64_body.hpp): block_fusion.0 writes its output as fp16 pairs, block_fusion.1 (+ .2 fused) stages them by LDS-DMA alone.
+    // Both layers see the same map, so both take the same decision; the buffer between them has the size of the fp32 tensor either way.
+    const bool sp_link = in_backbone && (h->opt.fx & 65) == 65 && use_bx && ((use_bx & 2) || ((use_bx & 4) && big_map)) && h->nw.conv[L_FUSION_0].w_fx && h->nw.conv[L_FUSION_1].w_fx &&
+                         h->nw.conv[L_FUSION_2].w_fx;
+    if (sp_link && layer == L_FUSION_1 && c2 && nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, true, 1, h->status, 1, h->nw.zeros);
+    if (sp_link && layer == L_FUSION_0 && !c2 && !nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status, 2, h->nw.zeros);
+    if (rc && use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
@@ -600,7 +606,7 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     // block1 + skip1 per input pixel: conv1 9*4*2 + conv2 36*8*2/4 + conv3 72*8*2/4 + conv4 72*24*2/16 = 720 FLOP; gray in, x1 out: 10 bytes
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 720.0 * B * H * W, 10.0 * B * H * W);
 #define CONV(layer, fused, in, hin, win, out, nhwc) \
-    if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st))) return rc
+    if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st, true))) return rc
     CONV(L_BLOCK2_0, -1, w.x1, H4, W4, w.x2a, false);
     CONV(L_BLOCK2_1, -1, w.x2a, H4, W4, w.x2b, false);
     CONV(L_BLOCK3_0, -1, w.x2b, H4, W4, w.x3a, false);
@@ -910,7 +916,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 63}};
+        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 127}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

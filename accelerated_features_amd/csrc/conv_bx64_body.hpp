@@ -9,7 +9,7 @@
 #endif
 #define XFH_LDS_ADDR(p, base) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(p))
 /* LDS-DMA of 16 bytes per lane: M0 = LDS address of the 1-KiB piece, the lane's part of the global address in voff (inline asm: hipcc would make every LDS read wait for all DMA it can see) */
-#define XFH_DMA_B128_TO_LDS(m0v, voff, rsrc, soff) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+#define XFH_DMA_B128_TO_LDS(m0v, voff, rsrc, soff) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)(m0v))), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane((int)(soff))) : "memory")      /* (readfirstlane: both are wave-uniform by construction; where hipcc cannot see it, it hands the asm a vector register) */
 #define XFH_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define XFH_NOP16() asm volatile("s_nop 7\n\ts_nop 7")
 #ifndef XFH_NOP16_2
@@ -17,6 +17,11 @@
 #endif
 #define XFH_NOP16_4(a, b, c, d) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b), "+v"(c), "+v"(d))
 #define XFH_NOP32_2(a, b) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(a), "+v"(b))
+#ifndef XFH_GPTR_DEFINED
+#define XFH_GPTR_DEFINED
+typedef __attribute__((address_space(1))) const void* xfh_gptr_t;
+typedef __attribute__((address_space(3))) void* xfh_lptr_t;
+#endif
 #endif
 #include "bx_split.hpp"
 
@@ -38,6 +43,7 @@ struct Bx64Args {
     int relu2;
     int cold;
     int* status;               // fx: range guard (bx_split.hpp), may be NULL
+    const void* zeros;         // SP input: >= 16 bytes of zeros (the halo outside the map is DMA'd from there)
 };
 
 namespace bx64 {
@@ -47,6 +53,13 @@ template <bool FX> constexpr int pixb() { return FX ? 80 : 112; }
 constexpr int X_BYTES = IH * XROWB;                    // 36864
 constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;      // 6 KiB per K step, 18 per slot
 constexpr int RING_OFF = X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, LDS_BYTES = BIAS_OFF + 128 * 4;      // bias of the 3x3, bias of the fused 1x1
+// SP ("split, producer-side"): the input arrives as fp16 pairs written by the layer before -- per image [16-channel chunk][pixel][64 bytes: hi ch 0-7 | hi 8-15 | lo 0-7 | lo 8-15]
+// (4 bytes per value: the HBM traffic of fp32) -- and is staged by LDS-DMA alone: no raw values in registers, no split, no ds_write, no staging phase between barriers.
+// LDS tile of a chunk: [18 rows][18 pixels][64 bytes], two of them (chunk c + 1 lands while chunk c is multiplied); the 16-byte slot of a pixel sits at
+// slot ^ ((column >> 2) & 3): with the 64-byte pitch that keeps the 16 lanes of a ds_read_b128 group on distinct banks (unit 4 (x & 3) + (slot ^ (x >> 2)) mod 16) without padding.
+constexpr int XSP_ROWB = IW * 64, XSP_BYTES = IH * XSP_ROWB, XSP_UNITS = XSP_BYTES / 16, XSP_NDMA = (XSP_BYTES + 1023) / 1024;      // 1152, 20736, 1296, 21
+constexpr int SP_RING_OFF = 2 * XSP_BYTES, SP_BIAS_OFF = SP_RING_OFF + 2 * SLOT_BYTES, SP_LDS_BYTES = SP_BIAS_OFF + 128 * 4;                 // 78848: two workgroups per CU
+static_assert(2 * SP_LDS_BYTES <= 160 * 1024, "two workgroups per CU");
 constexpr int NQ = 6;                                   // aligned 4-pixel quads per halo row
 static_assert(IH * NQ * 2 <= 256, "one (row, quad, 8-channel group) item per thread");
 }
@@ -55,10 +68,15 @@ static_assert(IH * NQ * 2 <= 256, "one (row, quad, 8-channel group) item per thr
 // FX: the fp16-pair arithmetic (bx_split.hpp) -- two input fragments per pixel, three MFMAs per K step and accumulator instead of six
 // FXM: 0 = bf16 three-way split, 1 = fp16 pair, 2 = fp16 pair with TWO weight fragments per (tap, cout block) in the stream and in LDS (q0, q2; q1 = fp16(w) = 2^-11 q0
 // derived with four v_pk_mul_f16 per cout block and K step): a third less weight DMA, 8 instead of 10 LDS reads per 12 MFMAs
-template <int CIN, int FUSE, int FXM>
+// SP: bit 1 = the input is in the split format above (a.in), bit 2 = the output is written in it (FUSE 0 only) -- both need the fp16-pair arithmetic
+template <int CIN, int FUSE, int FXM, int SP = 0>
 __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
     using namespace bx64;
     constexpr bool FX = FXM > 0;
+    constexpr bool IN_SP = (SP & 1) != 0, OUT_SP = (SP & 2) != 0;
+    static_assert(!SP || (FX && CIN == 64), "the split format is the fp16 pair's");
+    static_assert(!OUT_SP || FUSE == 0, "only the plain 3x3 writes the split format");
+    constexpr int ROFF = IN_SP ? SP_RING_OFF : RING_OFF, BOFF = IN_SP ? SP_BIAS_OFF : BIAS_OFF;
     constexpr int NWF = FXM == 2 ? 2 : 3;
     constexpr int STEP_B = 2 * NWF * 1024, SLOT_B = 3 * STEP_B, NPC = SLOT_B / 1024;      // (the ring keeps the room of the three-fragment form: bx64::LDS_BYTES)
     constexpr int PIXB = pixb<FX>(), NXS = FX ? 2 : 3;
@@ -73,7 +91,7 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t HW = (size_t)a.H * a.W;
-    float* bias_lds = reinterpret_cast<float*>(smem_b64 + BIAS_OFF);
+    float* bias_lds = reinterpret_cast<float*>(smem_b64 + BOFF);
     if (tid < 64) bias_lds[tid] = a.bias[tid];
     if (FUSE && tid >= 64 && tid < 128) bias_lds[tid] = a.bias2[tid - 64];
 
@@ -119,7 +137,7 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
     auto lds_addr = [&](const unsigned char* p) { return XFH_LDS_ADDR(p, smem_b64); };
     auto issue_row = [&](int r) __attribute__((always_inline)) {             // weights of row r (chunk r / 3, tap row r % 3) -> slot r & 1
         for (int j = wave; j < NPC; j += 4) {
-            const unsigned m0v = lds_addr(smem_b64 + RING_OFF + (r & 1) * SLOT_B + j * 1024);
+            const unsigned m0v = lds_addr(smem_b64 + ROFF + (r & 1) * SLOT_B + j * 1024);
             const int soff = r * SLOT_B + j * 1024;
             XFH_DMA_B128_TO_LDS(m0v, dma_voff, rs_w, soff);
         }
@@ -194,6 +212,43 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
         if constexpr (FX) fx_report_h(amax, a.status);
     };
 
+    // ---- SP input: the chunk tiles by LDS-DMA.  DMA instruction i of a chunk fills LDS units [64 i, 64 i + 64) of the tile (16 bytes per lane); wave w issues i = w, w + 4, ...
+    // Per lane and instruction the (row, column, logical slot) of its unit are constants of the kernel; per tile and chunk they give the source address (or the zeros).
+    int sp_it[(XSP_NDMA + 3) / 4];
+    if constexpr (IN_SP) {
+#pragma unroll
+        for (int k = 0; k < (XSP_NDMA + 3) / 4; ++k) {
+            const int i = wave + 4 * k, u = i * 64 + lane;
+            const int row = u / (IW * 4), rem = u - row * (IW * 4), px = rem >> 2, logical = (rem & 3) ^ ((px >> 2) & 3);
+            sp_it[k] = i < XSP_NDMA && u < XSP_UNITS ? (row << 16) | (px << 8) | logical : -1;
+        }
+    }
+    auto issue_chunk = [&](const Tile& t, int chunk, int buf) __attribute__((always_inline)) {
+        if constexpr (IN_SP) {
+            const int nrow = t.full ? 18 : 10;
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(a.in) + ((size_t)t.b * NCH + chunk) * HW * 64;
+#pragma unroll
+            for (int k = 0; k < (XSP_NDMA + 3) / 4; ++k) {
+                const int it = sp_it[k], row = it >> 16, px = (it >> 8) & 0xff, logical = it & 0xff;
+                if (it < 0 || row >= nrow) continue;                      // (wave-uniform only for whole instructions; partly live ones run under the exec mask)
+                const int gy = t.y0 - 1 + row, gx = t.x0 - 1 + px;
+                const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const unsigned char* g = in ? src + ((size_t)gy * a.W + gx) * 64 + logical * 16 : reinterpret_cast<const unsigned char*>(a.zeros);
+                __builtin_amdgcn_global_load_lds((xfh_gptr_t)g, (xfh_lptr_t)(smem_b64 + buf * XSP_BYTES + (wave + 4 * k) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // the lane's read offsets: pixel (row l31 >> 4, column (l31 & 15) + s) of the block, part q (0 = high, 1 = low), channel half `half`: slot (2 q + half) ^ ((x >> 2) & 3)
+    int xsp[3][2];
+    if constexpr (IN_SP) {
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int x = (l31 & 15) + s3;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xsp[s3][q] = (l31 >> 4) * XSP_ROWB + x * 64 + (((2 * q + half) ^ ((x >> 2) & 3)) << 4);
+        }
+    }
+
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
     int tix = 0;
 #define BX_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }      /* second tile of the workgroup: [0] start, per row r: [1+4r] staged / row start, [2+4r] barrier passed, [3+4r] DMA + loads issued, [4+4r] MFMAs issued; [50] stores issued, [51] end barrier */
@@ -215,8 +270,10 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
         const int br0 = NPB == 2 ? 2 * wave : wave, br1 = 2 * wave + 1;
         const int xb[2] = {2 * br0 * XROWB + lane_px, 2 * br1 * XROWB + lane_px};
         for (int c = 0; c < NCH; ++c) {
-            if (c > 0) dma_barrier();          // every wave has finished the previous chunk's last tap row (the tile loop ends on a barrier)
-            stage_write();
+            if constexpr (!IN_SP) {
+                if (c > 0) dma_barrier();      // every wave has finished the previous chunk's last tap row (the tile loop ends on a barrier)
+                stage_write();
+            }
             for (int dy = 0; dy < 3; ++dy) {
                 const int r = c * 3 + dy;
                 BX_STAMP(1 + 4 * r)
@@ -224,14 +281,16 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
                 BX_STAMP(2 + 4 * r)                 // row r's weights landed; (dy = 0) the chunk is staged; (dy > 0) row r - 1 is finished
                 BX_STAMP(3 + 4 * r)
                 // ---- one tap row: 3 K steps x (NPB pixel blocks x 2 cout blocks) x 6 MFMAs; operands of step s+1 read under step s
-                const unsigned char* wslot = smem_b64 + RING_OFF + (r & 1) * SLOT_B + lane * 16;
-                const unsigned char* xrow = smem_b64 + dy * XROWB;
+                const unsigned char* wslot = smem_b64 + ROFF + (r & 1) * SLOT_B + lane * 16;
+                const unsigned char* xrow = smem_b64 + (IN_SP ? (c & 1) * XSP_BYTES + dy * XSP_ROWB : dy * XROWB);
                 Frag f[2];
                 auto load = [&](int s, Frag& o) {
 #pragma unroll
                     for (int j = 0; j < NPB; ++j)
 #pragma unroll
-                        for (int q = 0; q < NXS; ++q) o.x[j][q] = *reinterpret_cast<const frag_t*>(xrow + xb[j] + s * PIXB + q * SPLB);
+                        for (int q = 0; q < NXS; ++q)
+                            o.x[j][q] = IN_SP ? *reinterpret_cast<const frag_t*>(xrow + 2 * (j ? br1 : br0) * XSP_ROWB + xsp[s][q < 2 ? q : 0])
+                                              : *reinterpret_cast<const frag_t*>(xrow + xb[j] + s * PIXB + q * SPLB);
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -264,7 +323,7 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
                         const bool same = c + 1 < NCH;
                         Tile lt;
                         lt.b = same ? cur.b : nxt.b; lt.y0 = same ? cur.y0 : nxt.y0; lt.x0 = same ? cur.x0 : nxt.x0; lt.full = same ? cur.full : nxt.full;
-                        if (same || has_next) issue_loads(lt, same ? c + 1 : 0);
+                        if (same || has_next) { if constexpr (IN_SP) issue_chunk(lt, same ? c + 1 : 0, (c + 1) & 1); else issue_loads(lt, same ? c + 1 : 0); }
                     }
                 }
                 if constexpr (NPB == 2) XFH_NOP16_4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);      // (tied to the accumulators: an asm
@@ -273,7 +332,41 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
                 BX_STAMP(4 + 4 * r)
             }
         }
-        if constexpr (FUSE == 0) {
+        if constexpr (FUSE == 0 && OUT_SP) {
+            // ---- bias, ReLU, and the output as fp16 pairs in the split format of the next layer: the lane's four channels of a register quad g4 (cout block cb) are
+            // channels 8 (g4 & 1) + 4 half + e of chunk 2 cb + (g4 >> 1): 8 bytes into the high slot g4 & 1, 8 bytes into the low slot (+ 32) of the pixel's record
+            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<unsigned char*>(a.out) + (size_t)cur.b * NCH * HW * 64), 0, (int)(NCH * HW * 64), 0x00020000);
+            const int ox = cur.x0 + (l31 & 15);
+            unsigned amaxo = 0;                   // range guard of what the next layer will multiply (on the high parts: bx_split.hpp)
+#pragma unroll
+            for (int j = 0; j < NPB; ++j) {
+                const int oy = cur.y0 + 2 * (j ? br1 : br0) + (l31 >> 4);
+                const int voff = oy < a.H && ox < a.W ? (oy * a.W + ox) * 64 + half * 8 : (int)0x80000000;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const float4 t = *reinterpret_cast<const float4*>(bias_lds + cb * 32 + 8 * g4 + 4 * half);
+                        const float bq[4] = {t.x, t.y, t.z, t.w};
+                        float y[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            y[e] = fmaf(acc[j][cb][4 * g4 + e], FX_SCALE_INV, bq[e]);
+                            if (a.relu) y[e] = fmaxf(y[e], 0.f);
+                        }
+                        u32x2v h, l;
+                        unsigned h0, l0, h1, l1;
+                        split2_f16(y[0], y[1], h0, l0); split2_f16(y[2], y[3], h1, l1);
+                        fx_track_h(amaxo, h0, true); fx_track_h(amaxo, h1, true);
+                        h[0] = h0; h[1] = h1; l[0] = l0; l[1] = l1;
+                        const int soff = (2 * cb + (g4 >> 1)) * (int)HW * 64 + (g4 & 1) * 16;
+                        __builtin_amdgcn_raw_buffer_store_b64(h, rs_out, voff, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(l, rs_out, voff, soff + 32, 0);
+                    }
+            }
+            fx_report_h(amaxo, a.status);
+        } else if constexpr (FUSE == 0) {
             // ---- bias, ReLU, buffer stores (lanes outside the image carry an out-of-range offset).  A = weights, B = pixels: lane (pixel,
             // half) holds couts (r & 3) + 8 (r >> 2) + 4 half; a store instruction writes four 64-byte row segments.  (The transposed
             // product -- lane = cout, four consecutive pixels per register quad, dwordx4 stores -- has a quarter of the instructions but
@@ -422,7 +515,7 @@ __device__ __forceinline__ void conv_bx64_body(const Bx64Args& a) {
     u += tile_at(u, cur);
     nxt = cur;
     issue_row(0);
-    issue_loads(cur, 0);
+    if constexpr (IN_SP) issue_chunk(cur, 0, 0); else issue_loads(cur, 0);
     for (;;) {
         const bool has_next = u < u1;
         if (has_next) u += tile_at(u, nxt);

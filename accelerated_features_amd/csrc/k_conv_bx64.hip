@@ -23,34 +23,42 @@
 namespace xfh {
 
 // body in conv_bx64_body.hpp (also compiled for the host by tests/emu/)
-template <int CIN, int FUSE, int FXM>      // FXM: 0 bf16 three-way split, 1 fp16 pair, 2 fp16 pair with two weight fragments in the stream (conv_bx64_body.hpp)
+template <int CIN, int FUSE, int FXM, int SP = 0>      // FXM: 0 bf16 three-way split, 1 fp16 pair, 2 fp16 pair with two weight fragments in the stream; SP: 1 input / 2 output in the split format (conv_bx64_body.hpp)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64_kernel(Bx64Args a) {
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    conv_bx64_body<CIN, FUSE, FXM>(a);
+    conv_bx64_body<CIN, FUSE, FXM, SP>(a);
 }
 
-template <int CIN, int FUSE, int FXM>
-static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
+template <int CIN, int FUSE, int FXM, int SP = 0>
+static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status, const float* zeros = nullptr) {
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     Bx64Args a;
     a.cold = g_debug_cold;
     a.status = status;
+    a.zeros = zeros;
     a.in = in; a.wq = FXM == 2 ? c.w_fq : FXM ? c.w_fx : c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
     a.wq2 = c2 ? reinterpret_cast<const uint4*>(FXM ? c2->w_fx : c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     a.ncols = ceil_div(W, 16); a.nhr = ceil_div(H, 8); a.upi = a.ncols * a.nhr;
     static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE, FXM>), bx64::LDS_BYTES, attr_done);
+    constexpr int lds_bytes = (SP & 1) ? bx64::SP_LDS_BYTES : bx64::LDS_BYTES;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE, FXM, SP>), lds_bytes, attr_done);
     const long long units = (long long)B * a.upi;
     int grid = 2 * num_cus();                  // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
     if (units < grid) grid = (int)units;       // (small inputs: one unit per workgroup; the XCD mapping then needs grid % 8 == 0 or is skipped)
-    conv_bx64_kernel<CIN, FUSE, FXM><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
+    conv_bx64_kernel<CIN, FUSE, FXM, SP><<<grid, 256, lds_bytes, st>>>(a);
     return 0;
 }
 
-int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, int fx, int* status) {
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, int fx, int* status, int sp, const float* zeros) {
     if (c.ks != 3 || c.stride != 1 || !c.w_bx || c.cout != 64 || c.cin != 64) return -1;
     if (c2 && (c2->ks != 1 || c2->cin != 64 || c2->cout != 64 || !c2->w_bx)) return -1;
+    if (sp) {      // the split-format link (conv_bx64_body.hpp): 2 = the plain 3x3 writes it, 1 = the fused channels-last form reads it; fp16 pair, three weight fragments
+        if (!(fx && c.w_fx) || !zeros) return -1;
+        if (sp == 2 && !c2 && !nhwc) return run_bx64<64, 0, 1, 2>(c, nullptr, in, B, H, W, out, st, trace, status, zeros);
+        if (sp == 1 && c2 && c2->w_fx && nhwc) return run_bx64<64, 2, 1, 1>(c, c2, in, B, H, W, out, st, trace, status, zeros);
+        return -1;
+    }
     if (fx && c.w_fx && (!c2 || c2->w_fx)) {      // the fp16-pair arithmetic: three MFMAs per product instead of six; fx = 2: two weight fragments in the stream
         if (fx == 2 && c.w_fq) {
             if (!c2) return nhwc ? -1 : run_bx64<64, 0, 2>(c, nullptr, in, B, H, W, out, st, trace, status);

@@ -15,6 +15,26 @@ int main() {
     int hdr[8];
     if (fread(hdr, 4, 8, stdin) != 8) return 2;
     const int B = hdr[0], H = hdr[1], W = hdr[2], fuse = hdr[3], fx = hdr[4], relu = hdr[5], relu2 = hdr[6], grid = hdr[7];
+    if (fuse == 3) {      // the split-format link: conv A (plain 3x3, writes fp16 pairs) -> conv B (3x3 + 1x1, channels-last, reads them).  stdin continues: in, wA, bA, wB, bB, w2, b2
+        auto in = rd((size_t)B * 64 * H * W), wA = rd(64 * 64 * 9), bA = rd(64), wB = rd(64 * 64 * 9), bB = rd(64), w2 = rd(64 * 64), b2 = rd(64);
+        std::vector<uint16_t> qA((size_t)4 * 9 * 2 * 3 * 64 * 8 + 8192), qB(qA.size()), q2((size_t)4 * 2 * 3 * 64 * 8);
+        xfh::pack_bx64(wA.data(), 64, 64, 1, qA.data()); xfh::pack_bx64(wB.data(), 64, 64, 1, qB.data()); xfh::pack_bx1x1(w2.data(), 1, q2.data());
+        std::vector<float> mid((size_t)B * 64 * H * W, NAN), out((size_t)B * 64 * H * W, NAN), zeros(256, 0.f);
+        int status = 0;
+        xfh::Bx64Args a{};
+        a.status = &status; a.zeros = zeros.data();
+        a.in = in.data(); a.wq = qA.data(); a.bias = bA.data(); a.out = mid.data(); a.relu = relu; a.H = H; a.W = W; a.B = B;
+        a.ncols = (W + 15) / 16; a.nhr = (H + 7) / 8; a.upi = a.ncols * a.nhr;
+        const long long units = (long long)B * a.upi;
+        const int g = units < grid ? (int)units : grid;
+        emu::launch(g, 256, xfh::bx64::LDS_BYTES, [&] { xfh::conv_bx64_body<64, 0, 1, 2>(a); });
+        xfh::Bx64Args b = a;
+        b.in = mid.data(); b.wq = qB.data(); b.bias = bB.data(); b.out = out.data(); b.wq2 = reinterpret_cast<const uint4*>(q2.data()); b.bias2 = b2.data(); b.relu2 = relu2;
+        emu::launch(g, 256, xfh::bx64::SP_LDS_BYTES, [&] { xfh::conv_bx64_body<64, 2, 1, 1>(b); });
+        fwrite(out.data(), 4, out.size(), stdout);
+        fwrite(&status, 4, 1, stdout);
+        return 0;
+    }
     auto in = rd((size_t)B * 64 * H * W), w = rd(64 * 64 * 9), bias = rd(64);
     std::vector<float> w2, bias2;
     if (fuse) { w2 = rd(64 * 64); bias2 = rd(64); }

@@ -45,3 +45,25 @@ def test_conv_bx64_body_on_the_host(emu_bin, fuse, fx, shape, grid):
     print(f"fuse {fuse} fx {fx} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
     assert status == 0 and np.isfinite(y).all()
     assert d.max() <= 3e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("shape,grid", [((1, 24, 40), 3), ((2, 18, 20), 4), ((8, 8, 16), 8)])
+def test_split_format_link_on_the_host(emu_bin, shape, grid):
+    """producer-side split: a plain 3x3 writes its output as fp16 pairs in the record format of conv_bx64_body.hpp, the next layer (3x3 + 1x1, channels-last) stages it by
+    LDS-DMA alone (swizzled 64-byte records, double-buffered chunks, zeros for the halo outside the map): the pair against two float64 convolutions"""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H)
+    x = torch.relu(torch.randn(B, 64, H, W, generator=g)) * 2
+    wA, wB = (torch.randn(64, 64, 3, 3, generator=g) / 24 for _ in range(2))
+    bA, bB, b2 = (torch.randn(64, generator=g) * 0.3 for _ in range(3))
+    w2 = torch.randn(64, 64, generator=g) / 8
+    blob = np.concatenate([np.array([B, H, W, 3, 1, 1, 0, grid], np.int32).view(np.float32)] + [t.numpy().astype(np.float32).reshape(-1) for t in (x, wA, bA, wB, bB, w2, b2)])
+    out = subprocess.run([emu_bin], input=blob.tobytes(), capture_output=True, check=True, timeout=240).stdout
+    y = np.frombuffer(out[:-4], np.float32).reshape(B, H, W, 64).transpose(0, 3, 1, 2)
+    F = torch.nn.functional
+    ref = torch.relu(F.conv2d(x.double(), wA.double(), bA.double(), padding=1))
+    ref = torch.relu(F.conv2d(ref, wB.double(), bB.double(), padding=1))
+    ref = F.conv2d(ref, w2.double().view(64, 64, 1, 1), b2.double())
+    d = np.abs(y - ref.numpy())
+    print(f"split-format link {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0 and np.isfinite(y).all() and d.max() <= 5e-6 * float(ref.abs().max())

@@ -10,7 +10,7 @@ echo "new-kernel tests rc=$?"; tail -5 ${O}_pytest_new.log | grep -v amdgpu.ids
 # 2. what they are worth (in-run A/B, one process): block1 forms; heads; ~2 min
 timeout 300 python tools/ab_configs.py "block1=0" "block1=6" "block1=7" --spans 3 2>&1 | grep -v amdgpu.ids > ${O}_ab_block1.log; tail -12 ${O}_ab_block1.log
 timeout 400 python tools/ab_configs.py "heads_f32=3" "heads_f32=2" "heads_f32=0" "heads_f32=0,fx=11" "heads_f32=0,fx=27" "heads_f32=0,fx=43" --spans 202,203 2>&1 | grep -v amdgpu.ids > ${O}_ab_heads.log; tail -12 ${O}_ab_heads.log
-timeout 300 python tools/ab_configs.py "fx=3" "fx=7" --spans 108,111,112,117,118 2>&1 | grep -v amdgpu.ids > ${O}_ab_bx64.log; tail -8 ${O}_ab_bx64.log      # (spans: 100 + index in spec.CONVS: block3.1 (+3.2 fused), block4.1, block4.2, block_fusion.0, block_fusion.1 (+.2 fused))
+timeout 300 python tools/ab_configs.py "fx=3" "fx=7" "fx=67" --spans 108,111,112,117,118 2>&1 | grep -v amdgpu.ids > ${O}_ab_bx64.log; tail -8 ${O}_ab_bx64.log      # (spans: 100 + index in spec.CONVS: block3.1 (+3.2 fused), block4.1, block4.2, block_fusion.0, block_fusion.1 (+.2 fused))
 # 3. the fp16-pair head under the cold-start torture: 16 code positions next to the bf16 head as the box's control (needs libxfeat_hip_scan.so); ~4 min
 if [ -f accelerated_features_amd/libxfeat_hip_scan.so ]; then
   XFH_LIB_PATH=accelerated_features_amd/libxfeat_hip_scan.so timeout 600 python tools/head_soak.py --variants $(seq -s, 1000 1015),$(seq -s, 4000 4015),$(seq -s, 5000 5015) --foreign none --max-seconds 6 --logits 0 2>&1 | grep -v amdgpu.ids > ${O}_head_scan.log
