@@ -34,8 +34,23 @@ __global__ void mfma_layout(const _Float16* A /* 16 x 32 */, const _Float16* B /
     for (int j = 0; j < 4; ++j) D[(4 * (l >> 4) + j) * 16 + (l & 15)] = d[j];
 }
 
+__global__ __launch_bounds__(512) void occ_probe(float* p) {      // (a small kernel of 512 threads: what limits its residency is the dynamic LDS it is launched with)
+    extern __shared__ float sm[];
+    sm[threadIdx.x] = p[threadIdx.x];
+    __syncthreads();
+    p[threadIdx.x] = sm[511 - threadIdx.x];
+}
+
 int main() {
     int bad = 0;
+    // 3. how many 512-thread workgroups with N bytes of dynamic LDS the runtime places on a CU: block1 needs three with 51 728 (mode 5), 51 216 (mode 6), 53 616 (mode 7);
+    //    160 KB / 3 = 54 613, less whatever granule LDS is handed out in
+    for (int bytes : {51216, 51728, 52480, 53616, 53760, 54128, 54272, 54613, 55296}) {
+        int n = -1;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(occ_probe), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, occ_probe, 512, bytes);
+        printf("512 threads + %d bytes of LDS: %d workgroups per CU\n", bytes, n);
+    }
     unsigned *src, *out;
     hipMalloc(&src, 1024); hipMalloc(&out, 1024);
     std::vector<unsigned> hs(256), ho(256);

@@ -5,7 +5,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
 O=gpurun_out/r05_first
 # 0. two hardware assumptions of the CPU-prepared kernels (partial-exec LDS-DMA, the 16x16x32 operand layout): milliseconds
-/opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 tools/bench_src/hw_semantics.hip -o /tmp/hw_semantics 2>/dev/null && timeout 60 /tmp/hw_semantics | tee ${O}_hw_semantics.log
+/opt/rocm/bin/hipcc -O2 -w --offload-arch=gfx950 tools/bench_src/hw_semantics.hip -o /tmp/hw_semantics 2>/dev/null && timeout 60 /tmp/hw_semantics | tee ${O}_hw_semantics.log
 # 1. parity of the new forms alone and in the backbone (~1 min)
 timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q --tb=short -p no:cacheprovider -x -k "block1_forms_alone or alternative_kernels or fp16_pair_arithmetic or conv_layers_isolated" > ${O}_pytest_new.log 2>&1
 echo "new-kernel tests rc=$?"; tail -5 ${O}_pytest_new.log | grep -v amdgpu.ids
