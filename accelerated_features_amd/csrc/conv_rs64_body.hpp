@@ -1,0 +1,297 @@
+// conv_rs64_kernel (k_conv_rs64.hip): 3x3 / stride 1 / 64 -> 64 convolution (block4.1, block4.2, block_fusion.0; modules/model.py:69-70,84) in the fp16-pair
+// arithmetic (bx_split.hpp) with the WEIGHTS RESIDENT IN REGISTERS.  The body sits in a header so that tests/emu/ compiles the same source for the host.
+//
+// Why another kernel for these layers: conv_bx64_kernel streams all 216 KiB of split weights through LDS for EVERY 128-pixel unit (twelve tap rows, each behind a
+// barrier and a DMA wait), which is what its small-map launches pay for (1/16 scale: 0.16 of the matrix floor) and a good part of the large ones (0.30).  Here a
+// workgroup is four waves, one per SIMD (512 registers each), and the K = 576 of the product is split FOUR ways:
+//   * wave w holds the weights of input channels 16 w .. 16 w + 15 -- all 9 taps x 64 couts x 3 fragments = 54 A operands of v_mfma_f32_32x32x16_f16, 216 registers,
+//     loaded once per workgroup -- and multiplies only its own channel chunk: per 32 pixels and tap 2 ds_read_b128 (high, low parts) feed 6 MFMAs;
+//   * so a wave also STAGES only its own chunk, into a ring of its own: no barrier between staging and use (LDS operations of a wave are ordered);
+//   * the map is walked in PADDED RASTER order (pitch P = W + 2: one zero column left and right): the input of output position p under tap (dy, dx) is the staged
+//     position p + dy P + dx -- one constant shift per tap, no tile halo, every input pixel is split once per run (+ 2 P + 2 at its start).  The two pad positions
+//     of a row are computed and dropped (2 / P of the work);
+//   * the four partial sums of a 32-position x 64-cout block meet in LDS: wave w owns couts 16 w .. + 15 (8 of its accumulator registers), writes the other 24
+//     to their owners' slots (6 ds_write_b128), and after the block's ONE barrier adds three partials to its own (double-buffered: 48 KiB).
+// Per block and wave: 54 MFMAs (1728 matrix-pipe cycles), 18 + 6 LDS reads, 6 LDS writes.  LDS: 48 KiB + 4 x nseg x 5 KiB of rings (nseg = 3 + (2 P + 1) / 64
+// segments of 64 positions: the current unit's window and the segment being written): 150 KiB at P = 82 (VGA 1/8 scale) -- one workgroup per CU; maps wider than 93
+// columns do not fit and stay with conv_bx64_kernel.
+#pragma once
+#ifndef XFH_HOST_EMU
+#include "kernels.hpp"
+#ifndef XFH_DYN_LDS_BYTES
+#define XFH_DYN_LDS_BYTES(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#endif
+/* a wave's LDS operations are ordered and its lanes run in lock-step: a position one lane wrote is there when another lane reads it -- nothing to wait for (the host
+   emulation, where lanes are threads, meets here) */
+#define XFH_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+/* workgroup barrier for LDS traffic alone: the wave's global loads and stores stay in flight (__syncthreads waits for them too) */
+#define XFH_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define XFH_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+/* a value whose home is an accumulation register: the matrix instructions read their A operand from there directly; left to itself hipcc parks the weights that do not fit into
+   the 256 architectural registers there too, but copies each fragment back (four v_accvgpr_read) in front of every use */
+#define XFH_AGPR(x) asm volatile("" : "+a"(x))
+#endif
+#include <type_traits>
+#include "bx_split.hpp"
+
+namespace xfh {
+
+struct Rs64Args {
+    const float* in;
+    const void* wq;            // [wave = channel chunk 4][tap 9][cout block 2][fragment 3][64 lanes][8 fp16]   (weight_split.hpp: pack_rs64)
+    const float* bias;
+    float* out;
+    int relu, H, W, B;
+    int P;                     // W + 2
+    float inv_p;               // 1 / P
+    int nu;                    // 64-position units per image: ceil(H P / 64)
+    int nseg;                  // ring capacity in segments
+    int k;                     // runs per image (a run = consecutive units of one image, one workgroup)
+    int cold;
+    int* status;               // range guard of the fp16 pair (bx_split.hpp), may be NULL
+};
+
+namespace rs64 {
+constexpr int PIXB = 80;                                      // staged position: 16 channels x (high, low) fp16 + 16: an odd multiple of 16 B (distinct banks for the 16 lanes of a ds_read_b128 group)
+constexpr int SEG_PX = 64, SEG_BYTES = SEG_PX * PIXB;         // 5120
+constexpr int RED_BYTES = 4 * 3 * 2048;                       // [owner 4][source slot 3][part 2][64 lanes] float4
+constexpr int RING_OFF = 2 * RED_BYTES;                       // 49152
+constexpr int MAX_NSEG = 5;
+constexpr int WQ_HALFS = 4 * 9 * 2 * 3 * 64 * 8;              // 110592 fp16 = 216 KiB
+inline int nseg_for(int P) { return 3 + (2 * P + 1) / 64; }
+inline int lds_bytes(int nseg) { return RING_OFF + 4 * nseg * SEG_BYTES; }
+// runs per image for `grid` workgroups: whole images while there are enough of them, else every image in grid / B parts (at least one unit each)
+inline int runs_per_image(int B, int nu, int grid) { const int k = B >= grid ? 1 : grid / B; return k < 1 ? 1 : k > nu ? nu : k; }
+static_assert(RING_OFF + 4 * MAX_NSEG * SEG_BYTES <= 160 * 1024, "LDS of a CU");
+}
+
+// the code of ONE wave of the workgroup (wave = its K quarter and the couts it finishes): four copies, so that which accumulator registers are a wave's own and which go to
+// whom is static (selected at run time it costs a v_cndmask per register and use, or a branch tree in the middle of the MFMA stream)
+template <int wave>
+__device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
+    using namespace rs64;
+    XFH_DYN_LDS_BYTES(smem_rs);
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kg = lane >> 5;
+    const int P = a.P, H = a.H, W = a.W, HW = H * W;
+    const float inv_p = a.inv_p;
+
+    // ---- this wave's weights: channels 16 wave .. + 15 under every tap, all 64 couts, three fragments (q0, q1, q2 of split_weight mode 1)
+    f16x8 A[9][2][3];
+    {
+        const f16x8* wp = reinterpret_cast<const f16x8*>(a.wq) + (size_t)wave * (9 * 2 * 3 * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    A[t][cb][q] = wp[((t * 2 + cb) * 3 + q) * 64];
+                    if (q < 2) XFH_AGPR(A[t][cb][q]);          // 144 of the 216 weight registers live in the accumulation half of the register file (next to the 64 accumulators)
+                }
+    }
+    // ---- the couts this wave finishes: 16 wave + 8 (k >> 2) + 4 kg + (k & 3), k = 0 .. 7 = registers 8 (wave & 1) + k of accumulator wave >> 1
+    float bs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bs[k] = a.bias[16 * wave + 8 * (k >> 2) + 4 * kg + (k & 3)];
+    const float floor_y = a.relu ? 0.f : -__builtin_inff();
+
+    unsigned char* ring = smem_rs + RING_OFF + wave * a.nseg * SEG_BYTES;
+    const unsigned Rb = (unsigned)a.nseg * SEG_BYTES;
+    const unsigned lane_b = (unsigned)(n * PIXB + kg * 16);
+    unsigned amax = 0;
+    int kb = 0;                                    // blocks this workgroup has reduced: parity = reduction buffer
+    const int nruns = a.B * a.k;
+
+    // position i of a padded raster = (row, column): i < 2^20, P >= 3: (i + 0.5) / P is at least 1 / (2 P) away from an integer, the product's error is below 1e-4
+    auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_p); };
+    // the B operands of a tap: positions t0 + shift + n of the ring, high parts and low parts of this lane's 8 channels
+    struct Xf { f16x8 h, l; };
+    auto ldb = [&](unsigned tb /* byte offset of the block's first position under this tap, < 2 Rb */, Xf& x) __attribute__((always_inline)) {
+        tb = tb >= Rb ? tb - Rb : tb;                                                 // (wave-uniform)
+        unsigned ab = tb + lane_b;
+        ab = min(ab, ab - Rb);                                                        // positions beyond the ring's end continue at its start
+        x.h = *reinterpret_cast<const f16x8*>(ring + ab);
+        x.l = *reinterpret_cast<const f16x8*>(ring + ab + 32);
+        // the B operands live in accumulation registers too (ds_read writes them there directly): registers no vector-ALU result is ever allocated to, so none can land in
+        // an operand the matrix core is still reading (tools/check_mfma_war.py) -- without idle slots or keep-alive fences in the MFMA stream
+        XFH_AGPR(x.h); XFH_AGPR(x.l);
+    };
+    unsigned shift_b[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) shift_b[t] = (unsigned)(((t / 3) * P + (t % 3)) * PIXB);
+
+    // where a finished block goes: the block's accumulators wait one block long for their reduction (it runs inside the next block's MFMAs)
+    struct Pend { __amdgpu_buffer_rsrc_t rs; int voff; };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+    // ---- the partial sums of a block meet: registers 8 (o & 1) .. + 7 of accumulator o >> 1 belong to wave o.  red_write: the 24 foreign ones to their owners' slots
+    // (buffer kb & 1); red_read: the three partials for this wave's couts; red_finish: sum, bias, ReLU, stores
+    auto red_write = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
+        unsigned char* red = smem_rs + (kb & 1) * RED_BYTES;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            if (o == wave) continue;
+            float4* d = reinterpret_cast<float4*>(red + o * (3 * 2048) + (wave < o ? wave : wave - 1) * 2048) + lane;      // this wave is source slot wave - (wave > o) of owner o
+            const f32x16& c = (o >> 1) ? c1 : c0;
+            d[0] = make_float4(c[8 * (o & 1)], c[8 * (o & 1) + 1], c[8 * (o & 1) + 2], c[8 * (o & 1) + 3]);
+            d[64] = make_float4(c[8 * (o & 1) + 4], c[8 * (o & 1) + 5], c[8 * (o & 1) + 6], c[8 * (o & 1) + 7]);
+        }
+    };
+    auto red_read = [&](float4 (&part)[3][2]) __attribute__((always_inline)) {
+        const unsigned char* red = smem_rs + (kb & 1) * RED_BYTES;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const float4* d = reinterpret_cast<const float4*>(red + wave * (3 * 2048) + s * 2048) + lane;
+            part[s][0] = d[0]; part[s][1] = d[64];
+        }
+    };
+    auto red_finish = [&](const f32x16& c0, const f32x16& c1, const float4 (&part)[3][2], const Pend& pd) __attribute__((always_inline)) {
+        float own[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) own[k] = ((wave >> 1) ? c1 : c0)[8 * (wave & 1) + k];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            own[0] += part[s][0].x; own[1] += part[s][0].y; own[2] += part[s][0].z; own[3] += part[s][0].w;
+            own[4] += part[s][1].x; own[5] += part[s][1].y; own[6] += part[s][1].z; own[7] += part[s][1].w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float y = fmaxf(own[k] * FX_SCALE_INV + bs[k], floor_y);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), pd.rs, pd.voff, ((k & 3) + 8 * (k >> 2)) * HW * 4, 0);
+        }
+    };
+    // ---- taps T0 .. T1 - 1 of a block: the operands of tap t + 1 are read while tap t is multiplied (x[t & 1] <-> x[(t + 1) & 1]); behind tap 8: tap 0 of the NEXT block
+    // (32 positions on: the second block of the unit, or the first of the next unit -- its segment has been in the ring since this unit began)
+    auto taps = [&](auto T0C, auto T1C, auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[2]) __attribute__((always_inline)) {
+        constexpr int T0 = decltype(T0C)::value, T1 = decltype(T1C)::value, PAR = decltype(PARC)::value;
+#pragma unroll
+        for (int t = T0; t < T1; ++t) {
+            const int cur = (t + PAR) & 1;
+            ldb(t < 8 ? t0b + shift_b[t < 8 ? t + 1 : 0] : t0b + 32 * PIXB, x[cur ^ 1]);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][2], x[cur].h, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][2], x[cur].h, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][1], x[cur].l, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][1], x[cur].l, c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][0], x[cur].h, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][0], x[cur].h, c1, 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I3 = std::integral_constant<int, 3>;
+    using I5 = std::integral_constant<int, 5>; using I9 = std::integral_constant<int, 9>;
+
+    f32x16 ca0, ca1, cb0, cb1;                     // accumulator sets of the unit's first / second block
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ca0[i] = 0.f; ca1[i] = 0.f; cb0[i] = 0.f; cb1[i] = 0.f; }
+    Pend pend_a, pend_b;                            // (b: the second block of the unit BEFORE: nothing yet -- a resource of zero bytes drops the stores)
+    pend_b.rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);
+    pend_b.voff = (int)0x80000000;
+    pend_a = pend_b;
+    Xf x[2];
+
+    for (int run = (int)blockIdx.x; run < nruns; run += (int)gridDim.x) {
+        const int b = run / a.k, part_i = run - b * a.k;
+        const int ua = (int)((long long)a.nu * part_i / a.k), ub = (int)((long long)a.nu * (part_i + 1) / a.k);
+        if (ua >= ub) continue;
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + ((size_t)b * 64 + 16 * wave) * HW), 0, (int)(16 * HW * sizeof(float)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + ((size_t)b * 64 + 16 * wave) * HW), 0, (int)(16 * HW * sizeof(float)), 0x00020000);
+        // segment s of the image's padded raster: position 64 s + lane = (row r, column c) of the (H + 2) x P frame = pixel (r - 1, c - 1); outside the map: zeros
+        auto seg_load = [&](int s, bool en, float (&v)[16]) __attribute__((always_inline)) {
+            const int i = 64 * s + lane, r = row_of(i), c = i - r * P;
+            const int iy = r - 1, ix = c - 1;
+            const int voff = en && iy >= 0 && iy < H && ix >= 0 && ix < W ? (iy * W + ix) * 4 : (int)0x80000000;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, j * HW * 4, 0));
+        };
+        auto seg_write = [&](int slot, const float (&v)[16]) __attribute__((always_inline)) {
+            u32x4 h[2], l[2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned hh, ll;
+                split2_f16(v[2 * j], v[2 * j + 1], hh, ll);
+                fx_track_h(amax, hh, true);
+                h[j >> 2][j & 3] = hh; l[j >> 2][j & 3] = ll;
+            }
+            unsigned char* p = ring + (slot * SEG_PX + lane) * PIXB;
+            *reinterpret_cast<u32x4*>(p) = h[0];
+            *reinterpret_cast<u32x4*>(p + 16) = h[1];
+            *reinterpret_cast<u32x4*>(p + 32) = l[0];
+            *reinterpret_cast<u32x4*>(p + 48) = l[1];
+        };
+        auto out_voff = [&](int p) {               // output position p of the padded raster -> this lane's store offset (its first cout), or "dropped"
+            const int oy = row_of(p), ox = p - oy * P;
+            return oy < H && ox < W ? ((4 * kg) * HW + oy * W + ox) * 4 : (int)0x80000000;
+        };
+        // prologue: the window of the run's first unit (segments ua .. ua + nseg - 2) with every pipe idle; the segment the first unit will write travels
+        int wslot = 0;
+        float v[16];
+        for (int q = 0; q < a.nseg - 1; ++q) {
+            seg_load(ua + q, true, v);
+            seg_write(wslot, v);
+            ++wslot;
+        }
+        XFH_WAVE_SYNC();
+        seg_load(ua + a.nseg - 1, ua + 1 < ub, v);
+        int rslot = 0;                             // slot of segment u
+        ldb(0u, x[0]);
+        for (int u = ua; u < ub; ++u) {
+            const unsigned t0b = (unsigned)(rslot * SEG_BYTES);
+            float4 part[3][2];
+            // ---- first block (accumulators a); inside it: the reduction of the block before (accumulators b: the previous unit's, or run's, second block)
+            pend_a.rs = rs_out; pend_a.voff = out_voff(64 * u + n);
+            taps(I0{}, I3{}, I0{}, t0b, ca0, ca1, x);
+            XFH_SCHED_FENCE();
+            red_write(cb0, cb1);
+            taps(I3{}, I5{}, I0{}, t0b, ca0, ca1, x);
+            XFH_SCHED_FENCE();
+            XFH_LDS_BARRIER();
+            red_read(part);
+            ++kb;
+            XFH_SCHED_FENCE();
+            taps(I5{}, I9{}, I0{}, t0b, ca0, ca1, x);
+            red_finish(cb0, cb1, part, pend_b);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { cb0[i] = 0.f; cb1[i] = 0.f; }
+            XFH_SCHED_FENCE();
+            // ---- second block (accumulators b); inside it: the segment the next unit needs goes into the ring, the first block is reduced, the segment after that is requested
+            pend_b.rs = rs_out; pend_b.voff = out_voff(64 * u + 32 + n);
+            taps(I0{}, I3{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
+            seg_write(wslot, v);                    // (the last unit of a run writes zeros into a free slot)
+            XFH_SCHED_FENCE();
+            red_write(ca0, ca1);
+            taps(I3{}, I5{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
+            XFH_SCHED_FENCE();
+            XFH_LDS_BARRIER();                      // (also orders the ring: the segment written above is read from the next unit on)
+            red_read(part);
+            ++kb;
+            XFH_SCHED_FENCE();
+            taps(I5{}, I9{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
+            red_finish(ca0, ca1, part, pend_a);
+            seg_load(u + a.nseg, u + 2 < ub, v);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ca0[i] = 0.f; ca1[i] = 0.f; }
+            XFH_SCHED_FENCE();
+            wslot = wslot + 1 == a.nseg ? 0 : wslot + 1;
+            rslot = rslot + 1 == a.nseg ? 0 : rslot + 1;
+        }
+    }
+    // ---- the last block of all
+    {
+        float4 part[3][2];
+        red_write(cb0, cb1);
+        XFH_LDS_BARRIER();
+        red_read(part);
+        red_finish(cb0, cb1, part, pend_b);
+    }
+    fx_report_h(amax, a.status);
+}
+
+__device__ __forceinline__ void conv_rs64_body(const Rs64Args& a) {
+    switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {
+        case 0: conv_rs64_wave<0>(a); break;
+        case 1: conv_rs64_wave<1>(a); break;
+        case 2: conv_rs64_wave<2>(a); break;
+        default: conv_rs64_wave<3>(a); break;
+    }
+}
+
+}  // namespace xfh

@@ -1,0 +1,35 @@
+// 3x3 stride-1 convolution, 64 -> 64 channels, fp16-pair arithmetic, weights resident in registers (K split over the four waves of a workgroup, partial sums
+// reduced through LDS, padded-raster walk of the map): body and design notes in conv_rs64_body.hpp (also compiled for the host by tests/emu/).
+#include "kernels.hpp"
+#include "conv_rs64_body.hpp"
+
+namespace xfh {
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void conv_rs64_kernel(Rs64Args a) {
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
+    conv_rs64_body(a);
+}
+
+// -1: not this kernel's layer or map (the caller keeps conv_bx64_kernel)
+int launch_conv_rs64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status) {
+    if (c.ks != 3 || c.stride != 1 || c.cout != 64 || c.cin != 64 || !c.w_rs) return -1;
+    if ((size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
+    Rs64Args a;
+    a.cold = g_debug_cold;
+    a.status = status;
+    a.in = in; a.wq = c.w_rs; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B;
+    a.P = W + 2; a.inv_p = 1.f / (float)a.P; a.nu = ceil_div(H * a.P, 64); a.nseg = rs64::nseg_for(a.P);
+    if (a.nseg > rs64::MAX_NSEG) return -1;                                  // the rings of a map wider than 93 columns do not fit
+    const int lds = rs64::lds_bytes(a.nseg);
+    static unsigned attr_done = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_rs64_kernel), rs64::lds_bytes(rs64::MAX_NSEG), attr_done);
+    int grid = num_cus();                      // one workgroup (four waves, one per SIMD) per CU
+    a.k = rs64::runs_per_image(B, a.nu, grid);
+    const long long nruns = (long long)B * a.k;
+    if (nruns < grid) grid = (int)nruns;
+    conv_rs64_kernel<<<grid, 256, lds, st>>>(a);
+    return 0;
+}
+
+}  // namespace xfh

@@ -106,6 +106,23 @@ inline size_t pack_bx64(const float* w, int cin, int cout, int mode, uint16_t* d
                         }
     return (size_t)nhf * nch * 9 * 2 * nfrag * 64 * 8;
 }
+// 3x3 convolution weights (64 -> 64) for conv_rs64_kernel (conv_rs64_body.hpp: weights resident in registers, K split over the four waves of a workgroup):
+// [wave = 16-channel chunk][tap 9][cout block 2][fragment 3][lane = half * 32 + cout][8], channel = 16 wave + 8 half + i; fp16-pair fragments (split_weight mode 1).
+// w: (64, 64, 3, 3) fp32 (BatchNorm folded).  Returns the 16-bit words written.
+constexpr size_t kRs64Halfs = (size_t)4 * 9 * 2 * 3 * 64 * 8;      // 216 KiB
+inline size_t pack_rs64(const float* w, uint16_t* dst) {
+    for (int wv = 0; wv < 4; ++wv)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int o = cb * 32 + (lane & 31), ci = wv * 16 + 8 * (lane >> 5) + i;
+                        uint16_t q[3];
+                        split_weight(w[((size_t)o * 64 + ci) * 9 + tap], 1, q);
+                        for (int sp = 0; sp < 3; ++sp) dst[(((((size_t)wv * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                    }
+    return kRs64Halfs;
+}
 // the 1x1 (64 -> 64) fused behind a 64 -> 64 3x3 in conv_bx64_kernel: K order of the 3x3's D registers (as a chained head layer): [K step 4][cout block 2][split 3][lane][8]
 inline size_t pack_bx1x1(const float* w /* (64, 64) */, int mode, uint16_t* dst) { return pack_head_layer(w, 64, false, mode, dst); }
 

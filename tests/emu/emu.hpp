@@ -133,6 +133,11 @@ inline void dma_b128_to_lds(unsigned m0v, unsigned voff, i4 rs, unsigned soff) {
     unsigned char* dst = wg->lds_base() + m0v + 16 * (tidx.x & 63);
     if ((uint64_t)voff + 16 <= (unsigned)rs.z) std::memcpy(dst, base + voff + soff, 16); else std::memset(dst, 0, 16);
 }
+inline unsigned buffer_load_b32(Rsrc rs, unsigned voff, unsigned soff) {
+    unsigned r = 0;
+    if ((uint64_t)voff + 4 <= rs.bytes) std::memcpy(&r, rs.base + voff + soff, 4);
+    return r;
+}
 inline float med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 inline unsigned perm(unsigned hi, unsigned lo, unsigned sel) {
     const uint64_t v = ((uint64_t)hi << 32) | lo;
@@ -178,6 +183,10 @@ inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_REL
 #define XFH_DMA_B128_TO_LDS(m0v, voff, rsrc, soff) emu::dma_b128_to_lds(m0v, voff, rsrc, soff)
 #define XFH_NOP16_3(a, b, c) ((void)0)
 #define XFH_PIN(x) ((void)0)
+#define XFH_AGPR(x) ((void)0)
+#define XFH_LDS_BARRIER() __syncthreads()
+#define XFH_SCHED_FENCE() ((void)0)
+#define XFH_WAVE_SYNC() emu::wg->wave_bar[emu::tidx.x >> 6]->arrive_and_wait()      /* lanes of a wave run in lock-step on the GPU; here they are threads */
 typedef const void* xfh_gptr_t;
 typedef void* xfh_lptr_t;
 typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
@@ -195,6 +204,7 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu::dma(g, l, size)
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{reinterpret_cast<unsigned char*>(p), (unsigned)(bytes)}
 #define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) emu::buffer_load_b128(rs, (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, aux) emu::buffer_load_b32(rs, (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_store_b64(val, rs, voff, soff, aux)                                                               \
     do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 8 <= (rs).bytes) { const auto v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 8); } } while (0)
 #define __builtin_amdgcn_raw_buffer_store_b32(val, rs, voff, soff, aux)                                                               \

@@ -1,0 +1,57 @@
+"""conv_rs64_kernel's body (csrc/conv_rs64_body.hpp: 64 -> 64 3x3 convolution in the fp16-pair arithmetic with the weights resident in registers, K split over the four waves
+of a workgroup, padded-raster walk of the map, partial sums reduced through LDS) compiled for the HOST (tests/emu/) against a float64 convolution."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.fixture(scope="module")
+def emu_bin():
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang")
+    out = os.path.join(tempfile.mkdtemp(), "conv_rs64_emu")
+    subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", os.path.join(ROOT, "accelerated_features_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "emu"),
+                    os.path.join(ROOT, "tests", "emu", "conv_rs64_emu.cpp"), "-o", out], check=True)
+    return out
+
+
+def run(emu_bin, x, w, b, relu, grid, k):
+    B, _, H, W = x.shape
+    blob = np.concatenate([np.array([B, H, W, relu, grid, k], np.int32).view(np.float32)] + [t.numpy().astype(np.float32).reshape(-1) for t in (x, w, b)])
+    out = subprocess.run([emu_bin], input=blob.tobytes(), capture_output=True, check=True, timeout=240).stdout
+    return np.frombuffer(out[:-4], np.float32).reshape(B, 64, H, W), int(np.frombuffer(out[-4:], np.int32)[0])
+
+
+# (30 x 40: the 1/16-scale VGA map, nseg 4, runs of 5 units; 15 x 80: the 1/8-scale pitch, nseg 5; 7 x 33: a map smaller than a ring; 9 x 93: the widest map that fits;
+#  k = 1: whole images per run, two runs for one workgroup; k = nu: one unit per run)
+@pytest.mark.parametrize("shape,relu,grid,k", [((1, 30, 40), 1, 4, 0), ((2, 15, 80), 0, 3, 2), ((3, 7, 33), 1, 2, 1), ((1, 9, 93), 1, 2, 0), ((1, 12, 20), 1, 64, 0), ((1, 1, 1), 0, 1, 0)])
+def test_conv_rs64_body_on_the_host(emu_bin, shape, relu, grid, k):
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.randn(B, 64, H, W, generator=g) * 2              # (signed inputs: block_fusion.0 reads the pyramid sum)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b = torch.randn(64, generator=g) * 0.3
+    y, status = run(emu_bin, x, w, b, relu, grid, k)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    d = np.abs(y - ref.numpy())
+    print(f"{shape} relu {relu} grid {grid} k {k}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert status == 0 and np.isfinite(y).all()
+    assert d.max() <= 3e-6 * float(ref.abs().max())
+
+
+def test_conv_rs64_reports_its_range(emu_bin):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 64, 6, 10, generator=g)
+    x[0, 37, 3, 4] = 7e4
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    _, status = run(emu_bin, x, w, torch.zeros(64), 1, 2, 0)
+    assert status == 1
