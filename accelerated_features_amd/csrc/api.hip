@@ -275,7 +275,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     std::vector<float> blob;
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
     const size_t zoff = reserve(256);
-    struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx, fq, rs; bool has_wino, has_bx, fx_ok, has_fq; } coff[L_NUM];
+    struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx, fq, rs; bool has_wino, has_bx, fx_ok, has_fq, has_rs; } coff[L_NUM];
     struct FOff { size_t w, b; } foff[5];
     int ai = 0;
     for (int li = 0; li < L_NUM; ++li) {
@@ -379,12 +379,19 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                         }
             if (bx64 || bx64s2) pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, mode, dst);      // (weight_split.hpp)
         }
+        coff[li].has_rs = false;
+        if (bx1x1 && coff[li].fx_ok) {      // the 1x1 behind a 64 -> 64 3x3 in conv_rs64_kernel's order (16 couts per wave, natural K order)
+            coff[li].rs = reserve((size_t)4 * 2 * 3 * 64 * 4);
+            pack_rs64_1x1(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
+            coff[li].has_rs = true;
+        }
         coff[li].has_fq = bx64 && coff[li].fx_ok;
         if (coff[li].has_fq) {      // two fragments per weight (q0, q2): conv_bx64_body.hpp FXM 2
             coff[li].fq = reserve((size_t)(c.cin / 16) * 9 * 2 * 2 * 64 * 4);
             pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, 1, reinterpret_cast<uint16_t*>(&blob[coff[li].fq]), 2);
             coff[li].rs = reserve(kRs64Halfs / 2);      // the same three fragments in conv_rs64_kernel's order (one K quarter per wave)
             pack_rs64(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
+            coff[li].has_rs = true;
         }
     }
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].
@@ -482,7 +489,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.w_bx = coff[li].has_bx ? ctx->blob + coff[li].bx : nullptr;
         w.w_fx = coff[li].has_bx && coff[li].fx_ok ? ctx->blob + coff[li].fx : nullptr;
         w.w_fq = coff[li].has_fq ? ctx->blob + coff[li].fq : nullptr;
-        w.w_rs = coff[li].has_fq ? ctx->blob + coff[li].rs : nullptr;
+        w.w_rs = coff[li].has_rs ? ctx->blob + coff[li].rs : nullptr;
     }
     ctx->nw.zeros = ctx->blob + zoff;
     for (int hd = 0; hd < 2; ++hd) {
@@ -567,6 +574,7 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
     // fx bit 128 (with bit 1): the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on conv_rs64_kernel -- weights resident in registers; -1 (map too wide for its rings): the paths below
     if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status);
+    if (rc && use_bx && (h->opt.fx & 257) == 257 && c.w_rs && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc);      // bit 256: block3.1 + 3.2, block_fusion.1 + .2
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, (h->opt.fx & 2) != 0, h->status);      // (bx = 9: block3.0 stays on the f32 kernel)
         else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // (bx = 5: large maps only)
@@ -925,7 +933,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 255}};
+        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 511}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

@@ -12,9 +12,9 @@
 //     of a row are computed and dropped (2 / P of the work);
 //   * the four partial sums of a 32-position x 64-cout block meet in LDS: wave w owns couts 16 w .. + 15 (8 of its accumulator registers), writes the other 24
 //     to their owners' slots (6 ds_write_b128), and after the block's ONE barrier adds three partials to its own (double-buffered: 48 KiB).
-// Per block and wave: 54 MFMAs (1728 matrix-pipe cycles), 18 + 6 LDS reads, 6 LDS writes.  LDS: 48 KiB + 4 x nseg x 5 KiB of rings (nseg = 3 + (2 P + 1) / 64
-// segments of 64 positions: the current unit's window and the segment being written): 150 KiB at P = 82 (VGA 1/8 scale) -- one workgroup per CU; maps wider than 93
-// columns do not fit and stay with conv_bx64_kernel.
+// Per block and wave: 54 MFMAs (1728 matrix-pipe cycles), 18 + 6 LDS reads, 6 LDS writes.  LDS: 48 KiB + 4 x nseg x 5 KiB of rings (nseg = 2 + (2 P + 1) / 64
+// segments of 64 positions = exactly one unit's window: the next unit's new segment is converted inside the unit's MFMAs and stored behind its last operand read, over the
+// segment the unit started with): 128 KiB at P = 82 (VGA 1/8 scale) -- one workgroup per CU; maps wider than 125 columns (nseg > 5) stay with conv_bx64_kernel.
 #pragma once
 #ifndef XFH_HOST_EMU
 #include "kernels.hpp"
@@ -49,27 +49,34 @@ struct Rs64Args {
     int k;                     // runs per image (a run = consecutive units of one image, one workgroup)
     int cold;
     int* status;               // range guard of the fp16 pair (bx_split.hpp), may be NULL
+    // fused trailing 1x1 (64 -> 64; FUSE 1: NCHW output, 2: channels-last): [wave = 16 couts][K step 2][fragment 3][64 lanes][8 fp16] (weight_split.hpp: pack_rs64_1x1)
+    const void* wq2;
+    const float* bias2;
+    int relu2;
 };
 
 namespace rs64 {
 constexpr int PIXB = 80;                                      // staged position: 16 channels x (high, low) fp16 + 16: an odd multiple of 16 B (distinct banks for the 16 lanes of a ds_read_b128 group)
 constexpr int SEG_PX = 64, SEG_BYTES = SEG_PX * PIXB;         // 5120
 constexpr int RED_BYTES = 4 * 3 * 2048;                       // [owner 4][source slot 3][part 2][64 lanes] float4
-constexpr int RING_OFF = 2 * RED_BYTES;                       // 49152
+constexpr int Y_PITCH = 272, Y_BYTES = 32 * Y_PITCH;           // fused 1x1: a block's 3x3 outputs as fp16 pairs, [position 32][high parts of the 64 channels | low parts] + 16 (bank spread)
+template <int FUSE> constexpr int ring_off() { return 2 * RED_BYTES + (FUSE ? 2 * Y_BYTES : 0); }      // 49152 | 66560
 constexpr int MAX_NSEG = 5;
 constexpr int WQ_HALFS = 4 * 9 * 2 * 3 * 64 * 8;              // 110592 fp16 = 216 KiB
-inline int nseg_for(int P) { return 3 + (2 * P + 1) / 64; }
-inline int lds_bytes(int nseg) { return RING_OFF + 4 * nseg * SEG_BYTES; }
+inline int nseg_for(int P) { return 2 + (2 * P + 1) / 64; }
+inline int lds_bytes(int nseg, bool fuse = false) { return (fuse ? ring_off<1>() : ring_off<0>()) + 4 * nseg * SEG_BYTES; }
+inline int max_nseg(bool fuse) { return fuse ? 4 : 5; }
 // runs per image for `grid` workgroups: whole images while there are enough of them, else every image in grid / B parts (at least one unit each)
 inline int runs_per_image(int B, int nu, int grid) { const int k = B >= grid ? 1 : grid / B; return k < 1 ? 1 : k > nu ? nu : k; }
-static_assert(RING_OFF + 4 * MAX_NSEG * SEG_BYTES <= 160 * 1024, "LDS of a CU");
+static_assert(ring_off<0>() + 4 * 5 * SEG_BYTES <= 160 * 1024 && ring_off<1>() + 4 * 4 * SEG_BYTES <= 160 * 1024, "LDS of a CU");
 }
 
 // the code of ONE wave of the workgroup (wave = its K quarter and the couts it finishes): four copies, so that which accumulator registers are a wave's own and which go to
 // whom is static (selected at run time it costs a v_cndmask per register and use, or a branch tree in the middle of the MFMA stream)
-template <int wave>
+template <int wave, int FUSE>
 __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     using namespace rs64;
+    constexpr int RING_OFF = ring_off<FUSE>();
     XFH_DYN_LDS_BYTES(smem_rs);
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kg = lane >> 5;
     const int P = a.P, H = a.H, W = a.W, HW = H * W;
@@ -145,7 +152,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             part[s][0] = d[0]; part[s][1] = d[64];
         }
     };
-    auto red_finish = [&](const f32x16& c0, const f32x16& c1, const float4 (&part)[3][2], const Pend& pd) __attribute__((always_inline)) {
+    auto red_finish = [&](const f32x16& c0, const f32x16& c1, const float4 (&part)[3][2], const Pend& pd, int ybuf) __attribute__((always_inline)) {
         float own[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) own[k] = ((wave >> 1) ? c1 : c0)[8 * (wave & 1) + k];
@@ -154,13 +161,69 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             own[0] += part[s][0].x; own[1] += part[s][0].y; own[2] += part[s][0].z; own[3] += part[s][0].w;
             own[4] += part[s][1].x; own[5] += part[s][1].y; own[6] += part[s][1].z; own[7] += part[s][1].w;
         }
+        float y[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float y = fmaxf(own[k] * FX_SCALE_INV + bs[k], floor_y);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), pd.rs, pd.voff, ((k & 3) + 8 * (k >> 2)) * HW * 4, 0);
+        for (int k = 0; k < 8; ++k) y[k] = fmaxf(own[k] * FX_SCALE_INV + bs[k], floor_y);
+        if constexpr (FUSE == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[k]), pd.rs, pd.voff, ((k & 3) + 8 * (k >> 2)) * HW * 4, 0);
+        } else {
+            // the 1x1's B operands: this lane's channels 16 wave + 4 kg + {0 .. 3} and 16 wave + 8 + 4 kg + {0 .. 3} of position n, as fp16 pairs, into Y[ybuf]
+            unsigned char* yp = smem_rs + 2 * RED_BYTES + ybuf * Y_BYTES + n * Y_PITCH + (16 * wave + 4 * kg) * 2;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint2 hh, ll;
+                split2_f16(y[4 * g], y[4 * g + 1], hh.x, ll.x);
+                split2_f16(y[4 * g + 2], y[4 * g + 3], hh.y, ll.y);
+                fx_track_h(amax, hh.x, true); fx_track_h(amax, hh.y, true);
+                *reinterpret_cast<uint2*>(yp + 16 * g) = hh;
+                *reinterpret_cast<uint2*>(yp + 16 * g + 128) = ll;
+            }
         }
     };
-    // ---- taps T0 .. T1 - 1 of a block: the operands of tap t + 1 are read while tap t is multiplied (x[t & 1] <-> x[(t + 1) & 1]); behind tap 8: tap 0 of the NEXT block
+    // ---- fused 1x1 on a block whose 3x3 outputs wait in Y[ybuf] (written one block ago, published by the barrier since): this wave's 16 couts x 32 positions,
+    // K = 64 as two steps of v_mfma_f32_16x16x32_f16 (lane: position l & 15 of the 16-position half, K values 8 (l >> 4) .. + 7; D: couts 4 (l >> 4) + j)
+    struct Pend2 { __amdgpu_buffer_rsrc_t rs; int voff[2]; };
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f16x8 A2[2][3];
+    float bs2[4];
+    if constexpr (FUSE != 0) {
+        const f16x8* wp2 = reinterpret_cast<const f16x8*>(a.wq2) + (size_t)wave * (2 * 3 * 64) + lane;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) A2[s2][q] = wp2[(s2 * 3 + q) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs2[j] = a.bias2[16 * wave + 4 * (lane >> 4) + j];
+    }
+    const float floor_y2 = a.relu2 ? 0.f : -__builtin_inff();
+    auto conv1x1 = [&](int ybuf, const Pend2& pd) __attribute__((always_inline)) {
+        const unsigned char* yp = smem_rs + 2 * RED_BYTES + ybuf * Y_BYTES + (lane & 15) * Y_PITCH + (lane >> 4) * 16;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 xh = *reinterpret_cast<const f16x8*>(yp + nb * 16 * Y_PITCH + s2 * 64);
+                f16x8 xl = *reinterpret_cast<const f16x8*>(yp + nb * 16 * Y_PITCH + s2 * 64 + 128);
+                XFH_AGPR(xh); XFH_AGPR(xl);           // (as the 3x3's B operands: registers no vector-ALU result is allocated to)
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][2], xh, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][1], xl, d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][0], xh, d, 0, 0, 0);
+            }
+            float z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = fmaxf(d[j] * FX_SCALE_INV + bs2[j], floor_y2);
+            if constexpr (FUSE == 2) {
+                typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+                const u32x4s q = {__float_as_uint(z[0]), __float_as_uint(z[1]), __float_as_uint(z[2]), __float_as_uint(z[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(q, pd.rs, pd.voff[nb], 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z[j]), pd.rs, pd.voff[nb], j * HW * 4, 0);
+            }
+        }
+    };    // ---- taps T0 .. T1 - 1 of a block: the operands of tap t + 1 are read while tap t is multiplied (x[t & 1] <-> x[(t + 1) & 1]); behind tap 8: tap 0 of the NEXT block
     // (32 positions on: the second block of the unit, or the first of the next unit -- its segment has been in the ring since this unit began)
     auto taps = [&](auto T0C, auto T1C, auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[2]) __attribute__((always_inline)) {
         constexpr int T0 = decltype(T0C)::value, T1 = decltype(T1C)::value, PAR = decltype(PARC)::value;
@@ -186,6 +249,9 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     pend_b.rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, 0, 0x00020000);
     pend_b.voff = (int)0x80000000;
     pend_a = pend_b;
+    Pend2 p2a, p2b, p2a_prev, p2b_prev;             // fused 1x1: where the unit's first / second block goes, and the same of the unit before (a block's 1x1 runs a unit later)
+    p2a.rs = pend_b.rs; p2a.voff[0] = p2a.voff[1] = (int)0x80000000;
+    p2b = p2a; p2a_prev = p2a; p2b_prev = p2a;
     Xf x[2];
 
     for (int run = (int)blockIdx.x; run < nruns; run += (int)gridDim.x) {
@@ -202,8 +268,9 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
 #pragma unroll
             for (int j = 0; j < 16; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, j * HW * 4, 0));
         };
-        auto seg_write = [&](int slot, const float (&v)[16]) __attribute__((always_inline)) {
-            u32x4 h[2], l[2];
+        // a segment's values -> fp16 pairs (vector ALU work, placed inside the unit's MFMAs) ... and into the ring (four ds_write_b128, placed behind the unit's LAST operand read:
+        // the segment replaces the one the unit itself started with -- the ring holds exactly one unit's window)
+        auto seg_convert = [&](const float (&v)[16], u32x4 (&h)[2], u32x4 (&l)[2]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 unsigned hh, ll;
@@ -211,33 +278,43 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
                 fx_track_h(amax, hh, true);
                 h[j >> 2][j & 3] = hh; l[j >> 2][j & 3] = ll;
             }
+        };
+        auto seg_store = [&](int slot, const u32x4 (&h)[2], const u32x4 (&l)[2]) __attribute__((always_inline)) {
             unsigned char* p = ring + (slot * SEG_PX + lane) * PIXB;
             *reinterpret_cast<u32x4*>(p) = h[0];
             *reinterpret_cast<u32x4*>(p + 16) = h[1];
             *reinterpret_cast<u32x4*>(p + 32) = l[0];
             *reinterpret_cast<u32x4*>(p + 48) = l[1];
         };
+        __amdgpu_buffer_rsrc_t rs_out2 = rs_out;    // fused 1x1, channels-last: the image's (H W, 64) block
+        if constexpr (FUSE == 2) rs_out2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
+        auto out2_voff = [&](int p) {              // fused 1x1: lane (position l & 15 of a 16-position half, couts 16 wave + 4 (l >> 4) + j)
+            const int oy = row_of(p), ox = p - oy * P;
+            if (!(oy < H && ox < W)) return (int)0x80000000;
+            return FUSE == 2 ? ((oy * W + ox) * 64 + 16 * wave + 4 * (lane >> 4)) * 4 : ((4 * (lane >> 4)) * HW + oy * W + ox) * 4;
+        };
         auto out_voff = [&](int p) {               // output position p of the padded raster -> this lane's store offset (its first cout), or "dropped"
             const int oy = row_of(p), ox = p - oy * P;
             return oy < H && ox < W ? ((4 * kg) * HW + oy * W + ox) * 4 : (int)0x80000000;
         };
-        // prologue: the window of the run's first unit (segments ua .. ua + nseg - 2) with every pipe idle; the segment the first unit will write travels
-        int wslot = 0;
+        // prologue: the window of the run's first unit (segments ua .. ua + nseg - 1: the whole ring) with every pipe idle; the segment the first unit will write travels
         float v[16];
-        for (int q = 0; q < a.nseg - 1; ++q) {
+        u32x4 sh[2], sl[2];
+        for (int q = 0; q < a.nseg; ++q) {
             seg_load(ua + q, true, v);
-            seg_write(wslot, v);
-            ++wslot;
+            seg_convert(v, sh, sl);
+            seg_store(q, sh, sl);
         }
         XFH_WAVE_SYNC();
-        seg_load(ua + a.nseg - 1, ua + 1 < ub, v);
+        seg_load(ua + a.nseg, ua + 1 < ub, v);
         int rslot = 0;                             // slot of segment u
         ldb(0u, x[0]);
         for (int u = ua; u < ub; ++u) {
             const unsigned t0b = (unsigned)(rslot * SEG_BYTES);
             float4 part[3][2];
             // ---- first block (accumulators a); inside it: the reduction of the block before (accumulators b: the previous unit's, or run's, second block)
-            pend_a.rs = rs_out; pend_a.voff = out_voff(64 * u + n);
+            if constexpr (FUSE == 0) { pend_a.rs = rs_out; pend_a.voff = out_voff(64 * u + n); }
+            else { p2a_prev = p2a; p2a.rs = rs_out2; p2a.voff[0] = out2_voff(64 * u + (lane & 15)); p2a.voff[1] = out2_voff(64 * u + 16 + (lane & 15)); }
             taps(I0{}, I3{}, I0{}, t0b, ca0, ca1, x);
             XFH_SCHED_FENCE();
             red_write(cb0, cb1);
@@ -248,29 +325,33 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             ++kb;
             XFH_SCHED_FENCE();
             taps(I5{}, I9{}, I0{}, t0b, ca0, ca1, x);
-            red_finish(cb0, cb1, part, pend_b);
+            red_finish(cb0, cb1, part, pend_b, 1);
+            if constexpr (FUSE != 0) conv1x1(0, p2a_prev);      // the first block of the unit before: its 3x3 outputs were published by this block's barrier
 #pragma unroll
             for (int i = 0; i < 16; ++i) { cb0[i] = 0.f; cb1[i] = 0.f; }
             XFH_SCHED_FENCE();
             // ---- second block (accumulators b); inside it: the segment the next unit needs goes into the ring, the first block is reduced, the segment after that is requested
-            pend_b.rs = rs_out; pend_b.voff = out_voff(64 * u + 32 + n);
+            if constexpr (FUSE == 0) { pend_b.rs = rs_out; pend_b.voff = out_voff(64 * u + 32 + n); }
+            else { p2b_prev = p2b; p2b.rs = rs_out2; p2b.voff[0] = out2_voff(64 * u + 32 + (lane & 15)); p2b.voff[1] = out2_voff(64 * u + 48 + (lane & 15)); }
             taps(I0{}, I3{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
-            seg_write(wslot, v);                    // (the last unit of a run writes zeros into a free slot)
+            seg_convert(v, sh, sl);
             XFH_SCHED_FENCE();
             red_write(ca0, ca1);
             taps(I3{}, I5{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
             XFH_SCHED_FENCE();
-            XFH_LDS_BARRIER();                      // (also orders the ring: the segment written above is read from the next unit on)
+            XFH_LDS_BARRIER();
             red_read(part);
             ++kb;
             XFH_SCHED_FENCE();
             taps(I5{}, I9{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
-            red_finish(ca0, ca1, part, pend_a);
-            seg_load(u + a.nseg, u + 2 < ub, v);
+            red_finish(ca0, ca1, part, pend_a, 0);
+            if constexpr (FUSE != 0) conv1x1(1, p2b_prev);
+            seg_load(u + 1 + a.nseg, u + 2 < ub, v);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ca0[i] = 0.f; ca1[i] = 0.f; }
             XFH_SCHED_FENCE();
-            wslot = wslot + 1 == a.nseg ? 0 : wslot + 1;
+            seg_store(rslot, sh, sl);               // segment u + nseg over segment u (the last unit of a run writes zeros); every operand read of this unit has been issued
+            XFH_WAVE_SYNC();
             rslot = rslot + 1 == a.nseg ? 0 : rslot + 1;
         }
     }
@@ -280,17 +361,23 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         red_write(cb0, cb1);
         XFH_LDS_BARRIER();
         red_read(part);
-        red_finish(cb0, cb1, part, pend_b);
+        red_finish(cb0, cb1, part, pend_b, 1);
+        if constexpr (FUSE != 0) {
+            XFH_LDS_BARRIER();
+            conv1x1(0, p2a);
+            conv1x1(1, p2b);
+        }
     }
     fx_report_h(amax, a.status);
 }
 
+template <int FUSE>      // 0: the 3x3 alone; 1: + trailing 1x1 (64 -> 64), NCHW output; 2: the same with channels-last output
 __device__ __forceinline__ void conv_rs64_body(const Rs64Args& a) {
     switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {
-        case 0: conv_rs64_wave<0>(a); break;
-        case 1: conv_rs64_wave<1>(a); break;
-        case 2: conv_rs64_wave<2>(a); break;
-        default: conv_rs64_wave<3>(a); break;
+        case 0: conv_rs64_wave<0, FUSE>(a); break;
+        case 1: conv_rs64_wave<1, FUSE>(a); break;
+        case 2: conv_rs64_wave<2, FUSE>(a); break;
+        default: conv_rs64_wave<3, FUSE>(a); break;
     }
 }
 

@@ -123,6 +123,19 @@ inline size_t pack_rs64(const float* w, uint16_t* dst) {
                     }
     return kRs64Halfs;
 }
+// the 1x1 (64 -> 64) fused behind the 3x3 in conv_rs64_kernel: A operands of v_mfma_f32_16x16x32_f16, [wave = couts 16 wave .. + 15][K step 2][fragment 3][lane = (K group l >> 4, cout l & 15)][8],
+// channel = 32 step + 8 (l >> 4) + i (the natural order: the kernel lays the 3x3's outputs out that way).  w: (64, 64) fp32.
+inline size_t pack_rs64_1x1(const float* w, uint16_t* dst) {
+    for (int wv = 0; wv < 4; ++wv)
+        for (int s = 0; s < 2; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int i = 0; i < 8; ++i) {
+                    uint16_t q[3];
+                    split_weight(w[(size_t)(16 * wv + (lane & 15)) * 64 + 32 * s + 8 * (lane >> 4) + i], 1, q);
+                    for (int sp = 0; sp < 3; ++sp) dst[((((size_t)wv * 2 + s) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
+                }
+    return (size_t)4 * 2 * 3 * 64 * 8;
+}
 // the 1x1 (64 -> 64) fused behind a 64 -> 64 3x3 in conv_bx64_kernel: K order of the 3x3's D registers (as a chained head layer): [K step 4][cout block 2][split 3][lane][8]
 inline size_t pack_bx1x1(const float* w /* (64, 64) */, int mode, uint16_t* dst) { return pack_head_layer(w, 64, false, mode, dst); }
 

@@ -205,6 +205,8 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{reinterpret_cast<unsigned char*>(p), (unsigned)(bytes)}
 #define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) emu::buffer_load_b128(rs, (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, aux) emu::buffer_load_b32(rs, (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_store_b128(val, rs, voff, soff, aux)                                                              \
+    do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 16 <= (rs).bytes) { const auto v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 16); } } while (0)
 #define __builtin_amdgcn_raw_buffer_store_b64(val, rs, voff, soff, aux)                                                               \
     do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 8 <= (rs).bytes) { const auto v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 8); } } while (0)
 #define __builtin_amdgcn_raw_buffer_store_b32(val, rs, voff, soff, aux)                                                               \

@@ -22,16 +22,19 @@ def emu_bin():
     return out
 
 
-def run(emu_bin, x, w, b, relu, grid, k):
+def run(emu_bin, x, w, b, relu, grid, k, fuse=0, w2=None, b2=None, relu2=0):
     B, _, H, W = x.shape
-    blob = np.concatenate([np.array([B, H, W, relu, grid, k], np.int32).view(np.float32)] + [t.numpy().astype(np.float32).reshape(-1) for t in (x, w, b)])
+    arrs = [x, w, b] + ([w2, b2] if fuse else [])
+    blob = np.concatenate([np.array([B, H, W, relu, grid, k, fuse, relu2], np.int32).view(np.float32)] + [t.numpy().astype(np.float32).reshape(-1) for t in arrs])
     out = subprocess.run([emu_bin], input=blob.tobytes(), capture_output=True, check=True, timeout=240).stdout
-    return np.frombuffer(out[:-4], np.float32).reshape(B, 64, H, W), int(np.frombuffer(out[-4:], np.int32)[0])
+    y = np.frombuffer(out[:-4], np.float32)
+    y = y.reshape(B, H, W, 64).transpose(0, 3, 1, 2) if fuse == 2 else y.reshape(B, 64, H, W)
+    return y, int(np.frombuffer(out[-4:], np.int32)[0])
 
 
-# (30 x 40: the 1/16-scale VGA map, nseg 4, runs of 5 units; 15 x 80: the 1/8-scale pitch, nseg 5; 7 x 33: a map smaller than a ring; 9 x 93: the widest map that fits;
-#  k = 1: whole images per run, two runs for one workgroup; k = nu: one unit per run)
-@pytest.mark.parametrize("shape,relu,grid,k", [((1, 30, 40), 1, 4, 0), ((2, 15, 80), 0, 3, 2), ((3, 7, 33), 1, 2, 1), ((1, 9, 93), 1, 2, 0), ((1, 12, 20), 1, 64, 0), ((1, 1, 1), 0, 1, 0)])
+# (30 x 40: the 1/16-scale VGA map, nseg 4, runs of 5 units; 15 x 80: the 1/8-scale pitch, nseg 5; 7 x 33: a map smaller than a ring; 9 x 93: nseg 4 at its widest;
+#  6 x 125: the widest map that fits (nseg 5);  k = 1: whole images per run, two runs for one workgroup; k = nu: one unit per run)
+@pytest.mark.parametrize("shape,relu,grid,k", [((1, 30, 40), 1, 4, 0), ((2, 15, 80), 0, 3, 2), ((3, 7, 33), 1, 2, 1), ((1, 9, 93), 1, 2, 0), ((1, 6, 125), 0, 2, 0), ((1, 12, 20), 1, 64, 0), ((1, 1, 1), 0, 1, 0)])
 def test_conv_rs64_body_on_the_host(emu_bin, shape, relu, grid, k):
     B, H, W = shape
     g = torch.Generator().manual_seed(H * W)
@@ -55,3 +58,25 @@ def test_conv_rs64_reports_its_range(emu_bin):
     w = torch.randn(64, 64, 3, 3, generator=g) / 24
     _, status = run(emu_bin, x, w, torch.zeros(64), 1, 2, 0)
     assert status == 1
+
+
+# the trailing 1x1 (block3.2 behind block3.1: NCHW; block_fusion.2 behind block_fusion.1: channels-last) fused: a block's 3x3 outputs go through LDS as fp16 pairs, its 1x1 runs
+# inside the MFMAs of the block after next
+@pytest.mark.parametrize("fuse,shape,relu2,grid,k", [(1, (1, 30, 40), 0, 4, 0), (2, (2, 15, 80), 0, 3, 2), (2, (3, 7, 33), 1, 2, 1), (1, (1, 9, 93), 0, 2, 0), (2, (1, 1, 1), 0, 1, 0), (1, (1, 5, 7), 1, 8, 0)])
+def test_conv_rs64_with_the_trailing_1x1_fused(emu_bin, fuse, shape, relu2, grid, k):
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W + fuse)
+    x = torch.randn(B, 64, H, W, generator=g) * 2
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b = torch.randn(64, generator=g) * 0.3
+    w2 = torch.randn(64, 64, generator=g) / 8
+    b2 = torch.randn(64, generator=g) * 0.3
+    y, status = run(emu_bin, x, w, b, 1, grid, k, fuse, w2, b2, relu2)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    ref = torch.nn.functional.conv2d(ref, w2.double().view(64, 64, 1, 1), b2.double())
+    if relu2:
+        ref = torch.relu(ref)
+    d = np.abs(y - ref.numpy())
+    print(f"fuse {fuse} {shape} relu2 {relu2} grid {grid} k {k}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert status == 0 and np.isfinite(y).all()
+    assert d.max() <= 3e-6 * float(ref.abs().max())

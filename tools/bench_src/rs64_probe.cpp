@@ -1,7 +1,7 @@
 // Stand-alone probe of conv_rs64_kernel (conv_rs64_body.hpp: 64 -> 64 3x3 in the fp16-pair arithmetic with the weights resident in registers) through the C ABI -- no Python,
 // no torch: a gpurun call with a prebuilt binary costs ~15 s of GPU budget.  For block4.1 (VGA 1/16 scale: 30 x 40), block_fusion.0 (1/8: 60 x 80) and a ragged map, batch 64:
 //   xfh_conv_layer variant 1 (generic direct kernel: the reference), 11 (conv_bx64_kernel, fp16 pair), 12 (conv_rs64_kernel): max |diff| against variant 1, HIP-event time per
-//   launch; then `repeats` cold-started launches (xfh_debug_cold_start) of variant 12 compared bit for bit with its first result; then the backbone with fx = 3 / 131.
+//   launch; then `repeats` cold-started launches (xfh_debug_cold_start) of variant 12 compared bit for bit with its first result; then the backbone with fx = 3 / 131 / 387 (387: all five 64 -> 64 launches on conv_rs64_kernel).
 //     hipcc -O2 -w tools/bench_src/rs64_probe.cpp -o gpurun_probe/rs64_probe -ldl ; gpurun_probe/rs64_probe <libxfeat_hip.so> <weights.bin> [repeats = 200]
 //     (weights.bin: int32 count, then per array int32 n + n floats -- the arrays of XFeatModel.weight_arrays(); tools/ab_configs.py --dump-weights writes it)
 #include <hip/hip_runtime.h>
@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
         HIPCHK(hipMalloc(&feats, ncell * 64 * 4)); HIPCHK(hipMalloc(&heat, npx * 4)); HIPCHK(hipMalloc(&rel, ncell * 4)); HIPCHK(hipMalloc(&ws, wsb + 256));
         void* wsa = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t(255));
         std::vector<float> ref(ncell * 64), got(ncell * 64);
-        for (int fx : {3, 131, 135, 3}) {
+        for (int fx : {3, 131, 387, 391, 3}) {      // 131: the unfused 64 -> 64 layers on conv_rs64_kernel; 387: the 3x3 + 1x1 pairs too; 391: + two-fragment conv_bx64 for whatever stays there
             if (xfh_set_option(h, "fx", fx)) { printf("fx = %d: %s\n", fx, xfh_last_error()); continue; }
             if (xfh_backbone(h, img, B, 3, Hh, W, feats, nullptr, heat, rel, nullptr, wsa, wsb, nullptr)) { printf("backbone fx %d: %s\n", fx, xfh_last_error()); continue; }
             HIPCHK(hipMemcpy(got.data(), feats, ncell * 64 * 4, hipMemcpyDeviceToHost));
