@@ -385,6 +385,15 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
             pack_rs64_1x1(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
             coff[li].has_rs = true;
         }
+        if (c.ks == 3 && c.stride == 1 && c.cin == 128 && c.cout == 128) {      // block5.1, block5.2: conv_rs64_kernel's 128-channel form (fp16 pair only)
+            float wmax = 0.f;
+            for (size_t i = 0; i < (size_t)128 * 128 * 9; ++i) wmax = std::max(wmax, std::fabs(blob[coff[li].oihw + i]));
+            if (wmax < kFxMaxWeight) {
+                coff[li].rs = reserve(4 * kRs64Halfs / 2);
+                pack_rs128(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
+                coff[li].has_rs = true;
+            }
+        }
         coff[li].has_fq = bx64 && coff[li].fx_ok;
         if (coff[li].has_fq) {      // two fragments per weight (q0, q2): conv_bx64_body.hpp FXM 2
             coff[li].fq = reserve((size_t)(c.cin / 16) * 9 * 2 * 2 * 64 * 4);
@@ -573,7 +582,8 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
     // fx bit 128 (with bit 1): the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on conv_rs64_kernel -- weights resident in registers; -1 (map too wide for its rings): the paths below
-    if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status);
+    if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc && c.cin == 64) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status);
+    if (rc && use_bx && (h->opt.fx & 513) == 513 && c.w_rs && !c2 && !nhwc && c.cin == 128) rc = launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status);      // bit 512: block5.1, block5.2
     if (rc && use_bx && (h->opt.fx & 257) == 257 && c.w_rs && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc);      // bit 256: block3.1 + 3.2, block_fusion.1 + .2
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, (h->opt.fx & 2) != 0, h->status);      // (bx = 9: block3.0 stays on the f32 kernel)
@@ -629,6 +639,10 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     CONV(L_BLOCK4_2, -1, w.x4b, H16, W16, w.x4c, false);
     CONV(L_BLOCK5_0, -1, w.x4c, H16, W16, w.x5a, false);
     CONV(L_BLOCK5_1, -1, w.x5a, H32, W32, w.x5b, false);
+    if ((h->opt.fx & 513) == 513 && h->opt.bx && nw.conv[L_BLOCK5_2].w_rs && conv_rs128_fits(W32)) {
+        CONV(L_BLOCK5_2, -1, w.x5b, H32, W32, w.x5a, false);          // conv_rs64_kernel's 128-channel form holds a quarter of the couts per workgroup: the 1x1 (128 -> 64) runs on its own (x5a is free since block5.1)
+        CONV(L_BLOCK5_3, -1, w.x5a, H32, W32, w.x5d, false);
+    } else
     CONV(L_BLOCK5_2, L_BLOCK5_3, w.x5b, H32, W32, w.x5d, false);      // 3x3 + fused 1x1 (128->64)
     prof_begin(&h->prof, XFH_SPAN_PYRAMID, st);
     launch_pyramid_sum(w.x3c, w.x4c, w.x5d, w.pyr, B * 64, H8, W8, H16, W16, H32, W32, st);
@@ -690,7 +704,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
         return check_launch("xfh_conv_layer(fp16 pair)");
     }
     if (variant == 12) {      // 64 -> 64 3x3/s1: the fp16-pair kernel with the weights resident in registers
-        if (launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: conv_rs64_kernel does not take layer %d at width %d", layer, Win);
+        if (c.cin == 128 ? launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status) : launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: conv_rs64_kernel does not take layer %d at width %d", layer, Win);
         return check_launch("xfh_conv_layer(fp16 pair, resident weights)");
     }
     if (variant >= 2) {
@@ -933,7 +947,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 511}};
+        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 1023}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

@@ -56,8 +56,11 @@ struct Rs64Args {
 };
 
 namespace rs64 {
-constexpr int PIXB = 80;                                      // staged position: 16 channels x (high, low) fp16 + 16: an odd multiple of 16 B (distinct banks for the 16 lanes of a ds_read_b128 group)
+// staged position: a wave's channels (16; 32 for the 128-channel layers) x (high, low) fp16 + 16: an odd multiple of 16 B (distinct banks for the 16 lanes of a ds_read_b128 group)
+template <int CIN> constexpr int pixb() { return CIN == 128 ? 144 : 80; }
+constexpr int PIXB = 80;
 constexpr int SEG_PX = 64, SEG_BYTES = SEG_PX * PIXB;         // 5120
+template <int CIN> constexpr int seg_bytes() { return SEG_PX * pixb<CIN>(); }                                  // 5120 | 9216
 constexpr int RED_BYTES = 4 * 3 * 2048;                       // [owner 4][source slot 3][part 2][64 lanes] float4
 constexpr int Y_PITCH = 272, Y_BYTES = 32 * Y_PITCH;           // fused 1x1: a block's 3x3 outputs as fp16 pairs, [position 32][high parts of the 64 channels | low parts] + 16 (bank spread)
 template <int FUSE> constexpr int ring_off() { return 2 * RED_BYTES + (FUSE ? 2 * Y_BYTES : 0); }      // 49152 | 66560
@@ -66,6 +69,11 @@ constexpr int WQ_HALFS = 4 * 9 * 2 * 3 * 64 * 8;              // 110592 fp16 = 2
 inline int nseg_for(int P) { return 2 + (2 * P + 1) / 64; }
 inline int lds_bytes(int nseg, bool fuse = false) { return (fuse ? ring_off<1>() : ring_off<0>()) + 4 * nseg * SEG_BYTES; }
 inline int max_nseg(bool fuse) { return fuse ? 4 : 5; }
+// CIN = COUT = 128 (block5.1, block5.2): a workgroup computes a QUARTER of the couts (32) and a wave multiplies 32 input channels (two 16-channel chunks, one accumulator each)
+constexpr int RED128_BYTES = 4 * 3 * 1024;                    // [owner 4][source slot 3][64 lanes] float4: wave w owns couts 8 w .. + 7 of the quarter (4 registers per lane)
+inline int lds_bytes128(int nseg) { return 2 * RED128_BYTES + 4 * nseg * seg_bytes<128>(); }
+constexpr int MAX_NSEG128 = 3;
+static_assert(2 * RED128_BYTES + 4 * MAX_NSEG128 * seg_bytes<128>() <= 160 * 1024, "LDS of a CU");
 // runs per image for `grid` workgroups: whole images while there are enough of them, else every image in grid / B parts (at least one unit each)
 inline int runs_per_image(int B, int nu, int grid) { const int k = B >= grid ? 1 : grid / B; return k < 1 ? 1 : k > nu ? nu : k; }
 static_assert(ring_off<0>() + 4 * 5 * SEG_BYTES <= 160 * 1024 && ring_off<1>() + 4 * 4 * SEG_BYTES <= 160 * 1024, "LDS of a CU");
@@ -73,19 +81,25 @@ static_assert(ring_off<0>() + 4 * 5 * SEG_BYTES <= 160 * 1024 && ring_off<1>() +
 
 // the code of ONE wave of the workgroup (wave = its K quarter and the couts it finishes): four copies, so that which accumulator registers are a wave's own and which go to
 // whom is static (selected at run time it costs a v_cndmask per register and use, or a branch tree in the middle of the MFMA stream)
-template <int wave, int FUSE>
+template <int wave, int FUSE, int CIN = 64>
 __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     using namespace rs64;
-    constexpr int RING_OFF = ring_off<FUSE>();
+    constexpr bool C128 = CIN == 128;            // 128 -> 128: the workgroup's cout quarter a.cq-th of four is part of the run index; this wave multiplies channels 32 wave .. + 31
+    static_assert(!C128 || FUSE == 0, "the 128-channel form has no fused 1x1 (a workgroup holds a quarter of the 3x3's outputs)");
+    constexpr int PIXB = pixb<CIN>(), SEG_BYTES = seg_bytes<CIN>(), RED_BYTES = C128 ? RED128_BYTES : rs64::RED_BYTES;
+    constexpr int LO_OFF = C128 ? 64 : 32;       // low parts behind the high parts of the wave's channels
+    constexpr int RING_OFF = C128 ? 2 * RED128_BYTES : ring_off<FUSE>();
     XFH_DYN_LDS_BYTES(smem_rs);
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kg = lane >> 5;
     const int P = a.P, H = a.H, W = a.W, HW = H * W;
     const float inv_p = a.inv_p;
 
     // ---- this wave's weights: channels 16 wave .. + 15 under every tap, all 64 couts, three fragments (q0, q1, q2 of split_weight mode 1)
+    // (128 channels: the middle index is the 16-channel CHUNK of the wave's 32 channels instead of the cout block; the quarter's weights are selected per run -- every run of a
+    // workgroup has the same quarter: the launcher makes the grid a multiple of four)
     f16x8 A[9][2][3];
     {
-        const f16x8* wp = reinterpret_cast<const f16x8*>(a.wq) + (size_t)wave * (9 * 2 * 3 * 64) + lane;
+        const f16x8* wp = reinterpret_cast<const f16x8*>(a.wq) + ((size_t)(C128 ? (int)(blockIdx.x & 3) * 4 : 0) + wave) * (9 * 2 * 3 * 64) + lane;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -99,7 +113,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     // ---- the couts this wave finishes: 16 wave + 8 (k >> 2) + 4 kg + (k & 3), k = 0 .. 7 = registers 8 (wave & 1) + k of accumulator wave >> 1
     float bs[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bs[k] = a.bias[16 * wave + 8 * (k >> 2) + 4 * kg + (k & 3)];
+    for (int k = 0; k < 8; ++k) bs[k] = C128 ? a.bias[32 * (int)(blockIdx.x & 3) + 8 * wave + 4 * kg + (k & 3)] : a.bias[16 * wave + 8 * (k >> 2) + 4 * kg + (k & 3)];
     const float floor_y = a.relu ? 0.f : -__builtin_inff();
 
     unsigned char* ring = smem_rs + RING_OFF + wave * a.nseg * SEG_BYTES;
@@ -112,13 +126,18 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     // position i of a padded raster = (row, column): i < 2^20, P >= 3: (i + 0.5) / P is at least 1 / (2 P) away from an integer, the product's error is below 1e-4
     auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_p); };
     // the B operands of a tap: positions t0 + shift + n of the ring, high parts and low parts of this lane's 8 channels
-    struct Xf { f16x8 h, l; };
+    struct Xf { f16x8 h, l, h1, l1; };            // (h1, l1: the second channel chunk of the 128-channel form)
     auto ldb = [&](unsigned tb /* byte offset of the block's first position under this tap, < 2 Rb */, Xf& x) __attribute__((always_inline)) {
         tb = tb >= Rb ? tb - Rb : tb;                                                 // (wave-uniform)
         unsigned ab = tb + lane_b;
         ab = min(ab, ab - Rb);                                                        // positions beyond the ring's end continue at its start
         x.h = *reinterpret_cast<const f16x8*>(ring + ab);
-        x.l = *reinterpret_cast<const f16x8*>(ring + ab + 32);
+        x.l = *reinterpret_cast<const f16x8*>(ring + ab + LO_OFF);
+        if constexpr (C128) {
+            x.h1 = *reinterpret_cast<const f16x8*>(ring + ab + 32);
+            x.l1 = *reinterpret_cast<const f16x8*>(ring + ab + LO_OFF + 32);
+            XFH_AGPR(x.h1); XFH_AGPR(x.l1);
+        }
         // the B operands live in accumulation registers too (ds_read writes them there directly): registers no vector-ALU result is ever allocated to, so none can land in
         // an operand the matrix core is still reading (tools/check_mfma_war.py) -- without idle slots or keep-alive fences in the MFMA stream
         XFH_AGPR(x.h); XFH_AGPR(x.l);
@@ -135,6 +154,15 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     // (buffer kb & 1); red_read: the three partials for this wave's couts; red_finish: sum, bias, ReLU, stores
     auto red_write = [&](const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
         unsigned char* red = smem_rs + (kb & 1) * RED_BYTES;
+        if constexpr (C128) {      // one cout block, two chunk accumulators: registers 4 o .. + 3 of their sum belong to wave o
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o == wave) continue;
+                float4* d = reinterpret_cast<float4*>(red + o * (3 * 1024) + (wave < o ? wave : wave - 1) * 1024) + lane;
+                d[0] = make_float4(c0[4 * o] + c1[4 * o], c0[4 * o + 1] + c1[4 * o + 1], c0[4 * o + 2] + c1[4 * o + 2], c0[4 * o + 3] + c1[4 * o + 3]);
+            }
+            return;
+        }
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             if (o == wave) continue;
@@ -148,11 +176,23 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         const unsigned char* red = smem_rs + (kb & 1) * RED_BYTES;
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
+            if constexpr (C128) { part[s][0] = reinterpret_cast<const float4*>(red + wave * (3 * 1024) + s * 1024)[lane]; continue; }
             const float4* d = reinterpret_cast<const float4*>(red + wave * (3 * 2048) + s * 2048) + lane;
             part[s][0] = d[0]; part[s][1] = d[64];
         }
     };
     auto red_finish = [&](const f32x16& c0, const f32x16& c1, const float4 (&part)[3][2], const Pend& pd, int ybuf) __attribute__((always_inline)) {
+        if constexpr (C128) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float p3[3] = {k == 0 ? part[0][0].x : k == 1 ? part[0][0].y : k == 2 ? part[0][0].z : part[0][0].w, k == 0 ? part[1][0].x : k == 1 ? part[1][0].y : k == 2 ? part[1][0].z : part[1][0].w,
+                                     k == 0 ? part[2][0].x : k == 1 ? part[2][0].y : k == 2 ? part[2][0].z : part[2][0].w};
+                const float sum = (((c0[4 * wave + k] + c1[4 * wave + k]) + p3[0]) + p3[1]) + p3[2];
+                const float y = fmaxf(sum * FX_SCALE_INV + bs[k], floor_y);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), pd.rs, pd.voff, k * HW * 4, 0);
+            }
+            return;
+        }
         float own[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) own[k] = ((wave >> 1) ? c1 : c0)[8 * (wave & 1) + k];
@@ -199,21 +239,29 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     const float floor_y2 = a.relu2 ? 0.f : -__builtin_inff();
     auto conv1x1 = [&](int ybuf, const Pend2& pd) __attribute__((always_inline)) {
         const unsigned char* yp = smem_rs + 2 * RED_BYTES + ybuf * Y_BYTES + (lane & 15) * Y_PITCH + (lane >> 4) * 16;
+        // the two 16-position halves take turns (two accumulators): a dependent MFMA waits for its predecessor
+        f32x4 d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f16x8 xh[2], xl[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                xh[nb] = *reinterpret_cast<const f16x8*>(yp + nb * 16 * Y_PITCH + s2 * 64);
+                xl[nb] = *reinterpret_cast<const f16x8*>(yp + nb * 16 * Y_PITCH + s2 * 64 + 128);
+                XFH_AGPR(xh[nb]); XFH_AGPR(xl[nb]);           // (as the 3x3's B operands: registers no vector-ALU result is allocated to)
+            }
+            d[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][2], xh[0], d[0], 0, 0, 0);
+            d[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][2], xh[1], d[1], 0, 0, 0);
+            d[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][1], xl[0], d[0], 0, 0, 0);
+            d[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][1], xl[1], d[1], 0, 0, 0);
+            d[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][0], xh[0], d[0], 0, 0, 0);
+            d[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][0], xh[1], d[1], 0, 0, 0);
+        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
-            f32x4 d = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                f16x8 xh = *reinterpret_cast<const f16x8*>(yp + nb * 16 * Y_PITCH + s2 * 64);
-                f16x8 xl = *reinterpret_cast<const f16x8*>(yp + nb * 16 * Y_PITCH + s2 * 64 + 128);
-                XFH_AGPR(xh); XFH_AGPR(xl);           // (as the 3x3's B operands: registers no vector-ALU result is allocated to)
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][2], xh, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][1], xl, d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][0], xh, d, 0, 0, 0);
-            }
             float z[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) z[j] = fmaxf(d[j] * FX_SCALE_INV + bs2[j], floor_y2);
+            for (int j = 0; j < 4; ++j) z[j] = fmaxf(d[nb][j] * FX_SCALE_INV + bs2[j], floor_y2);
             if constexpr (FUSE == 2) {
                 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
                 const u32x4s q = {__float_as_uint(z[0]), __float_as_uint(z[1]), __float_as_uint(z[2]), __float_as_uint(z[3])};
@@ -232,11 +280,11 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             const int cur = (t + PAR) & 1;
             ldb(t < 8 ? t0b + shift_b[t < 8 ? t + 1 : 0] : t0b + 32 * PIXB, x[cur ^ 1]);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][2], x[cur].h, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][2], x[cur].h, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][2], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][1], x[cur].l, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][1], x[cur].l, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][1], C128 ? x[cur].l1 : x[cur].l, c1, 0, 0, 0);
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][0], x[cur].h, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][0], x[cur].h, c1, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][0], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
         }
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I3 = std::integral_constant<int, 3>;
@@ -254,37 +302,41 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     p2b = p2a; p2a_prev = p2a; p2b_prev = p2a;
     Xf x[2];
 
-    for (int run = (int)blockIdx.x; run < nruns; run += (int)gridDim.x) {
+    constexpr int NV = C128 ? 32 : 16, NQ = NV / 8;      // values a lane stages per segment (its position's channels), 16-byte groups of their high / low parts
+    const int cq = C128 ? (int)(blockIdx.x & 3) : 0;      // 128 channels: this workgroup's cout quarter (the grid is a multiple of four; the runs go to the groups of four)
+    for (int run = C128 ? (int)(blockIdx.x >> 2) : (int)blockIdx.x; run < nruns; run += C128 ? (int)(gridDim.x >> 2) : (int)gridDim.x) {
         const int b = run / a.k, part_i = run - b * a.k;
         const int ua = (int)((long long)a.nu * part_i / a.k), ub = (int)((long long)a.nu * (part_i + 1) / a.k);
         if (ua >= ub) continue;
-        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + ((size_t)b * 64 + 16 * wave) * HW), 0, (int)(16 * HW * sizeof(float)), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + ((size_t)b * 64 + 16 * wave) * HW), 0, (int)(16 * HW * sizeof(float)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + ((size_t)b * CIN + NV * wave) * HW), 0, (int)(NV * HW * sizeof(float)), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = C128 ? __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + ((size_t)b * 128 + 32 * cq + 8 * wave) * HW), 0, (int)(8 * HW * sizeof(float)), 0x00020000)
+                                                   : __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + ((size_t)b * 64 + 16 * wave) * HW), 0, (int)(16 * HW * sizeof(float)), 0x00020000);
         // segment s of the image's padded raster: position 64 s + lane = (row r, column c) of the (H + 2) x P frame = pixel (r - 1, c - 1); outside the map: zeros
-        auto seg_load = [&](int s, bool en, float (&v)[16]) __attribute__((always_inline)) {
+        auto seg_load = [&](int s, bool en, float (&v)[NV]) __attribute__((always_inline)) {
             const int i = 64 * s + lane, r = row_of(i), c = i - r * P;
             const int iy = r - 1, ix = c - 1;
             const int voff = en && iy >= 0 && iy < H && ix >= 0 && ix < W ? (iy * W + ix) * 4 : (int)0x80000000;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, j * HW * 4, 0));
+            for (int j = 0; j < NV; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, j * HW * 4, 0));
         };
         // a segment's values -> fp16 pairs (vector ALU work, placed inside the unit's MFMAs) ... and into the ring (four ds_write_b128, placed behind the unit's LAST operand read:
         // the segment replaces the one the unit itself started with -- the ring holds exactly one unit's window)
-        auto seg_convert = [&](const float (&v)[16], u32x4 (&h)[2], u32x4 (&l)[2]) __attribute__((always_inline)) {
+        auto seg_convert = [&](const float (&v)[NV], u32x4 (&h)[NQ], u32x4 (&l)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NV / 2; ++j) {
                 unsigned hh, ll;
                 split2_f16(v[2 * j], v[2 * j + 1], hh, ll);
                 fx_track_h(amax, hh, true);
                 h[j >> 2][j & 3] = hh; l[j >> 2][j & 3] = ll;
             }
         };
-        auto seg_store = [&](int slot, const u32x4 (&h)[2], const u32x4 (&l)[2]) __attribute__((always_inline)) {
+        auto seg_store = [&](int slot, const u32x4 (&h)[NQ], const u32x4 (&l)[NQ]) __attribute__((always_inline)) {
             unsigned char* p = ring + (slot * SEG_PX + lane) * PIXB;
-            *reinterpret_cast<u32x4*>(p) = h[0];
-            *reinterpret_cast<u32x4*>(p + 16) = h[1];
-            *reinterpret_cast<u32x4*>(p + 32) = l[0];
-            *reinterpret_cast<u32x4*>(p + 48) = l[1];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                *reinterpret_cast<u32x4*>(p + 16 * i) = h[i];
+                *reinterpret_cast<u32x4*>(p + LO_OFF + 16 * i) = l[i];
+            }
         };
         __amdgpu_buffer_rsrc_t rs_out2 = rs_out;    // fused 1x1, channels-last: the image's (H W, 64) block
         if constexpr (FUSE == 2) rs_out2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
@@ -298,20 +350,23 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             return oy < H && ox < W ? ((4 * kg) * HW + oy * W + ox) * 4 : (int)0x80000000;
         };
         // prologue: the window of the run's first unit (segments ua .. ua + nseg - 1: the whole ring) with every pipe idle; the segment the first unit will write travels
-        float v[16];
-        u32x4 sh[2], sl[2];
+        float v[NV];
+        u32x4 sh[NQ], sl[NQ];
         for (int q = 0; q < a.nseg; ++q) {
             seg_load(ua + q, true, v);
             seg_convert(v, sh, sl);
             seg_store(q, sh, sl);
         }
         XFH_WAVE_SYNC();
-        seg_load(ua + a.nseg, ua + 1 < ub, v);
+        if constexpr (!C128) seg_load(ua + a.nseg, ua + 1 < ub, v);
         int rslot = 0;                             // slot of segment u
         ldb(0u, x[0]);
         for (int u = ua; u < ub; ++u) {
             const unsigned t0b = (unsigned)(rslot * SEG_BYTES);
             float4 part[3][2];
+            // (128 channels: the next segment's 32 loads are issued here, not a unit earlier -- their registers would overlap the converted segment's for a whole unit,
+            // and the maps of these layers sit in L2)
+            if constexpr (C128) seg_load(u + a.nseg, u + 1 < ub, v);
             // ---- first block (accumulators a); inside it: the reduction of the block before (accumulators b: the previous unit's, or run's, second block)
             if constexpr (FUSE == 0) { pend_a.rs = rs_out; pend_a.voff = out_voff(64 * u + n); }
             else { p2a_prev = p2a; p2a.rs = rs_out2; p2a.voff[0] = out2_voff(64 * u + (lane & 15)); p2a.voff[1] = out2_voff(64 * u + 16 + (lane & 15)); }
@@ -346,7 +401,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             taps(I5{}, I9{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
             red_finish(ca0, ca1, part, pend_a, 0);
             if constexpr (FUSE != 0) conv1x1(1, p2b_prev);
-            seg_load(u + 1 + a.nseg, u + 2 < ub, v);
+            if constexpr (!C128) seg_load(u + 1 + a.nseg, u + 2 < ub, v);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ca0[i] = 0.f; ca1[i] = 0.f; }
             XFH_SCHED_FENCE();
@@ -371,13 +426,13 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     fx_report_h(amax, a.status);
 }
 
-template <int FUSE>      // 0: the 3x3 alone; 1: + trailing 1x1 (64 -> 64), NCHW output; 2: the same with channels-last output
+template <int FUSE, int CIN = 64>      // FUSE 0: the 3x3 alone; 1: + trailing 1x1 (64 -> 64), NCHW output; 2: the same with channels-last output.  CIN 128: the 128 -> 128 layers (FUSE 0)
 __device__ __forceinline__ void conv_rs64_body(const Rs64Args& a) {
     switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {
-        case 0: conv_rs64_wave<0, FUSE>(a); break;
-        case 1: conv_rs64_wave<1, FUSE>(a); break;
-        case 2: conv_rs64_wave<2, FUSE>(a); break;
-        default: conv_rs64_wave<3, FUSE>(a); break;
+        case 0: conv_rs64_wave<0, FUSE, CIN>(a); break;
+        case 1: conv_rs64_wave<1, FUSE, CIN>(a); break;
+        case 2: conv_rs64_wave<2, FUSE, CIN>(a); break;
+        default: conv_rs64_wave<3, FUSE, CIN>(a); break;
     }
 }
 

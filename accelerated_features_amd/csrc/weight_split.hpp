@@ -123,6 +123,22 @@ inline size_t pack_rs64(const float* w, uint16_t* dst) {
                     }
     return kRs64Halfs;
 }
+// the 128 -> 128 form of conv_rs64_kernel: [cout quarter 4][wave = 32-channel group 4][tap 9][chunk 2][fragment 3][lane = half * 32 + cout][8],
+// channel = 32 wave + 16 chunk + 8 half + i, cout = 32 quarter + (lane & 31).  w: (128, 128, 3, 3) fp32.  Returns the 16-bit words written (4 x kRs64Halfs).
+inline size_t pack_rs128(const float* w, uint16_t* dst) {
+    for (int cq = 0; cq < 4; ++cq)
+        for (int wv = 0; wv < 4; ++wv)
+            for (int tap = 0; tap < 9; ++tap)
+                for (int ck = 0; ck < 2; ++ck)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i < 8; ++i) {
+                            const int o = cq * 32 + (lane & 31), ci = wv * 32 + ck * 16 + 8 * (lane >> 5) + i;
+                            uint16_t q[3];
+                            split_weight(w[((size_t)o * 128 + ci) * 9 + tap], 1, q);
+                            for (int sp = 0; sp < 3; ++sp) dst[(((((((size_t)cq * 4 + wv) * 9 + tap) * 2 + ck) * 3 + sp) * 64) + lane) * 8 + i] = q[sp];
+                        }
+    return 4 * kRs64Halfs;
+}
 // the 1x1 (64 -> 64) fused behind the 3x3 in conv_rs64_kernel: A operands of v_mfma_f32_16x16x32_f16, [wave = couts 16 wave .. + 15][K step 2][fragment 3][lane = (K group l >> 4, cout l & 15)][8],
 // channel = 32 step + 8 (l >> 4) + i (the natural order: the kernel lays the 3x3's outputs out that way).  w: (64, 64) fp32.
 inline size_t pack_rs64_1x1(const float* w, uint16_t* dst) {

@@ -15,6 +15,23 @@ int main() {
     int hdr[8];
     if (fread(hdr, 4, 8, stdin) != 8) return 2;
     const int B = hdr[0], H = hdr[1], W = hdr[2], relu = hdr[3], grid = hdr[4], fuse = hdr[6];
+    if (fuse == 128) {      // the 128 -> 128 form: in (B*128*H*W), w (128*128*9), bias (128); grid = workgroup GROUPS (x 4 cout quarters)
+        auto in = rd((size_t)B * 128 * H * W), w = rd(128 * 128 * 9), bias = rd(128);
+        std::vector<uint16_t> wq(4 * xfh::kRs64Halfs);
+        xfh::pack_rs128(w.data(), wq.data());
+        std::vector<float> out((size_t)B * 128 * H * W, NAN);
+        int status = 0;
+        xfh::Rs64Args a{};
+        a.in = in.data(); a.wq = wq.data(); a.bias = bias.data(); a.out = out.data(); a.relu = relu; a.H = H; a.W = W; a.B = B; a.status = &status;
+        a.P = W + 2; a.inv_p = 1.f / (float)a.P; a.nu = (H * a.P + 63) / 64; a.nseg = xfh::rs64::nseg_for(a.P);
+        if (a.nseg > xfh::rs64::MAX_NSEG128) { fprintf(stderr, "map too wide\n"); return 3; }
+        a.k = hdr[5] > 0 ? hdr[5] : xfh::rs64::runs_per_image(B, a.nu, grid);
+        const int nruns = B * a.k, g = 4 * (nruns < grid ? nruns : grid);
+        emu::launch(g, 256, xfh::rs64::lds_bytes128(a.nseg), [&] { xfh::conv_rs64_body<0, 128>(a); });
+        fwrite(out.data(), 4, out.size(), stdout);
+        fwrite(&status, 4, 1, stdout);
+        return 0;
+    }
     auto in = rd((size_t)B * 64 * H * W), w = rd(64 * 64 * 9), bias = rd(64);
     std::vector<uint16_t> wq(xfh::rs64::WQ_HALFS), wq2(4 * 2 * 3 * 64 * 8);
     xfh::pack_rs64(w.data(), wq.data());

@@ -80,3 +80,23 @@ def test_conv_rs64_with_the_trailing_1x1_fused(emu_bin, fuse, shape, relu2, grid
     print(f"fuse {fuse} {shape} relu2 {relu2} grid {grid} k {k}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
     assert status == 0 and np.isfinite(y).all()
     assert d.max() <= 3e-6 * float(ref.abs().max())
+
+
+# the 128 -> 128 layers (block5.1, block5.2) on the same body: a workgroup computes a quarter of the couts, a wave multiplies 32 input channels (two chunks, one accumulator each)
+@pytest.mark.parametrize("shape,relu,groups,k", [((2, 15, 20), 1, 2, 0), ((1, 7, 33), 0, 1, 2), ((3, 4, 5), 1, 2, 1), ((1, 3, 61), 1, 1, 0)])
+def test_conv_rs64_body_with_128_channels(emu_bin, shape, relu, groups, k):
+    B, H, W = shape
+    g = torch.Generator().manual_seed(H * W + 128)
+    x = torch.randn(B, 128, H, W, generator=g) * 2
+    w = torch.randn(128, 128, 3, 3, generator=g) / 34
+    b = torch.randn(128, generator=g) * 0.3
+    blob = np.concatenate([np.array([B, H, W, relu, groups, k, 128, 0], np.int32).view(np.float32)] + [t.numpy().astype(np.float32).reshape(-1) for t in (x, w, b)])
+    out = subprocess.run([emu_bin], input=blob.tobytes(), capture_output=True, check=True, timeout=400).stdout
+    y = np.frombuffer(out[:-4], np.float32).reshape(B, 128, H, W)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    d = np.abs(y - ref.numpy())
+    print(f"128 channels {shape} relu {relu} groups {groups} k {k}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0 and np.isfinite(y).all()
+    assert d.max() <= 3e-6 * float(ref.abs().max())

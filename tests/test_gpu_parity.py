@@ -127,7 +127,7 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
 
 
 @pytest.mark.parametrize("opts", [{"heads_f32": 0, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}, {"fx": 0}, {"fx": 15, "bx": 23},
-                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"heads_f32": 3}, {"block1": 6}, {"block1": 7}, {"fx": 7}, {"fx": 67}, {"fx": 131}, {"fx": 387}, {"fx": 11, "heads_f32": 0}, {"fx": 27, "heads_f32": 0}, {"fx": 43, "heads_f32": 0}])
+                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"heads_f32": 3}, {"block1": 6}, {"block1": 7}, {"fx": 7}, {"fx": 67}, {"fx": 131}, {"fx": 387}, {"fx": 899}, {"fx": 11, "heads_f32": 0}, {"fx": 27, "heads_f32": 0}, {"fx": 43, "heads_f32": 0}])
 def test_backbone_alternative_kernels_same_results(opts, sd):
     """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on the split-bf16 kernels -- opt-in since round 4 --, 24->24
     layers on Winograd; every unfused 64->64 layer on the split kernel; direct implicit GEMM instead of Winograd; block1 with a c1 tile; the split-operand
@@ -592,7 +592,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
     h = xf.net.handle()
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 0
-    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1", "block4.0", "block5.0"):       # block3.0: the 24-channel stride-2 kernel; block_fusion.0 / block4.1: conv_bx64_kernel; the last two: conv_bx64s2_kernel (64 / 128 couts)
+    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1", "block4.0", "block5.0", "block5.1"):       # (block5.1: 128 -> 128, variants 1 and 12 only: conv_rs64_kernel's 128-channel form)       # block3.0: the 24-channel stride-2 kernel; block_fusion.0 / block4.1: conv_bx64_kernel; the last two: conv_bx64s2_kernel (64 / 128 couts)
         c = next(c for c in CONVS if c.name == name)
         w = sd[f"{name}.layer.0.weight"].double().cuda()
         rm, rv = sd[f"{name}.layer.1.running_mean"].double().cuda(), sd[f"{name}.layer.1.running_var"].double().cuda()
@@ -604,6 +604,17 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
                 truth = torch.relu(torch.nn.functional.conv2d(x.double(), wf, bf, stride=c.stride, padding=1))
                 ref = float(truth.abs().max())
                 err = {}
+                if c.cin == 128:
+                    variants = (1, 12) if ww <= 61 else (1,)
+                    for variant in variants:
+                        y = torch.full(tuple(truth.shape), float("nan"), device="cuda")
+                        rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
+                        assert rc == 0, (name, variant, lib.xfh_last_error())
+                        err[variant] = float((y.double() - truth).abs().nan_to_num(1e9).max()) / ref
+                    if 12 in err:
+                        assert err[12] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
+                    n += 1
+                    continue
                 rs64 = c.stride == 1 and c.cin == 64 and ww <= 125         # 12: the fp16-pair kernel with the weights resident in registers (conv_rs64_kernel; maps up to 125 columns)
                 for variant in ((1, 10, 11, 12) if rs64 else (1, 10, 11)) if c.stride == 1 or c.cin == 24 else (1, 10):      # 11: the same kernel in the fp16-pair arithmetic (three MFMAs per product)
                     y = torch.full(tuple(truth.shape), float("nan"), device="cuda")
@@ -615,7 +626,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
                     if v in err:
                         assert err[v] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
                 n += 1
-    assert n == 7 * 8 * 3
+    assert n == 8 * 8 * 3
     assert xf.net.take_status() == 0                      # |x| stayed far below the fp16 range: no range report
 
 

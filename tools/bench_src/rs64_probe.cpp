@@ -59,15 +59,17 @@ int main(int argc, char** argv) {
     // layer indices of accelerated_features_amd/spec.py: CONVS (skip1.1 = 0, block1.0-.3 = 1-4, block2.0-.1, block3.0-.2, block4.0-.2 = 10-12, block5.0-.3, block_fusion.0-.2 = 17-19, heads)
     struct Case { const char* name; int layer, B, Hm, Wm; };
     const Case cases[] = {{"block4.1  B 64  30 x 40", 11, 64, 30, 40}, {"block4.2  B 64  30 x 40", 12, 64, 30, 40}, {"block_fusion.0  B 64  60 x 80", 17, 64, 60, 80},
-                          {"block_fusion.0  B 3  41 x 93", 17, 3, 41, 93}, {"block4.1  B 1  30 x 40", 11, 1, 30, 40}};
+                          {"block_fusion.0  B 3  41 x 93", 17, 3, 41, 93}, {"block4.1  B 1  30 x 40", 11, 1, 30, 40}, {"block5.1  B 64  15 x 20 (128 ch)", 14, 64, 15, 20}};
     for (const Case& c : cases) {
-        const size_t n = (size_t)c.B * 64 * c.Hm * c.Wm;
+        const int nch = c.layer == 14 || c.layer == 15 ? 128 : 64;
+        const size_t n = (size_t)c.B * nch * c.Hm * c.Wm;
         auto hx = rnd(n, (unsigned)c.layer + c.B, -1.f, 3.f);
         float *x, *y;
         HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, n * 4));
         HIPCHK(hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice));
         std::vector<float> ref(n), got(n), first(n);
         for (int v : {1, 11, 12}) {
+            if (v == 11 && nch == 128) continue;      // (no conv_bx64 form of the 128-channel layers: the backbone runs them as Winograd)
             HIPCHK(hipMemset(y, 0xff, n * 4));
             if (xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, v, nullptr)) { printf("%s variant %d: %s\n", c.name, v, xfh_last_error()); continue; }
             HIPCHK(hipMemcpy(got.data(), y, n * 4, hipMemcpyDeviceToHost));
@@ -102,7 +104,7 @@ int main(int argc, char** argv) {
         HIPCHK(hipMalloc(&feats, ncell * 64 * 4)); HIPCHK(hipMalloc(&heat, npx * 4)); HIPCHK(hipMalloc(&rel, ncell * 4)); HIPCHK(hipMalloc(&ws, wsb + 256));
         void* wsa = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t(255));
         std::vector<float> ref(ncell * 64), got(ncell * 64);
-        for (int fx : {3, 131, 387, 391, 3}) {      // 131: the unfused 64 -> 64 layers on conv_rs64_kernel; 387: the 3x3 + 1x1 pairs too; 391: + two-fragment conv_bx64 for whatever stays there
+        for (int fx : {3, 131, 387, 899, 903, 3}) {      // 131: the unfused 64 -> 64 layers on conv_rs64_kernel; 387: the 3x3 + 1x1 pairs too; 899: + block5.1 / block5.2 on the 128-channel form; 903: + two-fragment conv_bx64 for whatever stays there
             if (xfh_set_option(h, "fx", fx)) { printf("fx = %d: %s\n", fx, xfh_last_error()); continue; }
             if (xfh_backbone(h, img, B, 3, Hh, W, feats, nullptr, heat, rel, nullptr, wsa, wsb, nullptr)) { printf("backbone fx %d: %s\n", fx, xfh_last_error()); continue; }
             HIPCHK(hipMemcpy(got.data(), feats, ncell * 64 * 4, hipMemcpyDeviceToHost));
