@@ -21,6 +21,7 @@ static int run_rs64(const ConvW& c, const ConvW* c2, const float* in, int B, int
     a.in = in; a.wq = c.w_rs; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B;
     a.wq2 = c2 ? c2->w_rs : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     a.P = W + 2; a.inv_p = 1.f / (float)a.P; a.nu = ceil_div(H * a.P, 64); a.nseg = rs64::nseg_for(a.P);
+    if ((long long)(H + 4) * a.P + 512 >= (1 << 20)) return -1;               // row_of (conv_rs64_body.hpp): positions below 2^20 (exact there for every P <= 127: tests/test_conv_rs64_emulated.py)
     if (a.nseg > rs64::max_nseg(FUSE != 0)) return -1;                       // the rings of a wider map do not fit (125 columns; 93 with the fused 1x1's buffers)
     const int lds = rs64::lds_bytes(a.nseg, FUSE != 0);
     static unsigned attr_done = 0;
@@ -53,6 +54,7 @@ int launch_conv_rs128(const ConvW& c, const float* in, int B, int H, int W, floa
     a.in = in; a.wq = c.w_rs; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B;
     a.wq2 = nullptr; a.bias2 = nullptr; a.relu2 = 0;
     a.P = W + 2; a.inv_p = 1.f / (float)a.P; a.nu = ceil_div(H * a.P, 64); a.nseg = rs64::nseg_for(a.P);
+    if ((long long)(H + 4) * a.P + 512 >= (1 << 20)) return -1;
     if (a.nseg > rs64::MAX_NSEG128) return -1;
     static unsigned attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_rs64_kernel<0, 128>), rs64::lds_bytes128(rs64::MAX_NSEG128), attr_done);

@@ -100,3 +100,12 @@ def test_conv_rs64_body_with_128_channels(emu_bin, shape, relu, groups, k):
     print(f"128 channels {shape} relu {relu} groups {groups} k {k}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
     assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0 and np.isfinite(y).all()
     assert d.max() <= 3e-6 * float(ref.abs().max())
+
+
+def test_row_of_a_padded_raster_position_is_exact():
+    """conv_rs64_body.hpp: row_of(i) = (int)((i + 0.5f) * (1.f / P)) replaces the integer division of a position by the raster's pitch: exact for every position below 2^20 and
+    every pitch the kernel's rings admit (the launcher refuses larger maps)"""
+    i = np.arange(0, 1 << 20, dtype=np.int64)
+    for P in range(3, 128):
+        r = ((i.astype(np.float32) + np.float32(0.5)) * (np.float32(1.0) / np.float32(P))).astype(np.int32)
+        assert (r == i // P).all(), P
