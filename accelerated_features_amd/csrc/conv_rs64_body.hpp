@@ -105,10 +105,14 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    A[t][cb][q] = wp[((t * 2 + cb) * 3 + q) * 64];
-                    if (q < 2) XFH_AGPR(A[t][cb][q]);          // 144 of the 216 weight registers live in the accumulation half of the register file (next to the 64 accumulators)
-                }
+                for (int q = 0; q < 3; ++q) A[t][cb][q] = wp[((t * 2 + cb) * 3 + q) * 64];
+        // (all 54 loads are in flight before the first value is pinned: a pin right behind its load makes the prologue twenty round trips long)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) XFH_AGPR(A[t][cb][q]);          // 144 of the 216 weight registers live in the accumulation half of the register file (next to the 64 accumulators)
     }
     // ---- the couts this wave finishes: 16 wave + 8 (k >> 2) + 4 kg + (k & 3), k = 0 .. 7 = registers 8 (wave & 1) + k of accumulator wave >> 1
     float bs[8];
@@ -352,10 +356,17 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         // prologue: the window of the run's first unit (segments ua .. ua + nseg - 1: the whole ring) with every pipe idle; the segment the first unit will write travels
         float v[NV];
         u32x4 sh[NQ], sl[NQ];
-        for (int q = 0; q < a.nseg; ++q) {
-            seg_load(ua + q, true, v);
-            seg_convert(v, sh, sl);
-            seg_store(q, sh, sl);
+        {
+            constexpr int MAXN = C128 ? MAX_NSEG128 : FUSE ? 4 : MAX_NSEG;
+            float vp[MAXN][NV];                     // every segment's loads travel together (one memory latency for the ring, not one per segment)
+#pragma unroll
+            for (int q = 0; q < MAXN; ++q) seg_load(ua + q, q < a.nseg, vp[q]);
+#pragma unroll
+            for (int q = 0; q < MAXN; ++q)
+                if (q < a.nseg) {
+                    seg_convert(vp[q], sh, sl);
+                    seg_store(q, sh, sl);
+                }
         }
         XFH_WAVE_SYNC();
         if constexpr (!C128) seg_load(ua + a.nseg, ua + 1 < ub, v);
