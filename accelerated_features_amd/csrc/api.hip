@@ -582,9 +582,9 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
     // fx bit 128 (with bit 1): the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on conv_rs64_kernel -- weights resident in registers; -1 (map too wide for its rings): the paths below
-    if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc && c.cin == 64) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status);
+    if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc && c.cin == 64) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace);
     if (rc && use_bx && (h->opt.fx & 513) == 513 && c.w_rs && !c2 && !nhwc && c.cin == 128) rc = launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status);      // bit 512: block5.1, block5.2
-    if (rc && use_bx && (h->opt.fx & 257) == 257 && c.w_rs && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc);      // bit 256: block3.1 + 3.2, block_fusion.1 + .2
+    if (rc && use_bx && (h->opt.fx & 257) == 257 && c.w_rs && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc, h->trace);      // bit 256: block3.1 + 3.2, block_fusion.1 + .2
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, (h->opt.fx & 2) != 0, h->status);      // (bx = 9: block3.0 stays on the f32 kernel)
         else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // (bx = 5: large maps only)
@@ -704,7 +704,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
         return check_launch("xfh_conv_layer(fp16 pair)");
     }
     if (variant == 12) {      // 64 -> 64 3x3/s1: the fp16-pair kernel with the weights resident in registers
-        if (c.cin == 128 ? launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status) : launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: conv_rs64_kernel does not take layer %d at width %d", layer, Win);
+        if (c.cin == 128 ? launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status) : launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: conv_rs64_kernel does not take layer %d at width %d", layer, Win);
         return check_launch("xfh_conv_layer(fp16 pair, resident weights)");
     }
     if (variant >= 2) {

@@ -53,6 +53,7 @@ struct Rs64Args {
     const void* wq2;
     const float* bias2;
     int relu2;
+    long long* trace;          // debug (the TRACE instantiations only): s_memtime stamps of wave 0, 32 per workgroup (see conv_rs64_wave)
 };
 
 namespace rs64 {
@@ -81,7 +82,10 @@ static_assert(ring_off<0>() + 4 * 5 * SEG_BYTES <= 160 * 1024 && ring_off<1>() +
 
 // the code of ONE wave of the workgroup (wave = its K quarter and the couts it finishes): four copies, so that which accumulator registers are a wave's own and which go to
 // whom is static (selected at run time it costs a v_cndmask per register and use, or a branch tree in the middle of the MFMA stream)
-template <int wave, int FUSE, int CIN = 64>
+// TRACE (a separate instantiation: the stamps' branches would cut the unit's basic block in the production code): lane 0 of wave 0 writes s_memtime to trace[32 workgroup + k]:
+// k = 0 entry, 1 weights in registers, 2 the first run's ring filled; of the workgroup's SECOND unit: 3 start, 4 / 5 / 6 / 7 first block (taps 0-2 issued, taps 3-4 issued =
+// at the barrier, barrier passed, taps 5-8 + reduction issued), 8 .. 11 the same of the second block, 12 unit end (segment stored); 13 exit, 14 = units this workgroup processed
+template <int wave, int FUSE, int CIN = 64, bool TRACE = false>
 __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     using namespace rs64;
     constexpr bool C128 = CIN == 128;            // 128 -> 128: the workgroup's cout quarter a.cq-th of four is part of the run index; this wave multiplies channels 32 wave .. + 31
@@ -93,6 +97,11 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kg = lane >> 5;
     const int P = a.P, H = a.H, W = a.W, HW = H * W;
     const float inv_p = a.inv_p;
+    long long* tr = TRACE && wave == 0 && a.trace && lane == 0 ? a.trace + (size_t)blockIdx.x * 32 : nullptr;
+    int n_units = 0;
+#define RS_STAMP(k) { if constexpr (TRACE) { if (tr) tr[k] = __builtin_amdgcn_s_memtime(); } }
+#define RS_STAMP_U(k) { if constexpr (TRACE) { if (tr && n_units == 1) tr[k] = __builtin_amdgcn_s_memtime(); } }
+    RS_STAMP(0)
 
     // ---- this wave's weights: channels 16 wave .. + 15 under every tap, all 64 couts, three fragments (q0, q1, q2 of split_weight mode 1)
     // (128 channels: the middle index is the 16-channel CHUNK of the wave's 32 channels instead of the cout block; the quarter's weights are selected per run -- every run of a
@@ -114,6 +123,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
 #pragma unroll
                 for (int q = 0; q < 2; ++q) XFH_AGPR(A[t][cb][q]);          // 144 of the 216 weight registers live in the accumulation half of the register file (next to the 64 accumulators)
     }
+    RS_STAMP(1)
     // ---- the couts this wave finishes: 16 wave + 8 (k >> 2) + 4 kg + (k & 3), k = 0 .. 7 = registers 8 (wave & 1) + k of accumulator wave >> 1
     float bs[8];
 #pragma unroll
@@ -369,6 +379,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
                 }
         }
         XFH_WAVE_SYNC();
+        if constexpr (TRACE) { if (tr && n_units == 0) tr[2] = __builtin_amdgcn_s_memtime(); }
         if constexpr (!C128) seg_load(ua + a.nseg, ua + 1 < ub, v);
         int rslot = 0;                             // slot of segment u
         ldb(0u, x[0]);
@@ -377,16 +388,20 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             float4 part[3][2];
             // (128 channels: the next segment's 32 loads are issued here, not a unit earlier -- their registers would overlap the converted segment's for a whole unit,
             // and the maps of these layers sit in L2)
+            RS_STAMP_U(3)
             if constexpr (C128) seg_load(u + a.nseg, u + 1 < ub, v);
             // ---- first block (accumulators a); inside it: the reduction of the block before (accumulators b: the previous unit's, or run's, second block)
             if constexpr (FUSE == 0) { pend_a.rs = rs_out; pend_a.voff = out_voff(64 * u + n); }
             else { p2a_prev = p2a; p2a.rs = rs_out2; p2a.voff[0] = out2_voff(64 * u + (lane & 15)); p2a.voff[1] = out2_voff(64 * u + 16 + (lane & 15)); }
             taps(I0{}, I3{}, I0{}, t0b, ca0, ca1, x);
             XFH_SCHED_FENCE();
+            RS_STAMP_U(4)
             red_write(cb0, cb1);
             taps(I3{}, I5{}, I0{}, t0b, ca0, ca1, x);
             XFH_SCHED_FENCE();
+            RS_STAMP_U(5)
             XFH_LDS_BARRIER();
+            RS_STAMP_U(6)
             red_read(part);
             ++kb;
             XFH_SCHED_FENCE();
@@ -396,16 +411,20 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { cb0[i] = 0.f; cb1[i] = 0.f; }
             XFH_SCHED_FENCE();
+            RS_STAMP_U(7)
             // ---- second block (accumulators b); inside it: the segment the next unit needs goes into the ring, the first block is reduced, the segment after that is requested
             if constexpr (FUSE == 0) { pend_b.rs = rs_out; pend_b.voff = out_voff(64 * u + 32 + n); }
             else { p2b_prev = p2b; p2b.rs = rs_out2; p2b.voff[0] = out2_voff(64 * u + 32 + (lane & 15)); p2b.voff[1] = out2_voff(64 * u + 48 + (lane & 15)); }
             taps(I0{}, I3{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
             seg_convert(v, sh, sl);
             XFH_SCHED_FENCE();
+            RS_STAMP_U(8)
             red_write(ca0, ca1);
             taps(I3{}, I5{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
             XFH_SCHED_FENCE();
+            RS_STAMP_U(9)
             XFH_LDS_BARRIER();
+            RS_STAMP_U(10)
             red_read(part);
             ++kb;
             XFH_SCHED_FENCE();
@@ -416,8 +435,11 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ca0[i] = 0.f; ca1[i] = 0.f; }
             XFH_SCHED_FENCE();
+            RS_STAMP_U(11)
             seg_store(rslot, sh, sl);               // segment u + nseg over segment u (the last unit of a run writes zeros); every operand read of this unit has been issued
             XFH_WAVE_SYNC();
+            RS_STAMP_U(12)
+            ++n_units;
             rslot = rslot + 1 == a.nseg ? 0 : rslot + 1;
         }
     }
@@ -435,15 +457,19 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         }
     }
     fx_report_h(amax, a.status);
+    RS_STAMP(13)
+    if constexpr (TRACE) { if (tr) tr[14] = n_units; }
+#undef RS_STAMP
+#undef RS_STAMP_U
 }
 
-template <int FUSE, int CIN = 64>      // FUSE 0: the 3x3 alone; 1: + trailing 1x1 (64 -> 64), NCHW output; 2: the same with channels-last output.  CIN 128: the 128 -> 128 layers (FUSE 0)
+template <int FUSE, int CIN = 64, bool TRACE = false>      // FUSE 0: the 3x3 alone; 1: + trailing 1x1 (64 -> 64), NCHW output; 2: the same with channels-last output.  CIN 128: the 128 -> 128 layers (FUSE 0)
 __device__ __forceinline__ void conv_rs64_body(const Rs64Args& a) {
     switch (__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)) {
-        case 0: conv_rs64_wave<0, FUSE, CIN>(a); break;
-        case 1: conv_rs64_wave<1, FUSE, CIN>(a); break;
-        case 2: conv_rs64_wave<2, FUSE, CIN>(a); break;
-        default: conv_rs64_wave<3, FUSE, CIN>(a); break;
+        case 0: conv_rs64_wave<0, FUSE, CIN, TRACE>(a); break;
+        case 1: conv_rs64_wave<1, FUSE, CIN, TRACE>(a); break;
+        case 2: conv_rs64_wave<2, FUSE, CIN, TRACE>(a); break;
+        default: conv_rs64_wave<3, FUSE, CIN, TRACE>(a); break;
     }
 }
 

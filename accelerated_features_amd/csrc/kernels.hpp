@@ -102,7 +102,8 @@ int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* 
 int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr,
                      const ConvW* fused1x1 = nullptr, bool nhwc = false, int fx = 0, int* status = nullptr, int sp = 0, const float* zeros = nullptr);
 // 3x3/s1, 64 -> 64, fp16 pair, weights resident in registers (k_conv_rs64.hip / conv_rs64_body.hpp); -1: not this layer, or the map is wider than its LDS rings allow
-int launch_conv_rs64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status = nullptr, const ConvW* fused1x1 = nullptr, bool nhwc = false);
+int launch_conv_rs64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status = nullptr, const ConvW* fused1x1 = nullptr, bool nhwc = false,
+                     long long* trace = nullptr);
 bool conv_rs128_fits(int W);      // the map's rings fit into a CU's LDS
 int launch_conv_rs128(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status = nullptr);      // the 128 -> 128 form (block5.1, block5.2)
 // 3x3/s2, 64 -> 64 | 128 (block4.0, block5.0; k_conv_bx64s2.hip); -1 if no instantiation

@@ -93,6 +93,42 @@ int main(int argc, char** argv) {
         printf("%-32s variant 12, %d cold-started launches: %zu differ from the first\n", c.name, repeats, bad);
         HIPCHK(hipFree(x)); HIPCHK(hipFree(y));
     }
+    // ---- where a unit's cycles go: the stamped twin of the kernel (xfh_debug_trace; conv_rs64_body.hpp documents the 15 stamps per workgroup)
+    if (void* pt = dlsym(lib, "xfh_debug_trace")) {
+        auto xfh_debug_trace = reinterpret_cast<int (*)(H, long long*)>(pt);
+        const size_t ntr = ((size_t)1 << 21) + ((size_t)1 << 17);
+        long long* tr; HIPCHK(hipMalloc(&tr, ntr * 8));
+        for (const Case& c : {cases[0], cases[2]}) {
+            const size_t n = (size_t)c.B * 64 * c.Hm * c.Wm;
+            auto hx = rnd(n, 99, -1.f, 3.f);
+            float *x, *y;
+            HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, n * 4));
+            HIPCHK(hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice));
+            for (int i = 0; i < 3; ++i) xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, 12, nullptr);
+            HIPCHK(hipMemset(tr, 0, ntr * 8));
+            xfh_debug_trace(h, tr);
+            xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, 12, nullptr);
+            HIPCHK(hipDeviceSynchronize());
+            xfh_debug_trace(h, nullptr);
+            std::vector<long long> t(256 * 32);
+            HIPCHK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
+            double sum[16] = {0}; int nw = 0;
+            const char* what[13] = {"entry -> weights in registers", "-> first ring filled", "", "unit: taps 0-2 issued", "taps 3-4 issued (at the barrier)", "barrier passed", "taps 5-8 + reduction issued (first block done)",
+                                    "second block: taps 0-2 + conversion", "taps 3-4 (at the barrier)", "barrier passed", "taps 5-8 + reduction", "segment stored (unit end)", ""};
+            for (int g = 0; g < 256; ++g) {
+                const long long* q = &t[g * 32];
+                if (!q[0] || !q[13] || q[14] < 2 || !q[12]) continue;
+                ++nw;
+                sum[0] += (double)(q[1] - q[0]); sum[1] += (double)(q[2] - q[1]);
+                for (int k = 3; k < 12; ++k) sum[k] += (double)(q[k + 1] - q[k]);
+                sum[12] += (double)(q[13] - q[0]); sum[13] += (double)q[14]; sum[14] += (double)(q[12] - q[3]);
+            }
+            printf("%s: %d workgroups with a second unit; s_memtime ticks (means): whole kernel %.0f for %.1f units; ONE unit %.0f (108 MFMAs: floor 3456 cycles)\n", c.name, nw, sum[12] / (nw ? nw : 1), sum[13] / (nw ? nw : 1), sum[14] / (nw ? nw : 1));
+            for (int k = 0; k < 12; ++k) if (what[k][0]) printf("    %-52s %8.0f\n", what[k], sum[k] / (nw ? nw : 1));
+            HIPCHK(hipFree(x)); HIPCHK(hipFree(y));
+        }
+        HIPCHK(hipFree(tr));
+    }
     // ---- the backbone with the three unfused 64 -> 64 layers on conv_rs64_kernel (fx bit 128)
     {
         const int B = 64, Hh = 480, W = 640;
