@@ -218,11 +218,13 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2, block
         add(100 + ci[n_], f"conv_bx_kernel<24,24> ({n_})", 4.0 * 48 * px["4"], fl, fl * bx24, PEAK_BF16_TFLOPS, pipe24)
     fl = conv_flops("block3.0", px["8"])
     add(100 + ci["block3.0"], "conv_bxs2_kernel<24> (block3.0, stride 2)", 4.0 * (24 * px["4"] + 64 * px["8"]), fl, fl * nm24 * (224 / 216), PEAK_BF16_TFLOPS, pipe24)
-    for n3, n1, tag in (("block3.1", "block3.2", "conv_bx64_kernel<64,1>"), ("block_fusion.1", "block_fusion.2", "conv_bx64_kernel<64,2> (channels-last out)")):
+    rs_plain, rs_fused, rs_128 = (fx & 129) == 129, (fx & 257) == 257, (fx & 513) == 513      # conv_rs64_kernel (weights resident in registers): unfused 64 -> 64 layers, 3x3 + 1x1 pairs, block5.1 / 5.2
+    for n3, n1, tag in (("block3.1", "block3.2", "conv_rs64_kernel<1>" if rs_fused else "conv_bx64_kernel<64,1>"),
+                        ("block_fusion.1", "block_fusion.2", "conv_rs64_kernel<2> (channels-last out)" if rs_fused else "conv_bx64_kernel<64,2> (channels-last out)")):
         fl = conv_flops(n3, px["8"]) + conv_flops(n1, px["8"])
         add(100 + ci[n3], f"{tag} ({n3} + {n1})", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
     fl = conv_flops("block_fusion.0", px["8"])
-    add(100 + ci["block_fusion.0"], "conv_bx64_kernel<64,0> (block_fusion.0)", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
+    add(100 + ci["block_fusion.0"], ("conv_rs64_kernel<0>" if rs_plain else "conv_bx64_kernel<64,0>") + " (block_fusion.0)", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
     for n_, cin, cout, sc_in, sc_out in (("block4.0", 64, 64, "8", "16"), ("block5.0", 64, 128, "16", "32")):
         fl = conv_flops(n_, px[sc_out])
         ho, wo = H // int(sc_out), W // int(sc_out)
@@ -232,12 +234,20 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2, block
     units16 = B * (-(-(H // 16) // 8)) * (-(-(W // 16) // 16))          # half-tile units of conv_bx64_kernel at 1/16 scale (api.hip: big_map)
     for n_, ch, sc in (("block4.1", 64, "16"), ("block4.2", 64, "16"), ("block5.1", 128, "32")):
         fl = conv_flops(n_, px[sc])
-        if ch == 64 and (fx & 1) and units16 >= 768:      # the 64 -> 64 layers at 1/16 scale join the fp16-pair split kernel when the batch fills its grid
+        if ch == 64 and rs_plain:
+            add(100 + ci[n_], f"conv_rs64_kernel<0> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
+        elif ch == 128 and rs_128:
+            add(100 + ci[n_], f"conv_rs64_kernel<0, 128> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
+        elif ch == 64 and (fx & 1) and units16 >= 768:      # the 64 -> 64 layers at 1/16 scale join the fp16-pair split kernel when the batch fills its grid
             add(100 + ci[n_], f"conv_bx64_kernel<64,0> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
         else:
             add(100 + ci[n_], f"conv_wino_kernel ({n_})", 4.0 * 2 * ch * px[sc], fl, fl / 2.25, f32, "f32 mfma, Winograd F(2x2,3x3)")
     fl3, fl1 = conv_flops("block5.2", px["32"]), conv_flops("block5.3", px["32"])
-    add(100 + ci["block5.2"], "conv_wino_kernel (block5.2 + block5.3)", 4.0 * (128 + 64) * px["32"], fl3 + fl1, fl3 / 2.25 + fl1, f32, "f32 mfma, Winograd F(2x2,3x3)")
+    if rs_128:      # block5.2 on the 128-channel form, block5.3 as a 1x1 of its own (two spans: the 3x3's and the 1x1's)
+        add(100 + ci["block5.2"], "conv_rs64_kernel<0, 128> (block5.2)", 4.0 * 2 * 128 * px["32"], fl3, fl3 * 3, PEAK_BF16_TFLOPS, pipe64)
+        add(100 + ci["block5.3"], "conv_mfma_kernel<128,64,1x1> (block5.3)", 4.0 * (128 + 64) * px["32"], fl1, fl1, f32, "f32 mfma")
+    else:
+        add(100 + ci["block5.2"], "conv_wino_kernel (block5.2 + block5.3)", 4.0 * (128 + 64) * px["32"], fl3 + fl1, fl3 / 2.25 + fl1, f32, "f32 mfma, Winograd F(2x2,3x3)")
     add(201, "pyramid_sum_kernel (x3 + up(x4) + up(x5))", 4.0 * 64 * (2 * px["8"] + px["16"] + px["32"]), 3.0 * 64 * px["8"], 3.0 * 64 * px["8"], 0, "valu")
     fl = 2.0 * (2 * 64 * 64 + 64) * px["8"]
     hk = {0: "head_bx_kernel", 1: "head_fused_kernel", 2: "head_f32r_kernel", 3: "head_f32r_kernel (dustbin on the matrix cores)"}[heads_f32]
