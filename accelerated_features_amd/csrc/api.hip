@@ -580,6 +580,7 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     if (sp_link && layer == L_FUSION_0 && !c2 && !nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status, 2, h->nw.zeros);
     if (rc && use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
+    if (rc && (use_bx & 16) && (h->opt.fx & 1025) == 1025 && c.w_fx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status);      // fx bit 1024: block4.0, block5.0 in the fp16-pair arithmetic
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
     // fx bit 128 (with bit 1): the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on conv_rs64_kernel -- weights resident in registers; -1 (map too wide for its rings): the paths below
     if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc && c.cin == 64) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace);
@@ -699,6 +700,7 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
     }
     if (variant == 11) {      // the split kernel of the layer in the fp16-pair arithmetic
         if (!c.w_fx || (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, true, h->status)
+                                    : c.cin == 64 && c.stride == 2 ? launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status)
                                     : (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status))))
             return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fp16-pair instantiation for layer %d", layer);
         return check_launch("xfh_conv_layer(fp16 pair)");
@@ -947,7 +949,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 1023}};
+        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 2047}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

@@ -97,7 +97,7 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *                           i.e. whenever other kernels (a second stream, another process) evict its code between launches (profiles/r04_head_hazard/);
  *                           both f32 kernels are clean under the same torture at every code position.  For A/B measurements only.
  *   "fx"            bitmask split-operand convolutions in the fp16-pair arithmetic (three MFMAs per product instead of the six of the bf16 three-way split):
- *                           1 = the 64 -> 64 layers on large maps (conv_bx64_kernel), 2 = the 24-channel layers, 4 = (with 1) the 64 -> 64 layers with two weight fragments in their stream, 8 = the split heads (with heads_f32 = 0), + 16 = with two weight fragments in LDS, + 32 = (instead) the pixel-side fragments through LDS; 64 = (with 1) block_fusion.0 hands block_fusion.1 its output as fp16 pairs, 128 = (with 1) the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on the kernel with the weights resident in registers (conv_rs64_kernel; maps up to 125 columns), 256 = (with 1) the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) on it too (maps up to 93 columns), 512 = (with 1) block5.1 and block5.2 on its 128-channel form (block5.3 then runs as a 1x1 of its own; maps up to 61 columns) (0..1023)
+ *                           1 = the 64 -> 64 layers on large maps (conv_bx64_kernel), 2 = the 24-channel layers, 4 = (with 1) the 64 -> 64 layers with two weight fragments in their stream, 8 = the split heads (with heads_f32 = 0), + 16 = with two weight fragments in LDS, + 32 = (instead) the pixel-side fragments through LDS; 64 = (with 1) block_fusion.0 hands block_fusion.1 its output as fp16 pairs, 128 = (with 1) the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on the kernel with the weights resident in registers (conv_rs64_kernel; maps up to 125 columns), 256 = (with 1) the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) on it too (maps up to 93 columns), 512 = (with 1) block5.1 and block5.2 on its 128-channel form (block5.3 then runs as a 1x1 of its own; maps up to 61 columns), 1024 = (with 1) the stride-2 64-channel layers (block4.0, block5.0) in the fp16-pair arithmetic too (0..2047)
  *   "block1"        0..7    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile;
  *                           6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too (both set XFH_STATUS_FX_RANGE like "fx")
  * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.

@@ -127,7 +127,7 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
 
 
 @pytest.mark.parametrize("opts", [{"heads_f32": 0, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}, {"fx": 0}, {"fx": 15, "bx": 23},
-                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"heads_f32": 3}, {"block1": 6}, {"block1": 7}, {"fx": 7}, {"fx": 67}, {"fx": 131}, {"fx": 387}, {"fx": 899}, {"fx": 11, "heads_f32": 0}, {"fx": 27, "heads_f32": 0}, {"fx": 43, "heads_f32": 0}])
+                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"heads_f32": 3}, {"block1": 6}, {"block1": 7}, {"fx": 7}, {"fx": 67}, {"fx": 131}, {"fx": 387}, {"fx": 899}, {"fx": 1027}, {"fx": 11, "heads_f32": 0}, {"fx": 27, "heads_f32": 0}, {"fx": 43, "heads_f32": 0}])
 def test_backbone_alternative_kernels_same_results(opts, sd):
     """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on the split-bf16 kernels -- opt-in since round 4 --, 24->24
     layers on Winograd; every unfused 64->64 layer on the split kernel; direct implicit GEMM instead of Winograd; block1 with a c1 tile; the split-operand
@@ -616,7 +616,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
                     n += 1
                     continue
                 rs64 = c.stride == 1 and c.cin == 64 and ww <= 125         # 12: the fp16-pair kernel with the weights resident in registers (conv_rs64_kernel; maps up to 125 columns)
-                for variant in ((1, 10, 11, 12) if rs64 else (1, 10, 11)) if c.stride == 1 or c.cin == 24 else (1, 10):      # 11: the same kernel in the fp16-pair arithmetic (three MFMAs per product)
+                for variant in ((1, 10, 11, 12) if rs64 else (1, 10, 11)):      # (11 for the stride-2 64-channel layers: conv_bx64s2x_kernel)      # 11: the same kernel in the fp16-pair arithmetic (three MFMAs per product)
                     y = torch.full(tuple(truth.shape), float("nan"), device="cuda")
                     rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
                     assert rc == 0, (name, variant, lib.xfh_last_error())
@@ -1148,7 +1148,7 @@ def test_frame_stream_at_the_bench_shape_is_bit_stable_over_many_steps(xf, sd, c
         raise AssertionError(f"{len(bad)} of 40 results differ from the synchronous one (synchronous result reproducible: {ref_stable}): {bad[:6]}")
 
 
-@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 0}, {"block1": 7}, {"heads_f32": 0, "fx": 11}, {"fx": 7}, {"fx": 67}, {"fx": 387}])
+@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 0}, {"block1": 7}, {"heads_f32": 0, "fx": 11}, {"fx": 7}, {"fx": 67}, {"fx": 387}, {"fx": 1027}])
 def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
     """Time-boxed soak.  The bench-shape backbone + sparse step + match on one HIP stream while a second stream runs foreign kernels (another
     model's backbone = every kernel of this library incl. f32-MFMA and vector-only ones, a large copy, a rocBLAS GEMM), then the same with every matrix-core

@@ -59,38 +59,39 @@ int main(int argc, char** argv) {
     // layer indices of accelerated_features_amd/spec.py: CONVS (skip1.1 = 0, block1.0-.3 = 1-4, block2.0-.1, block3.0-.2, block4.0-.2 = 10-12, block5.0-.3, block_fusion.0-.2 = 17-19, heads)
     struct Case { const char* name; int layer, B, Hm, Wm; };
     const Case cases[] = {{"block4.1  B 64  30 x 40", 11, 64, 30, 40}, {"block4.2  B 64  30 x 40", 12, 64, 30, 40}, {"block_fusion.0  B 64  60 x 80", 17, 64, 60, 80},
-                          {"block_fusion.0  B 3  41 x 93", 17, 3, 41, 93}, {"block4.1  B 1  30 x 40", 11, 1, 30, 40}, {"block5.1  B 64  15 x 20 (128 ch)", 14, 64, 15, 20}};
+                          {"block_fusion.0  B 3  41 x 93", 17, 3, 41, 93}, {"block4.1  B 1  30 x 40", 11, 1, 30, 40}, {"block5.1  B 64  15 x 20 (128 ch)", 14, 64, 15, 20}, {"block4.0  B 64  60 x 80 (stride 2: variants 1 / 10 / 11)", 10, 64, 60, 80}, {"block5.0  B 64  30 x 40 (stride 2)", 13, 64, 30, 40}};
     for (const Case& c : cases) {
         const int nch = c.layer == 14 || c.layer == 15 ? 128 : 64;
-        const size_t n = (size_t)c.B * nch * c.Hm * c.Wm;
+        const bool s2 = c.layer == 10 || c.layer == 13;      // stride 2: output 64 | 128 channels at half the size
+        const size_t n = (size_t)c.B * nch * c.Hm * c.Wm, nout = s2 ? (size_t)c.B * (c.layer == 13 ? 128 : 64) * (c.Hm / 2) * (c.Wm / 2) : n;
         auto hx = rnd(n, (unsigned)c.layer + c.B, -1.f, 3.f);
         float *x, *y;
-        HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, n * 4));
+        HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, nout * 4));
         HIPCHK(hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice));
-        std::vector<float> ref(n), got(n), first(n);
-        for (int v : {1, 11, 12}) {
-            if (v == 11 && nch == 128) continue;      // (no conv_bx64 form of the 128-channel layers: the backbone runs them as Winograd)
-            HIPCHK(hipMemset(y, 0xff, n * 4));
+        std::vector<float> ref(nout), got(nout), first(nout);
+        for (int v : {1, 10, 11, 12}) {
+            if ((v == 11 && nch == 128) || (v == 12 && s2) || (v == 10 && !s2)) continue;      // (no conv_bx64 form of the 128-channel layers: the backbone runs them as Winograd)
+            HIPCHK(hipMemset(y, 0xff, nout * 4));
             if (xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, v, nullptr)) { printf("%s variant %d: %s\n", c.name, v, xfh_last_error()); continue; }
-            HIPCHK(hipMemcpy(got.data(), y, n * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(got.data(), y, nout * 4, hipMemcpyDeviceToHost));
             const double us = timed(20, [&] { xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, v, nullptr); });
             if (v == 1) ref = got;
-            if (v == 12) first = got;
+            if (v == (s2 ? 11 : 12)) first = got;
             double d = 0, m = 0;
-            for (size_t i = 0; i < n; ++i) { const double e = std::fabs((double)got[i] - ref[i]); if (!(e <= d)) d = e; m = std::fmax(m, std::fabs((double)ref[i])); }
+            for (size_t i = 0; i < nout; ++i) { const double e = std::fabs((double)got[i] - ref[i]); if (!(e <= d)) d = e; m = std::fmax(m, std::fabs((double)ref[i])); }
             printf("%-32s variant %2d: %8.1f us per launch; vs variant 1: max |diff| %.3g (max |y| %.3g); status %d\n", c.name, v, us, d, m, take_status());
         }
         // cold instruction cache: every launch must reproduce the first result bit for bit
         xfh_debug_cold_start(1);
         size_t bad = 0;
         for (int r = 0; r < repeats; ++r) {
-            HIPCHK(hipMemset(y, 0xff, n * 4));
-            if (xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, 12, nullptr)) break;
-            HIPCHK(hipMemcpy(got.data(), y, n * 4, hipMemcpyDeviceToHost));
-            if (memcmp(got.data(), first.data(), n * 4)) ++bad;
+            HIPCHK(hipMemset(y, 0xff, nout * 4));
+            if (xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, s2 ? 11 : 12, nullptr)) break;
+            HIPCHK(hipMemcpy(got.data(), y, nout * 4, hipMemcpyDeviceToHost));
+            if (memcmp(got.data(), first.data(), nout * 4)) ++bad;
         }
         xfh_debug_cold_start(0);
-        printf("%-32s variant 12, %d cold-started launches: %zu differ from the first\n", c.name, repeats, bad);
+        printf("%-32s variant %d, %d cold-started launches: %zu differ from the first\n", c.name, s2 ? 11 : 12, repeats, bad);
         HIPCHK(hipFree(x)); HIPCHK(hipFree(y));
     }
     // ---- where a unit's cycles go: the stamped twin of the kernel (xfh_debug_trace; conv_rs64_body.hpp documents the 15 stamps per workgroup)
@@ -140,7 +141,7 @@ int main(int argc, char** argv) {
         HIPCHK(hipMalloc(&feats, ncell * 64 * 4)); HIPCHK(hipMalloc(&heat, npx * 4)); HIPCHK(hipMalloc(&rel, ncell * 4)); HIPCHK(hipMalloc(&ws, wsb + 256));
         void* wsa = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(ws) + 255) & ~uintptr_t(255));
         std::vector<float> ref(ncell * 64), got(ncell * 64);
-        for (int fx : {3, 131, 387, 899, 903, 3}) {      // 131: the unfused 64 -> 64 layers on conv_rs64_kernel; 387: the 3x3 + 1x1 pairs too; 899: + block5.1 / block5.2 on the 128-channel form; 903: + two-fragment conv_bx64 for whatever stays there
+        for (int fx : {3, 131, 387, 899, 1027, 1923, 3}) {      // 131: the unfused 64 -> 64 layers on conv_rs64_kernel; 387: the 3x3 + 1x1 pairs too; 899: + block5.1 / block5.2 on the 128-channel form; 1027: the stride-2 layers in the fp16-pair arithmetic alone; 1923: all of it
             if (xfh_set_option(h, "fx", fx)) { printf("fx = %d: %s\n", fx, xfh_last_error()); continue; }
             if (xfh_backbone(h, img, B, 3, Hh, W, feats, nullptr, heat, rel, nullptr, wsa, wsb, nullptr)) { printf("backbone fx %d: %s\n", fx, xfh_last_error()); continue; }
             HIPCHK(hipMemcpy(got.data(), feats, ncell * 64 * 4, hipMemcpyDeviceToHost));
