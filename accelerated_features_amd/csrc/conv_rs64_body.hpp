@@ -15,6 +15,16 @@
 // Per block and wave: 54 MFMAs (1728 matrix-pipe cycles), 18 + 6 LDS reads, 6 LDS writes.  LDS: 48 KiB + 4 x nseg x 5 KiB of rings (nseg = 2 + (2 P + 1) / 64
 // segments of 64 positions = exactly one unit's window: the next unit's new segment is converted inside the unit's MFMAs and stored behind its last operand read, over the
 // segment the unit started with): 128 KiB at P = 82 (VGA 1/8 scale) -- one workgroup per CU; maps wider than 125 columns (nseg > 5) stay with conv_bx64_kernel.
+//
+// How a unit (64 positions = two blocks of 32) is laid out in time -- ONE basic block of 108 MFMAs, everything else placed between them (one wave per SIMD: nobody else hides a gap):
+//   first block:   taps 0-2 | partial sums of the block BEFORE -> LDS | taps 3-4 | LDS-only barrier, read three partials | taps 5-8 + sum, bias, ReLU, stores of the block before
+//   second block:  taps 0-2 + conversion of the next unit's new segment | partial sums of the first block -> LDS | taps 3-4 | barrier, read | taps 5-8 + finish of the first block
+//                  + loads of the segment after next | the converted segment -> ring (over the segment this unit started with)
+// A tap's B operands are read one tap ahead (tap 8 reads the next block's tap 0), straight into accumulation registers (XFH_AGPR): registers no vector-ALU result is allocated
+// to, so no idle slots guard the matrix core's operand reads.  The four waves run four COPIES of this code (template parameter wave): which accumulator registers go to whom is static.
+// Forms: FUSE 1 / 2 = the trailing 1x1 (block3.2 NCHW, block_fusion.2 channels-last) on v_mfma_f32_16x16x32_f16, a block's 3x3 outputs handed over as fp16 pairs through LDS
+// (Y buffers), its 1x1 two blocks later; CIN 128 = block5.1 / block5.2: a workgroup per cout QUARTER, a wave multiplies 32 channels (two chunks, an accumulator each);
+// TRACE = the stamped twin (xfh_debug_trace).  tests/test_conv_rs64_emulated.py, tools/fuzz_conv_rs64_emulated.py, tools/bench_src/rs64_probe.cpp.
 #pragma once
 #ifndef XFH_HOST_EMU
 #include "kernels.hpp"
