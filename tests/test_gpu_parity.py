@@ -636,13 +636,14 @@ def test_fp16_pair_arithmetic_reports_its_range_and_the_model_falls_back(sd):
     that ran the bf16 form from the start -- and the model stays there.  Small subnormal-range activations are exact in both."""
     import warnings
     from accelerated_features_amd import XFeat
-    from accelerated_features_amd.xfeat import DEFAULT_FX
+    from accelerated_features_amd.xfeat import DEFAULT_FX, DEFAULT_HEADS_F32, DEFAULT_BLOCK1
     from accelerated_features_amd.spec import CONV_INDEX
     lib = _lib().load()
     a, b = XFeat(weights=sd, top_k=512), XFeat(weights=sd, top_k=512)
     v = C.c_int(-1)
-    assert lib.xfh_get_option(a.net.handle(), b"fx", C.byref(v)) == 0 and v.value == DEFAULT_FX      # the Python mirror of the library default
-    b.set_option("fx", 0)
+    for key, mirror in ((b"fx", DEFAULT_FX), (b"heads_f32", DEFAULT_HEADS_F32), (b"block1", DEFAULT_BLOCK1)):      # the Python mirrors of the library defaults
+        assert lib.xfh_get_option(a.net.handle(), key, C.byref(v)) == 0 and v.value == mirror, (key, v.value, mirror)
+    b.set_option("fx", 0); b.set_option("heads_f32", DEFAULT_HEADS_F32 or 2); b.set_option("block1", 5)      # the fp32-range forms the fallback lands on
     # (a) a single layer: 1e6-sized activations -> flag, and inf / nan in the fx output; the bf16 form is fine
     x = torch.relu(torch.randn(2, 64, 24, 32, device="cuda")) * 3.0e5
     y = torch.empty(2, 64, 24, 32, device="cuda")
@@ -662,7 +663,7 @@ def test_fp16_pair_arithmetic_reports_its_range_and_the_model_falls_back(sd):
         ra = a.detectAndCompute(img, top_k=512)
     rb = b.detectAndCompute(img, top_k=512)
     assert any("fp16-pair" in str(m.message) for m in w)
-    assert a.net._options.get("fx") == 0
+    assert a.net._options.get("fx") == 0 and a.net._effective_option("heads_f32") != 0 and a.net._effective_option("block1") < 6
     for u, v_ in zip(ra, rb):
         assert torch.equal(u["keypoints"], v_["keypoints"]) and torch.equal(u["scores"], v_["scores"]) and torch.equal(u["descriptors"], v_["descriptors"])
     # (c) tiny activations (fp16 subnormals of the high part): the pair still carries them -- same accuracy as the bf16 form against fp64
