@@ -126,7 +126,7 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
 
 
-@pytest.mark.parametrize("opts", [{"heads_f32": 0, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}, {"fx": 0}, {"fx": 15, "bx": 23},
+@pytest.mark.parametrize("opts", [{"heads_f32": 0, "fx": 3, "bx": 0, "block1": 1}, {"heads_f32": 2, "block1": 5, "fx": 3}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}, {"fx": 0}, {"fx": 15, "bx": 23},
                                   {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"heads_f32": 3}, {"block1": 6}, {"block1": 7}, {"fx": 7}, {"fx": 67}, {"fx": 131}, {"fx": 387}, {"fx": 899}, {"fx": 1027}, {"fx": 11, "heads_f32": 0}, {"fx": 27, "heads_f32": 0}, {"fx": 43, "heads_f32": 0}])
 def test_backbone_alternative_kernels_same_results(opts, sd):
     """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on the split-bf16 kernels -- opt-in since round 4 --, 24->24
@@ -1149,13 +1149,14 @@ def test_frame_stream_at_the_bench_shape_is_bit_stable_over_many_steps(xf, sd, c
         raise AssertionError(f"{len(bad)} of 40 results differ from the synchronous one (synchronous result reproducible: {ref_stable}): {bad[:6]}")
 
 
-@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 0}, {"block1": 7}, {"heads_f32": 0, "fx": 11}, {"fx": 7}, {"fx": 67}, {"fx": 387}, {"fx": 1027}])
+@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 2, "block1": 5, "fx": 3}, {"heads_f32": 0, "fx": 3}, {"block1": 7}, {"heads_f32": 0, "fx": 11}, {"fx": 7}, {"fx": 67}, {"fx": 387}, {"fx": 1027}])
 def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
     """Time-boxed soak.  The bench-shape backbone + sparse step + match on one HIP stream while a second stream runs foreign kernels (another
     model's backbone = every kernel of this library incl. f32-MFMA and vector-only ones, a large copy, a rocBLAS GEMM), then the same with every matrix-core
     kernel starting on an invalidated instruction cache (xfh_debug_cold_start: the condition that made the split-bf16 key-point head deliver wrong 16-cell blocks,
     DESIGN 9.0) -- every network output and every match list of every step bit-identical to the quiet, warm reference.  Parametrised over the per-handle kernel
-    options; {"heads_f32": 0} is the opt-in split-bf16 head: it runs the two-stream part only as a record (its failures are rare and known), the assertion covers what ships."""
+    options (every set names what it needs, so the list means the same whatever the library defaults are: {"heads_f32": 2, "block1": 5, "fx": 3} is round 4's shipped mix);
+    {"heads_f32": 0, "fx": 3} is the opt-in split-bf16 head: it runs the two-stream part only as a record (its failures are rare and known), the assertion covers what ships."""
     import threading
     import time
     from accelerated_features_amd import XFeat
@@ -1221,6 +1222,7 @@ def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
         lib.xfh_debug_cold_start(0)
     print(f"options {opts}: {n1} steps next to foreign kernels: differing {dict(zip(names, bad1))}; {n2} cold-start steps: differing {dict(zip(names, bad2))}")
     assert n1 >= 200 and n2 >= 200
-    if opts.get("heads_f32", 1) == 0 and not opts.get("fx", 0) & 8:
+    from accelerated_features_amd.xfeat import DEFAULT_FX, DEFAULT_HEADS_F32
+    if opts.get("heads_f32", DEFAULT_HEADS_F32) == 0 and not opts.get("fx", DEFAULT_FX) & 8:
         return                                          # the opt-in bf16 head: recorded above, not asserted.  (The fp16-pair head IS asserted: it has to earn its place.)
     assert not any(bad1) and not any(bad2), (dict(zip(names, bad1)), dict(zip(names, bad2)))
