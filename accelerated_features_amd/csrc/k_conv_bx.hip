@@ -483,7 +483,7 @@ static int run_bxs2(const ConvW& c, const float* in, int B, int H, int W, float*
     a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B;
     a.tiles_x = ceil_div(W, 32);
     a.tiles = a.tiles_x * ceil_div(H, 8);
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN, FX>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();
@@ -503,7 +503,7 @@ static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* o
     a.lag = 11;
     a.tiles_x = ceil_div(W, Cfg::TW);
     a.tiles = a.tiles_x * ceil_div(H, Cfg::TH);
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx_kernel<CIN, COUT, FX>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();            // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD

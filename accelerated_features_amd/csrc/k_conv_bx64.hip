@@ -40,7 +40,7 @@ static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int
     a.in = in; a.wq = FXM == 2 ? c.w_fq : FXM ? c.w_fx : c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
     a.wq2 = c2 ? reinterpret_cast<const uint4*>(FXM ? c2->w_fx : c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     a.ncols = ceil_div(W, 16); a.nhr = ceil_div(H, 8); a.upi = a.ncols * a.nhr;
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     constexpr int lds_bytes = (SP & 1) ? bx64::SP_LDS_BYTES : bx64::LDS_BYTES;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE, FXM, SP>), lds_bytes, attr_done);
     const long long units = (long long)B * a.upi;

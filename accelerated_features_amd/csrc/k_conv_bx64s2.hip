@@ -357,7 +357,7 @@ static int run_bx64s2(const ConvW& c, const float* in, int B, int H, int W, floa
     a.cold = g_debug_cold;
     a.in = in; a.wq = c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B; a.trace = trace;
     a.nrows = ceil_div(Ho, 8); a.upi = ceil_div(Wo, 16) * a.nrows;
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64s2_kernel<NCO, W4>), bx64s2::LDS_BYTES, attr_done);
     const long long units = (long long)NCO * B * a.upi;
     int grid = num_cus();                      // one 8-wave workgroup per CU (all 160 KiB of LDS); a multiple of 8 keeps a workgroup on its XCD

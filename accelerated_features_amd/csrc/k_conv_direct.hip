@@ -175,7 +175,7 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     // and LDS round trip come on top.  What the vector pipe is short of is issue slots (PMC: 116 M vector instructions, 54 % FMAs, inner loops
     // already 95 % v_pk_fma_f32) -- the remaining lever is the per-item prologue / epilogue arithmetic of the stages, not another pipe.
     const int c1 = (variant == 1 || variant == 3 || variant == 4) ? variant : ((variant == 6 || variant == 7) && nw.block1_fx && nw.block1_fx3) ? variant : 5;      // (6 / 7 without the fp16-pair images -- a weight of magnitude >= 31 -- are 5)      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels on packed FMAs; default (0 / 5): conv1 recomputed inside conv2 (xfh_set_option rejects every other value)
-    static unsigned attr1 = 0, attr3 = 0, attr4 = 0, attr5 = 0, attr6 = 0, attr7 = 0;
+    static AttrMask attr1{0}, attr3{0}, attr4{0}, attr5{0}, attr6{0}, attr7{0};
 #define XFH_B1_LAUNCH(MODE, ATTR)                                                                                                       \
     {                                                                                                                                    \
         constexpr int lds_floats = MODE >= 5 ? b1::F_LDS_FLOATS : b1::LDS_FLOATS;                                                        \

@@ -25,7 +25,7 @@ static int run_rs64(const ConvW& c, const ConvW* c2, const float* in, int B, int
     if ((long long)(H + 4) * a.P + 512 >= (1 << 20)) return -1;               // row_of (conv_rs64_body.hpp): positions below 2^20 (exact there for every P <= 127: tests/test_conv_rs64_emulated.py)
     if (a.nseg > rs64::max_nseg(FUSE != 0)) return -1;                       // the rings of a wider map do not fit (125 columns; 93 with the fused 1x1's buffers)
     const int lds = rs64::lds_bytes(a.nseg, FUSE != 0);
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_rs64_kernel<FUSE>), rs64::lds_bytes(rs64::max_nseg(FUSE != 0), FUSE != 0), attr_done);
     int grid = num_cus();                      // one workgroup (four waves, one per SIMD) per CU
     a.k = rs64::runs_per_image(B, a.nu, grid);
@@ -33,7 +33,7 @@ static int run_rs64(const ConvW& c, const ConvW* c2, const float* in, int B, int
     if (nruns < grid) grid = (int)nruns;
     if constexpr (FUSE != 1) {
         if (trace) {      // the stamped twin (debug: xfh_debug_trace)
-            static unsigned attr_done_t = 0;
+            static AttrMask attr_done_t = 0;
             set_max_dynamic_lds(reinterpret_cast<const void*>(conv_rs64_kernel<FUSE, 64, true>), rs64::lds_bytes(rs64::max_nseg(FUSE != 0), FUSE != 0), attr_done_t);
             conv_rs64_kernel<FUSE, 64, true><<<grid, 256, lds, st>>>(a);
             return 0;
@@ -65,7 +65,7 @@ int launch_conv_rs128(const ConvW& c, const float* in, int B, int H, int W, floa
     a.P = W + 2; a.inv_p = 1.f / (float)a.P; a.nu = ceil_div(H * a.P, 64); a.nseg = rs64::nseg_for(a.P);
     if ((long long)(H + 4) * a.P + 512 >= (1 << 20)) return -1;
     if (a.nseg > rs64::MAX_NSEG128) return -1;
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_rs64_kernel<0, 128>), rs64::lds_bytes128(rs64::MAX_NSEG128), attr_done);
     int groups = num_cus() / 4;                // one workgroup per CU; the four cout quarters of a run on neighbouring workgroups
     if (groups < 1) groups = 1;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 static size_t head_bx_lds(bool kp, int fxm) { return (size_t)(kp ? (fxm ? 8 : 9) : 4) * 4 * (fxm == 2 ? 2 : 3) * 1024 + ((kp ? 288 : 128) + 64) * sizeof(float) + (fxm == 3 ? 8 * 4096 : 0); }
 template <bool KP, int SHIFT, int FXM>
 static void launch_head_bx(const HeadBxArgs& h, hipStream_t st) {
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<KP, SHIFT, FXM>), 160 * 1024, attr);
     head_bx_kernel<KP, SHIFT, FXM><<<min(h.ntiles, num_cus()), 512, head_bx_lds(KP, FXM), st>>>(h);
 }
@@ -251,7 +251,7 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
     const int L[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3};
     for (int i = 0; i < 4; ++i) { a.w[i] = nw.conv[L[i]].w_kcp; a.bias[i] = nw.conv[L[i]].bias; }
     if (f32_kernels >= 2) {      // the register-input form (no activation tile, no barrier per tile); 3: with the dustbin logit on the matrix cores (round 4)
-        static unsigned attr_r = 0, attr_o = 0;
+        static AttrMask attr_r{0}, attr_o{0};
         if (f32_kernels == 3) {
             set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<true, 0, false>), 160 * 1024, attr_o);
             head_f32r_kernel<true, 0, false><<<min(a.ntiles, num_cus()), 512, (size_t)(3 * 64 * 64 + 64 * 96) * sizeof(float), st>>>(a);
@@ -262,7 +262,7 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
         return;
     }
     const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<true>), 160 * 1024, attr);
     head_fused_kernel<true><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
@@ -294,13 +294,13 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
     a.w[1] = nw.conv[L_HEAT_1].w_kcp; a.bias[1] = nw.conv[L_HEAT_1].bias;
     a.w[2] = nw.conv[L_HEAT_2].w_oihw; a.bias[2] = nw.conv[L_HEAT_2].bias;
     if (f32_kernels >= 2) {
-        static unsigned attr_r = 0;
+        static AttrMask attr_r = 0;
         set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<false>), 160 * 1024, attr_r);
         head_f32r_kernel<false><<<min(a.ntiles, num_cus()), 512, (size_t)(2 * 64 * 64 + 64) * sizeof(float), st>>>(a);
         return;
     }
     const size_t lds = (size_t)(2 * 64 * 64 + 64 + HD_CELLS * HD_XS) * sizeof(float);
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<false>), 160 * 1024, attr);
     head_fused_kernel<false><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
@@ -337,13 +337,13 @@ static void launch_kp_head_fl_shift(const HeadBxArgs& h, hipStream_t st) { launc
 template <int SHIFT>
 static void launch_kp_head_f32_shift(const HeadArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<true, SHIFT>), 160 * 1024, attr);
     head_fused_kernel<true, SHIFT><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 template <int SHIFT>
 static void launch_kp_head_f32r_shift(const HeadArgs& a, hipStream_t st) {
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<true, SHIFT>), 160 * 1024, attr);
     head_f32r_kernel<true, SHIFT><<<min(a.ntiles, num_cus()), 512, (size_t)(3 * 64 * 64 + 64 * 96) * sizeof(float), st>>>(a);
 }
