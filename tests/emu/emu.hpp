@@ -133,6 +133,12 @@ inline void dma_b128_to_lds(unsigned m0v, unsigned voff, i4 rs, unsigned soff) {
     unsigned char* dst = wg->lds_base() + m0v + 16 * (tidx.x & 63);
     if ((uint64_t)voff + 16 <= (unsigned)rs.z) std::memcpy(dst, base + voff + soff, 16); else std::memset(dst, 0, 16);
 }
+// buffer_load_dword ... lds: 4 bytes per lane to the LDS offset m0 + 4 lane; a lane whose offset is out of the resource's range (the kernels use 0x80000000) writes zero
+inline void dma_b32_to_lds(unsigned m0v, unsigned voff, i4 rs, unsigned soff) {
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(((uint64_t)((unsigned)rs.y & 0xffffu) << 32) | (unsigned)rs.x);
+    unsigned char* dst = wg->lds_base() + m0v + 4 * (tidx.x & 63);
+    if ((uint64_t)voff + 4 <= (unsigned)rs.z) std::memcpy(dst, base + voff + soff, 4); else std::memset(dst, 0, 4);
+}
 inline unsigned buffer_load_b32(Rsrc rs, unsigned voff, unsigned soff) {
     unsigned r = 0;
     if ((uint64_t)voff + 4 <= rs.bytes) std::memcpy(&r, rs.base + voff + soff, 4);

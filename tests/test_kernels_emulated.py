@@ -48,6 +48,37 @@ def _slice_conv_bx64s2():
     return "typedef int i32x4 __attribute__((ext_vector_type(4)));\n" + s
 
 
+def _slice_conv_wino():
+    """conv_wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: input planes and transformed weights by LDS-DMA into a two-slot ring, output transform through an LDS
+    exchange, optional trailing 1x1 with a K-split reduction across waves): the three DMA forms become emulator calls, the LDS address a byte offset"""
+    t = open(os.path.join(CSRC, "k_conv_wino.hip")).read()
+    s = _between(t, "struct WinoArgs {", "// ------------------------------------------------------------------------------------------\n// host side")
+    s = _must_sub(s, "__global__ __launch_bounds__(256 * (CB / NCBW) * (TBG / NTBW)) __attribute__((amdgpu_waves_per_eu(2, 2)))\nvoid conv_wino_kernel(WinoArgs a) {", "inline void conv_wino_kernel(WinoArgs a) {")
+    s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) float smem[];", "XFH_DYN_LDS(smem);")
+    s = _must_sub(s, "auto lds_addr = [](const float* p) { return (unsigned)(size_t)(lptr_t)p; };", "auto lds_addr = [&](const float* p) { return (unsigned)((p - smem) * 4); };")
+    n0 = s.count("asm volatile")
+    s = _must_sub(s, 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(uvoff), "s"(rs_u), "s"(soff) : "memory");', "emu::dma_b128_to_lds(m0v, uvoff, rs_u, soff);")
+    s = _must_sub(s, 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(m0v), "v"(xvoff[s]), "s"(rin), "s"(soff) : "memory");', "emu::dma_b32_to_lds(m0v, xvoff[s], rin, soff);")
+    s = _must_sub(s, 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(uvoff), "s"(rs_w2), "s"(soff) : "memory");', "emu::dma_b128_to_lds(m0v, uvoff, rs_w2, soff);")
+    s = s.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', ";")
+    s = re.sub(r'unsigned (\w+); asm volatile\("s_getreg_b32[^;]*;', r"unsigned \1 = 0;", s)      # (the trace's XCC / hardware ids: a.trace is NULL here)
+    assert n0 == 6 and "asm volatile" not in s, "an inline-assembly statement of conv_wino_kernel is not covered"
+    assert "<<<" not in s
+    s = s.replace("#define XFH_PIN __builtin_amdgcn_sched_barrier(0)", "#undef XFH_PIN\n#define XFH_PIN __builtin_amdgcn_sched_barrier(0)")
+    return "typedef float f32x16 __attribute__((ext_vector_type(16)));\ntypedef int i32x4 __attribute__((ext_vector_type(4)));\n#define __builtin_amdgcn_s_memrealtime() 0ll\n" + s
+
+
+def _slice_pyramid():
+    """pyramid_sum_kernel (x3 + up(x4) + up(x5): source planes and per-plane coefficient tables in LDS) with the interpolation helpers it shares with the resize kernels"""
+    t = open(os.path.join(CSRC, "k_preproc.hip")).read()
+    s = _between(t, "__device__ inline void lin_coef(", "__global__ __launch_bounds__(256) void resize_bilinear_kernel(")
+    s += _between(t, "__device__ inline float bilerp_at(", "void launch_pyramid_sum(")
+    s = _must_sub(s, "__global__ __launch_bounds__(256) void pyramid_sum_kernel(", "inline void pyramid_sum_kernel(")
+    s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) float sm[];", "XFH_DYN_LDS(sm);")
+    assert "asm volatile" not in s and "<<<" not in s
+    return s
+
+
 def _slice_conv_bx24():
     """conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0): weights in registers, one staged halo tile per output tile"""
     t = open(os.path.join(CSRC, "k_conv_bx.hip")).read()
@@ -83,10 +114,12 @@ def emu_bins():
     td = tempfile.mkdtemp()
     open(os.path.join(td, "conv_bx64s2_slice.hpp"), "w").write(_slice_conv_bx64s2())
     open(os.path.join(td, "conv_bx24_slice.hpp"), "w").write(_slice_conv_bx24())
+    open(os.path.join(td, "conv_wino_slice.hpp"), "w").write(_slice_conv_wino())
+    open(os.path.join(td, "pyramid_slice.hpp"), "w").write(_slice_pyramid())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("conv_bx64s2_slice_emu", "conv_bx24_emu"):
+    for name in ("conv_bx64s2_slice_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -132,6 +165,45 @@ def test_conv_bx24_kernels_on_the_host(emu_bins, stride, fx, shape, grid):
     d = np.abs(y - ref.numpy())
     print(f"conv_bx24 stride {stride} fx {fx} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
     assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0 and np.isfinite(y).all() and d.max() <= 3e-6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("cin,fuse,shape,tall", [(64, 0, (1, 8, 16), 0), (64, 1, (2, 9, 13), 1), (64, 2, (1, 16, 8), 1), (128, 0, (1, 6, 10), 0), (128, 1, (2, 15, 20), 0), (128, 0, (1, 15, 20), 1)])
+def test_conv_wino_kernel_on_the_host(emu_bins, cin, fuse, shape, tall):
+    """Winograd F(2x2,3x3) on the f32 matrix cores (block5.1, block5.2 + 5.3 on the default path; every >= 64-channel 3x3/s1 layer under option wino): 64 and 128 channels, alone and
+    with the trailing 1x1 fused (NCHW / channels-last output, the K-split reduction across two or four waves), both tile-region shapes, full and partial regions, odd sizes"""
+    B, H, W = shape
+    g = torch.Generator().manual_seed(cin + fuse)
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g)) * 2
+    w = torch.randn(cin, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cin, generator=g) * 0.3
+    w2 = torch.randn(64, cin, generator=g) / cin ** 0.5
+    b2 = torch.randn(64, generator=g) * 0.3
+    out = subprocess.run([emu_bins["conv_wino_emu"]], input=_blob([B, H, W, cin, fuse, 1, 0, tall], [x, w, b] + ([w2, b2] if fuse else [])), capture_output=True, check=True, timeout=600).stdout
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1))
+    if fuse:
+        ref = torch.nn.functional.conv2d(ref, w2.double().view(64, cin, 1, 1), b2.double())
+    y = np.frombuffer(out, np.float32)
+    y = y.reshape(B, H, W, 64).transpose(0, 3, 1, 2) if fuse == 2 else y.reshape(tuple(ref.shape))
+    d = np.abs(y - ref.numpy())
+    print(f"conv_wino cin {cin} fuse {fuse} {shape} tall {tall}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
+    assert np.isfinite(y).all() and d.max() <= 1e-6 * float(ref.abs().max())      # (Winograd's transforms cost a few ulps: DESIGN 3.2)
+
+
+@pytest.mark.parametrize("shape,use_lds", [((3, 12, 16), 1), ((2, 60, 80), 1), ((2, 9, 14), 1), ((2, 12, 16), 0), ((1, 10, 13), 0)])
+def test_pyramid_sum_kernel_on_the_host(emu_bins, shape, use_lds):
+    """x3 + up(x4) + up(x5) (modules/model.py:146-148: F.interpolate bilinear, align_corners=False): planes whose width is / is not a multiple of four (float4 / scalar path),
+    the LDS-staged form with its coefficient tables and the direct-gather fall-back, against ATen in float64"""
+    planes, H3, W3 = shape
+    H4, W4, H5, W5 = (H3 + 1) // 2, (W3 + 1) // 2, (H3 + 3) // 4, (W3 + 3) // 4
+    g = torch.Generator().manual_seed(H3 * W3)
+    x3, x4, x5 = torch.randn(1, planes, H3, W3, generator=g), torch.randn(1, planes, H4, W4, generator=g), torch.randn(1, planes, H5, W5, generator=g)
+    out = subprocess.run([emu_bins["pyramid_emu"]], input=_blob([planes, H3, W3, H4, W4, H5, W5, use_lds], [x3, x4, x5]), capture_output=True, check=True, timeout=240).stdout
+    F = torch.nn.functional
+    ref = x3.double() + F.interpolate(x4.double(), (H3, W3), mode="bilinear") + F.interpolate(x5.double(), (H3, W3), mode="bilinear")
+    y = np.frombuffer(out, np.float32).reshape(1, planes, H3, W3)
+    d = np.abs(y - ref.numpy())
+    print(f"pyramid_sum {shape} lds {use_lds}: max |err| {d.max():.3g}")
+    assert np.isfinite(y).all() and d.max() <= 2e-6
 
 
 # (main's end-to-end test of the sliced kernels against the reference-made goldens lives in tests/test_prepared_defaults_emulated.py on this branch: the kernel bodies are

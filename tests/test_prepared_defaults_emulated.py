@@ -35,10 +35,11 @@ def bins():
         pytest.skip("no host clang")
     td = tempfile.mkdtemp()
     import test_kernels_emulated as sliced      # (the 24-channel kernels are still emulated as slices of k_conv_bx.hip on this branch)
-    for fname, fn in (("conv_bx24_slice.hpp", sliced._slice_conv_bx24), ("weight_split_slice.hpp", sliced._slice_weight_split), ("bx_split_slice.hpp", sliced._slice_bx_split)):
+    for fname, fn in (("conv_bx24_slice.hpp", sliced._slice_conv_bx24), ("weight_split_slice.hpp", sliced._slice_weight_split), ("bx_split_slice.hpp", sliced._slice_bx_split),
+                      ("pyramid_slice.hpp", sliced._slice_pyramid)):
         open(os.path.join(td, fname), "w").write(fn())
     out = Bins()
-    for name in ("block1_emu", "head_emu", "conv_bx24_emu", "conv_bx64s2_emu", "conv_rs64_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx24_emu", "conv_bx64s2_emu", "conv_rs64_emu", "pyramid_emu"):
         out.append(os.path.join(td, name))
         out.by_name[name] = out[-1]
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", os.path.join(ROOT, "accelerated_features_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "emu"),
@@ -114,11 +115,13 @@ def run_rel_head(bins, sd, feats, fx):
     return torch.from_numpy(np.frombuffer(out[:4 * len(cl)], np.float32).reshape(B, 1, h, w).copy())
 
 
-def conv_emu(bins, kind, hdr, x, tensors, shape, cl=False):
+def conv_emu(bins, kind, hdr, x, tensors, shape, cl=False, status=True):
     blob = np.concatenate([np.array(hdr, np.int32).view(np.float32)] + [np.asarray(a, np.float32).reshape(-1) for a in [x] + tensors]).tobytes()
     out = subprocess.run([bins.by_name[kind]], input=blob, capture_output=True, check=True, timeout=3000).stdout
-    assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0, (kind, hdr, "an activation left the range of the fp16 pair")
-    y = torch.from_numpy(np.frombuffer(out[:-4], np.float32).copy())
+    if status:
+        assert int(np.frombuffer(out[-4:], np.int32)[0]) == 0, (kind, hdr, "an activation left the range of the fp16 pair")
+        out = out[:-4]
+    y = torch.from_numpy(np.frombuffer(out, np.float32).copy())
     return y.view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2).contiguous() if cl else y.view(shape)
 
 
@@ -126,7 +129,7 @@ def rest_of_backbone_prepared(bins, sd, x1):
     """block2 .. block_fusion.2 on the kernels this branch would route the bench batch to with every prepared form on (fx = 1 | 2 | 128 | 256 | 512 | 1024): the 24-channel
     layers on conv_bx_kernel / conv_bxs2_kernel (shipped), every 64 -> 64 3x3 layer on conv_rs64_kernel (weights resident in registers; block3.1 + 3.2 and block_fusion.1 + .2
     with the trailing 1x1 fused, the latter channels-last), block5.1 / 5.2 on its 128-channel form, block4.0 / block5.0 on conv_bx64s2x_kernel -- 16 of the 17 convolution
-    layers; block5.3 (a 1x1 of its own on the f32 matrix cores) and the pyramid sum stay with the oracle.  Every kernel's range flag must stay clear on the fixtures."""
+    layers, pyramid_sum_kernel between them; block5.3 (a 1x1 of its own on the f32 matrix cores) stays with the oracle.  Every kernel's range flag must stay clear on the fixtures."""
     B, _, H4, W4 = x1.shape
     H8, W8, H16, W16, H32, W32 = H4 // 2, W4 // 2, H4 // 4, W4 // 4, H4 // 8, W4 // 8
     a = conv_emu(bins, "conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], x1, list(fold(sd, "block2.0")), (B, 24, H4, W4))
@@ -141,7 +144,7 @@ def rest_of_backbone_prepared(bins, sd, x1):
     x5 = conv_emu(bins, "conv_rs64_emu", [B, H32, W32, 1, 2, 0, 128, 0], x5, list(fold(sd, "block5.1")), (B, 128, H32, W32))
     x5 = conv_emu(bins, "conv_rs64_emu", [B, H32, W32, 1, 1, 0, 128, 0], x5, list(fold(sd, "block5.2")), (B, 128, H32, W32))
     x5 = O._basic(sd, "block5.3", x5, 1, 1)
-    f = x3 + F.interpolate(x4, (H8, W8), mode="bilinear") + F.interpolate(x5, (H8, W8), mode="bilinear")
+    f = conv_emu(bins, "pyramid_emu", [B * 64, H8, W8, H16, W16, H32, W32, 1], x3, [x4, x5], (B, 64, H8, W8), status=False)      # pyramid_sum_kernel (sliced, shipped)
     f = conv_emu(bins, "conv_rs64_emu", [B, H8, W8, 1, 3, 0, 0, 0], f, list(fold(sd, "block_fusion.0")), (B, 64, H8, W8))
     return conv_emu(bins, "conv_rs64_emu", [B, H8, W8, 1, 3, 0, 2, 0], f, list(fold(sd, "block_fusion.1")) + [sd["block_fusion.2.weight"].view(64, 64).float(), sd["block_fusion.2.bias"].float()],
                     (B, 64, H8, W8), cl=True)
