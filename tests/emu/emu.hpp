@@ -117,6 +117,15 @@ inline float shfl_xor(float v, int mask) {
     wg->wave_bar[w]->arrive_and_wait();
     return r;
 }
+inline double shfl_xor(double v, int mask) {      // (a thread's exchange slot is 32 bytes wide)
+    const int t = tidx.x, w = t >> 6, l = t & 63;
+    std::memcpy(&wg->opa32[t * 8], &v, 8);
+    wg->wave_bar[w]->arrive_and_wait();
+    double r;
+    std::memcpy(&r, &wg->opa32[(w * 64 + (l ^ mask)) * 8], 8);
+    wg->wave_bar[w]->arrive_and_wait();
+    return r;
+}
 inline void dma(const void* g, void* l_base, int size) { std::memcpy(static_cast<unsigned char*>(l_base) + size * (tidx.x & 63), g, size); }      // (M0 base + lane x size)
 struct Rsrc { unsigned char* base; unsigned bytes; };
 typedef unsigned u4 __attribute__((ext_vector_type(4)));

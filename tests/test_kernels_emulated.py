@@ -79,6 +79,20 @@ def _slice_pyramid():
     return s
 
 
+def _slice_gray():
+    """gray_stats_kernel<CT> (channel mean + fp64 partial sums per chunk) and gray_coef_kernel (the instance normalisation as {alpha, beta} per image): the 2-D grid becomes a
+    1-D one, the static LDS array a pointer into the emulator's LDS"""
+    t = open(os.path.join(CSRC, "k_preproc.hip")).read()
+    s = _between(t, "constexpr int GS_UNROLL = 5;", "// uint8 ingest (XFeat.parse_input")
+    s += _between(t, "__global__ __launch_bounds__(64) void gray_coef_kernel(", "void launch_gray_norm(")
+    s = _must_sub(s, "__global__ __launch_bounds__(256) void gray_stats_kernel(", "inline void gray_stats_kernel(")
+    s = _must_sub(s, "__global__ __launch_bounds__(64) void gray_coef_kernel(", "inline void gray_coef_kernel(")
+    s = _must_sub(s, "const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;", "const int b = blockIdx.x / GS_CHUNKS, ch = blockIdx.x % GS_CHUNKS, tid = threadIdx.x;")
+    s = _must_sub(s, "__shared__ double sm[8];", "double* sm = reinterpret_cast<double*>(emu::wg->lds_base());")
+    assert "asm volatile" not in s and "<<<" not in s and "blockIdx.y" not in s
+    return s
+
+
 def _slice_conv_bx24():
     """conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0): weights in registers, one staged halo tile per output tile"""
     t = open(os.path.join(CSRC, "k_conv_bx.hip")).read()
@@ -116,10 +130,11 @@ def emu_bins():
     open(os.path.join(td, "conv_bx24_slice.hpp"), "w").write(_slice_conv_bx24())
     open(os.path.join(td, "conv_wino_slice.hpp"), "w").write(_slice_conv_wino())
     open(os.path.join(td, "pyramid_slice.hpp"), "w").write(_slice_pyramid())
+    open(os.path.join(td, "gray_slice.hpp"), "w").write(_slice_gray())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("conv_bx64s2_slice_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu"):
+    for name in ("conv_bx64s2_slice_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu", "gray_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -204,6 +219,23 @@ def test_pyramid_sum_kernel_on_the_host(emu_bins, shape, use_lds):
     d = np.abs(y - ref.numpy())
     print(f"pyramid_sum {shape} lds {use_lds}: max |err| {d.max():.3g}")
     assert np.isfinite(y).all() and d.max() <= 2e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 96, 128), (1, 1, 64, 96), (2, 2, 32, 40), (1, 3, 480, 640)])
+def test_gray_stats_kernels_on_the_host(emu_bins, shape):
+    """x.mean(1) and InstanceNorm2d(1) (modules/model.py:135-136, 35) as the raw gray image + a per-image {alpha, beta}: three, one and "any" channels (the three instantiations),
+    chunks that end inside a 256-thread row, VGA -- against float64"""
+    B, C, H, W = shape
+    x = torch.rand(B, C, H, W, generator=torch.Generator().manual_seed(C * H)) * 3 - 1
+    out = subprocess.run([emu_bins["gray_emu"]], input=_blob([B, C, H, W], [x]), capture_output=True, check=True, timeout=240).stdout
+    gray = np.frombuffer(out[:4 * B * H * W], np.float32).reshape(B, H, W)
+    coef = np.frombuffer(out[4 * B * H * W:], np.float32).reshape(B, 2)
+    gd = x.double().mean(1)
+    alpha = 1.0 / torch.sqrt(gd.var((1, 2), unbiased=False) + 1e-5)
+    ref = torch.stack([alpha, -gd.mean((1, 2)) * alpha], 1).numpy()
+    e_g, e_c = float(np.abs(gray - gd.numpy()).max()), float(np.abs(coef / ref - 1).max())
+    print(f"gray_stats {shape}: gray max |err| {e_g:.3g}, coef max rel err {e_c:.3g}")
+    assert np.isfinite(gray).all() and e_g <= 3e-7 and e_c <= 1e-6      # (gray: an fp32 sum of C values and one division)
 
 
 # (main's end-to-end test of the sliced kernels against the reference-made goldens lives in tests/test_prepared_defaults_emulated.py on this branch: the kernel bodies are

@@ -36,10 +36,10 @@ def bins():
     td = tempfile.mkdtemp()
     import test_kernels_emulated as sliced      # (the 24-channel kernels are still emulated as slices of k_conv_bx.hip on this branch)
     for fname, fn in (("conv_bx24_slice.hpp", sliced._slice_conv_bx24), ("weight_split_slice.hpp", sliced._slice_weight_split), ("bx_split_slice.hpp", sliced._slice_bx_split),
-                      ("pyramid_slice.hpp", sliced._slice_pyramid)):
+                      ("pyramid_slice.hpp", sliced._slice_pyramid), ("gray_slice.hpp", sliced._slice_gray)):
         open(os.path.join(td, fname), "w").write(fn())
     out = Bins()
-    for name in ("block1_emu", "head_emu", "conv_bx24_emu", "conv_bx64s2_emu", "conv_rs64_emu", "pyramid_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx24_emu", "conv_bx64s2_emu", "conv_rs64_emu", "pyramid_emu", "gray_emu"):
         out.append(os.path.join(td, name))
         out.by_name[name] = out[-1]
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", os.path.join(ROOT, "accelerated_features_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "emu"),
@@ -198,8 +198,11 @@ def test_every_prepared_kernel_in_one_chain_keeps_the_references_key_points(bins
         else:
             g = np.load(os.path.join(ROOT, "tests", "golden", "g2_vga_pair.npz")); x = torch.cat(fixtures.shifted_pair(1, 480, 640, seed=7)); top_k = 4096
             gold = [{"keypoints": g[f"kp_{t}"].astype(np.float32), "scores": g[f"sc_{t}"]} for t in ("a", "b")]
-        B, _, H, W = x.shape
-        gray, coef = gray_coef(x)
+        B, Cc, H, W = x.shape
+        o_ = subprocess.run([bins.by_name["gray_emu"]], input=np.concatenate([np.array([B, Cc, H, W], np.int32).view(np.float32), x.numpy().reshape(-1)]).tobytes(),
+                            capture_output=True, check=True, timeout=600).stdout      # gray_stats_kernel + gray_coef_kernel (sliced, shipped)
+        gray = torch.from_numpy(np.frombuffer(o_[:4 * B * H * W], np.float32).reshape(B, H, W).copy())
+        coef = torch.from_numpy(np.frombuffer(o_[4 * B * H * W:], np.float32).reshape(B, 2).copy())
         _, _, _, taps = O.backbone(sd, x, keep=True)
         oheat = O.kpts_heatmap(taps["logits"])
         x1 = run_block1(bins, sd, gray, coef, 7)
