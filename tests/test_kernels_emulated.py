@@ -93,6 +93,23 @@ def _slice_gray():
     return s
 
 
+def _slice_match_sweep():
+    """mnn_f16_sweep_kernel with its constants and the 16-value maximum tree: the three static LDS arrays become pointers into the emulator's LDS, the register keep-alive an
+    empty statement"""
+    t = open(os.path.join(CSRC, "k_match_f16.hip")).read()
+    s = _between(t, "typedef float f32x16 __attribute__((ext_vector_type(16)));", "// 16 lanes per descriptor row (float4 each), 16 rows per pass")
+    s += _between(t, "// maximum of 16 accumulator values as a v_max3_f32 tree (8 ops)", "// E in the units of the scaled product")
+    s += _between(t, "constexpr int FT_TILES = FT_COLS / 32;", "// thresholds, once the maxima are complete")
+    s = _must_sub(s, "__global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(", "inline void mnn_f16_sweep_kernel(")
+    s = _must_sub(s, "__shared__ __attribute__((aligned(16))) _Float16 Dl[FT_COLS * FT_DS];", "_Float16* Dl = reinterpret_cast<_Float16*>(emu::wg->lds_base());")
+    s = _must_sub(s, "__shared__ float colx[8][FT_COLS];", "float (*colx)[FT_COLS] = reinterpret_cast<float (*)[FT_COLS]>(emu::wg->lds_base() + sizeof(_Float16) * FT_COLS * FT_DS);")
+    s = _must_sub(s, "__shared__ int next_block;", "int& next_block = *reinterpret_cast<int*>(emu::wg->lds_base() + sizeof(_Float16) * FT_COLS * FT_DS + sizeof(float) * 8 * FT_COLS);")
+    s = _must_sub(s, "XFH_KEEP_FRAGS(bfrag[ct & 1]);", ";")
+    s = _must_sub(s, "nxt = __builtin_amdgcn_readfirstlane(t);", "nxt = emu_bcast0(t);")      # (only lane 0 holds t: a real broadcast, emu.hpp's readfirstlane is the identity)
+    assert "asm volatile" not in s and "<<<" not in s and "__shared__" not in s
+    return s
+
+
 def _slice_conv_bx24():
     """conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0): weights in registers, one staged halo tile per output tile"""
     t = open(os.path.join(CSRC, "k_conv_bx.hip")).read()
@@ -131,10 +148,11 @@ def emu_bins():
     open(os.path.join(td, "conv_wino_slice.hpp"), "w").write(_slice_conv_wino())
     open(os.path.join(td, "pyramid_slice.hpp"), "w").write(_slice_pyramid())
     open(os.path.join(td, "gray_slice.hpp"), "w").write(_slice_gray())
+    open(os.path.join(td, "match_sweep_slice.hpp"), "w").write(_slice_match_sweep())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("conv_bx64s2_slice_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu", "gray_emu"):
+    for name in ("conv_bx64s2_slice_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu", "gray_emu", "match_sweep_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -236,6 +254,32 @@ def test_gray_stats_kernels_on_the_host(emu_bins, shape):
     e_g, e_c = float(np.abs(gray - gd.numpy()).max()), float(np.abs(coef / ref - 1).max())
     print(f"gray_stats {shape}: gray max |err| {e_g:.3g}, coef max rel err {e_c:.3g}")
     assert np.isfinite(gray).all() and e_g <= 3e-7 and e_c <= 1e-6      # (gray: an fp32 sum of C values and one division)
+
+
+@pytest.mark.parametrize("P,N1,N2,n1,n2,nsplit", [(1, 96, 64, 96, 64, 1), (2, 300, 280, 290, 259, 0), (1, 520, 300, 520, 300, 2), (1, 40, 700, 33, 690, 0)])
+def test_match_sweep_kernel_on_the_host(emu_bins, P, N1, N2, n1, n2, nsplit):
+    """The matcher's filter pass (modules/xfeat.py:327-348 computes D1 @ D2.T; here one fp16-MFMA sweep that keeps only maxima): row / column maxima and the per-block maxima
+    R / C of the fp16 product against numpy on the same fp16 numbers -- several column chunks (N2 > 256), row blocks shared out over workgroups (nsplit), partial blocks, valid
+    counts below the capacity (the rows / columns beyond them must not leak into any maximum)."""
+    g = torch.Generator().manual_seed(N1 + N2)
+    a = torch.nn.functional.normalize(torch.randn(P, N1, 64, generator=g), dim=-1) * 256
+    b = torch.nn.functional.normalize(torch.randn(P, N2, 64, generator=g), dim=-1) * 256
+    a[:, n1:] = 1.0e3; b[:, n2:] = 1.0e3                      # beyond the valid counts: rows that would win every maximum if they were read
+    a16, b16 = a.half().float(), b.half().float()
+    out = subprocess.run([emu_bins["match_sweep_emu"]], input=_blob([P, N1, N2, n1, n2, nsplit], [a16, b16]), capture_output=True, check=True, timeout=300).stdout
+    y = np.frombuffer(out, np.float32)
+    ncb, nrb = -(-N2 // 32), -(-N1 // 32)
+    rm, cm = y[:P * N1].reshape(P, N1), y[P * N1:P * (N1 + N2)].reshape(P, N2)
+    R = y[P * (N1 + N2):P * (N1 + N2) + P * ncb * N1].reshape(P, ncb, N1)
+    C = y[P * (N1 + N2) + P * ncb * N1:].reshape(P, nrb, N2)
+    S = (a16.double() @ b16.double().transpose(1, 2)).numpy()[:, :n1, :n2]
+    tol = 1e-6 * float(np.abs(S).max()) + 1e-3
+    assert np.abs(rm[:, :n1] - S.max(2)).max() <= tol and np.abs(cm[:, :n2] - S.max(1)).max() <= tol
+    for cb in range(-(-n2 // 32)):
+        assert np.abs(R[:, cb, :n1] - S[:, :, cb * 32:(cb + 1) * 32].max(2)).max() <= tol, ("R", cb)
+    for rb in range(-(-n1 // 32)):
+        assert np.abs(C[:, rb, :n2] - S[:, rb * 32:(rb + 1) * 32, :].max(1)).max() <= tol, ("C", rb)
+    print(f"match sweep P {P} {N1} x {N2} (valid {n1} x {n2}): row / column / block maxima within {tol:.3g} of numpy (max |S| {float(np.abs(S).max()):.4g})")
 
 
 # (main's end-to-end test of the sliced kernels against the reference-made goldens lives in tests/test_prepared_defaults_emulated.py on this branch: the kernel bodies are
