@@ -65,6 +65,7 @@ SIGNATURES = {
     "xfh_debug_head_soak": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, C.c_uint, _p]),
     "xfh_debug_match_occupancy": (_i, []),
     "xfh_debug_cold_start": (_i, [_i]),
+    "xfh_debug_block1": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "xfh_set_option": (_i, [_p, C.c_char_p, _i]),
     "xfh_get_option": (_i, [_p, C.c_char_p, C.POINTER(_i)]),
     "xfh_set_status_buffer": (_i, [_p, _p]),

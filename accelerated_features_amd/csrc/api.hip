@@ -2,6 +2,8 @@
 // launch sequences of the hot path.  No compute happens on the host; there is no CPU fallback.
 #include "../../include/xfeat_hip.h"
 #include "kernels.hpp"
+#include "weight_split.hpp"
+#include "block1_fx.hpp"
 
 #include <cmath>
 #include <cstdarg>
@@ -245,69 +247,6 @@ static int check_ws(const void* ws, size_t have, size_t need) {
     return XFH_OK;
 }
 
-static uint16_t bf16_rne(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-static float bf16_float(uint16_t h) {
-    const uint32_t u = (uint32_t)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-
-// fp32 -> fp16, round to nearest even (subnormals kept, overflow -> inf) and back: the host side of the two-term fp16 weights
-static uint16_t f16_rne(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    const uint32_t sign = (u >> 16) & 0x8000u;
-    u &= 0x7fffffffu;
-    if (u >= 0x7f800000u) return (uint16_t)(sign | (u > 0x7f800000u ? 0x7e00u : 0x7c00u));      // NaN / inf
-    if (u >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                       // >= 65520: rounds to inf
-    if (u < 0x38800000u) {                                                                        // < 2^-14: subnormal result, spacing 2^-24
-        if (u < 0x33000000u) return (uint16_t)sign;                                               // < 2^-25: rounds to zero (2^-25 itself ties to even = 0)
-        const int e = (int)(u >> 23);                                                             // biased fp32 exponent, 102 .. 112
-        const uint32_t m = (u & 0x7fffffu) | 0x800000u;                                           // 24-bit significand
-        const int sh = 126 - e;                                                                   // value = m * 2^(e - 150); result units of 2^-24: m >> (126 - e)
-        const uint32_t q = m >> sh, rem = m & ((1u << sh) - 1u), halfway = 1u << (sh - 1);
-        return (uint16_t)(sign | (q + ((rem > halfway || (rem == halfway && (q & 1u))) ? 1u : 0u)));
-    }
-    const uint32_t v = u - 0x38000000u;                                                           // rebias 127 -> 15
-    return (uint16_t)(sign | ((v + 0xfffu + ((v >> 13) & 1u)) >> 13));
-}
-static float f16_float(uint16_t h) {
-    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
-    uint32_t u;
-    if (e == 0) {
-        const float f = (float)m * 5.9604644775390625e-8f;                                        // m * 2^-24, exact
-        memcpy(&u, &f, 4);
-        u |= sign;
-    } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
-    else u = sign | ((e + 112u) << 23) | (m << 13);
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-// The three weight fragments of one fp32 weight, per arithmetic of the split-operand MFMA kernels (k_conv_bx*.hip, k_heads.hip):
-//   mode 0: bf16, w = q0 + q1 + q2 (three-way split, round to nearest even)
-//   mode 1: fp16 at scale 2^11 ("fx"): q0 = fp16(2^11 w), q2 = fp16(2^11 w - q0) -- together 22 bits of 2^11 w, multiplied with the activation's high
-//           part -- and q1 = fp16(w), multiplied with the activation's 2^11-scaled low part: all three products carry the factor 2^11
-static void split_weight(float v, int mode, uint16_t (&q)[3]) {
-    if (mode == 0) {
-        q[0] = bf16_rne(v);
-        const float r1 = v - bf16_float(q[0]);
-        q[1] = bf16_rne(r1);
-        q[2] = bf16_rne(r1 - bf16_float(q[1]));
-    } else {
-        const float s = v * 2048.f;                    // exact
-        q[0] = f16_rne(s);
-        q[1] = f16_rne(v);
-        q[2] = f16_rne(s - f16_float(q[0]));            // exact difference
-    }
-}
-constexpr float kFxMaxWeight = 31.f;                   // |w| * 2^11 must stay below the fp16 maximum (65504)
 
 // ------------------------------------------------------------------------------------------
 // exported functions
@@ -336,7 +275,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     std::vector<float> blob;
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
     const size_t zoff = reserve(256);
-    struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx; bool has_wino, has_bx, fx_ok; } coff[L_NUM];
+    struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx, fq, rs; bool has_wino, has_bx, fx_ok, has_fq, has_rs; } coff[L_NUM];
     struct FOff { size_t w, b; } foff[5];
     int ai = 0;
     for (int li = 0; li < L_NUM; ++li) {
@@ -414,16 +353,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
             (mode == 0 ? coff[li].bx : coff[li].fx) = off;
             uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[off]);
             uint16_t q[3];
-            if (bx1x1)        // trailing 1x1 fused into conv_bx64_kernel: K order of the 3x3's D registers (as the heads' chained layers): [K step 4][cout block 2][split 3][lane][8]
-                for (int t = 0; t < 4; ++t)
-                    for (int mb = 0; mb < 2; ++mb)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int i = 0; i < 8; ++i) {
-                                const int o = mb * 32 + (lane & 31), hf = lane >> 5;
-                                const int ch = 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
-                                split_weight(blob[coff[li].oihw + (size_t)o * 64 + ch], mode, q);
-                                for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * 2 + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                            }
+            if (bx1x1) pack_bx1x1(&blob[coff[li].oihw], mode, dst);      // trailing 1x1 fused into conv_bx64_kernel (weight_split.hpp)
             if (bx24)         // [step][split][lane = half * 32 + cout][8]
                 for (int st = 0; st < nstep; ++st)
                     for (int lane = 0; lane < 64; ++lane) {
@@ -447,17 +377,30 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                                 for (int sp = 0; sp < 3; ++sp) dst[((((size_t)cb * nstep + st) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                             }
                         }
-            if (bx64 || bx64s2)      // [cout half][cin/16][dy][dx][cout block][split][lane = half * 32 + cout][8]: channel = 16 chunk + 8 half + i
-                for (int hf = 0; hf < nhf; ++hf)
-                    for (int ch = 0; ch < nch; ++ch)
-                        for (int tap = 0; tap < 9; ++tap)
-                            for (int cb = 0; cb < 2; ++cb)
-                                for (int lane = 0; lane < 64; ++lane)
-                                    for (int i = 0; i < 8; ++i) {
-                                        const int o = hf * 64 + cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
-                                        split_weight(blob[coff[li].oihw + ((size_t)o * c.cin + ci) * 9 + tap], mode, q);
-                                        for (int sp = 0; sp < 3; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                                    }
+            if (bx64 || bx64s2) pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, mode, dst);      // (weight_split.hpp)
+        }
+        coff[li].has_rs = false;
+        if (bx1x1 && coff[li].fx_ok) {      // the 1x1 behind a 64 -> 64 3x3 in conv_rs64_kernel's order (16 couts per wave, natural K order)
+            coff[li].rs = reserve((size_t)4 * 2 * 3 * 64 * 4);
+            pack_rs64_1x1(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
+            coff[li].has_rs = true;
+        }
+        if (c.ks == 3 && c.stride == 1 && c.cin == 128 && c.cout == 128) {      // block5.1, block5.2: conv_rs64_kernel's 128-channel form (fp16 pair only)
+            float wmax = 0.f;
+            for (size_t i = 0; i < (size_t)128 * 128 * 9; ++i) wmax = std::max(wmax, std::fabs(blob[coff[li].oihw + i]));
+            if (wmax < kFxMaxWeight) {
+                coff[li].rs = reserve(4 * kRs64Halfs / 2);
+                pack_rs128(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
+                coff[li].has_rs = true;
+            }
+        }
+        coff[li].has_fq = bx64 && coff[li].fx_ok;
+        if (coff[li].has_fq) {      // two fragments per weight (q0, q2): conv_bx64_body.hpp FXM 2
+            coff[li].fq = reserve((size_t)(c.cin / 16) * 9 * 2 * 2 * 64 * 4);
+            pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, 1, reinterpret_cast<uint16_t*>(&blob[coff[li].fq]), 2);
+            coff[li].rs = reserve(kRs64Halfs / 2);      // the same three fragments in conv_rs64_kernel's order (one K quarter per wave)
+            pack_rs64(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
+            coff[li].has_rs = true;
         }
     }
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].
@@ -466,38 +409,47 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     size_t head_off[2][2] = {{0, 0}, {0, 0}}, head_boff[2] = {0, 0};      // [arithmetic: 0 = bf16 x3, 1 = fp16 pair][head]
     bool head_fx_ok[2] = {true, true};
     float head_b_last = 0.f;
-    for (int mode = 0; mode < 2; ++mode) {
+    size_t head_fq_off[2] = {0, 0};
+    for (int mode = 0; mode < 3; ++mode) {      // 0: bf16 x3, 1: fp16 pair (three fragments), 2: fp16 pair with q0 / q2 alone
         const int kp[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3}, rel[2] = {L_HEAT_0, L_HEAT_1};
         for (int hd = 0; hd < 2; ++hd) {
             const int nl = hd == 0 ? 4 : 2;
             const int* ls = hd == 0 ? kp : rel;
             size_t words = 0, nbias = 0;
-            for (int p = 0; p < nl; ++p) { const int mbo = (kConvs[ls[p]].cout + 31) / 32; words += (size_t)4 * mbo * 3 * 64 * 4; nbias += 32 * mbo; }
-            head_off[mode][hd] = reserve(words);
+            // (the fp16-pair images hold 64 of keypoint_head.3's 65 outputs: the dustbin logit is a dot product on the vector ALUs there -- head_bx_body.hpp)
+            auto couts = [&](int p) { return mode && hd == 0 && p == 3 ? 64 : kConvs[ls[p]].cout; };
+            for (int p = 0; p < nl; ++p) { words += (size_t)4 * ((couts(p) + 31) / 32) * (mode == 2 ? 2 : 3) * 64 * 4; nbias += 32 * ((kConvs[ls[p]].cout + 31) / 32); }
+            (mode == 2 ? head_fq_off[hd] : head_off[mode][hd]) = reserve(words);
             if (mode == 0) head_boff[hd] = reserve(nbias);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[head_off[mode][hd]]);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[mode == 2 ? head_fq_off[hd] : head_off[mode][hd]]);
             size_t bo = head_boff[hd];
             for (int p = 0; p < nl; ++p) {
                 const ConvSpec& c = kConvs[ls[p]];
                 const int mbo = (c.cout + 31) / 32;
-                for (int t = 0; t < 4; ++t)
-                    for (int mb = 0; mb < mbo; ++mb)
-                        for (int lane = 0; lane < 64; ++lane)
-                            for (int i = 0; i < 8; ++i) {
-                                const int o = mb * 32 + (lane & 31), hf = lane >> 5;
-                                const int ch = p == 0 ? 16 * t + 8 * hf + i : 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
-                                const float v = o < c.cout ? blob[coff[ls[p]].oihw + (size_t)o * 64 + ch] : 0.f;
-                                if (!(std::fabs(v) < kFxMaxWeight)) head_fx_ok[hd] = false;
-                                uint16_t q[3];
-                                split_weight(v, mode, q);
-                                for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * mbo + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                            }
-                dst += (size_t)4 * mbo * 3 * 64 * 8;
+                for (size_t i = 0; i < (size_t)c.cout * 64; ++i)
+                    if (!(std::fabs(blob[coff[ls[p]].oihw + i]) < kFxMaxWeight)) head_fx_ok[hd] = false;
+                dst += pack_head_layer(&blob[coff[ls[p]].oihw], couts(p), p == 0, mode ? 1 : 0, dst, mode == 2 ? 2 : 3);      // (weight_split.hpp)
                 for (int o = 0; o < 32 * mbo; ++o) blob[bo + o] = o < c.cout ? blob[coff[ls[p]].bias + o] : 0.f;
                 bo += 32 * mbo;
             }
         }
         head_b_last = blob[coff[L_HEAT_2].bias];
+    }
+    // block1.3 (8 -> 24, stride 2) for block1_fused_kernel<6>: the compact fp16-pair image of block1_fx.hpp (only if every |w| stays below kFxMaxWeight)
+    size_t b1fx_off = 0;
+    bool b1fx_ok = true;
+    {
+        const float* wkc = &blob[coff[L_BLOCK1_3].kc];
+        for (int i = 0; i < 8 * 9 * 24; ++i) b1fx_ok = b1fx_ok && std::fabs(wkc[i]) < kFxMaxWeight;
+        b1fx_off = reserve(b1fx::W4_BYTES / 4);
+        b1fx::pack_w4(&blob[coff[L_BLOCK1_3].kc], reinterpret_cast<uint16_t*>(&blob[b1fx_off]), [](float v, uint16_t (&q)[3]) { split_weight(v, 1, q); });
+    }
+    size_t b1fx3_off = 0;      // block1.2 (8 -> 8) for block1_fused_kernel<7>
+    {
+        const float* wkc = &blob[coff[L_BLOCK1_2].kc];
+        for (int i = 0; i < 8 * 9 * 8; ++i) b1fx_ok = b1fx_ok && std::fabs(wkc[i]) < kFxMaxWeight;
+        b1fx3_off = reserve(b1fx::W3_IMAGE_BYTES / 4);
+        b1fx::pack_w3(&blob[coff[L_BLOCK1_2].kc], reinterpret_cast<uint16_t*>(&blob[b1fx3_off]), [](float v, uint16_t (&q)[3]) { split_weight(v, 1, q); });
     }
     for (int fi = 0; fi < 5; ++fi) {
         const FineSpec& f = kFine[fi];
@@ -545,14 +497,20 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.w_wino = coff[li].has_wino ? ctx->blob + coff[li].wino : nullptr;
         w.w_bx = coff[li].has_bx ? ctx->blob + coff[li].bx : nullptr;
         w.w_fx = coff[li].has_bx && coff[li].fx_ok ? ctx->blob + coff[li].fx : nullptr;
+        w.w_fq = coff[li].has_fq ? ctx->blob + coff[li].fq : nullptr;
+        w.w_rs = coff[li].has_rs ? ctx->blob + coff[li].rs : nullptr;
     }
     ctx->nw.zeros = ctx->blob + zoff;
     for (int hd = 0; hd < 2; ++hd) {
         ctx->nw.head_bx[hd] = ctx->blob + head_off[0][hd];
         ctx->nw.head_fx[hd] = head_fx_ok[hd] ? ctx->blob + head_off[1][hd] : nullptr;
+        ctx->nw.head_fq[hd] = head_fx_ok[hd] ? ctx->blob + head_fq_off[hd] : nullptr;
         ctx->nw.head_bx_bias[hd] = ctx->blob + head_boff[hd];
     }
+    ctx->nw.block1_fx = b1fx_ok ? ctx->blob + b1fx_off : nullptr;
+    ctx->nw.block1_fx3 = b1fx_ok ? ctx->blob + b1fx3_off : nullptr;
     ctx->nw.head_rel_b_last = head_b_last;
+    ctx->nw.head_kp_b_dust = blob[coff[L_KP_3].bias + 64];
     for (int fi = 0; fi < 5; ++fi) {
         LinW& l = ctx->nw.fine[fi];
         l.k = kFine[fi].k; l.n = kFine[fi].n; l.n_pad = (kFine[fi].n + 63) / 64 * 64; l.relu = kFine[fi].bn;
@@ -595,7 +553,7 @@ size_t xfh_backbone_workspace_bytes(int B, int C, int H, int W) {
 }
 
 static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const float* in, int B, int Hin, int Win, float* out,
-                             bool nhwc, hipStream_t st) {
+                             bool nhwc, hipStream_t st, bool in_backbone = false) {      // in_backbone: the layer's neighbours are this call's (the split-format link may be used)
     const ConvW& c = h->nw.conv[layer];
     const ConvW* c2 = fused_layer >= 0 ? &h->nw.conv[fused_layer] : nullptr;
     const int pad = c.ks / 2;
@@ -614,12 +572,23 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     // "large map" = enough half-tile units for the persistent grid of conv_bx64_kernel (512 workgroups): >= 2 per workgroup in the bf16 arithmetic (B=8 164x164: 92 vs 124 us
     // stand-alone against Winograd), >= 1.5 in the fp16-pair arithmetic, whose units are a third cheaper (VGA batch 64 at 1/16 scale, 768 units: 45 us against Winograd's 54)
     const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= ((h->opt.fx & 1) ? 768 : 1024);
-    if (use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
-        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) != 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
+    // the split-format link (fx bit 64; conv_bx64_body.hpp): block_fusion.0 writes its output as fp16 pairs, block_fusion.1 (+ .2 fused) stages them by LDS-DMA alone.
+    // Both layers see the same map, so both take the same decision; the buffer between them has the size of the fp32 tensor either way.
+    const bool sp_link = in_backbone && (h->opt.fx & 65) == 65 && use_bx && ((use_bx & 2) || ((use_bx & 4) && big_map)) && h->nw.conv[L_FUSION_0].w_fx && h->nw.conv[L_FUSION_1].w_fx &&
+                         h->nw.conv[L_FUSION_2].w_fx;
+    if (sp_link && layer == L_FUSION_1 && c2 && nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, true, 1, h->status, 1, h->nw.zeros);
+    if (sp_link && layer == L_FUSION_0 && !c2 && !nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status, 2, h->nw.zeros);
+    if (rc && use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
+        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
+    if (rc && (use_bx & 16) && (h->opt.fx & 1025) == 1025 && c.w_fx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status);      // fx bit 1024: block4.0, block5.0 in the fp16-pair arithmetic
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
+    // fx bit 128 (with bit 1): the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on conv_rs64_kernel -- weights resident in registers; -1 (map too wide for its rings): the paths below
+    if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc && c.cin == 64) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace);
+    if (rc && use_bx && (h->opt.fx & 513) == 513 && c.w_rs && !c2 && !nhwc && c.cin == 128) rc = launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status);      // bit 512: block5.1, block5.2
+    if (rc && use_bx && (h->opt.fx & 257) == 257 && c.w_rs && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc, h->trace);      // bit 256: block3.1 + 3.2, block_fusion.1 + .2
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, (h->opt.fx & 2) != 0, h->status);      // (bx = 9: block3.0 stays on the f32 kernel)
-        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) != 0, h->status);      // (bx = 5: large maps only)
+        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // (bx = 5: large maps only)
     }
     if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
@@ -657,11 +626,11 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     else launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
     prof_end(&h->prof, XFH_SPAN_GRAY, st, 0, 0);
     prof_begin(&h->prof, XFH_PROF_BLOCK1, st);
-    launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st, h->opt.block1);
+    launch_block1_fused(nw, w.gray, w.coef, B, H, W, w.x1, st, h->opt.block1, h->status);
     // block1 + skip1 per input pixel: conv1 9*4*2 + conv2 36*8*2/4 + conv3 72*8*2/4 + conv4 72*24*2/16 = 720 FLOP; gray in, x1 out: 10 bytes
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 720.0 * B * H * W, 10.0 * B * H * W);
 #define CONV(layer, fused, in, hin, win, out, nhwc) \
-    if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st))) return rc
+    if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st, true))) return rc
     CONV(L_BLOCK2_0, -1, w.x1, H4, W4, w.x2a, false);
     CONV(L_BLOCK2_1, -1, w.x2a, H4, W4, w.x2b, false);
     CONV(L_BLOCK3_0, -1, w.x2b, H4, W4, w.x3a, false);
@@ -671,6 +640,10 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     CONV(L_BLOCK4_2, -1, w.x4b, H16, W16, w.x4c, false);
     CONV(L_BLOCK5_0, -1, w.x4c, H16, W16, w.x5a, false);
     CONV(L_BLOCK5_1, -1, w.x5a, H32, W32, w.x5b, false);
+    if ((h->opt.fx & 513) == 513 && h->opt.bx && nw.conv[L_BLOCK5_2].w_rs && conv_rs128_fits(W32)) {
+        CONV(L_BLOCK5_2, -1, w.x5b, H32, W32, w.x5a, false);          // conv_rs64_kernel's 128-channel form holds a quarter of the couts per workgroup: the 1x1 (128 -> 64) runs on its own (x5a is free since block5.1)
+        CONV(L_BLOCK5_3, -1, w.x5a, H32, W32, w.x5d, false);
+    } else
     CONV(L_BLOCK5_2, L_BLOCK5_3, w.x5b, H32, W32, w.x5d, false);      // 3x3 + fused 1x1 (128->64)
     prof_begin(&h->prof, XFH_SPAN_PYRAMID, st);
     launch_pyramid_sum(w.x3c, w.x4c, w.x5d, w.pyr, B * 64, H8, W8, H16, W16, H32, W32, st);
@@ -682,9 +655,9 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     // fused heads: reliability from the channels-last features, key-point head from the gray image
     const bool all = h->prof.which == XFH_PROF_ALL;      // one span per head instead of one for both
     prof_begin(&h->prof, all ? XFH_SPAN_HEAD_REL : XFH_PROF_HEADS, st);
-    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32);
+    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32, h->opt.fx, h->status);
     if (all) { prof_end(&h->prof, XFH_SPAN_HEAD_REL, st, 0, 0); prof_begin(&h->prof, XFH_SPAN_HEAD_KP, st); }
-    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32);
+    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32, h->opt.fx, h->status);
     prof_end(&h->prof, all ? XFH_SPAN_HEAD_KP : XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }
@@ -727,9 +700,14 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
     }
     if (variant == 11) {      // the split kernel of the layer in the fp16-pair arithmetic
         if (!c.w_fx || (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, true, h->status)
-                                    : (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, true, h->status))))
+                                    : c.cin == 64 && c.stride == 2 ? launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status)
+                                    : (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status))))
             return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fp16-pair instantiation for layer %d", layer);
         return check_launch("xfh_conv_layer(fp16 pair)");
+    }
+    if (variant == 12) {      // 64 -> 64 3x3/s1: the fp16-pair kernel with the weights resident in registers
+        if (c.cin == 128 ? launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status) : launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: conv_rs64_kernel does not take layer %d at width %d", layer, Win);
+        return check_launch("xfh_conv_layer(fp16 pair, resident weights)");
     }
     if (variant >= 2) {
         if (launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, variant - 1, h->trace))
@@ -961,11 +939,17 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
 
 int xfh_debug_match_occupancy(void) { return xfh::match_debug_occupancy(); }
 int xfh_debug_cold_start(int enable) { xfh::g_debug_cold = enable ? 1 : 0; return XFH_OK; }
+int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, int H, int W, float* x1, xfh_stream stream) {
+    if (!h || !gray || !coef || !x1) return fail(XFH_ERR_ARG, "xfh_debug_block1: NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0 || (H & 3) || (W & 3)) return fail(XFH_ERR_ARG, "xfh_debug_block1: bad shape (%d,%d,%d)", B, H, W);
+    launch_block1_fused(h->nw, gray, coef, B, H, W, x1, (hipStream_t)stream, h->opt.block1, h->status);
+    return check_launch("xfh_debug_block1");
+}
 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 2}, {"block1", &Options::block1, 0, 5}, {"fx", &Options::fx, 0, 15}};
+        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 2047}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;
@@ -976,7 +960,7 @@ int xfh_set_option(xfh_handle h, const char* key, int value) {
     int* slot = option_slot(h, key, lo, hi);
     if (!slot) return fail(XFH_ERR_ARG, "xfh_set_option: unknown option '%s'", key);
     if (value < lo || value > hi) return fail(XFH_ERR_ARG, "xfh_set_option: %s = %d outside [%d, %d]", key, value, lo, hi);
-    if (!strcmp(key, "block1") && value == 2) return fail(XFH_ERR_ARG, "xfh_set_option: block1 = 2 names no kernel (0 | 5 = shipped, 1, 3, 4 = earlier forms)");
+    if (!strcmp(key, "block1") && value == 2) return fail(XFH_ERR_ARG, "xfh_set_option: block1 = 2 names no kernel (0 | 5 = shipped, 1, 3, 4 = earlier forms, 6 / 7 = conv4 / conv3 + conv4 on the fp16 matrix cores)");
     *slot = value;
     return XFH_OK;
 }

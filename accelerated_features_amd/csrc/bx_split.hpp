@@ -1,6 +1,8 @@
 // Three-way bf16 split of fp32 values (shared by the split-operand MFMA convolutions k_conv_bx.hip / k_conv_bx64.hip).
 #pragma once
+#ifndef XFH_HOST_EMU      // (tests/emu/ compiles this header for the host)
 #include "common.hpp"
+#endif
 
 namespace xfh {
 
@@ -62,6 +64,17 @@ constexpr float FX_SCALE_INV = 1.f / 2048.f;
 // fp16 high part cannot hold -- by setting bit 0 of the caller's status word (xfh_set_status_buffer; the host re-runs the batch in the bf16 arithmetic).
 constexpr float FX_MAX_INPUT = 65504.f;
 __device__ inline void fx_track(float& amax, float a, float b) { amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b))); }
+// The same on the converted HIGH PARTS, for kernels where the float form costs too much (k_heads.hip: tracking the fp32 values kept them alive next to their
+// fragments: + 44 registers, + 300 instructions): x left the fp16 range exactly when its high part became inf (0x7c00; NaN above), and as unsigned 16-bit
+// integers the magnitudes of fp16 numbers order like their values -- one v_pk_max_u16 per converted pair (sign bits masked off where the values are signed).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ inline void fx_track_h(unsigned& amax, unsigned h, bool is_signed) {
+    if (is_signed) h &= 0x7fff7fffu;
+    amax = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, amax), __builtin_bit_cast(u16x2, h)));
+}
+__device__ inline void fx_report_h(unsigned amax, int* status) {
+    if (status && ((amax & 0xffffu) >= 0x7c00u || (amax >> 16) >= 0x7c00u)) atomicOr(status, 1);
+}
 __device__ inline void fx_report(float amax, int* status) {
     if (status && amax >= FX_MAX_INPUT) atomicOr(status, 1);
 }

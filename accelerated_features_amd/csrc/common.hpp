@@ -1,5 +1,6 @@
 // Shared device/host helpers for libxfeat_hip (gfx950 only: 64-lane wavefronts assumed).
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -87,13 +88,15 @@ __device__ inline void kernel_entry_hooks(int cold) {
 
 // Raise a kernel's dynamic-LDS limit once per device.  `mask` is a static of the call site (bit d = done on device d): function
 // attributes are per device, so a process that drives several GPUs must set them on each (a per-process "done" flag would leave
-// every device but the first at the 64 KB default).  Racing threads at worst repeat the idempotent call.
-inline void set_max_dynamic_lds(const void* fn, int bytes, unsigned& mask) {
+// every device but the first at the 64 KB default).  The mask is an atomic: threads of one process (one handle per stream) race on
+// it by design -- at worst both make the idempotent call -- and the only process-wide mutable state of the library stays well defined.
+using AttrMask = std::atomic<unsigned>;
+inline void set_max_dynamic_lds(const void* fn, int bytes, AttrMask& mask) {
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 32 && ((mask >> dev) & 1u)) return;
+    if (dev >= 0 && dev < 32 && ((mask.load(std::memory_order_acquire) >> dev) & 1u)) return;
     (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (dev >= 0 && dev < 32) mask |= 1u << dev;
+    if (dev >= 0 && dev < 32) mask.fetch_or(1u << dev, std::memory_order_release);
 }
 
 // compute units of the current device (256 on MI355X); persistent kernels size their grids with it

@@ -1,3 +1,7 @@
+// conv_bx64s2x_kernel (k_conv_bx64s2x.hip): conv_bx64s2_kernel (k_conv_bx64s2.hip, which stays as it was soaked) with the arithmetic as a template parameter -- FX = the fp16-pair
+// arithmetic, three MFMAs per K step instead of six -- and the body in a header of its own, so that tests/emu/ can compile the SAME source for the host (XFH_HOST_EMU); the
+// bf16 form of this body is the emulator's control, the library instantiates the fp16-pair form only.
+//
 // 3x3 stride-2 convolution, 64 -> 64 or 64 -> 128 channels (block4.0 / block5.0; modules/model.py:68,75), on the bf16 matrix cores with
 // three-way split operands (the arithmetic of k_conv_bx.hip; the weight stream and the input chunks of k_conv_bx64.hip).
 //
@@ -18,47 +22,56 @@
 //     MFMAs (no branch: lanes without an item write to a dump slot; waves 5 - 7 run a copy of the unit's code without loads and splits).  Raw fp32 values are loaded two chunks ahead (two register sets), also across units;
 //   * the split weights (216 KiB per cout half) stream through a two-slot LDS ring by LDS-DMA, one slot = one tap row of one chunk
 //     (3 K steps, 18 KiB); the DMA of row r + 1 is issued behind the barrier that opens row r.  One barrier per tap row, none per chunk.
+#pragma once
+#ifndef XFH_HOST_EMU
 #include "kernels.hpp"
-#include "bx_split.hpp"
 #include <type_traits>
+#endif
+#include "conv_bx64_body.hpp"      // (the macros both bodies share: XFH_DYN_LDS_BYTES, XFH_LDS_ADDR, XFH_DMA_B128_TO_LDS, XFH_WAIT_VMCNT0, XFH_NOP16; bx_split.hpp)
+#ifndef XFH_HOST_EMU
+/* six just-read fragments stay occupied up to here (the staging's results are not handed their registers while an MFMA may still be reading them) */
+#define XFH_S2_KEEP6(a, b, c, d, e, f) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f))
+#endif
 
 namespace xfh {
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-struct Bx64S2Args {
+struct Bx64S2xArgs {
     const float* in;
-    const void* wq;            // [cout half][cin/16][3 dy][3 dx][2 cout blocks][3 splits][64 lanes][8 bf16]   (api.hip)
+    const void* wq;            // [cout half][cin/16][3 dy][3 dx][2 cout blocks][3 splits][64 lanes][8 bf16 | fp16]   (weight_split.hpp: pack_bx64)
     const float* bias;
     float* out;
     int relu, H, W, Ho, Wo, B;
     int nrows, upi;            // 8-row tiles per strip, units per image and cout half
     long long* trace;          // debug: s_memtime stamps of the workgroup's second unit (NULL in production)
     int cold;
+    int* status;               // fp16 pair: range guard (bx_split.hpp), may be NULL
 };
 
-namespace bx64s2 {
-constexpr int PIXB = 112, SPLB = 32, IH = 17, NEVEN = 17;
-constexpr int PARB = NEVEN * PIXB;                      // odd columns of a row behind its even ones
-constexpr int XROWB = 3712;                             // >= (17 + 16) * 112
-constexpr int X_BYTES = IH * XROWB;                     // 63104
+namespace bx64s2x {
+constexpr int SPLB = 32, IH = 17, NEVEN = 17;
+template <bool FX> constexpr int pixb() { return FX ? 80 : 112; }          // bytes per staged pixel: 16 channels x (3 bf16 | 2 fp16 fragments) + 16
+template <bool FX> constexpr int xrowb() { return FX ? 2688 : 3712; }      // >= (17 + 16) pixels; odd columns of a row behind its even ones
 constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;
-constexpr int RING_OFF = 2 * X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, DUMP_OFF = BIAS_OFF + 128 * 4, LDS_BYTES = DUMP_OFF + 256;
+template <bool FX> constexpr int lds_bytes() { return 2 * IH * xrowb<FX>() + 2 * SLOT_BYTES + 128 * 4 + 256; }      // two X buffers, the weight ring, bias, dump slot
 constexpr int NQ = 9;                                   // 4-pixel quads [2 ox0 - 4, 2 ox0 + 32) per halo row
 constexpr int NITEM = IH * NQ * 2;                      // (row, quad, 8-channel group)
-static_assert(NITEM <= 512 && RING_OFF % 64 == 0 && LDS_BYTES <= 160 * 1024, "one staging item per thread; all of a CU's LDS");
+static_assert(NITEM <= 512 && (2 * IH * xrowb<false>()) % 64 == 0 && (2 * IH * xrowb<true>()) % 64 == 0 && lds_bytes<false>() <= 160 * 1024, "one staging item per thread; all of a CU's LDS");
+static_assert(xrowb<true>() >= (17 + 16) * pixb<true>() && xrowb<true>() % 128 == 0 && xrowb<false>() >= (17 + 16) * pixb<false>(), "row pitch");
 }
 
+typedef unsigned u32x4_s2 __attribute__((ext_vector_type(4)));
+
 // NCO: cout halves, 1 (64 couts) or 2 (128).  W4: W % 4 == 0 (no quad straddles the right border: no masking of its tail)
-template <int NCO, bool W4>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void conv_bx64s2_kernel(Bx64S2Args a) {
-    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    using namespace bx64s2;
+// FX: the fp16-pair arithmetic (bx_split.hpp: two input fragments per pixel, three MFMAs per K step instead of six; PIXB 80, rows 2688 B apart -- a multiple of 128 B, so that the eight
+// lanes of the block's second output row in a ds_read_b128 group fall between the banks of the first row's eight)
+template <int NCO, bool W4, bool FX>
+__device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
+    using namespace bx64s2x;
+    constexpr int PIXB = pixb<FX>(), PARB = NEVEN * PIXB, XROWB = xrowb<FX>(), X_BYTES = IH * XROWB, RING_OFF = 2 * X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, DUMP_OFF = BIAS_OFF + 128 * 4;
+    constexpr int NXF = FX ? 2 : 3;                  // input fragments per pixel
     constexpr int CIN = 64, NCH = CIN / 16, NROW = NCH * 3, COUT = 64 * NCO;
     static_assert(NROW % 2 == 0 && NCH % 2 == 0, "ring slot, X buffer and register set of a chunk must not depend on the unit");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_s2[];
+    XFH_DYN_LDS_BYTES(smem_s2);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pb = wave >> 1, cb = wave & 1;
@@ -106,12 +119,12 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
     };
     const i32x4 rs_w = make_rsrc(a.wq, (unsigned)(NCO * NROW * SLOT_BYTES));
     const int dma_voff = lane * 16;
-    auto lds_addr = [](const unsigned char* p) { return (unsigned)(size_t)(lptr_t)p; };
+    auto lds_addr = [&](const unsigned char* p) { return XFH_LDS_ADDR(p, smem_s2); };
     auto issue_row = [&](int r, int hf) __attribute__((always_inline)) {      // weights of row r (chunk r / 3, tap row r % 3) of cout half hf -> slot r & 1
         for (int j = wave; j < NPIECE; j += 8) {
             const unsigned m0v = lds_addr(smem_s2 + RING_OFF + (r & 1) * SLOT_BYTES + j * 1024);
             const int soff = (hf * NROW + r) * SLOT_BYTES + j * 1024;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(dma_voff), "s"(rs_w), "s"(soff) : "memory");
+            XFH_DMA_B128_TO_LDS(m0v, dma_voff, rs_w, soff);
         }
     };
 
@@ -151,7 +164,9 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
     int tix = 0;
 #define S2_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }      /* [0] unit start; row r: [1+4r] start, [2+4r] barrier passed, [3+4r] MFMAs issued; [50] stores issued */
-    struct Frag { bf16x8 x[3]; bf16x8 w[3]; };
+    typedef typename std::conditional<FX, f16x8, bf16x8>::type frag_t;
+    struct Frag { frag_t x[3]; frag_t w[3]; };      // (fp16 pair: x[0] = high parts, x[1] = low parts)
+    unsigned amax = 0;                                // fp16 pair: range guard on the converted high parts (bx_split.hpp)
     // lane (pixel l31 of block pb): output row 2 pb + (l31 >> 4), column l31 & 15 -> input row 2 * that (+ dy), even column index = column (+ dx >> 1)
     const int lane_px = 2 * (2 * pb + (l31 >> 4)) * XROWB + (l31 & 15) * PIXB + half * 16;
     f32x16 acc, acc2;
@@ -168,7 +183,7 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         constexpr int MODE = decltype(STGC)::value;      // 0: this wave only multiplies (waves 5 - 7); 1: it also loads and splits an item (waves 0 - 4), half in each of a chunk's
         constexpr bool STG = MODE != 0;                  // first two rows.  (Wave 4 -- the last 50 items, on wave 0's SIMD -- doing both halves in the third row instead: slower.)
         S2_STAMP(1 + 4 * r)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        XFH_WAIT_VMCNT0();
         __syncthreads();
         S2_STAMP(2 + 4 * r)
         issue_row(r + 1 < NROW ? r + 1 : 0, r + 1 < NROW ? cur.hf : nxt.hf);          // (the stream is cyclic over the units)
@@ -177,9 +192,9 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         Frag f[2];                             // steps 0 and 1; step 2 is read into f[0] behind the last MFMA of step 0 (slot 6)
         auto load = [&](int s, Frag& o) {          // tap column s: parity s & 1, pixel index + (s >> 1)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) o.x[q] = *reinterpret_cast<const bf16x8*>(xrow + (s & 1) * PARB + (s >> 1) * PIXB + q * SPLB);
+            for (int q = 0; q < NXF; ++q) o.x[q] = *reinterpret_cast<const frag_t*>(xrow + (s & 1) * PARB + (s >> 1) * PIXB + q * SPLB);
 #pragma unroll
-            for (int q = 0; q < 3; ++q) o.w[q] = *reinterpret_cast<const bf16x8*>(wslot + s * STEP_BYTES + q * 1024);
+            for (int q = 0; q < 3; ++q) o.w[q] = *reinterpret_cast<const frag_t*>(wslot + s * STEP_BYTES + q * 1024);
         };
         load(0, f[0]);
         load(1, f[1]);
@@ -206,7 +221,7 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
 #define S2_FENCE __builtin_amdgcn_sched_barrier(0);
         // a fragment's registers stay occupied until every MFMA of its step has long been issued: they are not handed to the staging's results
         // while an MFMA may still be reading them (tools/check_mfma_war.py)
-#define S2_KEEP(F) asm volatile("" :: "v"(F.x[0]), "v"(F.x[1]), "v"(F.x[2]), "v"(F.w[0]), "v"(F.w[1]), "v"(F.w[2]));
+#define S2_KEEP(F) XFH_S2_KEEP6(F.x[0], F.x[1], F.x[NXF - 1], F.w[0], F.w[1], F.w[2]);
 #define S2_HI(A, B) __builtin_amdgcn_perm(__float_as_uint(B), __float_as_uint(A), 0x07060302u)      /* split3_trunc, step by step */
 #define S2_ON(PP) if constexpr (MODE == 1 && DY == (PP))
         // unit U = (pixel e2 of the half, channel pair j): channels 2 j, 2 j + 1 of ONE pixel -> word j of the pixel's h / m / l rows.  (Pairs of
@@ -225,6 +240,28 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         const bool wr_ = en && has_item && !(it_quad == 0 && e_ < 3); \
         *reinterpret_cast<u32x4*>(smem_s2 + (wr_ ? SS * X_BYTES + row_base + par_ * PARB + idx_ * PIXB + (Q) * SPLB : DUMP_OFF)) = (Q) == 0 ? qH[E2] : (Q) == 1 ? qM[E2] : qL[E2]; }
 #define S2_LD(k) if constexpr (STG && DY == 0) load_plane(std::integral_constant<int, P>{}, std::integral_constant<int, k>{}, la, same2 ? C + 2 : C + 2 - NCH);
+        if constexpr (FX) {
+            // fp16 pair: 9 slots of { 1 MFMA, one unit of the split (pixel e2, channel pair j: high parts, the two residuals, low parts: ~10 vector ops), a pixel's two ds_write_b128
+            // or two planes of raw loads }.  Products, small terms first: (q2, xh) (q1, xl) (q0, xh); the two accumulators take turns.
+            constexpr int PP1 = DY & 1;
+#define S2_MFX(I) { if constexpr ((I) == 3) { S2_KEEP(f[0]) load(2, f[0]); } constexpr int s_ = ((I) / 3) & 1, j_ = (I) % 3; \
+        if constexpr ((I) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[s_].w[2 - j_], f[s_].x[j_ == 1 ? 1 : 0], acc2, 0, 0, 0); \
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[s_].w[2 - j_], f[s_].x[j_ == 1 ? 1 : 0], acc, 0, 0, 0); }
+#define S2_FX(PP, U) S2_ON(PP) { constexpr int e2_ = (U) >> 2, j_ = (U) & 3; float xa_ = v[SS][2 * j_][2 * (PP) + e2_], xb_ = v[SS][2 * j_ + 1][2 * (PP) + e2_]; \
+        if (!W4) { const bool z_ = v_gx[SS] + 2 * (PP) + e2_ >= a.W; xa_ = z_ ? 0.f : xa_; xb_ = z_ ? 0.f : xb_; } \
+        unsigned hh_, ll_; split2_f16(xa_, xb_, hh_, ll_); fx_track_h(amax, hh_, true); qH[e2_][j_] = hh_; qM[e2_][j_] = ll_; }
+            S2_MFX(0) S2_FX(PP1, 0) S2_FENCE
+            S2_MFX(1) S2_FX(PP1, 1) S2_FENCE
+            S2_MFX(2) S2_FX(PP1, 2) S2_FENCE
+            S2_MFX(3) S2_FX(PP1, 3) S2_P(PP1, 0, 0) S2_P(PP1, 0, 1) S2_FENCE
+            S2_MFX(4) S2_FX(PP1, 4) S2_LD(0) S2_LD(1) S2_FENCE
+            S2_MFX(5) S2_FX(PP1, 5) S2_LD(2) S2_LD(3) S2_FENCE
+            S2_MFX(6) S2_FX(PP1, 6) S2_LD(4) S2_LD(5) S2_FENCE
+            S2_MFX(7) S2_FX(PP1, 7) S2_LD(6) S2_LD(7) S2_FENCE
+            S2_MFX(8) S2_P(PP1, 1, 0) S2_P(PP1, 1, 1) S2_FENCE
+#undef S2_MFX
+#undef S2_FX
+        } else
         {
             constexpr int PP1 = DY & 1;
             S2_MF(0) S2_A1(PP1, 0) S2_A2(PP1, 0) S2_A3(PP1, 0) S2_B1(PP1, 0) S2_FENCE
@@ -262,7 +299,7 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         S2_KEEP(f[0]) S2_KEEP(f[1])
 #undef S2_KEEP
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 7\n\ts_nop 7");      // idle slots: whatever follows must not land in operand registers of the last MFMAs
+        XFH_NOP16();      // idle slots: whatever follows must not land in operand registers of the last MFMAs
         __builtin_amdgcn_sched_barrier(0);
         S2_STAMP(3 + 4 * r)
     };
@@ -291,7 +328,7 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         const int voff = oy < a.Ho && ox < a.Wo ? (int)(((size_t)(4 * half) * HWo + (size_t)oy * a.Wo + ox) * 4) : (int)0x80000000;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float y = (acc[r] + acc2[r]) + bs[r];
+            float y = FX ? (acc[r] + acc2[r]) * FX_SCALE_INV + bs[r] : (acc[r] + acc2[r]) + bs[r];
             if (a.relu) y = fmaxf(y, 0.f);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)(((r & 3) + 8 * (r >> 2)) * HWo * 4), 0);
         }
@@ -323,8 +360,9 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
             for (int j = 0; j < 4; ++j) {
                 float x0 = v[0][2 * j][e], x1 = v[0][2 * j + 1][e];
                 if (!W4) { const bool z = v_gx[0] + e >= a.W; x0 = z ? 0.f : x0; x1 = z ? 0.f : x1; }
-                unsigned hh, mm, ll;
-                split3_trunc(x0, x1, hh, mm, ll);
+                unsigned hh, mm, ll = 0;
+                if constexpr (FX) { split2_f16(x0, x1, hh, mm); fx_track_h(amax, hh, true); }
+                else split3_trunc(x0, x1, hh, mm, ll);
                 h[j] = hh; m[j] = mm; l[j] = ll;
             }
             const bool wr = has_item && !(it_quad == 0 && e < 3);
@@ -332,7 +370,7 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
             unsigned char* p = smem_s2 + (wr ? row_base + par * PARB + idx * PIXB : DUMP_OFF);
             *reinterpret_cast<u32x4*>(p) = h;
             *reinterpret_cast<u32x4*>(p + SPLB) = m;
-            *reinterpret_cast<u32x4*>(p + 2 * SPLB) = l;
+            if constexpr (!FX) *reinterpret_cast<u32x4*>(p + 2 * SPLB) = l;
         }
     }
     for (;;) {
@@ -345,33 +383,10 @@ void conv_bx64s2_kernel(Bx64S2Args a) {
         ++tix;
         cur = nxt;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the cyclic stream's last DMA must not outlive the workgroup's LDS
+    XFH_WAIT_VMCNT0();      // the cyclic stream's last DMA must not outlive the workgroup's LDS
+    if constexpr (FX) fx_report_h(amax, a.status);
 #undef S2_STAMP
 }
 
-template <int NCO, bool W4>
-static int run_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
-    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    if ((size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
-    Bx64S2Args a;
-    a.cold = g_debug_cold;
-    a.in = in; a.wq = c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B; a.trace = trace;
-    a.nrows = ceil_div(Ho, 8); a.upi = ceil_div(Wo, 16) * a.nrows;
-    static AttrMask attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64s2_kernel<NCO, W4>), bx64s2::LDS_BYTES, attr_done);
-    const long long units = (long long)NCO * B * a.upi;
-    int grid = num_cus();                      // one 8-wave workgroup per CU (all 160 KiB of LDS); a multiple of 8 keeps a workgroup on its XCD
-    if (units < grid) grid = (int)units;       // (small inputs: one unit per workgroup; the XCD mapping then needs grid % 8 == 0 or is skipped)
-    conv_bx64s2_kernel<NCO, W4><<<grid, 512, bx64s2::LDS_BYTES, st>>>(a);
-    return 0;
-}
-
-int launch_conv_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace) {
-    if (c.ks != 3 || c.stride != 2 || !c.w_bx || c.cin != 64) return -1;
-    const bool w4 = (W & 3) == 0;
-    if (c.cout == 64) return w4 ? run_bx64s2<1, true>(c, in, B, H, W, out, st, trace) : run_bx64s2<1, false>(c, in, B, H, W, out, st, trace);
-    if (c.cout == 128) return w4 ? run_bx64s2<2, true>(c, in, B, H, W, out, st, trace) : run_bx64s2<2, false>(c, in, B, H, W, out, st, trace);
-    return -1;
-}
 
 }  // namespace xfh

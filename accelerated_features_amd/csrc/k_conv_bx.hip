@@ -127,7 +127,7 @@ void conv_bx_kernel(BxArgs a) {
     // raw fp32 values of a tile: 8 channels of one pixel per item, all loads of a thread in flight together; out-of-image pixels
     // carry an out-of-range offset (the buffer load returns the zero padding)
     float v[NIT][8];
-    float amax = 0.f;                         // fx: the largest |x| converted (range guard)
+    unsigned amax = 0;                        // fx: the largest fp16 high parts converted (range guard: bx_split.hpp)
     auto issue_loads = [&](int vid) {
         int b, oy0, ox0;
         tile_of(vid, b, oy0, ox0);
@@ -146,9 +146,9 @@ void conv_bx_kernel(BxArgs a) {
         for (int i = 0; i < NIT; ++i) {
             uint4 h, m, l;
             if constexpr (FX) {
-                fx_track(amax, v[i][0], v[i][1]); fx_track(amax, v[i][2], v[i][3]); fx_track(amax, v[i][4], v[i][5]); fx_track(amax, v[i][6], v[i][7]);
                 split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
                 split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
+                fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);      // (on the high parts: bx_split.hpp)
             } else {
                 split3(v[i][0], v[i][1], h.x, m.x, l.x);
                 split3(v[i][2], v[i][3], h.y, m.y, l.y);
@@ -266,7 +266,7 @@ void conv_bx_kernel(BxArgs a) {
         ++tix;
         vid = nvid;
     }
-    if constexpr (FX) fx_report(amax, a.status);
+    if constexpr (FX) fx_report_h(amax, a.status);
 #undef BX_STAMP
 }
 
@@ -361,7 +361,7 @@ void conv_bxs2_kernel(BxS2Args a) {
         iy0 = tyi * 8; ix0 = txi * 32;
     };
     float v[NIT][8];
-    float amax = 0.f;                         // fx: the largest |x| converted (range guard)
+    unsigned amax = 0;                        // fx: the largest fp16 high parts converted (range guard: bx_split.hpp)
     auto issue_loads = [&](int vid) __attribute__((always_inline)) {
         int b, iy0, ix0;
         tile_of(vid, b, iy0, ix0);
@@ -380,9 +380,9 @@ void conv_bxs2_kernel(BxS2Args a) {
         for (int i = 0; i < NIT; ++i) {
             uint4 h, m, l;
             if constexpr (FX) {
-                fx_track(amax, v[i][0], v[i][1]); fx_track(amax, v[i][2], v[i][3]); fx_track(amax, v[i][4], v[i][5]); fx_track(amax, v[i][6], v[i][7]);
                 split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
                 split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
+                fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);      // (on the high parts: bx_split.hpp)
             } else {
                 split3(v[i][0], v[i][1], h.x, m.x, l.x);
                 split3(v[i][2], v[i][3], h.y, m.y, l.y);
@@ -468,7 +468,7 @@ void conv_bxs2_kernel(BxS2Args a) {
         __syncthreads();
         vid = nvid;
     }
-    if constexpr (FX) fx_report(amax, a.status);
+    if constexpr (FX) fx_report_h(amax, a.status);
 }
 
 template <int CIN, bool FX>
@@ -483,7 +483,7 @@ static int run_bxs2(const ConvW& c, const float* in, int B, int H, int W, float*
     a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B;
     a.tiles_x = ceil_div(W, 32);
     a.tiles = a.tiles_x * ceil_div(H, 8);
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN, FX>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();
@@ -503,7 +503,7 @@ static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* o
     a.lag = 11;
     a.tiles_x = ceil_div(W, Cfg::TW);
     a.tiles = a.tiles_x * ceil_div(H, Cfg::TH);
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx_kernel<CIN, COUT, FX>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();            // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD

@@ -18,446 +18,57 @@
 #include "bx_split.hpp"
 #include <cstdlib>
 #include <type_traits>
+#include "conv_bx64_body.hpp"
 
 namespace xfh {
 
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-struct Bx64Args {
-    const float* in;
-    const void* wq;            // [cin/16][3 dy][3 dx][2 cout blocks][3 splits][64 lanes][8 bf16]   (api.hip)
-    const float* bias;
-    float* out;
-    int relu, H, W, B;
-    int ncols, nhr, upi;       // 16-column strips, 8-row half tiles per strip, units per image
-    long long* trace;
-    // fused trailing 1x1 (64 -> 64): split weights in the K order of the 3x3's D registers, [K step 4][cout block 2][split 3][64 lanes] 8 bf16
-    const uint4* wq2;
-    const float* bias2;
-    int relu2;
-    int cold;
-    int* status;               // fx: range guard (bx_split.hpp), may be NULL
-};
-
-namespace bx64 {
-constexpr int XROWB = 2048, SPLB = 32, IW = 18, IH = 18;
-// bytes per staged pixel: 16 channels x (3 bf16 | 2 fp16 fragments) + 16: an ODD multiple of 16 B keeps the 16 lanes of a ds_read_b128 group on distinct banks
-template <bool FX> constexpr int pixb() { return FX ? 80 : 112; }
-constexpr int X_BYTES = IH * XROWB;                    // 36864
-constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;      // 6 KiB per K step, 18 per slot
-constexpr int RING_OFF = X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, LDS_BYTES = BIAS_OFF + 128 * 4;      // bias of the 3x3, bias of the fused 1x1
-constexpr int NQ = 6;                                   // aligned 4-pixel quads per halo row
-static_assert(IH * NQ * 2 <= 256, "one (row, quad, 8-channel group) item per thread");
-}
-
-// FUSE: 0 = the 3x3 alone; 1 = + trailing 1x1 (64 -> 64), NCHW output; 2 = the same with channels-last output
-// FX: the fp16-pair arithmetic (bx_split.hpp) -- two input fragments per pixel, three MFMAs per K step and accumulator instead of six
-template <int CIN, int FUSE, bool FX>
+// body in conv_bx64_body.hpp (also compiled for the host by tests/emu/)
+template <int CIN, int FUSE, int FXM, int SP = 0>      // FXM: 0 bf16 three-way split, 1 fp16 pair, 2 fp16 pair with two weight fragments in the stream; SP: 1 input / 2 output in the split format (conv_bx64_body.hpp)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx64_kernel(Bx64Args a) {
-    using namespace bx64;
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    constexpr int PIXB = pixb<FX>(), NXS = FX ? 2 : 3;
-    using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
-    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {
-        if constexpr (FX) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
-        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
-    };
-    constexpr int NCH = CIN / 16, NROW = NCH * 3, COUT = 64;
-    static_assert(NROW % 2 == 0, "the ring slot of a row must not depend on the tile");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b64[];
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t HW = (size_t)a.H * a.W;
-    float* bias_lds = reinterpret_cast<float*>(smem_b64 + BIAS_OFF);
-    if (tid < 64) bias_lds[tid] = a.bias[tid];
-    if (FUSE && tid >= 64 && tid < 128) bias_lds[tid] = a.bias2[tid - 64];
-
-    // ---- this workgroup's units -----------------------------------------------------------------------------------------
-    // unit u of an image list = (image, 16-column strip, half-tile row), strips and rows fastest.  With a batch that is a multiple of
-    // 8 the images of XCD x are x, x + 8, ... (workgroup id & 7 = XCD): a strip's neighbours share an L2.
-    int u0, u1, img0, img_step;
-    {
-        const int G = (int)gridDim.x, g = (int)blockIdx.x;
-        if (xcd_swizzled(a.B) && (G & 7) == 0) {
-            const long long U = (long long)(a.B >> 3) * a.upi;
-            const int slot = g >> 3, nslot = G >> 3;
-            u0 = (int)(U * slot / nslot); u1 = (int)(U * (slot + 1) / nslot);
-            img0 = g & 7; img_step = 8;
-        } else {
-            const long long U = (long long)a.B * a.upi;
-            u0 = (int)(U * g / G); u1 = (int)(U * (g + 1) / G);
-            img0 = 0; img_step = 1;
-        }
-    }
-    if (u0 >= u1) return;
-    struct Tile { int b, y0, x0, full; };
-    auto tile_at = [&](int u, Tile& t) {      // returns the units consumed (2 = a full 16-row tile)
-        const int im = u / a.upi, rem = u - im * a.upi;
-        const int col = rem / a.nhr, hr = rem - col * a.nhr;
-        t.b = img0 + img_step * im; t.y0 = hr * 8; t.x0 = col * 16;
-        t.full = (u + 1 < u1 && hr + 1 < a.nhr) ? 1 : 0;
-        return 1 + t.full;
-    };
-
-    // ---- LDS-DMA of the weight stream (inline asm: hipcc would make every LDS read wait for all DMA it can see) -------------
-    auto make_rsrc = [](const void* p, unsigned bytes) {
-        const unsigned long long ba = (unsigned long long)p;
-        i32x4 r;
-        r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)ba);
-        r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(ba >> 32) & 0xffffu));
-        r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-        r.w = 0x00020000;
-        return r;
-    };
-    const i32x4 rs_w = make_rsrc(a.wq, (unsigned)(NROW * SLOT_BYTES));
-    const int dma_voff = lane * 16;
-    auto lds_addr = [](const unsigned char* p) { return (unsigned)(size_t)(lptr_t)p; };
-    auto issue_row = [&](int r) __attribute__((always_inline)) {             // weights of row r (chunk r / 3, tap row r % 3) -> slot r & 1
-        for (int j = wave; j < NPIECE; j += 4) {
-            const unsigned m0v = lds_addr(smem_b64 + RING_OFF + (r & 1) * SLOT_BYTES + j * 1024);
-            const int soff = r * SLOT_BYTES + j * 1024;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(dma_voff), "s"(rs_w), "s"(soff) : "memory");
-        }
-    };
-    auto dma_barrier = [&]() {                // everything this workgroup has in flight has landed, for every wave
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-
-    // ---- raw fp32 values of one 16-channel chunk of a tile.  Item of a thread = 4 consecutive pixels x 8 channels: eight
-    // buffer_load_dwordx4 (one per channel plane) instead of 32 dword loads -- the texture addresser takes ~16 cycles per wave
-    // instruction whatever its width, and eight waves loading dword by dword kept it busy for 3 k cycles per chunk.  The halo row
-    // [x0 - 1, x0 + 17) is covered by the six aligned quads [x0 - 4, x0 + 20); W % 4 == 0 keeps every quad entirely inside or outside.
-    const bool has_item = tid < IH * NQ * 2;
-    const int it_g8 = tid / (IH * NQ), it_row = (tid - it_g8 * (IH * NQ)) / NQ, it_quad = tid % NQ;
-    float v[8][4];
-    int v_gx = 0;                             // first column of the quad in flight (the tail of a quad that straddles the right border is masked
-                                              // when it is consumed: touching the values where they are loaded would park a vmcnt(0) there)
-    auto issue_loads = [&](const Tile& t, int chunk) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)t.b * CIN * HW), 0, (int)(CIN * HW * sizeof(float)), 0x00020000);
-        const int nrow = t.full ? 18 : 10;
-        const int gy = t.y0 - 1 + it_row, gx = t.x0 - 4 + 4 * it_quad;
-        const bool ok = has_item && it_row < nrow && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        v_gx = gx;
-        const int voff = ok ? (int)((((size_t)it_g8 * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const auto q = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, (int)((chunk * 16 + k) * HW * 4), 0);
-            v[k][0] = __uint_as_float(q[0]); v[k][1] = __uint_as_float(q[1]); v[k][2] = __uint_as_float(q[2]); v[k][3] = __uint_as_float(q[3]);
-        }
-    };
-    // split3 works on the two neighbouring PIXELS of a loaded quad (adjacent registers of one dwordx4: pairing channels instead made
-    // hipcc re-arrange all 32 values with moves right behind the loads -- and wait for them there); v_perm_b32 then gathers the
-    // channel pairs of each pixel: 16 + 16 bits from two registers in one op.
-    auto stage_write = [&]() __attribute__((always_inline)) {
-        if (!has_item) return;
-        float amax = 0.f;                         // fx: the largest |x| of this item (range guard, bx_split.hpp; a kernel-long register cost the fused forms eight spills)
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            unsigned H[8], M[8], L[8];                     // {pixel 2 pp, pixel 2 pp + 1} of channel k
-            // beyond the right border (W % 4 != 0 only) the quad's tail holds the next row's first pixels: zero them as values, not in v
-            // (conditional stores into the array sent it to scratch memory)
-            const bool z0 = (a.W & 3) && v_gx + 2 * pp >= a.W, z1 = (a.W & 3) && v_gx + 2 * pp + 1 >= a.W;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                float x0 = v[k][2 * pp], x1 = v[k][2 * pp + 1];
-                if (a.W & 3) { x0 = z0 ? 0.f : x0; x1 = z1 ? 0.f : x1; }
-                if constexpr (FX) { fx_track(amax, x0, x1); split2_f16(x0, x1, H[k], L[k]); M[k] = 0; }
-                else split3(x0, x1, H[k], M[k], L[k]);
-            }
-#pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-                const int cc = 4 * it_quad + 2 * pp + e2 - 3;          // halo column of this pixel
-                if (cc < 0 || cc >= IW) continue;                     // (quad 0: its last pixel only; quad 5: its first only)
-                const unsigned sel = e2 ? 0x07060302u : 0x05040100u;
-                uint4 h, m, l;
-                h.x = __builtin_amdgcn_perm(H[1], H[0], sel); h.y = __builtin_amdgcn_perm(H[3], H[2], sel);
-                h.z = __builtin_amdgcn_perm(H[5], H[4], sel); h.w = __builtin_amdgcn_perm(H[7], H[6], sel);
-                m.x = __builtin_amdgcn_perm(M[1], M[0], sel); m.y = __builtin_amdgcn_perm(M[3], M[2], sel);
-                m.z = __builtin_amdgcn_perm(M[5], M[4], sel); m.w = __builtin_amdgcn_perm(M[7], M[6], sel);
-                l.x = __builtin_amdgcn_perm(L[1], L[0], sel); l.y = __builtin_amdgcn_perm(L[3], L[2], sel);
-                l.z = __builtin_amdgcn_perm(L[5], L[4], sel); l.w = __builtin_amdgcn_perm(L[7], L[6], sel);
-                unsigned char* p = smem_b64 + it_row * XROWB + cc * PIXB + it_g8 * 16;
-                *reinterpret_cast<uint4*>(p) = h;
-                if constexpr (FX) *reinterpret_cast<uint4*>(p + SPLB) = l;
-                else {
-                    *reinterpret_cast<uint4*>(p + SPLB) = m;
-                    *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
-                }
-            }
-        }
-        if constexpr (FX) fx_report(amax, a.status);
-    };
-
-    long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
-    int tix = 0;
-#define BX_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }      /* second tile of the workgroup: [0] start, per row r: [1+4r] staged / row start, [2+4r] barrier passed, [3+4r] DMA + loads issued, [4+4r] MFMAs issued; [50] stores issued, [51] end barrier */
-    struct Frag { frag_t x[2][NXS]; frag_t w[2][3]; };
-    const int lane_px = (l31 >> 4) * XROWB + (l31 & 15) * PIXB + half * 16;
-
-    // ---- one tile: NPB pixel blocks per wave (2 = 16x16 tile, 1 = 8x16 half tile).  Two instantiations of the whole tile body:
-    // accumulators that live across a branch between two tap-row variants were given a second register set and 64 moves per row.
-    auto do_tile = [&](auto NPBC, const Tile& cur, const Tile& nxt, bool has_next) __attribute__((always_inline)) {
-        constexpr int NPB = decltype(NPBC)::value;
-        f32x16 acc[NPB][2];                   // [pixel block][cout block]
-#pragma unroll
-        for (int j = 0; j < NPB; ++j)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][cb][r] = 0.f;
-        // block rows of this wave: full tile 2 w, 2 w + 1 ; half tile w
-        const int br0 = NPB == 2 ? 2 * wave : wave, br1 = 2 * wave + 1;
-        const int xb[2] = {2 * br0 * XROWB + lane_px, 2 * br1 * XROWB + lane_px};
-        for (int c = 0; c < NCH; ++c) {
-            if (c > 0) dma_barrier();          // every wave has finished the previous chunk's last tap row (the tile loop ends on a barrier)
-            stage_write();
-            for (int dy = 0; dy < 3; ++dy) {
-                const int r = c * 3 + dy;
-                BX_STAMP(1 + 4 * r)
-                dma_barrier();
-                BX_STAMP(2 + 4 * r)                 // row r's weights landed; (dy = 0) the chunk is staged; (dy > 0) row r - 1 is finished
-                BX_STAMP(3 + 4 * r)
-                // ---- one tap row: 3 K steps x (NPB pixel blocks x 2 cout blocks) x 6 MFMAs; operands of step s+1 read under step s
-                const unsigned char* wslot = smem_b64 + RING_OFF + (r & 1) * SLOT_BYTES + lane * 16;
-                const unsigned char* xrow = smem_b64 + dy * XROWB;
-                Frag f[2];
-                auto load = [&](int s, Frag& o) {
-#pragma unroll
-                    for (int j = 0; j < NPB; ++j)
-#pragma unroll
-                        for (int q = 0; q < NXS; ++q) o.x[j][q] = *reinterpret_cast<const frag_t*>(xrow + xb[j] + s * PIXB + q * SPLB);
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) o.w[cb][q] = *reinterpret_cast<const frag_t*>(wslot + s * STEP_BYTES + (cb * 3 + q) * 1024);
-                };
-                load(0, f[0]);
-#pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    const Frag& cf = f[s & 1];
-                    if (s + 1 < 3) load(s + 1, f[(s + 1) & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); independent accumulators
-#define BX_MM(WQ, XQ) { _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) _Pragma("unroll") for (int j = 0; j < NPB; ++j) \
-                        acc[j][cb] = mfma(cf.w[cb][WQ], cf.x[j][XQ], acc[j][cb]); }
-                    if constexpr (FX) { BX_MM(2, 0) BX_MM(1, 1) BX_MM(0, 0) }      // fp16 pair: (2^11 w - q0) xh, w xl, q0 xh -- all at scale 2^11
-                    else { BX_MM(2, 0) BX_MM(0, 2) BX_MM(1, 1) BX_MM(1, 0) BX_MM(0, 1) BX_MM(0, 0) }
-#undef BX_MM
-                    __builtin_amdgcn_sched_barrier(0);
-                    // memory instructions go BETWEEN the MFMA groups: their issue (~100 cycles per LDS-DMA piece or load with the CU's
-                    // eight waves at it) overlaps the matrix pipe's backlog instead of preceding it
-                    // (and idle slots first: VALU address arithmetic right behind an MFMA may land in operand lanes it has not read yet)
-                    if (s < 2) { asm volatile("s_nop 7\n\ts_nop 7"); __builtin_amdgcn_sched_barrier(0); }
-                    if (s == 0) issue_row(r + 1 < NROW ? r + 1 : 0);          // next row (of the next tile after the last one: the stream is cyclic)
-                    if (s == 1 && dy == 0) {   // raw values of the next chunk (or the next tile's first) fly under this chunk's MFMAs
-                        // (ONE load site: two sites load into two register sets and merge them with moves -- behind a wait for the loads)
-                        const bool same = c + 1 < NCH;
-                        Tile lt;
-                        lt.b = same ? cur.b : nxt.b; lt.y0 = same ? cur.y0 : nxt.y0; lt.x0 = same ? cur.x0 : nxt.x0; lt.full = same ? cur.full : nxt.full;
-                        if (same || has_next) issue_loads(lt, same ? c + 1 : 0);
-                    }
-                }
-                if constexpr (NPB == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));      // (tied to the accumulators: an asm
-                else asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[0][1]));                                                            // without operands is no anchor)
-                __builtin_amdgcn_sched_barrier(0);
-                BX_STAMP(4 + 4 * r)
-            }
-        }
-        if constexpr (FUSE == 0) {
-            // ---- bias, ReLU, buffer stores (lanes outside the image carry an out-of-range offset).  A = weights, B = pixels: lane (pixel,
-            // half) holds couts (r & 3) + 8 (r >> 2) + 4 half; a store instruction writes four 64-byte row segments.  (The transposed
-            // product -- lane = cout, four consecutive pixels per register quad, dwordx4 stores -- has a quarter of the instructions but
-            // every lane in its own cache line: 64 lines per instruction instead of 4, and was slower: the addresser works per line.)
-            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * COUT * HW), 0, (int)(COUT * HW * sizeof(float)), 0x00020000);
-            const int ox = cur.x0 + (l31 & 15);
-    #pragma unroll
-            for (int j = 0; j < NPB; ++j) {
-                const int oy = cur.y0 + 2 * (j ? br1 : br0) + (l31 >> 4);
-                const int voff = oy < a.H && ox < a.W ? (int)(((size_t)(4 * half) * HW + (size_t)oy * a.W + ox) * 4) : (int)0x80000000;
-    #pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    float bs[16];
-    #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const float4 t = *reinterpret_cast<const float4*>(bias_lds + cb * 32 + 8 * g4 + 4 * half);
-                        bs[4 * g4] = t.x; bs[4 * g4 + 1] = t.y; bs[4 * g4 + 2] = t.z; bs[4 * g4 + 3] = t.w;
-                    }
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float y = FX ? fmaf(acc[j][cb][r], FX_SCALE_INV, bs[r]) : acc[j][cb][r] + bs[r];
-                        if (a.relu) y = fmaxf(y, 0.f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((cb * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
-                    }
-                }
-            }
-        } else {
-            // ---- fused trailing 1x1 (block3.2 / block_fusion.2) on the same matrix cores: the 3x3's D registers (lane = pixel, registers =
-            // couts (r & 3) + 8 (r >> 2) + 4 half), biased and ReLU'd, ARE the 1x1's pixel-side fragments once split: K step t of lane half h
-            // takes the register quads 8 (t & 1), 8 (t & 1) + 4 of cout block t >> 1 (the weights are packed in that K order, as for the
-            // heads' chained layers).  Weight fragments come straight from L2 (24 KiB, the same for every wave; no LDS left for them),
-            // one K step per load batch; the split fragments are double-buffered and kept alive as in head_bx_layer (MFMA operand hazard).
-            float amax = 0.f;
-#pragma unroll
-            for (int j = 0; j < NPB; ++j)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const float4 t = *reinterpret_cast<const float4*>(bias_lds + cb * 32 + 8 * g4 + 4 * half);
-                        const float bq[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float y = FX ? fmaf(acc[j][cb][4 * g4 + e], FX_SCALE_INV, bq[e]) : acc[j][cb][4 * g4 + e] + bq[e];
-                            if (a.relu) y = fmaxf(y, 0.f);
-                            if constexpr (FX) amax = fmaxf(amax, fabsf(y));      // range guard of the 1x1's input (tracked here: inside the split it cost eight spilled registers)
-                            acc[j][cb][4 * g4 + e] = y;
-                        }
-                    }
-            if constexpr (FX) fx_report(amax, a.status);
-            // one pixel block at a time (its two 1x1 accumulators, stores included): both blocks at once do not fit into 256 registers next to
-            // the 3x3's results and the next tile's prefetched input
-            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)cur.b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
-            frag_t w2[2][3], xf[2][NXS];
-            // (buffer loads: ONE address register per lane, the fragment in the scalar offset -- as global loads the 24 fragment addresses were
-            // 48 registers, spilled, and re-read from scratch in front of every load)
-            const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wq2, 0, 4 * 2 * 3 * 1024, 0x00020000);
-            auto ldw2 = [&](int t) {
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) w2[m2][q] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rs_w2, lane * 16, ((t * 2 + m2) * 3 + q) * 1024, 0));
-            };
-#pragma unroll
-            for (int j = 0; j < NPB; ++j) {
-                f32x16 acc2[2];                   // [cout block of the 1x1]
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)      // FUSE 1: D2 rows = couts ; FUSE 2 (transposed product): D2 columns = couts
-                        acc2[m2][r] = (FUSE == 1 ? bias_lds[64 + m2 * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] : bias_lds[64 + m2 * 32 + l31]) * (FX ? 2048.f : 1.f);      // (fx: the accumulator lives at scale 2^11)
-                auto split_step = [&](int t, frag_t (&o)[NXS]) {
-                    uint4 uh, um, ul;
-                    unsigned* ph = &uh.x; unsigned* pm = &um.x; unsigned* pl = &ul.x;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if constexpr (FX) split2_f16(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pl[i]);
-                        else split3(acc[j][t >> 1][8 * (t & 1) + 2 * i], acc[j][t >> 1][8 * (t & 1) + 2 * i + 1], ph[i], pm[i], pl[i]);
-                    }
-                    o[0] = __builtin_bit_cast(frag_t, uh);
-                    if constexpr (FX) o[1] = __builtin_bit_cast(frag_t, ul);
-                    else { o[1] = __builtin_bit_cast(frag_t, um); o[2] = __builtin_bit_cast(frag_t, ul); }
-                };
-                asm volatile("" ::: "memory");
-                ldw2(0);
-                split_step(0, xf[0]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int sb = t & 1;
-                    __builtin_amdgcn_sched_barrier(0);
-                    // products (weight split, input split), small terms first; FUSE 2 swaps the operands (rows = pixels, lane = cout)
-#define BX_MM2(WQ, XQ) { _Pragma("unroll") for (int m2 = 0; m2 < 2; ++m2) acc2[m2] = FUSE == 1 \
-                        ? mfma(w2[m2][WQ], xf[sb][XQ], acc2[m2]) : mfma(xf[sb][XQ], w2[m2][WQ], acc2[m2]); }
-                    if constexpr (FX) { BX_MM2(2, 0) BX_MM2(1, 1) BX_MM2(0, 0) }
-                    else { BX_MM2(2, 0) BX_MM2(0, 2) BX_MM2(1, 1) BX_MM2(1, 0) BX_MM2(0, 1) BX_MM2(0, 0) }
-#undef BX_MM2
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (t + 1 < 4) {
-                        split_step(t + 1, xf[sb ^ 1]);
-                        // the new fragments pass through an asm that uses the old ones and this step's weights: their registers stay occupied
-                        // while the split's results and temporaries are written
-                        asm volatile("" : "+v"(xf[sb ^ 1][0]), "+v"(xf[sb ^ 1][1]), "+v"(xf[sb ^ 1][NXS - 1])
-                                        : "v"(xf[sb][0]), "v"(xf[sb][1]), "v"(xf[sb][NXS - 1]), "v"(w2[0][0]), "v"(w2[0][1]), "v"(w2[0][2]), "v"(w2[1][0]), "v"(w2[1][1]), "v"(w2[1][2]));
-                        __builtin_amdgcn_sched_barrier(0);
-                        ldw2(t + 1);                  // (the loads land hundreds of cycles after the last MFMA read these registers)
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(acc2[0]), "+v"(acc2[1]));      // idle slots before the VALU code of the stores
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (FUSE == 1) {
-                    const int ox = cur.x0 + (l31 & 15);
-                    const int oy = cur.y0 + 2 * (j ? br1 : br0) + (l31 >> 4);
-                    const int voff = oy < a.H && ox < a.W ? (int)(((size_t)(4 * half) * HW + (size_t)oy * a.W + ox) * 4) : (int)0x80000000;
-#pragma unroll
-                    for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float y = FX ? acc2[m2][r] * FX_SCALE_INV : acc2[m2][r];
-                            if (a.relu2) y = fmaxf(y, 0.f);
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((m2 * 32 + (r & 3) + 8 * (r >> 2)) * HW * 4), 0);
-                        }
-                } else {
-                    // channels-last: lane (cout l31, half) holds pixels (r & 3) + 8 (r >> 2) + 4 half of the block: 32 lanes = 128 contiguous bytes
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pm = (r & 3) + 8 * (r >> 2) + 4 * half;          // pixel of the block: row pm >> 4, column pm & 15
-                        const int oy = cur.y0 + 2 * (j ? br1 : br0) + (pm >> 4), ox = cur.x0 + (pm & 15);
-                        const int voff = oy < a.H && ox < a.W ? (int)((((size_t)oy * a.W + ox) * 64 + l31) * 4) : (int)0x80000000;
-#pragma unroll
-                        for (int m2 = 0; m2 < 2; ++m2) {
-                            float y = FX ? acc2[m2][r] * FX_SCALE_INV : acc2[m2][r];
-                            if (a.relu2) y = fmaxf(y, 0.f);
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, m2 * 128, 0);
-                        }
-                    }
-                }
-            }
-        }
-    };
-
-    Tile cur, nxt;
-    int u = u0;
-    u += tile_at(u, cur);
-    nxt = cur;
-    issue_row(0);
-    issue_loads(cur, 0);
-    for (;;) {
-        const bool has_next = u < u1;
-        if (has_next) u += tile_at(u, nxt);
-        BX_STAMP(0)
-        if (cur.full) do_tile(std::integral_constant<int, 2>{}, cur, nxt, has_next);
-        else do_tile(std::integral_constant<int, 1>{}, cur, nxt, has_next);
-        BX_STAMP(50)
-        if (!has_next) break;
-        dma_barrier();                         // every wave is done with the tile's last tap row before the next chunk is staged
-        BX_STAMP(51)
-        ++tix;
-        cur = nxt;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the cyclic stream's last DMA must not outlive the workgroup's LDS
-#undef BX_STAMP
+    conv_bx64_body<CIN, FUSE, FXM, SP>(a);
 }
 
-template <int CIN, int FUSE, bool FX>
-static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
+template <int CIN, int FUSE, int FXM, int SP = 0>
+static int run_bx64(const ConvW& c, const ConvW* c2, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status, const float* zeros = nullptr) {
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     Bx64Args a;
     a.cold = g_debug_cold;
     a.status = status;
-    a.in = in; a.wq = FX ? c.w_fx : c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
-    a.wq2 = c2 ? reinterpret_cast<const uint4*>(FX ? c2->w_fx : c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
+    a.zeros = zeros;
+    a.in = in; a.wq = FXM == 2 ? c.w_fq : FXM ? c.w_fx : c.w_bx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    a.wq2 = c2 ? reinterpret_cast<const uint4*>(FXM ? c2->w_fx : c2->w_bx) : nullptr; a.bias2 = c2 ? c2->bias : nullptr; a.relu2 = c2 ? c2->relu : 0;
     a.ncols = ceil_div(W, 16); a.nhr = ceil_div(H, 8); a.upi = a.ncols * a.nhr;
-    static unsigned attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE, FX>), bx64::LDS_BYTES, attr_done);
+    static AttrMask attr_done = 0;
+    constexpr int lds_bytes = (SP & 1) ? bx64::SP_LDS_BYTES : bx64::LDS_BYTES;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64_kernel<CIN, FUSE, FXM, SP>), lds_bytes, attr_done);
     const long long units = (long long)B * a.upi;
     int grid = 2 * num_cus();                  // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
     if (units < grid) grid = (int)units;       // (small inputs: one unit per workgroup; the XCD mapping then needs grid % 8 == 0 or is skipped)
-    conv_bx64_kernel<CIN, FUSE, FX><<<grid, 256, bx64::LDS_BYTES, st>>>(a);
+    conv_bx64_kernel<CIN, FUSE, FXM, SP><<<grid, 256, lds_bytes, st>>>(a);
     return 0;
 }
 
-int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, bool fx, int* status) {
+int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, const ConvW* c2, bool nhwc, int fx, int* status, int sp, const float* zeros) {
     if (c.ks != 3 || c.stride != 1 || !c.w_bx || c.cout != 64 || c.cin != 64) return -1;
     if (c2 && (c2->ks != 1 || c2->cin != 64 || c2->cout != 64 || !c2->w_bx)) return -1;
-    if (fx && c.w_fx && (!c2 || c2->w_fx)) {      // the fp16-pair arithmetic: three MFMAs per product instead of six
-        if (!c2) return nhwc ? -1 : run_bx64<64, 0, true>(c, nullptr, in, B, H, W, out, st, trace, status);
-        return nhwc ? run_bx64<64, 2, true>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, true>(c, c2, in, B, H, W, out, st, trace, status);
+    if (sp) {      // the split-format link (conv_bx64_body.hpp): 2 = the plain 3x3 writes it, 1 = the fused channels-last form reads it; fp16 pair, three weight fragments
+        if (!(fx && c.w_fx) || !zeros) return -1;
+        if (sp == 2 && !c2 && !nhwc) return run_bx64<64, 0, 1, 2>(c, nullptr, in, B, H, W, out, st, trace, status, zeros);
+        if (sp == 1 && c2 && c2->w_fx && nhwc) return run_bx64<64, 2, 1, 1>(c, c2, in, B, H, W, out, st, trace, status, zeros);
+        return -1;
     }
-    if (!c2) return nhwc ? -1 : run_bx64<64, 0, false>(c, nullptr, in, B, H, W, out, st, trace, status);
-    return nhwc ? run_bx64<64, 2, false>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, false>(c, c2, in, B, H, W, out, st, trace, status);
+    if (fx && c.w_fx && (!c2 || c2->w_fx)) {      // the fp16-pair arithmetic: three MFMAs per product instead of six; fx = 2: two weight fragments in the stream
+        if (fx == 2 && c.w_fq) {
+            if (!c2) return nhwc ? -1 : run_bx64<64, 0, 2>(c, nullptr, in, B, H, W, out, st, trace, status);
+            return nhwc ? run_bx64<64, 2, 2>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, 2>(c, c2, in, B, H, W, out, st, trace, status);
+        }
+        if (!c2) return nhwc ? -1 : run_bx64<64, 0, 1>(c, nullptr, in, B, H, W, out, st, trace, status);
+        return nhwc ? run_bx64<64, 2, 1>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, 1>(c, c2, in, B, H, W, out, st, trace, status);
+    }
+    if (!c2) return nhwc ? -1 : run_bx64<64, 0, 0>(c, nullptr, in, B, H, W, out, st, trace, status);
+    return nhwc ? run_bx64<64, 2, 0>(c, c2, in, B, H, W, out, st, trace, status) : run_bx64<64, 1, 0>(c, c2, in, B, H, W, out, st, trace, status);
 }
 
 }  // namespace xfh

@@ -9,6 +9,8 @@
 //  * conv_direct_generic_kernel: any layer, slow; the independent check used by
 //    xfh_conv_layer(variant=1) to A/B the MFMA kernels on the device.
 #include "kernels.hpp"
+#include "bx_split.hpp"
+#include "block1_fx.hpp"
 #include <type_traits>
 #include <cstdlib>
 #include <cstring>
@@ -102,364 +104,22 @@ int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B,
     return -1;
 }
 
-// ------------------------------------------------------------------------------------------
-// block1 fused: gray (B,1,H,W) -> x1 = block1(gray) + skip1(gray)  (B,24,H/4,W/4)
-//   (modules/model.py:40-48,140).  One workgroup = 8 x 16 output pixels.  The four
-//   low-channel layers run back to back on LDS-resident tiles (halo recomputed per tile,
-//   ~15 % extra FMAs), so the 4/8/8-channel full- and half-resolution activations
-//   (19.7 MB/frame written and re-read by the layer-at-a-time version) never reach HBM:
-//   the kernel reads the gray tile once and writes x1 once.
-//
-//   tile extents (rows x cols), origin in its own map:
-//     out  8 x 16  at (Y4, X4)            [H/4 x W/4]
-//     c3  17 x 33  at (2Y4-1, 2X4-1)      [H/2 x W/2]   conv3 8->8 s1
-//     c2  19 x 35  at (2Y4-2, 2X4-2)      [H/2 x W/2]   conv2 4->8 s2
-//     c1  39 x 71  at (4Y4-5, 4X4-5)      [H x W]       conv1 1->4 s1
-//     g   41 x 73  at (4Y4-6, 4X4-6)      [H x W]       normalised gray
-//   Positions outside a map are stored as 0 = the next conv's zero padding.
-//   Weights are read with wave-uniform addresses (scalar loads, SGPR operands of v_fmac).
-// ------------------------------------------------------------------------------------------
-namespace b1 {
-constexpr int OH = 8, OW = 16;
-constexpr int C3H = 17, C3W = 33, C2H = 19, C2W = 35, C1H = 39, C1W = 71, GH = 41, GW = 73;
-constexpr int G_OFF = 0, G_SZ = GH * GW;                  // 2993 (+ 1: rows are loaded as column pairs, the last pair of the last row spills one element)
-constexpr int SK_OFF = G_OFF + G_SZ + 1, SK_SZ = OH * OW; // 4 x 4 averages of the gray tile (skip1's AvgPool2d), one per output pixel
-constexpr int C1_OFF = SK_OFF + SK_SZ, C1_SZ = 4 * C1H * C1W;  // 11076
-constexpr int C2_OFF = C1_OFF + C1_SZ, C2_SZ = 8 * C2H * C2W;  // 5320
-constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead once c2 exists)
-constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19518 floats = 78.1 KB
-// mode 5 (conv1 recomputed inside conv2, no c1 tile): g | sk | c2 | c3 = 51.7 KB -> three workgroups per CU.  (c3 over the dead gray tile
-// = 39.7 KB = four per CU measured 0.947 of mode 4's time against 0.924 for three: more waves than the LDS pipe and L1 feed.)
-constexpr int F_SK_OFF = SK_OFF, F_C2_OFF = SK_OFF + SK_SZ, F_C3_OFF = F_C2_OFF + C2_SZ, F_LDS_FLOATS = F_C3_OFF + 8 * C3H * C3W;      // 12930 floats
-}  // namespace b1
+}  // namespace xfh
+#include "block1_body.hpp"      // block1_fused_body<MODE>: the fused block1 + skip1 (also compiled for the host by tests/emu/)
+namespace xfh {
 
-template <int C1MODE>      // conv1: 1 = a pixel per thread, 3 = three adjacent pixels (scalar FMAs), 4 = three adjacent pixels on packed FMAs,
-                           // 5 = recomputed from the gray tile inside conv2 (no c1 tile in LDS)
-__global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int B, int H, int W,
-                                                           int tiles_x, int tiles_y,
-                                                           const float* __restrict__ w1, const float* __restrict__ bb1,
-                                                           const float* __restrict__ w2, const float* __restrict__ bb2,
-                                                           const float* __restrict__ w3, const float* __restrict__ bb3,
-                                                           const float* __restrict__ w4, const float* __restrict__ bb4,
-                                                           const float* __restrict__ skw, const float* __restrict__ skb) {
-    using namespace b1;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* G = lds + G_OFF;
-    float* SK = lds + (C1MODE == 5 ? F_SK_OFF : SK_OFF);
-    float* C1 = lds + C1_OFF;
-    float* C2 = lds + (C1MODE == 5 ? F_C2_OFF : C2_OFF);
-    float* C3 = lds + (C1MODE == 5 ? F_C3_OFF : C3_OFF);
-    const int tid = threadIdx.x;
-    // the tiles of an image run on one XCD: the 4-pixel gray halos of neighbouring tiles hit its L2
-    int b, item;
-    if (!xcd_group_map(blockIdx.x, tiles_x * tiles_y, B, b, item)) return;
-    const int Y4 = (item / tiles_x) * OH, X4 = (item % tiles_x) * OW;
-    const int H2 = H >> 1, W2 = W >> 1, H4 = H >> 2, W4 = W >> 2;
-    const float* gb = gray + (size_t)b * H * W;
-
-    // ---- stage 0: gray tile, instance-normalised on the way in (zero padding stays zero) -------
-    const float alpha = coef[2 * b], beta = coef[2 * b + 1];
-    {   // the tile as 8-byte column pairs (its origin 4 X4 - 6 and W are even: a pair never straddles the image border), all three loads of a
-        // thread in flight together (a rolled loop waits for each one); half the index arithmetic of the dword version (PMC: the kernel is bound
-        // by the number of vector instructions it issues, and 46 % of them are not FMAs)
-        constexpr int PW = (GW + 1) / 2, NP = GH * PW, NL = (NP + 511) / 512;      // 37 pairs per row (the last one holds column 72 and a spill)
-        float2 raw[NL];
-        bool in[NL];
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            const int e = tid + k * 512;
-            const int r = e / PW, c = 2 * (e - r * PW);
-            const int gy = 4 * Y4 - 6 + r, gx = 4 * X4 - 6 + c;
-            in[k] = e < NP && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            raw[k] = in[k] ? *reinterpret_cast<const float2*>(gb + (size_t)gy * W + gx) : make_float2(0.f, 0.f);
-        }
-#pragma unroll
-        for (int k = 0; k < NL; ++k) {
-            const int e = tid + k * 512;
-            if (e < NP) {
-                const int r = e / PW, c = 2 * (e - r * PW);
-                float* g = G + r * GW + c;                   // (row pitch 73: odd rows are only 4-byte aligned -> two dword stores)
-                g[0] = in[k] ? fmaf(raw[k].x, alpha, beta) : 0.f;
-                if (c + 1 < GW || r + 1 == GH) g[1] = in[k] ? fmaf(raw[k].y, alpha, beta) : 0.f;      // (column 73 of rows 0..39 is column 0 of the next row: its own pair writes it)
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- stage 1: conv1 1->4, s1 --------------------------------------------------------------
-    if constexpr (C1MODE == 5) {
-        // (no c1 tile: stage 2 recomputes the nine c1 pixels of its window from the gray tile)
-    } else if constexpr (C1MODE == 4) {
-        // three adjacent pixels per thread, cout pairs on v_pk_fma_f32 (written as 2-vectors: left to itself hipcc emits 108 v_fmac_f32 here)
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        constexpr int NG = (C1W + 2) / 3;
-        for (int e = tid; e < C1H * NG; e += 512) {
-            const int r = e / NG, c0 = (e - r * NG) * 3;
-            const int gy = 4 * Y4 - 5 + r, gx0 = 4 * X4 - 5 + c0;
-            f2 acc[3][2];
-#pragma unroll
-            for (int px = 0; px < 3; ++px) { acc[px][0] = f2{bb1[0], bb1[1]}; acc[px][1] = f2{bb1[2], bb1[3]}; }
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                float v[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) v[j] = G[(r + dy) * GW + c0 + j];          // (the last group reads one element past its row: unused pixel)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* w = w1 + (dy * 3 + dx) * 4;
-                    const f2 w01 = f2{w[0], w[1]}, w23 = f2{w[2], w[3]};
-#pragma unroll
-                    for (int px = 0; px < 3; ++px) {
-                        const f2 vv = f2{v[px + dx], v[px + dx]};
-                        acc[px][0] = __builtin_elementwise_fma(vv, w01, acc[px][0]);
-                        acc[px][1] = __builtin_elementwise_fma(vv, w23, acc[px][1]);
-                    }
-                }
-            }
-            const bool rowok = gy >= 0 && gy < H;
-#pragma unroll
-            for (int px = 0; px < 3; ++px) {
-                const int gx = gx0 + px;
-                const bool ok = rowok && gx >= 0 && gx < W;
-                if (c0 + px < C1W) {
-                    float* o = C1 + r * C1W + c0 + px;
-                    o[0] = ok ? fmaxf(acc[px][0].x, 0.f) : 0.f;
-                    o[C1H * C1W] = ok ? fmaxf(acc[px][0].y, 0.f) : 0.f;
-                    o[2 * C1H * C1W] = ok ? fmaxf(acc[px][1].x, 0.f) : 0.f;
-                    o[3 * C1H * C1W] = ok ? fmaxf(acc[px][1].y, 0.f) : 0.f;
-                }
-            }
-        }
-    } else if constexpr (C1MODE == 3) {
-        // three adjacent pixels per thread: one index computation and 15 LDS reads for 3 x 36 FMAs (a pixel alone: 9 reads for 36)
-        constexpr int NG = (C1W + 2) / 3;
-        for (int e = tid; e < C1H * NG; e += 512) {
-            const int r = e / NG, c0 = (e - r * NG) * 3;
-            const int gy = 4 * Y4 - 5 + r, gx0 = 4 * X4 - 5 + c0;
-            float acc[3][4];
-#pragma unroll
-            for (int px = 0; px < 3; ++px)
-#pragma unroll
-                for (int co = 0; co < 4; ++co) acc[px][co] = bb1[co];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                float v[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) v[j] = G[(r + dy) * GW + c0 + j];          // (the last group reads one element past its row: unused pixel)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* w = w1 + (dy * 3 + dx) * 4;
-#pragma unroll
-                    for (int px = 0; px < 3; ++px)
-#pragma unroll
-                        for (int co = 0; co < 4; ++co) acc[px][co] = fmaf(v[px + dx], w[co], acc[px][co]);
-                }
-            }
-            const bool rowok = gy >= 0 && gy < H;
-#pragma unroll
-            for (int px = 0; px < 3; ++px) {
-                const int gx = gx0 + px;
-                const bool ok = rowok && gx >= 0 && gx < W;
-                if (c0 + px < C1W) {
-#pragma unroll
-                    for (int co = 0; co < 4; ++co) C1[co * (C1H * C1W) + r * C1W + c0 + px] = ok ? fmaxf(acc[px][co], 0.f) : 0.f;
-                }
-            }
-        }
-    } else
-    for (int e = tid; e < C1H * C1W; e += 512) {
-        const int r = e / C1W, c = e - r * C1W;
-        const int gy = 4 * Y4 - 5 + r, gx = 4 * X4 - 5 + c;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-#pragma unroll
-            for (int co = 0; co < 4; ++co) acc[co] = bb1[co];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float v = G[(r + dy) * GW + c + dx];
-                    const float* w = w1 + (dy * 3 + dx) * 4;
-#pragma unroll
-                    for (int co = 0; co < 4; ++co) acc[co] = fmaf(v, w[co], acc[co]);
-                }
-#pragma unroll
-            for (int co = 0; co < 4; ++co) acc[co] = fmaxf(acc[co], 0.f);
-        }
-#pragma unroll
-        for (int co = 0; co < 4; ++co) C1[co * (C1H * C1W) + e] = acc[co];
-    }
-    if (tid >= 384) {       // skip1's 4 x 4 averages, once per output pixel (the second pass of conv1 occupies threads 0..410: these 128 are the least loaded;
-                            // round 2 had each of stage 4's four cout groups recompute them: 16 LDS reads + 16 adds per thread)
-        const int p = tid - 384, r = p >> 4, c = p & 15;
-        float sm = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) sm += G[(4 * r + 6 + i) * GW + 4 * c + 6 + jj];
-        SK[p] = sm * 0.0625f;
-    }
-    if constexpr (C1MODE != 5) __syncthreads();
-
-    // ---- stage 2: conv2 4->8, s2 --------------------------------------------------------------
-    if constexpr (C1MODE == 5) {
-        // conv1 inside conv2: a c2 pixel needs the 3 x 3 c1 pixels (2r + py, 2c + px), each a 3 x 3 window of the gray tile: 25 LDS reads
-        // and 9 x 36 FMAs in registers instead of 36 reads of a c1 tile that first had to be computed, written (44 KB of LDS, the largest
-        // tile of the kernel) and waited for behind a barrier.  2.25x the conv1 FLOPs (+ 12 % of the kernel's), one stage and 26 KB less.
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        for (int e = tid; e < C2H * C2W; e += 512) {
-            const int r = e / C2W, c = e - r * C2W;
-            const int gy = 2 * Y4 - 2 + r, gx = 2 * X4 - 2 + c;
-            float acc[8];
-#pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = 0.f;
-            if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
-                float g[5][5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i)
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) g[i][j] = G[(2 * r + i) * GW + 2 * c + j];
-                // c1[py][px][ch]: ReLU(conv1), zero outside the full-resolution map (= conv2's zero padding)
-                f2 c1v[3][3][2];
-#pragma unroll
-                for (int py = 0; py < 3; ++py)
-#pragma unroll
-                    for (int px = 0; px < 3; ++px) {
-                        f2 a01 = f2{bb1[0], bb1[1]}, a23 = f2{bb1[2], bb1[3]};
-#pragma unroll
-                        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                            for (int dx = 0; dx < 3; ++dx) {
-                                const float* w = w1 + (dy * 3 + dx) * 4;
-                                const f2 vv = f2{g[py + dy][px + dx], g[py + dy][px + dx]};
-                                a01 = __builtin_elementwise_fma(vv, f2{w[0], w[1]}, a01);
-                                a23 = __builtin_elementwise_fma(vv, f2{w[2], w[3]}, a23);
-                            }
-                        const int y1 = 4 * Y4 - 5 + 2 * r + py, x1 = 4 * X4 - 5 + 2 * c + px;
-                        const bool ok = y1 >= 0 && y1 < H && x1 >= 0 && x1 < W;
-                        // ReLU and the zero padding in ONE op per value: median(a, 0, hi) = max(a, 0) for hi = +inf, = 0 for hi = 0
-                        const float hi = ok ? __builtin_inff() : 0.f;
-                        c1v[py][px][0] = f2{__builtin_amdgcn_fmed3f(a01.x, 0.f, hi), __builtin_amdgcn_fmed3f(a01.y, 0.f, hi)};
-                        c1v[py][px][1] = f2{__builtin_amdgcn_fmed3f(a23.x, 0.f, hi), __builtin_amdgcn_fmed3f(a23.y, 0.f, hi)};
-                    }
-                // conv2 on explicit 2-vectors: hipcc left the scalar form as 288 v_fmac_f32 per pixel (the PMC count of the kernel, 125 M vector
-                // wave-instructions per launch = 93 % of its duration at 4 cycles each, says the kernel IS vector-issue bound: 45 % of them were this stage)
-                f2 q[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = f2{bb2[2 * j], bb2[2 * j + 1]};
-#pragma unroll
-                for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-                    for (int py = 0; py < 3; ++py)
-#pragma unroll
-                        for (int px = 0; px < 3; ++px) {
-                            const float v = ci & 1 ? c1v[py][px][ci >> 1].y : c1v[py][px][ci >> 1].x;
-                            const float* w = w2 + ((ci * 9) + py * 3 + px) * 8;
-                            const f2 vv = f2{v, v};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) q[j] = __builtin_elementwise_fma(vv, f2{w[2 * j], w[2 * j + 1]}, q[j]);
-                        }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { acc[2 * j] = fmaxf(q[j].x, 0.f); acc[2 * j + 1] = fmaxf(q[j].y, 0.f); }
-            }
-#pragma unroll
-            for (int co = 0; co < 8; ++co) C2[co * (C2H * C2W) + e] = acc[co];
-        }
-    } else
-    for (int e = tid; e < C2H * C2W; e += 512) {
-        const int r = e / C2W, c = e - r * C2W;
-        const int gy = 2 * Y4 - 2 + r, gx = 2 * X4 - 2 + c;
-        float acc[8];
-#pragma unroll
-        for (int co = 0; co < 8; ++co) acc[co] = 0.f;
-        if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
-#pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = bb2[co];
-#pragma unroll 1
-            for (int ci = 0; ci < 4; ++ci) {
-                const float* src = C1 + ci * (C1H * C1W) + (2 * r) * C1W + 2 * c;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float v = src[dy * C1W + dx];
-                        const float* w = w2 + ((ci * 9) + dy * 3 + dx) * 8;
-#pragma unroll
-                        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, w[co], acc[co]);
-                    }
-            }
-#pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = fmaxf(acc[co], 0.f);
-        }
-#pragma unroll
-        for (int co = 0; co < 8; ++co) C2[co * (C2H * C2W) + e] = acc[co];
-    }
-    __syncthreads();
-
-    // ---- stage 3: conv3 8->8, s1 (writes over the dead c1 tile) ----------------------------------
-    for (int e = tid; e < C3H * C3W; e += 512) {
-        const int r = e / C3W, c = e - r * C3W;
-        const int gy = 2 * Y4 - 1 + r, gx = 2 * X4 - 1 + c;
-        float acc[8];
-#pragma unroll
-        for (int co = 0; co < 8; ++co) acc[co] = 0.f;
-        if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
-#pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = bb3[co];
-#pragma unroll 1
-            for (int ci = 0; ci < 8; ++ci) {
-                const float* src = C2 + ci * (C2H * C2W) + r * C2W + c;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float v = src[dy * C2W + dx];
-                        const float* w = w3 + ((ci * 9) + dy * 3 + dx) * 8;
-#pragma unroll
-                        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, w[co], acc[co]);
-                    }
-            }
-#pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = fmaxf(acc[co], 0.f);
-        }
-#pragma unroll
-        for (int co = 0; co < 8; ++co) C3[co * (C3H * C3W) + e] = acc[co];
-    }
-    __syncthreads();
-
-    // ---- stage 4: conv4 8->24, s2 + skip1 + residual add; thread = (pixel, 6 of 24 couts) -------
-    {
-        const int p = tid & 127, r = p >> 4, c = p & 15;
-        const int g = __builtin_amdgcn_readfirstlane(tid >> 7);      // wave pair -> couts 6g .. 6g+5
-        const int oy = Y4 + r, ox = X4 + c;
-        float acc[6];
-#pragma unroll
-        for (int j = 0; j < 6; ++j) acc[j] = bb4[g * 6 + j];
-#pragma unroll 1
-        for (int ci = 0; ci < 8; ++ci) {
-            const float* src = C3 + ci * (C3H * C3W) + (2 * r) * C3W + 2 * c;
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float v = src[dy * C3W + dx];
-                    const float* w = w4 + ((ci * 9) + dy * 3 + dx) * 24 + g * 6;
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) acc[j] = fmaf(v, w[j], acc[j]);
-                }
-        }
-        // skip1: 4x4 average of the gray tile (AvgPool2d(4,4), computed once in stage 1), then 1x1 conv 1->24 with bias
-        const float sk = SK[p];
-        if (oy < H4 && ox < W4) {
-            float* op = x1 + (((size_t)b * 24 + g * 6) * H4 + oy) * W4 + ox;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float v = fmaxf(acc[j], 0.f) + fmaf(sk, skw[g * 6 + j], skb[g * 6 + j]);
-                op[(size_t)j * H4 * W4] = v;
-            }
-        }
-    }
-}
+#define XFH_B1_PARAMS const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int B, int H, int W, int tiles_x, int tiles_y,                      \
+                      const float* __restrict__ w1, const float* __restrict__ bb1, const float* __restrict__ w2, const float* __restrict__ bb2, const float* __restrict__ w3,     \
+                      const float* __restrict__ bb3, const float* __restrict__ w4, const float* __restrict__ bb4, const float* __restrict__ skw, const float* __restrict__ skb, \
+                      const void* __restrict__ w4fx, const void* __restrict__ w3fx, int* __restrict__ status, int cold
+#define XFH_B1_ARGS gray, coef, x1, B, H, W, tiles_x, tiles_y, w1, bb1, w2, bb2, w3, bb3, w4, bb4, skw, skb, w4fx, w3fx, status, cold
+template <int C1MODE>
+__global__ __launch_bounds__(512) void block1_fused_kernel(XFH_B1_PARAMS) { block1_fused_body<C1MODE>(XFH_B1_ARGS); }
+// modes 6, 7 keep the three workgroups per CU of mode 5: six waves per SIMD = at most 80 vector registers
+template <int MODE>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) void block1_mx_kernel(XFH_B1_PARAMS) { block1_fused_body<MODE>(XFH_B1_ARGS); }
+#undef XFH_B1_PARAMS
+#undef XFH_B1_ARGS
 
 // Split-bf16 MFMA variants of block1_fused_kernel (round 2: measured, identical results within fp32 rounding, slower, removed -- DESIGN 3.6).
 // conv3 (8 -> 8) and conv4 (8 -> 24, s2) have K = 72 = 9 taps x 8 channels: four taps per v_mfma_f32_16x16x32_bf16, three K steps of six MFMAs;
@@ -490,7 +150,7 @@ __global__ __launch_bounds__(512) void block1_fused_kernel(const float* __restri
 //   * workgroup size (same tiles, conv4 on 24 / (threads / 128) couts per thread): 256 threads 330 us, 512 threads 280 us, 1024 threads
 //     380 us (alternating in-run pairs): with 16 waves conv4 reads its 72 inputs twice as often per FMA, with 4 waves nothing hides the LDS latency.
 
-void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant) {
+void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant, int* status) {
     const ConvW& c0 = nw.conv[L_BLOCK1_0];
     const ConvW& c1w = nw.conv[L_BLOCK1_1];
     const ConvW& c2 = nw.conv[L_BLOCK1_2];
@@ -514,18 +174,29 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     // blocks on 8 waves), the two workgroups of a CU run their stages in phase (no matrix / vector overlap to collect), and the extra barrier
     // and LDS round trip come on top.  What the vector pipe is short of is issue slots (PMC: 116 M vector instructions, 54 % FMAs, inner loops
     // already 95 % v_pk_fma_f32) -- the remaining lever is the per-item prologue / epilogue arithmetic of the stages, not another pipe.
-    const int c1 = (variant == 1 || variant == 3 || variant == 4) ? variant : 5;      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels on packed FMAs; default (0 / 5): conv1 recomputed inside conv2 (xfh_set_option rejects every other value)
-    static unsigned attr1 = 0, attr3 = 0, attr4 = 0, attr5 = 0;
+    const int c1 = (variant == 1 || variant == 3 || variant == 4) ? variant : ((variant == 6 || variant == 7) && nw.block1_fx && nw.block1_fx3) ? variant : 5;      // (6 / 7 without the fp16-pair images -- a weight of magnitude >= 31 -- are 5)      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels on packed FMAs; default (0 / 5): conv1 recomputed inside conv2 (xfh_set_option rejects every other value)
+    static AttrMask attr1{0}, attr3{0}, attr4{0}, attr5{0}, attr6{0}, attr7{0};
 #define XFH_B1_LAUNCH(MODE, ATTR)                                                                                                       \
     {                                                                                                                                    \
-        constexpr int lds_floats = MODE == 5 ? b1::F_LDS_FLOATS : b1::LDS_FLOATS;                                                        \
+        constexpr int lds_floats = MODE >= 5 ? b1::F_LDS_FLOATS : b1::LDS_FLOATS;                                                        \
         set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<MODE>), lds_floats * 4, ATTR);                             \
         block1_fused_kernel<MODE><<<xcd_grid_size(tx * ty, B), 512, lds_floats * 4, st>>>(                                               \
-            gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias); \
+            gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold); \
     }
     if (c1 == 1) XFH_B1_LAUNCH(1, attr1)
     else if (c1 == 3) XFH_B1_LAUNCH(3, attr3)
     else if (c1 == 5) XFH_B1_LAUNCH(5, attr5)
+    else if (c1 == 6) {
+        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_mx_kernel<6>), b1::M_LDS_FLOATS * 4, attr6);
+        block1_mx_kernel<6><<<xcd_grid_size(tx * ty, B), 512, b1::M_LDS_FLOATS * 4, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
+                                                                                           c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold);
+    } else if (c1 == 7) {      // (+ conv3's weight image behind the tiles: 53.6 KB, still three workgroups per CU)
+        constexpr int lds7 = b1::M_LDS_FLOATS * 4 + b1fx::W3_BYTES;
+        static_assert(3 * ((lds7 + 1279) / 1280 * 1280) <= 160 * 1024, "three workgroups per CU, also with 1280-byte allocation granules");
+        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_mx_kernel<7>), lds7, attr7);
+        block1_mx_kernel<7><<<xcd_grid_size(tx * ty, B), 512, lds7, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
+                                                                           c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold);
+    }
     else XFH_B1_LAUNCH(4, attr4)
 #undef XFH_B1_LAUNCH
 }

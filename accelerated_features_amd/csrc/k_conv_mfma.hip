@@ -379,7 +379,7 @@ static int run(const ConvW& c, const ConvW* c2, const float* zeros, const float*
     g.tiles = tiles; g.B = B;
     const size_t lds = ((size_t)2 * (WCH + CK * g.PS) + (size_t)COUT * COUT2_PAD * (COUT2 > 0)) * sizeof(float);
     if (lds > 160 * 1024) return -1;
-    static unsigned attr_a = 0, attr_b = 0;     // per instantiation of run<>, per device
+    static AttrMask attr_a{0}, attr_b{0};     // per instantiation of run<>, per device
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, true, COUT2, NBO>), 160 * 1024, attr_a);
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, false, COUT2, NBO>), 160 * 1024, attr_b);
     if (nhwc) conv_mfma_kernel<CIN, COUT, KS, STRIDE, CK, NSEG, true, COUT2, NBO><<<xcd_grid_size(tiles, B), 256, lds, st>>>(a);

@@ -471,7 +471,7 @@ static int run_wino(const ConvW& c, const float* in, int B, int H, int W, float*
     a.tiles = a.tiles_x * ceil_div(ceil_div(H, 2), TTH);
     const size_t lds = (size_t)Cfg::LDS_FLOATS * sizeof(float);
     static_assert(Cfg::LDS_FLOATS * sizeof(float) <= 160 * 1024, "LDS budget");
-    static unsigned attr_done = 0;
+    static AttrMask attr_done = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC>), 160 * 1024, attr_done);
     int grid = xcd_grid_size(a.tiles, B);
     conv_wino_kernel<CIN, COUT, CB, TBG, NCBW, NTBW, TTH, TTW, COUT2, NHWC><<<grid, Cfg::NTHR, lds, st>>>(a);

@@ -435,7 +435,7 @@ static void run_topk(const ScoreSrc* src, const float* vals, unsigned long long*
     else
         topk_sort_runs_kernel<1><<<xcd_grid_size(qmax, B), 1024, 0, st>>>(ScoreSrc{}, vals, n_dev, n_const, n_cap, top_k, qmax, B, runs, nsel, n_valid);
     const int lds_runs = min(ceil_div(n_cap, TK_CH), TK_LDS_RUNS);
-    static unsigned attr_mask = 0;
+    static AttrMask attr_mask = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(topk_rank_merge_kernel), TK_LDS_RUNS * TK_CH * 8, attr_mask);
     topk_rank_merge_kernel<<<xcd_grid_size(qmax, B), 1024, (size_t)lds_runs * TK_CH * 8, st>>>(runs, n_dev, n_const, n_cap, top_k, qmax, B, lds_runs, skeys);
 }

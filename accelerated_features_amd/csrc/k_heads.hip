@@ -16,8 +16,12 @@
 // The kernels are persistent: grid = #CUs, the head's weights are copied to LDS once per
 // workgroup, and the next tile's activations are in flight while layers 2..4 run.
 #include "kernels.hpp"
+#include "bx_split.hpp"
+#include "head_bx_body.hpp"
+#include "head_f32r_body.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace xfh {
 
@@ -25,56 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int HD_CELLS = 256;    // cells per tile
 constexpr int HD_XS = 65;        // LDS row stride of the activation tile
-
-struct HeadArgs {
-    const float* src;        // KP: raw gray (B,H,W) ; REL: feats (B*hc*wc, 64)
-    const float* coef;       // KP: per-image instance-norm {alpha, beta}
-    const float* zeros;
-    const float* w[4];       // [64][n_pad] per layer (BN folded)
-    const float* bias[4];
-    float* out;              // KP: heat (B,H,W) ; REL: reliability (B*hc*wc)
-    float* logits;           // KP only, optional: (B*hc*wc, 65)
-    float* inv;              // REL only, optional: 1 / max(||feats[cell,:]||, 1e-12)  (F.normalize(M1, dim=1), xfeat.py:70)
-    int H, W, hc, wc, ncell, ntiles;
-    int cold;
-};
-
-// one chained 64 -> 32*MBO layer: out = bias + W^T relu(in)   (in/out in D[feature][cell] layout)
-template <int MBO>
-__device__ inline void chain_layer(const float* __restrict__ Wl, int npad, const float* __restrict__ bias,
-                                   const f32x16 (&in)[2], f32x16 (&out)[MBO], int l31, int half) {
-#pragma unroll
-    for (int m = 0; m < MBO; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[m][r] = bias[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-    const float* wb = Wl + (4 * half) * npad + l31;     // this lane's channel offset (c or c+4)
-    float av[2][MBO];
-    auto ld = [&](int st, float (&ao)[MBO]) {
-        const int m = st >> 4, r = st & 15;
-        const int k0 = m * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-        for (int mo = 0; mo < MBO; ++mo) ao[mo] = wb[k0 * npad + mo * 32];
-    };
-    ld(0, av[0]);
-    __builtin_amdgcn_sched_group_barrier(0x100, MBO, 0);
-#pragma unroll
-    for (int st = 0; st < 32; ++st) {
-        if (st + 1 < 32) ld(st + 1, av[(st + 1) & 1]);
-        const float y = fmaxf(in[st >> 4][st & 15], 0.f);
-#pragma unroll
-        for (int mo = 0; mo < MBO; ++mo)
-            out[mo] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st & 1][mo], y, out[mo], 0, 0, 0);
-        if (st + 1 < 32) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, MBO, 0);
-            if (MBO > 1) __builtin_amdgcn_sched_group_barrier(0x008, MBO - 1, 0);
-        } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, MBO, 0);
-        }
-    }
-}
 
 // SHIFT (debug, tools/head_soak.py; torture build only): the kernel body moved by SHIFT x 4 bytes against the 64-byte instruction-cache lines
 template <bool KP, int SHIFT = 0>
@@ -238,434 +193,53 @@ __global__ __launch_bounds__(512) void head_fused_kernel(HeadArgs a) {
 }
 
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// The f32-MFMA heads without the activation tile (round 4; option heads_f32 = 2).  head_fused_kernel stages a tile's first-layer input in LDS and
-// needs two barriers per tile for it: its eight waves run every phase together, and the softmax / store epilogue of all of them meets idle matrix
-// cores (157 + 61 us per 64-frame step against ~105 us of f32 MFMA work).  Here the first layer's B operand comes straight from registers: with the K
-// order  step p = 4 dy + i, lane half h  <->  channel 8 dy + 4 h + i  a lane's 32 channels are eight float4 (half a pixel row of the 8x8 cell for the
-// unfold; half of every 8-channel group of the channels-last feature row), loaded one tile ahead; the weights' LDS address follows the same order.
-// After the weights have landed there is no barrier: the waves drift apart and cover each other's epilogues, as in head_bx_kernel -- on the f32
-// instruction (v_mfma_f32_32x32x2_f32, one VGPR per operand), which the cold-instruction-cache torture of tools/head_soak.py does not trip.
-// ------------------------------------------------------------------------------------------------------------------------------
-template <bool KP, int SHIFT = 0>
+// the default heads: body in head_f32r_body.hpp (also compiled for the host by tests/emu/)
+template <bool KP, int SHIFT = 0, bool DUST = true>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_f32r_kernel(HeadArgs a) {
     code_shift<SHIFT>();
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    constexpr int NL = KP ? 4 : 3;
-    extern __shared__ __attribute__((aligned(16))) float smem_r[];
-    float* Wl = smem_r;
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hw = a.hc * a.wc;
-    {
-        int off = 0;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const int n = (KP && l == 3) ? 64 * 96 : ((!KP && l == 2) ? 64 : 64 * 64);
-            if (n >= 256) {
-                for (int j = wave; j < n / 256; j += 8)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(a.w[l] + j * 256 + lane * 4), (lptr_t)(Wl + off + j * 256), 16, 0, 0);
-            } else if (wave == 0) {
-                __builtin_amdgcn_global_load_lds((gptr_t)(a.w[l] + lane), (lptr_t)(Wl + off), 4, 0, 0);
-            }
-            off += n;
-        }
-    }
-    float4 xin[8];
-    float nalpha = 1.f, nbeta = 0.f;                                   // (of the tile xin belongs to)
-    auto issue_x = [&](int tile) __attribute__((always_inline)) {
-        const int g = min(tile * HD_CELLS + wave * 32 + l31, a.ncell - 1);      // cells past the end: copies of the last one, never stored
-        const float* p;
-        size_t step;
-        if (KP) {
-            const int b = g / hw, rem = g - b * hw;
-            const int ci = rem / a.wc, cj = rem - ci * a.wc;
-            p = a.src + (size_t)b * a.H * a.W + (size_t)(8 * ci) * a.W + 8 * cj + 4 * half;      // pixel row dy, columns 4 h .. 4 h + 3
-            step = (size_t)a.W;
-            nalpha = a.coef[2 * b]; nbeta = a.coef[2 * b + 1];
-        } else {
-            p = a.src + (size_t)g * 64 + 4 * half;
-            step = 8;
-        }
-#pragma unroll
-        for (int dy = 0; dy < 8; ++dy) xin[dy] = *reinterpret_cast<const float4*>(p + dy * step);
-    };
-    int tile = blockIdx.x;
-    if (tile < a.ntiles) issue_x(tile);
-    lds_dma_barrier();                                                // the weights have landed; no barrier from here on
-    for (; tile < a.ntiles; tile += gridDim.x) {
-        const int gcell = tile * HD_CELLS + wave * 32 + l31;          // this lane's cell
-        f32x16 accA[2], accB[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accA[m][r] = a.bias[0][m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-        {
-            const float* wb = Wl + (4 * half) * 64 + l31;               // step p -> channel 8 (p >> 2) + 4 half + (p & 3)
-            const float al = nalpha, be = nbeta;
-            float av[2][2];
-            auto ld = [&](int p, float (&ao)[2]) {
-                const int k = 8 * (p >> 2) + (p & 3);
-                ao[0] = wb[k * 64];
-                ao[1] = wb[k * 64 + 32];
-            };
-            ld(0, av[0]);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            float nrm2 = 0.f;          // REL: this lane walks 32 of its cell's 64 channels anyway -> squared norm for free
-#pragma unroll
-            for (int p = 0; p < 32; ++p) {
-                if (p + 1 < 32) ld(p + 1, av[(p + 1) & 1]);
-                const float4 q = xin[p >> 2];
-                const float raw = (p & 3) == 0 ? q.x : (p & 3) == 1 ? q.y : (p & 3) == 2 ? q.z : q.w;
-                const float xv = KP ? fmaf(raw, al, be) : raw;
-                if (!KP) nrm2 = fmaf(xv, xv, nrm2);
-                accA[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][0], xv, accA[0], 0, 0, 0);
-                accA[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][1], xv, accA[1], 0, 0, 0);
-                if (p + 1 < 32) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                } else {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                }
-            }
-            if (!KP && a.inv) {
-                nrm2 += xhalf(nrm2);                       // the other 32 channels sit in the other half-wave
-                if (half == 0 && gcell < a.ncell) a.inv[gcell] = 1.f / fmaxf(sqrtf(nrm2), 1e-12f);
-            }
-        }
-        if (tile + (int)gridDim.x < a.ntiles) issue_x(tile + gridDim.x);      // the next tile's input flies during the chained layers
-        if (KP) {
-            chain_layer<2>(Wl + 64 * 64, 64, a.bias[1], accA, accB, l31, half);
-            chain_layer<2>(Wl + 2 * 64 * 64, 64, a.bias[2], accB, accA, l31, half);
-            f32x16 lg[3];
-            chain_layer<3>(Wl + 3 * 64 * 64, 96, a.bias[3], accA, lg, l31, half);
-            // lane (l31,half) holds logits c = 32m + (r&3) + 8(r>>2) + 4*half of its cell; c == 64 (dustbin) is m=2,r=0,half=0
-            float mx = -INFINITY;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, lg[m][r]);
-            if (half == 0) mx = fmaxf(mx, lg[2][0]);
-            mx = fmaxf(mx, xhalf(mx));
-            float sum = 0.f;
-            f32x16 e[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { e[m][r] = expf(lg[m][r] - mx); sum += e[m][r]; }
-            if (half == 0) sum += expf(lg[2][0] - mx);
-            sum += xhalf(sum);
-            if (gcell < a.ncell) {
-                const int b = gcell / hw, rem = gcell - b * hw;
-                const int ci = rem / a.wc, cj = rem - ci * a.wc;
-                float* o = a.out + (size_t)b * a.H * a.W + (size_t)(8 * ci) * a.W + 8 * cj + 4 * half;
-                const float rs = 1.f / sum;                // one correctly-rounded divide, then 64 multiplies
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {          // dy = q + 4m, dx = 4*half .. +3
-                        const float4 v = make_float4(e[m][4 * q] * rs, e[m][4 * q + 1] * rs, e[m][4 * q + 2] * rs, e[m][4 * q + 3] * rs);
-                        *reinterpret_cast<float4*>(o + (size_t)(q + 4 * m) * a.W) = v;
-                    }
-                if (a.logits) {
-                    float* lp = a.logits + (size_t)gcell * 65;
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) lp[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = lg[m][r];
-                    if (half == 0) lp[64] = lg[2][0];
-                }
-            }
-        } else {
-            chain_layer<2>(Wl + 64 * 64, 64, a.bias[1], accA, accB, l31, half);
-            const float* w3 = Wl + 2 * 64 * 64;
-            float sdot = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    sdot = fmaf(fmaxf(accB[m][r], 0.f), w3[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half], sdot);
-            sdot += __shfl_xor(sdot, 32, 64);
-            if (half == 0 && gcell < a.ncell) a.out[gcell] = 1.f / (1.f + expf(-(sdot + a.bias[2][0])));
-        }
-    }
+    head_f32r_body<KP, DUST>(a);
 }
 
-
-// ------------------------------------------------------------------------------------------------------------------------------
-// The same heads on the bf16 matrix cores with three-way split operands (k_conv_bx.hip has the arithmetic: six
-// v_mfma_f32_32x32x16_bf16 per K = 16 carry an fp32 product sum at 3/8 of the f32-MFMA pipe time).
-//
-// A head is a chain of K = 64 layers on a wave's 32 cells, so nothing is staged: the split weights of every layer sit in LDS in operand
-// order (111 KiB for the key-point head), the activations stay in registers -- a layer's D registers (lane = cell, registers = features
-// (r & 3) + 8 (r >> 2) + 4 half) become the next layer's B fragments once ReLU'd and split (K step t of lane half h takes the register
-// quads 8 (t & 1) and 8 (t & 1) + 4 of block t >> 1: features 32 (t >> 1) + 16 (t & 1) + 8 q + 4 h + i; the weights are packed in that K
-// order) -- and the first layer's eight consecutive channels per K step are 32 contiguous bytes of the source (one pixel row of the 8x8
-// cell for the unfold, one slice of the channels-last feature row), loaded straight into registers one tile ahead.  No barrier after the
-// weights have landed: the eight waves of a workgroup drift apart and fill each other's split / softmax phases.
-// ------------------------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct HeadBxArgs {
-    const float* src;        // KP: raw gray (B,H,W) ; REL: feats (B*hc*wc, 64)
-    const float* coef;       // KP: per-image instance-norm {alpha, beta}
-    const uint4* wq;         // all layers: [layer][K step 4][cout block][split 3][64 lanes] 8 bf16   (api.hip: pack_head_bx)
-    const float* bias;       // all layers' biases, padded to the cout blocks: KP 64,64,64,96 ; REL 64,64
-    const float* w_last;     // REL: the 64 weights of the final 64 -> 1 layer
-    float b_last;            //      and its bias
-    float* out;              // KP: heat (B,H,W) ; REL: reliability (B*hc*wc)
-    float* logits;           // KP only, optional: (B*hc*wc, 65)
-    float* inv;              // REL only, optional: 1 / max(||feats[cell,:]||, 1e-12)
-    int H, W, hc, wc, ncell, ntiles;
-    long long* trace;        // debug: s_memtime stamps of wave 0's second tile, 16 per workgroup
-    int cold;                // debug (xfh_debug_cold_start)
-};
-
-__device__ inline unsigned hb_pk_bf16(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-// eight fp32 values -> the three bf16 fragments h, m, l (x = h + m + l up to 2^-27 |x|; round to nearest even, exact residuals)
-__device__ inline void hb_split8(const float (&y)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
-    uint4 uh, um, ul;
-    unsigned* ph = &uh.x; unsigned* pm = &um.x; unsigned* pl = &ul.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = y[2 * i], b = y[2 * i + 1];
-        const unsigned hh = hb_pk_bf16(a, b);
-        const float ra = a - __uint_as_float(hh << 16), rb = b - __uint_as_float(hh & 0xffff0000u);
-        const unsigned mm = hb_pk_bf16(ra, rb);
-        const float sa = ra - __uint_as_float(mm << 16), sb = rb - __uint_as_float(mm & 0xffff0000u);
-        ph[i] = hh; pm[i] = mm; pl[i] = hb_pk_bf16(sa, sb);
-    }
-    h = __builtin_bit_cast(bf16x8, uh); m = __builtin_bit_cast(bf16x8, um); l = __builtin_bit_cast(bf16x8, ul);
-}
-
-// one K = 64 layer: out[mb] = bias + W x, x given per K step by `xs(t, y[8])`; weights of the layer at wl (LDS, operand order)
-template <int MBO, typename XS>
-__device__ inline void head_bx_layer(const unsigned char* wl, const float* bias_lds, XS xs, f32x16 (&out)[MBO], int lane, int half) {
-#pragma unroll
-    for (int mb = 0; mb < MBO; ++mb)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const float4 t = *reinterpret_cast<const float4*>(bias_lds + mb * 32 + 8 * g4 + 4 * half);
-            out[mb][4 * g4] = t.x; out[mb][4 * g4 + 1] = t.y; out[mb][4 * g4 + 2] = t.z; out[mb][4 * g4 + 3] = t.w;
-        }
-    // (compiler fence: the weights never change, so hipcc hoists every fragment read of every layer out of the persistent tile loop --
-    // 432 registers' worth, straight into scratch memory)
-    asm volatile("" ::: "memory");
-    bf16x8 w[2][MBO][3];
-    auto ldw = [&](int t, bf16x8 (&o)[MBO][3]) {
-#pragma unroll
-        for (int mb = 0; mb < MBO; ++mb)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) o[mb][q] = *reinterpret_cast<const bf16x8*>(wl + (((t * MBO + mb) * 3 + q) * 64 + lane) * 16);
-    };
-    ldw(0, w[0]);
-    // The B fragments are VALU results, and a VALU write that follows an MFMA by a few cycles can land in that MFMA's A/B registers
-    // before the matrix core has read all 64 lanes of them (seen here: the cells of lanes 16-31 of a wave wrong in a few launches out
-    // of many; hipcc's hazard recogniser only covers SrcC).  So the fragments of step t+1 are built into a second register set while
-    // step t's are still alive: the empty asm below is a use of step t's set AFTER the split, which keeps the allocator from handing
-    // its registers to the new values; a set is rewritten one full step (12-18 MFMAs) after its last read.
-    bf16x8 xf[2][3];
-    {
-        float y[8];
-        xs(0, y);
-        hb_split8(y, xf[0][0], xf[0][1], xf[0][2]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        if (t + 1 < 4) ldw(t + 1, w[(t + 1) & 1]);
-        asm volatile("" ::: "memory");
-        const bf16x8 xh = xf[t & 1][0], xm = xf[t & 1][1], xl = xf[t & 1][2];
-        __builtin_amdgcn_sched_barrier(0);      // the MFMAs of a step stay together: left free, hipcc floats the NEXT steps' splits in between them
-        // products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-#define HB_MM(WQ, X) { _Pragma("unroll") for (int mb = 0; mb < MBO; ++mb) out[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[t & 1][mb][WQ], X, out[mb], 0, 0, 0); }
-        HB_MM(2, xh) HB_MM(0, xl) HB_MM(1, xm) HB_MM(1, xh) HB_MM(0, xm) HB_MM(0, xh)
-#undef HB_MM
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < 4) {
-            float y[8];
-            xs(t + 1, y);
-            hb_split8(y, xf[(t + 1) & 1][0], xf[(t + 1) & 1][1], xf[(t + 1) & 1][2]);
-            // the new fragments pass THROUGH the asm that uses the old ones (and this step's weights): it cannot move above the split,
-            // so the old registers stay occupied while the split's results and temporaries are written
-            asm volatile("" : "+v"(xf[(t + 1) & 1][0]), "+v"(xf[(t + 1) & 1][1]), "+v"(xf[(t + 1) & 1][2])
-                            : "v"(xf[t & 1][0]), "v"(xf[t & 1][1]), "v"(xf[t & 1][2]), "v"(w[t & 1][0][0]), "v"(w[t & 1][0][1]), "v"(w[t & 1][0][2]),
-                              "v"(w[t & 1][MBO - 1][0]), "v"(w[t & 1][MBO - 1][1]), "v"(w[t & 1][MBO - 1][2]));
-            if (MBO == 3) asm volatile("" : "+v"(xf[(t + 1) & 1][0]) : "v"(w[t & 1][1][0]), "v"(w[t & 1][1][1]), "v"(w[t & 1][1][2]));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // Nothing keeps the last step's operand registers from whatever VALU code follows the layer (the next tile's address arithmetic, the next layer's
-    // split): idle cycles.  One MFMA's worth (32) was enough while every wave on the SIMD ran this kernel; with a second batch in flight on another
-    // stream (FrameStream) a wave of ANOTHER kernel -- 64-cycle f32 MFMAs, its own register traffic -- shares the SIMD, the operand fetch of lanes
-    // 16-31 comes later, and one 16-cell block of the heat map in ~6000 concurrent steps was wrong (tools/lanes_backbone_soak.py).  128 cycles.
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
-                 "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// NOT on the default path since round 4 (option heads_f32 = 0 selects it): with a cold instruction cache -- other kernels evicting its code between launches, or
-// xfh_debug_cold_start -- the FIRST tile of a workgroup comes out with the cells of lanes 16..31 of one wave wrong once in 10^3 .. 10^5 launches, depending on
-// where the 64-byte instruction lines fall in the MFMA groups (tools/head_soak.py scans 16 code positions: three fail) and on the chip; not understood at the
-// instruction level (profiles/r04_head_hazard/).  SHIFT moves the body by 4 x SHIFT bytes for that scan.
-template <bool KP, int SHIFT = 0>
+// the split-operand heads: body in head_bx_body.hpp (also compiled for the host by tests/emu/)
+template <bool KP, int SHIFT = 0, int FXM = 0>      // FXM: 0 bf16 three-way split, 1 .. 3 the fp16-pair forms (head_bx_body.hpp)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void head_bx_kernel(HeadBxArgs a) {
     code_shift<SHIFT>();
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    constexpr int NB = KP ? 288 : 128;                                 // bias floats
-    constexpr int W_BYTES = KP ? (3 * 2 + 3) * 4 * 3 * 1024 : 2 * 2 * 4 * 3 * 1024;      // cout blocks x K steps x splits x 1 KiB
-    constexpr int L_BYTES = 2 * 4 * 3 * 1024;                         // a 64 -> 64 layer
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
-    float* bias_lds = reinterpret_cast<float*>(smem_h + W_BYTES);
-    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hw = a.hc * a.wc;
-    for (int j = wave; j < W_BYTES / 1024; j += 8)
-        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned char*>(a.wq) + j * 1024 + lane * 16), (lptr_t)(smem_h + j * 1024), 16, 0, 0);
-    if (tid < NB) bias_lds[tid] = a.bias[tid];
-
-    // first-layer input of this lane's cell: K step t, lane half h = channels 16 t + 8 h .. + 7 = 32 contiguous bytes
-    float xin[4][8];
-    float nalpha = 1.f, nbeta = 0.f;                                   // (of the tile xin belongs to)
-    auto issue_x = [&](int tile) __attribute__((always_inline)) {
-        const int g = min(tile * HD_CELLS + wave * 32 + l31, a.ncell - 1);      // cells past the end: copies of the last one, never stored
-        const float* p;
-        size_t step;
-        if (KP) {
-            const int b = g / hw, rem = g - b * hw;
-            const int ci = rem / a.wc, cj = rem - ci * a.wc;
-            p = a.src + (size_t)b * a.H * a.W + (size_t)(8 * ci + half) * a.W + 8 * cj;       // pixel row dy = 2 t + h of the cell
-            step = 2 * (size_t)a.W;
-            nalpha = a.coef[2 * b]; nbeta = a.coef[2 * b + 1];
-        } else {
-            p = a.src + (size_t)g * 64 + 8 * half;
-            step = 16;
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 u0 = *reinterpret_cast<const float4*>(p + t * step), u1 = *reinterpret_cast<const float4*>(p + t * step + 4);
-            xin[t][0] = u0.x; xin[t][1] = u0.y; xin[t][2] = u0.z; xin[t][3] = u0.w;
-            xin[t][4] = u1.x; xin[t][5] = u1.y; xin[t][6] = u1.z; xin[t][7] = u1.w;
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile < a.ntiles) issue_x(tile);
-    lds_dma_barrier();                                                // the weights (and biases) have landed; no barrier from here on
-    long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 16 : nullptr;
-    int tix = 0;
-#define HB_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }
-    for (; tile < a.ntiles; tile += gridDim.x, ++tix) {
-        const int gcell = tile * HD_CELLS + wave * 32 + l31;          // this lane's cell
-        HB_STAMP(0)
-        f32x16 accA[2], accB[2];
-        float nrm2 = 0.f;
-        {
-            const float al = nalpha, be = nbeta;
-            head_bx_layer<2>(smem_h, bias_lds, [&](int t, float (&y)[8]) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    y[i] = KP ? fmaf(xin[t][i], al, be) : xin[t][i];
-                    if (!KP) nrm2 = fmaf(y[i], y[i], nrm2);
-                }
-            }, accA, lane, half);
-        }
-        if (!KP && a.inv) {
-            nrm2 += xhalf(nrm2);                                      // the other 32 channels sit in the other half-wave
-            if (half == 0 && gcell < a.ncell) a.inv[gcell] = 1.f / fmaxf(sqrtf(nrm2), 1e-12f);
-        }
-        HB_STAMP(1)
-        if (tile + (int)gridDim.x < a.ntiles) issue_x(tile + gridDim.x);      // the next tile's input flies during the chained layers
-        // chained layers: K step t = register quads 8 (t & 1), 8 (t & 1) + 4 of block t >> 1, ReLU'd
-        auto chain = [](const f32x16 (&in)[2]) {
-            return [&in](int t, float (&y)[8]) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) y[i] = fmaxf(in[t >> 1][8 * (t & 1) + i], 0.f);
-            };
-        };
-        if (KP) {
-            head_bx_layer<2>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half);
-            HB_STAMP(2)
-            head_bx_layer<2>(smem_h + 2 * L_BYTES, bias_lds + 128, chain(accB), accA, lane, half);
-            HB_STAMP(3)
-            f32x16 lg[3];
-            head_bx_layer<3>(smem_h + 3 * L_BYTES, bias_lds + 192, chain(accA), lg, lane, half);
-            HB_STAMP(4)
-            // lane (l31,half) holds logits c = 32m + (r&3) + 8(r>>2) + 4*half of its cell; c == 64 (dustbin) is m=2,r=0,half=0
-            float mx = -INFINITY;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, lg[m][r]);
-            if (half == 0) mx = fmaxf(mx, lg[2][0]);
-            mx = fmaxf(mx, xhalf(mx));
-            float sum = 0.f;
-            f32x16 e[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { e[m][r] = expf(lg[m][r] - mx); sum += e[m][r]; }
-            if (half == 0) sum += expf(lg[2][0] - mx);
-            sum += xhalf(sum);
-            if (gcell < a.ncell) {
-                const int b = gcell / hw, rem = gcell - b * hw;
-                const int ci = rem / a.wc, cj = rem - ci * a.wc;
-                float* o = a.out + (size_t)b * a.H * a.W + (size_t)(8 * ci) * a.W + 8 * cj + 4 * half;
-                const float rs = 1.f / sum;                // one correctly-rounded divide, then 64 multiplies
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {          // dy = q + 4m, dx = 4*half .. +3
-                        const float4 v = make_float4(e[m][4 * q] * rs, e[m][4 * q + 1] * rs, e[m][4 * q + 2] * rs, e[m][4 * q + 3] * rs);
-                        *reinterpret_cast<float4*>(o + (size_t)(q + 4 * m) * a.W) = v;
-                    }
-                if (a.logits) {
-                    float* lp = a.logits + (size_t)gcell * 65;
-#pragma unroll
-                    for (int m = 0; m < 2; ++m)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) lp[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = lg[m][r];
-                    if (half == 0) lp[64] = lg[2][0];
-                }
-            }
-            HB_STAMP(5)
-        } else {
-            head_bx_layer<2>(smem_h + L_BYTES, bias_lds + 64, chain(accA), accB, lane, half);
-            // final 64 -> 1: dot over this lane's 32 channels, other half via one shuffle
-            float s = 0.f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    s = fmaf(fmaxf(accB[m][r], 0.f), a.w_last[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half], s);
-            s += __shfl_xor(s, 32, 64);
-            if (half == 0 && gcell < a.ncell) a.out[gcell] = 1.f / (1.f + expf(-(s + a.b_last)));
-        }
-    }
-#undef HB_STAMP
+    head_bx_body<KP, FXM>(a);
+}
+// dynamic LDS of a form: weight fragments (1 KiB each), biases, (FXM 3) a 4-KiB slot pair per wave
+static size_t head_bx_lds(bool kp, int fxm) { return (size_t)(kp ? (fxm ? 8 : 9) : 4) * 4 * (fxm == 2 ? 2 : 3) * 1024 + ((kp ? 288 : 128) + 64) * sizeof(float) + (fxm == 3 ? 8 * 4096 : 0); }
+template <bool KP, int SHIFT, int FXM>
+static void launch_head_bx(const HeadBxArgs& h, hipStream_t st) {
+    static AttrMask attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<KP, SHIFT, FXM>), 160 * 1024, attr);
+    head_bx_kernel<KP, SHIFT, FXM><<<min(h.ntiles, num_cus()), 512, head_bx_lds(KP, FXM), st>>>(h);
+}
+// option fx -> the form: bit 8 the fp16 pair, + 16 two weight fragments in LDS, + 32 (instead) B through LDS
+static int head_fxm(int fx, const NetWeights& nw, int hd) {
+    if (!(fx & 8) || !nw.head_fx[hd]) return 0;
+    return (fx & 32) ? 3 : (fx & 16) ? 2 : 1;
 }
 
 long long* g_head_trace = nullptr;        // debug (xfh_debug_trace): stamps of head_bx_kernel<true>
 
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels) {
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels, int fx, int* status) {
     if (!f32_kernels && nw.head_bx[0]) {
+        const int fxm = head_fxm(fx, nw, 0);
         HeadBxArgs h{};
         h.cold = g_debug_cold;
-        h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
+        h.status = status;
+        h.src = gray; h.coef = coef; h.wq = reinterpret_cast<const uint4*>(fxm == 2 ? nw.head_fq[0] : fxm ? nw.head_fx[0] : nw.head_bx[0]); h.bias = nw.head_bx_bias[0]; h.out = heat; h.logits = logits;
         h.H = H; h.W = W; h.hc = H / 8; h.wc = W / 8;
         h.ncell = B * h.hc * h.wc;
         h.ntiles = ceil_div(h.ncell, HD_CELLS);
         h.trace = g_head_trace;
-        const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float);
-        static unsigned attr = 0;
-        set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true>), 160 * 1024, attr);
-        head_bx_kernel<true><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+        h.w_dust = nw.conv[L_KP_3].w_oihw + 64 * 64; h.b_dust = nw.head_kp_b_dust;
+        if (fxm == 3) launch_head_bx<true, 0, 3>(h, st);
+        else if (fxm == 2) launch_head_bx<true, 0, 2>(h, st);
+        else if (fxm == 1) launch_head_bx<true, 0, 1>(h, st);
+        else launch_head_bx<true, 0, 0>(h, st);
         return;
     }
     HeadArgs a{};
@@ -676,31 +250,38 @@ void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, 
     a.ntiles = ceil_div(a.ncell, HD_CELLS);
     const int L[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3};
     for (int i = 0; i < 4; ++i) { a.w[i] = nw.conv[L[i]].w_kcp; a.bias[i] = nw.conv[L[i]].bias; }
-    if (f32_kernels == 2) {      // the register-input form (no activation tile, no barrier per tile)
-        static unsigned attr_r = 0;
+    if (f32_kernels >= 2) {      // the register-input form (no activation tile, no barrier per tile); 3: with the dustbin logit on the matrix cores (round 4)
+        static AttrMask attr_r{0}, attr_o{0};
+        if (f32_kernels == 3) {
+            set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<true, 0, false>), 160 * 1024, attr_o);
+            head_f32r_kernel<true, 0, false><<<min(a.ntiles, num_cus()), 512, (size_t)(3 * 64 * 64 + 64 * 96) * sizeof(float), st>>>(a);
+            return;
+        }
         set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<true>), 160 * 1024, attr_r);
         head_f32r_kernel<true><<<min(a.ntiles, num_cus()), 512, (size_t)(3 * 64 * 64 + 64 * 96) * sizeof(float), st>>>(a);
         return;
     }
     const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<true>), 160 * 1024, attr);
     head_fused_kernel<true><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels) {
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels, int fx, int* status) {
     if (!f32_kernels && nw.head_bx[1]) {
+        const int fxm = head_fxm(fx, nw, 1);
         HeadBxArgs h{};
         h.cold = g_debug_cold;
-        h.src = feats; h.wq = reinterpret_cast<const uint4*>(nw.head_bx[1]); h.bias = nw.head_bx_bias[1]; h.out = reliab; h.inv = invnorm;
+        h.status = status;
+        h.src = feats; h.wq = reinterpret_cast<const uint4*>(fxm == 2 ? nw.head_fq[1] : fxm ? nw.head_fx[1] : nw.head_bx[1]); h.bias = nw.head_bx_bias[1]; h.out = reliab; h.inv = invnorm;
         h.w_last = nw.conv[L_HEAT_2].w_oihw; h.b_last = nw.head_rel_b_last;
         h.hc = 1; h.wc = 1; h.H = 8; h.W = 8;
         h.ncell = ncell;
         h.ntiles = ceil_div(ncell, HD_CELLS);
-        const size_t lds = (size_t)2 * 2 * 4 * 3 * 1024 + 128 * sizeof(float);
-        static unsigned attr = 0;
-        set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<false>), 160 * 1024, attr);
-        head_bx_kernel<false><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
+        if (fxm == 3) launch_head_bx<false, 0, 3>(h, st);
+        else if (fxm == 2) launch_head_bx<false, 0, 2>(h, st);
+        else if (fxm == 1) launch_head_bx<false, 0, 1>(h, st);
+        else launch_head_bx<false, 0, 0>(h, st);
         return;
     }
     HeadArgs a{};
@@ -712,14 +293,14 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
     a.w[0] = nw.conv[L_HEAT_0].w_kcp; a.bias[0] = nw.conv[L_HEAT_0].bias;
     a.w[1] = nw.conv[L_HEAT_1].w_kcp; a.bias[1] = nw.conv[L_HEAT_1].bias;
     a.w[2] = nw.conv[L_HEAT_2].w_oihw; a.bias[2] = nw.conv[L_HEAT_2].bias;
-    if (f32_kernels == 2) {
-        static unsigned attr_r = 0;
+    if (f32_kernels >= 2) {
+        static AttrMask attr_r = 0;
         set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<false>), 160 * 1024, attr_r);
         head_f32r_kernel<false><<<min(a.ntiles, num_cus()), 512, (size_t)(2 * 64 * 64 + 64) * sizeof(float), st>>>(a);
         return;
     }
     const size_t lds = (size_t)(2 * 64 * 64 + 64 + HD_CELLS * HD_XS) * sizeof(float);
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<false>), 160 * 1024, attr);
     head_fused_kernel<false><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
@@ -728,8 +309,8 @@ void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float*
 // Debug (xfh_debug_head_soak, tools/head_soak.py): the key-point head alone, launched `iters` times, every result compared on the
 // device with a reference result; differing float4s are counted and the first `cap` of them recorded as {iteration, float4 index,
 // bits got, bits expected} behind a 4-word header {count, 0, 0, 0}.  variant: 0 = the split-bf16 kernel, 100 = the f32-MFMA kernel with
-// an activation tile (head_fused_kernel), 101 = the f32-MFMA kernel with register input (head_f32r_kernel, the default head);
-// 1000 + s / 2000 + s / 3000 + s = the same three kernels COLD-STARTED (s_icache_inv per workgroup) with the body moved by 4 s bytes,
+// an activation tile (head_fused_kernel), 101 = the f32-MFMA kernel with register input (head_f32r_kernel, the default head), 102 / 103 / 104 = the split head in the fp16-pair arithmetic (three weight fragments | two | three and B through LDS);
+// 1000 + s / 2000 + s / 3000 + s / 4000 + s / 5000 + s = 0, 100, 101, 102, 104 COLD-STARTED (s_icache_inv per workgroup) with the body moved by 4 s bytes,
 // s = 0 .. 15: the code-position scan that separates a kernel that trips on instruction-cache refills from one that does not.
 // (The experiment builds of round 4 -- reloads, pads, dumps, dry passes: variants 1 .. 26 of profiles/r04_head_hazard -- lived here until commit 9607d16.)
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -748,22 +329,21 @@ __global__ __launch_bounds__(256) void soak_compare_kernel(const uint4* __restri
 }
 
 template <int SHIFT>
-static void launch_kp_head_bx_shift(const HeadBxArgs& h, hipStream_t st) {
-    const size_t lds = (size_t)(3 * 2 + 3) * 4 * 3 * 1024 + 288 * sizeof(float);
-    static unsigned attr = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(head_bx_kernel<true, SHIFT>), 160 * 1024, attr);
-    head_bx_kernel<true, SHIFT><<<min(h.ntiles, num_cus()), 512, lds, st>>>(h);
-}
+static void launch_kp_head_bx_shift(const HeadBxArgs& h, hipStream_t st) { launch_head_bx<true, SHIFT, 0>(h, st); }
+template <int SHIFT>
+static void launch_kp_head_fx_shift(const HeadBxArgs& h, hipStream_t st) { launch_head_bx<true, SHIFT, 1>(h, st); }
+template <int SHIFT>
+static void launch_kp_head_fl_shift(const HeadBxArgs& h, hipStream_t st) { launch_head_bx<true, SHIFT, 3>(h, st); }
 template <int SHIFT>
 static void launch_kp_head_f32_shift(const HeadArgs& a, hipStream_t st) {
     const size_t lds = (size_t)(3 * 64 * 64 + 64 * 96 + HD_CELLS * HD_XS) * sizeof(float);
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_fused_kernel<true, SHIFT>), 160 * 1024, attr);
     head_fused_kernel<true, SHIFT><<<min(a.ntiles, num_cus()), 512, lds, st>>>(a);
 }
 template <int SHIFT>
 static void launch_kp_head_f32r_shift(const HeadArgs& a, hipStream_t st) {
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(head_f32r_kernel<true, SHIFT>), 160 * 1024, attr);
     head_f32r_kernel<true, SHIFT><<<min(a.ntiles, num_cus()), 512, (size_t)(3 * 64 * 64 + 64 * 96) * sizeof(float), st>>>(a);
 }
@@ -773,9 +353,14 @@ static void launch_kp_head_f32r_shift(const HeadArgs& a, hipStream_t st) {
 #define XFH_HEAD_SCAN_SHIFTS 1
 #endif
 template <int S>
-static bool launch_shift(int shift, const HeadBxArgs& h, const HeadArgs& a, int kind, hipStream_t st) {      // shift -> the instantiation; kind 1 bf16, 2 f32 (LDS tile), 3 f32 (registers)
-    if (shift == S) { if (kind == 2) launch_kp_head_f32_shift<S>(a, st); else if (kind == 3) launch_kp_head_f32r_shift<S>(a, st); else launch_kp_head_bx_shift<S>(h, st); return true; }
-    if constexpr (S + 1 < XFH_HEAD_SCAN_SHIFTS) return launch_shift<S + 1>(shift, h, a, kind, st);
+static bool launch_shift(int shift, const HeadBxArgs& h, const HeadBxArgs& hx, const HeadBxArgs& hq, const HeadArgs& a, int kind, hipStream_t st) {      // shift -> the instantiation; kind 1 bf16, 2 f32 (LDS tile), 3 f32 (registers), 4 fp16 pair, 5 fp16 pair with B through LDS
+    if (shift == S) {
+        if (kind == 2) launch_kp_head_f32_shift<S>(a, st); else if (kind == 3) launch_kp_head_f32r_shift<S>(a, st); else if (kind == 4) launch_kp_head_fx_shift<S>(hx, st);
+        else if (kind == 5) launch_kp_head_fl_shift<S>(hx, st);
+        else launch_kp_head_bx_shift<S>(h, st);
+        return true;
+    }
+    if constexpr (S + 1 < XFH_HEAD_SCAN_SHIFTS) return launch_shift<S + 1>(shift, h, hx, hq, a, kind, st);
     return false;
 }
 
@@ -793,11 +378,19 @@ int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B,
         for (int i = 0; i < 4; ++i) { fa.w[i] = nw.conv[L[i]].w_kcp; fa.bias[i] = nw.conv[L[i]].bias; }
     }
     fa.cold = h.cold = (variant >= 1000) ? 1 : g_debug_cold;
+    h.w_dust = nw.conv[L_KP_3].w_oihw + 64 * 64; h.b_dust = nw.head_kp_b_dust;
+    HeadBxArgs hx = h;                     // the fp16-pair head (variants 102, 4000 + s)
+    hx.wq = reinterpret_cast<const uint4*>(nw.head_fx[0]);
+    HeadBxArgs hq = h;                     // its two-fragment image (variant 103)
+    hq.wq = reinterpret_cast<const uint4*>(nw.head_fq[0]);
     const size_t n4h = (size_t)B * H * W / 4, n4l = (size_t)h.ncell * 65 / 4;
     for (int it = 0; it < iters; ++it) {
         if (variant >= 1000) {
-            if (variant >= 4000 || !launch_shift<0>(variant % 1000, h, fa, variant / 1000, st)) return -1;
+            if (variant >= 6000 || (variant >= 4000 && !nw.head_fx[0]) || !launch_shift<0>(variant % 1000, h, hx, hq, fa, variant / 1000, st)) return -1;
         } else if (variant == 0) launch_kp_head_bx_shift<0>(h, st);
+        else if (variant == 102 && nw.head_fx[0]) launch_kp_head_fx_shift<0>(hx, st);
+        else if (variant == 103 && nw.head_fx[0]) launch_head_bx<true, 0, 2>(hq, st);
+        else if (variant == 104 && nw.head_fx[0]) launch_kp_head_fl_shift<0>(hx, st);
         else if (variant == 100) launch_kp_head_f32_shift<0>(fa, st);
         else if (variant == 101) launch_kp_head_f32r_shift<0>(fa, st);
         else return -1;

@@ -559,7 +559,7 @@ int launch_find_homography(const float* p0, const float* p1, const int64_t* idx0
     const size_t front = ((size_t)a.iters_pad * 12 > red_bytes ? (size_t)a.iters_pad * 12 : red_bytes) + 15 & ~(size_t)15;
     a.sel_cache_off = (int)front;
     const size_t lds = front + (size_t)hg::SEL_CACHE * sizeof(float4);
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(homog_select_kernel), 96 * 1024, attr);
     homog_select_kernel<<<P, 256, lds, st>>>(a);
     return 0;

@@ -299,7 +299,7 @@ int launch_gray_norm_resized(const float* img, int B, int C, int Hin, int Win, i
     // LDS: C planes of the largest intermediate region this (s2h, s2w) can need
     const int rh = (int)(s2h * (R2_TH - 1)) + 3, rw = (int)(s2w * (R2_TW - 1)) + 3;
     const size_t lds = (size_t)C * rh * rw * sizeof(float);
-    static unsigned attr = 0;
+    static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(resize2_gray_stats_kernel), 72 * 1024, attr);
     if (lds > 72 * 1024) return -1;
     resize2_gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, lds, st>>>(img, C, Hin, Win, Hm, Wm, s1h, s1w, Ho, Wo, s2h, s2w, part, gray);

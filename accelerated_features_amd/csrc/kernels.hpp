@@ -22,6 +22,8 @@ struct ConvW {
     const float* bias;     // [cout_pad] folded BN shift or conv bias, zero padded
     const float* w_wino;   // [cin/4][16][2][cout_pad][2] Winograd F(2x2,3x3) G g G^T (3x3/s1 layers, cin >= 24), else NULL
     const void* w_fx;      // the same fragments in the fp16-pair arithmetic (api.hip: split_weight mode 1), NULL if the layer has none or a weight is too large for it
+    const void* w_rs;      // 64 -> 64 3x3 stride-1 layers: the fp16-pair image in conv_rs64_kernel's order (weight_split.hpp: pack_rs64); the 1x1 behind one: pack_rs64_1x1; else NULL
+    const void* w_fq;      // 64 -> 64 3x3 stride-1 layers: the fp16-pair image with two fragments per weight (q0, q2; conv_bx64_body.hpp FXM 2), else NULL
     const void* w_bx;      // three-way split bf16 weights in MFMA operand order, else NULL: cin 24: [step][split h,m,l][64 lanes][8] (k_conv_bx.hip);
                            // cin 64 -> 64: [cin/16][dy][dx][cout block][split][64 lanes][8] (k_conv_bx64.hip)
 };
@@ -39,8 +41,12 @@ struct NetWeights {
     // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): [0] key-point head, [1] reliability head
     const void* head_bx[2];          // per layer [K step 4][cout block][split 3][64 lanes][8] bf16
     const void* head_fx[2];          // the same in the fp16-pair arithmetic (or NULL)
+    const void* head_fq[2];          // the fp16-pair form with two fragments per weight (q0, q2): [K step][cout block][2][64 lanes][8] (or NULL)
     const float* head_bx_bias[2];    // biases padded to the cout blocks (KP 64,64,64,96 ; REL 64,64)
     float head_rel_b_last;           // bias of the final 64 -> 1 layer of the reliability head
+    float head_kp_b_dust;            // bias of the dustbin logit (output 64 of keypoint_head.3)
+    const void* block1_fx;           // block1.3 in the fp16-pair arithmetic, compact LDS image (block1_fx.hpp), or NULL
+    const void* block1_fx3;          // block1.2 likewise (q0 / q2 fragments)
 };
 
 struct Profiler;   // api.hip
@@ -57,9 +63,9 @@ struct Options {
                             // activation tile in LDS, two barriers per tile; + 33 us per 64-frame step); 0: the split-bf16 kernels (head_bx_kernel) -- 60 us faster than 2, but
                             // head_bx_kernel<true> delivers a wrong 16-cell block once in 10^3..10^5 launches when a workgroup's first tile runs on instruction-cache
                             // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
-    int fx = 3;             // split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
-                            // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel); 0 = the bf16 three-way split everywhere
-    int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected)
+    int fx = 3;             // (bit 128, with 1: the unfused 64 -> 64 layers on conv_rs64_kernel -- weights resident in registers, conv_rs64_body.hpp; bit 256, with 1: the 3x3 + 1x1 pairs too; bit 512, with 1: block5.1 and block5.2 on its 128-channel form, block5.3 then runs as a 1x1 of its own; bit 1024, with 1: block4.0 / block5.0 (stride 2) in the fp16-pair arithmetic, conv_bx64s2x_kernel)  split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
+                            // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel), 4 = (with 1) conv_bx64_kernel with two weight fragments in its stream, 8 = the split heads (with heads_f32 = 0: head_bx_kernel<.., 1>), + 16 = with two weight fragments in LDS (<.., 2>), + 32 = (instead) the B fragments through LDS (<.., 3>), 64 = (with 1) the split-format link block_fusion.0 -> block_fusion.1 (conv_bx64_body.hpp: SP); 0 = the bf16 three-way split everywhere
+    int block1 = 0;         // block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected); 6 = 5 with conv4 on the fp16 matrix cores (fp16-pair arithmetic, block1_fx.hpp), 7 = conv3 too
 };
 
 // ---- k_preproc.hip ----------------------------------------------------------------------
@@ -77,7 +83,7 @@ void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float
 // ---- k_conv_direct.hip ------------------------------------------------------------------
 void launch_block1(const NetWeights& nw, const float* gray, int B, int H, int W, float* t0, float* t1, float* t2,
                    float* x1, hipStream_t st);
-void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant = 0);
+void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant = 0, int* status = nullptr);
 int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B, int Hin, int Win, float* out,
                         hipStream_t st);
 void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, hipStream_t st);
@@ -94,9 +100,16 @@ int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, 
 // 3x3/s1 on bf16 MFMAs with three-way split operands (fp32-equivalent; k_conv_bx.hip); -1 if no instantiation
 int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr, bool fx = false, int* status = nullptr);
 int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr,
-                     const ConvW* fused1x1 = nullptr, bool nhwc = false, bool fx = false, int* status = nullptr);
+                     const ConvW* fused1x1 = nullptr, bool nhwc = false, int fx = 0, int* status = nullptr, int sp = 0, const float* zeros = nullptr);
+// 3x3/s1, 64 -> 64, fp16 pair, weights resident in registers (k_conv_rs64.hip / conv_rs64_body.hpp); -1: not this layer, or the map is wider than its LDS rings allow
+int launch_conv_rs64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status = nullptr, const ConvW* fused1x1 = nullptr, bool nhwc = false,
+                     long long* trace = nullptr);
+bool conv_rs128_fits(int W);      // the map's rings fit into a CU's LDS
+int launch_conv_rs128(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status = nullptr);      // the 128 -> 128 form (block5.1, block5.2)
 // 3x3/s2, 64 -> 64 | 128 (block4.0, block5.0; k_conv_bx64s2.hip); -1 if no instantiation
 int launch_conv_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
+// the same layers in the fp16-pair arithmetic (k_conv_bx64s2x.hip / conv_bx64s2_body.hpp); -1 if the layer has no fp16-pair weights
+int launch_conv_bx64s2_fx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr, int* status = nullptr);
 int bx_steps(int cin);      // K steps of 16 = 2 groups of 8 channels of one tap
 // ---- k_homography.hip (RANSAC + MAGSAC++ homography from match lists) ----
 size_t homography_workspace_bytes(int P, int max_iters);
@@ -132,9 +145,9 @@ void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat
 // reliability head -> sigmoid map
 int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, const float* heat_ref, float* logits, const float* logits_ref,
               int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, hipStream_t st);      // debug, k_heads.hip
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels = 0);
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels = 0, int fx = 0, int* status = nullptr);
 // invnorm (optional): 1 / max(||feats[cell,:]||, 1e-12) per cell, a by-product of the layer-1 operand loads
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels = 0);
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels = 0, int fx = 0, int* status = nullptr);
 
 // ---- k_detect.hip -----------------------------------------------------------------------
 struct DetectWs {          // carved from the caller's workspace by api.hip

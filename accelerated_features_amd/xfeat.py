@@ -18,7 +18,10 @@ import torch.nn as nn
 from . import _lib
 from .spec import CONVS, FINE
 
-DEFAULT_FX = 3          # the library's default of option "fx" (csrc/kernels.hpp: Options; tests/test_gpu_parity.py checks the two agree)
+# the library's defaults of the options the range fallback below has to know (csrc/kernels.hpp: Options; tests/test_gpu_parity.py checks that the mirrors agree)
+DEFAULT_FX = 3
+DEFAULT_HEADS_F32 = 2
+DEFAULT_BLOCK1 = 0
 
 __all__ = ["XFeat", "XFeatModel"]
 
@@ -194,7 +197,7 @@ class XFeatModel(nn.Module):
         _lib.check(lib.xfh_set_status_buffer(h, C.c_void_p(self._status.data_ptr())), "xfh_set_status_buffer")
         return h
 
-    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 2), "block1": (0, 5), "fx": (0, 15)}      # include/xfeat_hip.h: xfh_set_option
+    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 3), "block1": (0, 7), "fx": (0, 2047)}      # include/xfeat_hip.h: xfh_set_option
 
     def set_option(self, key, value):
         """Kernel-variant switch of this model's handle (include/xfeat_hip.h: xfh_set_option) -- A/B runs and variant-vs-variant tests.
@@ -229,18 +232,30 @@ class XFeatModel(nn.Module):
             self._status_target[:1].zero_()
         return v
 
+    def _effective_option(self, key):
+        return self._options.get(key, {"fx": DEFAULT_FX, "heads_f32": DEFAULT_HEADS_F32, "block1": DEFAULT_BLOCK1}[key])
+
     def fx_range_exceeded(self, status=None):
         """True if a call since the last check left the range of the fp16-pair arithmetic (|activation| >= 65504; never seen on images): the model then falls
-        back to the bf16 three-way split for good (option fx = 0) and the caller repeats the call -- results are exact either way."""
-        if status is None and not self._options.get("fx", DEFAULT_FX):
-            return False                               # (the bf16 arithmetic has fp32's range: nothing to read back)
+        back for good to the forms with fp32's range -- the bf16 three-way split for the convolutions (option fx = 0), the f32-MFMA heads where the split heads
+        were on (heads_f32 = 2: with fx = 0 the split heads would be the retired bf16 kernel), the vector-ALU block1 (block1 = 5) -- and the caller
+        repeats the call; results are exact either way.  Written against the EFFECTIVE options (override or library default), so it holds whatever the defaults are."""
+        fx_on = self._effective_option("fx") != 0 or self._effective_option("block1") >= 6
+        if status is None and not fx_on:
+            return False                               # (the bf16 / f32 forms have fp32's range: nothing to read back)
         v = self.take_status() if status is None else int(status)
         if not (v & 1):
             return False
+        if not fx_on:
+            return False                               # (a stale flag of a caller's buffer: nothing left to switch off, and repeating the call would not end)
         import warnings
         warnings.warn("accelerated_features_amd: an activation left the range of the fp16-pair arithmetic (|x| >= 65504); this model falls back to the "
                       "bf16 three-way split (option fx = 0) and the call is repeated")
         self.set_option("fx", 0)
+        if self._effective_option("heads_f32") == 0:   # (the split heads: fp16 pair with fx bit 8 -- never fall through to the bf16 head)
+            self.set_option("heads_f32", 2)
+        if self._effective_option("block1") >= 6:      # (block1's matrix-core forms are fp16-pair kernels too)
+            self.set_option("block1", 5)
         return True
 
     def workspace(self, name, nbytes):

@@ -173,7 +173,7 @@ PEAK_BF16_TFLOPS = 2500.0         # dense bf16 / fp16 MFMA
 MATCH_MAXIMA_BYTES_PER_ENTRY = 4.0      # the matcher's block maxima (k_match_f16.hip): fp32
 
 
-def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2):
+def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2, block1=0):
     """roofline_kernels: one row per kernel (or tight kernel group) of the step, from the HIP-event spans of an untimed pass
     (xfh_profile_select(XFH_PROF_ALL)).  Per row: us per step; algorithmic HBM bytes (inputs read once + outputs written once) and FLOPs;
     the FLOPs the shipped kernel EXECUTES on the instruction it uses (Winograd: 2.25x fewer than direct; fp32 on bf16 MFMAs: 6 MFMAs per
@@ -203,7 +203,11 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2):
 
     ci = {c.name: i for i, c in enumerate(CONVS)}
     add(200, "gray_stats + gray_coef (channel mean, InstanceNorm statistics)", 4.0 * px["1"] * 4, 4.0 * px["1"], 4.0 * px["1"], 0, "valu")
-    add(3, "block1_fused_kernel (block1.0-.3 + skip1)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32, "fp32 valu (v_pk_fma_f32)")
+    if block1 >= 6:      # block1.3 (and block1.2) on v_mfma_f32_16x16x32_f16 in the fp16-pair arithmetic: the row keeps the algorithmic FLOPs against the fp32 peak -- the kernel stays
+        add(3, f"block1_mx_kernel<{block1}> (block1.0-.3 + skip1; block1.{'2, .3' if block1 >= 7 else '3'} on fp16-pair MFMAs)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32,      # bound by the
+            "fp32 valu (v_pk_fma_f32) + fp16 mfma x3")                                                                                                                                    # vector stages
+    else:
+        add(3, "block1_fused_kernel (block1.0-.3 + skip1)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32, "fp32 valu (v_pk_fma_f32)")
     # split-operand convolutions: the fp16-pair arithmetic (option fx, default: 3 MFMAs per product) or the bf16 three-way split (6)
     nm24, nm64 = (3 if fx & 2 else 6), (3 if fx & 1 else 6)
     pipe24 = "fp16 mfma x3 (fp16 pair, fp32-equivalent)" if fx & 2 else "bf16 mfma x6 (fp32-equivalent)"
@@ -214,11 +218,13 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2):
         add(100 + ci[n_], f"conv_bx_kernel<24,24> ({n_})", 4.0 * 48 * px["4"], fl, fl * bx24, PEAK_BF16_TFLOPS, pipe24)
     fl = conv_flops("block3.0", px["8"])
     add(100 + ci["block3.0"], "conv_bxs2_kernel<24> (block3.0, stride 2)", 4.0 * (24 * px["4"] + 64 * px["8"]), fl, fl * nm24 * (224 / 216), PEAK_BF16_TFLOPS, pipe24)
-    for n3, n1, tag in (("block3.1", "block3.2", "conv_bx64_kernel<64,1>"), ("block_fusion.1", "block_fusion.2", "conv_bx64_kernel<64,2> (channels-last out)")):
+    rs_plain, rs_fused, rs_128 = (fx & 129) == 129, (fx & 257) == 257, (fx & 513) == 513      # conv_rs64_kernel (weights resident in registers): unfused 64 -> 64 layers, 3x3 + 1x1 pairs, block5.1 / 5.2
+    for n3, n1, tag in (("block3.1", "block3.2", "conv_rs64_kernel<1>" if rs_fused else "conv_bx64_kernel<64,1>"),
+                        ("block_fusion.1", "block_fusion.2", "conv_rs64_kernel<2> (channels-last out)" if rs_fused else "conv_bx64_kernel<64,2> (channels-last out)")):
         fl = conv_flops(n3, px["8"]) + conv_flops(n1, px["8"])
         add(100 + ci[n3], f"{tag} ({n3} + {n1})", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
     fl = conv_flops("block_fusion.0", px["8"])
-    add(100 + ci["block_fusion.0"], "conv_bx64_kernel<64,0> (block_fusion.0)", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
+    add(100 + ci["block_fusion.0"], ("conv_rs64_kernel<0>" if rs_plain else "conv_bx64_kernel<64,0>") + " (block_fusion.0)", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
     for n_, cin, cout, sc_in, sc_out in (("block4.0", 64, 64, "8", "16"), ("block5.0", 64, 128, "16", "32")):
         fl = conv_flops(n_, px[sc_out])
         ho, wo = H // int(sc_out), W // int(sc_out)
@@ -228,23 +234,34 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2):
     units16 = B * (-(-(H // 16) // 8)) * (-(-(W // 16) // 16))          # half-tile units of conv_bx64_kernel at 1/16 scale (api.hip: big_map)
     for n_, ch, sc in (("block4.1", 64, "16"), ("block4.2", 64, "16"), ("block5.1", 128, "32")):
         fl = conv_flops(n_, px[sc])
-        if ch == 64 and (fx & 1) and units16 >= 768:      # the 64 -> 64 layers at 1/16 scale join the fp16-pair split kernel when the batch fills its grid
+        if ch == 64 and rs_plain:
+            add(100 + ci[n_], f"conv_rs64_kernel<0> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
+        elif ch == 128 and rs_128:
+            add(100 + ci[n_], f"conv_rs64_kernel<0, 128> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
+        elif ch == 64 and (fx & 1) and units16 >= 768:      # the 64 -> 64 layers at 1/16 scale join the fp16-pair split kernel when the batch fills its grid
             add(100 + ci[n_], f"conv_bx64_kernel<64,0> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
         else:
             add(100 + ci[n_], f"conv_wino_kernel ({n_})", 4.0 * 2 * ch * px[sc], fl, fl / 2.25, f32, "f32 mfma, Winograd F(2x2,3x3)")
     fl3, fl1 = conv_flops("block5.2", px["32"]), conv_flops("block5.3", px["32"])
-    add(100 + ci["block5.2"], "conv_wino_kernel (block5.2 + block5.3)", 4.0 * (128 + 64) * px["32"], fl3 + fl1, fl3 / 2.25 + fl1, f32, "f32 mfma, Winograd F(2x2,3x3)")
+    if rs_128:      # block5.2 on the 128-channel form, block5.3 as a 1x1 of its own (two spans: the 3x3's and the 1x1's)
+        add(100 + ci["block5.2"], "conv_rs64_kernel<0, 128> (block5.2)", 4.0 * 2 * 128 * px["32"], fl3, fl3 * 3, PEAK_BF16_TFLOPS, pipe64)
+        add(100 + ci["block5.3"], "conv_mfma_kernel<128,64,1x1> (block5.3)", 4.0 * (128 + 64) * px["32"], fl1, fl1, f32, "f32 mfma")
+    else:
+        add(100 + ci["block5.2"], "conv_wino_kernel (block5.2 + block5.3)", 4.0 * (128 + 64) * px["32"], fl3 + fl1, fl3 / 2.25 + fl1, f32, "f32 mfma, Winograd F(2x2,3x3)")
     add(201, "pyramid_sum_kernel (x3 + up(x4) + up(x5))", 4.0 * 64 * (2 * px["8"] + px["16"] + px["32"]), 3.0 * 64 * px["8"], 3.0 * 64 * px["8"], 0, "valu")
     fl = 2.0 * (2 * 64 * 64 + 64) * px["8"]
-    hk = {0: "head_bx_kernel", 1: "head_fused_kernel", 2: "head_f32r_kernel"}[heads_f32]
-    if heads_f32:      # (default) the heads on f32 MFMAs: executed = algorithmic FLOPs (+ the 65 -> 96 padding of the last key-point layer) against the f32 peak
+    hk = {0: "head_bx_kernel", 1: "head_fused_kernel", 2: "head_f32r_kernel", 3: "head_f32r_kernel (dustbin on the matrix cores)"}[heads_f32]
+    last = 64 if heads_f32 == 2 or (heads_f32 == 0 and fx & 8) else 96      # outputs of the last key-point layer that run on the matrix cores (the dustbin logit is a vector dot product in those forms)
+    if heads_f32:      # (default) the heads on f32 MFMAs: executed = algorithmic FLOPs (+ the 65 -> 96 padding of the last key-point layer where it is still there) against the f32 peak
         add(202, f"{hk}<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl, fl, f32, "f32 mfma")
         fl = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
-        add(203, f"{hk}<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * 96) * px["8"], f32, "f32 mfma")
+        add(203, f"{hk}<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * last) * px["8"], f32, "f32 mfma")
     else:
-        add(202, f"{hk}<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl, fl * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
+        nmh = 3 if fx & 8 else 6
+        pipeh = "fp16 mfma x3 (fp16 pair, fp32-equivalent)" if fx & 8 else "bf16 mfma x6 (fp32-equivalent)"
+        add(202, f"{hk}<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl, fl * nmh, PEAK_BF16_TFLOPS, pipeh)
         fl = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
-        add(203, f"{hk}<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * 96) * px["8"] * 6, PEAK_BF16_TFLOPS, "bf16 mfma x6 (fp32-equivalent)")
+        add(203, f"{hk}<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * last) * px["8"] * nmh, PEAK_BF16_TFLOPS, pipeh)
     add(210, "nms_flags_kernel", 4.0 * px["1"] + px["1"] / 8, 25.0 * px["1"], 25.0 * px["1"], 0, "valu")
     add(211, "nms_compact_kernel", px["1"] / 8 + 4.0 * px["1"] / 64, 0, 0, 0, "latency")
     add(212, "topk_sort_runs + topk_rank_merge", 4.0 * 3 * B * 2 * n_kpts, 0, 0, 0, "lds sort / latency")
@@ -862,9 +879,9 @@ def main():
     if rank == 0:
         n_valid = counts[:B].tolist()
         n_match = counts[2 * B:].tolist()
-        opt_fx, opt_heads = C.c_int(), C.c_int()
-        lib.xfh_get_option(handle, b"fx", C.byref(opt_fx)); lib.xfh_get_option(handle, b"heads_f32", C.byref(opt_heads))
-        k_rows, k_sum = kernel_roofline_table(spans_us, B, B // 2, fx=opt_fx.value, heads_f32=opt_heads.value)
+        opt_fx, opt_heads, opt_b1 = C.c_int(), C.c_int(), C.c_int()
+        lib.xfh_get_option(handle, b"fx", C.byref(opt_fx)); lib.xfh_get_option(handle, b"heads_f32", C.byref(opt_heads)); lib.xfh_get_option(handle, b"block1", C.byref(opt_b1))
+        k_rows, k_sum = kernel_roofline_table(spans_us, B, B // 2, fx=opt_fx.value, heads_f32=opt_heads.value, block1=opt_b1.value)
         achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
         fps = sharding.aggregate_rate(B, args.steps, world, dt_max, "weak")
         fps_gpu = fps / world
@@ -901,8 +918,11 @@ def main():
             # block1 x4 + skip1 in one kernel: fp32 FMA work on the vector ALUs (v_pk_fma_f32), LDS-tiled.  Neither HBM nor the matrix
             # cores bound it (1 -> 4 -> 8 -> 8 -> 24 channels: no K for an MFMA); it is priced against the dense fp32 rate of the chip,
             # which is the same 157.3 TFLOP/s for the packed vector FMA and for the f32 MFMA.
-            "roofline": {"bound": "mfma", "kernel": "block1_fused_kernel (block1.0-.3 + skip1 fused: 3x3 convs 1->4, 4->8 s2, 8->8, 8->24 s2 on v_pk_fma_f32, "
-                                                    "LDS-tiled; one launch per step; 'mfma' = the dense fp32 peak, shared by the packed vector FMA)",
+            "roofline": {"bound": "mfma", "kernel": ("block1_fused_kernel (block1.0-.3 + skip1 fused: 3x3 convs 1->4, 4->8 s2, 8->8, 8->24 s2 on v_pk_fma_f32, "
+                                                     "LDS-tiled; one launch per step; 'mfma' = the dense fp32 peak, shared by the packed vector FMA)") if opt_b1.value < 6 else
+                                                    (f"block1_mx_kernel<{opt_b1.value}> (block1.0-.3 + skip1 fused, LDS-tiled, one launch per step: 1->4 and 4->8 s2 on v_pk_fma_f32, "
+                                                     f"{'8->8 and ' if opt_b1.value >= 7 else ''}8->24 s2 on v_mfma_f32_16x16x32_f16 in the fp16-pair arithmetic = fp32 results; priced as before: "
+                                                     "algorithmic fp32 FLOPs against the dense fp32 peak)"),
                          "achieved": round(achieved, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
                          "launches": n_l, "avg_launch_us": round(1e3 * ms / max(n_l, 1), 2),

@@ -91,14 +91,15 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   "wino"          0..2    3x3/s1 layers: 0 never Winograd, 1 unfused layers only, 2 (default) also the 3x3 + 1x1 pairs
  *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
  *                           8 not block3.0, 16 the stride-2 64 -> 64 | 128 layers (block4.0, block5.0) (default 21)
- *   "heads_f32"     0..2    both heads on f32 MFMAs: 2 (default) the register-input kernels (head_f32r_kernel), 1 the round-1 kernels with an activation tile in LDS
+ *   "heads_f32"     0..3    both heads on f32 MFMAs: 2 (default) the register-input kernels (head_f32r_kernel; 3 = their round-4 form with the dustbin logit on the matrix cores), 1 the round-1 kernels with an activation tile in LDS
  *                           (+ 33 us per 64-frame VGA step).  0: the split-bf16 head kernels -- another 60 us faster, and NOT safe: the key-point head was found to deliver
  *                           one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever the first tile of a workgroup runs on instruction-cache misses,
  *                           i.e. whenever other kernels (a second stream, another process) evict its code between launches (profiles/r04_head_hazard/);
  *                           both f32 kernels are clean under the same torture at every code position.  For A/B measurements only.
  *   "fx"            bitmask split-operand convolutions in the fp16-pair arithmetic (three MFMAs per product instead of the six of the bf16 three-way split):
- *                           1 = the 64 -> 64 layers on large maps (conv_bx64_kernel), 2 = the 24-channel layers, 4 = the stride-2 64-channel layers
- *   "block1"        0..5    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile
+ *                           1 = the 64 -> 64 layers on large maps (conv_bx64_kernel), 2 = the 24-channel layers, 4 = (with 1) the 64 -> 64 layers with two weight fragments in their stream, 8 = the split heads (with heads_f32 = 0), + 16 = with two weight fragments in LDS, + 32 = (instead) the pixel-side fragments through LDS; 64 = (with 1) block_fusion.0 hands block_fusion.1 its output as fp16 pairs, 128 = (with 1) the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on the kernel with the weights resident in registers (conv_rs64_kernel; maps up to 125 columns), 256 = (with 1) the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) on it too (maps up to 93 columns), 512 = (with 1) block5.1 and block5.2 on its 128-channel form (block5.3 then runs as a 1x1 of its own; maps up to 61 columns), 1024 = (with 1) the stride-2 64-channel layers (block4.0, block5.0) in the fp16-pair arithmetic too (0..2047)
+ *   "block1"        0..7    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile;
+ *                           6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too (both set XFH_STATUS_FX_RANGE like "fx")
  * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.
  * ---------------------------------------------------------------------------------------- */
 int xfh_set_option(xfh_handle h, const char* key, int value);
@@ -154,7 +155,8 @@ int xfh_backbone_resized(xfh_handle h, const float* img, int B, int C, int Hin, 
  * activations).  layer = index into spec.CONVS; in (B,Cin,Hin,Win) NCHW, out (B,Cout,Hout,Wout)
  * NCHW with the layer's own stride/padding, folded BN and ReLU where the reference has them.
  * variant: 0 = the kernel the backbone uses for this layer, 1 = the generic direct kernel,
- * 10 = the split-bf16 kernel of the layer, 11 = the same kernel in the fp16-pair arithmetic, other values >= 2 = explicit Winograd
+ * 10 = the split-bf16 kernel of the layer, 11 = the same kernel in the fp16-pair arithmetic, 12 = (64 -> 64 3x3/s1 layers, maps up to 125 columns) the fp16-pair kernel
+ * with the weights resident in registers, other values >= 2 = explicit Winograd
  * configurations of the 3x3/s1 layers (tuning; XFH_ERR_UNSUPPORTED elsewhere). */
 int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out,
                    int variant, xfh_stream stream);
@@ -363,6 +365,9 @@ int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int
  * workgroup starts, so that its first tile runs on instruction-fetch misses -- the condition under which head_bx_kernel<true> was found to deliver a wrong
  * 16-cell block; the concurrency / cold-start soaks of tests/test_gpu_parity.py and tools/head_soak.py use it. */
 int xfh_debug_cold_start(int enable);
+/* debug: block1 + skip1 alone in the form option "block1" selects: gray (B,H,W) raw gray image, coef (B,2) the per-image {alpha, beta} of the instance
+ * normalisation (x -> alpha x + beta), x1 (B,24,H/4,W/4); H % 4 == W % 4 == 0.  For the variant-against-variant tests of tests/test_gpu_parity.py. */
+int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, int H, int W, float* x1, xfh_stream stream);
 /* debug: resident workgroups per CU the runtime reports for mnn_sim_kernel */
 int xfh_debug_match_occupancy(void);
 int xfh_profile_read(xfh_handle h, int* n_launches, double* total_ms, double* total_flops, double* total_bytes);

@@ -198,6 +198,10 @@ inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_REL
 #define XFH_DMA_B128_TO_LDS(m0v, voff, rsrc, soff) emu::dma_b128_to_lds(m0v, voff, rsrc, soff)
 #define XFH_NOP16_3(a, b, c) ((void)0)
 #define XFH_PIN(x) ((void)0)
+#define XFH_AGPR(x) ((void)0)
+#define XFH_LDS_BARRIER() __syncthreads()
+#define XFH_SCHED_FENCE() ((void)0)
+#define XFH_WAVE_SYNC() emu::wg->wave_bar[emu::tidx.x >> 6]->arrive_and_wait()      /* lanes of a wave run in lock-step on the GPU; here they are threads */
 typedef const void* xfh_gptr_t;
 typedef void* xfh_lptr_t;
 typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
@@ -216,6 +220,10 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_make_buffer_rsrc(p, stride, bytes, flags) emu::Rsrc{reinterpret_cast<unsigned char*>(p), (unsigned)(bytes)}
 #define __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, aux) emu::buffer_load_b128(rs, (unsigned)(voff), (unsigned)(soff))
 #define __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, aux) emu::buffer_load_b32(rs, (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_store_b128(val, rs, voff, soff, aux)                                                              \
+    do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 16 <= (rs).bytes) { const auto v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 16); } } while (0)
+#define __builtin_amdgcn_raw_buffer_store_b64(val, rs, voff, soff, aux)                                                               \
+    do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 8 <= (rs).bytes) { const auto v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 8); } } while (0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_raw_buffer_store_b32(val, rs, voff, soff, aux)                                                               \
     do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 4 <= (rs).bytes) { const unsigned v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 4); } } while (0)

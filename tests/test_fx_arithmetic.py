@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SPLIT = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "bx_split.hpp")).read()
-API = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "api.hip")).read()
+API = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "api.hip")).read() + open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "weight_split.hpp")).read()
 
 
 def pair(v):
@@ -114,4 +114,5 @@ def test_python_option_table_mirrors_the_library():
     assert ranges == lib and len(lib) >= 6
     hpp = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "kernels.hpp")).read()
     assert int(re.search(r"int fx = (\d+);", hpp).group(1)) == int(re.search(r"DEFAULT_FX = (\d+)", py).group(1))
-    assert int(re.search(r"int heads_f32 = (\d+);", hpp).group(1)) >= 1          # the split-bf16 heads are not the default
+    fx_default = int(re.search(r"int fx = (\d+);", hpp).group(1))
+    assert int(re.search(r"int heads_f32 = (\d+);", hpp).group(1)) >= 1 or fx_default & 8          # the split-bf16 heads are not the default: split heads only as fp16 pairs (fx bit 8)

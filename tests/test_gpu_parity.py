@@ -126,8 +126,8 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
 
 
-@pytest.mark.parametrize("opts", [{"heads_f32": 0, "bx": 0, "block1": 1}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}, {"fx": 0}, {"fx": 15, "bx": 23},
-                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}])
+@pytest.mark.parametrize("opts", [{"heads_f32": 0, "fx": 3, "bx": 0, "block1": 1}, {"heads_f32": 2, "block1": 5, "fx": 3}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}, {"fx": 0}, {"fx": 15, "bx": 23},
+                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"heads_f32": 3}, {"block1": 6}, {"block1": 7}, {"fx": 7}, {"fx": 67}, {"fx": 131}, {"fx": 387}, {"fx": 899}, {"fx": 1027}, {"fx": 11, "heads_f32": 0}, {"fx": 27, "heads_f32": 0}, {"fx": 43, "heads_f32": 0}])
 def test_backbone_alternative_kernels_same_results(opts, sd):
     """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on the split-bf16 kernels -- opt-in since round 4 --, 24->24
     layers on Winograd; every unfused 64->64 layer on the split kernel; direct implicit GEMM instead of Winograd; block1 with a c1 tile; the split-operand
@@ -148,6 +148,46 @@ def test_backbone_alternative_kernels_same_results(opts, sd):
         xf2.set_option("no_such_option", 1)
     with pytest.raises(Exception):
         xf2.set_option("wino", 7)
+
+
+@pytest.mark.parametrize("mode", [5, 6, 7])
+def test_block1_forms_alone(sd, acts, mode):
+    """block1 + skip1 alone (xfh_debug_block1) in the shipped vector form (5), with block1.3 on the fp16 matrix cores (6) and with block1.2 there too (7; fp16-pair
+    arithmetic, csrc/block1_fx.hpp): against the oracle's x1 on its own normalised gray images, and form against form on shapes whose last tiles are partial
+    (W / 4 = 88: five and a half 16-column tiles; H / 4 = 60: seven and a half 8-row tiles) -- with the position of the largest difference, for whoever has to debug it."""
+    from accelerated_features_amd import XFeat
+    lib = _lib().load()
+    m = XFeat(weights=sd, top_k=512)
+    m.set_option("block1", mode)
+    ref = XFeat(weights=sd, top_k=512)
+    ref.set_option("block1", 5)
+
+    def run(model, gray):
+        B, H, W = gray.shape
+        coef = torch.tensor([[1.0, 0.0]] * B, device="cuda")
+        x1 = torch.full((B, 24, H // 4, W // 4), float("nan"), device="cuda")
+        assert lib.xfh_debug_block1(model.net.handle(), C.c_void_p(gray.data_ptr()), C.c_void_p(coef.data_ptr()), B, H, W, C.c_void_p(x1.data_ptr()), None) == 0, lib.xfh_last_error()
+        torch.cuda.synchronize()
+        return x1
+
+    def where(d):
+        i = int(d.argmax())
+        return tuple(int(v) for v in np.unravel_index(i, tuple(d.shape)))
+    for tag, (x, t) in acts.items():
+        g = t["gray"].cuda().contiguous()[:, 0]
+        got = run(m, g)
+        d = (got.cpu() - t["x1"]).abs()
+        assert bool(torch.isfinite(got).all()) and float(d.max()) <= TOL_ACT, (tag, mode, float(d.max()), where(d))
+    assert m.net.take_status() == 0
+    for B, H, W, seed in ((3, 224, 352, 5), (2, 240, 320, 6), (1, 32, 32, 7)):
+        g = torch.randn(B, H, W, generator=torch.Generator().manual_seed(seed)).cuda()
+        a, b = run(m, g), run(ref, g)
+        d = (a - b).abs().cpu()
+        assert bool(torch.isfinite(a).all()) and float(d.max()) <= 2e-5 * max(1.0, float(b.abs().max())), (mode, (B, H, W), float(d.max()), where(d))
+    if mode >= 6:      # the range guard of the pair: activations beyond 65504 in c2 / c3 are reported
+        g = torch.randn(1, 64, 64, generator=torch.Generator().manual_seed(8)).cuda() * 1.0e7
+        run(m, g)
+        assert m.net.take_status() & 1
 
 
 def test_split_bf16_backbone_equals_f32_mfma_backbone_at_bench_shape(xf, sd):
@@ -552,7 +592,7 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
     h = xf.net.handle()
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 0
-    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1", "block4.0", "block5.0"):       # block3.0: the 24-channel stride-2 kernel; block_fusion.0 / block4.1: conv_bx64_kernel; the last two: conv_bx64s2_kernel (64 / 128 couts)
+    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1", "block4.0", "block5.0", "block5.1"):       # (block5.1: 128 -> 128, variants 1 and 12 only: conv_rs64_kernel's 128-channel form)       # block3.0: the 24-channel stride-2 kernel; block_fusion.0 / block4.1: conv_bx64_kernel; the last two: conv_bx64s2_kernel (64 / 128 couts)
         c = next(c for c in CONVS if c.name == name)
         w = sd[f"{name}.layer.0.weight"].double().cuda()
         rm, rv = sd[f"{name}.layer.1.running_mean"].double().cuda(), sd[f"{name}.layer.1.running_var"].double().cuda()
@@ -564,16 +604,29 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
                 truth = torch.relu(torch.nn.functional.conv2d(x.double(), wf, bf, stride=c.stride, padding=1))
                 ref = float(truth.abs().max())
                 err = {}
-                for variant in (1, 10, 11) if c.stride == 1 or c.cin == 24 else (1, 10):      # 11: the same kernel in the fp16-pair arithmetic (three MFMAs per product)
+                if c.cin == 128:
+                    variants = (1, 12) if ww <= 61 else (1,)
+                    for variant in variants:
+                        y = torch.full(tuple(truth.shape), float("nan"), device="cuda")
+                        rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
+                        assert rc == 0, (name, variant, lib.xfh_last_error())
+                        err[variant] = float((y.double() - truth).abs().nan_to_num(1e9).max()) / ref
+                    if 12 in err:
+                        assert err[12] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
+                    n += 1
+                    continue
+                rs64 = c.stride == 1 and c.cin == 64 and ww <= 125         # 12: the fp16-pair kernel with the weights resident in registers (conv_rs64_kernel; maps up to 125 columns)
+                for variant in ((1, 10, 11, 12) if rs64 else (1, 10, 11)):      # (11 for the stride-2 64-channel layers: conv_bx64s2x_kernel)      # 11: the same kernel in the fp16-pair arithmetic (three MFMAs per product)
                     y = torch.full(tuple(truth.shape), float("nan"), device="cuda")
                     rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
                     assert rc == 0, (name, variant, lib.xfh_last_error())
                     err[variant] = float((y.double() - truth).abs().nan_to_num(1e9).max()) / ref
                 assert err[10] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
-                if 11 in err:
-                    assert err[11] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
+                for v in (11, 12):
+                    if v in err:
+                        assert err[v] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
                 n += 1
-    assert n == 7 * 8 * 3
+    assert n == 8 * 8 * 3
     assert xf.net.take_status() == 0                      # |x| stayed far below the fp16 range: no range report
 
 
@@ -583,13 +636,14 @@ def test_fp16_pair_arithmetic_reports_its_range_and_the_model_falls_back(sd):
     that ran the bf16 form from the start -- and the model stays there.  Small subnormal-range activations are exact in both."""
     import warnings
     from accelerated_features_amd import XFeat
-    from accelerated_features_amd.xfeat import DEFAULT_FX
+    from accelerated_features_amd.xfeat import DEFAULT_FX, DEFAULT_HEADS_F32, DEFAULT_BLOCK1
     from accelerated_features_amd.spec import CONV_INDEX
     lib = _lib().load()
     a, b = XFeat(weights=sd, top_k=512), XFeat(weights=sd, top_k=512)
     v = C.c_int(-1)
-    assert lib.xfh_get_option(a.net.handle(), b"fx", C.byref(v)) == 0 and v.value == DEFAULT_FX      # the Python mirror of the library default
-    b.set_option("fx", 0)
+    for key, mirror in ((b"fx", DEFAULT_FX), (b"heads_f32", DEFAULT_HEADS_F32), (b"block1", DEFAULT_BLOCK1)):      # the Python mirrors of the library defaults
+        assert lib.xfh_get_option(a.net.handle(), key, C.byref(v)) == 0 and v.value == mirror, (key, v.value, mirror)
+    b.set_option("fx", 0); b.set_option("heads_f32", DEFAULT_HEADS_F32 or 2); b.set_option("block1", 5)      # the fp32-range forms the fallback lands on
     # (a) a single layer: 1e6-sized activations -> flag, and inf / nan in the fx output; the bf16 form is fine
     x = torch.relu(torch.randn(2, 64, 24, 32, device="cuda")) * 3.0e5
     y = torch.empty(2, 64, 24, 32, device="cuda")
@@ -609,7 +663,7 @@ def test_fp16_pair_arithmetic_reports_its_range_and_the_model_falls_back(sd):
         ra = a.detectAndCompute(img, top_k=512)
     rb = b.detectAndCompute(img, top_k=512)
     assert any("fp16-pair" in str(m.message) for m in w)
-    assert a.net._options.get("fx") == 0
+    assert a.net._options.get("fx") == 0 and a.net._effective_option("heads_f32") != 0 and a.net._effective_option("block1") < 6
     for u, v_ in zip(ra, rb):
         assert torch.equal(u["keypoints"], v_["keypoints"]) and torch.equal(u["scores"], v_["scores"]) and torch.equal(u["descriptors"], v_["descriptors"])
     # (c) tiny activations (fp16 subnormals of the high part): the pair still carries them -- same accuracy as the bf16 form against fp64
@@ -1095,13 +1149,14 @@ def test_frame_stream_at_the_bench_shape_is_bit_stable_over_many_steps(xf, sd, c
         raise AssertionError(f"{len(bad)} of 40 results differ from the synchronous one (synchronous result reproducible: {ref_stable}): {bad[:6]}")
 
 
-@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 0}])
+@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 2, "block1": 5, "fx": 3}, {"heads_f32": 0, "fx": 3}, {"block1": 7}, {"heads_f32": 0, "fx": 11}, {"fx": 7}, {"fx": 67}, {"fx": 387}, {"fx": 1027}])
 def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
     """Time-boxed soak.  The bench-shape backbone + sparse step + match on one HIP stream while a second stream runs foreign kernels (another
     model's backbone = every kernel of this library incl. f32-MFMA and vector-only ones, a large copy, a rocBLAS GEMM), then the same with every matrix-core
     kernel starting on an invalidated instruction cache (xfh_debug_cold_start: the condition that made the split-bf16 key-point head deliver wrong 16-cell blocks,
     DESIGN 9.0) -- every network output and every match list of every step bit-identical to the quiet, warm reference.  Parametrised over the per-handle kernel
-    options; {"heads_f32": 0} is the opt-in split-bf16 head: it runs the two-stream part only as a record (its failures are rare and known), the assertion covers what ships."""
+    options (every set names what it needs, so the list means the same whatever the library defaults are: {"heads_f32": 2, "block1": 5, "fx": 3} is round 4's shipped mix);
+    {"heads_f32": 0, "fx": 3} is the opt-in split-bf16 head: it runs the two-stream part only as a record (its failures are rare and known), the assertion covers what ships."""
     import threading
     import time
     from accelerated_features_amd import XFeat
@@ -1167,6 +1222,7 @@ def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
         lib.xfh_debug_cold_start(0)
     print(f"options {opts}: {n1} steps next to foreign kernels: differing {dict(zip(names, bad1))}; {n2} cold-start steps: differing {dict(zip(names, bad2))}")
     assert n1 >= 200 and n2 >= 200
-    if opts.get("heads_f32", 1) == 0:
-        return                                          # the opt-in head: recorded above, not asserted
+    from accelerated_features_amd.xfeat import DEFAULT_FX, DEFAULT_HEADS_F32
+    if opts.get("heads_f32", DEFAULT_HEADS_F32) == 0 and not opts.get("fx", DEFAULT_FX) & 8:
+        return                                          # the opt-in bf16 head: recorded above, not asserted.  (The fp16-pair head IS asserted: it has to earn its place.)
     assert not any(bad1) and not any(bad2), (dict(zip(names, bad1)), dict(zip(names, bad2)))

@@ -139,6 +139,41 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
     assert lib.xfh_create(ptrs, 3, 0, C.byref(h)) == -2       # malformed weight table
 
 
+def test_range_fallback_lands_on_fp32_range_forms_whatever_the_defaults_are(monkeypatch):
+    """XFeatModel.fx_range_exceeded (the reaction to bit 0 of the status word: an activation beyond fp16's range) must end on kernels with fp32's range -- fx = 0,
+    NO split heads (with fx = 0 they would be the retired bf16 head), block1 on the vector ALUs -- and must not ask for a second repeat; checked for the
+    shipped defaults and for the ones the next round's probe points at (block1 = 7, fp16-pair heads), without a GPU (options are remembered until a handle exists)."""
+    import warnings
+    from accelerated_features_amd import XFeat, xfeat as xm
+    for defaults, overrides in (((3, 2, 0), {}), ((11, 0, 7), {}), ((3, 2, 0), {"fx": 11, "heads_f32": 0, "block1": 7}), ((3, 2, 0), {"heads_f32": 1}), ((0, 2, 0), {"block1": 6})):
+        monkeypatch.setattr(xm, "DEFAULT_FX", defaults[0]); monkeypatch.setattr(xm, "DEFAULT_HEADS_F32", defaults[1]); monkeypatch.setattr(xm, "DEFAULT_BLOCK1", defaults[2])
+        net = XFeat(weights=None).net
+        for k, v in overrides.items():
+            net.set_option(k, v)
+        assert net.fx_range_exceeded(status=0) is False and net.fx_range_exceeded(status=2) is False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert net.fx_range_exceeded(status=1) is True
+        assert any("fp16-pair" in str(m.message) for m in w)
+        assert net._effective_option("fx") == 0 and net._effective_option("heads_f32") in (1, 2, 3) and net._effective_option("block1") < 6
+        if overrides.get("heads_f32") == 1:
+            assert net._effective_option("heads_f32") == 1                      # (a caller's f32 choice is left alone)
+        assert net.fx_range_exceeded(status=1) is False                          # nothing left to switch off: no endless repeat on a stale flag
+    monkeypatch.setattr(xm, "DEFAULT_FX", 0); monkeypatch.setattr(xm, "DEFAULT_HEADS_F32", 2); monkeypatch.setattr(xm, "DEFAULT_BLOCK1", 0)
+    assert XFeat(weights=None).net.fx_range_exceeded() is False                 # fp32-range forms only: no read-back at all
+
+
+def test_python_mirrors_of_the_library_defaults_agree_with_kernels_hpp():
+    """xfeat.DEFAULT_FX / DEFAULT_HEADS_F32 / DEFAULT_BLOCK1 mirror csrc/kernels.hpp: Options (the GPU suite asks the live handle; this is the same check without one)."""
+    import re
+    from accelerated_features_amd import xfeat as xm
+    src = open(os.path.join(os.path.dirname(xm.__file__), "csrc", "kernels.hpp"), encoding="utf-8").read()
+    body = src[src.index("struct Options {"):]
+    body = body[:body.index("};")]
+    got = {k: int(v) for k, v in re.findall(r"^\s*int\s+(\w+)\s*=\s*(\d+)\s*;", body, flags=re.M)}
+    assert (got["fx"], got["heads_f32"], got["block1"]) == (xm.DEFAULT_FX, xm.DEFAULT_HEADS_F32, xm.DEFAULT_BLOCK1), got
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "accelerated_features_amd")
     for dp, _, files in os.walk(pkg):
@@ -158,8 +193,11 @@ def test_every_barrier_in_dma_kernels_waits_for_the_dma():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     import glob
+    def _src_dma(f):      # the file and the kernel-body headers it includes (csrc/*_body.hpp)
+        t = open(f).read()
+        return t + "".join(open(os.path.join(os.path.dirname(f), h)).read() for h in re.findall(r'#include "(\w+_body\.hpp)"', t))
     files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip")))
-             if re.search(r"global_load_lds|buffer_load[^\n]* lds", open(f).read())]
+             if re.search(r"global_load_lds|buffer_load[^\n]* lds", _src_dma(f))]
     assert len(files) >= 3
     mod.isa_asm.prefetch(sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "k_*.hip"))))      # (every kernel file once, in parallel; the audit below shares them)
     for f in files:
@@ -177,7 +215,10 @@ def test_no_valu_write_lands_in_a_freshly_read_bf16_mfma_operand():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     import glob
-    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_(bf16|f16)\(", open(f).read())]
+    def _src(f):      # the file and the kernel-body headers it includes (csrc/*_body.hpp)
+        t = open(f).read()
+        return t + "".join(open(os.path.join(os.path.dirname(f), h)).read() for h in re.findall(r'#include "(\w+_body\.hpp)"', t))
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_(bf16|f16)\(", _src(f))]
     assert len(files) >= 4
     for f in files:
         nk, nm, bad = mod.audit(f)

@@ -52,8 +52,11 @@ def audit(src):
 
 
 def main():
+    def _src_dma(f):      # the file and the kernel-body headers it includes (csrc/*_body.hpp), transitively
+        t = open(f).read()
+        return t + "".join(_src_dma(os.path.join(os.path.dirname(f), h)) for h in re.findall(r'#include "(\w+_body\.hpp)"', t))
     files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip")))
-             if re.search(r"global_load_lds|buffer_load[^\n]* lds", open(f).read())]
+             if re.search(r"global_load_lds|buffer_load[^\n]* lds", _src_dma(f))]
     total_bad = 0
     for f in files:
         nk, nb, bad = audit(f)

@@ -57,7 +57,10 @@ def audit(src):
 
 
 def main():
-    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_(bf16|f16)\(", open(f).read())]
+    def _src(f):      # the file and the kernel-body headers it includes (csrc/*_body.hpp), transitively
+        t = open(f).read()
+        return t + "".join(_src(os.path.join(os.path.dirname(f), h)) for h in re.findall(r'#include "(\w+_body\.hpp)"', t))
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*.hip"))) if re.search(r"mfma_f32_\d+x\d+x\d+_(bf16|f16)\(", _src(f))]
     total = 0
     for f in files:
         nk, nm, bad = audit(f)

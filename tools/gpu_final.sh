@@ -1,11 +1,11 @@
 #!/bin/bash
 # The round's final GPU sequence: proof soaks of the shipped defaults, the GPU test-suite, the default bench line, rocprofv3 kernel stats (default + one lane), PMC traffic.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-N=${SOAK_STEPS:-300000}
+N=${SOAK_STEPS:-300000}; TAG=${TAG:-r05}      # (round 4's logs: profiles/r04_soak_*.txt)
 timeout 120 python tools/final_soak.py concurrent 600 > gpurun_out/soak_sanity.log 2>&1 && timeout 120 python tools/final_soak.py single 600 >> gpurun_out/soak_sanity.log 2>&1; echo "sanity rc=$?"; grep RESULT gpurun_out/soak_sanity.log
 if [ "$1" != "nosoak" ]; then
-timeout 1500 python tools/final_soak.py concurrent $N 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_soak_concurrent.txt; echo "concurrent rc=${PIPESTATUS[0]}"; tail -2 gpurun_out/r04_soak_concurrent.txt
-timeout 1500 python tools/final_soak.py single $N 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_soak_single_stream.txt; echo "single rc=${PIPESTATUS[0]}"; tail -3 gpurun_out/r04_soak_single_stream.txt
+timeout 1500 python tools/final_soak.py concurrent $N 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_soak_concurrent.txt; echo "concurrent rc=${PIPESTATUS[0]}"; tail -2 gpurun_out/${TAG}_soak_concurrent.txt
+timeout 1500 python tools/final_soak.py single $N 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_soak_single_stream.txt; echo "single rc=${PIPESTATUS[0]}"; tail -3 gpurun_out/${TAG}_soak_single_stream.txt
 fi
 if [ "$1" != "soakonly" ]; then
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log | grep -v amdgpu.ids

@@ -3,8 +3,9 @@
 
 Every launch's heat map (and logits) is compared on the device with the result of a quiet run; differing float4s are recorded
 (iteration, index, bits) and decoded here into (image, cell, workgroup tile, wave, lane) so that a rare wrong block can be placed.
-Variants (xfh_debug_head_soak): 0 = the split-bf16 head, 100 / 101 = the f32-MFMA heads (activation tile in LDS / register input = the default);
-1000 + s, 2000 + s, 3000 + s = the same three started on an invalidated instruction cache with the code moved by 4 s bytes (s = 0 .. 15).
+Variants (xfh_debug_head_soak): 0 = the split-bf16 head, 100 / 101 = the f32-MFMA heads (activation tile in LDS / register input = the default), 102 / 103 / 104 = the split head in the
+fp16-pair arithmetic (three weight fragments | two | three and the pixel-side fragments through LDS);
+1000 + s, 2000 + s, 3000 + s, 4000 + s, 5000 + s = 0, 100, 101, 102, 104 started on an invalidated instruction cache with the code moved by 4 s bytes (s = 0 .. 15).
 
     python tools/head_soak.py --variants 0,101 --foreign backbone,copy,none --max-seconds 45           # two streams
     python -m accelerated_features_amd.build --scan          # (the 3 x 16 scan instantiations live in libxfeat_hip_scan.so only)
