@@ -19,9 +19,9 @@ from . import _lib
 from .spec import CONVS, FINE
 
 # the library's defaults of the options the range fallback below has to know (csrc/kernels.hpp: Options; tests/test_gpu_parity.py checks that the mirrors agree)
-DEFAULT_FX = 3
-DEFAULT_HEADS_F32 = 2
-DEFAULT_BLOCK1 = 0
+DEFAULT_FX = 11
+DEFAULT_HEADS_F32 = 0
+DEFAULT_BLOCK1 = 7
 
 __all__ = ["XFeat", "XFeatModel"]
 
