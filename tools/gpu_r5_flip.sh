@@ -16,7 +16,7 @@ timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > $
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > ${O}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 ${O}_smoke.log
 # 3. what it is worth: the default line, then round 4's mix in the same process class (same box) for the A/B (~3 min)
 timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids > ${O}_bench.log; tail -c 400 ${O}_bench.log
-timeout 300 python tools/ab_configs.py "heads_f32=2,block1=5,fx=3" "heads_f32=2,block1=7,fx=3" "heads_f32=0,block1=5,fx=11" "heads_f32=0,block1=7,fx=11" "heads_f32=0,block1=7,fx=15" --spans 3,202,203 2>&1 | grep -v amdgpu.ids > ${O}_ab.log; tail -14 ${O}_ab.log
+timeout 400 python tools/ab_configs.py "heads_f32=2,block1=5,fx=3" "heads_f32=2,block1=7,fx=3" "heads_f32=0,block1=5,fx=11" "heads_f32=0,block1=7,fx=11" "heads_f32=0,block1=7,fx=139" "heads_f32=0,block1=7,fx=395" "heads_f32=0,block1=7,fx=907" "heads_f32=0,block1=7,fx=1035" "heads_f32=0,block1=7,fx=1931" --spans 3,202,203 2>&1 | grep -v amdgpu.ids > ${O}_ab.log; tail -14 ${O}_ab.log
 # 4. kernel stats of the flipped default (~2 min)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof2" -o it --output-format csv -- python "$OLDPWD/bench.py" --steps 10 --warmup 3 --cpu-seconds 0 --no-side-passes > "$OLDPWD/${O}_rocprof.log" 2>&1); echo "rocprof rc=$?"
 find gpurun_out/prof2 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} ${O}_kernel_stats.csv; rm -rf gpurun_out/prof2
