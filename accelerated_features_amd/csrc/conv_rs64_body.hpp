@@ -40,6 +40,15 @@
 /* a value whose home is an accumulation register: the matrix instructions read their A operand from there directly; left to itself hipcc parks the weights that do not fit into
    the 256 architectural registers there too, but copies each fragment back (four v_accvgpr_read) in front of every use */
 #define XFH_AGPR(x) asm volatile("" : "+a"(x))
+#define XFH_VGPR(x) asm volatile("" : "+v"(x))
+/* the end of a tap: the NEXT tap's B operands (read while this tap was multiplied) and the accumulators in one statement -- it follows this tap's MFMAs (it takes their results)
+   and precedes the next tap's, so the wait for the LDS read sits BEHIND the six MFMAs it travelled under (a pin right behind the read puts the wait in front of them: the matrix
+   pipe then idles one LDS latency per tap) */
+#define XFH_AGPR_TAP(h, l, c0, c1) asm volatile("" : "+a"(h), "+a"(l), "+a"(c0), "+a"(c1))
+/* the start of a tap, behind the read of the next tap's operands: the tap's MFMAs take the accumulators from here, so they are issued behind the read (left to itself the
+   instruction selector lists the six MFMAs first and the read right in front of its wait) */
+#define XFH_AGPR_ACC(c0, c1) asm volatile("" : "+a"(c0), "+a"(c1))
+#define XFH_AGPR_TAP2(h, l, h1, l1, c0, c1) asm volatile("" : "+a"(h), "+a"(l), "+a"(h1), "+a"(l1), "+a"(c0), "+a"(c1))
 #endif
 #include <type_traits>
 #include "bx_split.hpp"
@@ -92,7 +101,7 @@ static_assert(ring_off<0>() + 4 * 5 * SEG_BYTES <= 160 * 1024 && ring_off<1>() +
 
 // the code of ONE wave of the workgroup (wave = its K quarter and the couts it finishes): four copies, so that which accumulator registers are a wave's own and which go to
 // whom is static (selected at run time it costs a v_cndmask per register and use, or a branch tree in the middle of the MFMA stream)
-// TRACE (a separate instantiation: the stamps' branches would cut the unit's basic block in the production code): lane 0 of wave 0 writes s_memtime to trace[32 workgroup + k]:
+// TRACE (a separate instantiation: the stamps' branches would cut the unit's basic block in the production code): lane 0 of wave 0 writes s_memtime to trace[128 workgroup + k] (k = 32 + 27 block + slot: the slots of the second unit):
 // k = 0 entry, 1 weights in registers, 2 the first run's ring filled; of the workgroup's SECOND unit: 3 start, 4 / 5 / 6 / 7 first block (taps 0-2 issued, taps 3-4 issued =
 // at the barrier, barrier passed, taps 5-8 + reduction issued), 8 .. 11 the same of the second block, 12 unit end (segment stored); 13 exit, 14 = units this workgroup processed
 template <int wave, int FUSE, int CIN = 64, bool TRACE = false>
@@ -107,7 +116,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, kg = lane >> 5;
     const int P = a.P, H = a.H, W = a.W, HW = H * W;
     const float inv_p = a.inv_p;
-    long long* tr = TRACE && wave == 0 && a.trace && lane == 0 ? a.trace + (size_t)blockIdx.x * 32 : nullptr;
+    long long* tr = TRACE && wave == 0 && a.trace && lane == 0 ? a.trace + (size_t)blockIdx.x * 128 : nullptr;
     int n_units = 0;
 #define RS_STAMP(k) { if constexpr (TRACE) { if (tr) tr[k] = __builtin_amdgcn_s_memtime(); } }
 #define RS_STAMP_U(k) { if constexpr (TRACE) { if (tr && n_units == 1) tr[k] = __builtin_amdgcn_s_memtime(); } }
@@ -151,7 +160,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_p); };
     // the B operands of a tap: positions t0 + shift + n of the ring, high parts and low parts of this lane's 8 channels
     struct Xf { f16x8 h, l, h1, l1; };            // (h1, l1: the second channel chunk of the 128-channel form)
-    auto ldb = [&](unsigned tb /* byte offset of the block's first position under this tap, < 2 Rb */, Xf& x) __attribute__((always_inline)) {
+    auto ldb = [&](unsigned tb /* byte offset of the block's first position under this tap, < 2 Rb */, Xf& x, bool pin = true) __attribute__((always_inline)) {
         tb = tb >= Rb ? tb - Rb : tb;                                                 // (wave-uniform)
         unsigned ab = tb + lane_b;
         ab = min(ab, ab - Rb);                                                        // positions beyond the ring's end continue at its start
@@ -160,11 +169,11 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         if constexpr (C128) {
             x.h1 = *reinterpret_cast<const f16x8*>(ring + ab + 32);
             x.l1 = *reinterpret_cast<const f16x8*>(ring + ab + LO_OFF + 32);
-            XFH_AGPR(x.h1); XFH_AGPR(x.l1);
+            if (pin) { XFH_AGPR(x.h1); XFH_AGPR(x.l1); }
         }
         // the B operands live in accumulation registers too (ds_read writes them there directly): registers no vector-ALU result is ever allocated to, so none can land in
         // an operand the matrix core is still reading (tools/check_mfma_war.py) -- without idle slots or keep-alive fences in the MFMA stream
-        XFH_AGPR(x.h); XFH_AGPR(x.l);
+        if (pin) { XFH_AGPR(x.h); XFH_AGPR(x.l); }
     };
     unsigned shift_b[9];
 #pragma unroll
@@ -295,21 +304,78 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
                 for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z[j]), pd.rs, pd.voff[nb], j * HW * 4, 0);
             }
         }
-    };    // ---- taps T0 .. T1 - 1 of a block: the operands of tap t + 1 are read while tap t is multiplied (x[t & 1] <-> x[(t + 1) & 1]); behind tap 8: tap 0 of the NEXT block
-    // (32 positions on: the second block of the unit, or the first of the next unit -- its segment has been in the ring since this unit began)
-    auto taps = [&](auto T0C, auto T1C, auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[2]) __attribute__((always_inline)) {
-        constexpr int T0 = decltype(T0C)::value, T1 = decltype(T1C)::value, PAR = decltype(PARC)::value;
-#pragma unroll
-        for (int t = T0; t < T1; ++t) {
-            const int cur = (t + PAR) & 1;
-            ldb(t < 8 ? t0b + shift_b[t < 8 ? t + 1 : 0] : t0b + 32 * PIXB, x[cur ^ 1]);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][2], x[cur].h, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][2], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][1], x[cur].l, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][1], C128 ? x[cur].l1 : x[cur].l, c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][0], x[cur].h, c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][0], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
+    };
+    // ---- the same in PIECES, one per slot of the MFMA stream (below): piece p of a block's foreign partial sums (6 ds_write_b128; 128 channels: 3) ...
+    constexpr int NPIECE = C128 ? 3 : 6, NSTORE = C128 ? 4 : 8;
+    auto red_write_piece = [&](auto PC, const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
+        constexpr int p = decltype(PC)::value;
+        unsigned char* red = smem_rs + (kb & 1) * RED_BYTES;
+        if constexpr (C128) {
+            constexpr int o = p < wave ? p : p + 1;
+            float4* d = reinterpret_cast<float4*>(red + o * (3 * 1024) + (wave < o ? wave : wave - 1) * 1024) + lane;
+            d[0] = make_float4(c0[4 * o] + c1[4 * o], c0[4 * o + 1] + c1[4 * o + 1], c0[4 * o + 2] + c1[4 * o + 2], c0[4 * o + 3] + c1[4 * o + 3]);
+        } else {
+            constexpr int q = p >> 1, o = q < wave ? q : q + 1, half = p & 1;
+            float4* d = reinterpret_cast<float4*>(red + o * (3 * 2048) + (wave < o ? wave : wave - 1) * 2048) + lane;
+            const f32x16& c = (o >> 1) ? c1 : c0;
+            d[64 * half] = make_float4(c[8 * (o & 1) + 4 * half], c[8 * (o & 1) + 4 * half + 1], c[8 * (o & 1) + 4 * half + 2], c[8 * (o & 1) + 4 * half + 3]);
         }
+    };
+    // ... the finished values of this wave's couts (sum of the four partials, bias, ReLU) and their stores one by one (the unfused forms)
+    auto finish_values = [&](const f32x16& c0, const f32x16& c1, const float4 (&part)[3][2], float (&y)[8]) __attribute__((always_inline)) {
+        if constexpr (C128) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float p3[3] = {k == 0 ? part[0][0].x : k == 1 ? part[0][0].y : k == 2 ? part[0][0].z : part[0][0].w, k == 0 ? part[1][0].x : k == 1 ? part[1][0].y : k == 2 ? part[1][0].z : part[1][0].w,
+                                     k == 0 ? part[2][0].x : k == 1 ? part[2][0].y : k == 2 ? part[2][0].z : part[2][0].w};
+                const float sum = (((c0[4 * wave + k] + c1[4 * wave + k]) + p3[0]) + p3[1]) + p3[2];
+                y[k] = fmaxf(sum * FX_SCALE_INV + bs[k], floor_y);
+            }
+        } else {
+            float own[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) own[k] = ((wave >> 1) ? c1 : c0)[8 * (wave & 1) + k];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                own[0] += part[s][0].x; own[1] += part[s][0].y; own[2] += part[s][0].z; own[3] += part[s][0].w;
+                own[4] += part[s][1].x; own[5] += part[s][1].y; own[6] += part[s][1].z; own[7] += part[s][1].w;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = fmaxf(own[k] * FX_SCALE_INV + bs[k], floor_y);
+        }
+    };
+    auto finish_store = [&](auto KC, const float (&y)[8], const Pend& pd) __attribute__((always_inline)) {
+        constexpr int k = decltype(KC)::value;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[k]), pd.rs, pd.voff, (C128 ? k : (k & 3) + 8 * (k >> 2)) * HW * 4, 0);
+    };
+    // ---- ONE tap of a block = six MFMAs in three pairs, a SLOT behind each pair (27 per block).  The operands of tap t + 1 are requested first and awaited last (x[t & 1] <->
+    // x[(t + 1) & 1]; behind tap 8: tap 0 of the NEXT block -- 32 positions on: the second block of the unit, or the first of the next unit, whose segment has been in the ring
+    // since this unit began).  The pins (XFH_AGPR_ACC / _TAP) take and return the accumulators, so MFMA pairs and pins alternate in program order, and every MEMORY operation a
+    // slot issues (LDS writes of the partial sums, global stores and loads, the ring's segment) stays between its two pairs: one wave per SIMD means nobody else fills the matrix
+    // pipe while this wave transfers a burst of them (a ds_write_b128 is 13 cycles of the store path, a burst of six from each of the four waves 300: measured as + 270 cycles on
+    // the two taps behind it; the eight stores and sixteen loads of a unit likewise).  Vector-ALU work is not ordered by the pins: the scheduler spreads it over the gaps.
+    auto tap = [&](auto TC, auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[2], auto&& slot) __attribute__((always_inline)) {
+        constexpr int t = decltype(TC)::value, PAR = decltype(PARC)::value, cur = (t + PAR) & 1;
+        ldb(t < 8 ? t0b + shift_b[t < 8 ? t + 1 : 0] : t0b + 32 * PIXB, x[cur ^ 1], false);
+        if constexpr (t > 0) XFH_AGPR_ACC(c0, c1);      // (tap 0 starts from the literal zero: a pinned accumulator would have to be written first, 32 v_accvgpr_write per block)
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][2], x[cur].h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][2], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
+        XFH_AGPR_ACC(c0, c1);
+        slot(std::integral_constant<int, 3 * t>{});
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][1], x[cur].l, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][1], C128 ? x[cur].l1 : x[cur].l, c1, 0, 0, 0);
+        XFH_AGPR_ACC(c0, c1);
+        slot(std::integral_constant<int, 3 * t + 1>{});
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][0], x[cur].h, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][0], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
+        if constexpr (C128) { XFH_AGPR_TAP2(x[cur ^ 1].h, x[cur ^ 1].l, x[cur ^ 1].h1, x[cur ^ 1].l1, c0, c1); }
+        else { XFH_AGPR_TAP(x[cur ^ 1].h, x[cur ^ 1].l, c0, c1); }
+        slot(std::integral_constant<int, 3 * t + 2>{});
+    };
+    auto taps9 = [&](auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[2], auto&& slot) __attribute__((always_inline)) {
+        tap(std::integral_constant<int, 0>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 1>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 2>{}, PARC, t0b, c0, c1, x, slot);
+        tap(std::integral_constant<int, 3>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 4>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 5>{}, PARC, t0b, c0, c1, x, slot);
+        tap(std::integral_constant<int, 6>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 7>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 8>{}, PARC, t0b, c0, c1, x, slot);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I3 = std::integral_constant<int, 3>;
     using I5 = std::integral_constant<int, 5>; using I9 = std::integral_constant<int, 9>;
@@ -339,7 +405,9 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         auto seg_load = [&](int s, bool en, float (&v)[NV]) __attribute__((always_inline)) {
             const int i = 64 * s + lane, r = row_of(i), c = i - r * P;
             const int iy = r - 1, ix = c - 1;
-            const int voff = en && iy >= 0 && iy < H && ix >= 0 && ix < W ? (iy * W + ix) * 4 : (int)0x80000000;
+            // (one select, no short-circuit: a branch here would cut the unit's basic block and strand the conversion and the loads behind the last MFMA)
+            const bool inside = (int)en & (int)((unsigned)iy < (unsigned)H) & (int)((unsigned)ix < (unsigned)W);
+            const int voff = inside ? (iy * W + ix) * 4 : (int)0x80000000;
 #pragma unroll
             for (int j = 0; j < NV; ++j) v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, j * HW * 4, 0));
         };
@@ -366,12 +434,14 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         if constexpr (FUSE == 2) rs_out2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
         auto out2_voff = [&](int p) {              // fused 1x1: lane (position l & 15 of a 16-position half, couts 16 wave + 4 (l >> 4) + j)
             const int oy = row_of(p), ox = p - oy * P;
-            if (!(oy < H && ox < W)) return (int)0x80000000;
-            return FUSE == 2 ? ((oy * W + ox) * 64 + 16 * wave + 4 * (lane >> 4)) * 4 : ((4 * (lane >> 4)) * HW + oy * W + ox) * 4;
+            const bool inside = (int)(oy < H) & (int)(ox < W);
+            const int off = FUSE == 2 ? ((oy * W + ox) * 64 + 16 * wave + 4 * (lane >> 4)) * 4 : ((4 * (lane >> 4)) * HW + oy * W + ox) * 4;
+            return inside ? off : (int)0x80000000;
         };
         auto out_voff = [&](int p) {               // output position p of the padded raster -> this lane's store offset (its first cout), or "dropped"
             const int oy = row_of(p), ox = p - oy * P;
-            return oy < H && ox < W ? ((4 * kg) * HW + oy * W + ox) * 4 : (int)0x80000000;
+            const bool inside = (int)(oy < H) & (int)(ox < W);
+            return inside ? ((4 * kg) * HW + oy * W + ox) * 4 : (int)0x80000000;
         };
         // prologue: the window of the run's first unit (segments ua .. ua + nseg - 1: the whole ring) with every pipe idle; the segment the first unit will write travels
         float v[NV];
@@ -393,60 +463,105 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         if constexpr (!C128) seg_load(ua + a.nseg, ua + 1 < ub, v);
         int rslot = 0;                             // slot of segment u
         ldb(0u, x[0]);
+        // the segment's loads one by one (64 channels: two per slot of the second block, behind the conversion that empties their registers)
+        int sv_off = (int)0x80000000;
+        auto seg_voff = [&](int s, bool en) __attribute__((always_inline)) {
+            const int i = 64 * s + lane, r = row_of(i), c = i - r * P;
+            const int iy = r - 1, ix = c - 1;
+            const bool inside = (int)en & (int)((unsigned)iy < (unsigned)H) & (int)((unsigned)ix < (unsigned)W);
+            sv_off = inside ? (iy * W + ix) * 4 : (int)0x80000000;
+        };
+        auto seg_load_piece = [&](auto JC, float (&v)[NV]) __attribute__((always_inline)) {
+            constexpr int j = decltype(JC)::value;
+            v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, sv_off, j * HW * 4, 0));
+        };
+        auto seg_store_piece = [&](auto IC, int slot, const u32x4 (&h)[NQ], const u32x4 (&l)[NQ]) __attribute__((always_inline)) {
+            constexpr int i = decltype(IC)::value;
+            unsigned char* p = ring + (slot * SEG_PX + lane) * PIXB;
+            *reinterpret_cast<u32x4*>(p + 16 * i) = h[i];
+            *reinterpret_cast<u32x4*>(p + LO_OFF + 16 * i) = l[i];
+        };
         for (int u = ua; u < ub; ++u) {
             const unsigned t0b = (unsigned)(rslot * SEG_BYTES);
-            float4 part[3][2];
             // (128 channels: the next segment's 32 loads are issued here, not a unit earlier -- their registers would overlap the converted segment's for a whole unit,
             // and the maps of these layers sit in L2)
             RS_STAMP_U(3)
             if constexpr (C128) seg_load(u + a.nseg, u + 1 < ub, v);
-            // ---- first block (accumulators a); inside it: the reduction of the block before (accumulators b: the previous unit's, or run's, second block)
+            // ---- first block (accumulators a); in its slots: the reduction of the block before (accumulators b: the previous unit's, or run's, second block)
             if constexpr (FUSE == 0) { pend_a.rs = rs_out; pend_a.voff = out_voff(64 * u + n); }
             else { p2a_prev = p2a; p2a.rs = rs_out2; p2a.voff[0] = out2_voff(64 * u + (lane & 15)); p2a.voff[1] = out2_voff(64 * u + 16 + (lane & 15)); }
-            taps(I0{}, I3{}, I0{}, t0b, ca0, ca1, x);
-            XFH_SCHED_FENCE();
-            RS_STAMP_U(4)
-            red_write(cb0, cb1);
-            taps(I3{}, I5{}, I0{}, t0b, ca0, ca1, x);
-            XFH_SCHED_FENCE();
-            RS_STAMP_U(5)
-            XFH_LDS_BARRIER();
-            RS_STAMP_U(6)
-            red_read(part);
-            ++kb;
-            XFH_SCHED_FENCE();
-            taps(I5{}, I9{}, I0{}, t0b, ca0, ca1, x);
-            red_finish(cb0, cb1, part, pend_b, 1);
+            {
+                float4 part[3][2];
+                float y[8];
+                auto slot = [&](auto IDC) __attribute__((always_inline)) {
+                    constexpr int id = decltype(IDC)::value;
+                    RS_STAMP_U(32 + id)
+                    if constexpr (id < NPIECE) red_write_piece(IDC, cb0, cb1);
+                    if constexpr (id == 8) { RS_STAMP_U(4) }
+                    if constexpr (id == 14) {
+                        RS_STAMP_U(5)
+                        XFH_LDS_BARRIER();
+                        RS_STAMP_U(6)
+                        red_read(part);
+                        ++kb;
+                    }
+                    if constexpr (id == 15) {
+                        if constexpr (FUSE == 0) finish_values(cb0, cb1, part, y);
+                        else red_finish(cb0, cb1, part, pend_b, 1);
+                    }
+                    if constexpr (FUSE == 0 && id >= 17 && id < 17 + NSTORE) finish_store(std::integral_constant<int, id - 17>{}, y, pend_b);
+                };
+                taps9(I0{}, t0b, ca0, ca1, x, slot);
+            }
             if constexpr (FUSE != 0) conv1x1(0, p2a_prev);      // the first block of the unit before: its 3x3 outputs were published by this block's barrier
 #pragma unroll
             for (int i = 0; i < 16; ++i) { cb0[i] = 0.f; cb1[i] = 0.f; }
-            XFH_SCHED_FENCE();
             RS_STAMP_U(7)
-            // ---- second block (accumulators b); inside it: the segment the next unit needs goes into the ring, the first block is reduced, the segment after that is requested
+            // ---- second block (accumulators b); in its slots: the first block's reduction, the conversion of the segment the NEXT unit needs (taps 0-2), the loads of the segment
+            // after that (into the registers the conversion emptied), and behind the unit's last read of the ring the converted segment (over the segment this unit started with)
             if constexpr (FUSE == 0) { pend_b.rs = rs_out; pend_b.voff = out_voff(64 * u + 32 + n); }
             else { p2b_prev = p2b; p2b.rs = rs_out2; p2b.voff[0] = out2_voff(64 * u + 32 + (lane & 15)); p2b.voff[1] = out2_voff(64 * u + 48 + (lane & 15)); }
-            taps(I0{}, I3{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
-            seg_convert(v, sh, sl);
-            XFH_SCHED_FENCE();
-            RS_STAMP_U(8)
-            red_write(ca0, ca1);
-            taps(I3{}, I5{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
-            XFH_SCHED_FENCE();
-            RS_STAMP_U(9)
-            XFH_LDS_BARRIER();
-            RS_STAMP_U(10)
-            red_read(part);
-            ++kb;
-            XFH_SCHED_FENCE();
-            taps(I5{}, I9{}, I1{}, t0b + 32 * PIXB, cb0, cb1, x);
-            red_finish(ca0, ca1, part, pend_a, 0);
+            {
+                float4 part[3][2];
+                float y[8];
+                auto slot = [&](auto IDC) __attribute__((always_inline)) {
+                    constexpr int id = decltype(IDC)::value;
+                    RS_STAMP_U(32 + 27 + id)
+                    if constexpr (id < NPIECE) red_write_piece(IDC, ca0, ca1);
+                    if constexpr (id == 0) seg_convert(v, sh, sl);
+                    if constexpr (id == 8) {
+#pragma unroll
+                        for (int i = 0; i < NQ; ++i) { XFH_VGPR(sh[i]); XFH_VGPR(sl[i]); }      // the conversion is complete here (left alone the compiler sinks it to the segment's store)
+                        RS_STAMP_U(8)
+                        if constexpr (!C128) seg_voff(u + 1 + a.nseg, u + 2 < ub);
+                    }
+                    if constexpr (!C128 && id >= 9 && id < 17) {
+                        seg_load_piece(std::integral_constant<int, 2 * (id - 9)>{}, v);
+                        seg_load_piece(std::integral_constant<int, 2 * (id - 9) + 1>{}, v);
+                    }
+                    if constexpr (id == 14) {
+                        RS_STAMP_U(9)
+                        XFH_LDS_BARRIER();
+                        RS_STAMP_U(10)
+                        red_read(part);
+                        ++kb;
+                    }
+                    if constexpr (id == 15) {
+                        if constexpr (FUSE == 0) finish_values(ca0, ca1, part, y);
+                        else red_finish(ca0, ca1, part, pend_a, 0);
+                    }
+                    if constexpr (FUSE == 0 && id >= 17 && id < 17 + NSTORE) finish_store(std::integral_constant<int, id - 17>{}, y, pend_a);
+                    // the ring's new segment: every operand read of this unit that touches the old one has been issued (tap 8 reads the next block's tap 0)
+                    if constexpr (id == 24) { seg_store_piece(std::integral_constant<int, 0>{}, rslot, sh, sl); if constexpr (C128) seg_store_piece(std::integral_constant<int, 1>{}, rslot, sh, sl); }
+                    if constexpr (id == 25) seg_store_piece(std::integral_constant<int, C128 ? 2 : 1>{}, rslot, sh, sl);
+                    if constexpr (C128 && id == 26) seg_store_piece(std::integral_constant<int, C128 ? 3 : 0>{}, rslot, sh, sl);
+                };
+                taps9(I1{}, t0b + 32 * PIXB, cb0, cb1, x, slot);
+            }
             if constexpr (FUSE != 0) conv1x1(1, p2b_prev);
-            if constexpr (!C128) seg_load(u + 1 + a.nseg, u + 2 < ub, v);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ca0[i] = 0.f; ca1[i] = 0.f; }
-            XFH_SCHED_FENCE();
             RS_STAMP_U(11)
-            seg_store(rslot, sh, sl);               // segment u + nseg over segment u (the last unit of a run writes zeros); every operand read of this unit has been issued
             XFH_WAVE_SYNC();
             RS_STAMP_U(12)
             ++n_units;

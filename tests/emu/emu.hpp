@@ -199,6 +199,10 @@ inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_REL
 #define XFH_NOP16_3(a, b, c) ((void)0)
 #define XFH_PIN(x) ((void)0)
 #define XFH_AGPR(x) ((void)0)
+#define XFH_VGPR(x) ((void)0)
+#define XFH_AGPR_ACC(c0, c1) ((void)0)
+#define XFH_AGPR_TAP(h, l, c0, c1) ((void)0)
+#define XFH_AGPR_TAP2(h, l, h1, l1, c0, c1) ((void)0)
 #define XFH_LDS_BARRIER() __syncthreads()
 #define XFH_SCHED_FENCE() ((void)0)
 #define XFH_WAVE_SYNC() emu::wg->wave_bar[emu::tidx.x >> 6]->arrive_and_wait()      /* lanes of a wave run in lock-step on the GPU; here they are threads */

@@ -111,21 +111,26 @@ int main(int argc, char** argv) {
             xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, 12, nullptr);
             HIPCHK(hipDeviceSynchronize());
             xfh_debug_trace(h, nullptr);
-            std::vector<long long> t(256 * 32);
+            std::vector<long long> t(256 * 128);
             HIPCHK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
             double sum[16] = {0}; int nw = 0;
+            double slot[54] = {0};
             const char* what[13] = {"entry -> weights in registers", "-> first ring filled", "", "unit: taps 0-2 issued", "taps 3-4 issued (at the barrier)", "barrier passed", "taps 5-8 + reduction issued (first block done)",
                                     "second block: taps 0-2 + conversion", "taps 3-4 (at the barrier)", "barrier passed", "taps 5-8 + reduction", "segment stored (unit end)", ""};
             for (int g = 0; g < 256; ++g) {
-                const long long* q = &t[g * 32];
+                const long long* q = &t[g * 128];
                 if (!q[0] || !q[13] || q[14] < 2 || !q[12]) continue;
                 ++nw;
                 sum[0] += (double)(q[1] - q[0]); sum[1] += (double)(q[2] - q[1]);
                 for (int k = 3; k < 12; ++k) sum[k] += (double)(q[k + 1] - q[k]);
+                for (int k = 0; k < 54; ++k) slot[k] += (double)((k < 53 ? q[33 + k] : q[12]) - q[32 + k]);
                 sum[12] += (double)(q[13] - q[0]); sum[13] += (double)q[14]; sum[14] += (double)(q[12] - q[3]);
             }
             printf("%s: %d workgroups with a second unit; s_memtime ticks (means): whole kernel %.0f for %.1f units; ONE unit %.0f (108 MFMAs: floor 3456 cycles)\n", c.name, nw, sum[12] / (nw ? nw : 1), sum[13] / (nw ? nw : 1), sum[14] / (nw ? nw : 1));
             for (int k = 0; k < 12; ++k) if (what[k][0]) printf("    %-52s %8.0f\n", what[k], sum[k] / (nw ? nw : 1));
+            printf("    slot -> next slot (two MFMAs = 64 cycles + what the slot issues), first block:");
+            for (int k = 0; k < 54; ++k) { if (k == 27) printf("\n    second block:"); printf(" %.0f", slot[k] / (nw ? nw : 1)); }
+            printf("\n");
             HIPCHK(hipFree(x)); HIPCHK(hipFree(y));
         }
         HIPCHK(hipFree(tr));
