@@ -25,7 +25,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 # registers of the Y row into pairs first (32 more registers: spills).
 EXTRA_FLAGS = {"k_match_f16.hip": ["-fno-honor-nans", "-fno-slp-vectorize"],
                # block1 is vector-issue bound (PMC): with NaN semantics every ReLU is a canonicalising v_max(x, x) + the v_max(x, 0); activations are finite
-               "k_conv_direct.hip": ["-fno-honor-nans"]}
+               "k_conv_direct.hip": ["-fno-honor-nans"],
+               # conv_rs64 runs one wave per SIMD: every instruction beside its MFMA stream is an issue slot, and packed fp32 ops (v_pk_add_f32 / v_pk_mul_f32, which the SLP
+               # vectoriser makes of the segment conversion's adjacent subtractions and multiplications) cost ~ 13 cycles each beside MFMAs instead of a slot
+               "k_conv_rs64.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}      # (no NaN semantics: the range guard's max3 takes |x| operands without canonicalising them first)
 
 
 def _hipcc():

@@ -709,6 +709,15 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
         if (c.cin == 128 ? launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status) : launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: conv_rs64_kernel does not take layer %d at width %d", layer, Win);
         return check_launch("xfh_conv_layer(fp16 pair, resident weights)");
     }
+    if (variant >= 13 && variant <= 16) {      // a 3x3 + the 1x1 behind it as ONE launch (block3.1 + .2, block_fusion.1 + .2): 13 / 14 conv_rs64_kernel (NCHW / channels-last output), 15 / 16 conv_bx64_kernel in the fp16-pair arithmetic
+        if (layer + 1 >= L_NUM) return fail(XFH_ERR_ARG, "xfh_conv_layer: layer %d has no successor", layer);
+        const ConvW& c2 = h->nw.conv[layer + 1];
+        const bool nhwc = variant == 14 || variant == 16;
+        if (c2.ks != 1 || c2.cin != 64 || c2.cout != 64 || c.cin != 64 || c.ks != 3 || c.stride != 1 ||
+            (variant <= 14 ? launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, &c2, nhwc, nullptr) : (!c.w_fx || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, &c2, nhwc, 1, h->status))))
+            return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fused 3x3 + 1x1 instantiation for layers %d, %d at width %d", layer, layer + 1, Win);
+        return check_launch("xfh_conv_layer(3x3 + 1x1)");
+    }
     if (variant >= 2) {
         if (launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, variant - 1, h->trace))
             return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no Winograd instantiation for layer %d", layer);

@@ -59,6 +59,16 @@ __device__ inline void split2_f16(float a, float b, unsigned& h, unsigned& l) {
     h = __builtin_bit_cast(unsigned, hh);
     l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
+// The same bits from scalar operations (conv_rs64_body.hpp: a lone wave per SIMD pays three issue slots for a packed fp32 instruction beside its MFMA stream): the residual
+// 2^11 (x - xh) = fma(xh, -2^11, 2^11 x) is exact in fp32, as the difference above is, so the low parts agree bit for bit; hipcc selects v_fma_mix_f32 (the fp16 high part
+// as an operand: no conversion back)
+__device__ inline void split2_f16_scalar(float a, float b, unsigned& h, unsigned& l) {
+    const f32x2 v = {a, b};
+    const f16x2 hh = __builtin_convertvector(v, f16x2);
+    const f32x2 r = {__builtin_fmaf((float)hh[0], -2048.f, a * 2048.f), __builtin_fmaf((float)hh[1], -2048.f, b * 2048.f)};
+    h = __builtin_bit_cast(unsigned, hh);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
 constexpr float FX_SCALE_INV = 1.f / 2048.f;
 // Range guard of the fp16 pair: a kernel keeps the largest |x| it converted (one v_max3 per value pair) and, when it ends, reports |x| >= 65504 -- a value the
 // fp16 high part cannot hold -- by setting bit 0 of the caller's status word (xfh_set_status_buffer; the host re-runs the batch in the bf16 arithmetic).

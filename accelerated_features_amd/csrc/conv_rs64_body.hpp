@@ -85,18 +85,23 @@ constexpr int RED_BYTES = 4 * 3 * 2048;                       // [owner 4][sourc
 constexpr int Y_PITCH = 272, Y_BYTES = 32 * Y_PITCH;           // fused 1x1: a block's 3x3 outputs as fp16 pairs, [position 32][high parts of the 64 channels | low parts] + 16 (bank spread)
 template <int FUSE> constexpr int ring_off() { return 2 * RED_BYTES + (FUSE ? 2 * Y_BYTES : 0); }      // 49152 | 66560
 constexpr int MAX_NSEG = 5;
+// behind a wave's ring: a MIRROR of its first 34 positions, so that the 32 positions of a tap (and the + 1, + 2 of the taps to its right, which share its address register)
+// never straddle the ring's end -- the wrap is a wave-uniform decision (scalar ALU), one address computation serves a tap ROW
+constexpr int MIRROR_PX = 34;
+template <int CIN> constexpr int mirror_bytes() { return MIRROR_PX * pixb<CIN>(); }                           // 2720 | 4896
+template <int CIN> constexpr int ring_stride(int nseg) { return nseg * seg_bytes<CIN>() + mirror_bytes<CIN>(); }
 constexpr int WQ_HALFS = 4 * 9 * 2 * 3 * 64 * 8;              // 110592 fp16 = 216 KiB
 inline int nseg_for(int P) { return 2 + (2 * P + 1) / 64; }
-inline int lds_bytes(int nseg, bool fuse = false) { return (fuse ? ring_off<1>() : ring_off<0>()) + 4 * nseg * SEG_BYTES; }
+inline int lds_bytes(int nseg, bool fuse = false) { return (fuse ? ring_off<1>() : ring_off<0>()) + 4 * ring_stride<64>(nseg); }
 inline int max_nseg(bool fuse) { return fuse ? 4 : 5; }
 // CIN = COUT = 128 (block5.1, block5.2): a workgroup computes a QUARTER of the couts (32) and a wave multiplies 32 input channels (two 16-channel chunks, one accumulator each)
 constexpr int RED128_BYTES = 4 * 3 * 1024;                    // [owner 4][source slot 3][64 lanes] float4: wave w owns couts 8 w .. + 7 of the quarter (4 registers per lane)
-inline int lds_bytes128(int nseg) { return 2 * RED128_BYTES + 4 * nseg * seg_bytes<128>(); }
+inline int lds_bytes128(int nseg) { return 2 * RED128_BYTES + 4 * ring_stride<128>(nseg); }
 constexpr int MAX_NSEG128 = 3;
-static_assert(2 * RED128_BYTES + 4 * MAX_NSEG128 * seg_bytes<128>() <= 160 * 1024, "LDS of a CU");
+static_assert(2 * RED128_BYTES + 4 * ring_stride<128>(MAX_NSEG128) <= 160 * 1024, "LDS of a CU");
 // runs per image for `grid` workgroups: whole images while there are enough of them, else every image in grid / B parts (at least one unit each)
 inline int runs_per_image(int B, int nu, int grid) { const int k = B >= grid ? 1 : grid / B; return k < 1 ? 1 : k > nu ? nu : k; }
-static_assert(ring_off<0>() + 4 * 5 * SEG_BYTES <= 160 * 1024 && ring_off<1>() + 4 * 4 * SEG_BYTES <= 160 * 1024, "LDS of a CU");
+static_assert(ring_off<0>() + 4 * ring_stride<64>(5) <= 160 * 1024 && ring_off<1>() + 4 * ring_stride<64>(4) <= 160 * 1024, "LDS of a CU");
 }
 
 // the code of ONE wave of the workgroup (wave = its K quarter and the couts it finishes): four copies, so that which accumulator registers are a wave's own and which go to
@@ -134,13 +139,6 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) A[t][cb][q] = wp[((t * 2 + cb) * 3 + q) * 64];
-        // (all 54 loads are in flight before the first value is pinned: a pin right behind its load makes the prologue twenty round trips long)
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) XFH_AGPR(A[t][cb][q]);          // 144 of the 216 weight registers live in the accumulation half of the register file (next to the 64 accumulators)
     }
     RS_STAMP(1)
     // ---- the couts this wave finishes: 16 wave + 8 (k >> 2) + 4 kg + (k & 3), k = 0 .. 7 = registers 8 (wave & 1) + k of accumulator wave >> 1
@@ -149,10 +147,11 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     for (int k = 0; k < 8; ++k) bs[k] = C128 ? a.bias[32 * (int)(blockIdx.x & 3) + 8 * wave + 4 * kg + (k & 3)] : a.bias[16 * wave + 8 * (k >> 2) + 4 * kg + (k & 3)];
     const float floor_y = a.relu ? 0.f : -__builtin_inff();
 
-    unsigned char* ring = smem_rs + RING_OFF + wave * a.nseg * SEG_BYTES;
+    unsigned char* ring = smem_rs + RING_OFF + wave * ring_stride<CIN>(a.nseg);
     const unsigned Rb = (unsigned)a.nseg * SEG_BYTES;
     const unsigned lane_b = (unsigned)(n * PIXB + kg * 16);
     unsigned amax = 0;
+    float amaxf = 0.f;                             // range guard of the staged segments (on the fp32 values: one v_max3_f32 per pair)
     int kb = 0;                                    // blocks this workgroup has reduced: parity = reduction buffer
     const int nruns = a.B * a.k;
 
@@ -160,24 +159,28 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_p); };
     // the B operands of a tap: positions t0 + shift + n of the ring, high parts and low parts of this lane's 8 channels
     struct Xf { f16x8 h, l, h1, l1; };            // (h1, l1: the second channel chunk of the 128-channel form)
-    auto ldb = [&](unsigned tb /* byte offset of the block's first position under this tap, < 2 Rb */, Xf& x, bool pin = true) __attribute__((always_inline)) {
-        tb = tb >= Rb ? tb - Rb : tb;                                                 // (wave-uniform)
-        unsigned ab = tb + lane_b;
-        ab = min(ab, ab - Rb);                                                        // positions beyond the ring's end continue at its start
-        x.h = *reinterpret_cast<const f16x8*>(ring + ab);
-        x.l = *reinterpret_cast<const f16x8*>(ring + ab + LO_OFF);
+    // the B operands of a tap ROW: rowb = byte offset of this lane's position under the row's LEFT tap; the taps to its right read PIXB, 2 PIXB further on (immediate offsets)
+    auto row_base = [&](unsigned tb /* byte offset of the block's first position under the row's left tap, < 2 Rb */) __attribute__((always_inline)) {
+        tb = tb >= Rb ? tb - Rb : tb;                                                 // (wave-uniform; the positions behind the ring's end are in its mirror)
+        return tb + lane_b;
+    };
+    auto ldx = [&](unsigned rowb, auto DXC, Xf& x, bool pin = true) __attribute__((always_inline)) {
+        constexpr int dxo = decltype(DXC)::value * PIXB;
+        x.h = *reinterpret_cast<const f16x8*>(ring + rowb + dxo);
+        x.l = *reinterpret_cast<const f16x8*>(ring + rowb + dxo + LO_OFF);
         if constexpr (C128) {
-            x.h1 = *reinterpret_cast<const f16x8*>(ring + ab + 32);
-            x.l1 = *reinterpret_cast<const f16x8*>(ring + ab + LO_OFF + 32);
+            x.h1 = *reinterpret_cast<const f16x8*>(ring + rowb + dxo + 32);
+            x.l1 = *reinterpret_cast<const f16x8*>(ring + rowb + dxo + LO_OFF + 32);
             if (pin) { XFH_AGPR(x.h1); XFH_AGPR(x.l1); }
         }
         // the B operands live in accumulation registers too (ds_read writes them there directly): registers no vector-ALU result is ever allocated to, so none can land in
         // an operand the matrix core is still reading (tools/check_mfma_war.py) -- without idle slots or keep-alive fences in the MFMA stream
         if (pin) { XFH_AGPR(x.h); XFH_AGPR(x.l); }
     };
-    unsigned shift_b[9];
+    unsigned rowshift_b[3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) shift_b[t] = (unsigned)(((t / 3) * P + (t % 3)) * PIXB);
+    for (int dy = 0; dy < 3; ++dy) rowshift_b[dy] = (unsigned)(dy * P * PIXB);
+    unsigned rowb = 0;                                   // the current tap row's base (a register that lives across three taps -- and across the block boundary for row 0)
 
     // where a finished block goes: the block's accumulators wait one block long for their reduction (it runs inside the next block's MFMAs)
     struct Pend { __amdgpu_buffer_rsrc_t rs; int voff; };
@@ -246,8 +249,8 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 uint2 hh, ll;
-                split2_f16(y[4 * g], y[4 * g + 1], hh.x, ll.x);
-                split2_f16(y[4 * g + 2], y[4 * g + 3], hh.y, ll.y);
+                split2_f16_scalar(y[4 * g], y[4 * g + 1], hh.x, ll.x);
+                split2_f16_scalar(y[4 * g + 2], y[4 * g + 3], hh.y, ll.y);
                 fx_track_h(amax, hh.x, true); fx_track_h(amax, hh.y, true);
                 *reinterpret_cast<uint2*>(yp + 16 * g) = hh;
                 *reinterpret_cast<uint2*>(yp + 16 * g + 128) = ll;
@@ -305,7 +308,54 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             }
         }
     };
-    // ---- the same in PIECES, one per slot of the MFMA stream (below): piece p of a block's foreign partial sums (6 ds_write_b128; 128 channels: 3) ...
+    // ---- the fused 1x1 in PIECES for the slots of the 3x3's MFMA stream (below): slots 16 / 17 read the two K halves of Y[ybuf], 18 .. 23 one MFMA pair each
+    // (both 16-position halves: two accumulators), 24 / 25 finish and store one half each.  Its twelve small MFMAs join the stream (16 matrix-pipe cycles each); run
+    // behind the block instead, reads -> wait -> MFMAs -> stores cost 470 cycles per block with the pipe mostly idle (87 us against 68 for the 3x3 alone)
+    struct C1x1 { f16x8 xh[2][2], xl[2][2]; f32x4 d[2]; };
+    auto conv1x1_piece = [&](auto IDC, C1x1& w, int ybuf, const Pend2& pd) __attribute__((always_inline)) {
+        constexpr int id = decltype(IDC)::value;
+        const unsigned char* yp = smem_rs + 2 * RED_BYTES + ybuf * Y_BYTES + (lane & 15) * Y_PITCH + (lane >> 4) * 16;
+        if constexpr (id == 16 || id == 17) {
+            constexpr int s2 = id - 16;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                w.xh[s2][nb] = *reinterpret_cast<const f16x8*>(yp + nb * 16 * Y_PITCH + s2 * 64);
+                w.xl[s2][nb] = *reinterpret_cast<const f16x8*>(yp + nb * 16 * Y_PITCH + s2 * 64 + 128);
+            }
+        }
+        if constexpr (id >= 18 && id < 24) {
+            constexpr int s2 = (id - 18) / 3, q = 2 - (id - 18) % 3;        // fragment order q2 (high parts), q1 (low parts), q0 (high parts) as in conv1x1
+            if constexpr (q == 2) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) { XFH_AGPR(w.xh[s2][nb]); XFH_AGPR(w.xl[s2][nb]); }
+            }
+            if constexpr (id == 18) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                w.d[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[0][2], w.xh[0][0], zero, 0, 0, 0);
+                w.d[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[0][2], w.xh[0][1], zero, 0, 0, 0);
+            } else {
+                XFH_AGPR(w.d[0]); XFH_AGPR(w.d[1]);
+                w.d[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][q], q == 1 ? w.xl[s2][0] : w.xh[s2][0], w.d[0], 0, 0, 0);
+                w.d[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[s2][q], q == 1 ? w.xl[s2][1] : w.xh[s2][1], w.d[1], 0, 0, 0);
+            }
+            XFH_AGPR(w.d[0]); XFH_AGPR(w.d[1]);
+        }
+        if constexpr (id == 24 || id == 25) {
+            constexpr int nb = id - 24;
+            float z[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[j] = fmaxf(w.d[nb][j] * FX_SCALE_INV + bs2[j], floor_y2);
+            if constexpr (FUSE == 2) {
+                typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+                const u32x4s qv = {__float_as_uint(z[0]), __float_as_uint(z[1]), __float_as_uint(z[2]), __float_as_uint(z[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(qv, pd.rs, pd.voff[nb], 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(z[j]), pd.rs, pd.voff[nb], j * HW * 4, 0);
+            }
+        }
+    };
+    // ---- the reduction in PIECES, one per slot of the MFMA stream (below): piece p of a block's foreign partial sums (6 ds_write_b128; 128 channels: 3) ...
     constexpr int NPIECE = C128 ? 3 : 6, NSTORE = C128 ? 4 : 8;
     auto red_write_piece = [&](auto PC, const f32x16& c0, const f32x16& c1) __attribute__((always_inline)) {
         constexpr int p = decltype(PC)::value;
@@ -356,7 +406,9 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     // the two taps behind it; the eight stores and sixteen loads of a unit likewise).  Vector-ALU work is not ordered by the pins: the scheduler spreads it over the gaps.
     auto tap = [&](auto TC, auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[2], auto&& slot) __attribute__((always_inline)) {
         constexpr int t = decltype(TC)::value, PAR = decltype(PARC)::value, cur = (t + PAR) & 1;
-        ldb(t < 8 ? t0b + shift_b[t < 8 ? t + 1 : 0] : t0b + 32 * PIXB, x[cur ^ 1], false);
+        constexpr int nt = t < 8 ? t + 1 : 0;          // the tap whose operands travel under this one (tap 0 of the next block behind tap 8)
+        if constexpr (nt % 3 == 0) rowb = row_base(t < 8 ? t0b + rowshift_b[nt / 3] : t0b + 32 * PIXB);
+        ldx(rowb, std::integral_constant<int, nt % 3>{}, x[cur ^ 1], false);
         if constexpr (t > 0) XFH_AGPR_ACC(c0, c1);      // (tap 0 starts from the literal zero: a pinned accumulator would have to be written first, 32 v_accvgpr_write per block)
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][2], x[cur].h, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][2], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
@@ -416,18 +468,23 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         auto seg_convert = [&](const float (&v)[NV], u32x4 (&h)[NQ], u32x4 (&l)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < NV / 2; ++j) {
+                const float a0 = v[2 * j], a1 = v[2 * j + 1];
                 unsigned hh, ll;
-                split2_f16(v[2 * j], v[2 * j + 1], hh, ll);
-                fx_track_h(amax, hh, true);
+                split2_f16_scalar(a0, a1, hh, ll);
+                fx_track(amaxf, a0, a1);
                 h[j >> 2][j & 3] = hh; l[j >> 2][j & 3] = ll;
             }
         };
+        // (the ring's first MIRROR_PX positions are kept twice: the lanes that hold them write the copy behind the ring's end, every other lane writes its own position again)
         auto seg_store = [&](int slot, const u32x4 (&h)[NQ], const u32x4 (&l)[NQ]) __attribute__((always_inline)) {
             unsigned char* p = ring + (slot * SEG_PX + lane) * PIXB;
+            unsigned char* pm = p + (((int)(slot == 0) & (int)(lane < MIRROR_PX)) ? Rb : 0u);
 #pragma unroll
             for (int i = 0; i < NQ; ++i) {
                 *reinterpret_cast<u32x4*>(p + 16 * i) = h[i];
                 *reinterpret_cast<u32x4*>(p + LO_OFF + 16 * i) = l[i];
+                *reinterpret_cast<u32x4*>(pm + 16 * i) = h[i];
+                *reinterpret_cast<u32x4*>(pm + LO_OFF + 16 * i) = l[i];
             }
         };
         __amdgpu_buffer_rsrc_t rs_out2 = rs_out;    // fused 1x1, channels-last: the image's (H W, 64) block
@@ -459,10 +516,20 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
                 }
         }
         XFH_WAVE_SYNC();
+        // the weights' home: 144 of the 216 registers in the accumulation half of the register file (next to the 64 accumulators).  Pinned HERE, behind the first run's ring
+        // fill: their 54 loads were issued at the kernel's entry and travel together with the segments' (a pin right behind the loads makes the prologue two memory
+        // latencies long instead of one; later runs find them pinned: an empty statement)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) XFH_AGPR(A[t][cb][q]);
         if constexpr (TRACE) { if (tr && n_units == 0) tr[2] = __builtin_amdgcn_s_memtime(); }
         if constexpr (!C128) seg_load(ua + a.nseg, ua + 1 < ub, v);
         int rslot = 0;                             // slot of segment u
-        ldb(0u, x[0]);
+        rowb = row_base(0u);
+        ldx(rowb, std::integral_constant<int, 0>{}, x[0]);
         // the segment's loads one by one (64 channels: two per slot of the second block, behind the conversion that empties their registers)
         int sv_off = (int)0x80000000;
         auto seg_voff = [&](int s, bool en) __attribute__((always_inline)) {
@@ -478,8 +545,11 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         auto seg_store_piece = [&](auto IC, int slot, const u32x4 (&h)[NQ], const u32x4 (&l)[NQ]) __attribute__((always_inline)) {
             constexpr int i = decltype(IC)::value;
             unsigned char* p = ring + (slot * SEG_PX + lane) * PIXB;
+            unsigned char* pm = p + (((int)(slot == 0) & (int)(lane < MIRROR_PX)) ? Rb : 0u);
             *reinterpret_cast<u32x4*>(p + 16 * i) = h[i];
             *reinterpret_cast<u32x4*>(p + LO_OFF + 16 * i) = l[i];
+            *reinterpret_cast<u32x4*>(pm + 16 * i) = h[i];
+            *reinterpret_cast<u32x4*>(pm + LO_OFF + 16 * i) = l[i];
         };
         for (int u = ua; u < ub; ++u) {
             const unsigned t0b = (unsigned)(rslot * SEG_BYTES);
@@ -493,6 +563,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             {
                 float4 part[3][2];
                 float y[8];
+                C1x1 w1;
                 auto slot = [&](auto IDC) __attribute__((always_inline)) {
                     constexpr int id = decltype(IDC)::value;
                     RS_STAMP_U(32 + id)
@@ -510,10 +581,10 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
                         else red_finish(cb0, cb1, part, pend_b, 1);
                     }
                     if constexpr (FUSE == 0 && id >= 17 && id < 17 + NSTORE) finish_store(std::integral_constant<int, id - 17>{}, y, pend_b);
+                    if constexpr (FUSE != 0 && id >= 16 && id < 26) conv1x1_piece(IDC, w1, 0, p2a_prev);      // the first block of the unit before: its 3x3 outputs were published by this block's barrier
                 };
                 taps9(I0{}, t0b, ca0, ca1, x, slot);
             }
-            if constexpr (FUSE != 0) conv1x1(0, p2a_prev);      // the first block of the unit before: its 3x3 outputs were published by this block's barrier
 #pragma unroll
             for (int i = 0; i < 16; ++i) { cb0[i] = 0.f; cb1[i] = 0.f; }
             RS_STAMP_U(7)
@@ -524,6 +595,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
             {
                 float4 part[3][2];
                 float y[8];
+                C1x1 w1;
                 auto slot = [&](auto IDC) __attribute__((always_inline)) {
                     constexpr int id = decltype(IDC)::value;
                     RS_STAMP_U(32 + 27 + id)
@@ -551,14 +623,13 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
                         else red_finish(ca0, ca1, part, pend_a, 0);
                     }
                     if constexpr (FUSE == 0 && id >= 17 && id < 17 + NSTORE) finish_store(std::integral_constant<int, id - 17>{}, y, pend_a);
+                    if constexpr (FUSE != 0 && id >= 16 && id < 26) conv1x1_piece(IDC, w1, 1, p2b_prev);
                     // the ring's new segment: every operand read of this unit that touches the old one has been issued (tap 8 reads the next block's tap 0)
-                    if constexpr (id == 24) { seg_store_piece(std::integral_constant<int, 0>{}, rslot, sh, sl); if constexpr (C128) seg_store_piece(std::integral_constant<int, 1>{}, rslot, sh, sl); }
-                    if constexpr (id == 25) seg_store_piece(std::integral_constant<int, C128 ? 2 : 1>{}, rslot, sh, sl);
-                    if constexpr (C128 && id == 26) seg_store_piece(std::integral_constant<int, C128 ? 3 : 0>{}, rslot, sh, sl);
+                    if constexpr (!C128 && (id == 24 || id == 25)) seg_store_piece(std::integral_constant<int, id - 24>{}, rslot, sh, sl);
+                    if constexpr (C128 && id >= 23) seg_store_piece(std::integral_constant<int, C128 ? id - 23 : 0>{}, rslot, sh, sl);
                 };
                 taps9(I1{}, t0b + 32 * PIXB, cb0, cb1, x, slot);
             }
-            if constexpr (FUSE != 0) conv1x1(1, p2b_prev);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ca0[i] = 0.f; ca1[i] = 0.f; }
             RS_STAMP_U(11)
@@ -582,6 +653,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         }
     }
     fx_report_h(amax, a.status);
+    fx_report(amaxf, a.status);
     RS_STAMP(13)
     if constexpr (TRACE) { if (tr) tr[14] = n_units; }
 #undef RS_STAMP

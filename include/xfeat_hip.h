@@ -156,7 +156,8 @@ int xfh_backbone_resized(xfh_handle h, const float* img, int B, int C, int Hin, 
  * NCHW with the layer's own stride/padding, folded BN and ReLU where the reference has them.
  * variant: 0 = the kernel the backbone uses for this layer, 1 = the generic direct kernel,
  * 10 = the split-bf16 kernel of the layer, 11 = the same kernel in the fp16-pair arithmetic, 12 = (64 -> 64 3x3/s1 layers, maps up to 125 columns) the fp16-pair kernel
- * with the weights resident in registers, other values >= 2 = explicit Winograd
+ * with the weights resident in registers, 13 .. 16 = this 3x3 layer AND the 1x1 layer behind it in one launch (layers block3.1, block_fusion.1: out = the 1x1's output;
+ * 13 / 14 = conv_rs64_kernel with NCHW / channels-last output, 15 / 16 = conv_bx64_kernel likewise), other values >= 2 = explicit Winograd
  * configurations of the 3x3/s1 layers (tuning; XFH_ERR_UNSUPPORTED elsewhere). */
 int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out,
                    int variant, xfh_stream stream);

@@ -60,6 +60,20 @@ int main(int argc, char** argv) {
     struct Case { const char* name; int layer, B, Hm, Wm; };
     const Case cases[] = {{"block4.1  B 64  30 x 40", 11, 64, 30, 40}, {"block4.2  B 64  30 x 40", 12, 64, 30, 40}, {"block_fusion.0  B 64  60 x 80", 17, 64, 60, 80},
                           {"block_fusion.0  B 3  41 x 93", 17, 3, 41, 93}, {"block4.1  B 1  30 x 40", 11, 1, 30, 40}, {"block5.1  B 64  15 x 20 (128 ch)", 14, 64, 15, 20}, {"block4.0  B 64  60 x 80 (stride 2: variants 1 / 10 / 11)", 10, 64, 60, 80}, {"block5.0  B 64  30 x 40 (stride 2)", 13, 64, 30, 40}};
+    if (argc > 3 && !strcmp(argv[3], "one")) {      // one layer, one variant, a few launches: the command rocprofv3 --pmc runs (argv: lib weights one <case> <variant> [launches])
+        const Case& c = cases[atoi(argv[4])];
+        const int v = atoi(argv[5]), nl = argc > 6 ? atoi(argv[6]) : 5;
+        const int nch = c.layer == 14 || c.layer == 15 ? 128 : 64;
+        const size_t n = (size_t)c.B * nch * c.Hm * c.Wm;
+        auto hx = rnd(n, (unsigned)c.layer + c.B, -1.f, 3.f);
+        float *x, *y;
+        HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, n * 4));
+        HIPCHK(hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice));
+        for (int i = 0; i < nl; ++i) if (xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, v, nullptr)) { printf("%s\n", xfh_last_error()); return 2; }
+        HIPCHK(hipDeviceSynchronize());
+        printf("%s variant %d: %d launches\n", c.name, v, nl);
+        return 0;
+    }
     for (const Case& c : cases) {
         const int nch = c.layer == 14 || c.layer == 15 ? 128 : 64;
         const bool s2 = c.layer == 10 || c.layer == 13;      // stride 2: output 64 | 128 channels at half the size
@@ -92,6 +106,27 @@ int main(int argc, char** argv) {
         }
         xfh_debug_cold_start(0);
         printf("%-32s variant %d, %d cold-started launches: %zu differ from the first\n", c.name, s2 ? 11 : 12, repeats, bad);
+        HIPCHK(hipFree(x)); HIPCHK(hipFree(y));
+    }
+    // ---- the 3x3 + 1x1 pairs as one launch: conv_rs64_kernel (13 NCHW / 14 channels-last) against conv_bx64_kernel (15 / 16); parity of 13 vs 15 and 14 vs 16
+    for (const Case& c : {Case{"block3.1 + .2  B 64  60 x 80", 8, 64, 60, 80}, Case{"block_fusion.1 + .2  B 64  60 x 80", 18, 64, 60, 80}, Case{"block_fusion.1 + .2  B 3  41 x 61", 18, 3, 41, 61}}) {
+        const size_t n = (size_t)c.B * 64 * c.Hm * c.Wm;
+        auto hx = rnd(n, (unsigned)c.layer + c.B, -1.f, 3.f);
+        float *x, *y;
+        HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, n * 4));
+        HIPCHK(hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice));
+        std::vector<float> ref[2], got(n);
+        for (int v : {15, 16, 13, 14}) {
+            HIPCHK(hipMemset(y, 0xff, n * 4));
+            if (xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, v, nullptr)) { printf("%s variant %d: %s\n", c.name, v, xfh_last_error()); continue; }
+            HIPCHK(hipMemcpy(got.data(), y, n * 4, hipMemcpyDeviceToHost));
+            const double us = timed(20, [&] { xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, v, nullptr); });
+            if (v >= 15) ref[v - 15] = got;
+            const std::vector<float>& r = ref[(v - 13) & 1];
+            double d = 0, m = 0;
+            if (r.size() == n) for (size_t i = 0; i < n; ++i) { const double e = std::fabs((double)got[i] - r[i]); if (!(e <= d)) d = e; m = std::fmax(m, std::fabs((double)r[i])); }
+            printf("%-36s variant %2d: %8.1f us per launch; vs variant %d: max |diff| %.3g (max |y| %.3g); status %d\n", c.name, v, us, 15 + ((v - 13) & 1), d, m, take_status());
+        }
         HIPCHK(hipFree(x)); HIPCHK(hipFree(y));
     }
     // ---- where a unit's cycles go: the stamped twin of the kernel (xfh_debug_trace; conv_rs64_body.hpp documents the 15 stamps per workgroup)
