@@ -5,8 +5,8 @@ The reference's benchmarks call `matcher_fn(img0, img1)` one pair at a time
 leaves the device almost idle; this runner takes the whole list of pairs, groups it by image size,
 pushes each group through `XFeat._detect_device` + `XFeat.match_pairs_device` in batches of up to
 `max_pairs`, and reads back one small tensor of counts per batch.  The results are what
-`XFeat.match_xfeat` returns pair by pair, in the original order (identical in tests/test_gpu_parity.py at its sizes; in general
-a large batch may run some convolutions on another -- equally fp32-accurate -- kernel than a single pair does, api.hip: big_map).
+`XFeat.match_xfeat` returns pair by pair, in the original order: an image's result does not depend on the batch it travels in
+(every kernel choice of the library is by image size, never by batch size: tests/test_gpu_census.py).
 """
 import numpy as np
 import torch
@@ -88,10 +88,14 @@ def _collect(out, chunk, kp0, kp1, idx0, idx1, nm):
 def _detect_exact(xfeat, x, top_k):
     """_detect_device with the capacity re-run of detectAndCompute (plateau images), results still on the device."""
     cap = None
+    B = x.shape[0]
     while True:
-        kpts, scores, desc, n_valid, n_cand, cap, hw = xfeat._detect_device(x, top_k, None, cap)
-        ncmax = int(n_cand.max())
-        if xfeat.net.fx_range_exceeded():            # fp16-pair arithmetic out of range (never on images): exact re-run on the bf16 split, like detectAndCompute
+        cnt = torch.zeros((3, B), dtype=torch.int32, device=xfeat.dev)      # n_valid, n_candidates, [2, 0] = the status word: one read-back for all of it
+        with xfeat.net.status_into(cnt[2]):
+            kpts, scores, desc, n_valid, n_cand, cap, hw = xfeat._detect_device(x, top_k, None, cap, counts_out=cnt[:2])
+        host = cnt.cpu()
+        ncmax = int(host[1].max())
+        if xfeat.net.fx_range_exceeded(status=int(host[2, 0])):      # fp16-pair arithmetic out of range (never on images): exact re-run on the bf16 split, like detectAndCompute
             continue
         if cap >= hw or ncmax <= cap:
             return kpts, desc, n_valid

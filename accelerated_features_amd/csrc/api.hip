@@ -569,23 +569,27 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     // 24-channel 3x3 layers (block2.0/.1 s1, block3.0 s2): bf16 MFMAs on three-way split operands (k_conv_bx.hip); bx = 0 keeps them on the f32-MFMA kernels
     const int use_bx = h->opt.bx;      // 1: 24-channel layers; 4: unfused 64 -> 64 layers on large maps (2: on every map); 8: not block3.0
     int rc = -1;
-    // "large map" = enough half-tile units for the persistent grid of conv_bx64_kernel (512 workgroups): >= 2 per workgroup in the bf16 arithmetic (B=8 164x164: 92 vs 124 us
-    // stand-alone against Winograd), >= 1.5 in the fp16-pair arithmetic, whose units are a third cheaper (VGA batch 64 at 1/16 scale, 768 units: 45 us against Winograd's 54)
-    const bool big_map = (long)B * ((Hin + 7) / 8) * ((Win + 15) / 16) >= ((h->opt.fx & 1) ? 768 : 1024);
+    // "large map" (only where conv_rs64_kernel is switched off: it takes these layers at any size): conv_bx64_kernel instead of Winograd for the unfused 64 -> 64 layers.
+    // Decided by the IMAGE's size alone (>= 12 half-tile units in the fp16-pair arithmetic = the 1/16-scale map of a VGA frame, 16 in the bf16 arithmetic), never by the
+    // batch: an image's features must not depend on which batch it travels in (round 4 decided by B x units -- a batch that filled the persistent grid -- and the same
+    // pair gave two fp32-accurate but different results alone and batched)
+    const bool big_map = (long)((Hin + 7) / 8) * ((Win + 15) / 16) >= ((h->opt.fx & 1) ? 12 : 16);
     // the split-format link (fx bit 64; conv_bx64_body.hpp): block_fusion.0 writes its output as fp16 pairs, block_fusion.1 (+ .2 fused) stages them by LDS-DMA alone.
     // Both layers see the same map, so both take the same decision; the buffer between them has the size of the fp32 tensor either way.
     const bool sp_link = in_backbone && (h->opt.fx & 65) == 65 && use_bx && ((use_bx & 2) || ((use_bx & 4) && big_map)) && h->nw.conv[L_FUSION_0].w_fx && h->nw.conv[L_FUSION_1].w_fx &&
                          h->nw.conv[L_FUSION_2].w_fx;
     if (sp_link && layer == L_FUSION_1 && c2 && nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, true, 1, h->status, 1, h->nw.zeros);
     if (sp_link && layer == L_FUSION_0 && !c2 && !nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status, 2, h->nw.zeros);
+    // conv_rs64_kernel (weights resident in registers, any map width: column strips) FIRST -- fx bit 128 (with bit 1): the unfused 64 -> 64 layers (block4.1, block4.2,
+    // block_fusion.0); bit 256: the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) -- in round 5's first builds these two stood BEHIND conv_bx64_kernel's fused form,
+    // which always took the pairs: bit 256 had no effect in the backbone; bit 512: block5.1, block5.2.  -1 (positions beyond the raster's exact range): the paths below
+    if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc && c.cin == 64) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace);
+    if (rc && use_bx && (h->opt.fx & 513) == 513 && c.w_rs && !c2 && !nhwc && c.cin == 128) rc = launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status);
+    if (rc && use_bx && (h->opt.fx & 257) == 257 && c.w_rs && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc, h->trace);
     if (rc && use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
         rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
     if (rc && (use_bx & 16) && (h->opt.fx & 1025) == 1025 && c.w_fx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status);      // fx bit 1024: block4.0, block5.0 in the fp16-pair arithmetic
     if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
-    // fx bit 128 (with bit 1): the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on conv_rs64_kernel -- weights resident in registers; -1 (map too wide for its rings): the paths below
-    if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc && c.cin == 64) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace);
-    if (rc && use_bx && (h->opt.fx & 513) == 513 && c.w_rs && !c2 && !nhwc && c.cin == 128) rc = launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status);      // bit 512: block5.1, block5.2
-    if (rc && use_bx && (h->opt.fx & 257) == 257 && c.w_rs && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc, h->trace);      // bit 256: block3.1 + 3.2, block_fusion.1 + .2
     if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
         if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, (h->opt.fx & 2) != 0, h->status);      // (bx = 9: block3.0 stays on the f32 kernel)
         else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // (bx = 5: large maps only)

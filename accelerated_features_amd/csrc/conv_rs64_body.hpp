@@ -61,7 +61,9 @@ struct Rs64Args {
     const float* bias;
     float* out;
     int relu, H, W, B;
-    int P;                     // W + 2
+    int ns, ws;                // column STRIPS per image and their width: a map wider than the rings reach (125 columns; 93 with the fused 1x1) runs as ns strips of ws columns,
+                               // each a padded raster of its own whose pad columns hold the neighbouring strips' pixels (zeros only beyond the map); ns = 1, ws = W otherwise
+    int P;                     // ws + 2
     float inv_p;               // 1 / P
     int nu;                    // 64-position units per image: ceil(H P / 64)
     int nseg;                  // ring capacity in segments
@@ -92,6 +94,13 @@ template <int CIN> constexpr int mirror_bytes() { return MIRROR_PX * pixb<CIN>()
 template <int CIN> constexpr int ring_stride(int nseg) { return nseg * seg_bytes<CIN>() + mirror_bytes<CIN>(); }
 constexpr int WQ_HALFS = 4 * 9 * 2 * 3 * 64 * 8;              // 110592 fp16 = 216 KiB
 inline int nseg_for(int P) { return 2 + (2 * P + 1) / 64; }
+// column strips of a map of width W for rings of at most max_seg segments: the fewest strips whose width fits (equal widths, the last one takes what is left)
+inline void strips_for(int W, int max_seg, int& ns, int& ws) {
+    for (ns = 1;; ++ns) {
+        ws = (W + ns - 1) / ns;
+        if (nseg_for(ws + 2) <= max_seg) return;
+    }
+}
 inline int lds_bytes(int nseg, bool fuse = false) { return (fuse ? ring_off<1>() : ring_off<0>()) + 4 * ring_stride<64>(nseg); }
 inline int max_nseg(bool fuse) { return fuse ? 4 : 5; }
 // CIN = COUT = 128 (block5.1, block5.2): a workgroup computes a QUARTER of the couts (32) and a wave multiplies 32 input channels (two 16-channel chunks, one accumulator each)
@@ -153,7 +162,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     unsigned amax = 0;
     float amaxf = 0.f;                             // range guard of the staged segments (on the fp32 values: one v_max3_f32 per pair)
     int kb = 0;                                    // blocks this workgroup has reduced: parity = reduction buffer
-    const int nruns = a.B * a.k;
+    const int nruns = a.B * a.ns * a.k;
 
     // position i of a padded raster = (row, column): i < 2^20, P >= 3: (i + 0.5) / P is at least 1 / (2 P) away from an integer, the product's error is below 1e-4
     auto row_of = [&](int i) { return (int)(((float)i + 0.5f) * inv_p); };
@@ -447,7 +456,9 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     constexpr int NV = C128 ? 32 : 16, NQ = NV / 8;      // values a lane stages per segment (its position's channels), 16-byte groups of their high / low parts
     const int cq = C128 ? (int)(blockIdx.x & 3) : 0;      // 128 channels: this workgroup's cout quarter (the grid is a multiple of four; the runs go to the groups of four)
     for (int run = C128 ? (int)(blockIdx.x >> 2) : (int)blockIdx.x; run < nruns; run += C128 ? (int)(gridDim.x >> 2) : (int)gridDim.x) {
-        const int b = run / a.k, part_i = run - b * a.k;
+        const int bs_i = run / a.k, part_i = run - bs_i * a.k;        // (image, strip), part of the strip's raster
+        const int b = bs_i / a.ns, x0 = (bs_i - b * a.ns) * a.ws;     // the strip's first column
+        const int wv = min(a.ws, W - x0);                             // its columns (the last strip of a map may be narrower)
         const int ua = (int)((long long)a.nu * part_i / a.k), ub = (int)((long long)a.nu * (part_i + 1) / a.k);
         if (ua >= ub) continue;
         const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + ((size_t)b * CIN + NV * wave) * HW), 0, (int)(NV * HW * sizeof(float)), 0x00020000);
@@ -456,7 +467,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         // segment s of the image's padded raster: position 64 s + lane = (row r, column c) of the (H + 2) x P frame = pixel (r - 1, c - 1); outside the map: zeros
         auto seg_load = [&](int s, bool en, float (&v)[NV]) __attribute__((always_inline)) {
             const int i = 64 * s + lane, r = row_of(i), c = i - r * P;
-            const int iy = r - 1, ix = c - 1;
+            const int iy = r - 1, ix = x0 + c - 1;
             // (one select, no short-circuit: a branch here would cut the unit's basic block and strand the conversion and the loads behind the last MFMA)
             const bool inside = (int)en & (int)((unsigned)iy < (unsigned)H) & (int)((unsigned)ix < (unsigned)W);
             const int voff = inside ? (iy * W + ix) * 4 : (int)0x80000000;
@@ -491,14 +502,14 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         if constexpr (FUSE == 2) rs_out2 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * 64 * HW), 0, (int)(64 * HW * sizeof(float)), 0x00020000);
         auto out2_voff = [&](int p) {              // fused 1x1: lane (position l & 15 of a 16-position half, couts 16 wave + 4 (l >> 4) + j)
             const int oy = row_of(p), ox = p - oy * P;
-            const bool inside = (int)(oy < H) & (int)(ox < W);
-            const int off = FUSE == 2 ? ((oy * W + ox) * 64 + 16 * wave + 4 * (lane >> 4)) * 4 : ((4 * (lane >> 4)) * HW + oy * W + ox) * 4;
+            const bool inside = (int)(oy < H) & (int)(ox < wv);
+            const int off = FUSE == 2 ? ((oy * W + x0 + ox) * 64 + 16 * wave + 4 * (lane >> 4)) * 4 : ((4 * (lane >> 4)) * HW + oy * W + x0 + ox) * 4;
             return inside ? off : (int)0x80000000;
         };
         auto out_voff = [&](int p) {               // output position p of the padded raster -> this lane's store offset (its first cout), or "dropped"
             const int oy = row_of(p), ox = p - oy * P;
-            const bool inside = (int)(oy < H) & (int)(ox < W);
-            return inside ? ((4 * kg) * HW + oy * W + ox) * 4 : (int)0x80000000;
+            const bool inside = (int)(oy < H) & (int)(ox < wv);
+            return inside ? ((4 * kg) * HW + oy * W + x0 + ox) * 4 : (int)0x80000000;
         };
         // prologue: the window of the run's first unit (segments ua .. ua + nseg - 1: the whole ring) with every pipe idle; the segment the first unit will write travels
         float v[NV];
@@ -534,7 +545,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         int sv_off = (int)0x80000000;
         auto seg_voff = [&](int s, bool en) __attribute__((always_inline)) {
             const int i = 64 * s + lane, r = row_of(i), c = i - r * P;
-            const int iy = r - 1, ix = c - 1;
+            const int iy = r - 1, ix = x0 + c - 1;
             const bool inside = (int)en & (int)((unsigned)iy < (unsigned)H) & (int)((unsigned)ix < (unsigned)W);
             sv_off = inside ? (iy * W + ix) * 4 : (int)0x80000000;
         };

@@ -63,7 +63,7 @@ struct Options {
                             // activation tile in LDS, two barriers per tile; + 33 us per 64-frame step); 0: the split-bf16 kernels (head_bx_kernel) -- 60 us faster than 2, but
                             // head_bx_kernel<true> delivers a wrong 16-cell block once in 10^3..10^5 launches when a workgroup's first tile runs on instruction-cache
                             // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
-    int fx = 11;            // (r5-flip: bits 1 | 2 | 8)   (bit 128, with 1: the unfused 64 -> 64 layers on conv_rs64_kernel -- weights resident in registers, conv_rs64_body.hpp; bit 256, with 1: the 3x3 + 1x1 pairs too; bit 512, with 1: block5.1 and block5.2 on its 128-channel form, block5.3 then runs as a 1x1 of its own; bit 1024, with 1: block4.0 / block5.0 (stride 2) in the fp16-pair arithmetic, conv_bx64s2x_kernel)  split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
+    int fx = 1931;          // (round 5: bits 1 | 2 | 8 | 128 | 256 | 512 | 1024: every 64 -> 64 and 128 -> 128 3x3 on conv_rs64_kernel, the stride-2 layers in the fp16-pair arithmetic)   (bit 128, with 1: the unfused 64 -> 64 layers on conv_rs64_kernel -- weights resident in registers, conv_rs64_body.hpp; bit 256, with 1: the 3x3 + 1x1 pairs too; bit 512, with 1: block5.1 and block5.2 on its 128-channel form, block5.3 then runs as a 1x1 of its own; bit 1024, with 1: block4.0 / block5.0 (stride 2) in the fp16-pair arithmetic, conv_bx64s2x_kernel)  split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
                             // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel), 4 = (with 1) conv_bx64_kernel with two weight fragments in its stream, 8 = the split heads (with heads_f32 = 0: head_bx_kernel<.., 1>), + 16 = with two weight fragments in LDS (<.., 2>), + 32 = (instead) the B fragments through LDS (<.., 3>), 64 = (with 1) the split-format link block_fusion.0 -> block_fusion.1 (conv_bx64_body.hpp: SP); 0 = the bf16 three-way split everywhere
     int block1 = 7;         // (r5-flip: block1.2 and block1.3 on the fp16 matrix cores; 0 / 5 = the vector-ALU kernel)   block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected); 6 = 5 with conv4 on the fp16 matrix cores (fp16-pair arithmetic, block1_fx.hpp), 7 = conv3 too
 };

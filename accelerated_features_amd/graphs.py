@@ -62,9 +62,9 @@ class CapturedSparsePipeline:
         self.kpts, self.scores, self.desc, self.n_valid, self.n_cand, self.cap = kp, sc, de, nv, nc, cap
         if self.match:
             self.idx0, self.idx1, self.n_match = self.xf.match_pairs_device(de, nv, self.min_cossim, d16)
-            self.counts = torch.cat([nv, nc, self.n_match])
+            self.counts = torch.cat([nv, nc, self.n_match, self.xf.net._status_target[:1]])
         else:
-            self.counts = torch.cat([nv, nc])
+            self.counts = torch.cat([nv, nc, self.xf.net._status_target[:1]])      # (last: the replica's status word of the fp16-pair arithmetic)
 
     @torch.inference_mode()
     def __call__(self, frames):
@@ -75,6 +75,12 @@ class CapturedSparsePipeline:
         self.x.copy_(frames, non_blocking=True)
         self.graph.replay()
         c = self.counts.cpu()                                   # the one read-back
+        if int(c[-1]):                                          # an activation left the range of the fp16-pair arithmetic (never seen on images): the captured kernels' results
+            self.xf.net._status_target[:1].zero_()              # are not valid.  The replica falls back to the bf16 split and is re-captured (the graph bakes the kernel choice
+            self.xf.net.fx_range_exceeded(status=1)             # in); this call is answered eagerly by the user's model, whose own check makes the same switch
+            self._capture()
+            return self._eager(frames)
+        c = c[:-1]
         B = self.B
         n_valid, n_cand = c[:B].tolist(), c[B:2 * B]
         if self.cap < self.hw and int(n_cand.max()) > self.cap:

@@ -127,8 +127,17 @@ class ReferenceTracker:
         idx0, idx1, n = self.xfeat.match_sets_device(de0, nv0, de1, nv1, self.min_cossim)
         r = find_homography_matches(kp0, kp1, idx0, idx1, n, self.ransac_thr, self.max_iters, self.confidence, self.seed)
         r.update(valid=(r['info'][:, 0] > 0) & (r['info'][:, 3] >= self.min_inliers), idx0=idx0, idx1=idx1, n_matches=n, keypoints=kp1,
-                 n_candidates=nc, nms_capacity=cap)
+                 n_candidates=nc, nms_capacity=cap, fx_status=self.xfeat.net._status_target)      # fx_status: see `range_exceeded`
         return r
+
+    def range_exceeded(self, fx_status):
+        """True if an activation left the range of the fp16-pair arithmetic since the last check (device int32 `fx_status` of track()'s result, non-zero; never seen on
+        images): the step's results are not valid -- the model has been switched to the bf16 split, call set_reference / track again.  Costs a read-back, like
+        `overflowed`: check it where the caller reads the step's results back anyway."""
+        v = int(fx_status[0].item())
+        if v:
+            fx_status[:1].zero_()
+        return self.xfeat.net.fx_range_exceeded(status=v)
 
     @staticmethod
     def overflowed(n_candidates, nms_capacity):

@@ -104,10 +104,13 @@ class FrameStream:
         cur = torch.cuda.current_stream()
         cur.wait_event(ln.event)
         kp, sc, de, i0, i1, cap, B, hw, x = ln.out
-        ncmax = int(ln.host[1].max())
-        redo = ln.xf.net.fx_range_exceeded(status=int(ln.host[3, 0]))      # fp16-pair arithmetic out of range (never on images): the lane's model is on the bf16 split now
-        if ncmax > cap or redo:                                     # a plateau image overflowed the NMS candidate list: exact re-run with room (as detectAndCompute)
-            cap = min(hw, max(ncmax, 2 * cap)) if ncmax > cap else cap
+        while True:                                                 # (as detectAndCompute: repeated until neither the range flag nor the candidate capacity asks for it)
+            ncmax = int(ln.host[1].max())
+            redo = ln.xf.net.fx_range_exceeded(status=int(ln.host[3, 0]))      # fp16-pair arithmetic out of range (never on images): the lane's model is on the bf16 split now
+            if not redo and (cap >= hw or ncmax <= cap):
+                break
+            if ncmax > cap:                                         # a plateau image overflowed the NMS candidate list: exact re-run with room
+                cap = min(hw, max(ncmax, 2 * cap))
             with torch.cuda.stream(ln.stream), torch.inference_mode():
                 ln.dev[3, :1].zero_()
                 kp, sc, de, nv, nc, cap, hw, d16 = ln.xf._detect_device(x, self.top_k, self.thr, cap=cap, want_f16=True, counts_out=ln.dev[:2])

@@ -19,7 +19,7 @@ from . import _lib
 from .spec import CONVS, FINE
 
 # the library's defaults of the options the range fallback below has to know (csrc/kernels.hpp: Options; tests/test_gpu_parity.py checks that the mirrors agree)
-DEFAULT_FX = 11
+DEFAULT_FX = 1931
 DEFAULT_HEADS_F32 = 0
 DEFAULT_BLOCK1 = 7
 
@@ -223,6 +223,22 @@ class XFeatModel(nn.Module):
         assert self._status_target.dtype == torch.int32 and self._status_target.is_cuda
         _lib.check(_lib.load().xfh_set_status_buffer(h, C.c_void_p(self._status_target.data_ptr())), "xfh_set_status_buffer")
 
+    def status_into(self, t):
+        """Context manager: while it is open the handle's kernels report into `t` (a zeroed int32 device slot of a buffer the caller reads back anyway), afterwards
+        into the model's own word again -- the status costs no read-back of its own.  Kernels take the pointer when they are enqueued, so closing the context
+        right behind the last launch is safe."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self.set_status_target(t)
+            try:
+                yield t
+            finally:
+                if self._handle is not None:
+                    self.set_status_target(None)
+        return cm()
+
     def take_status(self):
         """Read and clear the model's own status word (one 4-byte read-back; 0 without a handle)."""
         if self._handle is None or getattr(self, "_status_target", None) is None:
@@ -327,6 +343,9 @@ class XFeatModel(nn.Module):
         return ret
 
     def forward(self, x):
+        """feats, keypoint logits, reliability like the reference's XFeatModel.forward; everything stays on the device and nothing is read back: the status word of the
+        fp16-pair arithmetic (|activation| >= 65504: never seen on images) is the caller's to check -- `fx_range_exceeded()` after the call, then repeat (XFeat's
+        detectAndCompute / match_xfeat* do it inside their own read-backs)."""
         feats, logits, _, rel = self.backbone(x, want_logits=True, want_heat=False)
         return feats.permute(0, 3, 1, 2), logits.permute(0, 3, 1, 2), rel[:, None]
 
@@ -408,10 +427,14 @@ class XFeat(nn.Module):
                     'descriptors'  ->   torch.Tensor(N, 64): local features
         """
         cap = None
+        B = x.shape[0] if len(getattr(x, "shape", ())) == 4 else 1      # (a numpy (H,W[,C]) image is one frame; other shapes are refused by preprocess_tensor)
         while True:
-            kpts, scores, desc, n_valid, n_cand, cap, hw = self._detect_device(x, top_k, detection_threshold, cap)
-            cnt = _counts_pair(n_valid, n_cand).cpu()            # the one read-back per batch
-            if self.net.fx_range_exceeded():                     # (fp16-pair arithmetic out of range: never on images; exact re-run on the bf16 split)
+            self._require_gpu()
+            cnt_dev = torch.zeros((3, B), dtype=torch.int32, device=self.dev)      # n_valid, n_candidates, [2, 0] = the status word of the fp16-pair arithmetic
+            with self.net.status_into(cnt_dev[2]):
+                kpts, scores, desc, n_valid, n_cand, cap, hw = self._detect_device(x, top_k, detection_threshold, cap, counts_out=cnt_dev[:2])
+            cnt = cnt_dev.cpu()                                  # the ONE read-back per batch (counts and status together)
+            if self.net.fx_range_exceeded(status=int(cnt[2, 0])):      # (fp16-pair arithmetic out of range: never on images; exact re-run on the bf16 split)
                 continue
             ncmax = int(cnt[1].max())
             if cap >= hw or ncmax <= cap:
@@ -485,10 +508,12 @@ class XFeat(nn.Module):
                     'scales'       ->   torch.Tensor(B, top_k): extraction scale
                     'descriptors'  ->   torch.Tensor(B, top_k, 64): coarse local features
         """
-        while True:
-            out = self._dense_device(x, top_k, multiscale)
-            if not self.net.fx_range_exceeded():      # (one 4-byte read-back while the fp16-pair arithmetic is on; see detectAndCompute)
-                return out
+        out = self._dense_device(x, top_k, multiscale)
+        # no read-back here (the results stay on the device, as in the reference): 'fx_status' is the model's status word, a device int32 -- non-zero if an activation
+        # left the range of the fp16-pair arithmetic (never seen on images); a caller that reads anything back can read it along and, if set, call
+        # net.fx_range_exceeded() (which switches the model to the bf16 split) and repeat.  match_xfeat_star does exactly that.
+        out['fx_status'] = self.net._status_target
+        return out
 
     def _dense_device(self, x, top_k=None, multiscale=True):
         """detectAndComputeDense without the status read-back (match_xfeat_star checks once per call)."""
@@ -557,8 +582,11 @@ class XFeat(nn.Module):
 
             idx0, idx1, n_matches = self._batch_match_device(out1['descriptors'], out2['descriptors'], -1)
             out, n_out = self._refine_device(out1, out2, idx0, idx1, n_matches, 0.25)
-            counts = n_out.cpu().tolist()               # the one read-back
-            if not self.net.fx_range_exceeded():        # (see detectAndCompute)
+            counts = torch.cat([n_out.to(torch.int32), self.net._status_target[:1]]).cpu().tolist()      # the ONE read-back: the counts and the status word behind them
+            status = counts.pop()
+            if status:
+                self.net._status_target[:1].zero_()
+            if not self.net.fx_range_exceeded(status=status):        # (see detectAndCompute)
                 break
         matches = [out[b, :counts[b]] for b in range(len(counts))]
         B = len(im_set1)

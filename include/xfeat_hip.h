@@ -91,15 +91,26 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   "wino"          0..2    3x3/s1 layers: 0 never Winograd, 1 unfused layers only, 2 (default) also the 3x3 + 1x1 pairs
  *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
  *                           8 not block3.0, 16 the stride-2 64 -> 64 | 128 layers (block4.0, block5.0) (default 21)
- *   "heads_f32"     0..3    both heads on f32 MFMAs: 2 (default) the register-input kernels (head_f32r_kernel; 3 = their round-4 form with the dustbin logit on the matrix cores), 1 the round-1 kernels with an activation tile in LDS
- *                           (+ 33 us per 64-frame VGA step).  0: the split-bf16 head kernels -- another 60 us faster, and NOT safe: the key-point head was found to deliver
- *                           one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever the first tile of a workgroup runs on instruction-cache misses,
- *                           i.e. whenever other kernels (a second stream, another process) evict its code between launches (profiles/r04_head_hazard/);
- *                           both f32 kernels are clean under the same torture at every code position.  For A/B measurements only.
- *   "fx"            bitmask split-operand convolutions in the fp16-pair arithmetic (three MFMAs per product instead of the six of the bf16 three-way split):
- *                           1 = the 64 -> 64 layers on large maps (conv_bx64_kernel), 2 = the 24-channel layers, 4 = (with 1) the 64 -> 64 layers with two weight fragments in their stream, 8 = the split heads (with heads_f32 = 0), + 16 = with two weight fragments in LDS, + 32 = (instead) the pixel-side fragments through LDS; 64 = (with 1) block_fusion.0 hands block_fusion.1 its output as fp16 pairs, 128 = (with 1) the unfused 64 -> 64 layers (block4.1, block4.2, block_fusion.0) on the kernel with the weights resident in registers (conv_rs64_kernel; maps up to 125 columns), 256 = (with 1) the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) on it too (maps up to 93 columns), 512 = (with 1) block5.1 and block5.2 on its 128-channel form (block5.3 then runs as a 1x1 of its own; maps up to 61 columns), 1024 = (with 1) the stride-2 64-channel layers (block4.0, block5.0) in the fp16-pair arithmetic too (0..2047)
- *   "block1"        0..7    block1's first convolution: 0 / 5 = shipped (recomputed inside conv2, no c1 tile in LDS), 1 / 3 / 4 = earlier forms writing a c1 tile;
- *                           6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too (both set XFH_STATUS_FX_RANGE like "fx")
+ *   "heads_f32"     0..3    0 (default): the heads in the split-operand kernel head_bx_kernel -- with "fx" bit 8 (default) its fp16-pair form (clean under the cold-start torture
+ *                           at every code position where the bf16 form fails: DESIGN 9.0, profiles/r05_scan_*); WITHOUT that bit the round-3 split-bf16 form, which is NOT safe
+ *                           (one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever a workgroup's first tile runs on instruction-cache misses; A/B only).
+ *                           2: both heads on f32 MFMAs (head_f32r_kernel: the range fallback of the fp16-pair arithmetic; 3 = its round-4 form), 1: the round-1 f32 kernels.
+ *   "fx"            bitmask the fp16-pair arithmetic (x = xh + 2^-11 xl: three fp16 MFMAs per product instead of the six of the bf16 three-way split).
+ *                           DEFAULT 1931 = 1 | 2 | 8 | 128 | 256 | 512 | 1024.  0 = the bf16 three-way split everywhere (fp32's range: the fallback on XFH_STATUS_FX_RANGE).
+ *                             1     the 64 -> 64 layers (master bit of 4, 64, 128, 256, 512, 1024)
+ *                             2     the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel)
+ *                             4     (with 1) conv_bx64_kernel with two weight fragments in its stream            [opt-in: no gain measured]
+ *                             8     the heads (with heads_f32 = 0);  + 16: two weight fragments in LDS, + 32: pixel-side fragments through LDS   [16, 32: opt-in]
+ *                             64    (with 1) block_fusion.0 hands block_fusion.1 its output as fp16 pairs        [opt-in: no gain measured]
+ *                             128   the unfused 64 -> 64 3x3 layers (block4.1, block4.2, block_fusion.0) on conv_rs64_kernel (weights resident in registers)
+ *                             256   the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) on it too
+ *                             512   block5.1 and block5.2 on its 128-channel form (block5.3 then runs as a 1x1 of its own)
+ *                             1024  the stride-2 64-channel layers (block4.0, block5.0) on conv_bx64s2x_kernel
+ *                           conv_rs64_kernel takes maps of any width (beyond 125 / 93 / 61 columns -- unfused / with the 1x1 / 128 channels -- as column strips).   (0..2047)
+ *   "block1"        0..7    DEFAULT 7.  0 / 5 = block1 on the vector ALUs (conv1 recomputed inside conv2, no c1 tile in LDS; the range fallback), 1 / 3 / 4 = earlier forms
+ *                           writing a c1 tile; 6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too
+ *                           (6 and 7 set XFH_STATUS_FX_RANGE like "fx")
+ * Every kernel choice the options leave open is made by the IMAGE's size, never by the batch size: an image's results do not depend on the batch it travels in.
  * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.
  * ---------------------------------------------------------------------------------------- */
 int xfh_set_option(xfh_handle h, const char* key, int value);

@@ -23,10 +23,10 @@ int main() {
         int status = 0;
         xfh::Rs64Args a{};
         a.in = in.data(); a.wq = wq.data(); a.bias = bias.data(); a.out = out.data(); a.relu = relu; a.H = H; a.W = W; a.B = B; a.status = &status;
-        a.P = W + 2; a.inv_p = 1.f / (float)a.P; a.nu = (H * a.P + 63) / 64; a.nseg = xfh::rs64::nseg_for(a.P);
-        if (a.nseg > xfh::rs64::MAX_NSEG128) { fprintf(stderr, "map too wide\n"); return 3; }
-        a.k = hdr[5] > 0 ? hdr[5] : xfh::rs64::runs_per_image(B, a.nu, grid);
-        const int nruns = B * a.k, g = 4 * (nruns < grid ? nruns : grid);
+        xfh::rs64::strips_for(W, xfh::rs64::MAX_NSEG128, a.ns, a.ws);
+        a.P = a.ws + 2; a.inv_p = 1.f / (float)a.P; a.nu = (H * a.P + 63) / 64; a.nseg = xfh::rs64::nseg_for(a.P);
+        a.k = hdr[5] > 0 ? hdr[5] : xfh::rs64::runs_per_image(B * a.ns, a.nu, grid);
+        const int nruns = B * a.ns * a.k, g = 4 * (nruns < grid ? nruns : grid);
         emu::launch(g, 256, xfh::rs64::lds_bytes128(a.nseg), [&] { xfh::conv_rs64_body<0, 128>(a); });
         fwrite(out.data(), 4, out.size(), stdout);
         fwrite(&status, 4, 1, stdout);
@@ -41,11 +41,11 @@ int main() {
     int status = 0;
     xfh::Rs64Args a{};
     a.in = in.data(); a.wq = wq.data(); a.bias = bias.data(); a.out = out.data(); a.relu = relu; a.H = H; a.W = W; a.B = B; a.status = &status;
-    a.P = W + 2; a.inv_p = 1.f / (float)a.P; a.nu = (H * a.P + 63) / 64; a.nseg = xfh::rs64::nseg_for(a.P);
-    if (a.nseg > xfh::rs64::max_nseg(fuse != 0)) { fprintf(stderr, "map too wide\n"); return 3; }
+    xfh::rs64::strips_for(W, xfh::rs64::max_nseg(fuse != 0), a.ns, a.ws);
+    a.P = a.ws + 2; a.inv_p = 1.f / (float)a.P; a.nu = (H * a.P + 63) / 64; a.nseg = xfh::rs64::nseg_for(a.P);
     a.wq2 = wq2.data(); a.bias2 = fuse ? bias2.data() : nullptr; a.relu2 = hdr[7];
-    a.k = hdr[5] > 0 ? hdr[5] : xfh::rs64::runs_per_image(B, a.nu, grid);
-    const int nruns = B * a.k, g = nruns < grid ? nruns : grid;
+    a.k = hdr[5] > 0 ? hdr[5] : xfh::rs64::runs_per_image(B * a.ns, a.nu, grid);
+    const int nruns = B * a.ns * a.k, g = nruns < grid ? nruns : grid;
     if (fuse == 0) emu::launch(g, 256, xfh::rs64::lds_bytes(a.nseg), [&] { xfh::conv_rs64_body<0>(a); });
     else if (fuse == 1) emu::launch(g, 256, xfh::rs64::lds_bytes(a.nseg, true), [&] { xfh::conv_rs64_body<1>(a); });
     else emu::launch(g, 256, xfh::rs64::lds_bytes(a.nseg, true), [&] { xfh::conv_rs64_body<2>(a); });

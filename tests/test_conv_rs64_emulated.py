@@ -33,8 +33,10 @@ def run(emu_bin, x, w, b, relu, grid, k, fuse=0, w2=None, b2=None, relu2=0):
 
 
 # (30 x 40: the 1/16-scale VGA map, nseg 4, runs of 5 units; 15 x 80: the 1/8-scale pitch, nseg 5; 7 x 33: a map smaller than a ring; 9 x 93: nseg 4 at its widest;
-#  6 x 125: the widest map that fits (nseg 5);  k = 1: whole images per run, two runs for one workgroup; k = nu: one unit per run)
-@pytest.mark.parametrize("shape,relu,grid,k", [((1, 30, 40), 1, 4, 0), ((2, 15, 80), 0, 3, 2), ((3, 7, 33), 1, 2, 1), ((1, 9, 93), 1, 2, 0), ((1, 6, 125), 0, 2, 0), ((1, 12, 20), 1, 64, 0), ((1, 1, 1), 0, 1, 0)])
+#  6 x 125: the widest map ONE ring holds (nseg 5);  k = 1: whole images per run, two runs for one workgroup; k = nu: one unit per run;
+#  5 x 150, 4 x 260: wider maps run as two / three column strips, the last one narrower (260 = 87 + 87 + 86), pad columns = the neighbouring strips' pixels)
+@pytest.mark.parametrize("shape,relu,grid,k", [((1, 30, 40), 1, 4, 0), ((2, 15, 80), 0, 3, 2), ((3, 7, 33), 1, 2, 1), ((1, 9, 93), 1, 2, 0), ((1, 6, 125), 0, 2, 0), ((1, 12, 20), 1, 64, 0), ((1, 1, 1), 0, 1, 0),
+                                               ((2, 5, 150), 1, 3, 0), ((1, 4, 260), 0, 4, 2), ((1, 3, 126), 1, 2, 1)])
 def test_conv_rs64_body_on_the_host(emu_bin, shape, relu, grid, k):
     B, H, W = shape
     g = torch.Generator().manual_seed(H * W)
@@ -62,7 +64,8 @@ def test_conv_rs64_reports_its_range(emu_bin):
 
 # the trailing 1x1 (block3.2 behind block3.1: NCHW; block_fusion.2 behind block_fusion.1: channels-last) fused: a block's 3x3 outputs go through LDS as fp16 pairs, its 1x1 runs
 # inside the MFMAs of the block after next
-@pytest.mark.parametrize("fuse,shape,relu2,grid,k", [(1, (1, 30, 40), 0, 4, 0), (2, (2, 15, 80), 0, 3, 2), (2, (3, 7, 33), 1, 2, 1), (1, (1, 9, 93), 0, 2, 0), (2, (1, 1, 1), 0, 1, 0), (1, (1, 5, 7), 1, 8, 0)])
+@pytest.mark.parametrize("fuse,shape,relu2,grid,k", [(1, (1, 30, 40), 0, 4, 0), (2, (2, 15, 80), 0, 3, 2), (2, (3, 7, 33), 1, 2, 1), (1, (1, 9, 93), 0, 2, 0), (2, (1, 1, 1), 0, 1, 0), (1, (1, 5, 7), 1, 8, 0),
+                                                     (2, (1, 5, 128), 0, 3, 0), (1, (2, 3, 94), 1, 2, 1)])      # (128, 94 columns: two strips under the fused form's 93-column rings)
 def test_conv_rs64_with_the_trailing_1x1_fused(emu_bin, fuse, shape, relu2, grid, k):
     B, H, W = shape
     g = torch.Generator().manual_seed(H * W + fuse)
@@ -83,7 +86,7 @@ def test_conv_rs64_with_the_trailing_1x1_fused(emu_bin, fuse, shape, relu2, grid
 
 
 # the 128 -> 128 layers (block5.1, block5.2) on the same body: a workgroup computes a quarter of the couts, a wave multiplies 32 input channels (two chunks, one accumulator each)
-@pytest.mark.parametrize("shape,relu,groups,k", [((2, 15, 20), 1, 2, 0), ((1, 7, 33), 0, 1, 2), ((3, 4, 5), 1, 2, 1), ((1, 3, 61), 1, 1, 0)])
+@pytest.mark.parametrize("shape,relu,groups,k", [((2, 15, 20), 1, 2, 0), ((1, 7, 33), 0, 1, 2), ((3, 4, 5), 1, 2, 1), ((1, 3, 61), 1, 1, 0), ((1, 3, 100), 1, 2, 0)])      # (100 columns: two strips)
 def test_conv_rs64_body_with_128_channels(emu_bin, shape, relu, groups, k):
     B, H, W = shape
     g = torch.Generator().manual_seed(H * W + 128)

@@ -192,15 +192,8 @@ def test_star_1024_batch_pair_vs_oracle(xf, sd):
         assert torch.equal(r, r2_)
     m0, m1 = xf.match_xfeat_star(a[:1].cuda(), b[:1].cuda(), top_k=4096)     # B == 1: the numpy tuple, like the reference
     assert isinstance(m0, np.ndarray) and m0.shape == m1.shape and m0.shape[1] == 2
-    # the same pair alone and as item 0 of the batch: the library picks some convolution kernels by the size of the WHOLE batch (a batch that fills the persistent grid
-    # of the fp16-pair kernel runs the 64 -> 64 layers at 1/16 scale there, a single image on Winograd: api.hip big_map), i.e. the two runs are two fp32-accurate
-    # computations of the network, not one: rows agree to ~1e-4 pixels, and a refined row whose confidence sits at the 0.25 cut may appear in one of them only
-    one, bat = np.concatenate([m0, m1], 1), res[0].cpu().numpy()
-    key = lambda r: {tuple(np.round(v[[0, 1]] * 4).astype(np.int64)) + tuple(np.round(v[[2, 3]] * 4).astype(np.int64)): v for v in r}
-    ko, kb = key(one), key(bat)
-    common = set(ko) & set(kb)
-    assert len(common) >= 0.99 * max(len(ko), len(kb)) and abs(len(one) - len(bat)) <= 0.01 * len(bat), (len(one), len(bat), len(common))
-    assert max(float(np.abs(ko[k] - kb[k]).max()) for k in common) <= 5e-3
+    # the same pair alone and as item 0 of the batch: kernel choice is by image size, never by batch size (round 4 chose by B x units and this test had to be loosened)
+    assert np.allclose(np.concatenate([m0, m1], 1), res[0].cpu().numpy())
 
 
 # ----------------------------------------------------------------------------------------------
