@@ -20,7 +20,7 @@
 //   first block:   taps 0-2 | partial sums of the block BEFORE -> LDS | taps 3-4 | LDS-only barrier, read three partials | taps 5-8 + sum, bias, ReLU, stores of the block before
 //   second block:  taps 0-2 + conversion of the next unit's new segment | partial sums of the first block -> LDS | taps 3-4 | barrier, read | taps 5-8 + finish of the first block
 //                  + loads of the segment after next | the converted segment -> ring (over the segment this unit started with)
-// A tap's B operands are read one tap ahead (tap 8 reads the next block's tap 0), straight into accumulation registers (XFH_AGPR): registers no vector-ALU result is allocated
+// A tap's B operands are read TWO taps ahead (taps 7 / 8 read the next block's taps 0 / 1), straight into accumulation registers (XFH_AGPR): registers no vector-ALU result is allocated
 // to, so no idle slots guard the matrix core's operand reads.  The four waves run four COPIES of this code (template parameter wave): which accumulator registers go to whom is static.
 // Forms: FUSE 1 / 2 = the trailing 1x1 (block3.2 NCHW, block_fusion.2 channels-last) on v_mfma_f32_16x16x32_f16, a block's 3x3 outputs handed over as fp16 pairs through LDS
 // (Y buffers), its 1x1 two blocks later; CIN 128 = block5.1 / block5.2: a workgroup per cout QUARTER, a wave multiplies 32 channels (two chunks, an accumulator each);
@@ -413,11 +413,15 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     // slot issues (LDS writes of the partial sums, global stores and loads, the ring's segment) stays between its two pairs: one wave per SIMD means nobody else fills the matrix
     // pipe while this wave transfers a burst of them (a ds_write_b128 is 13 cycles of the store path, a burst of six from each of the four waves 300: measured as + 270 cycles on
     // the two taps behind it; the eight stores and sixteen loads of a unit likewise).  Vector-ALU work is not ordered by the pins: the scheduler spreads it over the gaps.
-    auto tap = [&](auto TC, auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[2], auto&& slot) __attribute__((always_inline)) {
-        constexpr int t = decltype(TC)::value, PAR = decltype(PARC)::value, cur = (t + PAR) & 1;
-        constexpr int nt = t < 8 ? t + 1 : 0;          // the tap whose operands travel under this one (tap 0 of the next block behind tap 8)
-        if constexpr (nt % 3 == 0) rowb = row_base(t < 8 ? t0b + rowshift_b[nt / 3] : t0b + 32 * PIXB);
-        ldx(rowb, std::integral_constant<int, nt % 3>{}, x[cur ^ 1], false);
+    auto tap = [&](auto TC, auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[3], auto&& slot) __attribute__((always_inline)) {
+        // operands travel TWO taps ahead (three register sets; a block has nine taps, so every block starts on set 0): the read issued here is awaited at the end of the NEXT
+        // tap, 384 matrix-pipe cycles on -- one tap ahead (192) the wait was still exposed whenever the read queued behind a burst of the partial sums' ds_write_b128
+        // (PMC: the waves spent ~ 7 % of a unit parked at these waits)
+        constexpr int t = decltype(TC)::value, cur = t % 3, nxt = (t + 1) % 3, far = (t + 2) % 3;
+        (void)PARC;
+        constexpr int ft = t + 2;                      // the tap whose operands leave LDS now: of this block (< 9), or tap ft - 9 (0 or 1) of the next one, 32 positions on
+        if constexpr (ft % 3 == 0) rowb = row_base(ft < 9 ? t0b + rowshift_b[ft < 9 ? ft / 3 : 0] : t0b + 32 * PIXB);
+        ldx(rowb, std::integral_constant<int, ft % 3>{}, x[far], false);
         if constexpr (t > 0) XFH_AGPR_ACC(c0, c1);      // (tap 0 starts from the literal zero: a pinned accumulator would have to be written first, 32 v_accvgpr_write per block)
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][2], x[cur].h, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][2], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
@@ -429,11 +433,11 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         slot(std::integral_constant<int, 3 * t + 1>{});
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][0][0], x[cur].h, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[t][1][0], C128 ? x[cur].h1 : x[cur].h, c1, 0, 0, 0);
-        if constexpr (C128) { XFH_AGPR_TAP2(x[cur ^ 1].h, x[cur ^ 1].l, x[cur ^ 1].h1, x[cur ^ 1].l1, c0, c1); }
-        else { XFH_AGPR_TAP(x[cur ^ 1].h, x[cur ^ 1].l, c0, c1); }
+        if constexpr (C128) { XFH_AGPR_TAP2(x[nxt].h, x[nxt].l, x[nxt].h1, x[nxt].l1, c0, c1); }
+        else { XFH_AGPR_TAP(x[nxt].h, x[nxt].l, c0, c1); }
         slot(std::integral_constant<int, 3 * t + 2>{});
     };
-    auto taps9 = [&](auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[2], auto&& slot) __attribute__((always_inline)) {
+    auto taps9 = [&](auto PARC, unsigned t0b, f32x16& c0, f32x16& c1, Xf (&x)[3], auto&& slot) __attribute__((always_inline)) {
         tap(std::integral_constant<int, 0>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 1>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 2>{}, PARC, t0b, c0, c1, x, slot);
         tap(std::integral_constant<int, 3>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 4>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 5>{}, PARC, t0b, c0, c1, x, slot);
         tap(std::integral_constant<int, 6>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 7>{}, PARC, t0b, c0, c1, x, slot); tap(std::integral_constant<int, 8>{}, PARC, t0b, c0, c1, x, slot);
@@ -451,7 +455,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
     Pend2 p2a, p2b, p2a_prev, p2b_prev;             // fused 1x1: where the unit's first / second block goes, and the same of the unit before (a block's 1x1 runs a unit later)
     p2a.rs = pend_b.rs; p2a.voff[0] = p2a.voff[1] = (int)0x80000000;
     p2b = p2a; p2a_prev = p2a; p2b_prev = p2a;
-    Xf x[2];
+    Xf x[3];
 
     constexpr int NV = C128 ? 32 : 16, NQ = NV / 8;      // values a lane stages per segment (its position's channels), 16-byte groups of their high / low parts
     const int cq = C128 ? (int)(blockIdx.x & 3) : 0;      // 128 channels: this workgroup's cout quarter (the grid is a multiple of four; the runs go to the groups of four)
@@ -541,6 +545,7 @@ __device__ __forceinline__ void conv_rs64_wave(const Rs64Args& a) {
         int rslot = 0;                             // slot of segment u
         rowb = row_base(0u);
         ldx(rowb, std::integral_constant<int, 0>{}, x[0]);
+        ldx(rowb, std::integral_constant<int, 1>{}, x[1], false);      // (tap 1's operands: pinned at the end of tap 0)
         // the segment's loads one by one (64 channels: two per slot of the second block, behind the conversion that empties their registers)
         int sv_off = (int)0x80000000;
         auto seg_voff = [&](int s, bool en) __attribute__((always_inline)) {

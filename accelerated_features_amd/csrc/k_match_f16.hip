@@ -117,6 +117,16 @@ __global__ __launch_bounds__(256) void mnn_prep_kernel(const float* __restrict__
     }
 }
 
+// Block maxima and thresholds travel as fp16 (round 5: they were fp32): the sweep writes, and the refine's scan reads, half the bytes -- 67 instead of 134 MB per
+// 64-frame step.  The comparison stays CONSERVATIVE: a block maximum is rounded UP, a threshold DOWN, so every block with R >= thr in fp32 still has R16 >= thr16 (the
+// flagged set only grows -- by the blocks within ~2^-9 |value| of the threshold: the refine evaluates a few more blocks exactly, decisions are taken on fp32 dot products
+// as before).  Scaled products reach 2^16 (unit rows at scale 256 on both sides), fp16 ends at 65504: the stored value is S^' / 4 (exact).
+//   up(x):   y = x + 2^-10 |x| + 2^-24, then round-to-nearest-even to fp16.  RNE moves a normal y by at most half an ulp <= 2^-11 |y|, a subnormal one by at most 2^-25:
+//            fp16(y) >= y - max(2^-11 |y|, 2^-25) >= x.        down(x) = -up(-x).
+constexpr float F16_STORE_SCALE = 0.25f;
+__device__ inline _Float16 f16_up(float x) { return (_Float16)(__builtin_fmaf(__builtin_fabsf(x), 0.0009765625f, x) + 5.9604644775390625e-8f); }
+__device__ inline _Float16 f16_down(float x) { return (_Float16)(__builtin_fmaf(__builtin_fabsf(x), -0.0009765625f, x) - 5.9604644775390625e-8f); }
+
 // maximum of 16 accumulator values as a v_max3_f32 tree (8 ops)
 __device__ inline float max16(const f32x16& v) {
     const float a = fmaxf(fmaxf(v[0], v[1]), v[2]);
@@ -164,13 +174,13 @@ __device__ inline PairWindow pair_window(float unit_bound, const unsigned* __res
 //     then the fragments of the next tile leave LDS                       ||  row epilogue of accT
 //   colmaxh (P,N2) u32  : ord(column maximum), 32-bit atomic max across the row shares (zeroed by the caller)
 //   rowmaxh (P,N1) u32  : ord(row maximum), 32-bit atomic max across the column-chunk workgroups (zeroed by the caller)
-//   R (P, ceil(N2/32), N1), C (P, ceil(N1/32), N2) : block maxima
+//   R (P, ceil(N2/32), N1), C (P, ceil(N1/32), N2) : block maxima, fp16, a quarter of the scaled product rounded UP (f16_up)
 constexpr int FT_TILES = FT_COLS / 32;
 __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __restrict__ a16, size_t sa16, const _Float16* __restrict__ b16, size_t sb16,
                                                             const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
                                                             int N1, int N2, int ncc, int nsplit, int P,
                                                             unsigned* __restrict__ colmaxh, unsigned* __restrict__ rowmaxh,
-                                                            float* __restrict__ R, float* __restrict__ C
+                                                            _Float16* __restrict__ R, _Float16* __restrict__ C
 #if XFH_CODE_SHIFT > 0      // torture builds only (build.py --shift N): the production kernel is, byte for byte, the one the round-4 proof soaks ran
                                                             , int cold
 #endif
@@ -239,10 +249,10 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
         const int myrow = blk * 32 + l31;
         // branch-free stores (a branch would end the basic block and with it the MFMA / VALU interleave below): buffer stores, lanes that
         // must not store carry an out-of-range offset and the hardware drops them; the C row's range check also drops columns >= n2
-        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)p * nrb32 + blk) * N2 + c0, 0, (min(n2, c0 + FT_COLS) - c0) * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(R + ((size_t)p * ncb32 + (c0 >> 5)) * N1, 0, FT_TILES * N1 * 4, 0x00020000);
-        const int offC = half == 0 ? l31 * 4 : (int)0x80000000;
-        const int offR = (half == 1 && myrow < n1) ? myrow * 4 : (int)0x80000000;
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(C + ((size_t)p * nrb32 + blk) * N2 + c0, 0, (min(n2, c0 + FT_COLS) - c0) * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(R + ((size_t)p * ncb32 + (c0 >> 5)) * N1, 0, FT_TILES * N1 * 2, 0x00020000);
+        const int offC = half == 0 ? l31 * 2 : (int)0x80000000;
+        const int offR = (half == 1 && myrow < n1) ? myrow * 2 : (int)0x80000000;
         float rowrun = -INFINITY;
         f16x8 bfrag[2][4];
 #pragma unroll
@@ -257,7 +267,7 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
             float rm = max16(accT);                                                                       \
             rm = fmaxf(rm, xhalf(rm));                                                                    \
             rowrun = fmaxf(rowrun, rm);                                                                   \
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rm), rR, offR, (CT) * N1 * 4, 0);       \
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, f16_up(rm * F16_STORE_SCALE)), rR, offR, (CT) * N1 * 2, 0);       \
         }
 #define XFH_INTERLEAVE_4x5()                                                                              \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);   \
@@ -288,7 +298,7 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
                     float cm = max16(acc);
                     cm = fmaxf(cm, xhalf(cm));
                     __hip_atomic_fetch_max(mycolx + ct * 32, cm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (both half-waves hold cm)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(cm), rC, offC + ct * 128, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, f16_up(cm * F16_STORE_SCALE)), rC, offC + ct * 64, 0, 0);
                 }
                 XFH_INTERLEAVE_4x5()
                 __builtin_amdgcn_sched_barrier(0);
@@ -311,17 +321,17 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
     }
 }
 
-// thresholds, once the maxima are complete: thr = max^ - 2 E (scaled units).  grid (ceil(max(N1,N2)/256), P, 2 sides)
+// thresholds, once the maxima are complete: thr = max^ - 2 E (scaled units), stored like the block maxima (a quarter, fp16) but rounded DOWN.  grid (ceil(max(N1,N2)/256), P, 2 sides)
 __global__ __launch_bounds__(256) void mnn_f16_thr_kernel(float unit_bound, const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
                                                           int N1, int N2, int P, const float* __restrict__ na, const float* __restrict__ nb,
                                                           const unsigned* __restrict__ nmax, const unsigned* __restrict__ rowmaxh, const unsigned* __restrict__ colmaxh,
-                                                          float* __restrict__ thr_row, float* __restrict__ thr_col) {
+                                                          _Float16* __restrict__ thr_row, _Float16* __restrict__ thr_col) {
     const int p = blockIdx.y, side = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
     const int N = side ? N2 : N1;
     if (i >= (side ? fpair_count(n2p, p * n_stride + n_off2, N2) : fpair_count(n1p, p * n_stride, N1))) return;
     const PairWindow w = pair_window(unit_bound, nmax, P, p, side == 0);
     const float nx = unit_bound > 0.f ? unit_bound : (side ? nb : na)[(size_t)p * N + i];
-    (side ? thr_col : thr_row)[(size_t)p * N + i] = ord_float((side ? colmaxh : rowmaxh)[(size_t)p * N + i]) - fmaf(w.two_c, nx, w.two_k);
+    (side ? thr_col : thr_row)[(size_t)p * N + i] = f16_down((ord_float((side ? colmaxh : rowmaxh)[(size_t)p * N + i]) - fmaf(w.two_c, nx, w.two_k)) * F16_STORE_SCALE);
 }
 
 constexpr int RF_ROUND = 512;      // x per scan round
@@ -332,8 +342,8 @@ constexpr int RF_WAVES = 2;        // waves (= Y blocks) per workgroup
 __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void mnn_f16_refine_kernel(
     const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2, size_t ps2, const int32_t* __restrict__ n1p,
     const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1, int N2, int nyb_max, int P,
-    const float* __restrict__ thr_row, const float* __restrict__ thr_col, const float* __restrict__ R,
-    const float* __restrict__ C, unsigned long long* __restrict__ rowkey, unsigned long long* __restrict__ colkey) {
+    const _Float16* __restrict__ thr_row, const _Float16* __restrict__ thr_col, const _Float16* __restrict__ R,
+    const _Float16* __restrict__ C, unsigned long long* __restrict__ rowkey, unsigned long long* __restrict__ colkey) {
     __shared__ unsigned short queue[RF_WAVES][RF_QUEUE];                       // per wave: flagged x (offsets into the current chunk)
     __shared__ __attribute__((aligned(16))) float tile[RF_WAVES][32 * RF_XS];   // per wave: 32 rows x 64 channels on their way into MFMA operand order
     const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
@@ -348,16 +358,16 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4
     if (yb * 32 >= nY) return;                              // (whole waves leave: nothing below synchronises across waves)
     const float* X = side ? d2 + (size_t)p * ps2 : d1 + (size_t)p * ps1;
     const float* Y = side ? d1 + (size_t)p * ps1 : d2 + (size_t)p * ps2;
-    const float* M = (side ? C + (size_t)p * ceil_div(N1, 32) * N2 : R + (size_t)p * ceil_div(N2, 32) * N1) + (size_t)yb * NX;
-    const float* T = side ? thr_col + (size_t)p * N2 : thr_row + (size_t)p * N1;
+    const _Float16* M = (side ? C + (size_t)p * ceil_div(N1, 32) * N2 : R + (size_t)p * ceil_div(N2, 32) * N1) + (size_t)yb * NX;
+    const _Float16* T = side ? thr_col + (size_t)p * N2 : thr_row + (size_t)p * N1;
     unsigned long long* key = side ? colkey + (size_t)p * N2 : rowkey + (size_t)p * N1;
-    const bool vec_ok = (NX & 3) == 0;                      // 16-byte loads need 16-byte aligned rows of M / thresholds
+    const bool vec_ok = (NX & 7) == 0;                      // 16-byte loads (eight fp16 values) need 16-byte aligned rows of M / thresholds
     unsigned short* q = queue[wv];
     float* xt = tile[wv];
     // buffer resources (uniform bases in SGPRs, 32-bit lane offsets; reads past the end return 0): one address register per lane instead of
     // a 64-bit pointer per array
-    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(M), 0, nX * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(T), 0, nX * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(M), 0, nX * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(T), 0, nX * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, nX * 256, 0x00020000);
     const __amdgpu_buffer_rsrc_t rY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Y), 0, nY * 256, 0x00020000);
 
@@ -419,48 +429,47 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4
         // ---- phase 1: scan.  Eight block maxima per lane and round (two 16-byte loads of each array); the next round is in flight while
         //      this one is tested: one compare per element, the queue bookkeeping only for the (rare) hits.
         const int nround = ceil_div(min(RF_CHUNK, nX - xc), RF_ROUND);
-        float4 ma0, ma1, ta0, ta1, mb0, mb1, tb0, tb1;         // two rounds in flight: set a (even rounds), set b (odd rounds)
-        auto issue = [&](int r, float4& m0, float4& m1, float4& t0, float4& t1) {
+        f16x8 ma, ta, mb, tb;                                  // two rounds in flight: set a (even rounds), set b (odd rounds); ONE 16-byte load per array, lane and round
+        auto issue = [&](int r, f16x8& m, f16x8& t) {
             const int xb = xc + r * RF_ROUND + lane * 8;
             if (vec_ok) {
-                m0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rM, xb * 4, 0, 0));
-                m1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rM, xb * 4 + 16, 0, 0));
-                t0 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rT, xb * 4, 0, 0));
-                t1 = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rT, xb * 4 + 16, 0, 0));
+                m = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rM, xb * 2, 0, 0));
+                t = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rT, xb * 2, 0, 0));
             } else {
-                float mm[8], tt[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    mm[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rM, (xb + j) * 4, 0, 0));
-                    tt[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rT, (xb + j) * 4, 0, 0));
+                    m[j] = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rM, (xb + j) * 2, 0, 0));
+                    t[j] = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rT, (xb + j) * 2, 0, 0));
                 }
-                m0 = make_float4(mm[0], mm[1], mm[2], mm[3]); m1 = make_float4(mm[4], mm[5], mm[6], mm[7]);
-                t0 = make_float4(tt[0], tt[1], tt[2], tt[3]); t1 = make_float4(tt[4], tt[5], tt[6], tt[7]);
             }
         };
-        auto test = [&](int r, const float4& m0, const float4& m1, const float4& t0, const float4& t1) {
+        auto test = [&](int r, const f16x8& m, const f16x8& t) {
             if (cnt > RF_QUEUE - RF_ROUND) drain();          // (uniform; identical descriptor sets get here)
             const int xl = r * RF_ROUND + lane * 8;
             const int left = nX - (xc + xl);                 // elements of this lane that exist (entries past nX read 0 >= 0: mask them)
-            const float mv[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-            const float tv[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            // flagged: m >= t, i.e. the SIGN of m - t (four v_pk_add_f16 for the eight values; a difference of fp16 numbers never rounds across zero, and a flushed
+            // tiny one keeps its sign: -0 = below the threshold)
+            const f16x8 d = m - t;
+            const uint4 db = __builtin_bit_cast(uint4, d);
+            const unsigned dw[4] = {db.x, db.y, db.z, db.w};
             // ordered compaction into the wave's queue: ballot per j, prefix by popcount
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const unsigned long long bal = __ballot(mv[j] >= tv[j] && j < left);
+                const bool neg = (dw[j >> 1] >> (15 + 16 * (j & 1))) & 1u;
+                const unsigned long long bal = __ballot(!neg && j < left);
                 if (bal) {                                   // (uniform)
                     if ((bal >> lane) & 1ull) q[cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(xl + j);
                     cnt += __popcll(bal);
                 }
             }
         };
-        issue(0, ma0, ma1, ta0, ta1);
+        issue(0, ma, ta);
         for (int r = 0; r < nround; r += 2) {
-            if (r + 1 < nround) issue(r + 1, mb0, mb1, tb0, tb1);
-            test(r, ma0, ma1, ta0, ta1);
+            if (r + 1 < nround) issue(r + 1, mb, tb);
+            test(r, ma, ta);
             if (r + 1 < nround) {
-                if (r + 2 < nround) issue(r + 2, ma0, ma1, ta0, ta1);
-                test(r + 1, mb0, mb1, tb0, tb1);
+                if (r + 2 < nround) issue(r + 2, ma, ta);
+                test(r + 1, mb, tb);
             }
         }
         drain();
@@ -488,7 +497,7 @@ void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const floa
     // two workgroups per CU fill the chip; with few pairs the row blocks of a column chunk are shared out over more workgroups (>= 8 blocks each)
     const int nsplit = max(1, min(ceil_div(2 * num_cus(), ncc * P), ceil_div(N1, 256)));
     mnn_f16_sweep_kernel<<<xcd_grid_size(ncc * nsplit, P), 512, 0, st>>>(a16, sa, b16, sb, n1, n2, n_stride, n_off2, N1, N2, ncc, nsplit, P,
-                                                                        ws.colmaxh, ws.rowmaxh, ws.R, ws.C
+                                                                        ws.colmaxh, ws.rowmaxh, reinterpret_cast<_Float16*>(ws.R), reinterpret_cast<_Float16*>(ws.C)
 #if XFH_CODE_SHIFT > 0
                                                                         , g_debug_cold
 #endif
@@ -497,9 +506,10 @@ void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const floa
     const int nyb = ceil_div(ceil_div(N1 > N2 ? N1 : N2, 32), RF_WAVES) * RF_WAVES;
     prof_begin(prof, XFH_SPAN_MATCH_REFINE, st);
     mnn_f16_thr_kernel<<<dim3(ceil_div(N1 > N2 ? N1 : N2, 256), P, 2), 256, 0, st>>>(ub, n1, n2, n_stride, n_off2, N1, N2, P, ws.na, ws.nb, ws.nmax, ws.rowmaxh, ws.colmaxh,
-                                                                                        ws.thr_row, ws.thr_col);
+                                                                                        reinterpret_cast<_Float16*>(ws.thr_row), reinterpret_cast<_Float16*>(ws.thr_col));
     mnn_f16_refine_kernel<<<xcd_grid_size(2 * (nyb / RF_WAVES), P), 64 * RF_WAVES, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nyb, P,
-                                                                          ws.thr_row, ws.thr_col, ws.R, ws.C, ws.rowkey, ws.colkey);
+                                                                          reinterpret_cast<const _Float16*>(ws.thr_row), reinterpret_cast<const _Float16*>(ws.thr_col), reinterpret_cast<const _Float16*>(ws.R),
+                                                                          reinterpret_cast<const _Float16*>(ws.C), ws.rowkey, ws.colkey);
     prof_end(prof, XFH_SPAN_MATCH_REFINE, st, 0, 0);
 }
 

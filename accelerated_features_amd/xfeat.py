@@ -432,7 +432,7 @@ class XFeat(nn.Module):
             self._require_gpu()
             cnt_dev = torch.zeros((3, B), dtype=torch.int32, device=self.dev)      # n_valid, n_candidates, [2, 0] = the status word of the fp16-pair arithmetic
             with self.net.status_into(cnt_dev[2]):
-                kpts, scores, desc, n_valid, n_cand, cap, hw = self._detect_device(x, top_k, detection_threshold, cap, counts_out=cnt_dev[:2])
+                kpts, scores, desc, n_valid, n_cand, cap, hw, d16 = self._detect_device(x, top_k, detection_threshold, cap, want_f16=True, counts_out=cnt_dev[:2])
             cnt = cnt_dev.cpu()                                  # the ONE read-back per batch (counts and status together)
             if self.net.fx_range_exceeded(status=int(cnt[2, 0])):      # (fp16-pair arithmetic out of range: never on images; exact re-run on the bf16 split)
                 continue
@@ -441,6 +441,7 @@ class XFeat(nn.Module):
                 break
             cap = min(hw, max(ncmax, 2 * cap))                   # plateau image: exact re-run with room
         nv = cnt[0].tolist()
+        self._last_desc16 = (desc, d16)                          # the fp16 copies the descriptor kernel wrote along: match_many's filter reads them (saves its conversion passes)
         return [{'keypoints': kpts[b, :nv[b]], 'scores': scores[b, :nv[b]], 'descriptors': desc[b, :nv[b]]}
                 for b in range(len(nv))]
 
@@ -808,6 +809,79 @@ class XFeat(nn.Module):
         idx0, idx1, n = self._batch_match_device(feats1[None], feats2[None], min_cossim)
         k = int(n.item())
         return idx0[0, :k], idx1[0, :k]
+
+    @torch.inference_mode()
+    def match_many(self, feats1, feats2, min_cossim=0.82):
+        """The list form of `match` (modules/xfeat.py:327-348 applied to P pairs): pair p = (feats1[p], feats2[p]), each an (N_p, 64) descriptor tensor.
+        Returns a list of P tuples (idx0, idx1) -- exactly what `match(feats1[p], feats2[p], min_cossim)` returns for every p -- from ONE launch sequence and ONE
+        read-back (the P match counts) instead of P of each: on a 64-frame batch `[xf.match(a, b) for a, b in pairs]` spends its time in 32 host round trips.
+            res = xf.detectAndCompute(frames)                                   # List[Dict], as in the reference
+            ms = xf.match_many([r['descriptors'] for r in res[0::2]], [r['descriptors'] for r in res[1::2]])
+        Descriptor tensors that are row-prefix views of one padded (B, K, 64) tensor at a constant stride -- what detectAndCompute hands out -- are matched in place
+        (no copy; the fp16 copies that detectAndCompute's kernel wrote along are reused for the filter pass as long as the descriptors are the ones the LAST
+        detectAndCompute call returned -- do not modify those in place before matching them); anything else is padded into one tensor first."""
+        P = len(feats1)
+        if len(feats2) != P:
+            raise RuntimeError('match_many: the two lists must have the same length')
+        if P == 0:
+            return []
+        self._require_gpu()
+        lib = _lib.load()
+        lens1, lens2 = [int(f.shape[0]) for f in feats1], [int(f.shape[0]) for f in feats2]
+        lay = self._strided_layout(feats1, feats2)
+        if lay is None:                                          # general case: pad both sides
+            N1, N2 = max(max(lens1), 1), max(max(lens2), 1)
+            d1 = torch.zeros((P, N1, 64), dtype=torch.float32, device=self.dev)
+            d2 = torch.zeros((P, N2, 64), dtype=torch.float32, device=self.dev)
+            for p_, (a, b) in enumerate(zip(feats1, feats2)):
+                if a.dim() != 2 or b.dim() != 2 or a.shape[-1] != 64 or b.shape[-1] != 64:
+                    raise RuntimeError('descriptors must be (N,64)')
+                d1[p_, :lens1[p_]] = a
+                d2[p_, :lens2[p_]] = b
+            p1, ps1, p2, ps2, h1, h2 = d1.data_ptr(), N1 * 64, d2.data_ptr(), N2 * 64, None, None
+            keep = (d1, d2)
+        else:
+            p1, ps1, p2, ps2, h1, h2, keep = lay
+            N1, N2 = max(max(lens1), 1), max(max(lens2), 1)
+        nv = torch.tensor(lens1 + lens2, dtype=torch.int32).to(self.dev, non_blocking=True)      # one count array, both sides (n_stride 1, offset P)
+        idx0 = torch.empty((P, N1), dtype=torch.int64, device=self.dev)
+        idx1 = torch.empty((P, N1), dtype=torch.int64, device=self.dev)
+        n = torch.empty((P,), dtype=torch.int32, device=self.dev)
+        ws, nb = self.net.workspace("match", lib.xfh_match_workspace_bytes(P, N1, N2))
+        _lib.check(lib.xfh_match_mnn(self.net.handle(), C.c_void_p(p1), ps1, C.c_void_p(p2), ps2, C.c_void_p(h1) if h1 else None, C.c_void_p(h2) if h2 else None,
+                                     _ptr(nv), _ptr(nv), 1, P, P, N1, N2, float(min_cossim), _ptr(idx0), _ptr(idx1), _ptr(n), _ptr(ws), nb, _stream()), "xfh_match_mnn")
+        cnt = n.cpu().tolist()                                   # the one read-back
+        del keep
+        return [(idx0[p_, :cnt[p_]], idx1[p_, :cnt[p_]]) if lens1[p_] and lens2[p_] else (idx0[p_, :0], idx1[p_, :0]) for p_ in range(P)]
+
+    def _strided_layout(self, feats1, feats2):
+        """(first pointer 1, pair stride 1, first pointer 2, pair stride 2, fp16 pointers or None x 2, keep-alive) if every tensor of the two lists is a block of whole
+        64-float rows inside ONE fp32 storage on this device, the blocks of each list equally spaced -- what detectAndCompute's List[Dict] holds; None otherwise.
+        (Storage identity, not `_base`: tensors made under torch.inference_mode do not record their view base.)"""
+        f0 = feats1[0]
+        if not (torch.is_tensor(f0) and f0.is_cuda and f0.dtype == torch.float32 and (self.dev.index is None or f0.device.index == self.dev.index)
+                and f0.device.index == torch.cuda.current_device()):      # (self.dev is torch.device('cuda'): no index, never equal to a tensor's cuda:0)
+            return None
+        st = f0.untyped_storage().data_ptr()
+        offs = []
+        for lst in (feats1, feats2):
+            o = []
+            for f in lst:
+                if not (torch.is_tensor(f) and f.is_cuda and f.dtype == torch.float32 and f.dim() == 2 and f.shape[1] == 64 and f.untyped_storage().data_ptr() == st
+                        and (f.shape[0] <= 1 or f.stride(0) == 64) and f.stride(1) == 1 and f.storage_offset() % 8 == 0):
+                    return None
+                o.append(f.storage_offset())
+            stride = o[1] - o[0] if len(o) > 1 else 64 * max(int(lst[0].shape[0]), 1)
+            if stride <= 0 or stride % 8 or any(o[i + 1] - o[i] != stride for i in range(len(o) - 1)) or any(int(f.shape[0]) * 64 > stride for f in lst):
+                return None
+            offs.append((o[0], stride))
+        h1 = h2 = None
+        keep = [f0]
+        last = getattr(self, "_last_desc16", None)
+        if last is not None and last[0].untyped_storage().data_ptr() == st and last[0].storage_offset() == 0 and last[1].shape == last[0].shape:
+            h1, h2 = last[1].data_ptr() + 2 * offs[0][0], last[1].data_ptr() + 2 * offs[1][0]      # the fp16 copies sit at the same element offsets of their own tensor
+            keep += [last[0], last[1]]
+        return st + 4 * offs[0][0], offs[0][1], st + 4 * offs[1][0], offs[1][1], h1, h2, keep
 
     def create_xy(self, h, w, dev):
         y, x = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing='ij')

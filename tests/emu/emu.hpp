@@ -229,6 +229,8 @@ typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_raw_buffer_store_b64(val, rs, voff, soff, aux)                                                               \
     do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 8 <= (rs).bytes) { const auto v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 8); } } while (0)
 #define __builtin_amdgcn_s_sleep(n) ((void)0)
+#define __builtin_amdgcn_raw_buffer_store_b16(val, rs, voff, soff, aux)                                                               \
+    do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 2 <= (rs).bytes) { const short v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 2); } } while (0)
 #define __builtin_amdgcn_raw_buffer_store_b32(val, rs, voff, soff, aux)                                                               \
     do { const unsigned vo_ = (unsigned)(voff); if ((uint64_t)vo_ + 4 <= (rs).bytes) { const unsigned v_ = (val); std::memcpy((rs).base + vo_ + (unsigned)(soff), &v_, 4); } } while (0)
 

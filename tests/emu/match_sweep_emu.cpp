@@ -1,7 +1,7 @@
 // mnn_f16_sweep_kernel (csrc/k_match_f16.hip: the matcher's filter -- ONE pass over S^ = D1 D2^T on v_mfma_f32_32x32x16_f16, every 32 x 32 tile in both orientations, block maxima
 // R / C and the row / column maxima; sliced out of the product source by tests/test_kernels_emulated.py into match_sweep_slice.hpp) on the host.
 // stdin: {P, N1, N2, n1, n2, nsplit} int32 (n1 / n2: valid rows of every pair; nsplit 0: launch_match_f16's choice for 256 CUs), then a16 (P*N1*64), b16 (P*N2*64) as fp32
-// values that are exact fp16 numbers; stdout: rowmax (P*N1), colmax (P*N2) as floats, R (P*ceil(N2/32)*N1), C (P*ceil(N1/32)*N2).
+// values that are exact fp16 numbers; stdout: rowmax (P*N1), colmax (P*N2) as floats, R (P*ceil(N2/32)*N1), C (P*ceil(N1/32)*N2) (the kernel's fp16 quarter values x 4).
 #include "emu.hpp"
 #include <cstdio>
 #include <algorithm>
@@ -55,17 +55,20 @@ int main() {
     std::vector<int32_t> n1(P, n1v), n2(P, n2v);
     const int ncb32 = (N2 + 31) / 32, nrb32 = (N1 + 31) / 32;
     std::vector<unsigned> rowmaxh((size_t)P * N1, 0u), colmaxh((size_t)P * N2, 0u);      // (zeroed by the caller: MatchWs::zeroed)
-    std::vector<float> R((size_t)P * ncb32 * N1, NAN), C((size_t)P * nrb32 * N2, NAN);
+    std::vector<_Float16> R16((size_t)P * ncb32 * N1, (_Float16)NAN), C16((size_t)P * nrb32 * N2, (_Float16)NAN);      // block maxima: fp16, a quarter of the scaled product, rounded up
     const int ncc = (N2 + xfh::FT_COLS - 1) / xfh::FT_COLS;
     const int nsplit = h[5] > 0 ? h[5] : std::max(1, std::min((2 * 256 + ncc * P - 1) / (ncc * P), (N1 + 255) / 256));      // launch_match_f16, 256 CUs
     const size_t lds = sizeof(_Float16) * xfh::FT_COLS * xfh::FT_DS + sizeof(float) * 8 * xfh::FT_COLS + 64;
     emu::launch(ncc * nsplit * P, 512, lds, [&] {
-        xfh::mnn_f16_sweep_kernel(a16.data(), (size_t)N1 * 64, b16.data(), (size_t)N2 * 64, n1.data(), n2.data(), 1, 0, N1, N2, ncc, nsplit, P, colmaxh.data(), rowmaxh.data(), R.data(), C.data());
+        xfh::mnn_f16_sweep_kernel(a16.data(), (size_t)N1 * 64, b16.data(), (size_t)N2 * 64, n1.data(), n2.data(), 1, 0, N1, N2, ncc, nsplit, P, colmaxh.data(), rowmaxh.data(), R16.data(), C16.data());
     });
     std::vector<float> rm(rowmaxh.size()), cm(colmaxh.size());
     for (size_t i = 0; i < rm.size(); ++i) rm[i] = rowmaxh[i] ? xfh::ord_float(rowmaxh[i]) : NAN;      // (0 = never written)
     for (size_t i = 0; i < cm.size(); ++i) cm[i] = colmaxh[i] ? xfh::ord_float(colmaxh[i]) : NAN;
     fwrite(rm.data(), 4, rm.size(), stdout); fwrite(cm.data(), 4, cm.size(), stdout);
+    std::vector<float> R(R16.size()), C(C16.size());      // (written out in the product's units: x 4)
+    for (size_t i = 0; i < R.size(); ++i) R[i] = 4.f * (float)R16[i];
+    for (size_t i = 0; i < C.size(); ++i) C[i] = 4.f * (float)C16[i];
     fwrite(R.data(), 4, R.size(), stdout); fwrite(C.data(), 4, C.size(), stdout);
     return 0;
 }

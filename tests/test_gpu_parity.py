@@ -413,6 +413,41 @@ def test_batch_sizes_cover_both_workgroup_mappings(xf):
             assert torch.equal(bm[p][0], single[p][0]) and torch.equal(bm[p][1], single[p][1]), (P, p)
 
 
+def test_match_many_is_match_pair_by_pair(xf):
+    """XFeat.match_many (the list form of match: one launch sequence, one read-back) returns, pair by pair, exactly what XFeat.match returns -- on the descriptors
+    detectAndCompute hands out (matched in place: views of one padded tensor at a constant stride, fp16 copies reused), on the same lists in another order
+    (irregular stride: the padded path), on free-standing tensors of different lengths, with an empty set, and with and without the similarity test."""
+    x = torch.cat([fixtures.texture_images(4, 96, 160, seed=41), fixtures.texture_images(4, 96, 160, seed=41).roll((3, 5), (2, 3))]).cuda()
+    res = xf.detectAndCompute(x, top_k=400)
+    f1, f2 = [r["descriptors"] for r in res[0::2]], [r["descriptors"] for r in res[1::2]]
+    assert xf._strided_layout(f1, f2) is not None and xf._strided_layout(f1, f2)[4] is not None        # in place, with the fp16 copies
+    for mc in (-1, 0.82):
+        want = [xf.match(a, b, min_cossim=mc) for a, b in zip(f1, f2)]
+        for got in (xf.match_many(f1, f2, min_cossim=mc),                                              # in place
+                    xf.match_many([t.clone() for t in f1], [t.clone() for t in f2], min_cossim=mc)):      # padded copies
+            assert len(got) == len(want)
+            for (g0, g1), (w0, w1) in zip(got, want):
+                assert g0.dtype == torch.int64 and torch.equal(g0, w0) and torch.equal(g1, w1)
+    order = [3, 0, 2, 1]                                                                                # no constant stride: the padded path
+    assert xf._strided_layout([f1[i] for i in order], [f2[i] for i in order]) is None
+    got = xf.match_many([f1[i] for i in order], [f2[i] for i in order], min_cossim=-1)
+    for i, (g0, g1) in zip(order, got):
+        w0, w1 = xf.match(f1[i], f2[i], min_cossim=-1)
+        assert torch.equal(g0, w0) and torch.equal(g1, w1)
+    # the same frames against a shifted partner list (frame 2p against frame 2p + 3: another constant stride and offset)
+    g1l, g2l = [r["descriptors"] for r in res[0:5:2]], [r["descriptors"] for r in res[3:8:2]]
+    for (g0, g1), (a, b) in zip(xf.match_many(g1l, g2l, min_cossim=-1), zip(g1l, g2l)):
+        w0, w1 = xf.match(a, b, min_cossim=-1)
+        assert torch.equal(g0, w0) and torch.equal(g1, w1)
+    d = [torch.nn.functional.normalize(torch.randn(n, 64, device="cuda"), dim=-1) for n in (700, 33, 0, 257)]
+    e = [torch.nn.functional.normalize(torch.randn(n, 64, device="cuda"), dim=-1) for n in (512, 700, 40, 1)]
+    got = xf.match_many(d, e, min_cossim=-1)
+    for (g0, g1), (a, b) in zip(got, zip(d, e)):
+        w0, w1 = xf.match(a, b, min_cossim=-1)
+        assert torch.equal(g0, w0) and torch.equal(g1, w1), (len(a), len(b))
+    assert xf.match_many([], []) == []
+
+
 def test_batch_composition_and_determinism(xf):
     """An image's result does not depend on its batch neighbours, and reruns are bit-identical."""
     x = fixtures.texture_images(5, 96, 160, seed=17).cuda()

@@ -59,7 +59,8 @@ int main(int argc, char** argv) {
     // layer indices of accelerated_features_amd/spec.py: CONVS (skip1.1 = 0, block1.0-.3 = 1-4, block2.0-.1, block3.0-.2, block4.0-.2 = 10-12, block5.0-.3, block_fusion.0-.2 = 17-19, heads)
     struct Case { const char* name; int layer, B, Hm, Wm; };
     const Case cases[] = {{"block4.1  B 64  30 x 40", 11, 64, 30, 40}, {"block4.2  B 64  30 x 40", 12, 64, 30, 40}, {"block_fusion.0  B 64  60 x 80", 17, 64, 60, 80},
-                          {"block_fusion.0  B 3  41 x 93", 17, 3, 41, 93}, {"block4.1  B 1  30 x 40", 11, 1, 30, 40}, {"block5.1  B 64  15 x 20 (128 ch)", 14, 64, 15, 20}, {"block4.0  B 64  60 x 80 (stride 2: variants 1 / 10 / 11)", 10, 64, 60, 80}, {"block5.0  B 64  30 x 40 (stride 2)", 13, 64, 30, 40}};
+                          {"block_fusion.0  B 3  41 x 93", 17, 3, 41, 93}, {"block4.1  B 1  30 x 40", 11, 1, 30, 40}, {"block5.1  B 64  15 x 20 (128 ch)", 14, 64, 15, 20}, {"block4.0  B 64  60 x 80 (stride 2: variants 1 / 10 / 11)", 10, 64, 60, 80}, {"block5.0  B 64  30 x 40 (stride 2)", 13, 64, 30, 40},
+                          {"block_fusion.0  B 8  128 x 128 (2 strips)", 17, 8, 128, 128}, {"block_fusion.0  B 2  150 x 200 (2 strips)", 17, 2, 150, 200}, {"block5.1  B 8  32 x 100 (128 ch, 2 strips)", 14, 8, 32, 100}};
     if (argc > 3 && !strcmp(argv[3], "one")) {      // one layer, one variant, a few launches: the command rocprofv3 --pmc runs (argv: lib weights one <case> <variant> [launches])
         const Case& c = cases[atoi(argv[4])];
         const int v = atoi(argv[5]), nl = argc > 6 ? atoi(argv[6]) : 5;
@@ -109,7 +110,7 @@ int main(int argc, char** argv) {
         HIPCHK(hipFree(x)); HIPCHK(hipFree(y));
     }
     // ---- the 3x3 + 1x1 pairs as one launch: conv_rs64_kernel (13 NCHW / 14 channels-last) against conv_bx64_kernel (15 / 16); parity of 13 vs 15 and 14 vs 16
-    for (const Case& c : {Case{"block3.1 + .2  B 64  60 x 80", 8, 64, 60, 80}, Case{"block_fusion.1 + .2  B 64  60 x 80", 18, 64, 60, 80}, Case{"block_fusion.1 + .2  B 3  41 x 61", 18, 3, 41, 61}}) {
+    for (const Case& c : {Case{"block3.1 + .2  B 64  60 x 80", 8, 64, 60, 80}, Case{"block_fusion.1 + .2  B 64  60 x 80", 18, 64, 60, 80}, Case{"block_fusion.1 + .2  B 3  41 x 61", 18, 3, 41, 61}, Case{"block_fusion.1 + .2  B 8  128 x 128 (2 strips)", 18, 8, 128, 128}, Case{"block3.1 + .2  B 2  150 x 200 (3 strips)", 8, 2, 150, 200}}) {
         const size_t n = (size_t)c.B * 64 * c.Hm * c.Wm;
         auto hx = rnd(n, (unsigned)c.layer + c.B, -1.f, 3.f);
         float *x, *y;

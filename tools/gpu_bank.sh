@@ -3,7 +3,7 @@
 #   gpurun --timeout 1500 -- 'bash tools/gpu_bank.sh r05_b'      -> gpurun_out/<tag>_{pytest.log, smoke.log, bench.log, kernel_stats.csv, kernel_stats_1lane.csv}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
 T=${1:-bank}; O=gpurun_out/$T
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log | grep -v amdgpu.ids; grep -E "^(FAILED|ERROR)" ${O}_pytest.log | head
+timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > ${O}_pytest.log 2>&1; echo "pytest rc=$?"; tail -4 ${O}_pytest.log | grep -v amdgpu.ids; grep -E "^(FAILED|ERROR)" ${O}_pytest.log | head
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > ${O}_smoke.log 2>&1; echo "smoke rc=$?"; tail -2 ${O}_smoke.log
 timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids > ${O}_bench.log; tail -c 300 ${O}_bench.log
 if [ "$2" != "nostats" ]; then
