@@ -229,8 +229,11 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2, block
         fl = conv_flops(n_, px[sc_out])
         ho, wo = H // int(sc_out), W // int(sc_out)
         pad = (-(-ho // 8) * 8) * (-(-wo // 16) * 16) / float(ho * wo)          # 8x16-pixel units over the map (1.28 / 1.71 at VGA)
-        add(100 + ci[n_], f"conv_bx64s2_kernel<{cout // 64}> ({n_}, stride 2)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), fl, fl * 6 * pad, PEAK_BF16_TFLOPS,
-            "bf16 mfma x6 (fp32-equivalent)")
+        if (fx & 1025) == 1025:      # the stride-2 layers in the fp16-pair arithmetic (conv_bx64s2x_kernel: three MFMAs per product)
+            add(100 + ci[n_], f"conv_bx64s2x_kernel<{cout // 64}> ({n_}, stride 2)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), fl, fl * 3 * pad, PEAK_BF16_TFLOPS, pipe64)
+        else:
+            add(100 + ci[n_], f"conv_bx64s2_kernel<{cout // 64}> ({n_}, stride 2)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), fl, fl * 6 * pad, PEAK_BF16_TFLOPS,
+                "bf16 mfma x6 (fp32-equivalent)")
     units16 = B * (-(-(H // 16) // 8)) * (-(-(W // 16) // 16))          # half-tile units of conv_bx64_kernel at 1/16 scale (api.hip: big_map)
     for n_, ch, sc in (("block4.1", 64, "16"), ("block4.2", 64, "16"), ("block5.1", 128, "32")):
         fl = conv_flops(n_, px[sc])

@@ -374,8 +374,14 @@ int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int
                         const float* heat_ref, float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat,
                         unsigned* rep_logits, unsigned cap, xfh_stream stream);
 /* debug / torture (process-wide, not for production): with enable != 0 every matrix-core kernel of the backbone invalidates the instruction cache when a
- * workgroup starts, so that its first tile runs on instruction-fetch misses -- the condition under which head_bx_kernel<true> was found to deliver a wrong
- * 16-cell block; the concurrency / cold-start soaks of tests/test_gpu_parity.py and tools/head_soak.py use it. */
+ * workgroup starts, so that its first tile runs on instruction-fetch misses -- the condition under which the retired split-bf16 key-point head was found to
+ * deliver a wrong 16-cell block; the concurrency / cold-start soaks of tests/test_gpu_parity.py, tools/final_soak.py and the code-position scan
+ * (tools/bench_src/scan_probe.cpp) use it.
+ * WHY THE HOOK SHIPS IN THE PRODUCTION LIBRARY instead of a debug build: the hazard it provokes depends on where a kernel's instructions lie relative to the
+ * instruction-cache lines (3 of 16 code positions failed for the bf16 head).  Evidence gathered on a debug twin -- the same source compiled with another flag, i.e.
+ * other offsets -- would say nothing about the shipped bytes.  The in-suite soak and the scans therefore torture THE library that ships; the price is one scalar
+ * compare at kernel entry (cold == 0: not taken) and this one process-wide int, which no product path writes.  The xfh_debug_* entry points that only probe
+ * (head_soak, block1, trace, match_occupancy) are thin launchers of shipped kernels: they add no state. */
 int xfh_debug_cold_start(int enable);
 /* debug: block1 + skip1 alone in the form option "block1" selects: gray (B,H,W) raw gray image, coef (B,2) the per-image {alpha, beta} of the instance
  * normalisation (x -> alpha x + beta), x1 (B,24,H/4,W/4); H % 4 == W % 4 == 0.  For the variant-against-variant tests of tests/test_gpu_parity.py. */

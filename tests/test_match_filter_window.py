@@ -71,3 +71,37 @@ def test_measured_error_stays_inside_the_bound():
         assert r < 1.0, (name, r)
         worst = max(worst, r)
     assert worst > 0.8, worst
+
+
+def test_block_maxima_and_thresholds_round_the_conservative_way():
+    """k_match_f16.hip stores block maxima and thresholds as fp16 (round 5): f16_up(x) = fp16(x + 2^-10 |x| + 2^-24) must never be below x, f16_down(x) never above it --
+    then R >= thr in fp32 implies R16 >= thr16 and the flagged set only grows -- and neither may move a value by more than ~2^-9 of its size (the price: a few more blocks
+    evaluated exactly).  The constants are parsed from the source; fp32 operations and the fp16 rounding are restated in numpy (round-to-nearest-even both)."""
+    src = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "k_match_f16.hip")).read()
+    m = re.search(r"f16_up\(float x\) \{ return \(_Float16\)\(__builtin_fmaf\(__builtin_fabsf\(x\), ([0-9.e+-]+)f, x\) \+ ([0-9.e+-]+)f\); \}", src)
+    n = re.search(r"f16_down\(float x\) \{ return \(_Float16\)\(__builtin_fmaf\(__builtin_fabsf\(x\), -([0-9.e+-]+)f, x\) - ([0-9.e+-]+)f\); \}", src)
+    assert m and n and m.groups() == n.groups()
+    rel, tiny = np.float32(m.group(1)), np.float32(m.group(2))
+    assert float(rel) == 2.0 ** -10 and float(tiny) == 2.0 ** -24
+    scale = float(re.search(r"F16_STORE_SCALE = ([0-9.]+)f;", src).group(1))
+    assert scale * 65536.0 * (1 + 2.0 ** -9) < 65504.0            # the largest scaled product (unit rows at scale 256 on both sides) stays finite in fp16
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(200000) * 10.0 ** rng.uniform(-9, 4.2, 200000), [0.0, -0.0, 16384.0, -16384.0, 2.0 ** -14, -2.0 ** -14, 2.0 ** -24, 6e-8, -6e-8, 1e-30, 65536.0 * scale],
+                        np.float32(2.0) ** rng.integers(-24, 14, 1000) * (1 + 2.0 ** -11)]).astype(np.float32)      # (incl. fp16 subnormals, ties of the fp16 rounding, the top of the range)
+
+    def fma32(a, b, c):      # one fp32 rounding of a * b + c (a * b is exact in fp64 for fp32 inputs, the sum to 2^-53: no double rounding that matters here is possible across 2^-10)
+        return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(np.float32)
+    up = (fma32(np.abs(x), rel, x) + tiny).astype(np.float32).astype(np.float16).astype(np.float64)
+    down = (fma32(np.abs(x), -rel, x) - tiny).astype(np.float32).astype(np.float16).astype(np.float64)
+    xd = x.astype(np.float64)
+    assert (up >= xd).all() and (down <= xd).all()
+    reach = np.abs(xd) * 2.0 ** -9 + 2.0 ** -22
+    assert (up <= xd + reach).all() and (down >= xd - reach).all()
+    # and through the comparison the refine makes (the sign of the fp16 difference): whenever R >= thr holds in fp32, the stored pair compares the same way
+    r, t = x[:100000], x[100000:200000]
+    keep = r >= t
+    r16 = (fma32(np.abs(r), rel, r) + tiny).astype(np.float32).astype(np.float16)
+    t16 = (fma32(np.abs(t), -rel, t) - tiny).astype(np.float32).astype(np.float16)
+    d = (r16 - t16)                                                  # fp16 subtraction, as v_sub_f16 does it
+    flagged = ~np.signbit(d)
+    assert flagged[keep].all()
