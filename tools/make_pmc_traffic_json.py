@@ -4,7 +4,7 @@ HBM bytes per launch of every kernel of the step, the read side corrected as MI3
 coalesced reads: x 2, re-calibrated in the same run on gray_stats_kernel, which reads exactly B*3*H*W*4 bytes).      python tools/make_pmc_traffic_json.py <round tag>"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 raw = json.load(open(os.path.join(ROOT, "gpurun_out", "pmc_traffic_raw.json")))
 B, H, W = 64, 480, 640
 rgb = B * 3 * H * W * 4
@@ -17,9 +17,9 @@ table = {}
 for k, v in raw.items():
     table[k] = {"launches": v["launches"], "hbm_read_bytes": int(v["fetch_kib"] * 1024 * corr), "hbm_write_bytes": int(v["write_kib"] * 1024),
                 "hbm_bytes": int(v["fetch_kib"] * 1024 * corr + v["write_kib"] * 1024)}
-b1 = next((k for k in table if k.startswith("block1_fused_kernel")), None)
+b1 = next((k for k in table if k.startswith("block1_mx_kernel")), None) or next((k for k in table if k.startswith("block1_fused_kernel")), None)      # (the default block1 since round 5: block1_mx_kernel<7>)
 out = {"collected": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python bench.py --steps 3 --warmup 2 --cpu-seconds 0 --no-side-passes --wake-ms 0 --lanes 1` (every launch at the bench shape), tools/gpu_traffic.sh, "
-                    f"final build of round 4 ({tag}); raw table profiles/{tag}_pmc_traffic_raw.json; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B): calibration in this run on "
+                    f"final build of the round ({tag}); raw table profiles/{tag}_pmc_traffic_raw.json; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B): calibration in this run on "
                     f"gray_stats_kernel = {rgb} B of RGB per launch -> measured factor {cal:.3f}" if cal else "no calibration kernel found",
        "read_correction": corr, "read_calibration_on_gray_stats": cal,
        "dominant_kernel": b1.split("<")[0] if b1 else None,
