@@ -994,9 +994,9 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         # The contract line stays short enough for an 8 KB tail: the per-kernel table and the long notes go out FIRST, on a line of their own that is not JSON by itself
-        # ("# detail: {...}"); the ONE JSON line is the last line.
+        # ("# detail: {...}") on STDERR; stdout carries the ONE JSON line.
         detail = {k: out.pop(k) for k in ("roofline_kernels", "roofline_conv_family", "roofline_conv24", "side_workloads") if k in out}
-        print("# detail: " + json.dumps(detail), flush=True)
+        print("# detail: " + json.dumps(detail), file=sys.stderr, flush=True)      # (stderr: stdout carries exactly one line, the contract's JSON line)
         print(json.dumps(out))
     if dist is not None:
         sharding.sync_barrier(dist)

@@ -62,14 +62,17 @@ int main(int argc, char** argv) {
                           {"block_fusion.0  B 3  41 x 93", 17, 3, 41, 93}, {"block4.1  B 1  30 x 40", 11, 1, 30, 40}, {"block5.1  B 64  15 x 20 (128 ch)", 14, 64, 15, 20}, {"block4.0  B 64  60 x 80 (stride 2: variants 1 / 10 / 11)", 10, 64, 60, 80}, {"block5.0  B 64  30 x 40 (stride 2)", 13, 64, 30, 40},
                           {"block_fusion.0  B 8  128 x 128 (2 strips)", 17, 8, 128, 128}, {"block_fusion.0  B 2  150 x 200 (2 strips)", 17, 2, 150, 200}, {"block5.1  B 8  32 x 100 (128 ch, 2 strips)", 14, 8, 32, 100}};
     if (argc > 3 && !strcmp(argv[3], "one")) {      // one layer, one variant, a few launches: the command rocprofv3 --pmc runs (argv: lib weights one <case> <variant> [launches])
-        const Case& c = cases[atoi(argv[4])];
+        // (case >= 100: the 24-channel layers at 1/4 scale, VGA batch 64 -- 100 = block2.0, 101 = block2.1 (24 -> 24), 102 = block3.0 (24 -> 64, stride 2): the default kernel is variant 0)
+        static const Case c24[] = {{"block2.0  B 64  120 x 160 (24 ch)", 5, 64, 120, 160}, {"block2.1  B 64  120 x 160 (24 ch)", 6, 64, 120, 160}, {"block3.0  B 64  120 x 160 (24 -> 64, stride 2)", 7, 64, 120, 160}};
+        const int ci = atoi(argv[4]);
+        const Case& c = ci >= 100 ? c24[ci - 100] : cases[ci];
         const int v = atoi(argv[5]), nl = argc > 6 ? atoi(argv[6]) : 5;
-        const int nch = c.layer == 14 || c.layer == 15 ? 128 : 64;
-        const size_t n = (size_t)c.B * nch * c.Hm * c.Wm;
-        auto hx = rnd(n, (unsigned)c.layer + c.B, -1.f, 3.f);
+        const int nch = ci >= 100 ? 24 : c.layer == 14 || c.layer == 15 ? 128 : 64;
+        const size_t n = (size_t)c.B * 128 * c.Hm * c.Wm;      // (room for the widest output of any case)
+        auto hx = rnd((size_t)c.B * nch * c.Hm * c.Wm, (unsigned)c.layer + c.B, -1.f, 3.f);
         float *x, *y;
-        HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, n * 4));
-        HIPCHK(hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc(&x, hx.size() * 4)); HIPCHK(hipMalloc(&y, n * 4));
+        HIPCHK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
         for (int i = 0; i < nl; ++i) if (xfh_conv_layer(h, c.layer, x, c.B, c.Hm, c.Wm, y, v, nullptr)) { printf("%s\n", xfh_last_error()); return 2; }
         HIPCHK(hipDeviceSynchronize());
         printf("%s variant %d: %d launches\n", c.name, v, nl);
