@@ -78,6 +78,58 @@ int main(int argc, char** argv) {
         printf("%s variant %d: %d launches\n", c.name, v, nl);
         return 0;
     }
+    if (argc > 3 && !strcmp(argv[3], "trace24")) {      // conv_bx_kernel<24,24,fx>'s own stamps (k_conv_bx.hip: BX_STAMP 0 tile start, 1 staged, 2 barrier passed, 3 MFMAs issued; 6 per tile, 10 tiles, 64 slots per workgroup)
+        auto xfh_debug_trace = reinterpret_cast<int (*)(H, long long*)>(dlsym(lib, "xfh_debug_trace"));
+        const int B = 64, Hm = 120, Wm = 160;
+        const size_t n = (size_t)B * 24 * Hm * Wm;
+        auto hx = rnd(n, 5, 0.f, 3.f);
+        float *x, *y; long long* tr;
+        const size_t ntr = ((size_t)1 << 21) + ((size_t)1 << 17);
+        HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, n * 4)); HIPCHK(hipMalloc(&tr, ntr * 8));
+        HIPCHK(hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice));
+        for (int i = 0; i < 3; ++i) xfh_conv_layer(h, 5, x, B, Hm, Wm, y, 0, nullptr);
+        HIPCHK(hipMemset(tr, 0, ntr * 8));
+        xfh_debug_trace(h, tr);
+        xfh_conv_layer(h, 5, x, B, Hm, Wm, y, 0, nullptr);
+        HIPCHK(hipDeviceSynchronize());
+        xfh_debug_trace(h, nullptr);
+        std::vector<long long> t(512 * 64);
+        HIPCHK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
+        double ph[4] = {0, 0, 0, 0}, per = 0; long cnt = 0, cntp = 0;
+        double by_alloc[2][5] = {{0}}; long na[2] = {0, 0};
+        for (int g = 0; g < 512; ++g) {
+            const long long* q = &t[g * 64];
+            const int second = (q[62] & 0xff) != 0;
+            for (int k = 1; k < 8; ++k) {      // tiles 1 .. 7 of the workgroup (steady state)
+                const long long* a = q + k * 6;
+                if (!a[0] || !a[3] || !a[6]) continue;
+                ph[0] += (double)(a[1] - a[0]); ph[1] += (double)(a[2] - a[1]); ph[2] += (double)(a[3] - a[2]); ph[3] += (double)(a[6] - a[3]); ++cnt;
+                per += (double)(a[6] - a[0]); ++cntp;
+                by_alloc[second][0] += (double)(a[1] - a[0]); by_alloc[second][1] += (double)(a[2] - a[1]); by_alloc[second][2] += (double)(a[3] - a[2]); by_alloc[second][3] += (double)(a[6] - a[3]); ++na[second];
+            }
+        }
+        printf("conv_bx_kernel<24,24,fx> block2.0 B 64: per tile (wave 0 of %ld workgroup-tiles, cycles): stage (wait for the tile's loads + convert + LDS writes) %.0f, barrier %.0f, MFMAs (84) + next tile's loads issued %.0f, epilogue (24 stores) -> next tile %.0f; period %.0f\n",
+               cnt, ph[0] / cnt, ph[1] / cnt, ph[2] / cnt, ph[3] / cnt, per / cntp);
+        for (int s2 = 0; s2 < 2; ++s2) if (na[s2]) printf("  %s workgroup of a CU: stage %.0f barrier %.0f MFMA %.0f epilogue %.0f\n", s2 ? "second" : "first", by_alloc[s2][0] / na[s2], by_alloc[s2][1] / na[s2], by_alloc[s2][2] / na[s2], by_alloc[s2][3] / na[s2]);
+        return 0;
+    }
+    if (argc > 3 && !strcmp(argv[3], "lag")) {      // experiment: conv_bx_kernel<24,24,fx> under different phase lags of a CU's second workgroup (XFH_DBG_LAG, experiment builds only)
+        const int B = 64, Hm = 120, Wm = 160;
+        const size_t n = (size_t)B * 24 * Hm * Wm;
+        auto hx = rnd(n, 5, 0.f, 3.f);
+        float *x, *y;
+        HIPCHK(hipMalloc(&x, n * 4)); HIPCHK(hipMalloc(&y, (size_t)B * 64 * Hm * Wm * 4));
+        HIPCHK(hipMemcpy(x, hx.data(), n * 4, hipMemcpyHostToDevice));
+        for (int layer : {5, 7}) {
+            for (int lag : {11, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 20, 24, 11}) {
+                char buf[16]; snprintf(buf, sizeof buf, "%d", lag); setenv("XFH_DBG_LAG", buf, 1);
+                if (xfh_conv_layer(h, layer, x, B, Hm, Wm, y, 0, nullptr)) { printf("%s\n", xfh_last_error()); return 2; }
+                const double us = timed(30, [&] { xfh_conv_layer(h, layer, x, B, Hm, Wm, y, 0, nullptr); });
+                printf("layer %d lag %2d: %7.1f us\n", layer, lag, us);
+            }
+        }
+        return 0;
+    }
     for (const Case& c : cases) {
         const int nch = c.layer == 14 || c.layer == 15 ? 128 : 64;
         const bool s2 = c.layer == 10 || c.layer == 13;      // stride 2: output 64 | 128 channels at half the size
