@@ -276,7 +276,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
     const size_t zoff = reserve(256);
     struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx, fq, rs; bool has_wino, has_bx, fx_ok, has_fq, has_rs; } coff[L_NUM];
-    struct FOff { size_t w, b; } foff[5];
+    struct FOff { size_t w, b, fx; bool fx_ok; } foff[5];
     int ai = 0;
     for (int li = 0; li < L_NUM; ++li) {
         const ConvSpec& c = kConvs[li];
@@ -474,6 +474,16 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
             for (int i = 0; i < f.k; ++i) blob[foff[fi].w + (size_t)i * npad + o] = (float)((double)w[(size_t)o * f.k + i] * scale[o]);
             blob[foff[fi].b + o] = (float)shift[o];
         }
+        // the same layer as fp16-pair fragments for linear_fx_kernel (only if every |w| stays below kFxMaxWeight: 2^11 w must be an fp16 number)
+        float wmax = 0.f;
+        for (size_t i = 0; i < (size_t)f.k * npad; ++i) wmax = std::fmax(wmax, std::fabs(blob[foff[fi].w + i]));
+        foff[fi].fx_ok = wmax < kFxMaxWeight && f.k % 32 == 0;
+        foff[fi].fx = 0;
+        if (foff[fi].fx_ok) {
+            foff[fi].fx = reserve(((size_t)3 * f.k * npad + 1) / 2);
+            std::vector<float> wk(blob.begin() + foff[fi].w, blob.begin() + foff[fi].w + (size_t)f.k * npad);      // (reserve may have moved the blob)
+            pack_linear_fx(wk.data(), f.k, npad, reinterpret_cast<uint16_t*>(blob.data() + foff[fi].fx));
+        }
     }
 
     xfh_context* ctx = new xfh_context();
@@ -516,6 +526,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         l.k = kFine[fi].k; l.n = kFine[fi].n; l.n_pad = (kFine[fi].n + 63) / 64 * 64; l.relu = kFine[fi].bn;
         l.w_kn = ctx->blob + foff[fi].w;
         l.bias = ctx->blob + foff[fi].b;
+        l.w_fx = foff[fi].fx_ok ? ctx->blob + foff[fi].fx : nullptr;
     }
     *out = ctx;
     return XFH_OK;
@@ -819,6 +830,13 @@ size_t xfh_refine_workspace_bytes(int P, int N) {
     return carve_refine(nullptr, P, N, o);
 }
 
+// one fine_matcher layer: the fp16-pair kernel (option fx bits 1 | 2048, default) where the layer has its fragments, the f32-MFMA kernel otherwise
+static int fine_layer(xfh_handle h, int li, int K, bool relu, LinLoader loader, const LinSrc& src, int M, const int32_t* m_dev, float* y, int ldy, hipStream_t st) {
+    const LinW& f = h->nw.fine[li];
+    if ((h->opt.fx & 2049) == 2049 && f.w_fx && !launch_linear_fx(f.w_fx, f.bias, K, f.n, f.n_pad, relu, loader, src, M, m_dev, y, ldy, st, h->status)) return 0;
+    return launch_linear_mfma(f.w_kn, f.bias, K, f.n, f.n_pad, relu, loader, src, M, m_dev, y, ldy, st);
+}
+
 int xfh_refine_matches(xfh_handle h, const float* desc0, const float* desc1, const float* kp0, const float* kp1,
                        const float* scale0, const int64_t* idx0, const int64_t* idx1, const int32_t* n_matches, int P,
                        int N, float fine_conf, float* out, int32_t* n_out, void* workspace, size_t workspace_bytes,
@@ -833,20 +851,19 @@ int xfh_refine_matches(xfh_handle h, const float* desc0, const float* desc1, con
     hipStream_t st = (hipStream_t)stream;
     const int M = P * N;
     launch_refine_rowmap(n_matches, P, N, w.offs, w.rowmap, w.total, st);
-    const LinW* f = h->nw.fine;
     LinSrc g{};
     g.x = desc0; g.x2 = desc1; g.idx0 = idx0; g.idx1 = idx1; g.rowmap = w.rowmap; g.N = N;
-    int bad = launch_linear_mfma(f[0].w_kn, f[0].bias, 128, f[0].n, f[0].n_pad, true, LOAD_GATHER2, g, M, w.total, w.actA, 512, st);
+    int bad = fine_layer(h, 0, 128, true, LOAD_GATHER2, g, M, w.total, w.actA, 512, st);
     LinSrc r{};
     r.ldx = 512;
     r.x = w.actA;
-    bad |= launch_linear_mfma(f[1].w_kn, f[1].bias, 512, f[1].n, f[1].n_pad, true, LOAD_ROWMAJOR, r, M, w.total, w.actB, 512, st);
+    bad |= fine_layer(h, 1, 512, true, LOAD_ROWMAJOR, r, M, w.total, w.actB, 512, st);
     r.x = w.actB;
-    bad |= launch_linear_mfma(f[2].w_kn, f[2].bias, 512, f[2].n, f[2].n_pad, true, LOAD_ROWMAJOR, r, M, w.total, w.actA, 512, st);
+    bad |= fine_layer(h, 2, 512, true, LOAD_ROWMAJOR, r, M, w.total, w.actA, 512, st);
     r.x = w.actA;
-    bad |= launch_linear_mfma(f[3].w_kn, f[3].bias, 512, f[3].n, f[3].n_pad, true, LOAD_ROWMAJOR, r, M, w.total, w.actB, 512, st);
+    bad |= fine_layer(h, 3, 512, true, LOAD_ROWMAJOR, r, M, w.total, w.actB, 512, st);
     r.x = w.actB;
-    bad |= launch_linear_mfma(f[4].w_kn, f[4].bias, 512, f[4].n, f[4].n_pad, false, LOAD_ROWMAJOR, r, M, w.total, w.actA, 64, st);
+    bad |= fine_layer(h, 4, 512, false, LOAD_ROWMAJOR, r, M, w.total, w.actA, 64, st);
     if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_refine_matches: missing linear kernel instantiation");
     launch_refine_finish(w.actA, w.rowmap, w.offs, w.total, kp0, kp1, scale0, idx0, idx1, P, N, fine_conf, out, n_out,
                          w.rows, w.keep, st);
@@ -934,18 +951,17 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
     int rc = check_ws(workspace, workspace_bytes, need);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    const LinW* f = h->nw.fine;
     LinSrc r{};
     r.ldx = 128; r.x = x;
-    int bad = launch_linear_mfma(f[0].w_kn, f[0].bias, 128, f[0].n, f[0].n_pad, true, LOAD_ROWMAJOR, r, n, nullptr, w.actA, 512, st);
+    int bad = fine_layer(h, 0, 128, true, LOAD_ROWMAJOR, r, n, nullptr, w.actA, 512, st);
     r.ldx = 512; r.x = w.actA;
-    bad |= launch_linear_mfma(f[1].w_kn, f[1].bias, 512, f[1].n, f[1].n_pad, true, LOAD_ROWMAJOR, r, n, nullptr, w.actB, 512, st);
+    bad |= fine_layer(h, 1, 512, true, LOAD_ROWMAJOR, r, n, nullptr, w.actB, 512, st);
     r.x = w.actB;
-    bad |= launch_linear_mfma(f[2].w_kn, f[2].bias, 512, f[2].n, f[2].n_pad, true, LOAD_ROWMAJOR, r, n, nullptr, w.actA, 512, st);
+    bad |= fine_layer(h, 2, 512, true, LOAD_ROWMAJOR, r, n, nullptr, w.actA, 512, st);
     r.x = w.actA;
-    bad |= launch_linear_mfma(f[3].w_kn, f[3].bias, 512, f[3].n, f[3].n_pad, true, LOAD_ROWMAJOR, r, n, nullptr, w.actB, 512, st);
+    bad |= fine_layer(h, 3, 512, true, LOAD_ROWMAJOR, r, n, nullptr, w.actB, 512, st);
     r.x = w.actB;
-    bad |= launch_linear_mfma(f[4].w_kn, f[4].bias, 512, f[4].n, f[4].n_pad, false, LOAD_ROWMAJOR, r, n, nullptr, out, 64, st);
+    bad |= fine_layer(h, 4, 512, false, LOAD_ROWMAJOR, r, n, nullptr, out, 64, st);
     if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_fine_matcher: missing linear kernel instantiation");
     return check_launch("xfh_fine_matcher");
 }
@@ -962,7 +978,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 2047}};
+        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 4095}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

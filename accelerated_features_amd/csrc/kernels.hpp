@@ -32,6 +32,7 @@ struct LinW {             // fine_matcher layer: y = relu?(x W^T + b), BN folded
     int k, n, n_pad, relu;
     const float* w_kn;    // [k][n_pad]
     const float* bias;    // [n_pad]
+    const void* w_fx;     // the same weights as fp16-pair fragments in linear_fx_kernel's operand order (weight_split.hpp: pack_linear_fx), NULL if a weight is too large for the pair
 };
 
 struct NetWeights {
@@ -63,8 +64,8 @@ struct Options {
                             // activation tile in LDS, two barriers per tile; + 33 us per 64-frame step); 0: the split-bf16 kernels (head_bx_kernel) -- 60 us faster than 2, but
                             // head_bx_kernel<true> delivers a wrong 16-cell block once in 10^3..10^5 launches when a workgroup's first tile runs on instruction-cache
                             // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
-    int fx = 1931;          // (round 5: bits 1 | 2 | 8 | 128 | 256 | 512 | 1024: every 64 -> 64 and 128 -> 128 3x3 on conv_rs64_kernel, the stride-2 layers in the fp16-pair arithmetic)   (bit 128, with 1: the unfused 64 -> 64 layers on conv_rs64_kernel -- weights resident in registers, conv_rs64_body.hpp; bit 256, with 1: the 3x3 + 1x1 pairs too; bit 512, with 1: block5.1 and block5.2 on its 128-channel form, block5.3 then runs as a 1x1 of its own; bit 1024, with 1: block4.0 / block5.0 (stride 2) in the fp16-pair arithmetic, conv_bx64s2x_kernel)  split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
-                            // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel), 4 = (with 1) conv_bx64_kernel with two weight fragments in its stream, 8 = the split heads (with heads_f32 = 0: head_bx_kernel<.., 1>), + 16 = with two weight fragments in LDS (<.., 2>), + 32 = (instead) the B fragments through LDS (<.., 3>), 64 = (with 1) the split-format link block_fusion.0 -> block_fusion.1 (conv_bx64_body.hpp: SP); 0 = the bf16 three-way split everywhere
+    int fx = 3979;          // (round 5: bits 1 | 2 | 8 | 128 | 256 | 512 | 1024 | 2048: the fine_matcher on linear_fx_kernel; every 64 -> 64 and 128 -> 128 3x3 on conv_rs64_kernel, the stride-2 layers in the fp16-pair arithmetic)   (bit 128, with 1: the unfused 64 -> 64 layers on conv_rs64_kernel -- weights resident in registers, conv_rs64_body.hpp; bit 256, with 1: the 3x3 + 1x1 pairs too; bit 512, with 1: block5.1 and block5.2 on its 128-channel form, block5.3 then runs as a 1x1 of its own; bit 1024, with 1: block4.0 / block5.0 (stride 2) in the fp16-pair arithmetic, conv_bx64s2x_kernel)  split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
+                            // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel), 2048 = the fine_matcher's linear layers (linear_fx_kernel), 4 = (with 1) conv_bx64_kernel with two weight fragments in its stream, 8 = the split heads (with heads_f32 = 0: head_bx_kernel<.., 1>), + 16 = with two weight fragments in LDS (<.., 2>), + 32 = (instead) the B fragments through LDS (<.., 3>), 64 = (with 1) the split-format link block_fusion.0 -> block_fusion.1 (conv_bx64_body.hpp: SP); 0 = the bf16 three-way split everywhere
     int block1 = 7;         // (r5-flip: block1.2 and block1.3 on the fp16 matrix cores; 0 / 5 = the vector-ALU kernel)   block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected); 6 = 5 with conv4 on the fp16 matrix cores (fp16-pair arithmetic, block1_fx.hpp), 7 = conv3 too
 };
 
@@ -135,6 +136,10 @@ struct LinSrc {
 int launch_linear_mfma(const float* w_kn, const float* bias, int K, int N, int n_pad, bool relu,
                        LinLoader loader, const LinSrc& src, int M, const int32_t* m_dev,
                        float* y, int ldy, hipStream_t st);
+// the same layer in the fp16-pair arithmetic (bx_split.hpp): three fp16 MFMAs per K = 16 instead of eight f32 MFMAs, fp32-equivalent results; K = 128 (ROWMAJOR / GATHER2) or 512
+// (ROWMAJOR), n_pad a multiple of 64.  status: range guard of the pair.  -1: no instantiation
+int launch_linear_fx(const void* w_fx, const float* bias, int K, int N, int n_pad, bool relu, LinLoader loader, const LinSrc& src, int M, const int32_t* m_dev,
+                     float* y, int ldy, hipStream_t st, int* status);
 // reliability = sigmoid(x . w + b) per row of x (M,64)                     (model.py:82-83)
 void launch_dot_sigmoid(const float* x, int M, const float* w, const float* b, float* out, hipStream_t st);
 // heat (B,H,W) <- softmax over 65 logits per cell, depth-to-space 8x8       (xfeat.py:242-247)

@@ -69,6 +69,24 @@ inline void split_weight(float v, int mode, uint16_t (&q)[3]) {
 }
 constexpr float kFxMaxWeight = 31.f;                   // |w| * 2^11 must stay below the fp16 maximum (65504)
 
+// A linear layer y = x W for linear_fx_kernel (k_linear_mfma.hip: the fine_matcher's layers in the fp16-pair arithmetic): w_kn [K][n_pad] fp32 (BatchNorm folded, zero padded)
+// -> [column block of 64][K step of 16][fragment 3][column half-block 2][lane = half * 32 + column][8]: lane (column n = 64 nb + 32 cb + (lane & 31), half) holds k = 16 s + 8 half + i.
+// fp16-pair fragments (split_weight mode 1).  Returns the 16-bit words written (3 K n_pad).
+inline size_t pack_linear_fx(const float* w_kn, int K, int n_pad, uint16_t* dst) {
+    const int nbs = n_pad / 64, ns = K / 16;
+    for (int nb = 0; nb < nbs; ++nb)
+        for (int st = 0; st < ns; ++st)
+            for (int cb = 0; cb < 2; ++cb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = 16 * st + 8 * (lane >> 5) + i, n = 64 * nb + 32 * cb + (lane & 31);
+                        uint16_t q[3];
+                        split_weight(w_kn[(size_t)k * n_pad + n], 1, q);
+                        for (int sp = 0; sp < 3; ++sp) dst[(((((size_t)nb * ns + st) * 3 + sp) * 2 + cb) * 64 + lane) * 8 + i] = q[sp];
+                    }
+    return (size_t)3 * K * n_pad;
+}
+
 // One layer of a split-operand head (head_bx_body.hpp) in operand order: [K step t][cout block][split][lane = half * 32 + cout][8], cout blocks of 32 (zeros above cout).
 // K order: the first layer of a head takes its 64 input channels in natural order (16 t + 8 half + i); a chained layer takes the previous layer's D registers, i.e.
 // feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).  w: (cout, 64) fp32 (BatchNorm folded), mode: split_weight's.  nfrag = 2 (mode 1 only): q0 and q2 alone

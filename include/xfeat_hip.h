@@ -96,7 +96,7 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *                           (one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever a workgroup's first tile runs on instruction-cache misses; A/B only).
  *                           2: both heads on f32 MFMAs (head_f32r_kernel: the range fallback of the fp16-pair arithmetic; 3 = its round-4 form), 1: the round-1 f32 kernels.
  *   "fx"            bitmask the fp16-pair arithmetic (x = xh + 2^-11 xl: three fp16 MFMAs per product instead of the six of the bf16 three-way split).
- *                           DEFAULT 1931 = 1 | 2 | 8 | 128 | 256 | 512 | 1024.  0 = the bf16 three-way split everywhere (fp32's range: the fallback on XFH_STATUS_FX_RANGE).
+ *                           DEFAULT 3979 = 1 | 2 | 8 | 128 | 256 | 512 | 1024 | 2048.  0 = the bf16 three-way split everywhere (fp32's range: the fallback on XFH_STATUS_FX_RANGE).
  *                             1     the 64 -> 64 layers (master bit of 4, 64, 128, 256, 512, 1024)
  *                             2     the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel)
  *                             4     (with 1) conv_bx64_kernel with two weight fragments in its stream            [opt-in: no gain measured]
@@ -106,7 +106,8 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *                             256   the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) on it too
  *                             512   block5.1 and block5.2 on its 128-channel form (block5.3 then runs as a 1x1 of its own)
  *                             1024  the stride-2 64-channel layers (block4.0, block5.0) on conv_bx64s2x_kernel
- *                           conv_rs64_kernel takes maps of any width (beyond 125 / 93 / 61 columns -- unfused / with the 1x1 / 128 channels -- as column strips).   (0..2047)
+ *                             2048  (with 1) the fine_matcher's five linear layers (xfh_refine_matches, xfh_fine_matcher) on linear_fx_kernel
+ *                           conv_rs64_kernel takes maps of any width (beyond 125 / 93 / 61 columns -- unfused / with the 1x1 / 128 channels -- as column strips).   (0..4095)
  *   "block1"        0..7    DEFAULT 7.  0 / 5 = block1 on the vector ALUs (conv1 recomputed inside conv2, no c1 tile in LDS; the range fallback), 1 / 3 / 4 = earlier forms
  *                           writing a c1 tile; 6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too
  *                           (6 and 7 set XFH_STATUS_FX_RANGE like "fx")

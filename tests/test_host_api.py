@@ -145,7 +145,7 @@ def test_range_fallback_lands_on_fp32_range_forms_whatever_the_defaults_are(monk
     shipped defaults and for the ones the next round's probe points at (block1 = 7, fp16-pair heads), without a GPU (options are remembered until a handle exists)."""
     import warnings
     from accelerated_features_amd import XFeat, xfeat as xm
-    for defaults, overrides in (((3, 2, 0), {}), ((11, 0, 7), {}), ((1931, 0, 7), {}), ((3, 2, 0), {"fx": 11, "heads_f32": 0, "block1": 7}), ((3, 2, 0), {"heads_f32": 1}), ((0, 2, 0), {"block1": 6})):
+    for defaults, overrides in (((3, 2, 0), {}), ((11, 0, 7), {}), ((1931, 0, 7), {}), ((3979, 0, 7), {}), ((3, 2, 0), {"fx": 11, "heads_f32": 0, "block1": 7}), ((3, 2, 0), {"heads_f32": 1}), ((0, 2, 0), {"block1": 6})):
         monkeypatch.setattr(xm, "DEFAULT_FX", defaults[0]); monkeypatch.setattr(xm, "DEFAULT_HEADS_F32", defaults[1]); monkeypatch.setattr(xm, "DEFAULT_BLOCK1", defaults[2])
         net = XFeat(weights=None).net
         for k, v in overrides.items():

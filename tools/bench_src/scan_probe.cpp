@@ -48,6 +48,8 @@ struct Lib {
     size_t (*backbone_ws)(int, int, int, int) = nullptr;
     int (*match)(H, const float*, size_t, const float*, size_t, const uint16_t*, const uint16_t*, const int32_t*, const int32_t*, int, int, int, int, int, float, int64_t*, int64_t*, int32_t*, void*, size_t, void*) = nullptr;
     size_t (*match_ws)(int, int, int) = nullptr;
+    int (*fine)(H, const float*, int, float*, void*, size_t, void*) = nullptr;
+    size_t (*refine_ws)(int, int) = nullptr;
     const char* (*last_error)() = nullptr;
 };
 static bool open_lib(Lib& L, const std::string& path, const std::vector<const float*>& ptrs) {
@@ -56,6 +58,7 @@ static bool open_lib(Lib& L, const std::string& path, const std::vector<const fl
 #define SYM(f, name) L.f = reinterpret_cast<decltype(L.f)>(dlsym(L.so, name)); if (!L.f) { printf("%s: missing %s\n", path.c_str(), name); return false; }
     SYM(conv_layer, "xfh_conv_layer") SYM(cold, "xfh_debug_cold_start") SYM(block1, "xfh_debug_block1") SYM(head_soak, "xfh_debug_head_soak") SYM(backbone, "xfh_backbone")
     SYM(backbone_ws, "xfh_backbone_workspace_bytes") SYM(match, "xfh_match_mnn") SYM(match_ws, "xfh_match_workspace_bytes") SYM(last_error, "xfh_last_error")
+    SYM(fine, "xfh_fine_matcher") SYM(refine_ws, "xfh_refine_workspace_bytes")
     auto create = reinterpret_cast<int (*)(const float* const*, int, int, H*)>(dlsym(L.so, "xfh_create"));
     if (!create || create(ptrs.data(), (int)ptrs.size(), 0, &L.h)) { printf("%s: xfh_create failed: %s\n", path.c_str(), L.last_error ? L.last_error() : "?"); return false; }
     return true;
@@ -123,13 +126,14 @@ int main(int argc, char** argv) {
                     {"conv_rs64_kernel<0> (block4.1)", 11, 0, 16, 64, 64, 1}, {"conv_bx64s2x_kernel<2> (block5.0)", 13, 0, 16, 64, 128, 2},
                     {"conv_rs64_kernel<0,128> (block5.1)", 14, 0, 32, 128, 128, 1}, {"conv_rs64_kernel<0> (block_fusion.0)", 17, 0, 8, 64, 64, 1},
                     {"conv_rs64_kernel<2> (block_fusion.1 + .2)", 18, 14, 8, 64, 64, 1}};
+    const bool only_fine = argc > 5 && !strcmp(argv[5], "fine");      // (a later visit for one kernel added after the round's scan: the control + linear_fx_kernel alone)
     const int nk = (int)(sizeof(ks) / sizeof(ks[0])), NEXTRA = 4;      // + block1_mx<7>, the fp16-pair heads (whole backbone), mnn_f16_sweep (+ refine)
     std::vector<std::vector<long>> wrong(nk + NEXTRA, std::vector<long>(16, -1));
     std::vector<long> runs(nk + NEXTRA, 0);
     for (int pos = 0; pos < 16; ++pos) {
         Lib L;
         if (!open_lib(L, dir + (pos ? "/libxfeat_hip_shift" + std::to_string(pos) + ".so" : "/libxfeat_hip.so"), ptrs)) { printf("position %d: library missing -- skipped\n", pos); continue; }
-        for (int ki = 0; ki < nk; ++ki) {
+        for (int ki = 0; ki < (only_fine ? 0 : nk); ++ki) {
             const K& k = ks[ki];
             const int hin = Hh / k.div, win = W / k.div, ho = (hin - 1) / k.stride + 1, wo = (win - 1) / k.stride + 1;
             const size_t nin = (size_t)B * k.cin * hin * win, nout = (size_t)B * k.cout * ho * wo;
@@ -152,7 +156,7 @@ int main(int argc, char** argv) {
             wrong[ki][pos] = take_total(); runs[ki] = N;
             HIPCHK(hipFree(x)); HIPCHK(hipFree(y)); HIPCHK(hipFree(want));
         }
-        {   // block1_mx_kernel<7> alone
+        if (!only_fine) {   // block1_mx_kernel<7> alone
             const size_t npx = (size_t)B * Hh * W, nx1 = (size_t)B * 24 * (Hh / 4) * (W / 4);
             auto hgray = rnd(npx, 1, 0.f, 1.f);
             std::vector<float> hcoef(2 * B);
@@ -175,7 +179,7 @@ int main(int argc, char** argv) {
             wrong[nk][pos] = take_total(); runs[nk] = n1;
             HIPCHK(hipFree(gray)); HIPCHK(hipFree(coef)); HIPCHK(hipFree(x1)); HIPCHK(hipFree(want));
         }
-        {   // the whole backbone (every kernel above once more in sequence + both fp16-pair heads): feats and heat against the quiet run, B = 8
+        if (!only_fine) {   // the whole backbone (every kernel above once more in sequence + both fp16-pair heads): feats and heat against the quiet run, B = 8
             const int Bb = 8;
             const size_t np8 = (size_t)Bb * Hh * W, nc8 = (size_t)Bb * (Hh / 8) * (W / 8), wsb = L.backbone_ws(Bb, 3, Hh, W);
             auto himg = rnd(3 * np8, 11, 0.f, 1.f);
@@ -200,7 +204,7 @@ int main(int argc, char** argv) {
             wrong[nk + 1][pos] = take_total(); runs[nk + 1] = nb;
             HIPCHK(hipFree(img)); HIPCHK(hipFree(feats)); HIPCHK(hipFree(heat)); HIPCHK(hipFree(rel)); HIPCHK(hipFree(ws)); HIPCHK(hipFree(wf)); HIPCHK(hipFree(wh));
         }
-        {   // the matcher: mnn_f16_sweep_kernel (cold hook in the shifted builds only) + refine, 8 pairs of 2048 unit rows: match lists against the quiet run
+        if (!only_fine) {   // the matcher: mnn_f16_sweep_kernel (cold hook in the shifted builds only) + refine, 8 pairs of 2048 unit rows: match lists against the quiet run
             const int P = 8, Nk = 2048;
             auto hd = rnd((size_t)2 * P * Nk * 64, 77, -1.f, 1.f);
             for (size_t r = 0; r < (size_t)2 * P * Nk; ++r) { double s = 0; for (int c = 0; c < 64; ++c) s += (double)hd[r * 64 + c] * hd[r * 64 + c]; const float inv = (float)(1.0 / std::sqrt(s)); for (int c = 0; c < 64; ++c) hd[r * 64 + c] *= inv; }
@@ -230,11 +234,33 @@ int main(int argc, char** argv) {
             wrong[nk + 2][pos] = take_total(); runs[nk + 2] = nmr;
             HIPCHK(hipFree(d)); HIPCHK(hipFree(i0)); HIPCHK(hipFree(i1)); HIPCHK(hipFree(w0)); HIPCHK(hipFree(w1)); HIPCHK(hipFree(nm)); HIPCHK(hipFree(wn)); HIPCHK(hipFree(ws));
         }
+        {   // the fine_matcher (xfh_fine_matcher: linear_fx_kernel<128, rowmajor> + 4 x <512, rowmajor>): 20 000 rows of 128 features
+            const int n = 20000;
+            auto hx = rnd((size_t)n * 128, 31, -0.3f, 0.3f);
+            float *x, *o, *want; void* ws;
+            const size_t wsb = L.refine_ws(1, n);
+            HIPCHK(hipMalloc(&x, (size_t)n * 128 * 4)); HIPCHK(hipMalloc(&o, (size_t)n * 64 * 4)); HIPCHK(hipMalloc(&want, (size_t)n * 64 * 4)); HIPCHK(hipMalloc(&ws, wsb));
+            HIPCHK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+            L.cold(0);
+            if (L.fine(L.h, x, n, want, ws, wsb, nullptr)) printf("fine_matcher: %s\n", L.last_error());
+            HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemset(total, 0, 4));
+            L.cold(1);
+            const int nf = std::max(200, N / 5);
+            for (int i = 0; i < nf; ++i) {
+                L.fine(L.h, x, n, o, ws, wsb, nullptr);
+                cmp_kernel<<<256, 256>>>(reinterpret_cast<const uint4*>(o), reinterpret_cast<const uint4*>(want), (size_t)n * 16, flag);
+                tally_kernel<<<1, 1>>>(flag, total);
+            }
+            L.cold(0);
+            HIPCHK(hipDeviceSynchronize());
+            wrong[nk + 3][pos] = take_total(); runs[nk + 3] = nf;
+            HIPCHK(hipFree(x)); HIPCHK(hipFree(o)); HIPCHK(hipFree(want)); HIPCHK(hipFree(ws));
+        }
         printf("position %2d done\n", pos);
     }
-    const char* extra[NEXTRA] = {"block1_mx_kernel<7>", "whole backbone incl. head_bx_kernel<.., fx> x 2 (B = 8)", "xfh_match_mnn: mnn_f16_sweep + refine (match lists of 8 pairs; cold hook at positions 1-15)", ""};
+    const char* extra[NEXTRA] = {"block1_mx_kernel<7>", "whole backbone incl. head_bx_kernel<.., fx> x 2 (B = 8)", "xfh_match_mnn: mnn_f16_sweep + refine (match lists of 8 pairs; cold hook at positions 1-15)", "xfh_fine_matcher: linear_fx_kernel x 5 (20 000 rows; x 5 launches each)"};
     printf("\ncold-started launches with a result that differs from the quiet one, per code position 0 .. 15 (-1 = library missing):\n");
-    for (int ki = 0; ki < nk + NEXTRA - 1; ++ki) {
+    for (int ki = (only_fine ? nk + 3 : 0); ki < nk + NEXTRA; ++ki) {
         std::string line; long tot = 0;
         for (int p = 0; p < 16; ++p) { line += " " + std::to_string(wrong[ki][p]); tot += std::max(0l, wrong[ki][p]); }
         printf("%-66s %6ld launches per position:%s   (total wrong %ld)\n", ki < nk ? ks[ki].name : extra[ki - nk], runs[ki], line.c_str(), tot);
