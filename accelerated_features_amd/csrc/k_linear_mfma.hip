@@ -174,13 +174,18 @@ int launch_linear_mfma(const float* w_kn, const float* bias, int K, int N, int n
 // 512 x 512 layer).  Same orientation as above (A = x: lane = row, B = W: lane = column), same epilogue; the accumulator runs at scale 2^11.
 template <int K, int LOADER>
 __global__ __launch_bounds__(256) void linear_fx_kernel(const uint4* __restrict__ wq, const float* __restrict__ bias, int N, int relu, LinSrc s, int M,
-                                                        const int32_t* __restrict__ m_dev, float* __restrict__ y, int ldy, int* __restrict__ status, int cold) {
+                                                        const int32_t* __restrict__ m_dev, float* __restrict__ y, int ldy, int* __restrict__ status, int cold,
+                                                        int n_row_blocks, int n_col_blocks) {
     kernel_entry_hooks(cold);      // debug: code-position shift / cold instruction cache (common.hpp)
     constexpr int KC = 32, NKC = K / KC, NS = K / 16, ROWS = 256, XB = 80;
     __shared__ __attribute__((aligned(16))) unsigned char Xh[ROWS * XB];
     __shared__ __attribute__((aligned(16))) unsigned char Xl[ROWS * XB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    const int row0 = blockIdx.x * ROWS, nb = blockIdx.y, n0 = nb * 64;
+    // XCD-aware mapping (common.hpp): the column blocks of ONE row block run on one XCD, next to each other in time -- its rows come from HBM once and from that XCD's L2 for the
+    // other column blocks (a 512-column layer reads every row eight times; PMC: the waves of the plain 2-D grid were parked 47 % of their cycles, on these loads)
+    int rbk, nb;
+    if (!xcd_group_map((int)blockIdx.x, n_col_blocks, n_row_blocks, rbk, nb)) return;      // (n_row_blocks is padded to a multiple of 8: the padding workgroups leave)
+    const int row0 = rbk * ROWS, n0 = nb * 64;
     int Mlive = M;
     if (m_dev) Mlive = min(M, *m_dev);
     if (row0 >= Mlive) return;
@@ -306,12 +311,13 @@ int launch_linear_fx(const void* w_fx, const float* bias, int K, int N, int n_pa
                      float* y, int ldy, hipStream_t st, int* status) {
     if (M <= 0) return 0;
     if (!w_fx || n_pad % 64) return -1;
-    const dim3 g(ceil_div(M, 256), n_pad / 64);
+    const int nrb = (ceil_div(M, 256) + 7) / 8 * 8, ncb = n_pad / 64;      // row blocks padded to a multiple of 8: one XCD per row block (xcd_group_map)
+    const dim3 g(xcd_grid_size(ncb, nrb));
     const uint4* wq = reinterpret_cast<const uint4*>(w_fx);
     const int r = relu ? 1 : 0;
-    if (K == 128 && loader == LOAD_GATHER2) { linear_fx_kernel<128, LOAD_GATHER2><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold); return 0; }
-    if (K == 128 && loader == LOAD_ROWMAJOR) { linear_fx_kernel<128, LOAD_ROWMAJOR><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold); return 0; }
-    if (K == 512 && loader == LOAD_ROWMAJOR) { linear_fx_kernel<512, LOAD_ROWMAJOR><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold); return 0; }
+    if (K == 128 && loader == LOAD_GATHER2) { linear_fx_kernel<128, LOAD_GATHER2><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold, nrb, ncb); return 0; }
+    if (K == 128 && loader == LOAD_ROWMAJOR) { linear_fx_kernel<128, LOAD_ROWMAJOR><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold, nrb, ncb); return 0; }
+    if (K == 512 && loader == LOAD_ROWMAJOR) { linear_fx_kernel<512, LOAD_ROWMAJOR><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold, nrb, ncb); return 0; }
     return -1;
 }
 
