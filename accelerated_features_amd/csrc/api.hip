@@ -830,11 +830,29 @@ size_t xfh_refine_workspace_bytes(int P, int N) {
     return carve_refine(nullptr, P, N, o);
 }
 
-// one fine_matcher layer: the fp16-pair kernel (option fx bits 1 | 2048, default) where the layer has its fragments, the f32-MFMA kernel otherwise
-static int fine_layer(xfh_handle h, int li, int K, bool relu, LinLoader loader, const LinSrc& src, int M, const int32_t* m_dev, float* y, int ldy, hipStream_t st) {
-    const LinW& f = h->nw.fine[li];
-    if ((h->opt.fx & 2049) == 2049 && f.w_fx && !launch_linear_fx(f.w_fx, f.bias, K, f.n, f.n_pad, relu, loader, src, M, m_dev, y, ldy, st, h->status)) return 0;
-    return launch_linear_mfma(f.w_kn, f.bias, K, f.n, f.n_pad, relu, loader, src, M, m_dev, y, ldy, st);
+// the fine_matcher's five layers (modules/model.py:97-111).  Option fx bits 1 | 2048 (default) and every layer with its fragments: the fp16-pair kernels, the activations
+// between them in the split form (linear_fx_body.hpp; the same workspace bytes); otherwise the f32-MFMA kernels.  first: the 128-wide input (fp32 rows or the gather of the
+// two descriptors); y: (M, 64) fp32
+static int fine_chain(xfh_handle h, LinLoader loader, const LinSrc& first, int M, const int32_t* m_dev, float* actA, float* actB, float* y, hipStream_t st) {
+    const LinW* f = h->nw.fine;
+    bool fx = (h->opt.fx & 2049) == 2049;
+    for (int li = 0; li < 5; ++li) fx = fx && f[li].w_fx && (li == 0 || li == 4 || f[li].n_pad % 128 == 0);
+    float* bufs[2] = {actA, actB};
+    int bad = 0;
+    LinSrc r{};
+    r.ldx = 512;
+    for (int li = 0; li < 5; ++li) {
+        const int K = li ? 512 : 128;
+        const bool relu = li < 4;
+        float* dst = li < 4 ? bufs[li & 1] : y;
+        const int ldy = li < 4 ? 512 : 64;
+        const LinSrc& src = li ? r : first;
+        const LinLoader ld = li ? LOAD_ROWMAJOR : loader;
+        if (fx) bad |= launch_linear_fx(f[li].w_fx, f[li].bias, K, f[li].n, f[li].n_pad, relu, ld, src, M, m_dev, dst, ldy, st, h->status, li > 0, li < 4);
+        else bad |= launch_linear_mfma(f[li].w_kn, f[li].bias, K, f[li].n, f[li].n_pad, relu, ld, src, M, m_dev, dst, ldy, st);
+        r.x = dst;
+    }
+    return bad;
 }
 
 int xfh_refine_matches(xfh_handle h, const float* desc0, const float* desc1, const float* kp0, const float* kp1,
@@ -853,17 +871,8 @@ int xfh_refine_matches(xfh_handle h, const float* desc0, const float* desc1, con
     launch_refine_rowmap(n_matches, P, N, w.offs, w.rowmap, w.total, st);
     LinSrc g{};
     g.x = desc0; g.x2 = desc1; g.idx0 = idx0; g.idx1 = idx1; g.rowmap = w.rowmap; g.N = N;
-    int bad = fine_layer(h, 0, 128, true, LOAD_GATHER2, g, M, w.total, w.actA, 512, st);
-    LinSrc r{};
-    r.ldx = 512;
-    r.x = w.actA;
-    bad |= fine_layer(h, 1, 512, true, LOAD_ROWMAJOR, r, M, w.total, w.actB, 512, st);
-    r.x = w.actB;
-    bad |= fine_layer(h, 2, 512, true, LOAD_ROWMAJOR, r, M, w.total, w.actA, 512, st);
-    r.x = w.actA;
-    bad |= fine_layer(h, 3, 512, true, LOAD_ROWMAJOR, r, M, w.total, w.actB, 512, st);
-    r.x = w.actB;
-    bad |= fine_layer(h, 4, 512, false, LOAD_ROWMAJOR, r, M, w.total, w.actA, 64, st);
+    // (the last layer's (M, 64) lands in actA, as before: layer 3 wrote actB)
+    const int bad = fine_chain(h, LOAD_GATHER2, g, M, w.total, w.actA, w.actB, w.actA, st);
     if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_refine_matches: missing linear kernel instantiation");
     launch_refine_finish(w.actA, w.rowmap, w.offs, w.total, kp0, kp1, scale0, idx0, idx1, P, N, fine_conf, out, n_out,
                          w.rows, w.keep, st);
@@ -953,15 +962,7 @@ int xfh_fine_matcher(xfh_handle h, const float* x, int n, float* out, void* work
     hipStream_t st = (hipStream_t)stream;
     LinSrc r{};
     r.ldx = 128; r.x = x;
-    int bad = fine_layer(h, 0, 128, true, LOAD_ROWMAJOR, r, n, nullptr, w.actA, 512, st);
-    r.ldx = 512; r.x = w.actA;
-    bad |= fine_layer(h, 1, 512, true, LOAD_ROWMAJOR, r, n, nullptr, w.actB, 512, st);
-    r.x = w.actB;
-    bad |= fine_layer(h, 2, 512, true, LOAD_ROWMAJOR, r, n, nullptr, w.actA, 512, st);
-    r.x = w.actA;
-    bad |= fine_layer(h, 3, 512, true, LOAD_ROWMAJOR, r, n, nullptr, w.actB, 512, st);
-    r.x = w.actB;
-    bad |= fine_layer(h, 4, 512, false, LOAD_ROWMAJOR, r, n, nullptr, out, 64, st);
+    const int bad = fine_chain(h, LOAD_ROWMAJOR, r, n, nullptr, w.actA, w.actB, out, st);
     if (bad) return fail(XFH_ERR_UNSUPPORTED, "xfh_fine_matcher: missing linear kernel instantiation");
     return check_launch("xfh_fine_matcher");
 }

@@ -16,6 +16,7 @@
 // W chunk as [32][NT]; the next chunk is prefetched into registers during the MFMAs.
 #include "kernels.hpp"
 #include "bx_split.hpp"
+#include "linear_fx_body.hpp"
 
 namespace xfh {
 
@@ -167,157 +168,50 @@ int launch_linear_mfma(const float* w_kn, const float* bias, int K, int N, int n
 }
 
 // ------------------------------------------------------------------------------------------
-// The same layer in the fp16-pair arithmetic (bx_split.hpp; round 5): the fine_matcher (modules/model.py:97-111: 128 -> 512 -> 512 -> 512 -> 512 -> 64 on every
-// match of match_xfeat_star) was a fifth of the semi-dense step on the f32 matrix cores (eight v_mfma_f32_32x32x2_f32 = 512 pipe cycles per K = 16); three
-// v_mfma_f32_32x32x16_f16 take 96.  x = xh + 2^-11 xl converted while the chunk is staged (LDS: two fp16 planes, 80-byte rows: conflict-free ds_read_b128 down a
-// column of rows), W as the fragment triple of weight_split.hpp: pack_linear_fx straight from global memory into registers in operand order (L2-resident: 1.5 MB per
-// 512 x 512 layer).  Same orientation as above (A = x: lane = row, B = W: lane = column), same epilogue; the accumulator runs at scale 2^11.
-template <int K, int LOADER>
-__global__ __launch_bounds__(256) void linear_fx_kernel(const uint4* __restrict__ wq, const float* __restrict__ bias, int N, int relu, LinSrc s, int M,
-                                                        const int32_t* __restrict__ m_dev, float* __restrict__ y, int ldy, int* __restrict__ status, int cold,
-                                                        int n_row_blocks, int n_col_blocks) {
+// The same layer in the fp16-pair arithmetic (linear_fx_body.hpp; round 5): the fine_matcher's chain, activations in the split form between its layers.
+template <int K, int IN, int OUT>
+__global__ __launch_bounds__(256, 2) void linear_fx_kernel(LinFxArgs a, int cold) {
     kernel_entry_hooks(cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    constexpr int KC = 32, NKC = K / KC, NS = K / 16, ROWS = 256, XB = 80;
-    __shared__ __attribute__((aligned(16))) unsigned char Xh[ROWS * XB];
-    __shared__ __attribute__((aligned(16))) unsigned char Xl[ROWS * XB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    // XCD-aware mapping (common.hpp): the column blocks of ONE row block run on one XCD, next to each other in time -- its rows come from HBM once and from that XCD's L2 for the
-    // other column blocks (a 512-column layer reads every row eight times; PMC: the waves of the plain 2-D grid were parked 47 % of their cycles, on these loads)
-    int rbk, nb;
-    if (!xcd_group_map((int)blockIdx.x, n_col_blocks, n_row_blocks, rbk, nb)) return;      // (n_row_blocks is padded to a multiple of 8: the padding workgroups leave)
-    const int row0 = rbk * ROWS, n0 = nb * 64;
-    int Mlive = M;
-    if (m_dev) Mlive = min(M, *m_dev);
-    if (row0 >= Mlive) return;
+    linear_fx_body<K, IN, OUT>(a);
+}
 
-    const int q = tid & 7;      // this thread stages 8 rows (tid / 8 + 32 i), always the same float4 column q of the chunk
-    long src0[8], src1[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = row0 + (tid >> 3) + 32 * i;
-        src0[i] = -1; src1[i] = -1;
-        if (row < Mlive) {
-            if (LOADER == LOAD_ROWMAJOR) src0[i] = (long)row * s.ldx + 4 * q;
-            else {
-                const int code = s.rowmap[row];
-                const int p = code / s.N;
-                src0[i] = ((long)p * s.N + (long)s.idx0[code]) * 64 + 4 * q;
-                src1[i] = ((long)p * s.N + (long)s.idx1[code]) * 64 + 4 * q;
-            }
-        }
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-    float4 xreg[8];
-    auto prefetch = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src0[i] >= 0) {
-                if (LOADER == LOAD_ROWMAJOR) v = *reinterpret_cast<const float4*>(s.x + src0[i] + kc * KC);
-                else v = kc < 2 ? *reinterpret_cast<const float4*>(s.x + src0[i] + kc * KC) : *reinterpret_cast<const float4*>(s.x2 + src1[i] + (kc - 2) * KC);
-            }
-            xreg[i] = v;
-        }
-    };
-    const uint4* wp = wq + (size_t)nb * NS * 6 * 64 + lane;
-    unsigned amax = 0;
-    prefetch(0);
-    for (int kc = 0; kc < NKC; ++kc) {
-        // this chunk's weight fragments: [K step 2][fragment 3][column half-block 2], requested before the barriers they travel under
-        f16x8 w[2][3][2];
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) w[st][sp][cb] = __builtin_bit_cast(f16x8, wp[(((size_t)(2 * kc + st) * 3 + sp) * 2 + cb) * 64]);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint2 h, l;
-            split2_f16_scalar(xreg[i].x, xreg[i].y, h.x, l.x);
-            split2_f16_scalar(xreg[i].z, xreg[i].w, h.y, l.y);
-            fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true);
-            const int off = ((tid >> 3) + 32 * i) * XB + 8 * q;
-            *reinterpret_cast<uint2*>(Xh + off) = h;
-            *reinterpret_cast<uint2*>(Xl + off) = l;
-        }
-        __syncthreads();
-        if (kc + 1 < NKC) prefetch(kc + 1);
-        // every matrix operand lives in an accumulation register (the loads write them there directly): registers no vector-ALU result is ever allocated to, so none can land in
-        // an operand the matrix core is still reading (DESIGN 3.1 / tools/check_mfma_war.py) -- the next chunk's conversion follows the last MFMA without idle slots
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) asm volatile("" : "+a"(w[st][sp][cb]));
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            f16x8 ah[2], al[2];
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const int off = (wave * 64 + rb * 32 + l31) * XB + st * 32 + half * 16;
-                ah[rb] = *reinterpret_cast<const f16x8*>(Xh + off);
-                al[rb] = *reinterpret_cast<const f16x8*>(Xl + off);
-            }
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) { asm volatile("" : "+a"(ah[rb])); asm volatile("" : "+a"(al[rb])); }
-            // q2 xh + q1 xl + q0 xh (bx_split.hpp), the four accumulators in turn
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], w[st][2][cb], acc[rb][cb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[rb], w[st][1][cb], acc[rb][cb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[rb], w[st][0][cb], acc[rb][cb], 0, 0, 0);
-        }
-    }
-    float bs[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) bs[c] = bias[n0 + c * 32 + l31];           // (bias is padded to n_pad)
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + wave * 64 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (row < Mlive) {
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const int col = n0 + c * 32 + l31;
-                    if (col < N) {
-                        float v = fmaf(acc[rb][c][r], FX_SCALE_INV, bs[c]);
-                        if (relu) v = fmaxf(v, 0.f);
-                        y[(size_t)row * ldy + col] = v;
-                    }
-                }
-            }
-        }
-    fx_report_h(amax, status);
+template <int K>
+__global__ __launch_bounds__(512, 2) void linear_fxd_kernel(LinFxArgs a, int cold) {
+    kernel_entry_hooks(cold);
+    linear_fxd_body<K>(a);
 }
 
 int launch_linear_fx(const void* w_fx, const float* bias, int K, int N, int n_pad, bool relu, LinLoader loader, const LinSrc& src, int M, const int32_t* m_dev,
-                     float* y, int ldy, hipStream_t st, int* status) {
+                     void* y, int ldy, hipStream_t st, int* status, bool in_pair, bool out_pair) {
     if (M <= 0) return 0;
     if (!w_fx || n_pad % 64) return -1;
-    const int nrb = (ceil_div(M, 256) + 7) / 8 * 8, ncb = n_pad / 64;      // row blocks padded to a multiple of 8: one XCD per row block (xcd_group_map)
-    const dim3 g(xcd_grid_size(ncb, nrb));
-    const uint4* wq = reinterpret_cast<const uint4*>(w_fx);
-    const int r = relu ? 1 : 0;
-    if (K == 128 && loader == LOAD_GATHER2) { linear_fx_kernel<128, LOAD_GATHER2><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold, nrb, ncb); return 0; }
-    if (K == 128 && loader == LOAD_ROWMAJOR) { linear_fx_kernel<128, LOAD_ROWMAJOR><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold, nrb, ncb); return 0; }
-    if (K == 512 && loader == LOAD_ROWMAJOR) { linear_fx_kernel<512, LOAD_ROWMAJOR><<<g, 256, 0, st>>>(wq, bias, N, r, src, M, m_dev, y, ldy, status, g_debug_cold, nrb, ncb); return 0; }
+    if (out_pair ? (N != n_pad || ldy % 8) : (N % 4 || ldy % 4)) return -1;      // (the epilogues store 16 bytes at a time)
+    if (in_pair && (loader != LOAD_ROWMAJOR || src.ldx % 8)) return -1;
+    LinFxArgs a{};
+    a.wq = reinterpret_cast<const uint4*>(w_fx); a.bias = bias; a.N = N; a.relu = relu ? 1 : 0;
+    a.x = src.x; a.ldx = src.ldx; a.x2 = src.x2; a.idx0 = src.idx0; a.idx1 = src.idx1; a.rowmap = src.rowmap; a.cap = src.N;
+    a.M = M; a.m_dev = m_dev; a.y = y; a.ldy = ldy; a.status = status;
+    a.n_row_blocks = (ceil_div(M, 256) + 7) / 8 * 8;      // row blocks padded to a multiple of 8: one XCD per row block (xcd_group_map)
+    a.n_col_blocks = n_pad / 64;
+    const dim3 g(xcd_grid_size(a.n_col_blocks, a.n_row_blocks));
+#define XFH_LFX(KV, INV, OUTV)                                                                                              \
+    do {                                                                                                                    \
+        static AttrMask done{0};                                                                                            \
+        set_max_dynamic_lds(reinterpret_cast<const void*>(&linear_fx_kernel<KV, INV, OUTV>), linfx::LDS_BYTES, done);       \
+        linear_fx_kernel<KV, INV, OUTV><<<g, 256, linfx::LDS_BYTES, st>>>(a, g_debug_cold);                                 \
+        return 0;                                                                                                           \
+    } while (0)
+    if (K == 128 && !in_pair && out_pair && loader == LOAD_GATHER2) XFH_LFX(128, LFX_IN_GATHER2, LFX_OUT_PAIR);
+    if (K == 128 && !in_pair && out_pair && loader == LOAD_ROWMAJOR) XFH_LFX(128, LFX_IN_F32, LFX_OUT_PAIR);
+    if (K == 512 && in_pair && out_pair && n_pad % 128 == 0) {      // the chain's inner layers: 256 x 128 tiles, every operand by LDS-DMA
+        a.n_col_blocks = n_pad / 128;
+        static AttrMask done{0};
+        set_max_dynamic_lds(reinterpret_cast<const void*>(&linear_fxd_kernel<512>), linfxd::LDS_BYTES, done);
+        linear_fxd_kernel<512><<<dim3(xcd_grid_size(a.n_col_blocks, a.n_row_blocks)), linfxd::THREADS, linfxd::LDS_BYTES, st>>>(a, g_debug_cold);
+        return 0;
+    }
+    if (K == 512 && in_pair && !out_pair) XFH_LFX(512, LFX_IN_PAIR, LFX_OUT_F32);
+#undef XFH_LFX
     return -1;
 }
 

@@ -136,10 +136,11 @@ struct LinSrc {
 int launch_linear_mfma(const float* w_kn, const float* bias, int K, int N, int n_pad, bool relu,
                        LinLoader loader, const LinSrc& src, int M, const int32_t* m_dev,
                        float* y, int ldy, hipStream_t st);
-// the same layer in the fp16-pair arithmetic (bx_split.hpp): three fp16 MFMAs per K = 16 instead of eight f32 MFMAs, fp32-equivalent results; K = 128 (ROWMAJOR / GATHER2) or 512
-// (ROWMAJOR), n_pad a multiple of 64.  status: range guard of the pair.  -1: no instantiation
+// the same layer in the fp16-pair arithmetic (linear_fx_body.hpp): three fp16 MFMAs per K = 16 instead of eight f32 MFMAs, fp32-equivalent results.  in_pair / out_pair: the
+// rows are in the split form [ld halves xh | ld halves xl] (the bytes of an fp32 row of ld values) -- the fine_matcher's chain: 128 (fp32: ROWMAJOR / GATHER2) -> pair ->
+// ... -> pair -> fp32.  n_pad a multiple of 64.  status: range guard of the pair.  -1: no instantiation
 int launch_linear_fx(const void* w_fx, const float* bias, int K, int N, int n_pad, bool relu, LinLoader loader, const LinSrc& src, int M, const int32_t* m_dev,
-                     float* y, int ldy, hipStream_t st, int* status);
+                     void* y, int ldy, hipStream_t st, int* status, bool in_pair, bool out_pair);
 // reliability = sigmoid(x . w + b) per row of x (M,64)                     (model.py:82-83)
 void launch_dot_sigmoid(const float* x, int M, const float* w, const float* b, float* out, hipStream_t st);
 // heat (B,H,W) <- softmax over 65 logits per cell, depth-to-space 8x8       (xfeat.py:242-247)
