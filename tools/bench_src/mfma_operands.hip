@@ -42,12 +42,16 @@ int main() {
     hipMalloc(&out, 512 * 256 * sizeof(float));
     hipMalloc(&cyc, 512 * 4 * sizeof(long long));
     std::vector<long long> h(512 * 4);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto run = [&](const char* name, auto kern, int nb) {
-        for (int rep = 0; rep < 2; ++rep) { hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, 0, out, cyc, iters); hipDeviceSynchronize(); }
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) { hipEventRecord(e0); hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, 0, out, cyc, iters * (rep ? 50 : 1)); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1); }
         hipMemcpy(h.data(), cyc, nb * 4 * sizeof(long long), hipMemcpyDeviceToHost);
         double c = 0; for (int i = 0; i < nb * 4; ++i) c += (double)h[i];
-        const double per = c / (nb * 4.0 * iters * 8);
-        printf("%-34s %d wave(s) per SIMD: %7.2f cycles per MFMA of a wave, %7.2f per MFMA of the SIMD\n", name, nb / 256, per, per / (nb / 256));
+        const double per = c / (nb * 4.0 * iters * 50 * 8);
+        // (the second launch runs 50 x as long: its s_memtime count against the wall clock of the launch = the rate the counter ticks at, with every matrix pipe of the chip busy)
+        printf("%-34s %d wave(s) per SIMD: %7.2f counts per MFMA of a wave, %7.2f per MFMA of the SIMD; %.0f counts in %.3f ms = %.2f GHz\n", name, nb / 256, per, per / (nb / 256),
+               c / (nb * 4.0), ms, c / (nb * 4.0) / ms / 1e6);
     };
     for (int nb : {256, 512}) {
         run("A, B in VGPRs, C in AGPRs", k<0>, nb);
