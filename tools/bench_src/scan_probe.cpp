@@ -50,6 +50,7 @@ struct Lib {
     size_t (*match_ws)(int, int, int) = nullptr;
     int (*fine)(H, const float*, int, float*, void*, size_t, void*) = nullptr;
     size_t (*refine_ws)(int, int) = nullptr;
+    int (*refine)(H, const float*, const float*, const float*, const float*, const float*, const int64_t*, const int64_t*, const int32_t*, int, int, float, float*, int32_t*, void*, size_t, void*) = nullptr;
     const char* (*last_error)() = nullptr;
 };
 static bool open_lib(Lib& L, const std::string& path, const std::vector<const float*>& ptrs) {
@@ -58,7 +59,7 @@ static bool open_lib(Lib& L, const std::string& path, const std::vector<const fl
 #define SYM(f, name) L.f = reinterpret_cast<decltype(L.f)>(dlsym(L.so, name)); if (!L.f) { printf("%s: missing %s\n", path.c_str(), name); return false; }
     SYM(conv_layer, "xfh_conv_layer") SYM(cold, "xfh_debug_cold_start") SYM(block1, "xfh_debug_block1") SYM(head_soak, "xfh_debug_head_soak") SYM(backbone, "xfh_backbone")
     SYM(backbone_ws, "xfh_backbone_workspace_bytes") SYM(match, "xfh_match_mnn") SYM(match_ws, "xfh_match_workspace_bytes") SYM(last_error, "xfh_last_error")
-    SYM(fine, "xfh_fine_matcher") SYM(refine_ws, "xfh_refine_workspace_bytes")
+    SYM(fine, "xfh_fine_matcher") SYM(refine_ws, "xfh_refine_workspace_bytes") SYM(refine, "xfh_refine_matches")
     auto create = reinterpret_cast<int (*)(const float* const*, int, int, H*)>(dlsym(L.so, "xfh_create"));
     if (!create || create(ptrs.data(), (int)ptrs.size(), 0, &L.h)) { printf("%s: xfh_create failed: %s\n", path.c_str(), L.last_error ? L.last_error() : "?"); return false; }
     return true;
@@ -127,7 +128,7 @@ int main(int argc, char** argv) {
                     {"conv_rs64_kernel<0,128> (block5.1)", 14, 0, 32, 128, 128, 1}, {"conv_rs64_kernel<0> (block_fusion.0)", 17, 0, 8, 64, 64, 1},
                     {"conv_rs64_kernel<2> (block_fusion.1 + .2)", 18, 14, 8, 64, 64, 1}};
     const bool only_fine = argc > 5 && !strcmp(argv[5], "fine");      // (a later visit for one kernel added after the round's scan: the control + linear_fx_kernel alone)
-    const int nk = (int)(sizeof(ks) / sizeof(ks[0])), NEXTRA = 4;      // + block1_mx<7>, the fp16-pair heads (whole backbone), mnn_f16_sweep (+ refine)
+    const int nk = (int)(sizeof(ks) / sizeof(ks[0])), NEXTRA = 5;      // + block1_mx<7>, the fp16-pair heads (whole backbone), mnn_f16_sweep (+ refine)
     std::vector<std::vector<long>> wrong(nk + NEXTRA, std::vector<long>(16, -1));
     std::vector<long> runs(nk + NEXTRA, 0);
     for (int pos = 0; pos < 16; ++pos) {
@@ -234,7 +235,7 @@ int main(int argc, char** argv) {
             wrong[nk + 2][pos] = take_total(); runs[nk + 2] = nmr;
             HIPCHK(hipFree(d)); HIPCHK(hipFree(i0)); HIPCHK(hipFree(i1)); HIPCHK(hipFree(w0)); HIPCHK(hipFree(w1)); HIPCHK(hipFree(nm)); HIPCHK(hipFree(wn)); HIPCHK(hipFree(ws));
         }
-        {   // the fine_matcher (xfh_fine_matcher: linear_fx_kernel<128, rowmajor> + 4 x <512, rowmajor>): 20 000 rows of 128 features
+        {   // the fine_matcher chain: 20 000 rows of 128 features
             const int n = 20000;
             auto hx = rnd((size_t)n * 128, 31, -0.3f, 0.3f);
             float *x, *o, *want; void* ws;
@@ -254,11 +255,44 @@ int main(int argc, char** argv) {
             L.cold(0);
             HIPCHK(hipDeviceSynchronize());
             wrong[nk + 3][pos] = take_total(); runs[nk + 3] = nf;
+            // xfh_refine_matches on the same numbers (the first layer as linear_fx_kernel<128, gather>): desc0 = columns 0..63 of x's first half of rows, desc1 = the second half,
+            // every row matched with itself, fine_conf = -1 (every row kept): the (n / 2, 4) rows and the count against the quiet run
+            {
+                const int n2 = n / 2;
+                std::vector<int64_t> hid(n2); for (int r = 0; r < n2; ++r) hid[r] = (r * 7919) % n2;
+                auto hk = rnd((size_t)n2 * 2, 41, 0.f, 600.f);
+                std::vector<float> hs(n2, 1.f);
+                int64_t *i0, *i1; float *k0, *k1, *sc, *ro, *rw; int32_t *nm, *no, *nw;
+                HIPCHK(hipMalloc(&i0, (size_t)n2 * 8)); HIPCHK(hipMalloc(&i1, (size_t)n2 * 8)); HIPCHK(hipMalloc(&k0, (size_t)n2 * 8)); HIPCHK(hipMalloc(&k1, (size_t)n2 * 8)); HIPCHK(hipMalloc(&sc, (size_t)n2 * 4));
+                HIPCHK(hipMalloc(&ro, (size_t)n2 * 16)); HIPCHK(hipMalloc(&rw, (size_t)n2 * 16)); HIPCHK(hipMalloc(&nm, 16)); HIPCHK(hipMalloc(&no, 16)); HIPCHK(hipMalloc(&nw, 16));
+                HIPCHK(hipMemcpy(i0, hid.data(), (size_t)n2 * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(i1, hid.data(), (size_t)n2 * 8, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(k0, hk.data(), (size_t)n2 * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(k1, hk.data(), (size_t)n2 * 8, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(sc, hs.data(), (size_t)n2 * 4, hipMemcpyHostToDevice));
+                const int32_t hn[4] = {n2, 0, 0, 0};
+                HIPCHK(hipMemcpy(nm, hn, 16, hipMemcpyHostToDevice)); HIPCHK(hipMemset(no, 0, 16)); HIPCHK(hipMemset(nw, 0, 16));
+                HIPCHK(hipMemset(ro, 0, (size_t)n2 * 16)); HIPCHK(hipMemset(rw, 0, (size_t)n2 * 16));
+                auto rr = [&](float* out, int32_t* nout) { return L.refine(L.h, x, x + (size_t)n2 * 64, k0, k1, sc, i0, i1, nm, 1, n2, -1.f, out, nout, ws, wsb, nullptr); };
+                L.cold(0);
+                if (rr(rw, nw)) printf("refine_matches: %s\n", L.last_error());
+                HIPCHK(hipDeviceSynchronize()); HIPCHK(hipMemset(total, 0, 4));
+                L.cold(1);
+                for (int i = 0; i < nf; ++i) {
+                    HIPCHK(hipMemsetAsync(ro, 0, (size_t)n2 * 16, nullptr));
+                    rr(ro, no);
+                    cmp_kernel<<<64, 256>>>(reinterpret_cast<const uint4*>(ro), reinterpret_cast<const uint4*>(rw), (size_t)n2, flag);
+                    cmp_kernel<<<1, 64>>>(reinterpret_cast<const uint4*>(no), reinterpret_cast<const uint4*>(nw), 1, flag);
+                    tally_kernel<<<1, 1>>>(flag, total);
+                }
+                L.cold(0);
+                HIPCHK(hipDeviceSynchronize());
+                wrong[nk + 4][pos] = take_total(); runs[nk + 4] = nf;
+                HIPCHK(hipFree(i0)); HIPCHK(hipFree(i1)); HIPCHK(hipFree(k0)); HIPCHK(hipFree(k1)); HIPCHK(hipFree(sc)); HIPCHK(hipFree(ro)); HIPCHK(hipFree(rw)); HIPCHK(hipFree(nm)); HIPCHK(hipFree(no)); HIPCHK(hipFree(nw));
+            }
             HIPCHK(hipFree(x)); HIPCHK(hipFree(o)); HIPCHK(hipFree(want)); HIPCHK(hipFree(ws));
         }
         printf("position %2d done\n", pos);
     }
-    const char* extra[NEXTRA] = {"block1_mx_kernel<7>", "whole backbone incl. head_bx_kernel<.., fx> x 2 (B = 8)", "xfh_match_mnn: mnn_f16_sweep + refine (match lists of 8 pairs; cold hook at positions 1-15)", "xfh_fine_matcher: linear_fx_kernel x 5 (20 000 rows; x 5 launches each)"};
+    const char* extra[NEXTRA] = {"block1_mx_kernel<7>", "whole backbone incl. head_bx_kernel<.., fx> x 2 (B = 8)", "xfh_match_mnn: mnn_f16_sweep + refine (match lists of 8 pairs; cold hook at positions 1-15)", "xfh_fine_matcher: linear_fx_kernel<128, fp32> + 3 x linear_fxd_kernel<512> + linear_fx_kernel<512, pair, fp32> (20 000 rows)", "xfh_refine_matches: the same chain behind linear_fx_kernel<128, gather> (10 000 matches)"};
     printf("\ncold-started launches with a result that differs from the quiet one, per code position 0 .. 15 (-1 = library missing):\n");
     for (int ki = (only_fine ? nk + 3 : 0); ki < nk + NEXTRA; ++ki) {
         std::string line; long tot = 0;
