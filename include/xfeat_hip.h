@@ -106,7 +106,9 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *                             256   the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) on it too
  *                             512   block5.1 and block5.2 on its 128-channel form (block5.3 then runs as a 1x1 of its own)
  *                             1024  the stride-2 64-channel layers (block4.0, block5.0) on conv_bx64s2x_kernel
- *                             2048  (with 1) the fine_matcher's five linear layers (xfh_refine_matches, xfh_fine_matcher) on linear_fx_kernel
+ *                             2048  (with 1) the fine_matcher's five linear layers (xfh_refine_matches, xfh_fine_matcher) as one chain in the fp16-pair arithmetic:
+ *                                   linear_fx_kernel (first / last layer) and linear_fxd_kernel (the 512 -> 512 layers, LDS-DMA), the activations between them as
+ *                                   fp16 pairs in the workspace (csrc/linear_fx_body.hpp); without the bit, or when a layer has a weight beyond the pair's range: f32 MFMAs
  *                           conv_rs64_kernel takes maps of any width (beyond 125 / 93 / 61 columns -- unfused / with the 1x1 / 128 channels -- as column strips).   (0..4095)
  *   "block1"        0..7    DEFAULT 7.  0 / 5 = block1 on the vector ALUs (conv1 recomputed inside conv2, no c1 tile in LDS; the range fallback), 1 / 3 / 4 = earlier forms
  *                           writing a c1 tile; 6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too
