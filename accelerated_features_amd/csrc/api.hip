@@ -635,7 +635,7 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     prof_begin(&h->prof, XFH_SPAN_GRAY, st);
     if (rs) {
         if (launch_gray_norm_resized(img, B, C, rs->Hin, rs->Win, rs->Hm, rs->Wm, rs->s1h, rs->s1w, H, W, rs->s2h, rs->s2w, w.part, w.gray,
-                                     w.coef, st))
+                                     w.coef, st, h->opt.resize2))
             return fail(XFH_ERR_UNSUPPORTED, "xfh_backbone_resized: second resize step (%g, %g) must be below 2", rs->s2h, rs->s2w);
     } else if (img_u8) launch_gray_norm_u8(img_u8, u8_layout == XFH_LAYOUT_NHWC, u8_divisor, B, C, H, W, w.part, w.gray, w.coef, st);
     else launch_gray_norm(img, B, C, H, W, w.part, w.gray, w.coef, st);
@@ -979,7 +979,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
     struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
         {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 4095}};
+        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 4095}, {"resize2", &Options::resize2, 0, 1}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
     return nullptr;

@@ -292,16 +292,170 @@ __global__ __launch_bounds__(256) void resize2_gray_stats_kernel(const float* __
     }
 }
 
+// The same with the tile's INPUT region staged in LDS first (round 5; the dense workload's second kernel: 274 us per launch, waves 70 % at s_waitcnt --
+// profiles/r05_pmc_dense_linear_fx.txt -- behind 12 four-byte gathers per intermediate pixel): the rows [iy_lo, iy_hi] x 16-byte-aligned columns that stage 1's taps can touch
+// arrive as 16-byte loads, all of a thread's in flight at once and ONE TILE AHEAD (a twentieth of the requests at scale 1.3, a fifth at 0.6), and stage 1 takes its taps from LDS -- the same
+// values through the same expression: the gray plane stays bit-identical.  Needs Win % 4 == 0 (16-byte-aligned rows); LDS: [mid: C x mid_cap][in: C x in_rows x in_w].
+struct __attribute__((aligned(16))) R2Coef { int i0, i1; float l0, l1; };
+constexpr int R2_NTAB = R2_RH + R2_RW + R2_TH + R2_TW;      // 244 entries <= 256 threads
+static_assert(R2_NTAB <= 256, "one table entry per thread");
+constexpr int R2_MAXL = 12;      // 16-byte requests of a thread per tile: request i = (channel i >> 2, rows r0 + 8 (i & 3)): C <= 3, in_rows <= 32 (48 registers: four waves per SIMD)
+__global__ __launch_bounds__(256, 4) void resize2_gray_stats_lds_kernel(const float* __restrict__ img, int C, int Hin, int Win, int Hm, int Wm,
+                                                                      float s1h, float s1w, int Ho, int Wo, float s2h, float s2w,
+                                                                      double* __restrict__ part, float* __restrict__ gray, int mid_cap, int in_rows, int in_w) {
+    extern __shared__ __attribute__((aligned(16))) float r2sm[];
+    // the interpolation coefficients of a tile, ONE lin_coef per thread and tile instead of thirteen: [stage-1 rows R2_RH][stage-1 columns R2_RW][stage-2 rows][stage-2 columns]
+    R2Coef* tab = reinterpret_cast<R2Coef*>(r2sm);
+    float* mid = r2sm + 4 * R2_NTAB;                                // [C][rh * rw] of the current tile
+    float* inr = mid + (size_t)C * mid_cap;                         // [C][in_rows][in_w] of the input (mid_cap is a multiple of 4: 16-byte aligned)
+    const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+    const int tiles_x = ceil_div(Wo, R2_TW), tiles = tiles_x * ceil_div(Ho, R2_TH);
+    const float fC = (float)C;
+    const size_t plane = (size_t)Hin * Win;
+    const float* base = img + (size_t)b * C * plane;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)((size_t)C * plane * 4), 0x00020000);
+    const int lx = (tid & 15) * 4, ly = tid >> 4;
+    const int qx = tid & 31, r0 = tid >> 5;                        // stage 0: lane (piece qx of a row, rows r0, r0 + 8, ...): no division
+    struct Tile { int oy0, ox0, oy1, ox1, ym0, xm0, rh, rw, iy_lo, ix_lo, nrow, nq; };
+    auto tile_of = [&](int t) {
+        Tile T;
+        T.oy0 = (t / tiles_x) * R2_TH; T.ox0 = (t % tiles_x) * R2_TW;
+        T.oy1 = min(T.oy0 + R2_TH, Ho) - 1; T.ox1 = min(T.ox0 + R2_TW, Wo) - 1;
+        int ym1, xm1, d0, d1, iy_hi, ix_hi; float f0, f1;
+        lin_coef(s2h, T.oy0, Hm, T.ym0, d1, f0, f1);
+        lin_coef(s2h, T.oy1, Hm, d0, ym1, f0, f1);
+        lin_coef(s2w, T.ox0, Wm, T.xm0, d1, f0, f1);
+        lin_coef(s2w, T.ox1, Wm, d0, xm1, f0, f1);
+        T.rh = ym1 - T.ym0 + 1; T.rw = xm1 - T.xm0 + 1;
+        // the input rows / columns stage 1 can touch (lin_coef's indices are monotone in the destination index)
+        lin_coef(s1h, T.ym0, Hin, T.iy_lo, d1, f0, f1);
+        lin_coef(s1h, ym1, Hin, d0, iy_hi, f0, f1);
+        lin_coef(s1w, T.xm0, Win, T.ix_lo, d1, f0, f1);
+        lin_coef(s1w, xm1, Win, d0, ix_hi, f0, f1);
+        T.ix_lo &= ~3;
+        T.nrow = min(iy_hi - T.iy_lo + 1, in_rows); T.nq = min((ix_hi - T.ix_lo) / 4 + 1, in_w / 4);      // (the host sized the region for the steps: the clamps never bind)
+        return T;
+    };
+    uint4 pre[R2_MAXL];
+    // the requests of a tile's input region: all of a thread's in flight at once, and in flight while the PREVIOUS tile is computed
+    auto request = [&](const Tile& T) {
+#pragma unroll
+        for (int i = 0; i < R2_MAXL; ++i) {
+            const int c = i >> 2, r = r0 + 8 * (i & 3);
+            pre[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (c < C && r < T.nrow && qx < T.nq)
+                pre[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((T.iy_lo + r) * Win + T.ix_lo + 4 * qx) * 4, c * (int)(plane * 4), 0));
+        }
+    };
+    double s = 0.0, q = 0.0;
+    Tile T = tile_of(min(ch, tiles - 1));
+    if (ch < tiles) request(T);
+    for (int t = ch; t < tiles; t += GS_CHUNKS) {
+        const int rsz = T.rh * T.rw;
+        __syncthreads();                                            // the previous tile's readers are done
+        // stage 0: the region lands in LDS
+#pragma unroll
+        for (int i = 0; i < R2_MAXL; ++i) {
+            const int c = i >> 2, r = r0 + 8 * (i & 3);
+            if (c < C && r < T.nrow && qx < T.nq) *reinterpret_cast<uint4*>(inr + (c * in_rows + r) * in_w + 4 * qx) = pre[i];
+        }
+        // this thread's entry of the coefficient tables (offsets already in the units the stages index with)
+        {
+            R2Coef cf{0, 0, 0.f, 0.f};
+            if (tid < R2_RH) {
+                if (tid < T.rh) { lin_coef(s1h, T.ym0 + tid, Hin, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 = (cf.i0 - T.iy_lo) * in_w; cf.i1 = (cf.i1 - T.iy_lo) * in_w; }
+            } else if (tid < R2_RH + R2_RW) {
+                const int rx = tid - R2_RH;
+                if (rx < T.rw) { lin_coef(s1w, T.xm0 + rx, Win, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 -= T.ix_lo; cf.i1 -= T.ix_lo; }
+            } else if (tid < R2_RH + R2_RW + R2_TH) {
+                const int oy = T.oy0 + tid - (R2_RH + R2_RW);
+                if (oy <= T.oy1) { lin_coef(s2h, oy, Hm, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 = (cf.i0 - T.ym0) * T.rw; cf.i1 = (cf.i1 - T.ym0) * T.rw; }
+            } else if (tid < R2_NTAB) {
+                const int ox = T.ox0 + tid - (R2_RH + R2_RW + R2_TH);
+                if (ox <= T.ox1) { lin_coef(s2w, ox, Wm, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 -= T.xm0; cf.i1 -= T.xm0; }
+            }
+            if (tid < R2_NTAB) tab[tid] = cf;
+        }
+        Tile Tn = T;
+        if (t + GS_CHUNKS < tiles) { Tn = tile_of(t + GS_CHUNKS); request(Tn); }
+        __syncthreads();
+        const unsigned rw_magic = 0xffffffffu / (unsigned)T.rw + 1u;      // floor(e / rw) = umulhi(e, magic) for e < 2^16 (one division per tile instead of one per pixel)
+        // stage 1: input -> intermediate grid from LDS, all channels of one region pixel per thread (coefficients computed once)
+        for (int e = tid; e < rsz; e += 256) {
+            const int ry = (int)__umulhi((unsigned)e, rw_magic), rx = e - ry * T.rw;
+            const R2Coef cy = tab[ry], cx = tab[R2_RH + rx];
+            const float vy0 = cy.l0, vy1 = cy.l1, vx0 = cx.l0, vx1 = cx.l1;
+            const int o00 = cy.i0 + cx.i0, o01 = cy.i0 + cx.i1, o10 = cy.i1 + cx.i0, o11 = cy.i1 + cx.i1;
+            for (int c = 0; c < C; ++c) {
+                const float* p = inr + (size_t)c * in_rows * in_w;
+                const float v00 = p[o00], v01 = p[o01], v10 = p[o10], v11 = p[o11];
+                mid[c * rsz + e] = vy0 * (vx0 * v00 + vx1 * v01) + vy1 * (vx0 * v10 + vx1 * v11);
+            }
+        }
+        __syncthreads();
+        // stage 2: intermediate -> output grid from LDS, channel mean in gray_stats_kernel's order
+        const int oy = T.oy0 + ly, ox = T.ox0 + lx;
+        if (oy <= T.oy1 && ox <= T.ox1) {
+            const R2Coef cy = tab[R2_RH + R2_RW + ly];
+            const float wy0 = cy.l0, wy1 = cy.l1;
+            float a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] = 0.f;
+                if (ox + k <= T.ox1) {
+                    const R2Coef cx = tab[R2_RH + R2_RW + R2_TH + lx + k];
+                    const float wx0 = cx.l0, wx1 = cx.l1;
+                    const int o00 = cy.i0 + cx.i0, o01 = cy.i0 + cx.i1, o10 = cy.i1 + cx.i0, o11 = cy.i1 + cx.i1;
+                    for (int c = 0; c < C; ++c) {
+                        const float* p = mid + c * rsz;      // (bilerp's expression)
+                        const float v = wy0 * (wx0 * p[o00] + wx1 * p[o01]) + wy1 * (wx0 * p[o10] + wx1 * p[o11]);
+                        a[k] = c == 0 ? v : a[k] + v;
+                    }
+                }
+            }
+            float* g = gray + ((size_t)b * Ho + oy) * Wo + ox;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (ox + k <= T.ox1) {
+                    const float v = a[k] / fC;
+                    g[k] = v;
+                    s += (double)v;
+                    q += (double)v * v;
+                }
+        }
+        T = Tn;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    __shared__ double sm2[8];
+    if ((tid & 63) == 0) { sm2[(tid >> 6) * 2] = s; sm2[(tid >> 6) * 2 + 1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        part[((size_t)b * GS_CHUNKS + ch) * 2 + 0] = sm2[0] + sm2[2] + sm2[4] + sm2[6];
+        part[((size_t)b * GS_CHUNKS + ch) * 2 + 1] = sm2[1] + sm2[3] + sm2[5] + sm2[7];
+    }
+}
+
 // returns -1 when the stage-2 step is too large for the LDS region (callers then materialise the images)
 int launch_gray_norm_resized(const float* img, int B, int C, int Hin, int Win, int Hm, int Wm, float s1h, float s1w, int Ho, int Wo,
-                             float s2h, float s2w, double* part, float* gray, float* coef, hipStream_t st) {
+                             float s2h, float s2w, double* part, float* gray, float* coef, hipStream_t st, int form) {
     if (!(s2h > 0.f) || !(s2w > 0.f) || s2h * (R2_TH - 1) + 3.f > (float)R2_RH || s2w * (R2_TW - 1) + 3.f > (float)R2_RW || C > R2_MAXC || (size_t)C * Hin * Win * 4 >= (1ull << 31)) return -1;
     // LDS: C planes of the largest intermediate region this (s2h, s2w) can need
     const int rh = (int)(s2h * (R2_TH - 1)) + 3, rw = (int)(s2w * (R2_TW - 1)) + 3;
     const size_t lds = (size_t)C * rh * rw * sizeof(float);
+    if (lds > 72 * 1024) return -1;
+    // the input region of a tile: rows / columns the rh x rw intermediate pixels can touch, the columns widened to 16-byte pieces
+    const int in_rows = (int)(s1h * (rh - 1)) + 3, in_w = ((int)(s1w * (rw - 1)) + 3 + 3 + 3) / 4 * 4, mid_cap = (rh * rw + 3) / 4 * 4;
+    const size_t lds2 = ((size_t)4 * R2_NTAB + (size_t)C * mid_cap + (size_t)C * in_rows * in_w) * sizeof(float);
+    if (form == 1 && Win % 4 == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 && s1h > 0.f && s1w > 0.f && in_w <= 128 && in_rows <= 32 && C <= 3 && lds2 <= 78 * 1024) {      // (two workgroups per CU)
+        static AttrMask attr2 = 0;
+        set_max_dynamic_lds(reinterpret_cast<const void*>(resize2_gray_stats_lds_kernel), 78 * 1024, attr2);
+        resize2_gray_stats_lds_kernel<<<dim3(GS_CHUNKS, B), 256, lds2, st>>>(img, C, Hin, Win, Hm, Wm, s1h, s1w, Ho, Wo, s2h, s2w, part, gray, mid_cap, in_rows, in_w);
+        gray_coef_kernel<<<B, 64, 0, st>>>(part, Ho * Wo, 1e-5f, coef);
+        return 0;
+    }
     static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(resize2_gray_stats_kernel), 72 * 1024, attr);
-    if (lds > 72 * 1024) return -1;
     resize2_gray_stats_kernel<<<dim3(GS_CHUNKS, B), 256, lds, st>>>(img, C, Hin, Win, Hm, Wm, s1h, s1w, Ho, Wo, s2h, s2w, part, gray);
     gray_coef_kernel<<<B, 64, 0, st>>>(part, Ho * Wo, 1e-5f, coef);
     return 0;

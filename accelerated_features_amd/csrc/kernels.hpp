@@ -66,6 +66,7 @@ struct Options {
                             // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
     int fx = 3979;          // (round 5: bits 1 | 2 | 8 | 128 | 256 | 512 | 1024 | 2048: the fine_matcher on linear_fx_kernel; every 64 -> 64 and 128 -> 128 3x3 on conv_rs64_kernel, the stride-2 layers in the fp16-pair arithmetic)   (bit 128, with 1: the unfused 64 -> 64 layers on conv_rs64_kernel -- weights resident in registers, conv_rs64_body.hpp; bit 256, with 1: the 3x3 + 1x1 pairs too; bit 512, with 1: block5.1 and block5.2 on its 128-channel form, block5.3 then runs as a 1x1 of its own; bit 1024, with 1: block4.0 / block5.0 (stride 2) in the fp16-pair arithmetic, conv_bx64s2x_kernel)  split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
                             // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel), 2048 = the fine_matcher's linear layers (linear_fx_kernel), 4 = (with 1) conv_bx64_kernel with two weight fragments in its stream, 8 = the split heads (with heads_f32 = 0: head_bx_kernel<.., 1>), + 16 = with two weight fragments in LDS (<.., 2>), + 32 = (instead) the B fragments through LDS (<.., 3>), 64 = (with 1) the split-format link block_fusion.0 -> block_fusion.1 (conv_bx64_body.hpp: SP); 0 = the bf16 three-way split everywhere
+    int resize2 = 1;        // the fused two-stage resize of the dual-scale dense path: 1 = the tile's input region staged in LDS by 16-byte loads (round 5), 0 = four-byte gathers
     int block1 = 7;         // (r5-flip: block1.2 and block1.3 on the fp16 matrix cores; 0 / 5 = the vector-ALU kernel)   block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected); 6 = 5 with conv4 on the fp16 matrix cores (fp16-pair arithmetic, block1_fx.hpp), 7 = conv3 too
 };
 
@@ -73,7 +74,7 @@ struct Options {
 // gray = channel mean (raw), coef[b] = {alpha, beta} of the instance norm x = fmaf(gray, alpha, beta)
 void launch_gray_norm(const float* img, int B, int C, int H, int W, double* part, float* gray, float* coef, hipStream_t st);
 int launch_gray_norm_resized(const float* img, int B, int C, int Hin, int Win, int Hm, int Wm, float s1h, float s1w, int Ho, int Wo,
-                             float s2h, float s2w, double* part, float* gray, float* coef, hipStream_t st);
+                             float s2h, float s2w, double* part, float* gray, float* coef, hipStream_t st, int form = 1);
 void launch_gray_norm_u8(const unsigned char* img, bool nhwc, float divisor, int B, int C, int H, int W, double* part, float* gray,
                          float* coef, hipStream_t st);
 void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,

@@ -197,7 +197,7 @@ class XFeatModel(nn.Module):
         _lib.check(lib.xfh_set_status_buffer(h, C.c_void_p(self._status.data_ptr())), "xfh_set_status_buffer")
         return h
 
-    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 3), "block1": (0, 7), "fx": (0, 4095)}      # include/xfeat_hip.h: xfh_set_option
+    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 3), "block1": (0, 7), "fx": (0, 4095), "resize2": (0, 1)}      # include/xfeat_hip.h: xfh_set_option
 
     def set_option(self, key, value):
         """Kernel-variant switch of this model's handle (include/xfeat_hip.h: xfh_set_option) -- A/B runs and variant-vs-variant tests.

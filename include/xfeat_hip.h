@@ -110,6 +110,8 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *                                   linear_fx_kernel (first / last layer) and linear_fxd_kernel (the 512 -> 512 layers, LDS-DMA), the activations between them as
  *                                   fp16 pairs in the workspace (csrc/linear_fx_body.hpp); without the bit, or when a layer has a weight beyond the pair's range: f32 MFMAs
  *                           conv_rs64_kernel takes maps of any width (beyond 125 / 93 / 61 columns -- unfused / with the 1x1 / 128 channels -- as column strips).   (0..4095)
+ *   "resize2"       0..1    DEFAULT 1.  The fused two-stage resize of the dual-scale dense path (xfh_backbone_resized): 1 = the tile's input region staged in LDS by
+ *                           16-byte loads (needs Win % 4 == 0; otherwise, and with 0: four-byte gathers per tap).  Same bits either way.
  *   "block1"        0..7    DEFAULT 7.  0 / 5 = block1 on the vector ALUs (conv1 recomputed inside conv2, no c1 tile in LDS; the range fallback), 1 / 3 / 4 = earlier forms
  *                           writing a c1 tile; 6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too
  *                           (6 and 7 set XFH_STATUS_FX_RANGE like "fx")

@@ -832,6 +832,13 @@ def test_fused_two_stage_resize_backbone_is_bit_identical_to_materialised_resize
         xs = xf._resize(x, int(np.floor(200 * s)), int(np.floor(328 * s)), np.float32(1.0 / s), np.float32(1.0 / s))
         outs.append(xf.extractDense(xs, int(1000 * frac), _scale_div=s))
     assert torch.equal(mk, torch.cat([outs[0][0], outs[1][0]], 1)) and torch.equal(ft, torch.cat([outs[0][1], outs[1][1]], 1))
+    # both forms of the fused kernel (option resize2: 1 = the tile's input region staged in LDS, the default; 0 = four-byte gathers) give the same bits
+    try:
+        xf.net.set_option('resize2', 0)
+        mk0, sc0, ft0 = xf.extract_dualscale(x, 1000)
+    finally:
+        xf.net.set_option('resize2', None)
+    assert torch.equal(mk, mk0) and torch.equal(sc, sc0) and torch.equal(ft, ft0)
 
 
 def test_reference_minimal_example_runs_unchanged():
