@@ -93,6 +93,25 @@ def _slice_gray():
     return s
 
 
+def _slice_resize2():
+    """both forms of the fused two-stage resize (lin_coef / bilerp, the R2 constants, resize2_gray_stats_kernel, resize2_gray_stats_lds_kernel) and gray_coef_kernel: the 2-D
+    grid becomes a 1-D one, the dynamic LDS a pointer into the emulator's LDS, the static partial-sum array its last 64 bytes"""
+    t = open(os.path.join(CSRC, "k_preproc.hip")).read()
+    s = _between(t, "__device__ inline void lin_coef(", "__global__ __launch_bounds__(256) void resize_bilinear_kernel(")
+    s += _between(t, "constexpr int R2_TW = 64,", "// returns -1 when the stage-2 step is too large for the LDS region")
+    s += _between(t, "__global__ __launch_bounds__(64) void gray_coef_kernel(", "void launch_gray_norm(")
+    s = _must_sub(s, "__global__ __launch_bounds__(256) void resize2_gray_stats_kernel(", "inline void resize2_gray_stats_kernel(")
+    s = _must_sub(s, "__global__ __launch_bounds__(256, 4) void resize2_gray_stats_lds_kernel(", "inline void resize2_gray_stats_lds_kernel(")
+    s = _must_sub(s, "__global__ __launch_bounds__(64) void gray_coef_kernel(", "inline void gray_coef_kernel(")
+    s = _must_sub(s, "const int b = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;", "const int b = blockIdx.x / GS_CHUNKS, ch = blockIdx.x % GS_CHUNKS, tid = threadIdx.x;")
+    s = _must_sub(s, "extern __shared__ float mid[];", "float* mid = reinterpret_cast<float*>(emu::wg->lds_base());")
+    s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) float r2sm[];", "float* r2sm = reinterpret_cast<float*>(emu::wg->lds_base());")
+    s = _must_sub(s, "__shared__ double sm[8];", "double* sm = reinterpret_cast<double*>(emu::wg->lds_base() + emu::wg->lds.size() - 128);")
+    s = _must_sub(s, "__shared__ double sm2[8];", "double* sm2 = reinterpret_cast<double*>(emu::wg->lds_base() + emu::wg->lds.size() - 128);")
+    assert "asm volatile" not in s and "<<<" not in s and "blockIdx.y" not in s
+    return s
+
+
 def _slice_match_sweep():
     """mnn_f16_sweep_kernel with its constants and the 16-value maximum tree: the three static LDS arrays become pointers into the emulator's LDS, the register keep-alive an
     empty statement"""
@@ -148,11 +167,12 @@ def emu_bins():
     open(os.path.join(td, "conv_wino_slice.hpp"), "w").write(_slice_conv_wino())
     open(os.path.join(td, "pyramid_slice.hpp"), "w").write(_slice_pyramid())
     open(os.path.join(td, "gray_slice.hpp"), "w").write(_slice_gray())
+    open(os.path.join(td, "resize2_slice.hpp"), "w").write(_slice_resize2())
     open(os.path.join(td, "match_sweep_slice.hpp"), "w").write(_slice_match_sweep())
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("conv_bx64s2_slice_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu", "gray_emu", "match_sweep_emu"):
+    for name in ("conv_bx64s2_slice_emu", "conv_bx24_emu", "conv_wino_emu", "pyramid_emu", "gray_emu", "resize2_emu", "match_sweep_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -254,6 +274,33 @@ def test_gray_stats_kernels_on_the_host(emu_bins, shape):
     e_g, e_c = float(np.abs(gray - gd.numpy()).max()), float(np.abs(coef / ref - 1).max())
     print(f"gray_stats {shape}: gray max |err| {e_g:.3g}, coef max rel err {e_c:.3g}")
     assert np.isfinite(gray).all() and e_g <= 3e-7 and e_c <= 1e-6      # (gray: an fp32 sum of C values and one division)
+
+
+@pytest.mark.parametrize("shape,scale", [((2, 3, 100, 164), 1.3), ((1, 3, 110, 164), 0.6), ((1, 1, 68, 100), 1.0), ((2, 3, 88, 128), 0.77)])
+def test_fused_two_stage_resize_kernels_on_the_host(emu_bins, shape, scale):
+    """extract_dualscale's F.interpolate(x, scale_factor=s) + preprocess_tensor's resize to multiples of 32 + x.mean(1) + the InstanceNorm statistics (modules/xfeat.py:379-381,
+    234-238; modules/model.py:135-136) in ONE kernel: the gather form and the staged form (input region of the NEXT tile in flight, tap tables in LDS, several tiles per
+    workgroup, ragged last tiles) must agree BIT FOR BIT, and both with torch's two interpolations to fp32 rounding"""
+    B, C, Hin, Win = shape
+    x = torch.rand(B, C, Hin, Win, generator=torch.Generator().manual_seed(Hin + C)) * 3 - 1
+    Hm, Wm = int(np.floor(Hin * scale)), int(np.floor(Win * scale))
+    Ho, Wo = max(32, Hm // 32 * 32), max(32, Wm // 32 * 32)
+    s1 = np.float32(1.0 / scale)                                  # (F.interpolate with scale_factor: ATen uses 1 / scale_factor)
+    s2h, s2w = np.float32(Hm) / np.float32(Ho), np.float32(Wm) / np.float32(Wo)
+    blob = np.array([B, C, Hin, Win, Hm, Wm, Ho, Wo], np.int32).tobytes() + np.array([s1, s1, s2h, s2w], np.float32).tobytes() + x.numpy().astype(np.float32).tobytes()
+    out = subprocess.run([emu_bins["resize2_emu"]], input=blob, capture_output=True, check=True, timeout=600).stdout
+    n = B * Ho * Wo
+    g0 = np.frombuffer(out[:4 * n], np.float32).reshape(B, Ho, Wo)
+    g1 = np.frombuffer(out[4 * n:8 * n], np.float32).reshape(B, Ho, Wo)
+    c0 = np.frombuffer(out[8 * n:8 * n + 8 * B], np.float32)
+    c1 = np.frombuffer(out[8 * n + 8 * B:], np.float32)
+    assert np.isfinite(g0).all() and np.array_equal(g0, g1) and np.array_equal(c0, c1)
+    mid = torch.nn.functional.interpolate(x, size=(Hm, Wm), scale_factor=None, mode="bilinear", align_corners=False) if scale == 1.0 else \
+        torch.nn.functional.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=False)
+    ref = torch.nn.functional.interpolate(mid, size=(Ho, Wo), mode="bilinear", align_corners=False).mean(1).numpy()
+    err = float(np.abs(g0 - ref).max())
+    print(f"resize2 {shape} x {scale}: ({Hm}, {Wm}) -> ({Ho}, {Wo}); the two forms identical; max |gray - torch| {err:.3g}")
+    assert tuple(mid.shape[2:]) == (Hm, Wm) and err <= 2e-5      # (ATen's CPU kernel rounds its weights differently; the GPU suite compares with the oracle bit for bit)
 
 
 @pytest.mark.parametrize("P,N1,N2,n1,n2,nsplit", [(1, 96, 64, 96, 64, 1), (2, 300, 280, 290, 259, 0), (1, 520, 300, 520, 300, 2), (1, 40, 700, 33, 690, 0)])
