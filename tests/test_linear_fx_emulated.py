@@ -68,9 +68,16 @@ def _run(emu_bin, M, K, N, inn, out, relu, mlive, seed=0, scale=3.0, poke=None):
     (300, 512, 256, 4, 1, 1, 270),      # two column blocks of 128, a live count
     (256, 128, 128, 4, 1, 0, -1),       # the shortest K the three-stage ring takes (four chunks)
     (100, 64, 64, 0, 0, 0, -1),         # two chunks: the shortest K of the register-staged form
+    (1, 128, 64, 2, 1, 1, -1),          # one match (every staged row but one is the clamped last live row)
+    (300, 512, 128, 4, 1, 1, 1),        # one live row of 300: the second row block leaves, the DMA writes zeros behind row 0
+    (300, 512, 128, 4, 1, 1, 0),        # no live row: every workgroup leaves, nothing is written
+    (300, 512, 64, 3, 0, 1, 0),
 ])
 def test_linear_fx_bodies_on_the_host(emu_bin, M, K, N, inn, out, relu, mlive):
     y, ref, status, untouched = _run(emu_bin, M, K, N, inn, out, relu, mlive)
+    if mlive == 0:
+        assert status == 0 and untouched and y.shape[0] == 0
+        return
     err = np.abs(y - ref).max() / np.abs(ref).max()
     print(f"M {M} K {K} N {N} in {inn} out {out} live {mlive}: max |err| / max |y| = {err:.2e}")
     assert status == 0 and untouched
