@@ -276,7 +276,7 @@ def test_gray_stats_kernels_on_the_host(emu_bins, shape):
     assert np.isfinite(gray).all() and e_g <= 3e-7 and e_c <= 1e-6      # (gray: an fp32 sum of C values and one division)
 
 
-@pytest.mark.parametrize("shape,scale", [((2, 3, 100, 164), 1.3), ((1, 3, 110, 164), 0.6), ((1, 1, 68, 100), 1.0), ((2, 3, 88, 128), 0.77)])
+@pytest.mark.parametrize("shape,scale", [((1, 3, 100, 164), 1.3), ((1, 3, 110, 164), 0.6), ((1, 1, 68, 100), 1.0), ((2, 3, 88, 128), 0.77)])
 def test_fused_two_stage_resize_kernels_on_the_host(emu_bins, shape, scale):
     """extract_dualscale's F.interpolate(x, scale_factor=s) + preprocess_tensor's resize to multiples of 32 + x.mean(1) + the InstanceNorm statistics (modules/xfeat.py:379-381,
     234-238; modules/model.py:135-136) in ONE kernel: the gather form and the staged form (input region of the NEXT tile in flight, tap tables in LDS, several tiles per
