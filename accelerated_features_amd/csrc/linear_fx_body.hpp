@@ -306,7 +306,7 @@ __device__ __forceinline__ void linear_fx_body(const LinFxArgs& a) {
 // ------------------------------------------------------------------------------------------------------------------------------------------------------------------------
 // The chain's inner layers (pair in, pair out: 512 -> 512, three of the five and 85 % of the arithmetic) with EVERY operand brought in by LDS-DMA.  Measured on the form above
 // (profiles/r05_pmc_dense_linear_fx2.txt): its waves wait for an instruction to ISSUE 68 % of their cycles with the matrix pipes 29 % busy -- 160 global-load wave-instructions
-// per CU and chunk round (the fragments alone 96: each of a workgroup's four waves fetches the same 12 KB), ~33 cycles of the CU's one vector-memory path each.  Here a
+// per CU and chunk round (the fragments alone 96: each of a workgroup's four waves fetches the same 12 KB), 5300 cycles per round where the MFMAs need 1536.  Here a
 // workgroup of EIGHT waves takes 256 rows x 128 columns (wave: row group w & 3, column half w >> 2: two waves per SIMD, one workgroup per CU): per chunk its 32 KB of rows
 // and its 24 fragments arrive as 56 one-KiB DMA pieces (7 per wave) -- a third of the requests per MFMA, no staging registers, no LDS stores (13 cycles each: the LDS reads
 // that replace the fragments' global loads take 4).
@@ -416,9 +416,10 @@ __device__ __forceinline__ void linear_fxd_body(const LinFxArgs& a) {
     // tail: 0 = a chunk of the steady state, 1 = the last but one (no rows left to request), 2 = the last
     auto chunk = [&](int kc, int xs, auto tail) {
         constexpr int TAIL = decltype(tail)::value;
-        // The seven pieces this wave requests per chunk stand BETWEEN its MFMA quads, one at a time (trace of the first form, all seven at the chunk's top: the CU's one
-        // vector-memory path takes ~25 cycles per KiB piece -- 56 pieces per chunk and CU -- and a wave whose request finds the queue full sits there: waves 4-7 started
-        // their MFMAs 1250 cycles behind waves 0-3, who then waited as long at the barrier).  Order: the fragments first (the end-of-chunk wait leaves the four youngest in flight).
+        // The seven pieces this wave requests per chunk stand BETWEEN its MFMA quads, one at a time (trace of the first form, all seven at the chunk's top: waves 4-7 started
+        // their MFMAs 1250 counts behind waves 0-3, who then waited as long at the barrier.  Spreading the requests did not change the chunk's time: the pair of waves on a SIMD
+        // shares the matrix pipe and the loser of the arbitration is late either way -- DESIGN 3.7; a CU draws 55-60 B/clk by LDS-DMA from L2, this kernel asks for 22).
+        // Order: the fragments first (the end-of-chunk wait leaves the four youngest in flight).
         constexpr bool DW = TAIL < 2, DX = TAIL < 1;
         const int xn = xs == 0 ? 2 : xs - 1;      // stage (kc + 2) % 3 = (kc - 1) % 3: read in chunk kc - 1, everybody is past that chunk's barrier (so for the fragments' stage)
 #if XFH_LFXD_TRACE
