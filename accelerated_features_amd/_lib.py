@@ -62,7 +62,6 @@ SIGNATURES = {
     "xfh_lg_match_pairs": (_i, [_p, _p, _p, _p, _i, _i, _f, _f, _f, _i, _p, _p, _p, _p, _sz, _p]),
     "xfh_profile_select": (_i, [_p, _i]),
     "xfh_debug_trace": (_i, [_p, _p]),
-    "xfh_debug_head_soak": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, C.c_uint, _p]),
     "xfh_debug_match_occupancy": (_i, []),
     "xfh_debug_cold_start": (_i, [_i]),
     "xfh_debug_block1": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),

@@ -95,7 +95,7 @@ def _detect_exact(xfeat, x, top_k):
             kpts, scores, desc, n_valid, n_cand, cap, hw = xfeat._detect_device(x, top_k, None, cap, counts_out=cnt[:2])
         host = cnt.cpu()
         ncmax = int(host[1].max())
-        if xfeat.net.fx_range_exceeded(status=int(host[2, 0])):      # fp16-pair arithmetic out of range (never on images): exact re-run on the bf16 split, like detectAndCompute
+        if xfeat.net.fx_range_exceeded(status=int(host[2, 0])):      # fp16-pair arithmetic out of range (never on images): exact re-run on the fp32-range kernels, like detectAndCompute
             continue
         if cap >= hw or ncmax <= cap:
             return kpts, desc, n_valid

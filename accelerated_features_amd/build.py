@@ -55,11 +55,10 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True, scan=False, shift=0):
-    """scan: the torture build libxfeat_hip_scan.so -- the key-point head kernels at 16 code positions (tools/head_soak.py: XFH_LIB_PATH selects it).
-    shift = N > 0: libxfeat_hip_shiftN.so -- EVERY matrix-core kernel's body moved by 4 N bytes (common.hpp: XFH_CODE_SHIFT; tools/shift_scan.sh)."""
+def build(force=False, verbose=True, shift=0):
+    """shift = N > 0: libxfeat_hip_shiftN.so -- EVERY matrix-core kernel's body moved by 4 N bytes (common.hpp: XFH_CODE_SHIFT; tools/bench_src/scan_probe.cpp)."""
     hipcc = _hipcc()
-    tag = "_scan" if scan else (f"_shift{shift}" if shift else "")
+    tag = f"_shift{shift}" if shift else ""
     OBJ = globals()["OBJ"] + tag
     LIB = globals()["LIB"].replace(".so", tag + ".so")
     os.makedirs(OBJ, exist_ok=True)
@@ -72,7 +71,7 @@ def build(force=False, verbose=True, scan=False, shift=0):
 
     def compile_one(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + (["-DXFH_HEAD_SCAN_SHIFTS=16"] if scan else []) + ([f"-DXFH_CODE_SHIFT={shift}"] if shift else []) + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ([f"-DXFH_CODE_SHIFT={shift}"] if shift else []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, r.returncode, r.stdout + r.stderr
 
@@ -97,4 +96,4 @@ def build(force=False, verbose=True, scan=False, shift=0):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, scan="--scan" in sys.argv, shift=int(sys.argv[sys.argv.index("--shift") + 1]) if "--shift" in sys.argv else 0)
+    build(force="--force" in sys.argv, shift=int(sys.argv[sys.argv.index("--shift") + 1]) if "--shift" in sys.argv else 0)

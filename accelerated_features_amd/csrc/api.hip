@@ -275,7 +275,7 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
     std::vector<float> blob;
     auto reserve = [&](size_t n) { size_t o = align_up(blob.size(), 64); blob.resize(o + n, 0.f); return o; };
     const size_t zoff = reserve(256);
-    struct Off { size_t oihw, kc, kcp, bias, wino, bx, fx, fq, rs; bool has_wino, has_bx, fx_ok, has_fq, has_rs; } coff[L_NUM];
+    struct Off { size_t oihw, kc, kcp, bias, fx, rs; bool has_fx, has_rs; } coff[L_NUM];
     struct FOff { size_t w, b, fx; bool fx_ok; } foff[5];
     int ai = 0;
     for (int li = 0; li < L_NUM; ++li) {
@@ -309,63 +309,43 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                 }
             blob[coff[li].bias + o] = (float)shift[o];
         }
-        // Winograd F(2x2,3x3): U = G g G^T of the FOLDED fp32 weights, in fp64, rounded once.
-        // layout [cin/4][pos = 4*xi + nu][half = ci & 1][cout_pad][p = (ci >> 1) & 1]  (k_conv_wino.hip)
-        coff[li].has_wino = c.ks == 3 && c.stride == 1 && c.cin % 8 == 0 && c.cin >= 24;
-        if (coff[li].has_wino) {
-            coff[li].wino = reserve((size_t)c.cin * 16 * cpad);
-            static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-            for (int o = 0; o < c.cout; ++o)
-                for (int i = 0; i < c.cin; ++i) {
-                    const float* gk = &blob[coff[li].oihw + ((size_t)o * c.cin + i) * 9];
-                    for (int xi = 0; xi < 4; ++xi)
-                        for (int nu = 0; nu < 4; ++nu) {
-                            double u = 0;
-                            for (int r = 0; r < 3; ++r)
-                                for (int s2 = 0; s2 < 3; ++s2) u += G[xi][r] * (double)gk[r * 3 + s2] * G[nu][s2];
-                            blob[coff[li].wino + ((((size_t)(i / 4) * 16 + xi * 4 + nu) * 2 + (i & 1)) * cpad + o) * 2 + ((i >> 1) & 1)] = (float)u;
-                        }
-                }
-        }
-        // Split-operand MFMA paths (k_conv_bx*.hip): every fp32 weight as three 16-bit fragments in MFMA operand order, in two arithmetics (split_weight):
-        // bf16 three-way split (w_bx), and the fp16 pair at scale 2^11 (w_fx; only if every |w| of the layer stays below kFxMaxWeight).
+        // fp16-pair MFMA paths (k_conv_bx.hip, k_conv_bx64s2x.hip, k_conv_rs64.hip): every fp32 weight as three fp16 fragments (weight_split.hpp: split_weight) in MFMA
+        // operand order -- only if every |w| of the layer stays below kFxMaxWeight (the layer otherwise runs on the f32-MFMA kernel).
         // K group kg = 2 step + half = (tap, 8-channel group) for the 24-channel layers.
         const bool bx24 = c.ks == 3 && c.stride == 1 && c.cin == 24 && c.cout <= 32;
         const bool bx64 = c.ks == 3 && c.stride == 1 && c.cin == 64 && c.cout == 64;
         const bool bx24s2 = c.ks == 3 && c.stride == 2 && c.cin == 24 && c.cout == 64;
         const bool bx1x1 = c.ks == 1 && c.cin == 64 && c.cout == 64 && li > 0 && kConvs[li - 1].ks == 3 && kConvs[li - 1].cout == 64 && kConvs[li - 1].cin == 64;      // block3.2, block_fusion.2
         const bool bx64s2 = c.ks == 3 && c.stride == 2 && c.cin == 64 && (c.cout == 64 || c.cout == 128);      // block4.0, block5.0
-        coff[li].has_bx = bx24 || bx64 || bx24s2 || bx1x1 || bx64s2;
-        coff[li].fx_ok = false;
-        if (coff[li].has_bx) {
+        const bool bx128 = c.ks == 3 && c.stride == 1 && c.cin == 128 && c.cout == 128;      // block5.1, block5.2
+        bool fx_ok = bx24 || bx64 || bx24s2 || bx1x1 || bx64s2 || bx128;
+        if (fx_ok) {
             float wmax = 0.f;
             for (size_t i = 0; i < (size_t)c.cout * c.cin * kk; ++i) wmax = std::max(wmax, std::fabs(blob[coff[li].oihw + i]));
-            coff[li].fx_ok = wmax < kFxMaxWeight;
+            fx_ok = wmax < kFxMaxWeight;
         }
-        for (int mode = 0; mode < 2 && coff[li].has_bx; ++mode) {
+        coff[li].has_fx = fx_ok && (bx24 || bx24s2 || bx64s2);
+        if (coff[li].has_fx) {
             size_t words = 0;
             const int cg = c.cin / 8, nstep = bx_steps(c.cin), nch = c.cin / 16, nhf = c.cout / 64;
-            if (bx1x1) words = (size_t)4 * 2 * 3 * 64 * 4;
             if (bx24) words = (size_t)nstep * 3 * 64 * 4;
             if (bx24s2) words = (size_t)2 * nstep * 3 * 64 * 4;
-            if (bx64 || bx64s2) words = (size_t)nhf * nch * 9 * 2 * 3 * 64 * 4;
-            const size_t off = reserve(words);
-            (mode == 0 ? coff[li].bx : coff[li].fx) = off;
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[off]);
+            if (bx64s2) words = (size_t)nhf * nch * 9 * 2 * 3 * 64 * 4;
+            coff[li].fx = reserve(words);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[coff[li].fx]);
             uint16_t q[3];
-            if (bx1x1) pack_bx1x1(&blob[coff[li].oihw], mode, dst);      // trailing 1x1 fused into conv_bx64_kernel (weight_split.hpp)
-            if (bx24)         // [step][split][lane = half * 32 + cout][8]
+            if (bx24)         // [step][fragment][lane = half * 32 + cout][8]
                 for (int st = 0; st < nstep; ++st)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int o = lane & 31, kg = 2 * st + (lane >> 5);
                         for (int i = 0; i < 8; ++i) {
                             float v = 0.f;
                             if (o < c.cout && kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
-                            split_weight(v, mode, q);
+                            split_weight(v, q);
                             for (int sp = 0; sp < 3; ++sp) dst[(((size_t)st * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                         }
                     }
-            if (bx24s2)       // the stride-2 sibling: [cout block][step][split][lane][8], same K order as bx24
+            if (bx24s2)       // the stride-2 sibling: [cout block][step][fragment][lane][8], same K order as bx24
                 for (int cb = 0; cb < 2; ++cb)
                     for (int st = 0; st < nstep; ++st)
                         for (int lane = 0; lane < 64; ++lane) {
@@ -373,83 +353,74 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
                             for (int i = 0; i < 8; ++i) {
                                 float v = 0.f;
                                 if (kg < 9 * cg) v = blob[coff[li].oihw + ((size_t)o * c.cin + (kg % cg) * 8 + i) * 9 + kg / cg];
-                                split_weight(v, mode, q);
+                                split_weight(v, q);
                                 for (int sp = 0; sp < 3; ++sp) dst[((((size_t)cb * nstep + st) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                             }
                         }
-            if (bx64 || bx64s2) pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, mode, dst);      // (weight_split.hpp)
+            if (bx64s2) pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, dst);      // (weight_split.hpp)
         }
         coff[li].has_rs = false;
-        if (bx1x1 && coff[li].fx_ok) {      // the 1x1 behind a 64 -> 64 3x3 in conv_rs64_kernel's order (16 couts per wave, natural K order)
+        if (bx1x1 && fx_ok) {      // the 1x1 behind a 64 -> 64 3x3 in conv_rs64_kernel's order (16 couts per wave, natural K order)
             coff[li].rs = reserve((size_t)4 * 2 * 3 * 64 * 4);
             pack_rs64_1x1(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
             coff[li].has_rs = true;
         }
-        if (c.ks == 3 && c.stride == 1 && c.cin == 128 && c.cout == 128) {      // block5.1, block5.2: conv_rs64_kernel's 128-channel form (fp16 pair only)
-            float wmax = 0.f;
-            for (size_t i = 0; i < (size_t)128 * 128 * 9; ++i) wmax = std::max(wmax, std::fabs(blob[coff[li].oihw + i]));
-            if (wmax < kFxMaxWeight) {
-                coff[li].rs = reserve(4 * kRs64Halfs / 2);
-                pack_rs128(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
-                coff[li].has_rs = true;
-            }
+        if (bx128 && fx_ok) {      // block5.1, block5.2: conv_rs64_kernel's 128-channel form
+            coff[li].rs = reserve(4 * kRs64Halfs / 2);
+            pack_rs128(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
+            coff[li].has_rs = true;
         }
-        coff[li].has_fq = bx64 && coff[li].fx_ok;
-        if (coff[li].has_fq) {      // two fragments per weight (q0, q2): conv_bx64_body.hpp FXM 2
-            coff[li].fq = reserve((size_t)(c.cin / 16) * 9 * 2 * 2 * 64 * 4);
-            pack_bx64(&blob[coff[li].oihw], c.cin, c.cout, 1, reinterpret_cast<uint16_t*>(&blob[coff[li].fq]), 2);
-            coff[li].rs = reserve(kRs64Halfs / 2);      // the same three fragments in conv_rs64_kernel's order (one K quarter per wave)
+        if (bx64 && fx_ok) {      // conv_rs64_kernel's order (one K quarter per wave)
+            coff[li].rs = reserve(kRs64Halfs / 2);
             pack_rs64(&blob[coff[li].oihw], reinterpret_cast<uint16_t*>(&blob[coff[li].rs]));
             coff[li].has_rs = true;
         }
     }
-    // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][split][lane = half * 32 + cout][8].
+    // heads on the fp16 matrix cores (k_heads.hip: head_bx_kernel): per layer [K step t][cout block][fragment][lane = half * 32 + cout][8].
     // K order: the first layer takes its channels in natural order (16 t + 8 half + i); a chained layer takes the previous layer's D
     // registers, i.e. feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).
-    size_t head_off[2][2] = {{0, 0}, {0, 0}}, head_boff[2] = {0, 0};      // [arithmetic: 0 = bf16 x3, 1 = fp16 pair][head]
+    // (the images hold 64 of keypoint_head.3's 65 outputs: the dustbin logit is a dot product on the vector ALUs -- head_bx_body.hpp)
+    size_t head_off[2] = {0, 0}, head_boff[2] = {0, 0};      // [head]
     bool head_fx_ok[2] = {true, true};
-    float head_b_last = 0.f;
-    size_t head_fq_off[2] = {0, 0};
-    for (int mode = 0; mode < 3; ++mode) {      // 0: bf16 x3, 1: fp16 pair (three fragments), 2: fp16 pair with q0 / q2 alone
+    const float head_b_last = blob[coff[L_HEAT_2].bias];
+    {
         const int kp[4] = {L_KP_0, L_KP_1, L_KP_2, L_KP_3}, rel[2] = {L_HEAT_0, L_HEAT_1};
         for (int hd = 0; hd < 2; ++hd) {
             const int nl = hd == 0 ? 4 : 2;
             const int* ls = hd == 0 ? kp : rel;
             size_t words = 0, nbias = 0;
-            // (the fp16-pair images hold 64 of keypoint_head.3's 65 outputs: the dustbin logit is a dot product on the vector ALUs there -- head_bx_body.hpp)
-            auto couts = [&](int p) { return mode && hd == 0 && p == 3 ? 64 : kConvs[ls[p]].cout; };
-            for (int p = 0; p < nl; ++p) { words += (size_t)4 * ((couts(p) + 31) / 32) * (mode == 2 ? 2 : 3) * 64 * 4; nbias += 32 * ((kConvs[ls[p]].cout + 31) / 32); }
-            (mode == 2 ? head_fq_off[hd] : head_off[mode][hd]) = reserve(words);
-            if (mode == 0) head_boff[hd] = reserve(nbias);
-            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[mode == 2 ? head_fq_off[hd] : head_off[mode][hd]]);
+            auto couts = [&](int p) { return hd == 0 && p == 3 ? 64 : kConvs[ls[p]].cout; };
+            for (int p = 0; p < nl; ++p) { words += (size_t)4 * ((couts(p) + 31) / 32) * 3 * 64 * 4; nbias += 32 * ((kConvs[ls[p]].cout + 31) / 32); }
+            head_off[hd] = reserve(words);
+            head_boff[hd] = reserve(nbias);
+            uint16_t* dst = reinterpret_cast<uint16_t*>(&blob[head_off[hd]]);
             size_t bo = head_boff[hd];
             for (int p = 0; p < nl; ++p) {
                 const ConvSpec& c = kConvs[ls[p]];
                 const int mbo = (c.cout + 31) / 32;
                 for (size_t i = 0; i < (size_t)c.cout * 64; ++i)
                     if (!(std::fabs(blob[coff[ls[p]].oihw + i]) < kFxMaxWeight)) head_fx_ok[hd] = false;
-                dst += pack_head_layer(&blob[coff[ls[p]].oihw], couts(p), p == 0, mode ? 1 : 0, dst, mode == 2 ? 2 : 3);      // (weight_split.hpp)
+                dst += pack_head_layer(&blob[coff[ls[p]].oihw], couts(p), p == 0, dst);      // (weight_split.hpp)
                 for (int o = 0; o < 32 * mbo; ++o) blob[bo + o] = o < c.cout ? blob[coff[ls[p]].bias + o] : 0.f;
                 bo += 32 * mbo;
             }
         }
-        head_b_last = blob[coff[L_HEAT_2].bias];
     }
-    // block1.3 (8 -> 24, stride 2) for block1_fused_kernel<6>: the compact fp16-pair image of block1_fx.hpp (only if every |w| stays below kFxMaxWeight)
+    // block1.3 (8 -> 24, stride 2) for block1_mx_kernel: the compact fp16-pair image of block1_fx.hpp (only if every |w| stays below kFxMaxWeight)
     size_t b1fx_off = 0;
     bool b1fx_ok = true;
     {
         const float* wkc = &blob[coff[L_BLOCK1_3].kc];
         for (int i = 0; i < 8 * 9 * 24; ++i) b1fx_ok = b1fx_ok && std::fabs(wkc[i]) < kFxMaxWeight;
         b1fx_off = reserve(b1fx::W4_BYTES / 4);
-        b1fx::pack_w4(&blob[coff[L_BLOCK1_3].kc], reinterpret_cast<uint16_t*>(&blob[b1fx_off]), [](float v, uint16_t (&q)[3]) { split_weight(v, 1, q); });
+        b1fx::pack_w4(&blob[coff[L_BLOCK1_3].kc], reinterpret_cast<uint16_t*>(&blob[b1fx_off]), [](float v, uint16_t (&q)[3]) { split_weight(v, q); });
     }
-    size_t b1fx3_off = 0;      // block1.2 (8 -> 8) for block1_fused_kernel<7>
+    size_t b1fx3_off = 0;      // block1.2 (8 -> 8) likewise
     {
         const float* wkc = &blob[coff[L_BLOCK1_2].kc];
         for (int i = 0; i < 8 * 9 * 8; ++i) b1fx_ok = b1fx_ok && std::fabs(wkc[i]) < kFxMaxWeight;
         b1fx3_off = reserve(b1fx::W3_IMAGE_BYTES / 4);
-        b1fx::pack_w3(&blob[coff[L_BLOCK1_2].kc], reinterpret_cast<uint16_t*>(&blob[b1fx3_off]), [](float v, uint16_t (&q)[3]) { split_weight(v, 1, q); });
+        b1fx::pack_w3(&blob[coff[L_BLOCK1_2].kc], reinterpret_cast<uint16_t*>(&blob[b1fx3_off]), [](float v, uint16_t (&q)[3]) { split_weight(v, q); });
     }
     for (int fi = 0; fi < 5; ++fi) {
         const FineSpec& f = kFine[fi];
@@ -504,17 +475,12 @@ int xfh_create(const float* const* host_arrays, int n_arrays, int device, xfh_ha
         w.w_kc = ctx->blob + coff[li].kc;
         w.w_kcp = ctx->blob + coff[li].kcp;
         w.bias = ctx->blob + coff[li].bias;
-        w.w_wino = coff[li].has_wino ? ctx->blob + coff[li].wino : nullptr;
-        w.w_bx = coff[li].has_bx ? ctx->blob + coff[li].bx : nullptr;
-        w.w_fx = coff[li].has_bx && coff[li].fx_ok ? ctx->blob + coff[li].fx : nullptr;
-        w.w_fq = coff[li].has_fq ? ctx->blob + coff[li].fq : nullptr;
+        w.w_fx = coff[li].has_fx ? ctx->blob + coff[li].fx : nullptr;
         w.w_rs = coff[li].has_rs ? ctx->blob + coff[li].rs : nullptr;
     }
     ctx->nw.zeros = ctx->blob + zoff;
     for (int hd = 0; hd < 2; ++hd) {
-        ctx->nw.head_bx[hd] = ctx->blob + head_off[0][hd];
-        ctx->nw.head_fx[hd] = head_fx_ok[hd] ? ctx->blob + head_off[1][hd] : nullptr;
-        ctx->nw.head_fq[hd] = head_fx_ok[hd] ? ctx->blob + head_fq_off[hd] : nullptr;
+        ctx->nw.head_fx[hd] = head_fx_ok[hd] ? ctx->blob + head_off[hd] : nullptr;
         ctx->nw.head_bx_bias[hd] = ctx->blob + head_boff[hd];
     }
     ctx->nw.block1_fx = b1fx_ok ? ctx->blob + b1fx_off : nullptr;
@@ -574,38 +540,18 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
     if (h->prof.which == XFH_PROF_CONV_64_64_S1 && c.cin == 64 && c.cout == 64 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_64_64_S1;
     if (h->prof.which == XFH_PROF_CONV_24_24 && c.cin == 24 && c.cout == 24 && c.ks == 3 && c.stride == 1) pid = XFH_PROF_CONV_24_24;
     prof_begin(&h->prof, pid, st);
-    // 3x3/s1 layers with >= 24 channels: Winograd F(2x2,3x3) (k_conv_wino.hip), including the 3x3 + fused 1x1 pairs.
-    // A/B runs (xfh_set_option): wino = 0 forces the direct kernel, 1 keeps the fused pairs on the direct kernel.
-    const int use_wino = h->opt.wino;
-    // 24-channel 3x3 layers (block2.0/.1 s1, block3.0 s2): bf16 MFMAs on three-way split operands (k_conv_bx.hip); bx = 0 keeps them on the f32-MFMA kernels
-    const int use_bx = h->opt.bx;      // 1: 24-channel layers; 4: unfused 64 -> 64 layers on large maps (2: on every map); 8: not block3.0
+    // The fp16-pair kernels first (option fx: bit 1 = the 64- and 128-channel layers, bit 2 = the 24-channel layers); a layer they do not take -- the bit is off, a weight
+    // beyond the pair's range left the layer without its image, a map beyond a kernel's exact range -- runs on the f32-MFMA kernel (fp32's range: what the range guard's
+    // re-run uses).  Every choice is by layer and image size alone, never by the batch: an image's features do not depend on the batch it travels in.
     int rc = -1;
-    // "large map" (only where conv_rs64_kernel is switched off: it takes these layers at any size): conv_bx64_kernel instead of Winograd for the unfused 64 -> 64 layers.
-    // Decided by the IMAGE's size alone (>= 12 half-tile units in the fp16-pair arithmetic = the 1/16-scale map of a VGA frame, 16 in the bf16 arithmetic), never by the
-    // batch: an image's features must not depend on which batch it travels in (round 4 decided by B x units -- a batch that filled the persistent grid -- and the same
-    // pair gave two fp32-accurate but different results alone and batched)
-    const bool big_map = (long)((Hin + 7) / 8) * ((Win + 15) / 16) >= ((h->opt.fx & 1) ? 12 : 16);
-    // the split-format link (fx bit 64; conv_bx64_body.hpp): block_fusion.0 writes its output as fp16 pairs, block_fusion.1 (+ .2 fused) stages them by LDS-DMA alone.
-    // Both layers see the same map, so both take the same decision; the buffer between them has the size of the fp32 tensor either way.
-    const bool sp_link = in_backbone && (h->opt.fx & 65) == 65 && use_bx && ((use_bx & 2) || ((use_bx & 4) && big_map)) && h->nw.conv[L_FUSION_0].w_fx && h->nw.conv[L_FUSION_1].w_fx &&
-                         h->nw.conv[L_FUSION_2].w_fx;
-    if (sp_link && layer == L_FUSION_1 && c2 && nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, true, 1, h->status, 1, h->nw.zeros);
-    if (sp_link && layer == L_FUSION_0 && !c2 && !nhwc) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status, 2, h->nw.zeros);
-    // conv_rs64_kernel (weights resident in registers, any map width: column strips) FIRST -- fx bit 128 (with bit 1): the unfused 64 -> 64 layers (block4.1, block4.2,
-    // block_fusion.0); bit 256: the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) -- in round 5's first builds these two stood BEHIND conv_bx64_kernel's fused form,
-    // which always took the pairs: bit 256 had no effect in the backbone; bit 512: block5.1, block5.2.  -1 (positions beyond the raster's exact range): the paths below
-    if (rc && use_bx && (h->opt.fx & 129) == 129 && c.w_rs && !c2 && !nhwc && c.cin == 64) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace);
-    if (rc && use_bx && (h->opt.fx & 513) == 513 && c.w_rs && !c2 && !nhwc && c.cin == 128) rc = launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status);
-    if (rc && use_bx && (h->opt.fx & 257) == 257 && c.w_rs && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc, h->trace);
-    if (rc && use_bx && c.w_bx && c2 && c2->w_bx && c.cin == 64 && c.ks == 3 && ((use_bx & 2) || ((use_bx & 4) && big_map)))
-        rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, c2, nhwc, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // 3x3 + trailing 1x1 in one split-operand kernel
-    if (rc && (use_bx & 16) && (h->opt.fx & 1025) == 1025 && c.w_fx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status);      // fx bit 1024: block4.0, block5.0 in the fp16-pair arithmetic
-    if (rc && (use_bx & 16) && c.w_bx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace);      // block4.0, block5.0
-    if (rc && use_bx && c.w_bx && !c2 && !nhwc && (c.stride == 1 || c.cin == 24)) {
-        if (c.cin == 24 && !(c.stride == 2 && (use_bx & 8))) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, (h->opt.fx & 2) != 0, h->status);      // (bx = 9: block3.0 stays on the f32 kernel)
-        else if ((use_bx & 2) || ((use_bx & 4) && big_map)) rc = launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, (h->opt.fx & 1) ? ((h->opt.fx & 4) ? 2 : 1) : 0, h->status);      // (bx = 5: large maps only)
+    const int fx = h->opt.fx;
+    if ((fx & XFH_FX_CONV64) && c.ks == 3 && c.stride == 1 && c.w_rs) {
+        if (c.cin == 64 && !c2 && !nhwc) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace);          // block4.1, block4.2, block_fusion.0
+        else if (c.cin == 128 && !c2 && !nhwc) rc = launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status);                           // block5.1, block5.2
+        else if (c.cin == 64 && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc, h->trace);        // block3.1 + .2, block_fusion.1 + .2
     }
-    if (rc && use_wino && c.w_wino && (use_wino > 1 || !c2)) rc = launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, 0, h->trace, c2, nhwc);
+    if (rc && (fx & XFH_FX_CONV64) && c.w_fx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status);      // block4.0, block5.0
+    if (rc && (fx & XFH_FX_CONV24) && c.w_fx && !c2 && !nhwc && c.cin == 24) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, h->status);      // block2.0, block2.1, block3.0
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
     const int cl = c2 ? c2->cout : c.cout;
     double bytes = 4.0 * ((double)B * c.cin * Hin * Win + (double)B * cl * Hout * Wout + (double)c.cin * c.cout * c.ks * c.ks);
@@ -655,7 +601,7 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     CONV(L_BLOCK4_2, -1, w.x4b, H16, W16, w.x4c, false);
     CONV(L_BLOCK5_0, -1, w.x4c, H16, W16, w.x5a, false);
     CONV(L_BLOCK5_1, -1, w.x5a, H32, W32, w.x5b, false);
-    if ((h->opt.fx & 513) == 513 && h->opt.bx && nw.conv[L_BLOCK5_2].w_rs && conv_rs128_fits(W32)) {
+    if ((h->opt.fx & XFH_FX_CONV64) && nw.conv[L_BLOCK5_2].w_rs && conv_rs128_fits(W32)) {
         CONV(L_BLOCK5_2, -1, w.x5b, H32, W32, w.x5a, false);          // conv_rs64_kernel's 128-channel form holds a quarter of the couts per workgroup: the 1x1 (128 -> 64) runs on its own (x5a is free since block5.1)
         CONV(L_BLOCK5_3, -1, w.x5a, H32, W32, w.x5d, false);
     } else
@@ -670,9 +616,10 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     // fused heads: reliability from the channels-last features, key-point head from the gray image
     const bool all = h->prof.which == XFH_PROF_ALL;      // one span per head instead of one for both
     prof_begin(&h->prof, all ? XFH_SPAN_HEAD_REL : XFH_PROF_HEADS, st);
-    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, h->opt.heads_f32, h->opt.fx, h->status);
+    const bool heads_f32 = !(h->opt.fx & XFH_FX_HEADS);
+    launch_rel_head(nw, feats, B * H8 * W8, reliab, invnorm, st, heads_f32, h->status);
     if (all) { prof_end(&h->prof, XFH_SPAN_HEAD_REL, st, 0, 0); prof_begin(&h->prof, XFH_SPAN_HEAD_KP, st); }
-    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, h->opt.heads_f32, h->opt.fx, h->status);
+    launch_kp_head(nw, w.gray, w.coef, B, H, W, heat ? heat : w.heat_tmp, logits, st, heads_f32, h->status);
     prof_end(&h->prof, all ? XFH_SPAN_HEAD_KP : XFH_PROF_HEADS, st, 0, 0);
     return check_launch("xfh_backbone");
 }
@@ -705,39 +652,33 @@ int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int
     if (B <= 0 || Hin <= 0 || Win <= 0 || B > 4000) return fail(XFH_ERR_ARG, "xfh_conv_layer: bad shape");
     hipStream_t st = (hipStream_t)stream;
     const ConvW& c = h->nw.conv[layer];
-    if (variant == 1) {
+    if (variant == XFH_CONV_VARIANT_GENERIC) {
         launch_conv_generic(c, in, B, Hin, Win, out, st);
         return check_launch("xfh_conv_layer(generic)");
     }
-    if (variant == 10) {
-        if (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace) : c.stride == 2 ? launch_conv_bx64s2(c, in, B, Hin, Win, out, st, h->trace) : launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no split-bf16 instantiation for layer %d", layer);
-        return check_launch("xfh_conv_layer(split bf16)");
-    }
-    if (variant == 11) {      // the split kernel of the layer in the fp16-pair arithmetic
-        if (!c.w_fx || (c.cin == 24 ? launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, true, h->status)
-                                    : c.cin == 64 && c.stride == 2 ? launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status)
-                                    : (c.cin != 64 || c.stride != 1 || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, nullptr, false, 1, h->status))))
-            return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fp16-pair instantiation for layer %d", layer);
+    if (variant == XFH_CONV_VARIANT_FX) {      // the layer's fp16-pair kernel, or XFH_ERR_UNSUPPORTED -- no silent fallback (tests pin this kernel against the others)
+        int rc = -1;
+        if (c.ks == 3 && c.cin == 24) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, h->status);
+        else if (c.ks == 3 && c.cin == 64 && c.stride == 2) rc = launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status);
+        else if (c.ks == 3 && c.cin == 64 && c.stride == 1 && c.w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace);
+        else if (c.ks == 3 && c.cin == 128 && c.stride == 1 && c.w_rs) rc = launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status);
+        if (rc) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fp16-pair kernel for layer %d at %dx%d", layer, Hin, Win);
         return check_launch("xfh_conv_layer(fp16 pair)");
     }
-    if (variant == 12) {      // 64 -> 64 3x3/s1: the fp16-pair kernel with the weights resident in registers
-        if (c.cin == 128 ? launch_conv_rs128(c, in, B, Hin, Win, out, st, h->status) : launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, nullptr, false, h->trace)) return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: conv_rs64_kernel does not take layer %d at width %d", layer, Win);
-        return check_launch("xfh_conv_layer(fp16 pair, resident weights)");
-    }
-    if (variant >= 13 && variant <= 16) {      // a 3x3 + the 1x1 behind it as ONE launch (block3.1 + .2, block_fusion.1 + .2): 13 / 14 conv_rs64_kernel (NCHW / channels-last output), 15 / 16 conv_bx64_kernel in the fp16-pair arithmetic
+    if (variant == XFH_CONV_VARIANT_FX_PAIR || variant == XFH_CONV_VARIANT_FX_PAIR_NHWC) {      // a 3x3 + the 1x1 behind it as ONE launch of conv_rs64_kernel (block3.1 + .2, block_fusion.1 + .2): NCHW / channels-last output
         if (layer + 1 >= L_NUM) return fail(XFH_ERR_ARG, "xfh_conv_layer: layer %d has no successor", layer);
         const ConvW& c2 = h->nw.conv[layer + 1];
-        const bool nhwc = variant == 14 || variant == 16;
-        if (c2.ks != 1 || c2.cin != 64 || c2.cout != 64 || c.cin != 64 || c.ks != 3 || c.stride != 1 ||
-            (variant <= 14 ? launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, &c2, nhwc, nullptr) : (!c.w_fx || launch_conv_bx64(c, in, B, Hin, Win, out, st, h->trace, &c2, nhwc, 1, h->status))))
-            return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fused 3x3 + 1x1 instantiation for layers %d, %d at width %d", layer, layer + 1, Win);
+        if (c2.ks != 1 || c2.cin != 64 || c2.cout != 64 || c.cin != 64 || c.ks != 3 || c.stride != 1 || !c.w_rs || !c2.w_rs ||
+            launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, &c2, variant == XFH_CONV_VARIANT_FX_PAIR_NHWC, nullptr))
+            return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no fused 3x3 + 1x1 kernel for layers %d, %d at width %d", layer, layer + 1, Win);
         return check_launch("xfh_conv_layer(3x3 + 1x1)");
     }
-    if (variant >= 2) {
-        if (launch_conv_wino(c, h->nw.zeros, in, B, Hin, Win, out, st, variant - 1, h->trace))
-            return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no Winograd instantiation for layer %d", layer);
-        return check_launch("xfh_conv_layer(winograd)");
+    if (variant == XFH_CONV_VARIANT_F32) {      // the f32-MFMA kernel (the range fallback) of the layer
+        if (launch_conv_mfma(c, nullptr, h->nw.zeros, in, B, Hin, Win, out, false, st, h->trace))
+            return fail(XFH_ERR_UNSUPPORTED, "xfh_conv_layer: no f32-MFMA kernel for layer %d at %dx%d", layer, Hin, Win);
+        return check_launch("xfh_conv_layer(f32 mfma)");
     }
+    if (variant != 0) return fail(XFH_ERR_ARG, "xfh_conv_layer: unknown variant %d", variant);
     if (layer >= L_BLOCK1_0 && layer <= L_BLOCK1_3) {
         launch_block1_layer(h->nw, layer, in, B, Hin, Win, out, st);
         return check_launch("xfh_conv_layer(block1)");
@@ -835,7 +776,7 @@ size_t xfh_refine_workspace_bytes(int P, int N) {
 // two descriptors); y: (M, 64) fp32
 static int fine_chain(xfh_handle h, LinLoader loader, const LinSrc& first, int M, const int32_t* m_dev, float* actA, float* actB, float* y, hipStream_t st) {
     const LinW* f = h->nw.fine;
-    bool fx = (h->opt.fx & 2049) == 2049;
+    bool fx = (h->opt.fx & XFH_FX_FINE) != 0;
     for (int li = 0; li < 5; ++li) fx = fx && f[li].w_fx && (li == 0 || li == 4 || f[li].n_pad % 128 == 0);
     float* bufs[2] = {actA, actB};
     int bad = 0;
@@ -976,21 +917,22 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
     return check_launch("xfh_debug_block1");
 }
 
-static int* option_slot(xfh_handle h, const char* key, int& lo, int& hi) {
-    struct { const char* k; int Options::*m; int lo, hi; } tab[] = {
-        {"match_exact", &Options::match_exact, 0, 1}, {"wino", &Options::wino, 0, 2}, {"bx", &Options::bx, 0, 31},
-        {"heads_f32", &Options::heads_f32, 0, 3}, {"block1", &Options::block1, 0, 7}, {"fx", &Options::fx, 0, 4095}, {"resize2", &Options::resize2, 0, 1}};
+// option -> its slot and the values it takes (include/xfeat_hip.h: xfh_set_option)
+static int* option_slot(xfh_handle h, const char* key) {
+    struct { const char* k; int Options::*m; } tab[] = {{"match_exact", &Options::match_exact}, {"block1", &Options::block1}, {"fx", &Options::fx}, {"resize2", &Options::resize2}};
     for (auto& t : tab)
-        if (!strcmp(t.k, key)) { lo = t.lo; hi = t.hi; return &(h->opt.*(t.m)); }
+        if (!strcmp(t.k, key)) return &(h->opt.*(t.m));
     return nullptr;
 }
 int xfh_set_option(xfh_handle h, const char* key, int value) {
     if (!h || !key) return fail(XFH_ERR_ARG, "xfh_set_option: NULL argument");
-    int lo, hi;
-    int* slot = option_slot(h, key, lo, hi);
-    if (!slot) return fail(XFH_ERR_ARG, "xfh_set_option: unknown option '%s'", key);
-    if (value < lo || value > hi) return fail(XFH_ERR_ARG, "xfh_set_option: %s = %d outside [%d, %d]", key, value, lo, hi);
-    if (!strcmp(key, "block1") && value == 2) return fail(XFH_ERR_ARG, "xfh_set_option: block1 = 2 names no kernel (0 | 5 = shipped, 1, 3, 4 = earlier forms, 6 / 7 = conv4 / conv3 + conv4 on the fp16 matrix cores)");
+    int* slot = option_slot(h, key);
+    if (!slot) return fail(XFH_ERR_ARG, "xfh_set_option: unknown option '%s' (match_exact, block1, fx, resize2)", key);
+    bool ok;
+    if (!strcmp(key, "block1")) ok = value == 5 || value == 7;
+    else if (!strcmp(key, "fx")) ok = value >= 0 && (value & ~XFH_FX_ALL) == 0;
+    else ok = value == 0 || value == 1;
+    if (!ok) return fail(XFH_ERR_ARG, "xfh_set_option: %s = %d is not a value of this option", key, value);
     *slot = value;
     return XFH_OK;
 }
@@ -1001,8 +943,7 @@ int xfh_set_status_buffer(xfh_handle h, int32_t* device_word) {
 }
 int xfh_get_option(xfh_handle h, const char* key, int* value) {
     if (!h || !key || !value) return fail(XFH_ERR_ARG, "xfh_get_option: NULL argument");
-    int lo, hi;
-    const int* slot = option_slot(h, key, lo, hi);
+    const int* slot = option_slot(h, key);
     if (!slot) return fail(XFH_ERR_ARG, "xfh_get_option: unknown option '%s'", key);
     *value = *slot;
     return XFH_OK;
@@ -1013,16 +954,6 @@ int xfh_debug_trace(xfh_handle h, long long* device_buffer) {
     h->trace = device_buffer;
     g_head_trace = device_buffer ? device_buffer + (1 << 21) + (1 << 16) : nullptr;      // the key-point head's stamps live 2 Mi + 64 Ki entries into the buffer (the conv kernels use the front)
     return XFH_OK;
-}
-
-int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int W, float* gray, float* coef, double* part, float* heat, const float* heat_ref,
-                        float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, xfh_stream stream) {
-    if (!h || !gray || !coef || !heat) return fail(XFH_ERR_ARG, "xfh_debug_head_soak: NULL argument");
-    hipStream_t st = (hipStream_t)stream;
-    if (img) launch_gray_norm(img, B, C, H, W, part, gray, coef, st);      // (first call: the head's inputs)
-    if (head_soak(h->nw, gray, coef, B, H, W, heat, heat_ref, logits, logits_ref, variant, iters, iter0, rep_heat, rep_logits, cap, st))
-        return fail(XFH_ERR_ARG, "xfh_debug_head_soak: unknown variant %d", variant);
-    return check_launch("xfh_debug_head_soak");
 }
 
 int xfh_profile_select(xfh_handle h, int which) {

@@ -38,7 +38,7 @@ namespace xfh {
 //     out  8 x 16  at (Y4, X4)            [H/4 x W/4]
 //     c3  17 x 33  at (2Y4-1, 2X4-1)      [H/2 x W/2]   conv3 8->8 s1
 //     c2  19 x 35  at (2Y4-2, 2X4-2)      [H/2 x W/2]   conv2 4->8 s2
-//     c1  39 x 71  at (4Y4-5, 4X4-5)      [H x W]       conv1 1->4 s1
+//     c1  39 x 71  at (4Y4-5, 4X4-5)      [H x W]       conv1 1->4 s1 (never stored: recomputed inside conv2)
 //     g   41 x 73  at (4Y4-6, 4X4-6)      [H x W]       normalised gray
 //   Positions outside a map are stored as 0 = the next conv's zero padding.
 //   Weights are read with wave-uniform addresses (scalar loads, SGPR operands of v_fmac).
@@ -48,22 +48,19 @@ constexpr int OH = 8, OW = 16;
 constexpr int C3H = 17, C3W = 33, C2H = 19, C2W = 35, C1H = 39, C1W = 71, GH = 41, GW = 73;
 constexpr int G_OFF = 0, G_SZ = GH * GW;                  // 2993 (+ 1: rows are loaded as column pairs, the last pair of the last row spills one element)
 constexpr int SK_OFF = G_OFF + G_SZ + 3, SK_SZ = OH * OW; // 4 x 4 averages of the gray tile (skip1's AvgPool2d), one per output pixel  (+ 3: the spill element, and every tile behind it 16-byte aligned)
-constexpr int C1_OFF = SK_OFF + SK_SZ, C1_SZ = 4 * C1H * C1W;  // 11076
-constexpr int C2_OFF = C1_OFF + C1_SZ, C2_SZ = 8 * C2H * C2W;  // 5320
-constexpr int C3_OFF = C1_OFF;                            // overlays c1 (dead once c2 exists)
-constexpr int LDS_FLOATS = C2_OFF + C2_SZ;                // 19518 floats = 78.1 KB
-// mode 5 (conv1 recomputed inside conv2, no c1 tile): g | sk | c2 | c3 = 51.7 KB -> three workgroups per CU.  (c3 over the dead gray tile
-// = 39.7 KB = four per CU measured 0.947 of mode 4's time against 0.924 for three: more waves than the LDS pipe and L1 feed.)
+constexpr int C2_SZ = 8 * C2H * C2W;                      // 5320
+// mode 5 (vector ALUs only; conv1 recomputed inside conv2, no c1 tile): g | sk | c2 | c3 = 51.7 KB -> three workgroups per CU.  (c3 over the dead gray tile
+// = 39.7 KB = four per CU measured slower: more waves than the LDS pipe and L1 feed.)
 constexpr int F_SK_OFF = SK_OFF, F_C2_OFF = SK_OFF + SK_SZ, F_C3_OFF = F_C2_OFF + C2_SZ, F_LDS_FLOATS = F_C3_OFF + 8 * C3H * C3W;      // 12930 floats
-// modes 6, 7 (matrix-core stages): no skip table -- every thread of stage 4 holds its pixel's average in a register -- so the tiles move up by it and conv3's weight image
-// (mode 7) fits behind them in 53 616 bytes: three workgroups per CU also if LDS is handed out in 1280-byte granules (42 of them; 160 KB / 3 = 54 613 bytes)
+// mode 7 (conv3, conv4 on the matrix cores): no skip table -- every thread of stage 4 holds its pixel's average in a register -- so the tiles move up by it and conv3's weight image
+// fits behind them in 53 616 bytes: three workgroups per CU also if LDS is handed out in 1280-byte granules (42 of them; 160 KB / 3 = 54 613 bytes)
 constexpr int M_C2_OFF = SK_OFF, M_C3_OFF = M_C2_OFF + C2_SZ, M_LDS_FLOATS = M_C3_OFF + 8 * C3H * C3W;      // 12804 floats
 static_assert(SK_OFF % 4 == 0 && F_C2_OFF % 4 == 0 && F_C3_OFF % 4 == 0 && F_LDS_FLOATS % 4 == 0 && M_C3_OFF % 4 == 0 && M_LDS_FLOATS % 4 == 0,
-              "16-byte aligned tiles: the fp16-pair planes of modes 6 / 7 are read as b128");
+              "16-byte aligned tiles: the fp16-pair planes of mode 7 are read as b128");
 }  // namespace b1
 
-template <int C1MODE>      // conv1: 1 = a pixel per thread, 3 = three adjacent pixels (scalar FMAs), 4 = three adjacent pixels on packed FMAs,
-                           // 5 = recomputed from the gray tile inside conv2 (no c1 tile in LDS); 6 = 5 with conv4 on the fp16 matrix cores (below)
+template <int MODE>      // 5 = every layer on the vector ALUs (fp32's range: the fallback of the range guard); 7 = conv3 and conv4 on the fp16 matrix cores (the default).
+                         // Both recompute conv1 from the gray tile inside conv2 (no c1 tile in LDS)
 __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray, const float* __restrict__ coef, float* __restrict__ x1, int B, int H, int W,
                                                            int tiles_x, int tiles_y,
                                                            const float* __restrict__ w1, const float* __restrict__ bb1,
@@ -73,26 +70,25 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
                                                            const float* __restrict__ skw, const float* __restrict__ skb,
                                                            const void* __restrict__ w4fx, const void* __restrict__ w3fx, int* __restrict__ status, int cold) {
     using namespace b1;
-    constexpr bool F5 = C1MODE >= 5;                     // no c1 tile
-    constexpr bool MX = C1MODE >= 6;                     // conv4 (8 -> 24, stride 2) as 18 v_mfma_f32_16x16x32_f16 per wave in the fp16-pair arithmetic (block1_fx.hpp):
-                                                         // stage 3 leaves c3 as fp16 pairs, the compact weight image lands over the dead gray tile during stage 3
-    constexpr bool MX3 = C1MODE == 7;                    // conv3 (8 -> 8) too: stage 2 leaves c2 as fp16 pairs, 36 blocks of 16 pixels x 9 MFMAs over the 8 waves; its weight
+    static_assert(MODE == 5 || MODE == 7, "block1: 5 (vector ALUs) or 7 (conv3, conv4 on the matrix cores)");
+    constexpr bool MX = MODE == 7;                       // conv4 (8 -> 24, stride 2) as 18 v_mfma_f32_16x16x32_f16 per wave in the fp16-pair arithmetic (block1_fx.hpp):
+                                                         // stage 3 leaves c3 as fp16 pairs, the compact weight image lands over the dead gray tile during stage 3;
+                                                         // conv3 (8 -> 8) too: stage 2 leaves c2 as fp16 pairs, 19 blocks of 16 pixel pairs x 9 MFMAs over the 8 waves; its weight
                                                          // image (2.3 KB behind the tiles) is fetched when the kernel starts
     if constexpr (MX) kernel_entry_hooks(cold);          // debug: code-position shift / cold instruction cache (common.hpp)
     XFH_DYN_LDS(lds);
     typedef xfh_gptr_t gptr_t;
     typedef xfh_lptr_t lptr_t;
-    if constexpr (MX3) {      // three 1-KiB pieces, the last one 288 bytes = 18 lanes
+    if constexpr (MX) {      // three 1-KiB pieces, the last one 288 bytes = 18 lanes
         const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), ln64 = threadIdx.x & 63;
         if (wv < 3 && (wv < 2 || ln64 < (b1fx::W3_BYTES - 2048) / 16))
             __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const unsigned char*>(w3fx) + wv * 1024 + ln64 * 16),
                                              (lptr_t)(reinterpret_cast<unsigned char*>(lds + M_LDS_FLOATS) + wv * 1024), 16, 0, 0);
     }
     float* G = lds + G_OFF;
-    float* SK = lds + (F5 ? F_SK_OFF : SK_OFF);
-    float* C1 = lds + C1_OFF;
-    float* C2 = lds + (MX ? M_C2_OFF : F5 ? F_C2_OFF : C2_OFF);
-    float* C3 = lds + (MX ? M_C3_OFF : F5 ? F_C3_OFF : C3_OFF);
+    float* SK = lds + F_SK_OFF;
+    float* C2 = lds + (MX ? M_C2_OFF : F_C2_OFF);
+    float* C3 = lds + (MX ? M_C3_OFF : F_C3_OFF);
     const int tid = threadIdx.x;
     // the tiles of an image run on one XCD: the 4-pixel gray halos of neighbouring tiles hit its L2
     int b, item;
@@ -130,109 +126,7 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
     }
     if constexpr (MX) lds_dma_barrier(); else __syncthreads();      // (MX: every barrier of a kernel with LDS-DMA waits for it -- tools/check_dma_barriers.py; nothing is in flight that is not needed here)
 
-    // ---- stage 1: conv1 1->4, s1 --------------------------------------------------------------
-    if constexpr (F5) {
-        // (no c1 tile: stage 2 recomputes the nine c1 pixels of its window from the gray tile)
-    } else if constexpr (C1MODE == 4) {
-        // three adjacent pixels per thread, cout pairs on v_pk_fma_f32 (written as 2-vectors: left to itself hipcc emits 108 v_fmac_f32 here)
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        constexpr int NG = (C1W + 2) / 3;
-        for (int e = tid; e < C1H * NG; e += 512) {
-            const int r = e / NG, c0 = (e - r * NG) * 3;
-            const int gy = 4 * Y4 - 5 + r, gx0 = 4 * X4 - 5 + c0;
-            f2 acc[3][2];
-#pragma unroll
-            for (int px = 0; px < 3; ++px) { acc[px][0] = f2{bb1[0], bb1[1]}; acc[px][1] = f2{bb1[2], bb1[3]}; }
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                float v[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) v[j] = G[(r + dy) * GW + c0 + j];          // (the last group reads one element past its row: unused pixel)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* w = w1 + (dy * 3 + dx) * 4;
-                    const f2 w01 = f2{w[0], w[1]}, w23 = f2{w[2], w[3]};
-#pragma unroll
-                    for (int px = 0; px < 3; ++px) {
-                        const f2 vv = f2{v[px + dx], v[px + dx]};
-                        acc[px][0] = __builtin_elementwise_fma(vv, w01, acc[px][0]);
-                        acc[px][1] = __builtin_elementwise_fma(vv, w23, acc[px][1]);
-                    }
-                }
-            }
-            const bool rowok = gy >= 0 && gy < H;
-#pragma unroll
-            for (int px = 0; px < 3; ++px) {
-                const int gx = gx0 + px;
-                const bool ok = rowok && gx >= 0 && gx < W;
-                if (c0 + px < C1W) {
-                    float* o = C1 + r * C1W + c0 + px;
-                    o[0] = ok ? fmaxf(acc[px][0].x, 0.f) : 0.f;
-                    o[C1H * C1W] = ok ? fmaxf(acc[px][0].y, 0.f) : 0.f;
-                    o[2 * C1H * C1W] = ok ? fmaxf(acc[px][1].x, 0.f) : 0.f;
-                    o[3 * C1H * C1W] = ok ? fmaxf(acc[px][1].y, 0.f) : 0.f;
-                }
-            }
-        }
-    } else if constexpr (C1MODE == 3) {
-        // three adjacent pixels per thread: one index computation and 15 LDS reads for 3 x 36 FMAs (a pixel alone: 9 reads for 36)
-        constexpr int NG = (C1W + 2) / 3;
-        for (int e = tid; e < C1H * NG; e += 512) {
-            const int r = e / NG, c0 = (e - r * NG) * 3;
-            const int gy = 4 * Y4 - 5 + r, gx0 = 4 * X4 - 5 + c0;
-            float acc[3][4];
-#pragma unroll
-            for (int px = 0; px < 3; ++px)
-#pragma unroll
-                for (int co = 0; co < 4; ++co) acc[px][co] = bb1[co];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                float v[5];
-#pragma unroll
-                for (int j = 0; j < 5; ++j) v[j] = G[(r + dy) * GW + c0 + j];          // (the last group reads one element past its row: unused pixel)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* w = w1 + (dy * 3 + dx) * 4;
-#pragma unroll
-                    for (int px = 0; px < 3; ++px)
-#pragma unroll
-                        for (int co = 0; co < 4; ++co) acc[px][co] = fmaf(v[px + dx], w[co], acc[px][co]);
-                }
-            }
-            const bool rowok = gy >= 0 && gy < H;
-#pragma unroll
-            for (int px = 0; px < 3; ++px) {
-                const int gx = gx0 + px;
-                const bool ok = rowok && gx >= 0 && gx < W;
-                if (c0 + px < C1W) {
-#pragma unroll
-                    for (int co = 0; co < 4; ++co) C1[co * (C1H * C1W) + r * C1W + c0 + px] = ok ? fmaxf(acc[px][co], 0.f) : 0.f;
-                }
-            }
-        }
-    } else
-    for (int e = tid; e < C1H * C1W; e += 512) {
-        const int r = e / C1W, c = e - r * C1W;
-        const int gy = 4 * Y4 - 5 + r, gx = 4 * X4 - 5 + c;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-#pragma unroll
-            for (int co = 0; co < 4; ++co) acc[co] = bb1[co];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float v = G[(r + dy) * GW + c + dx];
-                    const float* w = w1 + (dy * 3 + dx) * 4;
-#pragma unroll
-                    for (int co = 0; co < 4; ++co) acc[co] = fmaf(v, w[co], acc[co]);
-                }
-#pragma unroll
-            for (int co = 0; co < 4; ++co) acc[co] = fmaxf(acc[co], 0.f);
-        }
-#pragma unroll
-        for (int co = 0; co < 4; ++co) C1[co * (C1H * C1W) + e] = acc[co];
-    }
+    // ---- (stage 1, conv1 1->4 s1, has no pass of its own: stage 2 recomputes the nine c1 pixels of its window from the gray tile) ----
     float sk_reg = 0.f;     // MX: skip1's 4 x 4 average of THIS thread's stage-4 pixel (wave = output row, lane & 15 = column): the four lanes that share a pixel sum a
                             // window row each and exchange (two wave shuffles); no table in LDS
     if constexpr (MX) {
@@ -243,8 +137,7 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
         sm += __shfl_xor(sm, 32, 64);
         sk_reg = sm * 0.0625f;
     } else
-    if (tid >= 384) {       // skip1's 4 x 4 averages, once per output pixel (the second pass of conv1 occupies threads 0..410: these 128 are the least loaded;
-                            // round 2 had each of stage 4's four cout groups recompute them: 16 LDS reads + 16 adds per thread)
+    if (tid >= 384) {       // skip1's 4 x 4 averages, once per output pixel
         const int p = tid - 384, r = p >> 4, c = p & 15;
         float sm = 0.f;
 #pragma unroll
@@ -253,11 +146,10 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
             for (int jj = 0; jj < 4; ++jj) sm += G[(4 * r + 6 + i) * GW + 4 * c + 6 + jj];
         SK[p] = sm * 0.0625f;
     }
-    if constexpr (!F5) __syncthreads();
 
     float amax = 0.f;        // MX: the largest activation this thread converted to an fp16 pair (range guard, bx_split.hpp)
     // ---- stage 2: conv2 4->8, s2 --------------------------------------------------------------
-    if constexpr (F5) {
+    {
         // conv1 inside conv2: a c2 pixel needs the 3 x 3 c1 pixels (2r + py, 2c + px), each a 3 x 3 window of the gray tile: 25 LDS reads
         // and 9 x 36 FMAs in registers instead of 36 reads of a c1 tile that first had to be computed, written (44 KB of LDS, the largest
         // tile of the kernel) and waited for behind a barrier.  2.25x the conv1 FLOPs (+ 12 % of the kernel's), one stage and 26 KB less.
@@ -317,7 +209,7 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc[2 * j] = fmaxf(q[j].x, 0.f); acc[2 * j + 1] = fmaxf(q[j].y, 0.f); }
             }
-            if constexpr (MX3) {      // the pixel's 8 channels as fp16 pairs (even and odd columns of a row apart: block1_fx.hpp)
+            if constexpr (MX) {      // the pixel's 8 channels as fp16 pairs (even and odd columns of a row apart: block1_fx.hpp)
                 uint4 h, l;
                 split2_f16(acc[0], acc[1], h.x, l.x); split2_f16(acc[2], acc[3], h.y, l.y);
                 split2_f16(acc[4], acc[5], h.z, l.z); split2_f16(acc[6], acc[7], h.w, l.w);
@@ -330,36 +222,8 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
                 for (int co = 0; co < 8; ++co) C2[co * (C2H * C2W) + e] = acc[co];
             }
         }
-    } else
-    for (int e = tid; e < C2H * C2W; e += 512) {
-        const int r = e / C2W, c = e - r * C2W;
-        const int gy = 2 * Y4 - 2 + r, gx = 2 * X4 - 2 + c;
-        float acc[8];
-#pragma unroll
-        for (int co = 0; co < 8; ++co) acc[co] = 0.f;
-        if (gy >= 0 && gy < H2 && gx >= 0 && gx < W2) {
-#pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = bb2[co];
-#pragma unroll 1
-            for (int ci = 0; ci < 4; ++ci) {
-                const float* src = C1 + ci * (C1H * C1W) + (2 * r) * C1W + 2 * c;
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) {
-                        const float v = src[dy * C1W + dx];
-                        const float* w = w2 + ((ci * 9) + dy * 3 + dx) * 8;
-#pragma unroll
-                        for (int co = 0; co < 8; ++co) acc[co] = fmaf(v, w[co], acc[co]);
-                    }
-            }
-#pragma unroll
-            for (int co = 0; co < 8; ++co) acc[co] = fmaxf(acc[co], 0.f);
-        }
-#pragma unroll
-        for (int co = 0; co < 8; ++co) C2[co * (C2H * C2W) + e] = acc[co];
     }
-    if constexpr (MX) lds_dma_barrier();       // (MX3: conv3's weight image has landed, for every wave)
+    if constexpr (MX) lds_dma_barrier();       // (conv3's weight image has landed, for every wave)
     else __syncthreads();
     if constexpr (MX) {      // the gray tile is dead: conv4's weight image takes its place (eleven 1-KiB pieces; it lands during stage 3)
         static_assert(b1fx::W4_BYTES <= (G_SZ + 3) * 4, "the weight image must fit into the gray tile");
@@ -371,7 +235,7 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
 
     // ---- stage 3 on the matrix cores: a column of the product = a pair of adjacent pixels (block1_fx.hpp); blocks of 16 consecutive pairs of the 17 x 17 pairs of
     // the tile; D: lane (pair ln, kg) holds couts 4 (kg & 1) + j of pixel 2 pc + (kg >> 1) ---------------------------------------------------------------------
-    if constexpr (MX3) {
+    if constexpr (MX) {
         static_assert(b1fx::C2H == C2H && b1fx::C2W == C2W && 2 * b1fx::C2_PLANE == 8 * C2H * C2W * 4, "the fp16-pair planes fill the c2 tile exactly");
         typedef float f32x4v __attribute__((ext_vector_type(4)));
         constexpr int NP = b1fx::NPAIR;
@@ -447,7 +311,7 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
         if (wv + 16 < b1fx::NBLK3) blocks(std::integral_constant<int, 3>{}, wv);
         else blocks(std::integral_constant<int, 2>{}, wv);
     } else
-    // ---- stage 3: conv3 8->8, s1 (writes over the dead c1 tile) ----------------------------------
+    // ---- stage 3: conv3 8->8, s1 ----------------------------------
     for (int e = tid; e < C3H * C3W; e += 512) {
         const int r = e / C3W, c = e - r * C3W;
         const int gy = 2 * Y4 - 1 + r, gx = 2 * X4 - 1 + c;
@@ -473,18 +337,8 @@ __device__ __forceinline__ void block1_fused_body(const float* __restrict__ gray
 #pragma unroll
             for (int co = 0; co < 8; ++co) acc[co] = fmaxf(acc[co], 0.f);
         }
-        if constexpr (MX) {      // the pixel's 8 channels as fp16 pairs: 16 bytes into the plane of high parts, 16 into the plane of low parts
-            uint4 h, l;
-            split2_f16(acc[0], acc[1], h.x, l.x); split2_f16(acc[2], acc[3], h.y, l.y);
-            split2_f16(acc[4], acc[5], h.z, l.z); split2_f16(acc[6], acc[7], h.w, l.w);
-            amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])), fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7]))));      // (ReLU'd: no fabs)
-            unsigned char* p = reinterpret_cast<unsigned char*>(C3) + b1fx::c3_pixel_off(r, c);
-            *reinterpret_cast<uint4*>(p) = h;
-            *reinterpret_cast<uint4*>(p + b1fx::C3_PLANE) = l;
-        } else {
 #pragma unroll
-            for (int co = 0; co < 8; ++co) C3[co * (C3H * C3W) + e] = acc[co];
-        }
+        for (int co = 0; co < 8; ++co) C3[co * (C3H * C3W) + e] = acc[co];
     }
     if constexpr (MX) {
         fx_report(amax, status);

@@ -1,24 +1,19 @@
-// conv_bx64s2x_kernel (k_conv_bx64s2x.hip): conv_bx64s2_kernel (k_conv_bx64s2.hip, which stays as it was soaked) with the arithmetic as a template parameter -- FX = the fp16-pair
-// arithmetic, three MFMAs per K step instead of six -- and the body in a header of its own, so that tests/emu/ can compile the SAME source for the host (XFH_HOST_EMU); the
-// bf16 form of this body is the emulator's control, the library instantiates the fp16-pair form only.
+// conv_bx64s2x_kernel (k_conv_bx64s2x.hip): the kernel body in a header of its own, so that tests/emu/ can compile the SAME source for the host (XFH_HOST_EMU).
 //
-// 3x3 stride-2 convolution, 64 -> 64 or 64 -> 128 channels (block4.0 / block5.0; modules/model.py:68,75), on the bf16 matrix cores with
-// three-way split operands (the arithmetic of k_conv_bx.hip; the weight stream and the input chunks of k_conv_bx64.hip).
-//
-// These two layers were the last direct convolutions on the f32 matrix cores (0.49 / 0.36 of THAT peak: 74 + 51 us per 64-frame step for
-// 5.7 + 2.8 GFLOP); six bf16 MFMAs per K = 16 carry the same fp32 product sums at 2.7x the rate.  The maps are small (30x40 / 15x20
-// outputs per VGA frame), so the kernel is shaped by balance, not by reuse:
+// 3x3 stride-2 convolution, 64 -> 64 or 64 -> 128 channels (block4.0 / block5.0; modules/model.py:68,75), on the fp16 matrix cores in the fp16-pair arithmetic
+// (bx_split.hpp: two input fragments per pixel, three v_mfma_f32_32x32x16_f16 per K step).  The maps are small (30x40 / 15x20 outputs per VGA frame), so the kernel is
+// shaped by balance, not by reuse:
 //   * unit = (cout half, image, 16-column strip, 8-row tile): 8x16 output pixels x 64 couts.  VGA batch 64: 768 units for block4.0
 //     (three per CU), 512 for block5.0 (two per CU: the second cout half of an image is another unit, not another accumulator);
 //   * ONE workgroup of 8 waves per CU (all of its LDS): wave (pb, cb) owns pixel block pb (2 output rows x 16 columns) and cout block
-//     cb: one 32x32 accumulator, per K step 3 + 3 ds_read_b128 for 6 MFMAs (half of the LDS read rate with two waves per SIMD);
+//     cb: one 32x32 accumulator pair, per K step 2 + 3 ds_read_b128 for 3 MFMAs;
 //   * the 17x33 input halo of a tile goes through LDS in chunks of 16 channels with EVEN and ODD columns apart
-//     ([17 rows, 3712 B apart][parity, 1904 B apart][17 / 16 pixels, 112 B apart][split h, m, l][16 channels] bf16): the 16 lanes of a
-//     ds_read_b128 group step by two input pixels and would collide pairwise in one plane; 112 B keeps them on distinct banks;
+//     ([17 rows, 2688 B apart][parity][17 / 16 pixels, 80 B apart][high parts, low parts][16 channels] fp16): the 16 lanes of a
+//     ds_read_b128 group step by two input pixels and would collide pairwise in one plane; 80 B keeps them on distinct banks, and a row pitch that is a multiple of 128 B puts the
+//     eight lanes of the block's second output row between the banks of the first row's eight;
 //   * TWO such buffers: chunk g + 1 is split and written while chunk g is multiplied.  With all eight waves of a CU in one workgroup
-//     nobody else covers a staging phase (first version: 13 k of a unit's 42 k cycles were split3 + ds_write between two barriers, all
-//     matrix pipes idle), and a wave's vector work only hides in the issue gaps of its OWN MFMAs: the five waves that hold staging items
-//     split half an item (two pixels x 8 channels) inside each of a chunk's first two tap rows, in the same basic block as that row's 18
+//     nobody else covers a staging phase, and a wave's vector work only hides in the issue gaps of its OWN MFMAs: the five waves that hold staging items
+//     split half an item (two pixels x 8 channels) inside each of a chunk's first two tap rows, in the same basic block as that row's 9
 //     MFMAs (no branch: lanes without an item write to a dump slot; waves 5 - 7 run a copy of the unit's code without loads and splits).  Raw fp32 values are loaded two chunks ahead (two register sets), also across units;
 //   * the split weights (216 KiB per cout half) stream through a two-slot LDS ring by LDS-DMA, one slot = one tap row of one chunk
 //     (3 K steps, 18 KiB); the DMA of row r + 1 is issued behind the barrier that opens row r.  One barrier per tap row, none per chunk.
@@ -26,18 +21,30 @@
 #ifndef XFH_HOST_EMU
 #include "kernels.hpp"
 #include <type_traits>
+#ifndef XFH_DYN_LDS_BYTES
+#define XFH_DYN_LDS_BYTES(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 #endif
-#include "conv_bx64_body.hpp"      // (the macros both bodies share: XFH_DYN_LDS_BYTES, XFH_LDS_ADDR, XFH_DMA_B128_TO_LDS, XFH_WAIT_VMCNT0, XFH_NOP16; bx_split.hpp)
-#ifndef XFH_HOST_EMU
-/* six just-read fragments stay occupied up to here (the staging's results are not handed their registers while an MFMA may still be reading them) */
-#define XFH_S2_KEEP6(a, b, c, d, e, f) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f))
+#ifndef XFH_LDS_ADDR
+#define XFH_LDS_ADDR(p, base) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(p))
 #endif
+#ifndef XFH_DMA_B128_TO_LDS
+/* LDS-DMA of 16 bytes per lane: M0 = LDS address of the 1-KiB piece, the lane's part of the global address in voff (inline asm: hipcc would make every LDS read wait for all DMA it can see) */
+#define XFH_DMA_B128_TO_LDS(m0v, voff, rsrc, soff) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)(m0v))), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane((int)(soff))) : "memory")      /* (readfirstlane: both are wave-uniform by construction; where hipcc cannot see it, it hands the asm a vector register) */
+#endif
+#ifndef XFH_WAIT_VMCNT0
+#define XFH_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#define XFH_NOP16() asm volatile("s_nop 7\n\ts_nop 7")
+/* five just-read fragments stay occupied up to here (the staging's results are not handed their registers while an MFMA may still be reading them) */
+#define XFH_S2_KEEP5(a, b, c, d, e) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e))
+#endif
+#include "bx_split.hpp"
 
 namespace xfh {
 
 struct Bx64S2xArgs {
     const float* in;
-    const void* wq;            // [cout half][cin/16][3 dy][3 dx][2 cout blocks][3 splits][64 lanes][8 bf16 | fp16]   (weight_split.hpp: pack_bx64)
+    const void* wq;            // [cout half][cin/16][3 dy][3 dx][2 cout blocks][3 fragments][64 lanes][8 fp16]   (weight_split.hpp: pack_bx64)
     const float* bias;
     float* out;
     int relu, H, W, Ho, Wo, B;
@@ -49,26 +56,24 @@ struct Bx64S2xArgs {
 
 namespace bx64s2x {
 constexpr int SPLB = 32, IH = 17, NEVEN = 17;
-template <bool FX> constexpr int pixb() { return FX ? 80 : 112; }          // bytes per staged pixel: 16 channels x (3 bf16 | 2 fp16 fragments) + 16
-template <bool FX> constexpr int xrowb() { return FX ? 2688 : 3712; }      // >= (17 + 16) pixels; odd columns of a row behind its even ones
+constexpr int PIXB = 80;          // bytes per staged pixel: 16 channels x 2 fp16 fragments + 16
+constexpr int XROWB = 2688;       // >= (17 + 16) pixels; odd columns of a row behind its even ones
 constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;
-template <bool FX> constexpr int lds_bytes() { return 2 * IH * xrowb<FX>() + 2 * SLOT_BYTES + 128 * 4 + 256; }      // two X buffers, the weight ring, bias, dump slot
+constexpr int LDS_BYTES = 2 * IH * XROWB + 2 * SLOT_BYTES + 128 * 4 + 256;      // two X buffers, the weight ring, bias, dump slot
 constexpr int NQ = 9;                                   // 4-pixel quads [2 ox0 - 4, 2 ox0 + 32) per halo row
 constexpr int NITEM = IH * NQ * 2;                      // (row, quad, 8-channel group)
-static_assert(NITEM <= 512 && (2 * IH * xrowb<false>()) % 64 == 0 && (2 * IH * xrowb<true>()) % 64 == 0 && lds_bytes<false>() <= 160 * 1024, "one staging item per thread; all of a CU's LDS");
-static_assert(xrowb<true>() >= (17 + 16) * pixb<true>() && xrowb<true>() % 128 == 0 && xrowb<false>() >= (17 + 16) * pixb<false>(), "row pitch");
+static_assert(NITEM <= 512 && (2 * IH * XROWB) % 64 == 0 && LDS_BYTES <= 160 * 1024, "one staging item per thread; all of a CU's LDS");
+static_assert(XROWB >= (17 + 16) * PIXB && XROWB % 128 == 0, "row pitch");
 }
 
-typedef unsigned u32x4_s2 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // NCO: cout halves, 1 (64 couts) or 2 (128).  W4: W % 4 == 0 (no quad straddles the right border: no masking of its tail)
-// FX: the fp16-pair arithmetic (bx_split.hpp: two input fragments per pixel, three MFMAs per K step instead of six; PIXB 80, rows 2688 B apart -- a multiple of 128 B, so that the eight
-// lanes of the block's second output row in a ds_read_b128 group fall between the banks of the first row's eight)
-template <int NCO, bool W4, bool FX>
+template <int NCO, bool W4>
 __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
     using namespace bx64s2x;
-    constexpr int PIXB = pixb<FX>(), PARB = NEVEN * PIXB, XROWB = xrowb<FX>(), X_BYTES = IH * XROWB, RING_OFF = 2 * X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, DUMP_OFF = BIAS_OFF + 128 * 4;
-    constexpr int NXF = FX ? 2 : 3;                  // input fragments per pixel
+    constexpr int PARB = NEVEN * PIXB, X_BYTES = IH * XROWB, RING_OFF = 2 * X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, DUMP_OFF = BIAS_OFF + 128 * 4;
+    constexpr int NXF = 2;                           // input fragments per pixel (high parts, low parts)
     constexpr int CIN = 64, NCH = CIN / 16, NROW = NCH * 3, COUT = 64 * NCO;
     static_assert(NROW % 2 == 0 && NCH % 2 == 0, "ring slot, X buffer and register set of a chunk must not depend on the unit");
     XFH_DYN_LDS_BYTES(smem_s2);
@@ -154,25 +159,24 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
         v[S][k][0] = __uint_as_float(q[0]); v[S][k][1] = __uint_as_float(q[1]); v[S][k][2] = __uint_as_float(q[2]); v[S][k][3] = __uint_as_float(q[3]);
     };
     // Half an item (pixels 2 PP, 2 PP + 1 of the quad x 8 channels) of a register set -> an X buffer, as micro-steps that a tap row places
-    // behind its MFMAs (S2_A1 ... S2_P below): split3_trunc of a channel pair of one pixel (h, residual, m, residual, l), ds_write_b128 of a pixel's rows.  Branch-free: a lane without a pixel to
+    // behind its MFMAs (S2_FX, S2_P below): split2_f16 of a channel pair of one pixel, ds_write_b128 of a pixel's rows.  Branch-free: a lane without a pixel to
     // write (no item, left of the halo, nothing to stage) writes to the dump slot.
     const int row_base = it_row * XROWB + it_g8 * 16 + 2 * it_quad * PIXB;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 qH[2], qM[2], qL[2];                         // [pixel of the half] h / m / l rows: word j = channels 2 j, 2 j + 1
-    float xa[8], xb[8];                                // a unit's two values, then their residuals
+    u32x4 qH[2], qM[2];                                // [pixel of the half] rows of high / low parts: word j = channels 2 j, 2 j + 1
 
     long long* tr = a.trace && tid == 0 ? a.trace + (size_t)blockIdx.x * 64 : nullptr;
     int tix = 0;
 #define S2_STAMP(k) { if (tr && tix == 1) tr[k] = __builtin_amdgcn_s_memtime(); }      /* [0] unit start; row r: [1+4r] start, [2+4r] barrier passed, [3+4r] MFMAs issued; [50] stores issued */
-    typedef typename std::conditional<FX, f16x8, bf16x8>::type frag_t;
-    struct Frag { frag_t x[3]; frag_t w[3]; };      // (fp16 pair: x[0] = high parts, x[1] = low parts)
-    unsigned amax = 0;                                // fp16 pair: range guard on the converted high parts (bx_split.hpp)
+    typedef f16x8 frag_t;
+    struct Frag { frag_t x[2]; frag_t w[3]; };      // x[0] = high parts, x[1] = low parts
+    unsigned amax = 0;                                // range guard on the converted high parts (bx_split.hpp)
     // lane (pixel l31 of block pb): output row 2 pb + (l31 >> 4), column l31 & 15 -> input row 2 * that (+ dy), even column index = column (+ dx >> 1)
     const int lane_px = 2 * (2 * pb + (l31 >> 4)) * XROWB + (l31 & 15) * PIXB + half * 16;
     f32x16 acc, acc2;
 
     // ---- one tap row (chunk C, tap row DY) of a unit: barrier, DMA of the next row, (DY = 0) loads of chunk C + 2, then ONE basic block of
-    // 18 MFMAs with the fragment reads of the later steps and (DY < 2) the split of half an item of chunk C + 1 in their issue gaps.
+    // 9 MFMAs with the fragment reads of the later steps and (DY < 2) the split of half an item of chunk C + 1 in their issue gaps.
     // Every barrier waits for EVERYTHING the wave has in flight (vmcnt(0)).  A first version left "the n youngest" operations in flight -- the eight raw loads
     // behind a row's DMA, the sixteen output stores of the previous unit behind the next unit's first DMA -- on the argument that vmcnt counts in issue order.
     // It does so for loads only: stores are acknowledged out of order with respect to loads, vmcnt(16) was satisfied by early store acks while the DMA was
@@ -211,38 +215,21 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
             for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
         }
         __builtin_amdgcn_sched_barrier(0);
-        // 18 fenced slots of { 1 MFMA, ~7 vector ops of the staging, (DY = 0) one plane of raw loads }: a wave's vector work hides in the
-        // issue gaps of its OWN MFMAs only, and only if no slot holds more of it than an MFMA takes (11 ops in eight slots: + 500 cycles
-        // per row).  Products (weight split, input split), small terms first: (l,h) (h,l) (m,m) (m,h) (h,m) (h,h); two accumulators take
-        // turns: a dependent MFMA stalls at issue until its predecessor has left the pipe, and blocks the ops behind it.
-#define S2_MF(I) { if constexpr ((I) == 6) { S2_KEEP(f[0]) load(2, f[0]); } constexpr int s_ = ((I) / 6) & 1, j_ = (I) % 6, wq_ = j_ == 0 ? 2 : (j_ == 2 || j_ == 3) ? 1 : 0, xq_ = j_ == 1 ? 2 : (j_ == 2 || j_ == 4) ? 1 : 0; \
-        if constexpr (j_ & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s_].w[wq_], f[s_].x[xq_], acc2, 0, 0, 0); \
-        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s_].w[wq_], f[s_].x[xq_], acc, 0, 0, 0); }
+        // 9 fenced slots of { 1 MFMA, one unit of the split (pixel e2, channel pair j: high parts, the two residuals, low parts: ~10 vector ops), a pixel's two ds_write_b128
+        // or two planes of raw loads }: a wave's vector work hides in the issue gaps of its OWN MFMAs only, and only if no slot holds more of it than an MFMA takes.
+        // Products, small terms first: (q2, xh) (q1, xl) (q0, xh); two accumulators take turns: a dependent MFMA stalls at issue until its predecessor has left the pipe,
+        // and blocks the ops behind it.
 #define S2_FENCE __builtin_amdgcn_sched_barrier(0);
         // a fragment's registers stay occupied until every MFMA of its step has long been issued: they are not handed to the staging's results
         // while an MFMA may still be reading them (tools/check_mfma_war.py)
-#define S2_KEEP(F) XFH_S2_KEEP6(F.x[0], F.x[1], F.x[NXF - 1], F.w[0], F.w[1], F.w[2]);
-#define S2_HI(A, B) __builtin_amdgcn_perm(__float_as_uint(B), __float_as_uint(A), 0x07060302u)      /* split3_trunc, step by step */
+#define S2_KEEP(F) XFH_S2_KEEP5(F.x[0], F.x[1], F.w[0], F.w[1], F.w[2]);
 #define S2_ON(PP) if constexpr (MODE == 1 && DY == (PP))
-        // unit U = (pixel e2 of the half, channel pair j): channels 2 j, 2 j + 1 of ONE pixel -> word j of the pixel's h / m / l rows.  (Pairs of
-        // pixels, as k_conv_bx64 splits them, need four more v_perm_b32 per row to gather the channel pairs; v_perm_b32 -- unlike the
-        // packed conversion -- takes any two registers, so pairing channels costs no moves here.)
-#define S2_A1(PP, U) S2_ON(PP) { constexpr int e2_ = (U) >> 2, j_ = (U) & 3; xa[U] = v[SS][2 * j_][2 * (PP) + e2_]; xb[U] = v[SS][2 * j_ + 1][2 * (PP) + e2_]; \
-        if (!W4) { const bool z_ = v_gx[SS] + 2 * (PP) + e2_ >= a.W; xa[U] = z_ ? 0.f : xa[U]; xb[U] = z_ ? 0.f : xb[U]; } qH[e2_][j_] = S2_HI(xa[U], xb[U]); }
-#define S2_A2(PP, U) S2_ON(PP) { xa[U] -= __uint_as_float(__float_as_uint(xa[U]) & 0xffff0000u); }
-#define S2_A3(PP, U) S2_ON(PP) { xb[U] -= __uint_as_float(__float_as_uint(xb[U]) & 0xffff0000u); }
-#define S2_B1(PP, U) S2_ON(PP) { qM[(U) >> 2][(U) & 3] = S2_HI(xa[U], xb[U]); }
-#define S2_B2(PP, U) S2_ON(PP) { xa[U] -= __uint_as_float(__float_as_uint(xa[U]) & 0xffff0000u); }
-#define S2_B3(PP, U) S2_ON(PP) { xb[U] -= __uint_as_float(__float_as_uint(xb[U]) & 0xffff0000u); }
-#define S2_C1(PP, U) S2_ON(PP) { qL[(U) >> 2][(U) & 3] = S2_HI(xa[U], xb[U]); }
         // pixel e = 2 PP + e2 of the quad: halo column c = 4 quad + e - 3 (c < 0: left of the halo), parity c & 1, index (c >> 1) - 2 quad
 #define S2_P(PP, E2, Q) S2_ON(PP) { constexpr int e_ = 2 * (PP) + (E2), par_ = (e_ + 1) & 1, idx_ = e_ == 0 ? -2 : e_ == 3 ? 0 : -1; \
         const bool wr_ = en && has_item && !(it_quad == 0 && e_ < 3); \
-        *reinterpret_cast<u32x4*>(smem_s2 + (wr_ ? SS * X_BYTES + row_base + par_ * PARB + idx_ * PIXB + (Q) * SPLB : DUMP_OFF)) = (Q) == 0 ? qH[E2] : (Q) == 1 ? qM[E2] : qL[E2]; }
+        *reinterpret_cast<u32x4*>(smem_s2 + (wr_ ? SS * X_BYTES + row_base + par_ * PARB + idx_ * PIXB + (Q) * SPLB : DUMP_OFF)) = (Q) == 0 ? qH[E2] : qM[E2]; }
 #define S2_LD(k) if constexpr (STG && DY == 0) load_plane(std::integral_constant<int, P>{}, std::integral_constant<int, k>{}, la, same2 ? C + 2 : C + 2 - NCH);
-        if constexpr (FX) {
-            // fp16 pair: 9 slots of { 1 MFMA, one unit of the split (pixel e2, channel pair j: high parts, the two residuals, low parts: ~10 vector ops), a pixel's two ds_write_b128
-            // or two planes of raw loads }.  Products, small terms first: (q2, xh) (q1, xl) (q0, xh); the two accumulators take turns.
+        {
             constexpr int PP1 = DY & 1;
 #define S2_MFX(I) { if constexpr ((I) == 3) { S2_KEEP(f[0]) load(2, f[0]); } constexpr int s_ = ((I) / 3) & 1, j_ = (I) % 3; \
         if constexpr ((I) & 1) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[s_].w[2 - j_], f[s_].x[j_ == 1 ? 1 : 0], acc2, 0, 0, 0); \
@@ -261,39 +248,9 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
             S2_MFX(8) S2_P(PP1, 1, 0) S2_P(PP1, 1, 1) S2_FENCE
 #undef S2_MFX
 #undef S2_FX
-        } else
-        {
-            constexpr int PP1 = DY & 1;
-            S2_MF(0) S2_A1(PP1, 0) S2_A2(PP1, 0) S2_A3(PP1, 0) S2_B1(PP1, 0) S2_FENCE
-            S2_MF(1) S2_B2(PP1, 0) S2_B3(PP1, 0) S2_C1(PP1, 0) S2_FENCE
-            S2_MF(2) S2_A1(PP1, 1) S2_A2(PP1, 1) S2_A3(PP1, 1) S2_B1(PP1, 1) S2_FENCE
-            S2_MF(3) S2_B2(PP1, 1) S2_B3(PP1, 1) S2_C1(PP1, 1) S2_FENCE
-            S2_MF(4) S2_A1(PP1, 2) S2_A2(PP1, 2) S2_A3(PP1, 2) S2_B1(PP1, 2) S2_FENCE
-            S2_MF(5) S2_B2(PP1, 2) S2_B3(PP1, 2) S2_C1(PP1, 2) S2_FENCE
-            S2_MF(6) S2_A1(PP1, 3) S2_A2(PP1, 3) S2_A3(PP1, 3) S2_B1(PP1, 3) S2_FENCE
-            S2_MF(7) S2_B2(PP1, 3) S2_B3(PP1, 3) S2_C1(PP1, 3) S2_FENCE
-            S2_MF(8) S2_A1(PP1, 4) S2_A2(PP1, 4) S2_A3(PP1, 4) S2_B1(PP1, 4) S2_P(PP1, 0, 0) S2_FENCE
-            S2_MF(9) S2_B2(PP1, 4) S2_B3(PP1, 4) S2_C1(PP1, 4) S2_P(PP1, 0, 1) S2_LD(0) S2_FENCE
-            S2_MF(10) S2_A1(PP1, 5) S2_A2(PP1, 5) S2_A3(PP1, 5) S2_B1(PP1, 5) S2_P(PP1, 0, 2) S2_LD(1) S2_FENCE
-            S2_MF(11) S2_B2(PP1, 5) S2_B3(PP1, 5) S2_C1(PP1, 5) S2_LD(2) S2_FENCE
-            S2_MF(12) S2_A1(PP1, 6) S2_A2(PP1, 6) S2_A3(PP1, 6) S2_B1(PP1, 6) S2_LD(3) S2_FENCE
-            S2_MF(13) S2_B2(PP1, 6) S2_B3(PP1, 6) S2_C1(PP1, 6) S2_LD(4) S2_FENCE
-            S2_MF(14) S2_A1(PP1, 7) S2_A2(PP1, 7) S2_A3(PP1, 7) S2_B1(PP1, 7) S2_LD(5) S2_FENCE
-            S2_MF(15) S2_B2(PP1, 7) S2_B3(PP1, 7) S2_C1(PP1, 7) S2_LD(6) S2_FENCE
-            S2_MF(16) S2_P(PP1, 1, 0) S2_P(PP1, 1, 1) S2_LD(7) S2_FENCE
-            S2_MF(17) S2_P(PP1, 1, 2) S2_FENCE
         }
-#undef S2_MF
 #undef S2_FENCE
 #undef S2_ON
-#undef S2_HI
-#undef S2_A1
-#undef S2_A2
-#undef S2_A3
-#undef S2_B1
-#undef S2_B2
-#undef S2_B3
-#undef S2_C1
 #undef S2_P
 #undef S2_LD
         S2_KEEP(f[0]) S2_KEEP(f[1])
@@ -328,7 +285,7 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
         const int voff = oy < a.Ho && ox < a.Wo ? (int)(((size_t)(4 * half) * HWo + (size_t)oy * a.Wo + ox) * 4) : (int)0x80000000;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float y = FX ? (acc[r] + acc2[r]) * FX_SCALE_INV + bs[r] : (acc[r] + acc2[r]) + bs[r];
+            float y = (acc[r] + acc2[r]) * FX_SCALE_INV + bs[r];
             if (a.relu) y = fmaxf(y, 0.f);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)(((r & 3) + 8 * (r >> 2)) * HWo * 4), 0);
         }
@@ -355,22 +312,21 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
         // chunk 0 of the first unit: split and written with every pipe idle (once per workgroup)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            u32x4 h, m, l;
+            u32x4 h, m;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float x0 = v[0][2 * j][e], x1 = v[0][2 * j + 1][e];
                 if (!W4) { const bool z = v_gx[0] + e >= a.W; x0 = z ? 0.f : x0; x1 = z ? 0.f : x1; }
-                unsigned hh, mm, ll = 0;
-                if constexpr (FX) { split2_f16(x0, x1, hh, mm); fx_track_h(amax, hh, true); }
-                else split3_trunc(x0, x1, hh, mm, ll);
-                h[j] = hh; m[j] = mm; l[j] = ll;
+                unsigned hh, mm;
+                split2_f16(x0, x1, hh, mm);
+                fx_track_h(amax, hh, true);
+                h[j] = hh; m[j] = mm;
             }
             const bool wr = has_item && !(it_quad == 0 && e < 3);
             const int par = (e + 1) & 1, idx = e == 0 ? -2 : e == 3 ? 0 : -1;
             unsigned char* p = smem_s2 + (wr ? row_base + par * PARB + idx * PIXB : DUMP_OFF);
             *reinterpret_cast<u32x4*>(p) = h;
             *reinterpret_cast<u32x4*>(p + SPLB) = m;
-            if constexpr (!FX) *reinterpret_cast<u32x4*>(p + 2 * SPLB) = l;
         }
     }
     for (;;) {
@@ -384,7 +340,7 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
         cur = nxt;
     }
     XFH_WAIT_VMCNT0();      // the cyclic stream's last DMA must not outlive the workgroup's LDS
-    if constexpr (FX) fx_report_h(amax, a.status);
+    fx_report_h(amax, a.status);
 #undef S2_STAMP
 }
 

@@ -1,23 +1,15 @@
-// 3x3 stride-1 convolution of the 24-channel layers (block2.0 / block2.1; modules/model.py:56-59) on the bf16 matrix cores
-// with three-way split operands -- fp32 arithmetic carried by bf16 MFMAs.
-//
-// Why: gfx950 issues v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) at 16x the rate of v_mfma_f32_32x32x2_f32 (64 cycles, K = 2).
-// An fp32 number is the exact sum of three bf16 numbers up to 2^-27 relative:  x = xh + xm + xl  with  xh = bf16(x),
-// xm = bf16(x - xh), xl = bf16(x - xh - xm)  (round to nearest even; both subtractions are exact in fp32).  A product
-//     w x  =  wh xh + (wh xm + wm xh) + (wh xl + wl xh + wm xm)  +  O(2^-25 |w x|)
-// needs six bf16 MFMAs; every bf16 x bf16 product is exact in the fp32 accumulator, so the result carries the rounding of an fp32
-// dot product (the three dropped cross terms are below one fp32 ulp of the product).  Six K=16 MFMAs cost 192 pipe cycles against
-// 512 for the same K on the f32 instruction -- as a direct convolution that is 0.84x the matrix time of Winograd F(2x2,3x3) on f32
-// MFMAs, with no input / output transforms, no cross-wave exchange and one barrier pair per tile.
+// 3x3 convolution of the 24-channel layers (block2.0 / block2.1 stride 1, block3.0 stride 2; modules/model.py:56-62) on the fp16 matrix cores in the fp16-pair
+// arithmetic (bx_split.hpp): fp32-equivalent product sums from three v_mfma_f32_32x32x16_f16 per K = 16 -- 96 pipe cycles against 512 for the same K on
+// v_mfma_f32_32x32x2_f32 -- as a direct convolution: no input / output transforms, no cross-wave exchange, one barrier pair per tile.
 //
 // Layout: a persistent workgroup (4 waves, two workgroups per CU) walks 8x32-pixel output tiles.
 //   * staging: thread (pixel, 8-channel group) loads its 8 raw fp32 values from the NCHW planes (32 loads in flight per thread),
-//     splits them and writes three 16-byte rows into LDS:  [pixel of the 10x34 halo tile][split][24 channels] bf16 (144 B per pixel:
-//     the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots);
+//     splits them and writes two 16-byte rows (high parts, low parts) into LDS:  [pixel of the 10x34 halo tile][fragment][24 channels] fp16 (112 B per pixel:
+//     an odd multiple of 16 B, so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots);
 //   * GEMM: M = cout (A = weights), N = 32 pixels of one output row (B), K = (tap, channel) in 8-channel groups, two groups per
-//     K=16 step (lane half 0 / 1), 27 groups + 1 zero group = 14 steps.  The split weights of ALL steps live in registers in operand
-//     order (168 VGPRs, loaded once per workgroup); a wave owns two output rows (two accumulators), reads three 16-byte B rows per
-//     row and step and issues 6 MFMAs on them: 48 B of LDS per 192 pipe cycles per wave = half the LDS bandwidth of a CU;
+//     K=16 step (lane half 0 / 1), 27 groups + 1 zero group = 14 steps.  The q0 weight fragments of ALL steps live in registers in operand
+//     order (loaded once per workgroup), q1 and q2 are read from LDS once per step; a wave owns two output rows (two accumulators), reads two 16-byte B rows per
+//     row and step and issues 3 MFMAs on them;
 //   * D: lane (pixel, half) holds couts (r&3) + 8 (r>>2) + 4 half: bias, ReLU, one coalesced 128-byte store per cout and half-wave.
 #include "kernels.hpp"
 #include "bx_split.hpp"
@@ -28,22 +20,21 @@ namespace xfh {
 
 struct BxArgs {
     const float* in;
-    const uint4* wfrag;        // [step][split][64 lanes] 8 bf16 each (api.hip: pack_bx_weights)
+    const uint4* wfrag;        // [step][fragment q0, q1, q2][64 lanes] 8 fp16 each (api.hip)
     const float* bias;
     float* out;
     int relu, H, W, B, tiles_x, tiles;
     int lag;                   // first-tile delay of the second workgroup of a CU, in units of 512 cycles
     long long* trace;          // debug: 6 s_memtime stamps per tile, 10 tiles, per workgroup (NULL in production)
     int cold;
-    int* status;               // fx: range guard (bx_split.hpp), may be NULL
+    int* status;               // range guard (bx_split.hpp), may be NULL
 };
 
-// FX: the fp16-pair arithmetic (bx_split.hpp): two input fragments per pixel (h, l), three MFMAs per K step and accumulator
-template <int CIN, int COUT, bool FX = false>
+template <int CIN, int COUT>
 struct BxCfg {
     static constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
-    static constexpr int NXS = FX ? 2 : 3;
-    // bytes per pixel / per split row; an ODD multiple of 16 B per pixel keeps the 16 lanes of a ds_read_b128 group on distinct banks (fx: 2 x 48 + 16 of padding)
+    static constexpr int NXS = 2;      // input fragments per pixel (high parts, low parts)
+    // bytes per pixel / per fragment row; an ODD multiple of 16 B per pixel keeps the 16 lanes of a ds_read_b128 group on distinct banks (2 x 48 + 16 of padding)
     static constexpr int CG = CIN / 8, SPLB = CIN * 2, PIXB = ((NXS * SPLB / 16) | 1) * 16;
     static constexpr int KG = 9 * CG, NSTEP = (KG + 1) / 2;
     static constexpr int NITEM = NPIX * CG, NIT = (NITEM + 255) / 256;
@@ -59,17 +50,14 @@ struct BxCfg {
     }
 };
 
-template <int CIN, int COUT, bool FX>
+template <int CIN, int COUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bx_kernel(BxArgs a) {
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    using Cfg = BxCfg<CIN, COUT, FX>;
+    using Cfg = BxCfg<CIN, COUT>;
     constexpr int NXS = Cfg::NXS;
-    using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
-    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {
-        if constexpr (FX) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
-        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
-    };
+    using frag_t = f16x8;
+    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); };
     constexpr int TH = Cfg::TH, TW = Cfg::TW, IW = Cfg::IW, NPIX = Cfg::NPIX, CG = Cfg::CG, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB;
     constexpr int NSTEP = Cfg::NSTEP, NIT = Cfg::NIT;
     constexpr bool WM_LDS = Cfg::WM_LDS;
@@ -78,8 +66,8 @@ void conv_bx_kernel(BxArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t HW = (size_t)a.H * a.W;
 
-    // split weights in operand order: lane (cout l31, half) holds K group 2 s + half of every step.  wh (3 uses per step and row)
-    // stays in registers for the whole kernel; wm (2 uses) and wl (1) are read from LDS once per step: all three in registers (168)
+    // weight fragments in operand order: lane (cout l31, half) holds K group 2 s + half of every step.  wh (= q0) stays in registers for the whole kernel;
+    // wm (= q1) and wl (= q2) are read from LDS once per step: all three in registers (168)
     // leave hipcc two fragment buffers and an lgkmcnt(0) in front of every MFMA group, and no room for the prefetched next tile
     frag_t wf[NSTEP][WM_LDS ? 1 : 2];
 #pragma unroll
@@ -127,7 +115,7 @@ void conv_bx_kernel(BxArgs a) {
     // raw fp32 values of a tile: 8 channels of one pixel per item, all loads of a thread in flight together; out-of-image pixels
     // carry an out-of-range offset (the buffer load returns the zero padding)
     float v[NIT][8];
-    unsigned amax = 0;                        // fx: the largest fp16 high parts converted (range guard: bx_split.hpp)
+    unsigned amax = 0;                        // the largest fp16 high parts converted (range guard: bx_split.hpp)
     auto issue_loads = [&](int vid) {
         int b, oy0, ox0;
         tile_of(vid, b, oy0, ox0);
@@ -144,25 +132,14 @@ void conv_bx_kernel(BxArgs a) {
     auto stage_write = [&]() {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            uint4 h, m, l;
-            if constexpr (FX) {
-                split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
-                split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
-                fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);      // (on the high parts: bx_split.hpp)
-            } else {
-                split3(v[i][0], v[i][1], h.x, m.x, l.x);
-                split3(v[i][2], v[i][3], h.y, m.y, l.y);
-                split3(v[i][4], v[i][5], h.z, m.z, l.z);
-                split3(v[i][6], v[i][7], h.w, m.w, l.w);
-            }
+            uint4 h, l;
+            split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
+            split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
+            fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);      // (on the high parts: bx_split.hpp)
             if (it_rc[i] >= 0) {
                 unsigned char* p = smem_bx + it_lds[i];
                 *reinterpret_cast<uint4*>(p) = h;
-                if constexpr (FX) *reinterpret_cast<uint4*>(p + SPLB) = l;
-                else {
-                    *reinterpret_cast<uint4*>(p + SPLB) = m;
-                    *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
-                }
+                *reinterpret_cast<uint4*>(p + SPLB) = l;
             }
         }
     };
@@ -194,7 +171,7 @@ void conv_bx_kernel(BxArgs a) {
         BX_STAMP(2)
         const int nvid = vid + (int)gridDim.x;
         if (nvid < total) issue_loads(nvid);          // the next tile's loads fly under this tile's MFMAs
-        // ---- 14 K steps x 2 rows x 6 MFMAs ---------------------------------------------------------------------------
+        // ---- 14 K steps x 2 rows x 3 MFMAs ---------------------------------------------------------------------------
         f32x16 acc[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -223,8 +200,7 @@ void conv_bx_kernel(BxArgs a) {
             const frag_t wh = wf[s][0], wm = WM_LDS ? c.wm : wf[s][WM_LDS ? 0 : 1];
             // small terms first; the two rows alternate (independent accumulators)
 #define BX_MM(A, Q) { acc[0] = mfma(A, c.x[0][Q], acc[0]); acc[1] = mfma(A, c.x[1][Q], acc[1]); }
-            if constexpr (FX) { BX_MM(c.wl, 0) BX_MM(wm, 1) BX_MM(wh, 0) }      // fragments (2^11 w - q0, w, q0 = fp16(2^11 w)) x (xh, xl, xh): all at scale 2^11
-            else { BX_MM(c.wl, 0) BX_MM(wh, 2) BX_MM(wm, 1) BX_MM(wm, 0) BX_MM(wh, 1) BX_MM(wh, 0) }
+            BX_MM(c.wl, 0) BX_MM(wm, 1) BX_MM(wh, 0)      // fragments (2^11 w - q0, w, q0 = fp16(2^11 w)) x (xh, xl, xh): all at scale 2^11
 #undef BX_MM
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -252,7 +228,7 @@ void conv_bx_kernel(BxArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int co0 = (r & 3) + 8 * (r >> 2);          // cout of lane half 0; half 1 holds co0 + 4
                 if (co0 < COUT) {                                // compile-time (r < 12 for 24 channels)
-                    float y = FX ? fmaf(acc[j][r], FX_SCALE_INV, bs[r]) : acc[j][r] + bs[r];
+                    float y = fmaf(acc[j][r], FX_SCALE_INV, bs[r]);
                     if (a.relu) y = fmaxf(y, 0.f);
                     const bool okc = COUT % 8 == 0 || co0 + 4 * half < COUT;
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, okc ? voff : (int)0x80000000, (int)(co0 * HW * 4), 0);
@@ -266,7 +242,7 @@ void conv_bx_kernel(BxArgs a) {
         ++tix;
         vid = nvid;
     }
-    if constexpr (FX) fx_report_h(amax, a.status);
+    fx_report_h(amax, a.status);
 #undef BX_STAMP
 }
 
@@ -277,9 +253,9 @@ void conv_bx_kernel(BxArgs a) {
 // multiple of 64 B, so that the second row of a pixel block lands on the same banks as the first): the lanes of a fragment read step by
 // two input pixels and would otherwise collide pairwise.  wh and wm of the wave's cout block live in registers, wl in LDS.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int CIN, bool FX = false>
+template <int CIN>
 struct BxS2Cfg {
-    static constexpr int NXS = FX ? 2 : 3;
+    static constexpr int NXS = 2;
     static constexpr int IH = 10, IW = 34, NPIX = IH * IW, CG = CIN / 8, SPLB = CIN * 2, PIXB = ((NXS * SPLB / 16) | 1) * 16;
     static constexpr int ROWQ = ((IW / 2) * PIXB + 63) / 64 * 64;          // bytes per (row, column parity)
     static constexpr int KG = 9 * CG, NSTEP = (KG + 1) / 2;
@@ -296,7 +272,7 @@ struct BxS2Cfg {
 
 struct BxS2Args {
     const float* in;
-    const uint4* wfrag;        // [cout block 2][step][split][64 lanes] 8 bf16 each
+    const uint4* wfrag;        // [cout block 2][step][fragment][64 lanes] 8 fp16 each
     const float* bias;
     float* out;
     int relu, H, W, Ho, Wo, B, tiles_x, tiles;
@@ -304,17 +280,14 @@ struct BxS2Args {
     int* status;
 };
 
-template <int CIN, bool FX>
+template <int CIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bxs2_kernel(BxS2Args a) {
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    using Cfg = BxS2Cfg<CIN, FX>;
+    using Cfg = BxS2Cfg<CIN>;
     constexpr int NXS = Cfg::NXS;
-    using frag_t = std::conditional_t<FX, f16x8, bf16x8>;
-    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) {
-        if constexpr (FX) return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0);
-        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
-    };
+    using frag_t = f16x8;
+    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); };
     constexpr int IW = Cfg::IW, NPIX = Cfg::NPIX, CG = Cfg::CG, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB, ROWQ = Cfg::ROWQ;
     constexpr int NSTEP = Cfg::NSTEP, NIT = Cfg::NIT, COUT = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
@@ -323,7 +296,7 @@ void conv_bxs2_kernel(BxS2Args a) {
     const int pb = wave >> 1, cb = wave & 1;
     const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
 
-    frag_t wf[NSTEP][2];                       // wh, wm of this wave's cout block (fx: q0 = fp16(2^11 w), q1 = fp16(w))
+    frag_t wf[NSTEP][2];                       // q0 = fp16(2^11 w), q1 = fp16(w) of this wave's cout block
 #pragma unroll
     for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
@@ -361,7 +334,7 @@ void conv_bxs2_kernel(BxS2Args a) {
         iy0 = tyi * 8; ix0 = txi * 32;
     };
     float v[NIT][8];
-    unsigned amax = 0;                        // fx: the largest fp16 high parts converted (range guard: bx_split.hpp)
+    unsigned amax = 0;                        // the largest fp16 high parts converted (range guard: bx_split.hpp)
     auto issue_loads = [&](int vid) __attribute__((always_inline)) {
         int b, iy0, ix0;
         tile_of(vid, b, iy0, ix0);
@@ -378,25 +351,14 @@ void conv_bxs2_kernel(BxS2Args a) {
     auto stage_write = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            uint4 h, m, l;
-            if constexpr (FX) {
-                split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
-                split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
-                fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);      // (on the high parts: bx_split.hpp)
-            } else {
-                split3(v[i][0], v[i][1], h.x, m.x, l.x);
-                split3(v[i][2], v[i][3], h.y, m.y, l.y);
-                split3(v[i][4], v[i][5], h.z, m.z, l.z);
-                split3(v[i][6], v[i][7], h.w, m.w, l.w);
-            }
+            uint4 h, l;
+            split2_f16(v[i][0], v[i][1], h.x, l.x); split2_f16(v[i][2], v[i][3], h.y, l.y);
+            split2_f16(v[i][4], v[i][5], h.z, l.z); split2_f16(v[i][6], v[i][7], h.w, l.w);
+            fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);      // (on the high parts: bx_split.hpp)
             if (it_rc[i] >= 0) {
                 unsigned char* p = smem_bx + it_lds[i];
                 *reinterpret_cast<uint4*>(p) = h;
-                if constexpr (FX) *reinterpret_cast<uint4*>(p + SPLB) = l;
-                else {
-                    *reinterpret_cast<uint4*>(p + SPLB) = m;
-                    *reinterpret_cast<uint4*>(p + 2 * SPLB) = l;
-                }
+                *reinterpret_cast<uint4*>(p + SPLB) = l;
             }
         }
     };
@@ -429,18 +391,9 @@ void conv_bxs2_kernel(BxS2Args a) {
             const Frag& c = f[s & 1];
             if (s + 1 < NSTEP) load(s + 1, f[(s + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (FX) {
-                acc = mfma(c.wl, c.x[0], acc);          // small terms first: (2^11 w - q0) xh, w xl, q0 xh
-                acc = mfma(wf[s][1], c.x[1], acc);
-                acc = mfma(wf[s][0], c.x[0], acc);
-            } else {
-                acc = mfma(c.wl, c.x[0], acc);          // small terms first
-                acc = mfma(wf[s][0], c.x[2], acc);
-                acc = mfma(wf[s][1], c.x[1], acc);
-                acc = mfma(wf[s][1], c.x[0], acc);
-                acc = mfma(wf[s][0], c.x[1], acc);
-                acc = mfma(wf[s][0], c.x[0], acc);
-            }
+            acc = mfma(c.wl, c.x[0], acc);          // small terms first: (2^11 w - q0) xh, w xl, q0 xh
+            acc = mfma(wf[s][1], c.x[1], acc);
+            acc = mfma(wf[s][0], c.x[0], acc);
             __builtin_amdgcn_sched_barrier(0);
         }
         // idle slots before the epilogue's address arithmetic: it must not land in operand registers of the last MFMAs
@@ -459,7 +412,7 @@ void conv_bxs2_kernel(BxS2Args a) {
             const int voff = oy < a.Ho && ox < a.Wo ? (int)(((size_t)(4 * half) * HWo + (size_t)oy * a.Wo + ox) * 4) : (int)0x80000000;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float y = FX ? fmaf(acc[r], FX_SCALE_INV, bs[r]) : acc[r] + bs[r];
+                float y = fmaf(acc[r], FX_SCALE_INV, bs[r]);
                 if (a.relu) y = fmaxf(y, 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, voff, (int)((cb * 32 + (r & 3) + 8 * (r >> 2)) * HWo * 4), 0);
             }
@@ -468,57 +421,57 @@ void conv_bxs2_kernel(BxS2Args a) {
         __syncthreads();
         vid = nvid;
     }
-    if constexpr (FX) fx_report_h(amax, a.status);
+    fx_report_h(amax, a.status);
 }
 
-template <int CIN, bool FX>
+template <int CIN>
 static int run_bxs2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status) {
-    using Cfg = BxS2Cfg<CIN, FX>;
+    using Cfg = BxS2Cfg<CIN>;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu || (size_t)64 * Ho * Wo * sizeof(float) >= 0x7fffffffu) return -1;
     BxS2Args a;
     a.cold = g_debug_cold;
     a.status = status;
-    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(FX ? c.w_fx : c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu;
+    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(c.w_fx); a.bias = c.bias; a.out = out; a.relu = c.relu;
     a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B;
     a.tiles_x = ceil_div(W, 32);
     a.tiles = a.tiles_x * ceil_div(H, 8);
     static AttrMask attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN, FX>), Cfg::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();
     if (grid > total) grid = total;
-    conv_bxs2_kernel<CIN, FX><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+    conv_bxs2_kernel<CIN><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
     return 0;
 }
 
-template <int CIN, int COUT, bool FX>
+template <int CIN, int COUT>
 static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
-    using Cfg = BxCfg<CIN, COUT, FX>;
+    using Cfg = BxCfg<CIN, COUT>;
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
     BxArgs a;
     a.cold = g_debug_cold;
     a.status = status;
-    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(FX ? c.w_fx : c.w_bx); a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
+    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(c.w_fx); a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = trace;
     a.lag = 11;
     a.tiles_x = ceil_div(W, Cfg::TW);
     a.tiles = a.tiles_x * ceil_div(H, Cfg::TH);
     static AttrMask attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx_kernel<CIN, COUT, FX>), Cfg::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx_kernel<CIN, COUT>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();            // two resident workgroups per CU; a multiple of 8 keeps a workgroup on its XCD
     if (grid > total) grid = total;
-    conv_bx_kernel<CIN, COUT, FX><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+    conv_bx_kernel<CIN, COUT><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
     return 0;
 }
 
 int bx_steps(int cin) { return (9 * (cin / 8) + 1) / 2; }
 
-int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, bool fx, int* status) {
-    if (c.ks != 3 || !c.w_bx) return -1;
-    fx = fx && c.w_fx;      // (a layer with a weight too large for the fp16 pair keeps the bf16 form)
-    if (c.stride == 1 && c.cin == 24 && c.cout == 24) return fx ? run_bx<24, 24, true>(c, in, B, H, W, out, st, trace, status) : run_bx<24, 24, false>(c, in, B, H, W, out, st, trace, status);
-    if (c.stride == 2 && c.cin == 24 && c.cout == 64) return fx ? run_bxs2<24, true>(c, in, B, H, W, out, st, status) : run_bxs2<24, false>(c, in, B, H, W, out, st, status);
+// -1: not one of this file's layers, or the layer has no fp16-pair weights (a |w| >= kFxMaxWeight): the caller falls back to the f32-MFMA kernel
+int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
+    if (c.ks != 3 || !c.w_fx) return -1;
+    if (c.stride == 1 && c.cin == 24 && c.cout == 24) return run_bx<24, 24>(c, in, B, H, W, out, st, trace, status);
+    if (c.stride == 2 && c.cin == 24 && c.cout == 64) return run_bxs2<24>(c, in, B, H, W, out, st, status);
     return -1;
 }
 

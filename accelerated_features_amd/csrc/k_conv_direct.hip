@@ -113,43 +113,27 @@ namespace xfh {
                       const float* __restrict__ bb3, const float* __restrict__ w4, const float* __restrict__ bb4, const float* __restrict__ skw, const float* __restrict__ skb, \
                       const void* __restrict__ w4fx, const void* __restrict__ w3fx, int* __restrict__ status, int cold
 #define XFH_B1_ARGS gray, coef, x1, B, H, W, tiles_x, tiles_y, w1, bb1, w2, bb2, w3, bb3, w4, bb4, skw, skb, w4fx, w3fx, status, cold
-template <int C1MODE>
-__global__ __launch_bounds__(512) void block1_fused_kernel(XFH_B1_PARAMS) { block1_fused_body<C1MODE>(XFH_B1_ARGS); }
-// modes 6, 7 keep the three workgroups per CU of mode 5: six waves per SIMD = at most 80 vector registers
-template <int MODE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) void block1_mx_kernel(XFH_B1_PARAMS) { block1_fused_body<MODE>(XFH_B1_ARGS); }
+// the vector-ALU form (fp32's range): the fallback of the fp16 pair's range guard
+__global__ __launch_bounds__(512) void block1_fused_kernel(XFH_B1_PARAMS) { block1_fused_body<5>(XFH_B1_ARGS); }
+// the default: conv3, conv4 on the fp16 matrix cores.  Three workgroups per CU as the vector form: six waves per SIMD = at most 80 vector registers
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 8))) void block1_mx_kernel(XFH_B1_PARAMS) { block1_fused_body<7>(XFH_B1_ARGS); }
 #undef XFH_B1_PARAMS
 #undef XFH_B1_ARGS
 
-// Split-bf16 MFMA variants of block1_fused_kernel (round 2: measured, identical results within fp32 rounding, slower, removed -- DESIGN 3.6).
-// conv3 (8 -> 8) and conv4 (8 -> 24, s2) have K = 72 = 9 taps x 8 channels: four taps per v_mfma_f32_16x16x32_bf16, three K steps of six MFMAs;
-// conv2's / conv3's epilogues wrote their 8 channels per pixel as three bf16 rows into LDS (48 B per pixel).
-// A variant with ONLY conv4 on the matrix cores (same tiles and LDS budget as the kernel above, one tile per workgroup, nothing held in
-// registers across stages) was no better: conv4 6.2 k -> 7.2 k cycles as written (its 36 MFMAs per wave are two dependent accumulator chains:
-// ~150 cycles per v_mfma_f32_16x16x32_bf16 with the operand reads in between; four chains would bring it to ~3 k) while conv3's epilogue pays
-// 2.6 k for splitting its outputs into bf16 rows -- a wash at best.  Removed.
-// With conv3 AND conv4 there (persistent workgroups, conv3's weights in registers): per tile 5.3 k cycles gray + 7.4 k conv1 + 7.5 k conv2 (+ split) + 9-10 k conv3 + 4-10 k conv4 = 34-41 k against
-// 32.9 k for the kernel above (325-371 us against 294).  conv3 / conv4 needed 90 + 36 MFMAs per wave (~2 k cycles of the pipe) but at 128 VGPRs
-// and ~100 SGPRs (two workgroups of 8 waves per CU, the VALU stages' scalar weight streams, a persistent loop, 14 pointer arguments) hipcc
-// spilled both register files, and every scratch reload parked a vmcnt(0) in the MFMA stages.  What it would take: conv3's weights in LDS
-// (no room next to C2s + C3s + conv4's weights in 80 KB), or one 8-wave workgroup per CU with 256 registers and the two halves of the
-// workgroup a stage apart.
-// Measured on MI355X, B = 64 VGA (round 2, tools/bench_src/pk_fma_chain.hip + in-kernel s_memtime stamps):
-//   * v_pk_fma_f32 (broadcast A, SGPR-pair B, the form hipcc emits here) issues at the full packed rate (115-123 TFLOP/s chip-wide
-//     at 8 or 16 waves per CU); two v_fma_f32 doing the same work run at 70: everything below must stay SLP-packable.
-//   * this kernel: 292 us = 48 TFLOP/s.  With the weight loads AND the LDS reads made loop-invariant (hoisted) it still takes
-//     258 us: neither scalar-cache latency nor LDS conflicts bound it.  A persistent variant (next tile's gray prefetched into
-//     registers, column-parity de-interleaved c1/c3 tiles = no bank conflicts, two columns per thread in conv1) measured 343 us
-//     with bit-identical results and was dropped: per tile 1.1 k cycles stage 0, 8.6 k conv1, 6.1 k conv2, 9.9 k conv3, 6.2 k conv4,
-//     2.4 k barriers -- the SIMDs issue FMAs ~45 % of the time; the rest is the lock-step stage structure (9 and 11 wave-loads
-//     on 8 waves, two barriers per stage, two workgroups per CU to cover each other).  Unrolling the channel loops made it slower
-//     (x2: +4 %, x8: +20 %).  What helped: issuing the six gray loads of a thread together (311 -> 292 us).
-//   * 7 x 16 output tiles (the conv3 tile = 15 x 33 = 495 pixels = ONE pass of the 512 threads instead of 561 = a full pass + one wave,
-//     conv1 5 passes instead of 6: 11 % fewer issue slots on a workgroup's critical path, 5 % more tiles): 299 us against 288 in
-//     three alternating in-run pairs -- the partial passes are not what the stages wait for; dropped.
-//   * workgroup size (same tiles, conv4 on 24 / (threads / 128) couts per thread): 256 threads 330 us, 512 threads 280 us, 1024 threads
-//     380 us (alternating in-run pairs): with 16 waves conv4 reads its 72 inputs twice as often per FMA, with 4 waves nothing hides the LDS latency.
+// What was measured on the way (MI355X, B = 64 VGA; FINDINGS.md has the long form):
+//   * v_pk_fma_f32 (broadcast A, SGPR-pair B, the form hipcc emits here) issues at the full packed rate; two v_fma_f32 doing the same work run at 0.6 of it:
+//     the vector stages must stay SLP-packable (written as explicit 2-vectors).
+//   * conv1 recomputed inside conv2 (no c1 tile: + 12 % FLOPs, one stage, one barrier and 26 KB of LDS less: three workgroups per CU instead of two): - 8 %.
+//   * conv3 / conv4 on v_mfma_f32_16x16x4_f32 (round 3): slower -- an f32 MFMA has the FLOP rate of the packed vector FMA; on the fp16 matrix cores in the fp16-pair
+//     arithmetic (round 5, this kernel): 212-264 -> 159-190 us.
+//   * conv2 (4 -> 8, stride 2, K = 36) on the matrix cores, by instruction count: of stage 2's 306 v_pk_fma_f32 per c2 pixel 162 are conv1's
+//     recomputation and 144 conv2's.  Without a c1 tile the B operand must be produced by the lane that owns it (a column = a pair of c2 pixels, K = 3 x 5 x 4 = 60 of
+//     64): 15 c1 pixels per pair instead of 18, but every lane computes four of them with their own index arithmetic, 24 LDS reads, ReLU and fp16-pair split:
+//     ~172 vector instructions per lane and block of 32 pixels = 344 per c2 pixel against today's ~400 -- stage 2 is 45 % of the kernel, so <= 7 % of the kernel
+//     before the 21.4 blocks meet 8 waves (3 per wave: 0.89).  With a c1 tile (conv1 once per pixel) LDS grows by 44 KB to 80 KB: two workgroups per CU, the
+//     configuration that measured 8 % slower than three.  Not built.
 
+// variant: 7 = block1_mx_kernel (needs the fp16-pair weight images: a layer weight of magnitude >= kFxMaxWeight leaves them NULL), anything else = the vector form
 void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant, int* status) {
     const ConvW& c0 = nw.conv[L_BLOCK1_0];
     const ConvW& c1w = nw.conv[L_BLOCK1_1];
@@ -158,47 +142,18 @@ void launch_block1_fused(const NetWeights& nw, const float* gray, const float* c
     const ConvW& sk = nw.conv[L_SKIP1];
     const int H4 = H / 4, W4 = W / 4;
     const int tx = ceil_div(W4, b1::OW), ty = ceil_div(H4, b1::OH);
-    // conv1 on three adjacent pixels per thread: 275 -> 266 us in alternating in-run pairs (PMC: the kernel issues VALU instructions 76 % of the
-    // time and only 54 % of them are FMAs -- index arithmetic, bounds and LDS addresses are the rest, and conv1 has the fewest FMAs per index).
-    // Mode 4 writes the same three pixels as 2-vectors so that hipcc emits 54 v_pk_fma_f32 per item instead of 108 v_fmac_f32 (-108 of ~1400 VALU
-    // instructions per thread); rocprof 280.5 us against 289.4 us for mode 3 on two comparable boxes in round 2.
-    // Mode 5 (the default since round 3) drops the c1 tile altogether: conv2 recomputes its nine c1 pixels from 25 gray values in registers.
-    // + 12 % FLOPs, but one stage, one barrier and 26 KB of LDS less: three workgroups per CU instead of two.  In-run A/B (tools/ab_option.py,
-    // alternating rounds on one box): 264.5 / 262.9 / 262.3 -> 244.8 / 241.8 / 242.7 us, step 1.788 -> 1.753 ms.
-    //
-    // Round 3, measured and removed: conv3 + conv4 (70 % of the FLOPs, 5.8 k of the kernel's 12.1 k vector wave-instructions per tile) on
-    // v_mfma_f32_16x16x4_f32 -- conv3 as N = 16 = two adjacent pixels x 8 couts over the union of their windows (K = 8 x 3 x 4 = 96, 72 used),
-    // conv4 as two 16-wide cout blocks with K = 72; every A operand one ds_read_b32 at base(lane) + constant(step), B operands packed per step
-    // and lane by the host, results back through LDS.  Parity-green on the first run (backbone / census tests), and 330 us against 283: an f32 MFMA
-    // has the FLOP rate of the packed vector FMA, so the matrix stages take the cycles the vector stages took (6.0 k vs 5.8 k per SIMD and tile, 19
-    // blocks on 8 waves), the two workgroups of a CU run their stages in phase (no matrix / vector overlap to collect), and the extra barrier
-    // and LDS round trip come on top.  What the vector pipe is short of is issue slots (PMC: 116 M vector instructions, 54 % FMAs, inner loops
-    // already 95 % v_pk_fma_f32) -- the remaining lever is the per-item prologue / epilogue arithmetic of the stages, not another pipe.
-    const int c1 = (variant == 1 || variant == 3 || variant == 4) ? variant : ((variant == 6 || variant == 7) && nw.block1_fx && nw.block1_fx3) ? variant : 5;      // (6 / 7 without the fp16-pair images -- a weight of magnitude >= 31 -- are 5)      // option "block1": 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels on packed FMAs; default (0 / 5): conv1 recomputed inside conv2 (xfh_set_option rejects every other value)
-    static AttrMask attr1{0}, attr3{0}, attr4{0}, attr5{0}, attr6{0}, attr7{0};
-#define XFH_B1_LAUNCH(MODE, ATTR)                                                                                                       \
-    {                                                                                                                                    \
-        constexpr int lds_floats = MODE >= 5 ? b1::F_LDS_FLOATS : b1::LDS_FLOATS;                                                        \
-        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel<MODE>), lds_floats * 4, ATTR);                             \
-        block1_fused_kernel<MODE><<<xcd_grid_size(tx * ty, B), 512, lds_floats * 4, st>>>(                                               \
-            gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc, c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold); \
-    }
-    if (c1 == 1) XFH_B1_LAUNCH(1, attr1)
-    else if (c1 == 3) XFH_B1_LAUNCH(3, attr3)
-    else if (c1 == 5) XFH_B1_LAUNCH(5, attr5)
-    else if (c1 == 6) {
-        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_mx_kernel<6>), b1::M_LDS_FLOATS * 4, attr6);
-        block1_mx_kernel<6><<<xcd_grid_size(tx * ty, B), 512, b1::M_LDS_FLOATS * 4, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
-                                                                                           c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold);
-    } else if (c1 == 7) {      // (+ conv3's weight image behind the tiles: 53.6 KB, still three workgroups per CU)
+    static AttrMask attr5{0}, attr7{0};
+    if (variant == 7 && nw.block1_fx && nw.block1_fx3) {      // (+ conv3's weight image behind the tiles: 53.6 KB, still three workgroups per CU)
         constexpr int lds7 = b1::M_LDS_FLOATS * 4 + b1fx::W3_BYTES;
         static_assert(3 * ((lds7 + 1279) / 1280 * 1280) <= 160 * 1024, "three workgroups per CU, also with 1280-byte allocation granules");
-        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_mx_kernel<7>), lds7, attr7);
-        block1_mx_kernel<7><<<xcd_grid_size(tx * ty, B), 512, lds7, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
-                                                                           c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold);
+        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_mx_kernel), lds7, attr7);
+        block1_mx_kernel<<<xcd_grid_size(tx * ty, B), 512, lds7, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
+                                                                        c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold);
+    } else {
+        set_max_dynamic_lds(reinterpret_cast<const void*>(block1_fused_kernel), b1::F_LDS_FLOATS * 4, attr5);
+        block1_fused_kernel<<<xcd_grid_size(tx * ty, B), 512, b1::F_LDS_FLOATS * 4, st>>>(gray, coef, x1, B, H, W, tx, ty, c0.w_kc, c0.bias, c1w.w_kc, c1w.bias, c2.w_kc, c2.bias, c3.w_kc,
+                                                                                           c3.bias, sk.w_oihw, sk.bias, nw.block1_fx, nw.block1_fx3, status, g_debug_cold);
     }
-    else XFH_B1_LAUNCH(4, attr4)
-#undef XFH_B1_LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------

@@ -20,12 +20,9 @@ struct ConvW {
     const float* w_kc;     // [(ci*kk+tap)][cout]      BN folded (block1 direct kernels)
     const float* w_kcp;    // [(ci*kk+tap)][cout_pad]  BN folded, zero padded (MFMA kernels)
     const float* bias;     // [cout_pad] folded BN shift or conv bias, zero padded
-    const float* w_wino;   // [cin/4][16][2][cout_pad][2] Winograd F(2x2,3x3) G g G^T (3x3/s1 layers, cin >= 24), else NULL
-    const void* w_fx;      // the same fragments in the fp16-pair arithmetic (api.hip: split_weight mode 1), NULL if the layer has none or a weight is too large for it
-    const void* w_rs;      // 64 -> 64 3x3 stride-1 layers: the fp16-pair image in conv_rs64_kernel's order (weight_split.hpp: pack_rs64); the 1x1 behind one: pack_rs64_1x1; else NULL
-    const void* w_fq;      // 64 -> 64 3x3 stride-1 layers: the fp16-pair image with two fragments per weight (q0, q2; conv_bx64_body.hpp FXM 2), else NULL
-    const void* w_bx;      // three-way split bf16 weights in MFMA operand order, else NULL: cin 24: [step][split h,m,l][64 lanes][8] (k_conv_bx.hip);
-                           // cin 64 -> 64: [cin/16][dy][dx][cout block][split][64 lanes][8] (k_conv_bx64.hip)
+    const void* w_fx;      // the fp16-pair fragments (weight_split.hpp: split_weight) in the operand order of the layer's kernel -- the 24-channel layers (k_conv_bx.hip:
+                           // [step][fragment][64 lanes][8]) and the stride-2 64-channel layers (pack_bx64) --, NULL if the layer has none or a weight is too large for the pair
+    const void* w_rs;      // 64 -> 64 / 128 -> 128 3x3 stride-1 layers: the fp16-pair image in conv_rs64_kernel's order (pack_rs64 / pack_rs128); the 1x1 behind one: pack_rs64_1x1; else NULL
 };
 
 struct LinW {             // fine_matcher layer: y = relu?(x W^T + b), BN folded
@@ -39,10 +36,8 @@ struct NetWeights {
     ConvW conv[L_NUM];
     LinW fine[5];
     const float* zeros;   // 1 KiB of zeros (padding source of the LDS-DMA loaders)
-    // heads on split-bf16 MFMAs (k_heads.hip: head_bx_kernel): [0] key-point head, [1] reliability head
-    const void* head_bx[2];          // per layer [K step 4][cout block][split 3][64 lanes][8] bf16
-    const void* head_fx[2];          // the same in the fp16-pair arithmetic (or NULL)
-    const void* head_fq[2];          // the fp16-pair form with two fragments per weight (q0, q2): [K step][cout block][2][64 lanes][8] (or NULL)
+    // heads on the fp16 matrix cores (k_heads.hip: head_bx_kernel): [0] key-point head, [1] reliability head
+    const void* head_fx[2];          // per layer [K step 4][cout block][fragment 3][64 lanes][8] fp16, or NULL (a weight beyond the pair's range: the head runs on head_f32r_kernel)
     const float* head_bx_bias[2];    // biases padded to the cout blocks (KP 64,64,64,96 ; REL 64,64)
     float head_rel_b_last;           // bias of the final 64 -> 1 layer of the reliability head
     float head_kp_b_dust;            // bias of the dustbin logit (output 64 of keypoint_head.3)
@@ -53,21 +48,12 @@ struct NetWeights {
 struct Profiler;   // api.hip
 extern int g_debug_cold;      // debug (xfh_debug_cold_start): MFMA kernels invalidate the instruction cache when they start (api.hip)
 
-// Per-handle variant switches (xfh_set_option): which of several equivalent kernels a call uses.  They exist for A/B measurements and for the
-// parity tests that pin one variant against another; the defaults are the shipped path.  No process-wide state: a handle carries its own copy.
+// Per-handle kernel switches (xfh_set_option; include/xfeat_hip.h documents them).  No process-wide state: a handle carries its own copy.
 struct Options {
     int match_exact = 0;    // 1: xfh_match_mnn runs the exact f32-MFMA kernel for every pair (no filter)
-    int wino = 2;           // 0: 3x3/s1 layers never use Winograd; 1: only unfused layers; 2: fused 3x3 + 1x1 pairs too
-    int bx = 21;            // split-bf16 MFMA convolutions: bit 1 = the 24-channel layers, 2 = 64 -> 64 on every map, 4 = 64 -> 64 on large maps, 8 = not block3.0,
-                            // 16 = the stride-2 64 -> 64 | 128 layers (block4.0, block5.0)
-    int heads_f32 = 0;      // (r5-flip: the split heads, which are the fp16-pair kernels under fx bit 8)   both heads on f32 MFMAs: 2 (default since round 4) = head_f32r_kernel (first-layer input in registers, no barrier per tile), 1 = head_fused_kernel (round 1:
-                            // activation tile in LDS, two barriers per tile; + 33 us per 64-frame step); 0: the split-bf16 kernels (head_bx_kernel) -- 60 us faster than 2, but
-                            // head_bx_kernel<true> delivers a wrong 16-cell block once in 10^3..10^5 launches when a workgroup's first tile runs on instruction-cache
-                            // misses (foreign kernels evicting its code), DESIGN 9.0: opt-in only
-    int fx = 3979;          // (round 5: bits 1 | 2 | 8 | 128 | 256 | 512 | 1024 | 2048: the fine_matcher on linear_fx_kernel; every 64 -> 64 and 128 -> 128 3x3 on conv_rs64_kernel, the stride-2 layers in the fp16-pair arithmetic)   (bit 128, with 1: the unfused 64 -> 64 layers on conv_rs64_kernel -- weights resident in registers, conv_rs64_body.hpp; bit 256, with 1: the 3x3 + 1x1 pairs too; bit 512, with 1: block5.1 and block5.2 on its 128-channel form, block5.3 then runs as a 1x1 of its own; bit 1024, with 1: block4.0 / block5.0 (stride 2) in the fp16-pair arithmetic, conv_bx64s2x_kernel)  split-operand kernels in the fp16-pair arithmetic (three MFMAs per product instead of six; bx_split.hpp): bit 1 = the 64 -> 64 layers
-                            // (conv_bx64_kernel), 2 = the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel), 2048 = the fine_matcher's linear layers (linear_fx_kernel), 4 = (with 1) conv_bx64_kernel with two weight fragments in its stream, 8 = the split heads (with heads_f32 = 0: head_bx_kernel<.., 1>), + 16 = with two weight fragments in LDS (<.., 2>), + 32 = (instead) the B fragments through LDS (<.., 3>), 64 = (with 1) the split-format link block_fusion.0 -> block_fusion.1 (conv_bx64_body.hpp: SP); 0 = the bf16 three-way split everywhere
-    int resize2 = 1;        // the fused two-stage resize of the dual-scale dense path: 1 = the tile's input region staged in LDS by 16-byte loads (round 5), 0 = four-byte gathers
-    int block1 = 7;         // (r5-flip: block1.2 and block1.3 on the fp16 matrix cores; 0 / 5 = the vector-ALU kernel)   block1's conv1: 0 = shipped (= 5: recomputed inside conv2, no c1 tile); 1 = one pixel per thread; 3 = three pixels, scalar FMAs; 4 = three pixels, packed FMAs (2 is rejected); 6 = 5 with conv4 on the fp16 matrix cores (fp16-pair arithmetic, block1_fx.hpp), 7 = conv3 too
+    int fx = 1 | 2 | 8 | 2048;      // XFH_FX_ALL: which layer families run in the fp16-pair arithmetic (a cleared bit: the f32-MFMA kernel of the family)
+    int resize2 = 1;        // the fused two-stage resize of the dual-scale dense path: 1 = the tile's input region staged in LDS by 16-byte loads, 0 = four-byte gathers
+    int block1 = 7;         // 7: block1.2 and block1.3 on the fp16 matrix cores; 5: the vector-ALU kernel
 };
 
 // ---- k_preproc.hip ----------------------------------------------------------------------
@@ -85,7 +71,7 @@ void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float
 // ---- k_conv_direct.hip ------------------------------------------------------------------
 void launch_block1(const NetWeights& nw, const float* gray, int B, int H, int W, float* t0, float* t1, float* t2,
                    float* x1, hipStream_t st);
-void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant = 0, int* status = nullptr);
+void launch_block1_fused(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* x1, hipStream_t st, int variant = 7, int* status = nullptr);
 int launch_block1_layer(const NetWeights& nw, int layer, const float* in, int B, int Hin, int Win, float* out,
                         hipStream_t st);
 void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Win, float* out, hipStream_t st);
@@ -94,23 +80,16 @@ void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Wi
 // 3x3 / 1x1 convolution as an implicit GEMM on f32 MFMA.  in NCHW; out NCHW or NHWC.
 // Returns 0, or -1 when no instantiation exists for the layer shape.
 // fused1x1 (optional): the 1x1 conv that follows, computed in the same kernel.  zeros: >= 256 B.
-// Winograd F(2x2,3x3) MFMA path for 3x3/s1 layers (k_conv_wino.hip); -1 if no instantiation
-int launch_conv_wino(const ConvW& c, const float* zeros, const float* in, int B, int H, int W, float* out, hipStream_t st, int cfg = 0, long long* trace = nullptr,
-                     const ConvW* fused1x1 = nullptr, bool nhwc = false);
 int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, const float* in, int B, int Hin, int Win,
                      float* out, bool nhwc_out, hipStream_t st, long long* trace = nullptr);
-// 3x3/s1 on bf16 MFMAs with three-way split operands (fp32-equivalent; k_conv_bx.hip); -1 if no instantiation
-int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr, bool fx = false, int* status = nullptr);
-int launch_conv_bx64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr,
-                     const ConvW* fused1x1 = nullptr, bool nhwc = false, int fx = 0, int* status = nullptr, int sp = 0, const float* zeros = nullptr);
+// the 24-channel 3x3 layers (stride 1 and 2) in the fp16-pair arithmetic (k_conv_bx.hip); -1 if no instantiation or no fp16-pair weights
+int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr, int* status = nullptr);
 // 3x3/s1, 64 -> 64, fp16 pair, weights resident in registers (k_conv_rs64.hip / conv_rs64_body.hpp); -1: not this layer, or the map is wider than its LDS rings allow
 int launch_conv_rs64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status = nullptr, const ConvW* fused1x1 = nullptr, bool nhwc = false,
                      long long* trace = nullptr);
 bool conv_rs128_fits(int W);      // the map's rings fit into a CU's LDS
 int launch_conv_rs128(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status = nullptr);      // the 128 -> 128 form (block5.1, block5.2)
-// 3x3/s2, 64 -> 64 | 128 (block4.0, block5.0; k_conv_bx64s2.hip); -1 if no instantiation
-int launch_conv_bx64s2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr);
-// the same layers in the fp16-pair arithmetic (k_conv_bx64s2x.hip / conv_bx64s2_body.hpp); -1 if the layer has no fp16-pair weights
+// 3x3/s2, 64 -> 64 | 128 (block4.0, block5.0) in the fp16-pair arithmetic (k_conv_bx64s2x.hip / conv_bx64s2_body.hpp); -1 if the layer has no fp16-pair weights
 int launch_conv_bx64s2_fx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr, int* status = nullptr);
 int bx_steps(int cin);      // K steps of 16 = 2 groups of 8 channels of one tap
 // ---- k_homography.hip (RANSAC + MAGSAC++ homography from match lists) ----
@@ -150,11 +129,9 @@ void launch_softmax_heat(const float* logits, int B, int hc, int wc, float* heat
 // ---- k_heads.hip -------------------------------------------------------------------------
 // fused heads (persistent, weights LDS-resident): key-point head -> heat (+ optional logits (M,65)),
 // reliability head -> sigmoid map
-int head_soak(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, const float* heat_ref, float* logits, const float* logits_ref,
-              int variant, int iters, int iter0, unsigned* rep_heat, unsigned* rep_logits, unsigned cap, hipStream_t st);      // debug, k_heads.hip
-void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, int f32_kernels = 0, int fx = 0, int* status = nullptr);
+void launch_kp_head(const NetWeights& nw, const float* gray, const float* coef, int B, int H, int W, float* heat, float* logits, hipStream_t st, bool f32_kernels = false, int* status = nullptr);
 // invnorm (optional): 1 / max(||feats[cell,:]||, 1e-12) per cell, a by-product of the layer-1 operand loads
-void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, int f32_kernels = 0, int fx = 0, int* status = nullptr);
+void launch_rel_head(const NetWeights& nw, const float* feats, int ncell, float* reliab, float* invnorm, hipStream_t st, bool f32_kernels = false, int* status = nullptr);
 
 // ---- k_detect.hip -----------------------------------------------------------------------
 struct DetectWs {          // carved from the caller's workspace by api.hip

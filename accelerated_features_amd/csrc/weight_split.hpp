@@ -1,22 +1,9 @@
-// Host side of the split-operand weight formats (api.hip packs every MFMA operand with these; tests/test_block1_fx_model.py compiles them with g++).
+// Host side of the fp16-pair weight formats (api.hip packs every MFMA operand with these; tests/test_block1_fx_model.py compiles them with g++).
 #pragma once
 #include <cstdint>
 #include <cstring>
 
 namespace xfh {
-
-inline uint16_t bf16_rne(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-inline float bf16_float(uint16_t h) {
-    const uint32_t u = (uint32_t)h << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
 
 // fp32 -> fp16, round to nearest even (subnormals kept, overflow -> inf) and back: the host side of the two-term fp16 weights
 inline uint16_t f16_rne(float f) {
@@ -50,28 +37,19 @@ inline float f16_float(uint16_t h) {
     memcpy(&f, &u, 4);
     return f;
 }
-// The three weight fragments of one fp32 weight, per arithmetic of the split-operand MFMA kernels (k_conv_bx*.hip, k_heads.hip):
-//   mode 0: bf16, w = q0 + q1 + q2 (three-way split, round to nearest even)
-//   mode 1: fp16 at scale 2^11 ("fx"): q0 = fp16(2^11 w), q2 = fp16(2^11 w - q0) -- together 22 bits of 2^11 w, multiplied with the activation's high
-//           part -- and q1 = fp16(w), multiplied with the activation's 2^11-scaled low part: all three products carry the factor 2^11
-inline void split_weight(float v, int mode, uint16_t (&q)[3]) {
-    if (mode == 0) {
-        q[0] = bf16_rne(v);
-        const float r1 = v - bf16_float(q[0]);
-        q[1] = bf16_rne(r1);
-        q[2] = bf16_rne(r1 - bf16_float(q[1]));
-    } else {
-        const float s = v * 2048.f;                    // exact
-        q[0] = f16_rne(s);
-        q[1] = f16_rne(v);
-        q[2] = f16_rne(s - f16_float(q[0]));            // exact difference
-    }
+// The three fp16 fragments of one fp32 weight in the fp16-pair arithmetic (bx_split.hpp), all at scale 2^11: q0 = fp16(2^11 w), q2 = fp16(2^11 w - q0) -- together 22 bits
+// of 2^11 w, multiplied with the activation's high part -- and q1 = fp16(w), multiplied with the activation's 2^11-scaled low part.
+inline void split_weight(float v, uint16_t (&q)[3]) {
+    const float s = v * 2048.f;                    // exact
+    q[0] = f16_rne(s);
+    q[1] = f16_rne(v);
+    q[2] = f16_rne(s - f16_float(q[0]));            // exact difference
 }
 constexpr float kFxMaxWeight = 31.f;                   // |w| * 2^11 must stay below the fp16 maximum (65504)
 
 // A linear layer y = x W for linear_fx_kernel (k_linear_mfma.hip: the fine_matcher's layers in the fp16-pair arithmetic): w_kn [K][n_pad] fp32 (BatchNorm folded, zero padded)
 // -> [column block of 64][K step of 16][fragment 3][column half-block 2][lane = half * 32 + column][8]: lane (column n = 64 nb + 32 cb + (lane & 31), half) holds k = 16 s + 8 half + i.
-// fp16-pair fragments (split_weight mode 1).  Returns the 16-bit words written (3 K n_pad).
+// Returns the 16-bit words written (3 K n_pad).
 inline size_t pack_linear_fx(const float* w_kn, int K, int n_pad, uint16_t* dst) {
     const int nbs = n_pad / 64, ns = K / 16;
     for (int nb = 0; nb < nbs; ++nb)
@@ -81,17 +59,16 @@ inline size_t pack_linear_fx(const float* w_kn, int K, int n_pad, uint16_t* dst)
                     for (int i = 0; i < 8; ++i) {
                         const int k = 16 * st + 8 * (lane >> 5) + i, n = 64 * nb + 32 * cb + (lane & 31);
                         uint16_t q[3];
-                        split_weight(w_kn[(size_t)k * n_pad + n], 1, q);
+                        split_weight(w_kn[(size_t)k * n_pad + n], q);
                         for (int sp = 0; sp < 3; ++sp) dst[(((((size_t)nb * ns + st) * 3 + sp) * 2 + cb) * 64 + lane) * 8 + i] = q[sp];
                     }
     return (size_t)3 * K * n_pad;
 }
 
-// One layer of a split-operand head (head_bx_body.hpp) in operand order: [K step t][cout block][split][lane = half * 32 + cout][8], cout blocks of 32 (zeros above cout).
+// One layer of a head (head_bx_body.hpp) in operand order: [K step t][cout block][fragment][lane = half * 32 + cout][8], cout blocks of 32 (zeros above cout).
 // K order: the first layer of a head takes its 64 input channels in natural order (16 t + 8 half + i); a chained layer takes the previous layer's D registers, i.e.
-// feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).  w: (cout, 64) fp32 (BatchNorm folded), mode: split_weight's.  nfrag = 2 (mode 1 only): q0 and q2 alone
-// ([.. ][2 fragments][lane][8]; the kernel derives q1 = 2^-11 q0).  Returns the 16-bit words written.
-inline size_t pack_head_layer(const float* w, int cout, bool first, int mode, uint16_t* dst, int nfrag = 3) {
+// feature 32 (t >> 1) + 16 (t & 1) + 8 (i >> 2) + 4 half + (i & 3).  w: (cout, 64) fp32 (BatchNorm folded).  Returns the 16-bit words written.
+inline size_t pack_head_layer(const float* w, int cout, bool first, uint16_t* dst) {
     const int mbo = (cout + 31) / 32;
     for (int t = 0; t < 4; ++t)
         for (int mb = 0; mb < mbo; ++mb)
@@ -100,16 +77,15 @@ inline size_t pack_head_layer(const float* w, int cout, bool first, int mode, ui
                     const int o = mb * 32 + (lane & 31), hf = lane >> 5;
                     const int ch = first ? 16 * t + 8 * hf + i : 32 * (t >> 1) + 16 * (t & 1) + 8 * (i >> 2) + 4 * hf + (i & 3);
                     uint16_t q[3];
-                    split_weight(o < cout ? w[(size_t)o * 64 + ch] : 0.f, mode, q);
-                    if (nfrag == 3) for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * mbo + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
-                    else for (int sp = 0; sp < 2; ++sp) dst[((((size_t)t * mbo + mb) * 2 + sp) * 64 + lane) * 8 + i] = q[2 * sp];
+                    split_weight(o < cout ? w[(size_t)o * 64 + ch] : 0.f, q);
+                    for (int sp = 0; sp < 3; ++sp) dst[((((size_t)t * mbo + mb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                 }
-    return (size_t)4 * mbo * nfrag * 64 * 8;
+    return (size_t)4 * mbo * 3 * 64 * 8;
 }
 
-// 3x3 convolution weights for conv_bx64_kernel / conv_bx64s2_kernel: [cout half][cin/16][tap 9][cout block 2][split 3][lane = half * 32 + cout][8], channel = 16 chunk + 8 half + i.
+// 3x3 stride-2 convolution weights for conv_bx64s2x_kernel: [cout half][cin/16][tap 9][cout block 2][fragment 3][lane = half * 32 + cout][8], channel = 16 chunk + 8 half + i.
 // w: (cout, cin, 3, 3) fp32 (BatchNorm folded), cin % 16 == 0, cout % 64 == 0.  Returns the 16-bit words written.
-inline size_t pack_bx64(const float* w, int cin, int cout, int mode, uint16_t* dst, int nfrag = 3) {      // nfrag = 2 (mode 1): q0, q2 alone -- [..][cout block][2][lane][8]
+inline size_t pack_bx64(const float* w, int cin, int cout, uint16_t* dst) {
     const int nch = cin / 16, nhf = cout / 64;
     for (int hf = 0; hf < nhf; ++hf)
         for (int ch = 0; ch < nch; ++ch)
@@ -119,13 +95,13 @@ inline size_t pack_bx64(const float* w, int cin, int cout, int mode, uint16_t* d
                         for (int i = 0; i < 8; ++i) {
                             const int o = hf * 64 + cb * 32 + (lane & 31), ci = ch * 16 + 8 * (lane >> 5) + i;
                             uint16_t q[3];
-                            split_weight(w[((size_t)o * cin + ci) * 9 + tap], mode, q);
-                            for (int sp = 0; sp < nfrag; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * nfrag + sp) * 64 + lane) * 8 + i] = q[nfrag == 3 ? sp : 2 * sp];
+                            split_weight(w[((size_t)o * cin + ci) * 9 + tap], q);
+                            for (int sp = 0; sp < 3; ++sp) dst[((((((size_t)hf * nch + ch) * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                         }
-    return (size_t)nhf * nch * 9 * 2 * nfrag * 64 * 8;
+    return (size_t)nhf * nch * 9 * 2 * 3 * 64 * 8;
 }
 // 3x3 convolution weights (64 -> 64) for conv_rs64_kernel (conv_rs64_body.hpp: weights resident in registers, K split over the four waves of a workgroup):
-// [wave = 16-channel chunk][tap 9][cout block 2][fragment 3][lane = half * 32 + cout][8], channel = 16 wave + 8 half + i; fp16-pair fragments (split_weight mode 1).
+// [wave = 16-channel chunk][tap 9][cout block 2][fragment 3][lane = half * 32 + cout][8], channel = 16 wave + 8 half + i;
 // w: (64, 64, 3, 3) fp32 (BatchNorm folded).  Returns the 16-bit words written.
 constexpr size_t kRs64Halfs = (size_t)4 * 9 * 2 * 3 * 64 * 8;      // 216 KiB
 inline size_t pack_rs64(const float* w, uint16_t* dst) {
@@ -136,7 +112,7 @@ inline size_t pack_rs64(const float* w, uint16_t* dst) {
                     for (int i = 0; i < 8; ++i) {
                         const int o = cb * 32 + (lane & 31), ci = wv * 16 + 8 * (lane >> 5) + i;
                         uint16_t q[3];
-                        split_weight(w[((size_t)o * 64 + ci) * 9 + tap], 1, q);
+                        split_weight(w[((size_t)o * 64 + ci) * 9 + tap], q);
                         for (int sp = 0; sp < 3; ++sp) dst[(((((size_t)wv * 9 + tap) * 2 + cb) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                     }
     return kRs64Halfs;
@@ -152,7 +128,7 @@ inline size_t pack_rs128(const float* w, uint16_t* dst) {
                         for (int i = 0; i < 8; ++i) {
                             const int o = cq * 32 + (lane & 31), ci = wv * 32 + ck * 16 + 8 * (lane >> 5) + i;
                             uint16_t q[3];
-                            split_weight(w[((size_t)o * 128 + ci) * 9 + tap], 1, q);
+                            split_weight(w[((size_t)o * 128 + ci) * 9 + tap], q);
                             for (int sp = 0; sp < 3; ++sp) dst[(((((((size_t)cq * 4 + wv) * 9 + tap) * 2 + ck) * 3 + sp) * 64) + lane) * 8 + i] = q[sp];
                         }
     return 4 * kRs64Halfs;
@@ -165,12 +141,9 @@ inline size_t pack_rs64_1x1(const float* w, uint16_t* dst) {
             for (int lane = 0; lane < 64; ++lane)
                 for (int i = 0; i < 8; ++i) {
                     uint16_t q[3];
-                    split_weight(w[(size_t)(16 * wv + (lane & 15)) * 64 + 32 * s + 8 * (lane >> 4) + i], 1, q);
+                    split_weight(w[(size_t)(16 * wv + (lane & 15)) * 64 + 32 * s + 8 * (lane >> 4) + i], q);
                     for (int sp = 0; sp < 3; ++sp) dst[((((size_t)wv * 2 + s) * 3 + sp) * 64 + lane) * 8 + i] = q[sp];
                 }
     return (size_t)4 * 2 * 3 * 64 * 8;
 }
-// the 1x1 (64 -> 64) fused behind a 64 -> 64 3x3 in conv_bx64_kernel: K order of the 3x3's D registers (as a chained head layer): [K step 4][cout block 2][split 3][lane][8]
-inline size_t pack_bx1x1(const float* w /* (64, 64) */, int mode, uint16_t* dst) { return pack_head_layer(w, 64, false, mode, dst); }
-
 }  // namespace xfh

@@ -76,7 +76,7 @@ class CapturedSparsePipeline:
         self.graph.replay()
         c = self.counts.cpu()                                   # the one read-back
         if int(c[-1]):                                          # an activation left the range of the fp16-pair arithmetic (never seen on images): the captured kernels' results
-            self.xf.net._status_target[:1].zero_()              # are not valid.  The replica falls back to the bf16 split and is re-captured (the graph bakes the kernel choice
+            self.xf.net._status_target[:1].zero_()              # are not valid.  The replica falls back to the fp32-range kernels and is re-captured (the graph bakes the kernel choice
             self.xf.net.fx_range_exceeded(status=1)             # in); this call is answered eagerly by the user's model, whose own check makes the same switch
             self._capture()
             return self._eager(frames)

@@ -132,7 +132,7 @@ class ReferenceTracker:
 
     def range_exceeded(self, fx_status):
         """True if an activation left the range of the fp16-pair arithmetic since the last check (device int32 `fx_status` of track()'s result, non-zero; never seen on
-        images): the step's results are not valid -- the model has been switched to the bf16 split, call set_reference / track again.  Costs a read-back, like
+        images): the step's results are not valid -- the model has been switched to the fp32-range kernels, call set_reference / track again.  Costs a read-back, like
         `overflowed`: check it where the caller reads the step's results back anyway."""
         v = int(fx_status[0].item())
         if v:

@@ -106,7 +106,7 @@ class FrameStream:
         kp, sc, de, i0, i1, cap, B, hw, x = ln.out
         while True:                                                 # (as detectAndCompute: repeated until neither the range flag nor the candidate capacity asks for it)
             ncmax = int(ln.host[1].max())
-            redo = ln.xf.net.fx_range_exceeded(status=int(ln.host[3, 0]))      # fp16-pair arithmetic out of range (never on images): the lane's model is on the bf16 split now
+            redo = ln.xf.net.fx_range_exceeded(status=int(ln.host[3, 0]))      # fp16-pair arithmetic out of range (never on images): the lane's model is on the fp32-range kernels now
             if not redo and (cap >= hw or ncmax <= cap):
                 break
             if ncmax > cap:                                         # a plateau image overflowed the NMS candidate list: exact re-run with room

@@ -19,8 +19,8 @@ from . import _lib
 from .spec import CONVS, FINE
 
 # the library's defaults of the options the range fallback below has to know (csrc/kernels.hpp: Options; tests/test_gpu_parity.py checks that the mirrors agree)
-DEFAULT_FX = 3979
-DEFAULT_HEADS_F32 = 0
+FX_CONV64, FX_CONV24, FX_HEADS, FX_FINE = 1, 2, 8, 2048      # include/xfeat_hip.h: XFH_FX_*
+DEFAULT_FX = FX_CONV64 | FX_CONV24 | FX_HEADS | FX_FINE
 DEFAULT_BLOCK1 = 7
 
 __all__ = ["XFeat", "XFeatModel"]
@@ -197,10 +197,11 @@ class XFeatModel(nn.Module):
         _lib.check(lib.xfh_set_status_buffer(h, C.c_void_p(self._status.data_ptr())), "xfh_set_status_buffer")
         return h
 
-    OPTION_RANGES = {"match_exact": (0, 1), "wino": (0, 2), "bx": (0, 31), "heads_f32": (0, 3), "block1": (0, 7), "fx": (0, 4095), "resize2": (0, 1)}      # include/xfeat_hip.h: xfh_set_option
+    # include/xfeat_hip.h: xfh_set_option (= api.hip: xfh_set_option's checks)
+    OPTION_VALUES = {"match_exact": lambda v: v in (0, 1), "resize2": lambda v: v in (0, 1), "block1": lambda v: v in (5, 7), "fx": lambda v: v >= 0 and (v & ~DEFAULT_FX) == 0}
 
     def set_option(self, key, value):
-        """Kernel-variant switch of this model's handle (include/xfeat_hip.h: xfh_set_option) -- A/B runs and variant-vs-variant tests.
+        """Kernel switch of this model's handle (include/xfeat_hip.h: xfh_set_option): the default kernel of a layer family or its fp32-range fallback.
         Remembered across handle re-creation (load_state_dict, device change).  value None restores the default."""
         if value is None:
             if self._options.pop(key, None) is not None:
@@ -208,9 +209,9 @@ class XFeatModel(nn.Module):
             return
         # validated BEFORE it is remembered (a bad entry in _options would fail every later handle creation half-way through the list): against the
         # live handle when there is one, against the table below (= api.hip: option_slot) otherwise
-        lo, hi = self.OPTION_RANGES.get(key, (None, None))
-        if lo is None or not lo <= int(value) <= hi or (key == "block1" and int(value) == 2):
-            raise _lib.XFeatHipError(f"set_option: unknown option or value out of range: {key} = {value} (options: {self.OPTION_RANGES})")
+        ok = self.OPTION_VALUES.get(key)
+        if ok is None or not ok(int(value)):
+            raise _lib.XFeatHipError(f"set_option: unknown option or value: {key} = {value} (options: {sorted(self.OPTION_VALUES)}; include/xfeat_hip.h)")
         if self._handle is not None:
             _lib.check(_lib.load().xfh_set_option(self._handle, key.encode(), int(value)), f"xfh_set_option({key})")
         self._options[key] = int(value)
@@ -231,13 +232,19 @@ class XFeatModel(nn.Module):
 
         @contextlib.contextmanager
         def cm():
+            prev = getattr(self, "_status_target", None)       # a caller's own target (FrameStream lane, tracker) comes back when the context closes
             self.set_status_target(t)
             try:
                 yield t
             finally:
                 if self._handle is not None:
-                    self.set_status_target(None)
+                    self.set_status_target(None if prev is None or prev is self._status else prev)
         return cm()
+
+    def clear_status(self):
+        """Zero the model's own status word on the current stream (no read-back): a path that does not read the word back itself starts from a clean one."""
+        if self._handle is not None and getattr(self, "_status", None) is not None:
+            self._status.zero_()
 
     def take_status(self):
         """Read and clear the model's own status word (one 4-byte read-back; 0 without a handle)."""
@@ -249,16 +256,16 @@ class XFeatModel(nn.Module):
         return v
 
     def _effective_option(self, key):
-        return self._options.get(key, {"fx": DEFAULT_FX, "heads_f32": DEFAULT_HEADS_F32, "block1": DEFAULT_BLOCK1}[key])
+        return self._options.get(key, {"fx": DEFAULT_FX, "block1": DEFAULT_BLOCK1}[key])
 
     def fx_range_exceeded(self, status=None):
         """True if a call since the last check left the range of the fp16-pair arithmetic (|activation| >= 65504; never seen on images): the model then falls
-        back for good to the forms with fp32's range -- the bf16 three-way split for the convolutions (option fx = 0), the f32-MFMA heads where the split heads
-        were on (heads_f32 = 2: with fx = 0 the split heads would be the retired bf16 kernel), the vector-ALU block1 (block1 = 5) -- and the caller
-        repeats the call; results are exact either way.  Written against the EFFECTIVE options (override or library default), so it holds whatever the defaults are."""
-        fx_on = self._effective_option("fx") != 0 or self._effective_option("block1") >= 6
+        back for good to the kernels with fp32's range -- the f32-MFMA convolutions, heads and linear layers (option fx = 0) and the vector-ALU block1 (block1 = 5;
+        include/xfeat_hip.h: THE RANGE FALLBACK) -- and the caller repeats the call; results are exact either way.  Written against the EFFECTIVE options (override or
+        library default), so it holds whatever the defaults are."""
+        fx_on = self._effective_option("fx") != 0 or self._effective_option("block1") == 7
         if status is None and not fx_on:
-            return False                               # (the bf16 / f32 forms have fp32's range: nothing to read back)
+            return False                               # (every kernel has fp32's range: nothing to read back)
         v = self.take_status() if status is None else int(status)
         if not (v & 1):
             return False
@@ -266,12 +273,9 @@ class XFeatModel(nn.Module):
             return False                               # (a stale flag of a caller's buffer: nothing left to switch off, and repeating the call would not end)
         import warnings
         warnings.warn("accelerated_features_amd: an activation left the range of the fp16-pair arithmetic (|x| >= 65504); this model falls back to the "
-                      "bf16 three-way split (option fx = 0) and the call is repeated")
+                      "f32-MFMA / vector-ALU kernels (options fx = 0, block1 = 5) and the call is repeated")
         self.set_option("fx", 0)
-        if self._effective_option("heads_f32") == 0:   # (the split heads: fp16 pair with fx bit 8 -- never fall through to the bf16 head)
-            self.set_option("heads_f32", 2)
-        if self._effective_option("block1") >= 6:      # (block1's matrix-core forms are fp16-pair kernels too)
-            self.set_option("block1", 5)
+        self.set_option("block1", 5)
         return True
 
     def workspace(self, name, nbytes):
@@ -432,16 +436,15 @@ class XFeat(nn.Module):
             self._require_gpu()
             cnt_dev = torch.zeros((3, B), dtype=torch.int32, device=self.dev)      # n_valid, n_candidates, [2, 0] = the status word of the fp16-pair arithmetic
             with self.net.status_into(cnt_dev[2]):
-                kpts, scores, desc, n_valid, n_cand, cap, hw, d16 = self._detect_device(x, top_k, detection_threshold, cap, want_f16=True, counts_out=cnt_dev[:2])
+                kpts, scores, desc, n_valid, n_cand, cap, hw = self._detect_device(x, top_k, detection_threshold, cap, counts_out=cnt_dev[:2])
             cnt = cnt_dev.cpu()                                  # the ONE read-back per batch (counts and status together)
-            if self.net.fx_range_exceeded(status=int(cnt[2, 0])):      # (fp16-pair arithmetic out of range: never on images; exact re-run on the bf16 split)
+            if self.net.fx_range_exceeded(status=int(cnt[2, 0])):      # (fp16-pair arithmetic out of range: never on images; exact re-run on the fp32-range kernels)
                 continue
             ncmax = int(cnt[1].max())
             if cap >= hw or ncmax <= cap:
                 break
             cap = min(hw, max(ncmax, 2 * cap))                   # plateau image: exact re-run with room
         nv = cnt[0].tolist()
-        self._last_desc16 = (desc, d16)                          # the fp16 copies the descriptor kernel wrote along: match_many's filter reads them (saves its conversion passes)
         return [{'keypoints': kpts[b, :nv[b]], 'scores': scores[b, :nv[b]], 'descriptors': desc[b, :nv[b]]}
                 for b in range(len(nv))]
 
@@ -509,12 +512,12 @@ class XFeat(nn.Module):
                     'scales'       ->   torch.Tensor(B, top_k): extraction scale
                     'descriptors'  ->   torch.Tensor(B, top_k, 64): coarse local features
         """
-        out = self._dense_device(x, top_k, multiscale)
-        # no read-back here (the results stay on the device, as in the reference): 'fx_status' is the model's status word, a device int32 -- non-zero if an activation
-        # left the range of the fp16-pair arithmetic (never seen on images); a caller that reads anything back can read it along and, if set, call
-        # net.fx_range_exceeded() (which switches the model to the bf16 split) and repeat.  match_xfeat_star does exactly that.
-        out['fx_status'] = self.net._status_target
-        return out
+        # The reference's dict, nothing added.  No read-back here (the results stay on the device, as in the reference), so the range guard of the fp16-pair arithmetic
+        # (never seen to fire on images) is the caller's to check: `self.net.fx_range_exceeded()` after the call reads the model's status word (4 bytes), switches the
+        # model to the fp32-range kernels if it was set and returns True -- then repeat the call.  match_xfeat_star does exactly that.  The word is cleared before the
+        # kernels are enqueued, so a flag left by an earlier call cannot trigger a spurious fallback.
+        self.net.clear_status()
+        return self._dense_device(x, top_k, multiscale)
 
     def _dense_device(self, x, top_k=None, multiscale=True):
         """detectAndComputeDense without the status read-back (match_xfeat_star checks once per call)."""
@@ -818,8 +821,8 @@ class XFeat(nn.Module):
             res = xf.detectAndCompute(frames)                                   # List[Dict], as in the reference
             ms = xf.match_many([r['descriptors'] for r in res[0::2]], [r['descriptors'] for r in res[1::2]])
         Descriptor tensors that are row-prefix views of one padded (B, K, 64) tensor at a constant stride -- what detectAndCompute hands out -- are matched in place
-        (no copy; the fp16 copies that detectAndCompute's kernel wrote along are reused for the filter pass as long as the descriptors are the ones the LAST
-        detectAndCompute call returned -- do not modify those in place before matching them); anything else is padded into one tensor first."""
+        (no copy; the rows are read as they are at the time of the call, so descriptors modified in place since detectAndCompute are matched as modified); anything
+        else is padded into one tensor first."""
         P = len(feats1)
         if len(feats2) != P:
             raise RuntimeError('match_many: the two lists must have the same length')
@@ -875,13 +878,9 @@ class XFeat(nn.Module):
             if stride <= 0 or stride % 8 or any(o[i + 1] - o[i] != stride for i in range(len(o) - 1)) or any(int(f.shape[0]) * 64 > stride for f in lst):
                 return None
             offs.append((o[0], stride))
-        h1 = h2 = None
-        keep = [f0]
-        last = getattr(self, "_last_desc16", None)
-        if last is not None and last[0].untyped_storage().data_ptr() == st and last[0].storage_offset() == 0 and last[1].shape == last[0].shape:
-            h1, h2 = last[1].data_ptr() + 2 * offs[0][0], last[1].data_ptr() + 2 * offs[1][0]      # the fp16 copies sit at the same element offsets of their own tensor
-            keep += [last[0], last[1]]
-        return st + 4 * offs[0][0], offs[0][1], st + 4 * offs[1][0], offs[1][1], h1, h2, keep
+        # No fp16 copies: the matcher's own conversion pass reads the rows as they are NOW (round 5 reused the copies detectAndCompute's descriptor kernel had written,
+        # keyed on the storage pointer: a caller who re-scaled or masked the returned descriptors in place got a filter on stale rows -- ADVICE r5; the pass is ~1 % of a step)
+        return st + 4 * offs[0][0], offs[0][1], st + 4 * offs[1][0], offs[1][1], None, None, [f0]
 
     def create_xy(self, h, w, dev):
         y, x = torch.meshgrid(torch.arange(h, device=dev), torch.arange(w, device=dev), indexing='ij')

@@ -22,8 +22,7 @@ own batch (weak scaling, no data-path collective; RCCL only for the barrier / ma
 
 Prints ONE JSON line on rank 0 (see the task contract): value = whole-job frames/s.
 `roofline` is measured live with HIP events around the dominant kernel (the largest single
-entry of the rocprofv3 kernel stats: block1_fused_kernel, since the 24->24 convolutions moved
-to split-bf16 MFMAs) inside the timed region; the match, the two 24->24 convolutions and the
+entry of the rocprofv3 kernel stats: block1_mx_kernel) inside the timed region; the match, the two 24->24 convolutions and the
 whole MFMA convolution family are reported next to it from short untimed passes of the same step;
 `cpu_baseline` times the CPU oracle (a port of the reference's CPU path) on the host cores
 for a bounded sample.
@@ -138,7 +137,7 @@ def cpu_sample(seconds, fn, unit, units_per_call, what):
 
 def conv_family_roofline(xf, step_fn, n=2):
     """Secondary, untimed pass shared by the dense / megadepth workloads: HIP events (xfh_profile_select) around every MFMA
-    convolution launch (Winograd + direct) of `n` steps -> achieved TFLOP/s with the direct form's algorithmic FLOPs."""
+    convolution launch of `n` steps -> achieved TFLOP/s with the direct form's algorithmic FLOPs."""
     from accelerated_features_amd import _lib
     lib, handle = _lib.load(), xf.net.handle()
     lib.xfh_profile_select(handle, _lib.PROF_CONV_MFMA)
@@ -154,7 +153,7 @@ def conv_family_roofline(xf, step_fn, n=2):
     return {"bound": "mfma", "kernel": "every MFMA convolution launch of the step behind block1: conv_bx_kernel<24,24> / conv_bxs2_kernel<24>, conv_rs64_kernel (64 -> 64 and 128 -> 128 3x3, "
                                        "with and without the fused 1x1; column strips on maps wider than its rings), conv_bx64s2x_kernel, the 128 -> 64 1x1 -- fp32 results on "
                                        "v_mfma_f32_32x32x16_f16 with an fp16 pair per operand (three MFMAs per product)",
-            "achieved": round(3 * ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(3 * ach / PEAK_BF16_TFLOPS, 4),
+            "achieved": round(3 * ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(3 * ach / PEAK_F16_TFLOPS, 4),
             "achieved_note": "executed fp16 MFMA rate = 3 x the algorithmic fp32 rate (channel / unit padding not counted)",
             "algorithmic_fp32_tflops": round(ach, 2), "algorithmic_vs_fp32_peak": round(ach / PEAK_MFMA_F32_TFLOPS, 4),
             "launches": cn.value, "ms_per_step": round(cms.value / n, 3), "traffic": None}
@@ -174,15 +173,15 @@ def load_pmc_traffic():
 
 
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-PEAK_BF16_TFLOPS = 2500.0         # dense bf16 / fp16 MFMA
+PEAK_F16_TFLOPS = 2500.0          # dense fp16 MFMA
 MATCH_MAXIMA_BYTES_PER_ENTRY = 2.0      # the matcher's block maxima (k_match_f16.hip): fp16 since round 5
 
 
-def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2, block1=0):
+def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=1 | 2 | 8 | 2048, block1=7):
     """roofline_kernels: one row per kernel (or tight kernel group) of the step, from the HIP-event spans of an untimed pass
     (xfh_profile_select(XFH_PROF_ALL)).  Per row: us per step; algorithmic HBM bytes (inputs read once + outputs written once) and FLOPs;
-    the FLOPs the shipped kernel EXECUTES on the instruction it uses (Winograd: 2.25x fewer than direct; fp32 on bf16 MFMAs: 6 MFMAs per
-    product and the channel padding); the peak of that instruction; frac = max(bytes / 8 TB/s, executed / peak) / measured time."""
+    the FLOPs the shipped kernel EXECUTES on the instruction it uses (the fp16-pair arithmetic: 3 MFMAs per product, and the channel / tile padding);
+    the peak of that instruction; frac = max(bytes / 8 TB/s, executed / peak) / measured time.  fx / block1: the handle's options (a cleared fx bit = that family on f32 MFMAs)."""
     from accelerated_features_amd.spec import CONVS
     HW = H * W
     px = {"1": B * HW, "2": B * HW // 4, "4": B * HW // 16, "8": B * HW // 64, "16": B * HW // 256, "32": B * HW // 1024}
@@ -207,69 +206,44 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2, block
                      **({"filter_design_traffic_bytes": int(design_bytes)} if design_bytes else {})})
 
     ci = {c.name: i for i, c in enumerate(CONVS)}
+    PAIR, F32P = "fp16 mfma x3 (fp16 pair, fp32-equivalent)", "f32 mfma"
+
+    def conv_row(name, kernel_fx, by, fl, exec_factor, on_fx):      # a convolution layer (or fused pair) on its fp16-pair kernel, or -- fx bit cleared -- on conv_mfma_kernel
+        if on_fx:
+            add(100 + ci[name], kernel_fx, by, fl, fl * exec_factor, PEAK_F16_TFLOPS, PAIR)
+        else:
+            add(100 + ci[name], f"conv_mfma_kernel ({name}; fp32-range fallback)", by, fl, fl, f32, F32P)
+
     add(200, "gray_stats + gray_coef (channel mean, InstanceNorm statistics)", 4.0 * px["1"] * 4, 4.0 * px["1"], 4.0 * px["1"], 0, "valu")
-    if block1 >= 6:      # block1.3 (and block1.2) on v_mfma_f32_16x16x32_f16 in the fp16-pair arithmetic: the row keeps the algorithmic FLOPs against the fp32 peak -- the kernel stays
-        add(3, f"block1_mx_kernel<{block1}> (block1.0-.3 + skip1; block1.{'2, .3' if block1 >= 7 else '3'} on fp16-pair MFMAs)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32,      # bound by the
-            "fp32 valu (v_pk_fma_f32) + fp16 mfma x3")                                                                                                                                    # vector stages
+    if block1 == 7:      # block1.2, .3 on v_mfma_f32_16x16x32_f16 in the fp16-pair arithmetic: the row keeps the algorithmic FLOPs against the fp32 peak -- the kernel stays bound by the vector stages
+        add(3, "block1_mx_kernel (block1.0-.3 + skip1; block1.2, .3 on fp16-pair MFMAs)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32, "fp32 valu (v_pk_fma_f32) + fp16 mfma x3")
     else:
-        add(3, "block1_fused_kernel (block1.0-.3 + skip1)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32, "fp32 valu (v_pk_fma_f32)")
-    # split-operand convolutions: the fp16-pair arithmetic (option fx, default: 3 MFMAs per product) or the bf16 three-way split (6)
-    nm24, nm64 = (3 if fx & 2 else 6), (3 if fx & 1 else 6)
-    pipe24 = "fp16 mfma x3 (fp16 pair, fp32-equivalent)" if fx & 2 else "bf16 mfma x6 (fp32-equivalent)"
-    pipe64 = "fp16 mfma x3 (fp16 pair, fp32-equivalent)" if fx & 1 else "bf16 mfma x6 (fp32-equivalent)"
-    bx24 = nm24 * (32 / 24) * (224 / 216)
-    for n_ in ("block2.0", "block2.1"):
-        fl = conv_flops(n_, px["4"])
-        add(100 + ci[n_], f"conv_bx_kernel<24,24> ({n_})", 4.0 * 48 * px["4"], fl, fl * bx24, PEAK_BF16_TFLOPS, pipe24)
-    fl = conv_flops("block3.0", px["8"])
-    add(100 + ci["block3.0"], "conv_bxs2_kernel<24> (block3.0, stride 2)", 4.0 * (24 * px["4"] + 64 * px["8"]), fl, fl * nm24 * (224 / 216), PEAK_BF16_TFLOPS, pipe24)
-    rs_plain, rs_fused, rs_128 = (fx & 129) == 129, (fx & 257) == 257, (fx & 513) == 513      # conv_rs64_kernel (weights resident in registers): unfused 64 -> 64 layers, 3x3 + 1x1 pairs, block5.1 / 5.2
-    for n3, n1, tag in (("block3.1", "block3.2", "conv_rs64_kernel<1>" if rs_fused else "conv_bx64_kernel<64,1>"),
-                        ("block_fusion.1", "block_fusion.2", "conv_rs64_kernel<2> (channels-last out)" if rs_fused else "conv_bx64_kernel<64,2> (channels-last out)")):
-        fl = conv_flops(n3, px["8"]) + conv_flops(n1, px["8"])
-        add(100 + ci[n3], f"{tag} ({n3} + {n1})", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
-    fl = conv_flops("block_fusion.0", px["8"])
-    add(100 + ci["block_fusion.0"], ("conv_rs64_kernel<0>" if rs_plain else "conv_bx64_kernel<64,0>") + " (block_fusion.0)", 4.0 * 128 * px["8"], fl, fl * nm64, PEAK_BF16_TFLOPS, pipe64)
+        add(3, "block1_fused_kernel (block1.0-.3 + skip1; fp32-range fallback)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32, "fp32 valu (v_pk_fma_f32)")
+    c24, c64 = bool(fx & 2), bool(fx & 1)
+    for n_ in ("block2.0", "block2.1"):      # executed: 3 MFMAs per product, couts padded 24 -> 32, K groups 27 -> 28
+        conv_row(n_, f"conv_bx_kernel<24,24> ({n_})", 4.0 * 48 * px["4"], conv_flops(n_, px["4"]), 3 * (32 / 24) * (224 / 216), c24)
+    conv_row("block3.0", "conv_bxs2_kernel<24> (block3.0, stride 2)", 4.0 * (24 * px["4"] + 64 * px["8"]), conv_flops("block3.0", px["8"]), 3 * (224 / 216), c24)
+    for n3, n1, tag in (("block3.1", "block3.2", "conv_rs64_kernel<1>"), ("block_fusion.1", "block_fusion.2", "conv_rs64_kernel<2> (channels-last out)")):
+        conv_row(n3, f"{tag} ({n3} + {n1})", 4.0 * 128 * px["8"], conv_flops(n3, px["8"]) + conv_flops(n1, px["8"]), 3, c64)
+    conv_row("block_fusion.0", "conv_rs64_kernel<0> (block_fusion.0)", 4.0 * 128 * px["8"], conv_flops("block_fusion.0", px["8"]), 3, c64)
     for n_, cin, cout, sc_in, sc_out in (("block4.0", 64, 64, "8", "16"), ("block5.0", 64, 128, "16", "32")):
-        fl = conv_flops(n_, px[sc_out])
         ho, wo = H // int(sc_out), W // int(sc_out)
         pad = (-(-ho // 8) * 8) * (-(-wo // 16) * 16) / float(ho * wo)          # 8x16-pixel units over the map (1.28 / 1.71 at VGA)
-        if (fx & 1025) == 1025:      # the stride-2 layers in the fp16-pair arithmetic (conv_bx64s2x_kernel: three MFMAs per product)
-            add(100 + ci[n_], f"conv_bx64s2x_kernel<{cout // 64}> ({n_}, stride 2)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), fl, fl * 3 * pad, PEAK_BF16_TFLOPS, pipe64)
-        else:
-            add(100 + ci[n_], f"conv_bx64s2_kernel<{cout // 64}> ({n_}, stride 2)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), fl, fl * 6 * pad, PEAK_BF16_TFLOPS,
-                "bf16 mfma x6 (fp32-equivalent)")
-    units16 = B * (-(-(H // 16) // 8)) * (-(-(W // 16) // 16))          # half-tile units of conv_bx64_kernel at 1/16 scale (api.hip: big_map)
-    for n_, ch, sc in (("block4.1", 64, "16"), ("block4.2", 64, "16"), ("block5.1", 128, "32")):
-        fl = conv_flops(n_, px[sc])
-        if ch == 64 and rs_plain:
-            add(100 + ci[n_], f"conv_rs64_kernel<0> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
-        elif ch == 128 and rs_128:
-            add(100 + ci[n_], f"conv_rs64_kernel<0, 128> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
-        elif ch == 64 and (fx & 1) and units16 >= 768:      # the 64 -> 64 layers at 1/16 scale join the fp16-pair split kernel when the batch fills its grid
-            add(100 + ci[n_], f"conv_bx64_kernel<64,0> ({n_})", 4.0 * 2 * ch * px[sc], fl, fl * 3, PEAK_BF16_TFLOPS, pipe64)
-        else:
-            add(100 + ci[n_], f"conv_wino_kernel ({n_})", 4.0 * 2 * ch * px[sc], fl, fl / 2.25, f32, "f32 mfma, Winograd F(2x2,3x3)")
-    fl3, fl1 = conv_flops("block5.2", px["32"]), conv_flops("block5.3", px["32"])
-    if rs_128:      # block5.2 on the 128-channel form, block5.3 as a 1x1 of its own (two spans: the 3x3's and the 1x1's)
-        add(100 + ci["block5.2"], "conv_rs64_kernel<0, 128> (block5.2)", 4.0 * 2 * 128 * px["32"], fl3, fl3 * 3, PEAK_BF16_TFLOPS, pipe64)
-        add(100 + ci["block5.3"], "conv_mfma_kernel<128,64,1x1> (block5.3)", 4.0 * (128 + 64) * px["32"], fl1, fl1, f32, "f32 mfma")
-    else:
-        add(100 + ci["block5.2"], "conv_wino_kernel (block5.2 + block5.3)", 4.0 * (128 + 64) * px["32"], fl3 + fl1, fl3 / 2.25 + fl1, f32, "f32 mfma, Winograd F(2x2,3x3)")
+        conv_row(n_, f"conv_bx64s2x_kernel<{cout // 64}> ({n_}, stride 2)", 4.0 * (cin * px[sc_in] + cout * px[sc_out]), conv_flops(n_, px[sc_out]), 3 * pad, c64)
+    for n_, ch, sc in (("block4.1", 64, "16"), ("block4.2", 64, "16"), ("block5.1", 128, "32"), ("block5.2", 128, "32")):
+        conv_row(n_, f"conv_rs64_kernel<0{', 128' if ch == 128 else ''}> ({n_})", 4.0 * 2 * ch * px[sc], conv_flops(n_, px[sc]), 3, c64)
+    fl1 = conv_flops("block5.3", px["32"])
+    add(100 + ci["block5.3"], "conv_mfma_kernel<128,64,1x1> (block5.3)", 4.0 * (128 + 64) * px["32"], fl1, fl1, f32, F32P)
     add(201, "pyramid_sum_kernel (x3 + up(x4) + up(x5))", 4.0 * 64 * (2 * px["8"] + px["16"] + px["32"]), 3.0 * 64 * px["8"], 3.0 * 64 * px["8"], 0, "valu")
-    fl = 2.0 * (2 * 64 * 64 + 64) * px["8"]
-    hk = {0: "head_bx_kernel", 1: "head_fused_kernel", 2: "head_f32r_kernel", 3: "head_f32r_kernel (dustbin on the matrix cores)"}[heads_f32]
-    last = 64 if heads_f32 == 2 or (heads_f32 == 0 and fx & 8) else 96      # outputs of the last key-point layer that run on the matrix cores (the dustbin logit is a vector dot product in those forms)
-    if heads_f32:      # (default) the heads on f32 MFMAs: executed = algorithmic FLOPs (+ the 65 -> 96 padding of the last key-point layer where it is still there) against the f32 peak
-        add(202, f"{hk}<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl, fl, f32, "f32 mfma")
-        fl = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
-        add(203, f"{hk}<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * last) * px["8"], f32, "f32 mfma")
+    fl_rel = 2.0 * (2 * 64 * 64 + 64) * px["8"]
+    fl_kp = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
+    fl_kp_mx = 2.0 * (3 * 64 * 64 + 64 * 64) * px["8"]      # (the dustbin logit is a vector dot product)
+    if fx & 8:
+        add(202, "head_bx_kernel<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl_rel, fl_rel * 3, PEAK_F16_TFLOPS, PAIR)
+        add(203, "head_bx_kernel<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl_kp, fl_kp_mx * 3, PEAK_F16_TFLOPS, PAIR)
     else:
-        nmh = 3 if fx & 8 else 6
-        pipeh = "fp16 mfma x3 (fp16 pair, fp32-equivalent)" if fx & 8 else "bf16 mfma x6 (fp32-equivalent)"
-        add(202, f"{hk}<false> (heatmap_head + 1/|feats|)", 4.0 * (64 + 2) * px["8"], fl, fl * nmh, PEAK_BF16_TFLOPS, pipeh)
-        fl = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
-        add(203, f"{hk}<true> (keypoint_head + softmax + depth-to-space)", 4.0 * 2 * px["1"], fl, 2.0 * (3 * 64 * 64 + 64 * last) * px["8"] * nmh, PEAK_BF16_TFLOPS, pipeh)
+        add(202, "head_f32r_kernel<false> (heatmap_head + 1/|feats|; fp32-range fallback)", 4.0 * (64 + 2) * px["8"], fl_rel, fl_rel, f32, F32P)
+        add(203, "head_f32r_kernel<true> (keypoint_head + softmax + depth-to-space; fp32-range fallback)", 4.0 * 2 * px["1"], fl_kp, fl_kp_mx, f32, F32P)
     add(210, "nms_flags_kernel", 4.0 * px["1"] + px["1"] / 8, 25.0 * px["1"], 25.0 * px["1"], 0, "valu")
     add(211, "nms_compact_kernel", px["1"] / 8 + 4.0 * px["1"] / 64, 0, 0, 0, "latency")
     add(212, "topk_sort_runs + topk_rank_merge", 4.0 * 3 * B * 2 * n_kpts, 0, 0, 0, "lds sort / latency")
@@ -278,7 +252,7 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=3, heads_f32=2, block
     mm = 2.0 * P * n_kpts * n_kpts * 64
     add(220, "match: memset of keys / maxima", 8.0 * 2 * P * n_kpts + 4.0 * P * n_kpts, 0, 0, 0, "hbm")
     maxima = MATCH_MAXIMA_BYTES_PER_ENTRY * 2 * P * n_kpts * (n_kpts / 32)      # R (P, N2/32, N1) + C (P, N1/32, N2): written by the sweep, read by the refine's scan
-    add(222, "mnn_f16_sweep_kernel (both tile orientations)", 2.0 * 2 * P * n_kpts * 64, mm, 2 * mm, PEAK_BF16_TFLOPS, "fp16 mfma (filter)", design_bytes=maxima)
+    add(222, "mnn_f16_sweep_kernel (both tile orientations)", 2.0 * 2 * P * n_kpts * 64, mm, 2 * mm, PEAK_F16_TFLOPS, "fp16 mfma (filter)", design_bytes=maxima)
     add(223, "mnn_f16_thr_row + mnn_f16_refine_kernel (scan of the block maxima, exact fp32 blocks on f32 mfma)", 4.0 * 2 * P * n_kpts * 64, 0,
         2.0 * 2 * P * n_kpts * 1.07 * 32 * 64, f32, "latency + f32 mfma", design_bytes=maxima)
     add(224, "mnn_finalize_kernel", 8.0 * 2 * P * n_kpts + 16.0 * P * n_kpts, 0, 0, 0, "latency")
@@ -415,9 +389,7 @@ def bench_dense(args, xf, rank, world, dist):
             "config": {"workload": "match_xfeat_star semi-dense on 1024x1024 pairs, batch=32 pairs per GPU (BASELINE configs[2])",
                        "pairs_per_gpu": P, "top_k": TOP_K, "pair": "image + 0.005*noise (see bench_dense)",
                        "mean_refined_matches": round(float(np.mean([len(r) for r in res])), 1)}}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    close_group(dist)
 
 
 def bench_lighterglue(args, xf, rank, world, dist):
@@ -479,9 +451,7 @@ def bench_lighterglue(args, xf, rank, world, dist):
                                                                                                prune=True, prune_min_kpts=lg.prune_min_kpts),
                                              "frames/s", 2, f"oracle LighterGlue on one pair of {n0} x {n1} key-points; extraction excluded")
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    close_group(dist)
 
 
 def bench_megadepth(args, xf, rank, world, dist):
@@ -533,10 +503,8 @@ def bench_megadepth(args, xf, rank, world, dist):
                                    "(BASELINE configs[3]); one step = all 1500 pairs",
                        "pairs": len(sizes), "pairs_this_rank": hi - lo, "distinct_size_pairs": n_distinct, "megapixels_per_pass": round(mpix, 1),
                        "top_k": TOP_K, "input": "uint8 tensors in HBM", "mean_matches_rank0": round(float(np.mean([len(r[0]) for r in res])), 1),
-                       "parallelism": f"pairs sharded x{world}, no collective"}}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+                       "parallelism": f"pairs sharded x{world}, no collective", "barrier": getattr(args, "barrier_name", None)}}))
+    close_group(dist)
 
 
 def bench_demo(args, xf, rank, world, dist):
@@ -607,23 +575,40 @@ def bench_demo(args, xf, rank, world, dist):
                        "mean_matches": round(nm, 1), "mean_inliers": round(float(info[:, 3].mean()), 1), "found": int(info[:, 0].sum()),
                        "mean_loop_iterations": round(float(info[:, 2].mean()), 1), "max_abs_H_error_vs_true_shift": round(err, 4),
                        "latency_one_stream_ms": round(1e3 * lat1, 3)}}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    close_group(dist)
 
 
 def launch_selftest(args, rank, world):
     """The rank side of `python bench.py --gpus N --launch-selftest` (no GPU touched): the same rendezvous, barrier / exactly-K-steps /
     max-over-ranks protocol and one-line report as the real run, with gloo and a sleep; rank 0 prints n_gpus = the world size it sees."""
-    dist = sharding.init_process_group("gloo", rank, world) if world > 1 else None
+    dist, note = (None, None)
+    if world > 1:      # the same bring-up as the real run (open_group: probe, agreement through files, fallback), with gloo in RCCL's place
+        dist, note = sharding.open_group("gloo", rank, world, None, probe_timeout_s=15.0 if "XFH_TEST_FAIL_COLLECTIVE" in os.environ else 60.0, force_host=args.barrier == "host",
+                                         fail_probe=os.environ.get("XFH_TEST_FAIL_COLLECTIVE") == str(rank))
     secs, last = sharding.timed_steps(lambda: time.sleep(0.01 * (rank + 1)) or rank, args.steps, args.warmup, dist, None, "cpu")
     if rank == 0:
         print(json.dumps({"metric": "launch self-test (no GPU work)", "value": round(sharding.aggregate_rate(1, args.steps, world, secs, "weak"), 3), "unit": "steps/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * secs / args.steps, 3), "selftest": True, "scaling": "weak",
+                          "barrier": barrier_name(dist, note, "gloo"),
                           "config": {"workload": "sleep of 10 ms x (rank + 1) per step", "units_per_rank_per_step": 1}}))
-    if dist is not None:
-        sharding.sync_barrier(dist)
-        dist.destroy_process_group()
+    close_group(dist)
+
+
+def barrier_name(dist, note, backend):
+    """what synchronised the ranks of this run: the collective backend, or the host-side file barrier and why"""
+    if dist is None:
+        return "none (one rank)"
+    return f"file ({note})" if isinstance(dist, sharding.HostGroup) else backend
+
+
+def close_group(dist):
+    if dist is None:
+        return
+    sharding.sync_barrier(dist)
+    dist.destroy_process_group()
+    if getattr(dist, "abandoned_backend", False):      # a collective library that never came up may hang in its own teardown: the line is out, leave
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 def main():
@@ -643,6 +628,9 @@ def main():
                     help="sparse = BASELINE configs[1] (the contract metric); dense = configs[2], match_xfeat_star on 1024^2 pairs, batch 32; "
                          "megadepth = configs[3], the MegaDepth-1500 pair list sharded across the GPUs; lighterglue = configs[4]; "
                          "demo = the reference demo's per-frame step (cached reference, match, MAGSAC++ homography; SURVEY 8f f4)")
+    ap.add_argument("--barrier", default="rccl", choices=["rccl", "host"],
+                    help="what synchronises the ranks of --gpus N > 1 (start / stop barrier, max-over-ranks time; the data path has no collective): rccl (default; if its bring-up "
+                         "fails or hangs on any rank, every rank falls back to the host-side file barrier and the line says so) or host (accelerated_features_amd.sharding.HostGroup)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="CPU self-test of the multi-rank launch path (tests/test_sharding_gloo.py): gloo instead of RCCL, a sleep instead of the hot path")
     args = ap.parse_args()
@@ -664,9 +652,12 @@ def main():
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
-    dist = None
+    dist, group_note = None, None
     if world > 1 or os.environ.get("XFH_BENCH_FORCE_DIST") == "1":      # (the env switch exercises the RCCL path with one rank)
-        dist = sharding.init_process_group("nccl", rank, world)      # backend "nccl" IS RCCL on ROCm
+        dist, group_note = sharding.open_group("nccl", rank, world, torch.device("cuda", local_rank), force_host=args.barrier == "host")      # backend "nccl" IS RCCL on ROCm
+        if rank == 0 and group_note:
+            print(f"# {group_note}", file=sys.stderr, flush=True)
+    args.barrier_name = barrier_name(dist, group_note, "rccl")
 
     import fixtures
     from accelerated_features_amd import XFeat, _lib
@@ -895,9 +886,9 @@ def main():
     if rank == 0:
         n_valid = counts[:B].tolist()
         n_match = counts[2 * B:].tolist()
-        opt_fx, opt_heads, opt_b1 = C.c_int(), C.c_int(), C.c_int()
-        lib.xfh_get_option(handle, b"fx", C.byref(opt_fx)); lib.xfh_get_option(handle, b"heads_f32", C.byref(opt_heads)); lib.xfh_get_option(handle, b"block1", C.byref(opt_b1))
-        k_rows, k_sum = kernel_roofline_table(spans_us, B, B // 2, fx=opt_fx.value, heads_f32=opt_heads.value, block1=opt_b1.value)
+        opt_fx, opt_b1 = C.c_int(), C.c_int()
+        lib.xfh_get_option(handle, b"fx", C.byref(opt_fx)); lib.xfh_get_option(handle, b"block1", C.byref(opt_b1))
+        k_rows, k_sum = kernel_roofline_table(spans_us, B, B // 2, fx=opt_fx.value, block1=opt_b1.value)
         achieved = (fl / 1e12) / (ms / 1e3) if ms > 0 else 0.0
         fps = sharding.aggregate_rate(B, args.steps, world, dt_max, "weak")
         fps_gpu = fps / world
@@ -920,23 +911,26 @@ def main():
                                    "the 32 consecutive frame pairs (BASELINE configs[1])",
                        "batch_per_gpu": B, "height": H, "width": W, "top_k": TOP_K, "weights": "synthetic (tests/fixtures.py)",
                        "arithmetic": "fp32 results; the 24-, 64- and 128-channel 3x3 convolutions, block1.2/.3 and both heads on fp16 MFMAs with an fp16 PAIR per operand "
-                                     "(x = xh + 2^-11 xl: three MFMAs per product, error <= an fp32 direct convolution's; range-guarded, bf16 three-way split / f32 MFMA as fallback); "
+                                     "(x = xh + 2^-11 xl: three MFMAs per product, error <= an fp32 direct convolution's; range-guarded, the f32-MFMA / vector-ALU kernels as fallback); "
                                      "the matcher decides on exact fp32 dot products (fp16 MFMAs only pre-select 32-wide blocks inside a derived error window)",
                        "parallelism": f"replicas x{world}, no collective; {lanes} batches in flight per GPU (FrameStream), "
                                       + ("a HIP stream per lane" if conc else "all lanes on one HIP stream"),
+                       "barrier": args.barrier_name,
                        "concurrent_lanes": conc,
                        "lanes": lanes,
                        "untimed_before_the_timed_region": f"GPU wake-up ({n_wake} steps: windows of {args.steps} until two agree within 1 %, >= {args.wake_ms:.0f} ms; a cold GPU runs its first ~150 ms 3-4 % slow), then the W warm-up steps",
                        "wake_up_window_fps": [round(r, 1) for r in wake_rates],
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
             # block1 x4 + skip1 in one kernel: fp32 FMA work on the vector ALUs (v_pk_fma_f32), LDS-tiled.  Neither HBM nor the matrix
-            # cores bound it (1 -> 4 -> 8 -> 8 -> 24 channels: no K for an MFMA); it is priced against the dense fp32 rate of the chip,
-            # which is the same 157.3 TFLOP/s for the packed vector FMA and for the f32 MFMA.
-            "roofline": {"bound": "mfma", "kernel": ("block1_fused_kernel (block1.0-.3 + skip1 fused: 3x3 convs 1->4, 4->8 s2, 8->8, 8->24 s2 on v_pk_fma_f32, "
-                                                     "LDS-tiled; one launch per step; 'mfma' = the dense fp32 peak, shared by the packed vector FMA)") if opt_b1.value < 6 else
-                                                    (f"block1_mx_kernel<{opt_b1.value}> (block1.0-.3 + skip1 fused, LDS-tiled, one launch per step: 1->4 and 4->8 s2 on v_pk_fma_f32, "
-                                                     f"{'8->8 and ' if opt_b1.value >= 7 else ''}8->24 s2 on v_mfma_f32_16x16x32_f16 in the fp16-pair arithmetic = fp32 results; priced as before: "
-                                                     "algorithmic fp32 FLOPs against the dense fp32 peak)"),
+            # cores bound it: its vector stages (conv1 recomputed inside conv2: DESIGN 3.2) do; it is priced against the dense fp32 rate of the chip,
+            # which is the same 157.3 TFLOP/s for the packed vector FMA and for the f32 MFMA.  The contract's "bound" takes "hbm" | "mfma": "mfma" here names that dense
+            # fp32 peak; "bound_detail" says which pipe it is.
+            "roofline": {"bound": "mfma", "bound_detail": "fp32 valu (v_pk_fma_f32) + fp16 mfma x3" if opt_b1.value == 7 else "fp32 valu (v_pk_fma_f32)",
+                         "kernel": ("block1_fused_kernel (block1.0-.3 + skip1 fused: 3x3 convs 1->4, 4->8 s2, 8->8, 8->24 s2 on v_pk_fma_f32, "
+                                    "LDS-tiled; one launch per step)") if opt_b1.value != 7 else
+                                   ("block1_mx_kernel (block1.0-.3 + skip1 fused, LDS-tiled, one launch per step: 1->4 and 4->8 s2 on v_pk_fma_f32, "
+                                    "8->8 and 8->24 s2 on v_mfma_f32_16x16x32_f16 in the fp16-pair arithmetic = fp32 results; priced as in every round: "
+                                    "algorithmic fp32 FLOPs against the dense fp32 peak)"),
                          # frac / achieved / avg_launch_us: the kernel with the chip to itself (single-lane pass of this run, HIP events on the launch stream = rocprofv3's
                          # per-dispatch duration in profiles/*_kernel_stats_1lane.csv) -- the figure that speaks about the kernel, comparable across rounds.  in_situ: the same
                          # launch inside the timed region, where with two lanes it shares the chip with the other lane's kernels (profiles/*_kernel_stats.csv)
@@ -957,21 +951,21 @@ def main():
                                "us_per_step": round(1e3 * m_ms / 3, 1), "algorithmic_f32_tflops": round((m_fl / 1e12) / (m_ms / 1e3), 2) if m_ms > 0 else None,
                                "executed": "2 x 2*P*N1*N2*64 FLOP on v_mfma_f32_32x32x16_f16 (one sweep, both orientations of every tile) + 32 exact fp32 similarities per flagged block",
                                # (m_fl = the algorithmic FLOPs of the 3 steps of the side pass; spans_us = us per ONE step)
-                               "executed_f16_tflops_sweep": round((2 * (m_fl / 3) / 1e12) / (spans_us.get(222, 0) / 1e6), 1) if spans_us.get(222) else None, "peak_f16_tflops": PEAK_BF16_TFLOPS,
+                               "executed_f16_tflops_sweep": round((2 * (m_fl / 3) / 1e12) / (spans_us.get(222, 0) / 1e6), 1) if spans_us.get(222) else None, "peak_f16_tflops": PEAK_F16_TFLOPS,
                                # the matcher's algorithmic floor: ONE fp16 GEMM per pair (2*N1*N2*64 FLOP) at the 2.5 PF peak, against everything xfh_match_mnn launches
-                               "floor_algorithmic_us": round((m_fl / 3) / PEAK_BF16_TFLOPS / 1e6, 1),
-                               "frac_algorithmic": round(((m_fl / 3) / PEAK_BF16_TFLOPS / 1e6) / (1e3 * m_ms / 3), 3) if m_ms > 0 else None},
-            # the two 24 -> 24 convolutions (round 1-2a: the dominant kernel as Winograd on f32 MFMAs, 2 x 151 us): bf16 MFMAs on three-way
-            # split operands, fp32-equivalent results.  "achieved" prices the ALGORITHMIC fp32 work against the f32 MFMA peak.
+                               "floor_algorithmic_us": round((m_fl / 3) / PEAK_F16_TFLOPS / 1e6, 1),
+                               "frac_algorithmic": round(((m_fl / 3) / PEAK_F16_TFLOPS / 1e6) / (1e3 * m_ms / 3), 3) if m_ms > 0 else None},
+            # the two 24 -> 24 convolutions on the fp16 matrix cores (fp16-pair arithmetic, fp32-equivalent results).  "achieved" prices the ALGORITHMIC fp32 work
+            # against the f32 MFMA peak (comparable across rounds), "executed_f16_tflops" the three MFMAs per product (+ channel padding) against the fp16 peak.
             "roofline_conv24": {"bound": "mfma", "kernel": "conv_bx_kernel<24,24> (block2.0 / block2.1 on v_mfma_f32_32x32x16_f16, three MFMAs per K = 16: fp16-pair arithmetic)",
                                 "us_per_step": round(1e3 * b_ms / 3, 1), "launches_per_step": 2,
                                 "achieved": round((b_fl / 1e12) / (b_ms / 1e3), 2) if b_ms > 0 else None, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                                "executed_f16_tflops": round((b_fl * (3 if opt_fx.value & 2 else 6) * (32 / 24) * (224 / 216) / 1e12) / (b_ms / 1e3), 1) if b_ms > 0 else None,
+                                "executed_f16_tflops": round((b_fl * 3 * (32 / 24) * (224 / 216) / 1e12) / (b_ms / 1e3), 1) if b_ms > 0 and opt_fx.value & 2 else None,
                                 "peak_f16_tflops": 2500.0},
             # Whole path.  frac: against the roofline of the INSTRUCTION MIX THAT SHIPS -- per kernel max(algorithmic bytes / 8 TB/s, executed FLOPs /
             # the peak of the pipe the kernel uses), summed (roofline_kernels) -- i.e. how close the kernels are to their own floors.
             # frac_vs_survey_roof: SURVEY 8(d)'s figure (direct fp32 convolutions at 157.3 TF + one f32 GEMM for the match = 26.9 us per frame): a
-            # bound the implementation has left behind (Winograd executes 2.25x fewer FLOPs, the split-bf16 and fp16 kernels run on a 16x faster pipe).
+            # bound the implementation has left behind (the fp16-pair kernels run on a 16x faster pipe at three MFMAs per product).
             # hbm_fraction: the north_star's bar (>= 0.8 of the HBM roofline on 78.6 MB per frame) -- NOT met: the path is compute-side bound.
             # frac_timed: the same sum of floors against the WALL time of a timed step (all lanes, host included): what the chip delivers per step.
             "roofline_path": {"frac": k_sum["frac"], "sum_of_kernel_floors_us_per_step": k_sum["sum_of_floors_us_per_step"], "kernels_us_per_step": k_sum["kernels_us_per_step"],
@@ -981,10 +975,13 @@ def main():
                               "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME, "algorithmic_flops_per_frame": ALGO_FLOPS_PER_FRAME,
                               "note": "per GPU; 78.6 MB and 2.622 + 1.074 GFLOP per frame (SURVEY 8d); at 8 TB/s the pure-HBM line is 102 k frames/s"},
             "roofline_kernels": k_rows,
-            "roofline_conv_family": {"bound": "mfma", "kernel": "conv_wino_kernel<...> + conv_mfma_kernel<...> + conv_bx_kernel<24,24> (all 12 MFMA conv launches per step; FLOPs of the "
-                                                                  "direct form -- the 3x3/s1 layers execute 2.25x fewer as Winograd F(2x2,3x3))",
-                                     "achieved": round((cfl / 1e12) / (cms / 1e3), 3) if cms > 0 else None,
-                                     "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+            # every MFMA convolution launch behind block1 (12 per step), priced like conv_family_roofline: the FLOPs the fp16-pair kernels EXECUTE (three fp16 MFMAs per
+            # product) against the fp16 MFMA peak, next to the algorithmic fp32 rate
+            "roofline_conv_family": {"bound": "mfma", "kernel": "conv_bx_kernel<24,24> x2, conv_bxs2_kernel<24>, conv_rs64_kernel (7 launches: 64 -> 64 and 128 -> 128 3x3, with and "
+                                                                  "without the fused 1x1), conv_bx64s2x_kernel x2, conv_mfma_kernel<128,64,1x1> -- fp16-pair arithmetic but for the 1x1",
+                                     "achieved": round(3 * (cfl / 1e12) / (cms / 1e3), 2) if cms > 0 else None, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": round(3 * (cfl / 1e12) / (cms / 1e3) / PEAK_F16_TFLOPS, 4) if cms > 0 else None,
+                                     "algorithmic_fp32_tflops": round((cfl / 1e12) / (cms / 1e3), 2) if cms > 0 else None,
                                      "us_per_step": round(1e3 * cms / 3, 1)},
         }
         if rep_fps:
@@ -998,9 +995,7 @@ def main():
         detail = {k: out.pop(k) for k in ("roofline_kernels", "roofline_conv_family", "roofline_conv24", "side_workloads") if k in out}
         print("# detail: " + json.dumps(detail), file=sys.stderr, flush=True)      # (stderr: stdout carries exactly one line, the contract's JSON line)
         print(json.dumps(out))
-    if dist is not None:
-        sharding.sync_barrier(dist)
-        dist.destroy_process_group()
+    close_group(dist)
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define XFH_VERSION 103          /* major*10000 + minor*100 + patch */
+#define XFH_VERSION 200          /* major*10000 + minor*100 + patch */
 
 enum {
     XFH_OK = 0,
@@ -85,45 +85,38 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
                         float scale_h, float scale_w, xfh_stream stream);
 
 /* ------------------------------------------------------------------------------------------
- * Kernel-variant switches of ONE handle (A/B measurements, variant-against-variant parity tests).  Results of every variant satisfy the
- * same parity contract; the defaults are the shipped path.  Not for concurrent use with calls on the same handle.
- *   "match_exact"   0 | 1   1: xfh_match_mnn computes every similarity on the f32 matrix cores (no fp16 filter)
- *   "wino"          0..2    3x3/s1 layers: 0 never Winograd, 1 unfused layers only, 2 (default) also the 3x3 + 1x1 pairs
- *   "bx"            bitmask split-bf16 MFMA convolutions: 1 the 24-channel layers, 2 64->64 on every map, 4 64->64 on large maps,
- *                           8 not block3.0, 16 the stride-2 64 -> 64 | 128 layers (block4.0, block5.0) (default 21)
- *   "heads_f32"     0..3    0 (default): the heads in the split-operand kernel head_bx_kernel -- with "fx" bit 8 (default) its fp16-pair form (clean under the cold-start torture
- *                           at every code position where the bf16 form fails: DESIGN 9.0, profiles/r05_scan_*); WITHOUT that bit the round-3 split-bf16 form, which is NOT safe
- *                           (one wrong 16-cell block of the heat map in 10^3 .. 10^5 launches whenever a workgroup's first tile runs on instruction-cache misses; A/B only).
- *                           2: both heads on f32 MFMAs (head_f32r_kernel: the range fallback of the fp16-pair arithmetic; 3 = its round-4 form), 1: the round-1 f32 kernels.
- *   "fx"            bitmask the fp16-pair arithmetic (x = xh + 2^-11 xl: three fp16 MFMAs per product instead of the six of the bf16 three-way split).
- *                           DEFAULT 3979 = 1 | 2 | 8 | 128 | 256 | 512 | 1024 | 2048.  0 = the bf16 three-way split everywhere (fp32's range: the fallback on XFH_STATUS_FX_RANGE).
- *                             1     the 64 -> 64 layers (master bit of 4, 64, 128, 256, 512, 1024)
- *                             2     the 24-channel layers (conv_bx_kernel, conv_bxs2_kernel)
- *                             4     (with 1) conv_bx64_kernel with two weight fragments in its stream            [opt-in: no gain measured]
- *                             8     the heads (with heads_f32 = 0);  + 16: two weight fragments in LDS, + 32: pixel-side fragments through LDS   [16, 32: opt-in]
- *                             64    (with 1) block_fusion.0 hands block_fusion.1 its output as fp16 pairs        [opt-in: no gain measured]
- *                             128   the unfused 64 -> 64 3x3 layers (block4.1, block4.2, block_fusion.0) on conv_rs64_kernel (weights resident in registers)
- *                             256   the 3x3 + 1x1 pairs (block3.1 + .2, block_fusion.1 + .2) on it too
- *                             512   block5.1 and block5.2 on its 128-channel form (block5.3 then runs as a 1x1 of its own)
- *                             1024  the stride-2 64-channel layers (block4.0, block5.0) on conv_bx64s2x_kernel
- *                             2048  (with 1) the fine_matcher's five linear layers (xfh_refine_matches, xfh_fine_matcher) as one chain in the fp16-pair arithmetic:
- *                                   linear_fx_kernel (first / last layer) and linear_fxd_kernel (the 512 -> 512 layers, LDS-DMA), the activations between them as
- *                                   fp16 pairs in the workspace (csrc/linear_fx_body.hpp); without the bit, or when a layer has a weight beyond the pair's range: f32 MFMAs
- *                           conv_rs64_kernel takes maps of any width (beyond 125 / 93 / 61 columns -- unfused / with the 1x1 / 128 channels -- as column strips).   (0..4095)
- *   "resize2"       0..1    DEFAULT 1.  The fused two-stage resize of the dual-scale dense path (xfh_backbone_resized): 1 = the tile's input region staged in LDS by
+ * Kernel switches of ONE handle.  Every layer has ONE default kernel and ONE fallback with fp32's range; the options choose between them (and two
+ * test switches).  Results of either choice satisfy the same parity contract; the defaults are the shipped path.  Not for concurrent use with calls
+ * on the same handle.
+ *   "fx"            bitmask of XFH_FX_*, DEFAULT XFH_FX_ALL.  A set bit runs that layer family in the fp16-pair arithmetic on the fp16 matrix cores
+ *                           (x = xh + 2^-11 xl, three fp16 MFMAs per product, fp32 accumulation: fp32-equivalent results for |x| < 65504, |w| < 31);
+ *                           a cleared bit runs it on the f32 matrix cores (v_mfma_f32_32x32x2_f32: fp32's range).  A layer with a weight beyond the pair's range
+ *                           runs on the f32 kernel whatever the bit says.
+ *                             XFH_FX_CONV64 (1)    the 64- and 128-channel 3x3 convolutions: conv_rs64_kernel (weights resident in registers; block3.1 + .2, block4.1,
+ *                                                  block4.2, block5.1, block5.2, block_fusion.0, block_fusion.1 + .2) and conv_bx64s2x_kernel (stride 2: block4.0, block5.0)
+ *                             XFH_FX_CONV24 (2)    the 24-channel 3x3 convolutions (block2.0, block2.1, block3.0): conv_bx_kernel, conv_bxs2_kernel
+ *                             XFH_FX_HEADS (8)     keypoint_head and heatmap_head: head_bx_kernel   (cleared: head_f32r_kernel)
+ *                             XFH_FX_FINE (2048)   the fine_matcher's five linear layers (xfh_refine_matches, xfh_fine_matcher) as one chain: linear_fx_kernel (first / last
+ *                                                  layer) and linear_fxd_kernel (the 512 -> 512 layers, LDS-DMA), the activations between them as fp16 pairs in the workspace
+ *                                                  (csrc/linear_fx_body.hpp)   (cleared: linear_mfma_kernel)
+ *                           Every other bit is rejected.
+ *   "block1"        5 | 7   DEFAULT 7: block1.2 (8 -> 8) and block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic (block1_mx_kernel);
+ *                           5: every layer of block1 on the vector ALUs (block1_fused_kernel: fp32's range).  Both recompute conv1 inside conv2 (no c1 tile in LDS).
+ *   "match_exact"   0 | 1   1: xfh_match_mnn computes every similarity on the f32 matrix cores (no fp16 filter): the kernel the default is tested against
+ *   "resize2"       0 | 1   DEFAULT 1.  The fused two-stage resize of the dual-scale dense path (xfh_backbone_resized): 1 = the tile's input region staged in LDS by
  *                           16-byte loads (needs Win % 4 == 0; otherwise, and with 0: four-byte gathers per tap).  Same bits either way.
- *   "block1"        0..7    DEFAULT 7.  0 / 5 = block1 on the vector ALUs (conv1 recomputed inside conv2, no c1 tile in LDS; the range fallback), 1 / 3 / 4 = earlier forms
- *                           writing a c1 tile; 6 = 5 with block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic, 7 = block1.2 (8 -> 8) too
- *                           (6 and 7 set XFH_STATUS_FX_RANGE like "fx")
+ * THE RANGE FALLBACK: on XFH_STATUS_FX_RANGE (below) repeat the call with fx = 0 and block1 = 5 -- every kernel then has fp32's range and none converts to fp16,
+ * so the status bit cannot be set again.
  * Every kernel choice the options leave open is made by the IMAGE's size, never by the batch size: an image's results do not depend on the batch it travels in.
  * xfh_set_option returns XFH_ERR_ARG for an unknown key or value; xfh_get_option writes the current value.
  * ---------------------------------------------------------------------------------------- */
+enum { XFH_FX_CONV64 = 1, XFH_FX_CONV24 = 2, XFH_FX_HEADS = 8, XFH_FX_FINE = 2048, XFH_FX_ALL = 1 | 2 | 8 | 2048 };
 int xfh_set_option(xfh_handle h, const char* key, int value);
 int xfh_get_option(xfh_handle h, const char* key, int* value);
 /* Status word of a handle's calls: a caller-owned DEVICE int32 (NULL = none) into which kernels OR status bits; the caller zeroes and reads it (e.g. with
  * the read-back of the key-point counts).  XFH_STATUS_FX_RANGE: a convolution in the fp16-pair arithmetic (option "fx") met an activation of magnitude
- * >= 65504, which the fp16 high part cannot hold -- the outputs of that call are not valid; repeat it with fx = 0 (the bf16 three-way split has fp32's range).
- * Set by xfh_backbone*, xfh_conv_layer.  The pointer is read at launch time; it may be changed between calls. */
+ * >= 65504, which the fp16 high part cannot hold -- the outputs of that call are not valid; repeat it with fx = 0 and block1 = 5 (the f32-MFMA / vector-ALU kernels have fp32's range).
+ * Set by xfh_backbone*, xfh_conv_layer, xfh_debug_block1, xfh_refine_matches, xfh_fine_matcher.  The pointer is read at launch time; it may be changed between calls. */
 enum { XFH_STATUS_FX_RANGE = 1 };
 int xfh_set_status_buffer(xfh_handle h, int32_t* device_word);
 
@@ -170,11 +163,11 @@ int xfh_backbone_resized(xfh_handle h, const float* img, int B, int C, int Hin, 
 /* One conv layer of the network in isolation (parity tests against per-layer oracle
  * activations).  layer = index into spec.CONVS; in (B,Cin,Hin,Win) NCHW, out (B,Cout,Hout,Wout)
  * NCHW with the layer's own stride/padding, folded BN and ReLU where the reference has them.
- * variant: 0 = the kernel the backbone uses for this layer, 1 = the generic direct kernel,
- * 10 = the split-bf16 kernel of the layer, 11 = the same kernel in the fp16-pair arithmetic, 12 = (64 -> 64 3x3/s1 layers, maps up to 125 columns) the fp16-pair kernel
- * with the weights resident in registers, 13 .. 16 = this 3x3 layer AND the 1x1 layer behind it in one launch (layers block3.1, block_fusion.1: out = the 1x1's output;
- * 13 / 14 = conv_rs64_kernel with NCHW / channels-last output, 15 / 16 = conv_bx64_kernel likewise), other values >= 2 = explicit Winograd
- * configurations of the 3x3/s1 layers (tuning; XFH_ERR_UNSUPPORTED elsewhere). */
+ * variant: XFH_CONV_VARIANT_*.  DEFAULT = the kernel the backbone uses for this layer under the handle's options; GENERIC = a plain direct convolution on the
+ * vector ALUs (any layer: the independent device-side check); FX = the layer's fp16-pair kernel and F32 = its f32-MFMA kernel, each without fallback
+ * (XFH_ERR_UNSUPPORTED where the layer has none); FX_PAIR / FX_PAIR_NHWC = this 3x3 layer AND the 1x1 layer behind it in one launch of conv_rs64_kernel
+ * (layers block3.1, block_fusion.1: out = the 1x1's output, NCHW / channels-last). */
+enum { XFH_CONV_VARIANT_DEFAULT = 0, XFH_CONV_VARIANT_GENERIC = 1, XFH_CONV_VARIANT_FX = 2, XFH_CONV_VARIANT_F32 = 3, XFH_CONV_VARIANT_FX_PAIR = 4, XFH_CONV_VARIANT_FX_PAIR_NHWC = 5 };
 int xfh_conv_layer(xfh_handle h, int layer, const float* in, int B, int Hin, int Win, float* out,
                    int variant, xfh_stream stream);
 
@@ -371,22 +364,15 @@ int xfh_profile_select(xfh_handle h, int which);
 int xfh_profile_read_spans(xfh_handle h, int* ids, double* ms, int capacity, int* n_spans);
 /* debug: 24 int64 s_memtime stamps per MFMA-conv workgroup are written to device_buffer (NULL = off) */
 int xfh_debug_trace(xfh_handle h, long long* device_buffer);
-/* debug (tools/head_soak.py): the key-point head alone, `iters` launches of kernel `variant` (0 = the split-bf16 kernel, 100 / 101 = the f32-MFMA kernels with an
- * activation tile / with register input; 1000 + s, 2000 + s, 3000 + s = the same three cold-started with the code moved by 4 s bytes, s = 0 .. 15), every result
- * compared on the device with heat_ref (and logits_ref); a report buffer holds {count, 0, 0, 0} followed by up to `cap` records {iteration, float4 index, bits got,
- * bits expected}.  img != NULL: gray / coef are computed from it first (part: B * 128 doubles of scratch). */
-int xfh_debug_head_soak(xfh_handle h, const float* img, int B, int C, int H, int W, float* gray, float* coef, double* part, float* heat,
-                        const float* heat_ref, float* logits, const float* logits_ref, int variant, int iters, int iter0, unsigned* rep_heat,
-                        unsigned* rep_logits, unsigned cap, xfh_stream stream);
 /* debug / torture (process-wide, not for production): with enable != 0 every matrix-core kernel of the backbone invalidates the instruction cache when a
- * workgroup starts, so that its first tile runs on instruction-fetch misses -- the condition under which the retired split-bf16 key-point head was found to
+ * workgroup starts, so that its first tile runs on instruction-fetch misses -- the condition under which round 3's split-bf16 key-point head (deleted in round 6) was found to
  * deliver a wrong 16-cell block; the concurrency / cold-start soaks of tests/test_gpu_parity.py, tools/final_soak.py and the code-position scan
  * (tools/bench_src/scan_probe.cpp) use it.
  * WHY THE HOOK SHIPS IN THE PRODUCTION LIBRARY instead of a debug build: the hazard it provokes depends on where a kernel's instructions lie relative to the
- * instruction-cache lines (3 of 16 code positions failed for the bf16 head).  Evidence gathered on a debug twin -- the same source compiled with another flag, i.e.
+ * instruction-cache lines (3 of 16 code positions failed for that head).  Evidence gathered on a debug twin -- the same source compiled with another flag, i.e.
  * other offsets -- would say nothing about the shipped bytes.  The in-suite soak and the scans therefore torture THE library that ships; the price is one scalar
  * compare at kernel entry (cold == 0: not taken) and this one process-wide int, which no product path writes.  The xfh_debug_* entry points that only probe
- * (head_soak, block1, trace, match_occupancy) are thin launchers of shipped kernels: they add no state. */
+ * (block1, trace, match_occupancy) are thin launchers of shipped kernels: they add no state. */
 int xfh_debug_cold_start(int enable);
 /* debug: block1 + skip1 alone in the form option "block1" selects: gray (B,H,W) raw gray image, coef (B,2) the per-image {alpha, beta} of the instance
  * normalisation (x -> alpha x + beta), x1 (B,24,H/4,W/4); H % 4 == W % 4 == 0.  For the variant-against-variant tests of tests/test_gpu_parity.py. */

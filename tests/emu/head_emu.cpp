@@ -1,4 +1,4 @@
-// head_bx_body<KP, FXM> (csrc/head_bx_body.hpp; fx = 0 .. 3) and head_f32r_body<KP> (csrc/head_f32r_body.hpp: the default heads; fx = -1) on the host.
+// head_bx_body<KP> (csrc/head_bx_body.hpp: the default heads, fp16-pair arithmetic; fx = 1) and head_f32r_body<KP> (csrc/head_f32r_body.hpp: the f32-MFMA fallback; fx = -1) on the host.
 // stdin: {kp, fx, B, H, W} int32 (REL: B = cells, H = W = 0), then
 //   KP : gray (B*H*W), coef (2B), w0..w2 (64x64 each), w3 (65x64), b0..b2 (64 each), b3 (65)         -> stdout heat (B*H*W), logits (cells*65), status
 //   REL: feats (cells*64), w0, w1 (64x64), w2 (64), b0, b1 (64), b2 (1)                               -> stdout reliability (cells), inv (cells), status
@@ -52,17 +52,18 @@ int main() {
         fwrite(&status, 4, 1, stdout);
         return 0;
     }
+    if (fx != 1) return 3;
     xfh::HeadBxArgs a{};
     a.status = &status;
     std::vector<uint16_t> wq;
     std::vector<float> bias;
     auto pack = [&](const std::vector<std::vector<float>>& ws, const std::vector<std::vector<float>>& bs, const std::vector<int>& couts) {
         size_t words = 0;
-        for (int c : couts) words += (size_t)4 * ((c + 31) / 32) * (fx == 2 ? 2 : 3) * 64 * 8;
+        for (int c : couts) words += (size_t)4 * ((c + 31) / 32) * 3 * 64 * 8;
         wq.assign(words, 0);
         uint16_t* dst = wq.data();
         for (size_t p = 0; p < couts.size(); ++p) {
-            dst += xfh::pack_head_layer(ws[p].data(), couts[p], p == 0, fx ? 1 : 0, dst, fx == 2 ? 2 : 3);
+            dst += xfh::pack_head_layer(ws[p].data(), couts[p], p == 0, dst);
             const int nb = (int)bs[p].size(), pad = 32 * ((nb + 31) / 32);          // (the bias table keeps the layout 64, 64, 64, 96)
             for (int o = 0; o < pad; ++o) bias.push_back(o < nb ? bs[p][o] : 0.f);
         }
@@ -72,18 +73,15 @@ int main() {
     if (kp) {
         auto gray = rd((size_t)B * H * W), coef = rd(2 * B);
         std::vector<std::vector<float>> ws = {rd(4096), rd(4096), rd(4096), rd(65 * 64)}, bs = {rd(64), rd(64), rd(64), rd(65)};
-        pack(ws, bs, {64, 64, 64, fx ? 64 : 65});          // (the fp16-pair forms take the dustbin logit as a dot product: w_dust / b_dust)
+        pack(ws, bs, {64, 64, 64, 64});          // (the dustbin logit is a dot product on the vector ALUs: w_dust / b_dust)
         a.w_dust = ws[3].data() + 64 * 64; a.b_dust = bs[3][64];
         a.src = gray.data(); a.coef = coef.data();
         a.H = H; a.W = W; a.hc = H / 8; a.wc = W / 8; a.ncell = B * a.hc * a.wc; a.ntiles = (a.ncell + 255) / 256;
         std::vector<float> heat((size_t)B * H * W, NAN), logits((size_t)a.ncell * 65, NAN);
         a.out = heat.data(); a.logits = logits.data();
-        const size_t lds = (size_t)(fx ? 8 : 9) * 4 * (fx == 2 ? 2 : 3) * 1024 + (288 + 64) * 4 + (fx == 3 ? 8 * 4096 : 0);
+        const size_t lds = (size_t)8 * 4 * 3 * 1024 + (288 + 64) * 4;
         const int grid = std::min(a.ntiles, 2);          // (persistent: each workgroup walks several tiles)
-        if (fx == 3) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, 3>(a); });
-        else if (fx == 2) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, 2>(a); });
-        else if (fx == 1) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, 1>(a); });
-        else emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true, 0>(a); });
+        emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<true>(a); });
         fwrite(heat.data(), 4, heat.size(), stdout);
         fwrite(logits.data(), 4, logits.size(), stdout);
     } else {
@@ -97,12 +95,9 @@ int main() {
         a.hc = 1; a.wc = 1; a.H = 8; a.W = 8; a.ncell = B; a.ntiles = (B + 255) / 256;
         std::vector<float> rel(B, NAN), inv(B, NAN);
         a.out = rel.data(); a.inv = inv.data();
-        const size_t lds = (size_t)2 * 2 * 4 * (fx == 2 ? 2 : 3) * 1024 + (128 + 64) * 4 + (fx == 3 ? 8 * 4096 : 0);
+        const size_t lds = (size_t)2 * 2 * 4 * 3 * 1024 + (128 + 64) * 4;
         const int grid = std::min(a.ntiles, 2);
-        if (fx == 3) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, 3>(a); });
-        else if (fx == 2) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, 2>(a); });
-        else if (fx == 1) emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, 1>(a); });
-        else emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false, 0>(a); });
+        emu::launch(grid, 512, lds, [&] { xfh::head_bx_body<false>(a); });
         fwrite(rel.data(), 4, rel.size(), stdout);
         fwrite(inv.data(), 4, inv.size(), stdout);
     }

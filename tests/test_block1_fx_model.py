@@ -1,4 +1,4 @@
-"""CPU model of block1's last convolution on the fp16 matrix cores (csrc/block1_fx.hpp, block1_fused_kernel<6>): the LDS layouts of the fp16-pair
+"""CPU model of block1's last convolution on the fp16 matrix cores (csrc/block1_fx.hpp, block1_mx_kernel): the LDS layouts of the fp16-pair
 activations and of the compact weight image, the lane -> address maps and the K order of v_mfma_f32_16x16x32_f16, restated in numpy and checked against a
 direct fp64 convolution; the host packer itself (the header compiled with g++) against the restatement, byte for byte."""
 import os
@@ -92,7 +92,7 @@ int main() {
     std::vector<float> w(72 * 24);
     if (fread(w.data(), 4, w.size(), stdin) != w.size()) return 1;
     std::vector<uint16_t> out(xfh::b1fx::W4_BYTES / 2);
-    xfh::b1fx::pack_w4(w.data(), out.data(), [](float v, uint16_t (&q)[3]) { xfh::split_weight(v, 1, q); });
+    xfh::b1fx::pack_w4(w.data(), out.data(), [](float v, uint16_t (&q)[3]) { xfh::split_weight(v, q); });
     fwrite(out.data(), 2, out.size(), stdout);
     return 0;
 }
@@ -217,7 +217,7 @@ int main() {
     std::vector<float> w(72 * 8);
     if (fread(w.data(), 4, w.size(), stdin) != w.size()) return 1;
     std::vector<uint16_t> out(xfh::b1fx::W3_IMAGE_BYTES / 2);
-    xfh::b1fx::pack_w3(w.data(), out.data(), [](float v, uint16_t (&q)[3]) { xfh::split_weight(v, 1, q); });
+    xfh::b1fx::pack_w3(w.data(), out.data(), [](float v, uint16_t (&q)[3]) { xfh::split_weight(v, q); });
     fwrite(out.data(), 2, out.size(), stdout);
     return 0;
 }

@@ -1,8 +1,8 @@
-"""The forms the round-4 probe points at as next defaults -- block1 with block1.2 / block1.3 on the fp16 matrix cores (mode 7), the fp16-pair key-point head -- END TO END against the
-reference-made goldens, without a GPU: the two kernel bodies run in the host emulation (tests/emu/) on the golden fixtures' images and weights, everything between and after
-them (block2 .. feats, reliability, NMS, scores, top-k, descriptors) is the oracle's fp32 restatement, and the resulting key-point lists are compared with what the UNMODIFIED
-reference wrote into tests/golden/ (g1_small: 2 x 256 key-points; g2_vga_pair: 2 x 4096 at VGA) by the GPU suite's own comparator.  The shipped forms (mode 5, the f32-MFMA
-head) run next to them as the control: a prepared form may not be further from the reference than the form that ships."""
+"""The shipped default kernels END TO END against the reference-made goldens, without a GPU: block1 with block1.2 / block1.3 on the fp16 matrix cores (mode 7), the fp16-pair
+heads and -- in the second test -- 16 of the 17 convolution layers run in the host emulation (tests/emu/) on the golden fixtures' images and weights, everything else (NMS, scores,
+top-k, descriptors; in the first test block2 .. feats too) is the oracle's fp32 restatement, and the resulting key-point lists are compared with what the UNMODIFIED
+reference wrote into tests/golden/ (g1_small: 2 x 256 key-points; g2_vga_pair: 2 x 4096 at VGA) by the GPU suite's own comparator.  The range fallback's forms (mode 5, the
+f32-MFMA head) run next to them as the control: the default may not be further from the reference than the fallback."""
 import os
 import subprocess
 import sys
@@ -34,7 +34,7 @@ def bins():
     if not os.path.exists(CLANG):
         pytest.skip("no host clang")
     td = tempfile.mkdtemp()
-    import test_kernels_emulated as sliced      # (the 24-channel kernels are still emulated as slices of k_conv_bx.hip on this branch)
+    import test_kernels_emulated as sliced      # (the 24-channel kernels are emulated as slices of k_conv_bx.hip)
     for fname, fn in (("conv_bx24_slice.hpp", sliced._slice_conv_bx24), ("weight_split_slice.hpp", sliced._slice_weight_split), ("bx_split_slice.hpp", sliced._slice_bx_split),
                       ("pyramid_slice.hpp", sliced._slice_pyramid), ("gray_slice.hpp", sliced._slice_gray)):
         open(os.path.join(td, fname), "w").write(fn())
@@ -125,22 +125,22 @@ def conv_emu(bins, kind, hdr, x, tensors, shape, cl=False, status=True):
     return y.view(shape[0], shape[2], shape[3], shape[1]).permute(0, 3, 1, 2).contiguous() if cl else y.view(shape)
 
 
-def rest_of_backbone_prepared(bins, sd, x1):
-    """block2 .. block_fusion.2 on the kernels this branch would route the bench batch to with every prepared form on (fx = 1 | 2 | 128 | 256 | 512 | 1024): the 24-channel
-    layers on conv_bx_kernel / conv_bxs2_kernel (shipped), every 64 -> 64 3x3 layer on conv_rs64_kernel (weights resident in registers; block3.1 + 3.2 and block_fusion.1 + .2
+def rest_of_backbone_emulated(bins, sd, x1):
+    """block2 .. block_fusion.2 on the kernels the backbone routes the bench batch to by default: the 24-channel
+    layers on conv_bx_kernel / conv_bxs2_kernel, every 64 -> 64 3x3 layer on conv_rs64_kernel (weights resident in registers; block3.1 + 3.2 and block_fusion.1 + .2
     with the trailing 1x1 fused, the latter channels-last), block5.1 / 5.2 on its 128-channel form, block4.0 / block5.0 on conv_bx64s2x_kernel -- 16 of the 17 convolution
     layers, pyramid_sum_kernel between them; block5.3 (a 1x1 of its own on the f32 matrix cores) stays with the oracle.  Every kernel's range flag must stay clear on the fixtures."""
     B, _, H4, W4 = x1.shape
     H8, W8, H16, W16, H32, W32 = H4 // 2, W4 // 2, H4 // 4, W4 // 4, H4 // 8, W4 // 8
-    a = conv_emu(bins, "conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], x1, list(fold(sd, "block2.0")), (B, 24, H4, W4))
-    a = conv_emu(bins, "conv_bx24_emu", [B, H4, W4, 1, 1, 1, 5], a, list(fold(sd, "block2.1")), (B, 24, H4, W4))
-    x3 = conv_emu(bins, "conv_bx24_emu", [B, H4, W4, 2, 1, 1, 5], a, list(fold(sd, "block3.0")), (B, 64, H8, W8))
+    a = conv_emu(bins, "conv_bx24_emu", [B, H4, W4, 1, 1, 5], x1, list(fold(sd, "block2.0")), (B, 24, H4, W4))
+    a = conv_emu(bins, "conv_bx24_emu", [B, H4, W4, 1, 1, 5], a, list(fold(sd, "block2.1")), (B, 24, H4, W4))
+    x3 = conv_emu(bins, "conv_bx24_emu", [B, H4, W4, 2, 1, 5], a, list(fold(sd, "block3.0")), (B, 64, H8, W8))
     w2, b2 = fold(sd, "block3.2")
     x3 = conv_emu(bins, "conv_rs64_emu", [B, H8, W8, 1, 3, 0, 1, 1], x3, list(fold(sd, "block3.1")) + [w2.view(64, 64), b2], (B, 64, H8, W8))
-    x4 = conv_emu(bins, "conv_bx64s2_emu", [B, H8, W8, 64, 1, 1, 3], x3, list(fold(sd, "block4.0")), (B, 64, H16, W16))
+    x4 = conv_emu(bins, "conv_bx64s2_emu", [B, H8, W8, 64, 1, 3], x3, list(fold(sd, "block4.0")), (B, 64, H16, W16))
     x4 = conv_emu(bins, "conv_rs64_emu", [B, H16, W16, 1, 3, 0, 0, 0], x4, list(fold(sd, "block4.1")), (B, 64, H16, W16))
     x4 = conv_emu(bins, "conv_rs64_emu", [B, H16, W16, 1, 2, 0, 0, 0], x4, list(fold(sd, "block4.2")), (B, 64, H16, W16))
-    x5 = conv_emu(bins, "conv_bx64s2_emu", [B, H16, W16, 128, 1, 1, 2], x4, list(fold(sd, "block5.0")), (B, 128, H32, W32))
+    x5 = conv_emu(bins, "conv_bx64s2_emu", [B, H16, W16, 128, 1, 2], x4, list(fold(sd, "block5.0")), (B, 128, H32, W32))
     x5 = conv_emu(bins, "conv_rs64_emu", [B, H32, W32, 1, 2, 0, 128, 0], x5, list(fold(sd, "block5.1")), (B, 128, H32, W32))
     x5 = conv_emu(bins, "conv_rs64_emu", [B, H32, W32, 1, 1, 0, 128, 0], x5, list(fold(sd, "block5.2")), (B, 128, H32, W32))
     x5 = O._basic(sd, "block5.3", x5, 1, 1)
@@ -151,7 +151,7 @@ def rest_of_backbone_prepared(bins, sd, x1):
 
 
 @pytest.mark.parametrize("which", ["g1_small", "g2_vga_pair"])
-def test_prepared_defaults_keep_the_references_key_points(bins, which):
+def test_default_block1_and_head_keep_the_references_key_points(bins, which):
     sd = fixtures.synthetic_state_dict(0)
     with torch.inference_mode():
         if which == "g1_small":
@@ -165,7 +165,7 @@ def test_prepared_defaults_keep_the_references_key_points(bins, which):
         _, _, _, taps = O.backbone(sd, x, keep=True)
         oheat = O.kpts_heatmap(taps["logits"])
         errs = {}
-        for tag, mode, fx in (("shipped", 5, -1), ("prepared", 7, 1)):
+        for tag, mode, fx in (("fallback", 5, -1), ("default", 7, 1)):
             x1 = run_block1(bins, sd, gray, coef, mode)
             heat = run_head(bins, sd, gray, coef, fx)
             feats, rel = rest_of_backbone(sd, x1)
@@ -183,12 +183,12 @@ def test_prepared_defaults_keep_the_references_key_points(bins, which):
                 assert rep.get("rank_moved", 0) <= 64 and rep.get("rank_moved_maxgap", 0.0) <= 5e-6, (tag, rep)      # (rank moves: only among scores a few ulps apart)
         print(which, errs)
         for k in ("x1", "feats", "rel", "heat"):
-            assert errs["prepared"][k] <= 1.5 * errs["shipped"][k] + 1e-6, (k, errs)      # no further from the reference than what ships
+            assert errs["default"][k] <= 1.5 * errs["fallback"][k] + 1e-6, (k, errs)      # no further from the reference than the fp32-range forms
 
 
 @pytest.mark.parametrize("which", ["g1_small", pytest.param("g2_vga_pair", marks=pytest.mark.skipif(not os.environ.get("XFH_EMU_VGA"), reason="minutes of emulation: XFH_EMU_VGA=1"))])
-def test_every_prepared_kernel_in_one_chain_keeps_the_references_key_points(bins, which):
-    """The whole prepared path at once: block1 mode 7, 16 of the 17 convolution layers on the kernels of rest_of_backbone_prepared, both heads in the fp16-pair form --
+def test_every_default_kernel_in_one_chain_keeps_the_references_key_points(bins, which):
+    """The whole default path at once: block1 mode 7, 16 of the 17 convolution layers on the kernels of rest_of_backbone_emulated, both heads in the fp16-pair form --
     the reference's key-point sets, no range flag on the fixtures' real weights and activations (a flag would send the model to the fallback and make the forms pointless)."""
     sd = fixtures.synthetic_state_dict(0)
     with torch.inference_mode():
@@ -206,11 +206,11 @@ def test_every_prepared_kernel_in_one_chain_keeps_the_references_key_points(bins
         _, _, _, taps = O.backbone(sd, x, keep=True)
         oheat = O.kpts_heatmap(taps["logits"])
         x1 = run_block1(bins, sd, gray, coef, 7)
-        feats = rest_of_backbone_prepared(bins, sd, x1)
+        feats = rest_of_backbone_emulated(bins, sd, x1)
         rel, heat = run_rel_head(bins, sd, feats, 1), run_head(bins, sd, gray, coef, 1)
         e = {"x1": float((x1 - taps["x1"]).abs().max()), "feats": float((feats - taps["feats"]).abs().max()),
              "rel": float((rel - taps["reliability"]).abs().max()), "heat": float((heat - oheat).abs().max())}
-        print(which, "every prepared form", e)
+        print(which, "every default kernel", e)
         assert e["x1"] <= 2e-5 and e["feats"] <= 1e-4 and e["rel"] <= 3e-5 and e["heat"] <= 1e-5, e
         for b, out in enumerate(detect(feats, heat, rel, top_k, H, W)):
             gd, t = dict(gold[b]), dict(out)

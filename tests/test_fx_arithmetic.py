@@ -1,4 +1,4 @@
-"""CPU restatement of the fp16-pair arithmetic of the split-operand convolutions (csrc/bx_split.hpp, api.hip: split_weight mode 1):
+"""CPU restatement of the fp16-pair arithmetic of the split-operand convolutions (csrc/bx_split.hpp, weight_split.hpp: split_weight):
 the identities and error bounds the kernels rely on, checked in numpy -- representation error of the pair, exactness of the partial products in an fp32
 accumulator, the error of a K = 576 product sum against fp64 next to an fp32 fma chain and the bf16 three-way split, the range limits the library guards.
 The constants are parsed from the sources, so a change there has to pass here."""
@@ -21,7 +21,7 @@ def pair(v):
 
 
 def weight_triple(w):
-    """w -> (q0, q1, q2): q0 = fp16(2^11 w), q1 = fp16(w), q2 = fp16(2^11 w - q0)  (api.hip: split_weight mode 1)."""
+    """w -> (q0, q1, q2): q0 = fp16(2^11 w), q1 = fp16(w), q2 = fp16(2^11 w - q0)  (weight_split.hpp: split_weight)."""
     w = np.asarray(w, np.float32)
     s = w * np.float32(2048.0)
     q0 = s.astype(np.float16).astype(np.float32)
@@ -107,12 +107,22 @@ def test_three_products_give_an_fp32_accurate_sum_more_accurate_than_six_bf16_on
 
 
 def test_python_option_table_mirrors_the_library():
-    """XFeatModel.OPTION_RANGES / DEFAULT_FX (host-side validation before a handle exists) against api.hip's option_slot table and kernels.hpp's defaults."""
+    """XFeatModel.OPTION_VALUES / DEFAULT_FX (host-side validation before a handle exists) against api.hip's option table, include/xfeat_hip.h's XFH_FX_* and kernels.hpp's defaults."""
     py = open(os.path.join(ROOT, "accelerated_features_amd", "xfeat.py")).read()
-    ranges = dict((k, (int(a), int(b))) for k, a, b in re.findall(r'"(\w+)": \((\d+), (\d+)\)', re.search(r"OPTION_RANGES = \{(.*?)\}", py).group(1)))
-    lib = dict((k, (int(a), int(b))) for k, a, b in re.findall(r'\{"(\w+)", &Options::\w+, (\d+), (\d+)\}', API))
-    assert ranges == lib and len(lib) >= 6
+    keys_py = set(re.findall(r'"(\w+)": lambda', re.search(r"OPTION_VALUES = \{(.*?)\}\n", py).group(1)))
+    keys_lib = set(re.findall(r'\{"(\w+)", &Options::\w+\}', API))
+    assert keys_py == keys_lib == {"match_exact", "block1", "fx", "resize2"}
+    hdr = open(os.path.join(ROOT, "include", "xfeat_hip.h")).read()
+    bits = {k: int(v) for k, v in re.findall(r"XFH_FX_(CONV64|CONV24|HEADS|FINE) = (\d+)", hdr)}
+    all_bits = bits["CONV64"] | bits["CONV24"] | bits["HEADS"] | bits["FINE"]
+    m = re.search(r"FX_CONV64, FX_CONV24, FX_HEADS, FX_FINE = (\d+), (\d+), (\d+), (\d+)", py)
+    assert [int(v) for v in m.groups()] == [bits["CONV64"], bits["CONV24"], bits["HEADS"], bits["FINE"]]
     hpp = open(os.path.join(ROOT, "accelerated_features_amd", "csrc", "kernels.hpp")).read()
-    assert int(re.search(r"int fx = (\d+);", hpp).group(1)) == int(re.search(r"DEFAULT_FX = (\d+)", py).group(1))
-    fx_default = int(re.search(r"int fx = (\d+);", hpp).group(1))
-    assert int(re.search(r"int heads_f32 = (\d+);", hpp).group(1)) >= 1 or fx_default & 8          # the split-bf16 heads are not the default (DESIGN 9.0): split heads only as fp16 pairs (fx bit 8)
+    assert eval(re.search(r"int fx = ([\d |]+);", hpp).group(1)) == all_bits
+    assert int(re.search(r"int block1 = (\d+);", hpp).group(1)) == int(re.search(r"DEFAULT_BLOCK1 = (\d+)", py).group(1)) == 7
+    from accelerated_features_amd.xfeat import XFeatModel, DEFAULT_FX
+    assert DEFAULT_FX == all_bits
+    ok = XFeatModel.OPTION_VALUES
+    assert ok["fx"](0) and ok["fx"](all_bits) and ok["fx"](bits["HEADS"]) and not ok["fx"](4) and not ok["fx"](all_bits | 128) and not ok["fx"](-1)
+    assert ok["block1"](5) and ok["block1"](7) and not ok["block1"](0) and not ok["block1"](6)
+    assert "heads_f32" not in ok and "wino" not in ok and "bx" not in ok

@@ -126,12 +126,14 @@ def test_backbone_intermediate_free_outputs_small(xf, sd):
     assert errs["rel_vs_oracle"] <= 1e-5 and errs["heat_vs_golden"] <= 1e-5, errs
 
 
-@pytest.mark.parametrize("opts", [{"heads_f32": 0, "fx": 3, "bx": 0, "block1": 1}, {"heads_f32": 2, "block1": 5, "fx": 3}, {"bx": 3, "block1": 3}, {"wino": 0}, {"block1": 4, "wino": 1}, {"fx": 0}, {"fx": 15, "bx": 23},
-                                  {"fx": 15, "heads_f32": 0}, {"heads_f32": 1}, {"heads_f32": 2}, {"heads_f32": 3}, {"block1": 6}, {"block1": 7}, {"fx": 7}, {"fx": 67}, {"fx": 131}, {"fx": 387}, {"fx": 899}, {"fx": 1027}, {"fx": 11, "heads_f32": 0}, {"fx": 27, "heads_f32": 0}, {"fx": 43, "heads_f32": 0}])
-def test_backbone_alternative_kernels_same_results(opts, sd):
-    """Per-handle variant switches (xfh_set_option) select other kernels for the same layers (heads on the split-bf16 kernels -- opt-in since round 4 --, 24->24
-    layers on Winograd; every unfused 64->64 layer on the split kernel; direct implicit GEMM instead of Winograd; block1 with a c1 tile; the split-operand
-    convolutions in the bf16 three-way split (fx = 0) or all of them in the fp16-pair arithmetic): the small golden backbone case on a model of its own with each setting."""
+FX_CONV64, FX_CONV24, FX_HEADS, FX_FINE = 1, 2, 8, 2048      # include/xfeat_hip.h: XFH_FX_*
+FX_ALL = FX_CONV64 | FX_CONV24 | FX_HEADS | FX_FINE
+
+
+@pytest.mark.parametrize("opts", [{"fx": 0, "block1": 5}, {"fx": 0}, {"block1": 5}, {"fx": FX_CONV64}, {"fx": FX_CONV24}, {"fx": FX_HEADS}, {"fx": FX_ALL & ~FX_CONV64}, {"fx": FX_ALL & ~FX_HEADS, "block1": 5}])
+def test_backbone_fallback_kernels_same_results(opts, sd):
+    """Per-handle switches (xfh_set_option) select, family by family, the fp32-range fallback instead of the fp16-pair default (the f32-MFMA convolutions and heads, block1 on the
+    vector ALUs; {"fx": 0, "block1": 5} = the range fallback as a whole): the small golden backbone case on a model of its own with each setting."""
     from accelerated_features_amd import XFeat
     g = np.load(os.path.join(G, "g1_small.npz"))
     xf2 = XFeat(weights=sd, top_k=4096)
@@ -146,13 +148,15 @@ def test_backbone_alternative_kernels_same_results(opts, sd):
     assert e[0] <= 1e-4 and e[1] <= 5e-4 and e[2] <= 1e-5 and e[3] <= 1e-5, (opts, e)
     with pytest.raises(Exception):
         xf2.set_option("no_such_option", 1)
-    with pytest.raises(Exception):
-        xf2.set_option("wino", 7)
+    for key, value in (("wino", 1), ("bx", 21), ("heads_f32", 0), ("block1", 6), ("fx", 4), ("fx", 3979)):      # (deleted in round 6: the library refuses them too)
+        with pytest.raises(Exception):
+            xf2.set_option(key, value)
+        assert _lib().load().xfh_set_option(xf2.net.handle(), key.encode(), value) != 0
 
 
-@pytest.mark.parametrize("mode", [5, 6, 7])
+@pytest.mark.parametrize("mode", [5, 7])
 def test_block1_forms_alone(sd, acts, mode):
-    """block1 + skip1 alone (xfh_debug_block1) in the shipped vector form (5), with block1.3 on the fp16 matrix cores (6) and with block1.2 there too (7; fp16-pair
+    """block1 + skip1 alone (xfh_debug_block1) in the vector form (5: the range fallback) and with block1.2 and block1.3 on the fp16 matrix cores (7: the default; fp16-pair
     arithmetic, csrc/block1_fx.hpp): against the oracle's x1 on its own normalised gray images, and form against form on shapes whose last tiles are partial
     (W / 4 = 88: five and a half 16-column tiles; H / 4 = 60: seven and a half 8-row tiles) -- with the position of the largest difference, for whoever has to debug it."""
     from accelerated_features_amd import XFeat
@@ -184,26 +188,25 @@ def test_block1_forms_alone(sd, acts, mode):
         a, b = run(m, g), run(ref, g)
         d = (a - b).abs().cpu()
         assert bool(torch.isfinite(a).all()) and float(d.max()) <= 2e-5 * max(1.0, float(b.abs().max())), (mode, (B, H, W), float(d.max()), where(d))
-    if mode >= 6:      # the range guard of the pair: activations beyond 65504 in c2 / c3 are reported
+    if mode == 7:      # the range guard of the pair: activations beyond 65504 in c2 / c3 are reported
         g = torch.randn(1, 64, 64, generator=torch.Generator().manual_seed(8)).cuda() * 1.0e7
         run(m, g)
         assert m.net.take_status() & 1
 
 
-def test_split_bf16_backbone_equals_f32_mfma_backbone_at_bench_shape(xf, sd):
-    """At the benchmark shape (B=64 VGA) the default path runs the 24-channel layers, the three 64 -> 64 layers at 1/8 scale (two of them with
-    their trailing 1x1 fused, one writing channels-last) and both heads on split-bf16 MFMAs.  Same network outputs as with every one of
-    them on the f32-MFMA kernels (a second model with bx = 0, heads_f32 = 1)."""
+def test_default_backbone_equals_fallback_backbone_at_bench_shape(xf, sd):
+    """At the benchmark shape (B=64 VGA) the default path runs every convolution from block1.2 on and both heads on the fp16 matrix cores in the fp16-pair arithmetic.  Same
+    network outputs as with every one of them on the fp32-range kernels (a second model with fx = 0, block1 = 5: the range fallback)."""
     from accelerated_features_amd import XFeat
     xr = XFeat(weights=sd, top_k=4096)
-    xr.set_option("bx", 0); xr.set_option("heads_f32", 1)
+    xr.set_option("fx", 0); xr.set_option("block1", 5)
     x = torch.cat([fixtures.texture_images(8, 480, 640, seed=s) for s in range(8)]).cuda()
     f_, l_, r_ = xr.net(x)
     ref = {"feats": f_[::8].cpu().numpy(), "logits": l_[::8].cpu().numpy(), "rel": r_.cpu().numpy()}
     del xr, f_, l_, r_
     xb = XFeat(weights=sd, top_k=4096)
-    xb.set_option("heads_f32", 0)                  # (the split-bf16 heads are opt-in since round 4: DESIGN 9.0)
     feats, logits, rel = xb.net(x)
+    assert xb.net.take_status() == 0
     e = {"feats": float(np.abs(feats[::8].cpu().numpy() - ref["feats"]).max()), "logits": float(np.abs(logits[::8].cpu().numpy() - ref["logits"]).max()),
          "rel": float(np.abs(rel.cpu().numpy() - ref["rel"]).max())}
     print(e, "feats absmax", float(np.abs(ref["feats"]).max()), "logits absmax", float(np.abs(ref["logits"]).max()))
@@ -420,7 +423,14 @@ def test_match_many_is_match_pair_by_pair(xf):
     x = torch.cat([fixtures.texture_images(4, 96, 160, seed=41), fixtures.texture_images(4, 96, 160, seed=41).roll((3, 5), (2, 3))]).cuda()
     res = xf.detectAndCompute(x, top_k=400)
     f1, f2 = [r["descriptors"] for r in res[0::2]], [r["descriptors"] for r in res[1::2]]
-    assert xf._strided_layout(f1, f2) is not None and xf._strided_layout(f1, f2)[4] is not None        # in place, with the fp16 copies
+    assert xf._strided_layout(f1, f2) is not None and xf._strided_layout(f1, f2)[4] is None        # in place; the fp16 filter copies are made from the rows as they are NOW
+    # ... so descriptors modified in place between detectAndCompute and match_many are matched AS MODIFIED (round 5 reused fp16 copies of the old rows)
+    keep0 = f1[0].clone()
+    f1[0].copy_(torch.nn.functional.normalize(torch.roll(f1[0], 7, dims=1) + 0.1, dim=-1))
+    want_mod = xf.match(f1[0], f2[0], min_cossim=-1)
+    got_mod = xf.match_many(f1, f2, min_cossim=-1)[0]
+    assert torch.equal(got_mod[0], want_mod[0]) and torch.equal(got_mod[1], want_mod[1])
+    f1[0].copy_(keep0)
     for mc in (-1, 0.82):
         want = [xf.match(a, b, min_cossim=mc) for a, b in zip(f1, f2)]
         for got in (xf.match_many(f1, f2, min_cossim=mc),                                              # in place
@@ -594,40 +604,46 @@ def test_repeated_backbone_and_sparse_path_bit_identical(xf):
             assert torch.equal(i0[p, :n0[p]], i00[p, :n0[p]]) and torch.equal(i1[p, :n0[p]], i10[p, :n0[p]]), (rep, p)
 
 
-def test_winograd_configurations_match_generic_kernel(xf):
-    """Every Winograd configuration of xfh_conv_layer (variants 2..6: workgroup shapes, 4/8 waves) against the
-    generic direct kernel, on odd / small / non-multiple-of-8 shapes (scalar-store path, clipped regions, B not a multiple of 8)."""
+V_DEFAULT, V_GENERIC, V_FX, V_F32, V_FX_PAIR, V_FX_PAIR_NHWC = 0, 1, 2, 3, 4, 5      # include/xfeat_hip.h: XFH_CONV_VARIANT_*
+
+
+def test_f32_mfma_fallback_kernels_match_generic_kernel(xf):
+    """The f32-MFMA kernel of every convolution layer (xfh_conv_layer variant F32: what the range fallback runs) against the generic direct kernel, on odd / small /
+    non-multiple-of-8 shapes (scalar-store path, clipped regions, B not a multiple of 8)."""
     from accelerated_features_amd.spec import CONVS, CONV_INDEX
     lib = _lib().load()
     h = xf.net.handle()
     g = torch.Generator(device="cuda").manual_seed(3)
     n_checked = 0
-    for name in ("block2.0", "block3.1", "block5.1"):
+    for name in ("block2.0", "block3.0", "block3.1", "block4.0", "block5.0", "block5.1", "block5.3"):
         c = next(c for c in CONVS if c.name == name)
         for (B, hh, ww) in ((3, 41, 41), (2, 60, 80), (9, 30, 40), (8, 15, 20), (1, 6, 10)):
             x = torch.randn(B, c.cin, hh, ww, device="cuda", generator=g)
-            ref = torch.empty(B, c.cout, hh, ww, device="cuda")
-            assert lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(ref.data_ptr()), 1, None) == 0
-            for variant in (0, 2, 3, 4, 5, 6):
+            ho, wo = (hh - 1) // c.stride + 1, (ww - 1) // c.stride + 1
+            ref = torch.empty(B, c.cout, ho, wo, device="cuda")
+            assert lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(ref.data_ptr()), V_GENERIC, None) == 0
+            for variant in (V_DEFAULT, V_F32):
                 y = torch.full_like(ref, float("nan"))
                 rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
                 assert rc == 0, (name, variant, lib.xfh_last_error())
                 err = float((y - ref).abs().nan_to_num(1e9).max())
                 assert err <= 2e-4, (name, (B, hh, ww), variant, err)
                 n_checked += 1
-    assert n_checked == 3 * 5 * 6
+    assert n_checked == 7 * 5 * 2
+    y = torch.empty(1, 24, 8, 8, device="cuda")
+    assert lib.xfh_conv_layer(h, CONV_INDEX["block2.0"], C.c_void_p(y.data_ptr()), 1, 8, 8, C.c_void_p(y.data_ptr()), 10, None) != 0      # (round 5's variant numbers are gone)
 
 
-def test_split_bf16_conv_is_fp32_accurate(xf, sd):
-    """The 24-channel 3x3 layers (stride 1 and 2) run on bf16 MFMAs with three-way split operands (k_conv_bx.hip, xfh_conv_layer variant 10): against an
-    fp64 convolution of the same folded weights the error must stay at the level of the fp32 direct kernel (variant 1), on odd / small /
-    clipped shapes, large magnitudes, and batches that are not a multiple of 8."""
+def test_fp16_pair_conv_is_fp32_accurate(xf, sd):
+    """The 3x3 layers from block2.0 on run on the fp16 matrix cores in the fp16-pair arithmetic (xfh_conv_layer variant FX: conv_bx_kernel / conv_bxs2_kernel, conv_rs64_kernel in
+    its 64- and 128-channel forms, conv_bx64s2x_kernel): against an fp64 convolution of the same folded weights the error must stay at the level of the fp32 direct kernel
+    (variant GENERIC) -- and of the f32-MFMA fallback kernel (variant F32) --, on odd / small / clipped shapes, large magnitudes, and batches that are not a multiple of 8."""
     from accelerated_features_amd.spec import CONVS, CONV_INDEX, BN_EPS
     lib = _lib().load()
     h = xf.net.handle()
     g = torch.Generator(device="cuda").manual_seed(5)
     n = 0
-    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1", "block4.0", "block5.0", "block5.1"):       # (block5.1: 128 -> 128, variants 1 and 12 only: conv_rs64_kernel's 128-channel form)       # block3.0: the 24-channel stride-2 kernel; block_fusion.0 / block4.1: conv_bx64_kernel; the last two: conv_bx64s2_kernel (64 / 128 couts)
+    for name in ("block2.0", "block2.1", "block3.0", "block_fusion.0", "block4.1", "block4.0", "block5.0", "block5.1"):
         c = next(c for c in CONVS if c.name == name)
         w = sd[f"{name}.layer.0.weight"].double().cuda()
         rm, rv = sd[f"{name}.layer.1.running_mean"].double().cuda(), sd[f"{name}.layer.1.running_var"].double().cuda()
@@ -639,56 +655,75 @@ def test_split_bf16_conv_is_fp32_accurate(xf, sd):
                 truth = torch.relu(torch.nn.functional.conv2d(x.double(), wf, bf, stride=c.stride, padding=1))
                 ref = float(truth.abs().max())
                 err = {}
-                if c.cin == 128:
-                    variants = (1, 12) if ww <= 61 else (1,)
-                    for variant in variants:
-                        y = torch.full(tuple(truth.shape), float("nan"), device="cuda")
-                        rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
-                        assert rc == 0, (name, variant, lib.xfh_last_error())
-                        err[variant] = float((y.double() - truth).abs().nan_to_num(1e9).max()) / ref
-                    if 12 in err:
-                        assert err[12] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
-                    n += 1
-                    continue
-                rs64 = c.stride == 1 and c.cin == 64 and ww <= 125         # 12: the fp16-pair kernel with the weights resident in registers (conv_rs64_kernel; maps up to 125 columns)
-                for variant in ((1, 10, 11, 12) if rs64 else (1, 10, 11)):      # (11 for the stride-2 64-channel layers: conv_bx64s2x_kernel)      # 11: the same kernel in the fp16-pair arithmetic (three MFMAs per product)
+                for variant in (V_GENERIC, V_FX, V_F32):
                     y = torch.full(tuple(truth.shape), float("nan"), device="cuda")
                     rc = lib.xfh_conv_layer(h, CONV_INDEX[name], C.c_void_p(x.data_ptr()), B, hh, ww, C.c_void_p(y.data_ptr()), variant, None)
+                    if rc != 0 and variant == V_FX and c.cin == 128 and ww > 61:
+                        continue                      # (conv_rs64_kernel's 128-channel form takes maps up to 61 columns; the backbone then runs the f32 kernel)
                     assert rc == 0, (name, variant, lib.xfh_last_error())
                     err[variant] = float((y.double() - truth).abs().nan_to_num(1e9).max()) / ref
-                assert err[10] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
-                for v in (11, 12):
-                    if v in err:
-                        assert err[v] <= max(2.0 * err[1], 1e-6), (name, (B, hh, ww), scale, err)
+                if V_FX in err:
+                    assert err[V_FX] <= max(2.0 * err[V_GENERIC], 1e-6), (name, (B, hh, ww), scale, err)
+                assert err[V_F32] <= max(4.0 * err[V_GENERIC], 5e-6), (name, (B, hh, ww), scale, err)      # (v_mfma_f32_32x32x2_f32 sums K in another order than the fma chain: a few ulps more)
                 n += 1
     assert n == 8 * 8 * 3
     assert xf.net.take_status() == 0                      # |x| stayed far below the fp16 range: no range report
 
 
+def test_weights_beyond_the_pair_range_run_on_the_f32_kernels(sd):
+    """A layer with a weight of magnitude >= 31 has no fp16-pair image (2^11 w would not be an fp16 number: xfh_create leaves it out) and must run on its fp32-range kernel
+    whatever the options say (the heads used to drop to a retired kernel there).  One oversized weight in each family -- a head layer, a 64-channel 3x3, a
+    24-channel 3x3, block1.3 -- on a model with the DEFAULT options: finite outputs equal to the oracle's within the usual tolerances (an fp16 image of such a weight holds
+    inf: the pair kernels would deliver NaN), no range flag; and xfh_conv_layer's FX variant refuses those layers instead of falling back silently."""
+    from accelerated_features_amd import XFeat
+    from accelerated_features_amd.spec import CONV_INDEX
+    lib = _lib().load()
+    x = fixtures.texture_images(2, 96, 128, seed=11)
+    for name in ("keypoint_head.1", "heatmap_head.0", "block3.1", "block4.0", "block5.1", "block2.1", "block1.3"):
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        w = sd2[f"{name}.layer.0.weight"]
+        sc = float(torch.sqrt(sd2[f"{name}.layer.1.running_var"][3] + 1e-5))
+        w[3, 5, w.shape[2] // 2, w.shape[3] // 2] = 40.0 * sc          # the FOLDED weight (BatchNorm scale applied) is 40
+        m = XFeat(weights=sd2, top_k=256)
+        feats, logits, rel = m.net(x.cuda())
+        of, ol, orl = O.backbone(sd2, x)
+        e = (float((feats.cpu() - of).abs().max()) / max(1.0, float(of.abs().max())), float((logits.cpu() - ol).abs().max()) / max(1.0, float(ol.abs().max())), float((rel.cpu() - orl).abs().max()))
+        print(name, e)
+        assert bool(torch.isfinite(feats).all() and torch.isfinite(logits).all() and torch.isfinite(rel).all()), name
+        assert e[0] <= 1e-4 and e[1] <= 1e-4 and e[2] <= 3e-5, (name, e)
+        assert m.net.take_status() == 0, name
+        if name.startswith("block") and name != "block1.3":
+            c = m.net.state_dict()[f"{name}.layer.0.weight"].shape
+            xin = torch.randn(1, c[1], 16, 24, device="cuda")
+            y = torch.empty(1, c[0], 16, 24, device="cuda")
+            assert lib.xfh_conv_layer(m.net.handle(), CONV_INDEX[name], C.c_void_p(xin.data_ptr()), 1, 16, 24, C.c_void_p(y.data_ptr()), V_FX, None) == -4, name      # XFH_ERR_UNSUPPORTED
+            assert lib.xfh_conv_layer(m.net.handle(), CONV_INDEX[name], C.c_void_p(xin.data_ptr()), 1, 16, 24, C.c_void_p(y.data_ptr()), V_DEFAULT, None) == 0, name
+
+
 def test_fp16_pair_arithmetic_reports_its_range_and_the_model_falls_back(sd):
     """The fp16-pair convolutions (option fx, the default) hold activations below 65504 only.  An input that drives a layer beyond that sets bit 0 of the
-    handle's status word (xfh_set_status_buffer); detectAndCompute then repeats the call on the bf16 three-way split (fp32's range) -- same results as a model
-    that ran the bf16 form from the start -- and the model stays there.  Small subnormal-range activations are exact in both."""
+    handle's status word (xfh_set_status_buffer); detectAndCompute then repeats the call on the fp32-range kernels (fx = 0, block1 = 5) -- same results as a model
+    that ran those from the start -- and the model stays there.  Small subnormal-range activations are exact in both."""
     import warnings
     from accelerated_features_amd import XFeat
-    from accelerated_features_amd.xfeat import DEFAULT_FX, DEFAULT_HEADS_F32, DEFAULT_BLOCK1
+    from accelerated_features_amd.xfeat import DEFAULT_FX, DEFAULT_BLOCK1
     from accelerated_features_amd.spec import CONV_INDEX
     lib = _lib().load()
     a, b = XFeat(weights=sd, top_k=512), XFeat(weights=sd, top_k=512)
     v = C.c_int(-1)
-    for key, mirror in ((b"fx", DEFAULT_FX), (b"heads_f32", DEFAULT_HEADS_F32), (b"block1", DEFAULT_BLOCK1)):      # the Python mirrors of the library defaults
+    for key, mirror in ((b"fx", DEFAULT_FX), (b"block1", DEFAULT_BLOCK1)):      # the Python mirrors of the library defaults
         assert lib.xfh_get_option(a.net.handle(), key, C.byref(v)) == 0 and v.value == mirror, (key, v.value, mirror)
-    b.set_option("fx", 0); b.set_option("heads_f32", DEFAULT_HEADS_F32 or 2); b.set_option("block1", 5)      # the fp32-range forms the fallback lands on
-    # (a) a single layer: 1e6-sized activations -> flag, and inf / nan in the fx output; the bf16 form is fine
+    b.set_option("fx", 0); b.set_option("block1", 5)      # the fp32-range kernels the fallback lands on
+    # (a) a single layer: 1e6-sized activations -> flag, and inf / nan in the fx output; the f32-MFMA kernel is fine
     x = torch.relu(torch.randn(2, 64, 24, 32, device="cuda")) * 3.0e5
     y = torch.empty(2, 64, 24, 32, device="cuda")
-    assert lib.xfh_conv_layer(a.net.handle(), CONV_INDEX["block_fusion.0"], C.c_void_p(x.data_ptr()), 2, 24, 32, C.c_void_p(y.data_ptr()), 11, None) == 0
+    assert lib.xfh_conv_layer(a.net.handle(), CONV_INDEX["block_fusion.0"], C.c_void_p(x.data_ptr()), 2, 24, 32, C.c_void_p(y.data_ptr()), V_FX, None) == 0
     assert a.net.take_status() & 1 and a.net.take_status() == 0
-    assert lib.xfh_conv_layer(a.net.handle(), CONV_INDEX["block_fusion.0"], C.c_void_p(x.data_ptr()), 2, 24, 32, C.c_void_p(y.data_ptr()), 10, None) == 0
+    assert lib.xfh_conv_layer(a.net.handle(), CONV_INDEX["block_fusion.0"], C.c_void_p(x.data_ptr()), 2, 24, 32, C.c_void_p(y.data_ptr()), V_F32, None) == 0
     assert a.net.take_status() == 0 and bool(torch.isfinite(y).all())
-    assert lib.xfh_conv_layer(a.net.handle(), CONV_INDEX["block2.0"], C.c_void_p((x[:, :24] * 1.0).contiguous().data_ptr()), 2, 24, 32, C.c_void_p(y.data_ptr()), 11, None) == 0
+    assert lib.xfh_conv_layer(a.net.handle(), CONV_INDEX["block2.0"], C.c_void_p((x[:, :24] * 1.0).contiguous().data_ptr()), 2, 24, 32, C.c_void_p(y.data_ptr()), V_FX, None) == 0
     assert a.net.take_status() & 1
-    # (b) end to end: weights whose block1 output is huge (skip1 bias) -> the fx layers overflow, the call is repeated on the bf16 split, results = model b's
+    # (b) end to end: weights whose block1 output is huge (skip1 bias) -> the fx layers overflow, the call is repeated on the fp32-range kernels, results = model b's
     sd2 = {k: v.clone() for k, v in sd.items()}
     sd2["skip1.1.bias"] = sd2["skip1.1.bias"] + 2.0e5
     a.net.load_state_dict(sd2); b.net.load_state_dict(sd2)
@@ -698,16 +733,18 @@ def test_fp16_pair_arithmetic_reports_its_range_and_the_model_falls_back(sd):
         ra = a.detectAndCompute(img, top_k=512)
     rb = b.detectAndCompute(img, top_k=512)
     assert any("fp16-pair" in str(m.message) for m in w)
-    assert a.net._options.get("fx") == 0 and a.net._effective_option("heads_f32") != 0 and a.net._effective_option("block1") < 6
+    assert a.net._options.get("fx") == 0 and a.net._effective_option("block1") == 5
+    for key, want in ((b"fx", 0), (b"block1", 5)):      # ... and the live handle agrees
+        assert lib.xfh_get_option(a.net.handle(), key, C.byref(v)) == 0 and v.value == want, (key, v.value)
     for u, v_ in zip(ra, rb):
         assert torch.equal(u["keypoints"], v_["keypoints"]) and torch.equal(u["scores"], v_["scores"]) and torch.equal(u["descriptors"], v_["descriptors"])
-    # (c) tiny activations (fp16 subnormals of the high part): the pair still carries them -- same accuracy as the bf16 form against fp64
+    # (c) tiny activations (fp16 subnormals of the high part): the pair still carries them -- same accuracy as the f32-MFMA kernel
     xs = torch.relu(torch.randn(2, 64, 24, 32, device="cuda")) * 1.0e-6
     ws = a.net.state_dict()
     c = CONV_INDEX["block_fusion.0"]
     ya, yb = torch.empty_like(y), torch.empty_like(y)
-    assert lib.xfh_conv_layer(a.net.handle(), c, C.c_void_p(xs.data_ptr()), 2, 24, 32, C.c_void_p(ya.data_ptr()), 11, None) == 0
-    assert lib.xfh_conv_layer(a.net.handle(), c, C.c_void_p(xs.data_ptr()), 2, 24, 32, C.c_void_p(yb.data_ptr()), 10, None) == 0
+    assert lib.xfh_conv_layer(a.net.handle(), c, C.c_void_p(xs.data_ptr()), 2, 24, 32, C.c_void_p(ya.data_ptr()), V_FX, None) == 0
+    assert lib.xfh_conv_layer(a.net.handle(), c, C.c_void_p(xs.data_ptr()), 2, 24, 32, C.c_void_p(yb.data_ptr()), V_F32, None) == 0
     assert float((ya - yb).abs().max()) <= 1e-6 * float(yb.abs().max()) + 1e-12
 
 
@@ -1191,14 +1228,13 @@ def test_frame_stream_at_the_bench_shape_is_bit_stable_over_many_steps(xf, sd, c
         raise AssertionError(f"{len(bad)} of 40 results differ from the synchronous one (synchronous result reproducible: {ref_stable}): {bad[:6]}")
 
 
-@pytest.mark.parametrize("opts", [{}, {"fx": 0}, {"heads_f32": 1}, {"heads_f32": 2, "block1": 5, "fx": 3}, {"heads_f32": 0, "fx": 3}, {"block1": 7}, {"heads_f32": 0, "fx": 11}, {"fx": 7}, {"fx": 67}, {"fx": 387}, {"fx": 1027}])
+@pytest.mark.parametrize("opts", [{}, {"fx": 0, "block1": 5}, {"fx": FX_CONV64 | FX_CONV24, "block1": 5}])
 def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
     """Time-boxed soak.  The bench-shape backbone + sparse step + match on one HIP stream while a second stream runs foreign kernels (another
-    model's backbone = every kernel of this library incl. f32-MFMA and vector-only ones, a large copy, a rocBLAS GEMM), then the same with every matrix-core
-    kernel starting on an invalidated instruction cache (xfh_debug_cold_start: the condition that made the split-bf16 key-point head deliver wrong 16-cell blocks,
-    DESIGN 9.0) -- every network output and every match list of every step bit-identical to the quiet, warm reference.  Parametrised over the per-handle kernel
-    options (every set names what it needs, so the list means the same whatever the library defaults are: {"heads_f32": 2, "block1": 5, "fx": 3} is round 4's shipped mix);
-    {"heads_f32": 0, "fx": 3} is the opt-in split-bf16 head: it runs the two-stream part only as a record (its failures are rare and known), the assertion covers what ships."""
+    model's backbone = every kernel of this library, a large copy, a rocBLAS GEMM), then the same with every matrix-core
+    kernel starting on an invalidated instruction cache (xfh_debug_cold_start: the condition that made round 3's split-bf16 key-point head -- deleted since -- deliver wrong
+    16-cell blocks) -- every network output and every match list of every step bit-identical to the quiet, warm reference.  Parametrised over the kernel sets that
+    ship: the defaults, the range fallback as a whole, and a mix (f32-MFMA heads and vector block1 next to the fp16-pair convolutions)."""
     import threading
     import time
     from accelerated_features_amd import XFeat
@@ -1264,7 +1300,4 @@ def test_two_streams_and_cold_instruction_cache_soak(sd, opts):
         lib.xfh_debug_cold_start(0)
     print(f"options {opts}: {n1} steps next to foreign kernels: differing {dict(zip(names, bad1))}; {n2} cold-start steps: differing {dict(zip(names, bad2))}")
     assert n1 >= 200 and n2 >= 200
-    from accelerated_features_amd.xfeat import DEFAULT_FX, DEFAULT_HEADS_F32
-    if opts.get("heads_f32", DEFAULT_HEADS_F32) == 0 and not opts.get("fx", DEFAULT_FX) & 8:
-        return                                          # the opt-in bf16 head: recorded above, not asserted.  (The fp16-pair head IS asserted: it has to earn its place.)
     assert not any(bad1) and not any(bad2), (dict(zip(names, bad1)), dict(zip(names, bad2)))

@@ -1,6 +1,5 @@
-"""The split-operand head kernels (csrc/head_bx_body.hpp) compiled for the HOST (tests/emu/) against a float64 reference: the bf16 three-way split (the form of
-rounds 2-4, validated on the GPU: the emulator's own control) and the fp16-pair form prepared for the next round (three MFMAs per product; accumulators at scale
-2^11, bias and scale applied by the consumer; the weight image of weight_split.hpp: pack_head_layer)."""
+"""The head kernels (csrc/head_bx_body.hpp: the default, fp16-pair arithmetic -- three MFMAs per product, accumulators at scale 2^11, bias and scale applied by the consumer,
+the weight image of weight_split.hpp: pack_head_layer; csrc/head_f32r_body.hpp: the f32-MFMA fallback) compiled for the HOST (tests/emu/) against a float64 reference."""
 import os
 import subprocess
 import tempfile
@@ -27,7 +26,7 @@ def _blob(hdr, arrs):
     return np.concatenate([np.array(hdr, np.int32).view(np.float32)] + [np.asarray(a, np.float32).reshape(-1) for a in arrs]).tobytes()
 
 
-@pytest.mark.parametrize("fx", [-1, 0, 1, 2, 3])      # -1: the f32-MFMA heads with register input (the default), 0: bf16 three-way split, 1 .. 3: the fp16-pair forms
+@pytest.mark.parametrize("fx", [-1, 1])      # 1: the fp16-pair heads (the default), -1: the f32-MFMA heads with register input (the range fallback)
 def test_keypoint_head_on_the_host(emu_bin, fx):
     g = torch.Generator().manual_seed(4 + fx)
     B, H, W = 2, 96, 136                              # 2 x 12 x 17 = 408 cells: one full tile and a partial one
@@ -55,7 +54,7 @@ def test_keypoint_head_on_the_host(emu_bin, fx):
     assert e_l <= 2e-5 * float(lg.abs().max()) and e_h <= 1e-6
 
 
-@pytest.mark.parametrize("fx", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("fx", [-1, 1])
 def test_keypoint_head_on_the_host_reproduces_the_reference_made_golden(emu_bin, fx):
     """The same kernel bodies on the fixture of tests/golden/g1_small.npz (image, synthetic weights with the calibrated BatchNorm statistics; heat map and logits written by the
     UNMODIFIED reference, tests/golden/make_golden.py): every form inside the tolerances the GPU suite applies to that golden (heat 1e-5, logits 5e-4) -- with margin, and
@@ -88,7 +87,7 @@ def test_keypoint_head_on_the_host_reproduces_the_reference_made_golden(emu_bin,
     assert e_h <= 5e-6 and e_l <= 1e-4                    # (GPU suite: 1e-5 / 5e-4; measured here: 3.1e-6 .. 3.9e-6 / 2.3e-5 .. 2.5e-5)
 
 
-@pytest.mark.parametrize("fx", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("fx", [-1, 1])
 def test_reliability_head_on_the_host(emu_bin, fx):
     g = torch.Generator().manual_seed(14 + fx)
     n = 300

@@ -139,14 +139,13 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
     assert lib.xfh_create(ptrs, 3, 0, C.byref(h)) == -2       # malformed weight table
 
 
-def test_range_fallback_lands_on_fp32_range_forms_whatever_the_defaults_are(monkeypatch):
-    """XFeatModel.fx_range_exceeded (the reaction to bit 0 of the status word: an activation beyond fp16's range) must end on kernels with fp32's range -- fx = 0,
-    NO split heads (with fx = 0 they would be the retired bf16 head), block1 on the vector ALUs -- and must not ask for a second repeat; checked for the
-    shipped defaults and for the ones the next round's probe points at (block1 = 7, fp16-pair heads), without a GPU (options are remembered until a handle exists)."""
+def test_range_fallback_lands_on_fp32_range_kernels(monkeypatch):
+    """XFeatModel.fx_range_exceeded (the reaction to bit 0 of the status word: an activation beyond fp16's range) must end on kernels with fp32's range -- fx = 0 (f32-MFMA
+    convolutions, heads, linear layers), block1 = 5 (vector ALUs): include/xfeat_hip.h "THE RANGE FALLBACK" -- and must not ask for a second repeat; checked for the shipped
+    defaults and for partial option sets, without a GPU (options are remembered until a handle exists)."""
     import warnings
-    from accelerated_features_amd import XFeat, xfeat as xm
-    for defaults, overrides in (((3, 2, 0), {}), ((11, 0, 7), {}), ((1931, 0, 7), {}), ((3979, 0, 7), {}), ((3, 2, 0), {"fx": 11, "heads_f32": 0, "block1": 7}), ((3, 2, 0), {"heads_f32": 1}), ((0, 2, 0), {"block1": 6})):
-        monkeypatch.setattr(xm, "DEFAULT_FX", defaults[0]); monkeypatch.setattr(xm, "DEFAULT_HEADS_F32", defaults[1]); monkeypatch.setattr(xm, "DEFAULT_BLOCK1", defaults[2])
+    from accelerated_features_amd import XFeat, _lib, xfeat as xm
+    for overrides in ({}, {"fx": xm.FX_HEADS}, {"fx": 0}, {"block1": 5}, {"fx": xm.FX_CONV64 | xm.FX_FINE, "block1": 5}):
         net = XFeat(weights=None).net
         for k, v in overrides.items():
             net.set_option(k, v)
@@ -155,23 +154,46 @@ def test_range_fallback_lands_on_fp32_range_forms_whatever_the_defaults_are(monk
             warnings.simplefilter("always")
             assert net.fx_range_exceeded(status=1) is True
         assert any("fp16-pair" in str(m.message) for m in w)
-        assert net._effective_option("fx") == 0 and net._effective_option("heads_f32") in (1, 2, 3) and net._effective_option("block1") < 6
-        if overrides.get("heads_f32") == 1:
-            assert net._effective_option("heads_f32") == 1                      # (a caller's f32 choice is left alone)
+        assert net._effective_option("fx") == 0 and net._effective_option("block1") == 5
         assert net.fx_range_exceeded(status=1) is False                          # nothing left to switch off: no endless repeat on a stale flag
-    monkeypatch.setattr(xm, "DEFAULT_FX", 0); monkeypatch.setattr(xm, "DEFAULT_HEADS_F32", 2); monkeypatch.setattr(xm, "DEFAULT_BLOCK1", 0)
-    assert XFeat(weights=None).net.fx_range_exceeded() is False                 # fp32-range forms only: no read-back at all
+    net = XFeat(weights=None).net
+    net.set_option("fx", 0); net.set_option("block1", 5)
+    assert net.fx_range_exceeded() is False                                      # fp32-range kernels only: no read-back at all
+    for key, value in (("heads_f32", 0), ("wino", 1), ("bx", 21), ("block1", 0), ("block1", 6), ("fx", 4), ("fx", 3979), ("fx", 4095)):      # what round 6 deleted is refused
+        with pytest.raises(_lib.XFeatHipError):
+            net.set_option(key, value)
 
 
 def test_python_mirrors_of_the_library_defaults_agree_with_kernels_hpp():
-    """xfeat.DEFAULT_FX / DEFAULT_HEADS_F32 / DEFAULT_BLOCK1 mirror csrc/kernels.hpp: Options (the GPU suite asks the live handle; this is the same check without one)."""
+    """xfeat.DEFAULT_FX / DEFAULT_BLOCK1 mirror csrc/kernels.hpp: Options (the GPU suite asks the live handle; this is the same check without one)."""
     import re
     from accelerated_features_amd import xfeat as xm
     src = open(os.path.join(os.path.dirname(xm.__file__), "csrc", "kernels.hpp"), encoding="utf-8").read()
     body = src[src.index("struct Options {"):]
     body = body[:body.index("};")]
-    got = {k: int(v) for k, v in re.findall(r"^\s*int\s+(\w+)\s*=\s*(\d+)\s*;", body, flags=re.M)}
-    assert (got["fx"], got["heads_f32"], got["block1"]) == (xm.DEFAULT_FX, xm.DEFAULT_HEADS_F32, xm.DEFAULT_BLOCK1), got
+    got = {k: eval(v) for k, v in re.findall(r"^\s*int\s+(\w+)\s*=\s*([\d |]+)\s*;", body, flags=re.M)}
+    assert (got["fx"], got["block1"]) == (xm.DEFAULT_FX, xm.DEFAULT_BLOCK1) and set(got) == {"match_exact", "fx", "resize2", "block1"}, got
+
+
+def test_the_library_holds_no_retired_kernel():
+    """one default and one fp32-range fallback per layer.  No bf16 matrix instruction, no Winograd / conv_bx64 / head_fused kernel and no debug soak entry in the
+    built library; the header does not describe anything as unsafe."""
+    import subprocess
+    from accelerated_features_amd import build
+    assert os.path.exists(build.LIB), "build the library first (python -m accelerated_features_amd.build)"
+    syms = subprocess.run(["nm", "-D", "--defined-only", build.LIB], check=True, capture_output=True, text=True).stdout
+    assert "xfh_debug_head_soak" not in syms and "xfh_set_option" in syms
+    names = subprocess.run(["strings", build.LIB], check=True, capture_output=True, text=True).stdout
+    for gone in ("conv_wino_kernel", "conv_bx64_kernel", "conv_bx64s2_kernel", "head_fused_kernel", "mfma_f32_32x32x16_bf16", "mfma_f32_16x16x32_bf16"):
+        assert gone not in names, gone
+    for kept in ("conv_rs64_kernel", "conv_bx64s2x_kernel", "conv_bx_kernel", "head_bx_kernel", "head_f32r_kernel", "block1_mx_kernel", "block1_fused_kernel", "conv_mfma_kernel"):
+        assert kept in names, kept
+    hdr = open(os.path.join(ROOT, "include", "xfeat_hip.h")).read()
+    assert "NOT safe" not in hdr and "heads_f32" not in hdr and "wino" not in hdr.lower()
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "accelerated_features_amd", "csrc", "*")):
+        assert "_bf16(" not in open(f).read() or os.path.basename(f) in ("k_lighterglue.hip", "api_lg.hip"), f
+
 
 
 def test_product_never_imports_the_oracle():

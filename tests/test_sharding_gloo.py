@@ -89,11 +89,38 @@ def test_two_process_gloo_sharding_and_timing_protocol():
         assert abs(rate - 32 * 3 * 2 / tmax) < 1e-9  # whole-job units / max time
 
 
+def _host_worker(rank, world, port, q):
+    os.environ["MASTER_PORT"] = str(port)
+    g = sharding.HostGroup(rank, world, token=f"pytest_{port}")
+    secs, last = sharding.timed_steps(lambda: time.sleep(0.02 * (rank + 1)) or rank, steps=3, warmup=1, dist=g, device_sync=None, device="cpu")
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    g.all_reduce(t, op=g.ReduceOp.SUM)
+    q.put((rank, secs, float(t.item())))
+    g.destroy_process_group()
+
+
+def test_host_group_is_a_barrier_and_a_max_without_a_collective_library():
+    """sharding.HostGroup (files under /dev/shm): timed_steps' bracket and max-over-ranks through it, three ranks"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = sharding.free_port()
+    procs = [ctx.Process(target=_host_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert len({r[1] for r in res}) == 1 and 3 * 0.06 <= res[0][1] < 3 * 0.06 + 0.5      # every rank holds the slowest rank's time
+    assert all(r[2] == 6.0 for r in res)
+
+
 def test_bench_launches_its_own_ranks_and_never_underreports(tmp_path):
     """`python bench.py --gpus 2` WITHOUT a launcher re-runs itself as two ranks under torch.distributed.run (it used to run one
     rank and print n_gpus = 1).  --launch-selftest swaps RCCL / the hot path for gloo / a sleep so that the launch path itself runs here;
     without it, on a box with fewer GPUs than asked for, the command must refuse loudly instead of printing a line."""
     import json
+    import re
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -116,6 +143,24 @@ def test_bench_launches_its_own_ranks_and_never_underreports(tmp_path):
     assert d["n_gpus"] == 8 and d["steps"] == 3 and d["selftest"] is True and d["scaling"] == "weak"
     assert d["ms_per_step"] >= 79.0                               # rank 7 sleeps 80 ms per step: MAX over ranks
     assert abs(d["value"] - 8 * d["config"]["units_per_rank_per_step"] / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]      # whole-job units / the slowest rank's time
+    assert d["barrier"] == "gloo"
+    # the same launch with the host-side file barrier (no collective library at all) ...
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--launch-selftest", "--steps", "3", "--warmup", "1", "--barrier", "host"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["barrier"].startswith("file (requested") and 39.0 <= d["ms_per_step"] < 60.0      # rank 3's 40 ms sleeps: MAX over ranks through the files
+    # ... and the fallback: the collective's bring-up fails on ONE rank (test hook; the others then fail or time out in the rendezvous that rank never joins) -> every
+    # rank agrees on the file barrier, the line still comes out, rc 0
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--launch-selftest", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env={**env, "XFH_TEST_FAIL_COLLECTIVE": "1"}, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 3 and re.match(r"file \(gloo bring-up failed on [1-3] of 3 ranks", d["barrier"]) and 29.0 <= d["ms_per_step"] < 50.0
     # the real workload on this GPU-less box: refuse, do not report
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))

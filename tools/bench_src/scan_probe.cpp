@@ -1,11 +1,11 @@
-// Cold-start code-position scan of every default matrix-core kernel, with the retired bf16 key-point head as the BOX's positive control, in ONE process (no Python: the
-// whole scan is ~5 GPU-minutes).  VERDICT r4 item 1: a scan counts only on a box where the control fires.
-//   build (CPU):  python -m accelerated_features_amd.build ; python -m accelerated_features_amd.build --scan ; for n in 1..15: python -m accelerated_features_amd.build --shift n
+// Cold-start code-position scan of every default matrix-core kernel in ONE process (no Python: the whole scan is ~4 GPU-minutes).
+//   build (CPU):  python -m accelerated_features_amd.build ; for n in 1..15: python -m accelerated_features_amd.build --shift n
 //                 hipcc -O2 -w --offload-arch=gfx950 tools/bench_src/scan_probe.cpp -o gpurun_probe/scan_probe -ldl
-//   run (GPU):    gpurun_probe/scan_probe accelerated_features_amd gpurun_probe/weights.bin <launches per kernel and position> [control launches per position]
-// 1. control: libxfeat_hip_scan.so, key-point head variants 1000 + s (split-bf16 head at code position s, cold-started), s = 0..15: launches with a wrong heat map.
-// 2. scan: libxfeat_hip.so (position 0) and libxfeat_hip_shift<N>.so (every matrix-core kernel moved by 4 N bytes), N = 1..15: each default kernel alone in a tight loop,
-//    every launch cold-started (xfh_debug_cold_start: each workgroup begins on an invalidated instruction cache), every result compared ON THE DEVICE with the quiet result.
+//   run (GPU):    gpurun_probe/scan_probe accelerated_features_amd gpurun_probe/weights.bin <launches per kernel and position>
+// libxfeat_hip.so (position 0) and libxfeat_hip_shift<N>.so (every matrix-core kernel moved by 4 N bytes), N = 1..15: each default kernel alone in a tight loop,
+// every launch cold-started (xfh_debug_cold_start: each workgroup begins on an invalidated instruction cache), every result compared ON THE DEVICE with the quiet result.
+// Rounds 4-5 ran the retired split-bf16 key-point head first as the box's positive control (a scan counted only on a box where that kernel failed:
+// profiles/r05_scan_all_kernels.txt); round 6 deleted that kernel from the tree -- the last source that holds it is commit 9802e34.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cmath>
@@ -43,7 +43,6 @@ struct Lib {
     int (*conv_layer)(H, int, const float*, int, int, int, float*, int, void*) = nullptr;
     int (*cold)(int) = nullptr;
     int (*block1)(H, const float*, const float*, int, int, int, float*, void*) = nullptr;
-    int (*head_soak)(H, const float*, int, int, int, int, float*, float*, double*, float*, const float*, float*, const float*, int, int, int, unsigned*, unsigned*, unsigned, void*) = nullptr;
     int (*backbone)(H, const float*, int, int, int, int, float*, float*, float*, float*, float*, void*, size_t, void*) = nullptr;
     size_t (*backbone_ws)(int, int, int, int) = nullptr;
     int (*match)(H, const float*, size_t, const float*, size_t, const uint16_t*, const uint16_t*, const int32_t*, const int32_t*, int, int, int, int, int, float, int64_t*, int64_t*, int32_t*, void*, size_t, void*) = nullptr;
@@ -57,7 +56,7 @@ static bool open_lib(Lib& L, const std::string& path, const std::vector<const fl
     L.so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!L.so) { printf("dlopen %s: %s\n", path.c_str(), dlerror()); return false; }
 #define SYM(f, name) L.f = reinterpret_cast<decltype(L.f)>(dlsym(L.so, name)); if (!L.f) { printf("%s: missing %s\n", path.c_str(), name); return false; }
-    SYM(conv_layer, "xfh_conv_layer") SYM(cold, "xfh_debug_cold_start") SYM(block1, "xfh_debug_block1") SYM(head_soak, "xfh_debug_head_soak") SYM(backbone, "xfh_backbone")
+    SYM(conv_layer, "xfh_conv_layer") SYM(cold, "xfh_debug_cold_start") SYM(block1, "xfh_debug_block1") SYM(backbone, "xfh_backbone")
     SYM(backbone_ws, "xfh_backbone_workspace_bytes") SYM(match, "xfh_match_mnn") SYM(match_ws, "xfh_match_workspace_bytes") SYM(last_error, "xfh_last_error")
     SYM(fine, "xfh_fine_matcher") SYM(refine_ws, "xfh_refine_workspace_bytes") SYM(refine, "xfh_refine_matches")
     auto create = reinterpret_cast<int (*)(const float* const*, int, int, H*)>(dlsym(L.so, "xfh_create"));
@@ -67,9 +66,9 @@ static bool open_lib(Lib& L, const std::string& path, const std::vector<const fl
 
 int main(int argc, char** argv) {
     setvbuf(stdout, nullptr, _IONBF, 0);
-    if (argc < 4) { printf("usage: scan_probe <dir of the libraries> <weights.bin> <launches per kernel and position> [control launches per position]\n"); return 1; }
+    if (argc < 4) { printf("usage: scan_probe <dir of the libraries> <weights.bin> <launches per kernel and position> [- fine]\n"); return 1; }
     const std::string dir = argv[1];
-    const int N = atoi(argv[3]), NC = argc > 4 ? atoi(argv[4]) : 6000;
+    const int N = atoi(argv[3]);
     FILE* f = fopen(argv[2], "rb");
     if (!f) { printf("cannot open %s\n", argv[2]); return 2; }
     int na = 0;
@@ -82,51 +81,15 @@ int main(int argc, char** argv) {
     HIPCHK(hipMalloc(&flag, 4)); HIPCHK(hipMalloc(&total, 4)); HIPCHK(hipMemset(flag, 0, 4));
     auto take_total = [&] { unsigned v; HIPCHK(hipMemcpy(&v, total, 4, hipMemcpyDeviceToHost)); return v; };
 
-    // ---------------- 1. the box's positive control: the split-bf16 key-point head at 16 code positions (B = 64 VGA, as in round 4)
-    {
-        Lib S;
-        if (!open_lib(S, dir + "/libxfeat_hip_scan.so", ptrs)) return 2;
-        const int B = 64, Hh = 480, W = 640;
-        const size_t npx = (size_t)B * Hh * W;
-        auto hgray = rnd(npx, 1, 0.f, 1.f);
-        std::vector<float> hcoef(2 * B);
-        for (int b = 0; b < B; ++b) { hcoef[2 * b] = 3.4f + 0.01f * b; hcoef[2 * b + 1] = -1.7f; }
-        float *gray, *coef, *heat, *href; double* part; unsigned* rep;
-        HIPCHK(hipMalloc(&gray, npx * 4)); HIPCHK(hipMalloc(&coef, 2 * B * 4)); HIPCHK(hipMalloc(&heat, npx * 4)); HIPCHK(hipMalloc(&href, npx * 4));
-        HIPCHK(hipMalloc(&part, 8 * B * 128)); HIPCHK(hipMalloc(&rep, (4 + 4 * 1024) * 4));
-        HIPCHK(hipMemcpy(gray, hgray.data(), npx * 4, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(coef, hcoef.data(), 2 * B * 4, hipMemcpyHostToDevice));
-        const int base[2] = {0, 102}, coldv[2] = {1000, 4000};
-        const char* nm[2] = {"CONTROL  split-bf16 key-point head (retired in round 4)", "fp16-pair key-point head (the default)"};
-        for (int k = 0; k < 2; ++k) {
-            if (S.head_soak(S.h, nullptr, B, 3, Hh, W, gray, coef, part, href, nullptr, nullptr, nullptr, base[k], 1, 0, nullptr, nullptr, 0, nullptr)) { printf("variant %d: %s\n", base[k], S.last_error()); continue; }
-            HIPCHK(hipDeviceSynchronize());
-            std::string line; long tot = 0;
-            for (int s = 0; s < 16; ++s) {
-                HIPCHK(hipMemset(rep, 0, (4 + 4 * 1024) * 4));
-                if (S.head_soak(S.h, nullptr, B, 3, Hh, W, gray, coef, part, heat, href, nullptr, nullptr, coldv[k] + s, k == 0 ? NC : std::max(NC, N / 4), 0, rep, nullptr, 1024, nullptr)) { line += " n/a"; continue; }
-                HIPCHK(hipDeviceSynchronize());
-                std::vector<unsigned> r(4 + 4 * 1024);
-                HIPCHK(hipMemcpy(r.data(), rep, r.size() * 4, hipMemcpyDeviceToHost));
-                std::vector<unsigned> its;
-                for (unsigned i = 0; i < std::min(r[0], 1024u); ++i) its.push_back(r[4 + 4 * i]);
-                std::sort(its.begin(), its.end()); its.erase(std::unique(its.begin(), its.end()), its.end());
-                line += " " + std::to_string(its.size()) + (r[0] > 1024 ? "+" : "");
-                tot += (long)its.size();
-            }
-            printf("%-58s cold-started, %d launches at each of 16 code positions (B = 64 VGA): launches with a wrong heat map:%s   (total %ld)\n", nm[k], k == 0 ? NC : std::max(NC, N / 4), line.c_str(), tot);
-        }
-        HIPCHK(hipFree(gray)); HIPCHK(hipFree(coef)); HIPCHK(hipFree(heat)); HIPCHK(hipFree(href)); HIPCHK(hipFree(part)); HIPCHK(hipFree(rep));
-    }
-
     // ---------------- 2. every default matrix-core kernel at 16 code positions (the whole library shifted), B = 16 VGA maps
     const int B = 16, Hh = 480, W = 640;
     struct K { const char* name; int layer, variant, div, cin, cout, stride; };
     // layer indices: accelerated_features_amd/spec.py (block2.0 = 5, block3.0 = 7, block3.1 = 8, block4.0 = 10, block4.1 = 11, block5.0 = 13, block5.1 = 14, block5.3 = 16, block_fusion.0 = 17, .1 = 18)
     const K ks[] = {{"conv_bx_kernel<24,24,fx> (block2.0)", 5, 0, 4, 24, 24, 1}, {"conv_bxs2_kernel<24,fx> (block3.0)", 7, 0, 4, 24, 64, 2},
-                    {"conv_rs64_kernel<1> (block3.1 + .2)", 8, 13, 8, 64, 64, 1}, {"conv_bx64s2x_kernel<1> (block4.0)", 10, 0, 8, 64, 64, 2},
+                    {"conv_rs64_kernel<1> (block3.1 + .2)", 8, 4, 8, 64, 64, 1}, {"conv_bx64s2x_kernel<1> (block4.0)", 10, 0, 8, 64, 64, 2},
                     {"conv_rs64_kernel<0> (block4.1)", 11, 0, 16, 64, 64, 1}, {"conv_bx64s2x_kernel<2> (block5.0)", 13, 0, 16, 64, 128, 2},
                     {"conv_rs64_kernel<0,128> (block5.1)", 14, 0, 32, 128, 128, 1}, {"conv_rs64_kernel<0> (block_fusion.0)", 17, 0, 8, 64, 64, 1},
-                    {"conv_rs64_kernel<2> (block_fusion.1 + .2)", 18, 14, 8, 64, 64, 1}};
+                    {"conv_rs64_kernel<2> (block_fusion.1 + .2)", 18, 5, 8, 64, 64, 1}};
     const bool only_fine = argc > 5 && !strcmp(argv[5], "fine");      // (a later visit for one kernel added after the round's scan: the control + linear_fx_kernel alone)
     const int nk = (int)(sizeof(ks) / sizeof(ks[0])), NEXTRA = 5;      // + block1_mx<7>, the fp16-pair heads (whole backbone), mnn_f16_sweep (+ refine)
     std::vector<std::vector<long>> wrong(nk + NEXTRA, std::vector<long>(16, -1));

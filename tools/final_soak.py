@@ -19,7 +19,7 @@ lib = _lib.load()
 sd = fixtures.synthetic_state_dict(0)
 x = torch.cat([fixtures.texture_images(8, 480, 640, seed=77)] * 8).cuda()
 ov = {}
-for k in (b"fx", b"bx", b"heads_f32", b"wino", b"block1", b"match_exact"):
+for k in (b"fx", b"block1", b"match_exact", b"resize2"):
     import ctypes as C
     v = C.c_int(); h0 = XFeat(weights=sd, top_k=4096); lib.xfh_get_option(h0.net.handle(), k, C.byref(v)); ov[k.decode()] = v.value; del h0
 print(f"final_soak {mode} {steps} steps; library defaults {ov}; overrides {opts}", flush=True)
