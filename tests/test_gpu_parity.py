@@ -426,11 +426,13 @@ def test_match_many_is_match_pair_by_pair(xf):
     assert xf._strided_layout(f1, f2) is not None and xf._strided_layout(f1, f2)[4] is None        # in place; the fp16 filter copies are made from the rows as they are NOW
     # ... so descriptors modified in place between detectAndCompute and match_many are matched AS MODIFIED (round 5 reused fp16 copies of the old rows)
     keep0 = f1[0].clone()
-    f1[0].copy_(torch.nn.functional.normalize(torch.roll(f1[0], 7, dims=1) + 0.1, dim=-1))
+    with torch.inference_mode():              # (detectAndCompute hands out inference tensors, as the reference does)
+        f1[0].copy_(torch.nn.functional.normalize(torch.roll(f1[0], 7, dims=1) + 0.1, dim=-1))
     want_mod = xf.match(f1[0], f2[0], min_cossim=-1)
     got_mod = xf.match_many(f1, f2, min_cossim=-1)[0]
     assert torch.equal(got_mod[0], want_mod[0]) and torch.equal(got_mod[1], want_mod[1])
-    f1[0].copy_(keep0)
+    with torch.inference_mode():
+        f1[0].copy_(keep0)
     for mc in (-1, 0.82):
         want = [xf.match(a, b, min_cossim=mc) for a, b in zip(f1, f2)]
         for got in (xf.match_many(f1, f2, min_cossim=mc),                                              # in place
@@ -744,8 +746,8 @@ def test_fp16_pair_arithmetic_reports_its_range_and_the_model_falls_back(sd):
     c = CONV_INDEX["block_fusion.0"]
     ya, yb = torch.empty_like(y), torch.empty_like(y)
     assert lib.xfh_conv_layer(a.net.handle(), c, C.c_void_p(xs.data_ptr()), 2, 24, 32, C.c_void_p(ya.data_ptr()), V_FX, None) == 0
-    assert lib.xfh_conv_layer(a.net.handle(), c, C.c_void_p(xs.data_ptr()), 2, 24, 32, C.c_void_p(yb.data_ptr()), V_F32, None) == 0
-    assert float((ya - yb).abs().max()) <= 1e-6 * float(yb.abs().max()) + 1e-12
+    assert lib.xfh_conv_layer(a.net.handle(), c, C.c_void_p(xs.data_ptr()), 2, 24, 32, C.c_void_p(yb.data_ptr()), V_GENERIC, None) == 0
+    assert float((ya - yb).abs().max()) <= 1e-6 * float(yb.abs().max()) + 1e-12      # (against the fp32 direct kernel: the f32-MFMA kernel sums K in another order, a few ulps of the bias)
 
 
 def test_uint8_ingest_is_bit_identical_to_host_conversion(xf):
