@@ -70,6 +70,59 @@ def make_frames(B, seed):
     return torch.stack(frames)
 
 
+def gpu_telemetry(device_index=0):
+    """Clock / power / temperature of the GPU this rank runs on, from the amdgpu sysfs nodes (no subprocess: cheap enough to call right before and right after the timed
+    region) -- what lets a reader of the line tell a slow BOX from a slow kernel (box-to-box spread of one kernel: +-8 %).  Values the node does not offer are
+    absent; no GPU / no sysfs: {"source": "unavailable"}."""
+    import glob
+    out = {}
+    try:
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        if not cards:
+            return {"source": "unavailable"}
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+        idx = device_index
+        try:
+            if vis:
+                idx = int(vis.split(",")[device_index])
+        except (ValueError, IndexError):
+            pass
+        d = cards[min(idx, len(cards) - 1)]
+        out["source"] = d
+
+        def cur_level(name):          # "0: 132Mhz\n1: 2400Mhz *" -> the starred level (MHz)
+            try:
+                for ln in open(os.path.join(d, name)).read().splitlines():
+                    if ln.rstrip().endswith("*"):
+                        return int("".join(ch for ch in ln.split(":")[1] if ch.isdigit()))
+            except (OSError, ValueError, IndexError):
+                return None
+            return None
+        for key, node in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+            v = cur_level(node)
+            if v is not None:
+                out[key] = v
+        for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+            def rd(name, scale):
+                try:
+                    return round(int(open(os.path.join(hw, name)).read().strip()) * scale, 1)
+                except (OSError, ValueError):
+                    return None
+            for key, node, scale in (("power_w", "power1_average", 1e-6), ("power_w", "power1_input", 1e-6), ("power_cap_w", "power1_cap", 1e-6),
+                                     ("temp_edge_c", "temp1_input", 1e-3), ("temp_junction_c", "temp2_input", 1e-3), ("temp_hbm_c", "temp3_input", 1e-3),
+                                     ("sclk_now_mhz", "freq1_input", 1e-6), ("mclk_now_mhz", "freq2_input", 1e-6)):
+                v = rd(node, scale)
+                if v is not None and key not in out:
+                    out[key] = v
+        try:
+            out["busy_percent"] = int(open(os.path.join(d, "gpu_busy_percent")).read().strip())
+        except (OSError, ValueError):
+            pass
+    except Exception as e:          # noqa: BLE001 -- telemetry must never cost the line
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def cpu_baseline(seconds):
     """Oracle (port of the reference CPU path) on the host cores: same workload shape,
     bounded sample: batches of 4 VGA frames + their 2 pair matches, repeated ~`seconds`."""
@@ -778,7 +831,9 @@ def main():
         lib.xfh_profile_select(h_, _lib.PROF_NONE)
 
     # (the barrier + torch.cuda.synchronize() that closes the timed region waits for every lane: all `steps` batches complete inside it)
+    tele_before = gpu_telemetry(local_rank)
     dt_max, _ = sharding.timed_steps(lane_step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
+    tele_after = gpu_telemetry(local_rank)
     timed_calls[0] = None
     assert len(retired) == args.steps and fs.in_flight == 0
     last = retired[-1]
@@ -920,6 +975,8 @@ def main():
                        "lanes": lanes,
                        "untimed_before_the_timed_region": f"GPU wake-up ({n_wake} steps: windows of {args.steps} until two agree within 1 %, >= {args.wake_ms:.0f} ms; a cold GPU runs its first ~150 ms 3-4 % slow), then the W warm-up steps",
                        "wake_up_window_fps": [round(r, 1) for r in wake_rates],
+                       # the box's state around the timed region (amdgpu sysfs): a slow box reads differently from a slow kernel
+                       "gpu_state": {"before_timed_region": tele_before, "after_timed_region": tele_after},
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
             # block1 x4 + skip1 in one kernel: fp32 FMA work on the vector ALUs (v_pk_fma_f32), LDS-tiled.  Neither HBM nor the matrix
             # cores bound it: its vector stages (conv1 recomputed inside conv2: DESIGN 3.2) do; it is priced against the dense fp32 rate of the chip,
