@@ -235,3 +235,97 @@ def test_config3_megadepth_sizes_through_match_pairs_vs_oracle(xf, sd):
         assert rep["n_ref"] > 300, rep
     print("MEGADEPTH SIZES", [tuple(p) for p in want], hist)
     assert hist["pairs"] == len(want) and hist["differing"] <= 2 * len(want) and hist["kpt_exceptions"] <= 2 * len(want), hist
+
+
+def test_sampling_coordinates_at_every_megadepth_size_class(xf):
+    """the W + H coordinate re-verification "for any new resolution".  Every x in [0, W) and every y in [0, H) through xfh_sample_sparse (the kernel behind
+    InterpolateSparse2d, modules/interpolator.py:17-32) in its three modes -- nearest on the full-resolution map (the heat-map score), bilinear and bicubic on the 1/8
+    map (reliability, descriptors) -- at all 20 image sizes of the MegaDepth-1500 list at long side 1600 and at 608^2, 1312^2 and 576 x 800, against the oracle's explicit
+    fp32 samplers (oracle.sample_coords, pinned to F.grid_sample in tests/test_oracle_sampling.py).  The coordinate map is separable: one line of all x (three rows) and
+    one of all y (three columns) cover every quotient p / (S - 1) the resolution can produce.  Nearest must be IDENTICAL (a one-ulp difference in u flips the pixel)."""
+    from accelerated_features_amd import sharding
+    from accelerated_features_amd.interpolator import InterpolateSparse2d
+    sizes, _ = sharding.megadepth_pair_sizes()
+    classes = sorted({s for p in sizes for s in p}) + [(608, 608), (1312, 1312), (576, 800)]
+    assert len(classes) == 23
+    g = torch.Generator().manual_seed(9)
+    mods = {m: InterpolateSparse2d(m) for m in ("nearest", "bilinear", "bicubic")}
+    n_checked = 0
+    for (H, W) in classes:
+        xs, ys = torch.arange(W), torch.arange(H)
+        pos = torch.cat([torch.stack([xs, torch.full_like(xs, y0)], -1) for y0 in (0, H // 2 + 1, H - 1)] +
+                        [torch.stack([torch.full_like(ys, x0), ys], -1) for x0 in (0, W // 2 + 1, W - 1)])[None]      # (1, 3 W + 3 H, 2) int64
+        full = torch.randn(1, 1, H, W, generator=g)
+        coarse = torch.randn(1, 2, H // 8, W // 8, generator=g)
+        for mode, m, fn, tol in (("nearest", full, O.sample_nearest, 0.0), ("bilinear", coarse, O.sample_bilinear, 2e-6), ("bicubic", coarse, O.sample_bicubic, 5e-6)):
+            got = mods[mode](m.cuda(), pos.cuda(), H, W).cpu()[0]
+            want = fn(m[0], pos[0], H, W)
+            if tol == 0.0:
+                assert torch.equal(got, want), (H, W, mode, int((got != want).sum()))
+            else:
+                parity.assert_close(got, want, tol, f"{mode} at {H} x {W}")
+            n_checked += pos.shape[1]
+    print("SAMPLING COORDINATES", len(classes), "sizes", n_checked, "positions")
+
+
+def test_config3_every_frequent_megadepth_size_pair_keypoints_and_matches(xf, sd):
+    """test_config3_megadepth_sizes_through_match_pairs_vs_oracle takes the four most frequent size pairs through the whole pipeline; this one takes EVERY size pair with
+    at least 20 occurrences in the MegaDepth-1500 list at long side 1600 (14 pairs, 1128 of the 1500) through batching.match_pairs and checks, per image, the key-point
+    list against the oracle's detect_and_compute with the exception accounting -- the sizes differ in their 1/8-map shapes, column strips and tile remainders, which is
+    where a size-dependent kernel choice would show.  (The matcher is size-independent: its parity at these sizes is the first test's.)"""
+    _threads()
+    from collections import Counter
+    from accelerated_features_amd import sharding
+    sizes, _ = sharding.megadepth_pair_sizes()
+    want = [p for p, n in Counter(sizes).most_common() if n >= 20]
+    assert len(want) >= 12
+    classes = sorted({s for p in want for s in p})
+    big = (fixtures.texture_images(1, 1600, 1600, seed=33) * 255).round().clamp(0, 255).to(torch.uint8)[0]
+    hist = {"images": 0, "kpt_exceptions": 0}
+    for i, (h, w) in enumerate(classes):
+        img = torch.roll(big, (5 * i, 11 * i), (1, 2))[:, :h, :w].contiguous()
+        mine = xf.detectAndCompute(img[None].cuda(), top_k=4096)[0]
+        orc, st = O.detect_and_compute(sd, img[None].float(), top_k=4096, keep=True)
+        rep = parity.compare_keypoints(mine, orc[0], heat=st["heat"][0, 0])
+        assert rep["n_test"] == 4096 and rep["n_ref"] == 4096, ((h, w), rep)
+        hist["images"] += 1; hist["kpt_exceptions"] += rep["exceptions"]
+    print("MEGADEPTH SIZE CLASSES OF THE FREQUENT PAIRS", classes, hist)
+    assert hist["kpt_exceptions"] <= 2 * len(classes), hist
+
+
+def test_non_finite_pixels_stay_in_their_image(sd):
+    """include/xfeat_hip.h documents that a NaN / Inf input pixel is NOT propagated the way F.relu / torch.max propagate it in the reference (-fno-honor-nans units):
+    the image that holds it gets unspecified (possibly finite) results.  What must hold -- and is pinned here so that it cannot regress silently -- is CONFINEMENT: every
+    other image of the batch is bit-identical to the same batch without the bad pixel (instance normalisation, every convolution tile, NMS, top-k and the descriptor
+    gather are per image), the call returns, and the bad image's lists have the documented shapes.  An infinite activation may trip the fp16-pair range guard: the
+    model then repeats the call on its fp32-range kernels and stays there (a warning says so) -- the clean reference is taken from a model in the same state."""
+    import warnings
+    from accelerated_features_amd import XFeat
+    x = fixtures.texture_images(4, 96, 128, seed=77).cuda()
+    fell_back = []
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        m, ref = XFeat(weights=sd, top_k=300), XFeat(weights=sd, top_k=300)
+        y = x.clone()
+        y[2, :, 40, 57] = bad
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = m.detectAndCompute(y, top_k=300)
+        fb = m.net._options.get("fx") == 0
+        fell_back.append(fb)
+        if fb:                                                     # the same kernels for the clean run
+            ref.net.fx_range_exceeded(status=1)
+            assert ref.net._options.get("fx") == 0
+        clean = ref.detectAndCompute(x, top_k=300)
+        assert len(got) == 4
+        for b in (0, 1, 3):
+            for k in ("keypoints", "scores", "descriptors"):
+                assert torch.equal(got[b][k], clean[b][k]), (bad, b, k, fb)
+        n = got[2]["keypoints"].shape[0]
+        assert 0 <= n <= 300 and got[2]["scores"].shape == (n,) and got[2]["descriptors"].shape == (n, 64)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            again = m.detectAndCompute(x, top_k=300)               # nothing but the kernel choice sticks to the model
+        for b in range(4):
+            for k in ("keypoints", "scores", "descriptors"):
+                assert torch.equal(again[b][k], clean[b][k]), (bad, b, k, fb)
+    print("NON-FINITE PIXELS: fell back to the fp32-range kernels for (nan, +inf, -inf):", fell_back)
