@@ -363,10 +363,10 @@ __global__ __launch_bounds__(256, 4) void resize2_gray_stats_lds_kernel(const fl
         {
             R2Coef cf{0, 0, 0.f, 0.f};
             if (tid < R2_RH) {
-                if (tid < T.rh) { lin_coef(s1h, T.ym0 + tid, Hin, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 = (cf.i0 - T.iy_lo) * in_w; cf.i1 = (cf.i1 - T.iy_lo) * in_w; }
+                if (tid < T.rh) { lin_coef(s1h, T.ym0 + tid, Hin, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 = min(cf.i0 - T.iy_lo, T.nrow - 1) * in_w; cf.i1 = min(cf.i1 - T.iy_lo, T.nrow - 1) * in_w; }      // (min: never beyond the staged rows, whatever the host's fp32 sizing rounded to)
             } else if (tid < R2_RH + R2_RW) {
                 const int rx = tid - R2_RH;
-                if (rx < T.rw) { lin_coef(s1w, T.xm0 + rx, Win, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 -= T.ix_lo; cf.i1 -= T.ix_lo; }
+                if (rx < T.rw) { lin_coef(s1w, T.xm0 + rx, Win, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 = min(cf.i0 - T.ix_lo, 4 * T.nq - 1); cf.i1 = min(cf.i1 - T.ix_lo, 4 * T.nq - 1); }
             } else if (tid < R2_RH + R2_RW + R2_TH) {
                 const int oy = T.oy0 + tid - (R2_RH + R2_RW);
                 if (oy <= T.oy1) { lin_coef(s2h, oy, Hm, cf.i0, cf.i1, cf.l0, cf.l1); cf.i0 = (cf.i0 - T.ym0) * T.rw; cf.i1 = (cf.i1 - T.ym0) * T.rw; }
@@ -379,10 +379,10 @@ __global__ __launch_bounds__(256, 4) void resize2_gray_stats_lds_kernel(const fl
         Tile Tn = T;
         if (t + GS_CHUNKS < tiles) { Tn = tile_of(t + GS_CHUNKS); request(Tn); }
         __syncthreads();
-        const unsigned rw_magic = 0xffffffffu / (unsigned)T.rw + 1u;      // floor(e / rw) = umulhi(e, magic) for e < 2^16 (one division per tile instead of one per pixel)
+        const unsigned rw_magic = T.rw > 1 ? 0xffffffffu / (unsigned)T.rw + 1u : 0u;      // floor(e / rw) = umulhi(e, magic) for e < 2^16 (one division per tile instead of one per pixel)
         // stage 1: input -> intermediate grid from LDS, all channels of one region pixel per thread (coefficients computed once)
         for (int e = tid; e < rsz; e += 256) {
-            const int ry = (int)__umulhi((unsigned)e, rw_magic), rx = e - ry * T.rw;
+            const int ry = rw_magic ? (int)__umulhi((unsigned)e, rw_magic) : e, rx = e - ry * T.rw;      // (a one-column region: the magic number would overflow to 0)
             const R2Coef cy = tab[ry], cx = tab[R2_RH + rx];
             const float vy0 = cy.l0, vy1 = cy.l1, vx0 = cx.l0, vx1 = cx.l1;
             const int o00 = cy.i0 + cx.i0, o01 = cy.i0 + cx.i1, o10 = cy.i1 + cx.i0, o11 = cy.i1 + cx.i1;
