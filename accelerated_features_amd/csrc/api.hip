@@ -601,14 +601,20 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     CONV(L_BLOCK4_2, -1, w.x4b, H16, W16, w.x4c, false);
     CONV(L_BLOCK5_0, -1, w.x4c, H16, W16, w.x5a, false);
     CONV(L_BLOCK5_1, -1, w.x5a, H32, W32, w.x5b, false);
+    bool pyr_done = false;
     if ((h->opt.fx & XFH_FX_CONV64) && nw.conv[L_BLOCK5_2].w_rs && conv_rs128_fits(W32)) {
-        CONV(L_BLOCK5_2, -1, w.x5b, H32, W32, w.x5a, false);          // conv_rs64_kernel's 128-channel form holds a quarter of the couts per workgroup: the 1x1 (128 -> 64) runs on its own (x5a is free since block5.1)
-        CONV(L_BLOCK5_3, -1, w.x5a, H32, W32, w.x5d, false);
+        CONV(L_BLOCK5_2, -1, w.x5b, H32, W32, w.x5a, false);          // conv_rs64_kernel's 128-channel form holds a quarter of the couts per workgroup: the 1x1 (128 -> 64) is not fused into it (x5a is free since block5.1) ...
+        prof_begin(&h->prof, XFH_SPAN_PYRAMID, st);
+        pyr_done = launch_pyramid53(nw.conv[L_BLOCK5_3], w.x3c, w.x4c, w.x5a, w.pyr, B, H8, W8, H16, W16, H32, W32, st) == 0;      // ... but into the pyramid sum: x5 never reaches HBM
+        if (pyr_done) prof_end(&h->prof, XFH_SPAN_PYRAMID, st, 0, 0);
+        else CONV(L_BLOCK5_3, -1, w.x5a, H32, W32, w.x5d, false);      // (the span begun above is simply begun again below: prof_begin alone records nothing)
     } else
     CONV(L_BLOCK5_2, L_BLOCK5_3, w.x5b, H32, W32, w.x5d, false);      // 3x3 + fused 1x1 (128->64)
-    prof_begin(&h->prof, XFH_SPAN_PYRAMID, st);
-    launch_pyramid_sum(w.x3c, w.x4c, w.x5d, w.pyr, B * 64, H8, W8, H16, W16, H32, W32, st);
-    prof_end(&h->prof, XFH_SPAN_PYRAMID, st, 0, 0);
+    if (!pyr_done) {
+        prof_begin(&h->prof, XFH_SPAN_PYRAMID, st);
+        launch_pyramid_sum(w.x3c, w.x4c, w.x5d, w.pyr, B * 64, H8, W8, H16, W16, H32, W32, st);
+        prof_end(&h->prof, XFH_SPAN_PYRAMID, st, 0, 0);
+    }
     CONV(L_FUSION_0, -1, w.pyr, H8, W8, w.f0, false);
     CONV(L_FUSION_1, L_FUSION_2, w.f0, H8, W8, feats, true);          // 3x3 + fused 1x1 -> channels-last M1
 #undef CONV

@@ -573,6 +573,164 @@ __global__ __launch_bounds__(256) void pyramid_sum_kernel(const float* __restric
     }
 }
 
+// block5.3 (1x1 convolution 128 -> 64, BN folded, ReLU; modules/model.py:78) AND the pyramid sum (model.py:146-148) in one launch: x5 never reaches HBM and the 1x1 has no
+// launch of its own (as a kernel of its own on the f32 matrix cores it took 17 us per 64-frame step for 0.3 GFLOP -- a launch, a weight prologue and 19 200 positions).
+// One workgroup = CG consecutive output channels of one image: it computes ITS x5 planes from block5.2's 128-channel output straight into LDS, stages its x4 planes
+// beside them and then runs pyramid_sum_kernel's emit arithmetic over its CG x3 planes (contiguous in memory).  Every x5 plane is computed exactly once; the only
+// redundancy is that the 64 / CG workgroups of an image each read block5.2's output (153 KB at VGA, L2-resident).  The kernel is made of memory latencies, so every
+// phase keeps many independent loads in flight:
+//   1x1      K split over the four waves (wave w: input channels 32 w .. + 31, fp32 fma chain in ascending order; the CG x 128 weights by wave-uniform scalar loads from
+//            the [k][cout] image, two couts per v_pk_fma_f32), a lane owning positions lane + 64 j: P53_PP x 8 loads in flight per lane; the four partial sums meet in LDS
+//            (where the x4 planes go afterwards) and are added in the fixed order ((w0 + w1) + w2) + w3, then bias and ReLU;
+//   x4       requested into registers behind the 1x1, written to LDS behind the reduction;
+//   emit     batches of P53_NB float4 of x3, the next batch requested before the current one is interpolated.
+// Needs W3 % 4 == 0 and the planes to fit in LDS (launch_pyramid53 checks).
+constexpr int P53_PP = 5, P53_KB = 8, P53_NB = 6, P53_X4R = 20;
+template <int CG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 registers: four workgroups per CU = the whole VGA batch (1024 workgroups) in ONE round
+void pyramid53_kernel(const float* __restrict__ x3, const float* __restrict__ x4, const float* __restrict__ y5,
+                                                        const float* __restrict__ w53 /* [128][64] */, const float* __restrict__ b53, int relu53,
+                                                        float* __restrict__ out, int H3, int W3, int H4, int W4, int H5, int W5) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    static_assert(64 % CG == 0 && CG % 2 == 0, "channel groups");
+    constexpr int NG = 64 / CG;
+    const int b = blockIdx.x / NG, c0 = (blockIdx.x - b * NG) * CG, tid = threadIdx.x;
+    const int n3 = H3 * W3, n4 = H4 * W4, n5 = H5 * W5;
+    const int n4s = max(CG * n4, 4 * CG * n5);      // the x4 planes' region also holds the 1x1's four partial sums before
+    float* s4 = sm;                                 // [CG][n4]   (before: [wave 4][CG][n5])
+    float* s5 = sm + ((n4s + 3) & ~3);              // [CG][n5]
+    PyrCoef* tab = reinterpret_cast<PyrCoef*>(s5 + ((CG * n5 + 3) & ~3));
+    const size_t base3 = ((size_t)b * 64 + c0) * n3;
+    const int nq = CG * n3 / 4;                     // float4 of this workgroup's x3 / out planes (W3 % 4 == 0)
+    const float* p4g = x4 + ((size_t)b * 64 + c0) * n4;
+    // ---- block5.3, this wave's quarter of K: partial[wv][c][p] = sum_{k in quarter} w[k][c0 + c] y5[k][p]
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;      // (wave-uniform: the weights come by scalar loads)
+        const float* wq = w53 + (size_t)(32 * wv) * 64 + c0;
+        const float* yq = y5 + ((size_t)b * 128 + 32 * wv) * n5;
+        for (int p0 = 0; p0 < n5; p0 += 64 * P53_PP) {
+            float acc[P53_PP][CG];
+            int po[P53_PP];
+#pragma unroll
+            for (int j = 0; j < P53_PP; ++j) {
+                po[j] = min(p0 + ln + 64 * j, n5 - 1);          // (positions beyond the map: a copy of the last one, never stored)
+#pragma unroll
+                for (int c = 0; c < CG; ++c) acc[j][c] = 0.f;
+            }
+#pragma unroll 1
+            for (int k0 = 0; k0 < 32; k0 += P53_KB) {      // (rolled: unrolled, hipcc requests all 160 values at once -- 229 registers, two waves per SIMD)
+                float v[P53_KB][P53_PP];                        // P53_KB x P53_PP loads in flight, then their fmas (k ascending per position)
+#pragma unroll
+                for (int kk = 0; kk < P53_KB; ++kk)
+#pragma unroll
+                    for (int j = 0; j < P53_PP; ++j) v[kk][j] = yq[(size_t)(k0 + kk) * n5 + po[j]];
+#pragma unroll
+                for (int kk = 0; kk < P53_KB; ++kk)
+#pragma unroll
+                    for (int j = 0; j < P53_PP; ++j)
+#pragma unroll
+                        for (int c = 0; c < CG; ++c) acc[j][c] = fmaf(v[kk][j], wq[(k0 + kk) * 64 + c], acc[j][c]);
+            }
+#pragma unroll
+            for (int j = 0; j < P53_PP; ++j) {
+                const int p = p0 + ln + 64 * j;
+                if (p < n5) {
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) s4[(wv * CG + c) * n5 + p] = acc[j][c];
+                }
+            }
+        }
+    }
+    // the x4 planes (CG contiguous planes): requested now, written to LDS behind the reduction of the partial sums that occupy their place
+    float r4[P53_X4R];
+#pragma unroll
+    for (int k = 0; k < P53_X4R; ++k) {
+        const int e = tid + k * 256;
+        r4[k] = p4g[min(e, CG * n4 - 1)];
+    }
+    // ... and the first batch of x3 (both travel under the coefficient tables, the barriers and the reduction)
+    float4 cur[P53_NB];
+#pragma unroll
+    for (int k = 0; k < P53_NB; ++k) {
+        const int e4 = tid + k * 256;
+        cur[k] = *reinterpret_cast<const float4*>(x3 + base3 + 4 * (size_t)min(e4, nq - 1));      // (clamped, not branched: the requests leave back to back)
+    }
+    // interpolation coefficients of every output column / row (as pyramid_sum_kernel: the same operands, the same results)
+    {
+        const float s4y = (float)H4 / (float)H3, s4x = (float)W4 / (float)W3;
+        const float s5y = (float)H5 / (float)H3, s5x = (float)W5 / (float)W3;
+        for (int e = tid; e < 2 * (W3 + H3); e += 256) {
+            const int lv = e >= W3 + H3, r = e - lv * (W3 + H3);
+            PyrCoef c;
+            if (r < W3) lin_coef(lv ? s5x : s4x, r, lv ? W5 : W4, c.i0, c.i1, c.l0, c.l1);
+            else lin_coef(lv ? s5y : s4y, r - W3, lv ? H5 : H4, c.i0, c.i1, c.l0, c.l1);
+            tab[e] = c;
+        }
+    }
+    __syncthreads();
+    {   // the four partial sums in a fixed order, bias, ReLU -> the x5 planes
+        const float floor_y = relu53 ? 0.f : -INFINITY;
+        for (int e = tid; e < CG * n5; e += 256) {
+            const int c = e / n5;
+            const float sum = ((s4[e] + s4[CG * n5 + e]) + s4[2 * CG * n5 + e]) + s4[3 * CG * n5 + e];
+            s5[e] = fmaxf(sum + b53[c0 + c], floor_y);
+        }
+    }
+    __syncthreads();
+    // ---- the x4 planes take the partial sums' place
+#pragma unroll
+    for (int k = 0; k < P53_X4R; ++k) {
+        const int e = tid + k * 256;
+        if (e < CG * n4) s4[e] = r4[k];
+    }
+    for (int e = tid + P53_X4R * 256; e < CG * n4; e += 256) s4[e] = p4g[e];
+    __syncthreads();
+    auto emit = [&](int e4, const float4 v) {
+        const int eg = e4 * 4, pl = eg / n3, e = eg - pl * n3, oy = e / W3, ox = e - oy * W3;
+        const float* p4 = s4 + pl * n4;
+        const float* p5 = s5 + pl * n5;
+        const PyrCoef y4 = tab[W3 + oy], y5c = tab[W3 + H3 + W3 + oy];
+        const float vin[4] = {v.x, v.y, v.z, v.w};
+        float r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const PyrCoef c4 = tab[ox + k], c5 = tab[W3 + H3 + ox + k];
+            r[k] = (vin[k] + bilerp(p4, W4, y4.i0, y4.i1, c4.i0, c4.i1, y4.l0, y4.l1, c4.l0, c4.l1))
+                 + bilerp(p5, W5, y5c.i0, y5c.i1, c5.i0, c5.i1, y5c.l0, y5c.l1, c5.l0, c5.l1);
+        }
+        *reinterpret_cast<float4*>(out + base3 + eg) = make_float4(r[0], r[1], r[2], r[3]);
+    };
+    for (int q0 = 0; q0 < nq; q0 += P53_NB * 256) {
+        float4 nxt[P53_NB];
+#pragma unroll
+        for (int k = 0; k < P53_NB; ++k) {        // the next batch's requests travel under this batch's arithmetic
+            const int e4 = q0 + P53_NB * 256 + tid + k * 256;
+            nxt[k] = *reinterpret_cast<const float4*>(x3 + base3 + 4 * (size_t)min(e4, nq - 1));
+        }
+#pragma unroll
+        for (int k = 0; k < P53_NB; ++k) {
+            const int e4 = q0 + tid + k * 256;
+            if (e4 < nq) emit(e4, cur[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < P53_NB; ++k) cur[k] = nxt[k];
+    }
+}
+
+constexpr int PYR53_CG = 4;
+// -1: not this kernel's case (the caller runs block5.3 and launch_pyramid_sum)
+int launch_pyramid53(const ConvW& c53, const float* x3, const float* x4, const float* y5, float* out, int B,
+                     int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st) {
+    if (c53.ks != 1 || c53.cin != 128 || c53.cout != 64 || c53.cout_pad != 64 || !c53.w_kcp || (W3 & 3)) return -1;
+    const size_t n4s = std::max((size_t)PYR53_CG * H4 * W4, (size_t)4 * PYR53_CG * H5 * W5);      // the x4 planes' region holds the 1x1's four partial sums first
+    const size_t lds = (((n4s + 3) & ~(size_t)3) + (((size_t)PYR53_CG * H5 * W5 + 3) & ~(size_t)3)) * sizeof(float) + 2 * (size_t)(W3 + H3) * sizeof(PyrCoef);
+    if (lds > 64 * 1024 || (size_t)PYR53_CG * H3 * W3 >= (1u << 30)) return -1;
+    static AttrMask attr = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(pyramid53_kernel<PYR53_CG>), 64 * 1024, attr);
+    pyramid53_kernel<PYR53_CG><<<B * (64 / PYR53_CG), 256, lds, st>>>(x3, x4, y5, c53.w_kcp, c53.bias, c53.relu, out, H3, W3, H4, W4, H5, W5);
+    return 0;
+}
+
 void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int planes,
                         int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st) {
     const size_t lds = ((((size_t)H4 * W4 + (size_t)H5 * W5 + 3) & ~(size_t)3) * sizeof(float)) + 2 * (size_t)(W3 + H3) * sizeof(PyrCoef);      // planes + coefficient tables

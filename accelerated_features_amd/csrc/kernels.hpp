@@ -65,6 +65,8 @@ void launch_gray_norm_u8(const unsigned char* img, bool nhwc, float divisor, int
                          float* coef, hipStream_t st);
 void launch_resize_bilinear(const float* src, int planes, int Hin, int Win, float* dst, int Hout, int Wout,
                             float sh, float sw, hipStream_t st);
+int launch_pyramid53(const ConvW& c53, const float* x3, const float* x4, const float* y5, float* out, int B,
+                     int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st);      // block5.3 + the pyramid sum in one launch; -1: not this kernel's case
 void launch_pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int planes,
                         int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st);
 

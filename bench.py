@@ -287,7 +287,11 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=1 | 2 | 8 | 2048, blo
         conv_row(n_, f"conv_rs64_kernel<0{', 128' if ch == 128 else ''}> ({n_})", 4.0 * 2 * ch * px[sc], conv_flops(n_, px[sc]), 3, c64)
     fl1 = conv_flops("block5.3", px["32"])
     add(100 + ci["block5.3"], "conv_mfma_kernel<128,64,1x1> (block5.3)", 4.0 * (128 + 64) * px["32"], fl1, fl1, f32, F32P)
-    add(201, "pyramid_sum_kernel (x3 + up(x4) + up(x5))", 4.0 * 64 * (2 * px["8"] + px["16"] + px["32"]), 3.0 * 64 * px["8"], 3.0 * 64 * px["8"], 0, "valu")
+    if spans_us.get(100 + ci["block5.3"]):      # block5.3 ran as a launch of its own (fp32-range fallback path): the pyramid sum reads its x5
+        add(201, "pyramid_sum_kernel (x3 + up(x4) + up(x5))", 4.0 * 64 * (2 * px["8"] + px["16"] + px["32"]), 3.0 * 64 * px["8"], 3.0 * 64 * px["8"], 0, "valu")
+    else:                                       # the default: block5.3 inside the pyramid sum (reads block5.2's 128 channels instead of x5; + the 1x1's FLOPs on the vector ALUs)
+        add(201, "pyramid53_kernel (block5.3's 1x1 fused in: x3 + up(x4) + up(relu(W y5 + b)))", 4.0 * (64 * (2 * px["8"] + px["16"]) + 128 * px["32"]),
+            3.0 * 64 * px["8"] + fl1, 3.0 * 64 * px["8"] + fl1, f32, "fp32 valu (v_pk_fma_f32)")
     fl_rel = 2.0 * (2 * 64 * 64 + 64) * px["8"]
     fl_kp = 2.0 * (3 * 64 * 64 + 64 * 65) * px["8"]
     fl_kp_mx = 2.0 * (3 * 64 * 64 + 64 * 64) * px["8"]      # (the dustbin logit is a vector dot product)

@@ -39,7 +39,7 @@ def bins():
                       ("pyramid_slice.hpp", sliced._slice_pyramid), ("gray_slice.hpp", sliced._slice_gray)):
         open(os.path.join(td, fname), "w").write(fn())
     out = Bins()
-    for name in ("block1_emu", "head_emu", "conv_bx24_emu", "conv_bx64s2_emu", "conv_rs64_emu", "pyramid_emu", "gray_emu"):
+    for name in ("block1_emu", "head_emu", "conv_bx24_emu", "conv_bx64s2_emu", "conv_rs64_emu", "pyramid53_emu", "gray_emu"):
         out.append(os.path.join(td, name))
         out.by_name[name] = out[-1]
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", os.path.join(ROOT, "accelerated_features_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "emu"),
@@ -128,8 +128,8 @@ def conv_emu(bins, kind, hdr, x, tensors, shape, cl=False, status=True):
 def rest_of_backbone_emulated(bins, sd, x1):
     """block2 .. block_fusion.2 on the kernels the backbone routes the bench batch to by default: the 24-channel
     layers on conv_bx_kernel / conv_bxs2_kernel, every 64 -> 64 3x3 layer on conv_rs64_kernel (weights resident in registers; block3.1 + 3.2 and block_fusion.1 + .2
-    with the trailing 1x1 fused, the latter channels-last), block5.1 / 5.2 on its 128-channel form, block4.0 / block5.0 on conv_bx64s2x_kernel -- 16 of the 17 convolution
-    layers, pyramid_sum_kernel between them; block5.3 (a 1x1 of its own on the f32 matrix cores) stays with the oracle.  Every kernel's range flag must stay clear on the fixtures."""
+    with the trailing 1x1 fused, the latter channels-last), block5.1 / 5.2 on its 128-channel form, block4.0 / block5.0 on conv_bx64s2x_kernel -- block5.3 inside pyramid53_kernel
+    (the pyramid sum with the 1x1 fused in): all 17 convolution layers.  Every kernel's range flag must stay clear on the fixtures."""
     B, _, H4, W4 = x1.shape
     H8, W8, H16, W16, H32, W32 = H4 // 2, W4 // 2, H4 // 4, W4 // 4, H4 // 8, W4 // 8
     a = conv_emu(bins, "conv_bx24_emu", [B, H4, W4, 1, 1, 5], x1, list(fold(sd, "block2.0")), (B, 24, H4, W4))
@@ -143,8 +143,8 @@ def rest_of_backbone_emulated(bins, sd, x1):
     x5 = conv_emu(bins, "conv_bx64s2_emu", [B, H16, W16, 128, 1, 2], x4, list(fold(sd, "block5.0")), (B, 128, H32, W32))
     x5 = conv_emu(bins, "conv_rs64_emu", [B, H32, W32, 1, 2, 0, 128, 0], x5, list(fold(sd, "block5.1")), (B, 128, H32, W32))
     x5 = conv_emu(bins, "conv_rs64_emu", [B, H32, W32, 1, 1, 0, 128, 0], x5, list(fold(sd, "block5.2")), (B, 128, H32, W32))
-    x5 = O._basic(sd, "block5.3", x5, 1, 1)
-    f = conv_emu(bins, "pyramid_emu", [B * 64, H8, W8, H16, W16, H32, W32, 1], x3, [x4, x5], (B, 64, H8, W8), status=False)      # pyramid_sum_kernel (sliced, shipped)
+    w53, b53 = fold(sd, "block5.3")
+    f = conv_emu(bins, "pyramid53_emu", [B, H8, W8, H16, W16, H32, W32, 1], x3, [x4, x5, w53.view(64, 128).t().contiguous(), b53], (B, 64, H8, W8), status=False)      # pyramid53_kernel (sliced, shipped): block5.3 + the pyramid sum
     f = conv_emu(bins, "conv_rs64_emu", [B, H8, W8, 1, 3, 0, 0, 0], f, list(fold(sd, "block_fusion.0")), (B, 64, H8, W8))
     return conv_emu(bins, "conv_rs64_emu", [B, H8, W8, 1, 3, 0, 2, 0], f, list(fold(sd, "block_fusion.1")) + [sd["block_fusion.2.weight"].view(64, 64).float(), sd["block_fusion.2.bias"].float()],
                     (B, 64, H8, W8), cl=True)

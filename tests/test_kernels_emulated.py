@@ -34,8 +34,9 @@ def _slice_pyramid():
     """pyramid_sum_kernel (x3 + up(x4) + up(x5): source planes and per-plane coefficient tables in LDS) with the interpolation helpers it shares with the resize kernels"""
     t = open(os.path.join(CSRC, "k_preproc.hip")).read()
     s = _between(t, "__device__ inline void lin_coef(", "__global__ __launch_bounds__(256) void resize_bilinear_kernel(")
-    s += _between(t, "__device__ inline float bilerp_at(", "void launch_pyramid_sum(")
+    s += _between(t, "__device__ inline float bilerp_at(", "constexpr int PYR53_CG = ")      # pyramid_sum_kernel and pyramid53_kernel (block5.3 fused in)
     s = _must_sub(s, "__global__ __launch_bounds__(256) void pyramid_sum_kernel(", "inline void pyramid_sum_kernel(")
+    s = _must_sub(s, "__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))", "inline")
     s = _must_sub(s, "extern __shared__ __attribute__((aligned(16))) float sm[];", "XFH_DYN_LDS(sm);")
     assert "asm volatile" not in s and "<<<" not in s
     return s
@@ -132,7 +133,7 @@ def emu_bins():
     open(os.path.join(td, "weight_split_slice.hpp"), "w").write(_slice_weight_split())
     open(os.path.join(td, "bx_split_slice.hpp"), "w").write(_slice_bx_split())
     out = {}
-    for name in ("conv_bx24_emu", "pyramid_emu", "gray_emu", "resize2_emu", "match_sweep_emu"):
+    for name in ("conv_bx24_emu", "pyramid_emu", "pyramid53_emu", "gray_emu", "resize2_emu", "match_sweep_emu"):
         out[name] = os.path.join(td, name)
         subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", td, "-I", EMU, os.path.join(EMU, name + ".cpp"), "-o", out[name]], check=True)
     return out
@@ -176,6 +177,28 @@ def test_pyramid_sum_kernel_on_the_host(emu_bins, shape, use_lds):
     d = np.abs(y - ref.numpy())
     print(f"pyramid_sum {shape} lds {use_lds}: max |err| {d.max():.3g}")
     assert np.isfinite(y).all() and d.max() <= 2e-6
+
+
+@pytest.mark.parametrize("shape", [(1, 60, 80), (2, 12, 16), (1, 36, 44), (1, 9, 12)])
+def test_pyramid53_kernel_on_the_host(emu_bins, shape):
+    """block5.3 (1x1, 128 -> 64, BN folded, ReLU) fused into the pyramid sum (pyramid53_kernel: the default path's form; modules/model.py:78,146-148): x3 + up(x4) +
+    up(relu(W y5 + b)) against ATen in float64 -- VGA's maps, small ones, a 1/32 map with more positions than threads' first pass covers only partly (36 x 44 -> 9 x 11),
+    odd 1/16 and 1/32 sizes; every output channel group of every image."""
+    B, H3, W3 = shape
+    H4, W4, H5, W5 = (H3 + 1) // 2, (W3 + 1) // 2, (H3 + 3) // 4, (W3 + 3) // 4
+    g = torch.Generator().manual_seed(H3 * W3 + 1)
+    x3, x4 = torch.randn(B, 64, H3, W3, generator=g), torch.randn(B, 64, H4, W4, generator=g)
+    y5 = torch.randn(B, 128, H5, W5, generator=g)
+    w = torch.randn(64, 128, generator=g) * 0.1
+    bias = torch.randn(64, generator=g) * 0.3
+    out = subprocess.run([emu_bins["pyramid53_emu"]], input=_blob([B, H3, W3, H4, W4, H5, W5, 1], [x3, x4, y5, w.t().contiguous(), bias]), capture_output=True, check=True, timeout=400).stdout
+    F = torch.nn.functional
+    x5 = torch.relu(torch.einsum("ok,bkhw->bohw", w.double(), y5.double()) + bias.double()[None, :, None, None])
+    ref = x3.double() + F.interpolate(x4.double(), (H3, W3), mode="bilinear") + F.interpolate(x5, (H3, W3), mode="bilinear")
+    y = np.frombuffer(out, np.float32).reshape(B, 64, H3, W3)
+    d = np.abs(y - ref.numpy())
+    print(f"pyramid53 {shape}: max |err| {d.max():.3g}, max |x5| {float(x5.abs().max()):.3g}")
+    assert np.isfinite(y).all() and d.max() <= 4e-6
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 96, 128), (1, 1, 64, 96), (2, 2, 32, 40), (1, 3, 480, 640)])

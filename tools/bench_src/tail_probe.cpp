@@ -27,11 +27,11 @@ static std::vector<float> rnd(size_t n, unsigned seed, float lo, float hi) {
 
 static const char* span_name(int id) {
     static const char* conv[] = {"skip1", "block1.0", "block1.1", "block1.2", "block1.3", "block2.0", "block2.1", "block3.0", "block3.1(+.2)", "block3.2", "block4.0", "block4.1", "block4.2",
-                                 "block5.0", "block5.1", "block5.2", "block5.3", "block_fusion.0", "block_fusion.1(+.2)", "block_fusion.2"};
+                                 "block5.0", "block5.1", "block5.2", "block5.3 (own launch)", "block_fusion.0", "block_fusion.1(+.2)", "block_fusion.2"};
     switch (id) {
         case 3: return "block1";
         case 200: return "gray_stats + coef";
-        case 201: return "pyramid_sum";
+        case 201: return "pyramid (+ block5.3)";
         case 202: return "head rel";
         case 203: return "head kp";
         case 220: return "match memset";
