@@ -445,6 +445,9 @@ class XFeat(nn.Module):
                 break
             cap = min(hw, max(ncmax, 2 * cap))                   # plateau image: exact re-run with room
         nv = cnt[0].tolist()
+        K = kpts.shape[1]
+        if min(nv) == K:            # every image filled its top_k (the usual case): three unbind calls instead of 3 B slicing calls (0.2 ms of Python per 64-frame batch)
+            return [{'keypoints': k, 'scores': s, 'descriptors': d} for k, s, d in zip(kpts.unbind(0), scores.unbind(0), desc.unbind(0))]
         return [{'keypoints': kpts[b, :nv[b]], 'scores': scores[b, :nv[b]], 'descriptors': desc[b, :nv[b]]}
                 for b in range(len(nv))]
 
