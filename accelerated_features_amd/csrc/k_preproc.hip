@@ -172,6 +172,10 @@ __device__ inline float bilerp(const float* __restrict__ p, int Win, int y0, int
     const float v10 = p[y1 * Win + x0], v11 = p[y1 * Win + x1];
     return wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
 }
+// the same expression on values a caller has fetched itself (pyramid53_kernel's exact-x2 / x4 path: one row window per float4 instead of four taps per pixel)
+__device__ inline float bilerp_vals(float v00, float v01, float v10, float v11, float wy0, float wy1, float wx0, float wx1) {
+    return wy0 * (wx0 * v00 + wx1 * v01) + wy1 * (wx0 * v10 + wx1 * v11);
+}
 
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ src, int Hin, int Win,
                                                               float* __restrict__ dst, int Hout, int Wout,
@@ -590,7 +594,7 @@ template <int CG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))      // 128 registers: four workgroups per CU = the whole VGA batch (1024 workgroups) in ONE round
 void pyramid53_kernel(const float* __restrict__ x3, const float* __restrict__ x4, const float* __restrict__ y5,
                                                         const float* __restrict__ w53 /* [128][64] */, const float* __restrict__ b53, int relu53,
-                                                        float* __restrict__ out, int H3, int W3, int H4, int W4, int H5, int W5) {
+                                                        float* __restrict__ out, int H3, int W3, int H4, int W4, int H5, int W5, int generic_taps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     static_assert(64 % CG == 0 && CG % 2 == 0, "channel groups");
     constexpr int NG = 64 / CG;
@@ -600,6 +604,10 @@ void pyramid53_kernel(const float* __restrict__ x3, const float* __restrict__ x4
     float* s4 = sm;                                 // [CG][n4]   (before: [wave 4][CG][n5])
     float* s5 = sm + ((n4s + 3) & ~3);              // [CG][n5]
     PyrCoef* tab = reinterpret_cast<PyrCoef*>(s5 + ((CG * n5 + 3) & ~3));
+    float2* wx = reinterpret_cast<float2*>(tab + 2 * (W3 + H3));      // [level 2][W3] column weights {l0, l1} alone: four consecutive columns = two 16-byte reads
+    // the backbone's maps are exact halves / quarters of each other: a float4 of outputs then needs the SAME four columns of an x4 row and three of an x5 row
+    // whatever the pixel (the border cases fall out of clamped column indices: a tap the table weights with 0 may be fetched from the neighbouring column)
+    const bool exact = !generic_taps && H3 == 2 * H4 && W3 == 2 * W4 && H3 == 4 * H5 && W3 == 4 * W5;
     const size_t base3 = ((size_t)b * 64 + c0) * n3;
     const int nq = CG * n3 / 4;                     // float4 of this workgroup's x3 / out planes (W3 % 4 == 0)
     const float* p4g = x4 + ((size_t)b * 64 + c0) * n4;
@@ -665,6 +673,7 @@ void pyramid53_kernel(const float* __restrict__ x3, const float* __restrict__ x4
             if (r < W3) lin_coef(lv ? s5x : s4x, r, lv ? W5 : W4, c.i0, c.i1, c.l0, c.l1);
             else lin_coef(lv ? s5y : s4y, r - W3, lv ? H5 : H4, c.i0, c.i1, c.l0, c.l1);
             tab[e] = c;
+            if (r < W3) wx[lv * W3 + r] = make_float2(c.l0, c.l1);
         }
     }
     __syncthreads();
@@ -700,6 +709,28 @@ void pyramid53_kernel(const float* __restrict__ x3, const float* __restrict__ x4
         }
         *reinterpret_cast<float4*>(out + base3 + eg) = make_float4(r[0], r[1], r[2], r[3]);
     };
+    // exact x2 / x4 maps: per float4 two row coefficients, four 16-byte reads of column weights, 3 + 3 reads per x4 / x5 row (the generic form: 10 + 32 reads)
+    auto emit_exact = [&](int e4, const float4 v) {
+        const int eg = e4 * 4, pl = eg / n3, e = eg - pl * n3, oy = e / W3, ox = e - oy * W3, q = ox >> 2;
+        const PyrCoef y4 = tab[W3 + oy], y5c = tab[W3 + H3 + W3 + oy];
+        const float4 wa = *reinterpret_cast<const float4*>(wx + ox), wb = *reinterpret_cast<const float4*>(wx + ox + 2);                  // x4: {l0, l1} of pixels 0, 1 | 2, 3
+        const float4 wc = *reinterpret_cast<const float4*>(wx + W3 + ox), wd = *reinterpret_cast<const float4*>(wx + W3 + ox + 2);        // x5
+        const float* r40 = s4 + pl * n4 + y4.i0 * W4;
+        const float* r41 = s4 + pl * n4 + y4.i1 * W4;
+        const int cl = max(2 * q - 1, 0), cr = min(2 * q + 2, W4 - 1);
+        const float a00 = r40[cl], a03 = r40[cr], a10 = r41[cl], a13 = r41[cr];
+        const float2 a0m = *reinterpret_cast<const float2*>(r40 + 2 * q), a1m = *reinterpret_cast<const float2*>(r41 + 2 * q);
+        const float* r50 = s5 + pl * n5 + y5c.i0 * W5;
+        const float* r51 = s5 + pl * n5 + y5c.i1 * W5;
+        const int dl = max(q - 1, 0), dr = min(q + 1, W5 - 1);
+        const float b00 = r50[dl], b01 = r50[q], b02 = r50[dr], b10 = r51[dl], b11 = r51[q], b12 = r51[dr];
+        float4 r;
+        r.x = (v.x + bilerp_vals(a00, a0m.x, a10, a1m.x, y4.l0, y4.l1, wa.x, wa.y)) + bilerp_vals(b00, b01, b10, b11, y5c.l0, y5c.l1, wc.x, wc.y);
+        r.y = (v.y + bilerp_vals(a0m.x, a0m.y, a1m.x, a1m.y, y4.l0, y4.l1, wa.z, wa.w)) + bilerp_vals(b00, b01, b10, b11, y5c.l0, y5c.l1, wc.z, wc.w);
+        r.z = (v.z + bilerp_vals(a0m.x, a0m.y, a1m.x, a1m.y, y4.l0, y4.l1, wb.x, wb.y)) + bilerp_vals(b01, b02, b11, b12, y5c.l0, y5c.l1, wd.x, wd.y);
+        r.w = (v.w + bilerp_vals(a0m.y, a03, a1m.y, a13, y4.l0, y4.l1, wb.z, wb.w)) + bilerp_vals(b01, b02, b11, b12, y5c.l0, y5c.l1, wd.z, wd.w);
+        *reinterpret_cast<float4*>(out + base3 + eg) = r;
+    };
     for (int q0 = 0; q0 < nq; q0 += P53_NB * 256) {
         float4 nxt[P53_NB];
 #pragma unroll
@@ -710,7 +741,7 @@ void pyramid53_kernel(const float* __restrict__ x3, const float* __restrict__ x4
 #pragma unroll
         for (int k = 0; k < P53_NB; ++k) {
             const int e4 = q0 + tid + k * 256;
-            if (e4 < nq) emit(e4, cur[k]);
+            if (e4 < nq) { if (exact) emit_exact(e4, cur[k]); else emit(e4, cur[k]); }
         }
 #pragma unroll
         for (int k = 0; k < P53_NB; ++k) cur[k] = nxt[k];
@@ -723,11 +754,11 @@ int launch_pyramid53(const ConvW& c53, const float* x3, const float* x4, const f
                      int H3, int W3, int H4, int W4, int H5, int W5, hipStream_t st) {
     if (c53.ks != 1 || c53.cin != 128 || c53.cout != 64 || c53.cout_pad != 64 || !c53.w_kcp || (W3 & 3)) return -1;
     const size_t n4s = std::max((size_t)PYR53_CG * H4 * W4, (size_t)4 * PYR53_CG * H5 * W5);      // the x4 planes' region holds the 1x1's four partial sums first
-    const size_t lds = (((n4s + 3) & ~(size_t)3) + (((size_t)PYR53_CG * H5 * W5 + 3) & ~(size_t)3)) * sizeof(float) + 2 * (size_t)(W3 + H3) * sizeof(PyrCoef);
+    const size_t lds = (((n4s + 3) & ~(size_t)3) + (((size_t)PYR53_CG * H5 * W5 + 3) & ~(size_t)3)) * sizeof(float) + 2 * (size_t)(W3 + H3) * sizeof(PyrCoef) + 2 * (size_t)W3 * sizeof(float2);
     if (lds > 64 * 1024 || (size_t)PYR53_CG * H3 * W3 >= (1u << 30)) return -1;
     static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(pyramid53_kernel<PYR53_CG>), 64 * 1024, attr);
-    pyramid53_kernel<PYR53_CG><<<B * (64 / PYR53_CG), 256, lds, st>>>(x3, x4, y5, c53.w_kcp, c53.bias, c53.relu, out, H3, W3, H4, W4, H5, W5);
+    pyramid53_kernel<PYR53_CG><<<B * (64 / PYR53_CG), 256, lds, st>>>(x3, x4, y5, c53.w_kcp, c53.bias, c53.relu, out, H3, W3, H4, W4, H5, W5, 0);
     return 0;
 }
 

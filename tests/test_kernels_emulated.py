@@ -199,6 +199,10 @@ def test_pyramid53_kernel_on_the_host(emu_bins, shape):
     d = np.abs(y - ref.numpy())
     print(f"pyramid53 {shape}: max |err| {d.max():.3g}, max |x5| {float(x5.abs().max()):.3g}")
     assert np.isfinite(y).all() and d.max() <= 4e-6
+    # exact halves / quarters run the row-window form of the interpolation: bit for bit what the table-driven taps give (same operands, same expression)
+    out_g = subprocess.run([emu_bins["pyramid53_emu"]], input=_blob([B, H3, W3, H4, W4, H5, W5, 1 | 2], [x3, x4, y5, w.t().contiguous(), bias]), capture_output=True, check=True, timeout=400).stdout
+    assert np.array_equal(np.frombuffer(out_g, np.float32).view(np.uint32), np.frombuffer(out, np.float32).view(np.uint32)) or \
+        np.array_equal(np.frombuffer(out_g, np.float32), np.frombuffer(out, np.float32))       # (a zero's sign may differ where a zero-weighted tap comes from the neighbouring column)
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 96, 128), (1, 1, 64, 96), (2, 2, 32, 40), (1, 3, 480, 640)])
