@@ -671,7 +671,10 @@ void pyramid53_kernel(const float* __restrict__ x3, const float* __restrict__ x4
             const int lv = e >= W3 + H3, r = e - lv * (W3 + H3);
             PyrCoef c;
             if (r < W3) lin_coef(lv ? s5x : s4x, r, lv ? W5 : W4, c.i0, c.i1, c.l0, c.l1);
-            else lin_coef(lv ? s5y : s4y, r - W3, lv ? H5 : H4, c.i0, c.i1, c.l0, c.l1);
+            else {
+                lin_coef(lv ? s5y : s4y, r - W3, lv ? H5 : H4, c.i0, c.i1, c.l0, c.l1);
+                if (exact) { c.i0 *= lv ? W5 : W4; c.i1 *= lv ? W5 : W4; }      // (the row-window form reads ROW OFFSETS here: one multiplication per table entry instead of four per float4)
+            }
             tab[e] = c;
             if (r < W3) wx[lv * W3 + r] = make_float2(c.l0, c.l1);
         }
@@ -710,18 +713,24 @@ void pyramid53_kernel(const float* __restrict__ x3, const float* __restrict__ x4
         *reinterpret_cast<float4*>(out + base3 + eg) = make_float4(r[0], r[1], r[2], r[3]);
     };
     // exact x2 / x4 maps: per float4 two row coefficients, four 16-byte reads of column weights, 3 + 3 reads per x4 / x5 row (the generic form: 10 + 32 reads)
+    // (plane and row of a float4 by reciprocal multiplication: e4 < 2^18, launch_pyramid53 -- the quotient is off an integer by >= 1 / (2 W3), the product by < 1e-3 of that)
+    const float inv_nq3 = 4.f / (float)n3, inv_w4 = 4.f / (float)W3;
+    const int n3q = n3 >> 2, w3q = W3 >> 2;
     auto emit_exact = [&](int e4, const float4 v) {
-        const int eg = e4 * 4, pl = eg / n3, e = eg - pl * n3, oy = e / W3, ox = e - oy * W3, q = ox >> 2;
+        const int pl = (int)(((float)e4 + 0.5f) * inv_nq3), f4 = e4 - __mul24(pl, n3q);      // float4 index inside the plane  (24-bit multiplications: full rate, every factor is below 2^20)
+        const int oy = (int)(((float)f4 + 0.5f) * inv_w4), q = f4 - __mul24(oy, w3q), ox = 4 * q, eg = 4 * e4;
         const PyrCoef y4 = tab[W3 + oy], y5c = tab[W3 + H3 + W3 + oy];
         const float4 wa = *reinterpret_cast<const float4*>(wx + ox), wb = *reinterpret_cast<const float4*>(wx + ox + 2);                  // x4: {l0, l1} of pixels 0, 1 | 2, 3
         const float4 wc = *reinterpret_cast<const float4*>(wx + W3 + ox), wd = *reinterpret_cast<const float4*>(wx + W3 + ox + 2);        // x5
-        const float* r40 = s4 + pl * n4 + y4.i0 * W4;
-        const float* r41 = s4 + pl * n4 + y4.i1 * W4;
+        const float* p4 = s4 + __mul24(pl, n4);
+        const float* r40 = p4 + y4.i0;             // (row offsets: see the table)
+        const float* r41 = p4 + y4.i1;
         const int cl = max(2 * q - 1, 0), cr = min(2 * q + 2, W4 - 1);
         const float a00 = r40[cl], a03 = r40[cr], a10 = r41[cl], a13 = r41[cr];
         const float2 a0m = *reinterpret_cast<const float2*>(r40 + 2 * q), a1m = *reinterpret_cast<const float2*>(r41 + 2 * q);
-        const float* r50 = s5 + pl * n5 + y5c.i0 * W5;
-        const float* r51 = s5 + pl * n5 + y5c.i1 * W5;
+        const float* p5 = s5 + __mul24(pl, n5);
+        const float* r50 = p5 + y5c.i0;
+        const float* r51 = p5 + y5c.i1;
         const int dl = max(q - 1, 0), dr = min(q + 1, W5 - 1);
         const float b00 = r50[dl], b01 = r50[q], b02 = r50[dr], b10 = r51[dl], b11 = r51[q], b12 = r51[dr];
         float4 r;
@@ -755,7 +764,7 @@ int launch_pyramid53(const ConvW& c53, const float* x3, const float* x4, const f
     if (c53.ks != 1 || c53.cin != 128 || c53.cout != 64 || c53.cout_pad != 64 || !c53.w_kcp || (W3 & 3)) return -1;
     const size_t n4s = std::max((size_t)PYR53_CG * H4 * W4, (size_t)4 * PYR53_CG * H5 * W5);      // the x4 planes' region holds the 1x1's four partial sums first
     const size_t lds = (((n4s + 3) & ~(size_t)3) + (((size_t)PYR53_CG * H5 * W5 + 3) & ~(size_t)3)) * sizeof(float) + 2 * (size_t)(W3 + H3) * sizeof(PyrCoef) + 2 * (size_t)W3 * sizeof(float2);
-    if (lds > 64 * 1024 || (size_t)PYR53_CG * H3 * W3 >= (1u << 30)) return -1;
+    if (lds > 64 * 1024 || (size_t)PYR53_CG * H3 * W3 >= (1u << 20)) return -1;      // (the kernel's index arithmetic: float4 indices below 2^18)
     static AttrMask attr = 0;
     set_max_dynamic_lds(reinterpret_cast<const void*>(pyramid53_kernel<PYR53_CG>), 64 * 1024, attr);
     pyramid53_kernel<PYR53_CG><<<B * (64 / PYR53_CG), 256, lds, st>>>(x3, x4, y5, c53.w_kcp, c53.bias, c53.relu, out, H3, W3, H4, W4, H5, W5, 0);

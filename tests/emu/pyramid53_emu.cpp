@@ -6,6 +6,7 @@
 #include <algorithm>
 using std::min;
 using std::max;
+inline int __mul24(int a, int b) { return a * b; }      // (v_mul_i32_i24: the kernel keeps both factors below 2^23)
 namespace xfh {
 #include "pyramid_slice.hpp"
 }

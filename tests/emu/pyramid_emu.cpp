@@ -5,6 +5,7 @@
 #include <algorithm>
 using std::min;
 using std::max;
+inline int __mul24(int a, int b) { return a * b; }
 namespace xfh {
 #include "pyramid_slice.hpp"
 }
