@@ -11,6 +11,7 @@
 // counts; ordering uses wave ballots + block scans (row-major order is preserved).
 #include "../../include/xfeat_hip.h"
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace xfh {
 
@@ -77,6 +78,86 @@ __global__ __launch_bounds__(256) void nms_flags_kernel(const float* __restrict_
             mask[o] = bal;
             wcount[o] = __popcll(bal);
         }
+    }
+}
+
+// Round 6: the same kernel for thr >= 0 (the hot path: detection_threshold 0.05), in 40 % of the vector instructions -- the PMC said the kernel above is bound by them (VALU
+// active 93 % of its cycles, 51 instructions per 64-pixel row: canonicalising v_max pairs instead of v_max3, 260 v_readlane / v_writelane per wave of SPILLED scalars -- the
+// per-row image-border masks --, a value select behind every load, a DPP move + a copy per shift).  What changes:
+//   * a pixel outside the image may read as 0 instead of -inf: a candidate is > thr >= 0, so a zero in its window never equals it and never exceeds it -- the flags are
+//     the same for ANY input values.  Rows outside the image are then simply out of the buffer's range (the hardware returns 0), columns outside carry an out-of-range
+//     offset: no mask, no select, one address add per load;
+//   * the halo columns sit in lanes 0, 1 (x0 - 2, x0 - 1) and 62, 63 (x0 + 64, x0 + 65); their contribution to lanes 0 / 1 / 62 / 63 is two DPP-shifted maxima
+//     and a select, without read-lanes;
+//   * the horizontal maximum is four v_max_f32 with a wave_shr:1 / wave_shl:1 operand (lanes beyond the wave read 0) on top of the vertical v_max3 pair;
+//   * lane r collects row r's ballot: two stores per wave instead of two per row.
+__device__ inline float vmax3(float a, float b, float c) {      // (no canonicalisation: the operands are plain loads; a NaN pixel is unspecified anyway, xfeat_hip.h)
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// the horizontal part of one row in ONE statement (the hazard rules of DPP operands -- a register a vector instruction wrote is readable by a DPP operand two
+// instructions later -- are kept by the order inside it; the compiler does not look into it): in: vm, hm; out: u = max over columns x - 2 .. x, w = x .. x + 2 (lanes
+// beyond the wave read 0), hm = the halo columns' part for lanes 0, 1 (row_mask 1: lanes 0-15) and 62, 63 (row_mask 8: lanes 48-63)
+__device__ inline void nms_row_dpp(float vm, float& hm, float& u, float& w) {
+    float t, s_;
+    asm("s_nop 1\n\t"
+        "v_max_f32_dpp %0, %5, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      /* t  = columns x - 1, x */
+        "v_max_f32_dpp %1, %5, %5 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      /* s  = columns x, x + 1 */
+        "v_max_f32_dpp %4, %4, %4 wave_shl:1 row_mask:0x1 bank_mask:0xf bound_ctrl:0\n\t"      /* hm: lane 0 <- max(h0, h1), lane 1 <- h1 (h2 = 0); lanes 16-63 keep their value */
+        "v_max_f32_dpp %2, %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      /* u  = columns x - 2 .. x   (t: two instructions old) */
+        "v_max_f32_dpp %3, %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"      /* w  = columns x .. x + 2 */
+        "v_max_f32_dpp %4, %4, %4 wave_shr:1 row_mask:0x8 bank_mask:0xf bound_ctrl:0"            /* hm: lane 63 <- max(h63, h62), lane 62 <- h62 (h61 = 0)   (hm: two instructions old) */
+        : "=&v"(t), "=&v"(s_), "=&v"(u), "=&v"(w), "+v"(hm) : "v"(vm));
+}
+template <int R>
+__device__ inline void put_lane(unsigned& m, unsigned sv) {      // lane R of m <- the scalar sv
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(m) : "s"(sv), "n"(R));
+}
+__global__ __launch_bounds__(256) void nms_flags_zp_kernel(const float* __restrict__ heat, int B, int H, int W, int WPR, int HT, float thr,
+                                                           unsigned long long* __restrict__ mask, int* __restrict__ wcount) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int b, item;
+    if (!xcd_group_map(blockIdx.x, ceil_div(WPR * HT, 4), B, b, item)) return;
+    const int unit = item * 4 + wave;
+    if (unit >= WPR * HT) return;
+    const int word = unit % WPR, y0 = (unit / WPR) * NMS_RB;
+    const int x = word * 64 + lane;
+    const int hx = lane < 2 ? word * 64 - 2 + lane : (lane >= 62 ? word * 64 + 2 + lane : -1);      // lanes 0, 1: x0 - 2, x0 - 1; lanes 62, 63: x0 + 64, x0 + 65
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(heat + (size_t)b * H * W), 0, H * W * 4, 0x00020000);
+    // a lane's offset in row 0, or "far out of range" (stays out of range under every row offset added below: |row offset| < 2^30, launch check)
+    const int vx = x < W ? x * 4 : (int)0x80000000, vh = (hx >= 0 && hx < W) ? hx * 4 : (int)0x80000000;
+    float v[NMS_RB + 4], h[NMS_RB + 4];
+#pragma unroll
+    for (int r = 0; r < NMS_RB + 4; ++r) {
+        const int ro = (y0 - 2 + r) * W * 4;             // (scalar; rows above / below the image: negative, or >= the buffer's size -> the load returns 0)
+        v[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, vx + ro, 0, 0));
+        h[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rh, vh + ro, 0, 0));
+    }
+    unsigned mlo = 0, mhi = 0;
+    auto row = [&](auto RC) __attribute__((always_inline)) {
+        constexpr int r = decltype(RC)::value;
+        const float vm = vmax3(vmax3(v[r], v[r + 1], v[r + 2]), v[r + 3], v[r + 4]);
+        float hm = vmax3(vmax3(h[r], h[r + 1], h[r + 2]), h[r + 3], h[r + 4]);      // lanes 0, 1, 62, 63: the halo columns' vertical maxima (0 elsewhere)
+        float u, w;
+        nms_row_dpp(vm, hm, u, w);
+        const float m = vmax3(u, w, hm);
+        const float c = v[r + 2];
+        const unsigned long long bal = __ballot((c > thr) & (c == m));      // (columns >= W read 0: never > thr)
+        // lane r keeps row r's ballot (v_writelane_b32: the ballot is already in scalar registers; the lane number is an immediate -- one scalar operand per instruction)
+        if (lane == r) { mlo = (unsigned)bal; mhi = (unsigned)(bal >> 32); }
+    };
+    static_assert(NMS_RB == 16, "sixteen rows per wave, spelled out");
+    row(std::integral_constant<int, 0>{}); row(std::integral_constant<int, 1>{}); row(std::integral_constant<int, 2>{}); row(std::integral_constant<int, 3>{});
+    row(std::integral_constant<int, 4>{}); row(std::integral_constant<int, 5>{}); row(std::integral_constant<int, 6>{}); row(std::integral_constant<int, 7>{});
+    row(std::integral_constant<int, 8>{}); row(std::integral_constant<int, 9>{}); row(std::integral_constant<int, 10>{}); row(std::integral_constant<int, 11>{});
+    row(std::integral_constant<int, 12>{}); row(std::integral_constant<int, 13>{}); row(std::integral_constant<int, 14>{}); row(std::integral_constant<int, 15>{});
+    const int y = y0 + lane;
+    if (lane < NMS_RB && y < H) {
+        const size_t o = ((size_t)b * H + y) * WPR + word;
+        mask[o] = ((unsigned long long)mhi << 32) | mlo;
+        wcount[o] = __popc(mlo) + __popc(mhi);
     }
 }
 
@@ -567,13 +648,22 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
 void prof_begin(Profiler* p, int which, hipStream_t st);
 void prof_end(Profiler* p, int which, hipStream_t st, double flops, double bytes);
 
+// 5 x 5 NMS flags: thr >= 0 (every detection threshold) takes the zero-padding form, a negative threshold (XFeat.NMS on arbitrary data) the -inf-padding one
+static void launch_nms_flags5(const float* heat, int B, int H, int W, int WPR, float thr, unsigned long long* mask, int* wcount, hipStream_t st) {
+    const unsigned grid = xcd_grid_size(ceil_div(WPR * ceil_div(H, NMS_TH), 4), B);
+    if (thr >= 0.f && (size_t)(H + 4) * W * 4 < (1u << 30))
+        nms_flags_zp_kernel<<<grid, 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, mask, wcount);
+    else
+        nms_flags_kernel<<<grid, 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, mask, wcount);
+}
+
 void launch_detect(const DetectWs& ws, const float* heat, const float* reliab, const float* feats, const float* invnorm, int B, int H, int W,
                    float thr, int top_k, int cap, float rw, float rh, float* kpts, float* scores, float* desc,
                    int32_t* n_valid, int32_t* n_cand, hipStream_t st, uint16_t* desc16, Profiler* prof) {
     const int WPR = ceil_div(W, 64);
     const int hc = H / 8, wc = W / 8;
     prof_begin(prof, XFH_SPAN_NMS_FLAGS, st);
-    nms_flags_kernel<<<xcd_grid_size(ceil_div(WPR * ceil_div(H, NMS_TH), 4), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
+    launch_nms_flags5(heat, B, H, W, WPR, thr, ws.mask, ws.wcount, st);
     prof_end(prof, XFH_SPAN_NMS_FLAGS, st, 0, 0);
     prof_begin(prof, XFH_SPAN_NMS_COMPACT, st);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
@@ -611,7 +701,7 @@ void launch_nms_only(const DetectWs& ws, const float* heat, int B, int H, int W,
     const int WPR = ceil_div(W, 64);
     // 5 x 5 (the hot path's window): the register / DPP kernel, any width; every other window goes to the per-pixel kernel
     if (kernel_size == 5)
-        nms_flags_kernel<<<xcd_grid_size(ceil_div(WPR * ceil_div(H, NMS_TH), 4), B), 256, 0, st>>>(heat, B, H, W, WPR, ceil_div(H, NMS_TH), thr, ws.mask, ws.wcount);
+        launch_nms_flags5(heat, B, H, W, WPR, thr, ws.mask, ws.wcount, st);
     else
         nms_flags_generic_kernel<<<(unsigned)(((size_t)B * H * WPR + 3) / 4), 256, 0, st>>>(heat, B, H, W, WPR, kernel_size / 2, thr, ws.mask, ws.wcount);
     nms_compact_kernel<<<B, 1024, 0, st>>>(ws.mask, ws.wcount, H, WPR, cap, ws.cand, n_cand);
