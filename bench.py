@@ -123,6 +123,53 @@ def gpu_telemetry(device_index=0):
     return out
 
 
+class GpuStateSampler:
+    """sclk / power sampled from the amdgpu sysfs nodes in a background thread WHILE a region runs (a read right before or after it sees an idle GPU: 94 MHz): start(),
+    stop() -> {"samples": n, "sclk_mhz": [min, median, max], "power_w": [min, median, max]}.  ~0.3 ms per sample, one sample per millisecond; no subprocess."""
+
+    def __init__(self, device_index=0, period_s=0.001):
+        import glob
+        import threading
+        self.period, self._stop, self.samples = period_s, threading.Event(), []
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")))
+        self.freq = self.power = None
+        if cards:
+            d = cards[min(device_index, len(cards) - 1)]
+            for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                f, p = os.path.join(hw, "freq1_input"), next((os.path.join(hw, n) for n in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, n))), None)
+                if os.path.exists(f):
+                    self.freq, self.power = f, p
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                f = int(open(self.freq).read()) * 1e-6
+                p = int(open(self.power).read()) * 1e-6 if self.power else None
+                self.samples.append((f, p))
+            except (OSError, ValueError):
+                pass
+            time.sleep(self.period)
+
+    def start(self):
+        if self.freq:
+            self.thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self.freq:
+            self.thread.join(1.0)
+        if not self.samples:
+            return {"samples": 0}
+        stat = lambda v: [round(min(v), 1), round(sorted(v)[len(v) // 2], 1), round(max(v), 1)]
+        out = {"samples": len(self.samples), "sclk_mhz_min_median_max": stat([s[0] for s in self.samples])}
+        pw = [s[1] for s in self.samples if s[1] is not None]
+        if pw:
+            out["power_w_min_median_max"] = stat(pw)
+        return out
+
+
 def cpu_baseline(seconds):
     """Oracle (port of the reference CPU path) on the host cores: same workload shape,
     bounded sample: batches of 4 VGA frames + their 2 pair matches, repeated ~`seconds`."""
@@ -836,7 +883,9 @@ def main():
 
     # (the barrier + torch.cuda.synchronize() that closes the timed region waits for every lane: all `steps` batches complete inside it)
     tele_before = gpu_telemetry(local_rank)
+    sampler = GpuStateSampler(local_rank).start()
     dt_max, _ = sharding.timed_steps(lane_step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
+    tele_during = sampler.stop()
     tele_after = gpu_telemetry(local_rank)
     timed_calls[0] = None
     assert len(retired) == args.steps and fs.in_flight == 0
@@ -980,7 +1029,8 @@ def main():
                        "untimed_before_the_timed_region": f"GPU wake-up ({n_wake} steps: windows of {args.steps} until two agree within 1 %, >= {args.wake_ms:.0f} ms; a cold GPU runs its first ~150 ms 3-4 % slow), then the W warm-up steps",
                        "wake_up_window_fps": [round(r, 1) for r in wake_rates],
                        # the box's state around the timed region (amdgpu sysfs): a slow box reads differently from a slow kernel
-                       "gpu_state": {"before_timed_region": tele_before, "after_timed_region": tele_after},
+                       "gpu_state": {"during_warmup_and_timed_region": tele_during, "before_timed_region": tele_before, "after_timed_region": tele_after,
+                                     "note": "before / after are single reads behind a synchronisation (an idle GPU: low sclk); `during` is sampled once per millisecond while the steps run"},
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
             # block1 x4 + skip1 in one kernel: fp32 FMA work on the vector ALUs (v_pk_fma_f32), LDS-tiled.  Neither HBM nor the matrix
             # cores bound it: its vector stages (conv1 recomputed inside conv2: DESIGN 3.2) do; it is priced against the dense fp32 rate of the chip,
