@@ -247,6 +247,207 @@ void conv_bx_kernel(BxArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Round 6: conv_bxd_kernel -- the same convolution with the STAGING INSIDE THE MFMA STREAM.  The counters said what conv_bx_kernel does with its time: matrix
+// pipe busy 38 % of its cycles, vector ALU 21 % -- it waits.  A workgroup there stages a tile, meets at a barrier, multiplies, meets again; the second workgroup of
+// the CU is meant to fill the gaps and does so for a third of them.  Here ONE workgroup of eight waves (two per SIMD) owns the CU and all of its LDS:
+//   * tiles of 16 x 32 outputs (halo 18 x 34: 1.20 x the pixels instead of 1.33), TWO tile buffers: while tile t is multiplied out of one, tile t + 1 is
+//     split and written into the other BY THE SAME WAVES, in the slots between the K steps (a staging item = 8 channels of a pixel: 8 conversions + 2 LDS writes, one item
+//     per slot in four of the fourteen steps; a wave's vector instructions beside its own MFMAs are free up to ~ 4 per MFMA), and the raw values of tile t + 2 are
+//     requested into the registers an item has just left -- a whole tile ahead of their use;
+//   * ONE barrier per tile (everybody is done reading buffer t and writing buffer t + 1), no staging phase, no phase lag to tune;
+//   * fp16(w) is not kept in LDS: q1 = 2^-11 q0 (exact scaling of the same significand, the block1 kernels' trick): four v_pk_mul_f16 per step buy the 14 KB the
+//     second tile buffer needs (2 x 68 544 + 14 336 + 128 = 151 552 bytes of LDS).
+// A wave owns output rows 2 w, 2 w + 1 of the tile (two accumulators), as in conv_bx_kernel; weights q0 of all steps in registers, q2 read from LDS per step.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int CIN, int COUT>
+struct BxdCfg {
+    static constexpr int TH = 16, TW = 32, IH = TH + 2, IW = TW + 2, NPIX = IH * IW;
+    static constexpr int NXS = 2;
+    static constexpr int CG = CIN / 8, SPLB = CIN * 2, PIXB = ((NXS * SPLB / 16) | 1) * 16;
+    static constexpr int KG = 9 * CG, NSTEP = (KG + 1) / 2;
+    static constexpr int NITEM = NPIX * CG, NIT = (NITEM + 511) / 512;
+    static constexpr int TILE_BYTES = NPIX * PIXB, WL_BYTES = NSTEP * 64 * 16;
+    static constexpr int WL_OFF = 2 * TILE_BYTES, BIAS_OFF = WL_OFF + WL_BYTES, LDS_BYTES = BIAS_OFF + 32 * 4;
+    static_assert(CIN % 8 == 0 && COUT <= 32 && NIT <= NSTEP / 3 && LDS_BYTES <= 160 * 1024, "one cout block, 8-channel groups, an item per three steps, one CU's LDS");
+    static constexpr int koff(int kg) {
+        const int g = kg < KG ? kg : KG - 1;
+        const int tap = g / CG, cg = g % CG;
+        return ((tap / 3) * IW + tap % 3) * PIXB + cg * 16;
+    }
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void conv_bxd_kernel(BxArgs a) {
+    kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
+    using Cfg = BxdCfg<CIN, COUT>;
+    constexpr int NXS = Cfg::NXS;
+    using frag_t = f16x8;
+    auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); };
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, IW = Cfg::IW, NPIX = Cfg::NPIX, CG = Cfg::CG, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB;
+    constexpr int NSTEP = Cfg::NSTEP, NIT = Cfg::NIT, TILE_BYTES = Cfg::TILE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t HW = (size_t)a.H * a.W;
+
+    // q0 = fp16(2^11 w) of every step in registers (operand order: lane (cout l31, half) holds K group 2 s + half); q2 in LDS
+    frag_t wf[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) wf[s] = __builtin_bit_cast(frag_t, a.wfrag[(s * 3 + 0) * 64 + lane]);
+    unsigned char* wl_lds = smem_bx + Cfg::WL_OFF;            // [step][lane] 16 B
+    for (int s = wave; s < NSTEP; s += 8) *reinterpret_cast<uint4*>(wl_lds + (s * 64 + lane) * 16) = a.wfrag[(s * 3 + 2) * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) asm volatile("" : "+v"(wf[s]));      // the wait for the weight loads belongs here, not into the tile loop
+    float* bias_lds = reinterpret_cast<float*>(smem_bx + Cfg::BIAS_OFF);
+    if (tid < 32) bias_lds[tid] = a.bias[tid];
+
+    // staging items of this thread: item = cg * NPIX + pixel -> (tile row, tile column, LDS byte offset).  4 x 512 slots for 1836 items: the threads behind the last item
+    // take an item a second time (the same values to the same place: no branch, no exec mask in the MFMA stream)
+    int it_rc[NIT], it_lds[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        int item = tid + 512 * i;
+        item = item >= Cfg::NITEM ? item - Cfg::NITEM : item;
+        const int cg = item / NPIX, pix = item - cg * NPIX;
+        const int r = pix / IW, c = pix - r * IW;
+        it_rc[i] = (cg << 16) | (r << 8) | c;
+        it_lds[i] = pix * PIXB + cg * 16;
+    }
+    const int lane_off = (2 * wave * IW + l31) * PIXB;
+    const int total = a.tiles * a.B;
+
+    auto tile_of = [&](int vid, int& b, int& oy0, int& ox0) {
+        int tile;
+        xcd_group_map(vid, a.tiles, a.B, b, tile);
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        oy0 = tyi * TH; ox0 = txi * TW;
+    };
+    unsigned amax = 0;                        // the largest fp16 high parts converted (range guard: bx_split.hpp)
+    // where a tile's raw values come from (vid >= total: every offset out of range -- the loads return zeros that are staged into a buffer nobody reads; no branch)
+    struct TileSrc { __amdgpu_buffer_rsrc_t rs; int oy0, ox0, live; };
+    auto src_of = [&](int vid) {
+        TileSrc t;
+        int b = 0, oy0 = 0, ox0 = 0;
+        t.live = vid < total;
+        if (t.live) tile_of(vid, b, oy0, ox0);
+        t.oy0 = oy0; t.ox0 = ox0;
+        t.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.in + (size_t)b * CIN * HW), 0, (int)(CIN * HW * sizeof(float)), 0x00020000);
+        return t;
+    };
+    auto issue_item = [&](const TileSrc& t, int i, float (&v)[8]) __attribute__((always_inline)) {
+        const int cg = it_rc[i] >> 16, gy = t.oy0 - 1 + ((it_rc[i] >> 8) & 0xff), gx = t.ox0 - 1 + (it_rc[i] & 0xff);
+        const bool ok = (bool)((int)(t.live != 0) & (int)((unsigned)gy < (unsigned)a.H) & (int)((unsigned)gx < (unsigned)a.W)); 
+        const int voff = ok ? (int)((((size_t)cg * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(t.rs, voff, (int)(k * HW * 4), 0));
+    };
+    auto stage_item = [&](unsigned char* buf, int i, const float (&v)[8]) __attribute__((always_inline)) {
+        uint4 h, l;
+        split2_f16(v[0], v[1], h.x, l.x); split2_f16(v[2], v[3], h.y, l.y);
+        split2_f16(v[4], v[5], h.z, l.z); split2_f16(v[6], v[7], h.w, l.w);
+        fx_track_h(amax, h.x, true); fx_track_h(amax, h.y, true); fx_track_h(amax, h.z, true); fx_track_h(amax, h.w, true);
+        unsigned char* p = buf + it_lds[i];
+        *reinterpret_cast<uint4*>(p) = h;
+        *reinterpret_cast<uint4*>(p + SPLB) = l;
+    };
+    static_assert(NIT == 4, "four staging items per thread, spelled out below");
+
+    int vid = blockIdx.x;
+    if (vid >= total) return;
+    float va[8], vb[8];                       // raw fp32 values of two staging items in flight
+    // prologue: tile 0 into buffer 0 with every pipe idle
+    {
+        const TileSrc t0 = src_of(vid);
+        issue_item(t0, 0, va); issue_item(t0, 1, vb);
+        stage_item(smem_bx, 0, va); issue_item(t0, 2, va);
+        stage_item(smem_bx, 1, vb); issue_item(t0, 3, vb);
+        stage_item(smem_bx, 2, va); stage_item(smem_bx, 3, vb);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (;;) {
+        int b, oy0, ox0;
+        tile_of(vid, b, oy0, ox0);
+        const unsigned char* tb = smem_bx + cur * TILE_BYTES;            // this tile
+        unsigned char* nb = smem_bx + (cur ^ 1) * TILE_BYTES;           // the next one is requested AND staged here, inside this tile's MFMAs
+        const TileSrc t1 = src_of(vid + (int)gridDim.x);
+        // ---- 14 K steps x 2 rows x 3 MFMAs; in their slots the next tile's four items, two in flight: requested at steps 0 / 3 / 6 / 9, split and written at 5 / 8 / 11 / 13
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        struct Frag { frag_t x[2][NXS]; frag_t wl; };
+        Frag f[2];
+        auto load = [&](int s, Frag& o) __attribute__((always_inline)) {
+            const int k0 = Cfg::koff(2 * s), dk = Cfg::koff(2 * s + 1) - k0;
+            const unsigned char* p = tb + (lane_off + half * dk) + k0;
+            o.wl = *reinterpret_cast<const frag_t*>(wl_lds + (s * 64 + lane) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < NXS; ++q) o.x[j][q] = *reinterpret_cast<const frag_t*>(p + j * IW * PIXB + q * SPLB);
+        };
+        load(0, f[0]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const Frag& c = f[s & 1];
+            if (s + 1 < NSTEP) load(s + 1, f[(s + 1) & 1]);
+            const frag_t wh = wf[s];
+            frag_t wm = wh * (_Float16)0.00048828125f;            // fp16(w) = 2^-11 fp16(2^11 w)
+            asm volatile("" : "+v"(wm));                           // (computed HERE, in front of the MFMA group)
+            __builtin_amdgcn_sched_barrier(0);
+#define BX_MM(A, Q) { acc[0] = mfma(A, c.x[0][Q], acc[0]); acc[1] = mfma(A, c.x[1][Q], acc[1]); }
+            BX_MM(c.wl, 0) BX_MM(wm, 1) BX_MM(wh, 0)      // fragments (2^11 w - q0, w, q0 = fp16(2^11 w)) x (xh, xl, xh): all at scale 2^11
+#undef BX_MM
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 0) issue_item(t1, 0, va);
+            if (s == 3) issue_item(t1, 1, vb);
+            if (s == 5) stage_item(nb, 0, va);
+            if (s == 6) issue_item(t1, 2, va);
+            if (s == 8) stage_item(nb, 1, vb);
+            if (s == 9) issue_item(t1, 3, vb);
+            if (s == 11) stage_item(nb, 2, va);
+            if (s == 13) stage_item(nb, 3, vb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]));      // idle slots: the epilogue's vector code must not land in operands of the last MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- bias, ReLU, store ------------------------------------------------------------------------------------------
+        const int ox = ox0 + l31;
+        float bs[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const float4 t = *reinterpret_cast<const float4*>(bias_lds + 8 * g4 + 4 * half);
+            bs[4 * g4] = t.x; bs[4 * g4 + 1] = t.y; bs[4 * g4 + 2] = t.z; bs[4 * g4 + 3] = t.w;
+        }
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * COUT * HW), 0, (int)(COUT * HW * sizeof(float)), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int oy = oy0 + 2 * wave + j;
+            const int voff = oy < a.H && ox < a.W ? (int)(((size_t)(4 * half) * HW + (size_t)oy * a.W + ox) * 4) : (int)0x80000000;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co0 = (r & 3) + 8 * (r >> 2);          // cout of lane half 0; half 1 holds co0 + 4
+                if (co0 < COUT) {
+                    float y = fmaf(acc[j][r], FX_SCALE_INV, bs[r]);
+                    if (a.relu) y = fmaxf(y, 0.f);
+                    const bool okc = COUT % 8 == 0 || co0 + 4 * half < COUT;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs_out, okc ? voff : (int)0x80000000, (int)(co0 * HW * 4), 0);
+                }
+            }
+        }
+        const int nvid = vid + (int)gridDim.x;
+        if (nvid >= total) break;
+        __syncthreads();         // every wave has read this tile and written its part of the next one
+        vid = nvid;
+        cur ^= 1;
+    }
+    fx_report_h(amax, a.status);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // The stride-2 sibling: block3.0 (3x3 / s2, 24 -> 64; modules/model.py:62) on the same staging.  The 10x34 halo tile around an 8x32
 // block of INPUT pixels feeds a 4x16 block of outputs (one 32-pixel MFMA block per two output rows); wave (pb, cb) owns pixel block pb
 // and cout block cb.  The tile is stored with even and odd columns apart ([row][column parity][column / 2], 2496 B per parity row: a
@@ -465,12 +666,32 @@ static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* o
     return 0;
 }
 
+template <int CIN, int COUT>
+static int run_bxd(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status) {
+    using Cfg = BxdCfg<CIN, COUT>;
+    if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
+    BxArgs a;
+    a.cold = g_debug_cold;
+    a.status = status;
+    a.in = in; a.wfrag = reinterpret_cast<const uint4*>(c.w_fx); a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.B = B; a.trace = nullptr;
+    a.lag = 0;
+    a.tiles_x = ceil_div(W, Cfg::TW);
+    a.tiles = a.tiles_x * ceil_div(H, Cfg::TH);
+    static AttrMask attr_done = 0;
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxd_kernel<CIN, COUT>), Cfg::LDS_BYTES, attr_done);
+    const int total = xcd_grid_size(a.tiles, B);
+    int grid = num_cus();                // one workgroup (eight waves) per CU; a multiple of 8 keeps a workgroup on its XCD
+    if (grid > total) grid = total;
+    conv_bxd_kernel<CIN, COUT><<<grid, 512, Cfg::LDS_BYTES, st>>>(a);
+    return 0;
+}
+
 int bx_steps(int cin) { return (9 * (cin / 8) + 1) / 2; }
 
 // -1: not one of this file's layers, or the layer has no fp16-pair weights (a |w| >= kFxMaxWeight): the caller falls back to the f32-MFMA kernel
 int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
     if (c.ks != 3 || !c.w_fx) return -1;
-    if (c.stride == 1 && c.cin == 24 && c.cout == 24) return run_bx<24, 24>(c, in, B, H, W, out, st, trace, status);
+    if (c.stride == 1 && c.cin == 24 && c.cout == 24) return trace ? run_bx<24, 24>(c, in, B, H, W, out, st, trace, status) : run_bxd<24, 24>(c, in, B, H, W, out, st, status);      // (the stamped kernel is the round-4 form)
     if (c.stride == 2 && c.cin == 24 && c.cout == 64) return run_bxs2<24>(c, in, B, H, W, out, st, status);
     return -1;
 }

@@ -1,6 +1,6 @@
 // conv_bx_kernel<24, 24> and conv_bxs2_kernel<24> (csrc/k_conv_bx.hip: the 24-channel layers block2.0 / block2.1 and the stride-2 24 -> 64 layer block3.0; sliced out of
 // the product source by tests/test_kernels_emulated.py into conv_bx24_slice.hpp, with the weight split helpers of api.hip in weight_split_slice.hpp) on the host.
-// stdin: {B, H, W, stride (1 | 2), relu, grid} int32, then in (B*24*H*W), w (cout*24*9; cout = 24 | 64), bias (cout) as fp32 (BatchNorm folded);
+// stdin: {B, H, W, stride (1 | 2; 3 = stride 1 on conv_bx_kernel, the round-4 form that the trace build still uses), relu, grid} int32, then in (B*24*H*W), w (cout*24*9; cout = 24 | 64), bias (cout) as fp32 (BatchNorm folded);
 // stdout: out (B*cout*Ho*Wo), status (int32).
 #include "emu.hpp"
 #include <cstdio>
@@ -36,7 +36,8 @@ static std::vector<float> rd(size_t n) {
 int main() {
     int hdr[6];
     if (fread(hdr, 4, 6, stdin) != 6) return 2;
-    const int B = hdr[0], H = hdr[1], W = hdr[2], stride = hdr[3], relu = hdr[4], grid = hdr[5];
+    const int B = hdr[0], H = hdr[1], W = hdr[2], stride = hdr[3] == 3 ? 1 : hdr[3], relu = hdr[4], grid = hdr[5];
+    const bool old_form = hdr[3] == 3;
     const int cout = stride == 2 ? 64 : 24, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     auto in = rd((size_t)B * 24 * H * W), w = rd((size_t)cout * 24 * 9);
     std::vector<float> bias = rd(cout);
@@ -47,7 +48,13 @@ int main() {
     int status = 0;
     const int tiles_x = (W + 31) / 32, tiles = tiles_x * ((H + 7) / 8);
     const int total = tiles * B, g = total < grid ? total : grid;
-    if (stride == 1) {
+    if (stride == 1 && !old_form) {      // what ships: conv_bxd_kernel (16 x 32 tiles, eight waves, two tile buffers)
+        xfh::BxArgs a{};
+        a.in = in.data(); a.wfrag = reinterpret_cast<const uint4*>(wq.data()); a.bias = bias.data(); a.out = out.data(); a.relu = relu; a.H = H; a.W = W; a.B = B;
+        a.tiles_x = tiles_x; a.tiles = tiles_x * ((H + 15) / 16); a.lag = 0; a.status = &status;
+        const int tot = a.tiles * B, gd = tot < grid ? tot : grid;
+        emu::launch(gd, 512, xfh::BxdCfg<24, 24>::LDS_BYTES, [&] { xfh::conv_bxd_kernel<24, 24>(a); });
+    } else if (stride == 1) {
         xfh::BxArgs a{};
         a.in = in.data(); a.wfrag = reinterpret_cast<const uint4*>(wq.data()); a.bias = bias.data(); a.out = out.data(); a.relu = relu; a.H = H; a.W = W; a.B = B;
         a.tiles_x = tiles_x; a.tiles = tiles; a.lag = 0; a.status = &status;
