@@ -222,7 +222,7 @@ static size_t carve_match(void* ws, int P, int N1, int N2, MatchWs& o) {
     o.thr_row = c.take<float>((size_t)P * N1);
     o.thr_col = c.take<float>((size_t)P * N2);
     o.R = c.take<float>((size_t)P * ceil_div(N2, 32) * N1);      // block maxima: 1/32 of the similarity matrix each
-    o.C = c.take<float>((size_t)P * ceil_div(N1, 32) * N2);
+    o.C = c.take<float>((size_t)P * (ceil_div(N1, 1024) * 32) * N2);      // (the one-orientation sweep's blocks: 32 residues per row group of 1024 rows; >= ceil(N1 / 32))
     return align_up(c.off, 256);
 }
 
@@ -767,7 +767,7 @@ int xfh_match_mnn(xfh_handle h, const float* d1, size_t pair_stride1, const floa
     int rc = check_ws(workspace, workspace_bytes, need);
     if (rc) return rc;
     launch_match(w, d1, pair_stride1, d2, pair_stride2, n1, n2, n_stride, n_offset2, P, N1, N2, min_cossim, idx0, idx1,
-                 n_matches, (hipStream_t)stream, h ? &h->prof : nullptr, d1_f16, d2_f16, h ? h->opt.match_exact != 0 : false);
+                 n_matches, (hipStream_t)stream, h ? &h->prof : nullptr, d1_f16, d2_f16, h ? h->opt.match_exact != 0 : false, h ? h->opt.match_sweep : 0);
     return check_launch("xfh_match_mnn");
 }
 
@@ -925,7 +925,7 @@ int xfh_debug_block1(xfh_handle h, const float* gray, const float* coef, int B, 
 
 // option -> its slot and the values it takes (include/xfeat_hip.h: xfh_set_option)
 static int* option_slot(xfh_handle h, const char* key) {
-    struct { const char* k; int Options::*m; } tab[] = {{"match_exact", &Options::match_exact}, {"block1", &Options::block1}, {"fx", &Options::fx}, {"resize2", &Options::resize2}};
+    struct { const char* k; int Options::*m; } tab[] = {{"match_exact", &Options::match_exact}, {"match_sweep", &Options::match_sweep}, {"block1", &Options::block1}, {"fx", &Options::fx}, {"resize2", &Options::resize2}};
     for (auto& t : tab)
         if (!strcmp(t.k, key)) return &(h->opt.*(t.m));
     return nullptr;
@@ -933,10 +933,11 @@ static int* option_slot(xfh_handle h, const char* key) {
 int xfh_set_option(xfh_handle h, const char* key, int value) {
     if (!h || !key) return fail(XFH_ERR_ARG, "xfh_set_option: NULL argument");
     int* slot = option_slot(h, key);
-    if (!slot) return fail(XFH_ERR_ARG, "xfh_set_option: unknown option '%s' (match_exact, block1, fx, resize2)", key);
+    if (!slot) return fail(XFH_ERR_ARG, "xfh_set_option: unknown option '%s' (match_exact, match_sweep, block1, fx, resize2)", key);
     bool ok;
     if (!strcmp(key, "block1")) ok = value == 5 || value == 7;
     else if (!strcmp(key, "fx")) ok = value >= 0 && (value & ~XFH_FX_ALL) == 0;
+    else if (!strcmp(key, "match_sweep")) ok = value >= 0 && value <= 2;
     else ok = value == 0 || value == 1;
     if (!ok) return fail(XFH_ERR_ARG, "xfh_set_option: %s = %d is not a value of this option", key, value);
     *slot = value;

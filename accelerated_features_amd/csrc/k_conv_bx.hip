@@ -284,7 +284,7 @@ void conv_bxd_kernel(BxArgs a) {
     constexpr int NXS = Cfg::NXS;
     using frag_t = f16x8;
     auto mfma = [](frag_t x, frag_t y, f32x16 c) __attribute__((always_inline)) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); };
-    constexpr int TH = Cfg::TH, TW = Cfg::TW, IW = Cfg::IW, NPIX = Cfg::NPIX, CG = Cfg::CG, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, IW = Cfg::IW, NPIX = Cfg::NPIX, PIXB = Cfg::PIXB, SPLB = Cfg::SPLB;
     constexpr int NSTEP = Cfg::NSTEP, NIT = Cfg::NIT, TILE_BYTES = Cfg::TILE_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;

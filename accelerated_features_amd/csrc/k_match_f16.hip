@@ -139,6 +139,13 @@ __device__ inline float max16(const f32x16& v) {
     return fmaxf(f, g);
 }
 
+// maximum of a value and the other half-wave's (lane ^ 32): v_permlane32_swap of two copies leaves {lo, lo} in one register and {hi, hi} in the other -- their maximum is
+// the answer in both halves (no select)
+__device__ inline float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // E in the units of the scaled product S^' = (sa sb) S^ :  2 E' = 2 sa sb (c |x| maxnorm_y + kappa maxnorm_x maxnorm_y)
 struct PairWindow { float two_c, two_k; };
 __device__ inline PairWindow pair_window(float unit_bound, const unsigned* __restrict__ nmax, int P, int p, bool row_side) {
@@ -163,6 +170,7 @@ __device__ inline PairWindow pair_window(float unit_bound, const unsigned* __res
 // after a K = 16 MFMA was issued can land in operand lanes the matrix core has not read yet, and hipcc reuses a dead fragment register
 // for address arithmetic right behind the last MFMA (tools/check_mfma_war.py audits the generated code).
 #define XFH_KEEP_FRAGS(f) asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]))
+#define XFH_WAVE_SYNC() __builtin_amdgcn_wave_barrier()      // (LDS operations of one wave execute in order; this keeps the compiler from reordering them)
 
 // Sweep.  A workgroup keeps 256 columns (rows of D2) in LDS for its whole life and streams the 32-row blocks of D1 past them: no barrier
 // inside the loop -- the waves take row blocks from a shared counter, so a wave the scheduler favours simply does more of them.  Per block
@@ -321,6 +329,196 @@ __global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(const _Float16* __re
     }
 }
 
+// Sweep, ONE orientation (round 6).  The kernel above pays the matrix pipe twice per tile to get both reductions in-lane, and the counters say the pipe is what it waits for
+// (busy 72-77 % of its cycles, at the 1.4-1.5 GHz the chip holds under that load).  Here a tile is multiplied once, as accT = b . a (lane = row of the block, registers = 16 of
+// the tile's columns), and the column direction is served by what a C block IS: any partition of a column's rows will do for the filter (the refine evaluates all rows of a flagged
+// block exactly), so a block is made of the rows that meet in one lane --
+//     C block (g, l) of column j = the rows {1024 g + 32 t + l : t = 0..31}         (row group g = 32 consecutive row blocks, residue l = the lane)
+// and its maximum is an ELEMENTWISE running maximum over the row blocks a wave walks: 16 v_max_f32 per tile, no reduction at all.  A wave owns one row group (32 row blocks x the
+// workgroup's 256 columns = 256 tiles, its 8 x 16 running maxima in registers), the R blocks stay what they were (32 consecutive columns: in-lane max3 tree), and when the group is
+// done the running maxima pass through a 32 x 32 LDS tile per column tile: read down the columns they give the column maxima (one atomic per column and wave), read along the rows
+// the C rows (fp16, a quarter, rounded up -- as before).  4 MFMAs (128 pipe cycles) and ~ 32 VALU ops per tile.
+// Every one of the 8 column tiles is always multiplied (columns >= n2 are copies of the last valid column in LDS; their stores are dropped by range checks): a row block is one basic block.
+//   C (P, 32 ceil(N1 / 1024), N2): row g * 32 + l = block (g, l)           R, rowmaxh, colmaxh: as above
+constexpr int S2_T = 32;                  // row blocks per row group
+constexpr int S2_GROUP = 32 * S2_T;       // rows per row group
+constexpr int S2_WAVES = 4;               // row groups (waves) per workgroup
+constexpr int S2_TILES = 4;              // column tiles per workgroup (128 columns in LDS): 64 registers of running maxima per wave
+constexpr int S2_COLS = 32 * S2_TILES;
+constexpr int S2_XP = 33;                 // pitch of a wave's 32 x 32 transposition tile, in floats
+__host__ __device__ inline int s2_c_blocks(int N1) { return ceil_div(N1, S2_GROUP) * 32; }
+__global__ __launch_bounds__(64 * S2_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void mnn_f16_sweep2_kernel(const _Float16* __restrict__ a16, size_t sa16, const _Float16* __restrict__ b16, size_t sb16,
+                           const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
+                           int N1, int N2, int ncc, int ngq, int P,
+                           unsigned* __restrict__ colmaxh, unsigned* __restrict__ rowmaxh, _Float16* __restrict__ R, _Float16* __restrict__ C) {
+    __shared__ __attribute__((aligned(16))) _Float16 Dl2[S2_COLS * FT_DS];      // the columns
+    __shared__ float xp[S2_WAVES][32 * S2_XP];                                  // per wave: the transposition tile of the flush
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int p, item;
+    if (!xcd_group_map(blockIdx.x, ncc * ngq, P, p, item)) return;
+    const int cc = item / ngq, gq = item - cc * ngq;           // column chunk, and which four row groups
+    const int n1 = fpair_count(n1p, p * n_stride, N1);
+    const int n2 = fpair_count(n2p, p * n_stride + n_off2, N2);
+    const int c0 = cc * S2_COLS;
+    if (n1 <= 0 || n2 <= 0 || c0 >= n2 || gq * S2_WAVES * S2_GROUP >= n1) return;
+    const _Float16* A = a16 + (size_t)p * sa16;
+    const _Float16* Bm = b16 + (size_t)p * sb16;
+    const int ncb32 = ceil_div(N2, 32);
+    {   // 128 columns x 64 fp16 = 1024 16-byte pieces, four per thread, all in flight; columns >= n2: copies of the last valid column
+        constexpr int NP = S2_COLS * 8 / (64 * S2_WAVES);
+        uint4 v[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = tid + i * (64 * S2_WAVES);
+            v[i] = *reinterpret_cast<const uint4*>(Bm + (size_t)min(c0 + (e >> 3), n2 - 1) * 64 + (e & 7) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int e = tid + i * (64 * S2_WAVES);
+            *reinterpret_cast<uint4*>(Dl2 + (e >> 3) * FT_DS + (e & 7) * 8) = v[i];
+        }
+    }
+    const int g = gq * S2_WAVES + wave;
+    const int blk_lo = g * S2_T, nblock = min(ceil_div(n1, 32), blk_lo + S2_T);
+    f16x8 a[4], an[4];
+    if (blk_lo < nblock) {
+        const int row = min(blk_lo * 32 + l31, n1 - 1);       // rows >= n1: copies of the last valid row (never reported)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) an[kk] = *reinterpret_cast<const f16x8*>(A + (size_t)row * 64 + kk * 16 + half * 8);
+    }
+    __syncthreads();
+    if (blk_lo >= nblock) return;                              // (whole waves leave: nothing below synchronises across waves)
+    const _Float16* bp0 = Dl2 + l31 * FT_DS + half * 8;
+    f32x16 M[S2_TILES];                                        // running maxima: M[ct][r] = max over this wave's row blocks of S^(32 blk + l31, column (r & 3) + 8 (r >> 2) + 4 half of tile ct)
+#pragma unroll
+    for (int ct = 0; ct < S2_TILES; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) M[ct][r] = -INFINITY;
+    // R rows of this chunk: tiles beyond the last column block of R are outside the resource's range (their stores are dropped)
+    const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(R + ((size_t)p * ncb32 + (c0 >> 5)) * N1, 0, min(S2_TILES, ncb32 - (c0 >> 5)) * N1 * 2, 0x00020000);
+    for (int blk = blk_lo; blk < nblock; ++blk) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
+        if (blk + 1 < nblock) {                                // the next block's fragments on their way under this block's MFMAs
+            const int row = min((blk + 1) * 32 + l31, n1 - 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) an[kk] = *reinterpret_cast<const f16x8*>(A + (size_t)row * 64 + kk * 16 + half * 8);
+        }
+        const int myrow = blk * 32 + l31;
+        const int offR = (half == 1 && myrow < n1) ? myrow * 2 : (int)0x80000000;      // (branch-free stores: lanes that must not store carry an out-of-range offset)
+        float rowrun = -INFINITY;
+        f16x8 bfrag[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) bfrag[0][kk] = *reinterpret_cast<const f16x8*>(bp0 + kk * 16);
+        f32x16 acc[2];
+        // Software pipeline over the tiles, one basic block, PROGRAM ORDER = ISSUE ORDER (scheduling fences between the groups; left alone, hipcc sank all 64 elementwise
+        // maxima of a row block behind its last MFMA): tile ct's first two MFMAs, then -- while the matrix pipe works through them and the next two -- tile ct - 1 is reduced
+        // in three groups of ~ 11 vector instructions: the max3 tree of its 16 values (its last MFMA is two MFMAs back by then: no wait for the result), the other half-wave's
+        // maximum / R store, the 16 elementwise maxima into M.  The fragments of tile ct + 1 leave LDS meanwhile.
+#define XFH_S2_FENCE() __builtin_amdgcn_sched_barrier(0)
+        // (the fence orders the machine scheduler; the empty asm statements pin the VALUES -- without them the optimiser moves the arithmetic itself, before any scheduling)
+#define XFH_S2_PIN3(CT, R0) asm volatile("" : "+v"(M[CT][R0]), "+v"(M[CT][(R0) + 1]), "+v"(M[CT][(R0) + 2]))
+#define XFH_S2_PIN2(CT, R0) asm volatile("" : "+v"(M[CT][R0]), "+v"(M[CT][(R0) + 1]))
+#define XFH_S2_PIN11(CT, R0) asm volatile("" : "+v"(M[CT][R0]), "+v"(M[CT][(R0) + 1]), "+v"(M[CT][(R0) + 2]), "+v"(M[CT][(R0) + 3]), "+v"(M[CT][(R0) + 4]), "+v"(M[CT][(R0) + 5]), \
+                                                "+v"(M[CT][(R0) + 6]), "+v"(M[CT][(R0) + 7]), "+v"(M[CT][(R0) + 8]), "+v"(M[CT][(R0) + 9]), "+v"(M[CT][(R0) + 10]))
+#define XFH_S2_PINACC(x) asm volatile("" : "+v"(x))
+#define XFH_S2_M(CT, R0, R1) { _Pragma("unroll") for (int r = (R0); r < (R1); ++r) M[CT][r] = fmaxf(M[CT][r], acc[(CT) & 1][r]); }
+#define XFH_S2_EPI_A(CT) float rm_ = max16(acc[(CT) & 1]); XFH_S2_M(CT, 0, 3) XFH_S2_PIN3(CT, 0); asm volatile("" : "+v"(rm_));
+#define XFH_S2_EPI_B(CT)                                                                                  \
+            rm_ = xhalf_max(rm_);                                                                         \
+            rowrun = fmaxf(rowrun, rm_);                                                                  \
+            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, f16_up(rm_ * F16_STORE_SCALE)), rR, offR + (CT) * N1 * 2, 0, 0);   /* (in the lane offset: the range check does not see a scalar offset) */ \
+            XFH_S2_M(CT, 3, 5) XFH_S2_PIN2(CT, 3); asm volatile("" : "+v"(rowrun));
+#define XFH_S2_EPI_C(CT) XFH_S2_M(CT, 5, 16) XFH_S2_PIN11(CT, 5);
+#pragma unroll
+        for (int ct = 0; ct < S2_TILES; ++ct) {
+            if (ct + 1 < S2_TILES) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) bfrag[(ct + 1) & 1][kk] = *reinterpret_cast<const f16x8*>(bp0 + (ct + 1) * 32 * FT_DS + kk * 16);
+            }
+            f32x16& c_ = acc[ct & 1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c_[r] = 0.f;
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][0], a[0], c_, 0, 0, 0);
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][1], a[1], c_, 0, 0, 0);
+            XFH_S2_PINACC(c_);
+            XFH_S2_FENCE();
+            if (ct > 0) {
+                XFH_S2_EPI_A(ct - 1)
+                XFH_S2_FENCE();
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][2], a[2], c_, 0, 0, 0);
+                XFH_S2_PINACC(c_);
+                XFH_S2_FENCE();
+                XFH_S2_EPI_B(ct - 1)
+                XFH_S2_FENCE();
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][3], a[3], c_, 0, 0, 0);
+                XFH_S2_PINACC(c_);
+                XFH_S2_FENCE();
+                XFH_S2_EPI_C(ct - 1)
+            } else {
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][2], a[2], c_, 0, 0, 0);
+                c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][3], a[3], c_, 0, 0, 0);
+            }
+            XFH_S2_FENCE();
+            XFH_KEEP_FRAGS(bfrag[ct & 1]);
+        }
+        {
+            XFH_S2_EPI_A(S2_TILES - 1)
+            XFH_S2_EPI_B(S2_TILES - 1)
+            XFH_S2_EPI_C(S2_TILES - 1)
+        }
+        XFH_S2_FENCE();
+        XFH_KEEP_FRAGS(a);          // (the next block's fragments must not be copied over this block's right behind its last MFMA)
+#undef XFH_S2_FENCE
+#undef XFH_S2_PIN3
+#undef XFH_S2_PIN2
+#undef XFH_S2_PIN11
+#undef XFH_S2_PINACC
+#undef XFH_S2_M
+#undef XFH_S2_EPI_A
+#undef XFH_S2_EPI_B
+#undef XFH_S2_EPI_C
+        if (half == 0 && myrow < n1) atomicMax(&rowmaxh[(size_t)p * N1 + myrow], float_ord(rowrun));      // (no return value: fire and forget)
+    }
+    // ---- flush: the running maxima of this row group, tile by tile through the wave's 32 x 32 LDS tile (row = residue l, column = column of the tile)
+    float* xw = xp[wave];
+    const bool vec_ok = (N2 & 7) == 0;                         // 16-byte stores (eight fp16 values) need 16-byte aligned rows of C
+    _Float16* crow = C + ((size_t)p * s2_c_blocks(N1) + g * 32 + l31) * N2 + c0;
+#pragma unroll
+    for (int ct = 0; ct < S2_TILES; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xw[l31 * S2_XP + (r & 3) + 8 * (r >> 2) + 4 * half] = M[ct][r];
+        XFH_WAVE_SYNC();
+        // down the columns: lane (c, half) takes residues 16 half .. 16 half + 15 of column c
+        float cm = xw[(16 * half) * S2_XP + l31];
+#pragma unroll
+        for (int t = 1; t < 16; ++t) cm = fmaxf(cm, xw[(16 * half + t) * S2_XP + l31]);
+        cm = fmaxf(cm, xhalf(cm));
+        const int col = c0 + ct * 32 + l31;
+        if (half == 0 && col < n2) atomicMax(&colmaxh[(size_t)p * N2 + col], float_ord(cm));
+        // along the rows: lane (l, half) takes columns 16 half .. 16 half + 15 of residue l
+        const int cs = ct * 32 + 16 * half;
+        _Float16 o[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) o[t] = f16_up(xw[l31 * S2_XP + 16 * half + t] * F16_STORE_SCALE);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f16x8 v;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = o[8 * q + t];
+            if (vec_ok && c0 + cs + 8 * q + 8 <= n2) *reinterpret_cast<f16x8*>(crow + cs + 8 * q) = v;
+            else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (c0 + cs + 8 * q + t < n2) crow[cs + 8 * q + t] = v[t];
+            }
+        }
+        XFH_WAVE_SYNC();
+    }
+}
+
 // thresholds, once the maxima are complete: thr = max^ - 2 E (scaled units), stored like the block maxima (a quarter, fp16) but rounded DOWN.  grid (ceil(max(N1,N2)/256), P, 2 sides)
 __global__ __launch_bounds__(256) void mnn_f16_thr_kernel(float unit_bound, const int32_t* __restrict__ n1p, const int32_t* __restrict__ n2p, int n_stride, int n_off2,
                                                           int N1, int N2, int P, const float* __restrict__ na, const float* __restrict__ nb,
@@ -341,7 +539,7 @@ constexpr int RF_XS = 68;          // LDS row stride of the 32 x 64 tile in floa
 constexpr int RF_WAVES = 2;        // waves (= Y blocks) per workgroup
 __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) void mnn_f16_refine_kernel(
     const float* __restrict__ d1, size_t ps1, const float* __restrict__ d2, size_t ps2, const int32_t* __restrict__ n1p,
-    const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1, int N2, int nyb_max, int P,
+    const int32_t* __restrict__ n2p, int n_stride, int n_off2, int N1, int N2, int nyb_max, int c_strided, int P,
     const _Float16* __restrict__ thr_row, const _Float16* __restrict__ thr_col, const _Float16* __restrict__ R,
     const _Float16* __restrict__ C, unsigned long long* __restrict__ rowkey, unsigned long long* __restrict__ colkey) {
     __shared__ unsigned short queue[RF_WAVES][RF_QUEUE];                       // per wave: flagged x (offsets into the current chunk)
@@ -355,10 +553,13 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4
     const int n2 = fpair_count(n2p, p * n_stride + n_off2, N2);
     if (n1 <= 0 || n2 <= 0) return;
     const int nX = side ? n2 : n1, nY = side ? n1 : n2, NX = side ? N2 : N1;
-    if (yb * 32 >= nY) return;                              // (whole waves leave: nothing below synchronises across waves)
+    // the 32 Y rows of block yb: consecutive (R blocks; C blocks of the two-orientation sweep), or -- C blocks of the one-orientation sweep -- the rows of residue yb & 31 in row group yb >> 5
+    const bool strided = side && c_strided;                 // (uniform)
+    const int ybase = strided ? (yb >> 5) * S2_GROUP + (yb & 31) : yb * 32, ystep = strided ? 32 : 1;
+    if (ybase >= nY) return;                                // (whole waves leave: nothing below synchronises across waves)
     const float* X = side ? d2 + (size_t)p * ps2 : d1 + (size_t)p * ps1;
     const float* Y = side ? d1 + (size_t)p * ps1 : d2 + (size_t)p * ps2;
-    const _Float16* M = (side ? C + (size_t)p * ceil_div(N1, 32) * N2 : R + (size_t)p * ceil_div(N2, 32) * N1) + (size_t)yb * NX;
+    const _Float16* M = (side ? C + (size_t)p * (c_strided ? s2_c_blocks(N1) : ceil_div(N1, 32)) * N2 : R + (size_t)p * ceil_div(N2, 32) * N1) + (size_t)yb * NX;
     const _Float16* T = side ? thr_col + (size_t)p * N2 : thr_row + (size_t)p * N1;
     unsigned long long* key = side ? colkey + (size_t)p * N2 : rowkey + (size_t)p * N1;
     const bool vec_ok = (NX & 7) == 0;                      // 16-byte loads (eight fp16 values) need 16-byte aligned rows of M / thresholds
@@ -389,8 +590,8 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4
         }
     };
     float yreg[32];                                         // Y row yb*32 + l31, channels 32 half .. ; rows past nY read 0 and are masked below
-    rows_to_operand(rY, [&](int r) { return yb * 32 + r; }, yreg);
-    const bool ragged = yb * 32 + 32 > nY;                  // (uniform) the last block of Y: rows past nY must not win
+    rows_to_operand(rY, [&](int r) { return ybase + r * ystep; }, yreg);
+    const bool ragged = ybase + 31 * ystep >= nY;           // (uniform) a block with rows past nY: they must not win
 
     for (int xc = 0; xc < nX; xc += RF_CHUNK) {
         int cnt = 0;
@@ -408,18 +609,18 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
                 for (int s_ = 0; s_ < 32; ++s_) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(yreg[s_], xreg[s_], acc, 0, 0, 0);
-                // acc[r] = S(x of entry l31, y = yb*32 + (r&3) + 8*(r>>2) + 4*half): y ascends with r
+                // acc[r] = S(x of entry l31, y = ybase + ((r&3) + 8*(r>>2) + 4*half) * ystep): y ascends with r
                 if (ragged) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (yb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= nY) acc[r] = -INFINITY;
+                        if (ybase + ((r & 3) + 8 * (r >> 2) + 4 * half) * ystep >= nY) acc[r] = -INFINITY;
                 }
                 const float m = max16(acc);
                 int ry = 0;
 #pragma unroll
                 for (int r = 15; r >= 0; --r)
                     if (acc[r] == m) ry = (r & 3) + 8 * (r >> 2);                  // the FIRST r attaining the maximum: the lowest y of this half
-                unsigned long long k = ((unsigned long long)float_ord(m) << 32) | (0xffffffffu - (unsigned)(yb * 32 + ry + 4 * half));
+                unsigned long long k = ((unsigned long long)float_ord(m) << 32) | (0xffffffffu - (unsigned)(ybase + (ry + 4 * half) * ystep));
                 k = u64_max(k, xhalf_u64(k));                                        // ties between the halves: the larger ~y = the lower y
                 const int e = e0 + l31;
                 if (half == 0 && e < cnt) atomicMax(&key[xc + q[e]], k);
@@ -479,7 +680,7 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4
 // d1_16 / d2_16 (optional, both or neither): fp16 copies the caller already holds (xfh_detect_sparse's desc_f16 = RNE(256 * row)), laid out
 // like d1 / d2 (same pair strides in elements), rows L2-normalised: |row| <= 1.00001.  They replace the prep passes.
 void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const uint16_t* d1_16, const uint16_t* d2_16,
-                      const int32_t* n1, const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st, Profiler* prof) {
+                      const int32_t* n1, const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, hipStream_t st, Profiler* prof, int sweep_form) {
     const bool prepared = d1_16 && d2_16;
     const _Float16* a16 = prepared ? reinterpret_cast<const _Float16*>(d1_16) : ws.a16;
     const _Float16* b16 = prepared ? reinterpret_cast<const _Float16*>(d2_16) : ws.b16;
@@ -493,6 +694,15 @@ void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const floa
         prof_end(prof, XFH_SPAN_MATCH_PREP, st, 0, 0);
     }
     prof_begin(prof, XFH_SPAN_MATCH_SWEEP, st);
+    // the one-orientation sweep (a wave per row group of 1024 rows and column chunk) when its wave tasks fill at least half of the chip's wave slots (two per SIMD);
+    // the two-orientation sweep below shares the row blocks out more finely: few pairs, short lists
+    const int ngroup = ceil_div(N1, S2_GROUP), ncc2 = ceil_div(N2, S2_COLS);
+    const bool one = sweep_form == 2 || ((long)P * ncc2 * ngroup >= 8L * num_cus() && sweep_form != 1);
+    if (one) {
+        const int ngq = ceil_div(ngroup, S2_WAVES);
+        mnn_f16_sweep2_kernel<<<xcd_grid_size(ncc2 * ngq, P), 64 * S2_WAVES, 0, st>>>(a16, sa, b16, sb, n1, n2, n_stride, n_off2, N1, N2, ncc2, ngq, P,
+                                                                                    ws.colmaxh, ws.rowmaxh, reinterpret_cast<_Float16*>(ws.R), reinterpret_cast<_Float16*>(ws.C));
+    } else {
     const int ncc = ceil_div(N2, FT_COLS);
     // two workgroups per CU fill the chip; with few pairs the row blocks of a column chunk are shared out over more workgroups (>= 8 blocks each)
     const int nsplit = max(1, min(ceil_div(2 * num_cus(), ncc * P), ceil_div(N1, 256)));
@@ -502,12 +712,13 @@ void launch_match_f16(const MatchWs& ws, const float* d1, size_t ps1, const floa
                                                                         , g_debug_cold
 #endif
                                                                         );
+    }
     prof_end(prof, XFH_SPAN_MATCH_SWEEP, st, 0, 0);
-    const int nyb = ceil_div(ceil_div(N1 > N2 ? N1 : N2, 32), RF_WAVES) * RF_WAVES;
+    const int nyb = ceil_div(max(ceil_div(N2, 32), one ? s2_c_blocks(N1) : ceil_div(N1, 32)), RF_WAVES) * RF_WAVES;
     prof_begin(prof, XFH_SPAN_MATCH_REFINE, st);
     mnn_f16_thr_kernel<<<dim3(ceil_div(N1 > N2 ? N1 : N2, 256), P, 2), 256, 0, st>>>(ub, n1, n2, n_stride, n_off2, N1, N2, P, ws.na, ws.nb, ws.nmax, ws.rowmaxh, ws.colmaxh,
                                                                                         reinterpret_cast<_Float16*>(ws.thr_row), reinterpret_cast<_Float16*>(ws.thr_col));
-    mnn_f16_refine_kernel<<<xcd_grid_size(2 * (nyb / RF_WAVES), P), 64 * RF_WAVES, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nyb, P,
+    mnn_f16_refine_kernel<<<xcd_grid_size(2 * (nyb / RF_WAVES), P), 64 * RF_WAVES, 0, st>>>(d1, ps1, d2, ps2, n1, n2, n_stride, n_off2, N1, N2, nyb, one ? 1 : 0, P,
                                                                           reinterpret_cast<const _Float16*>(ws.thr_row), reinterpret_cast<const _Float16*>(ws.thr_col), reinterpret_cast<const _Float16*>(ws.R),
                                                                           reinterpret_cast<const _Float16*>(ws.C), ws.rowkey, ws.colkey);
     prof_end(prof, XFH_SPAN_MATCH_REFINE, st, 0, 0);

@@ -51,6 +51,7 @@ extern int g_debug_cold;      // debug (xfh_debug_cold_start): MFMA kernels inva
 // Per-handle kernel switches (xfh_set_option; include/xfeat_hip.h documents them).  No process-wide state: a handle carries its own copy.
 struct Options {
     int match_exact = 0;    // 1: xfh_match_mnn runs the exact f32-MFMA kernel for every pair (no filter)
+    int match_sweep = 0;    // the filter's sweep: 0 = by shape (one orientation per tile when its wave tasks fill the chip, else two), 1 = two orientations, 2 = one
     int fx = 1 | 2 | 8 | 2048;      // XFH_FX_ALL: which layer families run in the fp16-pair arithmetic (a cleared bit: the f32-MFMA kernel of the family)
     int resize2 = 1;        // the fused two-stage resize of the dual-scale dense path: 1 = the tile's input region staged in LDS by 16-byte loads, 0 = four-byte gathers
     int block1 = 7;         // 7: block1.2 and block1.3 on the fp16 matrix cores; 5: the vector-ALU kernel
@@ -177,7 +178,7 @@ struct MatchWs {
 void launch_match(const MatchWs& ws, const float* d1, size_t ps1, const float* d2, size_t ps2, const int32_t* n1,
                   const int32_t* n2, int n_stride, int n_off2, int P, int N1, int N2, float min_cossim,
                   int64_t* idx0, int64_t* idx1, int32_t* n_matches, hipStream_t st, Profiler* prof, const uint16_t* d1_16 = nullptr, const uint16_t* d2_16 = nullptr,
-                  bool exact_only = false);
+                  bool exact_only = false, int sweep_form = 0);
 int match_row_blocks(int N1);
 int match_debug_occupancy();
 

@@ -198,7 +198,7 @@ class XFeatModel(nn.Module):
         return h
 
     # include/xfeat_hip.h: xfh_set_option (= api.hip: xfh_set_option's checks)
-    OPTION_VALUES = {"match_exact": lambda v: v in (0, 1), "resize2": lambda v: v in (0, 1), "block1": lambda v: v in (5, 7), "fx": lambda v: v >= 0 and (v & ~DEFAULT_FX) == 0}
+    OPTION_VALUES = {"match_exact": lambda v: v in (0, 1), "match_sweep": lambda v: v in (0, 1, 2), "resize2": lambda v: v in (0, 1), "block1": lambda v: v in (5, 7), "fx": lambda v: v >= 0 and (v & ~DEFAULT_FX) == 0}
 
     def set_option(self, key, value):
         """Kernel switch of this model's handle (include/xfeat_hip.h: xfh_set_option): the default kernel of a layer family or its fp32-range fallback.

@@ -103,6 +103,9 @@ int xfh_resize_bilinear(const float* src, int planes, int Hin, int Win, float* d
  *   "block1"        5 | 7   DEFAULT 7: block1.2 (8 -> 8) and block1.3 (8 -> 24, stride 2) on the fp16 matrix cores in the fp16-pair arithmetic (block1_mx_kernel);
  *                           5: every layer of block1 on the vector ALUs (block1_fused_kernel: fp32's range).  Both recompute conv1 inside conv2 (no c1 tile in LDS).
  *   "match_exact"   0 | 1   1: xfh_match_mnn computes every similarity on the f32 matrix cores (no fp16 filter): the kernel the default is tested against
+ *   "match_sweep"   0..2    DEFAULT 0: the filter's pass over the fp16 product multiplies every 32 x 32 tile ONCE (mnn_f16_sweep2_kernel: column-direction block maxima over
+ *                           the rows that meet in a lane) when P, N1, N2 give it enough wave tasks to fill the chip, else in both orientations (mnn_f16_sweep_kernel: finer
+ *                           work split); 1 / 2: always the two- / one-orientation form.  The same matches in every case: decisions are taken on exact fp32 dot products.
  *   "resize2"       0 | 1   DEFAULT 1.  The fused two-stage resize of the dual-scale dense path (xfh_backbone_resized): 1 = the tile's input region staged in LDS by
  *                           16-byte loads (needs Win % 4 == 0; otherwise, and with 0: four-byte gathers per tap).  Same bits either way.
  * THE RANGE FALLBACK: on XFH_STATUS_FX_RANGE (below) repeat the call with fx = 0 and block1 = 5 -- every kernel then has fp32's range and none converts to fp16,

@@ -1,6 +1,7 @@
 // mnn_f16_sweep_kernel (csrc/k_match_f16.hip: the matcher's filter -- ONE pass over S^ = D1 D2^T on v_mfma_f32_32x32x16_f16, every 32 x 32 tile in both orientations, block maxima
 // R / C and the row / column maxima; sliced out of the product source by tests/test_kernels_emulated.py into match_sweep_slice.hpp) on the host.
-// stdin: {P, N1, N2, n1, n2, nsplit} int32 (n1 / n2: valid rows of every pair; nsplit 0: launch_match_f16's choice for 256 CUs), then a16 (P*N1*64), b16 (P*N2*64) as fp32
+// stdin: {P, N1, N2, n1, n2, nsplit} int32 (n1 / n2: valid rows of every pair; nsplit 0: launch_match_f16's choice for 256 CUs; nsplit -1: mnn_f16_sweep2_kernel, the
+// one-orientation form -- its C has 32 ceil(N1 / 1024) rows per pair, row 32 g + l = the rows {1024 g + 32 t + l} of a column), then a16 (P*N1*64), b16 (P*N2*64) as fp32
 // values that are exact fp16 numbers; stdout: rowmax (P*N1), colmax (P*N2) as floats, R (P*ceil(N2/32)*N1), C (P*ceil(N1/32)*N2) (the kernel's fp16 quarter values x 4).
 #include "emu.hpp"
 #include <cstdio>
@@ -9,6 +10,8 @@
 using std::min;
 using std::max;
 #define XFH_CODE_SHIFT 0
+#define XFH_EMU_NOASM(...) ((void)0)
+#define XFH_KEEP_FRAGS(f) ((void)0)      // (register keep-alive of the product source: nothing to keep on the host)
 typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicMax(unsigned* p, unsigned v) {
@@ -53,12 +56,20 @@ int main() {
     for (size_t i = 0; i < af.size(); ++i) a16[i] = (_Float16)af[i];
     for (size_t i = 0; i < bf.size(); ++i) b16[i] = (_Float16)bf[i];
     std::vector<int32_t> n1(P, n1v), n2(P, n2v);
-    const int ncb32 = (N2 + 31) / 32, nrb32 = (N1 + 31) / 32;
+    const bool one = h[5] < 0;
+    const int ncb32 = (N2 + 31) / 32, nrb32 = one ? xfh::s2_c_blocks(N1) : (N1 + 31) / 32;
     std::vector<unsigned> rowmaxh((size_t)P * N1, 0u), colmaxh((size_t)P * N2, 0u);      // (zeroed by the caller: MatchWs::zeroed)
     std::vector<_Float16> R16((size_t)P * ncb32 * N1, (_Float16)NAN), C16((size_t)P * nrb32 * N2, (_Float16)NAN);      // block maxima: fp16, a quarter of the scaled product, rounded up
     const int ncc = (N2 + xfh::FT_COLS - 1) / xfh::FT_COLS;
     const int nsplit = h[5] > 0 ? h[5] : std::max(1, std::min((2 * 256 + ncc * P - 1) / (ncc * P), (N1 + 255) / 256));      // launch_match_f16, 256 CUs
     const size_t lds = sizeof(_Float16) * xfh::FT_COLS * xfh::FT_DS + sizeof(float) * 8 * xfh::FT_COLS + 64;
+    if (one) {
+        const int ncc2 = (N2 + xfh::S2_COLS - 1) / xfh::S2_COLS, ngq = ((N1 + xfh::S2_GROUP - 1) / xfh::S2_GROUP + xfh::S2_WAVES - 1) / xfh::S2_WAVES;
+        const size_t lds2 = sizeof(_Float16) * xfh::S2_COLS * xfh::FT_DS + sizeof(float) * xfh::S2_WAVES * 32 * xfh::S2_XP;
+        emu::launch(ncc2 * ngq * P, 64 * xfh::S2_WAVES, lds2, [&] {
+            xfh::mnn_f16_sweep2_kernel(a16.data(), (size_t)N1 * 64, b16.data(), (size_t)N2 * 64, n1.data(), n2.data(), 1, 0, N1, N2, ncc2, ngq, P, colmaxh.data(), rowmaxh.data(), R16.data(), C16.data());
+        });
+    } else
     emu::launch(ncc * nsplit * P, 512, lds, [&] {
         xfh::mnn_f16_sweep_kernel(a16.data(), (size_t)N1 * 64, b16.data(), (size_t)N2 * 64, n1.data(), n2.data(), 1, 0, N1, N2, ncc, nsplit, P, colmaxh.data(), rowmaxh.data(), R16.data(), C16.data());
     });

@@ -111,7 +111,7 @@ def test_python_option_table_mirrors_the_library():
     py = open(os.path.join(ROOT, "accelerated_features_amd", "xfeat.py")).read()
     keys_py = set(re.findall(r'"(\w+)": lambda', re.search(r"OPTION_VALUES = \{(.*?)\}\n", py).group(1)))
     keys_lib = set(re.findall(r'\{"(\w+)", &Options::\w+\}', API))
-    assert keys_py == keys_lib == {"match_exact", "block1", "fx", "resize2"}
+    assert keys_py == keys_lib == {"match_exact", "match_sweep", "block1", "fx", "resize2"}
     hdr = open(os.path.join(ROOT, "include", "xfeat_hip.h")).read()
     bits = {k: int(v) for k, v in re.findall(r"XFH_FX_(CONV64|CONV24|HEADS|FINE) = (\d+)", hdr)}
     all_bits = bits["CONV64"] | bits["CONV24"] | bits["HEADS"] | bits["FINE"]

@@ -172,7 +172,7 @@ def test_python_mirrors_of_the_library_defaults_agree_with_kernels_hpp():
     body = src[src.index("struct Options {"):]
     body = body[:body.index("};")]
     got = {k: eval(v) for k, v in re.findall(r"^\s*int\s+(\w+)\s*=\s*([\d |]+)\s*;", body, flags=re.M)}
-    assert (got["fx"], got["block1"]) == (xm.DEFAULT_FX, xm.DEFAULT_BLOCK1) and set(got) == {"match_exact", "fx", "resize2", "block1"}, got
+    assert (got["fx"], got["block1"]) == (xm.DEFAULT_FX, xm.DEFAULT_BLOCK1) and set(got) == {"match_exact", "match_sweep", "fx", "resize2", "block1"}, got
 
 
 def test_the_library_holds_no_retired_kernel():

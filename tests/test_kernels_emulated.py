@@ -83,12 +83,20 @@ def _slice_match_sweep():
     s += _between(t, "// Block maxima and thresholds travel as fp16", "// E in the units of the scaled product")
     s += _between(t, "constexpr int FT_TILES = FT_COLS / 32;", "// thresholds, once the maxima are complete")
     s = _must_sub(s, "__global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(", "inline void mnn_f16_sweep_kernel(")
+    s = _must_sub(s, "__global__ __launch_bounds__(64 * S2_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))\nvoid mnn_f16_sweep2_kernel(", "inline void mnn_f16_sweep2_kernel(")
+    s = _must_sub(s, "__shared__ __attribute__((aligned(16))) _Float16 Dl2[S2_COLS * FT_DS];", "_Float16* Dl2 = reinterpret_cast<_Float16*>(emu::wg->lds_base());")
+    s = _must_sub(s, "__shared__ float xp[S2_WAVES][32 * S2_XP];", "float (*xp)[32 * S2_XP] = reinterpret_cast<float (*)[32 * S2_XP]>(emu::wg->lds_base() + sizeof(_Float16) * S2_COLS * FT_DS);")
+    s = _must_sub(s, "__host__ __device__ inline int s2_c_blocks", "inline int s2_c_blocks")
+    s = _must_sub(s, "    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);\n    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));",
+                  "    return fmaxf(v, xhalf(v));")      # (the lane exchange by the emulator's shuffle)
     s = _must_sub(s, "__shared__ __attribute__((aligned(16))) _Float16 Dl[FT_COLS * FT_DS];", "_Float16* Dl = reinterpret_cast<_Float16*>(emu::wg->lds_base());")
     s = _must_sub(s, "__shared__ float colx[8][FT_COLS];", "float (*colx)[FT_COLS] = reinterpret_cast<float (*)[FT_COLS]>(emu::wg->lds_base() + sizeof(_Float16) * FT_COLS * FT_DS);")
     s = _must_sub(s, "__shared__ int next_block;", "int& next_block = *reinterpret_cast<int*>(emu::wg->lds_base() + sizeof(_Float16) * FT_COLS * FT_DS + sizeof(float) * 8 * FT_COLS);")
     s = _must_sub(s, "XFH_KEEP_FRAGS(bfrag[ct & 1]);", ";")
     s = _must_sub(s, "nxt = __builtin_amdgcn_readfirstlane(t);", "nxt = emu_bcast0(t);")      # (only lane 0 holds t: a real broadcast, emu.hpp's readfirstlane is the identity)
-    assert "asm volatile" not in s and "<<<" not in s and "__shared__" not in s
+    n0 = s.count('asm volatile("" :')
+    s = s.replace('asm volatile("" :', "XFH_EMU_NOASM(")      # value pins of the one-orientation sweep (empty statements with register constraints: nothing to run)
+    assert n0 == 6 and "asm volatile" not in s and "<<<" not in s and "__shared__" not in s
     return s
 
 
@@ -251,11 +259,13 @@ def test_fused_two_stage_resize_kernels_on_the_host(emu_bins, shape, scale):
     assert tuple(mid.shape[2:]) == (Hm, Wm) and err <= 2e-5      # (ATen's CPU kernel rounds its weights differently; the GPU suite compares with the oracle bit for bit)
 
 
-@pytest.mark.parametrize("P,N1,N2,n1,n2,nsplit", [(1, 96, 64, 96, 64, 1), (2, 300, 280, 290, 259, 0), (1, 520, 300, 520, 300, 2), (1, 40, 700, 33, 690, 0)])
+@pytest.mark.parametrize("P,N1,N2,n1,n2,nsplit", [(1, 96, 64, 96, 64, 1), (2, 300, 280, 290, 259, 0), (1, 520, 300, 520, 300, 2), (1, 40, 700, 33, 690, 0),
+                                                  (1, 96, 64, 96, 64, -1), (2, 300, 280, 290, 259, -1), (1, 40, 700, 33, 690, -1), (1, 1100, 150, 1061, 140, -1), (1, 2200, 40, 2200, 40, -1)])
 def test_match_sweep_kernel_on_the_host(emu_bins, P, N1, N2, n1, n2, nsplit):
     """The matcher's filter pass (modules/xfeat.py:327-348 computes D1 @ D2.T; here one fp16-MFMA sweep that keeps only maxima): row / column maxima and the per-block maxima
     R / C of the fp16 product against numpy on the same fp16 numbers -- several column chunks (N2 > 256), row blocks shared out over workgroups (nsplit), partial blocks, valid
-    counts below the capacity (the rows / columns beyond them must not leak into any maximum)."""
+    counts below the capacity (the rows / columns beyond them must not leak into any maximum).  nsplit -1: the one-orientation form (mnn_f16_sweep2_kernel), whose C block
+    (g, l) holds the maximum over the rows {1024 g + 32 t + l} of a column -- several row groups (N1 > 1024), a last group with residues that have no valid row."""
     g = torch.Generator().manual_seed(N1 + N2)
     a = torch.nn.functional.normalize(torch.randn(P, N1, 64, generator=g), dim=-1) * 256
     b = torch.nn.functional.normalize(torch.randn(P, N2, 64, generator=g), dim=-1) * 256
@@ -263,7 +273,8 @@ def test_match_sweep_kernel_on_the_host(emu_bins, P, N1, N2, n1, n2, nsplit):
     a16, b16 = a.half().float(), b.half().float()
     out = subprocess.run([emu_bins["match_sweep_emu"]], input=_blob([P, N1, N2, n1, n2, nsplit], [a16, b16]), capture_output=True, check=True, timeout=300).stdout
     y = np.frombuffer(out, np.float32)
-    ncb, nrb = -(-N2 // 32), -(-N1 // 32)
+    one = nsplit < 0
+    ncb, nrb = -(-N2 // 32), (-(-N1 // 1024) * 32 if one else -(-N1 // 32))
     rm, cm = y[:P * N1].reshape(P, N1), y[P * N1:P * (N1 + N2)].reshape(P, N2)
     R = y[P * (N1 + N2):P * (N1 + N2) + P * ncb * N1].reshape(P, ncb, N1)
     C = y[P * (N1 + N2) + P * ncb * N1:].reshape(P, nrb, N2)
@@ -276,8 +287,18 @@ def test_match_sweep_kernel_on_the_host(emu_bins, P, N1, N2, n1, n2, nsplit):
         return bool((got >= want - tol).all() and (got <= hi).all())
     for cb in range(-(-n2 // 32)):
         assert block_ok(R[:, cb, :n1], S[:, :, cb * 32:(cb + 1) * 32].max(2)), ("R", cb)
-    for rb in range(-(-n1 // 32)):
-        assert block_ok(C[:, rb, :n2], S[:, rb * 32:(rb + 1) * 32, :].max(1)), ("C", rb)
+    if one:
+        for gl in range(nrb):
+            g_, l_ = gl >> 5, gl & 31
+            rows = np.arange(1024 * g_ + l_, min(1024 * (g_ + 1), n1), 32)
+            if 1024 * g_ < n1 and len(rows):       # (a residue without a valid row in a live group: written, from copies of the last valid row, and never read)
+                last_blk = min(-(-n1 // 32), 32 * (g_ + 1)) - 1          # the group's last row block: its rows >= n1 are copies of row n1 - 1 (a valid row of ANOTHER block:
+                if 32 * last_blk + l_ >= n1:                             # the block maximum can only grow -- the filter stays conservative)
+                    rows = np.append(rows, n1 - 1)
+                assert block_ok(C[:, gl, :n2], S[:, rows, :].max(1)), ("C", g_, l_)
+    else:
+        for rb in range(-(-n1 // 32)):
+            assert block_ok(C[:, rb, :n2], S[:, rb * 32:(rb + 1) * 32, :].max(1)), ("C", rb)
     print(f"match sweep P {P} {N1} x {N2} (valid {n1} x {n2}): row / column / block maxima within {tol:.3g} of numpy (max |S| {float(np.abs(S).max()):.4g})")
 
 
