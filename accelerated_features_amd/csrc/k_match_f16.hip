@@ -353,7 +353,7 @@ void mnn_f16_sweep2_kernel(const _Float16* __restrict__ a16, size_t sa16, const 
                            int N1, int N2, int ncc, int ngq, int P,
                            unsigned* __restrict__ colmaxh, unsigned* __restrict__ rowmaxh, _Float16* __restrict__ R, _Float16* __restrict__ C) {
     __shared__ __attribute__((aligned(16))) _Float16 Dl2[S2_COLS * FT_DS];      // the columns
-    __shared__ float xp[S2_WAVES][32 * S2_XP];                                  // per wave: the transposition tile of the flush
+    __shared__ __attribute__((aligned(16))) _Float16 af[S2_WAVES][64 * FT_DS];  // per wave: the 64 rows of a block pair on their way into MFMA operand order (and, after the loop, the transposition tile of the flush)
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int p, item;
@@ -382,15 +382,26 @@ void mnn_f16_sweep2_kernel(const _Float16* __restrict__ a16, size_t sa16, const 
     }
     const int g = gq * S2_WAVES + wave;
     const int blk_lo = g * S2_T, nblock = min(ceil_div(n1, 32), blk_lo + S2_T);
-    f16x8 a[4], an[4];
-    if (blk_lo < nblock) {
-        const int row = min(blk_lo * 32 + l31, n1 - 1);       // rows >= n1: copies of the last valid row (never reported)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) an[kk] = *reinterpret_cast<const f16x8*>(A + (size_t)row * 64 + kk * 16 + half * 8);
+    // TWO row blocks per step (64 consecutive rows: lanes 0-31 and 32-63 of an A fragment hold the same 32 rows, so block X and block Y each have their own fragments):
+    // every B fragment that leaves LDS feeds two MFMAs, and the two accumulators of a tile meet in ONE v_max3 per running maximum
+    f16x8 ax[4], ay[4], anx[4], any_[4];
+    // The 64 rows of a block pair are 8 KB of consecutive memory.  A lane reading ITS row's 16-byte pieces straight into operand order is a 32-line gather per instruction
+    // (the CU's address unit takes one line per cycle: eight such loads per pair and wave were 22 us of this kernel); here a wave requests the 8 KB in eight fully coalesced
+    // instructions (lane i of instruction q: piece 64 q + i), passes them through its own LDS rows (the columns' padded layout: conflict-free both ways) and reads its fragments back.
+#define XFH_S2_REQUEST(BLK)                                                                                \
+    {                                                                                                     \
+        /* rows >= n1: copies of the last valid row (never reported); a pair without a second block multiplies the first one twice (no row of another residue gets into a C block) */ \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+            const int e = q * 64 + lane, rx = min((BLK) * 32 + (e >> 3), n1 - 1), ry = (BLK) + 1 < nblock ? min((BLK) * 32 + 32 + (e >> 3), n1 - 1) : rx;       \
+            anx[q] = *reinterpret_cast<const f16x8*>(A + (size_t)rx * 64 + (e & 7) * 8);                  \
+            any_[q] = *reinterpret_cast<const f16x8*>(A + (size_t)ry * 64 + (e & 7) * 8);                 \
+        }                                                                                                 \
     }
+    XFH_S2_REQUEST(min(blk_lo, max(nblock - 1, 0)))
     __syncthreads();
     if (blk_lo >= nblock) return;                              // (whole waves leave: nothing below synchronises across waves)
     const _Float16* bp0 = Dl2 + l31 * FT_DS + half * 8;
+    _Float16* afw = af[wave];
     f32x16 M[S2_TILES];                                        // running maxima: M[ct][r] = max over this wave's row blocks of S^(32 blk + l31, column (r & 3) + 8 (r >> 2) + 4 half of tile ct)
 #pragma unroll
     for (int ct = 0; ct < S2_TILES; ++ct)
@@ -398,92 +409,107 @@ void mnn_f16_sweep2_kernel(const _Float16* __restrict__ a16, size_t sa16, const 
         for (int r = 0; r < 16; ++r) M[ct][r] = -INFINITY;
     // R rows of this chunk: tiles beyond the last column block of R are outside the resource's range (their stores are dropped)
     const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(R + ((size_t)p * ncb32 + (c0 >> 5)) * N1, 0, min(S2_TILES, ncb32 - (c0 >> 5)) * N1 * 2, 0x00020000);
-    for (int blk = blk_lo; blk < nblock; ++blk) {
+    // B fragments: a rolling set of four (16 steps per block pair: the ring closes; step = tile ct, K chunk kk; the fragment of step s + 2 leaves LDS while step s is multiplied -- the steps of the next block pair read
+    // the same addresses, so the ring never drains)
+    constexpr int NSTEP = 4 * S2_TILES;
+    f16x8 bq[4];
+    bq[0] = *reinterpret_cast<const f16x8*>(bp0);
+    bq[1] = *reinterpret_cast<const f16x8*>(bp0 + 16);
+    for (int blk = blk_lo; blk < nblock; blk += 2) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a[kk] = an[kk];
-        if (blk + 1 < nblock) {                                // the next block's fragments on their way under this block's MFMAs
-            const int row = min((blk + 1) * 32 + l31, n1 - 1);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) an[kk] = *reinterpret_cast<const f16x8*>(A + (size_t)row * 64 + kk * 16 + half * 8);
+        for (int q = 0; q < 4; ++q) {
+            const int e = q * 64 + lane;
+            *reinterpret_cast<f16x8*>(afw + (e >> 3) * FT_DS + (e & 7) * 8) = anx[q];
+            *reinterpret_cast<f16x8*>(afw + (32 + (e >> 3)) * FT_DS + (e & 7) * 8) = any_[q];
         }
-        const int myrow = blk * 32 + l31;
-        const int offR = (half == 1 && myrow < n1) ? myrow * 2 : (int)0x80000000;      // (branch-free stores: lanes that must not store carry an out-of-range offset)
+        XFH_WAVE_SYNC();
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            ax[kk] = *reinterpret_cast<const f16x8*>(afw + l31 * FT_DS + kk * 16 + half * 8);
+            ay[kk] = *reinterpret_cast<const f16x8*>(afw + (32 + l31) * FT_DS + kk * 16 + half * 8);
+        }
+        XFH_WAVE_SYNC();
+        // NO BRANCH in this loop: behind a conditional memory operation hipcc waits for EVERY outstanding one (vmcnt(0)) -- the R stores and the row-maximum atomic of the pair
+        // before, a full trip to memory per iteration (the kernel ran at half its speed).  The last pair requests its own fragments again; the atomic goes to the row whose
+        // maximum the lane really holds.
+        XFH_S2_REQUEST(min(blk + 2, nblock - 1))               // the next pair's fragments on their way under this pair's MFMAs
+        const int myrow = blk * 32 + lane;                     // after the half-wave exchange below lane l holds row 32 blk + l of the 64
+        const int offR = myrow < n1 ? myrow * 2 : (int)0x80000000;      // (branch-free stores: lanes that must not store carry an out-of-range offset)
+        const int arow = half && blk + 1 >= nblock ? min(blk * 32 + l31, n1 - 1) : min(myrow, n1 - 1);      // (a pair without a second block multiplied the first one twice)
         float rowrun = -INFINITY;
-        f16x8 bfrag[2][4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) bfrag[0][kk] = *reinterpret_cast<const f16x8*>(bp0 + kk * 16);
-        f32x16 acc[2];
-        // Software pipeline over the tiles, one basic block, PROGRAM ORDER = ISSUE ORDER (scheduling fences between the groups; left alone, hipcc sank all 64 elementwise
-        // maxima of a row block behind its last MFMA): tile ct's first two MFMAs, then -- while the matrix pipe works through them and the next two -- tile ct - 1 is reduced
-        // in three groups of ~ 11 vector instructions: the max3 tree of its 16 values (its last MFMA is two MFMAs back by then: no wait for the result), the other half-wave's
-        // maximum / R store, the 16 elementwise maxima into M.  The fragments of tile ct + 1 leave LDS meanwhile.
+        f32x16 accx[2], accy[2];
+        // Software pipeline over the tiles, one basic block, PROGRAM ORDER = ISSUE ORDER (scheduling fences between the groups, the values pinned by empty asm statements;
+        // left alone, hipcc sank all the elementwise maxima of a row block behind its last MFMA): a tile is 4 K chunks x 2 MFMAs (block X, block Y), and behind each chunk's
+        // pair comes a quarter of the reduction of tile ct - 1 (~ 10 vector instructions): the max3 tree of X, the tree of Y, the half-wave exchange (v_permlane32_swap
+        // of the two row maxima: lanes 0-31 end up with block X's, lanes 32-63 with block Y's -- one fp16 conversion and ONE 128-byte store for 64 rows) and the running
+        // maxima M = max3(M, X, Y).
 #define XFH_S2_FENCE() __builtin_amdgcn_sched_barrier(0)
-        // (the fence orders the machine scheduler; the empty asm statements pin the VALUES -- without them the optimiser moves the arithmetic itself, before any scheduling)
-#define XFH_S2_PIN3(CT, R0) asm volatile("" : "+v"(M[CT][R0]), "+v"(M[CT][(R0) + 1]), "+v"(M[CT][(R0) + 2]))
+#define XFH_S2_M(CT, R0, R1) { _Pragma("unroll") for (int r = (R0); r < (R1); ++r) M[CT][r] = fmaxf(fmaxf(M[CT][r], accx[(CT) & 1][r]), accy[(CT) & 1][r]); }
 #define XFH_S2_PIN2(CT, R0) asm volatile("" : "+v"(M[CT][R0]), "+v"(M[CT][(R0) + 1]))
-#define XFH_S2_PIN11(CT, R0) asm volatile("" : "+v"(M[CT][R0]), "+v"(M[CT][(R0) + 1]), "+v"(M[CT][(R0) + 2]), "+v"(M[CT][(R0) + 3]), "+v"(M[CT][(R0) + 4]), "+v"(M[CT][(R0) + 5]), \
-                                                "+v"(M[CT][(R0) + 6]), "+v"(M[CT][(R0) + 7]), "+v"(M[CT][(R0) + 8]), "+v"(M[CT][(R0) + 9]), "+v"(M[CT][(R0) + 10]))
-#define XFH_S2_PINACC(x) asm volatile("" : "+v"(x))
-#define XFH_S2_M(CT, R0, R1) { _Pragma("unroll") for (int r = (R0); r < (R1); ++r) M[CT][r] = fmaxf(M[CT][r], acc[(CT) & 1][r]); }
-#define XFH_S2_EPI_A(CT) float rm_ = max16(acc[(CT) & 1]); XFH_S2_M(CT, 0, 3) XFH_S2_PIN3(CT, 0); asm volatile("" : "+v"(rm_));
-#define XFH_S2_EPI_B(CT)                                                                                  \
-            rm_ = xhalf_max(rm_);                                                                         \
-            rowrun = fmaxf(rowrun, rm_);                                                                  \
-            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, f16_up(rm_ * F16_STORE_SCALE)), rR, offR + (CT) * N1 * 2, 0, 0);   /* (in the lane offset: the range check does not see a scalar offset) */ \
-            XFH_S2_M(CT, 3, 5) XFH_S2_PIN2(CT, 3); asm volatile("" : "+v"(rowrun));
-#define XFH_S2_EPI_C(CT) XFH_S2_M(CT, 5, 16) XFH_S2_PIN11(CT, 5);
+#define XFH_S2_PIN10(CT, R0) asm volatile("" : "+v"(M[CT][R0]), "+v"(M[CT][(R0) + 1]), "+v"(M[CT][(R0) + 2]), "+v"(M[CT][(R0) + 3]), "+v"(M[CT][(R0) + 4]), "+v"(M[CT][(R0) + 5]), \
+                                                "+v"(M[CT][(R0) + 6]), "+v"(M[CT][(R0) + 7]), "+v"(M[CT][(R0) + 8]), "+v"(M[CT][(R0) + 9]))
+#define XFH_S2_EPI0(CT) rx_ = max16(accx[(CT) & 1]); XFH_S2_M(CT, 0, 2) XFH_S2_PIN2(CT, 0); asm volatile("" : "+v"(rx_));
+#define XFH_S2_EPI1(CT) ry_ = max16(accy[(CT) & 1]); XFH_S2_M(CT, 2, 4) XFH_S2_PIN2(CT, 2); asm volatile("" : "+v"(ry_));
+#define XFH_S2_EPI2(CT)                                                                                   \
+            {                                                                                             \
+                const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(rx_), __float_as_uint(ry_), false, false);      /* {x.lo, y.lo}, {x.hi, y.hi} */ \
+                const float rm_ = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));                \
+                rowrun = fmaxf(rowrun, rm_);                                                              \
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, f16_up(rm_ * F16_STORE_SCALE)), rR, offR + (CT) * N1 * 2, 0, 0);   /* (in the lane offset: the range check does not see a scalar offset) */ \
+            }                                                                                             \
+            XFH_S2_M(CT, 4, 6) XFH_S2_PIN2(CT, 4); asm volatile("" : "+v"(rowrun));
+#define XFH_S2_EPI3(CT) XFH_S2_M(CT, 6, 16) XFH_S2_PIN10(CT, 6);
+        float rx_ = 0.f, ry_ = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < S2_TILES; ++ct) {
-            if (ct + 1 < S2_TILES) {
+        for (int ct = 0; ct < S2_TILES; ++ct)
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) bfrag[(ct + 1) & 1][kk] = *reinterpret_cast<const f16x8*>(bp0 + (ct + 1) * 32 * FT_DS + kk * 16);
+        for (int kk = 0; kk < 4; ++kk) {
+            const int s_ = 4 * ct + kk;
+            {   // the fragment two steps ahead
+                const int sn = (s_ + 2) % NSTEP;
+                bq[(s_ + 2) & 3] = *reinterpret_cast<const f16x8*>(bp0 + (sn >> 2) * 32 * FT_DS + (sn & 3) * 16);
             }
-            f32x16& c_ = acc[ct & 1];
+            f32x16& cx = accx[ct & 1];
+            f32x16& cy = accy[ct & 1];
+            if (kk == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c_[r] = 0.f;
-            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][0], a[0], c_, 0, 0, 0);
-            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][1], a[1], c_, 0, 0, 0);
-            XFH_S2_PINACC(c_);
+                for (int r = 0; r < 16; ++r) { cx[r] = 0.f; cy[r] = 0.f; }
+            }
+            cx = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[s_ & 3], ax[kk], cx, 0, 0, 0);
+            cy = __builtin_amdgcn_mfma_f32_32x32x16_f16(bq[s_ & 3], ay[kk], cy, 0, 0, 0);
+            asm volatile("" : "+v"(cx), "+v"(cy));
             XFH_S2_FENCE();
             if (ct > 0) {
-                XFH_S2_EPI_A(ct - 1)
+                if (kk == 0) { XFH_S2_EPI0(ct - 1) }
+                if (kk == 1) { XFH_S2_EPI1(ct - 1) }
+                if (kk == 2) { XFH_S2_EPI2(ct - 1) }
+                if (kk == 3) { XFH_S2_EPI3(ct - 1) }
                 XFH_S2_FENCE();
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][2], a[2], c_, 0, 0, 0);
-                XFH_S2_PINACC(c_);
-                XFH_S2_FENCE();
-                XFH_S2_EPI_B(ct - 1)
-                XFH_S2_FENCE();
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][3], a[3], c_, 0, 0, 0);
-                XFH_S2_PINACC(c_);
-                XFH_S2_FENCE();
-                XFH_S2_EPI_C(ct - 1)
-            } else {
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][2], a[2], c_, 0, 0, 0);
-                c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bfrag[ct & 1][3], a[3], c_, 0, 0, 0);
             }
-            XFH_S2_FENCE();
-            XFH_KEEP_FRAGS(bfrag[ct & 1]);
+            asm volatile("" :: "v"(bq[s_ & 3]));          // (a fragment stays alive until the group behind its MFMAs is over: tools/check_mfma_war.py)
         }
         {
-            XFH_S2_EPI_A(S2_TILES - 1)
-            XFH_S2_EPI_B(S2_TILES - 1)
-            XFH_S2_EPI_C(S2_TILES - 1)
+            XFH_S2_EPI0(S2_TILES - 1)
+            XFH_S2_EPI1(S2_TILES - 1)
+            XFH_S2_EPI2(S2_TILES - 1)
+            XFH_S2_EPI3(S2_TILES - 1)
         }
         XFH_S2_FENCE();
-        XFH_KEEP_FRAGS(a);          // (the next block's fragments must not be copied over this block's right behind its last MFMA)
+        XFH_KEEP_FRAGS(ax);          // (the next pair's fragments must not be copied over this pair's right behind its last MFMA)
+        XFH_KEEP_FRAGS(ay);
 #undef XFH_S2_FENCE
-#undef XFH_S2_PIN3
 #undef XFH_S2_PIN2
-#undef XFH_S2_PIN11
-#undef XFH_S2_PINACC
+#undef XFH_S2_PIN10
 #undef XFH_S2_M
-#undef XFH_S2_EPI_A
-#undef XFH_S2_EPI_B
-#undef XFH_S2_EPI_C
-        if (half == 0 && myrow < n1) atomicMax(&rowmaxh[(size_t)p * N1 + myrow], float_ord(rowrun));      // (no return value: fire and forget)
+#undef XFH_S2_EPI0
+#undef XFH_S2_EPI1
+#undef XFH_S2_EPI2
+#undef XFH_S2_EPI3
+        atomicMax(&rowmaxh[(size_t)p * N1 + arow], float_ord(rowrun));      // (no return value: fire and forget; a row >= n1 is a copy of row n1 - 1 and carries that row's maximum)
     }
     // ---- flush: the running maxima of this row group, tile by tile through the wave's 32 x 32 LDS tile (row = residue l, column = column of the tile)
-    float* xw = xp[wave];
+    float* xw = reinterpret_cast<float*>(af[wave]);          // (the fragment rows are done with)
+    static_assert(32 * S2_XP * 4 <= 64 * FT_DS * 2, "the flush tile lives in the wave's fragment rows");
     const bool vec_ok = (N2 & 7) == 0;                         // 16-byte stores (eight fp16 values) need 16-byte aligned rows of C
     _Float16* crow = C + ((size_t)p * s2_c_blocks(N1) + g * 32 + l31) * N2 + c0;
 #pragma unroll

@@ -40,6 +40,14 @@ inline int emu_bcast0(int v) {
     emu::wg->wave_bar[w]->arrive_and_wait();
     return r;
 }
+// v_permlane32_swap_b32 (gfx950): the upper half of the first register changes places with the lower half of the second -- {a.lo, b.lo}, {a.hi, b.hi}
+struct EmuSwap { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+inline EmuSwap emu_permlane32_swap(unsigned a, unsigned b) {
+    const float ao = emu::shfl_xor(__uint_as_float(a), 32), bo = emu::shfl_xor(__uint_as_float(b), 32);
+    const bool hi = (emu::tidx.x & 32) != 0;
+    return EmuSwap{{hi ? __float_as_uint(bo) : a, hi ? b : __float_as_uint(ao)}};
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, x, y) emu_permlane32_swap(a, b)
 namespace xfh {
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }      // (common.hpp)
 inline unsigned float_ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }      // (common.hpp)
@@ -65,7 +73,7 @@ int main() {
     const size_t lds = sizeof(_Float16) * xfh::FT_COLS * xfh::FT_DS + sizeof(float) * 8 * xfh::FT_COLS + 64;
     if (one) {
         const int ncc2 = (N2 + xfh::S2_COLS - 1) / xfh::S2_COLS, ngq = ((N1 + xfh::S2_GROUP - 1) / xfh::S2_GROUP + xfh::S2_WAVES - 1) / xfh::S2_WAVES;
-        const size_t lds2 = sizeof(_Float16) * xfh::S2_COLS * xfh::FT_DS + sizeof(float) * xfh::S2_WAVES * 32 * xfh::S2_XP;
+        const size_t lds2 = sizeof(_Float16) * xfh::S2_COLS * xfh::FT_DS + sizeof(_Float16) * xfh::S2_WAVES * 64 * xfh::FT_DS;
         emu::launch(ncc2 * ngq * P, 64 * xfh::S2_WAVES, lds2, [&] {
             xfh::mnn_f16_sweep2_kernel(a16.data(), (size_t)N1 * 64, b16.data(), (size_t)N2 * 64, n1.data(), n2.data(), 1, 0, N1, N2, ncc2, ngq, P, colmaxh.data(), rowmaxh.data(), R16.data(), C16.data());
         });

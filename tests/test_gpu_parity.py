@@ -1017,6 +1017,13 @@ def test_match_filter_and_refine_equals_exact_kernel(xf):
         finally:
             xf.set_option("match_exact", 0)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (d1.shape, d2.shape, mc, len(a[0]), len(b[0]))
+        for form in (1, 2):          # the filter's sweep in its two-orientation and its one-orientation form (option match_sweep; the default chooses by shape)
+            xf.set_option("match_sweep", form)
+            try:
+                c = xf.match(d1.cuda(), d2.cuda(), min_cossim=mc)
+            finally:
+                xf.set_option("match_sweep", 0)
+            assert torch.equal(c[0], b[0]) and torch.equal(c[1], b[1]), ("match_sweep", form, d1.shape, d2.shape, mc, len(c[0]), len(b[0]))
         return a
 
     for n1, n2 in ((4096, 4096), (1000, 31), (33, 257), (1, 1), (2500, 4000), (5000, 300)):
@@ -1123,8 +1130,18 @@ def test_match_on_rounding_aligned_adversarial_sets(xf):
                 b = xf.match(t1.cuda(), t2.cuda(), min_cossim=mc)
             finally:
                 xf.set_option("match_exact", 0)
-            for got in (a, b):
+            forms = []
+            for form in (1, 2):      # both forms of the filter's sweep (option match_sweep)
+                xf.set_option("match_sweep", form)
+                try:
+                    forms.append(xf.match(t1.cuda(), t2.cuda(), min_cossim=mc))
+                finally:
+                    xf.set_option("match_sweep", 0)
+            for got in (a, b) + tuple(forms):
                 A.check_mnn_fp64(d1, d2, got[0].cpu().numpy(), got[1].cpu().numpy(), mc)
+            if "all_equal" not in name:
+                for c in forms:
+                    assert torch.equal(c[0], b[0]) and torch.equal(c[1], b[1]), (name, mc, "match_sweep")
             if "all_equal" not in name:               # (all-equal rows: every pair is a tie, any consistent answer passes the check above)
                 assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), (name, mc, len(a[0]), len(b[0]))
                 if mc < 0:

@@ -85,7 +85,7 @@ def _slice_match_sweep():
     s = _must_sub(s, "__global__ __launch_bounds__(512) void mnn_f16_sweep_kernel(", "inline void mnn_f16_sweep_kernel(")
     s = _must_sub(s, "__global__ __launch_bounds__(64 * S2_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))\nvoid mnn_f16_sweep2_kernel(", "inline void mnn_f16_sweep2_kernel(")
     s = _must_sub(s, "__shared__ __attribute__((aligned(16))) _Float16 Dl2[S2_COLS * FT_DS];", "_Float16* Dl2 = reinterpret_cast<_Float16*>(emu::wg->lds_base());")
-    s = _must_sub(s, "__shared__ float xp[S2_WAVES][32 * S2_XP];", "float (*xp)[32 * S2_XP] = reinterpret_cast<float (*)[32 * S2_XP]>(emu::wg->lds_base() + sizeof(_Float16) * S2_COLS * FT_DS);")
+    s = _must_sub(s, "__shared__ __attribute__((aligned(16))) _Float16 af[S2_WAVES][64 * FT_DS];", "_Float16 (*af)[64 * FT_DS] = reinterpret_cast<_Float16 (*)[64 * FT_DS]>(emu::wg->lds_base() + sizeof(_Float16) * S2_COLS * FT_DS);")
     s = _must_sub(s, "__host__ __device__ inline int s2_c_blocks", "inline int s2_c_blocks")
     s = _must_sub(s, "    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);\n    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));",
                   "    return fmaxf(v, xhalf(v));")      # (the lane exchange by the emulator's shuffle)
@@ -96,7 +96,7 @@ def _slice_match_sweep():
     s = _must_sub(s, "nxt = __builtin_amdgcn_readfirstlane(t);", "nxt = emu_bcast0(t);")      # (only lane 0 holds t: a real broadcast, emu.hpp's readfirstlane is the identity)
     n0 = s.count('asm volatile("" :')
     s = s.replace('asm volatile("" :', "XFH_EMU_NOASM(")      # value pins of the one-orientation sweep (empty statements with register constraints: nothing to run)
-    assert n0 == 6 and "asm volatile" not in s and "<<<" not in s and "__shared__" not in s
+    assert n0 == 7 and "asm volatile" not in s and "<<<" not in s and "__shared__" not in s
     return s
 
 
