@@ -610,9 +610,13 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     for (int i = 0; i < 4; ++i) cx[i] = (x0 + i >= 0 && x0 + i < wc) ? x0 + i : 0x00800000;      // 2^23 pixels = byte offset 2^31: outside any map, no 32-bit wrap
     // 1 / |feats| of the 16 taps: lane `sub` fetches tap `sub`'s factor (ONE load instruction per key-point group instead of sixteen
     // broadcast loads: the kernel is bound by the number of vector-memory instructions the texture addresser has to walk, not by misses --
-    // visiting the key-points in spatial instead of score order left its time unchanged), handed round by ds_bpermute below
+    // visiting the key-points in spatial instead of score order left its time unchanged), handed round by DPP row broadcasts below
     const float inv_mine = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ri, ((y0 + (sub >> 2)) * wc + cx[sub & 3]) * 4, 0, 0));
-    const int lane_base = (threadIdx.x & 63) & ~15;
+    // DPP row_newbcast: lane t of this key-point's 16 lanes to all of them -- one VALU move per tap (ds_bpermute was an address, an LDS trip and a wait per tap)
+#define XFH_ROW_BCAST(T) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(inv_mine), 0x150 + (T), 0xf, 0xf, false))
+    const float sc_tap[16] = {XFH_ROW_BCAST(0), XFH_ROW_BCAST(1), XFH_ROW_BCAST(2), XFH_ROW_BCAST(3), XFH_ROW_BCAST(4), XFH_ROW_BCAST(5), XFH_ROW_BCAST(6), XFH_ROW_BCAST(7),
+                              XFH_ROW_BCAST(8), XFH_ROW_BCAST(9), XFH_ROW_BCAST(10), XFH_ROW_BCAST(11), XFH_ROW_BCAST(12), XFH_ROW_BCAST(13), XFH_ROW_BCAST(14), XFH_ROW_BCAST(15)};
+#undef XFH_ROW_BCAST
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
             const int pix = rowpix + cx[i];
             const uint4 u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rf, pix * 256 + sub * 16, 0, 0));
             const float4 v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-            const float sc = __shfl(inv_mine, lane_base + 4 * r + i, 64);
+            const float sc = sc_tap[4 * r + i];
             row.x += (v.x * sc) * wx[i]; row.y += (v.y * sc) * wx[i];
             row.z += (v.z * sc) * wx[i]; row.w += (v.w * sc) * wx[i];
         }

@@ -36,6 +36,7 @@
 // bf16 and the window above is derived, and tested on rounding-aligned adversarial rows: tests/test_gpu_parity.py.)
 #include "../../include/xfeat_hip.h"
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace xfh {
 
@@ -653,13 +654,13 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4
             }
             cnt = 0;
         };
-        // ---- phase 1: scan.  Eight block maxima per lane and round (two 16-byte loads of each array); the next round is in flight while
-        //      this one is tested: one compare per element, the queue bookkeeping only for the (rare) hits.
+        // ---- phase 1: scan.  Eight block maxima per lane and round (ONE 16-byte load of each array), FOUR rounds in flight, every load UNCONDITIONAL (a round past the
+        //      end reads zeros through the resource's range check and is not tested): behind a conditional load hipcc waits for every outstanding one (vmcnt(0)), which made
+        //      the two-deep prefetch this loop had a chain of eight full memory round trips.  One compare per element, the queue bookkeeping only for the (rare) hits.
         const int nround = ceil_div(min(RF_CHUNK, nX - xc), RF_ROUND);
-        f16x8 ma, ta, mb, tb;                                  // two rounds in flight: set a (even rounds), set b (odd rounds); ONE 16-byte load per array, lane and round
-        auto issue = [&](int r, f16x8& m, f16x8& t) {
+        auto issue = [&](auto vec, int r, f16x8& m, f16x8& t) {      // vec: std::true_type / false_type -- the choice is made ONCE, outside the rounds (no branch between their loads)
             const int xb = xc + r * RF_ROUND + lane * 8;
-            if (vec_ok) {
+            if constexpr (decltype(vec)::value) {
                 m = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rM, xb * 2, 0, 0));
                 t = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rT, xb * 2, 0, 0));
             } else {
@@ -690,15 +691,19 @@ __global__ __launch_bounds__(64 * RF_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 }
             }
         };
-        issue(0, ma, ta);
-        for (int r = 0; r < nround; r += 2) {
-            if (r + 1 < nround) issue(r + 1, mb, tb);
-            test(r, ma, ta);
-            if (r + 1 < nround) {
-                if (r + 2 < nround) issue(r + 2, ma, ta);
-                test(r + 1, mb, tb);
+        auto scan = [&](auto vec) {
+            constexpr int NB = decltype(vec)::value ? 4 : 1;      // (unaligned rows: sixteen 2-byte loads per round, one round at a time)
+            for (int r0 = 0; r0 < nround; r0 += NB) {
+                f16x8 m4[NB], t4[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) issue(vec, r0 + k, m4[k], t4[k]);
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                    if (r0 + k < nround) test(r0 + k, m4[k], t4[k]);
             }
-        }
+        };
+        if (vec_ok) scan(std::true_type{});
+        else scan(std::false_type{});
         drain();
     }
 }

@@ -250,7 +250,7 @@ def conv_family_roofline(xf, step_fn, n=2):
     ach = (cfl.value / 1e12) / (cms.value / 1e3) if cms.value > 0 else 0.0
     # priced two ways: the algorithmic fp32 FLOPs of the direct form against the fp32 peak (the figure of rounds 1-4; above 1 since the layers run on the fp16 matrix cores),
     # and the FLOPs the fp16-pair kernels EXECUTE (three fp16 MFMAs per product) against the fp16 MFMA peak -- `frac`: the one that speaks about the kernels
-    return {"bound": "mfma", "kernel": "every MFMA convolution launch of the step behind block1: conv_bx_kernel<24,24> / conv_bxs2_kernel<24>, conv_rs64_kernel (64 -> 64 and 128 -> 128 3x3, "
+    return {"bound": "mfma", "kernel": "every MFMA convolution launch of the step behind block1: conv_bxd_kernel<24,24> / conv_bxs2_kernel<24>, conv_rs64_kernel (64 -> 64 and 128 -> 128 3x3, "
                                        "with and without the fused 1x1; column strips on maps wider than its rings), conv_bx64s2x_kernel, the 128 -> 64 1x1 -- fp32 results on "
                                        "v_mfma_f32_32x32x16_f16 with an fp16 pair per operand (three MFMAs per product)",
             "achieved": round(3 * ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(3 * ach / PEAK_F16_TFLOPS, 4),
@@ -321,7 +321,7 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=1 | 2 | 8 | 2048, blo
         add(3, "block1_fused_kernel (block1.0-.3 + skip1; fp32-range fallback)", 4.0 * (px["1"] + 24 * px["4"]), 720.0 * px["1"], 720.0 * px["1"], f32, "fp32 valu (v_pk_fma_f32)")
     c24, c64 = bool(fx & 2), bool(fx & 1)
     for n_ in ("block2.0", "block2.1"):      # executed: 3 MFMAs per product, couts padded 24 -> 32, K groups 27 -> 28
-        conv_row(n_, f"conv_bx_kernel<24,24> ({n_})", 4.0 * 48 * px["4"], conv_flops(n_, px["4"]), 3 * (32 / 24) * (224 / 216), c24)
+        conv_row(n_, f"conv_bxd_kernel<24,24> ({n_})", 4.0 * 48 * px["4"], conv_flops(n_, px["4"]), 3 * (32 / 24) * (224 / 216), c24)
     conv_row("block3.0", "conv_bxs2_kernel<24> (block3.0, stride 2)", 4.0 * (24 * px["4"] + 64 * px["8"]), conv_flops("block3.0", px["8"]), 3 * (224 / 216), c24)
     for n3, n1, tag in (("block3.1", "block3.2", "conv_rs64_kernel<1>"), ("block_fusion.1", "block_fusion.2", "conv_rs64_kernel<2> (channels-last out)")):
         conv_row(n3, f"{tag} ({n3} + {n1})", 4.0 * 128 * px["8"], conv_flops(n3, px["8"]) + conv_flops(n1, px["8"]), 3, c64)
@@ -356,7 +356,7 @@ def kernel_roofline_table(spans_us, B, P, n_kpts=TOP_K, fx=1 | 2 | 8 | 2048, blo
     mm = 2.0 * P * n_kpts * n_kpts * 64
     add(220, "match: memset of keys / maxima", 8.0 * 2 * P * n_kpts + 4.0 * P * n_kpts, 0, 0, 0, "hbm")
     maxima = MATCH_MAXIMA_BYTES_PER_ENTRY * 2 * P * n_kpts * (n_kpts / 32)      # R (P, N2/32, N1) + C (P, N1/32, N2): written by the sweep, read by the refine's scan
-    add(222, "mnn_f16_sweep_kernel (both tile orientations)", 2.0 * 2 * P * n_kpts * 64, mm, 2 * mm, PEAK_F16_TFLOPS, "fp16 mfma (filter)", design_bytes=maxima)
+    add(222, "mnn_f16_sweep2_kernel (every tile multiplied once; column-direction block maxima elementwise over the rows that meet in a lane)", 2.0 * 2 * P * n_kpts * 64, mm, mm, PEAK_F16_TFLOPS, "fp16 mfma (filter)", design_bytes=maxima)
     add(223, "mnn_f16_thr_row + mnn_f16_refine_kernel (scan of the block maxima, exact fp32 blocks on f32 mfma)", 4.0 * 2 * P * n_kpts * 64, 0,
         2.0 * 2 * P * n_kpts * 1.07 * 32 * 64, f32, "latency + f32 mfma", design_bytes=maxima)
     add(224, "mnn_finalize_kernel", 8.0 * 2 * P * n_kpts + 16.0 * P * n_kpts, 0, 0, 0, "latency")
@@ -1054,21 +1054,21 @@ def main():
                          "algorithmic": "720 FLOP per input pixel x B*H*W pixels per launch",
                          "traffic": traffic, "traffic_source": traffic_src,
                          "traffic_algorithmic": int(by / max(n_l, 1))},
-            # xfh_match_mnn = fp16 MFMA filter (derived error window, one sweep in both tile orientations) + exact fp32 refine of the flagged
+            # xfh_match_mnn = fp16 MFMA filter (derived error window, one sweep, every tile multiplied once) + exact fp32 refine of the flagged
             # 32-wide blocks (~1.07 per row and column) on f32 MFMAs; identical match lists to the exact f32 MFMA kernel (tests; option
             # match_exact selects the latter).  "algorithmic" prices the fp32 work of D1.D2^T against the f32 MFMA peak: above 1 means the
             # filter beat an exact f32 GEMM at its peak.
-            "roofline_match": {"bound": "mfma", "kernels": "mnn_f16_sweep_kernel + mnn_f16_thr_row + mnn_f16_refine_kernel (the fp16 copies come from the descriptor kernel)",
+            "roofline_match": {"bound": "mfma", "kernels": "mnn_f16_sweep2_kernel + mnn_f16_thr_kernel + mnn_f16_refine_kernel (the fp16 copies come from the descriptor kernel)",
                                "us_per_step": round(1e3 * m_ms / 3, 1), "algorithmic_f32_tflops": round((m_fl / 1e12) / (m_ms / 1e3), 2) if m_ms > 0 else None,
-                               "executed": "2 x 2*P*N1*N2*64 FLOP on v_mfma_f32_32x32x16_f16 (one sweep, both orientations of every tile) + 32 exact fp32 similarities per flagged block",
+                               "executed": "2*P*N1*N2*64 FLOP on v_mfma_f32_32x32x16_f16 (one sweep, every 32 x 32 tile multiplied once) + 32 exact fp32 similarities per flagged block",
                                # (m_fl = the algorithmic FLOPs of the 3 steps of the side pass; spans_us = us per ONE step)
-                               "executed_f16_tflops_sweep": round((2 * (m_fl / 3) / 1e12) / (spans_us.get(222, 0) / 1e6), 1) if spans_us.get(222) else None, "peak_f16_tflops": PEAK_F16_TFLOPS,
+                               "executed_f16_tflops_sweep": round(((m_fl / 3) / 1e12) / (spans_us.get(222, 0) / 1e6), 1) if spans_us.get(222) else None, "peak_f16_tflops": PEAK_F16_TFLOPS,
                                # the matcher's algorithmic floor: ONE fp16 GEMM per pair (2*N1*N2*64 FLOP) at the 2.5 PF peak, against everything xfh_match_mnn launches
                                "floor_algorithmic_us": round((m_fl / 3) / PEAK_F16_TFLOPS / 1e6, 1),
                                "frac_algorithmic": round(((m_fl / 3) / PEAK_F16_TFLOPS / 1e6) / (1e3 * m_ms / 3), 3) if m_ms > 0 else None},
             # the two 24 -> 24 convolutions on the fp16 matrix cores (fp16-pair arithmetic, fp32-equivalent results).  "achieved" prices the ALGORITHMIC fp32 work
             # against the f32 MFMA peak (comparable across rounds), "executed_f16_tflops" the three MFMAs per product (+ channel padding) against the fp16 peak.
-            "roofline_conv24": {"bound": "mfma", "kernel": "conv_bx_kernel<24,24> (block2.0 / block2.1 on v_mfma_f32_32x32x16_f16, three MFMAs per K = 16: fp16-pair arithmetic)",
+            "roofline_conv24": {"bound": "mfma", "kernel": "conv_bxd_kernel<24,24> (block2.0 / block2.1 on v_mfma_f32_32x32x16_f16, three MFMAs per K = 16: fp16-pair arithmetic; the next tile staged inside this tile's MFMAs)",
                                 "us_per_step": round(1e3 * b_ms / 3, 1), "launches_per_step": 2,
                                 "achieved": round((b_fl / 1e12) / (b_ms / 1e3), 2) if b_ms > 0 else None, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                                 "executed_f16_tflops": round((b_fl * 3 * (32 / 24) * (224 / 216) / 1e12) / (b_ms / 1e3), 1) if b_ms > 0 and opt_fx.value & 2 else None,
@@ -1088,7 +1088,7 @@ def main():
             "roofline_kernels": k_rows,
             # every MFMA convolution launch behind block1 (12 per step), priced like conv_family_roofline: the FLOPs the fp16-pair kernels EXECUTE (three fp16 MFMAs per
             # product) against the fp16 MFMA peak, next to the algorithmic fp32 rate
-            "roofline_conv_family": {"bound": "mfma", "kernel": "conv_bx_kernel<24,24> x2, conv_bxs2_kernel<24>, conv_rs64_kernel (7 launches: 64 -> 64 and 128 -> 128 3x3, with and "
+            "roofline_conv_family": {"bound": "mfma", "kernel": "conv_bxd_kernel<24,24> x2, conv_bxs2_kernel<24>, conv_rs64_kernel (7 launches: 64 -> 64 and 128 -> 128 3x3, with and "
                                                                   "without the fused 1x1), conv_bx64s2x_kernel x2, conv_mfma_kernel<128,64,1x1> -- fp16-pair arithmetic but for the 1x1",
                                      "achieved": round(3 * (cfl / 1e12) / (cms / 1e3), 2) if cms > 0 else None, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                                      "frac": round(3 * (cfl / 1e12) / (cms / 1e3) / PEAK_F16_TFLOPS, 4) if cms > 0 else None,
