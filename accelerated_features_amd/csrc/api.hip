@@ -530,7 +530,7 @@ size_t xfh_backbone_workspace_bytes(int B, int C, int H, int W) {
 }
 
 static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const float* in, int B, int Hin, int Win, float* out,
-                             bool nhwc, hipStream_t st, bool in_backbone = false) {      // in_backbone: the layer's neighbours are this call's (the split-format link may be used)
+                             bool nhwc, hipStream_t st, bool in_backbone = false, int link = 0) {      // link (backbone only): bit 0 = the input, bit 1 = the output is a channels-last link between two fp16-pair 24-channel layers      // in_backbone: the layer's neighbours are this call's (the split-format link may be used)
     const ConvW& c = h->nw.conv[layer];
     const ConvW* c2 = fused_layer >= 0 ? &h->nw.conv[fused_layer] : nullptr;
     const int pad = c.ks / 2;
@@ -551,7 +551,8 @@ static int conv_mfma_checked(xfh_handle h, int layer, int fused_layer, const flo
         else if (c.cin == 64 && c2 && c2->w_rs) rc = launch_conv_rs64(c, in, B, Hin, Win, out, st, h->status, c2, nhwc, h->trace);        // block3.1 + .2, block_fusion.1 + .2
     }
     if (rc && (fx & XFH_FX_CONV64) && c.w_fx && !c2 && !nhwc && c.stride == 2 && c.cin == 64) rc = launch_conv_bx64s2_fx(c, in, B, Hin, Win, out, st, h->trace, h->status);      // block4.0, block5.0
-    if (rc && (fx & XFH_FX_CONV24) && c.w_fx && !c2 && !nhwc && c.cin == 24) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, h->status);      // block2.0, block2.1, block3.0
+    if (rc && (fx & XFH_FX_CONV24) && c.w_fx && !c2 && !nhwc && c.cin == 24) rc = launch_conv_bx(c, in, B, Hin, Win, out, st, h->trace, h->status, link & 1, (link & 2) != 0);      // block2.0, block2.1, block3.0
+    if (rc && link) return fail(XFH_ERR_UNSUPPORTED, "layer %d: a channels-last link without its fp16-pair kernel", layer);      // (cannot happen: the links are chosen by the same conditions)
     if (rc) rc = launch_conv_mfma(c, c2, h->nw.zeros, in, B, Hin, Win, out, nhwc, st, h->trace);
     const int cl = c2 ? c2->cout : c.cout;
     double bytes = 4.0 * ((double)B * c.cin * Hin * Win + (double)B * cl * Hout * Wout + (double)c.cin * c.cout * c.ks * c.ks);
@@ -592,9 +593,15 @@ static int backbone_impl(xfh_handle h, const float* img, const unsigned char* im
     prof_end(&h->prof, XFH_PROF_BLOCK1, st, 720.0 * B * H * W, 10.0 * B * H * W);
 #define CONV(layer, fused, in, hin, win, out, nhwc) \
     if ((rc = conv_mfma_checked(h, layer, fused, in, B, hin, win, out, nhwc, st, true))) return rc
-    CONV(L_BLOCK2_0, -1, w.x1, H4, W4, w.x2a, false);
-    CONV(L_BLOCK2_1, -1, w.x2a, H4, W4, w.x2b, false);
-    CONV(L_BLOCK3_0, -1, w.x2b, H4, W4, w.x3a, false);
+    {   // block2.0 -> block2.1 -> block3.0: channels-last between them when all three run on their fp16-pair kernels (16-byte loads and stores: DESIGN 3.9); planes otherwise
+        const bool cl = (h->opt.fx & XFH_FX_CONV24) && conv_bx_links(nw.conv[L_BLOCK2_0], h->trace != nullptr) && conv_bx_links(nw.conv[L_BLOCK2_1], h->trace != nullptr) &&
+                        conv_bx_links(nw.conv[L_BLOCK3_0], h->trace != nullptr) && (size_t)24 * H4 * W4 * sizeof(float) < 0x7fffffffu;
+#define CONVL(layer, in, out, link) if ((rc = conv_mfma_checked(h, layer, -1, in, B, H4, W4, out, false, st, true, link))) return rc
+        CONVL(L_BLOCK2_0, w.x1, w.x2a, cl ? 2 : 0);
+        CONVL(L_BLOCK2_1, w.x2a, w.x2b, cl ? 3 : 0);
+        CONVL(L_BLOCK3_0, w.x2b, w.x3a, cl ? 1 : 0);
+#undef CONVL
+    }
     CONV(L_BLOCK3_1, L_BLOCK3_2, w.x3a, H8, W8, w.x3c, false);        // 3x3 + fused 1x1
     CONV(L_BLOCK4_0, -1, w.x3c, H8, W8, w.x4a, false);
     CONV(L_BLOCK4_1, -1, w.x4a, H16, W16, w.x4b, false);

@@ -276,7 +276,9 @@ struct BxdCfg {
     }
 };
 
-template <int CIN, int COUT>
+// IN_CL / OUT_CL: the input / output is channels-last ((B, H, W, C): the links block2.0 -> block2.1 -> block3.0 inside the backbone).  A memory instruction costs its issue time
+// whatever else the SIMD does: an item's 8 channels are then two 16-byte loads instead of eight 4-byte ones, a lane's 4 consecutive couts one 16-byte store instead of four.
+template <int CIN, int COUT, bool IN_CL = false, bool OUT_CL = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bxd_kernel(BxArgs a) {
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
@@ -309,7 +311,8 @@ void conv_bxd_kernel(BxArgs a) {
     for (int i = 0; i < NIT; ++i) {
         int item = tid + 512 * i;
         item = item >= Cfg::NITEM ? item - Cfg::NITEM : item;
-        const int cg = item / NPIX, pix = item - cg * NPIX;
+        // planes: consecutive lanes = consecutive pixels of a channel group; channels-last: consecutive lanes = the channel groups of a pixel, then the next pixel (32 contiguous bytes each)
+        const int cg = IN_CL ? item % Cfg::CG : item / NPIX, pix = IN_CL ? item / Cfg::CG : item - cg * NPIX;
         const int r = pix / IW, c = pix - r * IW;
         it_rc[i] = (cg << 16) | (r << 8) | c;
         it_lds[i] = pix * PIXB + cg * 16;
@@ -338,9 +341,16 @@ void conv_bxd_kernel(BxArgs a) {
     auto issue_item = [&](const TileSrc& t, int i, float (&v)[8]) __attribute__((always_inline)) {
         const int cg = it_rc[i] >> 16, gy = t.oy0 - 1 + ((it_rc[i] >> 8) & 0xff), gx = t.ox0 - 1 + (it_rc[i] & 0xff);
         const bool ok = (bool)((int)(t.live != 0) & (int)((unsigned)gy < (unsigned)a.H) & (int)((unsigned)gx < (unsigned)a.W)); 
-        const int voff = ok ? (int)((((size_t)cg * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
+        if constexpr (IN_CL) {
+            const int voff = ok ? (int)((((size_t)gy * a.W + gx) * CIN + cg * 8) * 4) : (int)0x80000000;
+            const uint4 lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(t.rs, voff, 0, 0)), hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(t.rs, voff, 16, 0));
+            v[0] = __uint_as_float(lo.x); v[1] = __uint_as_float(lo.y); v[2] = __uint_as_float(lo.z); v[3] = __uint_as_float(lo.w);
+            v[4] = __uint_as_float(hi.x); v[5] = __uint_as_float(hi.y); v[6] = __uint_as_float(hi.z); v[7] = __uint_as_float(hi.w);
+        } else {
+            const int voff = ok ? (int)((((size_t)cg * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(t.rs, voff, (int)(k * HW * 4), 0));
+            for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(t.rs, voff, (int)(k * HW * 4), 0));
+        }
     };
     auto stage_item = [&](unsigned char* buf, int i, const float (&v)[8]) __attribute__((always_inline)) {
         uint4 h, l;
@@ -423,6 +433,28 @@ void conv_bxd_kernel(BxArgs a) {
             bs[4 * g4] = t.x; bs[4 * g4 + 1] = t.y; bs[4 * g4 + 2] = t.z; bs[4 * g4 + 3] = t.w;
         }
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * COUT * HW), 0, (int)(COUT * HW * sizeof(float)), 0x00020000);
+        if constexpr (OUT_CL) {      // channels-last: couts (r & 3) + 8 g + 4 half, r & 3 = 0..3 are 16 consecutive bytes of pixel (oy, ox)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int oy = oy0 + 2 * wave + j;
+                const int voff = oy < a.H && ox < a.W ? (int)((((size_t)oy * a.W + ox) * COUT + 4 * half) * 4) : (int)0x80000000;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (8 * g < COUT) {
+                        float y4[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            y4[q] = fmaf(acc[j][4 * g + q], FX_SCALE_INV, bs[4 * g + q]);
+                            if (a.relu) y4[q] = fmaxf(y4[q], 0.f);
+                        }
+                        const bool okc = COUT % 8 == 0 || 8 * g + 4 * half < COUT;
+                        typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+                        const u32x4s u = {__float_as_uint(y4[0]), __float_as_uint(y4[1]), __float_as_uint(y4[2]), __float_as_uint(y4[3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(u, rs_out, okc ? voff : (int)0x80000000, (int)(8 * g * 4), 0);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int oy = oy0 + 2 * wave + j;
@@ -481,7 +513,7 @@ struct BxS2Args {
     int* status;
 };
 
-template <int CIN>
+template <int CIN, bool IN_CL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_bxs2_kernel(BxS2Args a) {
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
@@ -516,7 +548,7 @@ void conv_bxs2_kernel(BxS2Args a) {
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const int item = tid + 256 * i;
-        const int cg = item / NPIX, pix = item - cg * NPIX;
+        const int cg = IN_CL ? (item < NPIX * CG ? item % CG : CG) : item / NPIX, pix = IN_CL ? (item / CG) % NPIX : item - cg * NPIX;      // (channels-last: the channel groups of a pixel side by side)
         const int r = pix / IW, c = pix - r * IW;
         it_rc[i] = cg < CG ? (cg << 16) | (r << 8) | c : -1;
         it_lds[i] = (r * 2 + (c & 1)) * ROWQ + (c >> 1) * PIXB + cg * 16;
@@ -544,9 +576,16 @@ void conv_bxs2_kernel(BxS2Args a) {
         for (int i = 0; i < NIT; ++i) {
             const int cg = it_rc[i] >> 16, gy = iy0 - 1 + ((it_rc[i] >> 8) & 0xff), gx = ix0 - 1 + (it_rc[i] & 0xff);
             const bool ok = it_rc[i] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const int voff = ok ? (int)((((size_t)cg * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
+            if constexpr (IN_CL) {
+                const int voff = ok ? (int)((((size_t)gy * a.W + gx) * CIN + cg * 8) * 4) : (int)0x80000000;
+                const uint4 lo = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0)), hi = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 16, 0));
+                v[i][0] = __uint_as_float(lo.x); v[i][1] = __uint_as_float(lo.y); v[i][2] = __uint_as_float(lo.z); v[i][3] = __uint_as_float(lo.w);
+                v[i][4] = __uint_as_float(hi.x); v[i][5] = __uint_as_float(hi.y); v[i][6] = __uint_as_float(hi.z); v[i][7] = __uint_as_float(hi.w);
+            } else {
+                const int voff = ok ? (int)((((size_t)cg * 8) * HW + (size_t)gy * a.W + gx) * 4) : (int)0x80000000;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[i][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)(k * HW * 4), 0));
+                for (int k = 0; k < 8; ++k) v[i][k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, (int)(k * HW * 4), 0));
+            }
         }
     };
     auto stage_write = [&]() __attribute__((always_inline)) {
@@ -625,7 +664,7 @@ void conv_bxs2_kernel(BxS2Args a) {
     fx_report_h(amax, a.status);
 }
 
-template <int CIN>
+template <int CIN, bool IN_CL>
 static int run_bxs2(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status) {
     using Cfg = BxS2Cfg<CIN>;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -638,11 +677,11 @@ static int run_bxs2(const ConvW& c, const float* in, int B, int H, int W, float*
     a.tiles_x = ceil_div(W, 32);
     a.tiles = a.tiles_x * ceil_div(H, 8);
     static AttrMask attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN>), Cfg::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxs2_kernel<CIN, IN_CL>), Cfg::LDS_BYTES, attr_done);
     const int total = xcd_grid_size(a.tiles, B);
     int grid = 2 * num_cus();
     if (grid > total) grid = total;
-    conv_bxs2_kernel<CIN><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+    conv_bxs2_kernel<CIN, IN_CL><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
     return 0;
 }
 
@@ -666,7 +705,7 @@ static int run_bx(const ConvW& c, const float* in, int B, int H, int W, float* o
     return 0;
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, bool IN_CL, bool OUT_CL>
 static int run_bxd(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status) {
     using Cfg = BxdCfg<CIN, COUT>;
     if ((size_t)CIN * H * W * sizeof(float) >= 0x7fffffffu) return -1;      // buffer-resource range
@@ -678,21 +717,27 @@ static int run_bxd(const ConvW& c, const float* in, int B, int H, int W, float* 
     a.tiles_x = ceil_div(W, Cfg::TW);
     a.tiles = a.tiles_x * ceil_div(H, Cfg::TH);
     static AttrMask attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxd_kernel<CIN, COUT>), Cfg::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bxd_kernel<CIN, COUT, IN_CL, OUT_CL>), Cfg::LDS_BYTES, attr_done);      // (a mask per instantiation)
     const int total = xcd_grid_size(a.tiles, B);
     int grid = num_cus();                // one workgroup (eight waves) per CU; a multiple of 8 keeps a workgroup on its XCD
     if (grid > total) grid = total;
-    conv_bxd_kernel<CIN, COUT><<<grid, 512, Cfg::LDS_BYTES, st>>>(a);
+    conv_bxd_kernel<CIN, COUT, IN_CL, OUT_CL><<<grid, 512, Cfg::LDS_BYTES, st>>>(a);
     return 0;
 }
 
 int bx_steps(int cin) { return (9 * (cin / 8) + 1) / 2; }
 
 // -1: not one of this file's layers, or the layer has no fp16-pair weights (a |w| >= kFxMaxWeight): the caller falls back to the f32-MFMA kernel
-int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status) {
+// in_cl / out_cl: the input / output is channels-last (the backbone's links between these layers: conv_bx_links); the stamped round-4 kernel knows planes only
+bool conv_bx_links(const ConvW& c, bool tracing) { return !tracing && c.ks == 3 && c.w_fx && c.cin == 24 && ((c.stride == 1 && c.cout == 24) || (c.stride == 2 && c.cout == 64)); }
+int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace, int* status, bool in_cl, bool out_cl) {
     if (c.ks != 3 || !c.w_fx) return -1;
-    if (c.stride == 1 && c.cin == 24 && c.cout == 24) return trace ? run_bx<24, 24>(c, in, B, H, W, out, st, trace, status) : run_bxd<24, 24>(c, in, B, H, W, out, st, status);      // (the stamped kernel is the round-4 form)
-    if (c.stride == 2 && c.cin == 24 && c.cout == 64) return run_bxs2<24>(c, in, B, H, W, out, st, status);
+    if (c.stride == 1 && c.cin == 24 && c.cout == 24) {
+        if (trace) return in_cl || out_cl ? -1 : run_bx<24, 24>(c, in, B, H, W, out, st, trace, status);      // (the stamped kernel is the round-4 form)
+        if (in_cl) return out_cl ? run_bxd<24, 24, true, true>(c, in, B, H, W, out, st, status) : -1;      // (channels-last in, planes out: no layer of the network)
+        return out_cl ? run_bxd<24, 24, false, true>(c, in, B, H, W, out, st, status) : run_bxd<24, 24, false, false>(c, in, B, H, W, out, st, status);
+    }
+    if (c.stride == 2 && c.cin == 24 && c.cout == 64 && !out_cl) return in_cl ? run_bxs2<24, true>(c, in, B, H, W, out, st, status) : run_bxs2<24, false>(c, in, B, H, W, out, st, status);
     return -1;
 }
 

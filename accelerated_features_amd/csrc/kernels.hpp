@@ -86,7 +86,8 @@ void launch_conv_generic(const ConvW& c, const float* in, int B, int Hin, int Wi
 int launch_conv_mfma(const ConvW& c, const ConvW* fused1x1, const float* zeros, const float* in, int B, int Hin, int Win,
                      float* out, bool nhwc_out, hipStream_t st, long long* trace = nullptr);
 // the 24-channel 3x3 layers (stride 1 and 2) in the fp16-pair arithmetic (k_conv_bx.hip); -1 if no instantiation or no fp16-pair weights
-int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr, int* status = nullptr);
+int launch_conv_bx(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, long long* trace = nullptr, int* status = nullptr, bool in_cl = false, bool out_cl = false);
+bool conv_bx_links(const ConvW& c, bool tracing);      // the layer can take / hand over channels-last activations
 // 3x3/s1, 64 -> 64, fp16 pair, weights resident in registers (k_conv_rs64.hip / conv_rs64_body.hpp); -1: not this layer, or the map is wider than its LDS rings allow
 int launch_conv_rs64(const ConvW& c, const float* in, int B, int H, int W, float* out, hipStream_t st, int* status = nullptr, const ConvW* fused1x1 = nullptr, bool nhwc = false,
                      long long* trace = nullptr);

@@ -863,6 +863,10 @@ def main():
     # the timed region cost its first window 1.8 %).  Then the contract's W warm-up steps and K timed steps, back to back.
     for h_ in handles:
         lib.xfh_profile_select(h_, _lib.PROF_BLOCK1)
+    # sclk / power are sampled WHILE THE WAKE-UP WINDOWS RUN (the same steps as the timed region, untimed), not inside the timed region: a thread that reads the SMU's sysfs nodes
+    # once per millisecond beside the thread that launches 88 kernels per millisecond cost the timed steps 2-4 % (value against the windows measured right after it, which had no
+    # sampler: 53.3 / 54.6 k, 52.7 / 54.6, 53.6 / 55.7 and once 48.6 / 55.8; round 5, without a sampler: 49.8 / 49.7-50.5)
+    sampler = GpuStateSampler(local_rank, period_s=0.005).start() if args.wake_ms > 0 else None
     t_wake, n_wake, wake_rates = time.perf_counter(), 0, []
     while args.wake_ms > 0:                                # windows of `steps` untimed steps until two in a row agree within 1 % (and >= wake_ms, <= 8 x wake_ms have passed)
         torch.cuda.synchronize()
@@ -878,14 +882,13 @@ def main():
         if (el >= args.wake_ms and settled) or el >= 8 * args.wake_ms:
             break
     retired.clear()
+    tele_during = sampler.stop() if sampler else {"samples": 0}
     for h_ in handles:
         lib.xfh_profile_select(h_, _lib.PROF_NONE)
 
     # (the barrier + torch.cuda.synchronize() that closes the timed region waits for every lane: all `steps` batches complete inside it)
     tele_before = gpu_telemetry(local_rank)
-    sampler = GpuStateSampler(local_rank).start()
     dt_max, _ = sharding.timed_steps(lane_step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
-    tele_during = sampler.stop()
     tele_after = gpu_telemetry(local_rank)
     timed_calls[0] = None
     assert len(retired) == args.steps and fs.in_flight == 0
@@ -1029,8 +1032,8 @@ def main():
                        "untimed_before_the_timed_region": f"GPU wake-up ({n_wake} steps: windows of {args.steps} until two agree within 1 %, >= {args.wake_ms:.0f} ms; a cold GPU runs its first ~150 ms 3-4 % slow), then the W warm-up steps",
                        "wake_up_window_fps": [round(r, 1) for r in wake_rates],
                        # the box's state around the timed region (amdgpu sysfs): a slow box reads differently from a slow kernel
-                       "gpu_state": {"during_warmup_and_timed_region": tele_during, "before_timed_region": tele_before, "after_timed_region": tele_after,
-                                     "note": "before / after are single reads behind a synchronisation (an idle GPU: low sclk); `during` is sampled once per millisecond while the steps run"},
+                       "gpu_state": {"during_the_untimed_wake_up_windows": tele_during, "before_timed_region": tele_before, "after_timed_region": tele_after,
+                                     "note": "before / after are single reads behind a synchronisation (an idle GPU: low sclk); `during` is sampled every 5 ms while the untimed wake-up windows run (the same steps as the timed region; a sampler inside the timed region cost it 2-4 %)"},
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
             # block1 x4 + skip1 in one kernel: fp32 FMA work on the vector ALUs (v_pk_fma_f32), LDS-tiled.  Neither HBM nor the matrix
             # cores bound it: its vector stages (conv1 recomputed inside conv2: DESIGN 3.2) do; it is priced against the dense fp32 rate of the chip,

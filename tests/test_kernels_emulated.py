@@ -103,7 +103,7 @@ def _slice_match_sweep():
 def _slice_conv_bx24():
     """conv_bx_kernel<24, 24> (block2.0 / block2.1) and conv_bxs2_kernel<24> (block3.0): weights in registers, one staged halo tile per output tile"""
     t = open(os.path.join(CSRC, "k_conv_bx.hip")).read()
-    s = _between(t, "struct BxArgs {", "template <int CIN>\nstatic int run_bxs2(")
+    s = _between(t, "struct BxArgs {", "template <int CIN, bool IN_CL>\nstatic int run_bxs2(")
     for name, args, nthr in (("conv_bx_kernel", "BxArgs", 256), ("conv_bxd_kernel", "BxArgs", 512), ("conv_bxs2_kernel", "BxS2Args", 256)):
         s = _must_sub(s, f"__global__ __launch_bounds__({nthr}) __attribute__((amdgpu_waves_per_eu(2, 2)))\nvoid {name}({args} a) {{", f"inline void {name}({args} a) {{")
     assert s.count("extern __shared__ __attribute__((aligned(16))) unsigned char smem_bx[];") == 3
@@ -152,20 +152,22 @@ def _blob(hdr, arrs):
 
 
 @pytest.mark.parametrize("stride,shape,grid", [(1, (1, 16, 64), 2), (1, (1, 8, 32), 1), (1, (2, 21, 45), 3), (2, (1, 16, 64), 2), (2, (1, 8, 32), 1), (2, (2, 21, 45), 3), (1, (8, 8, 32), 8),
-                                               (1, (1, 48, 96), 2), (1, (3, 35, 70), 1), (1, (9, 16, 32), 8), (3, (2, 21, 45), 3), (3, (1, 16, 64), 2)])
+                                               (1, (1, 48, 96), 2), (1, (3, 35, 70), 1), (1, (9, 16, 32), 8), (3, (2, 21, 45), 3), (3, (1, 16, 64), 2),
+                                               (5, (2, 21, 45), 3), (5, (1, 48, 96), 2), (7, (2, 21, 45), 3), (7, (1, 48, 96), 2), (7, (9, 16, 32), 8), (8, (2, 21, 45), 3), (8, (1, 16, 64), 2)])
 def test_conv_bx24_kernels_on_the_host(emu_bins, stride, shape, grid):
     """the 24-channel layers on the fp16 matrix cores with their weights in registers: conv_bxd_kernel<24, 24> (block2.0 / block2.1: 16 x 32 tiles, the next tile requested and
     staged inside this tile's MFMAs, two tile buffers; stride code 3 = conv_bx_kernel, the form the trace build keeps) and conv_bxs2_kernel<24> (block3.0, stride 2,
     64 couts) in the fp16-pair arithmetic: full tiles, partial tiles with odd sizes (21 x 45, 35 x 70), several tiles per workgroup (three and more: both buffers re-used), one
-    workgroup for everything, more workgroups than tiles, the XCD mapping of the work list (B = 8 / 9 on a grid of 8)"""
+    workgroup for everything, more workgroups than tiles, the XCD mapping of the work list (B = 8 / 9 on a grid of 8); stride codes 5 / 7 / 8: the channels-last forms of the
+    backbone's links block2.0 -> block2.1 -> block3.0 (16-byte loads of an item's 8 channels, 16-byte stores of a lane's 4 couts)"""
     B, H, W = shape
-    cout = 64 if stride == 2 else 24
+    cout = 64 if stride in (2, 8) else 24
     g = torch.Generator().manual_seed(7 * stride + 1 + H)
     x = torch.relu(torch.randn(B, 24, H, W, generator=g)) * 2
     w = torch.randn(cout, 24, 3, 3, generator=g) / 15
     b = torch.randn(cout, generator=g) * 0.3
     out = subprocess.run([emu_bins["conv_bx24_emu"]], input=_blob([B, H, W, stride, 1, grid], [x, w, b]), capture_output=True, check=True, timeout=400).stdout
-    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=1 if stride == 3 else stride, padding=1))
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride={3: 1, 5: 1, 7: 1, 8: 2}.get(stride, stride), padding=1))
     y = np.frombuffer(out[:-4], np.float32).reshape(tuple(ref.shape))
     d = np.abs(y - ref.numpy())
     print(f"conv_bx24 stride {stride} {shape}: max |err| {d.max():.3g}, max |y| {float(ref.abs().max()):.3g}")
