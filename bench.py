@@ -866,6 +866,7 @@ def main():
     # sclk / power are sampled WHILE THE WAKE-UP WINDOWS RUN (the same steps as the timed region, untimed), not inside the timed region: a thread that reads the SMU's sysfs nodes
     # once per millisecond beside the thread that launches 88 kernels per millisecond cost the timed steps 2-4 % (value against the windows measured right after it, which had no
     # sampler: 53.3 / 54.6 k, 52.7 / 54.6, 53.6 / 55.7 and once 48.6 / 55.8; round 5, without a sampler: 49.8 / 49.7-50.5)
+    tele_before = gpu_telemetry(local_rank)
     sampler = GpuStateSampler(local_rank, period_s=0.005).start() if args.wake_ms > 0 else None
     t_wake, n_wake, wake_rates = time.perf_counter(), 0, []
     while args.wake_ms > 0:                                # windows of `steps` untimed steps until two in a row agree within 1 % (and >= wake_ms, <= 8 x wake_ms have passed)
@@ -873,7 +874,8 @@ def main():
         t0w = time.perf_counter()
         for _ in range(args.steps):
             lane_step()
-        retired.extend(fs.drain())
+        fs.drain()
+        retired.clear()                                    # (window by window: 160 retained results are 11 GB whose release right in front of the warm-up is an idle gap)
         torch.cuda.synchronize()
         wake_rates.append(B * args.steps / (time.perf_counter() - t0w))
         n_wake += args.steps
@@ -882,14 +884,17 @@ def main():
         if (el >= args.wake_ms and settled) or el >= 8 * args.wake_ms:
             break
     retired.clear()
-    tele_during = sampler.stop() if sampler else {"samples": 0}
+    if sampler:
+        sampler._stop.set()                                # (told to end; joined behind the timed region: no wait between the wake-up and the warm-up)
     for h_ in handles:
         lib.xfh_profile_select(h_, _lib.PROF_NONE)
 
     # (the barrier + torch.cuda.synchronize() that closes the timed region waits for every lane: all `steps` batches complete inside it)
-    tele_before = gpu_telemetry(local_rank)
+    # (nothing between the wake-up windows and the warm-up: the single reads of the sysfs nodes -- a dozen SMU queries with the GPU idle -- used to sit here and cost the timed
+    #  region the state the wake-up had just established: value 3.5 % below the windows measured before and after it.  `before` is now read in front of the wake-up.)
     dt_max, _ = sharding.timed_steps(lane_step, args.steps, args.warmup, dist, torch.cuda.synchronize, "cuda", before_timed=arm)
     tele_after = gpu_telemetry(local_rank)
+    tele_during = sampler.stop() if sampler else {"samples": 0}
     timed_calls[0] = None
     assert len(retired) == args.steps and fs.in_flight == 0
     last = retired[-1]
@@ -1032,7 +1037,7 @@ def main():
                        "untimed_before_the_timed_region": f"GPU wake-up ({n_wake} steps: windows of {args.steps} until two agree within 1 %, >= {args.wake_ms:.0f} ms; a cold GPU runs its first ~150 ms 3-4 % slow), then the W warm-up steps",
                        "wake_up_window_fps": [round(r, 1) for r in wake_rates],
                        # the box's state around the timed region (amdgpu sysfs): a slow box reads differently from a slow kernel
-                       "gpu_state": {"during_the_untimed_wake_up_windows": tele_during, "before_timed_region": tele_before, "after_timed_region": tele_after,
+                       "gpu_state": {"during_the_untimed_wake_up_windows": tele_during, "before_the_wake_up": tele_before, "after_timed_region": tele_after,
                                      "note": "before / after are single reads behind a synchronisation (an idle GPU: low sclk); `during` is sampled every 5 ms while the untimed wake-up windows run (the same steps as the timed region; a sampler inside the timed region cost it 2-4 %)"},
                        "mean_keypoints": round(float(np.mean(n_valid)), 1), "mean_matches": round(float(np.mean(n_match)), 1)},
             # block1 x4 + skip1 in one kernel: fp32 FMA work on the vector ALUs (v_pk_fma_f32), LDS-tiled.  Neither HBM nor the matrix
