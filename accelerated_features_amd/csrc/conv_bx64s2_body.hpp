@@ -15,8 +15,13 @@
 //     nobody else covers a staging phase, and a wave's vector work only hides in the issue gaps of its OWN MFMAs: the five waves that hold staging items
 //     split half an item (two pixels x 8 channels) inside each of a chunk's first two tap rows, in the same basic block as that row's 9
 //     MFMAs (no branch: lanes without an item write to a dump slot; waves 5 - 7 run a copy of the unit's code without loads and splits).  Raw fp32 values are loaded two chunks ahead (two register sets), also across units;
-//   * the split weights (216 KiB per cout half) stream through a two-slot LDS ring by LDS-DMA, one slot = one tap row of one chunk
-//     (3 K steps, 18 KiB); the DMA of row r + 1 is issued behind the barrier that opens row r.  One barrier per tap row, none per chunk.
+//   * the split weights (216 KiB per cout half) stream through a THREE-slot LDS ring by LDS-DMA, one slot = one tap row of one chunk
+//     (3 K steps, 18 KiB); the DMA of row r + 2 is issued behind the barrier that opens row r -- two rows ahead: a row of 9 MFMAs per wave is
+//     ~0.6-1.1 k cycles, the DMA's L2 round trip ~1.6 k (with two slots and one row of look-ahead every row waited ~1 k cycles for its weights:
+//     matrix pipe 18-22 % busy).  The DMA is issued by the three waves that hold no staging item (5 - 7), six pieces each, and ONLY they wait for it
+//     (vmcnt(6): the row just requested stays in flight); the staging waves' vector-memory queue holds nothing but their own raw loads, which
+//     hipcc counts exactly -- they stay in flight across the barriers until the split needs them (with vmcnt(0) at every barrier each chunk's
+//     raw loads cost a full memory latency too).  One barrier per tap row, none per chunk.
 #pragma once
 #ifndef XFH_HOST_EMU
 #include "kernels.hpp"
@@ -33,6 +38,13 @@
 #endif
 #ifndef XFH_WAIT_VMCNT0
 #define XFH_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+#ifndef XFH_WAIT_VMCNT
+#define XFH_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#endif
+#ifndef XFH_NO_DMA_WAVE
+/* marker for tools/check_dma_barriers.py: the barrier that follows is reached by a wave that has issued no LDS-DMA since its last vmcnt(0) (its queue holds compiler-counted loads only) */
+#define XFH_NO_DMA_WAVE() asm volatile("; xfh-no-dma-wave" ::: "memory")
 #endif
 #define XFH_NOP16() asm volatile("s_nop 7\n\ts_nop 7")
 /* five just-read fragments stay occupied up to here (the staging's results are not handed their registers while an MFMA may still be reading them) */
@@ -59,10 +71,13 @@ constexpr int SPLB = 32, IH = 17, NEVEN = 17;
 constexpr int PIXB = 80;          // bytes per staged pixel: 16 channels x 2 fp16 fragments + 16
 constexpr int XROWB = 2688;       // >= (17 + 16) pixels; odd columns of a row behind its even ones
 constexpr int STEP_BYTES = 2 * 3 * 1024, SLOT_BYTES = 3 * STEP_BYTES, NPIECE = SLOT_BYTES / 1024;
-constexpr int LDS_BYTES = 2 * IH * XROWB + 2 * SLOT_BYTES + 128 * 4 + 256;      // two X buffers, the weight ring, bias, dump slot
+constexpr int NSLOT = 3;                                // weight ring: row r in slot r % 3, requested two rows ahead
+constexpr int DMA_WAVE0 = 5, NDMA_WAVES = 3;            // the waves without a staging item issue the ring's DMA: NPIECE / 3 pieces each per row
+constexpr int LDS_BYTES = 2 * IH * XROWB + NSLOT * SLOT_BYTES + 128 * 4 + 256;      // two X buffers, the weight ring, bias, dump slot
 constexpr int NQ = 9;                                   // 4-pixel quads [2 ox0 - 4, 2 ox0 + 32) per halo row
 constexpr int NITEM = IH * NQ * 2;                      // (row, quad, 8-channel group)
 static_assert(NITEM <= 512 && (2 * IH * XROWB) % 64 == 0 && LDS_BYTES <= 160 * 1024, "one staging item per thread; all of a CU's LDS");
+static_assert(NITEM <= DMA_WAVE0 * 64 && NPIECE % NDMA_WAVES == 0, "the DMA waves hold no staging item; equal piece counts (the partial vmcnt is an immediate)");
 static_assert(XROWB >= (17 + 16) * PIXB && XROWB % 128 == 0, "row pitch");
 }
 
@@ -72,10 +87,10 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 template <int NCO, bool W4>
 __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
     using namespace bx64s2x;
-    constexpr int PARB = NEVEN * PIXB, X_BYTES = IH * XROWB, RING_OFF = 2 * X_BYTES, BIAS_OFF = RING_OFF + 2 * SLOT_BYTES, DUMP_OFF = BIAS_OFF + 128 * 4;
+    constexpr int PARB = NEVEN * PIXB, X_BYTES = IH * XROWB, RING_OFF = 2 * X_BYTES, BIAS_OFF = RING_OFF + NSLOT * SLOT_BYTES, DUMP_OFF = BIAS_OFF + 128 * 4;
     constexpr int NXF = 2;                           // input fragments per pixel (high parts, low parts)
     constexpr int CIN = 64, NCH = CIN / 16, NROW = NCH * 3, COUT = 64 * NCO;
-    static_assert(NROW % 2 == 0 && NCH % 2 == 0, "ring slot, X buffer and register set of a chunk must not depend on the unit");
+    static_assert(NROW % NSLOT == 0 && NCH % 2 == 0, "ring slot, X buffer and register set of a chunk must not depend on the unit");
     XFH_DYN_LDS_BYTES(smem_s2);
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,9 +140,11 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
     const i32x4 rs_w = make_rsrc(a.wq, (unsigned)(NCO * NROW * SLOT_BYTES));
     const int dma_voff = lane * 16;
     auto lds_addr = [&](const unsigned char* p) { return XFH_LDS_ADDR(p, smem_s2); };
-    auto issue_row = [&](int r, int hf) __attribute__((always_inline)) {      // weights of row r (chunk r / 3, tap row r % 3) of cout half hf -> slot r & 1
-        for (int j = wave; j < NPIECE; j += 8) {
-            const unsigned m0v = lds_addr(smem_s2 + RING_OFF + (r & 1) * SLOT_BYTES + j * 1024);
+    auto issue_row = [&](int r, int hf) __attribute__((always_inline)) {      // weights of row r (chunk r / 3, tap row r % 3) of cout half hf -> slot r % 3  (waves 5 - 7 only)
+#pragma unroll
+        for (int k = 0; k < NPIECE / NDMA_WAVES; ++k) {      // (a fixed trip count: no branch between the pieces)
+            const int j = wave - DMA_WAVE0 + k * NDMA_WAVES;
+            const unsigned m0v = lds_addr(smem_s2 + RING_OFF + (r % NSLOT) * SLOT_BYTES + j * 1024);
             const int soff = (hf * NROW + r) * SLOT_BYTES + j * 1024;
             XFH_DMA_B128_TO_LDS(m0v, dma_voff, rs_w, soff);
         }
@@ -186,12 +203,18 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
         constexpr int C = decltype(CC)::value, DY = decltype(DYC)::value, r = C * 3 + DY, P = C & 1;
         constexpr int MODE = decltype(STGC)::value;      // 0: this wave only multiplies (waves 5 - 7); 1: it also loads and splits an item (waves 0 - 4), half in each of a chunk's
         constexpr bool STG = MODE != 0;                  // first two rows.  (Wave 4 -- the last 50 items, on wave 0's SIMD -- doing both halves in the third row instead: slower.)
-        S2_STAMP(1 + 4 * r)
-        XFH_WAIT_VMCNT0();
+        if constexpr (MODE == 1) S2_STAMP(1 + 4 * r)      // (the stamps are wave 0's: no store in the DMA waves' copy of the rows)
+        // Row 0 of a unit: everything (the previous unit's output stores are in flight, and stores are acknowledged out of order with respect to loads: no
+        // partial count is sound while one is out).  Rows 1 - 11: no store has been issued since that wait.  A DMA wave leaves its youngest request -- row r + 1,
+        // NPIECE / 3 loads, issued behind the previous barrier -- in flight (loads return in order: row r has landed); a staging wave has issued no DMA at all.
+        if constexpr (r == 0) XFH_WAIT_VMCNT0();
+        else if constexpr (MODE == 0) XFH_WAIT_VMCNT(NPIECE / NDMA_WAVES);
+        else XFH_NO_DMA_WAVE();
         __syncthreads();
-        S2_STAMP(2 + 4 * r)
-        issue_row(r + 1 < NROW ? r + 1 : 0, r + 1 < NROW ? cur.hf : nxt.hf);          // (the stream is cyclic over the units)
-        const unsigned char* wslot = smem_s2 + RING_OFF + (r & 1) * SLOT_BYTES + cb * 3 * 1024 + lane * 16;
+        if constexpr (MODE == 1) S2_STAMP(2 + 4 * r)
+        // (slot (r + 2) % 3 held row r - 1: every wave's reads of it were waited for before its last MFMAs, in front of this barrier.  The stream is cyclic over the units.)
+        if constexpr (MODE == 0) issue_row(r + 2 < NROW ? r + 2 : r + 2 - NROW, r + 2 < NROW ? cur.hf : nxt.hf);
+        const unsigned char* wslot = smem_s2 + RING_OFF + (r % NSLOT) * SLOT_BYTES + cb * 3 * 1024 + lane * 16;
         const unsigned char* xrow = smem_s2 + P * X_BYTES + lane_px + DY * XROWB;
         Frag f[2];                             // steps 0 and 1; step 2 is read into f[0] behind the last MFMA of step 0 (slot 6)
         auto load = [&](int s, Frag& o) {          // tap column s: parity s & 1, pixel index + (s >> 1)
@@ -258,7 +281,7 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
         __builtin_amdgcn_sched_barrier(0);
         XFH_NOP16();      // idle slots: whatever follows must not land in operand registers of the last MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        S2_STAMP(3 + 4 * r)
+        if constexpr (MODE == 1) S2_STAMP(3 + 4 * r)
     };
 
     auto do_unit = [&](const Tile& cur, const Tile& nxt, bool has_next) __attribute__((always_inline)) {
@@ -270,7 +293,7 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
             row(I2{}, I0{}, STGC, cur, nxt, has_next); row(I2{}, I1{}, STGC, cur, nxt, has_next); row(I2{}, I2{}, STGC, cur, nxt, has_next);
             row(I3{}, I0{}, STGC, cur, nxt, has_next); row(I3{}, I1{}, STGC, cur, nxt, has_next); row(I3{}, I2{}, STGC, cur, nxt, has_next);
         };
-        if (wave * 64 < NITEM) rows(std::integral_constant<int, 1>{});          // (wave-uniform: two copies of the unit's code, no exec masking)
+        if (wave < DMA_WAVE0) rows(std::integral_constant<int, 1>{});          // (wave-uniform: two copies of the unit's code, no exec masking)
         else rows(std::integral_constant<int, 0>{});
         // ---- bias, ReLU, buffer stores: lane (pixel, half) holds couts 64 hf + 32 cb + (r & 3) + 8 (r >> 2) + 4 half --------------------
         float bs[16];
@@ -296,7 +319,7 @@ __device__ __forceinline__ void conv_bx64s2x_body(const Bx64S2xArgs& a) {
     tile_at(u++, cur);
     nxt = cur;
     // prologue: chunk 0 of the first unit is staged with every pipe idle (once per workgroup); chunk 1 waits in set 1
-    issue_row(0, cur.hf);
+    if (wave >= DMA_WAVE0) { issue_row(0, cur.hf); issue_row(1, cur.hf); }
     {
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         const LoadAddr l0 = load_addr(I0{}, cur, true);

@@ -390,9 +390,28 @@ void conv_bxd_kernel(BxArgs a) {
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         struct Frag { frag_t x[2][NXS]; frag_t wl; };
         Frag f[2];
+        // A step's operand address = tile + lane's pixel + (upper half-wave: the distance dk to the step's second K group) + a constant.  dk takes few values (16 within a tap,
+        // else the jump to the next tap / tap row): their bases are computed ONCE per tile, in front of its first MFMA.  Computed per step, the addition was the first vector
+        // instruction behind a step's MFMAs, and hipcc gave it a register the last of them had just read as an operand (tools/check_mfma_war.py).
+        struct DkTab { int n; int dk[8]; int ix[NSTEP]; };
+        constexpr DkTab DK = [] {
+            DkTab t{};
+            for (int s = 0; s < NSTEP; ++s) {
+                const int dk = Cfg::koff(2 * s + 1) - Cfg::koff(2 * s);
+                int ix = -1;
+                for (int k = 0; k < t.n; ++k) if (t.dk[k] == dk) ix = k;
+                if (ix < 0) { ix = t.n; if (t.n < 8) t.dk[t.n] = dk; ++t.n; }
+                t.ix[s] = ix;
+            }
+            return t;
+        }();
+        static_assert(DK.n <= 4, "a handful of distinct half-wave distances");
+        unsigned pbase[DK.n];
+#pragma unroll
+        for (int k = 0; k < DK.n; ++k) { pbase[k] = (unsigned)(cur * TILE_BYTES + lane_off + half * DK.dk[k]); asm volatile("" : "+v"(pbase[k])); }
         auto load = [&](int s, Frag& o) __attribute__((always_inline)) {
-            const int k0 = Cfg::koff(2 * s), dk = Cfg::koff(2 * s + 1) - k0;
-            const unsigned char* p = tb + (lane_off + half * dk) + k0;
+            const int k0 = Cfg::koff(2 * s);
+            const unsigned char* p = smem_bx + pbase[DK.ix[s]] + k0;
             o.wl = *reinterpret_cast<const frag_t*>(wl_lds + (s * 64 + lane) * 16);
 #pragma unroll
             for (int j = 0; j < 2; ++j)

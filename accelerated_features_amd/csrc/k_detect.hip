@@ -595,51 +595,59 @@ __global__ __launch_bounds__(256) void descriptor_kernel(const float* __restrict
     const int hc = H >> 3, wc = W >> 3;
     const float ux = sample_coord(x, W, wc), uy = sample_coord(y, H, hc);
     const float fx = floorf(ux), fy = floorf(uy);
-    float wx[4], wy[4];
-    cubic_w(ux - fx, wx);
-    cubic_w(uy - fy, wy);
     const int x0 = (int)fx - 1, y0 = (int)fy - 1;
-    // buffer loads: 32-bit offsets, and taps outside the map read 0 through the range check of the resource (rows above /
-    // below fall outside image b's buffer; columns left / right get an out-of-range offset) -- no per-tap branches or
-    // 64-bit pointer arithmetic.  A zero tap adds +-0 to the sums: the value a skipped tap leaves.
+    // Lane `sub` of a key-point's 16 lanes prepares TAP sub = (row sub >> 2, column sub & 3): its cubic weights, its 1 / |feats| (one load instruction per key-point group
+    // instead of sixteen broadcast loads), their product w = (wx wy) / |feats|, and the byte offset of its pixel.  A tap outside the map has w = 0 and a clamped (valid)
+    // address: 0 x finite = 0, the value a skipped tap leaves.  Every lane then needs every tap's (offset, w): both arrive as DPP OPERANDS (row_newbcast: lane t of the 16
+    // to all of them) of the instruction that uses them -- v_add_u32_dpp for the address, four v_fmac_f32_dpp per tap for its 16-byte slice of the row: 5 vector instructions
+    // per tap.  The round-6 counters had this kernel at 60 % vector-ALU busy with 353 instructions per wave (per tap: a DPP move, an address shift-or + add, four multiplications
+    // by 1 / |feats| and four fused multiply-adds, + four IEEE divisions by the norm, + four LDS round trips for its sum); it is bound by instruction count, not by misses.
+    const int tr = sub >> 2, ti = sub & 3;
+    float wxy;
+    {
+        // Keys cubic-convolution weight of tap offset i in 0 .. 3 at fraction t: the same operations as cubic_w on x = t + 1, t, 1 - t, 2 - t
+        auto cubic1 = [](float t, int i) {
+            const float A = -0.75f;
+            const float x = i == 0 ? t + 1.f : i == 1 ? t : i == 2 ? 1.f - t : 2.f - t;
+            const float outer = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+            const float inner = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+            return (i == 0 || i == 3) ? outer : inner;
+        };
+        wxy = cubic1(ux - fx, ti) * cubic1(uy - fy, tr);
+    }
     const int npix = hc * wc;
     const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feats + (size_t)b * npix * 64), 0, npix * 256, 0x00020000);
     const __amdgpu_buffer_rsrc_t ri = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inv + (size_t)b * npix), 0, npix * 4, 0x00020000);
-    int cx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cx[i] = (x0 + i >= 0 && x0 + i < wc) ? x0 + i : 0x00800000;      // 2^23 pixels = byte offset 2^31: outside any map, no 32-bit wrap
-    // 1 / |feats| of the 16 taps: lane `sub` fetches tap `sub`'s factor (ONE load instruction per key-point group instead of sixteen
-    // broadcast loads: the kernel is bound by the number of vector-memory instructions the texture addresser has to walk, not by misses --
-    // visiting the key-points in spatial instead of score order left its time unchanged), handed round by DPP row broadcasts below
-    const float inv_mine = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ri, ((y0 + (sub >> 2)) * wc + cx[sub & 3]) * 4, 0, 0));
-    // DPP row_newbcast: lane t of this key-point's 16 lanes to all of them -- one VALU move per tap (ds_bpermute was an address, an LDS trip and a wait per tap)
-#define XFH_ROW_BCAST(T) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(inv_mine), 0x150 + (T), 0xf, 0xf, false))
-    const float sc_tap[16] = {XFH_ROW_BCAST(0), XFH_ROW_BCAST(1), XFH_ROW_BCAST(2), XFH_ROW_BCAST(3), XFH_ROW_BCAST(4), XFH_ROW_BCAST(5), XFH_ROW_BCAST(6), XFH_ROW_BCAST(7),
-                              XFH_ROW_BCAST(8), XFH_ROW_BCAST(9), XFH_ROW_BCAST(10), XFH_ROW_BCAST(11), XFH_ROW_BCAST(12), XFH_ROW_BCAST(13), XFH_ROW_BCAST(14), XFH_ROW_BCAST(15)};
-#undef XFH_ROW_BCAST
+    const int ty = y0 + tr, tx = x0 + ti;
+    const bool t_in = (unsigned)ty < (unsigned)hc && (unsigned)tx < (unsigned)wc;
+    const int pix_mine = min(max(ty, 0), hc - 1) * wc + min(max(tx, 0), wc - 1);
+    const float inv_mine = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ri, pix_mine * 4, 0, 0));
+    const float w_mine = t_in ? wxy * inv_mine : 0.f;
+    const int off_mine = pix_mine * 256;
+    const int sub16 = sub * 16;
+    typedef unsigned u32x4d __attribute__((ext_vector_type(4)));
+    u32x4d tap[16];
+#define XFH_TAP_LOAD(T) tap[T] = __builtin_bit_cast(u32x4d, __builtin_amdgcn_raw_buffer_load_b128(rf, (int)__builtin_amdgcn_update_dpp(0u, (unsigned)off_mine, 0x150 + (T), 0xf, 0xf, true) + sub16, 0, 0));
+    XFH_TAP_LOAD(0) XFH_TAP_LOAD(1) XFH_TAP_LOAD(2) XFH_TAP_LOAD(3) XFH_TAP_LOAD(4) XFH_TAP_LOAD(5) XFH_TAP_LOAD(6) XFH_TAP_LOAD(7)
+    XFH_TAP_LOAD(8) XFH_TAP_LOAD(9) XFH_TAP_LOAD(10) XFH_TAP_LOAD(11) XFH_TAP_LOAD(12) XFH_TAP_LOAD(13) XFH_TAP_LOAD(14) XFH_TAP_LOAD(15)
+#undef XFH_TAP_LOAD
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int rowpix = (y0 + r) * wc;
-        float4 row = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int pix = rowpix + cx[i];
-            const uint4 u = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rf, pix * 256 + sub * 16, 0, 0));
-            const float4 v = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-            const float sc = sc_tap[4 * r + i];
-            row.x += (v.x * sc) * wx[i]; row.y += (v.y * sc) * wx[i];
-            row.z += (v.z * sc) * wx[i]; row.w += (v.w * sc) * wx[i];
-        }
-        acc.x += row.x * wy[r]; acc.y += row.y * wy[r]; acc.z += row.z * wy[r]; acc.w += row.w * wy[r];
-    }
+#define XFH_TAP_FMA(T) { const float w_ = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(w_mine), 0x150 + (T), 0xf, 0xf, true)); \
+        acc.x = fmaf(w_, __uint_as_float(tap[T].x), acc.x); acc.y = fmaf(w_, __uint_as_float(tap[T].y), acc.y); \
+        acc.z = fmaf(w_, __uint_as_float(tap[T].z), acc.z); acc.w = fmaf(w_, __uint_as_float(tap[T].w), acc.w); }
+    XFH_TAP_FMA(0) XFH_TAP_FMA(1) XFH_TAP_FMA(2) XFH_TAP_FMA(3) XFH_TAP_FMA(4) XFH_TAP_FMA(5) XFH_TAP_FMA(6) XFH_TAP_FMA(7)
+    XFH_TAP_FMA(8) XFH_TAP_FMA(9) XFH_TAP_FMA(10) XFH_TAP_FMA(11) XFH_TAP_FMA(12) XFH_TAP_FMA(13) XFH_TAP_FMA(14) XFH_TAP_FMA(15)
+#undef XFH_TAP_FMA
+    // |desc|^2 over the key-point's 16 lanes: an xor butterfly on DPP operands (quad_perm 1032 / 2301, row_half_mirror, row_mirror: every lane ends with the same bits)
     float n2 = acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
-    n2 += __shfl_xor(n2, 8, 64);
-    n2 += __shfl_xor(n2, 4, 64);
-    n2 += __shfl_xor(n2, 2, 64);
-    n2 += __shfl_xor(n2, 1, 64);
-    const float d = fmaxf(sqrtf(n2), 1e-12f);
-    const float4 o = make_float4(acc.x / d, acc.y / d, acc.z / d, acc.w / d);
+#define XFH_DPP_ADD(v, ctrl) v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), ctrl, 0xf, 0xf, true))
+    XFH_DPP_ADD(n2, 0xb1);       // quad_perm [1, 0, 3, 2]
+    XFH_DPP_ADD(n2, 0x4e);       // quad_perm [2, 3, 0, 1]
+    XFH_DPP_ADD(n2, 0x141);      // row_half_mirror
+    XFH_DPP_ADD(n2, 0x140);      // row_mirror
+#undef XFH_DPP_ADD
+    const float rd = 1.f / fmaxf(sqrtf(n2), 1e-12f);      // (one IEEE division; the four quotients are products with it: within an ulp of acc / d)
+    const float4 o = make_float4(acc.x * rd, acc.y * rd, acc.z * rd, acc.w * rd);
     *dp = o;
     if (dp16) {                       // fp16 copy of 256 * row (round-to-nearest-even) for the matcher's filter sweep: saves its conversion passes
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));

@@ -137,10 +137,24 @@ inline u4 buffer_load_b128(Rsrc rs, unsigned voff, unsigned soff) {
     return r;
 }
 // buffer_load_dwordx4 ... lds with a hand-built resource word (base address in .x/.y, bytes in .z): 16 bytes per lane to the LDS offset m0 + 16 lane
+// EMU_DEFER_DMA: the copy happens as LATE as the kernel's own waits allow -- a thread's requests queue up and s_waitcnt vmcnt(n) (XFH_WAIT_VMCNT) completes all but the n
+// youngest.  Without it the copy happens at issue, the EARLIEST the hardware could deliver it.  A ring that is right under both orders reads no slot before its
+// wait and overwrites none that is still being read.  (Only for kernels whose vector-memory queue holds nothing but these requests wherever they use a partial count.)
+struct PendingDma { unsigned char* dst; const unsigned char* src; };
+inline thread_local std::vector<PendingDma> dma_queue;
+inline void dma_wait(size_t keep) {
+    const size_t n = dma_queue.size() > keep ? dma_queue.size() - keep : 0;
+    for (size_t i = 0; i < n; ++i) { if (dma_queue[i].src) std::memcpy(dma_queue[i].dst, dma_queue[i].src, 16); else std::memset(dma_queue[i].dst, 0, 16); }
+    dma_queue.erase(dma_queue.begin(), dma_queue.begin() + n);
+}
 inline void dma_b128_to_lds(unsigned m0v, unsigned voff, i4 rs, unsigned soff) {
     const unsigned char* base = reinterpret_cast<const unsigned char*>(((uint64_t)((unsigned)rs.y & 0xffffu) << 32) | (unsigned)rs.x);
     unsigned char* dst = wg->lds_base() + m0v + 16 * (tidx.x & 63);
+#ifdef EMU_DEFER_DMA
+    dma_queue.push_back({dst, (uint64_t)voff + 16 <= (unsigned)rs.z ? base + voff + soff : nullptr});
+#else
     if ((uint64_t)voff + 16 <= (unsigned)rs.z) std::memcpy(dst, base + voff + soff, 16); else std::memset(dst, 0, 16);
+#endif
 }
 // buffer_load_dword ... lds: 4 bytes per lane to the LDS offset m0 + 4 lane; a lane whose offset is out of the resource's range (the kernels use 0x80000000) writes zero
 inline void dma_b32_to_lds(unsigned m0v, unsigned voff, i4 rs, unsigned soff) {
@@ -193,8 +207,14 @@ inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_REL
 #define XFH_NOP16() ((void)0)
 #define XFH_NOP16_4(a, b, c, d) ((void)0)
 #define XFH_NOP32_2(a, b) ((void)0)
+#ifdef EMU_DEFER_DMA
+#define XFH_WAIT_VMCNT0() emu::dma_wait(0)
+#define XFH_WAIT_VMCNT(n) emu::dma_wait(n)
+#else
 #define XFH_WAIT_VMCNT0() ((void)0)
 #define XFH_WAIT_VMCNT(n) ((void)0)
+#endif
+#define XFH_NO_DMA_WAVE() ((void)0)
 #define XFH_LDS_ADDR(p, base) ((unsigned)((p) - (base)))
 #define XFH_DMA_B128_TO_LDS(m0v, voff, rsrc, soff) emu::dma_b128_to_lds(m0v, voff, rsrc, soff)
 #define XFH_NOP16_3(a, b, c) ((void)0)

@@ -12,12 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-@pytest.fixture(scope="module")
-def emu_bin():
+# The weight ring's LDS-DMA is emulated twice: copied at issue (the earliest the hardware could deliver it) and copied as late as the kernel's own s_waitcnt vmcnt(n) allow
+# (EMU_DEFER_DMA: a thread's requests queue up, a wait completes all but the n youngest) -- a three-slot ring requested two rows ahead must be right under both.
+@pytest.fixture(scope="module", params=["dma_at_issue", "dma_at_wait"])
+def emu_bin(request):
     if not os.path.exists(CLANG):
         pytest.skip("no host clang")
     out = os.path.join(tempfile.mkdtemp(), "conv_bx64s2_emu")
-    subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread", "-I", os.path.join(ROOT, "accelerated_features_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "emu"),
+    subprocess.run([CLANG, "-O1", "-w", "-std=c++20", "-pthread"] + (["-DEMU_DEFER_DMA"] if request.param == "dma_at_wait" else []) + ["-I", os.path.join(ROOT, "accelerated_features_amd", "csrc"), "-I", os.path.join(ROOT, "tests", "emu"),
                     os.path.join(ROOT, "tests", "emu", "conv_bx64s2_emu.cpp"), "-o", out], check=True)
     return out
 

@@ -112,7 +112,7 @@ def _slice_conv_bx24():
     s = _must_sub(s, 'asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(lds_alloc));', "lds_alloc = 0;")      # (which workgroup of a CU this is: a start delay, nothing else)
     s = re.sub(r'asm volatile\("s_nop 7[^;]*;', ";", s)                                   # idle slots tied to the accumulators
     s = re.sub(r'asm volatile\("" : "\+v"[^;]*;', ";", s)                                 # "the wait for the weight loads belongs here": register pins
-    assert n0 == 8 and "asm volatile" not in s, "an inline-assembly statement of k_conv_bx.hip is not covered"
+    assert n0 == 9 and "asm volatile" not in s, "an inline-assembly statement of k_conv_bx.hip is not covered"
     assert "<<<" not in s
     return s
 
