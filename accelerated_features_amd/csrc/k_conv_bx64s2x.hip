@@ -8,10 +8,10 @@
 namespace xfh {
 
 template <int NCO, bool W4>      // NCO: cout halves; W4: W % 4 == 0
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void conv_bx64s2x_kernel(Bx64S2xArgs a) {
     kernel_entry_hooks(a.cold);      // debug: code-position shift / cold instruction cache (common.hpp)
-    conv_bx64s2x_body<NCO, W4>(a);
+    conv_bx64s2w_body<NCO, W4>(a);
 }
 
 template <int NCO, bool W4>
@@ -24,11 +24,11 @@ static int run_bx64s2x(const ConvW& c, const float* in, int B, int H, int W, flo
     a.in = in; a.wq = c.w_fx; a.bias = c.bias; a.out = out; a.relu = c.relu; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.B = B; a.trace = trace;
     a.nrows = ceil_div(Ho, 8); a.upi = ceil_div(Wo, 16) * a.nrows;
     static AttrMask attr_done = 0;
-    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64s2x_kernel<NCO, W4>), bx64s2x::LDS_BYTES, attr_done);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(conv_bx64s2x_kernel<NCO, W4>), bx64s2x::LDS_W_BYTES, attr_done);
     const long long units = (long long)NCO * B * a.upi;
     int grid = num_cus();                      // one 8-wave workgroup per CU; a multiple of 8 keeps a workgroup on its XCD
     if (units < grid) grid = (int)units;
-    conv_bx64s2x_kernel<NCO, W4><<<grid, 512, bx64s2x::LDS_BYTES, st>>>(a);
+    conv_bx64s2x_kernel<NCO, W4><<<grid, 768, bx64s2x::LDS_W_BYTES, st>>>(a);
     return 0;
 }
 

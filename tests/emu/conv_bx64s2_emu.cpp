@@ -1,4 +1,4 @@
-// conv_bx64s2x_body<NCO, W4> (csrc/conv_bx64s2_body.hpp) on the host.  stdin: {B, H, W, cout (64 | 128), relu, grid} int32, then in (B*64*H*W), w (cout*64*9), bias (cout)
+// conv_bx64s2w_body<NCO, W4> (csrc/conv_bx64s2_body.hpp: twelve waves, eight multiplying + four staging) on the host.  stdin: {B, H, W, cout (64 | 128), relu, grid} int32, then in (B*64*H*W), w (cout*64*9), bias (cout)
 // as fp32 (BatchNorm folded); stdout: out (B*cout*Ho*Wo), status (int32).
 #include "emu.hpp"
 #define XFH_S2_KEEP5(a, b, c, d, e) ((void)0)
@@ -29,7 +29,7 @@ int main() {
     const long long units = (long long)nco * B * a.upi;
     const int g = units < grid ? (int)units : grid;
     const bool w4 = (W & 3) == 0;
-    auto run = [&](auto N, auto W4) { emu::launch(g, 512, xfh::bx64s2x::LDS_BYTES, [&] { xfh::conv_bx64s2x_body<decltype(N)::value, decltype(W4)::value>(a); }); };
+    auto run = [&](auto N, auto W4) { emu::launch(g, 768, xfh::bx64s2x::LDS_W_BYTES, [&] { xfh::conv_bx64s2w_body<decltype(N)::value, decltype(W4)::value>(a); }); };
     using T = std::true_type; using F = std::false_type; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     auto r1 = [&](auto N) { if (w4) run(N, T{}); else run(N, F{}); };
     if (nco == 1) r1(I1{}); else r1(I2{});

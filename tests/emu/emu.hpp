@@ -214,7 +214,8 @@ inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_REL
 #define XFH_WAIT_VMCNT0() ((void)0)
 #define XFH_WAIT_VMCNT(n) ((void)0)
 #endif
-#define XFH_NO_DMA_WAVE() ((void)0)
+#define XFH_WAIT_LGKMCNT0() ((void)0)
+#define XFH_DMA_PROTOCOL_EMULATED() ((void)0)
 #define XFH_LDS_ADDR(p, base) ((unsigned)((p) - (base)))
 #define XFH_DMA_B128_TO_LDS(m0v, voff, rsrc, soff) emu::dma_b128_to_lds(m0v, voff, rsrc, soff)
 #define XFH_NOP16_3(a, b, c) ((void)0)

@@ -1,5 +1,5 @@
 """conv_bx64s2x_kernel's body (csrc/conv_bx64s2_body.hpp: the stride-2 64 -> 64 | 128 convolutions, block4.0 / block5.0, in the fp16-pair arithmetic with the split of the next
-chunk hand-placed inside the MFMA rows of the current one) compiled for the HOST (tests/emu/) against a float64 convolution."""
+chunk done by four staging waves beside eight multiplying ones) compiled for the HOST (tests/emu/) against a float64 convolution."""
 import os
 import subprocess
 import tempfile

@@ -62,7 +62,9 @@ int main(int argc, char** argv) {
     }
     std::vector<long long> t((size_t)NWG * 64);
     HIPCHK(hipMemcpy(t.data(), tr, t.size() * 8, hipMemcpyDeviceToHost));
-    printf("s_memtime counts (100 MHz = 10 ns) of the second unit, per row: wait+barrier / MFMA block / to the next row's stamp\n");
+    printf("s_memtime counts (~0.77 of a shader cycle here: three units + prologue = the launch) of wave 0's second unit, per row: wait+barrier / stamp 2 -> stamp 3 / stamp 3 -> the next row's stamp 1\n"
+           "(the multiplying waves open row r + 1 in front of row r's last MFMAs: stamp 3 of a row lies behind stamp 2 of the next, the third figure is negative;\n"
+           " barrier to barrier = second + third + the next row's first)\n");
     std::vector<long long> unit;
     std::vector<std::vector<long long>> wt(12), mf(12), gap(12);
     for (int g = 0; g < NWG; ++g) {
