@@ -21,6 +21,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // MPT: MFMAs per tap (6: both cout blocks, 3: one); NT: taps of this wave per block; READS: issue the two reads per tap; RED: reduction traffic (reads + writes per block)
 template <int MPT, int NT, bool READS, int RED>
 __device__ __forceinline__ void block_stream(f32x16& c0, f32x16& c1, const f16x8 (&w)[3], f16x8 (&x)[3][2], unsigned la, u32x4& q) {
+    u32x4 q2[2] = {q, q};
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int cur = t % 3, far = (t + 2) % 3;
@@ -31,7 +32,13 @@ __device__ __forceinline__ void block_stream(f32x16& c0, f32x16& c1, const f16x8
         if constexpr (MPT == 6) MF(c1, w[1], x[cur][1]);
         MF(c0, w[2], x[cur][0]);
         if constexpr (MPT == 6) MF(c1, w[2], x[cur][0]);
-        if constexpr (RED > 0) { if (t == 2) { for (int i = 0; i < RED; ++i) WR(la, q, 2048); } if (t == 4) { for (int i = 0; i < RED; ++i) RD(q, la, 2048); LGKM(0); } }
+        if constexpr (RED > 0 && RED < 100) { if (t == 2) { for (int i = 0; i < RED; ++i) WR(la, q, 2048); } if (t == 4) { for (int i = 0; i < RED; ++i) RD(q, la, 2048); LGKM(0); } }
+        // RED = 100 + n: the same n stores and n reads, the reads awaited two taps later (behind 12 more MFMAs; LDS returns in order: the four operand reads issued since stay out);
+        // RED = 200 + n: only the n stores; RED = 300 + n: only the n reads (awaited two taps later)
+        if constexpr (RED >= 100) { constexpr int n = RED % 100, kind = RED / 100;
+            if (t == 2 && kind != 3) { for (int i = 0; i < n; ++i) WR(la, q, 2048); }
+            if (t == 4 && kind != 2) { for (int i = 0; i < n; ++i) RD(q2[i & 1], la, 2048); }
+            if (t == 6 && kind != 2) { LGKM(4); q[0] += q2[0][0] + q2[1][0]; } }
     }
 }
 
@@ -78,6 +85,9 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
         if constexpr (KIND == 10) { for (int z = 0; z < 4; ++z) step_stream<7, 6>(c0, c1, x, y, la); if (it & 1) step_stream<7, 6>(c0, c1, x, y, la); }     // S3: one wave, two pixel blocks x one cout block: 7 reads + 6 MFMAs
         if constexpr (KIND == 11) { for (int z = 0; z < 2; ++z) step_stream<10, 12>(c0, c1, x, y, la); if ((it & 3) == 0) step_stream<10, 12>(c0, c1, x, y, la); }      // S4: one wave, 2 x 2 tile: 10 reads + 12 MFMAs (2.25 double steps)
         if constexpr (KIND == 12) { for (int z = 0; z < 4; ++z) step_stream<4, 3>(c0, c1, x, y, la); if (it & 1) step_stream<4, 3>(c0, c1, x, y, la); }           // S5: two waves per SIMD, 4 reads + 3 MFMAs (fp16(w) derived in registers)
+        if constexpr (KIND == 13) block_stream<6, 9, true, 106>(c0, c1, w, x, la, q);          // C2
+        if constexpr (KIND == 14) block_stream<6, 9, true, 206>(c0, c1, w, x, la, q);          // C3
+        if constexpr (KIND == 15) block_stream<6, 9, true, 306>(c0, c1, w, x, la, q);          // C4
         if constexpr (KIND == 7) { if (wave & 4) block_stream<6, 4, true, 3>(c0, c1, w, x, la, q); else block_stream<6, 5, true, 3>(c0, c1, w, x, la, q); }      // D2
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -111,6 +121,9 @@ int main() {
     const double a0 = run<0>("A0  one wave per SIMD, 54 MFMAs, no reads", 256, out, iters, 0);
     run<1>("A1  one wave per SIMD, 54 MFMAs + 18 ds_read_b128 (conv_rs64_kernel's stream)", 256, out, iters, a0);
     run<5>("C1  A1 + 6 reads + 6 writes per block (the K split's reduction)", 256, out, iters, a0);
+    run<13>("C2  C1 with the six reads awaited two taps later", 256, out, iters, a0);
+    run<14>("C3  A1 + the six ds_write_b128 only", 256, out, iters, a0);
+    run<15>("C4  A1 + the six reads only (awaited two taps later)", 256, out, iters, a0);
     run<2>("B0  two waves per SIMD, 27 MFMAs each, no reads", 512, out, iters, a0);
     run<3>("B1  two waves per SIMD split the cout blocks: 27 MFMAs + 18 reads each", 512, out, iters, a0);
     run<6>("D1  B1 + 3 reads + 3 writes per wave and block", 512, out, iters, a0);
