@@ -108,6 +108,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 //     pixel | pixel 3 in its three rows), raw values travel a chunk ahead (two register sets).  No DMA in these waves: hipcc counts their loads exactly, and they stay in
 //     flight across the barriers until the split needs them; the waves pass the same twelve barriers per unit.
 // 168 registers per wave (three waves per SIMD), 145 KiB of LDS.
+#ifndef XFH_S2_WAIT_PIECES
+#define XFH_S2_WAIT_PIECES NPW      /* (tests/test_conv_bx64s2_emulated.py builds the emulation once with 2 * NPW: a count that lets TWO rows stay out must fail under late delivery) */
+#endif
 template <int NCO, bool W4>
 __device__ __forceinline__ void conv_bx64s2w_body(const Bx64S2xArgs& a) {
     using namespace bx64s2x;
@@ -218,7 +221,7 @@ __device__ __forceinline__ void conv_bx64s2w_body(const Bx64S2xArgs& a) {
             auto open_row = [&](auto RC) __attribute__((always_inline)) {
                 constexpr int r = decltype(RC)::value;
                 S2W_STAMP(1 + 4 * r)
-                if constexpr (r > 0) XFH_WAIT_VMCNT(NPW);
+                if constexpr (r > 0) XFH_WAIT_VMCNT(XFH_S2_WAIT_PIECES);
                 XFH_WAIT_LGKMCNT0();               // (this wave's reads of the slot that is requested next have completed)
                 __syncthreads();
                 S2W_STAMP(2 + 4 * r)
