@@ -41,10 +41,12 @@ struct Workgroup {
     std::vector<unsigned char> lds;
     std::barrier<> bar;
     std::vector<std::unique_ptr<std::barrier<>>> wave_bar;
+    std::vector<std::unique_ptr<std::barrier<>>> row_bar;      // one per 16 lanes (a DPP row): for kernels whose 16-lane groups leave early as a whole (descriptor_kernel)
     std::vector<h8> opa, opb;      // [thread]
     std::vector<float> opa32, opb32;      // [thread][8]
     Workgroup(int n, size_t lds_bytes) : nthreads(n), lds(lds_bytes + 64, 0xff), bar(n), opa(n), opb(n), opa32(8 * n), opb32(8 * n) {      // (LDS starts as NaN patterns: nothing may rely on zeros)
         for (int w = 0; w < n / 64; ++w) wave_bar.emplace_back(new std::barrier<>(64));
+        for (int r = 0; r < n / 16; ++r) row_bar.emplace_back(new std::barrier<>(16));
     }
     unsigned char* lds_base() { return reinterpret_cast<unsigned char*>((reinterpret_cast<uintptr_t>(lds.data()) + 63) & ~uintptr_t(63)); }
 };
@@ -107,6 +109,25 @@ inline f16v mfma32x2(float a, float b, f16v c) {
     }
     wg->wave_bar[w]->arrive_and_wait();
     return d;
+}
+// v_mov_b32_dpp within a ROW of 16 lanes (all that the kernels emulated here use): quad_perm (ctrl < 0x100), row_mirror (0x140), row_half_mirror (0x141), row_newbcast:n
+// (0x150 + n).  Every source lane of these is in the lane's own row and the rows' lanes reach the instruction together, so the exchange synchronises the row, not the wave --
+// a row whose 16 lanes have all returned (descriptor_kernel: rows past the list) is simply absent.  row_mask / bank_mask 0xf, bound_ctrl irrelevant (no invalid source).
+inline unsigned update_dpp(unsigned, unsigned src, int ctrl, int row_mask, int bank_mask, bool) {
+    const int t = tidx.x, l = t & 15, base = t & ~15;
+    if (row_mask != 0xf || bank_mask != 0xf) std::abort();
+    std::memcpy(&wg->opb32[t * 8], &src, 4);
+    wg->row_bar[t >> 4]->arrive_and_wait();
+    int sl;
+    if (ctrl < 0x100) sl = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);
+    else if (ctrl == 0x140) sl = 15 - l;
+    else if (ctrl == 0x141) sl = (l & 8) | (7 - (l & 7));
+    else if (ctrl >= 0x150 && ctrl < 0x160) sl = ctrl - 0x150;
+    else std::abort();
+    unsigned r;
+    std::memcpy(&r, &wg->opb32[(base + sl) * 8], 4);
+    wg->row_bar[t >> 4]->arrive_and_wait();
+    return r;
 }
 // value of lane ^ mask of the same wave
 inline float shfl_xor(float v, int mask) {
@@ -232,6 +253,7 @@ typedef const void* xfh_gptr_t;
 typedef void* xfh_lptr_t;
 typedef emu::Rsrc __amdgpu_buffer_rsrc_t;
 #define __builtin_amdgcn_readfirstlane(x) (x)
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu::update_dpp(old, src, ctrl, rm, bm, bc)
 #define __builtin_amdgcn_fmed3f(a, b, c) emu::med3(a, b, c)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_perm(hi, lo, sel) emu::perm(hi, lo, sel)
